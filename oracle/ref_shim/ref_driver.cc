@@ -1,0 +1,271 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY -- never linked into the product library.
+//
+// C driver over the verbatim reference hot path (see oracle/Makefile): feeds
+// graphs straight into the reference storages the way LocalGraph::UpdateEdges
+// does (graphlearn/src/core/graph/local_graph.cc:50-64: SetSideInfo, Add, then
+// Build), looks operators up through the reference's own OpFactory
+// (graphlearn/src/core/operator/op_factory.cc:45-61) and calls
+// Operator::Process (graphlearn/src/core/operator/operator.h:36-37) on the
+// reference's own SamplingRequest / AggregatingRequest objects.
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "core/graph/graph_store.h"
+#include "core/io/element_value.h"
+#include "core/operator/op_factory.h"
+#include "include/aggregating_request.h"
+#include "include/config.h"
+#include "include/index_option.h"
+#include "include/sampling_request.h"
+
+namespace std {
+struct glx_fixed_random_device;  // from fixed_rd.h (force-included into sampler TUs)
+}
+// The seed hook lives in a function-local static of a header-only struct; we
+// re-declare the accessor through the same header so both sides agree.
+#include "fixed_rd.h"
+
+using namespace graphlearn;  // NOLINT
+
+namespace {
+struct Ref {
+  GraphStore* store;
+};
+
+template <class F>
+void RunMaybeFresh(int fresh_thread, F&& f) {
+  // thread_local mt19937 engines in the reference are seeded on first use in a
+  // thread; a fresh thread therefore restarts the stream from the pinned seed.
+  if (fresh_thread) {
+    std::thread t(f);
+    t.join();
+  } else {
+    f();
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// storage_mode: reference flag bits (graphlearn/src/core/graph/storage/storage_mode.cc:22-38)
+//   2 = default (vector-of-vectors + stats), 3 = CSR ("compressed") + stats.
+void* glref_create(int storage_mode, int padding_mode, int64_t default_neighbor_id,
+                   float default_float_attr) {
+  SetGlobalFlagStorageMode(storage_mode);
+  SetGlobalFlagPaddingMode(padding_mode);
+  SetGlobalFlagDefaultNeighborId(default_neighbor_id);
+  SetGlobalFlagDefaultFloatAttribute(default_float_attr);
+  Ref* r = new Ref;
+  r->store = new GraphStore(nullptr);
+  op::OpFactory::GetInstance()->Set(r->store);
+  return r;
+}
+
+void glref_destroy(void* h) {
+  Ref* r = static_cast<Ref*>(h);
+  op::OpFactory::GetInstance()->Set(nullptr);
+  delete r->store;
+  delete r;
+}
+
+void glref_set_flags(int padding_mode, int64_t default_neighbor_id, float default_float_attr) {
+  SetGlobalFlagPaddingMode(padding_mode);
+  SetGlobalFlagDefaultNeighborId(default_neighbor_id);
+  SetGlobalFlagDefaultFloatAttribute(default_float_attr);
+}
+
+void glref_set_seed(unsigned int seed) { std::glx_fixed_random_device::seed() = seed; }
+
+// weights may be NULL (unweighted edge type).  Edge ids are insertion indices,
+// exactly as MemoryEdgeStorage::Add assigns them.
+int glref_add_edges(void* h, const char* edge_type, const int64_t* src, const int64_t* dst,
+                    const float* weights, int64_t n) {
+  Ref* r = static_cast<Ref*>(h);
+  io::GraphStorage* st = r->store->GetGraph(edge_type)->GetLocalStorage();
+  io::SideInfo info;
+  info.format = weights ? io::kWeighted : io::kDefault;
+  info.type = edge_type;
+  st->SetSideInfo(&info);
+  io::EdgeValue v;
+  for (int64_t i = 0; i < n; ++i) {
+    v.src_id = src[i];
+    v.dst_id = dst[i];
+    v.weight = weights ? weights[i] : 0.0f;
+    st->Add(&v);
+  }
+  return 0;
+}
+
+int glref_build_graph(void* h, const char* edge_type) {
+  Ref* r = static_cast<Ref*>(h);
+  IndexOption opt;
+  opt.name = "sort";
+  return r->store->GetGraph(edge_type)->Build(opt).ok() ? 0 : 1;
+}
+
+int glref_add_nodes(void* h, const char* node_type, const int64_t* ids, const float* feats,
+                    int64_t n, int32_t dim) {
+  Ref* r = static_cast<Ref*>(h);
+  io::NodeStorage* st = r->store->GetNoder(node_type)->GetLocalStorage();
+  io::SideInfo info;
+  info.format = io::kAttributed;
+  info.f_num = dim;
+  info.type = node_type;
+  st->SetSideInfo(&info);
+  io::NodeValue v;
+  for (int64_t i = 0; i < n; ++i) {
+    v.id = ids[i];
+    v.attrs->Clear();
+    v.attrs->Add(feats + i * dim, dim);
+    st->Add(&v);
+  }
+  return 0;
+}
+
+int glref_build_nodes(void* h, const char* node_type) {
+  Ref* r = static_cast<Ref*>(h);
+  IndexOption opt;
+  opt.name = "sort";
+  return r->store->GetNoder(node_type)->Build(opt).ok() ? 0 : 1;
+}
+
+// Post-Build adjacency export (the device CSR must be built from exactly this
+// order: SURVEY.md 8(a) quirk 10).  Returns the degree; copies min(deg, cap).
+int64_t glref_get_row(void* h, const char* edge_type, int64_t src, int64_t* nbr, int64_t* eid,
+                      int64_t cap) {
+  Ref* r = static_cast<Ref*>(h);
+  io::GraphStorage* st = r->store->GetGraph(edge_type)->GetLocalStorage();
+  auto nb = st->GetNeighbors(src);
+  auto ed = st->GetOutEdges(src);
+  if (!nb) return 0;
+  int64_t deg = nb.Size();
+  for (int64_t i = 0; i < deg && i < cap; ++i) {
+    nbr[i] = nb[i];
+    eid[i] = ed[i];
+  }
+  return deg;
+}
+
+float glref_edge_weight(void* h, const char* edge_type, int64_t edge_id) {
+  Ref* r = static_cast<Ref*>(h);
+  return r->store->GetGraph(edge_type)->GetLocalStorage()->GetEdgeWeight(edge_id);
+}
+
+// Runs the reference sampler named `strategy` ("RandomSampler", ...).
+// Returns 0 on OK, else the reference error code (or -1: unknown op).
+int glref_sample(void* h, const char* edge_type, const char* strategy, const int64_t* src,
+                 int32_t batch, int32_t k, int64_t* nbr_out, int64_t* eid_out, int fresh_thread) {
+  (void)h;
+  int rc = 0;
+  RunMaybeFresh(fresh_thread, [&]() {
+    SamplingRequest req(edge_type, strategy, k);
+    SamplingResponse res;
+    req.Set(src, batch);
+    op::Operator* op = op::OpFactory::GetInstance()->Create(req.Name());
+    if (!op) { rc = -1; return; }
+    Status s = op->Process(&req, &res);
+    if (!s.ok()) { rc = static_cast<int>(s.code()); return; }
+    size_t n = static_cast<size_t>(batch) * k;
+    if (nbr_out) memcpy(nbr_out, res.GetNeighborIds(), n * sizeof(int64_t));
+    if (eid_out) memcpy(eid_out, res.GetEdgeIds(), n * sizeof(int64_t));
+  });
+  return rc;
+}
+
+int glref_aggregate(void* h, const char* node_type, const char* strategy, const int64_t* ids,
+                    const int32_t* segs, int32_t num_ids, int32_t num_segments, float* emb_out,
+                    int32_t* cnt_out, int32_t* dim_out) {
+  (void)h;
+  AggregatingRequest req(node_type, strategy);
+  AggregatingResponse res;
+  req.Set(ids, segs, num_ids, num_segments);
+  op::Operator* op = op::OpFactory::GetInstance()->Create(req.Name());
+  if (!op) return -1;
+  Status s = op->Process(&req, &res);
+  if (!s.ok()) return static_cast<int>(s.code());
+  int32_t dim = res.EmbeddingDim();
+  if (dim_out) *dim_out = dim;
+  if (emb_out) memcpy(emb_out, res.Embeddings(), sizeof(float) * dim * num_segments);
+  if (cnt_out) memcpy(cnt_out, res.Segments(), sizeof(int32_t) * num_segments);
+  return 0;
+}
+
+// ---- CPU-baseline timing legs (reference's concurrency model: one request per
+// pool thread, no intra-request parallelism:
+// graphlearn/src/service/local/in_memory_service.cc:64-71).
+// Each of `threads` workers issues `reps` independent 2-hop requests over its
+// own slice of `seeds` (per-request cost includes request/response
+// construction, as in the reference).  Returns wall seconds; *edges_out gets
+// the number of response slots produced.
+double glref_time_sample_2hop(void* h, const char* edge_type, const char* strategy,
+                              const int64_t* seeds, int32_t seeds_per_req, int32_t k1, int32_t k2,
+                              int32_t reps, int32_t threads, int64_t* edges_out) {
+  (void)h;
+  std::vector<std::thread> pool;
+  std::vector<int64_t> produced(threads, 0);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      op::Operator* op = op::OpFactory::GetInstance()->Create(strategy);
+      for (int r = 0; r < reps; ++r) {
+        const int64_t* s = seeds + (static_cast<int64_t>(t) * reps + r) * seeds_per_req;
+        SamplingRequest q1(edge_type, strategy, k1);
+        SamplingResponse r1;
+        q1.Set(s, seeds_per_req);
+        op->Process(&q1, &r1);
+        int32_t n1 = seeds_per_req * k1;
+        produced[t] += n1;
+        if (k2 > 0) {
+          SamplingRequest q2(edge_type, strategy, k2);
+          SamplingResponse r2;
+          q2.Set(r1.GetNeighborIds(), n1);
+          op->Process(&q2, &r2);
+          produced[t] += static_cast<int64_t>(n1) * k2;
+        }
+      }
+    });
+  }
+  for (auto& th : pool) th.join();
+  auto t1 = std::chrono::steady_clock::now();
+  int64_t tot = 0;
+  for (auto p : produced) tot += p;
+  if (edges_out) *edges_out = tot;
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// Each worker aggregates `reps` requests of `num_ids` ids in fixed-size
+// segments of `seg_len` (ids drawn by the caller).  Returns wall seconds.
+double glref_time_aggregate(void* h, const char* node_type, const char* strategy,
+                            const int64_t* ids, int32_t num_ids, int32_t seg_len, int32_t reps,
+                            int32_t threads, int64_t* vertices_out) {
+  (void)h;
+  int32_t num_segments = num_ids / seg_len;
+  std::vector<int32_t> segs(num_ids);
+  for (int32_t i = 0; i < num_ids; ++i) segs[i] = i / seg_len;
+  std::vector<std::thread> pool;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      op::Operator* op = op::OpFactory::GetInstance()->Create(strategy);
+      for (int r = 0; r < reps; ++r) {
+        const int64_t* p = ids + (static_cast<int64_t>(t) * reps + r) * num_ids;
+        AggregatingRequest req(node_type, strategy);
+        AggregatingResponse res;
+        req.Set(p, segs.data(), num_ids, num_segments);
+        op->Process(&req, &res);
+      }
+    });
+  }
+  for (auto& th : pool) th.join();
+  auto t1 = std::chrono::steady_clock::now();
+  if (vertices_out) *vertices_out = static_cast<int64_t>(threads) * reps * num_ids;
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"
