@@ -1,0 +1,396 @@
+// glx node features + segmented aggregation (Sum/Mean/Max/Min/Prod) + lookup.
+// Replaces graphlearn/src/core/operator/aggregator/{aggregator.cc:25-86,
+// sum_aggregator.cc:25-33, mean_aggregator.cc:26-61, max_aggregator.cc:26-40,
+// min_aggregator.cc, prod_aggregator.cc} and the GetAttribute()->GetFloats()
+// reads behind them (memory_node_storage.cc:127-138).
+//
+// SpMM-shaped but HBM-bound (0.25 flop/byte): the design goal is to keep many
+// independent 16-byte row loads in flight per lane and to touch every feature
+// byte once.  A group of G lanes owns one segment and walks its rows in the
+// reference's order; lane c of the group owns columns [4c, 4c+4) so each output
+// element is accumulated left-to-right exactly like the reference's serial loop
+// (bit-identical results, no cross-lane reduction at all).
+#include <float.h>
+#include <string.h>
+
+#include <new>
+
+#include "glx_common.h"
+
+namespace {
+
+// ---- segment bookkeeping ---------------------------------------------------
+// AggregatingRequest's cursor (aggregating_request.cc:86-105) consumes ids in
+// order and hands id c to segment segment_ids[c] only while the sequence stays
+// non-decreasing and inside [0, num_segments); the first violation stalls the
+// cursor for good.  valid_len = index of that first violation.
+__global__ void glx_seg_valid_kernel(const int32_t* __restrict__ seg, int32_t n, int32_t num_segments,
+                                     int32_t* valid_len) {
+  int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t cur = seg[i];
+  bool bad = cur < 0 || cur >= num_segments || (i > 0 && cur < seg[i - 1]);
+  if (bad) atomicMin(valid_len, i);
+}
+
+// seg_start[s] = lower_bound(seg[0..valid_len), s), s in [0, num_segments].
+__global__ void glx_seg_start_kernel(const int32_t* __restrict__ seg, const int32_t* valid_len,
+                                     int32_t num_segments, int32_t* __restrict__ seg_start) {
+  int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > num_segments) return;
+  int32_t lo = 0, hi = *valid_len;
+  while (lo < hi) {
+    int32_t mid = lo + ((hi - lo) >> 1);
+    if (seg[mid] < s) lo = mid + 1; else hi = mid;
+  }
+  seg_start[s] = lo;
+}
+
+__global__ void glx_set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
+
+// raw id -> feature row (int32, -1 = unknown id) for the hashed id map.
+__global__ void glx_rows_kernel(GlxIdMap map, const int64_t* __restrict__ ids, int64_t n,
+                                int32_t* __restrict__ rows) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rows[i] = (int32_t)glx_row_of(map, ids[i]);
+}
+
+template <int OP>
+__device__ __forceinline__ float agg_init() {
+  if (OP == GLX_AGG_MAX) return (float)FLT_MIN_10_EXP;  // max_aggregator.cc:28 (-37, sic)
+  if (OP == GLX_AGG_MIN) return FLT_MAX;                // min_aggregator.cc:28
+  if (OP == GLX_AGG_PROD) return 1.0f;                  // prod_aggregator.cc
+  return 0.0f;                                          // aggregator.cc:61-65
+}
+
+template <int OP>
+__device__ __forceinline__ float agg_combine(float l, float r) {
+  if (OP == GLX_AGG_MAX) return (l < r) ? r : l;  // std::max(l, r)
+  if (OP == GLX_AGG_MIN) return (r < l) ? r : l;  // std::min(l, r)
+  if (OP == GLX_AGG_PROD) return l * r;
+  return l + r;  // sum, mean
+}
+
+struct AggArgs {
+  const float* X;
+  const int64_t* node_ids;   // raw ids (dense map) ...
+  const int32_t* rows;       // ... or pre-translated rows (hashed map); one is null
+  const int32_t* seg_start;  // [num_segments + 1]
+  float* emb_out;
+  int32_t* cnt_out;
+  int64_t num_rows;
+  int32_t dim;
+  int32_t num_segments;
+  float default_attr;
+};
+
+__device__ __forceinline__ int64_t agg_row_at(const AggArgs& a, int32_t pos) {
+  if (a.rows) return a.rows[pos];
+  const int64_t id = a.node_ids[pos];
+  return (id >= 0 && id < a.num_rows) ? id : -1;
+}
+
+// G lanes per segment, VEC floats per lane per pass (VEC = 4: one dwordx4 per
+// row per lane; VEC = 1 for dims that are not a multiple of 4).  U rows are
+// issued back-to-back before the first is consumed.
+template <int OP, int G, int VEC, int U>
+__global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int c = threadIdx.x & (G - 1);
+  if (gid >= a.num_segments) return;
+  const int32_t s0 = a.seg_start[gid];
+  const int32_t s1 = a.seg_start[gid + 1];
+  const int32_t n = s1 - s0;
+  if (c == 0) a.cnt_out[gid] = n;
+  const int32_t dim = a.dim;
+  float* out = a.emb_out + gid * (int64_t)dim;
+  for (int32_t col = c * VEC; col < dim; col += G * VEC) {
+    vec_t acc;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = agg_init<OP>();
+    for (int32_t base = s0; base < s1; base += U) {
+      int64_t row[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) row[u] = (base + u < s1) ? agg_row_at(a, base + u) : -2;
+      vec_t val[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (row[u] >= 0) {
+          val[u] = *reinterpret_cast<const vec_t*>(a.X + row[u] * (int64_t)dim + col);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) val[u][v] = a.default_attr;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (row[u] != -2) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = agg_combine<OP>(acc[v], val[u][v]);
+        }
+      }
+    }
+    // FinalFunc: aggregator.cc:74-86 (empty -> default), mean_aggregator.cc:45-61.
+    if (n == 0) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = a.default_attr;
+    } else if (OP == GLX_AGG_MEAN) {
+      const float fn = (float)n;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = acc[v] / fn;
+    }
+    *reinterpret_cast<vec_t*>(out + col) = acc;
+  }
+}
+
+template <int OP, int G, int VEC>
+void launch_agg_g(const AggArgs& a, hipStream_t s) {
+  const int64_t threads = (int64_t)a.num_segments * G;
+  glx_aggregate_kernel<OP, G, VEC, 8><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+}
+
+template <int OP>
+void launch_agg(const AggArgs& a, hipStream_t s) {
+  const bool vec4 = a.dim % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0;
+  if (vec4) {
+    const int lanes = a.dim / 4;
+    if (lanes >= 64) launch_agg_g<OP, 64, 4>(a, s);
+    else if (lanes >= 32) launch_agg_g<OP, 32, 4>(a, s);
+    else if (lanes >= 16) launch_agg_g<OP, 16, 4>(a, s);
+    else if (lanes >= 8) launch_agg_g<OP, 8, 4>(a, s);
+    else if (lanes >= 4) launch_agg_g<OP, 4, 4>(a, s);
+    else if (lanes >= 2) launch_agg_g<OP, 2, 4>(a, s);
+    else launch_agg_g<OP, 1, 4>(a, s);
+  } else {
+    const int lanes = a.dim;
+    if (lanes >= 64) launch_agg_g<OP, 64, 1>(a, s);
+    else if (lanes >= 16) launch_agg_g<OP, 16, 1>(a, s);
+    else if (lanes >= 4) launch_agg_g<OP, 4, 1>(a, s);
+    else launch_agg_g<OP, 1, 1>(a, s);
+  }
+}
+
+// Feature gather (LookupNodes float attributes): G lanes per output row.
+__global__ __launch_bounds__(256) void glx_lookup_kernel(GlxIdMap map, const float* __restrict__ X,
+                                                         int32_t dim, const int64_t* __restrict__ ids,
+                                                         int64_t n, float default_attr,
+                                                         float* __restrict__ out, int G) {
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int c = threadIdx.x % G;
+  if (gid >= n) return;
+  const int64_t row = glx_row_of(map, ids[gid]);
+  float* o = out + gid * (int64_t)dim;
+  if ((dim & 3) == 0) {
+    for (int32_t col = c * 4; col < dim; col += G * 4) {
+      float4 v = make_float4(default_attr, default_attr, default_attr, default_attr);
+      if (row >= 0) v = *reinterpret_cast<const float4*>(X + row * (int64_t)dim + col);
+      *reinterpret_cast<float4*>(o + col) = v;
+    }
+  } else {
+    for (int32_t col = c; col < dim; col += G) o[col] = row >= 0 ? X[row * (int64_t)dim + col] : default_attr;
+  }
+}
+
+int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const int32_t* d_seg,
+                     int32_t num_ids, int32_t num_segments, float default_attr, float* d_emb,
+                     int32_t* d_cnt, hipStream_t s) {
+  // scratch: valid_len (1) + seg_start (Sg+1) [+ rows (N) for hashed ids]
+  const bool hashed = f->idmap.keys != nullptr;
+  const size_t n_i32 = 1 + (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
+  int32_t* scratch = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s);
+  if (rc != GLX_OK) return rc;
+  int32_t* valid_len = scratch;
+  int32_t* seg_start = scratch + 1;
+  int32_t* rows = hashed ? seg_start + num_segments + 1 : nullptr;
+  glx_set_i32_kernel<<<1, 1, 0, s>>>(valid_len, num_ids);
+  if (num_ids > 0) {
+    glx_seg_valid_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(d_seg, num_ids,
+                                                                          num_segments, valid_len);
+    if (hashed) {
+      glx_rows_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(f->map(), d_ids, num_ids, rows);
+    }
+  }
+  glx_seg_start_kernel<<<(unsigned)((num_segments + 1 + 255) / 256), 256, 0, s>>>(
+      d_seg, valid_len, num_segments, seg_start);
+
+  AggArgs a;
+  a.X = f->X;
+  a.node_ids = hashed ? nullptr : d_ids;
+  a.rows = rows;
+  a.seg_start = seg_start;
+  a.emb_out = d_emb;
+  a.cnt_out = d_cnt;
+  a.num_rows = f->num_rows;
+  a.dim = f->dim;
+  a.num_segments = num_segments;
+  a.default_attr = default_attr;
+  switch (op) {
+    case GLX_AGG_SUM: launch_agg<GLX_AGG_SUM>(a, s); break;
+    case GLX_AGG_MEAN: launch_agg<GLX_AGG_MEAN>(a, s); break;
+    case GLX_AGG_MAX: launch_agg<GLX_AGG_MAX>(a, s); break;
+    case GLX_AGG_MIN: launch_agg<GLX_AGG_MIN>(a, s); break;
+    case GLX_AGG_PROD: launch_agg<GLX_AGG_PROD>(a, s); break;
+    default: break;
+  }
+  hipError_t le = hipGetLastError();
+  glx_scratch_free(scratch, s);
+  GLX_HIP(le);
+  return GLX_OK;
+}
+
+}  // namespace
+
+extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
+                                   const int64_t* ids, int ptr_kind, void* stream,
+                                   glx_features** out) {
+  GLX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  GLX_REQUIRE(num_rows >= 0 && dim > 0, "bad shape [%lld, %d]", (long long)num_rows, dim);
+  GLX_REQUIRE(num_rows < INT32_MAX, "num_rows must be < 2^31");
+  GLX_REQUIRE(num_rows == 0 || X != nullptr, "X is NULL");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  int rc = glx_init_device(device);
+  if (rc != GLX_OK) return rc;
+  GlxDeviceGuard guard(device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", device);
+  hipStream_t s = glx_stream(stream);
+  glx_features* f = new (std::nothrow) glx_features();
+  GLX_REQUIRE(f != nullptr, "out of host memory");
+  memset(static_cast<void*>(f), 0, sizeof(*f));
+  f->device = device;
+  f->num_rows = num_rows;
+  f->dim = dim;
+  const size_t bytes = (size_t)(num_rows > 0 ? num_rows : 1) * dim * sizeof(float);
+  hipError_t e = hipMalloc(&f->X, bytes);
+  if (e == hipSuccess && num_rows > 0) {
+    e = hipMemcpyAsync(f->X, X, (size_t)num_rows * dim * sizeof(float),
+                       ptr_kind == GLX_PTR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s);
+  }
+  int64_t* tmp_ids = nullptr;
+  if (e == hipSuccess && ids) {
+    const int64_t* d_ids = ids;
+    if (ptr_kind == GLX_PTR_HOST) {
+      e = hipMalloc(&tmp_ids, (size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int64_t));
+      if (e == hipSuccess) e = hipMemcpyAsync(tmp_ids, ids, (size_t)num_rows * sizeof(int64_t), hipMemcpyHostToDevice, s);
+      d_ids = tmp_ids;
+    }
+    if (e == hipSuccess) rc = glx_idmap_build(d_ids, num_rows, &f->idmap, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (tmp_ids) (void)hipFree(tmp_ids);
+  if (e != hipSuccess || rc != GLX_OK) {
+    if (e != hipSuccess) glx_set_error("feature upload failed: %s", hipGetErrorString(e));
+    glx_features_destroy(f);
+    return e == hipErrorOutOfMemory ? GLX_RESOURCE_EXHAUSTED : (rc != GLX_OK ? rc : GLX_INTERNAL);
+  }
+  *out = f;
+  return GLX_OK;
+}
+
+extern "C" void glx_features_destroy(glx_features* f) {
+  if (!f) return;
+  GlxDeviceGuard guard(f->device);
+  if (f->X) (void)hipFree(f->X);
+  glx_idmap_free(&f->idmap);
+  delete f;
+}
+
+extern "C" int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t* dim,
+                                 int* has_id_map, int* device) {
+  GLX_REQUIRE(f != nullptr, "features is NULL");
+  if (num_rows) *num_rows = f->num_rows;
+  if (dim) *dim = f->dim;
+  if (has_id_map) *has_id_map = f->idmap.keys != nullptr;
+  if (device) *device = f->device;
+  return GLX_OK;
+}
+
+extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_ids,
+                             const int32_t* segment_ids, int32_t num_ids, int32_t num_segments,
+                             float default_attr, float* emb_out, int32_t* cnt_out, int ptr_kind,
+                             void* stream) {
+  GLX_REQUIRE(f != nullptr, "features is NULL");
+  GLX_REQUIRE(op >= GLX_AGG_SUM && op <= GLX_AGG_PROD, "unknown aggregator id %d", op);
+  GLX_REQUIRE(num_ids >= 0 && num_segments >= 0, "negative sizes");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  GLX_REQUIRE((int64_t)num_segments * f->dim <= INT32_MAX,
+              "num_segments * dim exceeds int32 (tensor.h:47)");
+  if (num_segments == 0) return GLX_OK;
+  GLX_REQUIRE(emb_out && cnt_out && (num_ids == 0 || (node_ids && segment_ids)), "NULL data pointer");
+  GlxDeviceGuard guard(f->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", f->device);
+  hipStream_t s = glx_stream(stream);
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    return aggregate_device(f, op, node_ids, segment_ids, num_ids, num_segments, default_attr,
+                            emb_out, cnt_out, s);
+  }
+  const size_t emb_n = (size_t)num_segments * f->dim;
+  const size_t bytes = (size_t)num_ids * 8 + (size_t)num_ids * 4 + emb_n * 4 + (size_t)num_segments * 4 + 64;
+  char* d = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), bytes, s);
+  if (rc != GLX_OK) return rc;
+  float* d_emb = reinterpret_cast<float*>(d);
+  int64_t* d_ids = reinterpret_cast<int64_t*>(d + ((emb_n * 4 + 15) & ~(size_t)15));
+  int32_t* d_seg = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(d_ids) + (size_t)num_ids * 8);
+  int32_t* d_cnt = d_seg + num_ids;
+  hipError_t e = hipSuccess;
+  if (num_ids > 0) {
+    e = hipMemcpyAsync(d_ids, node_ids, (size_t)num_ids * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seg, segment_ids, (size_t)num_ids * 4, hipMemcpyHostToDevice, s);
+  }
+  if (e == hipSuccess) {
+    rc = aggregate_device(f, op, d_ids, d_seg, num_ids, num_segments, default_attr, d_emb, d_cnt, s);
+    if (rc == GLX_OK) {
+      e = hipMemcpyAsync(emb_out, d_emb, emb_n * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(cnt_out, d_cnt, (size_t)num_segments * 4, hipMemcpyDeviceToHost, s);
+    }
+  }
+  hipError_t e2 = hipStreamSynchronize(s);
+  glx_scratch_free(d, s);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(e);
+  GLX_HIP(e2);
+  return GLX_OK;
+}
+
+extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_t n,
+                          float default_attr, float* out, int ptr_kind, void* stream) {
+  GLX_REQUIRE(f != nullptr, "features is NULL");
+  GLX_REQUIRE(n >= 0, "negative n");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  if (n == 0) return GLX_OK;
+  GLX_REQUIRE(node_ids && out, "NULL data pointer");
+  GlxDeviceGuard guard(f->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", f->device);
+  hipStream_t s = glx_stream(stream);
+  int G = 1;
+  const int want = (f->dim & 3) == 0 ? f->dim / 4 : f->dim;
+  while (G < 64 && G < want) G <<= 1;
+  const int64_t threads = n * G;
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->dim, node_ids,
+                                                                       n, default_attr, out, G);
+    GLX_HIP(hipGetLastError());
+    return GLX_OK;
+  }
+  const size_t out_bytes = (size_t)n * f->dim * 4;
+  char* d = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), out_bytes + (size_t)n * 8, s);
+  if (rc != GLX_OK) return rc;
+  float* d_out = reinterpret_cast<float*>(d);
+  int64_t* d_ids = reinterpret_cast<int64_t*>(d + out_bytes);
+  hipError_t e = hipMemcpyAsync(d_ids, node_ids, (size_t)n * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->dim, d_ids, n,
+                                                                       default_attr, d_out, G);
+    e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s);
+  }
+  hipError_t e2 = hipStreamSynchronize(s);
+  glx_scratch_free(d, s);
+  GLX_HIP(e);
+  GLX_HIP(e2);
+  return GLX_OK;
+}

@@ -1,0 +1,170 @@
+// glx internal header: handle layouts, error plumbing, the contract RNG and the
+// id->row translation shared by every kernel.  gfx950 (CDNA4) only; wave = 64.
+#ifndef GLX_COMMON_H_
+#define GLX_COMMON_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "glx.h"
+
+#define GLX_WAVE 64
+
+// ---------------------------------------------------------------- errors ----
+void glx_set_error(const char* fmt, ...);
+
+#define GLX_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      glx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,   \
+                    __LINE__);                                                          \
+      return e__ == hipErrorOutOfMemory ? GLX_RESOURCE_EXHAUSTED : GLX_INTERNAL;        \
+    }                                                                                   \
+  } while (0)
+
+#define GLX_REQUIRE(cond, ...)         \
+  do {                                 \
+    if (!(cond)) {                     \
+      glx_set_error(__VA_ARGS__);      \
+      return GLX_INVALID_ARGUMENT;     \
+    }                                  \
+  } while (0)
+
+// RAII device guard: every entry point runs on the handle's device and restores
+// the caller's current device (one process may drive several GPUs).
+struct GlxDeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit GlxDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) return;
+    ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+    if (prev == dev) prev = -1;
+  }
+  ~GlxDeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// Stream-ordered scratch (pool keeps memory cached: see glx_init_device).
+int glx_init_device(int device);
+int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s);
+void glx_scratch_free(void* p, hipStream_t s);
+
+// ---------------------------------------------------------- id -> row map ---
+// Open-addressing table over raw int64 ids (AutoIndex::Get, auto_indexing.cc:26-33).
+// keys == nullptr means the dense identity map (raw id v is row v).
+#define GLX_EMPTY_KEY INT64_MIN
+struct GlxIdMap {
+  const int64_t* keys;  // [cap], GLX_EMPTY_KEY = free slot
+  const int32_t* vals;  // [cap]
+  uint64_t mask;        // cap - 1 (cap is a power of two)
+  int64_t num_rows;
+};
+
+__host__ __device__ __forceinline__ uint64_t glx_mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+__device__ __forceinline__ int64_t glx_row_of(const GlxIdMap& m, int64_t id) {
+  if (m.keys == nullptr) return (id >= 0 && id < m.num_rows) ? id : -1;
+  if (id == GLX_EMPTY_KEY) return -1;
+  uint64_t h = glx_mix64((uint64_t)id) & m.mask;
+  while (true) {
+    int64_t k = m.keys[h];
+    if (k == id) return m.vals[h];
+    if (k == GLX_EMPTY_KEY) return -1;
+    h = (h + 1) & m.mask;
+  }
+}
+
+struct GlxIdMapStorage {
+  int64_t* keys = nullptr;
+  int32_t* vals = nullptr;
+  uint64_t cap = 0;
+};
+// Builds the table for ids[num_rows] (device pointer) on `s`.
+int glx_idmap_build(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out, hipStream_t s);
+void glx_idmap_free(GlxIdMapStorage* m);
+
+// ---------------------------------------------------------------- handles ---
+struct GlxAdj {  // one CSR slot: a single 16-byte gather per draw
+  int64_t nbr;
+  int64_t eid;
+};
+struct GlxAlias {  // AliasMethod probs_/alias_ of the slot's row (row-local index)
+  float prob;
+  int32_t alias;
+};
+
+struct glx_graph {
+  int device;
+  int64_t num_rows, num_edges;
+  int64_t* row_ptr;  // [V+1]
+  GlxAdj* adj;       // [E] 16-byte aligned records
+  float* weight;     // [E] or nullptr
+  GlxAlias* alias;   // [E] or nullptr
+  GlxIdMapStorage idmap;
+  GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
+};
+
+struct glx_features {
+  int device;
+  int64_t num_rows;
+  int32_t dim;
+  float* X;  // [V, D] row-major, base 256-byte aligned
+  GlxIdMapStorage idmap;
+  GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
+};
+
+// ------------------------------------------------------------- contract RNG -
+// Philox4x32-10; key = (seed lo, seed hi); counter = (j >> 1, row, cc lo, cc hi).
+// Draw j of a row is words {2(j&1), 2(j&1)+1} of block j >> 1.
+struct GlxPhilox {
+  uint32_t w[4];
+};
+
+__device__ __forceinline__ GlxPhilox glx_philox_block(uint32_t blk, uint32_t row, uint64_t seed,
+                                                      uint64_t cc) {
+  uint32_t c0 = blk, c1 = row, c2 = (uint32_t)cc, c3 = (uint32_t)(cc >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return GlxPhilox{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ uint64_t glx_draw_of(const GlxPhilox& b, uint32_t j) {
+  return (j & 1u) ? (((uint64_t)b.w[3] << 32) | b.w[2]) : (((uint64_t)b.w[1] << 32) | b.w[0]);
+}
+
+__device__ __forceinline__ uint64_t glx_draw64(uint64_t seed, uint64_t cc, uint32_t row,
+                                               uint32_t j) {
+  return glx_draw_of(glx_philox_block(j >> 1, row, seed, cc), j);
+}
+
+// [0, n): high 64 bits of u * n.
+__device__ __forceinline__ uint64_t glx_bounded(uint64_t u, uint64_t n) { return __umul64hi(u, n); }
+
+// alias_method.cc:117-121 under the contract: rand = float(U53 * (deg - 1)).
+__device__ __forceinline__ int32_t glx_alias_pick(uint64_t u, int64_t deg,
+                                                  const GlxAlias* __restrict__ row_alias) {
+  double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
+  float rnd = (float)rd;
+  int32_t ix = (int32_t)rnd;
+  GlxAlias a = row_alias[ix];
+  return (a.prob <= (rnd - (float)ix)) ? a.alias : ix;
+}
+
+static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#endif  // GLX_COMMON_H_

@@ -1,0 +1,398 @@
+// glx graph storage: device CSR (64-bit row_ptr, interleaved {nbr, eid} slots),
+// per-row alias tables built once on the device, optional id->row hash map.
+// Replaces graphlearn/src/core/graph/storage/{memory_adj_matrix.cc:159-225,
+// auto_indexing.cc:21-33} + the per-request AliasMethod::Build of
+// edge_weight_sampler.cc:78-92 (alias_method.cc:57-107).
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+
+#include "glx_common.h"
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[512] = "";
+
+void glx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* glx_last_error(void) { return g_err; }
+extern "C" int glx_abi_version(void) { return GLX_ABI_VERSION; }
+
+extern "C" int glx_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    if (count) *count = 0;
+    glx_set_error("no usable HIP device (%s); glx has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return GLX_UNAVAILABLE;
+  }
+  if (count) *count = n;
+  return GLX_OK;
+}
+
+int glx_init_device(int device) {
+  static std::mutex mtx;
+  static bool done[64] = {false};
+  std::lock_guard<std::mutex> g(mtx);
+  if (device < 0 || device >= 64) {
+    glx_set_error("bad device index %d", device);
+    return GLX_INVALID_ARGUMENT;
+  }
+  if (done[device]) return GLX_OK;
+  int n = 0;
+  int rc = glx_device_count(&n);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(device < n, "device %d out of range (%d visible)", device, n);
+  // Keep stream-ordered scratch cached in the pool instead of returning it to
+  // the driver at every synchronisation point.
+  hipMemPool_t pool;
+  GLX_HIP(hipDeviceGetDefaultMemPool(&pool, device));
+  uint64_t thr = UINT64_MAX;
+  GLX_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+  done[device] = true;
+  return GLX_OK;
+}
+
+int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) bytes = 16;
+  GLX_HIP(hipMallocAsync(p, bytes, s));
+  return GLX_OK;
+}
+
+void glx_scratch_free(void* p, hipStream_t s) {
+  if (p) (void)hipFreeAsync(p, s);
+}
+
+// ------------------------------------------------------------------ id map --
+__global__ void glx_idmap_fill_kernel(int64_t* keys, uint64_t cap) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) keys[i] = GLX_EMPTY_KEY;
+}
+
+// Ids are unique per storage (AutoIndex inserts once per new id); if a caller
+// passes duplicates the smallest row wins (first-insertion order).
+__global__ void glx_idmap_insert_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t* keys,
+                                        int32_t* vals, uint64_t mask) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int64_t id = ids[r];
+  if (id == GLX_EMPTY_KEY) return;
+  uint64_t h = glx_mix64((uint64_t)id) & mask;
+  while (true) {
+    unsigned long long prev =
+        atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]),
+                  (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)id);
+    if ((int64_t)prev == GLX_EMPTY_KEY) {
+      atomicMin(&vals[h], (int32_t)r);
+      return;
+    }
+    if ((int64_t)prev == id) {
+      atomicMin(&vals[h], (int32_t)r);
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+__global__ void glx_fill_i32_kernel(int32_t* p, uint64_t n, int32_t v) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+int glx_idmap_build(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out, hipStream_t s) {
+  uint64_t cap = 64;
+  while (cap < (uint64_t)num_rows * 2) cap <<= 1;
+  GLX_HIP(hipMalloc(&out->keys, cap * sizeof(int64_t)));
+  GLX_HIP(hipMalloc(&out->vals, cap * sizeof(int32_t)));
+  out->cap = cap;
+  int blocks = (int)((cap + 255) / 256 < 4096 ? (cap + 255) / 256 : 4096);
+  glx_idmap_fill_kernel<<<blocks, 256, 0, s>>>(out->keys, cap);
+  glx_fill_i32_kernel<<<blocks, 256, 0, s>>>(out->vals, cap, INT32_MAX);
+  if (num_rows > 0) {
+    glx_idmap_insert_kernel<<<(unsigned)((num_rows + 255) / 256), 256, 0, s>>>(
+        d_ids, num_rows, out->keys, out->vals, cap - 1);
+  }
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+void glx_idmap_free(GlxIdMapStorage* m) {
+  if (m->keys) (void)hipFree(m->keys);
+  if (m->vals) (void)hipFree(m->vals);
+  m->keys = nullptr;
+  m->vals = nullptr;
+  m->cap = 0;
+}
+
+// ------------------------------------------------------------ CSR kernels --
+// flag bits: 1 = row_ptr not monotone / bad ends.
+__global__ void glx_check_row_ptr_kernel(const int64_t* __restrict__ row_ptr, int64_t V, int64_t E,
+                                         int* flag) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r == 0 && (row_ptr[0] != 0 || row_ptr[V] != E)) atomicOr(flag, 1);
+  if (r < V && row_ptr[r + 1] < row_ptr[r]) atomicOr(flag, 1);
+}
+
+// SoA (col[], eid[]) -> 16-byte {nbr, eid} slots: one dwordx4 gather per draw.
+__global__ void glx_pack_adj_kernel(const int64_t* __restrict__ col, const int64_t* __restrict__ eid,
+                                    int64_t E, GlxAdj* __restrict__ adj) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < E; i += stride) adj[i] = GlxAdj{col[i], eid[i]};
+}
+
+// AliasMethod::Build (alias_method.cc:57-107), one lane per row, bit-identical
+// to the serial reference: LIFO low/high stacks (kept in `stk`: low grows up
+// from the row's first slot, high grows down from its last; |low|+|high| <= deg
+// always), sum accumulated in double then narrowed to float (:73), float
+// arithmetic without contraction (-ffp-contract=off).
+__global__ void glx_alias_build_kernel(const int64_t* __restrict__ row_ptr,
+                                       const float* __restrict__ weight, int64_t V,
+                                       GlxAlias* __restrict__ out, int32_t* __restrict__ stk) {
+  int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (row >= V) return;
+  const int64_t s = row_ptr[row];
+  const int32_t count = (int32_t)(row_ptr[row + 1] - s);
+  if (count == 0) return;
+  const float* dist = weight + s;
+  GlxAlias* tab = out + s;
+  int32_t* low = stk + s;
+  int32_t* high = stk + s + count - 1;  // high[-h]
+  const float avg_prob = (float)(1.0 / (double)count);
+  double acc = 0.0;
+  for (int32_t i = 0; i < count; ++i) acc += (double)dist[i];
+  const float sum = (float)acc;
+  int32_t low_num = 0, high_num = 0;
+  for (int32_t i = 0; i < count; ++i) {
+    float prob = dist[i] / sum;
+    tab[i] = GlxAlias{prob * (float)count, i};
+    if (prob < avg_prob) {
+      low[low_num++] = i;
+    } else if (prob > avg_prob) {
+      high[-(high_num++)] = i;
+    }
+  }
+  while (low_num > 0 && high_num > 0) {
+    int32_t low_idx = low[--low_num];
+    int32_t high_idx = high[-(--high_num)];
+    float p = tab[high_idx].prob - 1.0f + tab[low_idx].prob;
+    tab[high_idx].prob = p;
+    tab[low_idx].alias = high_idx;
+    if (p < 1.0f) {
+      low[low_num++] = high_idx;
+    } else if (p > 1.0f) {
+      high[-(high_num++)] = high_idx;
+    }
+  }
+  while (low_num > 0) tab[low[--low_num]].prob = 1.0f;
+  while (high_num > 0) tab[high[-(--high_num)]].prob = 1.0f;
+}
+
+__global__ void glx_unpack_alias_kernel(const GlxAlias* __restrict__ tab, int64_t E,
+                                        float* __restrict__ prob, int32_t* __restrict__ alias) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < E; i += stride) {
+    GlxAlias a = tab[i];
+    prob[i] = a.prob;
+    alias[i] = a.alias;
+  }
+}
+
+__global__ void glx_degrees_kernel(GlxIdMap map, const int64_t* __restrict__ row_ptr,
+                                   const int64_t* __restrict__ src, int64_t n,
+                                   int64_t* __restrict__ deg) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t row = glx_row_of(map, src[i]);
+  deg[i] = row < 0 ? 0 : row_ptr[row + 1] - row_ptr[row];
+}
+
+static inline unsigned grid_for(int64_t n, int cap = 8192) {
+  int64_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b < cap ? b : cap);
+}
+
+// ----------------------------------------------------------------- create --
+static void graph_free(glx_graph* g) {
+  if (!g) return;
+  if (g->row_ptr) (void)hipFree(g->row_ptr);
+  if (g->adj) (void)hipFree(g->adj);
+  if (g->weight) (void)hipFree(g->weight);
+  if (g->alias) (void)hipFree(g->alias);
+  glx_idmap_free(&g->idmap);
+  delete g;
+}
+
+static int graph_create_impl(glx_graph* g, const int64_t* row_ptr, const int64_t* col,
+                             const int64_t* eid, const float* weight, const int64_t* ids,
+                             int ptr_kind, hipStream_t s) {
+  const int64_t V = g->num_rows, E = g->num_edges;
+  const hipMemcpyKind kind = ptr_kind == GLX_PTR_HOST ? hipMemcpyHostToDevice
+                                                      : hipMemcpyDeviceToDevice;
+  GLX_HIP(hipMalloc(&g->row_ptr, (size_t)(V + 1) * sizeof(int64_t)));
+  GLX_HIP(hipMalloc(&g->adj, (size_t)(E > 0 ? E : 1) * sizeof(GlxAdj)));
+  GLX_HIP(hipMemcpyAsync(g->row_ptr, row_ptr, (size_t)(V + 1) * sizeof(int64_t), kind, s));
+
+  int* d_flag = nullptr;
+  GLX_HIP(hipMalloc(&d_flag, sizeof(int)));
+  GLX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+  glx_check_row_ptr_kernel<<<(unsigned)((V + 256) / 256), 256, 0, s>>>(g->row_ptr, V, E, d_flag);
+
+  // Stage col/eid on the device (host input) then pack them into 16-byte slots.
+  const int64_t* d_col = col;
+  const int64_t* d_eid = eid;
+  int64_t* tmp = nullptr;
+  if (ptr_kind == GLX_PTR_HOST && E > 0) {
+    GLX_HIP(hipMalloc(&tmp, (size_t)E * 2 * sizeof(int64_t)));
+    GLX_HIP(hipMemcpyAsync(tmp, col, (size_t)E * sizeof(int64_t), kind, s));
+    GLX_HIP(hipMemcpyAsync(tmp + E, eid, (size_t)E * sizeof(int64_t), kind, s));
+    d_col = tmp;
+    d_eid = tmp + E;
+  }
+  if (E > 0) glx_pack_adj_kernel<<<grid_for(E), 256, 0, s>>>(d_col, d_eid, E, g->adj);
+
+  if (weight) {
+    GLX_HIP(hipMalloc(&g->weight, (size_t)(E > 0 ? E : 1) * sizeof(float)));
+    GLX_HIP(hipMalloc(&g->alias, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
+    if (E > 0) {
+      GLX_HIP(hipMemcpyAsync(g->weight, weight, (size_t)E * sizeof(float), kind, s));
+      int32_t* stk = nullptr;
+      GLX_HIP(hipMalloc(&stk, (size_t)E * sizeof(int32_t)));
+      glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(g->row_ptr, g->weight, V,
+                                                                      g->alias, stk);
+      GLX_HIP(hipStreamSynchronize(s));
+      GLX_HIP(hipFree(stk));
+    }
+  }
+
+  if (ids) {
+    const int64_t* d_ids = ids;
+    int64_t* tmp_ids = nullptr;
+    if (ptr_kind == GLX_PTR_HOST) {
+      GLX_HIP(hipMalloc(&tmp_ids, (size_t)(V > 0 ? V : 1) * sizeof(int64_t)));
+      GLX_HIP(hipMemcpyAsync(tmp_ids, ids, (size_t)V * sizeof(int64_t), kind, s));
+      d_ids = tmp_ids;
+    }
+    int rc = glx_idmap_build(d_ids, V, &g->idmap, s);
+    GLX_HIP(hipStreamSynchronize(s));
+    if (tmp_ids) (void)hipFree(tmp_ids);
+    if (rc != GLX_OK) return rc;
+  }
+
+  int flag = 0;
+  GLX_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  GLX_HIP(hipGetLastError());
+  (void)hipFree(d_flag);
+  if (tmp) (void)hipFree(tmp);
+  GLX_REQUIRE(flag == 0, "row_ptr must start at 0, end at num_edges and be non-decreasing");
+  return GLX_OK;
+}
+
+extern "C" int glx_graph_create(int device, int64_t num_rows, int64_t num_edges,
+                                const int64_t* row_ptr, const int64_t* col, const int64_t* eid,
+                                const float* weight, const int64_t* ids, int ptr_kind, void* stream,
+                                glx_graph** out) {
+  GLX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  GLX_REQUIRE(num_rows >= 0 && num_edges >= 0, "negative sizes");
+  GLX_REQUIRE(num_rows < INT32_MAX, "num_rows must be < 2^31 (row indices are int32 in the id map)");
+  GLX_REQUIRE(row_ptr && (num_edges == 0 || (col && eid)), "row_ptr/col/eid must not be NULL");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  int rc = glx_init_device(device);
+  if (rc != GLX_OK) return rc;
+  GlxDeviceGuard guard(device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", device);
+  glx_graph* g = new (std::nothrow) glx_graph();
+  GLX_REQUIRE(g != nullptr, "out of host memory");
+  memset(static_cast<void*>(g), 0, sizeof(*g));
+  g->device = device;
+  g->num_rows = num_rows;
+  g->num_edges = num_edges;
+  rc = graph_create_impl(g, row_ptr, col, eid, weight, ids, ptr_kind, glx_stream(stream));
+  if (rc != GLX_OK) {
+    graph_free(g);
+    return rc;
+  }
+  *out = g;
+  return GLX_OK;
+}
+
+extern "C" void glx_graph_destroy(glx_graph* g) {
+  if (!g) return;
+  GlxDeviceGuard guard(g->device);
+  graph_free(g);
+}
+
+extern "C" int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges,
+                              int* weighted, int* has_id_map, int* device) {
+  GLX_REQUIRE(g != nullptr, "graph is NULL");
+  if (num_rows) *num_rows = g->num_rows;
+  if (num_edges) *num_edges = g->num_edges;
+  if (weighted) *weighted = g->alias != nullptr;
+  if (has_id_map) *has_id_map = g->idmap.keys != nullptr;
+  if (device) *device = g->device;
+  return GLX_OK;
+}
+
+extern "C" int glx_graph_export_alias(const glx_graph* g, float* prob, int32_t* alias,
+                                      int ptr_kind, void* stream) {
+  GLX_REQUIRE(g && prob && alias, "NULL argument");
+  GLX_REQUIRE(g->alias != nullptr, "graph has no weights, hence no alias table");
+  GlxDeviceGuard guard(g->device);
+  hipStream_t s = glx_stream(stream);
+  const int64_t E = g->num_edges;
+  if (E == 0) return GLX_OK;
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    glx_unpack_alias_kernel<<<grid_for(E), 256, 0, s>>>(g->alias, E, prob, alias);
+    GLX_HIP(hipGetLastError());
+    return GLX_OK;
+  }
+  float* d_prob = nullptr;
+  int32_t* d_alias = nullptr;
+  GLX_HIP(hipMalloc(&d_prob, (size_t)E * sizeof(float)));
+  GLX_HIP(hipMalloc(&d_alias, (size_t)E * sizeof(int32_t)));
+  glx_unpack_alias_kernel<<<grid_for(E), 256, 0, s>>>(g->alias, E, d_prob, d_alias);
+  GLX_HIP(hipMemcpyAsync(prob, d_prob, (size_t)E * sizeof(float), hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipMemcpyAsync(alias, d_alias, (size_t)E * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  (void)hipFree(d_prob);
+  (void)hipFree(d_alias);
+  return GLX_OK;
+}
+
+extern "C" int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t n,
+                                 int64_t* deg_out, int ptr_kind, void* stream) {
+  GLX_REQUIRE(g && (n == 0 || (src && deg_out)), "NULL argument");
+  GLX_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return GLX_OK;
+  GlxDeviceGuard guard(g->device);
+  hipStream_t s = glx_stream(stream);
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    glx_degrees_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->map(), g->row_ptr, src, n,
+                                                                   deg_out);
+    GLX_HIP(hipGetLastError());
+    return GLX_OK;
+  }
+  int64_t* d = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), (size_t)n * 2 * sizeof(int64_t), s);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(hipMemcpyAsync(d, src, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  glx_degrees_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->map(), g->row_ptr, d, n, d + n);
+  GLX_HIP(hipMemcpyAsync(deg_out, d + n, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  glx_scratch_free(d, s);
+  return GLX_OK;
+}

@@ -1,0 +1,181 @@
+// glx shard exchange helpers: device-side HashPartitioner + Stitcher.
+// Replaces graphlearn/src/core/partition/hash_partitioner.h:33-92 (shard =
+// llabs(id) % P, stable inside a shard, Sticker = original indices) and
+// graphlearn/src/core/partition/stitcher.h:67-107 (scatter rows back by
+// sticker).  These run between the two RCCL all-to-alls of a sharded request;
+// the exchange itself is done by the caller (torch.distributed / RCCL).
+#include "glx_common.h"
+
+namespace {
+
+constexpr int kTile = 2048;  // ids per workgroup (8 passes of 256)
+constexpr int kMaxShards = 64;
+
+__device__ __forceinline__ int32_t shard_of(int64_t id, int32_t P) {
+  // llabs(id) % P (hash_partitioner.h:90-92)
+  uint64_t a = id < 0 ? (uint64_t)0 - (uint64_t)id : (uint64_t)id;
+  return (int32_t)(a % (uint64_t)P);
+}
+
+// block_counts is shard-major: [P][nblocks].
+__global__ __launch_bounds__(256) void glx_part_count_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                             int32_t P, int64_t nblocks,
+                                                             int64_t* __restrict__ block_counts) {
+  __shared__ int32_t cnt[kMaxShards];
+  if (threadIdx.x < kMaxShards) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = blockIdx.x * (int64_t)kTile;
+  for (int it = 0; it < kTile / 256; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[shard_of(ids[i], P)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < P) block_counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// Exclusive scan of the flattened [P * nblocks] counts (single workgroup), plus
+// per-shard totals.
+__global__ __launch_bounds__(1024) void glx_part_scan_kernel(int64_t* __restrict__ block_counts,
+                                                             int64_t nblocks, int32_t P,
+                                                             int64_t* __restrict__ counts) {
+  __shared__ int64_t wave_sum[16];
+  __shared__ int64_t carry_s;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int64_t total = (int64_t)P * nblocks;
+  for (int64_t base = 0; base < total; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int64_t v = i < total ? block_counts[i] : 0;
+    int64_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int64_t y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wave_sum[w];
+    const int64_t carry = carry_s;
+    if (i < total) block_counts[i] = carry + woff + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  // shard totals from the scanned offsets
+  if (threadIdx.x < P) {
+    const int64_t p = threadIdx.x;
+    const int64_t begin = block_counts[p * nblocks];
+    const int64_t end = (p + 1 < P) ? block_counts[(p + 1) * nblocks] : carry_s;
+    counts[p] = end - begin;
+  }
+}
+
+__global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                               int32_t P, int64_t nblocks,
+                                                               const int64_t* __restrict__ block_off,
+                                                               int64_t* __restrict__ bucketed,
+                                                               int64_t* __restrict__ order) {
+  __shared__ int64_t run[kMaxShards];       // next output position per shard for this block
+  __shared__ int32_t wave_cnt[4][kMaxShards];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x < P) run[threadIdx.x] = block_off[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+  __syncthreads();
+  const int64_t base = blockIdx.x * (int64_t)kTile;
+  for (int it = 0; it < kTile / 256; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t id = valid ? ids[i] : 0;
+    const int32_t sh = valid ? shard_of(id, P) : -1;
+    int32_t my_rank = 0;
+    for (int32_t p = 0; p < P; ++p) {
+      const uint64_t b = __ballot(sh == p);
+      if (sh == p) my_rank = __popcll(b & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[wid][p] = __popcll(b);
+    }
+    __syncthreads();
+    if (valid) {
+      int64_t pos = run[sh] + my_rank;
+      for (int w = 0; w < wid; ++w) pos += wave_cnt[w][sh];
+      bucketed[pos] = id;
+      order[pos] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x < P) {
+      run[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] +
+                          wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void glx_stitch_kernel(const T* __restrict__ in,
+                                                         const int64_t* __restrict__ order, int64_t n,
+                                                         int32_t width, T* __restrict__ out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = n * width;
+  if (t >= total) return;
+  const int64_t i = t / width;
+  const int32_t c = (int32_t)(t - i * width);
+  out[order[i] * width + c] = in[t];
+}
+
+}  // namespace
+
+extern "C" int glx_partition(int device, const int64_t* ids, int64_t n, int32_t num_shards,
+                             int64_t* bucketed, int64_t* order, int64_t* counts, void* stream) {
+  GLX_REQUIRE(num_shards >= 1 && num_shards <= kMaxShards, "num_shards must be in [1, %d]", kMaxShards);
+  GLX_REQUIRE(n >= 0, "negative n");
+  GLX_REQUIRE(counts != nullptr && (n == 0 || (ids && bucketed && order)), "NULL data pointer");
+  int rc = glx_init_device(device);
+  if (rc != GLX_OK) return rc;
+  GlxDeviceGuard guard(device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", device);
+  hipStream_t s = glx_stream(stream);
+  if (n == 0) {
+    GLX_HIP(hipMemsetAsync(counts, 0, (size_t)num_shards * sizeof(int64_t), s));
+    return GLX_OK;
+  }
+  const int64_t nblocks = (n + kTile - 1) / kTile;
+  int64_t* block_counts = nullptr;
+  rc = glx_scratch_alloc(reinterpret_cast<void**>(&block_counts),
+                         (size_t)num_shards * nblocks * sizeof(int64_t), s);
+  if (rc != GLX_OK) return rc;
+  glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_shards, nblocks, block_counts);
+  glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_shards, counts);
+  glx_part_scatter_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_shards, nblocks, block_counts,
+                                                           bucketed, order);
+  hipError_t e = hipGetLastError();
+  glx_scratch_free(block_counts, s);
+  GLX_HIP(e);
+  return GLX_OK;
+}
+
+template <typename T>
+static int stitch_impl(int device, const T* in, const int64_t* order, int64_t n, int32_t width, T* out,
+                       void* stream) {
+  GLX_REQUIRE(n >= 0 && width >= 1, "bad sizes");
+  if (n == 0) return GLX_OK;
+  GLX_REQUIRE(in && order && out, "NULL data pointer");
+  int rc = glx_init_device(device);
+  if (rc != GLX_OK) return rc;
+  GlxDeviceGuard guard(device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", device);
+  const int64_t total = n * width;
+  glx_stitch_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, glx_stream(stream)>>>(in, order, n,
+                                                                                       width, out);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+extern "C" int glx_stitch_i64(int device, const int64_t* in, const int64_t* order, int64_t n,
+                              int32_t width, int64_t* out, void* stream) {
+  return stitch_impl<int64_t>(device, in, order, n, width, out, stream);
+}
+
+extern "C" int glx_stitch_f32(int device, const float* in, const int64_t* order, int64_t n,
+                              int32_t width, float* out, void* stream) {
+  return stitch_impl<float>(device, in, order, n, width, out, stream);
+}

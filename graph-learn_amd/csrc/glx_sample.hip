@@ -1,0 +1,311 @@
+// glx neighbour samplers: RandomSampler, RandomWithoutReplacementSampler,
+// EdgeWeightSampler (alias), TopkSampler + circular / replicate padding.
+// Replaces graphlearn/src/core/operator/sampler/{random_sampler.cc:33-76,
+// random_without_replacement_sampler.cc:31-75, edge_weight_sampler.cc:31-92,
+// alias_method.cc:109-124, topk_sampler.cc:29-68, padder/*.h}.
+//
+// HBM-bound integer work: the kernels are organised around the memory system,
+// not around arithmetic.  Output slots are the unit of parallelism (a request
+// has batch*k of them, >> 256 CUs x 32 waves), every draw costs exactly one
+// 16-byte {nbr, eid} gather (+ one 8-byte alias gather for EdgeWeight), and the
+// [batch, k] outputs are written fully coalesced.
+#include "glx_common.h"
+
+namespace {
+
+struct SampleArgs {
+  GlxIdMap map;
+  const int64_t* row_ptr;
+  const GlxAdj* adj;
+  const GlxAlias* alias;
+  const int64_t* src;
+  int64_t* nbr_out;
+  int64_t* eid_out;
+  int64_t default_nbr;
+  uint64_t seed;
+  uint64_t cc;
+  int32_t batch;
+  int32_t k;
+};
+
+enum SlotOp { kSlotRandom = 0, kSlotEdgeWeight = 1, kSlotCircular = 2, kSlotReplicate = 3 };
+
+// One thread = two consecutive output slots (2q, 2q+1) of one request row, i.e.
+// exactly one Philox block for the randomised ops.  Consecutive lanes own
+// consecutive slot pairs, so the nbr/eid stores of a wave cover one contiguous
+// 1 KiB span each.
+template <int OP>
+__global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int32_t kpairs) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.batch * kpairs;
+  if (t >= total) return;
+  const int32_t i = (int32_t)(t / kpairs);
+  const int32_t q = (int32_t)(t - (int64_t)i * kpairs);
+  const int64_t row = glx_row_of(a.map, a.src[i]);
+  int64_t start = 0, deg = 0;
+  if (row >= 0) {
+    start = a.row_ptr[row];
+    deg = a.row_ptr[row + 1] - start;
+  }
+  const int64_t obase = (int64_t)i * a.k;
+  GlxPhilox blk;
+  if (OP == kSlotRandom || OP == kSlotEdgeWeight) {
+    if (deg > 0) blk = glx_philox_block((uint32_t)q, (uint32_t)i, a.seed, a.cc);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int32_t j = 2 * q + h;
+    if (j >= a.k) break;
+    int64_t pick = -1;
+    if (deg > 0) {
+      if (OP == kSlotRandom) {
+        // random_sampler.cc:61-63: uniform index in [0, deg).
+        pick = (int64_t)glx_bounded(glx_draw_of(blk, (uint32_t)j), (uint64_t)deg);
+      } else if (OP == kSlotEdgeWeight) {
+        // alias_method.cc:117-121 then CircularPadder with indices.size()==k.
+        pick = glx_alias_pick(glx_draw_of(blk, (uint32_t)j), deg, a.alias + start);
+      } else if (OP == kSlotCircular) {
+        // circular_padder.h:46-63 over iota(deg) (TopkSampler).
+        pick = j % deg;
+      } else {
+        // replicate_padder.h:37-56: first min(k, deg) slots, then default fill.
+        pick = j < deg ? j : -1;
+      }
+    }
+    GlxAdj r = GlxAdj{a.default_nbr, -1};
+    if (pick >= 0) r = a.adj[start + pick];
+    a.nbr_out[obase + j] = r.nbr;
+    a.eid_out[obase + j] = r.eid;
+  }
+}
+
+// RandomWithoutReplacement, circular padding, k <= W <= 64.
+// A sub-group of W lanes owns one request row.  The contract permutation is a
+// forward Fisher-Yates over the virtual array A[p] = p: step j swaps A[j] with
+// A[r_j], r_j = j + bounded(draw_j, deg - j).  Only min(k, deg) steps matter,
+// and only the <= k touched entries of A are ever materialised: lane t keeps
+// r_t and w_t = A[t] at time t (the value step t moved into A[r_t]).  Looking
+// A[p] up at step j is "the latest t < j with r_t == p" -- one ballot + one
+// highest-set-bit per lookup -- so a row costs k cheap wave steps and touches
+// HBM only for the k selected slots (no O(deg) scan of hub rows).
+template <int W>
+__global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int l = lane & (W - 1);
+  const int base = lane - l;
+  const uint64_t wmask = (W == 64) ? ~0ull : ((1ull << W) - 1ull);
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / W;
+  const bool active = i < a.batch;
+  int64_t start = 0, deg = 0;
+  if (active) {
+    const int64_t row = glx_row_of(a.map, a.src[i]);
+    if (row >= 0) {
+      start = a.row_ptr[row];
+      deg = a.row_ptr[row + 1] - start;
+    }
+  }
+  const int32_t m = (int32_t)(deg < a.k ? deg : a.k);
+  int32_t r = -1;
+  if (l < m) {
+    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, (uint32_t)i, (uint32_t)l),
+                                 (uint64_t)(deg - l));
+  }
+  int32_t w = 0, perm = 0;
+  for (int32_t j = 0; j < a.k; ++j) {
+    const bool in = j < m;
+    if (!__any(in)) break;
+    const int32_t rj = __shfl(r, base + j);
+    const bool earlier = in && l < j;
+    const uint64_t bw = (__ballot(earlier && r == j) >> base) & wmask;
+    const uint64_t bp = (__ballot(earlier && r == rj) >> base) & wmask;
+    const int tw = bw ? 63 - __clzll(bw) : -1;
+    const int tp = bp ? 63 - __clzll(bp) : -1;
+    const int32_t wsrc = __shfl(w, base + (tw < 0 ? 0 : tw));
+    const int32_t psrc = __shfl(w, base + (tp < 0 ? 0 : tp));
+    if (in && l == j) {
+      w = tw < 0 ? j : wsrc;
+      perm = tp < 0 ? rj : psrc;
+    }
+  }
+  // Slot l of the row: circular_padder.h:46-63 with indices_ = the permutation.
+  const bool has_slot = l < a.k;
+  const int32_t c = (has_slot && m > 0) ? l % m : 0;
+  const int32_t pc = __shfl(perm, base + c);
+  if (active && has_slot) {
+    GlxAdj rec = GlxAdj{a.default_nbr, -1};
+    if (m > 0) rec = a.adj[start + pc];
+    a.nbr_out[i * a.k + l] = rec.nbr;
+    a.eid_out[i * a.k + l] = rec.eid;
+  }
+}
+
+// Same algorithm for 64 < k <= 8192: one wave per row, r/w/perm in LDS, the
+// "latest t < j" lookup is a strided scan + wave max.
+__device__ __forceinline__ int32_t glx_wave_max_i32(int32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int32_t o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void glx_rwor_lds_kernel(SampleArgs a) {
+  extern __shared__ int32_t lds[];
+  const int lane = threadIdx.x;
+  const int32_t k = a.k;
+  int32_t* r = lds;
+  int32_t* w = lds + k;
+  int32_t* perm = lds + 2 * k;
+  const int64_t i = blockIdx.x;
+  const int64_t row = glx_row_of(a.map, a.src[i]);
+  int64_t start = 0, deg = 0;
+  if (row >= 0) {
+    start = a.row_ptr[row];
+    deg = a.row_ptr[row + 1] - start;
+  }
+  const int32_t m = (int32_t)(deg < k ? deg : k);
+  for (int32_t t = lane; t < m; t += 64) {
+    r[t] = t + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, (uint32_t)i, (uint32_t)t),
+                                    (uint64_t)(deg - t));
+  }
+  __syncthreads();
+  for (int32_t j = 0; j < m; ++j) {
+    const int32_t rj = r[j];
+    int32_t tw = -1, tp = -1;
+    for (int32_t t = lane; t < j; t += 64) {
+      const int32_t rt = r[t];
+      if (rt == j) tw = t;
+      if (rt == rj) tp = t;
+    }
+    tw = glx_wave_max_i32(tw);
+    tp = glx_wave_max_i32(tp);
+    if (lane == 0) {
+      w[j] = tw < 0 ? j : w[tw];
+      perm[j] = tp < 0 ? rj : w[tp];
+    }
+    __syncthreads();
+  }
+  for (int32_t j = lane; j < k; j += 64) {
+    GlxAdj rec = GlxAdj{a.default_nbr, -1};
+    if (m > 0) rec = a.adj[start + perm[j % m]];
+    a.nbr_out[i * k + j] = rec.nbr;
+    a.eid_out[i * k + j] = rec.eid;
+  }
+}
+
+template <int OP>
+void launch_slots(const SampleArgs& a, hipStream_t s) {
+  const int32_t kpairs = (a.k + 1) / 2;
+  const int64_t total = (int64_t)a.batch * kpairs;
+  glx_sample_slots_kernel<OP><<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a, kpairs);
+}
+
+template <int W>
+void launch_rwor(const SampleArgs& a, hipStream_t s) {
+  const int64_t threads = (int64_t)a.batch * W;
+  glx_rwor_kernel<W><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+}
+
+int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padding_mode,
+                  hipStream_t s) {
+  const bool circular = padding_mode == GLX_PAD_CIRCULAR;
+  switch (sampler) {
+    case GLX_SAMPLER_RANDOM:
+      launch_slots<kSlotRandom>(a, s);
+      break;
+    case GLX_SAMPLER_EDGE_WEIGHT:
+      GLX_REQUIRE(g->alias != nullptr, "EdgeWeightSampler needs a weighted graph");
+      // Replicate mode: ReplicatePadder ignores the drawn indices and (in the
+      // reference) reads neighbors_[0..k) -- out of bounds when deg < k.  glx
+      // returns the first min(k, deg) slots then default-fills.
+      if (circular) launch_slots<kSlotEdgeWeight>(a, s);
+      else launch_slots<kSlotReplicate>(a, s);
+      break;
+    case GLX_SAMPLER_TOPK:
+      if (circular) launch_slots<kSlotCircular>(a, s);
+      else launch_slots<kSlotReplicate>(a, s);
+      break;
+    case GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT:
+      if (!circular) {
+        // ReplicatePadder discards the shuffle: first min(k, deg) in row order.
+        launch_slots<kSlotReplicate>(a, s);
+      } else if (a.k <= 8) {
+        launch_rwor<8>(a, s);
+      } else if (a.k <= 16) {
+        launch_rwor<16>(a, s);
+      } else if (a.k <= 32) {
+        launch_rwor<32>(a, s);
+      } else if (a.k <= 64) {
+        launch_rwor<64>(a, s);
+      } else {
+        GLX_REQUIRE(a.k <= 8192, "RandomWithoutReplacementSampler supports neighbor_count <= 8192");
+        glx_rwor_lds_kernel<<<(unsigned)a.batch, 64, (size_t)a.k * 3 * sizeof(int32_t), s>>>(a);
+      }
+      break;
+    default:
+      glx_set_error("unknown sampler id %d", sampler);
+      return GLX_INVALID_ARGUMENT;
+  }
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+}  // namespace
+
+extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batch,
+                          int32_t k, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+                          uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+                          void* stream) {
+  GLX_REQUIRE(g != nullptr, "graph is NULL");
+  GLX_REQUIRE(batch >= 0 && k >= 0, "negative batch / neighbor_count");
+  GLX_REQUIRE(padding_mode == GLX_PAD_CIRCULAR || padding_mode == GLX_PAD_REPLICATE,
+              "bad padding_mode %d", padding_mode);
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  // Tensor sizes are int32 in the reference (tensor.h:47): batch*k must fit.
+  GLX_REQUIRE((int64_t)batch * k <= INT32_MAX, "batch * neighbor_count exceeds int32 (tensor.h:47)");
+  if (batch == 0 || k == 0) return GLX_OK;
+  GLX_REQUIRE(src && nbr_out && eid_out, "NULL data pointer");
+  GlxDeviceGuard guard(g->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
+  hipStream_t s = glx_stream(stream);
+
+  SampleArgs a;
+  a.map = g->map();
+  a.row_ptr = g->row_ptr;
+  a.adj = g->adj;
+  a.alias = g->alias;
+  a.default_nbr = default_neighbor_id;
+  a.seed = seed;
+  a.cc = call_counter;
+  a.batch = batch;
+  a.k = k;
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    a.src = src;
+    a.nbr_out = nbr_out;
+    a.eid_out = eid_out;
+    return sample_device(g, sampler, a, padding_mode, s);
+  }
+  // Host pointers: stage through stream-ordered scratch; synchronous.
+  const size_t n_out = (size_t)batch * k;
+  int64_t* d = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch + 2 * n_out) * 8, s);
+  if (rc != GLX_OK) return rc;
+  a.src = d;
+  a.nbr_out = d + batch;
+  a.eid_out = d + batch + n_out;
+  hipError_t e = hipMemcpyAsync(d, src, (size_t)batch * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = sample_device(g, sampler, a, padding_mode, s);
+    if (rc == GLX_OK) {
+      e = hipMemcpyAsync(nbr_out, a.nbr_out, n_out * 8, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(eid_out, a.eid_out, n_out * 8, hipMemcpyDeviceToHost, s);
+    }
+  }
+  hipError_t e2 = hipStreamSynchronize(s);
+  glx_scratch_free(d, s);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(e);
+  GLX_HIP(e2);
+  return GLX_OK;
+}

@@ -1,0 +1,267 @@
+"""ctypes harness over the glx C-ABI (include/glx.h) for tests and bench.py.
+
+This is plumbing, not the product: the product is libglx.so (HIP kernels behind
+the C-ABI) and libglx_host.so (the C++ mirror of graphlearn::op).  numpy arrays
+are passed as host pointers (GLX_PTR_HOST), torch CUDA tensors as device
+pointers (GLX_PTR_DEVICE) on the current torch stream.  There is no CPU
+fallback anywhere: a missing library or a missing GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libglx.so")
+
+PTR_HOST, PTR_DEVICE = 0, 1
+RANDOM, RANDOM_WITHOUT_REPLACEMENT, EDGE_WEIGHT, TOPK = 0, 1, 2, 3
+SUM, MEAN, MAX, MIN, PROD = 0, 1, 2, 3, 4
+PAD_REPLICATE, PAD_CIRCULAR = 0, 1
+
+# registry names of the reference (REGISTER_OPERATOR(...)) -> ids of the C-ABI
+SAMPLER_IDS = {
+    "RandomSampler": RANDOM,
+    "RandomWithoutReplacementSampler": RANDOM_WITHOUT_REPLACEMENT,
+    "EdgeWeightSampler": EDGE_WEIGHT,
+    "TopkSampler": TOPK,
+}
+AGGREGATOR_IDS = {
+    "SumAggregator": SUM,
+    "MeanAggregator": MEAN,
+    "MaxAggregator": MAX,
+    "MinAggregator": MIN,
+    "ProdAggregator": PROD,
+}
+
+EXPORTS = [
+    "glx_abi_version", "glx_device_count", "glx_last_error",
+    "glx_graph_create", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
+    "glx_graph_degrees", "glx_sample",
+    "glx_features_create", "glx_features_destroy", "glx_features_info",
+    "glx_aggregate", "glx_lookup",
+    "glx_partition", "glx_stitch_i64", "glx_stitch_f32",
+]
+
+
+class GlxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("glx error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libglx.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GlxError(14, "libglx.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                               " (expected at %s)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64, u64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
+        ci = ctypes.c_int
+        L.glx_last_error.restype = ctypes.c_char_p
+        L.glx_device_count.argtypes = [ctypes.POINTER(ci)]
+        L.glx_graph_create.argtypes = [ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ctypes.POINTER(vp)]
+        L.glx_graph_destroy.argtypes = [vp]
+        L.glx_graph_destroy.restype = None
+        L.glx_graph_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ci),
+                                     ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.glx_graph_export_alias.argtypes = [vp, vp, vp, ci, vp]
+        L.glx_graph_degrees.argtypes = [vp, vp, i64, vp, ci, vp]
+        L.glx_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
+        L.glx_features_create.argtypes = [ci, i64, i32, vp, vp, ci, vp, ctypes.POINTER(vp)]
+        L.glx_features_destroy.argtypes = [vp]
+        L.glx_features_destroy.restype = None
+        L.glx_features_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(ci),
+                                        ctypes.POINTER(ci)]
+        L.glx_aggregate.argtypes = [vp, ci, vp, vp, i32, i32, f32, vp, vp, ci, vp]
+        L.glx_lookup.argtypes = [vp, vp, i64, f32, vp, ci, vp]
+        L.glx_partition.argtypes = [ci, vp, i64, i32, vp, vp, vp, vp]
+        L.glx_stitch_i64.argtypes = [ci, vp, vp, i64, i32, vp, vp]
+        L.glx_stitch_f32.argtypes = [ci, vp, vp, i64, i32, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise GlxError(rc, lib().glx_last_error().decode())
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(lib().glx_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x, dtype=None):
+    """(pointer, kind) of a numpy array or a torch CUDA tensor; None -> NULL."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        assert x.is_cuda and x.is_contiguous(), "torch inputs must be contiguous CUDA tensors"
+        return ctypes.c_void_p(x.data_ptr()), PTR_DEVICE
+    assert isinstance(x, np.ndarray) and x.flags["C_CONTIGUOUS"]
+    if dtype is not None:
+        assert x.dtype == dtype, (x.dtype, dtype)
+    return ctypes.c_void_p(x.ctypes.data), PTR_HOST
+
+
+def _kind(*xs):
+    kinds = set(k for _, k in xs if k is not None)
+    assert len(kinds) == 1, "all data pointers of a call must be host (numpy) or device (torch)"
+    return kinds.pop()
+
+
+def _stream(kind):
+    if kind == PTR_DEVICE:
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+class Graph:
+    """Device-resident CSR of one edge type (glx_graph)."""
+
+    def __init__(self, row_ptr, col, eid, weight=None, ids=None, device=0):
+        ptrs = [_ptr(row_ptr), _ptr(col), _ptr(eid), _ptr(weight), _ptr(ids)]
+        kind = _kind(*ptrs)
+        self.num_rows = int(row_ptr.shape[0]) - 1
+        self.num_edges = int(col.shape[0])
+        self.device = device
+        h = ctypes.c_void_p()
+        _check(lib().glx_graph_create(device, self.num_rows, self.num_edges, ptrs[0][0], ptrs[1][0],
+                                      ptrs[2][0], ptrs[3][0], ptrs[4][0], kind, _stream(kind),
+                                      ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().glx_graph_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def export_alias(self):
+        prob = np.empty(self.num_edges, np.float32)
+        alias = np.empty(self.num_edges, np.int32)
+        _check(lib().glx_graph_export_alias(self._h, _ptr(prob)[0], _ptr(alias)[0], PTR_HOST, None))
+        return prob, alias
+
+    def degrees(self, src):
+        if _is_torch(src):
+            import torch
+            out = torch.empty(src.shape[0], dtype=torch.int64, device=src.device)
+        else:
+            out = np.empty(src.shape[0], np.int64)
+        (ps, k1), (po, _) = _ptr(src), _ptr(out)
+        _check(lib().glx_graph_degrees(self._h, ps, src.shape[0], po, k1, _stream(k1)))
+        return out
+
+    def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR,
+               default_neighbor_id=0, out=None):
+        """-> (nbr[batch, k], eid[batch, k]) int64; numpy in -> numpy out, torch in -> torch out."""
+        if isinstance(sampler, str):
+            sampler = SAMPLER_IDS[sampler]
+        batch = int(src.shape[0])
+        if out is not None:
+            nbr, eid = out
+        elif _is_torch(src):
+            import torch
+            nbr = torch.empty((batch, k), dtype=torch.int64, device=src.device)
+            eid = torch.empty((batch, k), dtype=torch.int64, device=src.device)
+        else:
+            nbr = np.empty((batch, k), np.int64)
+            eid = np.empty((batch, k), np.int64)
+        ps, pn, pe = _ptr(src), _ptr(nbr), _ptr(eid)
+        kind = _kind(ps, pn, pe)
+        _check(lib().glx_sample(self._h, sampler, ps[0], batch, k, padding_mode, default_neighbor_id,
+                                seed, call_counter, pn[0], pe[0], kind, _stream(kind)))
+        return nbr, eid
+
+
+class Features:
+    """Device-resident [V, D] float32 node features of one node type (glx_features)."""
+
+    def __init__(self, X, ids=None, device=0):
+        ptrs = [_ptr(X), _ptr(ids)]
+        kind = _kind(*ptrs)
+        self.num_rows, self.dim = int(X.shape[0]), int(X.shape[1])
+        self.device = device
+        h = ctypes.c_void_p()
+        _check(lib().glx_features_create(device, self.num_rows, self.dim, ptrs[0][0], ptrs[1][0], kind,
+                                         _stream(kind), ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().glx_features_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, out=None):
+        """-> (emb[num_segments, D] float32, counts[num_segments] int32)."""
+        if isinstance(op, str):
+            op = AGGREGATOR_IDS[op]
+        n = int(node_ids.shape[0])
+        if out is not None:
+            emb, cnt = out
+        elif _is_torch(node_ids):
+            import torch
+            emb = torch.empty((num_segments, self.dim), dtype=torch.float32, device=node_ids.device)
+            cnt = torch.empty((num_segments,), dtype=torch.int32, device=node_ids.device)
+        else:
+            emb = np.empty((num_segments, self.dim), np.float32)
+            cnt = np.empty((num_segments,), np.int32)
+        pi, pg, pe, pc = _ptr(node_ids), _ptr(segment_ids), _ptr(emb), _ptr(cnt)
+        kind = _kind(pi, pg, pe, pc)
+        _check(lib().glx_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0],
+                                   pc[0], kind, _stream(kind)))
+        return emb, cnt
+
+    def lookup(self, node_ids, default_attr=0.0):
+        n = int(node_ids.shape[0])
+        if _is_torch(node_ids):
+            import torch
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=node_ids.device)
+        else:
+            out = np.empty((n, self.dim), np.float32)
+        pi, po = _ptr(node_ids), _ptr(out)
+        kind = _kind(pi, po)
+        _check(lib().glx_lookup(self._h, pi[0], n, default_attr, po[0], kind, _stream(kind)))
+        return out
+
+
+def partition(ids, num_shards):
+    """Device HashPartitioner: torch int64 CUDA ids -> (bucketed, order, counts)."""
+    import torch
+    n = int(ids.shape[0])
+    bucketed = torch.empty_like(ids)
+    order = torch.empty_like(ids)
+    counts = torch.empty(num_shards, dtype=torch.int64, device=ids.device)
+    dev = ids.device.index or 0
+    _check(lib().glx_partition(dev, _ptr(ids)[0], n, num_shards, _ptr(bucketed)[0], _ptr(order)[0],
+                               _ptr(counts)[0], _stream(PTR_DEVICE)))
+    return bucketed, order, counts
+
+
+def stitch(rows, order):
+    """Device Stitcher: out[order[i]] = rows[i]; rows is [n, width] int64 or float32 (torch CUDA)."""
+    import torch
+    n = int(rows.shape[0])
+    width = int(rows.numel() // max(n, 1)) if n else 1
+    out = torch.empty_like(rows)
+    dev = rows.device.index or 0
+    fn = lib().glx_stitch_i64 if rows.dtype == torch.int64 else lib().glx_stitch_f32
+    assert rows.dtype in (torch.int64, torch.float32)
+    _check(fn(dev, _ptr(rows)[0], _ptr(order)[0], n, width, _ptr(out)[0], _stream(PTR_DEVICE)))
+    return out

@@ -1,0 +1,168 @@
+/* glx -- MI355X-native drop-in for the graph-learn sampling / aggregation hot path.
+ *
+ * This is the C-ABI boundary (plain pointers and sizes; no C++/torch types).
+ * The C++ operators that mirror the reference's registry (graph-learn_amd/host)
+ * call it from their Process() bodies; a maintainer of the reference would call
+ * it the same way from graphlearn::op::Sampler / Aggregator subclasses (see
+ * INTEGRATION.md).  Every entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - return value: graphlearn::error::Code (graphlearn/src/include/status.h:29-49),
+ *     0 = OK; a message for the last failure on this thread: glx_last_error().
+ *   - `ptr_kind` says whether the data pointers of THAT call are host
+ *     (GLX_PTR_HOST: the call copies in/out and returns when results are in
+ *     host memory) or device pointers on the handle's GPU (GLX_PTR_DEVICE: the
+ *     call only enqueues work on `stream` and returns; the caller orders later
+ *     use on that stream).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - handles are immutable after creation and may be used concurrently from
+ *     any number of host threads (the reference calls Process() from up to 32
+ *     pool threads on one operator instance: in_memory_service.cc:64-71).
+ *   - no entry point throws or takes ownership of caller memory.
+ */
+#ifndef GLX_H_
+#define GLX_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLX_ABI_VERSION 1
+
+/* graphlearn::error::Code values used by this library (status.h:29-49). */
+#define GLX_OK 0
+#define GLX_INVALID_ARGUMENT 3
+#define GLX_RESOURCE_EXHAUSTED 8
+#define GLX_OUT_OF_RANGE 11
+#define GLX_UNIMPLEMENTED 12
+#define GLX_INTERNAL 13
+#define GLX_UNAVAILABLE 14
+
+#define GLX_PTR_HOST 0
+#define GLX_PTR_DEVICE 1
+
+/* Sampler ids; the registry names they serve are in the comments
+ * (REGISTER_OPERATOR in random_sampler.cc:80, random_without_replacement_sampler.cc:79,
+ * edge_weight_sampler.cc:128, topk_sampler.cc:72). */
+#define GLX_SAMPLER_RANDOM 0                     /* "RandomSampler" */
+#define GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT 1 /* "RandomWithoutReplacementSampler" */
+#define GLX_SAMPLER_EDGE_WEIGHT 2                /* "EdgeWeightSampler" */
+#define GLX_SAMPLER_TOPK 3                       /* "TopkSampler" */
+
+/* Aggregator ids ("SumAggregator" ... sum_aggregator.cc:36, mean_aggregator.cc:64,
+ * max_aggregator.cc:43, min_aggregator.cc:43, prod_aggregator.cc:43). */
+#define GLX_AGG_SUM 0
+#define GLX_AGG_MEAN 1
+#define GLX_AGG_MAX 2
+#define GLX_AGG_MIN 3
+#define GLX_AGG_PROD 4
+
+/* GLOBAL_FLAG(PaddingMode) values (constants.h:119-122, config.cc:94). */
+#define GLX_PAD_REPLICATE 0
+#define GLX_PAD_CIRCULAR 1
+
+typedef struct glx_graph glx_graph;       /* one edge type: device CSR + alias table + id map */
+typedef struct glx_features glx_features; /* one node type: device [V, D] float matrix + id map */
+
+/* ---- library ------------------------------------------------------------ */
+int glx_abi_version(void);
+/* Number of visible GPUs; GLX_UNAVAILABLE (and *count = 0) when there is no
+ * usable HIP device.  Nothing in this library falls back to the CPU. */
+int glx_device_count(int* count);
+const char* glx_last_error(void);
+
+/* ---- graph storage: replaces GraphStorage::GetNeighbors / GetOutEdges /
+ * GetEdgeWeight (graph_storage.h:40-57) + CompressedMemoryAdjMatrix
+ * (memory_adj_matrix.cc:159-225) + AutoIndex (auto_indexing.cc:21-33). -----
+ *
+ * Input is the adjacency exactly as the reference exposes it after Build():
+ * row r holds neighbours col[row_ptr[r] .. row_ptr[r+1]) and their edge ids
+ * eid[..] IN THE REFERENCE'S ROW ORDER (weight-descending for weighted edge
+ * types, memory_adj_matrix.cc:105-125).  `weight` is per CSR slot (the
+ * reference stores it per edge id: memory_edge_storage.cc:97-103) or NULL for
+ * an unweighted type.  `ids` maps row -> raw vertex id, or NULL when raw id v
+ * is row v.  row_ptr is 64-bit (the reference's int32 offsets overflow at
+ * E >= 2^31: types.h:28).  When weights are given the per-row alias tables of
+ * AliasMethod::Build (alias_method.cc:57-107) are built once, on the device.
+ */
+int glx_graph_create(int device, int64_t num_rows, int64_t num_edges, const int64_t* row_ptr,
+                     const int64_t* col, const int64_t* eid, const float* weight,
+                     const int64_t* ids, int ptr_kind, void* stream, glx_graph** out);
+void glx_graph_destroy(glx_graph* g);
+int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges, int* weighted,
+                   int* has_id_map, int* device);
+/* Copy the device alias table out (parity checks against alias_method.cc:57-107). */
+int glx_graph_export_alias(const glx_graph* g, float* prob, int32_t* alias, int ptr_kind,
+                           void* stream);
+/* Degrees of a batch of raw ids (0 for unknown ids), as GetNeighbors().Size(). */
+int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t n, int64_t* deg_out,
+                      int ptr_kind, void* stream);
+
+/* ---- neighbour sampling: replaces Sampler::Sample of the four samplers
+ * (random_sampler.cc:33-76, random_without_replacement_sampler.cc:31-75,
+ * edge_weight_sampler.cc:31-92, topk_sampler.cc:29-68) incl. the padders
+ * (padder/circular_padder.h:36-66, padder/replicate_padder.h:37-56) and
+ * SamplingResponse::FillWith for unknown / empty rows. --------------------
+ *
+ * src[batch] raw ids -> nbr_out[batch*k], eid_out[batch*k], row-major dense,
+ * the layout of SamplingResponse kNodeIds / kEdgeIds (sampling_request.cc:226-251).
+ * `padding_mode` and `default_neighbor_id` are the reference's global flags,
+ * passed explicitly.  (`seed`, `call_counter`) select the random stream (the
+ * seeding contract in DESIGN.md): the same pair gives the same output,
+ * bit-for-bit, on every run and every GPU count.  Filters are not supported
+ * on this path.
+ */
+int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batch, int32_t k,
+               int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+               uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+               void* stream);
+
+/* ---- node features: replaces NodeStorage::GetAttribute()->GetFloats()
+ * (node_storage.h:51-54, compressed_memory_node_storage.cc:149-176). -------
+ * X is [num_rows, dim] row-major float32 (SideInfo.f_num == dim). */
+int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
+                        const int64_t* ids, int ptr_kind, void* stream, glx_features** out);
+void glx_features_destroy(glx_features* f);
+int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t* dim, int* has_id_map,
+                      int* device);
+
+/* ---- aggregation: replaces Aggregator::Aggregate (aggregator.cc:25-59) with
+ * Sum/Mean/Max/Min/Prod Init/Agg/Final (sum_aggregator.cc:25-33,
+ * mean_aggregator.cc:26-61, max_aggregator.cc:26-40, min_aggregator.cc,
+ * prod_aggregator.cc). ---------------------------------------------------
+ * node_ids[num_ids], segment_ids[num_ids] (consumed with the reference's
+ * cursor rule, aggregating_request.cc:86-105) -> emb_out[num_segments*dim],
+ * cnt_out[num_segments].  Unknown ids contribute a row of `default_attr`;
+ * empty segments are `default_attr` (GLOBAL_FLAG(DefaultFloatAttribute)).
+ * Each output element is accumulated in the reference's left-to-right order,
+ * so results are bit-identical to the reference for every op. */
+int glx_aggregate(const glx_features* f, int op, const int64_t* node_ids,
+                  const int32_t* segment_ids, int32_t num_ids, int32_t num_segments,
+                  float default_attr, float* emb_out, int32_t* cnt_out, int ptr_kind,
+                  void* stream);
+
+/* ---- feature lookup: replaces LookupNodes' float-attribute gather
+ * (node_lookuper.cc:24-52); out[n*dim], unknown ids -> default_attr. */
+int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_t n, float default_attr,
+               float* out, int ptr_kind, void* stream);
+
+/* ---- shard exchange helpers: replace HashPartitioner::Partition
+ * (hash_partitioner.h:33-92; shard = llabs(id) % P, stable inside a shard) and
+ * Stitcher::DoStitch (stitcher.h:67-107).  These take device pointers only
+ * (they sit between two RCCL all-to-alls). ---------------------------------
+ * glx_partition: ids[n] -> bucketed[n] (ids grouped by shard, original order
+ *   kept inside a shard), order[n] (the concatenated Sticker lists: order[i] is
+ *   the original index of bucketed[i]), counts[num_shards] (int64, device).
+ * glx_stitch_i64 / _f32: out[order[i]*width + c] = in[i*width + c]. */
+int glx_partition(int device, const int64_t* ids, int64_t n, int32_t num_shards,
+                  int64_t* bucketed, int64_t* order, int64_t* counts, void* stream);
+int glx_stitch_i64(int device, const int64_t* in, const int64_t* order, int64_t n, int32_t width,
+                   int64_t* out, void* stream);
+int glx_stitch_f32(int device, const float* in, const int64_t* order, int64_t n, int32_t width,
+                   float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLX_H_ */

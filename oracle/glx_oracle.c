@@ -1,0 +1,366 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see glx_oracle.h).
+ *
+ * Plain-C restatement of the reference algorithms, one serial loop per
+ * request exactly like the reference.  Build: oracle/Makefile
+ * (-O2 -ffp-contract=off so float expressions round like the reference's
+ * x86-64 SSE build, no fused multiply-add).
+ */
+#include "glx_oracle.h"
+
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ RNG -- */
+/* Philox4x32-10 (Salmon et al., SC'11).  The reference draws from an
+ * unseedable thread_local mt19937 (random_sampler.cc:46-47); the glx seeding
+ * contract replaces only that entropy source, never the formulas around it. */
+void glxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Contract: key = (seed lo, seed hi); counter = (j >> 1, row, cc lo, cc hi);
+ * draw j takes words {2(j&1), 2(j&1)+1} of the block as lo, hi. */
+uint64_t glxo_draw64(uint64_t seed, uint64_t call_counter, uint32_t row, uint32_t j) {
+  uint32_t ctr[4] = {j >> 1, row, (uint32_t)call_counter, (uint32_t)(call_counter >> 32)};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t o[4];
+  glxo_philox4x32_10(ctr, key, o);
+  uint32_t w = (j & 1u) * 2u;
+  return ((uint64_t)o[w + 1] << 32) | o[w];
+}
+
+/* Bounded integer in [0, n): high 64 bits of u * n (bias <= n / 2^64). */
+static inline uint64_t bounded(uint64_t u, uint64_t n) {
+  return (uint64_t)(((unsigned __int128)u * n) >> 64);
+}
+
+/* ---------------------------------------------------------- id -> row ---- */
+typedef struct {
+  int64_t* keys;
+  int64_t* vals;
+  uint64_t mask;
+} idmap;
+
+static uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+static void idmap_build(idmap* m, const int64_t* ids, int64_t V) {
+  uint64_t cap = 16;
+  while (cap < (uint64_t)V * 2) cap <<= 1;
+  m->mask = cap - 1;
+  m->keys = (int64_t*)malloc(cap * sizeof(int64_t));
+  m->vals = (int64_t*)malloc(cap * sizeof(int64_t));
+  for (uint64_t i = 0; i < cap; ++i) m->vals[i] = -1;
+  for (int64_t r = 0; r < V; ++r) {
+    uint64_t h = mix64((uint64_t)ids[r]) & m->mask;
+    /* first insertion wins, like unordered_map::insert (auto_indexing.cc:21-24) */
+    while (m->vals[h] != -1 && m->keys[h] != ids[r]) h = (h + 1) & m->mask;
+    if (m->vals[h] == -1) { m->keys[h] = ids[r]; m->vals[h] = r; }
+  }
+}
+
+static int64_t idmap_get(const idmap* m, int64_t id) {
+  uint64_t h = mix64((uint64_t)id) & m->mask;
+  while (m->vals[h] != -1) {
+    if (m->keys[h] == id) return m->vals[h];
+    h = (h + 1) & m->mask;
+  }
+  return -1;
+}
+
+static void idmap_free(idmap* m) { free(m->keys); free(m->vals); }
+
+static inline int64_t row_of(const int64_t* ids, const idmap* m, int64_t V, int64_t id) {
+  if (!ids) return (id >= 0 && id < V) ? id : -1;
+  return idmap_get(m, id);
+}
+
+/* ---------------------------------------------------------------- alias -- */
+/* AliasMethod::Build, alias_method.cc:57-107, one CSR row at a time.  low /
+ * high sets are LIFO stacks; `sum` accumulates in double and is narrowed to
+ * float (std::accumulate(..., 0.0) assigned to a float, :73). */
+static void alias_build_row(const float* dist, int32_t count, float* probs, int32_t* alias,
+                            int32_t* low_set, int32_t* high_set) {
+  if (count == 0) return;
+  float avg_prob = (float)(1.0 / count);
+  double acc = 0.0;
+  for (int32_t i = 0; i < count; ++i) acc += dist[i];
+  float sum = (float)acc;
+  int32_t low_num = 0, high_num = 0;
+  for (int32_t i = 0; i < count; ++i) {
+    alias[i] = i;
+    float prob = dist[i] / sum;
+    probs[i] = prob * count;
+    if (prob < avg_prob) {
+      low_set[low_num++] = i;
+    } else if (prob > avg_prob) {
+      high_set[high_num++] = i;
+    }
+  }
+  while (low_num > 0 && high_num > 0) {
+    int32_t low_idx = low_set[--low_num];
+    int32_t high_idx = high_set[--high_num];
+    probs[high_idx] = probs[high_idx] - 1 + probs[low_idx];
+    alias[low_idx] = high_idx;
+    if (probs[high_idx] < 1.0) {
+      low_set[low_num++] = high_idx;
+    } else if (probs[high_idx] > 1.0) {
+      high_set[high_num++] = high_idx;
+    }
+  }
+  while (low_num > 0) probs[low_set[--low_num]] = 1.0f;
+  while (high_num > 0) probs[high_set[--high_num]] = 1.0f;
+}
+
+void glxo_alias_build(const int64_t* row_ptr, const float* weight, int64_t V, float* prob_out,
+                      int32_t* alias_out) {
+  int64_t maxdeg = 0;
+  for (int64_t r = 0; r < V; ++r) {
+    int64_t d = row_ptr[r + 1] - row_ptr[r];
+    if (d > maxdeg) maxdeg = d;
+  }
+  int32_t* low = (int32_t*)malloc((size_t)(maxdeg + 1) * sizeof(int32_t));
+  int32_t* high = (int32_t*)malloc((size_t)(maxdeg + 1) * sizeof(int32_t));
+  for (int64_t r = 0; r < V; ++r) {
+    int64_t s = row_ptr[r];
+    alias_build_row(weight + s, (int32_t)(row_ptr[r + 1] - s), prob_out + s, alias_out + s, low,
+                    high);
+  }
+  free(low);
+  free(high);
+}
+
+/* ----------------------------------------------------------- row sorting -- */
+typedef struct { int64_t col, eid; float w; int64_t pos; } sort_rec;
+
+static int cmp_weight_desc(const void* a, const void* b) {
+  const sort_rec* x = (const sort_rec*)a;
+  const sort_rec* y = (const sort_rec*)b;
+  if (x->w > y->w) return -1;
+  if (x->w < y->w) return 1;
+  return (x->pos > y->pos) - (x->pos < y->pos);
+}
+
+void glxo_sort_rows_by_weight_desc(const int64_t* row_ptr, int64_t V, int64_t* col, int64_t* eid,
+                                   float* weight) {
+  int64_t maxdeg = 0;
+  for (int64_t r = 0; r < V; ++r) {
+    int64_t d = row_ptr[r + 1] - row_ptr[r];
+    if (d > maxdeg) maxdeg = d;
+  }
+  sort_rec* buf = (sort_rec*)malloc((size_t)(maxdeg + 1) * sizeof(sort_rec));
+  for (int64_t r = 0; r < V; ++r) {
+    int64_t s = row_ptr[r], d = row_ptr[r + 1] - s;
+    for (int64_t i = 0; i < d; ++i) {
+      buf[i].col = col[s + i]; buf[i].eid = eid[s + i]; buf[i].w = weight[s + i]; buf[i].pos = i;
+    }
+    qsort(buf, (size_t)d, sizeof(sort_rec), cmp_weight_desc);
+    for (int64_t i = 0; i < d; ++i) {
+      col[s + i] = buf[i].col; eid[s + i] = buf[i].eid; weight[s + i] = buf[i].w;
+    }
+  }
+  free(buf);
+}
+
+/* -------------------------------------------------------------- samplers -- */
+static void fill_default(int64_t* nbr, int64_t* eid, int32_t k, int64_t def) {
+  /* SamplingResponse::FillWith, sampling_request.cc:279-290 */
+  for (int32_t j = 0; j < k; ++j) { nbr[j] = def; eid[j] = -1; }
+}
+
+/* Pad with an index list (indices == NULL means identity of length n_idx).
+ * CircularPadder::Pad circular_padder.h:36-66; ReplicatePadder::Pad
+ * replicate_padder.h:37-56 -- which ignores the VALUES of the index list
+ * (cursor = idx) and is clamped here to the row length instead of reading out
+ * of bounds. */
+static void pad_row(const int64_t* rn, const int64_t* re, int64_t deg, const int64_t* indices,
+                    int64_t n_idx, int32_t k, int padding_mode, int64_t def, int64_t* nbr,
+                    int64_t* eid) {
+  if (padding_mode == GLXO_PAD_CIRCULAR) {
+    if (n_idx == 0) { fill_default(nbr, eid, k, def); return; }
+    for (int32_t j = 0; j < k; ++j) {
+      int64_t cursor = j % n_idx;
+      if (indices) cursor = indices[cursor];
+      nbr[j] = rn[cursor];
+      eid[j] = re[cursor];
+    }
+  } else {
+    int64_t size = n_idx < k ? n_idx : k;
+    if (size > deg) size = deg;
+    for (int64_t j = 0; j < size; ++j) { nbr[j] = rn[j]; eid[j] = re[j]; }
+    for (int64_t j = size; j < k; ++j) { nbr[j] = def; eid[j] = -1; }
+  }
+}
+
+int glxo_sample(const glxo_graph* g, int op, const int64_t* src, int32_t batch, int32_t k,
+                int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+                uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out) {
+  if (op < GLXO_RANDOM || op > GLXO_TOPK) return 3;
+  if (op == GLXO_EDGE_WEIGHT && (!g->alias_prob || !g->alias_idx)) return 3;
+  idmap m;
+  if (g->ids) idmap_build(&m, g->ids, g->V);
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
+  int64_t* perm = NULL;
+  int64_t perm_cap = 0;
+  for (int32_t i = 0; i < batch; ++i) {
+    int64_t* nbr = nbr_out + (int64_t)i * k;
+    int64_t* eid = eid_out + (int64_t)i * k;
+    int64_t row = row_of(g->ids, &m, g->V, src[i]);
+    int64_t start = row < 0 ? 0 : g->row_ptr[row];
+    int64_t deg = row < 0 ? 0 : g->row_ptr[row + 1] - start;
+    if (deg == 0) { fill_default(nbr, eid, k, default_neighbor_id); continue; }
+    const int64_t* rn = g->col + start;
+    const int64_t* re = g->eid + start;
+    switch (op) {
+      case GLXO_RANDOM:
+        /* random_sampler.cc:61-71 without a filter: k draws in [0, deg). */
+        for (int32_t j = 0; j < k; ++j) {
+          int64_t d = (int64_t)bounded(glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j),
+                                       (uint64_t)deg);
+          nbr[j] = rn[d];
+          eid[j] = re[d];
+        }
+        break;
+      case GLXO_RANDOM_WITHOUT_REPLACEMENT: {
+        /* random_without_replacement_sampler.cc:57-68: shuffle(iota(deg)) then
+         * Pad.  Contract: forward Fisher-Yates, step j swaps a[j] with
+         * a[j + bounded(draw_j, deg - j)]; only the first min(k, deg) steps
+         * can influence the padded output, so only those are run. */
+        if (padding_mode != GLXO_PAD_CIRCULAR) {
+          pad_row(rn, re, deg, NULL, deg, k, padding_mode, default_neighbor_id, nbr, eid);
+          break;
+        }
+        if (deg > perm_cap) {
+          free(perm);
+          perm_cap = deg * 2;
+          perm = (int64_t*)malloc(sizeof(int64_t) * (size_t)perm_cap);
+        }
+        for (int64_t t = 0; t < deg; ++t) perm[t] = t;
+        int64_t msteps = deg < k ? deg : k;
+        for (int64_t j = 0; j < msteps; ++j) {
+          int64_t r = j + (int64_t)bounded(
+                              glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j),
+                              (uint64_t)(deg - j));
+          int64_t t = perm[j]; perm[j] = perm[r]; perm[r] = t;
+        }
+        /* circular pad over the full permutation (indices_->size() == deg);
+         * slots j < k only ever index perm[j % deg] with j % deg < msteps. */
+        pad_row(rn, re, deg, perm, deg, k, padding_mode, default_neighbor_id, nbr, eid);
+        break;
+      }
+      case GLXO_EDGE_WEIGHT: {
+        /* alias_method.cc:109-124: rand = float(U[0, deg-1)); idx = int(rand);
+         * ret = probs[idx] <= rand - idx ? alias[idx] : idx. */
+        const float* probs = g->alias_prob + start;
+        const int32_t* alias = g->alias_idx + start;
+        for (int32_t j = 0; j < k; ++j) {
+          uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j);
+          double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
+          float rnd = (float)rd;
+          int32_t ix = (int32_t)rnd;
+          idx[j] = (probs[ix] <= (rnd - ix)) ? alias[ix] : ix;
+        }
+        pad_row(rn, re, deg, idx, k, k, padding_mode, default_neighbor_id, nbr, eid);
+        break;
+      }
+      case GLXO_TOPK:
+        /* topk_sampler.cc:53-61: iota(deg) then Pad (rows pre-sorted by weight). */
+        pad_row(rn, re, deg, NULL, deg, k, padding_mode, default_neighbor_id, nbr, eid);
+        break;
+    }
+  }
+  free(idx);
+  free(perm);
+  if (g->ids) idmap_free(&m);
+  return 0;
+}
+
+/* ------------------------------------------------------------ aggregators -- */
+int glxo_aggregate(const float* feats, int64_t V, int32_t dim, const int64_t* ids, int op,
+                   const int64_t* node_ids, const int32_t* segment_ids, int32_t num_ids,
+                   int32_t num_segments, float default_attr, float* emb_out, int32_t* cnt_out) {
+  if (op < GLXO_SUM || op > GLXO_PROD) return 3;
+  idmap m;
+  if (ids) idmap_build(&m, ids, V);
+  float* defrow = (float*)malloc(sizeof(float) * (size_t)(dim > 0 ? dim : 1));
+  for (int32_t i = 0; i < dim; ++i) defrow[i] = default_attr;
+  int32_t cursor = 0; /* AggregatingRequest::cursor_, aggregating_request.cc:86-105 */
+  for (int32_t s = 0; s < num_segments; ++s) {
+    float* emb = emb_out + (int64_t)s * dim;
+    /* InitFunc: aggregator.cc:61-65; max_aggregator.cc:26-30 (FLT_MIN_10_EXP =
+     * -37); min_aggregator.cc:26-30; prod_aggregator.cc. */
+    float init = 0.0f;
+    if (op == GLXO_MAX) init = (float)FLT_MIN_10_EXP;
+    if (op == GLXO_MIN) init = FLT_MAX;
+    if (op == GLXO_PROD) init = 1.0f;
+    for (int32_t i = 0; i < dim; ++i) emb[i] = init;
+    int32_t n = 0;
+    while (cursor < num_ids && segment_ids[cursor] == s) {
+      int64_t row = row_of(ids, &m, V, node_ids[cursor]);
+      const float* a = row < 0 ? defrow : feats + row * (int64_t)dim;
+      ++cursor;
+      switch (op) {
+        case GLXO_SUM:
+        case GLXO_MEAN:
+          for (int32_t i = 0; i < dim; ++i) emb[i] = emb[i] + a[i];
+          break;
+        case GLXO_MAX: /* std::max(l, r) == (l < r) ? r : l */
+          for (int32_t i = 0; i < dim; ++i) emb[i] = (emb[i] < a[i]) ? a[i] : emb[i];
+          break;
+        case GLXO_MIN: /* std::min(l, r) == (r < l) ? r : l */
+          for (int32_t i = 0; i < dim; ++i) emb[i] = (a[i] < emb[i]) ? a[i] : emb[i];
+          break;
+        case GLXO_PROD:
+          for (int32_t i = 0; i < dim; ++i) emb[i] = emb[i] * a[i];
+          break;
+      }
+      ++n;
+    }
+    /* FinalFunc: aggregator.cc:74-86; mean_aggregator.cc:45-61. */
+    if (n == 0) {
+      for (int32_t i = 0; i < dim; ++i) emb[i] = default_attr;
+    } else if (op == GLXO_MEAN) {
+      for (int32_t i = 0; i < dim; ++i) emb[i] = emb[i] / n;
+    }
+    cnt_out[s] = n;
+  }
+  free(defrow);
+  if (ids) idmap_free(&m);
+  return 0;
+}
+
+/* ------------------------------------------------------ partition / stitch -- */
+void glxo_partition(const int64_t* ids, int64_t n, int32_t P, int64_t* order_out,
+                    int64_t* counts_out) {
+  for (int32_t p = 0; p < P; ++p) counts_out[p] = 0;
+  for (int64_t i = 0; i < n; ++i) counts_out[llabs(ids[i]) % P]++;
+  int64_t* off = (int64_t*)malloc(sizeof(int64_t) * (size_t)P);
+  int64_t acc = 0;
+  for (int32_t p = 0; p < P; ++p) { off[p] = acc; acc += counts_out[p]; }
+  for (int64_t i = 0; i < n; ++i) order_out[off[llabs(ids[i]) % P]++] = i;
+  free(off);
+}
+
+void glxo_stitch_i64(const int64_t* shard_major, const int64_t* order, int64_t n, int32_t width,
+                     int64_t* out) {
+  for (int64_t i = 0; i < n; ++i)
+    memcpy(out + order[i] * width, shard_major + i * width, sizeof(int64_t) * (size_t)width);
+}

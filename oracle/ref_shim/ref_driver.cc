@@ -16,6 +16,16 @@
 #include <thread>
 #include <vector>
 
+// Test-only access to the reference AliasMethod's private tables (probs_/alias_)
+// so that golden vectors can pin glx's device alias build bit-for-bit.
+#include <mutex>
+#include <unordered_map>
+#include <unordered_set>
+#include "common/threading/sync/lock.h"
+#include "core/graph/storage/types.h"
+#define private public
+#include "core/operator/sampler/alias_method.h"
+#undef private
 #include "core/graph/graph_store.h"
 #include "core/io/element_value.h"
 #include "core/operator/op_factory.h"
@@ -194,6 +204,17 @@ int glref_aggregate(void* h, const char* node_type, const char* strategy, const 
   if (emb_out) memcpy(emb_out, res.Embeddings(), sizeof(float) * dim * num_segments);
   if (cnt_out) memcpy(cnt_out, res.Segments(), sizeof(int32_t) * num_segments);
   return 0;
+}
+
+// The reference's own AliasMethod::Build (alias_method.cc:57-107) on one
+// weight vector; copies its private tables out.
+void glref_alias_build(const float* w, int32_t n, float* probs_out, int32_t* alias_out) {
+  std::vector<float> dist(w, w + n);
+  op::AliasMethod am(&dist);
+  for (int32_t i = 0; i < n; ++i) {
+    probs_out[i] = am.probs_[i];
+    alias_out[i] = am.alias_[i];
+  }
 }
 
 // ---- CPU-baseline timing legs (reference's concurrency model: one request per

@@ -1,0 +1,237 @@
+"""Generates tests/golden/*.npz from the REAL reference (oracle/_ref/libglref.so =
+the reference's own sampler / aggregator / storage sources, shim-compiled by
+oracle/Makefile).  Run in a container that has /root/reference:
+
+    python tests/golden/make_golden.py
+
+The GPU box has no /root/reference; the committed .npz files are what travels.
+Everything here is deterministic (fixed numpy seeds, pinned mt19937 seed).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle_bindings import RefLib, VP, SAMPLERS, AGGREGATORS  # noqa: E402
+
+
+def ref_alias(ref, w):
+    ref.L.glref_alias_build.argtypes = [VP, ctypes.c_int32, VP, VP]
+    p = np.zeros(w.shape[0], np.float32)
+    a = np.zeros(w.shape[0], np.int32)
+    ref.L.glref_alias_build(w.ctypes.data_as(VP), w.shape[0], p.ctypes.data_as(VP), a.ctypes.data_as(VP))
+    return p, a
+
+
+def first_appearance(ids):
+    """Row order the reference's AutoIndex assigns (auto_indexing.cc:21-24)."""
+    _, idx = np.unique(ids, return_index=True)
+    return ids[np.sort(idx)]
+
+
+def gen_kat(ref):
+    """sampler_unittest.cpp:76-83 graph; Topk KAT is {20,10,21,11} (:190-195)."""
+    src = np.array([0, 0, 0, 1, 1], np.int64)
+    dst = np.array([10, 20, 30, 11, 21], np.int64)
+    w = np.array([0.8, 1.0, 0.5, 0.88, 1.2], np.float32)
+    ref.add_edges("kat", src, dst, w)
+    rows = first_appearance(src)
+    rp, col, eid, ws = ref.export_csr("kat", rows, 8)
+    out = dict(src=src, dst=dst, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws)
+    q = np.array([0, 1, 2], np.int64)
+    out["query"] = q
+    for pad in (0, 1):
+        for dflt in (0, -1):
+            for k in (2, 4):
+                ref.set_flags(pad, dflt, 0.0)
+                n, e = ref.sample("kat", "TopkSampler", q, k)
+                out["topk_p%d_d%d_k%d_nbr" % (pad, dflt + 1, k)] = n
+                out["topk_p%d_d%d_k%d_eid" % (pad, dflt + 1, k)] = e
+    np.savez_compressed(os.path.join(HERE, "kat_sampler.npz"), **out)
+
+
+def gen_pyfixture(ref):
+    """GL/python/tests/utils.py:96,126-133: src 100..199, dst = src*it % 100 for
+    it in 1..src%5, weight = float('%f' % ((src + 0.1*dst)/10)); topk expectations
+    are pinned by test_topk_neighbor_sampling.py:31-66 / utils.py:304-326."""
+    src, dst, w = [], [], []
+    for s in range(100, 200):
+        for it in range(1, s % 5 + 1):
+            d = s * it % 100
+            src.append(s)
+            dst.append(d)
+            w.append(float("%f" % ((s + 0.1 * d) / 10.0)))
+    src = np.array(src, np.int64)
+    dst = np.array(dst, np.int64)
+    w = np.array(w, np.float32)
+    ref.add_edges("edge2", src, dst, w)
+    rows = first_appearance(src)
+    rp, col, eid, ws = ref.export_csr("edge2", rows, 8)
+    out = dict(src=src, dst=dst, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws)
+    q = np.array([102, 107, 108, 105, 110, 5], np.int64)
+    out["query"] = q
+    for pad in (0, 1):
+        ref.set_flags(pad, -1, 0.0)
+        n, e = ref.sample("edge2", "TopkSampler", q, 6)
+        out["topk_p%d_nbr" % pad] = n
+        out["topk_p%d_eid" % pad] = e
+        # replicate mode makes RWoR deterministic too (ReplicatePadder ignores indices)
+        if pad == 0:
+            n, e = ref.sample("edge2", "RandomWithoutReplacementSampler", q, 6)
+            out["rwor_p0_nbr"] = n
+            out["rwor_p0_eid"] = e
+    np.savez_compressed(os.path.join(HERE, "pyfixture_topk.npz"), **out)
+
+
+def gen_rand_graph(ref):
+    """Random weighted multigraph with sparse, partly negative raw ids."""
+    rng = np.random.default_rng(11)
+    V, E = 300, 6000
+    raw = (np.arange(V, dtype=np.int64) * 7 + 1000)
+    raw[::13] *= -1
+    s_idx = np.minimum((rng.pareto(1.2, E) * 6).astype(np.int64), V - 1)
+    src = raw[s_idx]
+    dst = raw[rng.integers(0, V, E)]
+    w = (rng.random(E) * 0.99 + 0.01).astype(np.float32)
+    w = (w + np.arange(E, dtype=np.float32) * np.float32(2.0 ** -20)).astype(np.float32)  # tie-free
+    ref.add_edges("rnd", src, dst, w)
+    rows = first_appearance(src)
+    maxdeg = int(np.bincount(s_idx).max())
+    rp, col, eid, ws = ref.export_csr("rnd", rows, maxdeg)
+    prob = np.zeros(E, np.float32)
+    alias = np.zeros(E, np.int32)
+    for r in range(rows.shape[0]):
+        a, b = rp[r], rp[r + 1]
+        prob[a:b], alias[a:b] = ref_alias(ref, ws[a:b])
+    out = dict(src=src, dst=dst, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws,
+               alias_prob=prob, alias_idx=alias)
+    q = np.concatenate([rows[:40], np.array([5, -5, 123456789], np.int64), rows[-10:]])
+    out["query"] = q
+    for pad in (0, 1):
+        for k in (1, 3, 10, 33, 70):
+            ref.set_flags(pad, -7, 0.0)
+            n, e = ref.sample("rnd", "TopkSampler", q, k)
+            out["topk_p%d_k%d_nbr" % (pad, k)] = n
+            out["topk_p%d_k%d_eid" % (pad, k)] = e
+    ref.set_flags(0, -7, 0.0)
+    for k in (3, 33):
+        n, e = ref.sample("rnd", "RandomWithoutReplacementSampler", q, k)
+        out["rwor_p0_k%d_nbr" % k] = n
+        out["rwor_p0_k%d_eid" % k] = e
+    np.savez_compressed(os.path.join(HERE, "rand_graph.npz"), **out)
+
+
+def gen_dist(ref):
+    """Reference sampling distributions (the reference is unseedable, so random
+    samplers are pinned distributionally): per (row, slot) histograms of the
+    picked row-local position over T independent requests."""
+    rng = np.random.default_rng(5)
+    degs = [1, 2, 3, 5, 8, 20]
+    src, dst, w = [], [], []
+    for r, d in enumerate(degs):
+        for j in range(d):
+            src.append(r)
+            dst.append(1000 * (r + 1) + j)
+            w.append(rng.random() * 0.99 + 0.01)
+    src = np.array(src, np.int64)
+    dst = np.array(dst, np.int64)
+    w = np.array(w, np.float32)
+    ref.add_edges("dist", src, dst, w)
+    rows = np.arange(len(degs), dtype=np.int64)
+    rp, col, eid, ws = ref.export_csr("dist", rows, max(degs))
+    out = dict(src=src, dst=dst, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws,
+               degs=np.array(degs, np.int64))
+    T = 40000
+    ref.set_flags(1, 0, 0.0)
+    ref.set_seed(12345)
+    for name in SAMPLERS[:3]:
+        for k in (2, 6):
+            q = np.tile(rows, T)
+            _, e = ref.sample("dist", name, q, k, fresh_thread=True)
+            e = e.reshape(T, len(degs), k)
+            hist = np.zeros((len(degs), k, max(degs)), np.int64)
+            pair = np.zeros((len(degs), max(degs), max(degs)), np.int64)  # joint of slots 0,1
+            for r, d in enumerate(degs):
+                pos_of = {int(x): i for i, x in enumerate(eid[rp[r]:rp[r + 1]])}
+                pos = np.vectorize(pos_of.get)(e[:, r, :])
+                for j in range(k):
+                    hist[r, j, :d] = np.bincount(pos[:, j], minlength=d)
+                np.add.at(pair[r], (pos[:, 0], pos[:, 1]), 1)
+            out["%s_k%d_hist" % (name, k)] = hist
+            out["%s_k%d_pair" % (name, k)] = pair
+    out["T"] = np.array(T)
+    np.savez_compressed(os.path.join(HERE, "dist.npz"), **out)
+
+
+def gen_agg(ref):
+    """aggregating_op_unittest.cpp:216-364 KAT (100 nodes, attr = id, segment
+    sizes {0,1,2,3,4}) + random cases with unknown ids, empty segments and a
+    cursor-stalling (unsorted) tail."""
+    out = {}
+    ids = np.arange(100, dtype=np.int64)
+    feats = np.arange(100, dtype=np.float32).reshape(100, 1).copy()
+    ref.set_flags(1, 0, 0.0)
+    ref.add_nodes("kat_user", ids, feats)
+    nid = np.arange(10, dtype=np.int64)
+    seg = np.array([1, 2, 2, 3, 3, 3, 4, 4, 4, 4], np.int32)
+    out["kat_ids"] = nid
+    out["kat_seg"] = seg
+    for name in AGGREGATORS:
+        emb, cnt = ref.aggregate("kat_user", name, nid, seg, 5, 1)
+        out["kat_%s_emb" % name] = emb
+        out["kat_%s_cnt" % name] = cnt
+    rng = np.random.default_rng(21)
+    case = 0
+    for D in (1, 3, 8, 128, 260):
+        for dflt in (0.0, 999.9):
+            V = 200
+            raw = np.arange(V, dtype=np.int64) * 5 - 300
+            X = (rng.standard_normal((V, D)) * 10).astype(np.float32)
+            ntype = "n%d" % case
+            ref.set_flags(1, 0, dflt)
+            ref.add_nodes(ntype, raw, X)
+            Sg = 37
+            sizes = rng.integers(0, 9, Sg)
+            sizes[[0, 5, 6, Sg - 1]] = 0
+            sizes[10] = 40
+            seg = np.repeat(np.arange(Sg, dtype=np.int32), sizes)
+            nid = raw[rng.integers(0, V, seg.shape[0])].copy()
+            nid[rng.random(seg.shape[0]) < 0.1] = 7777777  # unknown ids -> default row
+            if case % 2 == 1:  # stall the cursor: an out-of-order tail is never consumed
+                seg = np.concatenate([seg, np.array([3, 4, 50, -1], np.int32)])
+                nid = np.concatenate([nid, raw[:4]])
+            out["c%d_raw" % case] = raw
+            out["c%d_X" % case] = X
+            out["c%d_ids" % case] = nid
+            out["c%d_seg" % case] = seg
+            out["c%d_default" % case] = np.float32(dflt)
+            out["c%d_num_segments" % case] = np.array(Sg)
+            for name in AGGREGATORS:
+                emb, cnt = ref.aggregate(ntype, name, nid, seg, Sg, D)
+                out["c%d_%s_emb" % (case, name)] = emb
+                out["c%d_%s_cnt" % (case, name)] = cnt
+            case += 1
+    out["num_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(HERE, "agg.npz"), **out)
+
+
+def main():
+    ref = RefLib(storage_mode=2)
+    gen_kat(ref)
+    gen_pyfixture(ref)
+    gen_rand_graph(ref)
+    gen_dist(ref)
+    gen_agg(ref)
+    # The CSR ("compressed") storage mode must expose the same adjacency.
+    ref.close()
+    print("golden fixtures written to", HERE)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("  %-22s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == "__main__":
+    main()

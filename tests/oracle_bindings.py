@@ -1,0 +1,197 @@
+"""numpy bindings of the test oracles.
+
+  * `Oracle`  -- oracle/libglx_oracle.so, the C restatement under the glx
+                 seeding contract (bit-exact target of the HIP kernels);
+  * `RefLib`  -- oracle/_ref/libglref.so, the reference's OWN sampler /
+                 aggregator sources shim-compiled (present when built in a
+                 container that has /root/reference; it travels to the GPU box
+                 as a prebuilt .so).
+Test infrastructure only.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libglx_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libglref.so")
+
+VP = ctypes.c_void_p
+SAMPLERS = ["RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"]
+AGGREGATORS = ["SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(VP)
+
+
+class _CGraph(ctypes.Structure):
+    _fields_ = [("V", ctypes.c_int64), ("E", ctypes.c_int64), ("row_ptr", VP), ("col", VP), ("eid", VP),
+                ("weight", VP), ("alias_prob", VP), ("alias_idx", VP), ("ids", VP)]
+
+
+class Oracle:
+    def __init__(self):
+        L = ctypes.CDLL(ORACLE_SO)
+        i32, i64, u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+        L.glxo_philox4x32_10.argtypes = [VP, VP, VP]
+        L.glxo_draw64.argtypes = [u64, u64, ctypes.c_uint32, ctypes.c_uint32]
+        L.glxo_draw64.restype = u64
+        L.glxo_alias_build.argtypes = [VP, VP, i64, VP, VP]
+        L.glxo_sort_rows_by_weight_desc.argtypes = [VP, i64, VP, VP, VP]
+        L.glxo_sample.argtypes = [ctypes.POINTER(_CGraph), ctypes.c_int, VP, i32, i32, ctypes.c_int, i64, u64,
+                                  u64, VP, VP]
+        L.glxo_aggregate.argtypes = [VP, i64, i32, VP, ctypes.c_int, VP, VP, i32, i32, ctypes.c_float, VP, VP]
+        L.glxo_partition.argtypes = [VP, i64, i32, VP, VP]
+        L.glxo_stitch_i64.argtypes = [VP, VP, i64, i32, VP]
+        self.L = L
+
+    def philox(self, ctr, key):
+        c = np.asarray(ctr, np.uint32)
+        k = np.asarray(key, np.uint32)
+        o = np.zeros(4, np.uint32)
+        self.L.glxo_philox4x32_10(_p(c), _p(k), _p(o))
+        return o
+
+    def draw64(self, seed, cc, row, j):
+        return self.L.glxo_draw64(seed, cc, row, j)
+
+    def alias_build(self, row_ptr, weight):
+        prob = np.zeros(weight.shape[0], np.float32)
+        alias = np.zeros(weight.shape[0], np.int32)
+        self.L.glxo_alias_build(_p(row_ptr), _p(weight), row_ptr.shape[0] - 1, _p(prob), _p(alias))
+        return prob, alias
+
+    def sort_rows(self, row_ptr, col, eid, weight):
+        col, eid, weight = col.copy(), eid.copy(), weight.copy()
+        self.L.glxo_sort_rows_by_weight_desc(_p(row_ptr), row_ptr.shape[0] - 1, _p(col), _p(eid), _p(weight))
+        return col, eid, weight
+
+    def sample(self, g, sampler, src, k, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0):
+        """g: dict(row_ptr, col, eid, weight=None, alias=(prob, idx)|None, ids=None)."""
+        if isinstance(sampler, str):
+            sampler = SAMPLERS.index(sampler)
+        alias = g.get("alias")
+        cg = _CGraph(g["row_ptr"].shape[0] - 1, g["col"].shape[0], _p(g["row_ptr"]), _p(g["col"]), _p(g["eid"]),
+                     _p(g.get("weight")), _p(alias[0]) if alias else None, _p(alias[1]) if alias else None,
+                     _p(g.get("ids")))
+        batch = src.shape[0]
+        nbr = np.zeros((batch, k), np.int64)
+        eid = np.zeros((batch, k), np.int64)
+        rc = self.L.glxo_sample(ctypes.byref(cg), sampler, _p(src), batch, k, padding_mode, default_neighbor_id,
+                                seed, call_counter, _p(nbr), _p(eid))
+        assert rc == 0, rc
+        return nbr, eid
+
+    def aggregate(self, X, op, node_ids, segment_ids, num_segments, default_attr=0.0, ids=None):
+        if isinstance(op, str):
+            op = AGGREGATORS.index(op)
+        V, D = X.shape
+        emb = np.zeros((num_segments, D), np.float32)
+        cnt = np.zeros(num_segments, np.int32)
+        rc = self.L.glxo_aggregate(_p(X), V, D, _p(ids), op, _p(node_ids), _p(segment_ids), node_ids.shape[0],
+                                   num_segments, default_attr, _p(emb), _p(cnt))
+        assert rc == 0, rc
+        return emb, cnt
+
+    def partition(self, ids, P):
+        order = np.zeros(ids.shape[0], np.int64)
+        counts = np.zeros(P, np.int64)
+        self.L.glxo_partition(_p(ids), ids.shape[0], P, _p(order), _p(counts))
+        return order, counts
+
+    def stitch(self, shard_major, order):
+        n = order.shape[0]
+        width = shard_major.size // max(n, 1)
+        out = np.zeros_like(shard_major)
+        self.L.glxo_stitch_i64(_p(shard_major), _p(order), n, width, _p(out))
+        return out
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+class RefLib:
+    """One reference GraphStore (process-global flags: use one instance at a time)."""
+
+    def __init__(self, storage_mode=2, padding_mode=1, default_neighbor_id=0, default_float_attr=0.0):
+        L = ctypes.CDLL(REF_SO)
+        i32, i64 = ctypes.c_int32, ctypes.c_int64
+        cs = ctypes.c_char_p
+        L.glref_create.restype = VP
+        L.glref_create.argtypes = [ctypes.c_int, ctypes.c_int, i64, ctypes.c_float]
+        L.glref_destroy.argtypes = [VP]
+        L.glref_set_flags.argtypes = [ctypes.c_int, i64, ctypes.c_float]
+        L.glref_set_seed.argtypes = [ctypes.c_uint]
+        L.glref_add_edges.argtypes = [VP, cs, VP, VP, VP, i64]
+        L.glref_build_graph.argtypes = [VP, cs]
+        L.glref_add_nodes.argtypes = [VP, cs, VP, VP, i64, i32]
+        L.glref_build_nodes.argtypes = [VP, cs]
+        L.glref_get_row.argtypes = [VP, cs, i64, VP, VP, i64]
+        L.glref_get_row.restype = i64
+        L.glref_edge_weight.argtypes = [VP, cs, i64]
+        L.glref_edge_weight.restype = ctypes.c_float
+        L.glref_sample.argtypes = [VP, cs, cs, VP, i32, i32, VP, VP, ctypes.c_int]
+        L.glref_aggregate.argtypes = [VP, cs, cs, VP, VP, i32, i32, VP, VP, VP]
+        L.glref_time_sample_2hop.argtypes = [VP, cs, cs, VP, i32, i32, i32, i32, i32, VP]
+        L.glref_time_sample_2hop.restype = ctypes.c_double
+        L.glref_time_aggregate.argtypes = [VP, cs, cs, VP, i32, i32, i32, i32, VP]
+        L.glref_time_aggregate.restype = ctypes.c_double
+        self.L = L
+        self.h = L.glref_create(storage_mode, padding_mode, default_neighbor_id, default_float_attr)
+
+    def close(self):
+        if self.h:
+            self.L.glref_destroy(self.h)
+            self.h = None
+
+    def set_flags(self, padding_mode=1, default_neighbor_id=0, default_float_attr=0.0):
+        self.L.glref_set_flags(padding_mode, default_neighbor_id, default_float_attr)
+
+    def set_seed(self, seed):
+        self.L.glref_set_seed(seed)
+
+    def add_edges(self, etype, src, dst, weight=None):
+        self.L.glref_add_edges(self.h, etype.encode(), _p(src), _p(dst), _p(weight), src.shape[0])
+        self.L.glref_build_graph(self.h, etype.encode())
+
+    def add_nodes(self, ntype, ids, feats):
+        self.L.glref_add_nodes(self.h, ntype.encode(), _p(ids), _p(feats), ids.shape[0], feats.shape[1])
+        self.L.glref_build_nodes(self.h, ntype.encode())
+
+    def export_csr(self, etype, row_ids, max_deg):
+        """Post-Build adjacency of the given raw source ids -> (row_ptr, col, eid, weight-by-slot)."""
+        rp = [0]
+        cols, eids = [], []
+        nb = np.zeros(max_deg, np.int64)
+        ed = np.zeros(max_deg, np.int64)
+        for v in row_ids:
+            d = self.L.glref_get_row(self.h, etype.encode(), int(v), _p(nb), _p(ed), max_deg)
+            assert d <= max_deg
+            cols.append(nb[:d].copy())
+            eids.append(ed[:d].copy())
+            rp.append(rp[-1] + d)
+        col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+        eid = np.concatenate(eids) if eids else np.zeros(0, np.int64)
+        w = np.array([self.L.glref_edge_weight(self.h, etype.encode(), int(e)) for e in eid], np.float32)
+        return np.array(rp, np.int64), col, eid, w
+
+    def sample(self, etype, strategy, src, k, fresh_thread=True):
+        batch = src.shape[0]
+        nbr = np.zeros((batch, k), np.int64)
+        eid = np.zeros((batch, k), np.int64)
+        rc = self.L.glref_sample(self.h, etype.encode(), strategy.encode(), _p(src), batch, k, _p(nbr), _p(eid),
+                                 1 if fresh_thread else 0)
+        assert rc == 0, rc
+        return nbr, eid
+
+    def aggregate(self, ntype, strategy, node_ids, segment_ids, num_segments, dim):
+        emb = np.zeros((num_segments, dim), np.float32)
+        cnt = np.zeros(num_segments, np.int32)
+        d = ctypes.c_int32()
+        rc = self.L.glref_aggregate(self.h, ntype.encode(), strategy.encode(), _p(node_ids), _p(segment_ids),
+                                    node_ids.shape[0], num_segments, _p(emb), _p(cnt), ctypes.byref(d))
+        assert rc == 0 and d.value == dim, (rc, d.value)
+        return emb, cnt
