@@ -200,7 +200,7 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
   const bool hashed = f->idmap.keys != nullptr;
   const size_t n_i32 = 1 + (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
   int32_t* scratch = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s, 1);
   if (rc != GLX_OK) return rc;
   int32_t* valid_len = scratch;
   int32_t* seg_start = scratch + 1;
@@ -330,7 +330,7 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
   const size_t emb_n = (size_t)num_segments * f->dim;
   const size_t bytes = (size_t)num_ids * 8 + (size_t)num_ids * 4 + emb_n * 4 + (size_t)num_segments * 4 + 64;
   char* d = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), bytes, s);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), bytes, s, 0);
   if (rc != GLX_OK) return rc;
   float* d_emb = reinterpret_cast<float*>(d);
   int64_t* d_ids = reinterpret_cast<int64_t*>(d + ((emb_n * 4 + 15) & ~(size_t)15));
@@ -378,7 +378,7 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
   }
   const size_t out_bytes = (size_t)n * f->dim * 4;
   char* d = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), out_bytes + (size_t)n * 8, s);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), out_bytes + (size_t)n * 8, s, 0);
   if (rc != GLX_OK) return rc;
   float* d_out = reinterpret_cast<float*>(d);
   int64_t* d_ids = reinterpret_cast<int64_t*>(d + out_bytes);

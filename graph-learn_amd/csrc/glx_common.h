@@ -46,9 +46,10 @@ struct GlxDeviceGuard {
   }
 };
 
-// Stream-ordered scratch (pool keeps memory cached: see glx_init_device).
+// Cached per-(thread, device, stream, slot) workspaces (glx_graph.hip).  slot 0 =
+// host-pointer staging of an entry point, slot 1 = kernel-internal scratch.
 int glx_init_device(int device);
-int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s);
+int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot);
 void glx_scratch_free(void* p, hipStream_t s);
 
 // ---------------------------------------------------------- id -> row map ---

@@ -8,6 +8,7 @@
 
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "glx_common.h"
 
@@ -51,24 +52,79 @@ int glx_init_device(int device) {
   int rc = glx_device_count(&n);
   if (rc != GLX_OK) return rc;
   GLX_REQUIRE(device < n, "device %d out of range (%d visible)", device, n);
-  // Keep stream-ordered scratch cached in the pool instead of returning it to
-  // the driver at every synchronisation point.
-  hipMemPool_t pool;
-  GLX_HIP(hipDeviceGetDefaultMemPool(&pool, device));
-  uint64_t thr = UINT64_MAX;
-  GLX_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
   done[device] = true;
   return GLX_OK;
 }
 
-int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s) {
-  if (bytes == 0) bytes = 16;
-  GLX_HIP(hipMallocAsync(p, bytes, s));
+// Per-(thread, device, stream, slot) grow-only workspaces.  Work on one stream
+// is ordered, so consecutive calls on a stream may reuse the same buffer; calls
+// on different streams or from different host threads never share one (the
+// reference calls Process() concurrently from its thread pool).  This avoids
+// the stream-ordered allocator entirely: hipMallocAsync on the null stream
+// handed out blocks whose pageable H2D copies raced with the first kernel on
+// the ROCm 7.2 runtime (observed as all-zero inputs on the first call after a
+// pool reuse).  Growth frees with hipFree, which synchronises the device, so a
+// buffer is never released under a running kernel.
+namespace {
+struct WsKey {
+  int device;
+  hipStream_t stream;
+  int slot;
+  bool operator==(const WsKey& o) const {
+    return device == o.device && stream == o.stream && slot == o.slot;
+  }
+};
+struct WsBuf {
+  WsKey key;
+  void* p;
+  size_t cap;
+};
+struct WsCache {
+  std::vector<WsBuf> bufs;
+  ~WsCache() {
+    // Best effort: at process exit the runtime may already be gone.
+    for (auto& b : bufs) {
+      if (b.p && hipSetDevice(b.key.device) == hipSuccess) (void)hipFree(b.p);
+    }
+    (void)hipGetLastError();
+  }
+};
+thread_local WsCache g_ws;
+}  // namespace
+
+int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot) {
+  int dev = 0;
+  GLX_HIP(hipGetDevice(&dev));
+  if (bytes == 0) bytes = 256;
+  WsKey key{dev, s, slot};
+  WsBuf* hit = nullptr;
+  for (auto& b : g_ws.bufs) {
+    if (b.key == key) {
+      hit = &b;
+      break;
+    }
+  }
+  if (!hit) {
+    g_ws.bufs.push_back(WsBuf{key, nullptr, 0});
+    hit = &g_ws.bufs.back();
+  }
+  if (hit->cap < bytes) {
+    if (hit->p) GLX_HIP(hipFree(hit->p));
+    hit->p = nullptr;
+    hit->cap = 0;
+    size_t want = bytes + bytes / 4;
+    if (want < (1u << 20)) want = 1u << 20;
+    want = (want + 255) & ~(size_t)255;
+    GLX_HIP(hipMalloc(&hit->p, want));
+    hit->cap = want;
+  }
+  *p = hit->p;
   return GLX_OK;
 }
 
 void glx_scratch_free(void* p, hipStream_t s) {
-  if (p) (void)hipFreeAsync(p, s);
+  (void)p;
+  (void)s;  // workspaces are cached per thread/stream; nothing to release per call
 }
 
 // ------------------------------------------------------------------ id map --
@@ -387,7 +443,7 @@ extern "C" int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t
     return GLX_OK;
   }
   int64_t* d = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), (size_t)n * 2 * sizeof(int64_t), s);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), (size_t)n * 2 * sizeof(int64_t), s, 0);
   if (rc != GLX_OK) return rc;
   GLX_HIP(hipMemcpyAsync(d, src, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, s));
   glx_degrees_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->map(), g->row_ptr, d, n, d + n);

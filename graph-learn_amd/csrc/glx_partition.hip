@@ -141,7 +141,7 @@ extern "C" int glx_partition(int device, const int64_t* ids, int64_t n, int32_t 
   const int64_t nblocks = (n + kTile - 1) / kTile;
   int64_t* block_counts = nullptr;
   rc = glx_scratch_alloc(reinterpret_cast<void**>(&block_counts),
-                         (size_t)num_shards * nblocks * sizeof(int64_t), s);
+                         (size_t)num_shards * nblocks * sizeof(int64_t), s, 1);
   if (rc != GLX_OK) return rc;
   glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_shards, nblocks, block_counts);
   glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_shards, counts);

@@ -289,7 +289,7 @@ extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, i
   // Host pointers: stage through stream-ordered scratch; synchronous.
   const size_t n_out = (size_t)batch * k;
   int64_t* d = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch + 2 * n_out) * 8, s);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch + 2 * n_out) * 8, s, 0);
   if (rc != GLX_OK) return rc;
   a.src = d;
   a.nbr_out = d + batch;

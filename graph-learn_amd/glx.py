@@ -60,6 +60,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GlxError(14, "libglx.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
                                " (expected at %s)" % LIB_PATH)
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME
+        # libamdhip64.so.7).  It must be in the process BEFORE libglx.so so that
+        # libglx's NEEDED libamdhip64.so.7 binds to the same runtime; two HIP
+        # runtimes in one process cannot share device pointers.
+        if not os.environ.get("GLX_NO_TORCH"):  # (debug knob: run on the system HIP runtime)
+            import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         vp, i32, i64, u64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
         ci = ctypes.c_int

@@ -1,0 +1,73 @@
+"""CPU tests of the drop-in boundary: libglx.so loads, exports every symbol that
+include/glx.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import glx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "glx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(glx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    assert set(syms) == set(glx.EXPORTS), set(syms) ^ set(glx.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(glx.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(L, s), "libglx.so does not export %s" % s
+    assert L.glx_abi_version() == 1
+
+
+def test_product_does_not_link_oracle():
+    """The product library must not depend on anything under oracle/."""
+    import subprocess
+    out = subprocess.run(["ldd", glx.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle" not in out and "glref" not in out
+    nm = subprocess.run(["nm", "-D", glx.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "glxo_" not in nm and "glref_" not in nm
+    for root, _, files in os.walk(os.path.join(ROOT, "graph-learn_amd")):
+        for f in files:
+            if f.endswith((".hip", ".h", ".cc", ".cpp", ".py")):
+                src = open(os.path.join(root, f)).read()
+                assert "glx_oracle" not in src and "oracle_bindings" not in src, f
+
+
+def _no_gpu():
+    n = ctypes.c_int(-1)
+    rc = glx.lib().glx_device_count(ctypes.byref(n))
+    return rc != 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is visible")
+def test_fails_loudly_without_gpu():
+    n = ctypes.c_int(-1)
+    rc = glx.lib().glx_device_count(ctypes.byref(n))
+    assert rc == 14 and n.value == 0  # UNAVAILABLE
+    assert b"no CPU fallback" in glx.lib().glx_last_error()
+    rp = np.array([0, 1], np.int64)
+    with pytest.raises(glx.GlxError) as e:
+        glx.Graph(rp, np.array([0], np.int64), np.array([0], np.int64))
+    assert e.value.code == 14
+    with pytest.raises(glx.GlxError):
+        glx.Features(np.zeros((2, 4), np.float32))
+
+
+def test_argument_validation_needs_no_gpu():
+    L = glx.lib()
+    assert L.glx_graph_info(None, None, None, None, None, None) == 3  # INVALID_ARGUMENT
+    assert L.glx_features_info(None, None, None, None, None) == 3
+    assert L.glx_sample(None, 0, None, 1, 1, 1, 0, 0, 0, None, None, 0, None) == 3
+    assert L.glx_aggregate(None, 0, None, None, 0, 0, 0.0, None, None, 0, None) == 3
+    assert b"NULL" in L.glx_last_error()

@@ -1,0 +1,282 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X through gpurun).
+
+Everything goes through the C-ABI (include/glx.h) via the ctypes harness and is
+compared BIT-EXACTLY with the oracle (oracle/glx_oracle.c, itself pinned against
+the reference by test_oracle_golden.py) and with the golden fixtures generated
+from the real reference.  Aggregation is bit-exact too (tolerance 0; the
+north-star allowance is 1e-5 relative) because glx accumulates every output
+element in the reference's left-to-right order.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import glx
+import synth
+from oracle_bindings import AGGREGATORS, SAMPLERS, Oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def beq(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert glx.device_count() >= 1, "GPU tests need a HIP device; glx has no CPU fallback"
+
+
+# ------------------------------------------------------------ golden fixtures ---
+def test_golden_kat_topk():
+    g = load("kat_sampler.npz")
+    dev = glx.Graph(g["row_ptr"], g["col"], g["eid"], g["w_slot"], ids=g["rows"])
+    nbr, _ = dev.sample("TopkSampler", np.array([0, 1], np.int64), 2)
+    assert nbr.reshape(-1).tolist() == [20, 10, 21, 11]  # sampler_unittest.cpp:190-195
+    for pad in (0, 1):
+        for dflt in (0, -1):
+            for k in (2, 4):
+                nbr, eid = dev.sample("TopkSampler", g["query"], k, padding_mode=pad, default_neighbor_id=dflt)
+                key = "topk_p%d_d%d_k%d" % (pad, dflt + 1, k)
+                assert np.array_equal(nbr, g[key + "_nbr"]) and np.array_equal(eid, g[key + "_eid"]), key
+
+
+def test_golden_python_fixture_topk():
+    g = load("pyfixture_topk.npz")
+    dev = glx.Graph(g["row_ptr"], g["col"], g["eid"], g["w_slot"], ids=g["rows"])
+    for pad in (0, 1):
+        nbr, eid = dev.sample("TopkSampler", g["query"], 6, padding_mode=pad, default_neighbor_id=-1)
+        assert np.array_equal(nbr, g["topk_p%d_nbr" % pad]) and np.array_equal(eid, g["topk_p%d_eid" % pad])
+    nbr, eid = dev.sample("RandomWithoutReplacementSampler", g["query"], 6, padding_mode=0,
+                          default_neighbor_id=-1)
+    assert np.array_equal(nbr, g["rwor_p0_nbr"]) and np.array_equal(eid, g["rwor_p0_eid"])
+
+
+def test_golden_rand_graph_alias_and_topk():
+    g = load("rand_graph.npz")
+    dev = glx.Graph(g["row_ptr"], g["col"], g["eid"], g["w_slot"], ids=g["rows"])
+    prob, alias = dev.export_alias()
+    assert beq(prob, g["alias_prob"]) and np.array_equal(alias, g["alias_idx"])  # alias_method.cc:57-107
+    for pad in (0, 1):
+        for k in (1, 3, 10, 33, 70):
+            nbr, eid = dev.sample("TopkSampler", g["query"], k, padding_mode=pad, default_neighbor_id=-7)
+            assert np.array_equal(nbr, g["topk_p%d_k%d_nbr" % (pad, k)])
+            assert np.array_equal(eid, g["topk_p%d_k%d_eid" % (pad, k)])
+    for k in (3, 33):
+        nbr, eid = dev.sample("RandomWithoutReplacementSampler", g["query"], k, padding_mode=0,
+                              default_neighbor_id=-7)
+        assert np.array_equal(nbr, g["rwor_p0_k%d_nbr" % k]) and np.array_equal(eid, g["rwor_p0_k%d_eid" % k])
+
+
+def test_golden_aggregators():
+    a = load("agg.npz")
+    f = glx.Features(np.arange(100, dtype=np.float32).reshape(100, 1).copy())
+    for name in AGGREGATORS:
+        emb, cnt = f.aggregate(name, a["kat_ids"], a["kat_seg"], 5)
+        assert beq(emb, a["kat_%s_emb" % name]) and np.array_equal(cnt, a["kat_%s_cnt" % name]), name
+    for c in range(int(a["num_cases"])):
+        f = glx.Features(a["c%d_X" % c], ids=a["c%d_raw" % c])
+        for name in AGGREGATORS:
+            emb, cnt = f.aggregate(name, a["c%d_ids" % c], a["c%d_seg" % c], int(a["c%d_num_segments" % c]),
+                                   default_attr=float(a["c%d_default" % c]))
+            assert np.array_equal(cnt, a["c%d_%s_cnt" % (c, name)]), (c, name)
+            assert beq(emb, a["c%d_%s_emb" % (c, name)]), (c, name)
+
+
+# ------------------------------------------------------- seeded vs the oracle ---
+def _queries(rng, V, n, extra):
+    q = rng.integers(0, V, n).astype(np.int64)
+    return np.concatenate([q, np.asarray(extra, np.int64)])
+
+
+@pytest.fixture(scope="module")
+def graphs(orc):
+    out = {}
+    rp, col, eid, w = synth.small_graph(3000, 40000, seed=3, weighted=True, hub_degree=5000)
+    out["dense"] = (dict(row_ptr=rp, col=col, eid=eid, weight=w, alias=orc.alias_build(rp, w)),
+                    glx.Graph(rp, col, eid, w))
+    raw = np.arange(3000, dtype=np.int64) * 11 - 7000
+    rng = np.random.default_rng(8)
+    raw = raw[rng.permutation(3000)]
+    out["hashed"] = (dict(row_ptr=rp, col=raw[col], eid=eid, weight=w, alias=out["dense"][0]["alias"], ids=raw),
+                     glx.Graph(rp, raw[col], eid, w, ids=raw))
+    rp2, col2, eid2, _ = synth.small_graph(500, 3000, seed=4, weighted=False)
+    out["unweighted"] = (dict(row_ptr=rp2, col=col2, eid=eid2), glx.Graph(rp2, col2, eid2))
+    return out
+
+
+KS = [1, 2, 3, 5, 8, 9, 16, 17, 25, 32, 33, 64, 65, 100, 300]
+
+
+@pytest.mark.parametrize("which", ["dense", "hashed"])
+@pytest.mark.parametrize("name", SAMPLERS)
+def test_samplers_bit_exact(orc, graphs, which, name):
+    og, dev = graphs[which]
+    rng = np.random.default_rng(17)
+    if which == "dense":
+        q = _queries(rng, 3000, 700, [0, 0, -1, 3000, 10 ** 12])
+    else:
+        q = np.concatenate([og["ids"][rng.integers(0, 3000, 700)], og["ids"][:1], [5, -5, 1 << 40]]).astype(np.int64)
+    cc = 0
+    for pad in (1, 0):
+        for k in KS:
+            cc += 1
+            nbr, eid = dev.sample(name, q, k, seed=0xabcdef12345, call_counter=cc, padding_mode=pad,
+                                  default_neighbor_id=-3)
+            on, oe = orc.sample(og, name, q, k, seed=0xabcdef12345, call_counter=cc, padding_mode=pad,
+                                default_neighbor_id=-3)
+            assert np.array_equal(nbr, on), (name, which, pad, k)
+            assert np.array_equal(eid, oe), (name, which, pad, k)
+
+
+def test_unweighted_graph(orc, graphs):
+    og, dev = graphs["unweighted"]
+    q = np.arange(500, dtype=np.int64)
+    for name in ("RandomSampler", "RandomWithoutReplacementSampler", "TopkSampler"):
+        nbr, eid = dev.sample(name, q, 7, seed=5, call_counter=9)
+        on, oe = orc.sample(og, name, q, 7, seed=5, call_counter=9)
+        assert np.array_equal(nbr, on) and np.array_equal(eid, oe)
+    with pytest.raises(glx.GlxError) as e:
+        dev.sample("EdgeWeightSampler", q, 7)
+    assert e.value.code == 3
+
+
+def test_seed_and_counter_select_the_stream(graphs):
+    _, dev = graphs["dense"]
+    q = np.arange(1000, dtype=np.int64)
+    a = dev.sample("RandomSampler", q, 10, seed=1, call_counter=1)[1]
+    b = dev.sample("RandomSampler", q, 10, seed=1, call_counter=1)[1]
+    c = dev.sample("RandomSampler", q, 10, seed=1, call_counter=2)[1]
+    d = dev.sample("RandomSampler", q, 10, seed=2, call_counter=1)[1]
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, d)
+
+
+def test_device_pointers_match_host_pointers(graphs):
+    import torch
+    _, dev = graphs["dense"]
+    q = np.random.default_rng(2).integers(0, 3000, 4096).astype(np.int64)
+    tq = torch.from_numpy(q).cuda()
+    for name in SAMPLERS:
+        hn, he = dev.sample(name, q, 25, seed=3, call_counter=4)
+        dn, de = dev.sample(name, tq, 25, seed=3, call_counter=4)
+        torch.cuda.synchronize()
+        assert np.array_equal(hn, dn.cpu().numpy()) and np.array_equal(he, de.cpu().numpy())
+    deg_h = dev.degrees(q)
+    deg_d = dev.degrees(tq)
+    assert np.array_equal(deg_h, deg_d.cpu().numpy())
+
+
+def test_empty_and_degenerate_requests(orc, graphs):
+    og, dev = graphs["dense"]
+    n, e = dev.sample("RandomSampler", np.zeros(0, np.int64), 5)
+    assert n.shape == (0, 5)
+    n, e = dev.sample("TopkSampler", np.arange(4, dtype=np.int64), 0)
+    assert n.shape == (4, 0)
+    with pytest.raises(glx.GlxError):
+        dev.sample(17, np.arange(4, dtype=np.int64), 2)
+    # a graph without any edge
+    rp = np.zeros(11, np.int64)
+    g0 = glx.Graph(rp, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32))
+    for name in SAMPLERS:
+        n, e = g0.sample(name, np.arange(12, dtype=np.int64), 3, default_neighbor_id=42)
+        assert (n == 42).all() and (e == -1).all()
+    with pytest.raises(glx.GlxError):
+        glx.Graph(np.array([0, 2, 1], np.int64), np.zeros(1, np.int64), np.zeros(1, np.int64))
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 7, 8, 16, 32, 64, 100, 128, 256, 260, 512, 1024])
+def test_aggregators_bit_exact(orc, D):
+    rng = np.random.default_rng(D)
+    V = 1500
+    X = (rng.standard_normal((V, D)) * 4).astype(np.float32)
+    X[rng.random((V, D)) < 0.02] = -50.0  # exercise Max's -37 initialiser
+    raw = (np.arange(V, dtype=np.int64) * 3 + 17)
+    Sg = 301
+    sizes = rng.integers(0, 12, Sg)
+    sizes[[0, 1, 100, Sg - 1]] = 0
+    sizes[7] = 700
+    seg = np.repeat(np.arange(Sg, dtype=np.int32), sizes)
+    for ids_kind in ("dense", "hashed"):
+        f = glx.Features(X, ids=(raw if ids_kind == "hashed" else None))
+        pool = raw if ids_kind == "hashed" else np.arange(V, dtype=np.int64)
+        nid = pool[rng.integers(0, V, seg.shape[0])].copy()
+        nid[rng.random(seg.shape[0]) < 0.05] = -99  # unknown -> default row
+        for name in AGGREGATORS:
+            emb, cnt = f.aggregate(name, nid, seg, Sg, default_attr=2.5)
+            oemb, ocnt = orc.aggregate(X, name, nid, seg, Sg, 2.5, ids=(raw if ids_kind == "hashed" else None))
+            assert np.array_equal(cnt, ocnt), (name, D, ids_kind)
+            assert beq(emb, oemb), (name, D, ids_kind)
+
+
+def test_aggregator_cursor_semantics_and_edges(orc):
+    """aggregating_request.cc:86-105: an out-of-order / out-of-range segment id stalls the cursor."""
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((50, 8)).astype(np.float32)
+    f = glx.Features(X)
+    cases = [
+        (np.array([0, 0, 1, 3, 2, 3], np.int32), 5),      # 2 after 3: tail dropped
+        (np.array([1, 1, 0], np.int32), 3),
+        (np.array([0, 1, 9, 2], np.int32), 4),            # 9 >= num_segments
+        (np.array([-1, 0, 1], np.int32), 3),
+        (np.zeros(0, np.int32), 4),                       # no ids at all
+        (np.array([2, 2, 2], np.int32), 3),
+    ]
+    for seg, Sg in cases:
+        nid = rng.integers(0, 50, seg.shape[0]).astype(np.int64)
+        for name in AGGREGATORS:
+            emb, cnt = f.aggregate(name, nid, seg, Sg, default_attr=-1.5)
+            oemb, ocnt = orc.aggregate(X, name, nid, seg, Sg, -1.5)
+            assert np.array_equal(cnt, ocnt) and beq(emb, oemb), (seg, name)
+    e, c = f.aggregate("SumAggregator", np.zeros(0, np.int64), np.zeros(0, np.int32), 0)
+    assert e.shape == (0, 8)
+
+
+def test_aggregate_device_pointers_and_lookup(orc):
+    import torch
+    rng = np.random.default_rng(1)
+    V, D = 5000, 128
+    X = rng.standard_normal((V, D)).astype(np.float32)
+    f = glx.Features(torch.from_numpy(X).cuda())
+    nid = rng.integers(-5, V + 5, 40000).astype(np.int64)
+    seg = (np.arange(40000) // 10).astype(np.int32)
+    for name in AGGREGATORS:
+        emb, cnt = f.aggregate(name, torch.from_numpy(nid).cuda(), torch.from_numpy(seg).cuda(), 4000)
+        torch.cuda.synchronize()
+        oemb, ocnt = orc.aggregate(X, name, nid, seg, 4000)
+        assert np.array_equal(cnt.cpu().numpy(), ocnt) and beq(emb.cpu().numpy(), oemb), name
+    out = f.lookup(nid[:1000], default_attr=9.0)
+    exp = np.where(((nid[:1000] >= 0) & (nid[:1000] < V))[:, None], X[np.clip(nid[:1000], 0, V - 1)], 9.0)
+    assert beq(out, exp.astype(np.float32))
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8, 64])
+def test_partition_and_stitch(orc, P):
+    import torch
+    rng = np.random.default_rng(P)
+    for n in (0, 1, 255, 2048, 2049, 100003):
+        ids = rng.integers(-10 ** 9, 10 ** 9, n).astype(np.int64)
+        t = torch.from_numpy(ids).cuda()
+        bucketed, order, counts = glx.partition(t, P)
+        torch.cuda.synchronize()
+        oorder, ocounts = orc.partition(ids, P)
+        assert np.array_equal(counts.cpu().numpy(), ocounts), (P, n)
+        if n == 0:
+            continue
+        assert np.array_equal(order.cpu().numpy(), oorder), (P, n)
+        assert np.array_equal(bucketed.cpu().numpy(), ids[oorder])
+        rows = torch.stack([bucketed * 2, bucketed * 2 + 1], 1).contiguous()
+        back = glx.stitch(rows, order)
+        assert np.array_equal(back.cpu().numpy(), np.stack([ids * 2, ids * 2 + 1], 1))
+        fr = glx.stitch(rows.to(torch.float32), order)
+        assert np.array_equal(fr.cpu().numpy(), np.stack([ids * 2, ids * 2 + 1], 1).astype(np.float32))
