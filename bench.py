@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the glx sampling + aggregation hot path.
+
+One "step" = one pass of the hot path over one batch of B0 seed vertices:
+  hop-1 sample (B0 rows x k1) -> hop-2 sample (B0*k1 rows x k2)
+  -> aggregate the hop-2 neighbours into B0*k1 segments
+  -> aggregate the hop-1 neighbours into B0 segments,
+all through the C-ABI (include/glx.h) with inputs resident in HBM.  Every
+sampled neighbour is aggregated exactly once, so sampled-edges/s ==
+aggregated-vertices/s for the whole step; the per-phase rates are reported too.
+
+Default workload = BASELINE.json configs[2], the config its metric ("100M-edge
+graph") is quoted on: RMAT (0.57,0.19,0.19,0.05) 10M nodes / 100M edges,
+EdgeWeightSampler (alias) fanout [25,10], MaxAggregator, dim=256.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the graph and features are edge-cut partitioned (llabs(v) % N), every rank
+drives its own batch of B0 seeds (weak scaling) and requests are routed with
+RCCL all-to-all (graph-learn_amd/dist.py).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import glx  # noqa: E402
+import synth  # noqa: E402
+
+WORKLOADS = {
+    # name: (V, E, sampler, fanout, aggregator, dim, graph seed, description)
+    "c3": (10_000_000, 100_000_000, "EdgeWeightSampler", (25, 10), "MaxAggregator", 256, 4,
+           "BASELINE configs[2]: RMAT power-law 10M nodes / 100M edges, WeightedSampler(alias) "
+           "fanout [25,10], MaxAggregator, dim=256"),
+    "c2": (2_400_000, 62_000_000, "RandomWithoutReplacementSampler", (15, 10), "MeanAggregator", 128, 2,
+           "BASELINE configs[1] shape: RMAT 2.4M nodes / 62M edges, RandomWithoutReplacement "
+           "fanout [15,10], MeanAggregator, dim=128"),
+    "tiny": (200_000, 2_000_000, "EdgeWeightSampler", (25, 10), "MaxAggregator", 256, 4,
+             "tiny smoke workload (not a benchmark)"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(wl, row_ptr, col, eid, weight, args):
+    """Times the reference's own CPU path (oracle/_ref, built from the reference's
+    sources) on this box's host cores, on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_bindings import RefLib, have_ref, _p
+    V, E, sampler, (k1, k2), agg, D = wl[:6]
+    if not have_ref():
+        return None
+    t_all = time.time()
+    ref = RefLib(storage_mode=2, padding_mode=1)
+    # edges in insertion (= edge id) order, as the reference loader would add them
+    deg = (row_ptr[1:] - row_ptr[:-1])
+    src_slot = torch.repeat_interleave(torch.arange(V, device=row_ptr.device), deg)
+    o = torch.sort(eid).indices
+    src_h = src_slot[o].cpu().numpy()
+    dst_h = col[o].cpu().numpy()
+    w_h = weight[o].cpu().numpy() if weight is not None else None
+    del src_slot, o
+    # add a prefix of the edge stream until the build budget is spent
+    chunk = 5_000_000
+    added = 0
+    t0 = time.time()
+    info_ptr = w_h
+    while added < E and (time.time() - t0) < args.cpu_build_budget:
+        n = min(chunk, E - added)
+        ref.L.glref_add_edges(ref.h, b"e", _p(src_h[added:added + n]), _p(dst_h[added:added + n]),
+                              _p(info_ptr[added:added + n]) if info_ptr is not None else None, n)
+        added += n
+    ref.L.glref_build_graph(ref.h, b"e")
+    t_build = time.time() - t0
+    threads = min(os.cpu_count() or 1, 32)  # InterThreadNum default (config.cc:90)
+    B = 1024
+    rng = np.random.default_rng(123)
+    out = ctypes.c_int64()
+    # calibrate with one request per thread, then size the run to ~cpu_time_budget
+    seeds = rng.integers(0, V, B * threads).astype(np.int64)
+    dt1 = ref.L.glref_time_sample_2hop(ref.h, b"e", sampler.encode(), _p(seeds), B, k1, k2, 1, threads,
+                                       ctypes.byref(out))
+    reps = int(max(1, min(64, args.cpu_time_budget / max(dt1, 1e-3))))
+    seeds = rng.integers(0, V, B * threads * reps).astype(np.int64)
+    dts = ref.L.glref_time_sample_2hop(ref.h, b"e", sampler.encode(), _p(seeds), B, k1, k2, reps, threads,
+                                       ctypes.byref(out))
+    edges = out.value
+    r_sample = edges / dts
+    # aggregation: feature table restricted to Vc rows (ids taken modulo Vc)
+    Vc = min(V, 1_000_000)
+    feats = (np.random.default_rng(5).random((Vc, D), dtype=np.float32) * 2 - 1)
+    ref.add_nodes("n", np.arange(Vc, dtype=np.int64), feats)
+    n_ids = B * k1 * k2
+    ids = rng.integers(0, Vc, n_ids * threads).astype(np.int64)
+    dta1 = ref.L.glref_time_aggregate(ref.h, b"n", agg.encode(), _p(ids), n_ids, k2, 1, threads,
+                                      ctypes.byref(out))
+    areps = int(max(1, min(64, args.cpu_time_budget / max(dta1, 1e-3))))
+    ids = rng.integers(0, Vc, n_ids * threads * areps).astype(np.int64)
+    dta = ref.L.glref_time_aggregate(ref.h, b"n", agg.encode(), _p(ids), n_ids, k2, areps, threads,
+                                     ctypes.byref(out))
+    r_agg = out.value / dta
+    ref.close()
+    value = 1.0 / (1.0 / r_sample + 1.0 / r_agg)
+    return {
+        "value": value, "unit": "edges/s", "cores": threads, "kind": "reference",
+        "sampling_edges_per_s": r_sample, "aggregation_vertices_per_s": r_agg,
+        "sample": ("reference C++ %s [%d,%d] + %s on host threads (one request per thread, "
+                   "1024 seeds/request, %d requests/thread; %.1fs sampling + %.1fs aggregation timed); "
+                   "graph = first %d of %d generated edges of the same RMAT stream (build %.0fs, "
+                   "default vector-of-vectors storage); features = %d rows x %d (ids mod %d); "
+                   "value = 1/(1/sampling + 1/aggregation)"
+                   % (sampler, k1, k2, agg, reps, dts, dta, added, E, t_build, Vc, D, Vc)),
+        "wall_s": time.time() - t_all,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=65536, help="seed vertices per step per GPU (B0)")
+    ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
+    ap.add_argument("--cpu-build-budget", type=float, default=60.0, help="s of reference graph build")
+    ap.add_argument("--cpu-time-budget", type=float, default=10.0, help="s per timed CPU leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    V, E, sampler, (k1, k2), agg, D, gseed, desc = wl
+    B0 = args.batch
+    t0 = time.time()
+    weighted = sampler in ("EdgeWeightSampler", "TopkSampler")
+    row_ptr, col, eid, weight = synth.rmat_graph_torch(V, E, gseed, dev, weighted=weighted)
+    torch.cuda.synchronize()
+    log("graph generated in %.1fs (max degree %d)" % (time.time() - t0, int((row_ptr[1:] - row_ptr[:-1]).max())))
+
+    cpu = None
+    if args.cpu_baseline == "on" and world == 1:
+        t1 = time.time()
+        cpu = cpu_baseline(wl, row_ptr, col, eid, weight, args)
+        log("cpu baseline done in %.1fs: %s" % (time.time() - t1, cpu and "%.3g edges/s" % cpu["value"]))
+
+    t1 = time.time()
+    X = synth.features_torch(V, D, gseed + 1, dev)
+    if world == 1:
+        graph = glx.Graph(row_ptr, col, eid, weight, device=local_rank)
+        feats = glx.Features(X, device=local_rank)
+        store = None
+    else:
+        import dist as gdist
+        rp, c, e, w, ids = gdist.shard_graph(row_ptr, col, eid, weight, rank, world)
+        graph = glx.Graph(rp, c, e, w, ids=ids, device=local_rank)
+        feats = glx.Features(X[rank::world].contiguous(), ids=ids, device=local_rank)
+        store = gdist.ShardedStore(gdist.DeviceOps(), graph, feats)
+        del rp, c, e, w
+    del row_ptr, col, eid, weight, X
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    log("device store built in %.1fs" % (time.time() - t1))
+
+    # synthetic request stream: uniform seeds, a fresh batch per step
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    n_steps = args.warmup + args.steps
+    seeds = torch.randint(0, V, (n_steps, B0), generator=gen, device=dev, dtype=torch.int64)
+    n1, n2 = B0 * k1, B0 * k1 * k2
+    seg2 = (torch.arange(n2, device=dev) // k2).to(torch.int32)
+    seg1 = (torch.arange(n1, device=dev) // k1).to(torch.int32)
+    nbr1 = torch.empty((B0, k1), dtype=torch.int64, device=dev)
+    eid1 = torch.empty_like(nbr1)
+    nbr2 = torch.empty((n1, k2), dtype=torch.int64, device=dev)
+    eid2 = torch.empty_like(nbr2)
+    emb2 = torch.empty((n1, D), dtype=torch.float32, device=dev)
+    cnt2 = torch.empty((n1,), dtype=torch.int32, device=dev)
+    emb1 = torch.empty((B0, D), dtype=torch.float32, device=dev)
+    cnt1 = torch.empty((B0,), dtype=torch.int32, device=dev)
+
+    def step(i):
+        cc = 4 * i
+        if store is None:
+            graph.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nbr1, eid1))
+            graph.sample(sampler, nbr1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nbr2, eid2))
+            feats.aggregate(agg, nbr2.view(-1), seg2, n1, out=(emb2, cnt2))
+            feats.aggregate(agg, nbr1.view(-1), seg1, B0, out=(emb1, cnt1))
+        else:
+            a, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=cc)
+            b, _ = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=cc + 1)
+            store.aggregate(agg, b.view(-1), seg2, n1)
+            store.aggregate(agg, a.view(-1), seg1, B0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    glx.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    glx.profile_enable(False)
+    t_agg = glx.profile_collect(glx.KERNEL_AGGREGATE)
+    t_smp = glx.profile_collect(glx.KERNEL_SAMPLE)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    edges_per_step = n1 + n2  # response slots, padding included
+    value = world * edges_per_step * args.steps / elapsed
+    # dominant kernel: the hop-2 segmented reduce (first aggregate launch of each step)
+    agg2 = t_agg[0::2] if store is None else t_agg[0::2]
+    agg1 = t_agg[1::2]
+    bytes_agg2 = n2 * (4 * D + 12) + n1 * (4 * D + 4)  # algorithmic bytes
+    avg_agg2_ms = float(np.mean(agg2)) if len(agg2) else float("nan")
+    achieved = bytes_agg2 / (avg_agg2_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            key = "%s_b%d" % (args.workload, B0)
+            traffic = rec.get(key, {}).get("aggregate_hop2_bytes_per_launch")
+        except Exception:
+            traffic = None
+    smp_ms = float(np.sum(t_smp)) / max(args.steps, 1)
+    agg_ms = float(np.sum(t_agg)) / max(args.steps, 1)
+    res = {
+        "metric": "sampled-edges/sec + aggregated-vertices/sec (2-hop sample + aggregate per step; every "
+                  "sampled vertex is aggregated once, so the step rate counts both)",
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int64 ids + f32 features", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, desc), "seeds_per_step_per_gpu": B0,
+                   "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
+                   "nodes": V, "edges": E,
+                   "parallelism": "1 GPU" if world == 1 else "edge-cut llabs(v)%%%d + RCCL all-to-all" % world},
+        "phases": {
+            "sampling_kernels_ms_per_step": smp_ms,
+            "aggregation_kernels_ms_per_step": agg_ms,
+            "sampled_edges_per_s_sampling_only": world * edges_per_step / (smp_ms * 1e-3) if smp_ms > 0 else None,
+            "aggregated_vertices_per_s_aggregation_only": world * edges_per_step / (agg_ms * 1e-3) if agg_ms > 0 else None,
+            "aggregate_hop1_avg_ms": float(np.mean(agg1)) if len(agg1) else None,
+        },
+        "roofline": {"kernel": "glx_aggregate_kernel (hop-2 %s, dim=%d)" % (agg, D), "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "avg_launch_ms": avg_agg2_ms, "algorithmic_bytes_per_launch": bytes_agg2,
+                     "launches_timed": int(len(agg2))},
+        "cpu_baseline": cpu,
+    }
+    if cpu:
+        res["gpu_over_cpu"] = value / cpu["value"]
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,7 +153,8 @@ void launch_agg_g(const AggArgs& a, hipStream_t s) {
 
 template <int OP>
 void launch_agg(const AggArgs& a, hipStream_t s) {
-  const bool vec4 = a.dim % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0;
+  const bool vec4 = a.dim % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
   if (vec4) {
     const int lanes = a.dim / 4;
     if (lanes >= 64) launch_agg_g<OP, 64, 4>(a, s);
@@ -227,6 +228,7 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
   a.dim = f->dim;
   a.num_segments = num_segments;
   a.default_attr = default_attr;
+  GlxKernelTimer timer(GLX_KERNEL_AGGREGATE, s);
   switch (op) {
     case GLX_AGG_SUM: launch_agg<GLX_AGG_SUM>(a, s); break;
     case GLX_AGG_MEAN: launch_agg<GLX_AGG_MEAN>(a, s); break;
@@ -235,6 +237,7 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
     case GLX_AGG_PROD: launch_agg<GLX_AGG_PROD>(a, s); break;
     default: break;
   }
+  timer.stop();
   hipError_t le = hipGetLastError();
   glx_scratch_free(scratch, s);
   GLX_HIP(le);
@@ -263,6 +266,7 @@ extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, co
   f->device = device;
   f->num_rows = num_rows;
   f->dim = dim;
+  f->owns_x = true;
   const size_t bytes = (size_t)(num_rows > 0 ? num_rows : 1) * dim * sizeof(float);
   hipError_t e = hipMalloc(&f->X, bytes);
   if (e == hipSuccess && num_rows > 0) {
@@ -290,10 +294,31 @@ extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, co
   return GLX_OK;
 }
 
+extern "C" int glx_features_view(int device, int64_t num_rows, int32_t dim, const float* X_device,
+                                 glx_features** out) {
+  GLX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  GLX_REQUIRE(num_rows >= 0 && dim > 0, "bad shape [%lld, %d]", (long long)num_rows, dim);
+  GLX_REQUIRE(num_rows < INT32_MAX, "num_rows must be < 2^31");
+  GLX_REQUIRE(num_rows == 0 || X_device != nullptr, "X is NULL");
+  int rc = glx_init_device(device);
+  if (rc != GLX_OK) return rc;
+  glx_features* f = new (std::nothrow) glx_features();
+  GLX_REQUIRE(f != nullptr, "out of host memory");
+  memset(static_cast<void*>(f), 0, sizeof(*f));
+  f->device = device;
+  f->num_rows = num_rows;
+  f->dim = dim;
+  f->X = const_cast<float*>(X_device);
+  f->owns_x = false;
+  *out = f;
+  return GLX_OK;
+}
+
 extern "C" void glx_features_destroy(glx_features* f) {
   if (!f) return;
   GlxDeviceGuard guard(f->device);
-  if (f->X) (void)hipFree(f->X);
+  if (f->X && f->owns_x) (void)hipFree(f->X);
   glx_idmap_free(&f->idmap);
   delete f;
 }
@@ -371,8 +396,10 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
   while (G < 64 && G < want) G <<= 1;
   const int64_t threads = n * G;
   if (ptr_kind == GLX_PTR_DEVICE) {
+    GlxKernelTimer timer(GLX_KERNEL_LOOKUP, s);
     glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->dim, node_ids,
                                                                        n, default_attr, out, G);
+    timer.stop();
     GLX_HIP(hipGetLastError());
     return GLX_OK;
   }

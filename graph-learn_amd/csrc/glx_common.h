@@ -52,6 +52,14 @@ int glx_init_device(int device);
 int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot);
 void glx_scratch_free(void* p, hipStream_t s);
 
+// Kernel timing hook (glx_profile_enable): record an event on `s` when enabled.
+struct GlxKernelTimer {
+  int slot = -1;
+  hipStream_t s;
+  GlxKernelTimer(int kind, hipStream_t stream);  // records the start event
+  void stop();                                   // records the stop event
+};
+
 // ---------------------------------------------------------- id -> row map ---
 // Open-addressing table over raw int64 ids (AutoIndex::Get, auto_indexing.cc:26-33).
 // keys == nullptr means the dense identity map (raw id v is row v).
@@ -117,6 +125,7 @@ struct glx_features {
   int64_t num_rows;
   int32_t dim;
   float* X;  // [V, D] row-major, base 256-byte aligned
+  bool owns_x;
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
 };

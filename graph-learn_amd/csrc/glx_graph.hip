@@ -127,6 +127,72 @@ void glx_scratch_free(void* p, hipStream_t s) {
   (void)s;  // workspaces are cached per thread/stream; nothing to release per call
 }
 
+// ---------------------------------------------------------------- profiling --
+namespace {
+struct TimedLaunch {
+  int kind;
+  hipEvent_t start, stop;
+};
+struct ProfileState {
+  bool on = false;
+  std::vector<TimedLaunch> launches;
+  std::vector<hipEvent_t> free_events;
+};
+thread_local ProfileState g_prof;
+
+hipEvent_t prof_event() {
+  if (!g_prof.free_events.empty()) {
+    hipEvent_t e = g_prof.free_events.back();
+    g_prof.free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+GlxKernelTimer::GlxKernelTimer(int kind, hipStream_t stream) : s(stream) {
+  if (!g_prof.on) return;
+  TimedLaunch t{kind, prof_event(), prof_event()};
+  if (!t.start || !t.stop) return;
+  if (hipEventRecord(t.start, s) != hipSuccess) return;
+  g_prof.launches.push_back(t);
+  slot = (int)g_prof.launches.size() - 1;
+}
+
+void GlxKernelTimer::stop() {
+  if (slot >= 0) (void)hipEventRecord(g_prof.launches[slot].stop, s);
+}
+
+extern "C" int glx_profile_enable(int on) {
+  g_prof.on = on != 0;
+  return GLX_OK;
+}
+
+extern "C" int glx_profile_collect(int kind, float* ms_out, int32_t cap, int32_t* count) {
+  GLX_REQUIRE(count != nullptr, "count is NULL");
+  int32_t n = 0;
+  std::vector<TimedLaunch> keep;
+  for (auto& t : g_prof.launches) {
+    if (t.kind != kind) {
+      keep.push_back(t);
+      continue;
+    }
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(t.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t.start, t.stop);
+    if (e == hipSuccess && ms_out && n < cap) ms_out[n] = ms;
+    if (e == hipSuccess) ++n;
+    g_prof.free_events.push_back(t.start);
+    g_prof.free_events.push_back(t.stop);
+  }
+  g_prof.launches.swap(keep);
+  (void)hipGetLastError();
+  *count = n < cap || !ms_out ? n : cap;
+  return GLX_OK;
+}
+
 // ------------------------------------------------------------------ id map --
 __global__ void glx_idmap_fill_kernel(int64_t* keys, uint64_t cap) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;

@@ -19,6 +19,7 @@ struct SampleArgs {
   const GlxAdj* adj;
   const GlxAlias* alias;
   const int64_t* src;
+  const int64_t* rng_rows;  // nullptr: request row i uses stream i
   int64_t* nbr_out;
   int64_t* eid_out;
   int64_t default_nbr;
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
   const int64_t obase = (int64_t)i * a.k;
   GlxPhilox blk;
   if (OP == kSlotRandom || OP == kSlotEdgeWeight) {
-    if (deg > 0) blk = glx_philox_block((uint32_t)q, (uint32_t)i, a.seed, a.cc);
+    if (deg > 0) {
+      const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
+      blk = glx_philox_block((uint32_t)q, rr, a.seed, a.cc);
+    }
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
   const int32_t m = (int32_t)(deg < a.k ? deg : a.k);
   int32_t r = -1;
   if (l < m) {
-    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, (uint32_t)i, (uint32_t)l),
-                                 (uint64_t)(deg - l));
+    const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
+    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, (uint32_t)l), (uint64_t)(deg - l));
   }
   int32_t w = 0, perm = 0;
   for (int32_t j = 0; j < a.k; ++j) {
@@ -165,9 +169,9 @@ __global__ __launch_bounds__(64) void glx_rwor_lds_kernel(SampleArgs a) {
     deg = a.row_ptr[row + 1] - start;
   }
   const int32_t m = (int32_t)(deg < k ? deg : k);
+  const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
   for (int32_t t = lane; t < m; t += 64) {
-    r[t] = t + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, (uint32_t)i, (uint32_t)t),
-                                    (uint64_t)(deg - t));
+    r[t] = t + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, (uint32_t)t), (uint64_t)(deg - t));
   }
   __syncthreads();
   for (int32_t j = 0; j < m; ++j) {
@@ -210,6 +214,7 @@ void launch_rwor(const SampleArgs& a, hipStream_t s) {
 int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padding_mode,
                   hipStream_t s) {
   const bool circular = padding_mode == GLX_PAD_CIRCULAR;
+  GlxKernelTimer timer(GLX_KERNEL_SAMPLE, s);
   switch (sampler) {
     case GLX_SAMPLER_RANDOM:
       launch_slots<kSlotRandom>(a, s);
@@ -247,16 +252,17 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
       glx_set_error("unknown sampler id %d", sampler);
       return GLX_INVALID_ARGUMENT;
   }
+  timer.stop();
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
 
 }  // namespace
 
-extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batch,
-                          int32_t k, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
-                          uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
-                          void* stream) {
+extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src,
+                             const int64_t* rng_rows, int32_t batch, int32_t k, int padding_mode,
+                             int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                             int64_t* nbr_out, int64_t* eid_out, int ptr_kind, void* stream) {
   GLX_REQUIRE(g != nullptr, "graph is NULL");
   GLX_REQUIRE(batch >= 0 && k >= 0, "negative batch / neighbor_count");
   GLX_REQUIRE(padding_mode == GLX_PAD_CIRCULAR || padding_mode == GLX_PAD_REPLICATE,
@@ -282,6 +288,7 @@ extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, i
   a.k = k;
   if (ptr_kind == GLX_PTR_DEVICE) {
     a.src = src;
+    a.rng_rows = rng_rows;
     a.nbr_out = nbr_out;
     a.eid_out = eid_out;
     return sample_device(g, sampler, a, padding_mode, s);
@@ -289,12 +296,14 @@ extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, i
   // Host pointers: stage through stream-ordered scratch; synchronous.
   const size_t n_out = (size_t)batch * k;
   int64_t* d = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch + 2 * n_out) * 8, s, 0);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch * 2 + 2 * n_out) * 8, s, 0);
   if (rc != GLX_OK) return rc;
   a.src = d;
-  a.nbr_out = d + batch;
-  a.eid_out = d + batch + n_out;
+  a.rng_rows = rng_rows ? d + batch : nullptr;
+  a.nbr_out = d + 2 * (size_t)batch;
+  a.eid_out = d + 2 * (size_t)batch + n_out;
   hipError_t e = hipMemcpyAsync(d, src, (size_t)batch * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && rng_rows) e = hipMemcpyAsync(d + batch, rng_rows, (size_t)batch * 8, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     rc = sample_device(g, sampler, a, padding_mode, s);
     if (rc == GLX_OK) {
@@ -308,4 +317,12 @@ extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, i
   GLX_HIP(e);
   GLX_HIP(e2);
   return GLX_OK;
+}
+
+extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batch,
+                          int32_t k, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+                          uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+                          void* stream) {
+  return glx_sample_ex(g, sampler, src, nullptr, batch, k, padding_mode, default_neighbor_id, seed,
+                       call_counter, nbr_out, eid_out, ptr_kind, stream);
 }

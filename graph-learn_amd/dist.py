@@ -1,0 +1,115 @@
+"""Sharded execution of the hot path over torch.distributed (RCCL on GPUs).
+
+Replaces the reference's DistributeRunner (graphlearn/src/core/runner/
+op_runner.h:60-152): Partition (hash_partitioner.h:33-92) -> ship sub-requests
+-> Process on the owning shard -> ship results back -> Stitch
+(stitcher.h:67-107).  gRPC + protobuf become two all-to-all(v) exchanges per
+operator on the xGMI mesh; the bucketing and the stitch are HIP kernels
+(glx_partition / glx_stitch_*).
+
+Ownership rule (kept from the reference so results are comparable): the
+out-edges and the features of vertex v live on shard llabs(v) % P
+(hash_partitioner.h:90-92, graph_update_request.cc:151,234).
+
+Results are bit-identical to the unpartitioned operator for every shard count:
+  * sampling ships each row's index in the original request with its id and
+    the owner draws from THAT row's random stream (glx_sample_ex);
+  * aggregation ships ids to the owners, gathers feature rows there
+    (glx_lookup), ships the rows back (the halo exchange) and reduces them on
+    the requester in the original order -- so the reference's distributed
+    Max/Min/Prod divergence does not occur.
+
+`ops` abstracts the local compute: DeviceOps (HIP, the product) or, in the CPU
+tests only, an oracle-backed stand-in.  Tensors are torch tensors throughout.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DeviceOps:
+    """Local compute on this rank's GPU through the glx C-ABI."""
+
+    def __init__(self):
+        import glx
+        self.glx = glx
+
+    def partition(self, ids, num_shards):
+        return self.glx.partition(ids, num_shards)
+
+    def stitch(self, rows, order):
+        return self.glx.stitch(rows, order)
+
+    def sample(self, graph, sampler, ids, rng_rows, k, seed, cc, pad, dflt):
+        return graph.sample(sampler, ids, k, seed=seed, call_counter=cc, padding_mode=pad,
+                            default_neighbor_id=dflt, rng_rows=rng_rows)
+
+    def lookup(self, feats, ids, default_attr):
+        return feats.lookup(ids, default_attr)
+
+    def aggregate_rows(self, rows, pos, seg, num_segments, op, default_attr):
+        view = self.glx.Features(rows, view=True, device=rows.device.index or 0)
+        return view.aggregate(op, pos, seg, num_segments, default_attr)
+
+
+def _a2a(x, send_counts, recv_counts, group):
+    out = x.new_empty((int(sum(recv_counts)),) + tuple(x.shape[1:]))
+    dist.all_to_all_single(out, x.contiguous(), output_split_sizes=list(recv_counts),
+                           input_split_sizes=list(send_counts), group=group)
+    return out
+
+
+class ShardedStore:
+    """One rank's view of an edge-cut partitioned graph + feature store."""
+
+    def __init__(self, ops, graph_shard, feature_shard, group=None):
+        self.ops = ops
+        self.graph = graph_shard
+        self.feats = feature_shard
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def _route(self, ids):
+        """Bucket ids by owner and tell every owner how many it will receive."""
+        bucketed, order, counts = self.ops.partition(ids, self.world)
+        recv = torch.empty_like(counts)
+        dist.all_to_all_single(recv, counts, group=self.group)
+        return bucketed, order, counts.tolist(), recv.tolist()
+
+    def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0):
+        bucketed, order, send, recv = self._route(src)
+        ids_in = _a2a(bucketed, send, recv, self.group)
+        rows_in = _a2a(order, send, recv, self.group)  # original row index = random stream
+        nbr, eid = self.ops.sample(self.graph, sampler, ids_in, rows_in, k, seed, call_counter,
+                                   padding_mode, default_neighbor_id)
+        nbr = _a2a(nbr, recv, send, self.group)
+        eid = _a2a(eid, recv, send, self.group)
+        return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
+
+    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0):
+        bucketed, order, send, recv = self._route(node_ids)
+        ids_in = _a2a(bucketed, send, recv, self.group)
+        rows = self.ops.lookup(self.feats, ids_in, default_attr)
+        rows = _a2a(rows, recv, send, self.group)  # halo rows, in bucketed order
+        # pos[i] = where original element i sits in `rows` (inverse of `order`)
+        n = node_ids.shape[0]
+        pos = self.ops.stitch(torch.arange(n, dtype=torch.int64, device=node_ids.device).view(n, 1),
+                              order).view(n)
+        return self.ops.aggregate_rows(rows, pos, segment_ids, num_segments, op, default_attr)
+
+
+def shard_graph(row_ptr, col, eid, weight, rank, world):
+    """Rows of the (dense-id, torch) CSR owned by `rank`: v % world == rank.
+    -> (row_ptr, col, eid, weight, ids) of the shard; col keeps GLOBAL ids."""
+    V = row_ptr.shape[0] - 1
+    ids = torch.arange(rank, V, world, dtype=torch.int64, device=row_ptr.device)
+    deg = row_ptr[ids + 1] - row_ptr[ids]
+    rp = torch.zeros(ids.shape[0] + 1, dtype=torch.int64, device=row_ptr.device)
+    rp[1:] = torch.cumsum(deg, 0)
+    # slot indices of the kept rows, row-major
+    total = int(rp[-1].item())
+    row_of_slot = torch.repeat_interleave(torch.arange(ids.shape[0], device=row_ptr.device), deg,
+                                          output_size=total)
+    slot = row_ptr[ids][row_of_slot] + (torch.arange(total, device=row_ptr.device) - rp[row_of_slot])
+    w = weight[slot].contiguous() if weight is not None else None
+    return rp, col[slot].contiguous(), eid[slot].contiguous(), w, ids

@@ -37,10 +37,11 @@ AGGREGATOR_IDS = {
 EXPORTS = [
     "glx_abi_version", "glx_device_count", "glx_last_error",
     "glx_graph_create", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
-    "glx_graph_degrees", "glx_sample",
-    "glx_features_create", "glx_features_destroy", "glx_features_info",
+    "glx_graph_degrees", "glx_sample", "glx_sample_ex",
+    "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
     "glx_partition", "glx_stitch_i64", "glx_stitch_f32",
+    "glx_profile_enable", "glx_profile_collect",
 ]
 
 
@@ -79,6 +80,8 @@ def lib():
         L.glx_graph_export_alias.argtypes = [vp, vp, vp, ci, vp]
         L.glx_graph_degrees.argtypes = [vp, vp, i64, vp, ci, vp]
         L.glx_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
+        L.glx_sample_ex.argtypes = [vp, ci, vp, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
+        L.glx_features_view.argtypes = [ci, i64, i32, vp, ctypes.POINTER(vp)]
         L.glx_features_create.argtypes = [ci, i64, i32, vp, vp, ci, vp, ctypes.POINTER(vp)]
         L.glx_features_destroy.argtypes = [vp]
         L.glx_features_destroy.restype = None
@@ -89,6 +92,8 @@ def lib():
         L.glx_partition.argtypes = [ci, vp, i64, i32, vp, vp, vp, vp]
         L.glx_stitch_i64.argtypes = [ci, vp, vp, i64, i32, vp, vp]
         L.glx_stitch_f32.argtypes = [ci, vp, vp, i64, i32, vp, vp]
+        L.glx_profile_enable.argtypes = [ci]
+        L.glx_profile_collect.argtypes = [ci, vp, i32, ctypes.POINTER(i32)]
         _lib = L
     return _lib
 
@@ -173,7 +178,7 @@ class Graph:
         return out
 
     def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR,
-               default_neighbor_id=0, out=None):
+               default_neighbor_id=0, out=None, rng_rows=None):
         """-> (nbr[batch, k], eid[batch, k]) int64; numpy in -> numpy out, torch in -> torch out."""
         if isinstance(sampler, str):
             sampler = SAMPLER_IDS[sampler]
@@ -187,17 +192,28 @@ class Graph:
         else:
             nbr = np.empty((batch, k), np.int64)
             eid = np.empty((batch, k), np.int64)
-        ps, pn, pe = _ptr(src), _ptr(nbr), _ptr(eid)
-        kind = _kind(ps, pn, pe)
-        _check(lib().glx_sample(self._h, sampler, ps[0], batch, k, padding_mode, default_neighbor_id,
-                                seed, call_counter, pn[0], pe[0], kind, _stream(kind)))
+        ps, pn, pe, pr = _ptr(src), _ptr(nbr), _ptr(eid), _ptr(rng_rows)
+        kind = _kind(ps, pn, pe, pr)
+        _check(lib().glx_sample_ex(self._h, sampler, ps[0], pr[0], batch, k, padding_mode,
+                                   default_neighbor_id, seed, call_counter, pn[0], pe[0], kind,
+                                   _stream(kind)))
         return nbr, eid
 
 
 class Features:
     """Device-resident [V, D] float32 node features of one node type (glx_features)."""
 
-    def __init__(self, X, ids=None, device=0):
+    def __init__(self, X, ids=None, device=0, view=False):
+        """view=True: non-owning view of a torch CUDA matrix (dense ids); keeps X alive."""
+        if view:
+            assert ids is None and _is_torch(X)
+            self.num_rows, self.dim = int(X.shape[0]), int(X.shape[1])
+            self.device = device
+            self._keep = X
+            h = ctypes.c_void_p()
+            _check(lib().glx_features_view(device, self.num_rows, self.dim, _ptr(X)[0], ctypes.byref(h)))
+            self._h = h
+            return
         ptrs = [_ptr(X), _ptr(ids)]
         kind = _kind(*ptrs)
         self.num_rows, self.dim = int(X.shape[0]), int(X.shape[1])
@@ -271,3 +287,18 @@ def stitch(rows, order):
     assert rows.dtype in (torch.int64, torch.float32)
     _check(fn(dev, _ptr(rows)[0], _ptr(order)[0], n, width, _ptr(out)[0], _stream(PTR_DEVICE)))
     return out
+
+
+KERNEL_SAMPLE, KERNEL_AGGREGATE, KERNEL_LOOKUP = 0, 1, 2
+
+
+def profile_enable(on=True):
+    _check(lib().glx_profile_enable(1 if on else 0))
+
+
+def profile_collect(kind, cap=1 << 16):
+    """Durations (ms) of the timed dominant-kernel launches of `kind`, oldest first."""
+    buf = np.zeros(cap, np.float32)
+    n = ctypes.c_int32(0)
+    _check(lib().glx_profile_collect(kind, _ptr(buf)[0], cap, ctypes.byref(n)))
+    return buf[:n.value].copy()

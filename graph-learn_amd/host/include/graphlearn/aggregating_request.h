@@ -1,0 +1,60 @@
+// AggregatingRequest / AggregatingResponse with the reference's surface
+// (graphlearn/src/include/aggregating_request.h:24-91).
+#ifndef GLX_HOST_AGGREGATING_REQUEST_H_
+#define GLX_HOST_AGGREGATING_REQUEST_H_
+#include <string>
+
+#include "graphlearn/op_request.h"
+
+namespace graphlearn {
+
+class AggregatingRequest : public OpRequest {
+public:
+  AggregatingRequest();
+  AggregatingRequest(const std::string& type, const std::string& strategy);
+  OpRequest* Clone() const override;
+  void Set(const int64_t* node_ids, const int32_t* segment_ids, int32_t num_ids, int32_t num_segments);
+
+  const std::string& Type() const;
+  const std::string& Strategy() const;
+  // Cursor interface of the reference (aggregating_request.cc:86-105).
+  bool Next(int64_t* node_id, int32_t* segment_id);
+  bool SegmentEnd(int32_t segment_id) const;
+  int32_t NumIds() const;
+  int32_t NumSegments() const { return num_segments_; }
+  const int64_t* NodeIds() const;
+  const int32_t* SegmentIds() const;
+
+private:
+  int32_t cursor_;
+  int32_t num_segments_;
+};
+
+class AggregatingResponse : public OpResponse {
+public:
+  AggregatingResponse();
+  OpResponse* New() const override { return new AggregatingResponse; }
+  void Swap(OpResponse& right) override;
+
+  void SetName(const std::string& name);
+  void SetEmbeddingDim(int32_t dim);
+  void SetNumSegments(int32_t num_segments);
+  std::string Name() const { return name_; }
+  int32_t EmbeddingDim() const { return emb_dim_; }
+  int32_t NumSegments() const { return batch_size_; }
+  void AppendEmbedding(const float* value);
+  void AppendSegment(int32_t size);
+  const float* Embeddings() const;
+  const int32_t* Segments() const;
+
+  // Device-path addition: size outputs for one bulk write.
+  float* MutableEmbeddings();
+  int32_t* MutableSegments();
+
+private:
+  std::string name_;
+  int32_t emb_dim_;
+};
+
+}  // namespace graphlearn
+#endif  // GLX_HOST_AGGREGATING_REQUEST_H_

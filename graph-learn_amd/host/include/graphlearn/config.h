@@ -1,0 +1,32 @@
+// Global flags of the hot path.  Mirrors graphlearn/src/include/config.h:25-162
+// (GLOBAL_FLAG(name), SetGlobalFlag<Name>) with the defaults of
+// graphlearn/src/common/base/config.cc:77-163 for the flags the samplers and
+// aggregators read, plus the two flags the device path adds.
+#ifndef GLX_HOST_CONFIG_H_
+#define GLX_HOST_CONFIG_H_
+#include <cstdint>
+
+namespace graphlearn {
+#define GLOBAL_FLAG(name) ::graphlearn::g##name
+
+extern int32_t gPaddingMode;            // config.cc:94  (1 = circular)
+extern int64_t gDefaultNeighborId;      // config.cc:98  (0)
+extern float gDefaultFloatAttribute;    // config.cc:100 (0.0)
+extern float gDefaultWeight;            // config.cc:102 (0.0)
+extern int32_t gSamplingRetryTimes;     // config.cc:108 (5; filters only, unused on device)
+// New (the reference has no seed flag, include/config.h:77-118): the seed of the
+// glx seeding contract, and the GPU this process' GraphStore lives on.
+extern int64_t gSamplingSeed;
+extern int32_t gDeviceId;
+
+void SetGlobalFlagPaddingMode(int32_t v);
+void SetGlobalFlagDefaultNeighborId(int64_t v);
+void SetGlobalFlagDefaultFloatAttribute(float v);
+void SetGlobalFlagDefaultWeight(float v);
+void SetGlobalFlagSamplingRetryTimes(int32_t v);
+void SetGlobalFlagSamplingSeed(int64_t v);
+void SetGlobalFlagDeviceId(int32_t v);
+
+enum PaddingMode { kReplicate = 0, kCircular = 1 };  // include/constants.h:119-122
+}  // namespace graphlearn
+#endif  // GLX_HOST_CONFIG_H_

@@ -1,0 +1,141 @@
+// GraphStore: the heterogeneous type -> storage map of the reference
+// (graphlearn/src/core/graph/graph_store.h:32-66, heter_dispatcher.h:44-56), with
+// device-resident storages.  Edges / nodes are staged on the host exactly like
+// LocalGraph::UpdateEdges -> storage->Add (core/graph/local_graph.cc:50-64);
+// Build() sorts rows the way MemoryAdjMatrix::Build does
+// (memory_adj_matrix.cc:60-66,105-125: weight descending for weighted types),
+// converts to CSR (memory_adj_matrix.cc:169-189) and uploads it through the
+// C-ABI (glx_graph_create / glx_features_create).  After Build() the storage is
+// immutable and served from HBM.
+#ifndef GLX_HOST_GRAPH_STORE_H_
+#define GLX_HOST_GRAPH_STORE_H_
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "graphlearn/status.h"
+
+struct glx_graph;
+struct glx_features;
+
+namespace graphlearn {
+namespace io {
+
+enum DataFormat { kDefault = 1, kWeighted = 2, kLabeled = 4, kTimestamped = 8, kAttributed = 16 };
+
+// graphlearn/src/core/io/element_value.h:30-70 (fields used on this path).
+struct SideInfo {
+  int32_t i_num = 0, f_num = 0, s_num = 0;
+  int32_t format = 0;
+  std::string type, src_type, dst_type;
+  bool IsInitialized() const { return format != 0; }
+  bool IsWeighted() const { return format & kWeighted; }
+  bool IsAttributed() const { return format & kAttributed; }
+};
+
+struct EdgeValue {  // element_value.h:104-116
+  int64_t src_id = 0, dst_id = 0;
+  float weight = 0.f;
+  int32_t label = 0;
+  int64_t timestamp = 0;
+};
+
+struct NodeValue {  // element_value.h:118-132; attrs = the float attributes
+  int64_t id = 0;
+  float weight = 0.f;
+  int32_t label = 0;
+  std::vector<float> attrs;
+};
+
+}  // namespace io
+
+struct IndexOption {  // include/index_option.h
+  std::string name;
+};
+
+// Minimal UpdateEdges/UpdateNodes requests so that fixtures read like the
+// reference's tests (sampler_unittest.cpp:33-70); they only carry values.
+class UpdateEdgesRequest {
+public:
+  UpdateEdgesRequest(const io::SideInfo* info, int32_t batch_size);
+  void Append(const io::EdgeValue* value);
+  const io::SideInfo& GetSideInfo() const { return info_; }
+  const std::vector<io::EdgeValue>& Values() const { return values_; }
+private:
+  io::SideInfo info_;
+  std::vector<io::EdgeValue> values_;
+};
+class UpdateEdgesResponse {};
+class UpdateNodesRequest {
+public:
+  UpdateNodesRequest(const io::SideInfo* info, int32_t batch_size);
+  void Append(const io::NodeValue* value);
+  const io::SideInfo& GetSideInfo() const { return info_; }
+  const std::vector<io::NodeValue>& Values() const { return values_; }
+private:
+  io::SideInfo info_;
+  std::vector<io::NodeValue> values_;
+};
+class UpdateNodesResponse {};
+
+// One edge type.  Host staging + device CSR.
+class Graph {
+public:
+  explicit Graph(const std::string& type);
+  ~Graph();
+  Status UpdateEdges(const UpdateEdgesRequest* req, UpdateEdgesResponse* res);
+  void SetSideInfo(const io::SideInfo* info);
+  const io::SideInfo* GetSideInfo() const { return &info_; }
+  void Add(const io::EdgeValue* value);          // edge id = insertion index
+  Status Build(const IndexOption& option);       // sort (if option.name=="sort") + upload
+  int64_t GetEdgeCount() const { return (int64_t)src_.size(); }
+  const glx_graph* Device() const { return dev_; }  // nullptr before Build()
+
+private:
+  std::string type_;
+  io::SideInfo info_;
+  std::vector<int64_t> src_, dst_;
+  std::vector<float> weight_;
+  glx_graph* dev_;
+  std::mutex mtx_;
+};
+
+// One node type.  Host staging + device feature matrix.
+class Noder {
+public:
+  explicit Noder(const std::string& type);
+  ~Noder();
+  Status UpdateNodes(const UpdateNodesRequest* req, UpdateNodesResponse* res);
+  void SetSideInfo(const io::SideInfo* info);
+  const io::SideInfo* GetSideInfo() const { return &info_; }
+  void Add(const io::NodeValue* value);          // duplicate ids are ignored (node_storage.h:41)
+  Status Build(const IndexOption& option);
+  const glx_features* Device() const { return dev_; }
+
+private:
+  std::string type_;
+  io::SideInfo info_;
+  std::vector<int64_t> ids_;
+  std::vector<float> feats_;
+  std::unordered_map<int64_t, int32_t> index_;
+  glx_features* dev_;
+  std::mutex mtx_;
+};
+
+class GraphStore {
+public:
+  GraphStore();
+  ~GraphStore();
+  Graph* GetGraph(const std::string& edge_type);
+  Noder* GetNoder(const std::string& node_type);
+
+private:
+  std::mutex mtx_;
+  std::unordered_map<std::string, Graph*> graphs_;
+  std::unordered_map<std::string, Noder*> noders_;
+};
+
+}  // namespace graphlearn
+#endif  // GLX_HOST_GRAPH_STORE_H_

@@ -1,0 +1,79 @@
+// SamplingRequest / SamplingResponse / Shape with the reference's surface
+// (graphlearn/src/include/sampling_request.h:31-149).
+#ifndef GLX_HOST_SAMPLING_REQUEST_H_
+#define GLX_HOST_SAMPLING_REQUEST_H_
+#include <string>
+#include <vector>
+
+#include "graphlearn/op_request.h"
+
+namespace graphlearn {
+
+enum FilterType { kOperatorUnspecified = 0, kLargerThan = 1, kEqual = 2 };
+enum FilterField { kFieldUnspecified = 0, kId = 1, kTimestamp = 2 };
+
+struct Shape {
+  size_t dim1;  // batch size
+  size_t dim2;  // neighbor count
+  size_t size;  // dim1 * dim2 (dense)
+  std::vector<int32_t> segments;
+  bool sparse;
+  Shape() : dim1(0), dim2(0), size(0), sparse(false) {}
+  Shape(size_t x, size_t y) : dim1(x), dim2(y), size(x * y), segments(x, (int32_t)y), sparse(false) {}
+};
+
+class SamplingRequest : public OpRequest {
+public:
+  SamplingRequest();
+  SamplingRequest(const std::string& type, const std::string& strategy, int32_t neighbor_count,
+                  FilterType filter_type = kOperatorUnspecified,
+                  FilterField filter_field = kFieldUnspecified);
+  OpRequest* Clone() const override;
+  void Init(const Tensor::Map& params) override;
+  void Set(const Tensor::Map& tensors) override;
+  void Set(const int64_t* src_ids, int32_t batch_size);
+
+  const std::string& Type() const;
+  const std::string& Strategy() const;
+  int32_t BatchSize() const;
+  int32_t NeighborCount() const { return neighbor_count_; }
+  const int64_t* GetSrcIds() const;
+  // true when a filter was requested (sampler/filter.h:73-75); the device path
+  // rejects such requests with Unimplemented.
+  bool HasFilter() const { return filter_type_ != kOperatorUnspecified && filter_field_ != kFieldUnspecified; }
+
+private:
+  void InitParams(const std::string& type, const std::string& strategy);
+  int32_t neighbor_count_;
+  FilterType filter_type_;
+  FilterField filter_field_;
+};
+
+class SamplingResponse : public OpResponse {
+public:
+  SamplingResponse();
+  OpResponse* New() const override { return new SamplingResponse; }
+  void Swap(OpResponse& right) override;
+
+  void SetShape(size_t dim1, size_t dim2);
+  void InitNeighborIds();
+  void InitEdgeIds();
+  void AppendNeighborId(int64_t id);
+  void AppendEdgeId(int64_t id);
+  void FillWith(int64_t neighbor_id, int64_t edge_id = -1);
+
+  const Shape GetShape() const { return shape_; }
+  int64_t* GetNeighborIds();
+  int64_t* GetEdgeIds();
+  const int64_t* GetNeighborIds() const;
+  const int64_t* GetEdgeIds() const;
+
+  // Device-path addition: size both tensors to dim1*dim2 for one bulk write.
+  void ResizeDense();
+
+private:
+  Shape shape_;
+};
+
+}  // namespace graphlearn
+#endif  // GLX_HOST_SAMPLING_REQUEST_H_

@@ -1,0 +1,136 @@
+// Status, flags, constants and the vector-backed Tensor of the glx host layer.
+#include <cstring>
+
+#include "glx.h"
+#include "graphlearn/config.h"
+#include "graphlearn/constants.h"
+#include "graphlearn/status.h"
+#include "graphlearn/tensor.h"
+
+namespace graphlearn {
+
+// ----------------------------------------------------------------- status --
+std::string Status::ToString() const {
+  if (ok()) return "OK";
+  return "code " + std::to_string(static_cast<int>(code_)) + ": " + msg_;
+}
+
+namespace error {
+Status FromGlx(int code) {
+  if (code == GLX_OK) return Status::OK();
+  return Status(static_cast<Code>(code), glx_last_error());
+}
+}  // namespace error
+
+// ------------------------------------------------------------------ flags --
+int32_t gPaddingMode = 1;
+int64_t gDefaultNeighborId = 0;
+float gDefaultFloatAttribute = 0.0f;
+float gDefaultWeight = 0.0f;
+int32_t gSamplingRetryTimes = 5;
+int64_t gSamplingSeed = 0;
+int32_t gDeviceId = 0;
+
+void SetGlobalFlagPaddingMode(int32_t v) { gPaddingMode = v; }
+void SetGlobalFlagDefaultNeighborId(int64_t v) { gDefaultNeighborId = v; }
+void SetGlobalFlagDefaultFloatAttribute(float v) { gDefaultFloatAttribute = v; }
+void SetGlobalFlagDefaultWeight(float v) { gDefaultWeight = v; }
+void SetGlobalFlagSamplingRetryTimes(int32_t v) { gSamplingRetryTimes = v; }
+void SetGlobalFlagSamplingSeed(int64_t v) { gSamplingSeed = v; }
+void SetGlobalFlagDeviceId(int32_t v) { gDeviceId = v; }
+
+// -------------------------------------------------------------- constants --
+// Key strings only need to be distinct and stable inside one process (the
+// reference ships them in protobuf messages; here nothing is serialised).
+const char* kUnspecified = "unspecified";
+const char* kOpName = "op";
+const char* kNodeType = "node_type";
+const char* kEdgeType = "edge_type";
+const char* kType = "type";
+const char* kSrcIds = "src_ids";
+const char* kNodeIds = "node_ids";
+const char* kEdgeIds = "edge_ids";
+const char* kNeighborCount = "neighbor_count";
+const char* kStrategy = "strategy";
+const char* kFloatAttrKey = "float_attrs";
+const char* kSideInfo = "side_info";
+const char* kSegmentIds = "segment_ids";
+const char* kNumSegments = "num_segments";
+const char* kSegments = "segments";
+const char* kFilterType = "filter_type";
+const char* kFilterField = "filter_field";
+const char* kFilterValues = "filter_values";
+
+// ----------------------------------------------------------------- tensor --
+struct Tensor::Impl {
+  DataType type = kUnknown;
+  std::vector<int32_t> i32;
+  std::vector<int64_t> i64;
+  std::vector<float> f32;
+  std::vector<double> f64;
+  std::vector<std::string> str;
+};
+
+Tensor::Tensor() : impl_(std::make_shared<Impl>()) {}
+Tensor::Tensor(DataType dtype) : impl_(std::make_shared<Impl>()) { impl_->type = dtype; }
+Tensor::Tensor(DataType dtype, int32_t capacity) : impl_(std::make_shared<Impl>()) {
+  impl_->type = dtype;
+  if (capacity > 0) {
+    switch (dtype) {
+      case kInt32: impl_->i32.reserve(capacity); break;
+      case kInt64: impl_->i64.reserve(capacity); break;
+      case kFloat: impl_->f32.reserve(capacity); break;
+      case kDouble: impl_->f64.reserve(capacity); break;
+      case kString: impl_->str.reserve(capacity); break;
+      default: break;
+    }
+  }
+}
+DataType Tensor::DType() const { return impl_->type; }
+int32_t Tensor::Size() const {
+  switch (impl_->type) {
+    case kInt32: return (int32_t)impl_->i32.size();
+    case kInt64: return (int32_t)impl_->i64.size();
+    case kFloat: return (int32_t)impl_->f32.size();
+    case kDouble: return (int32_t)impl_->f64.size();
+    case kString: return (int32_t)impl_->str.size();
+    default: return 0;
+  }
+}
+void Tensor::Resize(int32_t size) {
+  switch (impl_->type) {
+    case kInt32: impl_->i32.resize(size); break;
+    case kInt64: impl_->i64.resize(size); break;
+    case kFloat: impl_->f32.resize(size); break;
+    case kDouble: impl_->f64.resize(size); break;
+    case kString: impl_->str.resize(size); break;
+    default: break;
+  }
+}
+void Tensor::AddInt32(int32_t v) { impl_->i32.push_back(v); }
+void Tensor::AddInt64(int64_t v) { impl_->i64.push_back(v); }
+void Tensor::AddFloat(float v) { impl_->f32.push_back(v); }
+void Tensor::AddDouble(double v) { impl_->f64.push_back(v); }
+void Tensor::AddString(const std::string& v) { impl_->str.push_back(v); }
+void Tensor::AddInt32(const int32_t* b, const int32_t* e) { impl_->i32.insert(impl_->i32.end(), b, e); }
+void Tensor::AddInt64(const int64_t* b, const int64_t* e) { impl_->i64.insert(impl_->i64.end(), b, e); }
+void Tensor::AddFloat(const float* b, const float* e) { impl_->f32.insert(impl_->f32.end(), b, e); }
+void Tensor::AddDouble(const double* b, const double* e) { impl_->f64.insert(impl_->f64.end(), b, e); }
+void Tensor::SetInt32(int32_t i, int32_t v) { impl_->i32[i] = v; }
+void Tensor::SetInt64(int32_t i, int64_t v) { impl_->i64[i] = v; }
+void Tensor::SetFloat(int32_t i, float v) { impl_->f32[i] = v; }
+int32_t Tensor::GetInt32(int32_t i) const { return impl_->i32[i]; }
+int64_t Tensor::GetInt64(int32_t i) const { return impl_->i64[i]; }
+float Tensor::GetFloat(int32_t i) const { return impl_->f32[i]; }
+double Tensor::GetDouble(int32_t i) const { return impl_->f64[i]; }
+const std::string& Tensor::GetString(int32_t i) const { return impl_->str[i]; }
+const int32_t* Tensor::GetInt32() const { return impl_->i32.data(); }
+const int64_t* Tensor::GetInt64() const { return impl_->i64.data(); }
+const float* Tensor::GetFloat() const { return impl_->f32.data(); }
+const double* Tensor::GetDouble() const { return impl_->f64.data(); }
+int32_t* Tensor::MutableInt32() { return impl_->i32.data(); }
+int64_t* Tensor::MutableInt64() { return impl_->i64.data(); }
+float* Tensor::MutableFloat() { return impl_->f32.data(); }
+void Tensor::Swap(Tensor& right) { std::swap(impl_, right.impl_); }
+
+}  // namespace graphlearn

@@ -1,0 +1,82 @@
+// The four neighbour samplers behind the reference's registry names.  Each
+// Process() is what a maintainer of the reference would put in
+// Sampler::Sample (core/operator/sampler/sampler.h:36-57): size the dense
+// response, then one C-ABI call that runs the HIP kernels and writes the
+// response tensors in place.  No CPU sampling code exists in this layer: if the
+// GPU library fails, the Status says so.
+#include <atomic>
+
+#include "glx.h"
+#include "graphlearn/config.h"
+#include "graphlearn/graph_store.h"
+#include "graphlearn/operator.h"
+#include "graphlearn/sampling_request.h"
+
+namespace graphlearn {
+namespace op {
+
+class Sampler : public Operator {
+public:
+  Status Process(const OpRequest* req, OpResponse* res) override {
+    return Sample(static_cast<const SamplingRequest*>(req), static_cast<SamplingResponse*>(res));
+  }
+
+protected:
+  virtual int SamplerId() const = 0;
+
+  Status Sample(const SamplingRequest* req, SamplingResponse* res) {
+    const int32_t count = req->NeighborCount();
+    const int32_t batch_size = req->BatchSize();
+    res->SetShape(batch_size, count);
+    res->InitNeighborIds();
+    res->InitEdgeIds();
+    if (req->HasFilter()) {
+      return error::Unimplemented("sampling filters are not supported on the device path");
+    }
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    const glx_graph* g = graph_store_->GetGraph(req->Type())->Device();
+    res->ResizeDense();
+    if (!g) {
+      // An edge type nobody loaded behaves like a storage without any row:
+      // every src id is unknown -> default fill (random_sampler.cc:58-59).
+      int64_t* n = res->GetNeighborIds();
+      int64_t* e = res->GetEdgeIds();
+      for (int64_t i = 0; i < (int64_t)batch_size * count; ++i) {
+        n[i] = GLOBAL_FLAG(DefaultNeighborId);
+        e[i] = -1;
+      }
+      return Status::OK();
+    }
+    // The reference's RNG state advances from call to call (thread_local
+    // mt19937); the contract's equivalent is a per-operator call counter.
+    const uint64_t cc = call_counter_.fetch_add(1, std::memory_order_relaxed);
+    int rc = glx_sample(g, SamplerId(), req->GetSrcIds(), batch_size, count, GLOBAL_FLAG(PaddingMode),
+                        GLOBAL_FLAG(DefaultNeighborId), (uint64_t)GLOBAL_FLAG(SamplingSeed), cc,
+                        res->GetNeighborIds(), res->GetEdgeIds(), GLX_PTR_HOST, nullptr);
+    return error::FromGlx(rc);
+  }
+
+private:
+  std::atomic<uint64_t> call_counter_{0};
+};
+
+class RandomSampler : public Sampler {
+  int SamplerId() const override { return GLX_SAMPLER_RANDOM; }
+};
+class RandomWithoutReplacementSampler : public Sampler {
+  int SamplerId() const override { return GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT; }
+};
+class EdgeWeightSampler : public Sampler {
+  int SamplerId() const override { return GLX_SAMPLER_EDGE_WEIGHT; }
+};
+class TopkSampler : public Sampler {
+  int SamplerId() const override { return GLX_SAMPLER_TOPK; }
+};
+
+REGISTER_OPERATOR("RandomSampler", RandomSampler)
+REGISTER_OPERATOR("RandomWithoutReplacementSampler", RandomWithoutReplacementSampler)
+REGISTER_OPERATOR("EdgeWeightSampler", EdgeWeightSampler)
+REGISTER_OPERATOR("TopkSampler", TopkSampler)
+
+}  // namespace op
+}  // namespace graphlearn

@@ -118,11 +118,27 @@ int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batc
                uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
                void* stream);
 
+/* Same as glx_sample, but request row i draws from the random stream of row
+ * rng_rows[i] instead of row i (rng_rows == NULL: identical to glx_sample).  A
+ * shard that serves a slice of a partitioned request (DistributeRunner::Run,
+ * op_runner.h:60-84) passes the rows' indices in the ORIGINAL request -- the
+ * Sticker values of hash_partitioner.h:69 -- so the stitched result is
+ * bit-identical to the unpartitioned one for every shard count. */
+int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src, const int64_t* rng_rows,
+                  int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id,
+                  uint64_t seed, uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out,
+                  int ptr_kind, void* stream);
+
 /* ---- node features: replaces NodeStorage::GetAttribute()->GetFloats()
  * (node_storage.h:51-54, compressed_memory_node_storage.cc:149-176). -------
  * X is [num_rows, dim] row-major float32 (SideInfo.f_num == dim). */
 int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
                         const int64_t* ids, int ptr_kind, void* stream, glx_features** out);
+/* Non-owning view of a device-resident [num_rows, dim] matrix with the dense id
+ * map (id v is row v): lets glx_aggregate reduce rows that arrived from other
+ * shards (the halo exchange) without a copy.  X must outlive the handle. */
+int glx_features_view(int device, int64_t num_rows, int32_t dim, const float* X_device,
+                      glx_features** out);
 void glx_features_destroy(glx_features* f);
 int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t* dim, int* has_id_map,
                       int* device);
@@ -161,6 +177,19 @@ int glx_stitch_i64(int device, const int64_t* in, const int64_t* order, int64_t 
                    int64_t* out, void* stream);
 int glx_stitch_f32(int device, const float* in, const int64_t* order, int64_t n, int32_t width,
                    float* out, void* stream);
+
+/* ---- kernel timing: the device-side counterpart of the reference's
+ * PROFILING(key) scope timers (common/base/profiling.h:24-71). ------------
+ * While enabled (per host thread), every glx_sample / glx_aggregate /
+ * glx_lookup call brackets its dominant kernel -- and only that kernel -- with
+ * a pair of HIP events on the call's stream.  glx_profile_collect synchronises
+ * those events, writes the launch durations of `kind` (oldest first, at most
+ * `cap`) to ms_out, stores their number in *count and forgets them. */
+#define GLX_KERNEL_SAMPLE 0
+#define GLX_KERNEL_AGGREGATE 1
+#define GLX_KERNEL_LOOKUP 2
+int glx_profile_enable(int on);
+int glx_profile_collect(int kind, float* ms_out, int32_t cap, int32_t* count);
 
 #ifdef __cplusplus
 }

@@ -210,7 +210,8 @@ static void pad_row(const int64_t* rn, const int64_t* re, int64_t deg, const int
   }
 }
 
-int glxo_sample(const glxo_graph* g, int op, const int64_t* src, int32_t batch, int32_t k,
+int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* rng_rows,
+                int32_t batch, int32_t k,
                 int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                 uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out) {
   if (op < GLXO_RANDOM || op > GLXO_TOPK) return 3;
@@ -223,6 +224,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, int32_t batch, 
   for (int32_t i = 0; i < batch; ++i) {
     int64_t* nbr = nbr_out + (int64_t)i * k;
     int64_t* eid = eid_out + (int64_t)i * k;
+    const uint32_t rr = rng_rows ? (uint32_t)rng_rows[i] : (uint32_t)i;
     int64_t row = row_of(g->ids, &m, g->V, src[i]);
     int64_t start = row < 0 ? 0 : g->row_ptr[row];
     int64_t deg = row < 0 ? 0 : g->row_ptr[row + 1] - start;
@@ -233,7 +235,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, int32_t batch, 
       case GLXO_RANDOM:
         /* random_sampler.cc:61-71 without a filter: k draws in [0, deg). */
         for (int32_t j = 0; j < k; ++j) {
-          int64_t d = (int64_t)bounded(glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j),
+          int64_t d = (int64_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j),
                                        (uint64_t)deg);
           nbr[j] = rn[d];
           eid[j] = re[d];
@@ -257,7 +259,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, int32_t batch, 
         int64_t msteps = deg < k ? deg : k;
         for (int64_t j = 0; j < msteps; ++j) {
           int64_t r = j + (int64_t)bounded(
-                              glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j),
+                              glxo_draw64(seed, call_counter, rr, (uint32_t)j),
                               (uint64_t)(deg - j));
           int64_t t = perm[j]; perm[j] = perm[r]; perm[r] = t;
         }
@@ -272,7 +274,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, int32_t batch, 
         const float* probs = g->alias_prob + start;
         const int32_t* alias = g->alias_idx + start;
         for (int32_t j = 0; j < k; ++j) {
-          uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j);
+          uint64_t u = glxo_draw64(seed, call_counter, rr, (uint32_t)j);
           double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
           float rnd = (float)rd;
           int32_t ix = (int32_t)rnd;

@@ -60,7 +60,10 @@ void glxo_sort_rows_by_weight_desc(const int64_t* row_ptr, int64_t V, int64_t* c
  * alias_method.cc:109-124, topk_sampler.cc:29-68) with the padders
  * (padder/circular_padder.h:36-66, padder/replicate_padder.h:37-56).
  * Returns 0, or 3 (InvalidArgument) for a bad op / missing alias table. */
-int glxo_sample(const glxo_graph* g, int op, const int64_t* src, int32_t batch, int32_t k,
+/* rng_rows (may be NULL): request row i draws from the stream of row rng_rows[i]
+ * (used when a shard serves a slice of a partitioned request). */
+int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* rng_rows,
+                int32_t batch, int32_t k,
                 int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                 uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out);
 

@@ -40,7 +40,7 @@ class Oracle:
         L.glxo_draw64.restype = u64
         L.glxo_alias_build.argtypes = [VP, VP, i64, VP, VP]
         L.glxo_sort_rows_by_weight_desc.argtypes = [VP, i64, VP, VP, VP]
-        L.glxo_sample.argtypes = [ctypes.POINTER(_CGraph), ctypes.c_int, VP, i32, i32, ctypes.c_int, i64, u64,
+        L.glxo_sample.argtypes = [ctypes.POINTER(_CGraph), ctypes.c_int, VP, VP, i32, i32, ctypes.c_int, i64, u64,
                                   u64, VP, VP]
         L.glxo_aggregate.argtypes = [VP, i64, i32, VP, ctypes.c_int, VP, VP, i32, i32, ctypes.c_float, VP, VP]
         L.glxo_partition.argtypes = [VP, i64, i32, VP, VP]
@@ -68,7 +68,8 @@ class Oracle:
         self.L.glxo_sort_rows_by_weight_desc(_p(row_ptr), row_ptr.shape[0] - 1, _p(col), _p(eid), _p(weight))
         return col, eid, weight
 
-    def sample(self, g, sampler, src, k, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0):
+    def sample(self, g, sampler, src, k, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0,
+               rng_rows=None):
         """g: dict(row_ptr, col, eid, weight=None, alias=(prob, idx)|None, ids=None)."""
         if isinstance(sampler, str):
             sampler = SAMPLERS.index(sampler)
@@ -79,7 +80,7 @@ class Oracle:
         batch = src.shape[0]
         nbr = np.zeros((batch, k), np.int64)
         eid = np.zeros((batch, k), np.int64)
-        rc = self.L.glxo_sample(ctypes.byref(cg), sampler, _p(src), batch, k, padding_mode, default_neighbor_id,
+        rc = self.L.glxo_sample(ctypes.byref(cg), sampler, _p(src), _p(rng_rows), batch, k, padding_mode, default_neighbor_id,
                                 seed, call_counter, _p(nbr), _p(eid))
         assert rc == 0, rc
         return nbr, eid

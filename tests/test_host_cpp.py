@@ -1,0 +1,51 @@
+"""The C++ host layer (graph-learn_amd/host: the mirror of graphlearn::op's
+registry / request / operator API) exercised by C++ test programs that restate
+the reference's sampler_unittest.cpp and aggregating_op_unittest.cpp."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import glx
+
+LIB = os.path.join(os.path.dirname(glx.LIB_PATH))
+BINARIES = ["sampler_unittest", "aggregating_op_unittest"]
+
+
+def run(name):
+    return subprocess.run([os.path.join(LIB, name)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                          timeout=300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BINARIES)
+def test_host_unittests_on_gpu(name):
+    r = run(name)
+    assert r.returncode == 0, r.stdout
+    assert "0 failure(s)" in r.stdout, r.stdout
+
+
+def _no_gpu():
+    n = ctypes.c_int(-1)
+    return glx.lib().glx_device_count(ctypes.byref(n)) != 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is visible")
+@pytest.mark.parametrize("name", BINARIES)
+def test_host_layer_fails_loudly_without_gpu(name):
+    """No silent CPU path: building the store without a GPU reports UNAVAILABLE."""
+    r = run(name)
+    assert r.returncode == 2, r.stdout
+    assert "no usable HIP device" in r.stdout and "no CPU fallback" in r.stdout
+
+
+def test_host_library_exports_registry():
+    import subprocess as sp
+    out = sp.run(["nm", "-DC", os.path.join(LIB, "libglx_host.so")], stdout=sp.PIPE, text=True).stdout
+    for sym in ["graphlearn::op::OpFactory::Create", "graphlearn::op::OpRegistry::Register",
+                "graphlearn::RequestFactory::NewRequest", "graphlearn::SamplingRequest::Set",
+                "graphlearn::AggregatingRequest::Set", "graphlearn::GraphStore::GetGraph"]:
+        assert sym in out, sym
+    ldd = sp.run(["ldd", os.path.join(LIB, "libglx_host.so")], stdout=sp.PIPE, text=True).stdout
+    assert "libglx.so" in ldd and "oracle" not in ldd
