@@ -16,9 +16,12 @@ EdgeWeightSampler (alias) fanout [25,10], MaxAggregator, dim=256.
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the graph and features are edge-cut partitioned (llabs(v) % N), every rank
-drives its own batch of B0 seeds (weak scaling) and requests are routed with
-RCCL all-to-all (graph-learn_amd/dist.py).
+N > 1: one process per GPU; the graph is edge-cut partitioned (llabs(v) % N), every
+rank drives its own batch of B0 seeds (weak scaling) and each hop's requests are
+routed to the owning shard and back with RCCL all-to-all (graph-learn_amd/dist.py).
+Features are replicated by one load-time RCCL all-gather when the table fits
+(--features auto: V*D*4 <= 96 GiB of the 288 GB), else kept sharded with a
+per-request halo exchange (--features sharded).
 """
 import argparse
 import ctypes
@@ -87,7 +90,7 @@ def cpu_baseline(wl, row_ptr, col, eid, weight, args):
     ref.L.glref_build_graph(ref.h, b"e")
     t_build = time.time() - t0
     threads = min(os.cpu_count() or 1, 32)  # InterThreadNum default (config.cc:90)
-    B = 1024
+    B = args.cpu_seeds_per_request
     rng = np.random.default_rng(123)
     out = ctypes.c_int64()
     # calibrate with one request per thread, then size the run to ~cpu_time_budget
@@ -119,11 +122,11 @@ def cpu_baseline(wl, row_ptr, col, eid, weight, args):
         "value": value, "unit": "edges/s", "cores": threads, "kind": "reference",
         "sampling_edges_per_s": r_sample, "aggregation_vertices_per_s": r_agg,
         "sample": ("reference C++ %s [%d,%d] + %s on host threads (one request per thread, "
-                   "1024 seeds/request, %d requests/thread; %.1fs sampling + %.1fs aggregation timed); "
+                   "%d seeds/request, %d requests/thread; %.1fs sampling + %.1fs aggregation timed); "
                    "graph = first %d of %d generated edges of the same RMAT stream (build %.0fs, "
                    "default vector-of-vectors storage); features = %d rows x %d (ids mod %d); "
                    "value = 1/(1/sampling + 1/aggregation)"
-                   % (sampler, k1, k2, agg, reps, dts, dta, added, E, t_build, Vc, D, Vc)),
+                   % (sampler, k1, k2, agg, B, reps, dts, dta, added, E, t_build, Vc, D, Vc)),
         "wall_s": time.time() - t_all,
     }
 
@@ -135,9 +138,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=65536, help="seed vertices per step per GPU (B0)")
+    ap.add_argument("--features", default="auto", choices=["auto", "replicated", "sharded"],
+                    help="N>1: replicate the feature table on every GPU (load-time all-gather) or keep it "
+                         "edge-cut sharded with a per-request halo exchange")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
     ap.add_argument("--cpu-build-budget", type=float, default=60.0, help="s of reference graph build")
     ap.add_argument("--cpu-time-budget", type=float, default=10.0, help="s per timed CPU leg")
+    ap.add_argument("--cpu-seeds-per-request", type=int, default=128)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,8 +155,11 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = WORKLOADS[args.workload]
     V, E, sampler, (k1, k2), agg, D, gseed, desc = wl
@@ -166,18 +178,33 @@ def main():
 
     t1 = time.time()
     X = synth.features_torch(V, D, gseed + 1, dev)
-    if world == 1:
+    if not sharded:
         graph = glx.Graph(row_ptr, col, eid, weight, device=local_rank)
         feats = glx.Features(X, device=local_rank)
         store = None
+        placement = "1 GPU"
     else:
         import dist as gdist
         rp, c, e, w, ids = gdist.shard_graph(row_ptr, col, eid, weight, rank, world)
         graph = glx.Graph(rp, c, e, w, ids=ids, device=local_rank)
-        feats = glx.Features(X[rank::world].contiguous(), ids=ids, device=local_rank)
-        store = gdist.ShardedStore(gdist.DeviceOps(), graph, feats)
+        x_shard = X[rank::world].contiguous()
+        del X
+        X = None
+        if args.features == "replicated" or (args.features == "auto" and V * D * 4 <= 96 * (1 << 30)):
+            # halo exchange done once, at load time: all-gather the shards over RCCL
+            full = gdist.replicate_features(x_shard, V)
+            del x_shard
+            replica = glx.Features(full, device=local_rank)
+            del full
+            store = gdist.ShardedStore(gdist.DeviceOps(), graph, None, feature_replica=replica)
+            placement = "graph edge-cut llabs(v)%%%d + RCCL all-to-all per hop; features replicated by one load-time RCCL all-gather" % world
+        else:
+            feats = glx.Features(x_shard, ids=ids, device=local_rank)
+            store = gdist.ShardedStore(gdist.DeviceOps(), graph, feats)
+            placement = "graph + features edge-cut llabs(v)%%%d; RCCL all-to-all per hop and per-request halo feature exchange" % world
         del rp, c, e, w
-    del row_ptr, col, eid, weight, X
+    del row_ptr, col, eid, weight
+    X = None
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
     log("device store built in %.1fs" % (time.time() - t1))
@@ -213,7 +240,7 @@ def main():
             store.aggregate(agg, a.view(-1), seg1, B0)
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -262,7 +289,7 @@ def main():
         "config": {"workload": "%s: %s" % (args.workload, desc), "seeds_per_step_per_gpu": B0,
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
                    "nodes": V, "edges": E,
-                   "parallelism": "1 GPU" if world == 1 else "edge-cut llabs(v)%%%d + RCCL all-to-all" % world},
+                   "parallelism": placement},
         "phases": {
             "sampling_kernels_ms_per_step": smp_ms,
             "aggregation_kernels_ms_per_step": agg_ms,
@@ -281,7 +308,7 @@ def main():
         res["gpu_over_cpu"] = value / cpu["value"]
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

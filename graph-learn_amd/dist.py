@@ -50,6 +50,9 @@ class DeviceOps:
         view = self.glx.Features(rows, view=True, device=rows.device.index or 0)
         return view.aggregate(op, pos, seg, num_segments, default_attr)
 
+    def aggregate_local(self, feats, op, node_ids, seg, num_segments, default_attr):
+        return feats.aggregate(op, node_ids, seg, num_segments, default_attr)
+
 
 def _a2a(x, send_counts, recv_counts, group):
     out = x.new_empty((int(sum(recv_counts)),) + tuple(x.shape[1:]))
@@ -61,10 +64,15 @@ def _a2a(x, send_counts, recv_counts, group):
 class ShardedStore:
     """One rank's view of an edge-cut partitioned graph + feature store."""
 
-    def __init__(self, ops, graph_shard, feature_shard, group=None):
+    def __init__(self, ops, graph_shard, feature_shard=None, group=None, feature_replica=None):
+        """feature_shard: this rank's rows (halo exchange per request, design H);
+        feature_replica: a full copy of the feature table on this GPU (built once by
+        `replicate_features`, i.e. the halo exchange done at load time) -- the
+        MI355X-first placement whenever V*D*4 bytes fit next to the graph in 288 GB."""
         self.ops = ops
         self.graph = graph_shard
         self.feats = feature_shard
+        self.replica = feature_replica
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -87,6 +95,9 @@ class ShardedStore:
         return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
 
     def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0):
+        if self.replica is not None:
+            return self.ops.aggregate_local(self.replica, op, node_ids, segment_ids, num_segments,
+                                            default_attr)
         bucketed, order, send, recv = self._route(node_ids)
         ids_in = _a2a(bucketed, send, recv, self.group)
         rows = self.ops.lookup(self.feats, ids_in, default_attr)
@@ -113,3 +124,17 @@ def shard_graph(row_ptr, col, eid, weight, rank, world):
     slot = row_ptr[ids][row_of_slot] + (torch.arange(total, device=row_ptr.device) - rp[row_of_slot])
     w = weight[slot].contiguous() if weight is not None else None
     return rp, col[slot].contiguous(), eid[slot].contiguous(), w, ids
+
+
+def replicate_features(x_shard, num_nodes, group=None):
+    """Load-time halo exchange: every rank holds rows rank::world of the [V, D]
+    table; one RCCL all-gather gives each GPU the whole table in id order."""
+    world = dist.get_world_size(group)
+    per = (num_nodes + world - 1) // world
+    pad = x_shard
+    if x_shard.shape[0] < per:
+        pad = torch.cat([x_shard, x_shard.new_zeros((per - x_shard.shape[0], x_shard.shape[1]))])
+    gathered = x_shard.new_empty((world, per, x_shard.shape[1]))
+    dist.all_gather_into_tensor(gathered.view(world * per, -1), pad.contiguous(), group=group)
+    # row v lives at gathered[v % world][v // world]
+    return gathered.permute(1, 0, 2).reshape(world * per, -1)[:num_nodes].contiguous()

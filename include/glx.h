@@ -30,6 +30,13 @@ extern "C" {
 
 #define GLX_ABI_VERSION 1
 
+/* Exported symbols: libglx.so is built with -fvisibility=hidden. */
+#if defined(__GNUC__)
+#define GLX_API __attribute__((visibility("default")))
+#else
+#define GLX_API
+#endif
+
 /* graphlearn::error::Code values used by this library (status.h:29-49). */
 #define GLX_OK 0
 #define GLX_INVALID_ARGUMENT 3
@@ -66,11 +73,11 @@ typedef struct glx_graph glx_graph;       /* one edge type: device CSR + alias t
 typedef struct glx_features glx_features; /* one node type: device [V, D] float matrix + id map */
 
 /* ---- library ------------------------------------------------------------ */
-int glx_abi_version(void);
+GLX_API int glx_abi_version(void);
 /* Number of visible GPUs; GLX_UNAVAILABLE (and *count = 0) when there is no
  * usable HIP device.  Nothing in this library falls back to the CPU. */
-int glx_device_count(int* count);
-const char* glx_last_error(void);
+GLX_API int glx_device_count(int* count);
+GLX_API const char* glx_last_error(void);
 
 /* ---- graph storage: replaces GraphStorage::GetNeighbors / GetOutEdges /
  * GetEdgeWeight (graph_storage.h:40-57) + CompressedMemoryAdjMatrix
@@ -86,17 +93,17 @@ const char* glx_last_error(void);
  * E >= 2^31: types.h:28).  When weights are given the per-row alias tables of
  * AliasMethod::Build (alias_method.cc:57-107) are built once, on the device.
  */
-int glx_graph_create(int device, int64_t num_rows, int64_t num_edges, const int64_t* row_ptr,
+GLX_API int glx_graph_create(int device, int64_t num_rows, int64_t num_edges, const int64_t* row_ptr,
                      const int64_t* col, const int64_t* eid, const float* weight,
                      const int64_t* ids, int ptr_kind, void* stream, glx_graph** out);
-void glx_graph_destroy(glx_graph* g);
-int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges, int* weighted,
+GLX_API void glx_graph_destroy(glx_graph* g);
+GLX_API int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges, int* weighted,
                    int* has_id_map, int* device);
 /* Copy the device alias table out (parity checks against alias_method.cc:57-107). */
-int glx_graph_export_alias(const glx_graph* g, float* prob, int32_t* alias, int ptr_kind,
+GLX_API int glx_graph_export_alias(const glx_graph* g, float* prob, int32_t* alias, int ptr_kind,
                            void* stream);
 /* Degrees of a batch of raw ids (0 for unknown ids), as GetNeighbors().Size(). */
-int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t n, int64_t* deg_out,
+GLX_API int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t n, int64_t* deg_out,
                       int ptr_kind, void* stream);
 
 /* ---- neighbour sampling: replaces Sampler::Sample of the four samplers
@@ -113,7 +120,7 @@ int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t n, int64_t
  * bit-for-bit, on every run and every GPU count.  Filters are not supported
  * on this path.
  */
-int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batch, int32_t k,
+GLX_API int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batch, int32_t k,
                int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
                void* stream);
@@ -124,7 +131,7 @@ int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batc
  * op_runner.h:60-84) passes the rows' indices in the ORIGINAL request -- the
  * Sticker values of hash_partitioner.h:69 -- so the stitched result is
  * bit-identical to the unpartitioned one for every shard count. */
-int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src, const int64_t* rng_rows,
+GLX_API int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src, const int64_t* rng_rows,
                   int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id,
                   uint64_t seed, uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out,
                   int ptr_kind, void* stream);
@@ -132,15 +139,15 @@ int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src, const int
 /* ---- node features: replaces NodeStorage::GetAttribute()->GetFloats()
  * (node_storage.h:51-54, compressed_memory_node_storage.cc:149-176). -------
  * X is [num_rows, dim] row-major float32 (SideInfo.f_num == dim). */
-int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
+GLX_API int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
                         const int64_t* ids, int ptr_kind, void* stream, glx_features** out);
 /* Non-owning view of a device-resident [num_rows, dim] matrix with the dense id
  * map (id v is row v): lets glx_aggregate reduce rows that arrived from other
  * shards (the halo exchange) without a copy.  X must outlive the handle. */
-int glx_features_view(int device, int64_t num_rows, int32_t dim, const float* X_device,
+GLX_API int glx_features_view(int device, int64_t num_rows, int32_t dim, const float* X_device,
                       glx_features** out);
-void glx_features_destroy(glx_features* f);
-int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t* dim, int* has_id_map,
+GLX_API void glx_features_destroy(glx_features* f);
+GLX_API int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t* dim, int* has_id_map,
                       int* device);
 
 /* ---- aggregation: replaces Aggregator::Aggregate (aggregator.cc:25-59) with
@@ -153,14 +160,14 @@ int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t* dim, in
  * empty segments are `default_attr` (GLOBAL_FLAG(DefaultFloatAttribute)).
  * Each output element is accumulated in the reference's left-to-right order,
  * so results are bit-identical to the reference for every op. */
-int glx_aggregate(const glx_features* f, int op, const int64_t* node_ids,
+GLX_API int glx_aggregate(const glx_features* f, int op, const int64_t* node_ids,
                   const int32_t* segment_ids, int32_t num_ids, int32_t num_segments,
                   float default_attr, float* emb_out, int32_t* cnt_out, int ptr_kind,
                   void* stream);
 
 /* ---- feature lookup: replaces LookupNodes' float-attribute gather
  * (node_lookuper.cc:24-52); out[n*dim], unknown ids -> default_attr. */
-int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_t n, float default_attr,
+GLX_API int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_t n, float default_attr,
                float* out, int ptr_kind, void* stream);
 
 /* ---- shard exchange helpers: replace HashPartitioner::Partition
@@ -171,11 +178,11 @@ int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_t n, float 
  *   kept inside a shard), order[n] (the concatenated Sticker lists: order[i] is
  *   the original index of bucketed[i]), counts[num_shards] (int64, device).
  * glx_stitch_i64 / _f32: out[order[i]*width + c] = in[i*width + c]. */
-int glx_partition(int device, const int64_t* ids, int64_t n, int32_t num_shards,
+GLX_API int glx_partition(int device, const int64_t* ids, int64_t n, int32_t num_shards,
                   int64_t* bucketed, int64_t* order, int64_t* counts, void* stream);
-int glx_stitch_i64(int device, const int64_t* in, const int64_t* order, int64_t n, int32_t width,
+GLX_API int glx_stitch_i64(int device, const int64_t* in, const int64_t* order, int64_t n, int32_t width,
                    int64_t* out, void* stream);
-int glx_stitch_f32(int device, const float* in, const int64_t* order, int64_t n, int32_t width,
+GLX_API int glx_stitch_f32(int device, const float* in, const int64_t* order, int64_t n, int32_t width,
                    float* out, void* stream);
 
 /* ---- kernel timing: the device-side counterpart of the reference's
@@ -188,8 +195,8 @@ int glx_stitch_f32(int device, const float* in, const int64_t* order, int64_t n,
 #define GLX_KERNEL_SAMPLE 0
 #define GLX_KERNEL_AGGREGATE 1
 #define GLX_KERNEL_LOOKUP 2
-int glx_profile_enable(int on);
-int glx_profile_collect(int kind, float* ms_out, int32_t cap, int32_t* count);
+GLX_API int glx_profile_enable(int on);
+GLX_API int glx_profile_collect(int kind, float* ms_out, int32_t cap, int32_t* count);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,170 @@
+"""world_size-2 (and 3) gloo tests of the sharded execution layer
+(graph-learn_amd/dist.py): Partition -> all-to-all -> Process on the owner ->
+all-to-all -> Stitch, the replacement of DistributeRunner (op_runner.h:60-152).
+
+The exchange logic is the product's; the local compute is injected: on the GPU
+it is DeviceOps (HIP through the C-ABI), here -- CPU only, test infrastructure
+-- it is an oracle-backed stand-in with the same interface.  The assertion is
+the strongest available: the stitched result of every rank's request equals,
+bit for bit, the unpartitioned single-shard result (oracle on the whole graph).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleOps:
+    """CPU stand-in for dist.DeviceOps (tests only)."""
+
+    def __init__(self):
+        from oracle_bindings import Oracle
+        self.o = Oracle()
+
+    def partition(self, ids, num_shards):
+        a = ids.numpy()
+        order, counts = self.o.partition(a, num_shards)
+        return torch.from_numpy(a[order]), torch.from_numpy(order), torch.from_numpy(counts)
+
+    def stitch(self, rows, order):
+        out = torch.empty_like(rows)
+        out[order] = rows
+        return out
+
+    def sample(self, graph, sampler, ids, rng_rows, k, seed, cc, pad, dflt):
+        n, e = self.o.sample(graph, sampler, ids.numpy(), k, seed=seed, call_counter=cc, padding_mode=pad,
+                             default_neighbor_id=dflt, rng_rows=rng_rows.numpy())
+        return torch.from_numpy(n), torch.from_numpy(e)
+
+    def lookup(self, feats, ids, default_attr):
+        X, raw = feats
+        row_of = {int(v): i for i, v in enumerate(raw)}
+        out = np.full((ids.shape[0], X.shape[1]), default_attr, np.float32)
+        for i, v in enumerate(ids.numpy()):
+            r = row_of.get(int(v))
+            if r is not None:
+                out[i] = X[r]
+        return torch.from_numpy(out)
+
+    def aggregate_rows(self, rows, pos, seg, num_segments, op, default_attr):
+        e, c = self.o.aggregate(rows.numpy(), op, pos.numpy(), seg.numpy(), num_segments, default_attr)
+        return torch.from_numpy(e), torch.from_numpy(c)
+
+    def aggregate_local(self, feats, op, node_ids, seg, num_segments, default_attr):
+        e, c = self.o.aggregate(feats.numpy(), op, node_ids.numpy(), seg.numpy(), num_segments, default_attr)
+        return torch.from_numpy(e), torch.from_numpy(c)
+
+
+def _world_graph():
+    import synth
+    rp, col, eid, w = synth.small_graph(600, 9000, seed=12, weighted=True, hub_degree=300)
+    X = np.random.default_rng(3).standard_normal((600, 24)).astype(np.float32)
+    return rp, col, eid, w, X
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dist as gdist
+        from oracle_bindings import Oracle
+        ops = OracleOps()
+        orc = Oracle()
+        rp, col, eid, w, X = _world_graph()
+        whole = dict(row_ptr=rp, col=col, eid=eid, weight=w, alias=orc.alias_build(rp, w))
+        t = lambda a: torch.from_numpy(a)  # noqa: E731
+        srp, scol, seid, sw, sids = gdist.shard_graph(t(rp), t(col), t(eid), t(w), rank, world)
+        shard = dict(row_ptr=srp.numpy(), col=scol.numpy(), eid=seid.numpy(), weight=sw.numpy(),
+                     ids=sids.numpy())
+        shard["alias"] = orc.alias_build(shard["row_ptr"], shard["weight"])
+        feats = (X[rank::world].copy(), sids.numpy())
+        store = gdist.ShardedStore(ops, shard, feats)
+        rng = np.random.default_rng(100 + rank)
+        # each rank drives its OWN request; sizes differ per rank on purpose
+        src = np.concatenate([rng.integers(0, 600, 150 + 37 * rank), [0, 0, -4, 600, 10 ** 9]]).astype(np.int64)
+        ok = True
+        cc = 0
+        for name in ("RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"):
+            for k, pad in ((4, 1), (9, 1), (5, 0)):
+                cc += 1
+                n1, e1 = store.sample(name, t(src), k, seed=77, call_counter=cc, padding_mode=pad,
+                                      default_neighbor_id=-2)
+                on, oe = orc.sample(whole, name, src, k, seed=77, call_counter=cc, padding_mode=pad,
+                                    default_neighbor_id=-2)
+                ok &= np.array_equal(n1.numpy(), on) and np.array_equal(e1.numpy(), oe)
+                # hop 2 on the hop-1 output (the NeighborSampler.get loop, neighbor_sampler.py:93-127)
+                cc += 1
+                n2, _ = store.sample(name, n1.reshape(-1), 3, seed=77, call_counter=cc, padding_mode=pad,
+                                     default_neighbor_id=-2)
+                on2, _ = orc.sample(whole, name, on.reshape(-1), 3, seed=77, call_counter=cc, padding_mode=pad,
+                                    default_neighbor_id=-2)
+                ok &= np.array_equal(n2.numpy(), on2)
+        ids = n2.reshape(-1).numpy().copy()
+        seg = (np.arange(ids.shape[0]) // 3).astype(np.int32)
+        Sg = ids.shape[0] // 3
+        for name in ("SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"):
+            emb, cnt = store.aggregate(name, t(ids), t(seg), Sg, default_attr=1.25)
+            oemb, ocnt = orc.aggregate(X, name, ids, seg, Sg, 1.25)
+            ok &= np.array_equal(cnt.numpy(), ocnt)
+            ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
+        # load-time halo exchange: all-gather the feature shards, then aggregate locally
+        full = gdist.replicate_features(t(X[rank::world].copy()), X.shape[0])
+        ok &= np.array_equal(full.numpy(), X)
+        store2 = gdist.ShardedStore(ops, shard, None, feature_replica=full)
+        for name in ("SumAggregator", "MaxAggregator"):
+            emb, cnt = store2.aggregate(name, t(ids), t(seg), Sg, default_attr=1.25)
+            oemb, ocnt = orc.aggregate(X, name, ids, seg, Sg, 1.25)
+            ok &= np.array_equal(cnt.numpy(), ocnt) and np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_store_equals_single_shard(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=5) for _ in range(world))
+    assert got == {r: True for r in range(world)}
+
+
+def test_shard_graph_partitions_every_row_once():
+    sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd"))
+    import dist as gdist
+    rp, col, eid, w, _ = _world_graph()
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    seen = np.zeros(col.shape[0], np.int32)
+    for rank in range(4):
+        srp, scol, seid, sw, sids = gdist.shard_graph(t(rp), t(col), t(eid), t(w), rank, 4)
+        assert (sids.numpy() % 4 == rank).all()
+        for i, v in enumerate(sids.numpy()):
+            a, b = srp[i].item(), srp[i + 1].item()
+            assert np.array_equal(scol[a:b].numpy(), col[rp[v]:rp[v + 1]])
+            assert np.array_equal(seid[a:b].numpy(), eid[rp[v]:rp[v + 1]])
+            seen[rp[v]:rp[v + 1]] += 1
+    assert (seen == 1).all()

@@ -1,0 +1,114 @@
+"""GPU tests at BASELINE.json's full size (configs[2]: RMAT 10M nodes / 100M edges,
+fanout [25,10], dim 256, 65,536 seeds) through size-independent properties:
+every sampled (src, nbr, eid) is a real edge, without-replacement rows are
+duplicate-free and circularly padded, Topk equals the row prefix, the stream is
+reproducible, Max equals an order-free torch reduction exactly, Sum matches torch
+within 1e-5 relative (the north-star tolerance; only the summation ORDER differs
+from torch's), Mean == Sum / count bit-for-bit, counts == segment sizes."""
+import numpy as np
+import pytest
+import torch
+
+import glx
+import synth
+
+pytestmark = pytest.mark.gpu
+V, E, D, B0, K1, K2 = 10_000_000, 100_000_000, 256, 65536, 25, 10
+
+
+@pytest.fixture(scope="module")
+def c3():
+    dev = torch.device("cuda", 0)
+    row_ptr, col, eid, w = synth.rmat_graph_torch(V, E, 4, dev, weighted=True)
+    g = glx.Graph(row_ptr, col, eid, w)
+    deg = row_ptr[1:] - row_ptr[:-1]
+    slot_of_eid = torch.empty(E, dtype=torch.int64, device=dev)
+    slot_of_eid[eid] = torch.arange(E, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    seeds = torch.randint(0, V, (B0,), generator=gen, device=dev)
+    return dict(dev=dev, row_ptr=row_ptr, col=col, eid=eid, deg=deg, slot_of_eid=slot_of_eid, g=g, seeds=seeds)
+
+
+def _check_membership(c, src, nbr, eid, default=0):
+    k = nbr.shape[1]
+    srcx = src.view(-1, 1).expand(-1, k)
+    real = eid >= 0
+    slot = c["slot_of_eid"][eid.clamp(min=0)]
+    start = c["row_ptr"][srcx]
+    end = c["row_ptr"][srcx + 1]
+    assert bool(((slot >= start) & (slot < end))[real].all()), "sampled edge id is not an out-edge of its source"
+    assert bool((c["col"][slot] == nbr)[real].all()), "neighbour id does not match the edge id"
+    empty = (c["deg"][src] == 0).view(-1, 1).expand(-1, k)
+    assert bool((real == ~empty).all()), "default fill must happen exactly for rows without neighbours"
+    assert bool((nbr[~real] == default).all())
+    return slot - start  # row-local positions
+
+
+@pytest.mark.parametrize("name", list(glx.SAMPLER_IDS))
+def test_two_hop_sampling_properties(c3, name):
+    c = c3
+    n1, e1 = c["g"].sample(name, c["seeds"], K1, seed=11, call_counter=1)
+    n2, e2 = c["g"].sample(name, n1.view(-1), K2, seed=11, call_counter=2)
+    torch.cuda.synchronize()
+    assert n1.shape == (B0, K1) and n2.shape == (B0 * K1, K2)
+    for src, nbr, eid, k in ((c["seeds"], n1, e1, K1), (n1.view(-1), n2, e2, K2)):
+        pos = _check_membership(c, src, nbr, eid)
+        deg = c["deg"][src].view(-1, 1)
+        if name == "TopkSampler":
+            j = torch.arange(k, device=c["dev"]).view(1, -1)
+            ok = (pos == j % deg.clamp(min=1)) | (deg == 0)
+            assert bool(ok.all())
+        if name == "RandomWithoutReplacementSampler":
+            m = deg.clamp(max=k)
+            j = torch.arange(k, device=c["dev"]).view(1, -1)
+            # circular padding: slot j repeats slot j % min(k, deg)
+            rep = torch.gather(pos, 1, (j % m.clamp(min=1)).expand_as(pos))
+            assert bool(((pos == rep) | (deg == 0)).all())
+            # the first min(k, deg) picks are distinct: sort and compare neighbours
+            big = torch.where(j < m, pos, torch.full_like(pos, -1) - j)  # unique fillers
+            s = torch.sort(big, dim=1).values
+            assert bool((s[:, 1:] != s[:, :-1]).all())
+        if name == "RandomSampler":
+            sel = (deg >= 100).expand_as(pos)
+            frac = (pos[sel].double() / deg.expand_as(pos)[sel].double()).mean().item()
+            assert abs(frac - 0.5) < 0.01, frac
+    # reproducible stream; a new call counter gives new draws
+    m1, f1 = c["g"].sample(name, c["seeds"], K1, seed=11, call_counter=1)
+    assert torch.equal(m1, n1) and torch.equal(f1, e1)
+    if name != "TopkSampler":
+        m2, _ = c["g"].sample(name, c["seeds"], K1, seed=11, call_counter=3)
+        assert not torch.equal(m2, n1)
+
+
+def test_aggregation_properties_full_size(c3):
+    c = c3
+    dev = c["dev"]
+    X = synth.features_torch(V, D, 5, dev)
+    f = glx.Features(X)
+    n1, _ = c["g"].sample("EdgeWeightSampler", c["seeds"], K1, seed=11, call_counter=1)
+    n2, _ = c["g"].sample("EdgeWeightSampler", n1.view(-1), K2, seed=11, call_counter=2)
+    ids = n2.view(-1)
+    Sg = B0 * K1
+    seg = (torch.arange(ids.shape[0], device=dev) // K2).to(torch.int32)
+    emb_max, cnt = f.aggregate("MaxAggregator", ids, seg, Sg)
+    emb_sum, cnt_s = f.aggregate("SumAggregator", ids, seg, Sg)
+    emb_mean, _ = f.aggregate("MeanAggregator", ids, seg, Sg)
+    torch.cuda.synchronize()
+    assert bool((cnt == K2).all()) and torch.equal(cnt, cnt_s)
+    # reference reductions in chunks (16.8 GB of gathered rows otherwise)
+    chunk = 1 << 16
+    for lo in range(0, Sg, chunk * 8):  # sample 1/8 of the segments, evenly spread
+        hi = min(lo + chunk, Sg)
+        rows = X[ids[lo * K2:hi * K2]].view(hi - lo, K2, D)
+        ref_max = torch.maximum(rows.amax(1), torch.full((), -37.0, device=dev))  # max_aggregator.cc:28
+        assert torch.equal(emb_max[lo:hi], ref_max)
+        ref_sum = rows.sum(1)
+        err = (emb_sum[lo:hi] - ref_sum).abs()
+        tol = 1e-5 * rows.abs().sum(1) + 1e-30
+        assert bool((err <= tol).all()), float((err / tol).max())
+    assert torch.equal(emb_mean, emb_sum / cnt.view(-1, 1).to(torch.float32))
+    # hop-1 level: segments of K1
+    e1, c1 = f.aggregate("MaxAggregator", n1.view(-1), (torch.arange(B0 * K1, device=dev) // K1).to(torch.int32), B0)
+    ref1 = torch.maximum(X[n1.view(-1)].view(B0, K1, D).amax(1), torch.full((), -37.0, device=dev))
+    assert torch.equal(e1, ref1) and bool((c1 == K1).all())

@@ -1,0 +1,108 @@
+"""GPU tests of the multi-shard path on ONE device: P shard stores live on the
+same GPU and the all-to-all is emulated by slicing, so every device kernel of
+the sharded pipeline (glx_partition, glx_sample_ex with rng_rows, glx_lookup,
+glx_features_view + glx_aggregate, glx_stitch_*) runs for real.  Claim under
+test: for every shard count the stitched result is bit-identical to the
+single-shard result (which the reference's own distributed Max/Min/Prod is not:
+SURVEY.md 8(a) quirk 8).  Also drives dist.ShardedStore over RCCL with
+world_size 1."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import glx
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    import dist as gdist
+    rp, col, eid, w = synth.small_graph(5000, 80000, seed=21, weighted=True, hub_degree=3000)
+    X = np.random.default_rng(4).standard_normal((5000, 64)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    whole = glx.Graph(t(rp), t(col), t(eid), t(w))
+    feats = glx.Features(t(X))
+    shards = {}
+    for P in (2, 4, 8):
+        gs, fs = [], []
+        for r in range(P):
+            srp, scol, seid, sw, sids = gdist.shard_graph(t(rp), t(col), t(eid), t(w), r, P)
+            gs.append(glx.Graph(srp, scol, seid, sw, ids=sids))
+            fs.append(glx.Features(t(X[r::P].copy()), ids=sids))
+        shards[P] = (gs, fs)
+    return whole, feats, shards, dev
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_sharded_sampling_equals_single_shard(world, P):
+    whole, _, shards, dev = world
+    gs, _ = shards[P]
+    rng = np.random.default_rng(P)
+    src = torch.from_numpy(np.concatenate([rng.integers(0, 5000, 3000), [0, 0, -1, 5000]]).astype(np.int64)).to(dev)
+    cc = 0
+    for name in glx.SAMPLER_IDS:
+        for k, pad in ((10, 1), (25, 1), (7, 0), (70, 1)):
+            cc += 1
+            ref_n, ref_e = whole.sample(name, src, k, seed=9, call_counter=cc, padding_mode=pad,
+                                        default_neighbor_id=-5)
+            bucketed, order, counts = glx.partition(src, P)
+            offs = np.concatenate([[0], np.cumsum(counts.cpu().numpy())])
+            parts_n, parts_e = [], []
+            for p in range(P):
+                a, b = int(offs[p]), int(offs[p + 1])
+                n, e = gs[p].sample(name, bucketed[a:b].contiguous(), k, seed=9, call_counter=cc,
+                                    padding_mode=pad, default_neighbor_id=-5,
+                                    rng_rows=order[a:b].contiguous())
+                parts_n.append(n)
+                parts_e.append(e)
+            n = glx.stitch(torch.cat(parts_n), order)
+            e = glx.stitch(torch.cat(parts_e), order)
+            assert torch.equal(n, ref_n) and torch.equal(e, ref_e), (name, k, pad)
+
+
+@pytest.mark.parametrize("P", [2, 8])
+def test_sharded_aggregation_equals_single_shard(world, P):
+    whole, feats, shards, dev = world
+    _, fs = shards[P]
+    rng = np.random.default_rng(50 + P)
+    n = 20000
+    ids = torch.from_numpy(rng.integers(-3, 5003, n).astype(np.int64)).to(dev)
+    seg = torch.from_numpy((np.arange(n) // 10).astype(np.int32)).to(dev)
+    for name in glx.AGGREGATOR_IDS:
+        ref_e, ref_c = feats.aggregate(name, ids, seg, n // 10, default_attr=0.5)
+        bucketed, order, counts = glx.partition(ids, P)
+        offs = np.concatenate([[0], np.cumsum(counts.cpu().numpy())])
+        rows = torch.cat([fs[p].lookup(bucketed[int(offs[p]):int(offs[p + 1])].contiguous(), 0.5)
+                          for p in range(P)])
+        pos = glx.stitch(torch.arange(n, dtype=torch.int64, device=dev).view(n, 1), order).view(n)
+        view = glx.Features(rows, view=True)
+        e, c = view.aggregate(name, pos, seg, n // 10, default_attr=0.5)
+        assert torch.equal(c, ref_c), name
+        assert torch.equal(e.view(torch.int32), ref_e.view(torch.int32)), name
+
+
+def test_sharded_store_over_rccl_world1(world):
+    import torch.distributed as dist
+    import dist as gdist
+    whole, feats, _, dev = world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        store = gdist.ShardedStore(gdist.DeviceOps(), whole, feats)
+        src = torch.arange(0, 4000, dtype=torch.int64, device=dev)
+        for name in glx.SAMPLER_IDS:
+            n, e = store.sample(name, src, 10, seed=3, call_counter=1)
+            rn, re = whole.sample(name, src, 10, seed=3, call_counter=1)
+            assert torch.equal(n, rn) and torch.equal(e, re)
+        seg = (torch.arange(40000, device=dev) // 10).to(torch.int32)
+        emb, cnt = store.aggregate("MeanAggregator", n.view(-1), seg, 4000)
+        remb, rcnt = feats.aggregate("MeanAggregator", n.view(-1), seg, 4000)
+        assert torch.equal(cnt, rcnt) and torch.equal(emb.view(torch.int32), remb.view(torch.int32))
+    finally:
+        dist.destroy_process_group()
