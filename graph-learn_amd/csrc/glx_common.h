@@ -52,6 +52,19 @@ int glx_init_device(int device);
 int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot);
 void glx_scratch_free(void* p, hipStream_t s);
 
+// Temporary device allocation released on every exit path.
+struct GlxTemp {
+  void* p = nullptr;
+  ~GlxTemp() {
+    if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+  GlxTemp() = default;
+  GlxTemp(const GlxTemp&) = delete;
+  GlxTemp& operator=(const GlxTemp&) = delete;
+};
+
 // Kernel timing hook (glx_profile_enable): record an event on `s` when enabled.
 struct GlxKernelTimer {
   int slot = -1;

@@ -257,12 +257,13 @@ void glx_idmap_free(GlxIdMapStorage* m) {
 }
 
 // ------------------------------------------------------------ CSR kernels --
-// flag bits: 1 = row_ptr not monotone / bad ends.
+// flag bits: 1 = row_ptr not monotone / bad ends; 2 = a row degree >= 2^31.
 __global__ void glx_check_row_ptr_kernel(const int64_t* __restrict__ row_ptr, int64_t V, int64_t E,
                                          int* flag) {
   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r == 0 && (row_ptr[0] != 0 || row_ptr[V] != E)) atomicOr(flag, 1);
   if (r < V && row_ptr[r + 1] < row_ptr[r]) atomicOr(flag, 1);
+  if (r < V && row_ptr[r + 1] - row_ptr[r] >= (int64_t)INT32_MAX) atomicOr(flag, 2);
 }
 
 // SoA (col[], eid[]) -> 16-byte {nbr, eid} slots: one dwordx4 gather per draw.
@@ -367,17 +368,24 @@ static int graph_create_impl(glx_graph* g, const int64_t* row_ptr, const int64_t
   GLX_HIP(hipMalloc(&g->adj, (size_t)(E > 0 ? E : 1) * sizeof(GlxAdj)));
   GLX_HIP(hipMemcpyAsync(g->row_ptr, row_ptr, (size_t)(V + 1) * sizeof(int64_t), kind, s));
 
-  int* d_flag = nullptr;
-  GLX_HIP(hipMalloc(&d_flag, sizeof(int)));
+  GlxTemp flag_buf, stage, stk_buf, ids_buf;
+  GLX_HIP(hipMalloc(&flag_buf.p, sizeof(int)));
+  int* d_flag = flag_buf.as<int>();
   GLX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
   glx_check_row_ptr_kernel<<<(unsigned)((V + 256) / 256), 256, 0, s>>>(g->row_ptr, V, E, d_flag);
+  // Validate before any kernel trusts row_ptr for addressing.
+  int flag = 0;
+  GLX_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  GLX_REQUIRE((flag & 1) == 0, "row_ptr must start at 0, end at num_edges and be non-decreasing");
+  GLX_REQUIRE((flag & 2) == 0, "a row has 2^31 or more neighbours (row-local indices are int32, as in the reference)");
 
   // Stage col/eid on the device (host input) then pack them into 16-byte slots.
   const int64_t* d_col = col;
   const int64_t* d_eid = eid;
-  int64_t* tmp = nullptr;
   if (ptr_kind == GLX_PTR_HOST && E > 0) {
-    GLX_HIP(hipMalloc(&tmp, (size_t)E * 2 * sizeof(int64_t)));
+    GLX_HIP(hipMalloc(&stage.p, (size_t)E * 2 * sizeof(int64_t)));
+    int64_t* tmp = stage.as<int64_t>();
     GLX_HIP(hipMemcpyAsync(tmp, col, (size_t)E * sizeof(int64_t), kind, s));
     GLX_HIP(hipMemcpyAsync(tmp + E, eid, (size_t)E * sizeof(int64_t), kind, s));
     d_col = tmp;
@@ -390,36 +398,25 @@ static int graph_create_impl(glx_graph* g, const int64_t* row_ptr, const int64_t
     GLX_HIP(hipMalloc(&g->alias, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
     if (E > 0) {
       GLX_HIP(hipMemcpyAsync(g->weight, weight, (size_t)E * sizeof(float), kind, s));
-      int32_t* stk = nullptr;
-      GLX_HIP(hipMalloc(&stk, (size_t)E * sizeof(int32_t)));
+      GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(int32_t)));
       glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(g->row_ptr, g->weight, V,
-                                                                      g->alias, stk);
-      GLX_HIP(hipStreamSynchronize(s));
-      GLX_HIP(hipFree(stk));
+                                                                      g->alias, stk_buf.as<int32_t>());
     }
   }
 
   if (ids) {
     const int64_t* d_ids = ids;
-    int64_t* tmp_ids = nullptr;
     if (ptr_kind == GLX_PTR_HOST) {
-      GLX_HIP(hipMalloc(&tmp_ids, (size_t)(V > 0 ? V : 1) * sizeof(int64_t)));
-      GLX_HIP(hipMemcpyAsync(tmp_ids, ids, (size_t)V * sizeof(int64_t), kind, s));
-      d_ids = tmp_ids;
+      GLX_HIP(hipMalloc(&ids_buf.p, (size_t)(V > 0 ? V : 1) * sizeof(int64_t)));
+      GLX_HIP(hipMemcpyAsync(ids_buf.p, ids, (size_t)V * sizeof(int64_t), kind, s));
+      d_ids = ids_buf.as<int64_t>();
     }
     int rc = glx_idmap_build(d_ids, V, &g->idmap, s);
-    GLX_HIP(hipStreamSynchronize(s));
-    if (tmp_ids) (void)hipFree(tmp_ids);
     if (rc != GLX_OK) return rc;
   }
 
-  int flag = 0;
-  GLX_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
   GLX_HIP(hipStreamSynchronize(s));
   GLX_HIP(hipGetLastError());
-  (void)hipFree(d_flag);
-  if (tmp) (void)hipFree(tmp);
-  GLX_REQUIRE(flag == 0, "row_ptr must start at 0, end at num_edges and be non-decreasing");
   return GLX_OK;
 }
 
