@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--features", default="auto", choices=["auto", "replicated", "sharded"],
                     help="N>1: replicate the feature table on every GPU (load-time all-gather) or keep it "
                          "edge-cut sharded with a per-request halo exchange")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
+                    help="overlap step i+1's sampling (+ xGMI exchange) with step i's aggregation on two "
+                         "HIP streams; auto = on for N>1")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
@@ -148,6 +151,13 @@ def main():
     ap.add_argument("--cpu-time-budget", type=float, default=10.0, help="s per timed CPU leg")
     ap.add_argument("--cpu-seeds-per-request", type=int, default=128)
     args = ap.parse_args()
+
+    # Contract: rank 0 prints exactly ONE JSON line on stdout.  Libraries (RCCL's
+    # version banner, rocm warnings) also write to fd 1, so keep a private copy of
+    # the real stdout for the result and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -217,27 +227,65 @@ def main():
     n1, n2 = B0 * k1, B0 * k1 * k2
     seg2 = (torch.arange(n2, device=dev) // k2).to(torch.int32)
     seg1 = (torch.arange(n1, device=dev) // k1).to(torch.int32)
-    nbr1 = torch.empty((B0, k1), dtype=torch.int64, device=dev)
-    eid1 = torch.empty_like(nbr1)
-    nbr2 = torch.empty((n1, k2), dtype=torch.int64, device=dev)
-    eid2 = torch.empty_like(nbr2)
     emb2 = torch.empty((n1, D), dtype=torch.float32, device=dev)
     cnt2 = torch.empty((n1,), dtype=torch.int32, device=dev)
     emb1 = torch.empty((B0, D), dtype=torch.float32, device=dev)
     cnt1 = torch.empty((B0,), dtype=torch.int32, device=dev)
 
-    def step(i):
+    # Two-stage software pipeline over two HIP streams: the sampling stage of step
+    # i+1 (id exchange over xGMI + gather kernels) overlaps the aggregation stage
+    # of step i (the HBM-bound segmented reduce).  Every step's work still completes
+    # inside the timed region; buffers are double-buffered and the sampler may run
+    # at most one step ahead.
+    pipelined = args.pipeline == "on" or (args.pipeline == "auto" and sharded)
+    bufs = []
+    for _ in range(2 if pipelined else 1):
+        b1 = torch.empty((B0, k1), dtype=torch.int64, device=dev)
+        b2 = torch.empty((n1, k2), dtype=torch.int64, device=dev)
+        bufs.append((b1, torch.empty_like(b1), b2, torch.empty_like(b2)))
+
+    def do_sample(i):
         cc = 4 * i
         if store is None:
-            graph.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nbr1, eid1))
-            graph.sample(sampler, nbr1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nbr2, eid2))
-            feats.aggregate(agg, nbr2.view(-1), seg2, n1, out=(emb2, cnt2))
-            feats.aggregate(agg, nbr1.view(-1), seg1, B0, out=(emb1, cnt1))
+            nb1, ed1, nb2, ed2 = bufs[i % len(bufs)]
+            graph.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
+            graph.sample(sampler, nb1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nb2, ed2))
+            return nb1, nb2
+        a, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=cc)
+        b, _ = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=cc + 1)
+        return a, b
+
+    def do_aggregate(a, b):
+        if store is None:
+            feats.aggregate(agg, b.view(-1), seg2, n1, out=(emb2, cnt2))
+            feats.aggregate(agg, a.view(-1), seg1, B0, out=(emb1, cnt1))
         else:
-            a, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=cc)
-            b, _ = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=cc + 1)
             store.aggregate(agg, b.view(-1), seg2, n1)
             store.aggregate(agg, a.view(-1), seg1, B0)
+
+    if pipelined:
+        s_smp, s_agg = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        agg_done = []
+
+    def step(i):
+        if not pipelined:
+            a, b = do_sample(i)
+            do_aggregate(a, b)
+            return
+        with torch.cuda.stream(s_smp):
+            if len(agg_done) >= 2:
+                s_smp.wait_event(agg_done[-2])  # the buffers of step i-2 are free again
+            a, b = do_sample(i)
+            a.record_stream(s_agg)
+            b.record_stream(s_agg)
+            sampled = torch.cuda.Event()
+            sampled.record(s_smp)
+        with torch.cuda.stream(s_agg):
+            s_agg.wait_event(sampled)
+            do_aggregate(a, b)
+            done = torch.cuda.Event()
+            done.record(s_agg)
+            agg_done.append(done)
 
     def barrier():
         if sharded:
@@ -289,7 +337,8 @@ def main():
         "config": {"workload": "%s: %s" % (args.workload, desc), "seeds_per_step_per_gpu": B0,
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
                    "nodes": V, "edges": E,
-                   "parallelism": placement},
+                   "parallelism": placement,
+                   "pipelined_two_streams": bool(pipelined)},
         "phases": {
             "sampling_kernels_ms_per_step": smp_ms,
             "aggregation_kernels_ms_per_step": agg_ms,
@@ -307,7 +356,8 @@ def main():
     if cpu:
         res["gpu_over_cpu"] = value / cpu["value"]
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        result_out.write(json.dumps(res) + "\n")
+        result_out.flush()
     if sharded:
         dist.destroy_process_group()
 

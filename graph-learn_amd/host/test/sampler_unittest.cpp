@@ -3,7 +3,9 @@
 // assertions -- membership + shape + default fill for the random samplers
 // (:112-126,150-166,219-236) and the exact Topk answer {20,10,21,11} (:190-195)
 // -- but the operators are the HIP-backed ones behind the same registry names.
+#include <thread>
 #include <unordered_set>
+#include <vector>
 
 #include "graphlearn/graphlearn.h"
 #include "test_util.h"
@@ -178,6 +180,36 @@ TEST(SamplerTest, ErrorConventions) {
     EXPECT_EQ(res2.GetNeighborIds()[i], 0);
     EXPECT_EQ(res2.GetEdgeIds()[i], -1);
   }
+}
+
+TEST(SamplerTest, ConcurrentProcessOnOneInstance) {
+  // up to 32 pool threads call Process() on the single operator instance
+  // (in_memory_service.cc:64-71): results must stay valid per request.
+  SetUpStore();
+  Operator* op = OpFactory::GetInstance()->Create("TopkSampler");
+  std::vector<std::thread> pool;
+  std::vector<int> ok(8, 0);
+  for (int t = 0; t < 8; ++t) {
+    pool.emplace_back([&, t]() {
+      for (int rep = 0; rep < 25; ++rep) {
+        SamplingRequest req("u-i", "TopkSampler", 3);
+        SamplingResponse res;
+        int64_t ids[3] = {t % 2, 1 - t % 2, 7};
+        req.Set(ids, 3);
+        if (!op->Process(&req, &res).ok()) return;
+        const int64_t* n = res.GetNeighborIds();
+        const int64_t r0[3] = {20, 10, 30}, r1[3] = {21, 11, 21};
+        for (int j = 0; j < 3; ++j) {
+          if (n[j] != (t % 2 == 0 ? r0[j] : r1[j])) return;
+          if (n[3 + j] != (t % 2 == 0 ? r1[j] : r0[j])) return;
+          if (n[6 + j] != 0) return;
+        }
+      }
+      ok[t] = 1;
+    });
+  }
+  for (auto& th : pool) th.join();
+  for (int t = 0; t < 8; ++t) EXPECT_TRUE(ok[t] == 1);
 }
 
 int main() { return RunAllTests(); }

@@ -280,3 +280,62 @@ def test_partition_and_stitch(orc, P):
         assert np.array_equal(back.cpu().numpy(), np.stack([ids * 2, ids * 2 + 1], 1))
         fr = glx.stitch(rows.to(torch.float32), order)
         assert np.array_equal(fr.cpu().numpy(), np.stack([ids * 2, ids * 2 + 1], 1).astype(np.float32))
+
+
+def test_size_limits_are_rejected_not_truncated(graphs):
+    """Tensor sizes are int32 in the reference (tensor.h:47): batch*k and
+    num_segments*dim beyond INT32_MAX are InvalidArgument, checked before any work."""
+    _, dev = graphs["dense"]
+    src = np.zeros(1 << 20, np.int64)
+    with pytest.raises(glx.GlxError) as e:
+        dev.sample("TopkSampler", src, 4096, out=(np.zeros((1, 1), np.int64), np.zeros((1, 1), np.int64)))
+    assert e.value.code == 3 and "int32" in str(e.value)
+    f = glx.Features(np.zeros((4, 1024), np.float32))
+    with pytest.raises(glx.GlxError) as e:
+        f.aggregate("SumAggregator", np.zeros(1, np.int64), np.zeros(1, np.int32), 1 << 22,
+                    out=(np.zeros((1, 1), np.float32), np.zeros(1, np.int32)))
+    assert e.value.code == 3
+    with pytest.raises(glx.GlxError):
+        dev.sample("TopkSampler", np.zeros(4, np.int64), 3, padding_mode=7)
+    with pytest.raises(glx.GlxError):
+        glx.partition(__import__("torch").zeros(4, dtype=__import__("torch").int64, device="cuda"), 65)
+
+
+def test_id_map_with_extreme_and_colliding_ids(orc):
+    """Hashed id map at its maximum load (V a power of two -> load 0.5), ids spread over
+    the whole int64 range incl. INT64_MAX / negatives, probes for many absent ids."""
+    rng = np.random.default_rng(99)
+    V = 4096
+    raw = np.unique(np.concatenate([
+        rng.integers(-(1 << 62), 1 << 62, V * 2),
+        np.array([np.iinfo(np.int64).max, np.iinfo(np.int64).min + 1, 0, -1, 1], np.int64)]))
+    raw = raw[rng.permutation(raw.shape[0])][:V].astype(np.int64)
+    # plus a run of ids that differ only in the high bits (same low-bit pattern)
+    raw[:256] = (np.arange(256, dtype=np.int64) << 40) + 12345
+    deg = rng.integers(0, 6, V)
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    E = int(rp[-1])
+    col = raw[rng.integers(0, V, E)]
+    eid = rng.permutation(E).astype(np.int64)
+    dev = glx.Graph(rp, col, eid, ids=raw)
+    og = dict(row_ptr=rp, col=col, eid=eid, ids=raw)
+    absent = rng.integers(-(1 << 62), 1 << 62, 3000).astype(np.int64)
+    q = np.concatenate([raw, absent, (np.arange(300, dtype=np.int64) << 40) + 12346])
+    for name in ("RandomSampler", "RandomWithoutReplacementSampler", "TopkSampler"):
+        n, e = dev.sample(name, q, 4, seed=8, call_counter=2, default_neighbor_id=-9)
+        on, oe = orc.sample(og, name, q, 4, seed=8, call_counter=2, default_neighbor_id=-9)
+        assert np.array_equal(n, on) and np.array_equal(e, oe), name
+    d = dev.degrees(q)
+    known = {int(v): int(deg[i]) for i, v in enumerate(raw)}
+    assert d.tolist() == [known.get(int(v), 0) for v in q]
+    X = rng.standard_normal((V, 12)).astype(np.float32)
+    f = glx.Features(X, ids=raw)
+    seg = (np.arange(q.shape[0]) // 7).astype(np.int32)
+    Sg = int(seg[-1]) + 1
+    emb, cnt = f.aggregate("SumAggregator", q, seg, Sg, default_attr=0.25)
+    oemb, ocnt = orc.aggregate(X, "SumAggregator", q, seg, Sg, 0.25, ids=raw)
+    assert np.array_equal(cnt, ocnt) and beq(emb, oemb)
+    out = f.lookup(q, default_attr=0.25)
+    row = {int(v): i for i, v in enumerate(raw)}
+    exp = np.stack([X[row[int(v)]] if int(v) in row else np.full(12, 0.25, np.float32) for v in q])
+    assert beq(out, exp)
