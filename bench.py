@@ -59,7 +59,7 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(wl, row_ptr, col, eid, weight, args):
+def cpu_baseline(wl, src, dst, weight, args):
     """Times the reference's own CPU path (oracle/_ref, built from the reference's
     sources) on this box's host cores, on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -70,13 +70,9 @@ def cpu_baseline(wl, row_ptr, col, eid, weight, args):
     t_all = time.time()
     ref = RefLib(storage_mode=2, padding_mode=1)
     # edges in insertion (= edge id) order, as the reference loader would add them
-    deg = (row_ptr[1:] - row_ptr[:-1])
-    src_slot = torch.repeat_interleave(torch.arange(V, device=row_ptr.device), deg)
-    o = torch.sort(eid).indices
-    src_h = src_slot[o].cpu().numpy()
-    dst_h = col[o].cpu().numpy()
-    w_h = weight[o].cpu().numpy() if weight is not None else None
-    del src_slot, o
+    src_h = src.cpu().numpy()
+    dst_h = dst.cpu().numpy()
+    w_h = weight.cpu().numpy() if weight is not None else None
     # add a prefix of the edge stream until the build budget is spent
     chunk = 5_000_000
     added = 0
@@ -176,27 +172,33 @@ def main():
     B0 = args.batch
     t0 = time.time()
     weighted = sampler in ("EdgeWeightSampler", "TopkSampler")
-    row_ptr, col, eid, weight = synth.rmat_graph_torch(V, E, gseed, dev, weighted=weighted)
+    src, dst, weight = synth.rmat_edges_torch(V, E, gseed, dev, weighted=weighted)
     torch.cuda.synchronize()
-    log("graph generated in %.1fs (max degree %d)" % (time.time() - t0, int((row_ptr[1:] - row_ptr[:-1]).max())))
+    log("edge list generated in %.1fs" % (time.time() - t0))
 
     cpu = None
     if args.cpu_baseline == "on" and world == 1:
         t1 = time.time()
-        cpu = cpu_baseline(wl, row_ptr, col, eid, weight, args)
+        cpu = cpu_baseline(wl, src, dst, weight, args)
         log("cpu baseline done in %.1fs: %s" % (time.time() - t1, cpu and "%.3g edges/s" % cpu["value"]))
 
+    # Storage build on the device (glx_graph_build: radix sorts + RLE + scan + alias
+    # tables + id map); rows end up weight-descending like the reference's Build().
     t1 = time.time()
     X = synth.features_torch(V, D, gseed + 1, dev)
     if not sharded:
-        graph = glx.Graph(row_ptr, col, eid, weight, device=local_rank)
+        graph = glx.Graph.from_edges(src, dst, weight, device=local_rank)
         feats = glx.Features(X, device=local_rank)
         store = None
         placement = "1 GPU"
     else:
         import dist as gdist
-        rp, c, e, w, ids = gdist.shard_graph(row_ptr, col, eid, weight, rank, world)
-        graph = glx.Graph(rp, c, e, w, ids=ids, device=local_rank)
+        own = (src % world) == rank  # edge-cut: out-edges of v live on shard llabs(v) % P
+        eids = torch.nonzero(own).view(-1)
+        graph = glx.Graph.from_edges(src[own].contiguous(), dst[own].contiguous(),
+                                     weight[own].contiguous() if weight is not None else None,
+                                     edge_ids=eids, device=local_rank)
+        del own, eids
         x_shard = X[rank::world].contiguous()
         del X
         X = None
@@ -209,15 +211,15 @@ def main():
             store = gdist.ShardedStore(gdist.DeviceOps(), graph, None, feature_replica=replica)
             placement = "graph edge-cut llabs(v)%%%d + RCCL all-to-all per hop; features replicated by one load-time RCCL all-gather" % world
         else:
+            ids = torch.arange(rank, V, world, dtype=torch.int64, device=dev)
             feats = glx.Features(x_shard, ids=ids, device=local_rank)
             store = gdist.ShardedStore(gdist.DeviceOps(), graph, feats)
             placement = "graph + features edge-cut llabs(v)%%%d; RCCL all-to-all per hop and per-request halo feature exchange" % world
-        del rp, c, e, w
-    del row_ptr, col, eid, weight
+    del src, dst, weight
     X = None
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
-    log("device store built in %.1fs" % (time.time() - t1))
+    log("device store built in %.1fs (%d rows, %d edges on this GPU)" % (time.time() - t1, graph.num_rows, graph.num_edges))
 
     # synthetic request stream: uniform seeds, a fresh batch per step
     gen = torch.Generator(device=dev)

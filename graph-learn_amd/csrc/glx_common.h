@@ -188,6 +188,12 @@ __device__ __forceinline__ int32_t glx_alias_pick(uint64_t u, int64_t deg,
   return (a.prob <= (rnd - (float)ix)) ? a.alias : ix;
 }
 
+// glx_graph.hip: shared tail of glx_graph_create / glx_graph_build.  Expects
+// g->row_ptr, g->adj and (for weighted graphs) g->weight filled on `s`; builds the
+// alias tables and, when d_ids != nullptr, the id map; synchronises `s`.
+int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s);
+void glx_graph_free(glx_graph* g);
+
 static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 #endif  // GLX_COMMON_H_

@@ -348,7 +348,7 @@ static inline unsigned grid_for(int64_t n, int cap = 8192) {
 }
 
 // ----------------------------------------------------------------- create --
-static void graph_free(glx_graph* g) {
+void glx_graph_free(glx_graph* g) {
   if (!g) return;
   if (g->row_ptr) (void)hipFree(g->row_ptr);
   if (g->adj) (void)hipFree(g->adj);
@@ -368,7 +368,7 @@ static int graph_create_impl(glx_graph* g, const int64_t* row_ptr, const int64_t
   GLX_HIP(hipMalloc(&g->adj, (size_t)(E > 0 ? E : 1) * sizeof(GlxAdj)));
   GLX_HIP(hipMemcpyAsync(g->row_ptr, row_ptr, (size_t)(V + 1) * sizeof(int64_t), kind, s));
 
-  GlxTemp flag_buf, stage, stk_buf, ids_buf;
+  GlxTemp flag_buf, stage, ids_buf;
   GLX_HIP(hipMalloc(&flag_buf.p, sizeof(int)));
   int* d_flag = flag_buf.as<int>();
   GLX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
@@ -395,26 +395,35 @@ static int graph_create_impl(glx_graph* g, const int64_t* row_ptr, const int64_t
 
   if (weight) {
     GLX_HIP(hipMalloc(&g->weight, (size_t)(E > 0 ? E : 1) * sizeof(float)));
-    GLX_HIP(hipMalloc(&g->alias, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
-    if (E > 0) {
-      GLX_HIP(hipMemcpyAsync(g->weight, weight, (size_t)E * sizeof(float), kind, s));
-      GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(int32_t)));
-      glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(g->row_ptr, g->weight, V,
-                                                                      g->alias, stk_buf.as<int32_t>());
-    }
+    if (E > 0) GLX_HIP(hipMemcpyAsync(g->weight, weight, (size_t)E * sizeof(float), kind, s));
   }
-
+  const int64_t* d_ids = nullptr;
   if (ids) {
-    const int64_t* d_ids = ids;
+    d_ids = ids;
     if (ptr_kind == GLX_PTR_HOST) {
       GLX_HIP(hipMalloc(&ids_buf.p, (size_t)(V > 0 ? V : 1) * sizeof(int64_t)));
       GLX_HIP(hipMemcpyAsync(ids_buf.p, ids, (size_t)V * sizeof(int64_t), kind, s));
       d_ids = ids_buf.as<int64_t>();
     }
+  }
+  return glx_graph_finalize(g, d_ids, s);
+}
+
+int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s) {
+  const int64_t V = g->num_rows, E = g->num_edges;
+  GlxTemp stk_buf;
+  if (g->weight) {
+    GLX_HIP(hipMalloc(&g->alias, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
+    if (E > 0) {
+      GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(int32_t)));
+      glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(g->row_ptr, g->weight, V,
+                                                                      g->alias, stk_buf.as<int32_t>());
+    }
+  }
+  if (d_ids) {
     int rc = glx_idmap_build(d_ids, V, &g->idmap, s);
     if (rc != GLX_OK) return rc;
   }
-
   GLX_HIP(hipStreamSynchronize(s));
   GLX_HIP(hipGetLastError());
   return GLX_OK;
@@ -442,7 +451,7 @@ extern "C" int glx_graph_create(int device, int64_t num_rows, int64_t num_edges,
   g->num_edges = num_edges;
   rc = graph_create_impl(g, row_ptr, col, eid, weight, ids, ptr_kind, glx_stream(stream));
   if (rc != GLX_OK) {
-    graph_free(g);
+    glx_graph_free(g);
     return rc;
   }
   *out = g;
@@ -452,7 +461,7 @@ extern "C" int glx_graph_create(int device, int64_t num_rows, int64_t num_edges,
 extern "C" void glx_graph_destroy(glx_graph* g) {
   if (!g) return;
   GlxDeviceGuard guard(g->device);
-  graph_free(g);
+  glx_graph_free(g);
 }
 
 extern "C" int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges,

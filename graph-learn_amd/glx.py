@@ -36,7 +36,7 @@ AGGREGATOR_IDS = {
 
 EXPORTS = [
     "glx_abi_version", "glx_device_count", "glx_last_error",
-    "glx_graph_create", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
+    "glx_graph_create", "glx_graph_build", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
     "glx_graph_degrees", "glx_sample", "glx_sample_ex",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
@@ -73,6 +73,7 @@ def lib():
         L.glx_last_error.restype = ctypes.c_char_p
         L.glx_device_count.argtypes = [ctypes.POINTER(ci)]
         L.glx_graph_create.argtypes = [ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ctypes.POINTER(vp)]
+        L.glx_graph_build.argtypes = [ci, i64, vp, vp, vp, vp, ci, ci, vp, ctypes.POINTER(vp)]
         L.glx_graph_destroy.argtypes = [vp]
         L.glx_graph_destroy.restype = None
         L.glx_graph_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ci),
@@ -153,6 +154,24 @@ class Graph:
                                       ptrs[2][0], ptrs[3][0], ptrs[4][0], kind, _stream(kind),
                                       ctypes.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_edges(cls, src, dst, weight=None, edge_ids=None, sort_by_weight=True, device=0):
+        """Device-side build from a raw edge list in insertion order (edge id = index,
+        or edge_ids[i] for a shard's subset of a global edge list)."""
+        self = cls.__new__(cls)
+        ptrs = [_ptr(src), _ptr(dst), _ptr(weight), _ptr(edge_ids)]
+        kind = _kind(*ptrs)
+        h = ctypes.c_void_p()
+        _check(lib().glx_graph_build(device, int(src.shape[0]), ptrs[0][0], ptrs[1][0], ptrs[2][0],
+                                     ptrs[3][0], 1 if sort_by_weight else 0, kind, _stream(kind),
+                                     ctypes.byref(h)))
+        self._h = h
+        self.device = device
+        v, e = ctypes.c_int64(), ctypes.c_int64()
+        _check(lib().glx_graph_info(h, ctypes.byref(v), ctypes.byref(e), None, None, None))
+        self.num_rows, self.num_edges = v.value, e.value
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

@@ -2,11 +2,11 @@
 // (graphlearn/src/core/graph/graph_store.h:32-66, heter_dispatcher.h:44-56), with
 // device-resident storages.  Edges / nodes are staged on the host exactly like
 // LocalGraph::UpdateEdges -> storage->Add (core/graph/local_graph.cc:50-64);
-// Build() sorts rows the way MemoryAdjMatrix::Build does
-// (memory_adj_matrix.cc:60-66,105-125: weight descending for weighted types),
-// converts to CSR (memory_adj_matrix.cc:169-189) and uploads it through the
-// C-ABI (glx_graph_create / glx_features_create).  After Build() the storage is
-// immutable and served from HBM.
+// Build() hands the raw edge list to the GPU (glx_graph_build), which orders rows
+// the way MemoryAdjMatrix::Build does (memory_adj_matrix.cc:60-66,105-125: weight
+// descending for weighted types), converts to CSR (memory_adj_matrix.cc:169-189)
+// and builds the alias tables and the id map there; node features go through
+// glx_features_create.  After Build() the storage is immutable and served from HBM.
 #ifndef GLX_HOST_GRAPH_STORE_H_
 #define GLX_HOST_GRAPH_STORE_H_
 #include <cstdint>

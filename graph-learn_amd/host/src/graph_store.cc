@@ -1,9 +1,6 @@
 // GraphStore / Graph / Noder: host staging -> CSR -> device (see graph_store.h).
 #include "graphlearn/graph_store.h"
 
-#include <algorithm>
-#include <numeric>
-
 #include "glx.h"
 #include "graphlearn/config.h"
 
@@ -43,48 +40,16 @@ Status Graph::UpdateEdges(const UpdateEdgesRequest* req, UpdateEdgesResponse*) {
 Status Graph::Build(const IndexOption& option) {
   std::lock_guard<std::mutex> g(mtx_);
   if (dev_) return Status::OK();
-  const int64_t E = (int64_t)src_.size();
-  // AutoIndex (auto_indexing.cc:21-24): rows in order of first appearance.
-  std::unordered_map<int64_t, int32_t> row_of;
-  std::vector<int64_t> ids;
-  std::vector<int32_t> row(E);
-  for (int64_t e = 0; e < E; ++e) {
-    auto it = row_of.find(src_[e]);
-    if (it == row_of.end()) {
-      it = row_of.emplace(src_[e], (int32_t)ids.size()).first;
-      ids.push_back(src_[e]);
-    }
-    row[e] = it->second;
-  }
-  const int64_t V = (int64_t)ids.size();
-  std::vector<int64_t> row_ptr(V + 1, 0);
-  for (int64_t e = 0; e < E; ++e) row_ptr[row[e] + 1]++;
-  for (int64_t r = 0; r < V; ++r) row_ptr[r + 1] += row_ptr[r];
-  // insertion order inside a row (counting sort is stable)
-  std::vector<int64_t> slot_edge(E);
-  {
-    std::vector<int64_t> fill(row_ptr.begin(), row_ptr.end() - 1);
-    for (int64_t e = 0; e < E; ++e) slot_edge[fill[row[e]]++] = e;
-  }
+  // The whole build runs on the GPU (glx_graph_build): rows = distinct source ids
+  // (AutoIndex, auto_indexing.cc:21-24), edge id = insertion index
+  // (memory_edge_storage.cc:53-57), and -- for weighted types built with
+  // IndexOption "sort" -- rows ordered by weight descending (MemoryAdjMatrix::Sort,
+  // memory_adj_matrix.cc:105-125; ties keep insertion order, which the reference's
+  // std::sort leaves unspecified).
   const bool weighted = info_.IsWeighted();
-  if (weighted && option.name == "sort") {
-    // MemoryAdjMatrix::Sort (memory_adj_matrix.cc:105-125): weight descending.
-    // The reference's std::sort leaves ties unspecified; ties keep insertion order here.
-    for (int64_t r = 0; r < V; ++r) {
-      std::stable_sort(slot_edge.begin() + row_ptr[r], slot_edge.begin() + row_ptr[r + 1],
-                       [&](int64_t a, int64_t b) { return weight_[a] > weight_[b]; });
-    }
-  }
-  std::vector<int64_t> col(E), eid(E);
-  std::vector<float> w(weighted ? E : 0);
-  for (int64_t s = 0; s < E; ++s) {
-    const int64_t e = slot_edge[s];
-    col[s] = dst_[e];
-    eid[s] = e;  // edge id = insertion index (memory_edge_storage.cc:53-57)
-    if (weighted) w[s] = weight_[e];
-  }
-  int rc = glx_graph_create(GLOBAL_FLAG(DeviceId), V, E, row_ptr.data(), col.data(), eid.data(),
-                            weighted ? w.data() : nullptr, ids.data(), GLX_PTR_HOST, nullptr, &dev_);
+  int rc = glx_graph_build(GLOBAL_FLAG(DeviceId), (int64_t)src_.size(), src_.data(), dst_.data(),
+                           weighted ? weight_.data() : nullptr, nullptr,
+                           (weighted && option.name == "sort") ? 1 : 0, GLX_PTR_HOST, nullptr, &dev_);
   return error::FromGlx(rc);
 }
 

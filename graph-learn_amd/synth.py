@@ -52,12 +52,10 @@ def small_graph(num_nodes=2000, num_edges=30000, seed=0, weighted=True, hub_degr
     return csr_numpy(src, dst, w, num_nodes)
 
 
-def rmat_graph_torch(num_nodes, num_edges, seed, device, weighted=True, a=0.57, b=0.19, c=0.19,
+def rmat_edges_torch(num_nodes, num_edges, seed, device, weighted=True, a=0.57, b=0.19, c=0.19,
                      chunk=1 << 25):
-    """RMAT graph generated and CSR-sorted on the GPU.
-
-    -> row_ptr[V+1], col[E], eid[E] (int64), weight[E] (float32 or None), all on `device`;
-    rows ordered by weight descending, edge id = generation index."""
+    """RMAT edge list in generation (= insertion) order: src, dst (int64), weight
+    (float32 U(0.01, 1) or None).  Edge id = index.  Feed it to glx_graph_build."""
     import torch
     scale = int(np.ceil(np.log2(max(num_nodes, 2))))
     gen = torch.Generator(device=device)
@@ -77,14 +75,24 @@ def rmat_graph_torch(num_nodes, num_edges, seed, device, weighted=True, a=0.57, 
         dsts.append(d % num_nodes)
     src = torch.cat(srcs)
     dst = torch.cat(dsts)
-    del srcs, dsts
-    eid = torch.arange(num_edges, dtype=torch.int64, device=device)
     weight = None
     if weighted:
-        # tie-free inside a row: U(0.01, 1) quantised to 2^-23 plus a distinct
-        # per-edge jitter
         weight = torch.rand(num_edges, generator=gen, device=device) * 0.99 + 0.01
-        # sort key: (src asc, weight desc, eid asc)  -- two stable sorts
+    return src, dst, weight
+
+
+def rmat_graph_torch(num_nodes, num_edges, seed, device, weighted=True, a=0.57, b=0.19, c=0.19,
+                     chunk=1 << 25):
+    """The same RMAT graph as rmat_edges_torch, CSR-sorted with torch (tests use this
+    independent construction to cross-check glx_graph_build).
+
+    -> row_ptr[V+1], col[E], eid[E] (int64), weight[E] (float32 or None), all on `device`;
+    rows ordered by weight descending, edge id = generation index."""
+    import torch
+    src, dst, weight = rmat_edges_torch(num_nodes, num_edges, seed, device, weighted, a, b, c, chunk)
+    eid = torch.arange(num_edges, dtype=torch.int64, device=device)
+    if weighted:
+        # sort key: (src asc, weight desc, eid asc) -- two stable sorts
         o = torch.sort(weight, descending=True, stable=True).indices
         src, dst, eid, weight = src[o], dst[o], eid[o], weight[o]
     o = torch.sort(src, stable=True).indices

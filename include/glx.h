@@ -96,6 +96,22 @@ GLX_API const char* glx_last_error(void);
 GLX_API int glx_graph_create(int device, int64_t num_rows, int64_t num_edges, const int64_t* row_ptr,
                      const int64_t* col, const int64_t* eid, const float* weight,
                      const int64_t* ids, int ptr_kind, void* stream, glx_graph** out);
+/* Device-side storage build from a raw edge list (the loader's output): replaces
+ * LocalGraph::UpdateEdges -> GraphStorage::Add (local_graph.cc:50-64,
+ * memory_graph_storage.cc:49-54), MemoryAdjMatrix::Build / Sort
+ * (memory_adj_matrix.cc:60-66,105-125) and CompressedMemoryAdjMatrix::Build
+ * (:169-189).  src/dst/weight[num_edges] are in insertion order, so edge id i is
+ * edge i (memory_edge_storage.cc:53-57); weight may be NULL.  Rows are the distinct
+ * source ids (a device hash map replaces AutoIndex).  edge_ids (may be NULL) overrides
+ * the ids -- a shard that holds a subset of the edges passes their GLOBAL ids; the
+ * array order is still the insertion order.  sort_by_weight != 0 orders
+ * every row by weight descending like Build() with IndexOption "sort" does; ties
+ * keep insertion order (the reference's std::sort leaves them unspecified).
+ * The whole build (two radix sorts, run-length encode, scan, gather, alias
+ * tables, id map) runs on the GPU. */
+GLX_API int glx_graph_build(int device, int64_t num_edges, const int64_t* src, const int64_t* dst,
+                    const float* weight, const int64_t* edge_ids, int sort_by_weight, int ptr_kind,
+                    void* stream, glx_graph** out);
 GLX_API void glx_graph_destroy(glx_graph* g);
 GLX_API int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges, int* weighted,
                    int* has_id_map, int* device);

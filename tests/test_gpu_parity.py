@@ -339,3 +339,50 @@ def test_id_map_with_extreme_and_colliding_ids(orc):
     row = {int(v): i for i, v in enumerate(raw)}
     exp = np.stack([X[row[int(v)]] if int(v) in row else np.full(12, 0.25, np.float32) for v in q])
     assert beq(out, exp)
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+def test_device_side_build_from_edge_list(orc, weighted):
+    """glx_graph_build (radix sorts + RLE + scan on the GPU) must give the storage the
+    reference builds on the host: rows by weight descending (ties by insertion),
+    edge id = insertion index (memory_adj_matrix.cc:105-125, memory_edge_storage.cc:53-57)."""
+    import torch
+    rng = np.random.default_rng(31 + weighted)
+    V, E = 4000, 120000
+    raw = (np.arange(V, dtype=np.int64) * 13 - 20000)
+    s_idx = np.minimum((rng.pareto(1.1, E) * 5).astype(np.int64), V - 1)
+    src = raw[s_idx]
+    dst = raw[rng.integers(0, V, E)]
+    w = None
+    if weighted:
+        w = (rng.integers(1, 200, E) / 200.0).astype(np.float32)  # many exact ties
+    # host-side construction the oracle way: rows in first-appearance order, stable sort
+    _, first = np.unique(src, return_index=True)
+    rows = src[np.sort(first)]
+    row_of = {int(v): i for i, v in enumerate(rows)}
+    r = np.array([row_of[int(x)] for x in src])
+    order = np.argsort(r, kind="stable")
+    rp = np.zeros(rows.shape[0] + 1, np.int64)
+    np.add.at(rp, r + 1, 1)
+    rp = np.cumsum(rp)
+    col, eid = dst[order].copy(), order.astype(np.int64)
+    ws = None
+    if weighted:
+        col, eid, ws = orc.sort_rows(rp, col, eid, w[order].copy())
+    og = dict(row_ptr=rp, col=col, eid=eid, weight=ws, ids=rows)
+    if weighted:
+        og["alias"] = orc.alias_build(rp, ws)
+    for dev_graph in (glx.Graph.from_edges(src, dst, w),
+                      glx.Graph.from_edges(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(),
+                                           torch.from_numpy(w).cuda() if weighted else None)):
+        assert dev_graph.num_rows == rows.shape[0] and dev_graph.num_edges == E
+        q = np.concatenate([rows, [7, -7, 10 ** 15]]).astype(np.int64)
+        names = SAMPLERS if weighted else ["RandomSampler", "RandomWithoutReplacementSampler", "TopkSampler"]
+        for name in names:
+            for k in (3, 40):
+                n, e = dev_graph.sample(name, q, k, seed=5, call_counter=k, default_neighbor_id=-1)
+                on, oe = orc.sample(og, name, q, k, seed=5, call_counter=k, default_neighbor_id=-1)
+                assert np.array_equal(n, on) and np.array_equal(e, oe), (name, k, weighted)
+    g0 = glx.Graph.from_edges(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32))
+    n, e = g0.sample("TopkSampler", np.arange(3, dtype=np.int64), 2, default_neighbor_id=5)
+    assert (n == 5).all() and (e == -1).all()
