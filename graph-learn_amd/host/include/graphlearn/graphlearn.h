@@ -3,6 +3,7 @@
 #define GLX_HOST_GRAPHLEARN_H_
 #include "graphlearn/aggregating_request.h"
 #include "graphlearn/config.h"
+#include "graphlearn/graph_request.h"
 #include "graphlearn/graph_store.h"
 #include "graphlearn/op_request.h"
 #include "graphlearn/operator.h"

@@ -112,4 +112,26 @@ TEST(AggregatingOpTest, ConcurrentProcessOnOneInstance) {
   for (int t = 0; t < 8; ++t) EXPECT_TRUE(ok[t] == 1);
 }
 
+TEST(NodeLookuperTest, LookupNodesFloatAttributes) {
+  // node_lookuper.cc:24-52 / local_noder.cc:85-97: attributes in request order,
+  // unknown ids -> the default attribute (here 999.9 as in python/sampler/tests).
+  SetUpStore();
+  SetGlobalFlagDefaultFloatAttribute(999.9f);
+  LookupNodesRequest req("user");
+  LookupNodesResponse res;
+  int64_t ids[6] = {7, 0, 99, 100, -3, 42};
+  req.Set(ids, 6);
+  Operator* op = OpFactory::GetInstance()->Create(req.Name());
+  EXPECT_TRUE(op != nullptr);
+  EXPECT_TRUE(op->Process(&req, &res).ok());
+  EXPECT_EQ(res.Size(), 6);
+  EXPECT_EQ(res.FloatAttrNum(), 1);
+  const float expect[6] = {7.f, 0.f, 99.f, 999.9f, 999.9f, 42.f};
+  for (int i = 0; i < 6; ++i) EXPECT_FLOAT_EQ(res.FloatAttrs()[i], expect[i]);
+  SetGlobalFlagDefaultFloatAttribute(0.0f);
+  OpRequest* rq = RequestFactory::GetInstance()->NewRequest("LookupNodes");
+  EXPECT_TRUE(rq != nullptr);
+  delete rq;
+}
+
 int main() { return RunAllTests(); }
