@@ -326,3 +326,77 @@ extern "C" int glx_sample(const glx_graph* g, int sampler, const int64_t* src, i
   return glx_sample_ex(g, sampler, src, nullptr, batch, k, padding_mode, default_neighbor_id, seed,
                        call_counter, nbr_out, eid_out, ptr_kind, stream);
 }
+
+extern "C" int glx_sample_hops(const glx_graph* const* graphs, int32_t num_hops, int sampler,
+                               const int64_t* seeds, int32_t batch, const int32_t* fanouts,
+                               int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+                               uint64_t call_counter, int64_t* const* nbr_out,
+                               int64_t* const* eid_out, int ptr_kind, void* stream) {
+  GLX_REQUIRE(graphs && fanouts && nbr_out, "NULL argument");
+  GLX_REQUIRE(num_hops >= 1 && num_hops <= 16, "num_hops must be in [1, 16]");
+  GLX_REQUIRE(batch >= 0, "negative batch");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  int64_t rows = batch;
+  for (int32_t h = 0; h < num_hops; ++h) {
+    GLX_REQUIRE(graphs[h] != nullptr && nbr_out[h] != nullptr, "hop %d: NULL graph / output", h);
+    GLX_REQUIRE(graphs[h]->device == graphs[0]->device, "all hops must live on one device");
+    GLX_REQUIRE(fanouts[h] >= 0, "negative fanout");
+    GLX_REQUIRE(rows <= INT32_MAX && rows * fanouts[h] <= INT32_MAX,
+                "hop %d exceeds int32 slots (tensor.h:47)", h);
+    rows *= fanouts[h];
+  }
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    const int64_t* frontier = seeds;
+    int64_t n = batch;
+    for (int32_t h = 0; h < num_hops; ++h) {
+      int64_t* e = eid_out ? eid_out[h] : nullptr;
+      GLX_REQUIRE(e != nullptr || n * fanouts[h] == 0, "device mode needs eid_out[%d]", h);
+      int rc = glx_sample(graphs[h], sampler, frontier, (int32_t)n, fanouts[h], padding_mode,
+                          default_neighbor_id, seed, call_counter + (uint64_t)h, nbr_out[h], e,
+                          GLX_PTR_DEVICE, stream);
+      if (rc != GLX_OK) return rc;
+      frontier = nbr_out[h];
+      n *= fanouts[h];
+    }
+    return GLX_OK;
+  }
+  // Host pointers: one upload of the seeds, every hop sampled from the previous
+  // hop's device buffer, one download per hop output.
+  GlxDeviceGuard guard(graphs[0]->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", graphs[0]->device);
+  hipStream_t s = glx_stream(stream);
+  size_t total = (size_t)batch;
+  {
+    int64_t n = batch;
+    for (int32_t h = 0; h < num_hops; ++h) {
+      n *= fanouts[h];
+      total += 2 * (size_t)n;
+    }
+  }
+  int64_t* d = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), total * 8, s, 0);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(hipMemcpyAsync(d, seeds, (size_t)batch * 8, hipMemcpyHostToDevice, s));
+  const int64_t* frontier = d;
+  int64_t* cursor = d + batch;
+  int64_t n = batch;
+  for (int32_t h = 0; h < num_hops; ++h) {
+    const int64_t slots = n * fanouts[h];
+    int64_t* dn = cursor;
+    int64_t* de = cursor + slots;
+    cursor += 2 * slots;
+    if (slots > 0) {
+      rc = glx_sample(graphs[h], sampler, frontier, (int32_t)n, fanouts[h], padding_mode,
+                      default_neighbor_id, seed, call_counter + (uint64_t)h, dn, de, GLX_PTR_DEVICE, s);
+      if (rc != GLX_OK) break;
+      GLX_HIP(hipMemcpyAsync(nbr_out[h], dn, (size_t)slots * 8, hipMemcpyDeviceToHost, s));
+      if (eid_out && eid_out[h]) GLX_HIP(hipMemcpyAsync(eid_out[h], de, (size_t)slots * 8, hipMemcpyDeviceToHost, s));
+    }
+    frontier = dn;
+    n = slots;
+  }
+  hipError_t e2 = hipStreamSynchronize(s);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(e2);
+  return GLX_OK;
+}

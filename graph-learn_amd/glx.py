@@ -37,7 +37,7 @@ AGGREGATOR_IDS = {
 EXPORTS = [
     "glx_abi_version", "glx_device_count", "glx_last_error",
     "glx_graph_create", "glx_graph_build", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
-    "glx_graph_degrees", "glx_sample", "glx_sample_ex",
+    "glx_graph_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
     "glx_partition", "glx_stitch_i64", "glx_stitch_f32",
@@ -82,6 +82,7 @@ def lib():
         L.glx_graph_degrees.argtypes = [vp, vp, i64, vp, ci, vp]
         L.glx_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_sample_ex.argtypes = [vp, ci, vp, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
+        L.glx_sample_hops.argtypes = [vp, i32, ci, vp, i32, vp, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_features_view.argtypes = [ci, i64, i32, vp, ctypes.POINTER(vp)]
         L.glx_features_create.argtypes = [ci, i64, i32, vp, vp, ci, vp, ctypes.POINTER(vp)]
         L.glx_features_destroy.argtypes = [vp]
@@ -280,6 +281,37 @@ class Features:
         kind = _kind(pi, po)
         _check(lib().glx_lookup(self._h, pi[0], n, default_attr, po[0], kind, _stream(kind)))
         return out
+
+
+def sample_hops(graphs, sampler, seeds, fanouts, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR,
+                default_neighbor_id=0):
+    """Multi-hop driver (NeighborSampler.get): hop h from graphs[h] with fanouts[h].
+    -> list of (nbr[rows_h, fanouts[h]], eid[...]) per hop."""
+    if isinstance(sampler, str):
+        sampler = SAMPLER_IDS[sampler]
+    L = len(fanouts)
+    assert len(graphs) == L
+    rows = int(seeds.shape[0])
+    outs = []
+    torch_mode = _is_torch(seeds)
+    for k in fanouts:
+        if torch_mode:
+            import torch
+            nbr = torch.empty((rows, k), dtype=torch.int64, device=seeds.device)
+            eid = torch.empty((rows, k), dtype=torch.int64, device=seeds.device)
+        else:
+            nbr = np.empty((rows, k), np.int64)
+            eid = np.empty((rows, k), np.int64)
+        outs.append((nbr, eid))
+        rows *= k
+    kind = PTR_DEVICE if torch_mode else PTR_HOST
+    gh = (ctypes.c_void_p * L)(*[g._h for g in graphs])
+    fo = (ctypes.c_int32 * L)(*fanouts)
+    pn = (ctypes.c_void_p * L)(*[_ptr(o[0])[0] for o in outs])
+    pe = (ctypes.c_void_p * L)(*[_ptr(o[1])[0] for o in outs])
+    _check(lib().glx_sample_hops(gh, L, sampler, _ptr(seeds)[0], int(seeds.shape[0]), fo, padding_mode,
+                                 default_neighbor_id, seed, call_counter, pn, pe, kind, _stream(kind)))
+    return outs
 
 
 def partition(ids, num_shards):

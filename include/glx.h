@@ -152,6 +152,20 @@ GLX_API int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src, c
                   uint64_t seed, uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out,
                   int ptr_kind, void* stream);
 
+/* Multi-hop driver: replaces the host-side hop loop of NeighborSampler.get
+ * (graphlearn/python/sampler/neighbor_sampler.py:93-127) / a chain of sampling
+ * DAG nodes (core/runner/dag_node_runner.cc:32-109).  Hop h samples fanouts[h]
+ * neighbours of every vertex of hop h-1 (hop 0 = `seeds`) from graphs[h] -- one
+ * edge type per hop, i.e. the meta-path -- with random stream (seed,
+ * call_counter + h).  Frontiers stay on the device between hops; hop h's
+ * batch * fanouts[0] * ... * fanouts[h] slots are written to nbr_out[h] /
+ * eid_out[h] (eid_out, or single entries of it, may be NULL).  Equivalent to
+ * num_hops glx_sample calls feeding each other. */
+GLX_API int glx_sample_hops(const glx_graph* const* graphs, int32_t num_hops, int sampler,
+                    const int64_t* seeds, int32_t batch, const int32_t* fanouts, int padding_mode,
+                    int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                    int64_t* const* nbr_out, int64_t* const* eid_out, int ptr_kind, void* stream);
+
 /* ---- node features: replaces NodeStorage::GetAttribute()->GetFloats()
  * (node_storage.h:51-54, compressed_memory_node_storage.cc:149-176). -------
  * X is [num_rows, dim] row-major float32 (SideInfo.f_num == dim). */

@@ -386,3 +386,24 @@ def test_device_side_build_from_edge_list(orc, weighted):
     g0 = glx.Graph.from_edges(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32))
     n, e = g0.sample("TopkSampler", np.arange(3, dtype=np.int64), 2, default_neighbor_id=5)
     assert (n == 5).all() and (e == -1).all()
+
+
+def test_multi_hop_driver_equals_chained_calls(orc, graphs):
+    """glx_sample_hops == the hop loop of NeighborSampler.get (neighbor_sampler.py:93-127)."""
+    import torch
+    og, dev = graphs["dense"]
+    _, dev2 = graphs["hashed"]
+    seeds = np.random.default_rng(6).integers(0, 3000, 300).astype(np.int64)
+    for name in SAMPLERS:
+        outs = glx.sample_hops([dev, dev, dev], name, seeds, [5, 3, 2], seed=12, call_counter=40)
+        n1, e1 = dev.sample(name, seeds, 5, seed=12, call_counter=40)
+        n2, e2 = dev.sample(name, n1.reshape(-1), 3, seed=12, call_counter=41)
+        n3, e3 = dev.sample(name, n2.reshape(-1), 2, seed=12, call_counter=42)
+        for (a, b), (c, d) in zip(outs, [(n1, e1), (n2, e2), (n3, e3)]):
+            assert np.array_equal(a, c) and np.array_equal(b, d), name
+        t = glx.sample_hops([dev, dev, dev], name, torch.from_numpy(seeds).cuda(), [5, 3, 2], seed=12,
+                            call_counter=40)
+        torch.cuda.synchronize()
+        assert np.array_equal(t[2][0].cpu().numpy(), n3) and np.array_equal(t[2][1].cpu().numpy(), e3)
+    with pytest.raises(glx.GlxError):
+        glx.sample_hops([dev], "TopkSampler", np.zeros(1 << 20, np.int64), [4096])
