@@ -48,6 +48,9 @@ WORKLOADS = {
     "c2": (2_400_000, 62_000_000, "RandomWithoutReplacementSampler", (15, 10), "MeanAggregator", 128, 2,
            "BASELINE configs[1] shape: RMAT 2.4M nodes / 62M edges, RandomWithoutReplacement "
            "fanout [15,10], MeanAggregator, dim=128"),
+    "c4": (111_000_000, 1_600_000_000, "RandomSampler", (20, 15), "MeanAggregator", 128, 6,
+           "BASELINE configs[3] shape on ONE GPU: RMAT 111M nodes / 1.6B edges (ogbn-papers100M-sized), "
+           "RandomSampler fanout [20,15], MeanAggregator, dim=128"),
     "tiny": (200_000, 2_000_000, "EdgeWeightSampler", (25, 10), "MaxAggregator", 256, 4,
              "tiny smoke workload (not a benchmark)"),
 }
