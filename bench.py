@@ -130,12 +130,93 @@ def cpu_baseline(wl, src, dst, weight, args):
     }
 
 
+def bench_c5(args, dev, result_out):
+    """BASELINE configs[4] shape on one GPU: heterogeneous user-item-shop graph, three
+    weighted edge types (u-i 300M, i-s 100M, u-s 100M edges over 40M / 9M / 1M nodes),
+    per-edge-type TopkSampler (k = 10, 10, 5) + type-wise SumAggregator, dim=256.
+    One storage handle per type replaces the reference's HeterDispatcher
+    (core/graph/heter_dispatcher.h:44-56)."""
+    D, B0 = 256, args.batch
+    n_user, n_item, n_shop = 40_000_000, 9_000_000, 1_000_000
+    spec = {"u-i": (n_user, n_item, 300_000_000, 10), "i-s": (n_item, n_shop, 100_000_000, 10),
+            "u-s": (n_user, n_shop, 100_000_000, 5)}
+    t0 = time.time()
+    graphs = {}
+    for i, (t, (ns, nd, ne, k)) in enumerate(spec.items()):
+        src, dst, w = synth.rmat_edges_torch(1 << 26, ne, 20 + i, dev, weighted=True)
+        graphs[t] = glx.Graph.from_edges(src % ns, dst % nd, w, device=dev.index)
+        del src, dst, w
+    x_item = glx.Features(synth.features_torch(n_item, D, 31, dev), device=dev.index)
+    x_shop = glx.Features(synth.features_torch(n_shop, D, 32, dev), device=dev.index)
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    log("c5 stores built in %.1fs: %s" % (time.time() - t0, {t: g.num_edges for t, g in graphs.items()}))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    n_steps = args.warmup + args.steps
+    seeds = torch.randint(0, n_user, (n_steps, B0), generator=gen, device=dev, dtype=torch.int64)
+    k1, k2, k3 = 10, 10, 5
+    i64 = dict(dtype=torch.int64, device=dev)
+    s1, e1 = torch.empty((B0, k1), **i64), torch.empty((B0, k1), **i64)
+    s2, e2 = torch.empty((B0 * k1, k2), **i64), torch.empty((B0 * k1, k2), **i64)
+    s3, e3 = torch.empty((B0, k3), **i64), torch.empty((B0, k3), **i64)
+    seg = lambda n, f: (torch.arange(n, device=dev) // f).to(torch.int32)  # noqa: E731
+    g2, g1, g3 = seg(B0 * k1 * k2, k2), seg(B0 * k1, k1), seg(B0 * k3, k3)
+    f32 = dict(dtype=torch.float32, device=dev)
+    o2 = (torch.empty((B0 * k1, D), **f32), torch.empty(B0 * k1, dtype=torch.int32, device=dev))
+    o1 = (torch.empty((B0, D), **f32), torch.empty(B0, dtype=torch.int32, device=dev))
+    o3 = (torch.empty((B0, D), **f32), torch.empty(B0, dtype=torch.int32, device=dev))
+
+    def step(i):
+        graphs["u-i"].sample("TopkSampler", seeds[i], k1, out=(s1, e1))
+        graphs["i-s"].sample("TopkSampler", s1.view(-1), k2, out=(s2, e2))
+        graphs["u-s"].sample("TopkSampler", seeds[i], k3, out=(s3, e3))
+        x_shop.aggregate("SumAggregator", s2.view(-1), g2, B0 * k1, out=o2)
+        x_item.aggregate("SumAggregator", s1.view(-1), g1, B0, out=o1)
+        x_shop.aggregate("SumAggregator", s3.view(-1), g3, B0, out=o3)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    glx.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        step(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    glx.profile_enable(False)
+    t_agg = glx.profile_collect(glx.KERNEL_AGGREGATE)
+    t_smp = glx.profile_collect(glx.KERNEL_SAMPLE)
+    slots = B0 * (k1 + k1 * k2 + k3)
+    n2, sg2 = B0 * k1 * k2, B0 * k1
+    bytes2 = n2 * (4 * D + 12) + sg2 * (4 * D + 4)
+    ms2 = float(np.mean(t_agg[0::3]))
+    achieved = bytes2 / (ms2 * 1e-3) / 1e9
+    res = {
+        "metric": "sampled-edges/sec + aggregated-vertices/sec (per-edge-type Topk + type-wise Sum per step)",
+        "value": slots * args.steps / elapsed, "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int64 ids + f32 features", "data": "synthetic",
+        "config": {"workload": "c5: " + bench_c5.__doc__.split("\n")[0], "seeds_per_step_per_gpu": B0,
+                   "edge_types": {t: {"edges": v[2], "k": v[3]} for t, v in spec.items()}, "dim": D,
+                   "parallelism": "1 GPU"},
+        "phases": {"sampling_kernels_ms_per_step": float(np.sum(t_smp)) / args.steps,
+                   "aggregation_kernels_ms_per_step": float(np.sum(t_agg)) / args.steps},
+        "roofline": {"kernel": "glx_aggregate_kernel (i-s hop SumAggregator, dim=256)", "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "avg_launch_ms": ms2, "algorithmic_bytes_per_launch": bytes2},
+        "cpu_baseline": None,
+    }
+    result_out.write(json.dumps(res) + "\n")
+    result_out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c5"])
     ap.add_argument("--batch", type=int, default=65536, help="seed vertices per step per GPU (B0)")
     ap.add_argument("--features", default="auto", choices=["auto", "replicated", "sharded"],
                     help="N>1: replicate the feature table on every GPU (load-time all-gather) or keep it "
@@ -170,6 +251,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "c5":
+        assert not sharded, "c5 is a single-GPU workload in this round"
+        bench_c5(args, dev, result_out)
+        return
     wl = WORKLOADS[args.workload]
     V, E, sampler, (k1, k2), agg, D, gseed, desc = wl
     B0 = args.batch
