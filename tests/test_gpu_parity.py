@@ -407,3 +407,14 @@ def test_multi_hop_driver_equals_chained_calls(orc, graphs):
         assert np.array_equal(t[2][0].cpu().numpy(), n3) and np.array_equal(t[2][1].cpu().numpy(), e3)
     with pytest.raises(glx.GlxError):
         glx.sample_hops([dev], "TopkSampler", np.zeros(1 << 20, np.int64), [4096])
+
+
+def test_partition_stitch_reference_unittest_layout():
+    """Device HashPartitioner / Stitcher on partition_stitch_unittest.cpp's DenseReq_DenseRes case."""
+    import torch
+    ids = torch.tensor([1, 2, 3, 4], dtype=torch.int64, device="cuda")
+    bucketed, order, counts = glx.partition(ids, 2)
+    assert counts.tolist() == [2, 2] and order.tolist() == [1, 3, 0, 2] and bucketed.tolist() == [2, 4, 1, 3]
+    rows = torch.stack([bucketed * 100 + j for j in range(6)], 1).contiguous()
+    out = glx.stitch(rows, order)
+    assert out.tolist() == [[i * 100 + j for j in range(6)] for i in (1, 2, 3, 4)]

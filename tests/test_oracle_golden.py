@@ -286,3 +286,15 @@ def test_live_reference_csr_mode_and_samplers(orc):
                     assert a == b == full
     finally:
         ref.close()
+
+
+def test_partition_stitch_reference_unittest_layout(orc):
+    """partition_stitch_unittest.cpp DenseReq_DenseRes: ids {1,2,3,4} on 2 servers ->
+    shard 0 serves {2,4} (stickers 1,3), shard 1 serves {1,3} (stickers 0,2); the
+    stitched dense [4,6] response has every row back at its request position."""
+    ids = np.array([1, 2, 3, 4], np.int64)
+    order, counts = orc.partition(ids, 2)
+    assert counts.tolist() == [2, 2] and order.tolist() == [1, 3, 0, 2]
+    shard_rows = np.stack([ids[order] * 100 + j for j in range(6)], 1)  # what each shard returns
+    out = orc.stitch(shard_rows, order)
+    assert np.array_equal(out, np.stack([ids * 100 + j for j in range(6)], 1))
