@@ -69,7 +69,7 @@ def cpu_baseline(wl, src, dst, weight, args):
     from oracle_bindings import RefLib, have_ref, _p
     V, E, sampler, (k1, k2), agg, D = wl[:6]
     if not have_ref():
-        return None
+        return cpu_baseline_port(wl, src, dst, weight, args)
     t_all = time.time()
     ref = RefLib(storage_mode=2, padding_mode=1)
     # edges in insertion (= edge id) order, as the reference loader would add them
@@ -128,6 +128,51 @@ def cpu_baseline(wl, src, dst, weight, args):
                    % (sampler, k1, k2, agg, B, reps, dts, dta, added, E, t_build, Vc, D, Vc)),
         "wall_s": time.time() - t_all,
     }
+
+
+def cpu_baseline_port(wl, src, dst, weight, args):
+    """Fallback when oracle/_ref (the reference's own code) is not on this box: the
+    C restatement (oracle/glx_oracle.c) timed single-threaded with the reference's cost
+    model switched on (per-row, per-request alias rebuild: edge_weight_sampler.cc:78-92)."""
+    from oracle_bindings import Oracle
+    import synth as _synth
+    V, E, sampler, (k1, k2), agg, D = wl[:6]
+    t_all = time.time()
+    orc = Oracle()
+    Ec = min(E, 20_000_000)  # bounded sample: a prefix of the edge stream
+    s_h = src[:Ec].cpu().numpy()
+    d_h = dst[:Ec].cpu().numpy()
+    w_h = weight[:Ec].cpu().numpy() if weight is not None else None
+    rp, col, eid, ws = _synth.csr_numpy(s_h, d_h, w_h, V)
+    g = dict(row_ptr=rp, col=col, eid=eid, weight=ws)
+    orc.L.glxo_set_reference_cost_model(1)
+    rng = np.random.default_rng(123)
+    B = max(8, args.cpu_seeds_per_request // 8)
+    edges, t0 = 0, time.time()
+    while time.time() - t0 < args.cpu_time_budget:
+        seeds = rng.integers(0, V, B).astype(np.int64)
+        n1, _ = orc.sample(g, sampler, seeds, k1, seed=1, call_counter=edges)
+        n2, _ = orc.sample(g, sampler, n1.reshape(-1), k2, seed=1, call_counter=edges + 1)
+        edges += n1.size + n2.size
+    dts = time.time() - t0
+    orc.L.glxo_set_reference_cost_model(0)
+    Vc = min(V, 1_000_000)
+    X = (np.random.default_rng(5).random((Vc, D), dtype=np.float32) * 2 - 1)
+    ids = (n2.reshape(-1) % Vc).astype(np.int64)
+    seg = (np.arange(ids.shape[0]) // k2).astype(np.int32)
+    verts, t0 = 0, time.time()
+    while time.time() - t0 < args.cpu_time_budget / 2:
+        orc.aggregate(X, agg, ids, seg, ids.shape[0] // k2)
+        verts += ids.shape[0]
+    dta = time.time() - t0
+    r_s, r_a = edges / dts, verts / dta
+    return {"value": 1.0 / (1.0 / r_s + 1.0 / r_a), "unit": "edges/s", "cores": 1, "kind": "port",
+            "sampling_edges_per_s": r_s, "aggregation_vertices_per_s": r_a,
+            "sample": ("oracle/glx_oracle.c (C restatement, reference cost model: alias table rebuilt per row per "
+                       "request) single-threaded; %s [%d,%d] + %s; graph = first %d of %d edges; %d seeds/request; "
+                       "%.1fs sampling + %.1fs aggregation timed; features = %d rows x %d"
+                       % (sampler, k1, k2, agg, Ec, E, B, dts, dta, Vc, D)),
+            "wall_s": time.time() - t_all}
 
 
 def bench_c5(args, dev, result_out):

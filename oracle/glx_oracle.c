@@ -181,6 +181,9 @@ void glxo_sort_rows_by_weight_desc(const int64_t* row_ptr, int64_t V, int64_t* c
 }
 
 /* -------------------------------------------------------------- samplers -- */
+static int g_reference_cost_model = 0;
+void glxo_set_reference_cost_model(int on) { g_reference_cost_model = on; }
+
 static void fill_default(int64_t* nbr, int64_t* eid, int32_t k, int64_t def) {
   /* SamplingResponse::FillWith, sampling_request.cc:279-290 */
   for (int32_t j = 0; j < k; ++j) { nbr[j] = def; eid[j] = -1; }
@@ -215,7 +218,8 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
                 int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                 uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out) {
   if (op < GLXO_RANDOM || op > GLXO_TOPK) return 3;
-  if (op == GLXO_EDGE_WEIGHT && (!g->alias_prob || !g->alias_idx)) return 3;
+  if (op == GLXO_EDGE_WEIGHT && !g_reference_cost_model && (!g->alias_prob || !g->alias_idx)) return 3;
+  if (op == GLXO_EDGE_WEIGHT && g_reference_cost_model && !g->weight) return 3;
   idmap m;
   if (g->ids) idmap_build(&m, g->ids, g->V);
   int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
@@ -271,8 +275,18 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
       case GLXO_EDGE_WEIGHT: {
         /* alias_method.cc:109-124: rand = float(U[0, deg-1)); idx = int(rand);
          * ret = probs[idx] <= rand - idx ? alias[idx] : idx. */
-        const float* probs = g->alias_prob + start;
-        const int32_t* alias = g->alias_idx + start;
+        const float* probs = g->alias_prob ? g->alias_prob + start : NULL;
+        const int32_t* alias = g->alias_idx ? g->alias_idx + start : NULL;
+        float* tmp_p = NULL;
+        int32_t* tmp_a = NULL;
+        if (g_reference_cost_model) {
+          /* the reference's per-row, per-request AliasMethod(&edge_weights) */
+          tmp_p = (float*)malloc(sizeof(float) * (size_t)deg);
+          tmp_a = (int32_t*)malloc(sizeof(int32_t) * (size_t)deg * 3);
+          alias_build_row(g->weight + start, (int32_t)deg, tmp_p, tmp_a, tmp_a + deg, tmp_a + 2 * deg);
+          probs = tmp_p;
+          alias = tmp_a;
+        }
         for (int32_t j = 0; j < k; ++j) {
           uint64_t u = glxo_draw64(seed, call_counter, rr, (uint32_t)j);
           double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
@@ -281,6 +295,8 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
           idx[j] = (probs[ix] <= (rnd - ix)) ? alias[ix] : ix;
         }
         pad_row(rn, re, deg, idx, k, k, padding_mode, default_neighbor_id, nbr, eid);
+        free(tmp_p);
+        free(tmp_a);
         break;
       }
       case GLXO_TOPK:

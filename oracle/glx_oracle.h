@@ -67,6 +67,13 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
                 int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                 uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out);
 
+/* Timing aid for bench.py's cpu_baseline of kind "port" (used only when the
+ * reference build oracle/_ref is not available): when on, EdgeWeight rebuilds the
+ * row's alias table from the weights on EVERY request row, which is the cost
+ * structure of the reference (edge_weight_sampler.cc:78-92 calls AliasMethod's
+ * constructor per row per request).  Results are unchanged. */
+void glxo_set_reference_cost_model(int on);
+
 /* Restates Aggregator::Aggregate (aggregator.cc:25-59) with the Sum/Mean/Max/
  * Min/Prod Init/Agg/Final functions.  feats is [V, dim] row-major; ids as in
  * glxo_graph.ids (NULL = dense). Unknown id -> a row of default_attr

@@ -45,6 +45,7 @@ class Oracle:
         L.glxo_aggregate.argtypes = [VP, i64, i32, VP, ctypes.c_int, VP, VP, i32, i32, ctypes.c_float, VP, VP]
         L.glxo_partition.argtypes = [VP, i64, i32, VP, VP]
         L.glxo_stitch_i64.argtypes = [VP, VP, i64, i32, VP]
+        L.glxo_set_reference_cost_model.argtypes = [ctypes.c_int]
         self.L = L
 
     def philox(self, ctr, key):
