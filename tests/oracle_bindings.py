@@ -112,7 +112,7 @@ class Oracle:
 
 
 def have_ref():
-    return os.path.exists(REF_SO)
+    return os.path.exists(REF_SO) and not os.environ.get("GLX_NO_REF")
 
 
 class RefLib:

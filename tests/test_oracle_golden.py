@@ -298,3 +298,29 @@ def test_partition_stitch_reference_unittest_layout(orc):
     shard_rows = np.stack([ids[order] * 100 + j for j in range(6)], 1)  # what each shard returns
     out = orc.stitch(shard_rows, order)
     assert np.array_equal(out, np.stack([ids * 100 + j for j in range(6)], 1))
+
+
+def test_python_fixture_random_without_replacement_sets(orc):
+    """test_random_worepl_neighbor_sampling.py:31-63: with expand_factor >= degree the
+    sampled set of every seed equals its full neighbour set (circular padding), and
+    additionally contains the default id (-1) under replicate padding."""
+    g = load("pyfixture_topk.npz")
+    og = graph_of(g)
+    seeds = np.array([102, 107, 108], np.int64)
+    for pad in (1, 0):
+        nbr, eid = orc.sample(og, "RandomWithoutReplacementSampler", seeds, 4, seed=9, call_counter=1,
+                              padding_mode=pad, default_neighbor_id=-1)
+        for i, s in enumerate(seeds):
+            full = set(int(s) * it % 100 for it in range(1, int(s) % 5 + 1))
+            want = full if pad == 1 else full | {-1}
+            assert set(nbr[i].tolist()) == want, (pad, s)
+
+
+def test_alias_method_unittest_membership(orc):
+    """alias_method_unittest.cpp:33-60: dist {1.2, .3, .4}, every draw is a valid index."""
+    rp = np.array([0, 3], np.int64)
+    w = np.array([1.2, 0.3, 0.4], np.float32)
+    g = dict(row_ptr=rp, col=np.arange(3, dtype=np.int64), eid=np.arange(3, dtype=np.int64), weight=w,
+             alias=orc.alias_build(rp, w))
+    nbr, _ = orc.sample(g, "EdgeWeightSampler", np.zeros(1000, np.int64), 10, seed=3)
+    assert set(np.unique(nbr).tolist()) <= {0, 1, 2}
