@@ -85,10 +85,12 @@ struct AggArgs {
   float default_attr;
 };
 
-__device__ __forceinline__ int64_t agg_row_at(const AggArgs& a, int32_t pos) {
+// Feature rows are < 2^31 (checked at creation), so a row index fits an int32 --
+// half the registers of the raw int64 id, which keeps the kernel at 8 waves/SIMD.
+__device__ __forceinline__ int32_t agg_row_at(const AggArgs& a, int32_t pos) {
   if (a.rows) return a.rows[pos];
   const int64_t id = a.node_ids[pos];
-  return (id >= 0 && id < a.num_rows) ? id : -1;
+  return (id >= 0 && id < a.num_rows) ? (int32_t)id : -1;
 }
 
 // G lanes per segment, VEC floats per lane per pass (VEC = 4: one dwordx4 per
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = agg_init<OP>();
     for (int32_t base = s0; base < s1; base += U) {
-      int64_t row[U];
+      int32_t row[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) row[u] = (base + u < s1) ? agg_row_at(a, base + u) : -2;
       vec_t val[U];

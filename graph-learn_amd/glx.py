@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libglx.so")
+LIB_PATH = os.environ.get("GLX_LIB") or os.path.join(_HERE, "lib", "libglx.so")  # GLX_LIB: A/B builds
 
 PTR_HOST, PTR_DEVICE = 0, 1
 RANDOM, RANDOM_WITHOUT_REPLACEMENT, EDGE_WEIGHT, TOPK = 0, 1, 2, 3
