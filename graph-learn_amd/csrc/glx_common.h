@@ -129,6 +129,7 @@ struct glx_graph {
   GlxAdj* adj;       // [E] 16-byte aligned records
   float* weight;     // [E] or nullptr
   GlxAlias* alias;   // [E] or nullptr
+  GlxAlias* alias_indeg;  // [E] alias tables over the neighbours' in-degrees, or nullptr
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
 };
@@ -192,6 +193,9 @@ __device__ __forceinline__ int32_t glx_alias_pick(uint64_t u, int64_t deg,
 // g->row_ptr, g->adj and (for weighted graphs) g->weight filled on `s`; builds the
 // alias tables and, when d_ids != nullptr, the id map; synchronises `s`.
 int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s);
+// Launches AliasMethod::Build for every row of `row_ptr` over per-slot weights.
+int glx_alias_build_launch(const int64_t* row_ptr, const float* weight, int64_t V, int64_t E,
+                           GlxAlias* out, hipStream_t s);
 void glx_graph_free(glx_graph* g);
 
 static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -354,6 +354,7 @@ void glx_graph_free(glx_graph* g) {
   if (g->adj) (void)hipFree(g->adj);
   if (g->weight) (void)hipFree(g->weight);
   if (g->alias) (void)hipFree(g->alias);
+  if (g->alias_indeg) (void)hipFree(g->alias_indeg);
   glx_idmap_free(&g->idmap);
   delete g;
 }
@@ -409,16 +410,24 @@ static int graph_create_impl(glx_graph* g, const int64_t* row_ptr, const int64_t
   return glx_graph_finalize(g, d_ids, s);
 }
 
+int glx_alias_build_launch(const int64_t* row_ptr, const float* weight, int64_t V, int64_t E,
+                           GlxAlias* out, hipStream_t s) {
+  if (E <= 0 || V <= 0) return GLX_OK;
+  GlxTemp stk_buf;
+  GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(int32_t)));
+  glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(row_ptr, weight, V, out,
+                                                                  stk_buf.as<int32_t>());
+  GLX_HIP(hipStreamSynchronize(s));  // stk_buf is released on return
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
 int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s) {
   const int64_t V = g->num_rows, E = g->num_edges;
-  GlxTemp stk_buf;
   if (g->weight) {
     GLX_HIP(hipMalloc(&g->alias, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
-    if (E > 0) {
-      GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(int32_t)));
-      glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(g->row_ptr, g->weight, V,
-                                                                      g->alias, stk_buf.as<int32_t>());
-    }
+    int rc = glx_alias_build_launch(g->row_ptr, g->weight, V, E, g->alias, s);
+    if (rc != GLX_OK) return rc;
   }
   if (d_ids) {
     int rc = glx_idmap_build(d_ids, V, &g->idmap, s);

@@ -227,6 +227,16 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
       if (circular) launch_slots<kSlotEdgeWeight>(a, s);
       else launch_slots<kSlotReplicate>(a, s);
       break;
+    case GLX_SAMPLER_IN_DEGREE: {
+      // in_degree_sampler.cc:79-92: the alias draw of EdgeWeightSampler over the
+      // neighbours' in-degrees (tables built once by glx_graph_enable_in_degree).
+      GLX_REQUIRE(g->alias_indeg != nullptr, "InDegreeSampler needs glx_graph_enable_in_degree()");
+      SampleArgs b = a;
+      b.alias = g->alias_indeg;
+      if (circular) launch_slots<kSlotEdgeWeight>(b, s);
+      else launch_slots<kSlotReplicate>(b, s);
+      break;
+    }
     case GLX_SAMPLER_TOPK:
       if (circular) launch_slots<kSlotCircular>(a, s);
       else launch_slots<kSlotReplicate>(a, s);

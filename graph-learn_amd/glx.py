@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GLX_LIB") or os.path.join(_HERE, "lib", "libglx.so")  # GLX_LIB: A/B builds
 
 PTR_HOST, PTR_DEVICE = 0, 1
-RANDOM, RANDOM_WITHOUT_REPLACEMENT, EDGE_WEIGHT, TOPK = 0, 1, 2, 3
+RANDOM, RANDOM_WITHOUT_REPLACEMENT, EDGE_WEIGHT, TOPK, IN_DEGREE = 0, 1, 2, 3, 4
 SUM, MEAN, MAX, MIN, PROD = 0, 1, 2, 3, 4
 PAD_REPLICATE, PAD_CIRCULAR = 0, 1
 
@@ -26,6 +26,8 @@ SAMPLER_IDS = {
     "EdgeWeightSampler": EDGE_WEIGHT,
     "TopkSampler": TOPK,
 }
+# further registry names served on the device
+EXTRA_SAMPLER_IDS = {"InDegreeSampler": IN_DEGREE}
 AGGREGATOR_IDS = {
     "SumAggregator": SUM,
     "MeanAggregator": MEAN,
@@ -38,6 +40,7 @@ EXPORTS = [
     "glx_abi_version", "glx_device_count", "glx_last_error",
     "glx_graph_create", "glx_graph_build", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
     "glx_graph_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
+    "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
     "glx_partition", "glx_stitch_i64", "glx_stitch_f32",
@@ -83,6 +86,9 @@ def lib():
         L.glx_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_sample_ex.argtypes = [vp, ci, vp, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_sample_hops.argtypes = [vp, i32, ci, vp, i32, vp, ci, i64, u64, u64, vp, vp, ci, vp]
+        L.glx_graph_enable_in_degree.argtypes = [vp, vp]
+        L.glx_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
+        L.glx_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, ci, vp]
         L.glx_features_view.argtypes = [ci, i64, i32, vp, ctypes.POINTER(vp)]
         L.glx_features_create.argtypes = [ci, i64, i32, vp, vp, ci, vp, ctypes.POINTER(vp)]
         L.glx_features_destroy.argtypes = [vp]
@@ -181,6 +187,37 @@ class Graph:
 
     __del__ = close
 
+    def enable_in_degree(self):
+        """Build the in-degree alias tables InDegreeSampler needs (once, on the device)."""
+        _check(lib().glx_graph_enable_in_degree(self._h, None))
+        return self
+
+    def sample_full(self, src, max_limit=0):
+        """FullSampler: -> (degrees[batch] int32, nbr[total], eid[total]) (sparse response)."""
+        batch = int(src.shape[0])
+        if _is_torch(src):
+            import torch
+            deg = torch.empty(batch, dtype=torch.int32, device=src.device)
+            off = torch.empty(batch + 1, dtype=torch.int64, device=src.device)
+            _check(lib().glx_sample_full_sizes(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0],
+                                               PTR_DEVICE, _stream(PTR_DEVICE)))
+            total = int(off[-1].item())
+            nbr = torch.empty(total, dtype=torch.int64, device=src.device)
+            eid = torch.empty(total, dtype=torch.int64, device=src.device)
+            _check(lib().glx_sample_full(self._h, _ptr(src)[0], batch, max_limit, _ptr(off)[0], _ptr(nbr)[0],
+                                         _ptr(eid)[0], PTR_DEVICE, _stream(PTR_DEVICE)))
+            return deg, nbr, eid
+        deg = np.empty(batch, np.int32)
+        off = np.empty(batch + 1, np.int64)
+        _check(lib().glx_sample_full_sizes(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0],
+                                           PTR_HOST, None))
+        total = int(off[-1])
+        nbr = np.empty(total, np.int64)
+        eid = np.empty(total, np.int64)
+        _check(lib().glx_sample_full(self._h, _ptr(src)[0], batch, max_limit, _ptr(off)[0], _ptr(nbr)[0],
+                                     _ptr(eid)[0], PTR_HOST, None))
+        return deg, nbr, eid
+
     def export_alias(self):
         prob = np.empty(self.num_edges, np.float32)
         alias = np.empty(self.num_edges, np.int32)
@@ -201,7 +238,7 @@ class Graph:
                default_neighbor_id=0, out=None, rng_rows=None):
         """-> (nbr[batch, k], eid[batch, k]) int64; numpy in -> numpy out, torch in -> torch out."""
         if isinstance(sampler, str):
-            sampler = SAMPLER_IDS[sampler]
+            sampler = SAMPLER_IDS[sampler] if sampler in SAMPLER_IDS else EXTRA_SAMPLER_IDS[sampler]
         batch = int(src.shape[0])
         if out is not None:
             nbr, eid = out

@@ -20,6 +20,11 @@ struct Shape {
   bool sparse;
   Shape() : dim1(0), dim2(0), size(0), sparse(false) {}
   Shape(size_t x, size_t y) : dim1(x), dim2(y), size(x * y), segments(x, (int32_t)y), sparse(false) {}
+  // sparse response (FullSampler): per-row counts (sampling_request.h:46-51)
+  Shape(size_t x, size_t y, const std::vector<int32_t>& inds)
+      : dim1(x), dim2(y), size(0), segments(inds), sparse(true) {
+    for (int32_t v : inds) size += (size_t)v;
+  }
 };
 
 class SamplingRequest : public OpRequest {
@@ -56,6 +61,7 @@ public:
   void Swap(OpResponse& right) override;
 
   void SetShape(size_t dim1, size_t dim2);
+  void SetShape(size_t dim1, size_t dim2, const std::vector<int32_t>& segments);  // sparse
   void InitNeighborIds();
   void InitEdgeIds();
   void AppendNeighborId(int64_t id);

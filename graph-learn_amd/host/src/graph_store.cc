@@ -50,6 +50,10 @@ Status Graph::Build(const IndexOption& option) {
   int rc = glx_graph_build(GLOBAL_FLAG(DeviceId), (int64_t)src_.size(), src_.data(), dst_.data(),
                            weighted ? weight_.data() : nullptr, nullptr,
                            (weighted && option.name == "sort") ? 1 : 0, GLX_PTR_HOST, nullptr, &dev_);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  // The reference keeps in/out-degree statistics by default (StorageMode bit 1,
+  // config.cc:93, topo_statics.cc); InDegreeSampler needs them as alias tables.
+  rc = glx_graph_enable_in_degree(dev_, nullptr);
   return error::FromGlx(rc);
 }
 

@@ -116,6 +116,13 @@ void SamplingResponse::SetShape(size_t dim1, size_t dim2) {
   shape_ = Shape(dim1, dim2);
 }
 
+void SamplingResponse::SetShape(size_t dim1, size_t dim2, const std::vector<int32_t>& segments) {
+  batch_size_ = (int32_t)dim1;
+  ADD_TENSOR(params_, kNeighborCount, kInt32, 1);
+  params_[kNeighborCount].AddInt32((int32_t)dim2);
+  shape_ = Shape(dim1, dim2, segments);
+}
+
 void SamplingResponse::InitNeighborIds() { ADD_TENSOR(tensors_, kNodeIds, kInt64, (int32_t)shape_.size); }
 void SamplingResponse::InitEdgeIds() { ADD_TENSOR(tensors_, kEdgeIds, kInt64, (int32_t)shape_.size); }
 void SamplingResponse::AppendNeighborId(int64_t id) { tensors_[kNodeIds].AddInt64(id); }
@@ -155,6 +162,8 @@ REGISTER_SAMPLING_REQUEST(Random)
 REGISTER_SAMPLING_REQUEST(RandomWithoutReplacement)
 REGISTER_SAMPLING_REQUEST(Topk)
 REGISTER_SAMPLING_REQUEST(EdgeWeight)
+REGISTER_SAMPLING_REQUEST(InDegree)
+REGISTER_SAMPLING_REQUEST(Full)
 #undef REGISTER_SAMPLING_REQUEST
 
 // ------------------------------------------------------------- aggregating --

@@ -5,6 +5,7 @@
 // response tensors in place.  No CPU sampling code exists in this layer: if the
 // GPU library fails, the Status says so.
 #include <atomic>
+#include <vector>
 
 #include "glx.h"
 #include "graphlearn/config.h"
@@ -72,11 +73,47 @@ class EdgeWeightSampler : public Sampler {
 class TopkSampler : public Sampler {
   int SamplerId() const override { return GLX_SAMPLER_TOPK; }
 };
+class InDegreeSampler : public Sampler {  // in_degree_sampler.cc:33-114
+  int SamplerId() const override { return GLX_SAMPLER_IN_DEGREE; }
+};
+
+// FullSampler (full_sampler.cc:28-97): sparse response = per-row counts + values.
+class FullSampler : public Operator {
+public:
+  Status Process(const OpRequest* req, OpResponse* res) override {
+    const SamplingRequest* request = static_cast<const SamplingRequest*>(req);
+    SamplingResponse* response = static_cast<SamplingResponse*>(res);
+    const int32_t batch_size = request->BatchSize();
+    const int32_t max_limit = request->NeighborCount();
+    if (request->HasFilter()) return error::Unimplemented("sampling filters are not supported on the device path");
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    const glx_graph* g = graph_store_->GetGraph(request->Type())->Device();
+    std::vector<int32_t> degrees(batch_size, 0);
+    std::vector<int64_t> offsets(batch_size + 1, 0);
+    if (g) {
+      int rc = glx_sample_full_sizes(g, request->GetSrcIds(), batch_size, max_limit, degrees.data(),
+                                     offsets.data(), GLX_PTR_HOST, nullptr);
+      if (rc != GLX_OK) return error::FromGlx(rc);
+    }
+    response->SetShape(batch_size, max_limit, degrees);
+    response->InitNeighborIds();
+    response->InitEdgeIds();
+    response->ResizeDense();  // sizes both tensors to shape.size (the sum of the counts)
+    if (g && offsets[batch_size] > 0) {
+      int rc = glx_sample_full(g, request->GetSrcIds(), batch_size, max_limit, offsets.data(),
+                               response->GetNeighborIds(), response->GetEdgeIds(), GLX_PTR_HOST, nullptr);
+      if (rc != GLX_OK) return error::FromGlx(rc);
+    }
+    return Status::OK();
+  }
+};
 
 REGISTER_OPERATOR("RandomSampler", RandomSampler)
 REGISTER_OPERATOR("RandomWithoutReplacementSampler", RandomWithoutReplacementSampler)
 REGISTER_OPERATOR("EdgeWeightSampler", EdgeWeightSampler)
 REGISTER_OPERATOR("TopkSampler", TopkSampler)
+REGISTER_OPERATOR("InDegreeSampler", InDegreeSampler)
+REGISTER_OPERATOR("FullSampler", FullSampler)
 
 }  // namespace op
 }  // namespace graphlearn

@@ -90,6 +90,36 @@ void CheckMembershipAndDefault(const char* strategy) {
 TEST(SamplerTest, Random) { CheckMembershipAndDefault("RandomSampler"); }
 TEST(SamplerTest, RandomWithoutReplacement) { CheckMembershipAndDefault("RandomWithoutReplacementSampler"); }
 TEST(SamplerTest, EdgeWeight) { CheckMembershipAndDefault("EdgeWeightSampler"); }
+TEST(SamplerTest, InDegree) { CheckMembershipAndDefault("InDegreeSampler"); }  // sampler_unittest.cpp:237-273
+
+TEST(SamplerTest, Full) {
+  // sampler_unittest.cpp:275-313: ids {0,1,2}, count 2 -> truncated to 2 per row,
+  // sparse shape; rows keep the storage (weight-descending) order.
+  SetUpStore();
+  SamplingRequest req("u-i", "FullSampler", 2);
+  SamplingResponse res;
+  int64_t ids[3] = {0, 1, 2};
+  req.Set(ids, 3);
+  Operator* op = OpFactory::GetInstance()->Create(req.Name());
+  EXPECT_TRUE(op != nullptr);
+  EXPECT_TRUE(op->Process(&req, &res).ok());
+  EXPECT_EQ(res.GetShape().dim1, (size_t)3);
+  EXPECT_EQ(res.GetShape().dim2, (size_t)2);
+  EXPECT_TRUE(res.GetShape().sparse);
+  EXPECT_EQ(res.GetShape().size, (size_t)4);
+  int32_t seg[3] = {2, 2, 0};
+  for (int i = 0; i < 3; ++i) EXPECT_EQ(res.GetShape().segments[i], seg[i]);
+  int64_t nbr[4] = {20, 10, 21, 11};
+  for (int i = 0; i < 4; ++i) EXPECT_EQ(res.GetNeighborIds()[i], nbr[i]);
+  // neighbor_count 0 = no limit
+  SamplingRequest req2("u-i", "FullSampler", 0);
+  SamplingResponse res2;
+  req2.Set(ids, 3);
+  EXPECT_TRUE(op->Process(&req2, &res2).ok());
+  EXPECT_EQ(res2.GetShape().size, (size_t)5);
+  int64_t all[5] = {20, 10, 30, 21, 11};
+  for (int i = 0; i < 5; ++i) EXPECT_EQ(res2.GetNeighborIds()[i], all[i]);
+}
 
 TEST(SamplerTest, Topk) {
   SetUpStore();

@@ -56,6 +56,8 @@ extern "C" {
 #define GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT 1 /* "RandomWithoutReplacementSampler" */
 #define GLX_SAMPLER_EDGE_WEIGHT 2                /* "EdgeWeightSampler" */
 #define GLX_SAMPLER_TOPK 3                       /* "TopkSampler" */
+#define GLX_SAMPLER_IN_DEGREE 4                  /* "InDegreeSampler" (in_degree_sampler.cc:117); needs
+                                                    glx_graph_enable_in_degree() */
 
 /* Aggregator ids ("SumAggregator" ... sum_aggregator.cc:36, mean_aggregator.cc:64,
  * max_aggregator.cc:43, min_aggregator.cc:43, prod_aggregator.cc:43). */
@@ -140,6 +142,29 @@ GLX_API int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int3
                int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
                void* stream);
+
+/* ---- further samplers of the registry -------------
+ * InDegreeSampler (in_degree_sampler.cc:33-114) is EdgeWeightSampler with the
+ * neighbour's in-degree inside this edge type as the weight (GraphStorage::
+ * GetInDegree, topo_statics.cc:33-69), rebuilt per row per request in the
+ * reference.  glx_graph_enable_in_degree counts the in-degrees and builds that
+ * second set of alias tables once, on the device; it MUTATES the handle: call it
+ * right after creation, before the handle is shared between threads. */
+GLX_API int glx_graph_enable_in_degree(glx_graph* g, void* stream);
+
+/* FullSampler (full_sampler.cc:28-97): every row returns its first
+ * min(max_limit, deg) neighbours in storage order (max_limit <= 0: all) as a
+ * sparse response -- SamplingResponse's segments + values (sampling_request.cc:
+ * 198-224).  Two calls, like the reference's two passes:
+ *   glx_sample_full_sizes  -> degrees_out[batch] (the segments) and
+ *                             offsets_out[batch+1] (exclusive prefix sum; the last
+ *                             entry is the total number of values);
+ *   glx_sample_full        -> nbr_out / eid_out[offsets[batch]], row i at offsets[i]. */
+GLX_API int glx_sample_full_sizes(const glx_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                          int32_t* degrees_out, int64_t* offsets_out, int ptr_kind, void* stream);
+GLX_API int glx_sample_full(const glx_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                    const int64_t* offsets, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+                    void* stream);
 
 /* Same as glx_sample, but request row i draws from the random stream of row
  * rng_rows[i] instead of row i (rng_rows == NULL: identical to glx_sample).  A

@@ -217,7 +217,8 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
                 int32_t batch, int32_t k,
                 int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                 uint64_t call_counter, int64_t* nbr_out, int64_t* eid_out) {
-  if (op < GLXO_RANDOM || op > GLXO_TOPK) return 3;
+  if (op < GLXO_RANDOM || op > GLXO_IN_DEGREE) return 3;
+  if (op == GLXO_IN_DEGREE && (!g->indeg_prob || !g->indeg_alias)) return 3;
   if (op == GLXO_EDGE_WEIGHT && !g_reference_cost_model && (!g->alias_prob || !g->alias_idx)) return 3;
   if (op == GLXO_EDGE_WEIGHT && g_reference_cost_model && !g->weight) return 3;
   idmap m;
@@ -272,14 +273,19 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
         pad_row(rn, re, deg, perm, deg, k, padding_mode, default_neighbor_id, nbr, eid);
         break;
       }
+      case GLXO_IN_DEGREE:
       case GLXO_EDGE_WEIGHT: {
         /* alias_method.cc:109-124: rand = float(U[0, deg-1)); idx = int(rand);
          * ret = probs[idx] <= rand - idx ? alias[idx] : idx. */
         const float* probs = g->alias_prob ? g->alias_prob + start : NULL;
         const int32_t* alias = g->alias_idx ? g->alias_idx + start : NULL;
+        if (op == GLXO_IN_DEGREE) {
+          probs = g->indeg_prob + start;
+          alias = g->indeg_alias + start;
+        }
         float* tmp_p = NULL;
         int32_t* tmp_a = NULL;
-        if (g_reference_cost_model) {
+        if (g_reference_cost_model && op == GLXO_EDGE_WEIGHT) {
           /* the reference's per-row, per-request AliasMethod(&edge_weights) */
           tmp_p = (float*)malloc(sizeof(float) * (size_t)deg);
           tmp_a = (int32_t*)malloc(sizeof(int32_t) * (size_t)deg * 3);
@@ -309,6 +315,46 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
   free(perm);
   if (g->ids) idmap_free(&m);
   return 0;
+}
+
+void glxo_in_degree_weights(const int64_t* col, int64_t E, float* w_out) {
+  /* distinct neighbour ids -> occurrence counts (TopoStatics::Add, topo_statics.cc:33-60) */
+  idmap m;
+  uint64_t cap = 16;
+  while (cap < (uint64_t)E * 2) cap <<= 1;
+  m.mask = cap - 1;
+  m.keys = (int64_t*)malloc(cap * sizeof(int64_t));
+  m.vals = (int64_t*)malloc(cap * sizeof(int64_t));
+  for (uint64_t i = 0; i < cap; ++i) m.vals[i] = -1;
+  for (int64_t e = 0; e < E; ++e) {
+    uint64_t h = mix64((uint64_t)col[e]) & m.mask;
+    while (m.vals[h] != -1 && m.keys[h] != col[e]) h = (h + 1) & m.mask;
+    if (m.vals[h] == -1) { m.keys[h] = col[e]; m.vals[h] = 0; }
+    m.vals[h]++;
+  }
+  for (int64_t e = 0; e < E; ++e) w_out[e] = (float)(int32_t)idmap_get(&m, col[e]);
+  idmap_free(&m);
+}
+
+int64_t glxo_sample_full(const glxo_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                         int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out, int64_t cap) {
+  idmap m;
+  if (g->ids) idmap_build(&m, g->ids, g->V);
+  int64_t total = 0;
+  for (int32_t i = 0; i < batch; ++i) {
+    int64_t row = row_of(g->ids, &m, g->V, src[i]);
+    int64_t start = row < 0 ? 0 : g->row_ptr[row];
+    int64_t deg = row < 0 ? 0 : g->row_ptr[row + 1] - start;
+    /* GetTruncatedSize, full_sampler.cc:89-96 */
+    int64_t take = (max_limit > 0 && max_limit < deg) ? max_limit : deg;
+    degrees_out[i] = (int32_t)take;
+    for (int64_t j = 0; j < take; ++j) {
+      if (total < cap) { nbr_out[total] = g->col[start + j]; eid_out[total] = g->eid[start + j]; }
+      ++total;
+    }
+  }
+  if (g->ids) idmap_free(&m);
+  return total;
 }
 
 /* ------------------------------------------------------------ aggregators -- */

@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-enum { GLXO_RANDOM = 0, GLXO_RANDOM_WITHOUT_REPLACEMENT = 1, GLXO_EDGE_WEIGHT = 2, GLXO_TOPK = 3 };
+enum { GLXO_RANDOM = 0, GLXO_RANDOM_WITHOUT_REPLACEMENT = 1, GLXO_EDGE_WEIGHT = 2, GLXO_TOPK = 3,
+       GLXO_IN_DEGREE = 4 };
 enum { GLXO_SUM = 0, GLXO_MEAN = 1, GLXO_MAX = 2, GLXO_MIN = 3, GLXO_PROD = 4 };
 enum { GLXO_PAD_REPLICATE = 0, GLXO_PAD_CIRCULAR = 1 };
 
@@ -43,11 +44,26 @@ typedef struct {
   const float* alias_prob; /* per CSR slot; from glxo_alias_build; may be NULL */
   const int32_t* alias_idx;
   const int64_t* ids;      /* may be NULL */
+  /* alias tables over float(in-degree of the neighbour) for InDegreeSampler
+   * (in_degree_sampler.cc:79-92); from glxo_in_degree_weights + glxo_alias_build */
+  const float* indeg_prob;
+  const int32_t* indeg_alias;
 } glxo_graph;
 
 /* Restates AliasMethod::Build (alias_method.cc:57-107) per CSR row. */
 void glxo_alias_build(const int64_t* row_ptr, const float* weight, int64_t V, float* prob_out,
                       int32_t* alias_out);
+
+/* In-degree of every slot's neighbour id inside this edge type, as float, i.e. the
+ * weights InDegreeSampler::SampleFrom gathers (in_degree_sampler.cc:79-92 via
+ * GraphStorage::GetInDegree, topo_statics.cc:33-69). */
+void glxo_in_degree_weights(const int64_t* col, int64_t E, float* w_out);
+
+/* Restates FullSampler::Sample (full_sampler.cc:28-97): row i yields its first
+ * min(limit, deg) neighbours in storage order (limit <= 0: all); degrees_out[batch];
+ * values appended to nbr_out / eid_out (capacity cap).  Returns the total count. */
+int64_t glxo_sample_full(const glxo_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                         int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out, int64_t cap);
 
 /* Restates MemoryAdjMatrix::Sort (memory_adj_matrix.cc:105-125): each row by
  * weight descending.  Ties keep insertion order (the reference's std::sort

@@ -206,6 +206,39 @@ int glref_aggregate(void* h, const char* node_type, const char* strategy, const 
   return 0;
 }
 
+// FullSampler (full_sampler.cc:28-97) answers with a sparse response: per-row
+// neighbour counts (Shape::segments) + concatenated values.  degrees_out[batch];
+// nbr_out / eid_out need capacity `cap`; returns the total or -(error code) - 1.
+int64_t glref_sample_full(void* h, const char* edge_type, const int64_t* src, int32_t batch,
+                          int32_t max_limit, int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out,
+                          int64_t cap) {
+  (void)h;
+  SamplingRequest req(edge_type, "FullSampler", max_limit);
+  SamplingResponse res;
+  req.Set(src, batch);
+  op::Operator* op = op::OpFactory::GetInstance()->Create(req.Name());
+  if (!op) return -2;
+  Status s = op->Process(&req, &res);
+  if (!s.ok()) return -static_cast<int64_t>(s.code()) - 1;
+  const Shape shape = res.GetShape();
+  int64_t total = 0;
+  for (int32_t i = 0; i < batch; ++i) {
+    degrees_out[i] = shape.segments[i];
+    total += shape.segments[i];
+  }
+  for (int64_t i = 0; i < total && i < cap; ++i) {
+    nbr_out[i] = res.GetNeighborIds()[i];
+    eid_out[i] = res.GetEdgeIds()[i];
+  }
+  return total;
+}
+
+// GraphStorage::GetInDegree (memory_topo_storage.cc:103-109, topo_statics.cc:62-69).
+int32_t glref_in_degree(void* h, const char* edge_type, int64_t dst_id) {
+  Ref* r = static_cast<Ref*>(h);
+  return r->store->GetGraph(edge_type)->GetLocalStorage()->GetInDegree(dst_id);
+}
+
 // The reference's own AliasMethod::Build (alias_method.cc:57-107) on one
 // weight vector; copies its private tables out.
 void glref_alias_build(const float* w, int32_t n, float* probs_out, int32_t* alias_out) {

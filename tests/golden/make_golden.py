@@ -121,6 +121,22 @@ def gen_rand_graph(ref):
         n, e = ref.sample("rnd", "RandomWithoutReplacementSampler", q, k)
         out["rwor_p0_k%d_nbr" % k] = n
         out["rwor_p0_k%d_eid" % k] = e
+    # FullSampler (sparse response) and the in-degree weights / alias tables InDegreeSampler uses
+    ref.set_flags(1, -7, 0.0)
+    for lim in (0, 3, 33):
+        d, n, e = ref.sample_full("rnd", q, lim)
+        out["full_l%d_deg" % lim] = d
+        out["full_l%d_nbr" % lim] = n
+        out["full_l%d_eid" % lim] = e
+    indeg = ref.in_degree("rnd", col).astype(np.float32)
+    ip = np.zeros(E, np.float32)
+    ia = np.zeros(E, np.int32)
+    for r in range(rows.shape[0]):
+        a, b = rp[r], rp[r + 1]
+        ip[a:b], ia[a:b] = ref_alias(ref, indeg[a:b].copy())
+    out["indeg_w"] = indeg
+    out["indeg_alias_prob"] = ip
+    out["indeg_alias_idx"] = ia
     np.savez_compressed(os.path.join(HERE, "rand_graph.npz"), **out)
 
 
@@ -164,6 +180,44 @@ def gen_dist(ref):
             out["%s_k%d_pair" % (name, k)] = pair
     out["T"] = np.array(T)
     np.savez_compressed(os.path.join(HERE, "dist.npz"), **out)
+
+
+def gen_dist_indegree(ref):
+    """InDegreeSampler distribution: neighbours with repeated destination ids so that
+    in-degrees differ (weights = in-degree of the neighbour, in_degree_sampler.cc:79-92)."""
+    rng = np.random.default_rng(6)
+    degs = [1, 2, 4, 7, 12]
+    pool = np.arange(500, 512, dtype=np.int64)
+    src, dst = [], []
+    for r, d in enumerate(degs):
+        src += [r] * d
+        dst += rng.choice(pool, d, replace=False).tolist()
+    # extra edges from other sources to skew the in-degrees of the pool
+    extra = rng.choice(pool, 60, p=np.arange(1, 13) / 78.0)
+    src += list(range(100, 160))
+    dst += extra.tolist()
+    src = np.array(src, np.int64)
+    dst = np.array(dst, np.int64)
+    ref.add_edges("indeg", src, dst)
+    rows = first_appearance(src)  # ALL rows: in-degrees count every edge of the type
+    rp, col, eid, _ = ref.export_csr("indeg", rows, max(degs))
+    out = dict(src=src, dst=dst, rows=rows, row_ptr=rp, col=col, eid=eid, degs=np.array(degs, np.int64),
+               indeg_w=ref.in_degree("indeg", col).astype(np.float32))
+    T = 40000
+    ref.set_flags(1, 0, 0.0)
+    ref.set_seed(777)
+    k = 4
+    _, e = ref.sample("indeg", "InDegreeSampler", np.tile(rows[:len(degs)], T), k, fresh_thread=True)
+    e = e.reshape(T, len(degs), k)
+    hist = np.zeros((len(degs), k, max(degs)), np.int64)
+    for r, d in enumerate(degs):
+        pos_of = {int(x): i for i, x in enumerate(eid[rp[r]:rp[r + 1]])}
+        pos = np.vectorize(pos_of.get)(e[:, r, :])
+        for j in range(k):
+            hist[r, j, :d] = np.bincount(pos[:, j], minlength=d)
+    out["hist"] = hist
+    out["T"] = np.array(T)
+    np.savez_compressed(os.path.join(HERE, "dist_indegree.npz"), **out)
 
 
 def gen_agg(ref):
@@ -224,6 +278,7 @@ def main():
     gen_pyfixture(ref)
     gen_rand_graph(ref)
     gen_dist(ref)
+    gen_dist_indegree(ref)
     gen_agg(ref)
     # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()

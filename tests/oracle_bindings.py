@@ -19,6 +19,7 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libglref.so")
 
 VP = ctypes.c_void_p
 SAMPLERS = ["RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"]
+ALL_SAMPLERS = SAMPLERS + ["InDegreeSampler"]  # ids of the C-ABI / oracle, in order
 AGGREGATORS = ["SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"]
 
 
@@ -28,7 +29,8 @@ def _p(a):
 
 class _CGraph(ctypes.Structure):
     _fields_ = [("V", ctypes.c_int64), ("E", ctypes.c_int64), ("row_ptr", VP), ("col", VP), ("eid", VP),
-                ("weight", VP), ("alias_prob", VP), ("alias_idx", VP), ("ids", VP)]
+                ("weight", VP), ("alias_prob", VP), ("alias_idx", VP), ("ids", VP), ("indeg_prob", VP),
+                ("indeg_alias", VP)]
 
 
 class Oracle:
@@ -43,6 +45,9 @@ class Oracle:
         L.glxo_sample.argtypes = [ctypes.POINTER(_CGraph), ctypes.c_int, VP, VP, i32, i32, ctypes.c_int, i64, u64,
                                   u64, VP, VP]
         L.glxo_aggregate.argtypes = [VP, i64, i32, VP, ctypes.c_int, VP, VP, i32, i32, ctypes.c_float, VP, VP]
+        L.glxo_in_degree_weights.argtypes = [VP, i64, VP]
+        L.glxo_sample_full.argtypes = [ctypes.POINTER(_CGraph), VP, i32, i32, VP, VP, VP, i64]
+        L.glxo_sample_full.restype = i64
         L.glxo_partition.argtypes = [VP, i64, i32, VP, VP]
         L.glxo_stitch_i64.argtypes = [VP, VP, i64, i32, VP]
         L.glxo_set_reference_cost_model.argtypes = [ctypes.c_int]
@@ -73,11 +78,8 @@ class Oracle:
                rng_rows=None):
         """g: dict(row_ptr, col, eid, weight=None, alias=(prob, idx)|None, ids=None)."""
         if isinstance(sampler, str):
-            sampler = SAMPLERS.index(sampler)
-        alias = g.get("alias")
-        cg = _CGraph(g["row_ptr"].shape[0] - 1, g["col"].shape[0], _p(g["row_ptr"]), _p(g["col"]), _p(g["eid"]),
-                     _p(g.get("weight")), _p(alias[0]) if alias else None, _p(alias[1]) if alias else None,
-                     _p(g.get("ids")))
+            sampler = ALL_SAMPLERS.index(sampler)
+        cg = self._cgraph(g)
         batch = src.shape[0]
         nbr = np.zeros((batch, k), np.int64)
         eid = np.zeros((batch, k), np.int64)
@@ -85,6 +87,29 @@ class Oracle:
                                 seed, call_counter, _p(nbr), _p(eid))
         assert rc == 0, rc
         return nbr, eid
+
+    def _cgraph(self, g):
+        alias = g.get("alias")
+        ind = g.get("indeg_alias")
+        return _CGraph(g["row_ptr"].shape[0] - 1, g["col"].shape[0], _p(g["row_ptr"]), _p(g["col"]), _p(g["eid"]),
+                       _p(g.get("weight")), _p(alias[0]) if alias else None, _p(alias[1]) if alias else None,
+                       _p(g.get("ids")), _p(ind[0]) if ind else None, _p(ind[1]) if ind else None)
+
+    def in_degree_alias(self, g):
+        """alias tables over float(in-degree of each slot's neighbour) (InDegreeSampler)."""
+        w = np.zeros(g["col"].shape[0], np.float32)
+        self.L.glxo_in_degree_weights(_p(g["col"]), g["col"].shape[0], _p(w))
+        return self.alias_build(g["row_ptr"], w), w
+
+    def sample_full(self, g, src, max_limit):
+        cg = self._cgraph(g)
+        batch = src.shape[0]
+        deg = np.zeros(batch, np.int32)
+        total = self.L.glxo_sample_full(ctypes.byref(cg), _p(src), batch, max_limit, _p(deg), None, None, 0)
+        nbr = np.zeros(total, np.int64)
+        eid = np.zeros(total, np.int64)
+        self.L.glxo_sample_full(ctypes.byref(cg), _p(src), batch, max_limit, _p(deg), _p(nbr), _p(eid), total)
+        return deg, nbr, eid
 
     def aggregate(self, X, op, node_ids, segment_ids, num_segments, default_attr=0.0, ids=None):
         if isinstance(op, str):
@@ -137,6 +162,11 @@ class RefLib:
         L.glref_edge_weight.restype = ctypes.c_float
         L.glref_sample.argtypes = [VP, cs, cs, VP, i32, i32, VP, VP, ctypes.c_int]
         L.glref_aggregate.argtypes = [VP, cs, cs, VP, VP, i32, i32, VP, VP, VP]
+        L.glref_sample_full.argtypes = [VP, cs, VP, i32, i32, VP, VP, VP, i64]
+        L.glref_sample_full.restype = i64
+        L.glref_in_degree.argtypes = [VP, cs, i64]
+        L.glref_in_degree.restype = i32
+        L.glref_alias_build.argtypes = [VP, i32, VP, VP]
         L.glref_time_sample_2hop.argtypes = [VP, cs, cs, VP, i32, i32, i32, i32, i32, VP]
         L.glref_time_sample_2hop.restype = ctypes.c_double
         L.glref_time_aggregate.argtypes = [VP, cs, cs, VP, i32, i32, i32, i32, VP]
@@ -188,6 +218,24 @@ class RefLib:
                                  1 if fresh_thread else 0)
         assert rc == 0, rc
         return nbr, eid
+
+    def sample_full(self, etype, src, max_limit, cap=1 << 22):
+        deg = np.zeros(src.shape[0], np.int32)
+        nbr = np.zeros(cap, np.int64)
+        eid = np.zeros(cap, np.int64)
+        total = self.L.glref_sample_full(self.h, etype.encode(), _p(src), src.shape[0], max_limit, _p(deg), _p(nbr),
+                                         _p(eid), cap)
+        assert 0 <= total <= cap, total
+        return deg, nbr[:total].copy(), eid[:total].copy()
+
+    def in_degree(self, etype, ids):
+        return np.array([self.L.glref_in_degree(self.h, etype.encode(), int(v)) for v in ids], np.int32)
+
+    def alias_build(self, w):
+        p = np.zeros(w.shape[0], np.float32)
+        a = np.zeros(w.shape[0], np.int32)
+        self.L.glref_alias_build(_p(w), w.shape[0], _p(p), _p(a))
+        return p, a
 
     def aggregate(self, ntype, strategy, node_ids, segment_ids, num_segments, dim):
         emb = np.zeros((num_segments, dim), np.float32)

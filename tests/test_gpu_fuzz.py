@@ -36,17 +36,22 @@ def test_fuzz_samplers(seed, V, maxdeg, k, pad, hashed, nq, rng_seed, cc):
     w = (rng.integers(1, 50, E) / 50.0).astype(np.float32)
     col, eid, w = ORC.sort_rows(rp, col, eid, w)
     og = dict(row_ptr=rp, col=col, eid=eid, weight=w, alias=ORC.alias_build(rp, w), ids=raw)
-    dev = glx.Graph(rp, col, eid, w, ids=raw)
+    og["indeg_alias"], _ = ORC.in_degree_alias(og)
+    dev = glx.Graph(rp, col, eid, w, ids=raw).enable_in_degree()
     prob, alias = dev.export_alias()
     assert beq(prob, og["alias"][0]) and np.array_equal(alias, og["alias"][1])
     q = np.concatenate([pool[rng.integers(0, V, nq)], rng.integers(-5, V * 3 + 5, 3)]).astype(np.int64)
     rows = rng.integers(0, 1 << 20, q.shape[0]).astype(np.int64) if seed % 3 == 0 else None
-    for name in SAMPLERS:
+    for name in SAMPLERS + ["InDegreeSampler"]:
         n, e = dev.sample(name, q, k, seed=rng_seed, call_counter=cc, padding_mode=pad, default_neighbor_id=-11,
                           rng_rows=rows)
         on, oe = ORC.sample(og, name, q, k, seed=rng_seed, call_counter=cc, padding_mode=pad,
                             default_neighbor_id=-11, rng_rows=rows)
         assert np.array_equal(n, on) and np.array_equal(e, oe), (name, k, pad)
+    lim = int(seed % 5)
+    d, n, e = dev.sample_full(q, lim)
+    od, on, oe = ORC.sample_full(og, q, lim)
+    assert np.array_equal(d, od) and np.array_equal(n, on) and np.array_equal(e, oe)
 
 
 @settings(**COMMON)

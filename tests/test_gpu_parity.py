@@ -418,3 +418,71 @@ def test_partition_stitch_reference_unittest_layout():
     rows = torch.stack([bucketed * 100 + j for j in range(6)], 1).contiguous()
     out = glx.stitch(rows, order)
     assert out.tolist() == [[i * 100 + j for j in range(6)] for i in (1, 2, 3, 4)]
+
+
+# -------------------------------------------- next rows: Full / InDegree samplers ---
+def test_full_sampler_golden_and_oracle(orc, graphs):
+    """FullSampler (full_sampler.cc:28-97) vs the reference's own outputs and the oracle."""
+    import torch
+    g = load("rand_graph.npz")
+    dev = glx.Graph(g["row_ptr"], g["col"], g["eid"], g["w_slot"], ids=g["rows"])
+    for lim in (0, 3, 33):
+        d, n, e = dev.sample_full(g["query"], lim)
+        assert np.array_equal(d, g["full_l%d_deg" % lim])
+        assert np.array_equal(n, g["full_l%d_nbr" % lim]) and np.array_equal(e, g["full_l%d_eid" % lim])
+    og, dev2 = graphs["dense"]
+    q = np.concatenate([np.random.default_rng(3).integers(0, 3000, 500), [0, -1, 3000]]).astype(np.int64)
+    for lim in (0, 1, 7, 100000):
+        d, n, e = dev2.sample_full(q, lim)
+        od, on, oe = orc.sample_full(og, q, lim)
+        assert np.array_equal(d, od) and np.array_equal(n, on) and np.array_equal(e, oe), lim
+        td, tn, te = dev2.sample_full(torch.from_numpy(q).cuda(), lim)
+        assert np.array_equal(td.cpu().numpy(), od) and np.array_equal(tn.cpu().numpy(), on)
+    d, n, e = dev2.sample_full(np.zeros(0, np.int64), 5)
+    assert d.shape == (0,) and n.shape == (0,)
+
+
+def test_in_degree_sampler_tables_and_parity(orc, graphs):
+    """InDegreeSampler: device in-degree alias tables == the reference's (golden), samples == oracle."""
+    g = load("rand_graph.npz")
+    dev = glx.Graph(g["row_ptr"], g["col"], g["eid"], g["w_slot"], ids=g["rows"])
+    with pytest.raises(glx.GlxError):
+        dev.sample("InDegreeSampler", g["query"], 3)  # tables not enabled yet
+    dev.enable_in_degree()
+    og = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], ids=g["rows"],
+              indeg_alias=(g["indeg_alias_prob"], g["indeg_alias_idx"]))  # the REFERENCE's tables
+    for pad in (1, 0):
+        for k in (1, 4, 33):
+            n, e = dev.sample("InDegreeSampler", g["query"], k, seed=21, call_counter=k, padding_mode=pad,
+                              default_neighbor_id=-7)
+            on, oe = orc.sample(og, "InDegreeSampler", g["query"], k, seed=21, call_counter=k, padding_mode=pad,
+                                default_neighbor_id=-7)
+            assert np.array_equal(n, on) and np.array_equal(e, oe), (pad, k)
+    # larger graph with hubs, unweighted + device-built
+    ogd, _ = graphs["dense"]
+    big = glx.Graph(ogd["row_ptr"], ogd["col"], ogd["eid"]).enable_in_degree()
+    o2 = dict(row_ptr=ogd["row_ptr"], col=ogd["col"], eid=ogd["eid"])
+    o2["indeg_alias"], _ = orc.in_degree_alias(o2)
+    q = np.arange(3000, dtype=np.int64)
+    n, e = big.sample("InDegreeSampler", q, 10, seed=2, call_counter=5)
+    on, oe = orc.sample(o2, "InDegreeSampler", q, 10, seed=2, call_counter=5)
+    assert np.array_equal(n, on) and np.array_equal(e, oe)
+
+
+def test_in_degree_sampler_matches_reference_distribution(orc):
+    from scipy import stats
+    g = load("dist_indegree.npz")
+    dev = glx.Graph(g["row_ptr"], g["col"], g["eid"], ids=g["rows"]).enable_in_degree()
+    T, degs, k = int(g["T"]), g["degs"], 4
+    _, eid = dev.sample("InDegreeSampler", np.tile(g["rows"][:len(degs)], T), k, seed=77, call_counter=3)
+    eid = eid.reshape(T, len(degs), k)
+    rp = g["row_ptr"]
+    for r, d in enumerate(degs):
+        pos_of = {int(x): i for i, x in enumerate(g["eid"][rp[r]:rp[r + 1]])}
+        pos = np.vectorize(pos_of.get)(eid[:, r, :])
+        for j in range(k):
+            a = np.bincount(pos[:, j], minlength=d).astype(float)
+            b = g["hist"][r, j, :d].astype(float)
+            keep = (a + b) > 0
+            if keep.sum() >= 2:
+                assert stats.chi2_contingency(np.stack([a[keep], b[keep]]))[1] > 1e-4, (r, j)

@@ -324,3 +324,39 @@ def test_alias_method_unittest_membership(orc):
              alias=orc.alias_build(rp, w))
     nbr, _ = orc.sample(g, "EdgeWeightSampler", np.zeros(1000, np.int64), 10, seed=3)
     assert set(np.unique(nbr).tolist()) <= {0, 1, 2}
+
+
+# ------------------------------------------------ next rows: Full / InDegree samplers ---
+def test_full_sampler_golden(orc):
+    """FullSampler (full_sampler.cc:28-97): sparse response, truncated at neighbor_count."""
+    g = load("rand_graph.npz")
+    og = graph_of(g)
+    for lim in (0, 3, 33):
+        d, n, e = orc.sample_full(og, g["query"], lim)
+        assert np.array_equal(d, g["full_l%d_deg" % lim])
+        assert np.array_equal(n, g["full_l%d_nbr" % lim]) and np.array_equal(e, g["full_l%d_eid" % lim])
+
+
+def test_in_degree_tables_golden(orc):
+    """InDegreeSampler's per-row weights (GetInDegree) and alias tables, vs the reference's own."""
+    g = load("rand_graph.npz")
+    og = graph_of(g)
+    (ip, ia), w = orc.in_degree_alias(og)
+    assert np.array_equal(w, g["indeg_w"])
+    assert beq(ip, g["indeg_alias_prob"]) and np.array_equal(ia, g["indeg_alias_idx"])
+
+
+def test_in_degree_sampler_distribution(orc):
+    g = load("dist_indegree.npz")
+    og = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], ids=g["rows"])
+    (ip, ia), w = orc.in_degree_alias(og)
+    assert np.array_equal(w, g["indeg_w"])
+    og["indeg_alias"] = (ip, ia)
+    T, degs, k = int(g["T"]), g["degs"], 4
+    _, eid = orc.sample(og, "InDegreeSampler", np.tile(g["rows"][:len(degs)], T), k, seed=5, call_counter=8)
+    eid = eid.reshape(T, len(degs), k)
+    for r, d in enumerate(degs):
+        pos = _positions(g, eid[:, r, :], r)
+        for j in range(k):
+            p = _two_sample_p(np.bincount(pos[:, j], minlength=d), g["hist"][r, j, :d])
+            assert p > 1e-4, (r, j, p)
