@@ -309,11 +309,11 @@ def main():
     torch.cuda.synchronize()
     log("edge list generated in %.1fs" % (time.time() - t0))
 
-    cpu = None
+    # The CPU baseline runs AFTER the timed GPU region (an idle GPU clocks down during
+    # 1-2 minutes of host work); keep host copies of the edge list for it.
+    host_edges = None
     if args.cpu_baseline == "on" and world == 1:
-        t1 = time.time()
-        cpu = cpu_baseline(wl, src, dst, weight, args)
-        log("cpu baseline done in %.1fs: %s" % (time.time() - t1, cpu and "%.3g edges/s" % cpu["value"]))
+        host_edges = (src.cpu(), dst.cpu(), weight.cpu() if weight is not None else None)
 
     # Storage build on the device (glx_graph_build: radix sorts + RLE + scan + alias
     # tables + id map); rows end up weight-descending like the reference's Build().
@@ -443,6 +443,12 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    cpu = None
+    if host_edges is not None:
+        t1 = time.time()
+        cpu = cpu_baseline(wl, host_edges[0], host_edges[1], host_edges[2], args)
+        log("cpu baseline done in %.1fs: %s" % (time.time() - t1, cpu and "%.3g edges/s" % cpu["value"]))
 
     edges_per_step = n1 + n2  # response slots, padding included
     value = world * edges_per_step * args.steps / elapsed
