@@ -19,6 +19,14 @@ enum DataType { kInt32, kInt64, kFloat, kDouble, kString, kUnknown };
 #define ADD_TENSOR(m, name, type, size) \
   m.emplace(std::piecewise_construct, std::forward_as_tuple(name), std::forward_as_tuple(type, size))
 
+// One block of typed accessors per element type; the method names are the
+// reference's (AddInt32 / SetInt32 / GetInt32(i) / GetInt32() ...).
+#define GLX_TENSOR_TYPED_API(Name, T)                     \
+  void Add##Name(T v);                                    \
+  void Add##Name(const T* begin, const T* end);           \
+  T Get##Name(int32_t index) const;                       \
+  const T* Get##Name() const;
+
 class Tensor {
 public:
   Tensor();
@@ -28,38 +36,25 @@ public:
   DataType DType() const;
   int32_t Size() const;
   void Resize(int32_t size);
+  void Swap(Tensor& right);
 
-  void AddInt32(int32_t v);
-  void AddInt64(int64_t v);
-  void AddFloat(float v);
-  void AddDouble(double v);
+  GLX_TENSOR_TYPED_API(Int32, int32_t)
+  GLX_TENSOR_TYPED_API(Int64, int64_t)
+  GLX_TENSOR_TYPED_API(Float, float)
+  GLX_TENSOR_TYPED_API(Double, double)
+
   void AddString(const std::string& v);
-  void AddInt32(const int32_t* begin, const int32_t* end);
-  void AddInt64(const int64_t* begin, const int64_t* end);
-  void AddFloat(const float* begin, const float* end);
-  void AddDouble(const double* begin, const double* end);
+  const std::string& GetString(int32_t index) const;
 
   void SetInt32(int32_t index, int32_t v);
   void SetInt64(int32_t index, int64_t v);
   void SetFloat(int32_t index, float v);
 
-  int32_t GetInt32(int32_t index) const;
-  int64_t GetInt64(int32_t index) const;
-  float GetFloat(int32_t index) const;
-  double GetDouble(int32_t index) const;
-  const std::string& GetString(int32_t index) const;
-
-  const int32_t* GetInt32() const;
-  const int64_t* GetInt64() const;
-  const float* GetFloat() const;
-  const double* GetDouble() const;
-
-  // Device-path additions: bulk-writable views (valid after Resize()).
+  // Device-path additions: bulk-writable views (valid after Resize()), so a whole
+  // response is one copy out of HBM instead of batch*k Add calls.
   int32_t* MutableInt32();
   int64_t* MutableInt64();
   float* MutableFloat();
-
-  void Swap(Tensor& right);
 
   typedef std::unordered_map<std::string, Tensor> Map;
 
@@ -67,6 +62,8 @@ private:
   struct Impl;
   std::shared_ptr<Impl> impl_;
 };
+
+#undef GLX_TENSOR_TYPED_API
 
 }  // namespace graphlearn
 #endif  // GLX_HOST_TENSOR_H_
