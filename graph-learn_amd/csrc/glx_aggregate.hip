@@ -349,7 +349,7 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
   GLX_REQUIRE(emb_out && cnt_out && (num_ids == 0 || (node_ids && segment_ids)), "NULL data pointer");
   GlxDeviceGuard guard(f->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", f->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, f->device) : glx_stream(stream);
   if (ptr_kind == GLX_PTR_DEVICE) {
     return aggregate_device(f, op, node_ids, segment_ids, num_ids, num_segments, default_attr,
                             emb_out, cnt_out, s);
@@ -392,7 +392,7 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
   GLX_REQUIRE(node_ids && out, "NULL data pointer");
   GlxDeviceGuard guard(f->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", f->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, f->device) : glx_stream(stream);
   int G = 1;
   const int want = (f->dim & 3) == 0 ? f->dim / 4 : f->dim;
   while (G < 64 && G < want) G <<= 1;

@@ -200,4 +200,14 @@ void glx_graph_free(glx_graph* g);
 
 static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Host-pointer calls are synchronous.  When the caller passes no stream they run on
+// a per-(host thread, device) non-blocking stream instead of the null stream, so the
+// reference's pool threads (up to 32 concurrent Process() calls on one operator,
+// in_memory_service.cc:64-71) overlap their copies and kernels instead of
+// serialising on -- and synchronising with -- each other.
+hipStream_t glx_thread_stream(int device);
+static inline hipStream_t glx_host_call_stream(void* s, int device) {
+  return s ? reinterpret_cast<hipStream_t>(s) : glx_thread_stream(device);
+}
+
 #endif  // GLX_COMMON_H_

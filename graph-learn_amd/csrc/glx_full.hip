@@ -158,7 +158,7 @@ extern "C" int glx_sample_full_sizes(const glx_graph* g, const int64_t* src, int
   GLX_REQUIRE(offsets_out != nullptr && (batch == 0 || (src && degrees_out)), "NULL data pointer");
   GlxDeviceGuard guard(g->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
   if (batch == 0) {
     if (ptr_kind == GLX_PTR_HOST) offsets_out[0] = 0;
     else glx_set_i64_kernel<<<1, 1, 0, s>>>(offsets_out, 0);
@@ -192,7 +192,7 @@ extern "C" int glx_sample_full(const glx_graph* g, const int64_t* src, int32_t b
   GLX_REQUIRE(src && offsets, "NULL data pointer");
   GlxDeviceGuard guard(g->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
   const unsigned blocks = (unsigned)(((int64_t)batch * 64 + 255) / 256);
   if (ptr_kind == GLX_PTR_DEVICE) {
     GLX_REQUIRE(nbr_out && eid_out, "NULL output pointer");

@@ -127,6 +127,33 @@ void glx_scratch_free(void* p, hipStream_t s) {
   (void)s;  // workspaces are cached per thread/stream; nothing to release per call
 }
 
+// ------------------------------------------------------- per-thread streams --
+namespace {
+struct ThreadStreams {
+  hipStream_t s[64] = {nullptr};
+  ~ThreadStreams() {
+    for (int d = 0; d < 64; ++d) {
+      if (s[d] && hipSetDevice(d) == hipSuccess) (void)hipStreamDestroy(s[d]);
+    }
+    (void)hipGetLastError();
+  }
+};
+thread_local ThreadStreams g_thread_streams;
+}  // namespace
+
+hipStream_t glx_thread_stream(int device) {
+  if (device < 0 || device >= 64) return nullptr;
+  hipStream_t& st = g_thread_streams.s[device];
+  if (!st) {
+    // the caller holds a GlxDeviceGuard for `device`
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      st = nullptr;  // fall back to the null stream
+    }
+  }
+  return st;
+}
+
 // ---------------------------------------------------------------- profiling --
 namespace {
 struct TimedLaunch {
@@ -489,7 +516,7 @@ extern "C" int glx_graph_export_alias(const glx_graph* g, float* prob, int32_t* 
   GLX_REQUIRE(g && prob && alias, "NULL argument");
   GLX_REQUIRE(g->alias != nullptr, "graph has no weights, hence no alias table");
   GlxDeviceGuard guard(g->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
   const int64_t E = g->num_edges;
   if (E == 0) return GLX_OK;
   if (ptr_kind == GLX_PTR_DEVICE) {
@@ -516,7 +543,7 @@ extern "C" int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t
   GLX_REQUIRE(n >= 0, "negative n");
   if (n == 0) return GLX_OK;
   GlxDeviceGuard guard(g->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
   if (ptr_kind == GLX_PTR_DEVICE) {
     glx_degrees_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->map(), g->row_ptr, src, n,
                                                                    deg_out);

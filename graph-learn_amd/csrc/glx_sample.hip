@@ -284,7 +284,7 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
   GLX_REQUIRE(src && nbr_out && eid_out, "NULL data pointer");
   GlxDeviceGuard guard(g->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
 
   SampleArgs a;
   a.map = g->map();
@@ -374,7 +374,7 @@ extern "C" int glx_sample_hops(const glx_graph* const* graphs, int32_t num_hops,
   // hop's device buffer, one download per hop output.
   GlxDeviceGuard guard(graphs[0]->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", graphs[0]->device);
-  hipStream_t s = glx_stream(stream);
+  hipStream_t s = glx_host_call_stream(stream, graphs[0]->device);
   size_t total = (size_t)batch;
   {
     int64_t n = batch;

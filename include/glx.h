@@ -14,7 +14,9 @@
  *     host memory) or device pointers on the handle's GPU (GLX_PTR_DEVICE: the
  *     call only enqueues work on `stream` and returns; the caller orders later
  *     use on that stream).
- *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - `stream` is a hipStream_t passed as void*.  NULL means the null stream for
+ *     device-pointer calls; host-pointer calls with NULL run on a private
+ *     per-(host thread, device) stream so that concurrent callers overlap.
  *   - handles are immutable after creation and may be used concurrently from
  *     any number of host threads (the reference calls Process() from up to 32
  *     pool threads on one operator instance: in_memory_service.cc:64-71).
