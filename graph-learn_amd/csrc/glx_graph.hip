@@ -181,6 +181,7 @@ hipEvent_t prof_event() {
 
 GlxKernelTimer::GlxKernelTimer(int kind, hipStream_t stream) : s(stream) {
   if (!g_prof.on) return;
+  if (g_prof.launches.size() >= (1u << 20)) return;  // never collected: stop recording
   TimedLaunch t{kind, prof_event(), prof_event()};
   if (!t.start || !t.stop) return;
   if (hipEventRecord(t.start, s) != hipSuccess) return;

@@ -182,7 +182,10 @@ class Graph:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().glx_graph_destroy(self._h)
+            try:
+                lib().glx_graph_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
             self._h = None
 
     __del__ = close
@@ -282,7 +285,10 @@ class Features:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().glx_features_destroy(self._h)
+            try:
+                lib().glx_features_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
             self._h = None
 
     __del__ = close
