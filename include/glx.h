@@ -216,7 +216,9 @@ GLX_API int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t*
  * cnt_out[num_segments].  Unknown ids contribute a row of `default_attr`;
  * empty segments are `default_attr` (GLOBAL_FLAG(DefaultFloatAttribute)).
  * Each output element is accumulated in the reference's left-to-right order,
- * so results are bit-identical to the reference for every op. */
+ * so results are bit-identical to the reference for every op.  Device-pointer
+ * callers get the float4 path when dim % 4 == 0 and emb_out (and a view's X) are
+ * 16-byte aligned; any other alignment silently takes the scalar path. */
 GLX_API int glx_aggregate(const glx_features* f, int op, const int64_t* node_ids,
                   const int32_t* segment_ids, int32_t num_ids, int32_t num_segments,
                   float default_attr, float* emb_out, int32_t* cnt_out, int ptr_kind,
