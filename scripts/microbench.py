@@ -9,6 +9,9 @@ dev = torch.device("cuda", 0)
 def run(tag, V, E, D, fan, B0=65536, reps=10):
     row_ptr, col, eid, w = synth.rmat_graph_torch(V, E, 4, dev, weighted=True)
     g = glx.Graph(row_ptr, col, eid, w)
+    import time as _t
+    t0 = _t.time(); g.enable_in_degree(); torch.cuda.synchronize()
+    print(json.dumps({"graph": tag, "op": "glx_graph_enable_in_degree (one-time)", "seconds": _t.time() - t0}))
     del row_ptr, col, eid, w
     X = synth.features_torch(V, D, 5, dev)
     f = glx.Features(X); del X
@@ -17,7 +20,7 @@ def run(tag, V, E, D, fan, B0=65536, reps=10):
     seeds = torch.randint(0, V, (B0,), generator=gen, device=dev)
     n1 = torch.empty((B0, k1), dtype=torch.int64, device=dev); e1 = torch.empty_like(n1)
     n2 = torch.empty((B0 * k1, k2), dtype=torch.int64, device=dev); e2 = torch.empty_like(n2)
-    for name in glx.SAMPLER_IDS:
+    for name in list(glx.SAMPLER_IDS) + ["InDegreeSampler"]:
         for pad in (1,):
             g.sample(name, seeds, k1, seed=1, call_counter=0, out=(n1, e1))
             g.sample(name, n1.view(-1), k2, seed=1, call_counter=1, out=(n2, e2))
@@ -29,9 +32,17 @@ def run(tag, V, E, D, fan, B0=65536, reps=10):
             t = glx.profile_collect(glx.KERNEL_SAMPLE)
             h1, h2 = float(np.mean(t[0::2])), float(np.mean(t[1::2]))
             slots = B0 * k1 + B0 * k1 * k2
-            alg = slots * 32 + (B0 + B0 * k1) * 24 + (slots * 8 if name == "EdgeWeightSampler" else 0)
+            alg = slots * 32 + (B0 + B0 * k1) * 24 + (slots * 8 if name in ("EdgeWeightSampler", "InDegreeSampler") else 0)
             print(json.dumps({"graph": tag, "op": name, "fanout": fan, "B0": B0, "hop1_ms": h1, "hop2_ms": h2,
                               "edges_per_s": slots / ((h1 + h2) * 1e-3), "algorithmic_GBps": alg / ((h1 + h2) * 1e-3) / 1e9}))
+    # FullSampler on the hop-1 frontier, limit 25 (sparse response)
+    fr = n1.view(-1)
+    g.sample_full(fr, 25); torch.cuda.synchronize(); t0 = _t.time()
+    for r in range(reps):
+        d, fn, fe = g.sample_full(fr, 25)
+    torch.cuda.synchronize(); dt = (_t.time() - t0) / reps
+    print(json.dumps({"graph": tag, "op": "FullSampler(limit 25)", "rows": int(fr.shape[0]), "values": int(fn.shape[0]),
+                      "ms_incl_size_readback": dt * 1e3, "values_per_s": fn.shape[0] / dt}))
     ids = n2.view(-1); Sg = B0 * k1
     seg = (torch.arange(ids.shape[0], device=dev) // k2).to(torch.int32)
     emb = torch.empty((Sg, D), dtype=torch.float32, device=dev); cnt = torch.empty(Sg, dtype=torch.int32, device=dev)
