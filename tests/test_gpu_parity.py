@@ -486,3 +486,47 @@ def test_in_degree_sampler_matches_reference_distribution(orc):
             keep = (a + b) > 0
             if keep.sum() >= 2:
                 assert stats.chi2_contingency(np.stack([a[keep], b[keep]]))[1] > 1e-4, (r, j)
+
+
+def test_concurrent_host_threads_on_private_streams(orc, graphs):
+    """Handles are immutable and entry points re-entrant: several host threads, each on its own
+    HIP stream (device pointers) or the per-thread stream (host pointers), get the same results
+    as a serial run (the reference calls Process() from up to 32 pool threads)."""
+    import threading
+    import torch
+    og, dev = graphs["dense"]
+    X = np.random.default_rng(5).standard_normal((3000, 64)).astype(np.float32)
+    f = glx.Features(X)
+    q = np.random.default_rng(6).integers(0, 3000, 2000).astype(np.int64)
+    seg = (np.arange(2000 * 8) // 8).astype(np.int32)
+    exp = {}
+    for t in range(8):
+        n, e = orc.sample(og, SAMPLERS[t % 4], q, 8, seed=t, call_counter=t)
+        emb, cnt = orc.aggregate(X, AGGREGATORS[t % 5], n.reshape(-1), seg, 2000)
+        exp[t] = (n, e, emb)
+    errors = []
+
+    def work(t, device_mode):
+        try:
+            for rep in range(10):
+                if device_mode:
+                    st = torch.cuda.Stream()
+                    with torch.cuda.stream(st):
+                        n, e = dev.sample(SAMPLERS[t % 4], torch.from_numpy(q).cuda(), 8, seed=t, call_counter=t)
+                        emb, _ = f.aggregate(AGGREGATORS[t % 5], n.view(-1), torch.from_numpy(seg).cuda(), 2000)
+                        st.synchronize()
+                    n, e, emb = n.cpu().numpy(), e.cpu().numpy(), emb.cpu().numpy()
+                else:
+                    n, e = dev.sample(SAMPLERS[t % 4], q, 8, seed=t, call_counter=t)
+                    emb, _ = f.aggregate(AGGREGATORS[t % 5], n.reshape(-1), seg, 2000)
+                if not (np.array_equal(n, exp[t][0]) and np.array_equal(e, exp[t][1]) and beq(emb, exp[t][2])):
+                    errors.append((t, device_mode, rep))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((t, device_mode, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(t, t % 2 == 0)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
