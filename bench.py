@@ -269,6 +269,13 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="overlap step i+1's sampling (+ xGMI exchange) with step i's aggregation on two "
                          "HIP streams; auto = on for N>1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = test rig only: collectives staged through host memory")
+    ap.add_argument("--share-device", action="store_true",
+                    help="test rig: every rank uses cuda:0 (several ranks on a 1-GPU box, with --backend gloo)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after timing, recompute one step on an unpartitioned copy of the graph held by this "
+                         "rank and require bit-identical outputs from the sharded path")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
@@ -286,7 +293,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -294,7 +301,10 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if args.workload == "c5":
         assert not sharded, "c5 is a single-GPU workload in this round"
@@ -326,6 +336,9 @@ def main():
         placement = "1 GPU"
     else:
         import dist as gdist
+        whole = None
+        if args.verify:
+            whole = (glx.Graph.from_edges(src, dst, weight, device=local_rank), glx.Features(X, device=local_rank))
         own = (src % world) == rank  # edge-cut: out-edges of v live on shard llabs(v) % P
         eids = torch.nonzero(own).view(-1)
         graph = glx.Graph.from_edges(src[own].contiguous(), dst[own].contiguous(),
@@ -440,7 +453,7 @@ def main():
     t_agg = glx.profile_collect(glx.KERNEL_AGGREGATE)
     t_smp = glx.profile_collect(glx.KERNEL_SAMPLE)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -449,6 +462,26 @@ def main():
         t1 = time.time()
         cpu = cpu_baseline(wl, host_edges[0], host_edges[1], host_edges[2], args)
         log("cpu baseline done in %.1fs: %s" % (time.time() - t1, cpu and "%.3g edges/s" % cpu["value"]))
+
+    verified = None
+    if args.verify and sharded:
+        i = n_steps - 1
+        a, ae = store.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
+        b, be = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=4 * i + 1)
+        e2, c2 = store.aggregate(agg, b.view(-1), seg2, n1)
+        wa, wae = whole[0].sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
+        wb, wbe = whole[0].sample(sampler, wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
+        we2, wc2 = whole[1].aggregate(agg, wb.view(-1), seg2, n1)
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(a, wa) and torch.equal(ae, wae) and torch.equal(b, wb) and torch.equal(be, wbe)
+                        and torch.equal(c2, wc2) and torch.equal(e2.view(torch.int32), we2.view(torch.int32)))
+        flag = torch.tensor([1 if verified else 0], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN) if args.backend == "gloo" else None
+        if args.backend == "nccl":
+            flag = flag.to(dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item())
+        log("verify: sharded == unpartitioned on every rank: %s" % verified)
 
     edges_per_step = n1 + n2  # response slots, padding included
     value = world * edges_per_step * args.steps / elapsed
@@ -494,6 +527,8 @@ def main():
                      "launches_timed": int(len(agg2))},
         "cpu_baseline": cpu,
     }
+    if verified is not None:
+        res["verified_sharded_equals_unpartitioned"] = verified
     if cpu:
         res["gpu_over_cpu"] = value / cpu["value"]
     if rank == 0:
@@ -501,6 +536,8 @@ def main():
         result_out.flush()
     if sharded:
         dist.destroy_process_group()
+    if verified is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -54,8 +54,22 @@ class DeviceOps:
         return feats.aggregate(op, node_ids, seg, num_segments, default_attr)
 
 
+def _staged(x, group):
+    """gloo cannot move device tensors: when the group is gloo and the tensor lives on a
+    GPU (the 2-ranks-on-one-GPU test rig), collectives bounce through host memory.  With
+    the production backend (nccl = RCCL) nothing is staged."""
+    return x.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _a2a(x, send_counts, recv_counts, group):
-    out = x.new_empty((int(sum(recv_counts)),) + tuple(x.shape[1:]))
+    shape = (int(sum(recv_counts)),) + tuple(x.shape[1:])
+    if _staged(x, group):
+        xc = x.contiguous().cpu()
+        out = xc.new_empty(shape)
+        dist.all_to_all_single(out, xc, output_split_sizes=list(recv_counts),
+                               input_split_sizes=list(send_counts), group=group)
+        return out.to(x.device)
+    out = x.new_empty(shape)
     dist.all_to_all_single(out, x.contiguous(), output_split_sizes=list(recv_counts),
                            input_split_sizes=list(send_counts), group=group)
     return out
@@ -80,6 +94,11 @@ class ShardedStore:
     def _route(self, ids):
         """Bucket ids by owner and tell every owner how many it will receive."""
         bucketed, order, counts = self.ops.partition(ids, self.world)
+        if _staged(counts, self.group):
+            cc = counts.cpu()
+            recv = torch.empty_like(cc)
+            dist.all_to_all_single(recv, cc, group=self.group)
+            return bucketed, order, cc.tolist(), recv.tolist()
         recv = torch.empty_like(counts)
         dist.all_to_all_single(recv, counts, group=self.group)
         return bucketed, order, counts.tolist(), recv.tolist()
@@ -134,7 +153,13 @@ def replicate_features(x_shard, num_nodes, group=None):
     pad = x_shard
     if x_shard.shape[0] < per:
         pad = torch.cat([x_shard, x_shard.new_zeros((per - x_shard.shape[0], x_shard.shape[1]))])
-    gathered = x_shard.new_empty((world, per, x_shard.shape[1]))
-    dist.all_gather_into_tensor(gathered.view(world * per, -1), pad.contiguous(), group=group)
+    if _staged(x_shard, group):
+        pc = pad.contiguous().cpu()
+        parts = [torch.empty_like(pc) for _ in range(world)]
+        dist.all_gather(parts, pc, group=group)
+        gathered = torch.stack(parts).to(x_shard.device)
+    else:
+        gathered = x_shard.new_empty((world, per, x_shard.shape[1]))
+        dist.all_gather_into_tensor(gathered.view(world * per, -1), pad.contiguous(), group=group)
     # row v lives at gathered[v % world][v // world]
     return gathered.permute(1, 0, 2).reshape(world * per, -1)[:num_nodes].contiguous()

@@ -1,0 +1,41 @@
+"""bench.py's N > 1 code path run for real with 2 and 3 ranks on ONE GPU: every rank
+shares cuda:0, collectives go through gloo staged via host memory (dist._staged), all
+device work is the production HIP path (DeviceOps).  --verify recomputes a step on an
+unpartitioned copy of the graph and requires bit-identical sampling + aggregation from
+the partitioned, pipelined path on every rank.  (RCCL itself is exercised with
+world-size 1 in test_gpu_sharded.py; N-GPU RCCL runs are the driver's scaling bench.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,features,pipeline", [(2, "replicated", "on"), (2, "sharded", "on"),
+                                                     (3, "replicated", "off")])
+def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--backend", "gloo", "--share-device", "--workload", "tiny", "--batch", "2048",
+           "--steps", "3", "--warmup", "1", "--features", features, "--pipeline", pipeline, "--verify",
+           "--cpu-baseline", "off"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints exactly one JSON line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == world and res["verified_sharded_equals_unpartitioned"] is True
+    assert res["value"] > 0 and res["scaling"] == "weak"
