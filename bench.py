@@ -269,6 +269,10 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="overlap step i+1's sampling (+ xGMI exchange) with step i's aggregation on two "
                          "HIP streams; auto = on for N>1")
+    ap.add_argument("--no-scramble", action="store_true",
+                    help="keep raw RMAT vertex ids (bit-skewed: 44%% of the edges land on shard 0 of 8 under "
+                         "llabs(id)%%P, and hub rows alias onto few HBM channels) instead of the Graph500-style "
+                         "random relabeling")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = test rig only: collectives staged through host memory")
     ap.add_argument("--share-device", action="store_true",
@@ -315,7 +319,7 @@ def main():
     B0 = args.batch
     t0 = time.time()
     weighted = sampler in ("EdgeWeightSampler", "TopkSampler")
-    src, dst, weight = synth.rmat_edges_torch(V, E, gseed, dev, weighted=weighted)
+    src, dst, weight = synth.rmat_edges_torch(V, E, gseed, dev, weighted=weighted, scramble=not args.no_scramble)
     torch.cuda.synchronize()
     log("edge list generated in %.1fs" % (time.time() - t0))
 
@@ -511,6 +515,7 @@ def main():
         "config": {"workload": "%s: %s" % (args.workload, desc), "seeds_per_step_per_gpu": B0,
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
                    "nodes": V, "edges": E,
+                   "vertex_labels": "raw RMAT ids" if args.no_scramble else "RMAT ids relabeled by a fixed random permutation (Graph500-style)",
                    "parallelism": placement,
                    "pipelined_two_streams": bool(pipelined)},
         "phases": {

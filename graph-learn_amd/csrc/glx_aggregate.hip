@@ -11,6 +11,7 @@
 // element is accumulated left-to-right exactly like the reference's serial loop
 // (bit-identical results, no cross-lane reduction at all).
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -80,6 +81,8 @@ struct AggArgs {
   float* emb_out;
   int32_t* cnt_out;
   int64_t num_rows;
+  int64_t stride;
+  int64_t swizzle_rows;
   int32_t dim;
   int32_t num_segments;
   float default_attr;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (row[u] >= 0) {
-          val[u] = *reinterpret_cast<const vec_t*>(a.X + row[u] * (int64_t)dim + col);
+          val[u] = *reinterpret_cast<const vec_t*>(a.X + glx_swizzle_row(row[u], a.swizzle_rows) * a.stride + col);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) val[u][v] = a.default_attr;
@@ -175,24 +178,37 @@ void launch_agg(const AggArgs& a, hipStream_t s) {
   }
 }
 
+// Upload: row r of the caller's dense [V, D] matrix -> its (swizzled, pitched) slot.
+__global__ void glx_place_rows_kernel(const float* __restrict__ src, int64_t num_rows, int32_t dim,
+                                      int64_t stride, int64_t swizzle_rows, float* __restrict__ dst) {
+  const int64_t total = num_rows * (int64_t)dim;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += step) {
+    const int64_t r = t / dim;
+    const int32_t c = (int32_t)(t - r * dim);
+    dst[glx_swizzle_row(r, swizzle_rows) * stride + c] = src[t];
+  }
+}
+
 // Feature gather (LookupNodes float attributes): G lanes per output row.
 __global__ __launch_bounds__(256) void glx_lookup_kernel(GlxIdMap map, const float* __restrict__ X,
-                                                         int32_t dim, const int64_t* __restrict__ ids,
+                                                         int64_t stride, int64_t swizzle_rows, int32_t dim, const int64_t* __restrict__ ids,
                                                          int64_t n, float default_attr,
                                                          float* __restrict__ out, int G) {
   const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
   const int c = threadIdx.x % G;
   if (gid >= n) return;
-  const int64_t row = glx_row_of(map, ids[gid]);
+  int64_t row = glx_row_of(map, ids[gid]);
+  if (row >= 0) row = glx_swizzle_row(row, swizzle_rows);
   float* o = out + gid * (int64_t)dim;
   if ((dim & 3) == 0) {
     for (int32_t col = c * 4; col < dim; col += G * 4) {
       float4 v = make_float4(default_attr, default_attr, default_attr, default_attr);
-      if (row >= 0) v = *reinterpret_cast<const float4*>(X + row * (int64_t)dim + col);
+      if (row >= 0) v = *reinterpret_cast<const float4*>(X + row * stride + col);
       *reinterpret_cast<float4*>(o + col) = v;
     }
   } else {
-    for (int32_t col = c; col < dim; col += G) o[col] = row >= 0 ? X[row * (int64_t)dim + col] : default_attr;
+    for (int32_t col = c; col < dim; col += G) o[col] = row >= 0 ? X[row * stride + col] : default_attr;
   }
 }
 
@@ -227,6 +243,8 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
   a.emb_out = d_emb;
   a.cnt_out = d_cnt;
   a.num_rows = f->num_rows;
+  a.stride = f->stride;
+  a.swizzle_rows = f->swizzle_rows;
   a.dim = f->dim;
   a.num_segments = num_segments;
   a.default_attr = default_attr;
@@ -269,11 +287,37 @@ extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, co
   f->num_rows = num_rows;
   f->dim = dim;
   f->owns_x = true;
-  const size_t bytes = (size_t)(num_rows > 0 ? num_rows : 1) * dim * sizeof(float);
+  // Row pitch.  When a row is a multiple of 256 bytes, rows whose ids share low
+  // zero bits (RMAT-style / power-of-two-structured ids are exactly the hub ids)
+  // alias onto the same cache sets and HBM channels; one extra 64-byte sector per
+  // row breaks the power-of-two stride.  GLX_FEATURE_ROW_PAD overrides (floats).
+  int64_t pad = 0;
+  if (const char* env = getenv("GLX_FEATURE_ROW_PAD")) pad = atoll(env);  // experiment knob (floats)
+  if (pad < 0 || (pad % 4) != 0) pad = 0;
+  f->stride = dim + pad;
+  f->swizzle_rows = (num_rows >> GLX_SWIZZLE_BITS) << GLX_SWIZZLE_BITS;
+  if (const char* env = getenv("GLX_FEATURE_SWIZZLE")) {
+    if (atoi(env) == 0) f->swizzle_rows = 0;
+  }
+  const size_t bytes = (size_t)(num_rows > 0 ? num_rows : 1) * f->stride * sizeof(float);
   hipError_t e = hipMalloc(&f->X, bytes);
+  GlxTemp staged;
   if (e == hipSuccess && num_rows > 0) {
-    e = hipMemcpyAsync(f->X, X, (size_t)num_rows * dim * sizeof(float),
-                       ptr_kind == GLX_PTR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s);
+    const float* d_src = X;
+    if (ptr_kind == GLX_PTR_HOST) {
+      e = hipMalloc(&staged.p, (size_t)num_rows * dim * sizeof(float));
+      if (e == hipSuccess) {
+        e = hipMemcpyAsync(staged.p, X, (size_t)num_rows * dim * sizeof(float), hipMemcpyHostToDevice, s);
+      }
+      d_src = staged.as<float>();
+    }
+    if (e == hipSuccess) {
+      const int64_t total = num_rows * (int64_t)dim;
+      int64_t blocks = (total + 255) / 256;
+      if (blocks > 65536) blocks = 65536;
+      glx_place_rows_kernel<<<(unsigned)blocks, 256, 0, s>>>(d_src, num_rows, dim, f->stride,
+                                                            f->swizzle_rows, f->X);
+    }
   }
   int64_t* tmp_ids = nullptr;
   if (e == hipSuccess && ids) {
@@ -311,6 +355,8 @@ extern "C" int glx_features_view(int device, int64_t num_rows, int32_t dim, cons
   f->device = device;
   f->num_rows = num_rows;
   f->dim = dim;
+  f->stride = dim;
+  f->swizzle_rows = 0;  // a view addresses the caller's rows as they are
   f->X = const_cast<float*>(X_device);
   f->owns_x = false;
   *out = f;
@@ -399,7 +445,7 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
   const int64_t threads = n * G;
   if (ptr_kind == GLX_PTR_DEVICE) {
     GlxKernelTimer timer(GLX_KERNEL_LOOKUP, s);
-    glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->dim, node_ids,
+    glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->stride, f->swizzle_rows, f->dim, node_ids,
                                                                        n, default_attr, out, G);
     timer.stop();
     GLX_HIP(hipGetLastError());
@@ -413,7 +459,7 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
   int64_t* d_ids = reinterpret_cast<int64_t*>(d + out_bytes);
   hipError_t e = hipMemcpyAsync(d_ids, node_ids, (size_t)n * 8, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
-    glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->dim, d_ids, n,
+    glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->stride, f->swizzle_rows, f->dim, d_ids, n,
                                                                        default_attr, d_out, G);
     e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s);
   }

@@ -65,6 +65,20 @@ struct GlxTemp {
   GlxTemp& operator=(const GlxTemp&) = delete;
 };
 
+// Storage slot of feature row r.  Row r of an owned feature table lives at slot
+// r' = r with its low 12 bits XOR-ed by a hash of the high bits (a bijection inside
+// every aligned block of 4096 rows).  Power-of-two-structured ids -- RMAT hubs are
+// exactly the ids with many low zero bits -- would otherwise put the hottest rows
+// at addresses that share their low bits, i.e. on the same cache sets and HBM
+// channels; the swizzle decorrelates address bits from id bits at zero memory cost.
+#define GLX_SWIZZLE_BITS 12
+__host__ __device__ __forceinline__ int64_t glx_swizzle_row(int64_t r, int64_t swizzle_rows) {
+  if (r >= swizzle_rows) return r;
+  const uint32_t hi = (uint32_t)(r >> GLX_SWIZZLE_BITS);
+  const uint32_t m = (hi * 0x9E3779B1u) >> (32 - GLX_SWIZZLE_BITS);
+  return r ^ (int64_t)m;
+}
+
 // Kernel timing hook (glx_profile_enable): record an event on `s` when enabled.
 struct GlxKernelTimer {
   int slot = -1;
@@ -138,7 +152,9 @@ struct glx_features {
   int device;
   int64_t num_rows;
   int32_t dim;
-  float* X;  // [V, D] row-major, base 256-byte aligned
+  int64_t stride;  // floats between consecutive rows (>= dim; see glx_features_create)
+  int64_t swizzle_rows;  // rows [0, swizzle_rows) are stored at glx_swizzle_row(r); 0 = off
+  float* X;  // [V, stride] row-major, base 256-byte aligned
   bool owns_x;
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }

@@ -53,9 +53,14 @@ def small_graph(num_nodes=2000, num_edges=30000, seed=0, weighted=True, hub_degr
 
 
 def rmat_edges_torch(num_nodes, num_edges, seed, device, weighted=True, a=0.57, b=0.19, c=0.19,
-                     chunk=1 << 25):
+                     chunk=1 << 25, scramble=True):
     """RMAT edge list in generation (= insertion) order: src, dst (int64), weight
-    (float32 U(0.01, 1) or None).  Edge id = index.  Feed it to glx_graph_build."""
+    (float32 U(0.01, 1) or None).  Edge id = index.  Feed it to glx_graph_build.
+
+    scramble: relabel vertices with a fixed random permutation, as Graph500 does.  Raw
+    RMAT ids are bit-skewed (every id bit is 0 with probability a+b = 0.76), so the
+    reference's `llabs(id) % P` ownership rule would put 44 % of all edges on shard 0
+    of 8; real-world ids (and scrambled ones) spread evenly."""
     import torch
     scale = int(np.ceil(np.log2(max(num_nodes, 2))))
     gen = torch.Generator(device=device)
@@ -75,9 +80,14 @@ def rmat_edges_torch(num_nodes, num_edges, seed, device, weighted=True, a=0.57, 
         dsts.append(d % num_nodes)
     src = torch.cat(srcs)
     dst = torch.cat(dsts)
+    del srcs, dsts
     weight = None
     if weighted:
         weight = torch.rand(num_edges, generator=gen, device=device) * 0.99 + 0.01
+    if scramble:
+        perm = torch.randperm(num_nodes, generator=gen, device=device)
+        src = perm[src]
+        dst = perm[dst]
     return src, dst, weight
 
 
