@@ -62,14 +62,14 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(wl, src, dst, weight, args):
+def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
     """Times the reference's own CPU path (oracle/_ref, built from the reference's
     sources) on this box's host cores, on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_bindings import RefLib, have_ref, _p
     V, E, sampler, (k1, k2), agg, D = wl[:6]
     if not have_ref():
-        return cpu_baseline_port(wl, src, dst, weight, args)
+        return cpu_baseline_port(wl, src, dst, weight, args, seed_pool)
     t_all = time.time()
     ref = RefLib(storage_mode=2, padding_mode=1)
     # edges in insertion (= edge id) order, as the reference loader would add them
@@ -93,11 +93,12 @@ def cpu_baseline(wl, src, dst, weight, args):
     rng = np.random.default_rng(123)
     out = ctypes.c_int64()
     # calibrate with one request per thread, then size the run to ~cpu_time_budget
-    seeds = rng.integers(0, V, B * threads).astype(np.int64)
+    pool = seed_pool if seed_pool is not None else np.arange(V, dtype=np.int64)
+    seeds = pool[rng.integers(0, pool.shape[0], B * threads)]
     dt1 = ref.L.glref_time_sample_2hop(ref.h, b"e", sampler.encode(), _p(seeds), B, k1, k2, 1, threads,
                                        ctypes.byref(out))
     reps = int(max(1, min(64, args.cpu_time_budget / max(dt1, 1e-3))))
-    seeds = rng.integers(0, V, B * threads * reps).astype(np.int64)
+    seeds = pool[rng.integers(0, pool.shape[0], B * threads * reps)]
     dts = ref.L.glref_time_sample_2hop(ref.h, b"e", sampler.encode(), _p(seeds), B, k1, k2, reps, threads,
                                        ctypes.byref(out))
     edges = out.value
@@ -130,7 +131,7 @@ def cpu_baseline(wl, src, dst, weight, args):
     }
 
 
-def cpu_baseline_port(wl, src, dst, weight, args):
+def cpu_baseline_port(wl, src, dst, weight, args, seed_pool=None):
     """Fallback when oracle/_ref (the reference's own code) is not on this box: the
     C restatement (oracle/glx_oracle.c) timed single-threaded with the reference's cost
     model switched on (per-row, per-request alias rebuild: edge_weight_sampler.cc:78-92)."""
@@ -150,7 +151,8 @@ def cpu_baseline_port(wl, src, dst, weight, args):
     B = max(8, args.cpu_seeds_per_request // 8)
     edges, t0 = 0, time.time()
     while time.time() - t0 < args.cpu_time_budget:
-        seeds = rng.integers(0, V, B).astype(np.int64)
+        pool = seed_pool if seed_pool is not None else np.arange(V, dtype=np.int64)
+        seeds = pool[rng.integers(0, pool.shape[0], B)]
         n1, _ = orc.sample(g, sampler, seeds, k1, seed=1, call_counter=edges)
         n2, _ = orc.sample(g, sampler, n1.reshape(-1), k2, seed=1, call_counter=edges + 1)
         edges += n1.size + n2.size
@@ -323,11 +325,18 @@ def main():
     torch.cuda.synchronize()
     log("edge list generated in %.1fs" % (time.time() - t0))
 
+    # Seed vertices = vertices that have out-edges (RMAT leaves about half of the ids
+    # without any; a training set is made of vertices that have neighbours).  Frontier
+    # vertices reached by sampling may still have no out-edges: those rows are
+    # default-filled exactly as the reference does (random_sampler.cc:58-59).
+    seed_pool = torch.unique(src)
+
     # The CPU baseline runs AFTER the timed GPU region (an idle GPU clocks down during
     # 1-2 minutes of host work); keep host copies of the edge list for it.
     host_edges = None
     if args.cpu_baseline == "on" and world == 1:
-        host_edges = (src.cpu(), dst.cpu(), weight.cpu() if weight is not None else None)
+        host_edges = (src.cpu(), dst.cpu(), weight.cpu() if weight is not None else None,
+                      seed_pool.cpu().numpy())
 
     # Storage build on the device (glx_graph_build: radix sorts + RLE + scan + alias
     # tables + id map); rows end up weight-descending like the reference's Build().
@@ -375,7 +384,8 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
     n_steps = args.warmup + args.steps
-    seeds = torch.randint(0, V, (n_steps, B0), generator=gen, device=dev, dtype=torch.int64)
+    seeds = seed_pool[torch.randint(0, seed_pool.shape[0], (n_steps, B0), generator=gen, device=dev)]
+    del seed_pool
     n1, n2 = B0 * k1, B0 * k1 * k2
     seg2 = (torch.arange(n2, device=dev) // k2).to(torch.int32)
     seg1 = (torch.arange(n1, device=dev) // k1).to(torch.int32)
@@ -464,8 +474,16 @@ def main():
     cpu = None
     if host_edges is not None:
         t1 = time.time()
-        cpu = cpu_baseline(wl, host_edges[0], host_edges[1], host_edges[2], args)
+        cpu = cpu_baseline(wl, host_edges[0], host_edges[1], host_edges[2], args, host_edges[3])
         log("cpu baseline done in %.1fs: %s" % (time.time() - t1, cpu and "%.3g edges/s" % cpu["value"]))
+
+    # how much of the hop-2 work is the reference's default-fill path (frontier vertices
+    # without out-edges)?  Reported so the workload can be judged.
+    empty_frac = None
+    if store is None:
+        a_last, _ = do_sample(n_steps - 1)
+        torch.cuda.synchronize()
+        empty_frac = float((graph.degrees(a_last.view(-1)) == 0).double().mean().item())
 
     verified = None
     if args.verify and sharded:
@@ -513,8 +531,9 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64 ids + f32 features", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, desc), "seeds_per_step_per_gpu": B0,
+                   "seeds": "uniform over the vertices that have out-edges, fresh batch every step",
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
-                   "nodes": V, "edges": E,
+                   "nodes": V, "edges": E, "hop2_rows_without_out_edges_fraction": empty_frac,
                    "vertex_labels": "raw RMAT ids" if args.no_scramble else "RMAT ids relabeled by a fixed random permutation (Graph500-style)",
                    "parallelism": placement,
                    "pipelined_two_streams": bool(pipelined)},
