@@ -189,9 +189,13 @@ def bench_c5(args, dev, result_out):
             "u-s": (n_user, n_shop, 100_000_000, 5)}
     t0 = time.time()
     graphs = {}
+    seed_pool = None
     for i, (t, (ns, nd, ne, k)) in enumerate(spec.items()):
         src, dst, w = synth.rmat_edges_torch(1 << 26, ne, 20 + i, dev, weighted=True)
-        graphs[t] = glx.Graph.from_edges(src % ns, dst % nd, w, device=dev.index)
+        src %= ns
+        graphs[t] = glx.Graph.from_edges(src, dst % nd, w, device=dev.index)
+        if t == "u-i":
+            seed_pool = torch.unique(src)  # users that have at least one u-i edge
         del src, dst, w
     x_item = glx.Features(synth.features_torch(n_item, D, 31, dev), device=dev.index)
     x_shop = glx.Features(synth.features_torch(n_shop, D, 32, dev), device=dev.index)
@@ -201,7 +205,7 @@ def bench_c5(args, dev, result_out):
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
     n_steps = args.warmup + args.steps
-    seeds = torch.randint(0, n_user, (n_steps, B0), generator=gen, device=dev, dtype=torch.int64)
+    seeds = seed_pool[torch.randint(0, seed_pool.shape[0], (n_steps, B0), generator=gen, device=dev)]
     k1, k2, k3 = 10, 10, 5
     i64 = dict(dtype=torch.int64, device=dev)
     s1, e1 = torch.empty((B0, k1), **i64), torch.empty((B0, k1), **i64)

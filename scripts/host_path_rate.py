@@ -7,10 +7,11 @@ import numpy as np, torch, glx, synth
 dev = torch.device("cuda", 0)
 V, E, D, B0, k1, k2 = 10_000_000, 100_000_000, 256, 65536, 25, 10
 src, dst, w = synth.rmat_edges_torch(V, E, 4, dev)
+pool = torch.unique(src)  # seeds = vertices that have out-edges (as in bench.py)
 g = glx.Graph.from_edges(src, dst, w); del src, dst, w
 f = glx.Features(synth.features_torch(V, D, 5, dev))
 rng = np.random.default_rng(0)
-seeds = rng.integers(0, V, B0).astype(np.int64)
+seeds = pool.cpu().numpy()[rng.integers(0, pool.shape[0], B0)]
 n1 = np.empty((B0, k1), np.int64); e1 = np.empty_like(n1)
 n2 = np.empty((B0 * k1, k2), np.int64); e2 = np.empty_like(n2)
 emb = np.empty((B0 * k1, D), np.float32); cnt = np.empty(B0 * k1, np.int32)

@@ -7,17 +7,18 @@ import numpy as np, torch, glx, synth
 
 dev = torch.device("cuda", 0)
 def run(tag, V, E, D, fan, B0=65536, reps=10):
-    row_ptr, col, eid, w = synth.rmat_graph_torch(V, E, 4, dev, weighted=True)
-    g = glx.Graph(row_ptr, col, eid, w)
+    src, dst, w = synth.rmat_edges_torch(V, E, 4, dev, weighted=True)
+    pool = torch.unique(src)  # seeds = vertices that have out-edges (as in bench.py)
+    g = glx.Graph.from_edges(src, dst, w)
     import time as _t
     t0 = _t.time(); g.enable_in_degree(); torch.cuda.synchronize()
     print(json.dumps({"graph": tag, "op": "glx_graph_enable_in_degree (one-time)", "seconds": _t.time() - t0}))
-    del row_ptr, col, eid, w
+    del src, dst, w
     X = synth.features_torch(V, D, 5, dev)
     f = glx.Features(X); del X
     k1, k2 = fan
     gen = torch.Generator(device=dev); gen.manual_seed(1)
-    seeds = torch.randint(0, V, (B0,), generator=gen, device=dev)
+    seeds = pool[torch.randint(0, pool.shape[0], (B0,), generator=gen, device=dev)]
     n1 = torch.empty((B0, k1), dtype=torch.int64, device=dev); e1 = torch.empty_like(n1)
     n2 = torch.empty((B0 * k1, k2), dtype=torch.int64, device=dev); e2 = torch.empty_like(n2)
     for name in list(glx.SAMPLER_IDS) + ["InDegreeSampler"]:

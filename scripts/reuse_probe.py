@@ -7,13 +7,14 @@ import numpy as np, torch, glx, synth
 dev = torch.device("cuda", 0)
 V, E, D, B0, k1, k2 = 10_000_000, 100_000_000, 256, 65536, 25, 10
 src, dst, w = synth.rmat_edges_torch(V, E, 4, dev)
+pool = torch.unique(src)  # seeds = vertices that have out-edges (as in bench.py)
 g = glx.Graph.from_edges(src, dst, w); del src, dst, w
 f = glx.Features(synth.features_torch(V, D, 5, dev))
 gen = torch.Generator(device=dev); gen.manual_seed(3)
 Sg = B0 * k1
 seg = (torch.arange(Sg * k2, device=dev) // k2).to(torch.int32)
 emb = torch.empty((Sg, D), dtype=torch.float32, device=dev); cnt = torch.empty(Sg, dtype=torch.int32, device=dev)
-seeds = torch.randint(0, V, (B0,), generator=gen, device=dev)
+seeds = pool[torch.randint(0, pool.shape[0], (B0,), generator=gen, device=dev)]
 n1, _ = g.sample("EdgeWeightSampler", seeds, k1, seed=1, call_counter=0)
 n2, _ = g.sample("EdgeWeightSampler", n1.view(-1), k2, seed=1, call_counter=1)
 ids = n2.view(-1)

@@ -53,8 +53,13 @@ out += ["", "Hop-2 aggregate launch (max over dispatches): read %.2f GB + write 
         "(N x (4D+12) + Sg x (4D+4)). Traffic is below the algorithmic bytes (hub rows re-hit in L2 / Infinity Cache): no wasted re-reads. "
         "At %.3f ms per launch that is %.2f TB/s of real traffic (copy ceiling of the part ~6.3 TB/s) and %.2f TB/s algorithmic = %.1f%% of the 8 TB/s peak."
         % (rd / 1e9, wr / 1e9, (rd + wr) / 1e9, alg / 1e9, ms, (rd + wr) / ms / 1e9, alg / ms / 1e9, alg / ms / 8e9 * 100),
-        "", "Calibration note (first round-1 pass, commit 'bench.py (C3 headline...)'): `glx_pack_adj_kernel` read 2 x 800 MB and wrote 1.6 GB; "
-        "FETCH_SIZE reported 781,368 KB (= 1/2 of the bytes read), WRITE_SIZE 1,562,500 KB (= the bytes written)."]
+        ""]
+cal = [x for x in f if "glx_place_rows_kernel" in x]
+if cal:
+    known = 10_000_000 * 256 * 4  # the C3 feature upload streams exactly V*D*4 bytes in and out
+    out.append("Calibration on a known byte count in this same run: `glx_place_rows_kernel` (the feature upload) reads and writes exactly "
+               "%.3f GB; FETCH_SIZE reports %.3f GB (ratio %.3f -> the x2 correction), WRITE_SIZE reports %.3f GB (ratio %.3f -> no correction)."
+               % (known / 1e9, max(f[cal[0]]) * 1024 / 1e9, max(f[cal[0]]) * 1024 / known, max(w[cal[0]]) * 1024 / 1e9, max(w[cal[0]]) * 1024 / known))
 open(os.path.join(dst, "SUMMARY.md"), "w").write("\n".join(out) + "\n")
 json.dump({"c3_b65536": {"aggregate_hop2_bytes_per_launch": rd + wr, "read_bytes_fetch_size_x2": rd, "write_bytes": wr,
                          "source": "profiles/%s/pmc_FETCH_SIZE_glx_only.csv + pmc_WRITE_SIZE_glx_only.csv (FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tag}},
