@@ -136,6 +136,20 @@ struct GlxAlias {  // AliasMethod probs_/alias_ of the slot's row (row-local ind
   int32_t alias;
 };
 
+// EdgeWeightSampler fast path: everything one alias draw needs in ONE 32-byte record
+// (half a 64-byte sector): the slot's probability, and the (nbr, eid) of both possible
+// outcomes -- the slot itself and its alias.  Halves the random sectors per draw of
+// the two-gather formulation (alias[idx] then adj[final]).  Built when every edge id
+// fits an int32 (edge ids are insertion indices, so E < 2^31 suffices).
+struct GlxEwRec {
+  float prob;
+  int32_t eid_self;
+  int32_t eid_alias;
+  int32_t pad_;
+  int64_t nbr_self;
+  int64_t nbr_alias;
+};
+
 struct glx_graph {
   int device;
   int64_t num_rows, num_edges;
@@ -144,6 +158,7 @@ struct glx_graph {
   float* weight;     // [E] or nullptr
   GlxAlias* alias;   // [E] or nullptr
   GlxAlias* alias_indeg;  // [E] alias tables over the neighbours' in-degrees, or nullptr
+  GlxEwRec* ew;           // [E] packed EdgeWeight records, or nullptr (edge ids beyond int32)
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
 };

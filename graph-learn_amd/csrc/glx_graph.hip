@@ -4,6 +4,7 @@
 // auto_indexing.cc:21-33} + the per-request AliasMethod::Build of
 // edge_weight_sampler.cc:78-92 (alias_method.cc:57-107).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -349,6 +350,25 @@ __global__ void glx_alias_build_kernel(const int64_t* __restrict__ row_ptr,
   while (high_num > 0) tab[high[-(--high_num)]].prob = 1.0f;
 }
 
+// Packs {prob, (nbr, eid) of the slot, (nbr, eid) of its alias} per slot; *bad is set
+// when an edge id does not fit an int32 (the records are then discarded).
+__global__ void glx_pack_ew_kernel(const int64_t* __restrict__ row_ptr, const GlxAdj* __restrict__ adj,
+                                   const GlxAlias* __restrict__ alias, int64_t V, GlxEwRec* __restrict__ out,
+                                   int* bad) {
+  // one wave per row: lanes stride over the row's slots
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= V) return;
+  const int64_t s = row_ptr[row], e = row_ptr[row + 1];
+  for (int64_t i = s + lane; i < e; i += 64) {
+    const GlxAlias a = alias[i];
+    const GlxAdj self = adj[i];
+    const GlxAdj other = adj[s + a.alias];
+    if (self.eid > INT32_MAX || self.eid < INT32_MIN || other.eid > INT32_MAX || other.eid < INT32_MIN) *bad = 1;
+    out[i] = GlxEwRec{a.prob, (int32_t)self.eid, (int32_t)other.eid, 0, self.nbr, other.nbr};
+  }
+}
+
 __global__ void glx_unpack_alias_kernel(const GlxAlias* __restrict__ tab, int64_t E,
                                         float* __restrict__ prob, int32_t* __restrict__ alias) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -383,6 +403,7 @@ void glx_graph_free(glx_graph* g) {
   if (g->weight) (void)hipFree(g->weight);
   if (g->alias) (void)hipFree(g->alias);
   if (g->alias_indeg) (void)hipFree(g->alias_indeg);
+  if (g->ew) (void)hipFree(g->ew);
   glx_idmap_free(&g->idmap);
   delete g;
 }
@@ -456,6 +477,22 @@ int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s) {
     GLX_HIP(hipMalloc(&g->alias, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
     int rc = glx_alias_build_launch(g->row_ptr, g->weight, V, E, g->alias, s);
     if (rc != GLX_OK) return rc;
+    const char* env = getenv("GLX_EW_PACKED");  // "0" disables the packed fast path
+    if (E > 0 && !(env && env[0] == '0')) {
+      GlxTemp bad;
+      GLX_HIP(hipMalloc(&bad.p, sizeof(int)));
+      GLX_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), s));
+      GLX_HIP(hipMalloc(&g->ew, (size_t)E * sizeof(GlxEwRec)));
+      glx_pack_ew_kernel<<<(unsigned)((V * 64 + 255) / 256), 256, 0, s>>>(g->row_ptr, g->adj, g->alias, V, g->ew,
+                                                                         bad.as<int>());
+      int h_bad = 0;
+      GLX_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      GLX_HIP(hipStreamSynchronize(s));
+      if (h_bad) {
+        (void)hipFree(g->ew);
+        g->ew = nullptr;
+      }
+    }
   }
   if (d_ids) {
     int rc = glx_idmap_build(d_ids, V, &g->idmap, s);

@@ -18,6 +18,7 @@ struct SampleArgs {
   const int64_t* row_ptr;
   const GlxAdj* adj;
   const GlxAlias* alias;
+  const GlxEwRec* ew;
   const int64_t* src;
   const int64_t* rng_rows;  // nullptr: request row i uses stream i
   int64_t* nbr_out;
@@ -29,7 +30,7 @@ struct SampleArgs {
   int32_t k;
 };
 
-enum SlotOp { kSlotRandom = 0, kSlotEdgeWeight = 1, kSlotCircular = 2, kSlotReplicate = 3 };
+enum SlotOp { kSlotRandom = 0, kSlotEdgeWeight = 1, kSlotCircular = 2, kSlotReplicate = 3, kSlotEdgeWeightPacked = 4 };
 
 // One thread = two consecutive output slots (2q, 2q+1) of one request row, i.e.
 // exactly one Philox block for the randomised ops.  Consecutive lanes own
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
   }
   const int64_t obase = (int64_t)i * a.k;
   GlxPhilox blk;
-  if (OP == kSlotRandom || OP == kSlotEdgeWeight) {
+  if (OP == kSlotRandom || OP == kSlotEdgeWeight || OP == kSlotEdgeWeightPacked) {
     if (deg > 0) {
       const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
       blk = glx_philox_block((uint32_t)q, rr, a.seed, a.cc);
@@ -77,7 +78,20 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
       }
     }
     GlxAdj r = GlxAdj{a.default_nbr, -1};
-    if (pick >= 0) r = a.adj[start + pick];
+    if (OP == kSlotEdgeWeightPacked) {
+      if (deg > 0) {
+        // alias_method.cc:117-121 on one packed record: a single 32-byte gather per draw
+        const uint64_t u = glx_draw_of(blk, (uint32_t)j);
+        const double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
+        const float rnd = (float)rd;
+        const int32_t ix = (int32_t)rnd;
+        const GlxEwRec rec = a.ew[start + ix];
+        const bool take_alias = rec.prob <= (rnd - (float)ix);
+        r = take_alias ? GlxAdj{rec.nbr_alias, (int64_t)rec.eid_alias} : GlxAdj{rec.nbr_self, (int64_t)rec.eid_self};
+      }
+    } else if (pick >= 0) {
+      r = a.adj[start + pick];
+    }
     a.nbr_out[obase + j] = r.nbr;
     a.eid_out[obase + j] = r.eid;
   }
@@ -224,8 +238,9 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
       // Replicate mode: ReplicatePadder ignores the drawn indices and (in the
       // reference) reads neighbors_[0..k) -- out of bounds when deg < k.  glx
       // returns the first min(k, deg) slots then default-fills.
-      if (circular) launch_slots<kSlotEdgeWeight>(a, s);
-      else launch_slots<kSlotReplicate>(a, s);
+      if (!circular) launch_slots<kSlotReplicate>(a, s);
+      else if (a.ew) launch_slots<kSlotEdgeWeightPacked>(a, s);
+      else launch_slots<kSlotEdgeWeight>(a, s);
       break;
     case GLX_SAMPLER_IN_DEGREE: {
       // in_degree_sampler.cc:79-92: the alias draw of EdgeWeightSampler over the
@@ -233,6 +248,7 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
       GLX_REQUIRE(g->alias_indeg != nullptr, "InDegreeSampler needs glx_graph_enable_in_degree()");
       SampleArgs b = a;
       b.alias = g->alias_indeg;
+      b.ew = nullptr;
       if (circular) launch_slots<kSlotEdgeWeight>(b, s);
       else launch_slots<kSlotReplicate>(b, s);
       break;
@@ -291,6 +307,7 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
   a.row_ptr = g->row_ptr;
   a.adj = g->adj;
   a.alias = g->alias;
+  a.ew = g->ew;
   a.default_nbr = default_neighbor_id;
   a.seed = seed;
   a.cc = call_counter;
