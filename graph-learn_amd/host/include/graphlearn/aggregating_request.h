@@ -5,6 +5,7 @@
 #include <string>
 
 #include "graphlearn/op_request.h"
+#include "graphlearn/partition.h"
 
 namespace graphlearn {
 
@@ -52,6 +53,9 @@ public:
   int32_t NumSegments() const { return batch_size_; }
   const float* Embeddings() const;
   const int32_t* Segments() const;
+
+  // Combine per-shard partial aggregates (aggregating_request.cc:172-213); see partition.h.
+  void Stitch(ShardsPtr<OpResponse> shards, float default_attr = 0.0f);
 
   // Device-path additions: size the outputs once, fill them with one copy.
   float* MutableEmbeddings();

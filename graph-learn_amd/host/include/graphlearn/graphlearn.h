@@ -7,6 +7,7 @@
 #include "graphlearn/graph_store.h"
 #include "graphlearn/op_request.h"
 #include "graphlearn/operator.h"
+#include "graphlearn/partition.h"
 #include "graphlearn/sampling_request.h"
 #include "graphlearn/status.h"
 #include "graphlearn/tensor.h"

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "graphlearn/op_request.h"
+#include "graphlearn/partition.h"
 
 namespace graphlearn {
 
@@ -43,6 +44,14 @@ public:
   int32_t BatchSize() const;
   int32_t NeighborCount() const { return neighbor_count_; }
   const int64_t* GetSrcIds() const;
+  // Original row indices of a part request (set by HashPartitioner), or nullptr.
+  const int64_t* GetRngRows() const;
+  // Pin the random stream of this request.  Unset (the default),
+  // the operator uses its own per-call counter; a caller that partitions a request
+  // sets one value on it so that every part draws from the same streams.
+  void SetCallCounter(int64_t call_counter);
+  bool HasCallCounter() const;
+  int64_t CallCounter() const;
   // true when a filter was requested (sampler/filter.h:73-75); the device path
   // rejects such requests with Unimplemented.
   bool HasFilter() const { return filter_type_ != kOperatorUnspecified && filter_field_ != kFieldUnspecified; }
@@ -76,6 +85,8 @@ public:
 
   // Device-path addition: size both tensors to dim1*dim2 for one bulk write.
   void ResizeDense();
+  // Scatter the shards' rows back to their request positions (stitcher.h:67-107).
+  void Stitch(ShardsPtr<OpResponse> shards);
 
 private:
   Shape shape_;

@@ -75,8 +75,18 @@ void SamplingRequest::InitParams(const std::string& type, const std::string& str
 }
 
 OpRequest* SamplingRequest::Clone() const {
-  return new SamplingRequest(Type(), Strategy(), neighbor_count_, filter_type_, filter_field_);
+  SamplingRequest* r = new SamplingRequest(Type(), Strategy(), neighbor_count_, filter_type_, filter_field_);
+  if (HasCallCounter()) r->SetCallCounter(CallCounter());
+  return r;
 }
+
+void SamplingRequest::SetCallCounter(int64_t call_counter) {
+  params_.erase("call_counter");
+  ADD_TENSOR(params_, "call_counter", kInt64, 1);
+  params_["call_counter"].AddInt64(call_counter);
+}
+bool SamplingRequest::HasCallCounter() const { return params_.count("call_counter") != 0; }
+int64_t SamplingRequest::CallCounter() const { return params_.at("call_counter").GetInt64(0); }
 
 // DagNodeRunner-style construction (sampling_request.cc:87-136).
 void SamplingRequest::Init(const Tensor::Map& params) {
@@ -101,6 +111,10 @@ const std::string& SamplingRequest::Type() const { return params_.at(kType).GetS
 const std::string& SamplingRequest::Strategy() const { return params_.at(kOpName).GetString(0); }
 int32_t SamplingRequest::BatchSize() const { return tensors_.at(kSrcIds).Size(); }
 const int64_t* SamplingRequest::GetSrcIds() const { return tensors_.at(kSrcIds).GetInt64(); }
+const int64_t* SamplingRequest::GetRngRows() const {
+  auto it = tensors_.find(kRngRows);
+  return (it == tensors_.end() || it->second.Size() != BatchSize()) ? nullptr : it->second.GetInt64();
+}
 
 SamplingResponse::SamplingResponse() : OpResponse() {}
 

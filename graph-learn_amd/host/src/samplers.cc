@@ -50,10 +50,13 @@ protected:
     }
     // The reference's RNG state advances from call to call (thread_local
     // mt19937); the contract's equivalent is a per-operator call counter.
-    const uint64_t cc = call_counter_.fetch_add(1, std::memory_order_relaxed);
-    int rc = glx_sample(g, SamplerId(), req->GetSrcIds(), batch_size, count, GLOBAL_FLAG(PaddingMode),
-                        GLOBAL_FLAG(DefaultNeighborId), (uint64_t)GLOBAL_FLAG(SamplingSeed), cc,
-                        res->GetNeighborIds(), res->GetEdgeIds(), GLX_PTR_HOST, nullptr);
+    const uint64_t cc = req->HasCallCounter() ? (uint64_t)req->CallCounter()
+                                               : call_counter_.fetch_add(1, std::memory_order_relaxed);
+    // A part of a partitioned request draws from its rows' ORIGINAL random streams.
+    int rc = glx_sample_ex(g, SamplerId(), req->GetSrcIds(), req->GetRngRows(), batch_size, count,
+                           GLOBAL_FLAG(PaddingMode), GLOBAL_FLAG(DefaultNeighborId),
+                           (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, res->GetNeighborIds(), res->GetEdgeIds(),
+                           GLX_PTR_HOST, nullptr);
     return error::FromGlx(rc);
   }
 

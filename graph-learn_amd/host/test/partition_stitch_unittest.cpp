@@ -1,0 +1,204 @@
+// Mirrors graphlearn/src/core/partition/test/partition_stitch_unittest.cpp (a
+// 2-server cluster faked in one process) and goes one step further: the parts are
+// really PROCESSED on two device-resident GraphStores (one per "server") and the
+// stitched answer must equal the answer of a single store holding everything.
+#include <cmath>
+#include <random>
+#include <vector>
+
+#include "graphlearn/graphlearn.h"
+#include "test_util.h"
+
+using namespace graphlearn;      // NOLINT
+using namespace graphlearn::op;  // NOLINT
+
+TEST(PartitionStitchTest, DenseReq_DenseRes) {
+  // partition_stitch_unittest.cpp DenseReq_DenseRes: ids {1,2,3,4}, 2 servers.
+  SamplingRequest req("i-i", "RandomSampler", 3);
+  int64_t src_ids[4] = {1, 2, 3, 4};
+  req.Set(src_ids, 4);
+  HashPartitioner partitioner(2);
+  ShardsPtr<OpRequest> req_shards = partitioner.Partition(&req);
+  EXPECT_EQ(req_shards->Size(), 2);
+  const SamplingRequest* p0 = static_cast<const SamplingRequest*>(req_shards->Get(0));
+  const SamplingRequest* p1 = static_cast<const SamplingRequest*>(req_shards->Get(1));
+  EXPECT_EQ(p0->BatchSize(), 2);
+  EXPECT_EQ(p0->GetSrcIds()[0], 2);
+  EXPECT_EQ(p0->GetSrcIds()[1], 4);
+  EXPECT_EQ(p1->GetSrcIds()[0], 1);
+  EXPECT_EQ(p1->GetSrcIds()[1], 3);
+  EXPECT_EQ(req_shards->StickerPtr()->At(0)[0], 1);
+  EXPECT_EQ(req_shards->StickerPtr()->At(0)[1], 3);
+  EXPECT_EQ(req_shards->StickerPtr()->At(1)[0], 0);
+  EXPECT_EQ(req_shards->StickerPtr()->At(1)[1], 2);
+  EXPECT_EQ(p0->GetRngRows()[0], 1);  // parts remember their original rows
+  EXPECT_EQ(p1->GetRngRows()[1], 2);
+  EXPECT_TRUE(!p0->IsShardable());
+
+  // hand-built shard responses: row of src id v holds v*10 + j
+  ShardsPtr<OpResponse> res_shards(new Shards<OpResponse>(2));
+  for (int s = 0; s < 2; ++s) {
+    SamplingResponse* r = new SamplingResponse;
+    r->SetShape(2, 3);
+    r->InitNeighborIds();
+    r->InitEdgeIds();
+    const SamplingRequest* p = s == 0 ? p0 : p1;
+    for (int i = 0; i < 2; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        r->AppendNeighborId(p->GetSrcIds()[i] * 10 + j);
+        r->AppendEdgeId(p->GetSrcIds()[i] * 100 + j);
+      }
+    }
+    res_shards->Add(s, r, true);
+    for (int32_t st : req_shards->StickerPtr()->At(s)) res_shards->StickerPtr()->Add(s, st);
+  }
+  SamplingResponse res;
+  res.Stitch(res_shards);
+  EXPECT_EQ(res.GetShape().dim1, (size_t)4);
+  EXPECT_EQ(res.GetShape().dim2, (size_t)3);
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      EXPECT_EQ(res.GetNeighborIds()[i * 3 + j], src_ids[i] * 10 + j);
+      EXPECT_EQ(res.GetEdgeIds()[i * 3 + j], src_ids[i] * 100 + j);
+    }
+  }
+}
+
+namespace {
+struct Cluster {
+  GraphStore whole;
+  GraphStore shard[2];
+};
+
+Cluster* BuildCluster() {
+  static Cluster* c = nullptr;
+  if (c) return c;
+  c = new Cluster;
+  std::mt19937_64 rng(9);
+  io::SideInfo einfo;
+  einfo.format = io::kWeighted;
+  einfo.type = "e";
+  io::SideInfo ninfo;
+  ninfo.format = io::kAttributed;
+  ninfo.f_num = 8;
+  ninfo.type = "n";
+  GraphStore* all[3] = {&c->whole, &c->shard[0], &c->shard[1]};
+  for (GraphStore* s : all) {
+    s->GetGraph("e")->SetSideInfo(&einfo);
+    s->GetNoder("n")->SetSideInfo(&ninfo);
+  }
+  for (int e = 0; e < 4000; ++e) {
+    io::EdgeValue v;
+    v.src_id = (int64_t)(rng() % 300);
+    v.dst_id = (int64_t)(rng() % 300);
+    v.weight = 0.01f + (float)(rng() % 100000) / 100000.0f + e * 1e-7f;
+    c->whole.GetGraph("e")->Add(&v);
+    c->shard[v.src_id % 2].GetGraph("e")->Add(&v);  // out-edges of v live on shard |v| % 2
+  }
+  for (int i = 0; i < 300; ++i) {
+    io::NodeValue nv;
+    nv.id = i;
+    for (int j = 0; j < 8; ++j) nv.attrs.push_back((float)((int64_t)(rng() % 2001) - 1000) / 10.0f);
+    c->whole.GetNoder("n")->Add(&nv);
+    c->shard[i % 2].GetNoder("n")->Add(&nv);
+  }
+  IndexOption opt;
+  opt.name = "sort";
+  for (GraphStore* s : all) {
+    Status st = s->GetGraph("e")->Build(opt);
+    if (st.ok()) st = s->GetNoder("n")->Build(opt);
+    if (!st.ok()) {
+      std::printf("store build failed: %s\n", st.ToString().c_str());
+      std::exit(2);
+    }
+  }
+  return c;
+}
+}  // namespace
+
+TEST(PartitionStitchTest, SamplersOnTwoDeviceStoresEqualOneStore) {
+  Cluster* c = BuildCluster();
+  std::vector<int64_t> ids;
+  for (int i = 0; i < 400; ++i) ids.push_back((i * 7) % 320);  // some ids have no edges at all
+  const char* names[4] = {"RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"};
+  HashPartitioner partitioner(2);
+  for (int n = 0; n < 4; ++n) {
+    Operator* op = OpFactory::GetInstance()->Create(names[n]);
+    SamplingRequest req("e", names[n], 6);
+    req.Set(ids.data(), (int32_t)ids.size());
+    req.SetCallCounter(1000 + n);  // one random stream for the whole logical request
+    SamplingResponse single;
+    OpFactory::GetInstance()->Set(&c->whole);
+    EXPECT_TRUE(op->Process(&req, &single).ok());
+
+    ShardsPtr<OpRequest> parts = partitioner.Partition(&req);
+    ShardsPtr<OpResponse> answers(new Shards<OpResponse>(2));
+    for (int s = 0; s < 2; ++s) {
+      OpFactory::GetInstance()->Set(&c->shard[s]);  // "server s"
+      SamplingResponse* r = new SamplingResponse;
+      EXPECT_TRUE(op->Process(parts->Get(s), r).ok());
+      answers->Add(s, r, true);
+      for (int32_t st : parts->StickerPtr()->At(s)) answers->StickerPtr()->Add(s, st);
+    }
+    SamplingResponse stitched;
+    stitched.Stitch(answers);
+    EXPECT_EQ(stitched.GetShape().dim1, ids.size());
+    bool same = true;
+    for (size_t i = 0; i < ids.size() * 6; ++i) same &= stitched.GetNeighborIds()[i] == single.GetNeighborIds()[i];
+    EXPECT_TRUE(same);  // edge ids are server-local in the reference too, so only neighbours are compared
+  }
+  OpFactory::GetInstance()->Set(&c->whole);
+}
+
+TEST(PartitionStitchTest, AggregatorsOnTwoDeviceStoresEqualOneStore) {
+  Cluster* c = BuildCluster();
+  std::vector<int64_t> ids;
+  std::vector<int32_t> seg;
+  std::mt19937 rng(3);
+  const int32_t sg = 120;
+  for (int32_t s = 0; s < sg; ++s) {
+    const int n = s % 7 == 0 ? 0 : 1 + rng() % 6;
+    for (int j = 0; j < n; ++j) {
+      ids.push_back(s % 11 == 3 ? (int64_t)(2 * (rng() % 150)) : (int64_t)(rng() % 300));  // some all-even segments
+      seg.push_back(s);
+    }
+  }
+  const char* names[5] = {"SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"};
+  HashPartitioner partitioner(2);
+  for (int n = 0; n < 5; ++n) {
+    Operator* op = OpFactory::GetInstance()->Create(names[n]);
+    AggregatingRequest req("n", names[n]);
+    req.Set(ids.data(), seg.data(), (int32_t)ids.size(), sg);
+    AggregatingResponse single;
+    OpFactory::GetInstance()->Set(&c->whole);
+    EXPECT_TRUE(op->Process(&req, &single).ok());
+    ShardsPtr<OpRequest> parts = partitioner.Partition(&req);
+    ShardsPtr<OpResponse> answers(new Shards<OpResponse>(2));
+    for (int s = 0; s < 2; ++s) {
+      if (parts->Get(s) == nullptr) continue;
+      OpFactory::GetInstance()->Set(&c->shard[s]);
+      AggregatingResponse* r = new AggregatingResponse;
+      EXPECT_TRUE(op->Process(parts->Get(s), r).ok());
+      answers->Add(s, r, true);
+    }
+    AggregatingResponse stitched;
+    stitched.Stitch(answers, GLOBAL_FLAG(DefaultFloatAttribute));
+    EXPECT_EQ(stitched.NumSegments(), sg);
+    bool ok = true;
+    for (int32_t i = 0; i < sg; ++i) {
+      ok &= stitched.Segments()[i] == single.Segments()[i];
+      for (int d = 0; d < 8; ++d) {
+        const float a = stitched.Embeddings()[i * 8 + d], b = single.Embeddings()[i * 8 + d];
+        // max / min: exact.  sum / mean / prod are re-associated across the two partials
+        // (1e-5 relative to the magnitudes summed; inputs are in [-100, 100]).
+        const bool good = (n == 2 || n == 3) ? a == b : std::fabs(a - b) <= 1e-5f * std::fabs(b) + 1e-3f * (n == 4 ? 0.f : 1.f);
+        if (!good && ok) std::printf("  %s segment %d dim %d: stitched %.9g single %.9g (count %d vs %d)\n", names[n], i, d, a, b, stitched.Segments()[i], single.Segments()[i]);
+        ok &= good;
+      }
+    }
+    EXPECT_TRUE(ok);
+  }
+  OpFactory::GetInstance()->Set(&c->whole);
+}
+
+int main() { return RunAllTests(); }

@@ -1,6 +1,7 @@
 """The C++ host layer (graph-learn_amd/host: the mirror of graphlearn::op's
-registry / request / operator API) exercised by C++ test programs that restate
-the reference's sampler_unittest.cpp and aggregating_op_unittest.cpp."""
+registry / request / operator / partition-stitch API) exercised by C++ test programs
+that restate the reference's sampler_unittest.cpp, aggregating_op_unittest.cpp and
+partition_stitch_unittest.cpp."""
 import ctypes
 import os
 import subprocess
@@ -10,7 +11,7 @@ import pytest
 import glx
 
 LIB = os.path.join(os.path.dirname(glx.LIB_PATH))
-BINARIES = ["sampler_unittest", "aggregating_op_unittest"]
+BINARIES = ["sampler_unittest", "aggregating_op_unittest", "partition_stitch_unittest"]
 
 
 def run(name):
