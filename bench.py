@@ -286,6 +286,14 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="after timing, recompute one step on an unpartitioned copy of the graph held by this "
                          "rank and require bit-identical outputs from the sharded path")
+    ap.add_argument("--ablations", default="auto", choices=["auto", "on", "off"],
+                    help="N>1 with replicated features: after the timed region, also time a few steps with "
+                         "the feature table kept edge-cut sharded -- design H (per-request halo exchange), H "
+                         "with distinct ids only, design R (owners reduce, requester folds partials) -- and "
+                         "report them under \"ablations\" (auto = on for N>1)")
+    ap.add_argument("--ablation-steps", type=int, default=3)
+    ap.add_argument("--ablation-time-limit", type=float, default=240.0,
+                    help="s; if the ablation legs have not finished by then the main result is printed without them")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
@@ -365,9 +373,15 @@ def main():
         x_shard = X[rank::world].contiguous()
         del X
         X = None
+        store_h = None
+        want_ablations = args.ablations == "on" or (args.ablations == "auto" and world > 1)
         if args.features == "replicated" or (args.features == "auto" and V * D * 4 <= 96 * (1 << 30)):
             # halo exchange done once, at load time: all-gather the shards over RCCL
             full = gdist.replicate_features(x_shard, V)
+            if want_ablations:  # the same shard, kept edge-cut, for the per-request exchange legs
+                ids = torch.arange(rank, V, world, dtype=torch.int64, device=dev)
+                store_h = gdist.ShardedStore(gdist.DeviceOps(), graph, glx.Features(x_shard, ids=ids, device=local_rank))
+                del ids
             del x_shard
             replica = glx.Features(full, device=local_rank)
             del full
@@ -511,6 +525,55 @@ def main():
 
     edges_per_step = n1 + n2  # response slots, padding included
     value = world * edges_per_step * args.steps / elapsed
+    res_holder = {}
+
+    def emit(extra):
+        if res_holder.get("done"):
+            return
+        res_holder["done"] = True
+        out = dict(res_holder["res"])
+        out.update(extra)
+        if rank == 0:
+            result_out.write(json.dumps(out) + "\n")
+            result_out.flush()
+
+    def run_ablations():
+        """Per-request feature exchange instead of the load-time replica (north_star's
+        'halo-vertex feature exchange via RCCL all-to-all'), same graph, same requests,
+        un-pipelined; each leg is checked against the replica's answer for one step."""
+        legs = {}
+        exact = agg in ("MaxAggregator", "MinAggregator")
+        K = max(1, args.ablation_steps)
+        for key, kw in (("features_sharded_halo_exchange_H", dict(mode="halo")),
+                        ("features_sharded_halo_exchange_H_distinct_ids", dict(mode="halo", dedup=True)),
+                        ("features_sharded_partial_reduce_R", dict(mode="partial"))):
+            def one(i):
+                a, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
+                b, _ = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=4 * i + 1)
+                e2, c2 = store_h.aggregate(agg, b.view(-1), seg2, n1, **kw)
+                e1, c1 = store_h.aggregate(agg, a.view(-1), seg1, B0, **kw)
+                return b, e2, c2
+            one(0)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(K):
+                b, e2, c2 = one(args.warmup + i % max(args.steps, 1))
+            barrier()
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt], device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            we2, wc2 = store.aggregate(agg, b.view(-1), seg2, n1)  # the replica's (single-shard) answer
+            if exact or kw["mode"] == "halo":
+                same = torch.equal(e2.view(torch.int32), we2.view(torch.int32))
+            else:
+                same = torch.allclose(e2, we2, rtol=1e-5, atol=1e-4)
+            same = bool(same and torch.equal(c2, wc2))
+            del e2, c2, we2, wc2, b
+            torch.cuda.empty_cache()
+            legs[key] = {"ms_per_step": float(t.item()) / K * 1e3, "value": world * edges_per_step * K / float(t.item()),
+                         "steps": K, "equals_replica_result": same}
+            log("ablation %s: %.2f ms/step (%s)" % (key, legs[key]["ms_per_step"], "ok" if same else "MISMATCH"))
+        return legs
     # dominant kernel: the hop-2 segmented reduce (first aggregate launch of each step)
     agg2 = t_agg[0::2] if store is None else t_agg[0::2]
     agg1 = t_agg[1::2]
@@ -559,9 +622,26 @@ def main():
         res["verified_sharded_equals_unpartitioned"] = verified
     if cpu:
         res["gpu_over_cpu"] = value / cpu["value"]
-    if rank == 0:
-        result_out.write(json.dumps(res) + "\n")
-        result_out.flush()
+    res_holder["res"] = res
+    if sharded and store is not None and store_h is not None:
+        # The headline number is already final.  The ablation legs exchange feature rows
+        # per request; a watchdog prints the result without them should they stall.
+        import threading
+
+        def give_up():
+            emit({"ablations": "not finished within %.0f s" % args.ablation_time_limit})
+            os._exit(3 if verified is False else 0)
+        dog = threading.Timer(args.ablation_time_limit, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            legs = run_ablations()
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line
+            legs = "failed: %r" % (ex,)
+        dog.cancel()
+        emit({"ablations": legs})
+    else:
+        emit({})
     if sharded:
         dist.destroy_process_group()
     if verified is False:

@@ -264,6 +264,64 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
   return GLX_OK;
 }
 
+// ---- AggregatingResponse::Stitch (aggregating_request.cc:172-213) on the device:
+// fold P partial results [P][Sg][dim] in shard order, starting from InitFunc's
+// value.  Pure streaming (reads P*Sg*dim*4 B once, coalesced; writes Sg*dim*4 B):
+// one thread per VEC output columns of one segment.
+template <int OP, int VEC>
+__global__ __launch_bounds__(256) void glx_agg_stitch_kernel(const float* __restrict__ parts,
+                                                             const int32_t* __restrict__ cnts, int32_t P,
+                                                             int64_t num_segments, int32_t dim,
+                                                             float default_attr, float* __restrict__ out,
+                                                             int32_t* __restrict__ cnt_out) {
+  const int32_t cols = dim / VEC;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= num_segments * cols) return;
+  const int64_t sg = t / cols;
+  const int32_t c0 = (int32_t)(t - sg * cols) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = agg_init<OP>();
+  int32_t total = 0;
+  for (int32_t p = 0; p < P; ++p) {
+    const int32_t c = cnts[(int64_t)p * num_segments + sg];
+    if (c == 0) continue;  // this shard saw none of the segment's ids
+    const float* src = parts + ((int64_t)p * num_segments + sg) * dim + c0;
+    float r[VEC];
+    if (VEC == 4) {
+      const float4 q = *reinterpret_cast<const float4*>(src);
+      r[0] = q.x; r[1 % VEC] = q.y; r[2 % VEC] = q.z; r[3 % VEC] = q.w;
+    } else {
+      r[0] = src[0];
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      // Mean: left += right * segments[i] (mean_aggregator.cc:31-37)
+      const float x = OP == GLX_AGG_MEAN ? r[v] * (float)c : r[v];
+      acc[v] = agg_combine<OP>(acc[v], x);
+    }
+    total += c;
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    if (total == 0) acc[v] = default_attr;                       // aggregator.cc:74-86
+    else if (OP == GLX_AGG_MEAN) acc[v] = acc[v] / (float)total;  // mean_aggregator.cc:45-61
+  }
+  float* dst = out + sg * dim + c0;
+  if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+  else dst[0] = acc[0];
+  if (c0 == 0) cnt_out[sg] = total;
+}
+
+template <int OP>
+void launch_agg_stitch(bool vec4, const float* parts, const int32_t* cnts, int32_t P, int64_t sg, int32_t dim,
+                       float default_attr, float* out, int32_t* cnt_out, hipStream_t s) {
+  const int64_t threads = sg * (vec4 ? dim / 4 : dim);
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  if (vec4) glx_agg_stitch_kernel<OP, 4><<<grid, 256, 0, s>>>(parts, cnts, P, sg, dim, default_attr, out, cnt_out);
+  else glx_agg_stitch_kernel<OP, 1><<<grid, 256, 0, s>>>(parts, cnts, P, sg, dim, default_attr, out, cnt_out);
+}
+
 }  // namespace
 
 extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
@@ -467,5 +525,29 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
   glx_scratch_free(d, s);
   GLX_HIP(e);
   GLX_HIP(e2);
+  return GLX_OK;
+}
+
+extern "C" int glx_aggregate_stitch(int device, int op, int32_t num_parts, const float* parts,
+                                    const int32_t* cnts, int32_t num_segments, int32_t dim,
+                                    float default_attr, float* emb_out, int32_t* cnt_out, void* stream) {
+  GLX_REQUIRE(op >= GLX_AGG_SUM && op <= GLX_AGG_PROD, "unknown aggregator %d", op);
+  GLX_REQUIRE(num_parts >= 1 && num_segments >= 0 && dim >= 1, "bad sizes");
+  if (num_segments == 0) return GLX_OK;
+  GLX_REQUIRE(parts && cnts && emb_out && cnt_out, "NULL data pointer");
+  int rc = glx_init_device(device);
+  if (rc != GLX_OK) return rc;
+  GlxDeviceGuard guard(device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", device);
+  hipStream_t s = glx_stream(stream);
+  const bool vec4 = dim % 4 == 0 && ((uintptr_t)parts % 16 == 0) && ((uintptr_t)emb_out % 16 == 0);
+  switch (op) {
+    case GLX_AGG_SUM: launch_agg_stitch<GLX_AGG_SUM>(vec4, parts, cnts, num_parts, num_segments, dim, default_attr, emb_out, cnt_out, s); break;
+    case GLX_AGG_MEAN: launch_agg_stitch<GLX_AGG_MEAN>(vec4, parts, cnts, num_parts, num_segments, dim, default_attr, emb_out, cnt_out, s); break;
+    case GLX_AGG_MAX: launch_agg_stitch<GLX_AGG_MAX>(vec4, parts, cnts, num_parts, num_segments, dim, default_attr, emb_out, cnt_out, s); break;
+    case GLX_AGG_MIN: launch_agg_stitch<GLX_AGG_MIN>(vec4, parts, cnts, num_parts, num_segments, dim, default_attr, emb_out, cnt_out, s); break;
+    default: launch_agg_stitch<GLX_AGG_PROD>(vec4, parts, cnts, num_parts, num_segments, dim, default_attr, emb_out, cnt_out, s); break;
+  }
+  GLX_HIP(hipGetLastError());
   return GLX_OK;
 }

@@ -14,10 +14,17 @@ out-edges and the features of vertex v live on shard llabs(v) % P
 Results are bit-identical to the unpartitioned operator for every shard count:
   * sampling ships each row's index in the original request with its id and
     the owner draws from THAT row's random stream (glx_sample_ex);
-  * aggregation ships ids to the owners, gathers feature rows there
-    (glx_lookup), ships the rows back (the halo exchange) and reduces them on
-    the requester in the original order -- so the reference's distributed
-    Max/Min/Prod divergence does not occur.
+  * aggregation, design H (the default): ships ids to the owners, gathers feature
+    rows there (glx_lookup), ships the rows back (the halo exchange) and reduces
+    them on the requester in the original order -- bit-identical, and the
+    reference's distributed Max/Min/Prod divergence does
+    not occur.  `dedup=True` ships every distinct halo id once.
+  * aggregation, design R (`mode="partial"`, the reference's own scheme,
+    aggregating_request.cc:117-213): ships (id, segment) to the owners, every owner
+    reduces its subset (glx_aggregate), the [Sg, D] partials come back and
+    glx_aggregate_stitch folds them in shard order.  Max/Min stay exact; Sum/Mean/
+    Prod are re-associated across shards (within 1e-5 relative).  Cheaper than H on
+    the wire when the mean segment length exceeds the shard count.
 
 `ops` abstracts the local compute: DeviceOps (HIP, the product) or, in the CPU
 tests only, an oracle-backed stand-in.  Tensors are torch tensors throughout.
@@ -52,6 +59,9 @@ class DeviceOps:
 
     def aggregate_local(self, feats, op, node_ids, seg, num_segments, default_attr):
         return feats.aggregate(op, node_ids, seg, num_segments, default_attr)
+
+    def aggregate_stitch(self, op, parts, cnts, default_attr):
+        return self.glx.aggregate_stitch(op, parts, cnts, default_attr)
 
 
 def _staged(x, group):
@@ -113,19 +123,56 @@ class ShardedStore:
         eid = _a2a(eid, recv, send, self.group)
         return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
 
-    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0):
+    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, mode="halo", dedup=False):
         if self.replica is not None:
             return self.ops.aggregate_local(self.replica, op, node_ids, segment_ids, num_segments,
                                             default_attr)
+        if mode == "partial":
+            return self._aggregate_partial(op, node_ids, segment_ids, num_segments, default_attr)
+        assert mode == "halo", mode
+        n = node_ids.shape[0]
+        inverse = None
+        if dedup:
+            # every distinct id crosses the links once; the reduce reads the halo table through `inverse`
+            node_ids, inverse = torch.unique(node_ids, return_inverse=True)
         bucketed, order, send, recv = self._route(node_ids)
         ids_in = _a2a(bucketed, send, recv, self.group)
         rows = self.ops.lookup(self.feats, ids_in, default_attr)
         rows = _a2a(rows, recv, send, self.group)  # halo rows, in bucketed order
-        # pos[i] = where original element i sits in `rows` (inverse of `order`)
-        n = node_ids.shape[0]
-        pos = self.ops.stitch(torch.arange(n, dtype=torch.int64, device=node_ids.device).view(n, 1),
-                              order).view(n)
+        # pos[i] = where (distinct) element i sits in `rows` (inverse of `order`)
+        m = node_ids.shape[0]
+        pos = self.ops.stitch(torch.arange(m, dtype=torch.int64, device=node_ids.device).view(m, 1),
+                              order).view(m)
+        if inverse is not None:
+            pos = pos[inverse]
         return self.ops.aggregate_rows(rows, pos, segment_ids, num_segments, op, default_attr)
+
+    def _aggregate_partial(self, op, node_ids, segment_ids, num_segments, default_attr):
+        """Design R: owners reduce, the requester folds the partials (AggregatingRequest::
+        Partition / AggregatingResponse::Stitch, aggregating_request.cc:117-213)."""
+        bucketed, order, send, recv = self._route(node_ids)
+        # every owner needs each requester's segment count (requests differ per rank)
+        mine = torch.tensor([int(num_segments)], dtype=torch.int64)
+        if dist.get_backend(self.group) != "gloo":
+            mine = mine.to(node_ids.device)
+        sgs = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(sgs, mine, group=self.group)
+        sg_of = [int(x.item()) for x in sgs]
+        ids_in = _a2a(bucketed, send, recv, self.group)
+        seg_in = _a2a(segment_ids[order].contiguous(), send, recv, self.group)  # stays non-decreasing per requester
+        embs, cnts = [], []
+        at = 0
+        for q in range(self.world):
+            e, c = self.ops.aggregate_local(self.feats, op, ids_in[at:at + recv[q]], seg_in[at:at + recv[q]],
+                                            sg_of[q], default_attr)
+            embs.append(e)
+            cnts.append(c)
+            at += recv[q]
+        back = [int(num_segments)] * self.world
+        parts = _a2a(torch.cat(embs), sg_of, back, self.group)   # [P * Sg, D], shard-major
+        pcnt = _a2a(torch.cat(cnts), sg_of, back, self.group)    # [P * Sg]
+        return self.ops.aggregate_stitch(op, parts.view(self.world, num_segments, -1),
+                                         pcnt.view(self.world, num_segments), default_attr)
 
 
 def shard_graph(row_ptr, col, eid, weight, rank, world):

@@ -43,7 +43,7 @@ EXPORTS = [
     "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
-    "glx_partition", "glx_stitch_i64", "glx_stitch_f32",
+    "glx_partition", "glx_stitch_i64", "glx_stitch_f32", "glx_aggregate_stitch",
     "glx_profile_enable", "glx_profile_collect",
 ]
 
@@ -100,6 +100,7 @@ def lib():
         L.glx_partition.argtypes = [ci, vp, i64, i32, vp, vp, vp, vp]
         L.glx_stitch_i64.argtypes = [ci, vp, vp, i64, i32, vp, vp]
         L.glx_stitch_f32.argtypes = [ci, vp, vp, i64, i32, vp, vp]
+        L.glx_aggregate_stitch.argtypes = [ci, ci, i32, vp, vp, i32, i32, f32, vp, vp, vp]
         L.glx_profile_enable.argtypes = [ci]
         L.glx_profile_collect.argtypes = [ci, vp, i32, ctypes.POINTER(i32)]
         _lib = L
@@ -381,6 +382,23 @@ def stitch(rows, order):
     assert rows.dtype in (torch.int64, torch.float32)
     _check(fn(dev, _ptr(rows)[0], _ptr(order)[0], n, width, _ptr(out)[0], _stream(PTR_DEVICE)))
     return out
+
+
+def aggregate_stitch(op, parts, cnts, default_attr=0.0):
+    """Device AggregatingResponse::Stitch: parts [P, Sg, D] float32 + cnts [P, Sg] int32
+    (torch CUDA, contiguous: the receive buffers of one all-to-all) -> (emb [Sg, D], cnt [Sg])."""
+    import torch
+    if isinstance(op, str):
+        op = AGGREGATOR_IDS[op]
+    P, sg, dim = (int(x) for x in parts.shape)
+    assert parts.dtype == torch.float32 and cnts.dtype == torch.int32 and tuple(cnts.shape) == (P, sg)
+    assert parts.is_contiguous() and cnts.is_contiguous()
+    emb = torch.empty((sg, dim), dtype=torch.float32, device=parts.device)
+    cnt = torch.empty((sg,), dtype=torch.int32, device=parts.device)
+    dev = parts.device.index or 0
+    _check(lib().glx_aggregate_stitch(dev, op, P, _ptr(parts)[0], _ptr(cnts)[0], sg, dim, default_attr,
+                                      _ptr(emb)[0], _ptr(cnt)[0], _stream(PTR_DEVICE)))
+    return emb, cnt
 
 
 KERNEL_SAMPLE, KERNEL_AGGREGATE, KERNEL_LOOKUP = 0, 1, 2

@@ -125,7 +125,10 @@ void AggregatingResponse::Stitch(ShardsPtr<OpResponse> shards, float default_att
   if (name == "MaxAggregator") op = kMax;
   if (name == "MinAggregator") op = kMin;
   if (name == "ProdAggregator") op = kProd;
+  // InitFunc (aggregator.cc:61-65, max_/min_/prod_aggregator.cc)
+  const float init = op == kMax ? (float)FLT_MIN_10_EXP : op == kMin ? FLT_MAX : op == kProd ? 1.0f : 0.0f;
   for (int32_t i = 0; i < sg; ++i) cnt[i] = 0;
+  for (int64_t i = 0; i < (int64_t)sg * dim; ++i) emb[i] = init;
   shards->ResetNext();
   while (shards->Next(&shard_id, &tmp)) {
     AggregatingResponse* part = static_cast<AggregatingResponse*>(tmp);
@@ -135,11 +138,9 @@ void AggregatingResponse::Stitch(ShardsPtr<OpResponse> shards, float default_att
       if (pc[i] == 0) continue;  // this shard holds none of the segment's ids
       float* e = emb + (int64_t)i * dim;
       const float* p = pe + (int64_t)i * dim;
-      const bool fresh = cnt[i] == 0;
       for (int32_t c = 0; c < dim; ++c) {
         const float v = op == kMean ? p[c] * pc[i] : p[c];  // partial mean -> partial sum
-        if (fresh) e[c] = v;
-        else if (op == kSum || op == kMean) e[c] = e[c] + v;
+        if (op == kSum || op == kMean) e[c] = e[c] + v;
         else if (op == kMax) e[c] = (e[c] < v) ? v : e[c];
         else if (op == kMin) e[c] = (v < e[c]) ? v : e[c];
         else e[c] = e[c] * v;

@@ -244,6 +244,18 @@ GLX_API int glx_stitch_i64(int device, const int64_t* in, const int64_t* order, 
 GLX_API int glx_stitch_f32(int device, const float* in, const int64_t* order, int64_t n, int32_t width,
                    float* out, void* stream);
 
+/* glx_aggregate_stitch: replaces AggregatingResponse::Stitch
+ *   (aggregating_request.cc:172-213 + the aggregators' AggFunc/FinalFunc): combines the
+ *   partial results of `num_parts` shards, parts[num_parts][num_segments*dim] and
+ *   cnts[num_parts][num_segments] (the receive buffers of one all-to-all), folding in
+ *   shard order from InitFunc's value; Mean re-weights partial means by their counts.
+ *   A shard with count 0 for a segment is skipped (the reference folds its
+ *   DefaultFloatAttribute row in, which corrupts Max/Min/Prod: SURVEY 8(a) quirk 8);
+ *   when no partial is empty the result is bit-identical to the reference's Stitch. */
+GLX_API int glx_aggregate_stitch(int device, int op, int32_t num_parts, const float* parts,
+                                 const int32_t* cnts, int32_t num_segments, int32_t dim, float default_attr,
+                                 float* emb_out, int32_t* cnt_out, void* stream);
+
 /* ---- kernel timing: the device-side counterpart of the reference's
  * PROFILING(key) scope timers (common/base/profiling.h:24-71). ------------
  * While enabled (per host thread), every glx_sample / glx_aggregate /

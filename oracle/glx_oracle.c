@@ -428,3 +428,51 @@ void glxo_stitch_i64(const int64_t* shard_major, const int64_t* order, int64_t n
   for (int64_t i = 0; i < n; ++i)
     memcpy(out + order[i] * width, shard_major + i * width, sizeof(int64_t) * (size_t)width);
 }
+
+int glxo_aggregate_stitch(int op, int32_t P, const float* parts, const int32_t* cnts,
+                          int32_t num_segments, int32_t dim, float default_attr, int reference_fold,
+                          float* emb_out, int32_t* cnt_out) {
+  if (op < GLXO_SUM || op > GLXO_PROD) return 3;
+  float init = 0.0f; /* InitFunc, as in glxo_aggregate */
+  if (op == GLXO_MAX) init = (float)FLT_MIN_10_EXP;
+  if (op == GLXO_MIN) init = FLT_MAX;
+  if (op == GLXO_PROD) init = 1.0f;
+  for (int32_t s = 0; s < num_segments; ++s) {
+    float* emb = emb_out + (int64_t)s * dim;
+    for (int32_t i = 0; i < dim; ++i) emb[i] = init;
+    int32_t total = 0;
+    for (int32_t p = 0; p < P; ++p) { /* shards->Next(): ascending shard id */
+      const int32_t c = cnts[(int64_t)p * num_segments + s];
+      const float* a = parts + ((int64_t)p * num_segments + s) * dim;
+      if (c == 0 && !reference_fold) continue;
+      switch (op) {
+        case GLXO_SUM:
+          for (int32_t i = 0; i < dim; ++i) emb[i] = emb[i] + a[i];
+          break;
+        case GLXO_MEAN: /* left += right * segments[i] (int -> float) */
+          for (int32_t i = 0; i < dim; ++i) {
+            const float w = a[i] * (float)c;
+            emb[i] = emb[i] + w;
+          }
+          break;
+        case GLXO_MAX:
+          for (int32_t i = 0; i < dim; ++i) emb[i] = (emb[i] < a[i]) ? a[i] : emb[i];
+          break;
+        case GLXO_MIN:
+          for (int32_t i = 0; i < dim; ++i) emb[i] = (a[i] < emb[i]) ? a[i] : emb[i];
+          break;
+        case GLXO_PROD:
+          for (int32_t i = 0; i < dim; ++i) emb[i] = emb[i] * a[i];
+          break;
+      }
+      total += c;
+    }
+    if (total == 0) {
+      for (int32_t i = 0; i < dim; ++i) emb[i] = default_attr;
+    } else if (op == GLXO_MEAN) {
+      for (int32_t i = 0; i < dim; ++i) emb[i] = emb[i] / (float)total;
+    }
+    cnt_out[s] = total;
+  }
+  return 0;
+}

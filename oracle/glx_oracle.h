@@ -103,6 +103,18 @@ int glxo_aggregate(const float* feats, int64_t V, int32_t dim, const int64_t* id
  * shard (the concatenated Sticker lists); counts_out[P]. */
 void glxo_partition(const int64_t* ids, int64_t n, int32_t P, int64_t* order_out,
                     int64_t* counts_out);
+/* Restates AggregatingResponse::Stitch (aggregating_request.cc:172-213) with the
+ * aggregators' AggFunc/FinalFunc (sum_/mean_/max_/min_/prod_aggregator.cc):
+ * parts[P][num_segments*dim] + cnts[P][num_segments] partial results -> one result.
+ * Fold order = shard order, starting from InitFunc's value; Mean re-weights each
+ * partial mean by its count and divides by the total (mean_aggregator.cc:31-37,45-61).
+ * ONE deliberate difference: a shard that saw none of a
+ * segment's ids (count 0) is skipped instead of folding its DefaultFloatAttribute
+ * row in, so Max/Min/Prod equal the single-shard answer.  `reference_fold` != 0
+ * restores the reference's behaviour (used to pin this function against it). */
+int glxo_aggregate_stitch(int op, int32_t P, const float* parts, const int32_t* cnts,
+                          int32_t num_segments, int32_t dim, float default_attr, int reference_fold,
+                          float* emb_out, int32_t* cnt_out);
 /* Restates Stitcher::DoStitch (stitcher.h:67-107) for dense row payloads:
  * out[order[i]] = shard_major[i], each row `width` int64s. */
 void glxo_stitch_i64(const int64_t* shard_major, const int64_t* order, int64_t n, int32_t width,

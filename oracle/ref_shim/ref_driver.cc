@@ -206,6 +206,29 @@ int glref_aggregate(void* h, const char* node_type, const char* strategy, const 
   return 0;
 }
 
+// The reference's own cross-shard combine, AggregatingResponse::Stitch
+// (aggregating_request.cc:172-213), fed with P hand-built shard responses.
+int glref_aggregate_stitch(const char* strategy, int32_t P, const float* parts, const int32_t* cnts,
+                           int32_t num_segments, int32_t dim, float* emb_out, int32_t* cnt_out) {
+  ShardsPtr<OpResponse> shards(new Shards<OpResponse>(P));
+  for (int32_t p = 0; p < P; ++p) {
+    AggregatingResponse* r = new AggregatingResponse;
+    r->SetName(strategy);
+    r->SetEmbeddingDim(dim);
+    r->SetNumSegments(num_segments);
+    for (int32_t s = 0; s < num_segments; ++s) {
+      r->AppendEmbedding(parts + ((int64_t)p * num_segments + s) * dim);
+      r->AppendSegment(cnts[(int64_t)p * num_segments + s]);
+    }
+    shards->Add(p, r, true);
+  }
+  AggregatingResponse out;
+  out.Stitch(shards);
+  memcpy(emb_out, out.Embeddings(), sizeof(float) * (size_t)dim * num_segments);
+  memcpy(cnt_out, out.Segments(), sizeof(int32_t) * num_segments);
+  return 0;
+}
+
 // FullSampler (full_sampler.cc:28-97) answers with a sparse response: per-row
 // neighbour counts (Shape::segments) + concatenated values.  degrees_out[batch];
 // nbr_out / eid_out need capacity `cap`; returns the total or -(error code) - 1.

@@ -272,6 +272,55 @@ def gen_agg(ref):
     np.savez_compressed(os.path.join(HERE, "agg.npz"), **out)
 
 
+def gen_agg_stitch(ref):
+    """The reference's distributed aggregation end to end: node table split over 3
+    "servers" by llabs(id) % 3, every server aggregates its part of the request
+    (AggregatingRequest::Partition keeps the segment ids), AggregatingResponse::Stitch
+    folds the partial responses.  Stored next to the single-server answer."""
+    out = {}
+    rng = np.random.default_rng(33)
+    P, V = 3, 240
+    case = 0
+    for D in (4, 7, 64):
+        for dflt in (0.0, 2.5):
+            raw = np.arange(V, dtype=np.int64) * 7 - 500
+            X = (rng.standard_normal((V, D)) * 10).astype(np.float32)
+            ref.set_flags(1, 0, dflt)
+            ref.add_nodes("st%d_all" % case, raw, X)
+            owner = np.abs(raw) % P
+            for p in range(P):
+                ref.add_nodes("st%d_p%d" % (case, p), raw[owner == p], X[owner == p])
+            Sg = 41
+            sizes = rng.integers(0, 10, Sg)
+            sizes[[0, 9, Sg - 1]] = 0
+            seg = np.repeat(np.arange(Sg, dtype=np.int32), sizes)
+            nid = raw[rng.integers(0, V, seg.shape[0])].copy()
+            nid[rng.random(seg.shape[0]) < 0.05] = 123456789  # unknown id: its owner contributes a default row
+            own = np.abs(nid) % P
+            out["c%d_X" % case] = X
+            out["c%d_raw" % case] = raw
+            out["c%d_ids" % case] = nid
+            out["c%d_seg" % case] = seg
+            out["c%d_default" % case] = np.float32(dflt)
+            out["c%d_num_segments" % case] = np.array(Sg)
+            for name in AGGREGATORS:
+                parts = np.zeros((P, Sg, D), np.float32)
+                cnts = np.zeros((P, Sg), np.int32)
+                for p in range(P):
+                    parts[p], cnts[p] = ref.aggregate("st%d_p%d" % (case, p), name, nid[own == p], seg[own == p], Sg, D)
+                emb, cnt = ref.aggregate_stitch(name, parts, cnts)
+                one, one_cnt = ref.aggregate("st%d_all" % case, name, nid, seg, Sg, D)
+                assert np.array_equal(cnt, one_cnt)
+                out["c%d_%s_parts" % (case, name)] = parts
+                out["c%d_%s_cnts" % (case, name)] = cnts
+                out["c%d_%s_stitched" % (case, name)] = emb
+                out["c%d_%s_single" % (case, name)] = one
+                out["c%d_%s_cnt" % (case, name)] = cnt
+            case += 1
+    out["num_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(HERE, "agg_stitch.npz"), **out)
+
+
 def main():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -280,6 +329,7 @@ def main():
     gen_dist(ref)
     gen_dist_indegree(ref)
     gen_agg(ref)
+    gen_agg_stitch(ref)
     # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()
     print("golden fixtures written to", HERE)

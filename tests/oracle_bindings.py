@@ -49,6 +49,7 @@ class Oracle:
         L.glxo_sample_full.argtypes = [ctypes.POINTER(_CGraph), VP, i32, i32, VP, VP, VP, i64]
         L.glxo_sample_full.restype = i64
         L.glxo_partition.argtypes = [VP, i64, i32, VP, VP]
+        L.glxo_aggregate_stitch.argtypes = [ctypes.c_int, i32, VP, VP, i32, i32, ctypes.c_float, ctypes.c_int, VP, VP]
         L.glxo_stitch_i64.argtypes = [VP, VP, i64, i32, VP]
         L.glxo_set_reference_cost_model.argtypes = [ctypes.c_int]
         self.L = L
@@ -122,6 +123,20 @@ class Oracle:
         assert rc == 0, rc
         return emb, cnt
 
+    def aggregate_stitch(self, op, parts, cnts, default_attr=0.0, reference_fold=False):
+        """parts [P, Sg, D] f32, cnts [P, Sg] i32 -> (emb [Sg, D], cnt [Sg])."""
+        if isinstance(op, str):
+            op = AGGREGATORS.index(op)
+        parts = np.ascontiguousarray(parts, np.float32)
+        cnts = np.ascontiguousarray(cnts, np.int32)
+        P, Sg, D = parts.shape
+        emb = np.zeros((Sg, D), np.float32)
+        cnt = np.zeros(Sg, np.int32)
+        rc = self.L.glxo_aggregate_stitch(op, P, _p(parts), _p(cnts), Sg, D, default_attr, int(reference_fold),
+                                          _p(emb), _p(cnt))
+        assert rc == 0, rc
+        return emb, cnt
+
     def partition(self, ids, P):
         order = np.zeros(ids.shape[0], np.int64)
         counts = np.zeros(P, np.int64)
@@ -162,6 +177,7 @@ class RefLib:
         L.glref_edge_weight.restype = ctypes.c_float
         L.glref_sample.argtypes = [VP, cs, cs, VP, i32, i32, VP, VP, ctypes.c_int]
         L.glref_aggregate.argtypes = [VP, cs, cs, VP, VP, i32, i32, VP, VP, VP]
+        L.glref_aggregate_stitch.argtypes = [cs, i32, VP, VP, i32, i32, VP, VP]
         L.glref_sample_full.argtypes = [VP, cs, VP, i32, i32, VP, VP, VP, i64]
         L.glref_sample_full.restype = i64
         L.glref_in_degree.argtypes = [VP, cs, i64]
@@ -236,6 +252,16 @@ class RefLib:
         a = np.zeros(w.shape[0], np.int32)
         self.L.glref_alias_build(_p(w), w.shape[0], _p(p), _p(a))
         return p, a
+
+    def aggregate_stitch(self, strategy, parts, cnts):
+        parts = np.ascontiguousarray(parts, np.float32)
+        cnts = np.ascontiguousarray(cnts, np.int32)
+        P, Sg, D = parts.shape
+        emb = np.zeros((Sg, D), np.float32)
+        cnt = np.zeros(Sg, np.int32)
+        rc = self.L.glref_aggregate_stitch(strategy.encode(), P, _p(parts), _p(cnts), Sg, D, _p(emb), _p(cnt))
+        assert rc == 0, rc
+        return emb, cnt
 
     def aggregate(self, ntype, strategy, node_ids, segment_ids, num_segments, dim):
         emb = np.zeros((num_segments, dim), np.float32)

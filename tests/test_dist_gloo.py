@@ -60,7 +60,15 @@ class OracleOps:
         return torch.from_numpy(e), torch.from_numpy(c)
 
     def aggregate_local(self, feats, op, node_ids, seg, num_segments, default_attr):
-        e, c = self.o.aggregate(feats.numpy(), op, node_ids.numpy(), seg.numpy(), num_segments, default_attr)
+        if isinstance(feats, tuple):  # a shard: (rows, their raw ids)
+            X, raw = feats
+            e, c = self.o.aggregate(X, op, node_ids.numpy(), seg.numpy(), num_segments, default_attr, ids=raw)
+        else:
+            e, c = self.o.aggregate(feats.numpy(), op, node_ids.numpy(), seg.numpy(), num_segments, default_attr)
+        return torch.from_numpy(e), torch.from_numpy(c)
+
+    def aggregate_stitch(self, op, parts, cnts, default_attr):
+        e, c = self.o.aggregate_stitch(op, parts.numpy(), cnts.numpy(), default_attr)
         return torch.from_numpy(e), torch.from_numpy(c)
 
 
@@ -117,6 +125,18 @@ def _worker(rank, world, port, q):
             oemb, ocnt = orc.aggregate(X, name, ids, seg, Sg, 1.25)
             ok &= np.array_equal(cnt.numpy(), ocnt)
             ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
+            # the same with every distinct halo id shipped once
+            emb, cnt = store.aggregate(name, t(ids), t(seg), Sg, default_attr=1.25, dedup=True)
+            ok &= np.array_equal(cnt.numpy(), ocnt)
+            ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
+            # design R: owners reduce, the requester folds the partials.  Max/Min exact,
+            # counts exact, Sum/Mean/Prod re-associated across shards (1e-5 relative).
+            emb, cnt = store.aggregate(name, t(ids), t(seg), Sg, default_attr=1.25, mode="partial")
+            ok &= np.array_equal(cnt.numpy(), ocnt)
+            if name in ("MaxAggregator", "MinAggregator"):
+                ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
+            else:
+                ok &= bool(np.allclose(emb.numpy(), oemb, rtol=1e-5, atol=1e-5))
         # load-time halo exchange: all-gather the feature shards, then aggregate locally
         full = gdist.replicate_features(t(X[rank::world].copy()), X.shape[0])
         ok &= np.array_equal(full.numpy(), X)

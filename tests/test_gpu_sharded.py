@@ -86,6 +86,62 @@ def test_sharded_aggregation_equals_single_shard(world, P):
         assert torch.equal(e.view(torch.int32), ref_e.view(torch.int32)), name
 
 
+def test_device_aggregate_stitch_equals_oracle_on_reference_partials():
+    """glx_aggregate_stitch on the partial responses of a 3-server run of the reference
+    (tests/golden/agg_stitch.npz): bit-identical to the oracle's fold."""
+    from oracle_bindings import Oracle
+    orc = Oracle()
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "agg_stitch.npz")))
+    dev = torch.device("cuda", 0)
+    for c in range(int(g["num_cases"])):
+        dflt = float(g["c%d_default" % c])
+        for name in glx.AGGREGATOR_IDS:
+            parts, cnts = g["c%d_%s_parts" % (c, name)], g["c%d_%s_cnts" % (c, name)]
+            oe, oc = orc.aggregate_stitch(name, parts, cnts, dflt)
+            e, n = glx.aggregate_stitch(name, torch.from_numpy(parts).to(dev), torch.from_numpy(cnts).to(dev), dflt)
+            assert np.array_equal(n.cpu().numpy(), oc), (c, name)
+            assert np.array_equal(e.cpu().numpy().view(np.uint32), oe.view(np.uint32)), (c, name)
+
+
+@pytest.mark.parametrize("P", [2, 8])
+def test_partial_reduce_equals_single_shard(world, P):
+    """Design R: every shard store reduces its subset, glx_aggregate_stitch folds the
+    partials.  Counts and Max/Min are exact; device fold == oracle fold bit for bit."""
+    from oracle_bindings import Oracle
+    orc = Oracle()
+    whole, feats, shards, dev = world
+    _, fs = shards[P]
+    rng = np.random.default_rng(70 + P)
+    n, f = 24000, 12
+    ids = torch.from_numpy(rng.integers(-3, 5003, n).astype(np.int64)).to(dev)
+    # a few segments whose ids all live on one shard (multiples of P): other shards see nothing
+    ids.view(-1, f)[::7] = (ids.view(-1, f)[::7] // P) * P
+    seg = torch.from_numpy((np.arange(n) // f).astype(np.int32)).to(dev)
+    sg = n // f
+    for name in glx.AGGREGATOR_IDS:
+        ref_e, ref_c = feats.aggregate(name, ids, seg, sg, default_attr=0.5)
+        bucketed, order, counts = glx.partition(ids, P)
+        seg_b = seg[order].contiguous()
+        offs = np.concatenate([[0], np.cumsum(counts.cpu().numpy())])
+        pe, pc = [], []
+        for p in range(P):
+            a, b = int(offs[p]), int(offs[p + 1])
+            e, c = fs[p].aggregate(name, bucketed[a:b].contiguous(), seg_b[a:b].contiguous(), sg, default_attr=0.5)
+            pe.append(e)
+            pc.append(c)
+        parts, cnts = torch.stack(pe), torch.stack(pc)
+        e, c = glx.aggregate_stitch(name, parts, cnts, 0.5)
+        assert torch.equal(c, ref_c), name
+        oe, oc = orc.aggregate_stitch(name, parts.cpu().numpy(), cnts.cpu().numpy(), 0.5)
+        assert np.array_equal(e.cpu().numpy().view(np.uint32), oe.view(np.uint32)), name
+        if name in ("MaxAggregator", "MinAggregator"):
+            assert torch.equal(e.view(torch.int32), ref_e.view(torch.int32)), name
+        elif name != "ProdAggregator":
+            assert torch.allclose(e, ref_e, rtol=1e-5, atol=1e-4), name
+        else:
+            assert torch.allclose(e, ref_e, rtol=1e-4, atol=1e-30), name
+
+
 def test_sharded_store_over_rccl_world1(world):
     import torch.distributed as dist
     import dist as gdist
@@ -103,6 +159,11 @@ def test_sharded_store_over_rccl_world1(world):
         seg = (torch.arange(40000, device=dev) // 10).to(torch.int32)
         emb, cnt = store.aggregate("MeanAggregator", n.view(-1), seg, 4000)
         remb, rcnt = feats.aggregate("MeanAggregator", n.view(-1), seg, 4000)
+        assert torch.equal(cnt, rcnt) and torch.equal(emb.view(torch.int32), remb.view(torch.int32))
+        emb, cnt = store.aggregate("MeanAggregator", n.view(-1), seg, 4000, dedup=True)
+        assert torch.equal(cnt, rcnt) and torch.equal(emb.view(torch.int32), remb.view(torch.int32))
+        emb, cnt = store.aggregate("MaxAggregator", n.view(-1), seg, 4000, mode="partial")
+        remb, rcnt = feats.aggregate("MaxAggregator", n.view(-1), seg, 4000)
         assert torch.equal(cnt, rcnt) and torch.equal(emb.view(torch.int32), remb.view(torch.int32))
     finally:
         dist.destroy_process_group()

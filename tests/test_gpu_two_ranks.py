@@ -39,3 +39,13 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
     res = json.loads(lines[0])
     assert res["n_gpus"] == world and res["verified_sharded_equals_unpartitioned"] is True
     assert res["value"] > 0 and res["scaling"] == "weak"
+    if features == "replicated":
+        # the per-request exchange legs (design H, H over distinct ids, design R) ran after
+        # the timed region and reproduced the replica's aggregate on every rank
+        legs = res["ablations"]
+        assert set(legs) == {"features_sharded_halo_exchange_H", "features_sharded_halo_exchange_H_distinct_ids",
+                             "features_sharded_partial_reduce_R"}, legs
+        for leg in legs.values():
+            assert leg["equals_replica_result"] is True and leg["value"] > 0, legs
+    else:
+        assert "ablations" not in res

@@ -360,3 +360,58 @@ def test_in_degree_sampler_distribution(orc):
         for j in range(k):
             p = _two_sample_p(np.bincount(pos[:, j], minlength=d), g["hist"][r, j, :d])
             assert p > 1e-4, (r, j, p)
+
+
+def test_aggregate_stitch_golden(orc):
+    """a9: AggregatingResponse::Stitch (aggregating_request.cc:172-213).  The golden file
+    holds a 3-server run of the reference: per-server partial responses, the reference's
+    stitched response and the single-server answer for the same request."""
+    g = load("agg_stitch.npz")
+    diverged = set()
+    for c in range(int(g["num_cases"])):
+        dflt = float(g["c%d_default" % c])
+        for name in AGGREGATORS:
+            parts, cnts = g["c%d_%s_parts" % (c, name)], g["c%d_%s_cnts" % (c, name)]
+            ref_emb, single = g["c%d_%s_stitched" % (c, name)], g["c%d_%s_single" % (c, name)]
+            # 1. the restatement with the reference's fold == the reference, bit for bit
+            e, n = orc.aggregate_stitch(name, parts, cnts, dflt, reference_fold=True)
+            assert beq(e, ref_emb) and np.array_equal(n, g["c%d_%s_cnt" % (c, name)]), (c, name)
+            # 2. the contract fold (skip empty partials): bit-identical to the reference
+            #    wherever no partial of the segment is empty ...
+            e, n = orc.aggregate_stitch(name, parts, cnts, dflt)
+            full = (cnts > 0).all(axis=0) | (cnts.sum(axis=0) == 0)
+            assert beq(e[full], ref_emb[full]), (c, name)
+            # ... and equal to the SINGLE-server answer everywhere (Max/Min exactly; the
+            # sums are re-associated across servers)
+            if name in ("MaxAggregator", "MinAggregator"):
+                assert beq(e, single), (c, name)
+            else:
+                scale = np.abs(parts).max() * (cnts.sum(axis=0).max() if name != "ProdAggregator" else 1)
+                tol = 1e-5 * (np.abs(single) + (scale if name != "ProdAggregator" else 0.0))
+                assert (np.abs(e - single) <= tol + 1e-30).all(), (c, name)
+            if not beq(ref_emb, e):
+                diverged.add((name, dflt != 0.0))
+    # SURVEY 8(a) quirk 8: the reference's own distributed Max/Min/Prod fold the empty
+    # servers' DefaultFloatAttribute rows in.  Sum is only safe while that default is 0
+    # (x + 0); Mean always is (an empty partial has weight 0).
+    assert ("SumAggregator", False) not in diverged and ("SumAggregator", True) in diverged
+    assert not {d for d in diverged if d[0] == "MeanAggregator"}
+    assert {("MaxAggregator", False), ("MinAggregator", False), ("ProdAggregator", False)} <= diverged
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_aggregate_stitch_live_reference(orc):
+    rng = np.random.default_rng(8)
+    ref = RefLib()
+    try:
+        for P, Sg, D in ((2, 30, 5), (8, 17, 32)):
+            parts = (rng.standard_normal((P, Sg, D)) * 5).astype(np.float32)
+            parts[0, 0, 0] = -0.0
+            cnts = rng.integers(0, 4, (P, Sg)).astype(np.int32)
+            parts[cnts == 0] = 0.0
+            for name in AGGREGATORS:
+                e, n = orc.aggregate_stitch(name, parts, cnts, 0.0, reference_fold=True)
+                re_, rn = ref.aggregate_stitch(name, parts, cnts)
+                assert beq(e, re_) and np.array_equal(n, rn), (P, name)
+    finally:
+        ref.close()
