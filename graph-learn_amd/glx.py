@@ -181,7 +181,21 @@ class Graph:
         self.num_rows, self.num_edges = v.value, e.value
         return self
 
+    @classmethod
+    def from_handle(cls, handle, device=0):
+        """Borrow a glx_graph* owned by someone else (e.g. the C++ host layer's GraphStore)."""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p(int(handle))
+        self._borrowed = True
+        self.device = device
+        v, e = ctypes.c_int64(), ctypes.c_int64()
+        _check(lib().glx_graph_info(self._h, ctypes.byref(v), ctypes.byref(e), None, None, None))
+        self.num_rows, self.num_edges = v.value, e.value
+        return self
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = None
         if getattr(self, "_h", None):
             try:
                 lib().glx_graph_destroy(self._h)
@@ -284,7 +298,21 @@ class Features:
                                          _stream(kind), ctypes.byref(h)))
         self._h = h
 
+    @classmethod
+    def from_handle(cls, handle, device=0):
+        """Borrow a glx_features* owned by someone else (the C++ host layer's Noder)."""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p(int(handle))
+        self._borrowed = True
+        self.device = device
+        v, d = ctypes.c_int64(), ctypes.c_int32()
+        _check(lib().glx_features_info(self._h, ctypes.byref(v), ctypes.byref(d), None, None))
+        self.num_rows, self.dim = v.value, d.value
+        return self
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = None
         if getattr(self, "_h", None):
             try:
                 lib().glx_features_destroy(self._h)

@@ -1,0 +1,68 @@
+// In-process Client / Server of the local deploy mode -- the two objects the Python
+// layer holds (python/graph.py:438-443: Client(...), Server(0, 1, "", "").start(),
+// .init(edge_sources, node_sources)).  Mirrors graphlearn/src/include/client.h:33-80
+// and include/server.h:30-62 for that mode only: there is no RPC, no queue and no
+// tracker here; Client::RunOp is Executor::RunOp (service/executor.cc:34-44), i.e.
+// OpFactory::Create(name)->Process(req, res) on the caller's thread.
+#ifndef GLX_HOST_CLIENT_H_
+#define GLX_HOST_CLIENT_H_
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "graphlearn/aggregating_request.h"
+#include "graphlearn/data_source.h"
+#include "graphlearn/graph_request.h"
+#include "graphlearn/sampling_request.h"
+#include "graphlearn/status.h"
+
+namespace graphlearn {
+
+class Client {
+public:
+  ~Client();
+  Status Sampling(const SamplingRequest* request, SamplingResponse* response);
+  Status Aggregating(const AggregatingRequest* request, AggregatingResponse* response);
+  Status LookupNodes(const LookupNodesRequest* request, LookupNodesResponse* response);
+  Status LookupEdges(const LookupEdgesRequest* request, LookupEdgesResponse* response);
+  Status GetDegree(const GetDegreeRequest* request, GetDegreeResponse* response);
+  Status RunOp(const OpRequest* request, OpResponse* response);
+  Status Stop();
+
+private:
+  Client();
+  friend Client* NewInMemoryClient();
+};
+
+Client* NewInMemoryClient();
+
+class Server {
+public:
+  ~Server();
+  void Start();
+  // Loads every source (files of one type in the order given), builds all storages
+  // on the device and binds the operators to the store.  The reference's Init
+  // returns void and logs; this one keeps the first error for Status().
+  void Init(const std::vector<io::EdgeSource>& edges, const std::vector<io::NodeSource>& nodes);
+  void Stop();
+  const Status& InitStatus() const { return status_; }
+  GraphStore* Store() { return store_; }
+  // Device objects of a built type, for callers that keep their data in HBM (torch / DLPack
+  // users go straight to the C-ABI with these): 0 when the type is unknown or not built.
+  uintptr_t DeviceGraph(const std::string& edge_type);
+  uintptr_t DeviceFeatures(const std::string& node_type);
+
+private:
+  Server();
+  friend Server* NewServer(int32_t, int32_t, const std::string&, const std::string&);
+  GraphStore* store_;
+  Status status_;
+  bool bound_;  // the process-wide OpFactory currently serves THIS server's store
+};
+
+// Only (server_id 0, server_count 1) exists in local mode; host/tracker are ignored.
+Server* NewServer(int32_t server_id, int32_t server_count, const std::string& server_host,
+                  const std::string& tracker);
+
+}  // namespace graphlearn
+#endif  // GLX_HOST_CLIENT_H_

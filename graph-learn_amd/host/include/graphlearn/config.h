@@ -5,6 +5,7 @@
 #ifndef GLX_HOST_CONFIG_H_
 #define GLX_HOST_CONFIG_H_
 #include <cstdint>
+#include <string>
 
 namespace graphlearn {
 #define GLOBAL_FLAG(name) ::graphlearn::g##name
@@ -13,6 +14,11 @@ extern int32_t gPaddingMode;            // config.cc:94  (1 = circular)
 extern int64_t gDefaultNeighborId;      // config.cc:98  (0)
 extern float gDefaultFloatAttribute;    // config.cc:100 (0.0)
 extern float gDefaultWeight;            // config.cc:102 (0.0)
+extern int64_t gDefaultIntAttribute;    // config.cc:99  (0)
+extern std::string gDefaultStringAttribute;  // config.cc:101 ("")
+extern int64_t gDefaultLabel;           // config.cc:103 (-1)
+extern int64_t gDefaultTimestamp;       // config.cc:104 (-1)
+extern int32_t gIgnoreInvalid;          // config.cc:109 (1: skip records that fail to parse)
 extern int32_t gSamplingRetryTimes;     // config.cc:108 (5; filters only, unused on device)
 // New (the reference has no seed flag, include/config.h:77-118): the seed of the
 // glx seeding contract, and the GPU this process' GraphStore lives on.
@@ -23,6 +29,11 @@ void SetGlobalFlagPaddingMode(int32_t v);
 void SetGlobalFlagDefaultNeighborId(int64_t v);
 void SetGlobalFlagDefaultFloatAttribute(float v);
 void SetGlobalFlagDefaultWeight(float v);
+void SetGlobalFlagDefaultIntAttribute(int64_t v);
+void SetGlobalFlagDefaultStringAttribute(const std::string& v);
+void SetGlobalFlagDefaultLabel(int64_t v);
+void SetGlobalFlagDefaultTimestamp(int64_t v);
+void SetGlobalFlagIgnoreInvalid(int32_t v);
 void SetGlobalFlagSamplingRetryTimes(int32_t v);
 void SetGlobalFlagSamplingSeed(int64_t v);
 void SetGlobalFlagDeviceId(int32_t v);

@@ -13,6 +13,11 @@ extern const char* kEdgeIds;
 extern const char* kNeighborCount;
 extern const char* kStrategy;
 extern const char* kFloatAttrKey;
+extern const char* kIntAttrKey;
+extern const char* kWeightKey;
+extern const char* kLabelKey;
+extern const char* kTimestampKey;
+extern const char* kDegreeKey;
 extern const char* kSideInfo;
 extern const char* kSegmentIds;
 extern const char* kNumSegments;

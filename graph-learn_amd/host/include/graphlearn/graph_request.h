@@ -1,13 +1,19 @@
-// LookupNodesRequest / LookupNodesResponse -- the float-attribute part of the
-// reference's node lookup (graphlearn/src/include/graph_request.h:240-322,
-// core/graph/local_noder.cc:85-97, core/operator/graph/node_lookuper.cc:24-52):
-// the step that follows sampling in every pipeline (NeighborSampler.get ->
-// graph.get_nodes, python/sampler/neighbor_sampler.py:105-109).  SURVEY 8(f) rank 1.
-// Weights / labels / int / string attributes are not mirrored on the device.
+// LookupNodes / LookupEdges requests and their response -- the property lookup
+// that follows sampling in every pipeline (NeighborSampler.get -> graph.get_nodes /
+// get_edges, python/sampler/neighbor_sampler.py:105-121).  Mirrors
+// graphlearn/src/include/graph_request.h:160-322 (LookupEdgesRequest,
+// LookupNodesRequest, LookupResponse) and the operators
+// core/operator/graph/{node,edge}_lookuper.cc over LocalNoder::LookupNodes /
+// LocalGraph::LookupEdges (core/graph/local_noder.cc:85-97, local_graph.cc:72-85).
+// Float attributes of nodes are gathered on the device (glx_lookup); weights,
+// labels, timestamps, int and string attributes are host-resident columns.
+// SURVEY 8(f) rank 1.
 #ifndef GLX_HOST_GRAPH_REQUEST_H_
 #define GLX_HOST_GRAPH_REQUEST_H_
 #include <string>
+#include <vector>
 
+#include "graphlearn/graph_store.h"
 #include "graphlearn/op_request.h"
 
 namespace graphlearn {
@@ -27,18 +33,80 @@ private:
   mutable int32_t cursor_;
 };
 
-class LookupNodesResponse : public OpResponse {
+class LookupEdgesRequest : public OpRequest {
 public:
-  LookupNodesResponse();
-  OpResponse* New() const override { return new LookupNodesResponse; }
-  void SetShape(int32_t batch_size, int32_t float_attr_num);
+  LookupEdgesRequest();
+  explicit LookupEdgesRequest(const std::string& edge_type);
+  OpRequest* Clone() const override;
+  // src_ids route the request in distributed mode (graph_request.h:171-173); the
+  // lookup itself is by edge id.
+  void Set(const int64_t* edge_ids, const int64_t* src_ids, int32_t batch_size);
+  const std::string& EdgeType() const;
+  int32_t Size() const;
+  bool Next(int64_t* edge_id, int64_t* src_id) const;
+  const int64_t* EdgeIds() const;
+  const int64_t* SrcIds() const;
+
+private:
+  mutable int32_t cursor_;
+};
+
+// One response type for both lookups (graph_request.h:200-260): per element a
+// weight / label / timestamp (if the type has them) and i_num + f_num + s_num
+// attribute values, each kind in its own row-major array.
+class LookupResponse : public OpResponse {
+public:
+  LookupResponse();
+  OpResponse* New() const override { return new LookupResponse; }
+  void SetSideInfo(const io::SideInfo* info, int32_t batch_size);
   int32_t Size() const { return batch_size_; }
-  int32_t FloatAttrNum() const { return f_num_; }
-  const float* FloatAttrs() const;  // [Size() * FloatAttrNum()], row-major
+  int32_t Format() const { return info_.format; }
+  int32_t IntAttrNum() const { return info_.i_num; }
+  int32_t FloatAttrNum() const { return info_.f_num; }
+  int32_t StringAttrNum() const { return info_.s_num; }
+  void AppendWeight(float weight);
+  void AppendLabel(int32_t label);
+  void AppendTimestamp(int64_t timestamp);
+  // nullptr = AttributeValue::Default(side_info) (element_value.cc:26-50)
+  void AppendAttribute(const int64_t* ints, const float* floats, const std::string* strings);
+  const float* Weights() const;
+  const int32_t* Labels() const;
+  const int64_t* Timestamps() const;
+  const int64_t* IntAttrs() const;
+  const float* FloatAttrs() const;
+  const std::vector<std::string>& StringAttrs() const { return strings_; }
+  // device path: the float attributes arrive as one block
+  void SetShape(int32_t batch_size, int32_t float_attr_num);
   float* MutableFloatAttrs();
 
 private:
-  int32_t f_num_;
+  io::SideInfo info_;
+  std::vector<std::string> strings_;
+};
+
+typedef LookupResponse LookupNodesResponse;
+typedef LookupResponse LookupEdgesResponse;
+
+// GetDegreeRequest / GetDegreeResponse (graph_request.h:324-370): out-degrees of a
+// batch of vertices for one edge type, read from the device CSR (glx_graph_degrees).
+class GetDegreeRequest : public OpRequest {
+public:
+  GetDegreeRequest();
+  explicit GetDegreeRequest(const std::string& edge_type);
+  OpRequest* Clone() const override;
+  void Set(const int64_t* node_ids, int32_t batch_size);
+  const std::string& EdgeType() const;
+  int32_t Size() const;
+  const int64_t* NodeIds() const;
+};
+
+class GetDegreeResponse : public OpResponse {
+public:
+  GetDegreeResponse();
+  OpResponse* New() const override { return new GetDegreeResponse; }
+  void InitDegrees(int32_t batch_size);
+  const int32_t* GetDegrees() const;
+  int32_t* MutableDegrees();
 };
 
 }  // namespace graphlearn

@@ -32,6 +32,8 @@ struct SideInfo {
   std::string type, src_type, dst_type;
   bool IsInitialized() const { return format != 0; }
   bool IsWeighted() const { return format & kWeighted; }
+  bool IsLabeled() const { return format & kLabeled; }
+  bool IsTimestamped() const { return format & kTimestamped; }
   bool IsAttributed() const { return format & kAttributed; }
 };
 
@@ -40,13 +42,19 @@ struct EdgeValue {  // element_value.h:104-116
   float weight = 0.f;
   int32_t label = 0;
   int64_t timestamp = 0;
+  std::vector<int64_t> i_attrs;  // AttributeValue (element_value.h:72-102), by kind
+  std::vector<float> f_attrs;
+  std::vector<std::string> s_attrs;
 };
 
 struct NodeValue {  // element_value.h:118-132; attrs = the float attributes
   int64_t id = 0;
   float weight = 0.f;
   int32_t label = 0;
+  int64_t timestamp = 0;
   std::vector<float> attrs;
+  std::vector<int64_t> i_attrs;
+  std::vector<std::string> s_attrs;
 };
 
 }  // namespace io
@@ -93,11 +101,29 @@ public:
   int64_t GetEdgeCount() const { return (int64_t)src_.size(); }
   const glx_graph* Device() const { return dev_; }  // nullptr before Build()
 
+  // Per-edge properties by edge id, host resident (they are not read by the samplers):
+  // EdgeStorage::GetWeight/GetLabel/GetTimestamp/GetAttribute
+  // (memory_edge_storage.cc:90-125).  An id outside [0, E) -- e.g. the -1 of a
+  // default-filled sample -- yields the DefaultWeight/DefaultLabel/... flags.
+  int64_t GetSrcId(int64_t edge_id) const;
+  int64_t GetDstId(int64_t edge_id) const;
+  float GetEdgeWeight(int64_t edge_id) const;
+  int32_t GetEdgeLabel(int64_t edge_id) const;
+  int64_t GetEdgeTimestamp(int64_t edge_id) const;
+  const int64_t* GetEdgeIntAttrs(int64_t edge_id) const;        // i_num values or nullptr
+  const float* GetEdgeFloatAttrs(int64_t edge_id) const;        // f_num values or nullptr
+  const std::string* GetEdgeStringAttrs(int64_t edge_id) const;  // s_num values or nullptr
+
 private:
   std::string type_;
   io::SideInfo info_;
   std::vector<int64_t> src_, dst_;
   std::vector<float> weight_;
+  std::vector<int32_t> label_;
+  std::vector<int64_t> timestamp_;
+  std::vector<int64_t> i_attrs_;
+  std::vector<float> f_attrs_;
+  std::vector<std::string> s_attrs_;
   glx_graph* dev_;
   std::mutex mtx_;
 };
@@ -113,12 +139,28 @@ public:
   void Add(const io::NodeValue* value);          // duplicate ids are ignored (node_storage.h:41)
   Status Build(const IndexOption& option);
   const glx_features* Device() const { return dev_; }
+  int64_t GetNodeCount() const { return (int64_t)ids_.size(); }
+
+  // NodeStorage::GetWeight/GetLabel/GetTimestamp/GetAttribute
+  // (memory_node_storage.cc:88-138) for the host-resident properties; -1 = unknown id.
+  int32_t RowOf(int64_t node_id) const;
+  float GetWeight(int64_t node_id) const;
+  int32_t GetLabel(int64_t node_id) const;
+  int64_t GetTimestamp(int64_t node_id) const;
+  const int64_t* GetIntAttrs(int32_t row) const { return i_attrs_.data() + (int64_t)row * info_.i_num; }
+  const float* GetFloatAttrs(int32_t row) const { return feats_.data() + (int64_t)row * info_.f_num; }
+  const std::string* GetStringAttrs(int32_t row) const { return s_attrs_.data() + (int64_t)row * info_.s_num; }
 
 private:
   std::string type_;
   io::SideInfo info_;
   std::vector<int64_t> ids_;
   std::vector<float> feats_;
+  std::vector<float> weights_;
+  std::vector<int32_t> labels_;
+  std::vector<int64_t> timestamps_;
+  std::vector<int64_t> i_attrs_;
+  std::vector<std::string> s_attrs_;
   std::unordered_map<int64_t, int32_t> index_;
   glx_features* dev_;
   std::mutex mtx_;
@@ -130,6 +172,8 @@ public:
   ~GraphStore();
   Graph* GetGraph(const std::string& edge_type);
   Noder* GetNoder(const std::string& node_type);
+  // Build every storage added so far (GraphStore::Build, graph_store.cc:252-276).
+  Status Build(const IndexOption& option);
 
 private:
   std::mutex mtx_;

@@ -2,7 +2,9 @@
 #ifndef GLX_HOST_GRAPHLEARN_H_
 #define GLX_HOST_GRAPHLEARN_H_
 #include "graphlearn/aggregating_request.h"
+#include "graphlearn/client.h"
 #include "graphlearn/config.h"
+#include "graphlearn/data_source.h"
 #include "graphlearn/graph_request.h"
 #include "graphlearn/graph_store.h"
 #include "graphlearn/op_request.h"

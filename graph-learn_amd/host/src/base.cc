@@ -27,6 +27,11 @@ int32_t gPaddingMode = 1;
 int64_t gDefaultNeighborId = 0;
 float gDefaultFloatAttribute = 0.0f;
 float gDefaultWeight = 0.0f;
+int64_t gDefaultIntAttribute = 0;
+std::string gDefaultStringAttribute = "";
+int64_t gDefaultLabel = -1;
+int64_t gDefaultTimestamp = -1;
+int32_t gIgnoreInvalid = 1;
 int32_t gSamplingRetryTimes = 5;
 int64_t gSamplingSeed = 0;
 int32_t gDeviceId = 0;
@@ -35,6 +40,11 @@ void SetGlobalFlagPaddingMode(int32_t v) { gPaddingMode = v; }
 void SetGlobalFlagDefaultNeighborId(int64_t v) { gDefaultNeighborId = v; }
 void SetGlobalFlagDefaultFloatAttribute(float v) { gDefaultFloatAttribute = v; }
 void SetGlobalFlagDefaultWeight(float v) { gDefaultWeight = v; }
+void SetGlobalFlagDefaultIntAttribute(int64_t v) { gDefaultIntAttribute = v; }
+void SetGlobalFlagDefaultStringAttribute(const std::string& v) { gDefaultStringAttribute = v; }
+void SetGlobalFlagDefaultLabel(int64_t v) { gDefaultLabel = v; }
+void SetGlobalFlagDefaultTimestamp(int64_t v) { gDefaultTimestamp = v; }
+void SetGlobalFlagIgnoreInvalid(int32_t v) { gIgnoreInvalid = v; }
 void SetGlobalFlagSamplingRetryTimes(int32_t v) { gSamplingRetryTimes = v; }
 void SetGlobalFlagSamplingSeed(int64_t v) { gSamplingSeed = v; }
 void SetGlobalFlagDeviceId(int32_t v) { gDeviceId = v; }
@@ -53,6 +63,11 @@ const char* kEdgeIds = "edge_ids";
 const char* kNeighborCount = "neighbor_count";
 const char* kStrategy = "strategy";
 const char* kFloatAttrKey = "float_attrs";
+const char* kIntAttrKey = "int_attrs";
+const char* kWeightKey = "weights";
+const char* kLabelKey = "labels";
+const char* kTimestampKey = "timestamps";
+const char* kDegreeKey = "degrees";
 const char* kSideInfo = "side_info";
 const char* kSegmentIds = "segment_ids";
 const char* kNumSegments = "num_segments";

@@ -1,0 +1,83 @@
+// Local-mode Client / Server (see client.h).
+#include "graphlearn/client.h"
+
+#include "graphlearn/operator.h"
+
+namespace graphlearn {
+
+Client::Client() {}
+Client::~Client() {}
+
+Status Client::RunOp(const OpRequest* request, OpResponse* response) {
+  // Executor::RunOp (service/executor.cc:34-44)
+  op::Operator* op = op::OpFactory::GetInstance()->Create(request->Name());
+  if (!op) return error::InvalidArgument("Invalid request name: " + request->Name());
+  return op->Process(request, response);
+}
+
+Status Client::Sampling(const SamplingRequest* request, SamplingResponse* response) { return RunOp(request, response); }
+Status Client::Aggregating(const AggregatingRequest* request, AggregatingResponse* response) {
+  return RunOp(request, response);
+}
+Status Client::LookupNodes(const LookupNodesRequest* request, LookupNodesResponse* response) {
+  return RunOp(request, response);
+}
+Status Client::LookupEdges(const LookupEdgesRequest* request, LookupEdgesResponse* response) {
+  return RunOp(request, response);
+}
+Status Client::GetDegree(const GetDegreeRequest* request, GetDegreeResponse* response) {
+  return RunOp(request, response);
+}
+Status Client::Stop() { return Status::OK(); }
+
+Client* NewInMemoryClient() { return new Client(); }
+
+Server::Server() : store_(nullptr), bound_(false) {}
+
+Server::~Server() { Stop(); }
+
+void Server::Start() {
+  if (!store_) store_ = new GraphStore();
+}
+
+void Server::Init(const std::vector<io::EdgeSource>& edges, const std::vector<io::NodeSource>& nodes) {
+  Start();
+  status_ = Status::OK();
+  IndexOption option;
+  option.name = "sort";
+  for (const io::EdgeSource& e : edges) {
+    if (!status_.ok()) break;
+    status_ = io::LoadEdges(e, store_);
+    option = e.option;
+  }
+  for (const io::NodeSource& n : nodes) {
+    if (!status_.ok()) break;
+    status_ = io::LoadNodes(n, store_);
+  }
+  if (status_.ok()) status_ = store_->Build(option);
+  if (status_.ok()) {
+    op::OpFactory::GetInstance()->Set(store_);  // one store per process, like the reference
+    bound_ = true;
+  }
+}
+
+uintptr_t Server::DeviceGraph(const std::string& edge_type) {
+  return store_ ? reinterpret_cast<uintptr_t>(store_->GetGraph(edge_type)->Device()) : 0;
+}
+
+uintptr_t Server::DeviceFeatures(const std::string& node_type) {
+  return store_ ? reinterpret_cast<uintptr_t>(store_->GetNoder(node_type)->Device()) : 0;
+}
+
+void Server::Stop() {
+  if (store_) {
+    if (bound_) op::OpFactory::GetInstance()->Set(nullptr);
+    bound_ = false;
+    delete store_;
+    store_ = nullptr;
+  }
+}
+
+Server* NewServer(int32_t, int32_t, const std::string&, const std::string&) { return new Server(); }
+
+}  // namespace graphlearn

@@ -28,7 +28,45 @@ void Graph::Add(const io::EdgeValue* value) {
   src_.push_back(value->src_id);
   dst_.push_back(value->dst_id);
   if (info_.IsWeighted()) weight_.push_back(value->weight);
+  if (info_.IsLabeled()) label_.push_back(value->label);
+  if (info_.IsTimestamped()) timestamp_.push_back(value->timestamp);
+  if (info_.IsAttributed()) {  // short values are padded with the defaults
+    for (int32_t i = 0; i < info_.i_num; ++i) {
+      i_attrs_.push_back(i < (int32_t)value->i_attrs.size() ? value->i_attrs[i] : GLOBAL_FLAG(DefaultIntAttribute));
+    }
+    for (int32_t i = 0; i < info_.f_num; ++i) {
+      f_attrs_.push_back(i < (int32_t)value->f_attrs.size() ? value->f_attrs[i] : GLOBAL_FLAG(DefaultFloatAttribute));
+    }
+    for (int32_t i = 0; i < info_.s_num; ++i) {
+      s_attrs_.push_back(i < (int32_t)value->s_attrs.size() ? value->s_attrs[i] : GLOBAL_FLAG(DefaultStringAttribute));
+    }
+  }
 }
+
+// The reference compares `edge_id < Size()` with an unsigned right-hand side, so a
+// negative id is "out of range" too (memory_edge_storage.cc:90-125).
+#define GLX_EDGE_IN_RANGE(vec, per) ((uint64_t)edge_id < (uint64_t)((vec).size() / (per)))
+int64_t Graph::GetSrcId(int64_t edge_id) const { return GLX_EDGE_IN_RANGE(src_, 1) ? src_[edge_id] : -1; }
+int64_t Graph::GetDstId(int64_t edge_id) const { return GLX_EDGE_IN_RANGE(dst_, 1) ? dst_[edge_id] : -1; }
+float Graph::GetEdgeWeight(int64_t edge_id) const {
+  return GLX_EDGE_IN_RANGE(weight_, 1) ? weight_[edge_id] : GLOBAL_FLAG(DefaultWeight);
+}
+int32_t Graph::GetEdgeLabel(int64_t edge_id) const {
+  return GLX_EDGE_IN_RANGE(label_, 1) ? label_[edge_id] : (int32_t)GLOBAL_FLAG(DefaultLabel);
+}
+int64_t Graph::GetEdgeTimestamp(int64_t edge_id) const {
+  return GLX_EDGE_IN_RANGE(timestamp_, 1) ? timestamp_[edge_id] : GLOBAL_FLAG(DefaultTimestamp);
+}
+const int64_t* Graph::GetEdgeIntAttrs(int64_t edge_id) const {
+  return info_.i_num > 0 && GLX_EDGE_IN_RANGE(i_attrs_, info_.i_num) ? i_attrs_.data() + edge_id * info_.i_num : nullptr;
+}
+const float* Graph::GetEdgeFloatAttrs(int64_t edge_id) const {
+  return info_.f_num > 0 && GLX_EDGE_IN_RANGE(f_attrs_, info_.f_num) ? f_attrs_.data() + edge_id * info_.f_num : nullptr;
+}
+const std::string* Graph::GetEdgeStringAttrs(int64_t edge_id) const {
+  return info_.s_num > 0 && GLX_EDGE_IN_RANGE(s_attrs_, info_.s_num) ? s_attrs_.data() + edge_id * info_.s_num : nullptr;
+}
+#undef GLX_EDGE_IN_RANGE
 
 Status Graph::UpdateEdges(const UpdateEdgesRequest* req, UpdateEdgesResponse*) {
   std::lock_guard<std::mutex> g(mtx_);
@@ -73,6 +111,35 @@ void Noder::Add(const io::NodeValue* value) {
   for (int32_t i = 0; i < dim; ++i) {
     feats_.push_back(i < (int32_t)value->attrs.size() ? value->attrs[i] : GLOBAL_FLAG(DefaultFloatAttribute));
   }
+  if (info_.IsWeighted()) weights_.push_back(value->weight);
+  if (info_.IsLabeled()) labels_.push_back(value->label);
+  if (info_.IsTimestamped()) timestamps_.push_back(value->timestamp);
+  for (int32_t i = 0; i < info_.i_num; ++i) {
+    i_attrs_.push_back(i < (int32_t)value->i_attrs.size() ? value->i_attrs[i] : GLOBAL_FLAG(DefaultIntAttribute));
+  }
+  for (int32_t i = 0; i < info_.s_num; ++i) {
+    s_attrs_.push_back(i < (int32_t)value->s_attrs.size() ? value->s_attrs[i] : GLOBAL_FLAG(DefaultStringAttribute));
+  }
+}
+
+int32_t Noder::RowOf(int64_t node_id) const {
+  auto it = index_.find(node_id);
+  return it == index_.end() ? -1 : it->second;
+}
+float Noder::GetWeight(int64_t node_id) const {  // memory_node_storage.cc:88-99
+  if (!info_.IsWeighted()) return 0.0f;
+  const int32_t r = RowOf(node_id);
+  return r < 0 ? GLOBAL_FLAG(DefaultWeight) : weights_[r];
+}
+int32_t Noder::GetLabel(int64_t node_id) const {  // memory_node_storage.cc:101-112
+  if (!info_.IsLabeled()) return -1;
+  const int32_t r = RowOf(node_id);
+  return r < 0 ? (int32_t)GLOBAL_FLAG(DefaultLabel) : labels_[r];
+}
+int64_t Noder::GetTimestamp(int64_t node_id) const {
+  if (!info_.IsTimestamped()) return -1;
+  const int32_t r = RowOf(node_id);
+  return r < 0 ? GLOBAL_FLAG(DefaultTimestamp) : timestamps_[r];
 }
 
 Status Noder::UpdateNodes(const UpdateNodesRequest* req, UpdateNodesResponse*) {
@@ -104,6 +171,25 @@ Graph* GraphStore::GetGraph(const std::string& edge_type) {
   auto it = graphs_.find(edge_type);
   if (it == graphs_.end()) it = graphs_.emplace(edge_type, new Graph(edge_type)).first;
   return it->second;
+}
+
+Status GraphStore::Build(const IndexOption& option) {
+  std::vector<Graph*> gs;
+  std::vector<Noder*> ns;
+  {
+    std::lock_guard<std::mutex> g(mtx_);
+    for (auto& it : graphs_) gs.push_back(it.second);
+    for (auto& it : noders_) ns.push_back(it.second);
+  }
+  for (Graph* g : gs) {
+    Status s = g->Build(option);
+    if (!s.ok()) return s;
+  }
+  for (Noder* n : ns) {
+    Status s = n->Build(option);
+    if (!s.ok()) return s;
+  }
+  return Status::OK();
 }
 
 Noder* GraphStore::GetNoder(const std::string& node_type) {

@@ -1,6 +1,6 @@
-// "LookupNodes" operator: float attributes of a batch of node ids, gathered on
-// the device (glx_lookup).  Unknown ids yield rows of DefaultFloatAttribute like
-// AttributeValue::Default (core/io/element_value.cc:26-50).
+// "LookupNodes" / "LookupEdges" / "GetDegree" operators (see graph_request.h).
+// Unknown node ids and out-of-range edge ids (the -1 of a default-filled sample)
+// yield the Default* flags, like AttributeValue::Default (core/io/element_value.cc:26-50).
 #include "glx.h"
 #include "graphlearn/config.h"
 #include "graphlearn/graph_request.h"
@@ -9,6 +9,7 @@
 
 namespace graphlearn {
 
+// ------------------------------------------------------------ LookupNodes --
 LookupNodesRequest::LookupNodesRequest() : OpRequest(kNodeIds), cursor_(0) {}
 
 LookupNodesRequest::LookupNodesRequest(const std::string& node_type) : OpRequest(kNodeIds), cursor_(0) {
@@ -35,19 +36,135 @@ bool LookupNodesRequest::Next(int64_t* node_id) const {
   return true;
 }
 
-LookupNodesResponse::LookupNodesResponse() : OpResponse(), f_num_(0) {}
+// ------------------------------------------------------------ LookupEdges --
+LookupEdgesRequest::LookupEdgesRequest() : OpRequest(kSrcIds), cursor_(0) {}
 
-void LookupNodesResponse::SetShape(int32_t batch_size, int32_t float_attr_num) {
+LookupEdgesRequest::LookupEdgesRequest(const std::string& edge_type) : OpRequest(kSrcIds), cursor_(0) {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("LookupEdges");
+  ADD_TENSOR(params_, kEdgeType, kString, 1);
+  params_[kEdgeType].AddString(edge_type);
+  ADD_TENSOR(tensors_, kEdgeIds, kInt64, 64);
+  ADD_TENSOR(tensors_, kSrcIds, kInt64, 64);
+}
+
+OpRequest* LookupEdgesRequest::Clone() const { return new LookupEdgesRequest(EdgeType()); }
+
+void LookupEdgesRequest::Set(const int64_t* edge_ids, const int64_t* src_ids, int32_t batch_size) {
+  tensors_[kEdgeIds].AddInt64(edge_ids, edge_ids + batch_size);
+  tensors_[kSrcIds].AddInt64(src_ids, src_ids + batch_size);
+}
+
+const std::string& LookupEdgesRequest::EdgeType() const { return params_.at(kEdgeType).GetString(0); }
+int32_t LookupEdgesRequest::Size() const { return tensors_.at(kEdgeIds).Size(); }
+const int64_t* LookupEdgesRequest::EdgeIds() const { return tensors_.at(kEdgeIds).GetInt64(); }
+const int64_t* LookupEdgesRequest::SrcIds() const { return tensors_.at(kSrcIds).GetInt64(); }
+
+bool LookupEdgesRequest::Next(int64_t* edge_id, int64_t* src_id) const {
+  if (cursor_ >= Size()) return false;
+  *edge_id = tensors_.at(kEdgeIds).GetInt64(cursor_);
+  *src_id = tensors_.at(kSrcIds).GetInt64(cursor_);
+  ++cursor_;
+  return true;
+}
+
+// --------------------------------------------------------- LookupResponse --
+LookupResponse::LookupResponse() : OpResponse() {}
+
+void LookupResponse::SetSideInfo(const io::SideInfo* info, int32_t batch_size) {
+  info_ = *info;
   batch_size_ = batch_size;
-  f_num_ = float_attr_num;
+  strings_.clear();
+  strings_.reserve((size_t)batch_size * (info_.s_num > 0 ? info_.s_num : 0));
+  tensors_.clear();
+  if (info_.IsWeighted()) ADD_TENSOR(tensors_, kWeightKey, kFloat, batch_size);
+  if (info_.IsLabeled()) ADD_TENSOR(tensors_, kLabelKey, kInt32, batch_size);
+  if (info_.IsTimestamped()) ADD_TENSOR(tensors_, kTimestampKey, kInt64, batch_size);
+  if (info_.i_num > 0) ADD_TENSOR(tensors_, kIntAttrKey, kInt64, batch_size * info_.i_num);
+  if (info_.f_num > 0) ADD_TENSOR(tensors_, kFloatAttrKey, kFloat, batch_size * info_.f_num);
+}
+
+void LookupResponse::AppendWeight(float weight) {
+  if (info_.IsWeighted()) tensors_[kWeightKey].AddFloat(weight);
+}
+void LookupResponse::AppendLabel(int32_t label) {
+  if (info_.IsLabeled()) tensors_[kLabelKey].AddInt32(label);
+}
+void LookupResponse::AppendTimestamp(int64_t timestamp) {
+  if (info_.IsTimestamped()) tensors_[kTimestampKey].AddInt64(timestamp);
+}
+
+void LookupResponse::AppendAttribute(const int64_t* ints, const float* floats, const std::string* strings) {
+  if (info_.i_num > 0) {
+    Tensor& t = tensors_[kIntAttrKey];
+    for (int32_t i = 0; i < info_.i_num; ++i) t.AddInt64(ints ? ints[i] : GLOBAL_FLAG(DefaultIntAttribute));
+  }
+  if (info_.f_num > 0) {
+    Tensor& t = tensors_[kFloatAttrKey];
+    for (int32_t i = 0; i < info_.f_num; ++i) t.AddFloat(floats ? floats[i] : GLOBAL_FLAG(DefaultFloatAttribute));
+  }
+  for (int32_t i = 0; i < info_.s_num; ++i) strings_.push_back(strings ? strings[i] : GLOBAL_FLAG(DefaultStringAttribute));
+}
+
+namespace {
+template <class T>
+const T* DataOrNull(const Tensor::Map& m, const char* key, const T* (Tensor::*get)() const) {
+  auto it = m.find(key);
+  return it == m.end() ? nullptr : (it->second.*get)();
+}
+}  // namespace
+
+const float* LookupResponse::Weights() const { return DataOrNull<float>(tensors_, kWeightKey, &Tensor::GetFloat); }
+const int32_t* LookupResponse::Labels() const { return DataOrNull<int32_t>(tensors_, kLabelKey, &Tensor::GetInt32); }
+const int64_t* LookupResponse::Timestamps() const {
+  return DataOrNull<int64_t>(tensors_, kTimestampKey, &Tensor::GetInt64);
+}
+const int64_t* LookupResponse::IntAttrs() const { return DataOrNull<int64_t>(tensors_, kIntAttrKey, &Tensor::GetInt64); }
+const float* LookupResponse::FloatAttrs() const { return DataOrNull<float>(tensors_, kFloatAttrKey, &Tensor::GetFloat); }
+
+void LookupResponse::SetShape(int32_t batch_size, int32_t float_attr_num) {
+  batch_size_ = batch_size;
+  info_.f_num = float_attr_num;
+  tensors_.erase(kFloatAttrKey);
   ADD_TENSOR(tensors_, kFloatAttrKey, kFloat, batch_size * float_attr_num);
   tensors_[kFloatAttrKey].Resize(batch_size * float_attr_num);
 }
 
-const float* LookupNodesResponse::FloatAttrs() const { return tensors_.at(kFloatAttrKey).GetFloat(); }
-float* LookupNodesResponse::MutableFloatAttrs() { return tensors_[kFloatAttrKey].MutableFloat(); }
+float* LookupResponse::MutableFloatAttrs() { return tensors_[kFloatAttrKey].MutableFloat(); }
 
-REGISTER_REQUEST(LookupNodes, LookupNodesRequest, LookupNodesResponse)
+REGISTER_REQUEST(LookupNodes, LookupNodesRequest, LookupResponse)
+REGISTER_REQUEST(LookupEdges, LookupEdgesRequest, LookupResponse)
+
+// -------------------------------------------------------------- GetDegree --
+GetDegreeRequest::GetDegreeRequest() : OpRequest(kNodeIds) {}
+
+GetDegreeRequest::GetDegreeRequest(const std::string& edge_type) : OpRequest(kNodeIds) {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("GetDegree");
+  ADD_TENSOR(params_, kEdgeType, kString, 1);
+  params_[kEdgeType].AddString(edge_type);
+  ADD_TENSOR(tensors_, kNodeIds, kInt64, 64);
+}
+
+OpRequest* GetDegreeRequest::Clone() const { return new GetDegreeRequest(EdgeType()); }
+void GetDegreeRequest::Set(const int64_t* node_ids, int32_t batch_size) {
+  tensors_[kNodeIds].AddInt64(node_ids, node_ids + batch_size);
+}
+const std::string& GetDegreeRequest::EdgeType() const { return params_.at(kEdgeType).GetString(0); }
+int32_t GetDegreeRequest::Size() const { return tensors_.at(kNodeIds).Size(); }
+const int64_t* GetDegreeRequest::NodeIds() const { return tensors_.at(kNodeIds).GetInt64(); }
+
+GetDegreeResponse::GetDegreeResponse() : OpResponse() {}
+void GetDegreeResponse::InitDegrees(int32_t batch_size) {
+  batch_size_ = batch_size;
+  tensors_.erase(kDegreeKey);
+  ADD_TENSOR(tensors_, kDegreeKey, kInt32, batch_size);
+  tensors_[kDegreeKey].Resize(batch_size);
+}
+const int32_t* GetDegreeResponse::GetDegrees() const { return tensors_.at(kDegreeKey).GetInt32(); }
+int32_t* GetDegreeResponse::MutableDegrees() { return tensors_[kDegreeKey].MutableInt32(); }
+
+REGISTER_REQUEST(GetDegree, GetDegreeRequest, GetDegreeResponse)
 
 namespace op {
 
@@ -55,20 +172,82 @@ class NodeLookuper : public Operator {
 public:
   Status Process(const OpRequest* req, OpResponse* res) override {
     const LookupNodesRequest* request = static_cast<const LookupNodesRequest*>(req);
-    LookupNodesResponse* response = static_cast<LookupNodesResponse*>(res);
+    LookupResponse* response = static_cast<LookupResponse*>(res);
     if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
     Noder* noder = graph_store_->GetNoder(request->NodeType());
-    const int32_t dim = noder->GetSideInfo()->f_num;
-    response->SetShape(request->Size(), dim);
+    const io::SideInfo* info = noder->GetSideInfo();
+    const int32_t n = request->Size();
+    const int64_t* ids = request->NodeIds();
+    // float attributes: one device gather for the whole batch
     const glx_features* f = noder->Device();
-    if (!f) return error::InvalidArgument("node type '" + request->NodeType() + "' has no float attributes on the device");
-    int rc = glx_lookup(f, request->NodeIds(), request->Size(), GLOBAL_FLAG(DefaultFloatAttribute),
-                        response->MutableFloatAttrs(), GLX_PTR_HOST, nullptr);
-    return error::FromGlx(rc);
+    io::SideInfo host_side = *info;  // everything except the float block is appended per element
+    host_side.f_num = 0;
+    response->SetSideInfo(&host_side, n);
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t row = noder->RowOf(ids[i]);
+      response->AppendWeight(noder->GetWeight(ids[i]));
+      response->AppendLabel(noder->GetLabel(ids[i]));
+      response->AppendTimestamp(noder->GetTimestamp(ids[i]));
+      if (info->IsAttributed() || info->i_num > 0 || info->s_num > 0) {
+        response->AppendAttribute(row < 0 || info->i_num == 0 ? nullptr : noder->GetIntAttrs(row), nullptr,
+                                  row < 0 || info->s_num == 0 ? nullptr : noder->GetStringAttrs(row));
+      }
+    }
+    if (info->f_num > 0) {
+      if (!f) return error::InvalidArgument("node type '" + request->NodeType() + "' is not built on the device");
+      response->SetShape(n, info->f_num);
+      int rc = glx_lookup(f, ids, n, GLOBAL_FLAG(DefaultFloatAttribute), response->MutableFloatAttrs(),
+                          GLX_PTR_HOST, nullptr);
+      return error::FromGlx(rc);
+    }
+    return Status::OK();
+  }
+};
+
+class EdgeLookuper : public Operator {
+public:
+  Status Process(const OpRequest* req, OpResponse* res) override {
+    const LookupEdgesRequest* request = static_cast<const LookupEdgesRequest*>(req);
+    LookupResponse* response = static_cast<LookupResponse*>(res);
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    Graph* graph = graph_store_->GetGraph(request->EdgeType());
+    const io::SideInfo* info = graph->GetSideInfo();
+    const int32_t n = request->Size();
+    const int64_t* eids = request->EdgeIds();
+    response->SetSideInfo(info, n);
+    for (int32_t i = 0; i < n; ++i) {  // local_graph.cc:72-85
+      response->AppendWeight(graph->GetEdgeWeight(eids[i]));
+      response->AppendLabel(graph->GetEdgeLabel(eids[i]));
+      response->AppendTimestamp(graph->GetEdgeTimestamp(eids[i]));
+      response->AppendAttribute(graph->GetEdgeIntAttrs(eids[i]), graph->GetEdgeFloatAttrs(eids[i]),
+                                graph->GetEdgeStringAttrs(eids[i]));
+    }
+    return Status::OK();
+  }
+};
+
+class DegreeGetter : public Operator {
+public:
+  Status Process(const OpRequest* req, OpResponse* res) override {
+    const GetDegreeRequest* request = static_cast<const GetDegreeRequest*>(req);
+    GetDegreeResponse* response = static_cast<GetDegreeResponse*>(res);
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    Graph* graph = graph_store_->GetGraph(request->EdgeType());
+    const int32_t n = request->Size();
+    response->InitDegrees(n);
+    if (!graph->Device()) return error::InvalidArgument("edge type '" + request->EdgeType() + "' is not built on the device");
+    std::vector<int64_t> deg((size_t)n);
+    int rc = glx_graph_degrees(graph->Device(), request->NodeIds(), n, deg.data(), GLX_PTR_HOST, nullptr);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    int32_t* out = response->MutableDegrees();
+    for (int32_t i = 0; i < n; ++i) out[i] = (int32_t)deg[i];
+    return Status::OK();
   }
 };
 
 REGISTER_OPERATOR("LookupNodes", NodeLookuper)
+REGISTER_OPERATOR("LookupEdges", EdgeLookuper)
+REGISTER_OPERATOR("GetDegree", DegreeGetter)
 
 }  // namespace op
 }  // namespace graphlearn

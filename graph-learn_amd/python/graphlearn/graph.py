@@ -1,0 +1,281 @@
+"""gl.Graph for the sampling path in local deploy mode.
+
+Same construction protocol as graphlearn/python/graph.py:
+    g = gl.Graph().node(path, "user", decoder).edge(path, ("user", "item", "buy"), decoder).init()
+    g.neighbor_sampler(["buy"], expand_factor=[10]).get(ids)
+`init()` parses the sources on the host (C++), builds CSR / alias tables / the feature
+matrix on the GPU and keeps them resident there; every sampler / aggregator call then
+goes Python -> pywrap -> Operator::Process -> HIP.  Distributed deploy modes
+(init(cluster=...), task_count > 1), GSL (`V()/E()`), subgraph / negative samplers and
+the vineyard backend are outside the path this engine replaces and raise
+NotImplementedError.
+"""
+import os
+import sys
+
+import numpy as np
+
+from graphlearn import pywrap_graphlearn as pywrap
+from graphlearn import errors
+from graphlearn import values as data
+from graphlearn.decoder import Decoder
+from graphlearn.topology import Topology
+from graphlearn.utils import Mask, get_mask_type
+
+# glx.py (the ctypes face of the C-ABI) lives next to the python/ directory
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+_PYWRAP_TYPE = {"int": pywrap.DataType.INT64, "float": pywrap.DataType.FLOAT, "string": pywrap.DataType.STRING}
+
+
+def _fill_source(source, path, decoder, option):
+  """Decoder -> the format bits / AttributeInfo the loader checks the file against."""
+  source.path = path
+  source.format = int(decoder.data_format)
+  if option is None:
+    option = pywrap.IndexOption()
+    option.name = "sort"  # rows ordered like the reference's default Build()
+  source.option = option
+  info = source.attr_info
+  if decoder.attributed:
+    info.delimiter = decoder.attr_delimiter
+    for spec in decoder.attr_types:
+      name, bucket, multi = Decoder.parse(spec)
+      info.append_hash_bucket(0 if (multi or bucket is None) else int(bucket))
+      info.append_type(_PYWRAP_TYPE[name])
+  source.attr_info = info
+  return source
+
+
+class Graph(object):
+
+  def __init__(self):
+    self._node_sources, self._edge_sources = [], []
+    self._node_decoders, self._edge_decoders = {}, {}
+    self._topology = Topology()
+    self._undirected_edges = []
+    self._client = None
+    self._server = None
+
+  # -- construction ---------------------------------------------------------------
+  def node(self, source, node_type, decoder, option=None, mask=Mask.NONE):
+    if not isinstance(source, str):
+      raise ValueError("source for node() must be string.")
+    if not isinstance(node_type, str):
+      raise ValueError("node_type for node() must be string.")
+    if not isinstance(decoder, Decoder):
+      raise ValueError("decoder must be an instance of `Decoder`, got {}".format(type(decoder)))
+    stored = get_mask_type(node_type, mask)
+    self._node_decoders[stored] = decoder
+    for path in (p.strip() for p in source.split(",")):
+      s = pywrap.NodeSource()
+      s.id_type = stored
+      self._node_sources.append(_fill_source(s, path, decoder, option))
+    return self
+
+  def _edge_source(self, path, types, decoder, direction, option):
+    s = pywrap.EdgeSource()
+    s.src_id_type, s.dst_id_type, s.edge_type = types
+    s.direction = direction
+    return _fill_source(s, path, decoder, option)
+
+  def edge(self, source, edge_type, decoder=None, directed=True, option=None, mask=Mask.NONE):
+    if not isinstance(source, str):
+      raise ValueError("source for edge() must be a string.")
+    if not isinstance(edge_type, tuple) or len(edge_type) != 3:
+      raise ValueError("edge_type for edge() must be a tuple of (src_type, dst_tye, edge_type).")
+    decoder = decoder or Decoder()
+    if not isinstance(decoder, Decoder):
+      raise ValueError("decoder must be an instance of Decoder, got {}".format(type(decoder)))
+    src, dst, name = edge_type
+    stored = get_mask_type(name, mask)
+    self._edge_decoders[stored] = decoder
+    self._topology.add(stored, src, dst)
+    paths = [p.strip() for p in source.split(",")]
+    for path in paths:
+      self._edge_sources.append(self._edge_source(path, (src, dst, stored), decoder, pywrap.Direction.ORIGIN, option))
+    if not directed:
+      # graph.py:357-380: a heterogeneous edge type gets a twin `<type>_reverse` with swapped
+      # end points; a homogeneous one gets the reversed records appended to the SAME type.
+      self._undirected_edges.append(name)
+      if src != dst:
+        twin = name + "_reverse"
+        self._edge_decoders[twin] = decoder
+        self._topology.add(twin, dst, src)
+        types = (dst, src, twin)
+      else:
+        types = (src, dst, name)
+      for path in paths:
+        self._edge_sources.append(self._edge_source(path, types, decoder, pywrap.Direction.REVERSED, option))
+    return self
+
+  def init(self, task_index=0, task_count=1, cluster="", job_name="", **kwargs):
+    """Load + build on this process' GPU.  `tracker=` is accepted and ignored."""
+    if cluster or task_count != 1 or kwargs.get("hosts") is not None:
+      raise NotImplementedError(
+          "only the local deploy mode is served by this engine; multi-GPU execution is one process per GPU "
+          "over RCCL (graph-learn_amd/dist.py), not the reference's client/server RPC")
+    self._client = pywrap.in_memory_client()
+    self._server = pywrap.server(0, 1, "", "")
+    self._server.start()
+    self._server.init(self._edge_sources, self._node_sources)
+    errors.raise_exception_on_not_ok_status(self._server.init_status())
+    return self
+
+  def close(self):
+    if self._client is not None:
+      self._client.stop()
+      self._client = None
+    if self._server is not None:
+      self._server.stop()
+      self._server = None
+
+  wait_for_close = close
+
+  # -- introspection ----------------------------------------------------------------
+  def get_client(self):
+    return self._client
+
+  def get_server(self):
+    return self._server
+
+  def get_topology(self):
+    return self._topology
+
+  def get_node_decoder(self, node_type):
+    if node_type not in self._node_decoders:
+      raise ValueError("node type {} not exist in graph.".format(node_type))
+    return self._node_decoders[node_type]
+
+  def get_edge_decoder(self, edge_type):
+    if edge_type not in self._edge_decoders:
+      raise ValueError("edge type {} not exist in graph.".format(edge_type))
+    return self._edge_decoders[edge_type]
+
+  def get_node_decoders(self):
+    return self._node_decoders
+
+  def get_edge_decoders(self):
+    return self._edge_decoders
+
+  @property
+  def undirected_edges(self):
+    return self._undirected_edges
+
+  def is_directed(self, edge_type):
+    self.get_edge_decoder(edge_type)
+    return edge_type not in self._undirected_edges
+
+  # -- values ---------------------------------------------------------------------
+  def get_nodes(self, node_type, ids, offsets=None, shape=None):
+    if offsets is None:
+      return data.Nodes(ids, node_type, shape=shape, graph=self)
+    width = shape[1] if shape and shape[1] and shape[1] > 0 else max(offsets)
+    return data.SparseNodes(ids, offsets, (len(offsets), width), node_type, graph=self)
+
+  def get_edges(self, edge_type, src_ids, dst_ids, edge_ids=None, offsets=None, shape=None, reverse=False):
+    if reverse:
+      edge_type = edge_type + "_reverse"
+    src_type = self._topology.get_src_type(edge_type)
+    dst_type = self._topology.get_dst_type(edge_type)
+    if offsets is None:
+      return data.Edges(src_ids, src_type, dst_ids, dst_type, edge_type, edge_ids, shape=shape, graph=self)
+    width = shape[1] if shape and shape[1] and shape[1] > 0 else max(offsets)
+    return data.SparseEdges(src_ids, src_type, dst_ids, dst_type, edge_type, offsets, (len(offsets), width),
+                            edge_ids, graph=self)
+
+  def _run_lookup(self, kind, type_name, decoder, set_request):
+    """One LookupNodes / LookupEdges call -> Values with the columns the decoder declares."""
+    req = getattr(pywrap, "new_lookup_%ss_request" % kind)(type_name)
+    set_request(req)
+    res = getattr(pywrap, "new_lookup_%ss_response" % kind)()
+    status = getattr(self._client, "lookup_%ss" % kind)(req, res)
+    cols = {}
+    if status.ok():
+      fetch = lambda what: getattr(pywrap, "get_%s_%s" % (kind, what))(res)  # noqa: E731
+      cols["weights"] = fetch("weights") if decoder.weighted else None
+      cols["labels"] = fetch("labels") if decoder.labeled else None
+      cols["timestamps"] = fetch("timestamps") if decoder.timestamped else None
+      if decoder.attributed:
+        cols["int_attrs"], cols["float_attrs"], cols["string_attrs"] = decoder.format_attrs(
+            fetch("int_attributes"), fetch("float_attributes"), fetch("string_attributes"))
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
+    return data.Values(graph=self, **cols)
+
+  def lookup_nodes(self, node_type, ids):
+    ids = np.ascontiguousarray(np.array(ids).reshape(-1), dtype=np.int64)
+    return self._run_lookup("node", node_type, self.get_node_decoder(node_type),
+                            lambda req: pywrap.set_lookup_nodes_request(req, ids))
+
+  def lookup_edges(self, edge_type, src_ids, edge_ids):
+    src_ids = np.ascontiguousarray(np.array(src_ids).reshape(-1), dtype=np.int64)
+    edge_ids = np.ascontiguousarray(np.array(edge_ids).reshape(-1), dtype=np.int64)
+    if src_ids.size != edge_ids.size:
+      raise ValueError("src_ids and edge_ids for lookup edges must be same, got {} and {}"
+                       .format(src_ids.size, edge_ids.size))
+    return self._run_lookup("edge", edge_type, self.get_edge_decoder(edge_type),
+                            lambda req: pywrap.set_lookup_edges_request(req, src_ids, edge_ids))
+
+  def out_degrees(self, ids, edge_type):
+    ids = np.array(ids)
+    req = pywrap.new_get_degree_request(edge_type, 0)
+    pywrap.set_degree_request(req, np.ascontiguousarray(ids.reshape(-1), dtype=np.int64))
+    res = pywrap.new_get_degree_response()
+    status = self._client.get_degree(req, res)
+    out = pywrap.get_degree(res).reshape(ids.shape) if status.ok() else None
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
+    return out
+
+  def in_degrees(self, ids, edge_type):
+    raise NotImplementedError("in-degree lookup is not served by the device engine")
+
+  # -- samplers -------------------------------------------------------------------
+  def neighbor_sampler(self, meta_path, expand_factor, strategy="random"):
+    """strategy: "random", "random_without_replacement", "topk", "in_degree", "edge_weight", "full"."""
+    from graphlearn import sampler
+    cls = getattr(sampler, "".join(w.capitalize() for w in strategy.split("_")) + "NeighborSampler", None)
+    if cls is None:
+      raise ValueError("unknown neighbor sampling strategy {!r}".format(strategy))
+    return cls(self, meta_path, expand_factor, strategy=strategy)
+
+  # -- device-resident access (new) ----------------------------------------------
+  def device_graph(self, edge_type):
+    """The edge type's CSR in HBM as a borrowed glx.Graph (torch-tensor in / out, zero copies)."""
+    import glx
+    h = self._server.device_graph(edge_type)
+    if not h:
+      raise ValueError("edge type {} is not built on the device".format(edge_type))
+    return glx.Graph.from_handle(h)
+
+  def device_features(self, node_type):
+    """The node type's float attributes in HBM as a borrowed glx.Features."""
+    import glx
+    h = self._server.device_features(node_type)
+    if not h:
+      raise ValueError("node type {} has no float attributes on the device".format(node_type))
+    return glx.Features.from_handle(h)
+
+  def _off_path(self, what):
+    raise NotImplementedError("%s is outside the sampling/aggregation path this engine replaces" % what)
+
+  def V(self, *args, **kwargs):  # pylint: disable=invalid-name
+    self._off_path("GSL (Graph.V)")
+
+  def E(self, *args, **kwargs):  # pylint: disable=invalid-name
+    self._off_path("GSL (Graph.E)")
+
+  def node_sampler(self, *args, **kwargs):
+    self._off_path("node_sampler")
+
+  def edge_sampler(self, *args, **kwargs):
+    self._off_path("edge_sampler")
+
+  def negative_sampler(self, *args, **kwargs):
+    self._off_path("negative_sampler")
+
+  def subgraph_sampler(self, *args, **kwargs):
+    self._off_path("subgraph_sampler")

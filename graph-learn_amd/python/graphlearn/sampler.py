@@ -1,0 +1,144 @@
+"""Neighbor samplers of the Python API (graphlearn/python/sampler/neighbor_sampler.py).
+
+`get(ids)` walks the meta path hop by hop: one sampling request per hop, the hop's
+output ids are the next hop's input.  Results come back as numpy arrays inside
+Layers, like the reference.  `get_device(ids)` is the MI355X-first variant: all hops
+run in ONE call (glx_sample_hops), frontiers never leave HBM, and the result is a list
+of torch CUDA tensors.
+"""
+import numpy as np
+
+from graphlearn import pywrap_graphlearn as pywrap
+from graphlearn import errors
+from graphlearn.utils import strategy2op
+from graphlearn.values import Layer, Layers
+
+__all__ = ["NeighborSampler", "RandomNeighborSampler", "RandomWithoutReplacementNeighborSampler",
+           "EdgeWeightNeighborSampler", "TopkNeighborSampler", "InDegreeNeighborSampler", "FullNeighborSampler"]
+
+
+def _as_list(value, what):
+  if isinstance(value, (list, tuple)):
+    return list(value)
+  if isinstance(value, (int, str)):
+    return [value]
+  raise ValueError("`%s` must be a value or a list of values." % what)
+
+
+class NeighborSampler(object):
+
+  def __init__(self, graph, meta_path, expand_factor, strategy="random"):
+    self._graph = graph
+    self._meta_path = _as_list(meta_path, "meta_path")
+    if isinstance(expand_factor, str):
+      raise ValueError("`expand_factor` must be int or list of int.")
+    self._expand_factor = _as_list(expand_factor, "expand_factor")
+    self._strategy = strategy
+    self._op = strategy2op(strategy, "Sampler")
+    topo = graph.get_topology()
+    self._dst_types = [topo.get_dst_type(e) for e in self._meta_path]
+    self._call_counter = None
+
+  def set_call_counter(self, value):
+    """Pin the random stream of the next get(): hop h uses counter value + h.  Unset,
+    every request draws a fresh stream from the operator's own counter."""
+    self._call_counter = value
+
+  def _check(self):
+    if len(self._meta_path) != len(self._expand_factor):
+      raise ValueError("The length of meta_path must be same with hop count.")
+
+  def _sample(self, hop, src_ids):
+    """-> (neighbor ids, edge ids, per-row counts) of one hop, flat."""
+    req = pywrap.new_sampling_request(self._meta_path[hop], self._op, int(self._expand_factor[hop]),
+                                      pywrap.FilterType.OPERATOR_UNSPECIFIED, pywrap.FilterField.FIELD_UNSPECIFIED)
+    pywrap.set_sampling_request(req, np.ascontiguousarray(src_ids.reshape(-1), dtype=np.int64))
+    if self._call_counter is not None:
+      pywrap.set_sampling_call_counter(req, int(self._call_counter) + hop)
+    res = pywrap.new_sampling_response()
+    status = self._graph.get_client().sample_neighbor(req, res)
+    out = None
+    if status.ok():
+      out = (pywrap.get_sampling_node_ids(res), pywrap.get_sampling_edge_ids(res),
+             pywrap.get_sampling_node_degrees(res))
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
+    return out
+
+  def get(self, ids):
+    """ids: 1-D int64 array.  -> Layers; layer h holds [len(previous layer), expand_factor[h]] nodes/edges."""
+    self._check()
+    src = np.array(ids)
+    layers = Layers()
+    for hop, edge_type in enumerate(self._meta_path):
+      k = self._expand_factor[hop]
+      nbr, eid, _ = self._sample(hop, src)
+      shape = (src.size, k)
+      nodes = self._graph.get_nodes(self._dst_types[hop], nbr, shape=shape)
+      edges = self._graph.get_edges(edge_type, np.repeat(src.reshape(-1), k), nbr, shape=shape)
+      edges.edge_ids = eid
+      layers.append_layer(Layer(nodes, edges))
+      src = nbr
+    return layers
+
+
+  def get_device(self, ids, seed=None, call_counter=0):
+    """All hops in one engine call on torch CUDA tensors (glx_sample_hops): the hop-h frontier is
+    hop h-1's output and never leaves HBM.  ids: int64 CUDA tensor [B].
+    -> [(neighbor ids [rows_h, k_h], edge ids [rows_h, k_h]) per hop], CUDA tensors.
+    Same draws as get() with set_call_counter(call_counter) under the same seed."""
+    import glx
+    self._check()
+    if self._strategy == "full":
+      raise ValueError("the full sampler returns ragged rows; use get()")
+    graphs = [self._graph.device_graph(e) for e in self._meta_path]
+    seed = _flag("sampling_seed") if seed is None else seed
+    return glx.sample_hops(graphs, self._op, ids, [int(k) for k in self._expand_factor], seed=seed,
+                           call_counter=call_counter, padding_mode=_flag("padding_mode"),
+                           default_neighbor_id=_flag("default_neighbor_id"))
+
+
+def _flag(name):
+  from graphlearn import settings
+  return settings._MIRROR[name]  # pylint: disable=protected-access
+
+
+class RandomNeighborSampler(NeighborSampler):
+  pass
+
+
+class RandomWithoutReplacementNeighborSampler(NeighborSampler):
+  pass
+
+
+class EdgeWeightNeighborSampler(NeighborSampler):
+  pass
+
+
+class TopkNeighborSampler(NeighborSampler):
+  pass
+
+
+class InDegreeNeighborSampler(NeighborSampler):
+  pass
+
+
+class FullNeighborSampler(NeighborSampler):
+  """All neighbours (at most expand_factor per vertex when it is > 0): ragged results,
+  returned as SparseNodes / SparseEdges."""
+
+  def get(self, ids):
+    self._check()
+    src = np.array(ids).reshape(-1)
+    layers = Layers()
+    for hop, edge_type in enumerate(self._meta_path):
+      nbr, eid, counts = self._sample(hop, src)
+      counts = [int(c) for c in counts]
+      dense = (src.size, max(counts) if counts else 0)
+      nodes = self._graph.get_nodes(self._dst_types[hop], nbr, offsets=counts, shape=dense)
+      edges = self._graph.get_edges(edge_type, np.repeat(src, counts), nbr, offsets=counts, shape=dense)
+      edges.edge_ids = eid
+      layers.append_layer(Layer(nodes, edges))
+      src = nbr
+    return layers

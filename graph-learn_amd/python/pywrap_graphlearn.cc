@@ -1,0 +1,310 @@
+// pywrap_graphlearn: the pybind11 surface the reference's Python layer is written
+// against (graphlearn/python/c/py_export.cc:36-277, py_client.cc:36-527), for the
+// sampling / aggregation / lookup path in local deploy mode, bound to the glx host
+// mirror (libglx_host.so -> libglx.so -> HIP).  Function and attribute names are the
+// reference's, so python code written for `graphlearn.pywrap_graphlearn` runs as is;
+// entry points outside the path (RPC deploy modes, DAG/GSL, subgraph, KNN, vineyard)
+// are not bound.  New: set_sampling_seed / set_device_id (the glx seeding contract
+// and GPU placement).
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "graphlearn/graphlearn.h"
+
+namespace py = pybind11;
+using namespace graphlearn;  // NOLINT
+
+namespace {
+
+template <class T>
+py::array_t<T> CopyOut(const T* data, size_t n) {
+  py::array_t<T> out(n);
+  if (n > 0 && data) std::memcpy(out.mutable_data(), data, n * sizeof(T));
+  return out;
+}
+
+template <class T>
+const T* Checked(const py::array_t<T, py::array::c_style | py::array::forcecast>& a) {
+  return a.data();
+}
+
+typedef py::array_t<int64_t, py::array::c_style | py::array::forcecast> I64Array;
+typedef py::array_t<int32_t, py::array::c_style | py::array::forcecast> I32Array;
+
+}  // namespace
+
+PYBIND11_MODULE(pywrap_graphlearn, m) {
+  m.doc() = "glx: MI355X-native engine behind graph-learn's pywrap_graphlearn interface (hot path only)";
+
+  // ---- global flags (py_export.cc:38-73) ----
+  m.def("set_default_neighbor_id", &SetGlobalFlagDefaultNeighborId);
+  m.def("set_padding_mode", &SetGlobalFlagPaddingMode);
+  m.def("set_default_int_attr", &SetGlobalFlagDefaultIntAttribute);
+  m.def("set_default_float_attr", &SetGlobalFlagDefaultFloatAttribute);
+  m.def("set_default_string_attr", &SetGlobalFlagDefaultStringAttribute);
+  m.def("set_default_weight", &SetGlobalFlagDefaultWeight);
+  m.def("set_default_label", &SetGlobalFlagDefaultLabel);
+  m.def("set_default_timestamp", &SetGlobalFlagDefaultTimestamp);
+  m.def("set_ignore_invalid", &SetGlobalFlagIgnoreInvalid);
+  m.def("set_sampler_retry_times", &SetGlobalFlagSamplingRetryTimes);
+  m.def("set_sampling_seed", &SetGlobalFlagSamplingSeed);
+  m.def("set_device_id", &SetGlobalFlagDeviceId);
+  // thread-pool / queue sizing of the reference's service layer: accepted, no effect
+  for (const char* name : {"set_inter_threadnum", "set_inner_threadnum", "set_intra_threadnum",
+                           "set_datainit_batchsize", "set_inmemory_queuesize", "set_shuffle_buffer_size",
+                           "set_tracker_mode", "set_storage_mode", "set_retry_times", "set_timeout"}) {
+    m.def(name, [](int32_t) {});
+  }
+
+  py::enum_<error::Code>(m, "ErrorCode")
+      .value("OK", error::OK)
+      .value("CANCELLED", error::CANCELLED)
+      .value("UNKNOWN", error::UNKNOWN)
+      .value("INVALID_ARGUMENT", error::INVALID_ARGUMENT)
+      .value("DEADLINE_EXCEEDED", error::DEADLINE_EXCEEDED)
+      .value("NOT_FOUND", error::NOT_FOUND)
+      .value("ALREADY_EXISTS", error::ALREADY_EXISTS)
+      .value("PERMISSION_DENIED", error::PERMISSION_DENIED)
+      .value("UNAUTHENTICATED", error::UNAUTHENTICATED)
+      .value("RESOURCE_EXHAUSTED", error::RESOURCE_EXHAUSTED)
+      .value("FAILED_PRECONDITION", error::FAILED_PRECONDITION)
+      .value("ABORTED", error::ABORTED)
+      .value("OUT_OF_RANGE", error::OUT_OF_RANGE)
+      .value("UNIMPLEMENTED", error::UNIMPLEMENTED)
+      .value("INTERNAL", error::INTERNAL)
+      .value("UNAVAILABLE", error::UNAVAILABLE)
+      .value("DATA_LOSS", error::DATA_LOSS)
+      .value("REQUEST_STOP", error::REQUEST_STOP);
+
+  py::enum_<DataType>(m, "DataType")
+      .value("INT32", kInt32)
+      .value("INT64", kInt64)
+      .value("FLOAT", kFloat)
+      .value("DOUBLE", kDouble)
+      .value("STRING", kString);
+
+  py::enum_<PaddingMode>(m, "PaddingMode").value("REPLICATE", kReplicate).value("CIRCULAR", kCircular);
+
+  py::enum_<FilterType>(m, "FilterType")
+      .value("OPERATOR_UNSPECIFIED", kOperatorUnspecified)
+      .value("EQUAL", kEqual)
+      .value("LARGER_THAN", kLargerThan);
+
+  py::enum_<FilterField>(m, "FilterField")
+      .value("FIELD_UNSPECIFIED", kFieldUnspecified)
+      .value("ID", kId)
+      .value("TIMESTAMP", kTimestamp);
+
+  py::enum_<io::DataFormat>(m, "DataFormat")
+      .value("DEFAULT", io::kDefault)
+      .value("WEIGHTED", io::kWeighted)
+      .value("LABELED", io::kLabeled)
+      .value("ATTRIBUTED", io::kAttributed)
+      .value("TIMESTAMPED", io::kTimestamped);
+
+  py::enum_<io::Direction>(m, "Direction").value("ORIGIN", io::kOrigin).value("REVERSED", io::kReversed);
+
+  py::class_<IndexOption>(m, "IndexOption").def(py::init<>()).def_readwrite("name", &IndexOption::name);
+
+  py::class_<io::AttributeInfo>(m, "AttributeInfo")
+      .def(py::init<>())
+      .def_readwrite("delimiter", &io::AttributeInfo::delimiter)
+      .def_readwrite("ignore_invalid", &io::AttributeInfo::ignore_invalid)
+      .def("append_type", &io::AttributeInfo::AppendType)
+      .def("append_hash_bucket", &io::AttributeInfo::AppendHashBucket);
+
+  py::class_<io::NodeSource>(m, "NodeSource")
+      .def(py::init<>())
+      .def_readwrite("path", &io::NodeSource::path)
+      .def_readwrite("id_type", &io::NodeSource::id_type)
+      .def_readwrite("format", &io::NodeSource::format)
+      .def_readwrite("attr_info", &io::NodeSource::attr_info)
+      .def_readwrite("option", &io::NodeSource::option);
+
+  py::class_<io::EdgeSource>(m, "EdgeSource")
+      .def(py::init<>())
+      .def_readwrite("path", &io::EdgeSource::path)
+      .def_readwrite("edge_type", &io::EdgeSource::edge_type)
+      .def_readwrite("src_id_type", &io::EdgeSource::src_id_type)
+      .def_readwrite("dst_id_type", &io::EdgeSource::dst_id_type)
+      .def_readwrite("format", &io::EdgeSource::format)
+      .def_readwrite("direction", &io::EdgeSource::direction)
+      .def_readwrite("attr_info", &io::EdgeSource::attr_info)
+      .def_readwrite("option", &io::EdgeSource::option);
+
+  py::class_<Status>(m, "Status")
+      .def("ok", &Status::ok)
+      .def("code", &Status::code)
+      .def("message", &Status::msg)
+      .def("to_string", &Status::ToString);
+
+  py::class_<Server>(m, "Server")
+      .def("start", &Server::Start)
+      .def("init", &Server::Init, py::call_guard<py::gil_scoped_release>())
+      .def("init_status", &Server::InitStatus)
+      .def("device_graph", &Server::DeviceGraph)
+      .def("device_features", &Server::DeviceFeatures)
+      .def("stop", &Server::Stop);
+  m.def("server", &NewServer, py::return_value_policy::take_ownership, py::arg("server_id"),
+        py::arg("server_count"), py::arg("server_host"), py::arg("tracker"));
+
+  py::class_<OpRequest>(m, "OpRequest");
+  py::class_<OpResponse>(m, "OpResponse");
+  m.def("del_op_request", [](OpRequest* req) { delete req; });
+  m.def("del_op_response", [](OpResponse* res) { delete res; });
+
+  // ---- client (py_client.cc:40-125) ----
+  py::class_<Client>(m, "Client")
+      .def("stop", &Client::Stop)
+      .def("sample_neighbor",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.Sampling(static_cast<SamplingRequest*>(req), static_cast<SamplingResponse*>(res));
+           },
+           py::call_guard<py::gil_scoped_release>())
+      .def("agg_nodes",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.Aggregating(static_cast<AggregatingRequest*>(req), static_cast<AggregatingResponse*>(res));
+           },
+           py::call_guard<py::gil_scoped_release>())
+      .def("lookup_nodes",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.LookupNodes(static_cast<LookupNodesRequest*>(req), static_cast<LookupResponse*>(res));
+           },
+           py::call_guard<py::gil_scoped_release>())
+      .def("lookup_edges",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.LookupEdges(static_cast<LookupEdgesRequest*>(req), static_cast<LookupResponse*>(res));
+           },
+           py::call_guard<py::gil_scoped_release>())
+      .def("get_degree",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.GetDegree(static_cast<GetDegreeRequest*>(req), static_cast<GetDegreeResponse*>(res));
+           },
+           py::call_guard<py::gil_scoped_release>())
+      .def("run_op", &Client::RunOp, py::call_guard<py::gil_scoped_release>());
+  m.def("in_memory_client", &NewInMemoryClient, py::return_value_policy::take_ownership);
+
+  // ---- sampling (py_client.cc:292-363) ----
+  m.def("new_sampling_request",
+        [](const std::string& type, const std::string& strategy, int32_t neighbor_count, FilterType filter_type,
+           FilterField filter_field) -> OpRequest* {
+          return new SamplingRequest(type, strategy, neighbor_count, filter_type, filter_field);
+        },
+        py::return_value_policy::reference);
+  m.def("new_sampling_response", []() -> OpResponse* { return new SamplingResponse(); },
+        py::return_value_policy::reference);
+  m.def("set_sampling_request", [](OpRequest* req, I64Array src_ids) {
+    static_cast<SamplingRequest*>(req)->Set(src_ids.data(), (int32_t)src_ids.size());
+  });
+  m.def("set_sampling_call_counter", [](OpRequest* req, int64_t call_counter) {
+    static_cast<SamplingRequest*>(req)->SetCallCounter(call_counter);
+  });
+  m.def("get_sampling_node_ids", [](OpResponse* res) {
+    SamplingResponse* r = static_cast<SamplingResponse*>(res);
+    return CopyOut(r->GetNeighborIds(), r->GetShape().size);
+  });
+  m.def("get_sampling_edge_ids", [](OpResponse* res) {
+    SamplingResponse* r = static_cast<SamplingResponse*>(res);
+    return CopyOut(r->GetEdgeIds(), r->GetShape().size);
+  });
+  m.def("get_sampling_node_degrees", [](OpResponse* res) {
+    SamplingResponse* r = static_cast<SamplingResponse*>(res);
+    const Shape& shape = r->GetShape();
+    return CopyOut(shape.segments.data(), shape.segments.size());
+  });
+
+  // ---- aggregation (py_client.cc:365-391) ----
+  m.def("new_aggregating_request",
+        [](const std::string& node_type, const std::string& strategy) -> OpRequest* {
+          return new AggregatingRequest(node_type, strategy);
+        },
+        py::return_value_policy::reference);
+  m.def("new_aggregating_response", []() -> OpResponse* { return new AggregatingResponse(); },
+        py::return_value_policy::reference);
+  m.def("set_aggregating_request", [](OpRequest* req, I64Array node_ids, I32Array segment_ids, int32_t num_segments) {
+    static_cast<AggregatingRequest*>(req)->Set(node_ids.data(), segment_ids.data(), (int32_t)node_ids.size(),
+                                               num_segments);
+  });
+  m.def("get_aggregating_nodes", [](OpResponse* res) {
+    AggregatingResponse* r = static_cast<AggregatingResponse*>(res);
+    return CopyOut(r->Embeddings(), (size_t)r->NumSegments() * r->EmbeddingDim());
+  });
+
+  // ---- lookups (py_client.cc:151-290) ----
+  m.def("new_lookup_nodes_request",
+        [](const std::string& node_type) -> OpRequest* { return new LookupNodesRequest(node_type); },
+        py::return_value_policy::reference);
+  m.def("set_lookup_nodes_request", [](OpRequest* req, I64Array node_ids) {
+    static_cast<LookupNodesRequest*>(req)->Set(node_ids.data(), (int32_t)node_ids.size());
+  });
+  m.def("new_lookup_nodes_response", []() -> OpResponse* { return new LookupResponse(); },
+        py::return_value_policy::reference);
+  m.def("new_lookup_edges_request",
+        [](const std::string& edge_type) -> OpRequest* { return new LookupEdgesRequest(edge_type); },
+        py::return_value_policy::reference);
+  m.def("set_lookup_edges_request", [](OpRequest* req, I64Array src_ids, I64Array edge_ids) {
+    static_cast<LookupEdgesRequest*>(req)->Set(edge_ids.data(), src_ids.data(), (int32_t)edge_ids.size());
+  });
+  m.def("new_lookup_edges_response", []() -> OpResponse* { return new LookupResponse(); },
+        py::return_value_policy::reference);
+  for (const char* prefix : {"node", "edge"}) {
+    const std::string p = std::string("get_") + prefix;
+    m.def((p + "_weights").c_str(), [](OpResponse* res) {
+      LookupResponse* r = static_cast<LookupResponse*>(res);
+      return CopyOut(r->Weights(), r->Weights() ? (size_t)r->Size() : 0);
+    });
+    m.def((p + "_labels").c_str(), [](OpResponse* res) {
+      LookupResponse* r = static_cast<LookupResponse*>(res);
+      return CopyOut(r->Labels(), r->Labels() ? (size_t)r->Size() : 0);
+    });
+    m.def((p + "_timestamps").c_str(), [](OpResponse* res) {
+      LookupResponse* r = static_cast<LookupResponse*>(res);
+      return CopyOut(r->Timestamps(), r->Timestamps() ? (size_t)r->Size() : 0);
+    });
+    m.def((p + "_int_attributes").c_str(), [](OpResponse* res) {
+      LookupResponse* r = static_cast<LookupResponse*>(res);
+      return CopyOut(r->IntAttrs(), r->IntAttrs() ? (size_t)r->Size() * r->IntAttrNum() : 0);
+    });
+    m.def((p + "_float_attributes").c_str(), [](OpResponse* res) {
+      LookupResponse* r = static_cast<LookupResponse*>(res);
+      return CopyOut(r->FloatAttrs(), r->FloatAttrs() ? (size_t)r->Size() * r->FloatAttrNum() : 0);
+    });
+    m.def((p + "_string_attributes").c_str(), [](OpResponse* res) {
+      LookupResponse* r = static_cast<LookupResponse*>(res);
+      py::list out;
+      for (const std::string& s : r->StringAttrs()) out.append(py::str(s));
+      return py::array(py::module_::import("numpy").attr("array")(out, py::arg("dtype") = "object"));
+    });
+  }
+
+  // ---- degrees (py_client.cc:468-491) ----
+  m.def("new_get_degree_request",
+        [](const std::string& edge_type, int32_t /*node_from*/) -> OpRequest* { return new GetDegreeRequest(edge_type); },
+        py::return_value_policy::reference);
+  m.def("set_degree_request", [](OpRequest* req, I64Array node_ids) {
+    static_cast<GetDegreeRequest*>(req)->Set(node_ids.data(), (int32_t)node_ids.size());
+  });
+  m.def("new_get_degree_response", []() -> OpResponse* { return new GetDegreeResponse(); },
+        py::return_value_policy::reference);
+  m.def("get_degree", [](OpResponse* res) {
+    GetDegreeResponse* r = static_cast<GetDegreeResponse*>(res);
+    return CopyOut(r->GetDegrees(), (size_t)r->batch_size_);
+  });
+
+  // ---- loader primitives exposed for the parity tests ----
+  m.def("hash64", [](const py::bytes& b) {
+    const std::string s = b;
+    return io::Hash64(s.data(), s.size());
+  });
+  m.def("parse_attribute", [](const py::bytes& b, const io::AttributeInfo& info) {
+    const std::string s = b;
+    std::vector<int64_t> ints;
+    std::vector<float> floats;
+    std::vector<std::string> strings;
+    Status st = io::ParseAttribute(s.data(), s.size(), info, &ints, &floats, &strings);
+    py::list out;
+    for (const std::string& x : strings) out.append(py::bytes(x));
+    return py::make_tuple((int)st.code(), ints, floats, out);
+  });
+}

@@ -26,7 +26,9 @@
 #define private public
 #include "core/operator/sampler/alias_method.h"
 #undef private
+#include "common/base/hash.h"
 #include "core/graph/graph_store.h"
+#include "core/io/parser.h"
 #include "core/io/element_value.h"
 #include "core/operator/op_factory.h"
 #include "include/aggregating_request.h"
@@ -227,6 +229,45 @@ int glref_aggregate_stitch(const char* strategy, int32_t P, const float* parts, 
   memcpy(emb_out, out.Embeddings(), sizeof(float) * (size_t)dim * num_segments);
   memcpy(cnt_out, out.Segments(), sizeof(int32_t) * num_segments);
   return 0;
+}
+
+// The loader's primitives: Hash64 (common/base/hash.cc:144-150) and ParseAttribute
+// (core/io/parser.cc:39-104) on one packed attribute string.  types[i]: io::DataType;
+// returns the status code; the three outputs are filled in attribute order per kind.
+uint64_t glref_hash64(const char* data, int64_t n) { return ::graphlearn::Hash64(data, (size_t)n); }
+
+int glref_parse_attribute(const char* input, int64_t len, const char* delimiter, const int32_t* types,
+                          const int64_t* hash_buckets, int32_t num_types, int32_t with_buckets, int64_t* ints_out,
+                          int32_t* num_ints, float* floats_out, int32_t* num_floats, char* strings_out,
+                          int64_t strings_cap, int32_t* num_strings) {
+  io::AttributeInfo info;
+  info.delimiter = delimiter;
+  for (int32_t i = 0; i < num_types; ++i) {
+    info.AppendType(static_cast<DataType>(types[i]));
+    if (with_buckets) info.AppendHashBucket(hash_buckets[i]);
+  }
+  io::AttributeValue* value = io::NewDataHeldAttributeValue();
+  LiteString s(input, (size_t)len);
+  Status st = io::ParseAttribute(s, info, value);
+  int ni = 0, nf = 0, ns = 0;
+  const int64_t* iv = value->GetInts(&ni);
+  const float* fv = value->GetFloats(&nf);
+  const std::string* sv = value->GetStrings(&ns);
+  for (int i = 0; i < ni; ++i) ints_out[i] = iv[i];
+  for (int i = 0; i < nf; ++i) floats_out[i] = fv[i];
+  int64_t at = 0;  // strings come back '\n'-separated
+  for (int i = 0; i < ns; ++i) {
+    for (char c : sv[i]) {
+      if (at < strings_cap - 1) strings_out[at++] = c;
+    }
+    if (at < strings_cap - 1) strings_out[at++] = '\n';
+  }
+  strings_out[at] = 0;
+  *num_ints = ni;
+  *num_floats = nf;
+  *num_strings = ns;
+  delete value;
+  return static_cast<int>(st.code());
 }
 
 // FullSampler (full_sampler.cc:28-97) answers with a sparse response: per-row

@@ -321,6 +321,46 @@ def gen_agg_stitch(ref):
     np.savez_compressed(os.path.join(HERE, "agg_stitch.npz"), **out)
 
 
+def gen_loader(ref):
+    """Loader primitives of the reference: Hash64
+    (common/base/hash.cc) on byte strings of every tail length, and ParseAttribute
+    (core/io/parser.cc:39-104) on well-formed and malformed attribute columns."""
+    import json
+    rng = np.random.default_rng(55)
+    hashes = []
+    samples = [b"", b"hehe", b"0", b"12345678", b"123456789", "\u00e9t\u00e9".encode()]
+    for n in range(0, 41):
+        samples.append(bytes(rng.integers(0, 256, n, dtype=np.uint8).tolist()))
+    for b in samples:
+        hashes.append([b.hex(), str(ref.hash64(b))])
+    I32, I64, F, D, S = 0, 1, 2, 3, 4
+    cases = []
+    for data, delim, types, buckets in [
+        (b"3:2.5:7:hehe", ":", [I64, F, S, S], [0, 0, 0, 10]),   # python/tests/utils.py ATTR_TYPES
+        (b"3:2.5:7:hehe", ":", [I64, F, S, S], None),
+        (b"3:x:7:hehe", ":", [I64, F, S, S], [0, 0, 0, 10]),      # bad float
+        (b"3:2.5:7", ":", [I64, F, S, S], [0, 0, 0, 10]),          # too few
+        (b"3:2.5:7:a:b", ":", [I64, F, S, S], [0, 0, 0, 10]),      # too many
+        (b"", ":", [], None),
+        (b"", ":", [S], None),                                      # empty input = zero tokens
+        (b"3::", ":", [I64, S, S], None),                           # empty tokens are kept
+        (b"1,2;3", ",;", [I64, I64, I64], None),                    # the delimiter is a SET of characters
+        (b" 12 :  1e3 :-7", ":", [I64, F, I32], None),              # blanks around numbers
+        (b"12a", ":", [I64], None),
+        (b"99999999999", ":", [I32], None),                          # int32 overflow
+        (b"99999999999", ":", [I64], None),
+        (b"0.1:1.5e-3", ":", [D, D], None),
+        (b"7:abc", ":", [S, S], [5, 0]),                             # hash the first, keep the second
+        (b"-0.0:nan:inf", ":", [F, F, F], None),
+    ]:
+        rc, ints, floats, strings = ref.parse_attribute(data, delim, types, buckets)
+        cases.append(dict(data=data.hex(), delimiter=delim, types=types, hash_buckets=buckets, code=int(rc),
+                          ints=[int(x) for x in ints], floats_bits=[int(x) for x in floats.view(np.uint32)],
+                          strings=[x.hex() for x in strings]))
+    with open(os.path.join(HERE, "loader.json"), "w") as f:
+        json.dump(dict(hash64=hashes, parse_attribute=cases), f, indent=1)
+
+
 def main():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -330,6 +370,7 @@ def main():
     gen_dist_indegree(ref)
     gen_agg(ref)
     gen_agg_stitch(ref)
+    gen_loader(ref)
     # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()
     print("golden fixtures written to", HERE)

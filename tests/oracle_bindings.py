@@ -178,6 +178,10 @@ class RefLib:
         L.glref_sample.argtypes = [VP, cs, cs, VP, i32, i32, VP, VP, ctypes.c_int]
         L.glref_aggregate.argtypes = [VP, cs, cs, VP, VP, i32, i32, VP, VP, VP]
         L.glref_aggregate_stitch.argtypes = [cs, i32, VP, VP, i32, i32, VP, VP]
+        L.glref_hash64.argtypes = [ctypes.c_char_p, i64]
+        L.glref_hash64.restype = ctypes.c_uint64
+        L.glref_parse_attribute.argtypes = [ctypes.c_char_p, i64, cs, VP, VP, i32, i32, VP, VP, VP, VP, ctypes.c_char_p,
+                                            i64, VP]
         L.glref_sample_full.argtypes = [VP, cs, VP, i32, i32, VP, VP, VP, i64]
         L.glref_sample_full.restype = i64
         L.glref_in_degree.argtypes = [VP, cs, i64]
@@ -252,6 +256,24 @@ class RefLib:
         a = np.zeros(w.shape[0], np.int32)
         self.L.glref_alias_build(_p(w), w.shape[0], _p(p), _p(a))
         return p, a
+
+    def hash64(self, data):
+        return int(self.L.glref_hash64(data, len(data)))
+
+    def parse_attribute(self, data, delimiter, types, hash_buckets=None):
+        """types: io::DataType values (0 int32, 1 int64, 2 float, 3 double, 4 string).
+        -> (status code, ints, floats, [bytes])"""
+        t = np.asarray(types, np.int32)
+        hb = np.asarray(hash_buckets if hash_buckets is not None else [0] * len(types), np.int64)
+        ints = np.zeros(max(len(types), 1) + 8, np.int64)
+        floats = np.zeros(max(len(types), 1) + 8, np.float32)
+        buf = ctypes.create_string_buffer(len(data) + 64)
+        ni, nf, ns = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        rc = self.L.glref_parse_attribute(data, len(data), delimiter.encode(), _p(t), _p(hb), len(types),
+                                          1 if hash_buckets is not None else 0, _p(ints), ctypes.byref(ni),
+                                          _p(floats), ctypes.byref(nf), buf, len(buf), ctypes.byref(ns))
+        strings = buf.value.split(b"\n")[:ns.value] if ns.value else []
+        return rc, ints[:ni.value].copy(), floats[:nf.value].copy(), strings
 
     def aggregate_stitch(self, strategy, parts, cnts):
         parts = np.ascontiguousarray(parts, np.float32)

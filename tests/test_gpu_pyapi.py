@@ -1,0 +1,314 @@
+"""The reference's Python unit tests for neighbour sampling, restated against the glx
+engine through the `graphlearn` Python API (graph-learn_amd/python/graphlearn):
+graphlearn/python/sampler/tests/test_{random,random_worepl,edge_weight,topk,in_degree,
+full}_neighbor_sampling.py over the fixture of test_sampling.py (TSV sources written by
+python/tests/utils.py generators -> gl.Graph().node().edge().init()).  Every call goes
+Python -> pywrap_graphlearn (pybind11) -> Operator::Process (C++ host mirror) -> HIP.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import pyapi_fixture as fx  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+NODE1, NODE2 = "node1", "node2"
+EDGE1, EDGE2, EDGE3 = "edge1", "edge2", "edge3"
+RANGE1, RANGE2 = (0, 100), (100, 200)
+DEFAULT_ID, DEFAULT_INT, DEFAULT_FLOAT, DEFAULT_STR = -1, 1000, 999.9, "hehe"
+
+
+@pytest.fixture(scope="module")
+def gl():
+    import graphlearn
+    return graphlearn
+
+
+@pytest.fixture(scope="module")
+def g(gl, tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("gl_data"))
+    gl.set_default_neighbor_id(DEFAULT_ID)
+    gl.set_default_int_attribute(DEFAULT_INT)
+    gl.set_default_float_attribute(DEFAULT_FLOAT)
+    gl.set_default_string_attribute(DEFAULT_STR)
+    gl.set_padding_mode(gl.REPLICATE)
+    gl.set_sampling_seed(20240923)
+    n1 = fx.write_nodes(d, "node1", RANGE1, [fx.ATTRIBUTED])
+    n2 = fx.write_nodes(d, "node2", RANGE2, [fx.WEIGHTED, fx.LABELED])
+    e1 = fx.write_edges(d, "edge1", RANGE1, RANGE2, [fx.ATTRIBUTED, fx.LABELED])
+    e2 = fx.write_edges(d, "edge2", RANGE2, RANGE1, [fx.ATTRIBUTED, fx.WEIGHTED])
+    e3 = fx.write_edges(d, "edge3", RANGE2, RANGE2, [fx.WEIGHTED])
+    n3 = fx.write_entity_nodes(d, "entity")
+    e4 = fx.write_relation_edges(d, "relation")
+    train = fx.write_nodes(d, "node1_train", (0, 50), [fx.WEIGHTED])
+    graph = gl.Graph() \
+        .node(n1, NODE1, gl.Decoder(attr_types=fx.ATTR_TYPES)) \
+        .node(n2, NODE2, gl.Decoder(weighted=True, labeled=True)) \
+        .node(n3, "entity", gl.Decoder(attr_types=["float"] * 4, labeled=True)) \
+        .node(train, NODE1, gl.Decoder(weighted=True), mask=gl.Mask.TRAIN) \
+        .edge(e1, (NODE1, NODE2, EDGE1), gl.Decoder(attr_types=fx.ATTR_TYPES, labeled=True), directed=False) \
+        .edge(e2, (NODE2, NODE1, EDGE2), gl.Decoder(attr_types=fx.ATTR_TYPES, weighted=True)) \
+        .edge(e3, (NODE2, NODE2, EDGE3), gl.Decoder(weighted=True), directed=False) \
+        .edge(e4, ("entity", "entity", "relation"), gl.Decoder(weighted=True), directed=False)
+    graph.init(tracker=d)
+    yield graph
+    graph.close()
+
+
+NODE2_IDS = fx.fixed_dst_ids(range(*RANGE1), RANGE2)
+SEEDS1 = np.array([2, 7, 8])
+SEEDS2 = np.array([102, 107, 108])
+SEEDS1_MISSING = np.array([5, 10, 110])  # no out-edges (multiples of 5) or not a node1 id at all
+
+
+class padding(object):
+    """The fixture's default is REPLICATE, like the reference's test_sampling.py.  Under REPLICATE the
+    reference's padder ignores the sampled indices (replicate_padder.h:45-50): the alias samplers
+    (edge_weight, in_degree) then return the FIRST min(k, degree) neighbours and, for degree < k, read
+    out of bounds; glx default-fills instead.  Tests that want draws use CIRCULAR."""
+
+    def __init__(self, gl, mode):
+        self.gl, self.mode = gl, mode
+
+    def __enter__(self):
+        self.gl.set_padding_mode(self.mode)
+
+    def __exit__(self, *exc):
+        self.gl.set_padding_mode(self.gl.REPLICATE)
+
+
+def one_hop_checks(gl, g, strategy, k=6):
+    with padding(gl, gl.CIRCULAR if strategy == "in_degree" else gl.REPLICATE):
+        nbrs = g.neighbor_sampler(EDGE1, expand_factor=k, strategy=strategy).get(SEEDS1)
+    edges, nodes = nbrs.layer_edges(1), nbrs.layer_nodes(1)
+    fx.expect_edges_follow_generator(edges, RANGE2, SEEDS1, DEFAULT_ID)
+    assert (edges.src_type, edges.dst_type, edges.edge_type) == (NODE1, NODE2, EDGE1)
+    assert edges.src_ids.size == SEEDS1.size * k and edges.shape == (SEEDS1.size, k)
+    fx.expect_edge_columns(edges, labeled=True, attributed=True)
+    np.testing.assert_equal(nodes.ids, edges.dst_ids)
+    assert set(nodes.ids.reshape(-1).tolist()) <= set(NODE2_IDS) and nodes.type == NODE2
+    fx.expect_node_columns(nodes, weighted=True, labeled=True)
+    return nbrs
+
+
+@pytest.mark.parametrize("strategy", ["random", "in_degree"])
+def test_1hop(gl, g, strategy):
+    """test_random_neighbor_sampling.py::test_1hop / test_in_degree_neighbor_sampling.py::test_1hop."""
+    nbrs = one_hop_checks(gl, g, strategy)
+    deg = nbrs.layer_edges(1).src_nodes.get_out_degrees(EDGE1)
+    np.testing.assert_equal(deg.reshape(-1), np.repeat(SEEDS1 % 5, 6))
+
+
+@pytest.mark.parametrize("strategy", ["random", "random_without_replacement", "in_degree"])
+def test_1hop_with_neighbor_missing(gl, g, strategy):
+    """Seeds without out-edges: default neighbour id and default columns everywhere."""
+    k = 6
+    nbrs = g.neighbor_sampler(EDGE1, expand_factor=k, strategy=strategy).get(SEEDS1_MISSING)
+    edges, nodes = nbrs.layer_edges(1), nbrs.layer_nodes(1)
+    np.testing.assert_equal(edges.dst_ids.reshape(-1), [DEFAULT_ID] * (3 * k))
+    fx.expect_default_edge_columns(edges, labeled=True, attributed=True, default_int=DEFAULT_INT,
+                                   default_float=DEFAULT_FLOAT, default_string=DEFAULT_STR)
+    np.testing.assert_equal(nodes.ids, edges.dst_ids)
+    np.testing.assert_equal(nodes.weights.reshape(-1), [0.0] * (3 * k))   # check_not_exist_node_weights
+    np.testing.assert_equal(nodes.labels.reshape(-1), [-1] * (3 * k))     # check_not_exist_node_labels
+
+
+@pytest.mark.parametrize("strategy", ["random", "random_without_replacement", "edge_weight"])
+def test_2hop(gl, g, strategy):
+    """node1 -edge1-> node2 -edge2-> node1 with fan-out [3, 2]."""
+    first = EDGE1 if strategy != "edge_weight" else EDGE3  # edge1 carries no weights
+    seeds = SEEDS1 if strategy != "edge_weight" else SEEDS2
+    ks = [3, 2]
+    # degree 2 < 3: replicate padding would default-fill the permutation / alias samplers
+    with padding(gl, gl.REPLICATE if strategy == "random" else gl.CIRCULAR):
+        nbrs = g.neighbor_sampler([first, EDGE2], expand_factor=ks, strategy=strategy).get(seeds)
+    edges, nodes = nbrs.layer_edges(1), nbrs.layer_nodes(1)
+    assert edges.shape == (3, 3)
+    np.testing.assert_equal(nodes.ids, edges.dst_ids)
+    if strategy != "edge_weight":
+        fx.expect_edges_follow_generator(edges, RANGE2, seeds, DEFAULT_ID)
+        fx.expect_edge_columns(edges, labeled=True, attributed=True)
+    fx.expect_node_columns(nodes, weighted=True, labeled=True)
+    hop1 = nodes.ids.reshape(-1)
+    edges, nodes = nbrs.layer_edges(2), nbrs.layer_nodes(2)
+    assert edges.shape == (9, 2) and (edges.src_type, edges.dst_type, edges.edge_type) == (NODE2, NODE1, EDGE2)
+    np.testing.assert_equal(edges.src_ids.reshape(-1), np.repeat(hop1, 2))
+    fx.expect_edges_follow_generator(edges, RANGE1, hop1, DEFAULT_ID)
+    exist = edges.dst_ids != DEFAULT_ID
+    np.testing.assert_almost_equal(edges.weights[exist], 0.1 * (edges.src_ids + 0.1 * edges.dst_ids)[exist], decimal=5)
+    np.testing.assert_equal(edges.weights[~exist], 0.0)
+    np.testing.assert_equal(nodes.ids, edges.dst_ids)
+    real = nodes.ids != DEFAULT_ID
+    np.testing.assert_equal(nodes.int_attrs[..., 0][real], nodes.ids[real])
+    np.testing.assert_equal(nodes.int_attrs[..., 0][~real], DEFAULT_INT)
+    # the 4th attribute ('string', 10) is stored as Hash64('hehe') % 10
+    np.testing.assert_equal(nodes.int_attrs[..., 1][real], gl.pywrap.hash64(b"hehe") % 10)
+
+
+@pytest.mark.parametrize("mode", ["replicate", "circular"])
+def test_random_without_replacement_1hop_padding(gl, g, mode):
+    """test_random_worepl_neighbor_sampling.py::test_1hop_{circular,replicate}_padding: k = 6 exceeds
+    every degree, so a row is exactly its neighbour set (plus the default id under replicate padding)."""
+    gl.set_padding_mode(gl.REPLICATE if mode == "replicate" else gl.CIRCULAR)
+    try:
+        nbrs = g.neighbor_sampler(EDGE1, expand_factor=6, strategy="random_without_replacement").get(SEEDS1)
+        for s, row in zip(SEEDS1, nbrs.layer_nodes(1).ids):
+            want = set(fx.fixed_dst_ids(int(s), RANGE2))
+            if mode == "replicate":
+                want.add(DEFAULT_ID)
+            assert set(row.tolist()) == want
+    finally:
+        gl.set_padding_mode(gl.REPLICATE)
+
+
+def test_random_without_replacement_returns_distinct_neighbours(gl, g):
+    """test_random_worepl_neighbor_sampling.py: with k >= degree every neighbour shows up."""
+    gl.set_padding_mode(gl.CIRCULAR)
+    try:
+        seeds = np.array([104, 109, 103])
+        k = 4
+        nbrs = g.neighbor_sampler(EDGE2, expand_factor=k, strategy="random_without_replacement").get(seeds)
+        got = nbrs.layer_nodes(1).ids
+        for row, s in zip(got, seeds):
+            want = fx.fixed_dst_ids(int(s), RANGE1)
+            assert set(row.tolist()) == set(want) and len(want) == s % 5
+            assert sorted(row[:len(want)].tolist()) == sorted(want)  # a permutation first, then it repeats
+    finally:
+        gl.set_padding_mode(gl.REPLICATE)
+
+
+@pytest.mark.parametrize("mode", ["replicate", "circular"])
+def test_topk_padding_modes(gl, g, mode):
+    """test_topk_neighbor_sampling.py: exact expectations for both padding modes."""
+    gl.set_padding_mode(gl.REPLICATE if mode == "replicate" else gl.CIRCULAR)
+    try:
+        seeds = np.array([102, 107, 108, 105, 104])
+        nbrs = g.neighbor_sampler(EDGE2, 6, strategy="topk").get(seeds)
+        edges = nbrs.layer_edges(1)
+        np.testing.assert_equal(edges.dst_ids.reshape(-1), fx.expected_topk(seeds, RANGE1, 6, DEFAULT_ID, mode))
+        src, dst, w = edges.src_ids.reshape(-1), edges.dst_ids.reshape(-1), edges.weights.reshape(-1)
+        for s, d_, w_ in zip(src, dst, w):  # check_half_exist_edge_weights
+            np.testing.assert_almost_equal(w_, 0.0 if d_ == DEFAULT_ID else 0.1 * (s + 0.1 * d_), decimal=5)
+    finally:
+        gl.set_padding_mode(gl.REPLICATE)
+
+
+def test_edge_weight_1hop(gl, g):
+    """test_edge_weight_neighbor_sampling.py::test_1hop on the weighted homogeneous type."""
+    k = 6
+    with padding(gl, gl.CIRCULAR):
+        nbrs = g.neighbor_sampler(EDGE3, expand_factor=k, strategy="edge_weight").get(SEEDS2)
+    edges, nodes = nbrs.layer_edges(1), nbrs.layer_nodes(1)
+    assert edges.shape == (3, k) and nodes.type == NODE2
+    # edge3 was added with directed=False: both directions live in one adjacency
+    src, dst = edges.src_ids.reshape(-1), edges.dst_ids.reshape(-1)
+    for s, d_ in zip(src.tolist(), dst.tolist()):
+        forward = d_ in fx.fixed_dst_ids(s, RANGE2)
+        backward = s in fx.fixed_dst_ids(d_, RANGE2)
+        assert forward or backward, (s, d_)
+    fx.expect_node_columns(nodes, weighted=True, labeled=True)
+
+
+def test_full_neighbor_sampler(gl, g):
+    """test_full_neighbor_sampling.py: every neighbour, ragged rows."""
+    nbrs = g.neighbor_sampler(EDGE1, 0, strategy="full").get(SEEDS1)
+    nodes, edges = nbrs.layer_nodes(1), nbrs.layer_edges(1)
+    assert nodes.offsets == [int(s % 5) for s in SEEDS1]
+    for row, s in zip(nodes, SEEDS1):
+        assert sorted(row.ids.tolist()) == sorted(fx.fixed_dst_ids(int(s), RANGE2))
+    assert len(nodes.indices) == sum(nodes.offsets) and nodes.dense_shape == (3, 3)
+    np.testing.assert_equal(edges.src_ids, np.repeat(SEEDS1, SEEDS1 % 5))
+    capped = g.neighbor_sampler(EDGE1, 2, strategy="full").get(SEEDS1).layer_nodes(1)
+    assert capped.offsets == [2, 2, 2]
+
+
+def test_reverse_edges_of_undirected_types(gl, g):
+    """directed=False on a heterogeneous type registers `<type>_reverse` (graph.py:357-380)."""
+    assert not g.is_directed(EDGE1) and g.is_directed(EDGE2)
+    topo = g.get_topology()
+    assert (topo.get_src_type(EDGE1 + "_reverse"), topo.get_dst_type(EDGE1 + "_reverse")) == (NODE2, NODE1)
+    dst = 102
+    want = sorted(s for s in range(*RANGE1) if dst in fx.fixed_dst_ids(s, RANGE2))
+    got = g.neighbor_sampler(EDGE1 + "_reverse", 0, strategy="full").get(np.array([dst])).layer_nodes(1)
+    assert sorted(got.ids.tolist()) == want
+
+
+def test_masked_source_is_a_separate_type(gl, g):
+    masked = gl.get_mask_type(NODE1, gl.Mask.TRAIN)
+    assert masked == "MASK*node1"
+    vals = g.lookup_nodes(masked, np.array([3, 49, 50]))
+    np.testing.assert_almost_equal(vals.weights, [0.3, 4.9, 0.0], decimal=5)  # 50 is not in the TRAIN file
+
+
+def test_embedding_agg_equals_numpy(gl, g):
+    """Nodes.embedding_agg -> Sum/Mean/Max/Min/Prod aggregators over float attributes."""
+    ids = np.array([[1, 2, 3], [10, 20, 119], [7, 7, 500]])  # 500 is unknown -> default row
+    nodes = g.get_nodes("entity", ids)
+    table = np.array([[v * 0.1, v * 0.2, v * 0.3, v * 0.4] for v in range(120)], np.float64)
+    rows = np.stack([table[v] if v < 120 else np.full(4, DEFAULT_FLOAT) for v in ids.reshape(-1)]).reshape(3, 3, 4)
+    np.testing.assert_allclose(nodes.embedding_agg("sum"), rows.sum(1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(nodes.embedding_agg("mean"), rows.mean(1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(nodes.embedding_agg("min"), rows.min(1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(nodes.embedding_agg("max"), np.maximum(rows.max(1), -37.0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(nodes.embedding_agg("prod"), rows.prod(1), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(nodes.float_attrs, rows, rtol=1e-5, atol=1e-5)
+    np.testing.assert_equal(nodes.labels, np.where(ids < 120, ids, -1))
+
+
+def test_seeded_sampling_is_reproducible(gl, g):
+    """New with this engine: a pinned call counter replays the same draws."""
+    s = g.neighbor_sampler([EDGE3, EDGE3], expand_factor=[5, 4], strategy="edge_weight")
+    with padding(gl, gl.CIRCULAR):
+        s.set_call_counter(77)
+        a = s.get(SEEDS2)
+        b = s.get(SEEDS2)
+        s.set_call_counter(78)
+        c = s.get(SEEDS2)
+    for hop in (1, 2):
+        np.testing.assert_equal(a.layer_nodes(hop).ids, b.layer_nodes(hop).ids)
+    assert not np.array_equal(a.layer_nodes(2).ids, c.layer_nodes(2).ids)
+
+
+def test_error_surface(gl, g, tmp_path):
+    with pytest.raises(ValueError):
+        g.neighbor_sampler("no_such_edge", 3)
+    with pytest.raises(ValueError):
+        g.neighbor_sampler([EDGE1, EDGE2], expand_factor=[3]).get(SEEDS1)
+    with pytest.raises(NotImplementedError):
+        g.V(NODE1)
+    bad = fx.write_nodes(str(tmp_path), "bad_nodes", (0, 5), [fx.WEIGHTED])
+    other = gl.Graph().node(bad, "x", gl.Decoder(labeled=True))  # file has weight:float, decoder says label
+    with pytest.raises(gl.InvalidArgumentError):
+        other.init()
+    other.close()
+
+
+def test_device_tensor_path_equals_numpy_path(gl, g):
+    """NeighborSampler.get_device: all hops in one glx_sample_hops call on torch CUDA tensors, same
+    draws as the request-per-hop numpy path; device_features().aggregate == Nodes.embedding_agg."""
+    import torch
+    s = g.neighbor_sampler([EDGE3, EDGE3], expand_factor=[5, 4], strategy="edge_weight")
+    with padding(gl, gl.CIRCULAR):
+        s.set_call_counter(500)
+        host = s.get(SEEDS2)
+        dev = s.get_device(torch.from_numpy(SEEDS2).cuda(), call_counter=500)
+    for hop in (1, 2):
+        nbr, eid = dev[hop - 1]
+        assert nbr.is_cuda and tuple(nbr.shape) == host.layer_nodes(hop).ids.shape
+        np.testing.assert_equal(nbr.cpu().numpy(), host.layer_nodes(hop).ids)
+        np.testing.assert_equal(eid.cpu().numpy(), host.layer_edges(hop).edge_ids)
+    feats = g.device_features("entity")
+    ids = np.array([[1, 2, 3], [10, 20, 119]])
+    seg = torch.arange(2, dtype=torch.int32).repeat_interleave(3).cuda()
+    emb, cnt = feats.aggregate("MeanAggregator", torch.from_numpy(ids.reshape(-1)).cuda(), seg, 2,
+                               default_attr=DEFAULT_FLOAT)
+    want = g.get_nodes("entity", ids).embedding_agg("mean")
+    np.testing.assert_equal(emb.cpu().numpy().view(np.uint32), want.astype(np.float32).view(np.uint32))
+    assert cnt.tolist() == [3, 3]

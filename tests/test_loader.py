@@ -1,0 +1,130 @@
+"""CPU tests of the data-format side of the path: the TSV loader's
+primitives against golden vectors produced by the reference's own code
+(tests/golden/loader.json: common/base/hash.cc Hash64, core/io/parser.cc ParseAttribute,
+generated through oracle/_ref by tests/golden/make_golden.py), the schema check of
+edge_loader.cc:110-141 / node_loader.cc, and the Python surface around them."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import graphlearn as gl  # noqa: E402
+import glx  # noqa: E402
+import pyapi_fixture as fx  # noqa: E402
+from oracle_bindings import RefLib, have_ref  # noqa: E402
+
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "loader.json")))
+PYWRAP_TYPES = [gl.pywrap.DataType.INT32, gl.pywrap.DataType.INT64, gl.pywrap.DataType.FLOAT,
+                gl.pywrap.DataType.DOUBLE, gl.pywrap.DataType.STRING]
+
+
+def _no_gpu():
+    n = ctypes.c_int(-1)
+    return glx.lib().glx_device_count(ctypes.byref(n)) != 0
+
+
+def test_hash64_matches_reference_golden():
+    for hexed, want in GOLD["hash64"]:
+        assert gl.pywrap.hash64(bytes.fromhex(hexed)) == int(want), hexed
+
+
+def _parse(case):
+    info = gl.pywrap.AttributeInfo()
+    info.delimiter = case["delimiter"]
+    for t in case["types"]:
+        info.append_type(PYWRAP_TYPES[t])
+    for b in case["hash_buckets"] or []:
+        info.append_hash_bucket(b)
+    return gl.pywrap.parse_attribute(bytes.fromhex(case["data"]), info)
+
+
+def test_parse_attribute_matches_reference_golden():
+    for case in GOLD["parse_attribute"]:
+        code, ints, floats, strings = _parse(case)
+        assert code == case["code"], case
+        if code != 0:
+            continue
+        assert list(ints) == case["ints"], case
+        assert [int(x) for x in np.asarray(floats, np.float32).view(np.uint32)] == case["floats_bits"], case
+        assert [s.hex() for s in strings] == case["strings"], case
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_loader_primitives_live_reference():
+    ref = RefLib()
+    rng = np.random.default_rng(5)
+    try:
+        for _ in range(300):
+            b = bytes(rng.integers(0, 256, int(rng.integers(0, 64)), dtype=np.uint8).tolist())
+            assert gl.pywrap.hash64(b) == ref.hash64(b)
+        alphabet = b"0123456789.-e:, ax"
+        for _ in range(400):
+            n = int(rng.integers(1, 5))
+            types = [int(t) for t in rng.integers(0, 5, n)]
+            buckets = [int(x) for x in rng.integers(0, 4, n)] if rng.random() < 0.5 else None
+            data = bytes(alphabet[i] for i in rng.integers(0, len(alphabet), int(rng.integers(0, 20))))
+            want = ref.parse_attribute(data, ":,", types, buckets)
+            got = _parse(dict(data=data.hex(), delimiter=":,", types=types, hash_buckets=buckets))
+            assert got[0] == want[0], (data, types)
+            if want[0] == 0:
+                assert list(got[1]) == list(want[1]) and [s for s in got[3]] == list(want[3]), (data, types)
+                assert np.array_equal(np.asarray(got[2], np.float32).view(np.uint32), want[2].view(np.uint32))
+    finally:
+        ref.close()
+
+
+def test_decoder_counts_and_format_bits():
+    d = gl.Decoder(weighted=True, labeled=True, attr_types=fx.ATTR_TYPES)
+    # ('string', 10) is hashed into an int attribute (parser.h:50-57)
+    assert (d.int_attr_num, d.float_attr_num, d.string_attr_num) == (2, 1, 1)
+    assert d.data_format == 2 + 4 + 16 and d.has_property and d.attributed
+    assert gl.Decoder().data_format == 0 and not gl.Decoder().has_property
+    assert gl.Decoder(attr_types=["int", ("string", 8, True)]).string_attr_num == 1  # multi-valued stays a string
+    with pytest.raises(ValueError):
+        gl.Decoder(attr_types=[("int", 3, True)])
+    assert gl.strategy2op("random_without_replacement", "Sampler") == "RandomWithoutReplacementSampler"
+    assert [gl.get_mask_type("u", m) for m in gl.Mask] == ["u", "MASK*u", "MASK**u", "MASK***u"]
+
+
+def test_schema_mismatch_is_invalid_argument(tmp_path):
+    """The header must spell the optional columns the decoder declares, in order."""
+    weighted = fx.write_nodes(str(tmp_path), "w_nodes", (0, 4), [fx.WEIGHTED])
+    g = gl.Graph().node(weighted, "n", gl.Decoder(attr_types=["int"]))
+    with pytest.raises(gl.InvalidArgumentError, match="Invalid node table schema"):
+        g.init()
+    g.close()
+    edges = fx.write_edges(str(tmp_path), "e", (0, 4), (10, 20), [fx.WEIGHTED])
+    g = gl.Graph().edge(edges, ("a", "b", "e"), gl.Decoder(weighted=True, labeled=True))
+    with pytest.raises(gl.InvalidArgumentError, match="Invalid edge table schema"):
+        g.init()
+    g.close()
+    g = gl.Graph().node(os.path.join(str(tmp_path), "missing"), "n", gl.Decoder())
+    with pytest.raises(gl.NotFoundError):
+        g.init()
+    g.close()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is visible")
+def test_python_api_fails_loudly_without_gpu(tmp_path):
+    """Parsing is host work, the store lives in HBM: without a GPU init() raises, nothing falls back."""
+    nodes = fx.write_nodes(str(tmp_path), "nodes", (0, 10), [fx.ATTRIBUTED])
+    edges = fx.write_edges(str(tmp_path), "edges", (0, 10), (0, 10), [fx.WEIGHTED])
+    g = gl.Graph().node(nodes, "n", gl.Decoder(attr_types=fx.ATTR_TYPES)) \
+        .edge(edges, ("n", "n", "e"), gl.Decoder(weighted=True))
+    with pytest.raises(gl.UnavailableError, match="no CPU fallback"):
+        g.init()
+    g.close()
+
+
+def test_distributed_modes_are_not_served():
+    with pytest.raises(NotImplementedError):
+        gl.Graph().init(task_count=2)
+    with pytest.raises(NotImplementedError):
+        gl.Graph().init(cluster={"server_count": 1, "client_count": 1})
