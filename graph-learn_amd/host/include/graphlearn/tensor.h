@@ -55,6 +55,9 @@ public:
   int32_t* MutableInt32();
   int64_t* MutableInt64();
   float* MutableFloat();
+  // Keeps the storage alive independently of this Tensor (zero-copy hand-off of a response
+  // block to a caller such as numpy).
+  std::shared_ptr<const void> Owner() const;
 
   typedef std::unordered_map<std::string, Tensor> Map;
 

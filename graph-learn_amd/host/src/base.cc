@@ -1,4 +1,8 @@
 // Status, flags, constants and the vector-backed Tensor of the glx host layer.
+#include <cstdlib>
+#include <mutex>
+#include <new>
+#include <vector>
 #include <cstring>
 
 #include "glx.h"
@@ -77,14 +81,97 @@ const char* kFilterField = "filter_field";
 const char* kFilterValues = "filter_values";
 
 // ----------------------------------------------------------------- tensor --
+// Storage of the numeric tensors.  A response of the device path is one large block
+// written by a single device->host copy, so two things matter on the host side:
+// (1) no value-initialisation of memory that is about to be overwritten, and
+// (2) no fresh mmap + page faults per request.  BlockPool recycles large blocks
+// (>= 256 KiB, power-of-two classes, at most kPoolCap bytes parked) across requests;
+// small tensors use the ordinary heap.
+namespace {
+class BlockPool {
+public:
+  static BlockPool& Get() {
+    static BlockPool* pool = new BlockPool;  // never destroyed: tensors may outlive static teardown
+    return *pool;
+  }
+  static constexpr size_t kMinBytes = 256u << 10;
+  static constexpr size_t kPoolCap = 4ull << 30;
+  static int ClassOf(size_t bytes) {
+    int c = 18;
+    while ((1ull << c) < bytes) ++c;
+    return c;
+  }
+  void* Take(size_t bytes) {
+    const int c = ClassOf(bytes);
+    {
+      std::lock_guard<std::mutex> g(mtx_);
+      if (c < 48 && !free_[c].empty()) {
+        void* p = free_[c].back();
+        free_[c].pop_back();
+        parked_ -= 1ull << c;
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (posix_memalign(&p, 4096, 1ull << c) != 0) throw std::bad_alloc();
+    return p;
+  }
+  void Give(void* p, size_t bytes) {
+    const int c = ClassOf(bytes);
+    {
+      std::lock_guard<std::mutex> g(mtx_);
+      if (c < 48 && parked_ + (1ull << c) <= kPoolCap) {
+        free_[c].push_back(p);
+        parked_ += 1ull << c;
+        return;
+      }
+    }
+    std::free(p);
+  }
+
+private:
+  std::mutex mtx_;
+  std::vector<void*> free_[48];
+  size_t parked_ = 0;
+};
+
+template <class T>
+struct PoolAlloc {
+  typedef T value_type;
+  PoolAlloc() = default;
+  template <class U>
+  PoolAlloc(const PoolAlloc<U>&) {}
+  T* allocate(size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= BlockPool::kMinBytes) return static_cast<T*>(BlockPool::Get().Take(bytes));
+    return static_cast<T*>(::operator new(bytes));
+  }
+  void deallocate(T* p, size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= BlockPool::kMinBytes) BlockPool::Get().Give(p, bytes);
+    else ::operator delete(p);
+  }
+  template <class U>
+  void construct(U* p) { ::new (static_cast<void*>(p)) U; }  // default-init: no zero fill
+  template <class U, class... Args>
+  void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+  template <class U>
+  bool operator==(const PoolAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const PoolAlloc<U>&) const { return false; }
+};
+}  // namespace
+
 struct Tensor::Impl {
   DataType type = kUnknown;
-  std::vector<int32_t> i32;
-  std::vector<int64_t> i64;
-  std::vector<float> f32;
-  std::vector<double> f64;
+  std::vector<int32_t, PoolAlloc<int32_t>> i32;
+  std::vector<int64_t, PoolAlloc<int64_t>> i64;
+  std::vector<float, PoolAlloc<float>> f32;
+  std::vector<double, PoolAlloc<double>> f64;
   std::vector<std::string> str;
 };
+
+std::shared_ptr<const void> Tensor::Owner() const { return impl_; }
 
 Tensor::Tensor() : impl_(std::make_shared<Impl>()) {}
 Tensor::Tensor(DataType dtype) : impl_(std::make_shared<Impl>()) { impl_->type = dtype; }

@@ -145,7 +145,7 @@ class Nodes(Values):
 
   def __init__(self, ids, node_type, int_attrs=None, float_attrs=None, string_attrs=None, weights=None,
                labels=None, timestamps=None, shape=None, graph=None):
-    ids = np.array(ids)
+    ids = np.asarray(ids)
     super(Nodes, self).__init__(int_attrs, float_attrs, string_attrs, weights, labels, timestamps,
                                 _resolve_shape(ids, shape), graph)
     self._ids = self._view(ids)
@@ -263,12 +263,12 @@ class Edges(Values):
       src_ids, src_type = src_nodes.ids, src_nodes.type
     if dst_nodes is not None:
       dst_ids, dst_type = dst_nodes.ids, dst_nodes.type
-    src_ids = np.array(src_ids)
+    src_ids = np.asarray(src_ids)
     super(Edges, self).__init__(int_attrs, float_attrs, string_attrs, weights, labels, timestamps,
                                 _resolve_shape(src_ids, shape), graph)
     self._src_ids = self._view(src_ids)
-    self._dst_ids = self._view(np.array(dst_ids))
-    self._edge_ids = self._view(None if edge_ids is None else np.array(edge_ids))
+    self._dst_ids = self._view(np.asarray(dst_ids))
+    self._edge_ids = self._view(None if edge_ids is None else np.asarray(edge_ids))
     self._src_type, self._dst_type, self._edge_type = src_type, dst_type, edge_type
     self._src_nodes, self._dst_nodes = src_nodes, dst_nodes
 
@@ -310,7 +310,7 @@ class Edges(Values):
 
   @edge_ids.setter
   def edge_ids(self, edge_ids):
-    self._edge_ids = self._view(np.array(edge_ids))
+    self._edge_ids = self._view(np.asarray(edge_ids))
 
   @property
   def type(self):  # pylint: disable=redefined-builtin

@@ -10,6 +10,8 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <type_traits>
+
 #include "graphlearn/graphlearn.h"
 
 namespace py = pybind11;
@@ -24,9 +26,21 @@ py::array_t<T> CopyOut(const T* data, size_t n) {
   return out;
 }
 
+// Zero-copy hand-off of a response block: the numpy array keeps the tensor's storage
+// alive (Tensor::Owner), so it stays valid after del_op_response; the block returns to
+// the host layer's pool when the array dies.
 template <class T>
-const T* Checked(const py::array_t<T, py::array::c_style | py::array::forcecast>& a) {
-  return a.data();
+py::array_t<T> ViewOf(const OpResponse* res, const char* key, size_t n) {
+  auto it = res->tensors_.find(key);
+  if (it == res->tensors_.end() || n == 0) return py::array_t<T>(0);
+  const Tensor& t = it->second;
+  const T* data = nullptr;
+  if (std::is_same<T, int64_t>::value) data = reinterpret_cast<const T*>(t.GetInt64());
+  else if (std::is_same<T, int32_t>::value) data = reinterpret_cast<const T*>(t.GetInt32());
+  else data = reinterpret_cast<const T*>(t.GetFloat());
+  auto* keep = new std::shared_ptr<const void>(t.Owner());
+  py::capsule owner(keep, [](void* p) { delete static_cast<std::shared_ptr<const void>*>(p); });
+  return py::array_t<T>({n}, {sizeof(T)}, data, owner);
 }
 
 typedef py::array_t<int64_t, py::array::c_style | py::array::forcecast> I64Array;
@@ -202,11 +216,11 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   });
   m.def("get_sampling_node_ids", [](OpResponse* res) {
     SamplingResponse* r = static_cast<SamplingResponse*>(res);
-    return CopyOut(r->GetNeighborIds(), r->GetShape().size);
+    return ViewOf<int64_t>(r, kNodeIds, r->GetShape().size);
   });
   m.def("get_sampling_edge_ids", [](OpResponse* res) {
     SamplingResponse* r = static_cast<SamplingResponse*>(res);
-    return CopyOut(r->GetEdgeIds(), r->GetShape().size);
+    return ViewOf<int64_t>(r, kEdgeIds, r->GetShape().size);
   });
   m.def("get_sampling_node_degrees", [](OpResponse* res) {
     SamplingResponse* r = static_cast<SamplingResponse*>(res);
@@ -228,7 +242,7 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   });
   m.def("get_aggregating_nodes", [](OpResponse* res) {
     AggregatingResponse* r = static_cast<AggregatingResponse*>(res);
-    return CopyOut(r->Embeddings(), (size_t)r->NumSegments() * r->EmbeddingDim());
+    return ViewOf<float>(r, kFloatAttrKey, (size_t)r->NumSegments() * r->EmbeddingDim());
   });
 
   // ---- lookups (py_client.cc:151-290) ----
@@ -268,7 +282,7 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
     });
     m.def((p + "_float_attributes").c_str(), [](OpResponse* res) {
       LookupResponse* r = static_cast<LookupResponse*>(res);
-      return CopyOut(r->FloatAttrs(), r->FloatAttrs() ? (size_t)r->Size() * r->FloatAttrNum() : 0);
+      return ViewOf<float>(r, kFloatAttrKey, r->FloatAttrs() ? (size_t)r->Size() * r->FloatAttrNum() : 0);
     });
     m.def((p + "_string_attributes").c_str(), [](OpResponse* res) {
       LookupResponse* r = static_cast<LookupResponse*>(res);
