@@ -158,6 +158,7 @@ struct glx_graph {
   float* weight;     // [E] or nullptr
   GlxAlias* alias;   // [E] or nullptr
   GlxAlias* alias_indeg;  // [E] alias tables over the neighbours' in-degrees, or nullptr
+  int64_t* nbr_sorted;    // [E] every row's neighbour ids ascending (strict negative sampling), or nullptr
   GlxEwRec* ew;           // [E] packed EdgeWeight records, or nullptr (edge ids beyond int32)
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
@@ -174,6 +175,45 @@ struct glx_features {
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
 };
+
+// AliasMethod::Build (alias_method.cc:57-107) for ONE distribution of `count` weights,
+// bit-identical to the serial reference: LIFO low/high stacks (`low` grows up from its
+// base, `high` grows down from its base; |low| + |high| <= count always, so both may
+// share one array of `count` ints from opposite ends), sum accumulated in double then
+// narrowed to float (:73), float arithmetic without contraction (-ffp-contract=off).
+// Runs per row on the device (one lane per row) and on the host for the one global
+// table of a negative sampler.
+__host__ __device__ inline void glx_alias_build_row(const float* dist, int32_t count, GlxAlias* tab,
+                                                    int32_t* low, int32_t* high) {
+  const float avg_prob = (float)(1.0 / (double)count);
+  double acc = 0.0;
+  for (int32_t i = 0; i < count; ++i) acc += (double)dist[i];
+  const float sum = (float)acc;
+  int32_t low_num = 0, high_num = 0;
+  for (int32_t i = 0; i < count; ++i) {
+    float prob = dist[i] / sum;
+    tab[i] = GlxAlias{prob * (float)count, i};
+    if (prob < avg_prob) {
+      low[low_num++] = i;
+    } else if (prob > avg_prob) {
+      high[-(high_num++)] = i;
+    }
+  }
+  while (low_num > 0 && high_num > 0) {
+    int32_t low_idx = low[--low_num];
+    int32_t high_idx = high[-(--high_num)];
+    float p = tab[high_idx].prob - 1.0f + tab[low_idx].prob;
+    tab[high_idx].prob = p;
+    tab[low_idx].alias = high_idx;
+    if (p < 1.0f) {
+      low[low_num++] = high_idx;
+    } else if (p > 1.0f) {
+      high[-(high_num++)] = high_idx;
+    }
+  }
+  while (low_num > 0) tab[low[--low_num]].prob = 1.0f;
+  while (high_num > 0) tab[high[-(--high_num)]].prob = 1.0f;
+}
 
 // ------------------------------------------------------------- contract RNG -
 // Philox4x32-10; key = (seed lo, seed hi); counter = (j >> 1, row, cc lo, cc hi).

@@ -316,38 +316,7 @@ __global__ void glx_alias_build_kernel(const int64_t* __restrict__ row_ptr,
   const int64_t s = row_ptr[row];
   const int32_t count = (int32_t)(row_ptr[row + 1] - s);
   if (count == 0) return;
-  const float* dist = weight + s;
-  GlxAlias* tab = out + s;
-  int32_t* low = stk + s;
-  int32_t* high = stk + s + count - 1;  // high[-h]
-  const float avg_prob = (float)(1.0 / (double)count);
-  double acc = 0.0;
-  for (int32_t i = 0; i < count; ++i) acc += (double)dist[i];
-  const float sum = (float)acc;
-  int32_t low_num = 0, high_num = 0;
-  for (int32_t i = 0; i < count; ++i) {
-    float prob = dist[i] / sum;
-    tab[i] = GlxAlias{prob * (float)count, i};
-    if (prob < avg_prob) {
-      low[low_num++] = i;
-    } else if (prob > avg_prob) {
-      high[-(high_num++)] = i;
-    }
-  }
-  while (low_num > 0 && high_num > 0) {
-    int32_t low_idx = low[--low_num];
-    int32_t high_idx = high[-(--high_num)];
-    float p = tab[high_idx].prob - 1.0f + tab[low_idx].prob;
-    tab[high_idx].prob = p;
-    tab[low_idx].alias = high_idx;
-    if (p < 1.0f) {
-      low[low_num++] = high_idx;
-    } else if (p > 1.0f) {
-      high[-(high_num++)] = high_idx;
-    }
-  }
-  while (low_num > 0) tab[low[--low_num]].prob = 1.0f;
-  while (high_num > 0) tab[high[-(--high_num)]].prob = 1.0f;
+  glx_alias_build_row(weight + s, count, out + s, stk + s, stk + s + count - 1);
 }
 
 // Packs {prob, (nbr, eid) of the slot, (nbr, eid) of its alias} per slot; *bad is set
@@ -403,6 +372,7 @@ void glx_graph_free(glx_graph* g) {
   if (g->weight) (void)hipFree(g->weight);
   if (g->alias) (void)hipFree(g->alias);
   if (g->alias_indeg) (void)hipFree(g->alias_indeg);
+  if (g->nbr_sorted) (void)hipFree(g->nbr_sorted);
   if (g->ew) (void)hipFree(g->ew);
   glx_idmap_free(&g->idmap);
   delete g;

@@ -44,6 +44,8 @@ EXPORTS = [
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
     "glx_partition", "glx_stitch_i64", "glx_stitch_f32", "glx_aggregate_stitch",
+    "glx_negative_create", "glx_negative_from_graph", "glx_negative_destroy", "glx_negative_info",
+    "glx_negative_export", "glx_graph_enable_negative", "glx_negative_sample",
     "glx_profile_enable", "glx_profile_collect",
 ]
 
@@ -101,6 +103,14 @@ def lib():
         L.glx_stitch_i64.argtypes = [ci, vp, vp, i64, i32, vp, vp]
         L.glx_stitch_f32.argtypes = [ci, vp, vp, i64, i32, vp, vp]
         L.glx_aggregate_stitch.argtypes = [ci, ci, i32, vp, vp, i32, i32, f32, vp, vp, vp]
+        L.glx_negative_create.argtypes = [ci, i64, vp, vp, ci, vp, ctypes.POINTER(vp)]
+        L.glx_negative_from_graph.argtypes = [vp, ci, vp, ctypes.POINTER(vp)]
+        L.glx_negative_destroy.argtypes = [vp]
+        L.glx_negative_destroy.restype = None
+        L.glx_negative_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(ci)]
+        L.glx_negative_export.argtypes = [vp, vp, vp, vp, vp]
+        L.glx_graph_enable_negative.argtypes = [vp, vp]
+        L.glx_negative_sample.argtypes = [vp, ci, vp, vp, i32, i32, i64, u64, u64, vp, ci, vp]
         L.glx_profile_enable.argtypes = [ci]
         L.glx_profile_collect.argtypes = [ci, vp, i32, ctypes.POINTER(i32)]
         _lib = L
@@ -204,6 +214,10 @@ class Graph:
             self._h = None
 
     __del__ = close
+
+    def enable_negative(self):
+        """Sort every row's neighbour ids (the exclusion test of strict negative sampling)."""
+        _check(lib().glx_graph_enable_negative(self._h, None))
 
     def enable_in_degree(self):
         """Build the in-degree alias tables InDegreeSampler needs (once, on the device)."""
@@ -410,6 +424,71 @@ def stitch(rows, order):
     assert rows.dtype in (torch.int64, torch.float32)
     _check(fn(dev, _ptr(rows)[0], _ptr(order)[0], n, width, _ptr(out)[0], _stream(PTR_DEVICE)))
     return out
+
+
+NEG_EXCLUDE_NONE, NEG_EXCLUDE_NEIGHBORS, NEG_EXCLUDE_BATCH = 0, 1, 2
+
+
+class Negative:
+    """Candidate list of the negative samplers in HBM (glx_negative)."""
+
+    def __init__(self, ids, weights=None, device=0):
+        ptrs = [_ptr(ids), _ptr(weights)]
+        kind = _kind(*ptrs)
+        h = ctypes.c_void_p()
+        _check(lib().glx_negative_create(device, int(ids.shape[0]), ptrs[0][0], ptrs[1][0], kind, _stream(kind),
+                                         ctypes.byref(h)))
+        self._h = h
+        self._info()
+
+    @classmethod
+    def from_graph(cls, graph, by_in_degree=False):
+        """Distinct destination ids of the edge type in first-appearance order, uniform or
+        weighted by in-degree."""
+        self = cls.__new__(cls)
+        h = ctypes.c_void_p()
+        _check(lib().glx_negative_from_graph(graph._h, 1 if by_in_degree else 0, None, ctypes.byref(h)))
+        self._h = h
+        self._info()
+        return self
+
+    def _info(self):
+        n, w = ctypes.c_int64(), ctypes.c_int()
+        _check(lib().glx_negative_info(self._h, ctypes.byref(n), ctypes.byref(w)))
+        self.num_ids, self.weighted = n.value, bool(w.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().glx_negative_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def export(self):
+        """-> (ids, prob or None, alias or None) as numpy arrays."""
+        ids = np.zeros(self.num_ids, np.int64)
+        prob = np.zeros(self.num_ids, np.float32) if self.weighted else None
+        alias = np.zeros(self.num_ids, np.int32) if self.weighted else None
+        _check(lib().glx_negative_export(self._h, _ptr(ids)[0], _ptr(prob)[0], _ptr(alias)[0], None))
+        return ids, prob, alias
+
+    def sample(self, src, count, exclude=NEG_EXCLUDE_NONE, graph=None, default_neighbor_id=0, seed=0,
+               call_counter=0):
+        """-> out[batch, count] candidate ids (numpy in -> numpy out, torch CUDA in -> torch CUDA out)."""
+        batch = int(src.shape[0])
+        if _is_torch(src):
+            import torch
+            out = torch.empty((batch, count), dtype=torch.int64, device=src.device)
+        else:
+            out = np.empty((batch, count), np.int64)
+        ps, po = _ptr(src), _ptr(out)
+        kind = _kind(ps, po)
+        _check(lib().glx_negative_sample(self._h, exclude, graph._h if graph is not None else None, ps[0], batch,
+                                         count, default_neighbor_id, seed, call_counter, po[0], kind, _stream(kind)))
+        return out
 
 
 def aggregate_stitch(op, parts, cnts, default_attr=0.0):

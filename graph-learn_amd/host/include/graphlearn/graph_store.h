@@ -19,6 +19,7 @@
 
 struct glx_graph;
 struct glx_features;
+struct glx_negative;
 
 namespace graphlearn {
 namespace io {
@@ -100,6 +101,11 @@ public:
   Status Build(const IndexOption& option);       // sort (if option.name=="sort") + upload
   int64_t GetEdgeCount() const { return (int64_t)src_.size(); }
   const glx_graph* Device() const { return dev_; }  // nullptr before Build()
+  // Candidate list of the negative samplers for this edge type (destination ids in
+  // first-appearance order, uniform or in-degree weighted), built on first use and
+  // cached like AliasMethodFactory::LookupOrCreate does; `strict` also prepares the
+  // per-row sorted neighbour lists the exclusion test searches.
+  Status Negative(bool by_in_degree, bool strict, const glx_negative** out);
 
   // Per-edge properties by edge id, host resident (they are not read by the samplers):
   // EdgeStorage::GetWeight/GetLabel/GetTimestamp/GetAttribute
@@ -125,6 +131,9 @@ private:
   std::vector<float> f_attrs_;
   std::vector<std::string> s_attrs_;
   glx_graph* dev_;
+  glx_negative* neg_uniform_;
+  glx_negative* neg_in_degree_;
+  bool neg_strict_ready_;
   std::mutex mtx_;
 };
 
@@ -140,6 +149,8 @@ public:
   Status Build(const IndexOption& option);
   const glx_features* Device() const { return dev_; }
   int64_t GetNodeCount() const { return (int64_t)ids_.size(); }
+  // Candidate list of NodeWeightNegativeSampler: this type's ids weighted by node weight.
+  Status Negative(const glx_negative** out);
 
   // NodeStorage::GetWeight/GetLabel/GetTimestamp/GetAttribute
   // (memory_node_storage.cc:88-138) for the host-resident properties; -1 = unknown id.
@@ -163,6 +174,7 @@ private:
   std::vector<std::string> s_attrs_;
   std::unordered_map<int64_t, int32_t> index_;
   glx_features* dev_;
+  glx_negative* neg_;
   std::mutex mtx_;
 };
 

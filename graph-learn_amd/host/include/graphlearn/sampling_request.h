@@ -85,6 +85,8 @@ public:
 
   // Device-path addition: size both tensors to dim1*dim2 for one bulk write.
   void ResizeDense();
+  // Negative samplers answer with neighbour ids only (random_negative_sampler.cc:55-61).
+  void ResizeNeighborIds();
   // Scatter the shards' rows back to their request positions (stitcher.h:67-107).
   void Stitch(ShardsPtr<OpResponse> shards);
 

@@ -16,9 +16,32 @@ UpdateNodesRequest::UpdateNodesRequest(const io::SideInfo* info, int32_t batch_s
 void UpdateNodesRequest::Append(const io::NodeValue* value) { values_.push_back(*value); }
 
 // ------------------------------------------------------------------ Graph --
-Graph::Graph(const std::string& type) : type_(type), dev_(nullptr) {}
+Graph::Graph(const std::string& type)
+    : type_(type), dev_(nullptr), neg_uniform_(nullptr), neg_in_degree_(nullptr), neg_strict_ready_(false) {}
 
-Graph::~Graph() { glx_graph_destroy(dev_); }
+Graph::~Graph() {
+  glx_negative_destroy(neg_uniform_);
+  glx_negative_destroy(neg_in_degree_);
+  glx_graph_destroy(dev_);
+}
+
+Status Graph::Negative(bool by_in_degree, bool strict, const glx_negative** out) {
+  std::lock_guard<std::mutex> g(mtx_);
+  *out = nullptr;
+  if (!dev_) return error::InvalidArgument("edge type '" + type_ + "' is not built on the device");
+  glx_negative*& slot = by_in_degree ? neg_in_degree_ : neg_uniform_;
+  if (!slot) {
+    int rc = glx_negative_from_graph(dev_, by_in_degree ? 1 : 0, nullptr, &slot);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+  }
+  if (strict && !neg_strict_ready_) {
+    int rc = glx_graph_enable_negative(dev_, nullptr);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    neg_strict_ready_ = true;
+  }
+  *out = slot;
+  return Status::OK();
+}
 
 void Graph::SetSideInfo(const io::SideInfo* info) {
   if (!info_.IsInitialized()) info_ = *info;  // first writer wins (memory_edge_storage.cc:35-39)
@@ -96,9 +119,25 @@ Status Graph::Build(const IndexOption& option) {
 }
 
 // ------------------------------------------------------------------ Noder --
-Noder::Noder(const std::string& type) : type_(type), dev_(nullptr) {}
+Noder::Noder(const std::string& type) : type_(type), dev_(nullptr), neg_(nullptr) {}
 
-Noder::~Noder() { glx_features_destroy(dev_); }
+Noder::~Noder() {
+  glx_negative_destroy(neg_);
+  glx_features_destroy(dev_);
+}
+
+Status Noder::Negative(const glx_negative** out) {
+  std::lock_guard<std::mutex> g(mtx_);
+  *out = nullptr;
+  if (!neg_) {
+    if (!info_.IsWeighted()) return error::InvalidArgument("node type '" + type_ + "' has no weights");
+    int rc = glx_negative_create(GLOBAL_FLAG(DeviceId), (int64_t)ids_.size(), ids_.data(), weights_.data(),
+                                 GLX_PTR_HOST, nullptr, &neg_);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+  }
+  *out = neg_;
+  return Status::OK();
+}
 
 void Noder::SetSideInfo(const io::SideInfo* info) {
   if (!info_.IsInitialized()) info_ = *info;

@@ -154,6 +154,8 @@ void SamplingResponse::ResizeDense() {
   tensors_[kEdgeIds].Resize((int32_t)shape_.size);
 }
 
+void SamplingResponse::ResizeNeighborIds() { tensors_[kNodeIds].Resize((int32_t)shape_.size); }
+
 int64_t* SamplingResponse::GetNeighborIds() {
   auto it = tensors_.find(kNodeIds);
   return it == tensors_.end() ? nullptr : it->second.MutableInt64();
@@ -178,6 +180,10 @@ REGISTER_SAMPLING_REQUEST(Topk)
 REGISTER_SAMPLING_REQUEST(EdgeWeight)
 REGISTER_SAMPLING_REQUEST(InDegree)
 REGISTER_SAMPLING_REQUEST(Full)
+REGISTER_SAMPLING_REQUEST(RandomNegative)
+REGISTER_SAMPLING_REQUEST(InDegreeNegative)
+REGISTER_SAMPLING_REQUEST(SoftInDegreeNegative)
+REGISTER_SAMPLING_REQUEST(NodeWeightNegative)
 #undef REGISTER_SAMPLING_REQUEST
 
 // ------------------------------------------------------------- aggregating --

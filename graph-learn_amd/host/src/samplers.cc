@@ -118,5 +118,72 @@ REGISTER_OPERATOR("TopkSampler", TopkSampler)
 REGISTER_OPERATOR("InDegreeSampler", InDegreeSampler)
 REGISTER_OPERATOR("FullSampler", FullSampler)
 
+// Negative samplers (random_negative_sampler.cc:30-63, in_degree_negative_sampler.cc:29-135,
+// node_weight_negative_sampler.cc:29-110): [batch, count] candidate ids, no edge ids.
+class NegativeSampler : public Operator {
+public:
+  Status Process(const OpRequest* req, OpResponse* res) override {
+    const SamplingRequest* request = static_cast<const SamplingRequest*>(req);
+    SamplingResponse* response = static_cast<SamplingResponse*>(res);
+    const int32_t count = request->NeighborCount();
+    const int32_t batch_size = request->BatchSize();
+    response->SetShape(batch_size, count);
+    response->InitEdgeIds();
+    response->InitNeighborIds();
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    const glx_negative* table = nullptr;
+    const glx_graph* graph = nullptr;
+    Status s = Candidates(request->Type(), &table, &graph);
+    if (!s.ok()) return s;
+    response->ResizeNeighborIds();
+    const uint64_t cc = request->HasCallCounter() ? (uint64_t)request->CallCounter()
+                                                   : call_counter_.fetch_add(1, std::memory_order_relaxed);
+    int rc = glx_negative_sample(table, Exclude(), graph, request->GetSrcIds(), batch_size, count,
+                                 GLOBAL_FLAG(DefaultNeighborId), (uint64_t)GLOBAL_FLAG(SamplingSeed), cc,
+                                 response->GetNeighborIds(), GLX_PTR_HOST, nullptr);
+    return error::FromGlx(rc);
+  }
+
+protected:
+  virtual int Exclude() const = 0;
+  virtual Status Candidates(const std::string& type, const glx_negative** table, const glx_graph** graph) = 0;
+
+private:
+  std::atomic<uint64_t> call_counter_{0};
+};
+
+class RandomNegativeSampler : public NegativeSampler {
+  int Exclude() const override { return GLX_NEG_EXCLUDE_NONE; }
+  Status Candidates(const std::string& type, const glx_negative** table, const glx_graph**) override {
+    return graph_store_->GetGraph(type)->Negative(false, false, table);
+  }
+};
+class SoftInDegreeNegativeSampler : public NegativeSampler {
+  int Exclude() const override { return GLX_NEG_EXCLUDE_NONE; }
+  Status Candidates(const std::string& type, const glx_negative** table, const glx_graph**) override {
+    return graph_store_->GetGraph(type)->Negative(true, false, table);
+  }
+};
+class InDegreeNegativeSampler : public NegativeSampler {
+  int Exclude() const override { return GLX_NEG_EXCLUDE_NEIGHBORS; }
+  Status Candidates(const std::string& type, const glx_negative** table, const glx_graph** graph) override {
+    Graph* g = graph_store_->GetGraph(type);
+    Status s = g->Negative(true, true, table);
+    *graph = g->Device();
+    return s;
+  }
+};
+class NodeWeightNegativeSampler : public NegativeSampler {
+  int Exclude() const override { return GLX_NEG_EXCLUDE_BATCH; }
+  Status Candidates(const std::string& type, const glx_negative** table, const glx_graph**) override {
+    return graph_store_->GetNoder(type)->Negative(table);  // Type() is a NODE type here
+  }
+};
+
+REGISTER_OPERATOR("RandomNegativeSampler", RandomNegativeSampler)
+REGISTER_OPERATOR("SoftInDegreeNegativeSampler", SoftInDegreeNegativeSampler)
+REGISTER_OPERATOR("InDegreeNegativeSampler", InDegreeNegativeSampler)
+REGISTER_OPERATOR("NodeWeightNegativeSampler", NodeWeightNegativeSampler)
+
 }  // namespace op
 }  // namespace graphlearn

@@ -121,6 +121,88 @@ TEST(SamplerTest, Full) {
   for (int i = 0; i < 5; ++i) EXPECT_EQ(res2.GetNeighborIds()[i], all[i]);
 }
 
+TEST(SamplerTest, NodeWeightNegative) {
+  // sampler_unittest.cpp:315-347 (disabled there: its fixture never loads the "user" nodes).
+  // Nodes {0..4} with weights; the request's own ids {0, 1} are never returned.
+  SetUpStore();
+  static bool nodes_loaded = false;
+  if (!nodes_loaded) {
+    io::SideInfo info;
+    info.format = io::kWeighted;
+    info.type = "user";
+    UpdateNodesRequest req(&info, 5);
+    for (int i = 0; i < 5; ++i) {
+      io::NodeValue v;
+      v.id = i;
+      v.weight = 0.5f + i;
+      req.Append(&v);
+    }
+    UpdateNodesResponse res;
+    g_store->GetNoder("user")->UpdateNodes(&req, &res);
+    nodes_loaded = true;
+  }
+  const int32_t nbr_count = 2, batch_size = 2;
+  SamplingRequest req("user", "NodeWeightNegativeSampler", nbr_count);
+  SamplingResponse res;
+  int64_t ids[2] = {0, 1};
+  req.Set(ids, batch_size);
+  Operator* op = OpFactory::GetInstance()->Create(req.Name());
+  EXPECT_TRUE(op != nullptr);
+  for (int round = 0; round < 20; ++round) {
+    SamplingResponse r;
+    EXPECT_TRUE(op->Process(&req, &r).ok());
+    EXPECT_EQ(r.GetShape().dim1, (size_t)batch_size);
+    EXPECT_EQ(r.GetShape().dim2, (size_t)nbr_count);
+    for (int i = 0; i < batch_size * nbr_count; ++i) {
+      const int64_t v = r.GetNeighborIds()[i];
+      EXPECT_TRUE(v >= 2 && v <= 4);
+    }
+  }
+}
+
+TEST(SamplerTest, EdgeTypeNegatives) {
+  // Random / SoftInDegree: any destination id of "u-i" (src 0 -> {10, 20, 30}, src 1 -> {11, 21}).
+  // InDegree follows in_degree_negative_sampler.cc:57-92 exactly: with the same pinned random
+  // stream, its answer is the Soft sampler's candidate stream taken in blocks of `count`,
+  // neighbours of the source dropped in the first three blocks, nothing dropped in the fourth.
+  SetUpStore();
+  const int32_t count = 4;
+  int64_t ids[3] = {0, 1, 99};
+  for (const char* name : {"RandomNegativeSampler", "SoftInDegreeNegativeSampler"}) {
+    SamplingRequest req("u-i", name, count);
+    req.Set(ids, 3);
+    Operator* op = OpFactory::GetInstance()->Create(req.Name());
+    EXPECT_TRUE(op != nullptr);
+    SamplingResponse res;
+    EXPECT_TRUE(op->Process(&req, &res).ok());
+    for (int i = 0; i < 3 * count; ++i) {
+      const int64_t v = res.GetNeighborIds()[i];
+      EXPECT_TRUE(v == 10 || v == 20 || v == 30 || v == 11 || v == 21);
+    }
+  }
+  for (int64_t cc = 100; cc < 130; ++cc) {
+    SamplingRequest soft("u-i", "SoftInDegreeNegativeSampler", 4 * count);
+    soft.Set(ids, 3);
+    soft.SetCallCounter(cc);
+    SamplingResponse stream;
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(soft.Name())->Process(&soft, &stream).ok());
+    SamplingRequest strict("u-i", "InDegreeNegativeSampler", count);
+    strict.Set(ids, 3);
+    strict.SetCallCounter(cc);
+    SamplingResponse res;
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(strict.Name())->Process(&strict, &res).ok());
+    for (int row = 0; row < 3; ++row) {
+      std::vector<int64_t> want;
+      for (int d = 0; d < 4 * count && (int)want.size() < count; ++d) {
+        const int64_t v = stream.GetNeighborIds()[row * 4 * count + d];
+        const bool neighbour = row == 0 ? (v == 10 || v == 20 || v == 30) : row == 1 ? (v == 11 || v == 21) : false;
+        if (d >= 3 * count || !neighbour) want.push_back(v);
+      }
+      for (int j = 0; j < count; ++j) EXPECT_EQ(res.GetNeighborIds()[row * count + j], want[j]);
+    }
+  }
+}
+
 TEST(SamplerTest, Topk) {
   SetUpStore();
   int32_t nbr_count = 2;

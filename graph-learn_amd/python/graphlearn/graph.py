@@ -6,8 +6,8 @@ Same construction protocol as graphlearn/python/graph.py:
 `init()` parses the sources on the host (C++), builds CSR / alias tables / the feature
 matrix on the GPU and keeps them resident there; every sampler / aggregator call then
 goes Python -> pywrap -> Operator::Process -> HIP.  Distributed deploy modes
-(init(cluster=...), task_count > 1), GSL (`V()/E()`), subgraph / negative samplers and
-the vineyard backend are outside the path this engine replaces and raise
+(init(cluster=...), task_count > 1), GSL (`V()/E()`), subgraph / conditional-negative samplers
+and the vineyard backend are outside the path this engine replaces and raise
 NotImplementedError.
 """
 import os
@@ -274,8 +274,16 @@ class Graph(object):
   def edge_sampler(self, *args, **kwargs):
     self._off_path("edge_sampler")
 
-  def negative_sampler(self, *args, **kwargs):
-    self._off_path("negative_sampler")
+  def negative_sampler(self, object_type, expand_factor, strategy="random", conditional=False, **kwargs):
+    """strategy: "random", "in_degree", "soft_in_degree" (object_type = an edge type) or
+    "node_weight" (object_type = a node type)."""
+    if conditional:
+      self._off_path("conditional negative sampling")
+    from graphlearn import sampler
+    cls = getattr(sampler, "".join(w.capitalize() for w in strategy.split("_")) + "NegativeSampler", None)
+    if cls is None:
+      raise ValueError("unknown negative sampling strategy {!r}".format(strategy))
+    return cls(self, object_type, expand_factor, strategy=strategy)
 
   def subgraph_sampler(self, *args, **kwargs):
     self._off_path("subgraph_sampler")

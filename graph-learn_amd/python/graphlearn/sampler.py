@@ -14,7 +14,9 @@ from graphlearn.utils import strategy2op
 from graphlearn.values import Layer, Layers
 
 __all__ = ["NeighborSampler", "RandomNeighborSampler", "RandomWithoutReplacementNeighborSampler",
-           "EdgeWeightNeighborSampler", "TopkNeighborSampler", "InDegreeNeighborSampler", "FullNeighborSampler"]
+           "EdgeWeightNeighborSampler", "TopkNeighborSampler", "InDegreeNeighborSampler", "FullNeighborSampler",
+           "NegativeSampler", "RandomNegativeSampler", "InDegreeNegativeSampler", "SoftInDegreeNegativeSampler",
+           "NodeWeightNegativeSampler"]
 
 
 def _as_list(value, what):
@@ -142,3 +144,62 @@ class FullNeighborSampler(NeighborSampler):
       layers.append_layer(Layer(nodes, edges))
       src = nbr
     return layers
+
+
+class NegativeSampler(object):
+  """Negative sampling (graphlearn/python/sampler/negative_sampler.py): for every given id,
+  `expand_factor` candidate destination ids.  object_type is an edge type ("random",
+  "in_degree", "soft_in_degree": candidates = the type's destination ids) or a node type
+  ("node_weight": candidates = the type's ids, weighted by node weight)."""
+
+  _needs = "edge"
+
+  def __init__(self, graph, object_type, expand_factor, strategy="random"):
+    self._graph = graph
+    self._object_type = object_type
+    self._expand_factor = int(expand_factor)
+    self._op = strategy2op(strategy, "NegativeSampler")
+    self._call_counter = None
+    if object_type in graph.get_node_decoders():
+      kind, self._dst_type = "node", object_type
+    elif object_type in graph.get_edge_decoders():
+      kind, self._dst_type = "edge", graph.get_topology().get_dst_type(object_type)
+    else:
+      raise ValueError("node or edge type {} is not in the graph".format(object_type))
+    if kind != self._needs:
+      raise ValueError("{} is not type of {}.".format(object_type, self._needs))
+
+  def set_call_counter(self, value):
+    self._call_counter = value
+
+  def get(self, ids):
+    """-> Nodes of shape [len(ids), expand_factor]"""
+    ids = np.ascontiguousarray(np.array(ids).reshape(-1), dtype=np.int64)
+    req = pywrap.new_sampling_request(self._object_type, self._op, self._expand_factor,
+                                      pywrap.FilterType.OPERATOR_UNSPECIFIED, pywrap.FilterField.FIELD_UNSPECIFIED)
+    pywrap.set_sampling_request(req, ids)
+    if self._call_counter is not None:
+      pywrap.set_sampling_call_counter(req, int(self._call_counter))
+    res = pywrap.new_sampling_response()
+    status = self._graph.get_client().sample_neighbor(req, res)
+    out = pywrap.get_sampling_node_ids(res) if status.ok() else None
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
+    return self._graph.get_nodes(self._dst_type, out, shape=(ids.shape[0], self._expand_factor))
+
+
+class RandomNegativeSampler(NegativeSampler):
+  pass
+
+
+class InDegreeNegativeSampler(NegativeSampler):
+  pass
+
+
+class SoftInDegreeNegativeSampler(NegativeSampler):
+  pass
+
+
+class NodeWeightNegativeSampler(NegativeSampler):
+  _needs = "node"

@@ -224,6 +224,46 @@ GLX_API int glx_aggregate(const glx_features* f, int op, const int64_t* node_ids
                   float default_attr, float* emb_out, int32_t* cnt_out, int ptr_kind,
                   void* stream);
 
+/* ---- negative sampling: replaces RandomNegativeSampler (random_negative_sampler.cc:30-63),
+ * InDegreeNegativeSampler / SoftInDegreeNegativeSampler (in_degree_negative_sampler.cc:29-135)
+ * and NodeWeightNegativeSampler (node_weight_negative_sampler.cc:29-110). ---------------
+ * A glx_negative is the candidate list all rows of a request draw from, in HBM:
+ *   glx_negative_from_graph: the edge type's distinct destination ids in first-appearance
+ *     order (TopoStatics::Add, topo_statics.cc:32-55 = GetAllDstIds()), uniform
+ *     (by_in_degree = 0) or weighted by in-degree (GetAllInDegrees()) through ONE alias
+ *     table over the whole list (AliasMethodFactory::LookupOrCreate), bit-identical to
+ *     AliasMethod::Build (alias_method.cc:57-107);
+ *   glx_negative_create: explicit ids (+ weights or NULL = uniform): a node type's ids and
+ *     node weights for NodeWeightNegativeSampler.
+ * glx_negative_sample: out[batch * count] candidates (no edge ids, as in the reference).
+ *   exclude = GLX_NEG_EXCLUDE_NONE      every draw is taken (Random, SoftInDegree);
+ *             GLX_NEG_EXCLUDE_NEIGHBORS a candidate that is an out-neighbour of src[i] in `g` is
+ *                                       skipped (InDegree; needs glx_graph_enable_negative(g));
+ *             GLX_NEG_EXCLUDE_BATCH     a candidate equal to ANY src id of the request is skipped
+ *                                       (NodeWeight).
+ *   The strict modes follow the reference's retry loop: blocks of `count` draws, accepted
+ *   candidates keep their order, the exclusion set is dropped from the 4th block on
+ *   (kRetryTimes = 3).  Row i draws from the random stream (seed, call_counter, i); draw
+ *   b * count + j is candidate j of block b.  Weighted draws use AliasMethod::Sample's formula
+ *   (alias_method.cc:117-121), uniform ones floor(u * num_ids / 2^64).  An empty candidate
+ *   list yields `default_neighbor_id` everywhere. */
+#define GLX_NEG_EXCLUDE_NONE 0
+#define GLX_NEG_EXCLUDE_NEIGHBORS 1
+#define GLX_NEG_EXCLUDE_BATCH 2
+typedef struct glx_negative glx_negative;
+GLX_API int glx_negative_create(int device, int64_t num_ids, const int64_t* ids, const float* weights, int ptr_kind,
+                                void* stream, glx_negative** out);
+GLX_API int glx_negative_from_graph(const glx_graph* g, int by_in_degree, void* stream, glx_negative** out);
+GLX_API void glx_negative_destroy(glx_negative* t);
+GLX_API int glx_negative_info(const glx_negative* t, int64_t* num_ids, int* weighted);
+/* Copies the candidate ids and the alias table to HOST arrays (parity checks). */
+GLX_API int glx_negative_export(const glx_negative* t, int64_t* ids, float* prob, int32_t* alias, void* stream);
+/* Builds every row's neighbour ids in ascending order (the exclusion test is a binary search). */
+GLX_API int glx_graph_enable_negative(glx_graph* g, void* stream);
+GLX_API int glx_negative_sample(const glx_negative* t, int exclude, const glx_graph* g, const int64_t* src,
+                                int32_t batch, int32_t count, int64_t default_neighbor_id, uint64_t seed,
+                                uint64_t call_counter, int64_t* out, int ptr_kind, void* stream);
+
 /* ---- feature lookup: replaces LookupNodes' float-attribute gather
  * (node_lookuper.cc:24-52); out[n*dim], unknown ids -> default_attr. */
 GLX_API int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_t n, float default_attr,

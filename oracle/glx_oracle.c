@@ -476,3 +476,126 @@ int glxo_aggregate_stitch(int op, int32_t P, const float* parts, const int32_t* 
   }
   return 0;
 }
+
+int64_t glxo_dst_statics(const int64_t* col, const int64_t* eid, int64_t E, int64_t* ids_out,
+                         int32_t* in_degrees_out) {
+  /* replay the insertions in edge-id order */
+  int64_t* by_eid = (int64_t*)malloc(sizeof(int64_t) * (size_t)(E > 0 ? E : 1));
+  int64_t max_eid = -1;
+  for (int64_t i = 0; i < E; ++i) {
+    if (eid[i] > max_eid) max_eid = eid[i];
+  }
+  int64_t* slot_of = (int64_t*)malloc(sizeof(int64_t) * (size_t)(max_eid + 2));
+  for (int64_t i = 0; i <= max_eid; ++i) slot_of[i] = -1;
+  for (int64_t i = 0; i < E; ++i) slot_of[eid[i]] = i;
+  int64_t n = 0;
+  for (int64_t e = 0; e <= max_eid; ++e) {
+    if (slot_of[e] >= 0) by_eid[n++] = col[slot_of[e]];
+  }
+  int64_t U = 0;
+  /* dst id -> index: the role of dst_indexing_ */
+  int64_t cap = 16;
+  while (cap < 2 * n + 2) cap <<= 1;
+  int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * (size_t)cap);
+  int32_t* vals = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  for (int64_t i = 0; i < cap; ++i) vals[i] = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t d = by_eid[i];
+    uint64_t h = (uint64_t)d * 0x9E3779B97F4A7C15ull;
+    int64_t at = (int64_t)(h >> 7) & (cap - 1);
+    while (vals[at] >= 0 && keys[at] != d) at = (at + 1) & (cap - 1);
+    if (vals[at] < 0) { /* new coming */
+      keys[at] = d;
+      vals[at] = (int32_t)U;
+      ids_out[U] = d;
+      in_degrees_out[U] = 1;
+      ++U;
+    } else { /* has appeared before */
+      in_degrees_out[vals[at]]++;
+    }
+  }
+  free(keys);
+  free(vals);
+  free(slot_of);
+  free(by_eid);
+  return U;
+}
+
+int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const int32_t* alias, int exclude,
+                         const glxo_graph* g, const int64_t* src, int32_t batch, int32_t count,
+                         int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter, int64_t* out) {
+  if (exclude < 0 || exclude > 2) return 3;
+  if (U == 0) { /* res->FillWith(DefaultNeighborId, -1) */
+    for (int64_t i = 0; i < (int64_t)batch * count; ++i) out[i] = default_neighbor_id;
+    return 0;
+  }
+  idmap m;
+  if (exclude == 1 && g->ids) idmap_build(&m, g->ids, g->V);
+  int32_t* indices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(count > 0 ? count : 1));
+  for (int32_t i = 0; i < batch; ++i) {
+    /* the exclusion set of this row */
+    const int64_t* ex = NULL;
+    int64_t exn = 0;
+    if (exclude == 1) {
+      int64_t row = row_of(g->ids, &m, g->V, src[i]);
+      if (row >= 0) {
+        ex = g->col + g->row_ptr[row];
+        exn = g->row_ptr[row + 1] - g->row_ptr[row];
+      }
+    } else if (exclude == 2) {
+      ex = src;
+      exn = batch;
+    }
+    int set_active = exclude != 0;
+    int32_t taken = 0, cursor = 0, blk = 0;
+    int32_t retry_times = 3 + 1; /* kRetryTimes + 1 */
+    if (exclude == 0) { /* one block, every candidate is taken */
+      for (int32_t j = 0; j < count; ++j) {
+        uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j);
+        int64_t ix;
+        if (prob) {
+          double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(U - 1);
+          float rnd = (float)rd;
+          int32_t k = (int32_t)rnd;
+          ix = (prob[k] <= (rnd - k)) ? alias[k] : k;
+        } else {
+          ix = (int64_t)bounded(u, (uint64_t)U);
+        }
+        out[(int64_t)i * count + j] = ids[ix];
+      }
+      continue;
+    }
+    while (taken < count && retry_times >= 0) {
+      cursor %= count;
+      if (cursor == 0) {
+        for (int32_t j = 0; j < count; ++j) { /* am->Sample(n, indices) */
+          uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)(blk * count + j));
+          if (prob) {
+            double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(U - 1);
+            float rnd = (float)rd;
+            int32_t k = (int32_t)rnd;
+            indices[j] = (prob[k] <= (rnd - k)) ? alias[k] : k;
+          } else {
+            indices[j] = (int32_t)bounded(u, (uint64_t)U);
+          }
+        }
+        ++blk;
+        if (--retry_times <= 0) set_active = 0; /* sets.clear() */
+      }
+      int64_t item = ids[indices[cursor++]];
+      int found = 0;
+      if (set_active) {
+        for (int64_t e = 0; e < exn; ++e) {
+          if (ex[e] == item) {
+            found = 1;
+            break;
+          }
+        }
+      }
+      if (!found) out[(int64_t)i * count + taken++] = item;
+    }
+  }
+  free(indices);
+  if (exclude == 1 && g->ids) idmap_free(&m);
+  return 0;
+}

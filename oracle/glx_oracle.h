@@ -98,6 +98,24 @@ int glxo_aggregate(const float* feats, int64_t V, int32_t dim, const int64_t* id
                    const int64_t* node_ids, const int32_t* segment_ids, int32_t num_ids,
                    int32_t num_segments, float default_attr, float* emb_out, int32_t* cnt_out);
 
+/* Restates TopoStatics::Add (topo_statics.cc:32-55) as seen through
+ * GetAllDstIds()/GetAllInDegrees(): distinct destination ids in first-appearance order
+ * (edges taken in edge-id = insertion order) and their in-degrees.  col/eid: the E CSR
+ * slots.  Returns the number of distinct ids; fills ids_out / in_degrees_out (capacity E). */
+int64_t glxo_dst_statics(const int64_t* col, const int64_t* eid, int64_t E, int64_t* ids_out,
+                         int32_t* in_degrees_out);
+
+/* Restates the negative samplers' sampling loops under the seeding contract:
+ * RandomNegativeSampler (random_negative_sampler.cc:55-61; exclude 0, alias NULL),
+ * SoftInDegreeNegativeSampler (in_degree_negative_sampler.cc:107-121; exclude 0),
+ * InDegreeNegativeSampler (in_degree_negative_sampler.cc:57-92; exclude 1: src's neighbours)
+ * and NodeWeightNegativeSampler (node_weight_negative_sampler.cc:58-92; exclude 2: the
+ * request's own ids).  ids[U] candidates; prob/alias: the global alias table or NULL
+ * (uniform).  Draw `blk * count + j` of row i's stream is candidate j of retry block blk. */
+int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const int32_t* alias, int exclude,
+                         const glxo_graph* g, const int64_t* src, int32_t batch, int32_t count,
+                         int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter, int64_t* out);
+
 /* Restates HashPartitioner::Partition (hash_partitioner.h:33-92): shard =
  * llabs(id) % P, stable within a shard.  order_out[n]: indices grouped by
  * shard (the concatenated Sticker lists); counts_out[P]. */

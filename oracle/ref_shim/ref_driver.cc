@@ -270,6 +270,38 @@ int glref_parse_attribute(const char* input, int64_t len, const char* delimiter,
   return static_cast<int>(st.code());
 }
 
+// Weighted node table for NodeWeightNegativeSampler (node_weight_negative_sampler.cc:29-110).
+int glref_add_weighted_nodes(void* h, const char* node_type, const int64_t* ids, const float* weights, int64_t n) {
+  Ref* r = static_cast<Ref*>(h);
+  io::NodeStorage* st = r->store->GetNoder(node_type)->GetLocalStorage();
+  io::SideInfo info;
+  info.format = io::kWeighted;
+  info.type = node_type;
+  st->SetSideInfo(&info);
+  io::NodeValue v;
+  for (int64_t i = 0; i < n; ++i) {
+    v.id = ids[i];
+    v.weight = weights[i];
+    st->Add(&v);
+  }
+  return 0;
+}
+
+// GetAllDstIds / GetAllInDegrees (memory_topo_storage.cc:119-141, topo_statics.cc:32-55): the
+// candidate list of the negative samplers.  Returns the count; copies min(count, cap).
+int64_t glref_dst_statics(void* h, const char* edge_type, int64_t* ids_out, int32_t* in_degrees_out, int64_t cap) {
+  Ref* r = static_cast<Ref*>(h);
+  io::GraphStorage* st = r->store->GetGraph(edge_type)->GetLocalStorage();
+  auto ids = st->GetAllDstIds();
+  auto deg = st->GetAllInDegrees();
+  const int64_t n = ids.Size();
+  for (int64_t i = 0; i < n && i < cap; ++i) {
+    ids_out[i] = ids[i];
+    in_degrees_out[i] = deg[i];
+  }
+  return n;
+}
+
 // FullSampler (full_sampler.cc:28-97) answers with a sparse response: per-row
 // neighbour counts (Shape::segments) + concatenated values.  degrees_out[batch];
 // nbr_out / eid_out need capacity `cap`; returns the total or -(error code) - 1.

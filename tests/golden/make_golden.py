@@ -361,6 +361,31 @@ def gen_loader(ref):
         json.dump(dict(hash64=hashes, parse_attribute=cases), f, indent=1)
 
 
+def gen_negative(ref):
+    """Candidate lists of the negative samplers as the reference holds them
+    (GetAllDstIds / GetAllInDegrees, topo_statics.cc:32-55) and its global alias tables
+    (AliasMethod over the in-degrees / node weights), for a graph with repeated and
+    late-appearing destinations."""
+    out = {}
+    rng = np.random.default_rng(77)
+    E = 3000
+    src = rng.integers(0, 150, E).astype(np.int64) * 2 + 1
+    dst = (rng.zipf(1.4, E) % 300).astype(np.int64) * 5 - 200
+    w = (rng.random(E) * 0.99 + 0.01 + np.arange(E) * 1e-7).astype(np.float32)
+    ref.add_edges("neg", src, dst, w)
+    rows = first_appearance(src)
+    rp, col, eid, ws = ref.export_csr("neg", rows, 4000)
+    ids, deg = ref.dst_statics("neg")
+    prob, alias = ref.alias_build(deg.astype(np.float32))
+    out.update(src=src, dst=dst, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws, dst_ids=ids, in_degrees=deg,
+               indeg_prob=prob, indeg_alias=alias)
+    nid = np.arange(400, dtype=np.int64) * 3 - 50
+    nw = (rng.random(400) + 0.02).astype(np.float32)
+    np_, na = ref.alias_build(nw)
+    out.update(node_ids=nid, node_weights=nw, node_prob=np_, node_alias=na)
+    np.savez_compressed(os.path.join(HERE, "negative.npz"), **out)
+
+
 def main():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -371,6 +396,7 @@ def main():
     gen_agg(ref)
     gen_agg_stitch(ref)
     gen_loader(ref)
+    gen_negative(ref)
     # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()
     print("golden fixtures written to", HERE)

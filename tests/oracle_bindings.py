@@ -49,6 +49,10 @@ class Oracle:
         L.glxo_sample_full.argtypes = [ctypes.POINTER(_CGraph), VP, i32, i32, VP, VP, VP, i64]
         L.glxo_sample_full.restype = i64
         L.glxo_partition.argtypes = [VP, i64, i32, VP, VP]
+        L.glxo_dst_statics.argtypes = [VP, VP, i64, VP, VP]
+        L.glxo_dst_statics.restype = i64
+        L.glxo_negative_sample.argtypes = [VP, i64, VP, VP, ctypes.c_int, ctypes.POINTER(_CGraph), VP, i32, i32, i64, u64,
+                                           u64, VP]
         L.glxo_aggregate_stitch.argtypes = [ctypes.c_int, i32, VP, VP, i32, i32, ctypes.c_float, ctypes.c_int, VP, VP]
         L.glxo_stitch_i64.argtypes = [VP, VP, i64, i32, VP]
         L.glxo_set_reference_cost_model.argtypes = [ctypes.c_int]
@@ -123,6 +127,26 @@ class Oracle:
         assert rc == 0, rc
         return emb, cnt
 
+    def dst_statics(self, col, eid):
+        """-> (distinct dst ids in first-appearance order, their in-degrees)"""
+        E = col.shape[0]
+        ids = np.zeros(max(E, 1), np.int64)
+        deg = np.zeros(max(E, 1), np.int32)
+        U = self.L.glxo_dst_statics(_p(col), _p(eid), E, _p(ids), _p(deg))
+        return ids[:U].copy(), deg[:U].copy()
+
+    def negative_sample(self, ids, table, exclude, g, src, count, default_neighbor_id=0, seed=0, call_counter=0):
+        """table: (prob, alias) or None (uniform); exclude 0 none / 1 src's neighbours in g / 2 the batch."""
+        cg = self._cgraph(g) if g is not None else None
+        src = np.ascontiguousarray(src, np.int64)
+        out = np.zeros((src.shape[0], count), np.int64)
+        rc = self.L.glxo_negative_sample(_p(ids), ids.shape[0], _p(table[0]) if table else None,
+                                         _p(table[1]) if table else None, exclude,
+                                         ctypes.byref(cg) if cg is not None else None, _p(src), src.shape[0], count,
+                                         default_neighbor_id, seed, call_counter, _p(out))
+        assert rc == 0, rc
+        return out
+
     def aggregate_stitch(self, op, parts, cnts, default_attr=0.0, reference_fold=False):
         """parts [P, Sg, D] f32, cnts [P, Sg] i32 -> (emb [Sg, D], cnt [Sg])."""
         if isinstance(op, str):
@@ -178,6 +202,9 @@ class RefLib:
         L.glref_sample.argtypes = [VP, cs, cs, VP, i32, i32, VP, VP, ctypes.c_int]
         L.glref_aggregate.argtypes = [VP, cs, cs, VP, VP, i32, i32, VP, VP, VP]
         L.glref_aggregate_stitch.argtypes = [cs, i32, VP, VP, i32, i32, VP, VP]
+        L.glref_add_weighted_nodes.argtypes = [VP, cs, VP, VP, i64]
+        L.glref_dst_statics.argtypes = [VP, cs, VP, VP, i64]
+        L.glref_dst_statics.restype = i64
         L.glref_hash64.argtypes = [ctypes.c_char_p, i64]
         L.glref_hash64.restype = ctypes.c_uint64
         L.glref_parse_attribute.argtypes = [ctypes.c_char_p, i64, cs, VP, VP, i32, i32, VP, VP, VP, VP, ctypes.c_char_p,
@@ -256,6 +283,27 @@ class RefLib:
         a = np.zeros(w.shape[0], np.int32)
         self.L.glref_alias_build(_p(w), w.shape[0], _p(p), _p(a))
         return p, a
+
+    def add_weighted_nodes(self, ntype, ids, weights):
+        ids = np.ascontiguousarray(ids, np.int64)
+        weights = np.ascontiguousarray(weights, np.float32)
+        assert self.L.glref_add_weighted_nodes(self.h, ntype.encode(), _p(ids), _p(weights), ids.shape[0]) == 0
+        assert self.L.glref_build_nodes(self.h, ntype.encode()) == 0
+
+    def dst_statics(self, etype, cap=1 << 22):
+        ids = np.zeros(cap, np.int64)
+        deg = np.zeros(cap, np.int32)
+        n = self.L.glref_dst_statics(self.h, etype.encode(), _p(ids), _p(deg), cap)
+        assert 0 <= n <= cap
+        return ids[:n].copy(), deg[:n].copy()
+
+    def negative_sample(self, type_name, strategy, src, k, fresh_thread=True):
+        src = np.ascontiguousarray(src, np.int64)
+        out = np.zeros((src.shape[0], k), np.int64)
+        rc = self.L.glref_sample(self.h, type_name.encode(), strategy.encode(), _p(src), src.shape[0], k, _p(out), None,
+                                 1 if fresh_thread else 0)
+        assert rc == 0, rc
+        return out
 
     def hash64(self, data):
         return int(self.L.glref_hash64(data, len(data)))

@@ -530,3 +530,75 @@ def test_concurrent_host_threads_on_private_streams(orc, graphs):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+# ---------------------------------------------------------------- negative samplers ----
+def _negative_world():
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "negative.npz")))
+    graph = glx.Graph(g["row_ptr"], g["col"], g["eid"], g["w_slot"], ids=g["rows"])
+    og = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"])
+    return g, graph, og
+
+
+def test_negative_tables_equal_reference_golden():
+    """glx_negative_from_graph: candidate order, in-degrees and the global alias table are the
+    reference's (tests/golden/negative.npz), bit for bit."""
+    g, graph, _ = _negative_world()
+    t = glx.Negative.from_graph(graph, by_in_degree=True)
+    ids, prob, alias = t.export()
+    assert np.array_equal(ids, g["dst_ids"])
+    assert np.array_equal(prob.view(np.uint32), g["indeg_prob"].view(np.uint32)) and np.array_equal(alias, g["indeg_alias"])
+    u = glx.Negative.from_graph(graph)
+    assert not u.weighted and np.array_equal(u.export()[0], g["dst_ids"])
+    n = glx.Negative(g["node_ids"], g["node_weights"])
+    ids, prob, alias = n.export()
+    assert np.array_equal(prob.view(np.uint32), g["node_prob"].view(np.uint32)) and np.array_equal(alias, g["node_alias"])
+
+
+@pytest.mark.parametrize("count", [1, 6, 64, 150])
+def test_negative_sampling_bit_exact_vs_oracle(count):
+    from oracle_bindings import Oracle
+    orc = Oracle()
+    g, graph, og = _negative_world()
+    graph.enable_negative()
+    rng = np.random.default_rng(count)
+    src = np.concatenate([g["rows"][rng.integers(0, g["rows"].shape[0], 300)], [10 ** 9, -7]]).astype(np.int64)
+    ids = g["dst_ids"]
+    uni = glx.Negative.from_graph(graph)
+    deg = glx.Negative.from_graph(graph, by_in_degree=True)
+    table = (g["indeg_prob"], g["indeg_alias"])
+    for cc in (0, 9):
+        a = uni.sample(src, count, seed=3, call_counter=cc)
+        assert np.array_equal(a, orc.negative_sample(ids, None, 0, og, src, count, seed=3, call_counter=cc))
+        a = deg.sample(src, count, seed=3, call_counter=cc)
+        assert np.array_equal(a, orc.negative_sample(ids, table, 0, og, src, count, seed=3, call_counter=cc))
+        a = deg.sample(src, count, exclude=glx.NEG_EXCLUDE_NEIGHBORS, graph=graph, seed=3, call_counter=cc)
+        assert np.array_equal(a, orc.negative_sample(ids, table, 1, og, src, count, seed=3, call_counter=cc))
+    nodes = glx.Negative(g["node_ids"], g["node_weights"])
+    batch = g["node_ids"][rng.integers(0, 400, 200)]
+    a = nodes.sample(batch, count, exclude=glx.NEG_EXCLUDE_BATCH, seed=11, call_counter=1)
+    want = orc.negative_sample(g["node_ids"], (g["node_prob"], g["node_alias"]), 2, None, batch, count, seed=11, call_counter=1)
+    assert np.array_equal(a, want)
+    # torch CUDA tensors in -> out, same draws
+    import torch
+    d = deg.sample(torch.from_numpy(src).cuda(), count, exclude=glx.NEG_EXCLUDE_NEIGHBORS, graph=graph, seed=3, call_counter=9)
+    assert d.is_cuda and np.array_equal(d.cpu().numpy(), orc.negative_sample(ids, table, 1, og, src, count, seed=3, call_counter=9))
+
+
+def test_negative_sampling_exhausted_candidates_and_empty_list():
+    from oracle_bindings import Oracle
+    orc = Oracle()
+    # every candidate is a neighbour of every source: only the 4th block can deliver
+    rp = np.array([0, 3, 6], np.int64)
+    col = np.array([5, 6, 7, 5, 6, 7], np.int64)
+    eid = np.arange(6, dtype=np.int64)
+    graph = glx.Graph(rp, col, eid, None)
+    graph.enable_negative()
+    og = dict(row_ptr=rp, col=col, eid=eid)
+    t = glx.Negative.from_graph(graph, by_in_degree=True)
+    ids, prob, alias = t.export()
+    src = np.array([0, 1, 1, 0], np.int64)
+    got = t.sample(src, 5, exclude=glx.NEG_EXCLUDE_NEIGHBORS, graph=graph, seed=2, call_counter=5)
+    assert np.array_equal(got, orc.negative_sample(ids, (prob, alias), 1, og, src, 5, seed=2, call_counter=5))
+    empty = glx.Negative(np.zeros(0, np.int64))
+    assert (empty.sample(src, 3, default_neighbor_id=-4) == -4).all()

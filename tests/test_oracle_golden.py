@@ -415,3 +415,98 @@ def test_aggregate_stitch_live_reference(orc):
                 assert beq(e, re_) and np.array_equal(n, rn), (P, name)
     finally:
         ref.close()
+
+
+def test_negative_candidates_and_tables_golden(orc):
+    """Negative samplers' inputs as the reference builds them: destination ids in
+    first-appearance order + in-degrees (topo_statics.cc:32-55) and the ONE alias table over
+    the whole list (AliasMethodFactory::LookupOrCreate), bit for bit."""
+    g = load("negative.npz")
+    ids, deg = orc.dst_statics(g["col"], g["eid"])
+    assert np.array_equal(ids, g["dst_ids"]) and np.array_equal(deg, g["in_degrees"])
+    p, a = orc.alias_build(np.array([0, ids.shape[0]], np.int64), deg.astype(np.float32))
+    assert beq(p, g["indeg_prob"]) and np.array_equal(a, g["indeg_alias"])
+    p, a = orc.alias_build(np.array([0, g["node_ids"].shape[0]], np.int64), g["node_weights"])
+    assert beq(p, g["node_prob"]) and np.array_equal(a, g["node_alias"])
+
+
+def test_negative_retry_schedule(orc):
+    """in_degree_negative_sampler.cc:57-92: blocks of `count` draws, accepted candidates keep
+    their order, the exclusion set is dropped from the 4th block on."""
+    g = load("negative.npz")
+    graph = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"])
+    ids = g["dst_ids"]
+    table = (g["indeg_prob"], g["indeg_alias"])
+    src = g["rows"][:40].copy()
+    k = 7
+    strict = orc.negative_sample(ids, table, 1, graph, src, k, seed=5, call_counter=2)
+    free = [orc.negative_sample(ids, table, 0, graph, src, k, seed=5, call_counter=2)]
+    # the strict result is the unrestricted candidate stream of blocks 0.. with neighbours removed
+    pos = {int(v): i for i, v in enumerate(g["rows"])}
+    for i, s in enumerate(src):
+        nb = set(g["col"][g["row_ptr"][pos[int(s)]]:g["row_ptr"][pos[int(s)] + 1]].tolist())
+        stream = free[0][i].tolist()
+        want = [c for c in stream if c not in nb]
+        assert strict[i].tolist()[:len(want)] == want[:k]
+    # all candidates excluded: only the 4th block (no exclusion) can deliver
+    few = ids[:3]
+    tab = orc.alias_build(np.array([0, 3], np.int64), np.ones(3, np.float32))
+    out = orc.negative_sample(few, tab, 2, None, few, 5, seed=1, call_counter=1)
+    assert set(out.reshape(-1).tolist()) <= set(few.tolist())
+    assert (orc.negative_sample(few[:0], None, 0, None, few, 4, default_neighbor_id=-9) == -9).all()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("name,exclude,weighted", [("RandomNegativeSampler", 0, False),
+                                                   ("SoftInDegreeNegativeSampler", 0, True),
+                                                   ("InDegreeNegativeSampler", 1, True)])
+def test_negative_samplers_match_reference_distribution(orc, name, exclude, weighted):
+    g = load("negative.npz")
+    ref = RefLib()
+    try:
+        ref.add_edges("neg", g["src"], g["dst"], g["w"])
+        graph = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"])
+        ids = g["dst_ids"]
+        table = (g["indeg_prob"], g["indeg_alias"]) if weighted else None
+        src = np.repeat(g["rows"][:10], 600)
+        got_ref = ref.negative_sample("neg", name, src, 6)
+        got = orc.negative_sample(ids, table, exclude, graph, src, 6, seed=31, call_counter=4)
+        index = {int(v): i for i, v in enumerate(ids)}
+        hr = np.bincount([index[int(v)] for v in got_ref.reshape(-1)], minlength=ids.shape[0])
+        ho = np.bincount([index[int(v)] for v in got.reshape(-1)], minlength=ids.shape[0])
+        keep = (hr + ho) >= 10
+        assert stats.chi2_contingency(np.stack([hr[keep], ho[keep]]))[1] > 1e-4, name
+        if exclude == 1:  # neighbours slip through equally rarely (only via the 4th block)
+            pos = {int(v): i for i, v in enumerate(g["rows"])}
+
+            def leaks(res):
+                n = 0
+                for s, row in zip(src, res):
+                    nb = g["col"][g["row_ptr"][pos[int(s)]]:g["row_ptr"][pos[int(s)] + 1]]
+                    n += int(np.isin(row, nb).sum())
+                return n
+            a, b = leaks(got), leaks(got_ref)
+            assert abs(a - b) <= 6 * np.sqrt(a + b + 1), (a, b)  # same leak rate (hub destinations exhaust 3 blocks)
+    finally:
+        ref.close()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_node_weight_negative_sampler_matches_reference_distribution(orc):
+    g = load("negative.npz")
+    ref = RefLib()
+    try:
+        nid, nw = g["node_ids"], g["node_weights"]
+        ref.add_weighted_nodes("nw", nid, nw)
+        batch = np.tile(nid[np.random.default_rng(1).integers(0, nid.shape[0], 50)], 60)
+        got_ref = ref.negative_sample("nw", "NodeWeightNegativeSampler", batch, 5)
+        got = orc.negative_sample(nid, (g["node_prob"], g["node_alias"]), 2, None, batch, 5, seed=8, call_counter=3)
+        assert not set(got.reshape(-1).tolist()) & set(batch.tolist())
+        assert not set(got_ref.reshape(-1).tolist()) & set(batch.tolist())
+        index = {int(v): i for i, v in enumerate(nid)}
+        hr = np.bincount([index[int(v)] for v in got_ref.reshape(-1)], minlength=nid.shape[0])
+        ho = np.bincount([index[int(v)] for v in got.reshape(-1)], minlength=nid.shape[0])
+        keep = (hr + ho) >= 10
+        assert stats.chi2_contingency(np.stack([hr[keep], ho[keep]]))[1] > 1e-4
+    finally:
+        ref.close()
