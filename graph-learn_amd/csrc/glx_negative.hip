@@ -93,45 +93,66 @@ struct NegArgs {
   const int64_t* batch_sorted;
 };
 
-// One wavefront per request row.  Draw d of row i is word d of the stream (seed, cc, i);
-// block b of the reference's retry loop uses draws [b * count, (b + 1) * count).
-template <int MODE>
+// One group of W lanes (W = 8, 16, 32 or 64: the smallest that covers `count`, so a
+// wavefront serves 64 / W request rows) per row.  Draw d of row i is word d of the stream
+// (seed, cc, i); block b of the reference's retry loop uses draws [b * count, (b + 1) * count).
+template <int MODE, int W>
 __global__ __launch_bounds__(256) void glx_negative_kernel(NegArgs a) {
+  constexpr int kGroups = 64 / W;  // per wavefront
   const int lane = threadIdx.x & 63;
-  const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.batch) return;
+  const int sub = lane & (W - 1);
+  const int grp = lane / W;
+  const int64_t row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (int64_t)kGroups + grp;
+  const bool live = row < a.batch;
   const int64_t* ex = nullptr;
   int64_t exn = 0;
-  if (MODE == GLX_NEG_EXCLUDE_NEIGHBORS) {
+  if (live && MODE == GLX_NEG_EXCLUDE_NEIGHBORS) {
     const int64_t r = glx_row_of(a.map, a.src[row]);
     if (r >= 0) {
       ex = a.nbr_sorted + a.row_ptr[r];
       exn = a.row_ptr[r + 1] - a.row_ptr[r];
     }
-  } else if (MODE == GLX_NEG_EXCLUDE_BATCH) {
+  } else if (live && MODE == GLX_NEG_EXCLUDE_BATCH) {
     ex = a.batch_sorted;
     exn = a.batch;
   }
   const int32_t n = a.count;
-  int32_t taken = 0;
-  for (int32_t blk = 0; blk < 4 && taken < n; ++blk) {
+  const uint64_t group_mask = W == 64 ? ~0ull : (((1ull << W) - 1ull) << (grp * W));
+  int32_t taken = live ? 0 : n;
+  // every lane of the wavefront runs the same trip count; finished groups just idle
+  for (int32_t blk = 0; blk < 4; ++blk) {
     const bool strict = MODE != GLX_NEG_EXCLUDE_NONE && blk < 3;  // the 4th block drops the set
-    for (int32_t base = 0; base < n && taken < n; base += 64) {
-      const int32_t j = base + lane;
+    for (int32_t base = 0; base < n; base += W) {
+      if (__ballot(taken < n) == 0) return;
+      const int32_t j = base + sub;
       bool ok = false;
       int64_t item = 0;
-      if (j < n) {
+      if (taken < n && j < n) {
         const uint64_t u = glx_draw64(a.seed, a.cc, (uint32_t)row, (uint32_t)(blk * n + j));
         const int64_t idx = a.table ? (int64_t)glx_alias_pick(u, a.num_ids, a.table)
                                     : (int64_t)glx_bounded(u, (uint64_t)a.num_ids);
         item = a.ids[idx];
         ok = !strict || !glx_sorted_contains(ex, exn, item);
       }
-      const uint64_t m = __ballot(ok);
+      const uint64_t m = __ballot(ok) & group_mask;
       const int32_t pos = taken + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (ok && pos < n) a.out[row * (int64_t)n + pos] = item;
       taken += (int32_t)__popcll(m);
     }
+  }
+}
+
+template <int MODE>
+void launch_negative(const NegArgs& a, hipStream_t s) {
+  const int32_t n = a.count;
+  const int w = n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64;
+  const int64_t rows_per_block = 4 * (64 / w);
+  const unsigned grid = (unsigned)((a.batch + rows_per_block - 1) / rows_per_block);
+  switch (w) {
+    case 8: glx_negative_kernel<MODE, 8><<<grid, 256, 0, s>>>(a); break;
+    case 16: glx_negative_kernel<MODE, 16><<<grid, 256, 0, s>>>(a); break;
+    case 32: glx_negative_kernel<MODE, 32><<<grid, 256, 0, s>>>(a); break;
+    default: glx_negative_kernel<MODE, 64><<<grid, 256, 0, s>>>(a); break;
   }
 }
 
@@ -410,12 +431,11 @@ extern "C" int glx_negative_sample(const glx_negative* t, int exclude, const glx
       GLX_HIP(e);
       a.batch_sorted = sorted;
     }
-    const unsigned grid = (unsigned)((batch + 3) / 4);
     GlxKernelTimer timer(GLX_KERNEL_SAMPLE, s);
     switch (exclude) {
-      case GLX_NEG_EXCLUDE_NONE: glx_negative_kernel<GLX_NEG_EXCLUDE_NONE><<<grid, 256, 0, s>>>(a); break;
-      case GLX_NEG_EXCLUDE_NEIGHBORS: glx_negative_kernel<GLX_NEG_EXCLUDE_NEIGHBORS><<<grid, 256, 0, s>>>(a); break;
-      default: glx_negative_kernel<GLX_NEG_EXCLUDE_BATCH><<<grid, 256, 0, s>>>(a); break;
+      case GLX_NEG_EXCLUDE_NONE: launch_negative<GLX_NEG_EXCLUDE_NONE>(a, s); break;
+      case GLX_NEG_EXCLUDE_NEIGHBORS: launch_negative<GLX_NEG_EXCLUDE_NEIGHBORS>(a, s); break;
+      default: launch_negative<GLX_NEG_EXCLUDE_BATCH>(a, s); break;
     }
     timer.stop();
   }

@@ -36,6 +36,27 @@ def run(tag, V, E, D, fan, B0=65536, reps=10):
             alg = slots * 32 + (B0 + B0 * k1) * 24 + (slots * 8 if name in ("EdgeWeightSampler", "InDegreeSampler") else 0)
             print(json.dumps({"graph": tag, "op": name, "fanout": fan, "B0": B0, "hop1_ms": h1, "hop2_ms": h2,
                               "edges_per_s": slots / ((h1 + h2) * 1e-3), "algorithmic_GBps": alg / ((h1 + h2) * 1e-3) / 1e9}))
+    # negative samplers: k = 10 candidates for each of the B0 * k1 hop-1 vertices
+    t0 = _t.time(); neg_u = glx.Negative.from_graph(g); neg_d = glx.Negative.from_graph(g, by_in_degree=True)
+    g.enable_negative(); torch.cuda.synchronize()
+    print(json.dumps({"graph": tag, "op": "negative tables + sorted adjacency (one-time)", "seconds": _t.time() - t0,
+                      "candidates": neg_u.num_ids}))
+    fr = n1.view(-1)
+    for label, tab, ex in (("RandomNegativeSampler", neg_u, glx.NEG_EXCLUDE_NONE),
+                           ("SoftInDegreeNegativeSampler", neg_d, glx.NEG_EXCLUDE_NONE),
+                           ("InDegreeNegativeSampler", neg_d, glx.NEG_EXCLUDE_NEIGHBORS)):
+        tab.sample(fr, 10, exclude=ex, graph=g, seed=1, call_counter=0)
+        torch.cuda.synchronize(); glx.profile_enable(True)
+        for r in range(reps):
+            tab.sample(fr, 10, exclude=ex, graph=g, seed=1, call_counter=r)
+        torch.cuda.synchronize(); glx.profile_enable(False)
+        ms = float(np.mean(glx.profile_collect(glx.KERNEL_SAMPLE)))
+        slots = fr.shape[0] * 10
+        # algorithmic bytes per candidate: 8 (read id) + 8 (write) [+ 8 alias entry]; per row 8 (src id)
+        alg = slots * (16 + (8 if tab.weighted else 0)) + fr.shape[0] * 8
+        print(json.dumps({"graph": tag, "op": label, "rows": int(fr.shape[0]), "count": 10, "ms": ms,
+                          "negatives_per_s": slots / (ms * 1e-3), "algorithmic_GBps": alg / (ms * 1e-3) / 1e9}))
+    del neg_u, neg_d
     # FullSampler on the hop-1 frontier, limit 25 (sparse response)
     fr = n1.view(-1)
     g.sample_full(fr, 25); torch.cuda.synchronize(); t0 = _t.time()
