@@ -102,3 +102,59 @@ def test_fuzz_partition_stitch(seed, n, P, width):
         exp = np.zeros((n, width), np.int64)
         exp[oo] = np.arange(n * width).reshape(n, width)
         assert np.array_equal(back, exp)
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2 ** 31 - 1), V=st.integers(1, 30), maxdeg=st.integers(0, 40), ndst=st.integers(1, 60),
+       count=st.integers(1, 140), hashed=st.booleans(), nq=st.integers(1, 40),
+       rng_seed=st.integers(0, 2 ** 63 - 1), cc=st.integers(0, 2 ** 40))
+def test_fuzz_negative_samplers(seed, V, maxdeg, ndst, count, hashed, nq, rng_seed, cc):
+    """Candidate lists, global alias tables and all three exclusion modes, tiny candidate sets
+    included (every candidate a neighbour: only the 4th retry block delivers)."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, maxdeg + 1, V)
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    E = int(rp[-1])
+    raw = (rng.permutation(V * 3)[:V] - V).astype(np.int64) if hashed else None
+    pool = raw if hashed else np.arange(V, dtype=np.int64)
+    dsts = (rng.permutation(ndst * 4)[:ndst] * 3 - 7).astype(np.int64)
+    col = dsts[rng.integers(0, ndst, E)] if E else np.zeros(0, np.int64)
+    eid = rng.permutation(E).astype(np.int64)
+    og = dict(row_ptr=rp, col=col, eid=eid, ids=raw)
+    dev = glx.Graph(rp, col, eid, None, ids=raw)
+    dev.enable_negative()
+    ids, indeg = ORC.dst_statics(col, eid)
+    table = ORC.alias_build(np.array([0, ids.shape[0]], np.int64), indeg.astype(np.float32)) if E else None
+    uni = glx.Negative.from_graph(dev)
+    wtd = glx.Negative.from_graph(dev, by_in_degree=True)
+    got_ids, prob, alias = wtd.export()
+    assert np.array_equal(got_ids, ids) and np.array_equal(uni.export()[0], ids)
+    if E:
+        assert beq(prob, table[0]) and np.array_equal(alias, table[1])
+    q = np.concatenate([pool[rng.integers(0, V, nq)], [10 ** 12]]).astype(np.int64)
+    a = uni.sample(q, count, default_neighbor_id=-3, seed=rng_seed, call_counter=cc)
+    assert np.array_equal(a, ORC.negative_sample(ids, None, 0, og, q, count, -3, rng_seed, cc))
+    for ex in (glx.NEG_EXCLUDE_NONE, glx.NEG_EXCLUDE_NEIGHBORS):
+        a = wtd.sample(q, count, exclude=ex, graph=dev, default_neighbor_id=-3, seed=rng_seed, call_counter=cc)
+        assert np.array_equal(a, ORC.negative_sample(ids, table, ex, og, q, count, -3, rng_seed, cc)), ex
+    nid = np.unique(rng.integers(-50, 50, int(rng.integers(1, 40)))).astype(np.int64)
+    nw = (rng.integers(1, 40, nid.shape[0]) / 8.0).astype(np.float32)
+    nt = ORC.alias_build(np.array([0, nid.shape[0]], np.int64), nw)
+    batch = nid[rng.integers(0, nid.shape[0], nq)]
+    a = glx.Negative(nid, nw).sample(batch, count, exclude=glx.NEG_EXCLUDE_BATCH, seed=rng_seed, call_counter=cc)
+    assert np.array_equal(a, ORC.negative_sample(nid, nt, 2, None, batch, count, 0, rng_seed, cc))
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2 ** 31 - 1), P=st.integers(1, 9), Sg=st.integers(1, 40), D=st.integers(1, 70),
+       dflt=st.sampled_from([0.0, -1.5, 999.9]))
+def test_fuzz_aggregate_stitch(seed, P, Sg, D, dflt):
+    import torch
+    rng = np.random.default_rng(seed)
+    parts = (rng.standard_normal((P, Sg, D)) * 20).astype(np.float32)
+    cnts = rng.integers(0, 4, (P, Sg)).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    for name in AGGREGATORS:
+        e, c = glx.aggregate_stitch(name, torch.from_numpy(parts).to(dev), torch.from_numpy(cnts).to(dev), dflt)
+        oe, oc = ORC.aggregate_stitch(name, parts, cnts, dflt)
+        assert np.array_equal(c.cpu().numpy(), oc) and beq(e.cpu().numpy(), oe), name
