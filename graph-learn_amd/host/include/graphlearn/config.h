@@ -39,5 +39,6 @@ void SetGlobalFlagSamplingSeed(int64_t v);
 void SetGlobalFlagDeviceId(int32_t v);
 
 enum PaddingMode { kReplicate = 0, kCircular = 1 };  // include/constants.h:119-122
+enum NodeFrom { kEdgeSrc = 0, kEdgeDst = 1, kNode = 2 };  // include/constants.h
 }  // namespace graphlearn
 #endif  // GLX_HOST_CONFIG_H_

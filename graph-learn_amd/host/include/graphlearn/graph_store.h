@@ -100,6 +100,9 @@ public:
   void Add(const io::EdgeValue* value);          // edge id = insertion index
   Status Build(const IndexOption& option);       // sort (if option.name=="sort") + upload
   int64_t GetEdgeCount() const { return (int64_t)src_.size(); }
+  // All edges in edge-id order (EdgeStorage::GetSrcIds/GetDstIds, memory_edge_storage.cc:127-133).
+  const std::vector<int64_t>& SrcIds() const { return src_; }
+  const std::vector<int64_t>& DstIds() const { return dst_; }
   const glx_graph* Device() const { return dev_; }  // nullptr before Build()
   // Candidate list of the negative samplers for this edge type (destination ids in
   // first-appearance order, uniform or in-degree weighted), built on first use and
@@ -149,6 +152,7 @@ public:
   Status Build(const IndexOption& option);
   const glx_features* Device() const { return dev_; }
   int64_t GetNodeCount() const { return (int64_t)ids_.size(); }
+  const std::vector<int64_t>& Ids() const { return ids_; }  // NodeStorage::GetIds, insertion order
   // Candidate list of NodeWeightNegativeSampler: this type's ids weighted by node weight.
   Status Negative(const glx_negative** out);
 

@@ -18,7 +18,11 @@ from graphlearn.decoder import Decoder  # noqa: F401
 from graphlearn.topology import Topology  # noqa: F401
 from graphlearn.values import Values, Nodes, Edges, SparseNodes, SparseEdges, Layer, Layers  # noqa: F401
 from graphlearn.sampler import *  # noqa: F401,F403
+from graphlearn.traversal import *  # noqa: F401,F403
 from graphlearn.graph import Graph  # noqa: F401
 
+NODE = pywrap.NodeFrom.NODE
+EDGE_SRC = pywrap.NodeFrom.EDGE_SRC
+EDGE_DST = pywrap.NodeFrom.EDGE_DST
 REPLICATE = pywrap.PaddingMode.REPLICATE
 CIRCULAR = pywrap.PaddingMode.CIRCULAR

@@ -268,11 +268,15 @@ class Graph(object):
   def E(self, *args, **kwargs):  # pylint: disable=invalid-name
     self._off_path("GSL (Graph.E)")
 
-  def node_sampler(self, *args, **kwargs):
-    self._off_path("node_sampler")
+  def node_sampler(self, t, batch_size=64, strategy="by_order", node_from=pywrap.NodeFrom.NODE, mask=Mask.NONE):
+    """Batches of seed vertices: strategy "by_order" | "shuffle" | "random" (see traversal.py)."""
+    from graphlearn import traversal
+    return traversal.NodeSampler(self, t, batch_size, strategy=strategy, node_from=node_from, mask=mask)
 
-  def edge_sampler(self, *args, **kwargs):
-    self._off_path("edge_sampler")
+  def edge_sampler(self, edge_type, batch_size=64, strategy="by_order", mask=Mask.NONE):
+    """Batches of seed edges: strategy "by_order" | "shuffle" | "random"."""
+    from graphlearn import traversal
+    return traversal.EdgeSampler(self, edge_type, batch_size, strategy=strategy, mask=mask)
 
   def negative_sampler(self, object_type, expand_factor, strategy="random", conditional=False, **kwargs):
     """strategy: "random", "in_degree", "soft_in_degree" (object_type = an edge type) or

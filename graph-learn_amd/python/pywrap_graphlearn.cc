@@ -117,6 +117,11 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       .value("ATTRIBUTED", io::kAttributed)
       .value("TIMESTAMPED", io::kTimestamped);
 
+  py::enum_<NodeFrom>(m, "NodeFrom")
+      .value("EDGE_SRC", kEdgeSrc)
+      .value("EDGE_DST", kEdgeDst)
+      .value("NODE", kNode);
+
   py::enum_<io::Direction>(m, "Direction").value("ORIGIN", io::kOrigin).value("REVERSED", io::kReversed);
 
   py::class_<IndexOption>(m, "IndexOption").def(py::init<>()).def_readwrite("name", &IndexOption::name);
@@ -158,6 +163,19 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       .def("init", &Server::Init, py::call_guard<py::gil_scoped_release>())
       .def("init_status", &Server::InitStatus)
       .def("device_graph", &Server::DeviceGraph)
+      // id lists of the store for the batch-traversal samplers (node_generator.h / edge_generator.h)
+      .def("node_ids", [](Server& self, const std::string& node_type) {
+        const std::vector<int64_t>& ids = self.Store()->GetNoder(node_type)->Ids();
+        return CopyOut(ids.data(), ids.size());
+      })
+      .def("edge_src_ids", [](Server& self, const std::string& edge_type) {
+        const std::vector<int64_t>& ids = self.Store()->GetGraph(edge_type)->SrcIds();
+        return CopyOut(ids.data(), ids.size());
+      })
+      .def("edge_dst_ids", [](Server& self, const std::string& edge_type) {
+        const std::vector<int64_t>& ids = self.Store()->GetGraph(edge_type)->DstIds();
+        return CopyOut(ids.data(), ids.size());
+      })
       .def("device_features", &Server::DeviceFeatures)
       .def("stop", &Server::Stop);
   m.def("server", &NewServer, py::return_value_policy::take_ownership, py::arg("server_id"),

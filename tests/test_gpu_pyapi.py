@@ -342,3 +342,50 @@ def test_negative_sampler_node_weight(gl, g):
         g.negative_sampler(NODE2, 3, strategy="random")  # needs an edge type
     with pytest.raises(gl.InvalidArgumentError):
         g.negative_sampler(NODE1, 3, strategy="node_weight").get(SEEDS1)  # node1 has no weights
+
+
+def test_node_and_edge_traversal_samplers(gl, g):
+    """g.node_sampler / g.edge_sampler (python/sampler/{node,edge}_sampler.py): by_order covers every id
+    once per epoch with a short last batch and an OutOfRangeError at the boundary; shuffle covers a
+    permutation; random never ends; EDGE_SRC / EDGE_DST walk the distinct end points."""
+    s = g.node_sampler(NODE2, batch_size=32, strategy="by_order")
+    seen = []
+    for _ in range(2):  # two epochs
+        got = []
+        while True:
+            try:
+                got.append(s.get().ids)
+            except gl.OutOfRangeError:
+                break
+        assert [b.size for b in got] == [32, 32, 32, 4]
+        seen.append(np.concatenate(got))
+    assert seen[0].tolist() == list(range(*RANGE2)) == seen[1].tolist()
+    nodes = g.node_sampler(NODE2, batch_size=5).get()
+    fx.expect_node_columns(nodes, weighted=True, labeled=True)  # the batch is a normal Nodes object
+    sh = g.node_sampler(NODE1, batch_size=64, strategy="shuffle")
+    epoch = np.concatenate([sh.get().ids, sh.get().ids])
+    assert sorted(epoch.tolist()) == list(range(*RANGE1)) and epoch.tolist() != list(range(*RANGE1))
+    with pytest.raises(gl.OutOfRangeError):
+        sh.get()
+    rnd = g.node_sampler(NODE1, batch_size=300, strategy="random").get()
+    assert rnd.ids.size == 300 and set(rnd.ids.tolist()) <= set(range(*RANGE1))
+    srcs = g.node_sampler(EDGE1, batch_size=1000, node_from=gl.EDGE_SRC).get()
+    assert srcs.type == NODE1 and srcs.ids.tolist() == [s_ for s_ in range(*RANGE1) if s_ % 5]
+    dsts = g.node_sampler(EDGE1, batch_size=1000, node_from=gl.EDGE_DST).get()
+    assert dsts.type == NODE2 and sorted(dsts.ids.tolist()) == sorted(set(NODE2_IDS))
+    es = g.edge_sampler(EDGE2, batch_size=50, strategy="by_order")
+    first = es.get()
+    assert first.edge_ids.tolist() == list(range(50)) and first.src_type == NODE2 and first.dst_type == NODE1
+    fx.expect_edges_follow_generator(first, RANGE1, range(*RANGE2), DEFAULT_ID)
+    fx.expect_edge_columns(first, weighted=True, attributed=True)  # lookups by the sampled edge ids
+    total = 50
+    while True:
+        try:
+            total += es.get().src_ids.size
+        except gl.OutOfRangeError:
+            break
+    assert total == len(fx.fixed_dst_ids(range(*RANGE2), RANGE1))
+    # seed batches feed the device samplers
+    seeds = g.node_sampler(NODE1, batch_size=16, strategy="random").get().ids
+    nbrs = g.neighbor_sampler(EDGE1, 3, strategy="random").get(seeds)
+    assert nbrs.layer_nodes(1).ids.shape == (16, 3)
