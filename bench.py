@@ -247,7 +247,7 @@ def bench_c5(args, dev, result_out):
         "metric": "sampled-edges/sec + aggregated-vertices/sec (per-edge-type Topk + type-wise Sum per step)",
         "value": slots * args.steps / elapsed, "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int64 ids + f32 features", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "c5: " + bench_c5.__doc__.split("\n")[0], "seeds_per_step_per_gpu": B0,
                    "edge_types": {t: {"edges": v[2], "k": v[3]} for t, v in spec.items()}, "dim": D,
                    "parallelism": "1 GPU"},
@@ -596,10 +596,11 @@ def main():
                   "sampled vertex is aggregated once, so the step rate counts both)",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int64 ids + f32 features", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, desc), "seeds_per_step_per_gpu": B0,
                    "seeds": "uniform over the vertices that have out-edges, fresh batch every step",
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
+                   "arithmetic": "int64 ids / edge ids (bit-exact), f32 features and aggregates",
                    "nodes": V, "edges": E, "hop2_rows_without_out_edges_fraction": empty_frac,
                    "vertex_labels": "raw RMAT ids" if args.no_scramble else "RMAT ids relabeled by a fixed random permutation (Graph500-style)",
                    "parallelism": placement,
