@@ -364,6 +364,11 @@ def main():
         whole = None
         if args.verify:
             whole = (glx.Graph.from_edges(src, dst, weight, device=local_rank), glx.Features(X, device=local_rank))
+        # ablation leg "everything replicated": the whole topology also fits next to the replica
+        # (C3: 5.6 GB), so requests could be served with no exchange at all
+        whole_graph = None
+        if (args.ablations == "on" or (args.ablations == "auto" and world > 1)) and E * 56 <= 64 * (1 << 30):
+            whole_graph = whole[0] if whole else glx.Graph.from_edges(src, dst, weight, device=local_rank)
         own = (src % world) == rank  # edge-cut: out-edges of v live on shard llabs(v) % P
         eids = torch.nonzero(own).view(-1)
         graph = glx.Graph.from_edges(src[own].contiguous(), dst[own].contiguous(),
@@ -544,6 +549,33 @@ def main():
         legs = {}
         exact = agg in ("MaxAggregator", "MinAggregator")
         K = max(1, args.ablation_steps)
+        if whole_graph is not None:
+            # upper bound of the placement space: topology AND features replicated, no collective on
+            # the data path (requests sharded across ranks, each served locally)
+            def local(i):
+                a, _ = whole_graph.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
+                b, _ = whole_graph.sample(sampler, a.view(-1), k2, seed=42, call_counter=4 * i + 1)
+                e2, c2 = store.aggregate(agg, b.view(-1), seg2, n1)
+                store.aggregate(agg, a.view(-1), seg1, B0)
+                return b, e2
+            local(0)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                b, e2 = local(args.warmup + i)
+            barrier()
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt], device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            i = args.warmup + args.steps - 1
+            sa, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
+            sb, _ = store.sample(sampler, sa.view(-1), k2, seed=42, call_counter=4 * i + 1)
+            legs["topology_and_features_replicated_no_exchange"] = {
+                "ms_per_step": float(t.item()) / args.steps * 1e3,
+                "value": world * edges_per_step * args.steps / float(t.item()), "steps": args.steps,
+                "equals_edge_cut_result": bool(torch.equal(sb, b))}
+            log("ablation all-replicated: %.2f ms/step" % legs["topology_and_features_replicated_no_exchange"]["ms_per_step"])
+            del b, e2, sa, sb
         for key, kw in (("features_sharded_halo_exchange_H", dict(mode="halo")),
                         ("features_sharded_halo_exchange_H_distinct_ids", dict(mode="halo", dedup=True)),
                         ("features_sharded_partial_reduce_R", dict(mode="partial"))):
