@@ -116,9 +116,23 @@ def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
     dta = ref.L.glref_time_aggregate(ref.h, b"n", agg.encode(), _p(ids), n_ids, k2, areps, threads,
                                      ctypes.byref(out))
     r_agg = out.value / dta
+    # optional: the same two legs at other thread counts (T = 1 and T = nproc)
+    sweep = []
+    for tc in [int(x) for x in args.cpu_thread_sweep.split(",") if x.strip()]:
+        tc = tc if tc > 0 else (os.cpu_count() or 1)
+        sd = pool[rng.integers(0, pool.shape[0], B * tc * 4)]
+        d1 = ref.L.glref_time_sample_2hop(ref.h, b"e", sampler.encode(), _p(sd), B, k1, k2, 4, tc, ctypes.byref(out))
+        rs = out.value / d1
+        ia = rng.integers(0, Vc, n_ids * tc * 4).astype(np.int64)
+        d2 = ref.L.glref_time_aggregate(ref.h, b"n", agg.encode(), _p(ia), n_ids, k2, 4, tc, ctypes.byref(out))
+        ra = out.value / d2
+        sweep.append({"cores": tc, "value": 1.0 / (1.0 / rs + 1.0 / ra), "sampling_edges_per_s": rs,
+                      "aggregation_vertices_per_s": ra})
+        log("cpu baseline at %d threads: %.3g edges/s" % (tc, sweep[-1]["value"]))
     ref.close()
     value = 1.0 / (1.0 / r_sample + 1.0 / r_agg)
     return {
+        "thread_sweep": sweep or None,
         "value": value, "unit": "edges/s", "cores": threads, "kind": "reference",
         "sampling_edges_per_s": r_sample, "aggregation_vertices_per_s": r_agg,
         "sample": ("reference C++ %s [%d,%d] + %s on host threads (one request per thread, "
@@ -300,6 +314,8 @@ def main():
     ap.add_argument("--cpu-build-budget", type=float, default=60.0, help="s of reference graph build")
     ap.add_argument("--cpu-time-budget", type=float, default=10.0, help="s per timed CPU leg")
     ap.add_argument("--cpu-seeds-per-request", type=int, default=128)
+    ap.add_argument("--cpu-thread-sweep", default="",
+                    help="comma separated extra thread counts for the CPU baseline (0 = nproc), e.g. '1,0'")
     args = ap.parse_args()
 
     # Contract: rank 0 prints exactly ONE JSON line on stdout.  Libraries (RCCL's
