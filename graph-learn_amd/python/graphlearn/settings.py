@@ -15,7 +15,7 @@ __all__ = [
 
 
 # flags the device-tensor path (NeighborSampler.get_device) passes to the C-ABI itself
-_MIRROR = {"padding_mode": 1, "default_neighbor_id": 0, "sampling_seed": 0}
+_MIRROR = {"padding_mode": 1, "default_neighbor_id": 0, "sampling_seed": 0, "default_float_attr": 0.0, "device_id": 0}
 
 
 def set_default_neighbor_id(nbr_id):
@@ -35,6 +35,7 @@ def set_default_int_attribute(value=0):
 
 def set_default_float_attribute(value=0.0):
   pywrap.set_default_float_attr(float(value))
+  _MIRROR["default_float_attr"] = float(value)
 
 
 def set_default_string_attribute(value=""):
@@ -71,6 +72,7 @@ def set_sampling_seed(seed):
 def set_device_id(device):
   """GPU that holds this process' graph store (one process per GPU)."""
   pywrap.set_device_id(int(device))
+  _MIRROR["device_id"] = int(device)
 
 
 def _ignored(name):

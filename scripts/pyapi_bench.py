@@ -79,6 +79,23 @@ def main():
     t_dev = (time.time() - t0) / 10
     print("device path  : %.2f ms/step  %.3g sampled edges/s (1 multi-hop call + 1 Max aggregation, torch CUDA tensors)"
           % (t_dev * 1e3, edges_per_step / t_dev))
+    # the loader: seeds -> 2 hops -> float attributes of all three frontiers, per batch, on the GPU
+    loader = gl.NeighborLoader(g, "v", ["e", "e"], [25, 10], batch_size=B, strategy="edge_weight", shuffle=True)
+    it = iter(loader)
+    for _ in range(3):
+        next(it)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    nb = 0
+    for batch in it:
+        nb += 1
+        if nb == 40:
+            break
+    torch.cuda.synchronize()
+    t_ld = (time.time() - t0) / nb
+    rows = B * (1 + 25 + 250)
+    print("NeighborLoader: %.2f ms/batch  %.3g sampled edges/s + %.3g feature rows/s gathered (%d floats each), device resident"
+          % (t_ld * 1e3, edges_per_step / t_ld, rows / t_ld, D))
     g.close()
 
 

@@ -389,3 +389,39 @@ def test_node_and_edge_traversal_samplers(gl, g):
     seeds = g.node_sampler(NODE1, batch_size=16, strategy="random").get().ids
     nbrs = g.neighbor_sampler(EDGE1, 3, strategy="random").get(seeds)
     assert nbrs.layer_nodes(1).ids.shape == (16, 3)
+
+
+def test_neighbor_loader_device_batches(gl, g):
+    """gl.NeighborLoader: every batch is produced and kept on the GPU; one epoch covers every seed once;
+    a batch equals what the request-per-hop numpy path returns for the same pinned call counter."""
+    import torch
+    with padding(gl, gl.CIRCULAR):
+        loader = gl.NeighborLoader(g, "entity", ["relation", "relation"], [4, 3], batch_size=32,
+                                   strategy="edge_weight", shuffle=True)
+        assert len(loader) == 4  # 120 entity nodes
+        seen = []
+        batches = list(loader)
+        for i, b in enumerate(batches):
+            assert b.seeds.is_cuda and b.num_hops == 2
+            bs = b.seeds.shape[0]
+            assert tuple(b.nbr[0].shape) == (bs, 4) and tuple(b.nbr[1].shape) == (bs * 4, 3)
+            assert tuple(b.x[0].shape) == (bs, 4) and tuple(b.x[2].shape) == (bs * 12, 4)
+            seen.append(b.seeds.cpu().numpy())
+            # features are the generator's closed form (0.1 id .. 0.4 id), default row for padding ids
+            ids = b.frontier(2).cpu().numpy()
+            want = np.where((ids >= 0) & (ids < 120), ids, np.nan)[:, None] * np.array([0.1, 0.2, 0.3, 0.4])
+            got = b.x[2].cpu().numpy()
+            known = ~np.isnan(want[:, 0])
+            np.testing.assert_allclose(got[known], want[known], rtol=1e-5, atol=1e-5)
+            src, dst = b.edge_index(1)
+            assert torch.equal(b.frontier(1)[src], b.nbr[0].reshape(-1).repeat_interleave(3))
+            # same draws as the numpy path with the same call counter
+            s = g.neighbor_sampler(["relation", "relation"], [4, 3], strategy="edge_weight")
+            s.set_call_counter(i * 2)
+            host = s.get(seen[-1])
+            np.testing.assert_equal(b.nbr[1].cpu().numpy(), host.layer_nodes(2).ids)
+            np.testing.assert_equal(b.eid[0].cpu().numpy(), host.layer_edges(1).edge_ids)
+        assert sorted(np.concatenate(seen).tolist()) == list(range(120))
+        second = [b.seeds.cpu().numpy() for b in loader]  # next epoch: another permutation
+        assert sorted(np.concatenate(second).tolist()) == list(range(120))
+        assert not np.array_equal(np.concatenate(second), np.concatenate(seen))
