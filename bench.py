@@ -489,9 +489,13 @@ def main():
             agg_done.append(done)
 
     def barrier():
+        # Drain the local queue first: an RCCL barrier issued while the GPU still has queued work
+        # was seen to take 100+ ms sporadically (world-size-1 probe), which would be charged to
+        # the timed region; with an idle GPU it costs ~0.06 ms.
+        torch.cuda.synchronize()
         if sharded:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -602,14 +606,18 @@ def main():
                 e1, c1 = store_h.aggregate(agg, a.view(-1), seg1, B0, **kw)
                 return b, e2, c2
             one(0)
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(K):
+            one(1 % n_steps)  # two warm-ups: the multi-GB exchange buffers settle in the caching allocator
+            per_step = []
+            for i in range(K):  # each step timed on its own (these legs are not pipelined); median reported
+                barrier()
+                t0 = time.perf_counter()
                 b, e2, c2 = one(args.warmup + i % max(args.steps, 1))
-            barrier()
-            dt = time.perf_counter() - t0
-            t = torch.tensor([dt], device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                torch.cuda.synchronize()
+                per_step.append(time.perf_counter() - t0)
+            t = torch.tensor(per_step, device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # a step takes as long as its slowest rank
+            per_step = sorted(t.tolist())
+            med = per_step[len(per_step) // 2]
             we2, wc2 = store.aggregate(agg, b.view(-1), seg2, n1)  # the replica's (single-shard) answer
             if exact or kw["mode"] == "halo":
                 same = torch.equal(e2.view(torch.int32), we2.view(torch.int32))
@@ -618,8 +626,8 @@ def main():
             same = bool(same and torch.equal(c2, wc2))
             del e2, c2, we2, wc2, b
             torch.cuda.empty_cache()
-            legs[key] = {"ms_per_step": float(t.item()) / K * 1e3, "value": world * edges_per_step * K / float(t.item()),
-                         "steps": K, "equals_replica_result": same}
+            legs[key] = {"ms_per_step": med * 1e3, "value": world * edges_per_step / med, "steps": K,
+                         "ms_per_step_all": [round(x * 1e3, 3) for x in per_step], "equals_replica_result": same}
             log("ablation %s: %.2f ms/step (%s)" % (key, legs[key]["ms_per_step"], "ok" if same else "MISMATCH"))
         return legs
     # dominant kernel: the hop-2 segmented reduce (first aggregate launch of each step)

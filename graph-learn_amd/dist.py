@@ -71,7 +71,14 @@ def _staged(x, group):
     return x.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def _a2a(x, send_counts, recv_counts, group):
+# RCCL (2.26, ROCm 7) delivers only the first half of an all-to-all message larger than
+# 1 GiB (measured with world_size 1: bytes beyond message_size / 2 are left untouched;
+# scripts/debug_rccl_big.py).  No peer message is allowed to exceed this many bytes; larger
+# exchanges are cut into rounds.  all_gather is chunked the same way to stay clear of the limit.
+MAX_MESSAGE_BYTES = 512 << 20
+
+
+def _a2a_once(x, send_counts, recv_counts, group):
     shape = (int(sum(recv_counts)),) + tuple(x.shape[1:])
     if _staged(x, group):
         xc = x.contiguous().cpu()
@@ -82,6 +89,37 @@ def _a2a(x, send_counts, recv_counts, group):
     out = x.new_empty(shape)
     dist.all_to_all_single(out, x.contiguous(), output_split_sizes=list(recv_counts),
                            input_split_sizes=list(send_counts), group=group)
+    return out
+
+
+def _a2a(x, send_counts, recv_counts, group, bound):
+    """all-to-all(v) of the rows of x: send_counts[p] consecutive rows go to rank p.
+    `bound` = the largest row count any rank sends to any rank in this exchange, known to
+    EVERY rank (from the gathered count matrix), so that all ranks agree on the number of
+    rounds without another collective."""
+    width = 1
+    for d in x.shape[1:]:
+        width *= int(d)
+    step = max(1, MAX_MESSAGE_BYTES // max(1, x.element_size() * width))  # rows per peer per round
+    most = int(bound)
+    if most <= step:
+        return _a2a_once(x, send_counts, recv_counts, group)
+    out = x.new_empty((int(sum(recv_counts)),) + tuple(x.shape[1:]))
+    send_off = [0]
+    for c in send_counts:
+        send_off.append(send_off[-1] + int(c))
+    recv_off = [0]
+    for c in recv_counts:
+        recv_off.append(recv_off[-1] + int(c))
+    for lo in range(0, most, step):  # the same number of rounds on every rank
+        sc = [max(0, min(int(c) - lo, step)) for c in send_counts]
+        rc = [max(0, min(int(c) - lo, step)) for c in recv_counts]
+        part = torch.cat([x[send_off[p] + lo:send_off[p] + lo + sc[p]] for p in range(len(sc))])
+        got = _a2a_once(part, sc, rc, group)
+        at = 0
+        for p in range(len(rc)):
+            out[recv_off[p] + lo:recv_off[p] + lo + rc[p]] = got[at:at + rc[p]]
+            at += rc[p]
     return out
 
 
@@ -102,25 +140,23 @@ class ShardedStore:
         self.rank = dist.get_rank(group)
 
     def _route(self, ids):
-        """Bucket ids by owner and tell every owner how many it will receive."""
+        """Bucket ids by owner and share the whole count matrix: -> bucketed, order, rows this
+        rank sends to each rank, rows it receives from each rank, and the global maximum."""
         bucketed, order, counts = self.ops.partition(ids, self.world)
-        if _staged(counts, self.group):
-            cc = counts.cpu()
-            recv = torch.empty_like(cc)
-            dist.all_to_all_single(recv, cc, group=self.group)
-            return bucketed, order, cc.tolist(), recv.tolist()
-        recv = torch.empty_like(counts)
-        dist.all_to_all_single(recv, counts, group=self.group)
-        return bucketed, order, counts.tolist(), recv.tolist()
+        mine = counts.cpu() if _staged(counts, self.group) else counts
+        rows = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(rows, mine, group=self.group)
+        matrix = torch.stack(rows).cpu()  # matrix[q][p] = rows rank q sends to rank p
+        return (bucketed, order, matrix[self.rank].tolist(), matrix[:, self.rank].tolist(), int(matrix.max().item()))
 
     def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0):
-        bucketed, order, send, recv = self._route(src)
-        ids_in = _a2a(bucketed, send, recv, self.group)
-        rows_in = _a2a(order, send, recv, self.group)  # original row index = random stream
+        bucketed, order, send, recv, most = self._route(src)
+        ids_in = _a2a(bucketed, send, recv, self.group, most)
+        rows_in = _a2a(order, send, recv, self.group, most)  # original row index = random stream
         nbr, eid = self.ops.sample(self.graph, sampler, ids_in, rows_in, k, seed, call_counter,
                                    padding_mode, default_neighbor_id)
-        nbr = _a2a(nbr, recv, send, self.group)
-        eid = _a2a(eid, recv, send, self.group)
+        nbr = _a2a(nbr, recv, send, self.group, most)
+        eid = _a2a(eid, recv, send, self.group, most)
         return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
 
     def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, mode="halo", dedup=False):
@@ -135,10 +171,10 @@ class ShardedStore:
         if dedup:
             # every distinct id crosses the links once; the reduce reads the halo table through `inverse`
             node_ids, inverse = torch.unique(node_ids, return_inverse=True)
-        bucketed, order, send, recv = self._route(node_ids)
-        ids_in = _a2a(bucketed, send, recv, self.group)
+        bucketed, order, send, recv, most = self._route(node_ids)
+        ids_in = _a2a(bucketed, send, recv, self.group, most)
         rows = self.ops.lookup(self.feats, ids_in, default_attr)
-        rows = _a2a(rows, recv, send, self.group)  # halo rows, in bucketed order
+        rows = _a2a(rows, recv, send, self.group, most)  # halo rows, in bucketed order
         # pos[i] = where (distinct) element i sits in `rows` (inverse of `order`)
         m = node_ids.shape[0]
         pos = self.ops.stitch(torch.arange(m, dtype=torch.int64, device=node_ids.device).view(m, 1),
@@ -150,7 +186,7 @@ class ShardedStore:
     def _aggregate_partial(self, op, node_ids, segment_ids, num_segments, default_attr):
         """Design R: owners reduce, the requester folds the partials (AggregatingRequest::
         Partition / AggregatingResponse::Stitch, aggregating_request.cc:117-213)."""
-        bucketed, order, send, recv = self._route(node_ids)
+        bucketed, order, send, recv, most = self._route(node_ids)
         # every owner needs each requester's segment count (requests differ per rank)
         mine = torch.tensor([int(num_segments)], dtype=torch.int64)
         if dist.get_backend(self.group) != "gloo":
@@ -158,8 +194,8 @@ class ShardedStore:
         sgs = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(sgs, mine, group=self.group)
         sg_of = [int(x.item()) for x in sgs]
-        ids_in = _a2a(bucketed, send, recv, self.group)
-        seg_in = _a2a(segment_ids[order].contiguous(), send, recv, self.group)  # stays non-decreasing per requester
+        ids_in = _a2a(bucketed, send, recv, self.group, most)
+        seg_in = _a2a(segment_ids[order].contiguous(), send, recv, self.group, most)  # stays non-decreasing per requester
         embs, cnts = [], []
         at = 0
         for q in range(self.world):
@@ -169,8 +205,8 @@ class ShardedStore:
             cnts.append(c)
             at += recv[q]
         back = [int(num_segments)] * self.world
-        parts = _a2a(torch.cat(embs), sg_of, back, self.group)   # [P * Sg, D], shard-major
-        pcnt = _a2a(torch.cat(cnts), sg_of, back, self.group)    # [P * Sg]
+        parts = _a2a(torch.cat(embs), sg_of, back, self.group, max(sg_of))   # [P * Sg, D], shard-major
+        pcnt = _a2a(torch.cat(cnts), sg_of, back, self.group, max(sg_of))    # [P * Sg]
         return self.ops.aggregate_stitch(op, parts.view(self.world, num_segments, -1),
                                          pcnt.view(self.world, num_segments), default_attr)
 
@@ -207,6 +243,15 @@ def replicate_features(x_shard, num_nodes, group=None):
         gathered = torch.stack(parts).to(x_shard.device)
     else:
         gathered = x_shard.new_empty((world, per, x_shard.shape[1]))
-        dist.all_gather_into_tensor(gathered.view(world * per, -1), pad.contiguous(), group=group)
+        pad = pad.contiguous()
+        blk = max(1, MAX_MESSAGE_BYTES // (4 * int(x_shard.shape[1])))  # rows per rank per call
+        if per <= blk:
+            dist.all_gather_into_tensor(gathered.view(world * per, -1), pad, group=group)
+        else:
+            for lo in range(0, per, blk):
+                hi = min(per, lo + blk)
+                piece = x_shard.new_empty((world, hi - lo, x_shard.shape[1]))
+                dist.all_gather_into_tensor(piece.view(world * (hi - lo), -1), pad[lo:hi], group=group)
+                gathered[:, lo:hi] = piece
     # row v lives at gathered[v % world][v // world]
     return gathered.permute(1, 0, 2).reshape(world * per, -1)[:num_nodes].contiguous()

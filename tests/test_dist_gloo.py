@@ -79,13 +79,15 @@ def _world_graph():
     return rp, col, eid, w, X
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, message_limit=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import dist as gdist
         from oracle_bindings import Oracle
+        if message_limit:  # force the multi-round exchange (peer messages cut into pieces)
+            gdist.MAX_MESSAGE_BYTES = message_limit
         ops = OracleOps()
         orc = Oracle()
         rp, col, eid, w, X = _world_graph()
@@ -158,12 +160,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_store_equals_single_shard(world):
+@pytest.mark.parametrize("world,message_limit", [(2, None), (3, None), (2, 200)])
+def test_sharded_store_equals_single_shard(world, message_limit):
+    """message_limit = 200 bytes: every exchange runs in several rounds (dist.MAX_MESSAGE_BYTES keeps
+    peer messages under RCCL's 1 GiB all-to-all limit on the GPU; here it is shrunk to exercise that path)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, message_limit)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
