@@ -71,7 +71,7 @@ def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
     if not have_ref():
         return cpu_baseline_port(wl, src, dst, weight, args, seed_pool)
     t_all = time.time()
-    ref = RefLib(storage_mode=2, padding_mode=1)
+    ref = RefLib(storage_mode=args.cpu_storage_mode, padding_mode=1)
     # edges in insertion (= edge id) order, as the reference loader would add them
     src_h = src.cpu().numpy()
     dst_h = dst.cpu().numpy()
@@ -138,9 +138,9 @@ def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
         "sample": ("reference C++ %s [%d,%d] + %s on host threads (one request per thread, "
                    "%d seeds/request, %d requests/thread; %.1fs sampling + %.1fs aggregation timed); "
                    "graph = first %d of %d generated edges of the same RMAT stream (build %.0fs, "
-                   "default vector-of-vectors storage); features = %d rows x %d (ids mod %d); "
+                   "StorageMode %d); features = %d rows x %d (ids mod %d); "
                    "value = 1/(1/sampling + 1/aggregation)"
-                   % (sampler, k1, k2, agg, B, reps, dts, dta, added, E, t_build, Vc, D, Vc)),
+                   % (sampler, k1, k2, agg, B, reps, dts, dta, added, E, t_build, args.cpu_storage_mode, Vc, D, Vc)),
         "wall_s": time.time() - t_all,
     }
 
@@ -311,9 +311,13 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
-    ap.add_argument("--cpu-build-budget", type=float, default=60.0, help="s of reference graph build")
+    ap.add_argument("--cpu-build-budget", type=float, default=85.0, help="s of reference graph build")
     ap.add_argument("--cpu-time-budget", type=float, default=10.0, help="s per timed CPU leg")
     ap.add_argument("--cpu-seeds-per-request", type=int, default=128)
+    ap.add_argument("--cpu-storage-mode", type=int, default=3, choices=[2, 3],
+                    help="reference StorageMode for the CPU baseline: 2 = its default (vector-of-vectors adjacency, "
+                         "per-node attribute objects), 3 = compressed (CSR + flat attributes): the faster of the "
+                         "two on this workload (5.15 M vs 4.5 M edges/s), hence the default here")
     ap.add_argument("--cpu-thread-sweep", default="",
                     help="comma separated extra thread counts for the CPU baseline (0 = nproc), e.g. '1,0'")
     args = ap.parse_args()
