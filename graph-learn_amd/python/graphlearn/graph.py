@@ -259,6 +259,28 @@ class Graph(object):
       raise ValueError("node type {} has no float attributes on the device".format(node_type))
     return glx.Features.from_handle(h)
 
+  def random_walk(self, edge_type, ids, walk_len, p=1.0, q=1.0, call_counter=0):
+    """DeepWalk-style uniform random walks (the p = q = 1 case of the reference's "RandomWalk"
+    operator, core/operator/random_walk/random_walk.cc:168-190): `walk_len` steps from every id, each
+    step = one uniform neighbour draw, the default neighbour id where a vertex has no out-edges.
+    All steps run in one glx_sample_hops call.  ids: numpy array or torch CUDA tensor
+    -> walks [len(ids), walk_len] of the same kind.  node2vec biases (p, q != 1) are not served."""
+    if p != 1.0 or q != 1.0:
+      self._off_path("node2vec-biased random walk (p, q != 1)")
+    import glx
+    import torch
+    from graphlearn import settings
+    as_numpy = not isinstance(ids, torch.Tensor)
+    dev = torch.device("cuda", settings._MIRROR.get("device_id", 0))  # pylint: disable=protected-access
+    seeds = torch.as_tensor(np.ascontiguousarray(np.array(ids).reshape(-1), dtype=np.int64)).to(dev) if as_numpy else ids
+    graph = self.device_graph(edge_type)
+    hops = glx.sample_hops([graph] * int(walk_len), "RandomSampler", seeds, [1] * int(walk_len),
+                           seed=settings._MIRROR["sampling_seed"], call_counter=call_counter,  # pylint: disable=protected-access
+                           padding_mode=settings._MIRROR["padding_mode"],  # pylint: disable=protected-access
+                           default_neighbor_id=settings._MIRROR["default_neighbor_id"])  # pylint: disable=protected-access
+    walks = torch.cat([h[0] for h in hops], dim=1)
+    return walks.cpu().numpy() if as_numpy else walks
+
   def _off_path(self, what):
     raise NotImplementedError("%s is outside the sampling/aggregation path this engine replaces" % what)
 

@@ -425,3 +425,26 @@ def test_neighbor_loader_device_batches(gl, g):
         second = [b.seeds.cpu().numpy() for b in loader]  # next epoch: another permutation
         assert sorted(np.concatenate(second).tolist()) == list(range(120))
         assert not np.array_equal(np.concatenate(second), np.concatenate(seen))
+
+
+def test_random_walk_deepwalk(gl, g):
+    """GSL random_walk(edge_type, walk_len, 1.0, 1.0) (python/gsl/tests/test_gsl_random_walk.py): every
+    step follows an edge of the type; a vertex without out-edges yields the default id."""
+    import torch
+    seeds = np.array([102, 107, 108, 111])
+    walks = g.random_walk(EDGE3, seeds, 10)
+    assert walks.shape == (4, 10)
+    prev = seeds
+    for step in range(10):
+        cur = walks[:, step]
+        for a, b in zip(prev.tolist(), cur.tolist()):
+            if a == DEFAULT_ID:
+                assert b == DEFAULT_ID
+                continue
+            out = set(fx.fixed_dst_ids(a, RANGE2)) | {s for s in range(*RANGE2) if a in fx.fixed_dst_ids(s, RANGE2)}
+            assert (b in out) if out else (b == DEFAULT_ID), (a, b)
+        prev = cur
+    dev = g.random_walk(EDGE3, torch.from_numpy(seeds).cuda(), 10)
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), walks)  # same pinned stream
+    with pytest.raises(NotImplementedError):
+        g.random_walk(EDGE3, seeds, 5, p=0.5)
