@@ -109,6 +109,8 @@ public:
   // cached like AliasMethodFactory::LookupOrCreate does; `strict` also prepares the
   // per-row sorted neighbour lists the exclusion test searches.
   Status Negative(bool by_in_degree, bool strict, const glx_negative** out);
+  // In-degree alias tables for InDegreeSampler, built on first use.
+  Status EnsureInDegree();
 
   // Per-edge properties by edge id, host resident (they are not read by the samplers):
   // EdgeStorage::GetWeight/GetLabel/GetTimestamp/GetAttribute
@@ -137,6 +139,7 @@ private:
   glx_negative* neg_uniform_;
   glx_negative* neg_in_degree_;
   bool neg_strict_ready_;
+  bool in_degree_ready_;
   std::mutex mtx_;
 };
 

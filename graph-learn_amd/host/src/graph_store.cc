@@ -17,7 +17,8 @@ void UpdateNodesRequest::Append(const io::NodeValue* value) { values_.push_back(
 
 // ------------------------------------------------------------------ Graph --
 Graph::Graph(const std::string& type)
-    : type_(type), dev_(nullptr), neg_uniform_(nullptr), neg_in_degree_(nullptr), neg_strict_ready_(false) {}
+    : type_(type), dev_(nullptr), neg_uniform_(nullptr), neg_in_degree_(nullptr), neg_strict_ready_(false),
+      in_degree_ready_(false) {}
 
 Graph::~Graph() {
   glx_negative_destroy(neg_uniform_);
@@ -111,11 +112,20 @@ Status Graph::Build(const IndexOption& option) {
   int rc = glx_graph_build(GLOBAL_FLAG(DeviceId), (int64_t)src_.size(), src_.data(), dst_.data(),
                            weighted ? weight_.data() : nullptr, nullptr,
                            (weighted && option.name == "sort") ? 1 : 0, GLX_PTR_HOST, nullptr, &dev_);
-  if (rc != GLX_OK) return error::FromGlx(rc);
-  // The reference keeps in/out-degree statistics by default (StorageMode bit 1,
-  // config.cc:93, topo_statics.cc); InDegreeSampler needs them as alias tables.
-  rc = glx_graph_enable_in_degree(dev_, nullptr);
   return error::FromGlx(rc);
+}
+
+Status Graph::EnsureInDegree() {
+  // The reference keeps in/out-degree statistics by default (StorageMode bit 1,
+  // config.cc:93, topo_statics.cc); InDegreeSampler needs them as per-row alias tables,
+  // built on the device the first time that sampler is used on this edge type.
+  std::lock_guard<std::mutex> g(mtx_);
+  if (in_degree_ready_) return Status::OK();
+  if (!dev_) return error::InvalidArgument("edge type '" + type_ + "' is not built on the device");
+  int rc = glx_graph_enable_in_degree(dev_, nullptr);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  in_degree_ready_ = true;
+  return Status::OK();
 }
 
 // ------------------------------------------------------------------ Noder --

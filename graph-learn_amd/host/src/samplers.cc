@@ -35,7 +35,12 @@ protected:
       return error::Unimplemented("sampling filters are not supported on the device path");
     }
     if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
-    const glx_graph* g = graph_store_->GetGraph(req->Type())->Device();
+    Graph* graph = graph_store_->GetGraph(req->Type());
+    const glx_graph* g = graph->Device();
+    if (g && SamplerId() == GLX_SAMPLER_IN_DEGREE) {
+      Status s = graph->EnsureInDegree();
+      if (!s.ok()) return s;
+    }
     res->ResizeDense();
     if (!g) {
       // An edge type nobody loaded behaves like a storage without any row:
