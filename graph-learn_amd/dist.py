@@ -73,7 +73,7 @@ def _staged(x, group):
 
 # RCCL (2.26, ROCm 7) delivers only the first half of an all-to-all message larger than
 # 1 GiB (measured with world_size 1: bytes beyond message_size / 2 are left untouched;
-# scripts/debug_rccl_big.py).  No peer message is allowed to exceed this many bytes; larger
+# scripts/probe_rccl_large_messages.py).  No peer message is allowed to exceed this many bytes; larger
 # exchanges are cut into rounds.  all_gather is chunked the same way to stay clear of the limit.
 MAX_MESSAGE_BYTES = 512 << 20
 
