@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
       blk = glx_philox_block((uint32_t)q, rr, a.seed, a.cc);
     }
   }
+  GlxAdj got[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int32_t j = 2 * q + h;
@@ -92,8 +93,23 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
     } else if (pick >= 0) {
       r = a.adj[start + pick];
     }
-    a.nbr_out[obase + j] = r.nbr;
-    a.eid_out[obase + j] = r.eid;
+    got[h] = r;
+  }
+  // Both slots of the pair in ONE 16-byte store per output array whenever the pair is
+  // complete and 16-byte aligned (always for even k): a wave then writes whole lines; two
+  // 8-byte stores with a 16-byte lane stride showed up as 1.8x WRITE_SIZE in the PMC pass.
+  int64_t* pn = a.nbr_out + obase + 2 * q;
+  int64_t* pe = a.eid_out + obase + 2 * q;
+  if (2 * q + 1 < a.k && ((reinterpret_cast<uintptr_t>(pn) | reinterpret_cast<uintptr_t>(pe)) & 15) == 0) {
+    *reinterpret_cast<longlong2*>(pn) = longlong2{got[0].nbr, got[1].nbr};
+    *reinterpret_cast<longlong2*>(pe) = longlong2{got[0].eid, got[1].eid};
+  } else {
+    pn[0] = got[0].nbr;
+    pe[0] = got[0].eid;
+    if (2 * q + 1 < a.k) {
+      pn[1] = got[1].nbr;
+      pe[1] = got[1].eid;
+    }
   }
 }
 
