@@ -165,5 +165,12 @@ def test_sharded_store_over_rccl_world1(world):
         emb, cnt = store.aggregate("MaxAggregator", n.view(-1), seg, 4000, mode="partial")
         remb, rcnt = feats.aggregate("MaxAggregator", n.view(-1), seg, 4000)
         assert torch.equal(cnt, rcnt) and torch.equal(emb.view(torch.int32), remb.view(torch.int32))
+        # Regression for the RCCL large-message limit (profiles/r01/rccl_large_message_probe.txt): a
+        # 1.25 GiB peer message must arrive whole -- dist._a2a cuts it into <= 512 MiB rounds.
+        rows = (5 << 28) // (64 * 4)
+        big = torch.arange(rows * 64, device=dev, dtype=torch.int32).view(rows, 64)
+        got = gdist._a2a(big, [rows], [rows], None, rows)
+        assert torch.equal(got, big)
+        del big, got
     finally:
         dist.destroy_process_group()
