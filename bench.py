@@ -191,33 +191,49 @@ def cpu_baseline_port(wl, src, dst, weight, args, seed_pool=None):
             "wall_s": time.time() - t_all}
 
 
-def bench_c5(args, dev, result_out):
-    """BASELINE configs[4] shape on one GPU: heterogeneous user-item-shop graph, three
+def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
+    """BASELINE configs[4] shape: heterogeneous user-item-shop graph, three
     weighted edge types (u-i 300M, i-s 100M, u-s 100M edges over 40M / 9M / 1M nodes),
     per-edge-type TopkSampler (k = 10, 10, 5) + type-wise SumAggregator, dim=256.
     One storage handle per type replaces the reference's HeterDispatcher
-    (core/graph/heter_dispatcher.h:44-56)."""
+    (core/graph/heter_dispatcher.h:44-56).  With N > 1 ranks every edge type is edge-cut by
+    llabs(src) % N (one ShardedStore per type: RCCL all-to-all per hop) and the two feature
+    tables (9.2 GB + 1 GB) are replicated."""
     D, B0 = 256, args.batch
-    n_user, n_item, n_shop = 40_000_000, 9_000_000, 1_000_000
-    spec = {"u-i": (n_user, n_item, 300_000_000, 10), "i-s": (n_item, n_shop, 100_000_000, 10),
-            "u-s": (n_user, n_shop, 100_000_000, 5)}
+    sc = max(1, args.c5_scale)
+    n_user, n_item, n_shop = 40_000_000 // sc, 9_000_000 // sc, 1_000_000 // sc
+    spec = {"u-i": (n_user, n_item, 300_000_000 // sc, 10), "i-s": (n_item, n_shop, 100_000_000 // sc, 10),
+            "u-s": (n_user, n_shop, 100_000_000 // sc, 5)}
     t0 = time.time()
-    graphs = {}
+    graphs, whole = {}, {}
     seed_pool = None
+    if sharded:
+        import dist as gdist
     for i, (t, (ns, nd, ne, k)) in enumerate(spec.items()):
         src, dst, w = synth.rmat_edges_torch(1 << 26, ne, 20 + i, dev, weighted=True)
         src %= ns
-        graphs[t] = glx.Graph.from_edges(src, dst % nd, w, device=dev.index)
+        dst %= nd
         if t == "u-i":
             seed_pool = torch.unique(src)  # users that have at least one u-i edge
+        if sharded:
+            if args.verify:
+                whole[t] = glx.Graph.from_edges(src, dst, w, device=dev.index)
+            own = (src % world) == rank
+            shard = glx.Graph.from_edges(src[own].contiguous(), dst[own].contiguous(), w[own].contiguous(),
+                                         edge_ids=torch.nonzero(own).view(-1), device=dev.index)
+            graphs[t] = gdist.ShardedStore(gdist.DeviceOps(), shard)
+            del own
+        else:
+            graphs[t] = glx.Graph.from_edges(src, dst, w, device=dev.index)
         del src, dst, w
     x_item = glx.Features(synth.features_torch(n_item, D, 31, dev), device=dev.index)
     x_shop = glx.Features(synth.features_torch(n_shop, D, 32, dev), device=dev.index)
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
-    log("c5 stores built in %.1fs: %s" % (time.time() - t0, {t: g.num_edges for t, g in graphs.items()}))
+    log("c5 stores built in %.1fs: %s" % (time.time() - t0, {t: (g.graph if sharded else g).num_edges
+                                                               for t, g in graphs.items()}))
     gen = torch.Generator(device=dev)
-    gen.manual_seed(7)
+    gen.manual_seed(7 + rank)
     n_steps = args.warmup + args.steps
     seeds = seed_pool[torch.randint(0, seed_pool.shape[0], (n_steps, B0), generator=gen, device=dev)]
     k1, k2, k3 = 10, 10, 5
@@ -232,24 +248,54 @@ def bench_c5(args, dev, result_out):
     o1 = (torch.empty((B0, D), **f32), torch.empty(B0, dtype=torch.int32, device=dev))
     o3 = (torch.empty((B0, D), **f32), torch.empty(B0, dtype=torch.int32, device=dev))
 
-    def step(i):
-        graphs["u-i"].sample("TopkSampler", seeds[i], k1, out=(s1, e1))
-        graphs["i-s"].sample("TopkSampler", s1.view(-1), k2, out=(s2, e2))
-        graphs["u-s"].sample("TopkSampler", seeds[i], k3, out=(s3, e3))
-        x_shop.aggregate("SumAggregator", s2.view(-1), g2, B0 * k1, out=o2)
-        x_item.aggregate("SumAggregator", s1.view(-1), g1, B0, out=o1)
-        x_shop.aggregate("SumAggregator", s3.view(-1), g3, B0, out=o3)
+    def step(i, check=False):
+        if sharded:
+            a1, b1 = graphs["u-i"].sample("TopkSampler", seeds[i], k1)
+            a2, b2 = graphs["i-s"].sample("TopkSampler", a1.view(-1), k2)
+            a3, b3 = graphs["u-s"].sample("TopkSampler", seeds[i], k3)
+        else:
+            graphs["u-i"].sample("TopkSampler", seeds[i], k1, out=(s1, e1))
+            graphs["i-s"].sample("TopkSampler", s1.view(-1), k2, out=(s2, e2))
+            graphs["u-s"].sample("TopkSampler", seeds[i], k3, out=(s3, e3))
+            a1, a2, a3 = s1, s2, s3
+        x_shop.aggregate("SumAggregator", a2.view(-1), g2, B0 * k1, out=o2)
+        x_item.aggregate("SumAggregator", a1.view(-1), g1, B0, out=o1)
+        x_shop.aggregate("SumAggregator", a3.view(-1), g3, B0, out=o3)
+        if check:  # the partitioned result against unpartitioned copies of the three graphs
+            w1, we1 = whole["u-i"].sample("TopkSampler", seeds[i], k1)
+            w2, we2 = whole["i-s"].sample("TopkSampler", w1.view(-1), k2)
+            w3, we3 = whole["u-s"].sample("TopkSampler", seeds[i], k3)
+            return bool(torch.equal(a1, w1) and torch.equal(b1, we1) and torch.equal(a2, w2) and torch.equal(b2, we2)
+                        and torch.equal(a3, w3) and torch.equal(b3, we3))
+        return None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
+    barrier()
     glx.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         step(i)
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     glx.profile_enable(False)
+    verified = None
+    if sharded:
+        t = torch.tensor([elapsed], device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if args.verify:
+            flag = torch.tensor([1 if step(n_steps - 1, check=True) else 0], dtype=torch.int64,
+                                device=(dev if args.backend == "nccl" else "cpu"))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified = bool(flag.item())
+            log("verify: sharded == unpartitioned on every rank: %s" % verified)
     t_agg = glx.profile_collect(glx.KERNEL_AGGREGATE)
     t_smp = glx.profile_collect(glx.KERNEL_SAMPLE)
     slots = B0 * (k1 + k1 * k2 + k3)
@@ -259,12 +305,14 @@ def bench_c5(args, dev, result_out):
     achieved = bytes2 / (ms2 * 1e-3) / 1e9
     res = {
         "metric": "sampled-edges/sec + aggregated-vertices/sec (per-edge-type Topk + type-wise Sum per step)",
-        "value": slots * args.steps / elapsed, "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
+        "value": world * slots * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "c5: " + bench_c5.__doc__.split("\n")[0], "seeds_per_step_per_gpu": B0,
                    "edge_types": {t: {"edges": v[2], "k": v[3]} for t, v in spec.items()}, "dim": D,
-                   "parallelism": "1 GPU"},
+                   "parallelism": ("1 GPU" if not sharded else
+                                   "3 edge types edge-cut llabs(src)%%%d + RCCL all-to-all per hop; item / shop "
+                                   "features replicated" % world)},
         "phases": {"sampling_kernels_ms_per_step": float(np.sum(t_smp)) / args.steps,
                    "aggregation_kernels_ms_per_step": float(np.sum(t_agg)) / args.steps},
         "roofline": {"kernel": "glx_aggregate_kernel (i-s hop SumAggregator, dim=256)", "bound": "hbm",
@@ -272,8 +320,15 @@ def bench_c5(args, dev, result_out):
                      "traffic": None, "avg_launch_ms": ms2, "algorithmic_bytes_per_launch": bytes2},
         "cpu_baseline": None,
     }
-    result_out.write(json.dumps(res) + "\n")
-    result_out.flush()
+    if verified is not None:
+        res["verified_sharded_equals_unpartitioned"] = verified
+    if rank == 0:
+        result_out.write(json.dumps(res) + "\n")
+        result_out.flush()
+    if sharded:
+        dist.destroy_process_group()
+    if verified is False:
+        sys.exit(3)
 
 
 def main():
@@ -310,6 +365,7 @@ def main():
                     help="s; if the ablation legs have not finished by then the main result is printed without them")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
+    ap.add_argument("--c5-scale", type=int, default=1, help="divide the c5 node / edge counts (test rig)")
     ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
     ap.add_argument("--cpu-build-budget", type=float, default=85.0, help="s of reference graph build")
     ap.add_argument("--cpu-time-budget", type=float, default=10.0, help="s per timed CPU leg")
@@ -345,8 +401,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if args.workload == "c5":
-        assert not sharded, "c5 is a single-GPU workload in this round"
-        bench_c5(args, dev, result_out)
+        bench_c5(args, dev, result_out, world=world, rank=rank, sharded=sharded)
         return
     wl = WORKLOADS[args.workload]
     V, E, sampler, (k1, k2), agg, D, gseed, desc = wl

@@ -50,3 +50,18 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
             assert ok is True and leg["value"] > 0, legs
     else:
         assert "ablations" not in res
+
+
+def test_bench_c5_hetero_two_ranks_on_one_gpu():
+    """BASELINE configs[4] (3 edge types, per-type Topk + Sum) through the N > 1 path: one ShardedStore
+    per edge type, verified against unpartitioned copies of the three graphs on every rank."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--backend", "gloo", "--share-device", "--workload", "c5", "--c5-scale", "500",
+           "--batch", "1024", "--steps", "2", "--warmup", "1", "--verify", "--cpu-baseline", "off"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["verified_sharded_equals_unpartitioned"] is True and res["value"] > 0
