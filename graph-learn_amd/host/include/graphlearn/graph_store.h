@@ -58,6 +58,25 @@ struct NodeValue {  // element_value.h:118-132; attrs = the float attributes
   std::vector<std::string> s_attrs;
 };
 
+// A batch of records in columnar form (what the file loader produces per chunk); the
+// attribute columns hold i_num / f_num / s_num values per record, row-major.
+struct EdgeColumns {
+  std::vector<int64_t> src, dst, timestamp;
+  std::vector<float> weight;
+  std::vector<int32_t> label;
+  std::vector<int64_t> i_attrs;
+  std::vector<float> f_attrs;
+  std::vector<std::string> s_attrs;
+};
+struct NodeColumns {
+  std::vector<int64_t> id, timestamp;
+  std::vector<float> weight;
+  std::vector<int32_t> label;
+  std::vector<int64_t> i_attrs;
+  std::vector<float> f_attrs;
+  std::vector<std::string> s_attrs;
+};
+
 }  // namespace io
 
 struct IndexOption {  // include/index_option.h
@@ -98,6 +117,8 @@ public:
   void SetSideInfo(const io::SideInfo* info);
   const io::SideInfo* GetSideInfo() const { return &info_; }
   void Add(const io::EdgeValue* value);          // edge id = insertion index
+  // Bulk form of Add for a parsed chunk (consumes the strings); same edge-id rule.
+  Status AppendColumns(const io::SideInfo& info, io::EdgeColumns* columns);
   Status Build(const IndexOption& option);       // sort (if option.name=="sort") + upload
   int64_t GetEdgeCount() const { return (int64_t)src_.size(); }
   // All edges in edge-id order (EdgeStorage::GetSrcIds/GetDstIds, memory_edge_storage.cc:127-133).
@@ -152,6 +173,7 @@ public:
   void SetSideInfo(const io::SideInfo* info);
   const io::SideInfo* GetSideInfo() const { return &info_; }
   void Add(const io::NodeValue* value);          // duplicate ids are ignored (node_storage.h:41)
+  Status AppendColumns(const io::SideInfo& info, io::NodeColumns* columns);
   Status Build(const IndexOption& option);
   const glx_features* Device() const { return dev_; }
   int64_t GetNodeCount() const { return (int64_t)ids_.size(); }

@@ -1,6 +1,8 @@
 // GraphStore / Graph / Noder: host staging -> CSR -> device (see graph_store.h).
 #include "graphlearn/graph_store.h"
 
+#include <iterator>
+
 #include "glx.h"
 #include "graphlearn/config.h"
 
@@ -91,6 +93,26 @@ const std::string* Graph::GetEdgeStringAttrs(int64_t edge_id) const {
   return info_.s_num > 0 && GLX_EDGE_IN_RANGE(s_attrs_, info_.s_num) ? s_attrs_.data() + edge_id * info_.s_num : nullptr;
 }
 #undef GLX_EDGE_IN_RANGE
+
+Status Graph::AppendColumns(const io::SideInfo& info, io::EdgeColumns* c) {
+  std::lock_guard<std::mutex> g(mtx_);
+  SetSideInfo(&info);
+  const size_t n = c->src.size();
+  if (c->dst.size() != n || (info_.IsWeighted() && c->weight.size() != n) || (info_.IsLabeled() && c->label.size() != n) ||
+      (info_.IsTimestamped() && c->timestamp.size() != n) || c->i_attrs.size() != n * (size_t)info_.i_num ||
+      c->f_attrs.size() != n * (size_t)info_.f_num || c->s_attrs.size() != n * (size_t)info_.s_num) {
+    return error::InvalidArgument("edge batch does not match the side info of type '" + type_ + "'");
+  }
+  src_.insert(src_.end(), c->src.begin(), c->src.end());
+  dst_.insert(dst_.end(), c->dst.begin(), c->dst.end());
+  if (info_.IsWeighted()) weight_.insert(weight_.end(), c->weight.begin(), c->weight.end());
+  if (info_.IsLabeled()) label_.insert(label_.end(), c->label.begin(), c->label.end());
+  if (info_.IsTimestamped()) timestamp_.insert(timestamp_.end(), c->timestamp.begin(), c->timestamp.end());
+  i_attrs_.insert(i_attrs_.end(), c->i_attrs.begin(), c->i_attrs.end());
+  f_attrs_.insert(f_attrs_.end(), c->f_attrs.begin(), c->f_attrs.end());
+  s_attrs_.insert(s_attrs_.end(), std::make_move_iterator(c->s_attrs.begin()), std::make_move_iterator(c->s_attrs.end()));
+  return Status::OK();
+}
 
 Status Graph::UpdateEdges(const UpdateEdgesRequest* req, UpdateEdgesResponse*) {
   std::lock_guard<std::mutex> g(mtx_);
@@ -189,6 +211,31 @@ int64_t Noder::GetTimestamp(int64_t node_id) const {
   if (!info_.IsTimestamped()) return -1;
   const int32_t r = RowOf(node_id);
   return r < 0 ? GLOBAL_FLAG(DefaultTimestamp) : timestamps_[r];
+}
+
+Status Noder::AppendColumns(const io::SideInfo& info, io::NodeColumns* c) {
+  std::lock_guard<std::mutex> g(mtx_);
+  SetSideInfo(&info);
+  const size_t n = c->id.size();
+  if ((info_.IsWeighted() && c->weight.size() != n) || (info_.IsLabeled() && c->label.size() != n) ||
+      (info_.IsTimestamped() && c->timestamp.size() != n) || c->i_attrs.size() != n * (size_t)info_.i_num ||
+      c->f_attrs.size() != n * (size_t)info_.f_num || c->s_attrs.size() != n * (size_t)info_.s_num) {
+    return error::InvalidArgument("node batch does not match the side info of type '" + type_ + "'");
+  }
+  index_.reserve(index_.size() + n);
+  ids_.reserve(ids_.size() + n);
+  feats_.reserve(feats_.size() + n * (size_t)info_.f_num);
+  for (size_t r = 0; r < n; ++r) {
+    if (!index_.emplace(c->id[r], (int32_t)ids_.size()).second) continue;  // duplicate id: ignore
+    ids_.push_back(c->id[r]);
+    if (info_.IsWeighted()) weights_.push_back(c->weight[r]);
+    if (info_.IsLabeled()) labels_.push_back(c->label[r]);
+    if (info_.IsTimestamped()) timestamps_.push_back(c->timestamp[r]);
+    feats_.insert(feats_.end(), c->f_attrs.begin() + r * info_.f_num, c->f_attrs.begin() + (r + 1) * info_.f_num);
+    i_attrs_.insert(i_attrs_.end(), c->i_attrs.begin() + r * info_.i_num, c->i_attrs.begin() + (r + 1) * info_.i_num);
+    for (int32_t j = 0; j < info_.s_num; ++j) s_attrs_.push_back(std::move(c->s_attrs[r * info_.s_num + j]));
+  }
+  return Status::OK();
 }
 
 Status Noder::UpdateNodes(const UpdateNodesRequest* req, UpdateNodesResponse*) {

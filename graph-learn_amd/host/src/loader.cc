@@ -77,6 +77,72 @@ bool ToFloat(const char* s, float* v) {
   return true;
 }
 
+// Fast paths that return exactly what strtoll / strtof return, with the general routine as
+// the fallback for everything else (blanks, exponents, long mantissas, overflow ...).
+//  * integers: [+-]digits, at most 18 digits.
+//  * floats: [+-]digits[.digits] with at most 15 significant digits.  The mantissa (an exact
+//    integer below 2^53) divided by an exact power of ten (<= 10^22) is ONE correctly rounded
+//    double operation; narrowing that double to float equals strtof's direct rounding unless
+//    the double sits exactly on a float rounding midpoint (the 29 dropped mantissa bits equal
+//    0x10000000) -- those strings, and results outside the normal float range, take the
+//    general routine.
+inline bool FastInt64(const char* s, size_t len, int64_t* v) {
+  if (len == 0 || len > 19) return false;
+  size_t i = 0;
+  bool neg = false;
+  if (s[0] == '-' || s[0] == '+') {
+    neg = s[0] == '-';
+    i = 1;
+  }
+  if (i == len || len - i > 18) return false;
+  int64_t r = 0;
+  for (; i < len; ++i) {
+    const unsigned d = (unsigned)(s[i] - '0');
+    if (d > 9) return false;
+    r = r * 10 + (int64_t)d;
+  }
+  *v = neg ? -r : r;
+  return true;
+}
+
+inline bool FastFloat(const char* s, size_t len, float* v) {
+  static const double kPow10[] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  size_t i = 0;
+  bool neg = false;
+  if (len > 0 && (s[0] == '-' || s[0] == '+')) {
+    neg = s[0] == '-';
+    i = 1;
+  }
+  uint64_t m = 0;
+  int digits = 0, frac = 0;
+  bool seen_dot = false, any = false;
+  for (; i < len; ++i) {
+    const char c = s[i];
+    if (c == '.') {
+      if (seen_dot) return false;
+      seen_dot = true;
+      continue;
+    }
+    const unsigned d = (unsigned)(c - '0');
+    if (d > 9) return false;
+    any = true;
+    if (m != 0 || d != 0) ++digits;  // significant digits
+    if (digits > 15) return false;
+    m = m * 10 + d;
+    if (seen_dot) ++frac;
+  }
+  if (!any || frac > 22) return false;
+  double d = (double)m / kPow10[frac];
+  if (m != 0 && !(d > 1e-30 && d < 1e30)) return false;
+  uint64_t bits;
+  std::memcpy(&bits, &d, 8);
+  if ((bits & 0x1FFFFFFFull) == 0x10000000ull) return false;  // on a float midpoint: let strtof decide
+  const float f = (float)d;
+  *v = neg ? -f : f;
+  return true;
+}
+
 DataType ToDataType(const std::string& t) {  // common/io/value.cc:21-36
   if (t == "int" || t == "int32") return kInt32;
   if (t == "long" || t == "int64") return kInt64;
@@ -168,8 +234,11 @@ void SplitTabs(char* begin, char* end, Fields* f) {
   }
 }
 
-template <class Value, class ParseOne>
-Status ParseChunks(File* f, int threads, const ParseOne& parse_one, std::vector<std::vector<Value>>* out) {
+// Cuts the records into line-aligned pieces, one per thread; parse_one(begin, end, &piece)
+// appends one record to its piece (columns) or reports why not.  Returning OUT_OF_RANGE
+// means "skip this record".
+template <class Piece, class ParseOne>
+Status ParseChunks(File* f, int threads, const ParseOne& parse_one, std::vector<Piece>* out) {
   char* base = &f->data[0];
   const size_t size = f->data.size();
   std::vector<size_t> cut;
@@ -181,11 +250,12 @@ Status ParseChunks(File* f, int threads, const ParseOne& parse_one, std::vector<
   }
   cut.push_back(size);
   const int parts = (int)cut.size() - 1;
-  out->assign(parts, {});
+  out->assign(parts, Piece());
   std::vector<Status> st(parts);
   auto work = [&](int part) {
     char* p = base + cut[part];
     char* stop = base + cut[part + 1];
+    Piece* piece = &(*out)[part];
     while (p < stop) {
       char* eol = static_cast<char*>(std::memchr(p, '\n', (size_t)(stop - p)));
       char* next = eol ? eol + 1 : stop;
@@ -193,14 +263,8 @@ Status ParseChunks(File* f, int threads, const ParseOne& parse_one, std::vector<
       if (end > p && end[-1] == '\r') --end;
       if (end > p) {
         *end = '\0';
-        Value v;
-        Status s = parse_one(p, end, &v);
-        if (s.ok()) {
-          (*out)[part].push_back(std::move(v));
-        } else if (s.code() != error::OUT_OF_RANGE) {  // OUT_OF_RANGE = "skip this record"
-          st[part] = s;
-          return;
-        }
+        const error::Code rc = parse_one(p, end, piece, &st[part]);
+        if (rc != error::OK && rc != error::OUT_OF_RANGE) return;  // st[part] holds the reason
       }
       p = next;
     }
@@ -228,50 +292,93 @@ int LoaderThreads(size_t bytes) {
 
 Status ParseAttribute(const char* data, size_t len, const AttributeInfo& info, std::vector<int64_t>* ints,
                       std::vector<float>* floats, std::vector<std::string>* strings) {
-  std::vector<std::string> tok;
+  // tokens in place: [tb[i], te[i]) -- the delimiter is a SET of characters, empty tokens count
+  const size_t want = info.types.size();
+  const char* tb[64];
+  const char* te[64];
+  std::vector<const char*> big_b, big_e;
+  const char** b = tb;
+  const char** e = te;
+  if (want > 64) {
+    big_b.resize(want);
+    big_e.resize(want);
+    b = big_b.data();
+    e = big_e.data();
+  }
+  size_t n = 0;
   if (len > 0) {
+    const bool one = info.delimiter.size() == 1;
+    const char d0 = one ? info.delimiter[0] : 0;
     size_t start = 0;
     for (size_t i = 0; i <= len; ++i) {
-      if (i == len || info.delimiter.find(data[i]) != std::string::npos) {
-        tok.emplace_back(data + start, i - start);
+      if (i == len || (one ? data[i] == d0 : info.delimiter.find(data[i]) != std::string::npos)) {
+        if (n < want) {
+          b[n] = data + start;
+          e[n] = data + i;
+        }
+        ++n;
         start = i + 1;
       }
     }
   }
-  if (tok.size() != info.types.size()) return error::InvalidArgument("Unexpected attribute count");
-  char msg[256];
-  for (size_t i = 0; i < tok.size(); ++i) {
+  if (n != want) return error::InvalidArgument("Unexpected attribute count");
+  const size_t i0 = ints->size(), f0 = floats->size(), s0 = strings->size();
+  for (size_t i = 0; i < n; ++i) {
     const DataType t = info.types[i];
+    const size_t tl = (size_t)(e[i] - b[i]);
     const char* kind = nullptr;
     if (t == kInt32 || t == kInt64) {
       int64_t v = 0;
-      if (t == kInt32 ? ToInt32(tok[i].c_str(), &v) : ToInt64(tok[i].c_str(), &v)) ints->push_back(v);
-      else kind = t == kInt32 ? "int" : "int64";
-    } else if (t == kFloat || t == kDouble) {
-      float v = 0.f;
-      if (t == kFloat) {
-        if (ToFloat(tok[i].c_str(), &v)) floats->push_back(v);
-        else kind = "float";
-      } else {
-        char* end = nullptr;
-        const double d = strtod(tok[i].c_str(), &end);
-        if (OnlyBlanksLeft(end)) floats->push_back(static_cast<float>(d));
-        else kind = "double";
+      bool ok = FastInt64(b[i], tl, &v);
+      if (ok && t == kInt32) ok = v <= INT32_MAX && v >= INT32_MIN;
+      if (!ok) {
+        const std::string z(b[i], tl);
+        ok = t == kInt32 ? ToInt32(z.c_str(), &v) : ToInt64(z.c_str(), &v);
       }
+      if (ok) ints->push_back(v);
+      else kind = t == kInt32 ? "int" : "int64";
+    } else if (t == kFloat) {
+      float v = 0.f;
+      bool ok = FastFloat(b[i], tl, &v);
+      if (!ok) {
+        const std::string z(b[i], tl);
+        ok = ToFloat(z.c_str(), &v);
+      }
+      if (ok) floats->push_back(v);
+      else kind = "float";
+    } else if (t == kDouble) {
+      const std::string z(b[i], tl);
+      char* end = nullptr;
+      const double d = strtod(z.c_str(), &end);
+      if (OnlyBlanksLeft(end)) floats->push_back(static_cast<float>(d));
+      else kind = "double";
     } else if (t == kString) {
       if (!info.hash_buckets.empty() && info.hash_buckets[i] > 0) {
-        ints->push_back((int64_t)(Hash64(tok[i].data(), tok[i].size()) % (uint64_t)info.hash_buckets[i]));
+        ints->push_back((int64_t)(Hash64(b[i], tl) % (uint64_t)info.hash_buckets[i]));
       } else {
-        strings->push_back(std::move(tok[i]));
+        strings->emplace_back(b[i], tl);
       }
     }
     if (kind) {
-      std::snprintf(msg, sizeof(msg), "The %dth attribute expect an %s, but got \"%s\".", (int)i, kind, tok[i].c_str());
+      ints->resize(i0);  // leave the outputs as they were: the record is rejected as a whole
+      floats->resize(f0);
+      strings->resize(s0);
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "The %dth attribute expect an %s, but got \"%.*s\".", (int)i, kind, (int)tl, b[i]);
       return error::InvalidArgument(msg);
     }
   }
   return Status::OK();
 }
+
+namespace {
+inline bool FieldInt64(const Fields& f, int c, int64_t* v) {
+  return FastInt64(f.ptr[c], f.len[c], v) || ToInt64(f.ptr[c], v);
+}
+inline bool FieldFloat(const Fields& f, int c, float* v) {
+  return FastFloat(f.ptr[c], f.len[c], v) || ToFloat(f.ptr[c], v);
+}
+}  // namespace
 
 Status LoadEdges(const EdgeSource& source, GraphStore* store) {
   if (source.src_id_type.empty() || source.dst_id_type.empty() || source.edge_type.empty()) {
@@ -292,38 +399,39 @@ Status LoadEdges(const EdgeSource& source, GraphStore* store) {
   info.dst_type = source.dst_id_type;
   const int columns = (int)expected.size();
   const bool skip_bad = source.attr_info.ignore_invalid;
-  auto parse_one = [&](char* begin, char* end, EdgeValue* v) -> Status {
+  const bool reversed = source.direction == kReversed;
+  auto parse_one = [&](char* begin, char* end, EdgeColumns* out, Status* why) -> error::Code {
     Fields fld;
     SplitTabs(begin, end, &fld);
+    int64_t src = 0, dst = 0, lab = 0, ts = 0;
+    float w = 0.f;
+    bool ok = fld.n == columns;
+    int c = 0;
+    if (ok) ok = FieldInt64(fld, c++, &src) && FieldInt64(fld, c++, &dst);
+    if (ok && source.IsWeighted()) ok = FieldFloat(fld, c++, &w);
+    if (ok && source.IsLabeled()) ok = FieldInt64(fld, c++, &lab);
+    if (ok && source.IsTimestamped()) ok = FieldInt64(fld, c++, &ts);
     Status bad;
-    if (fld.n != columns) {
-      bad = error::InvalidArgument("Invalid edge record in " + source.path);
-    } else {
-      int c = 0;
-      float w = 0.f;
-      int64_t lab = 0;
-      bool ok = ToInt64(fld.ptr[c++], &v->src_id) && ToInt64(fld.ptr[c++], &v->dst_id);
-      if (ok && source.IsWeighted()) ok = ToFloat(fld.ptr[c++], &w);
-      if (ok && source.IsLabeled()) ok = ToInt64(fld.ptr[c++], &lab);
-      if (ok && source.IsTimestamped()) ok = ToInt64(fld.ptr[c++], &v->timestamp);
-      v->weight = w;
-      v->label = (int32_t)lab;
-      if (!ok) bad = error::InvalidArgument("Invalid edge record in " + source.path);
-      else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &v->i_attrs, &v->f_attrs, &v->s_attrs);
+    if (!ok) bad = error::InvalidArgument("Invalid edge record in " + source.path);
+    else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
+    if (!bad.ok()) {
+      if (skip_bad) return error::OUT_OF_RANGE;  // edge_loader.cc:70-78: ignore the record, read on
+      *why = bad;
+      return bad.code();
     }
-    if (source.direction == kReversed) std::swap(v->src_id, v->dst_id);
-    if (!bad.ok() && skip_bad) return Status(error::OUT_OF_RANGE, "skipped");  // edge_loader.cc:70-78
-    return bad;
+    out->src.push_back(reversed ? dst : src);
+    out->dst.push_back(reversed ? src : dst);
+    if (source.IsWeighted()) out->weight.push_back(w);
+    if (source.IsLabeled()) out->label.push_back((int32_t)lab);
+    if (source.IsTimestamped()) out->timestamp.push_back(ts);
+    return error::OK;
   };
-  std::vector<std::vector<EdgeValue>> parts;
-  s = ParseChunks<EdgeValue>(&f, LoaderThreads(f.data.size()), parse_one, &parts);
+  std::vector<EdgeColumns> parts;
+  s = ParseChunks<EdgeColumns>(&f, LoaderThreads(f.data.size()), parse_one, &parts);
   if (!s.ok()) return s;
   Graph* graph = store->GetGraph(source.edge_type);
-  for (auto& part : parts) {
-    UpdateEdgesRequest req(&info, (int32_t)part.size());
-    for (auto& v : part) req.Append(&v);
-    UpdateEdgesResponse res;
-    s = graph->UpdateEdges(&req, &res);
+  for (EdgeColumns& part : parts) {  // file order: edge id = load order
+    s = graph->AppendColumns(info, &part);
     if (!s.ok()) return s;
   }
   return Status::OK();
@@ -344,35 +452,37 @@ Status LoadNodes(const NodeSource& source, GraphStore* store) {
   info.type = source.id_type;
   const int columns = (int)expected.size();
   const bool skip_bad = source.attr_info.ignore_invalid;
-  auto parse_one = [&](char* begin, char* end, NodeValue* v) -> Status {
+  auto parse_one = [&](char* begin, char* end, NodeColumns* out, Status* why) -> error::Code {
     Fields fld;
     SplitTabs(begin, end, &fld);
+    int64_t id = 0, lab = 0, ts = 0;
+    float w = 0.f;
+    bool ok = fld.n == columns;
+    int c = 0;
+    if (ok) ok = FieldInt64(fld, c++, &id);
+    if (ok && source.IsWeighted()) ok = FieldFloat(fld, c++, &w);
+    if (ok && source.IsLabeled()) ok = FieldInt64(fld, c++, &lab);
+    if (ok && source.IsTimestamped()) ok = FieldInt64(fld, c++, &ts);
     Status bad;
-    if (fld.n != columns) {
-      bad = error::InvalidArgument("Invalid node record in " + source.path);
-    } else {
-      int c = 0;
-      int64_t lab = 0;
-      bool ok = ToInt64(fld.ptr[c++], &v->id);
-      if (ok && source.IsWeighted()) ok = ToFloat(fld.ptr[c++], &v->weight);
-      if (ok && source.IsLabeled()) ok = ToInt64(fld.ptr[c++], &lab);
-      if (ok && source.IsTimestamped()) ok = ToInt64(fld.ptr[c++], &v->timestamp);
-      v->label = (int32_t)lab;
-      if (!ok) bad = error::InvalidArgument("Invalid node record in " + source.path);
-      else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &v->i_attrs, &v->attrs, &v->s_attrs);
+    if (!ok) bad = error::InvalidArgument("Invalid node record in " + source.path);
+    else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
+    if (!bad.ok()) {
+      if (skip_bad) return error::OUT_OF_RANGE;
+      *why = bad;
+      return bad.code();
     }
-    if (!bad.ok() && skip_bad) return Status(error::OUT_OF_RANGE, "skipped");
-    return bad;
+    out->id.push_back(id);
+    if (source.IsWeighted()) out->weight.push_back(w);
+    if (source.IsLabeled()) out->label.push_back((int32_t)lab);
+    if (source.IsTimestamped()) out->timestamp.push_back(ts);
+    return error::OK;
   };
-  std::vector<std::vector<NodeValue>> parts;
-  s = ParseChunks<NodeValue>(&f, LoaderThreads(f.data.size()), parse_one, &parts);
+  std::vector<NodeColumns> parts;
+  s = ParseChunks<NodeColumns>(&f, LoaderThreads(f.data.size()), parse_one, &parts);
   if (!s.ok()) return s;
   Noder* noder = store->GetNoder(source.id_type);
-  for (auto& part : parts) {
-    UpdateNodesRequest req(&info, (int32_t)part.size());
-    for (auto& v : part) req.Append(&v);
-    UpdateNodesResponse res;
-    s = noder->UpdateNodes(&req, &res);
+  for (NodeColumns& part : parts) {
+    s = noder->AppendColumns(info, &part);
     if (!s.ok()) return s;
   }
   return Status::OK();

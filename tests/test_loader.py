@@ -76,6 +76,27 @@ def test_loader_primitives_live_reference():
             if want[0] == 0:
                 assert list(got[1]) == list(want[1]) and [s for s in got[3]] == list(want[3]), (data, types)
                 assert np.array_equal(np.asarray(got[2], np.float32).view(np.uint32), want[2].view(np.uint32))
+        # the loader's fast number paths must be EXACTLY strtof / strtol: decimal strings of every
+        # shape (up to 17 significant digits, values near float rounding midpoints included)
+        for _ in range(6000):
+            nd = int(rng.integers(1, 18))
+            digits = "".join(str(int(x)) for x in rng.integers(0, 10, nd))
+            cut = int(rng.integers(0, nd + 1))
+            text = ("-" if rng.random() < 0.3 else "") + digits[:cut] + ("." + digits[cut:] if rng.random() < 0.8 else digits[cut:])
+            data = (text + ":" + text.replace(".", "")[:18] or "0").encode()
+            want = ref.parse_attribute(data, ":", [2, 1])
+            got = _parse(dict(data=data.hex(), delimiter=":", types=[2, 1], hash_buckets=None))
+            assert got[0] == want[0], text
+            if want[0] == 0:
+                assert list(got[1]) == list(want[1]), text
+                assert np.array_equal(np.asarray(got[2], np.float32).view(np.uint32), want[2].view(np.uint32)), text
+        for base in (16777217, 33554433, 8388609.5, 1.00000005960464477539, 0.100000001490116119384765625):
+            for text in (repr(base), "%.17g" % base, "%.9f" % base, "%.15g" % base):
+                data = text.encode()
+                want = ref.parse_attribute(data, ":", [2])
+                got = _parse(dict(data=data.hex(), delimiter=":", types=[2], hash_buckets=None))
+                assert got[0] == want[0] == 0 and np.array_equal(
+                    np.asarray(got[2], np.float32).view(np.uint32), want[2].view(np.uint32)), text
     finally:
         ref.close()
 
