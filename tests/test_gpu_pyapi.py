@@ -448,3 +448,35 @@ def test_random_walk_deepwalk(gl, g):
     assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), walks)  # same pinned stream
     with pytest.raises(NotImplementedError):
         g.random_walk(EDGE3, seeds, 5, p=0.5)
+
+
+def test_python_stack_equals_live_reference_on_the_same_records(gl, g):
+    """TSV file -> glx loader -> device build -> Python API  ==  the reference's own storages and
+    operators fed the same records (oracle/_ref): Topk rows, Full rows (post-Build row order) and
+    out-degrees are identical for every source id of the weighted edge type."""
+    from oracle_bindings import RefLib, have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    src, dst, w = [], [], []
+    for s in range(*RANGE2):
+        for d_ in fx.fixed_dst_ids(s, RANGE1):
+            src.append(s)
+            dst.append(d_)
+            w.append(np.float32(float("%f" % ((s + 0.1 * d_) / 10.0))))  # what the loader parses from the file
+    ref = RefLib(padding_mode=1, default_neighbor_id=DEFAULT_ID)
+    try:
+        ref.add_edges("edge2", np.array(src, np.int64), np.array(dst, np.int64), np.array(w, np.float32))
+        ids = np.arange(*RANGE2, dtype=np.int64)
+        with padding(gl, gl.CIRCULAR):
+            mine = g.neighbor_sampler(EDGE2, 4, strategy="topk").get(ids)
+        rn, re_ = ref.sample("edge2", "TopkSampler", ids, 4)
+        np.testing.assert_equal(mine.layer_nodes(1).ids, rn)
+        np.testing.assert_equal(mine.layer_edges(1).edge_ids, re_)
+        full = g.neighbor_sampler(EDGE2, 0, strategy="full").get(ids)
+        deg, fn, fe = ref.sample_full("edge2", ids, 0)
+        assert full.layer_nodes(1).offsets == deg.tolist()
+        np.testing.assert_equal(full.layer_nodes(1).ids, fn)
+        np.testing.assert_equal(full.layer_edges(1).edge_ids, fe)
+        np.testing.assert_equal(g.out_degrees(ids, EDGE2), deg)
+    finally:
+        ref.close()
