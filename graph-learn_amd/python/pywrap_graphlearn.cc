@@ -43,6 +43,15 @@ py::array_t<T> ViewOf(const OpResponse* res, const char* key, size_t n) {
   return py::array_t<T>({n}, {sizeof(T)}, data, owner);
 }
 
+// Requests / responses cross the boundary as base-class handles; a handle of the wrong kind is a
+// Python TypeError, not a crash.
+template <class T, class Base>
+T* As(Base* p, const char* what) {
+  T* t = dynamic_cast<T*>(p);
+  if (!t) throw py::type_error(std::string("expected a ") + what);
+  return t;
+}
+
 typedef py::array_t<int64_t, py::array::c_style | py::array::forcecast> I64Array;
 typedef py::array_t<int32_t, py::array::c_style | py::array::forcecast> I32Array;
 
@@ -191,27 +200,27 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       .def("stop", &Client::Stop)
       .def("sample_neighbor",
            [](Client& self, OpRequest* req, OpResponse* res) {
-             return self.Sampling(static_cast<SamplingRequest*>(req), static_cast<SamplingResponse*>(res));
+             return self.Sampling(As<SamplingRequest>(req, "SamplingRequest"), As<SamplingResponse>(res, "SamplingResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
       .def("agg_nodes",
            [](Client& self, OpRequest* req, OpResponse* res) {
-             return self.Aggregating(static_cast<AggregatingRequest*>(req), static_cast<AggregatingResponse*>(res));
+             return self.Aggregating(As<AggregatingRequest>(req, "AggregatingRequest"), As<AggregatingResponse>(res, "AggregatingResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
       .def("lookup_nodes",
            [](Client& self, OpRequest* req, OpResponse* res) {
-             return self.LookupNodes(static_cast<LookupNodesRequest*>(req), static_cast<LookupResponse*>(res));
+             return self.LookupNodes(As<LookupNodesRequest>(req, "LookupNodesRequest"), As<LookupResponse>(res, "LookupResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
       .def("lookup_edges",
            [](Client& self, OpRequest* req, OpResponse* res) {
-             return self.LookupEdges(static_cast<LookupEdgesRequest*>(req), static_cast<LookupResponse*>(res));
+             return self.LookupEdges(As<LookupEdgesRequest>(req, "LookupEdgesRequest"), As<LookupResponse>(res, "LookupResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
       .def("get_degree",
            [](Client& self, OpRequest* req, OpResponse* res) {
-             return self.GetDegree(static_cast<GetDegreeRequest*>(req), static_cast<GetDegreeResponse*>(res));
+             return self.GetDegree(As<GetDegreeRequest>(req, "GetDegreeRequest"), As<GetDegreeResponse>(res, "GetDegreeResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
       .def("run_op", &Client::RunOp, py::call_guard<py::gil_scoped_release>());
@@ -227,21 +236,21 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("new_sampling_response", []() -> OpResponse* { return new SamplingResponse(); },
         py::return_value_policy::reference);
   m.def("set_sampling_request", [](OpRequest* req, I64Array src_ids) {
-    static_cast<SamplingRequest*>(req)->Set(src_ids.data(), (int32_t)src_ids.size());
+    As<SamplingRequest>(req, "SamplingRequest")->Set(src_ids.data(), (int32_t)src_ids.size());
   });
   m.def("set_sampling_call_counter", [](OpRequest* req, int64_t call_counter) {
-    static_cast<SamplingRequest*>(req)->SetCallCounter(call_counter);
+    As<SamplingRequest>(req, "SamplingRequest")->SetCallCounter(call_counter);
   });
   m.def("get_sampling_node_ids", [](OpResponse* res) {
-    SamplingResponse* r = static_cast<SamplingResponse*>(res);
+    SamplingResponse* r = As<SamplingResponse>(res, "SamplingResponse");
     return ViewOf<int64_t>(r, kNodeIds, r->GetShape().size);
   });
   m.def("get_sampling_edge_ids", [](OpResponse* res) {
-    SamplingResponse* r = static_cast<SamplingResponse*>(res);
+    SamplingResponse* r = As<SamplingResponse>(res, "SamplingResponse");
     return ViewOf<int64_t>(r, kEdgeIds, r->GetShape().size);
   });
   m.def("get_sampling_node_degrees", [](OpResponse* res) {
-    SamplingResponse* r = static_cast<SamplingResponse*>(res);
+    SamplingResponse* r = As<SamplingResponse>(res, "SamplingResponse");
     const Shape& shape = r->GetShape();
     return CopyOut(shape.segments.data(), shape.segments.size());
   });
@@ -255,11 +264,11 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("new_aggregating_response", []() -> OpResponse* { return new AggregatingResponse(); },
         py::return_value_policy::reference);
   m.def("set_aggregating_request", [](OpRequest* req, I64Array node_ids, I32Array segment_ids, int32_t num_segments) {
-    static_cast<AggregatingRequest*>(req)->Set(node_ids.data(), segment_ids.data(), (int32_t)node_ids.size(),
+    As<AggregatingRequest>(req, "AggregatingRequest")->Set(node_ids.data(), segment_ids.data(), (int32_t)node_ids.size(),
                                                num_segments);
   });
   m.def("get_aggregating_nodes", [](OpResponse* res) {
-    AggregatingResponse* r = static_cast<AggregatingResponse*>(res);
+    AggregatingResponse* r = As<AggregatingResponse>(res, "AggregatingResponse");
     return ViewOf<float>(r, kFloatAttrKey, (size_t)r->NumSegments() * r->EmbeddingDim());
   });
 
@@ -268,7 +277,7 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
         [](const std::string& node_type) -> OpRequest* { return new LookupNodesRequest(node_type); },
         py::return_value_policy::reference);
   m.def("set_lookup_nodes_request", [](OpRequest* req, I64Array node_ids) {
-    static_cast<LookupNodesRequest*>(req)->Set(node_ids.data(), (int32_t)node_ids.size());
+    As<LookupNodesRequest>(req, "LookupNodesRequest")->Set(node_ids.data(), (int32_t)node_ids.size());
   });
   m.def("new_lookup_nodes_response", []() -> OpResponse* { return new LookupResponse(); },
         py::return_value_policy::reference);
@@ -276,34 +285,34 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
         [](const std::string& edge_type) -> OpRequest* { return new LookupEdgesRequest(edge_type); },
         py::return_value_policy::reference);
   m.def("set_lookup_edges_request", [](OpRequest* req, I64Array src_ids, I64Array edge_ids) {
-    static_cast<LookupEdgesRequest*>(req)->Set(edge_ids.data(), src_ids.data(), (int32_t)edge_ids.size());
+    As<LookupEdgesRequest>(req, "LookupEdgesRequest")->Set(edge_ids.data(), src_ids.data(), (int32_t)edge_ids.size());
   });
   m.def("new_lookup_edges_response", []() -> OpResponse* { return new LookupResponse(); },
         py::return_value_policy::reference);
   for (const char* prefix : {"node", "edge"}) {
     const std::string p = std::string("get_") + prefix;
     m.def((p + "_weights").c_str(), [](OpResponse* res) {
-      LookupResponse* r = static_cast<LookupResponse*>(res);
+      LookupResponse* r = As<LookupResponse>(res, "LookupResponse");
       return CopyOut(r->Weights(), r->Weights() ? (size_t)r->Size() : 0);
     });
     m.def((p + "_labels").c_str(), [](OpResponse* res) {
-      LookupResponse* r = static_cast<LookupResponse*>(res);
+      LookupResponse* r = As<LookupResponse>(res, "LookupResponse");
       return CopyOut(r->Labels(), r->Labels() ? (size_t)r->Size() : 0);
     });
     m.def((p + "_timestamps").c_str(), [](OpResponse* res) {
-      LookupResponse* r = static_cast<LookupResponse*>(res);
+      LookupResponse* r = As<LookupResponse>(res, "LookupResponse");
       return CopyOut(r->Timestamps(), r->Timestamps() ? (size_t)r->Size() : 0);
     });
     m.def((p + "_int_attributes").c_str(), [](OpResponse* res) {
-      LookupResponse* r = static_cast<LookupResponse*>(res);
+      LookupResponse* r = As<LookupResponse>(res, "LookupResponse");
       return CopyOut(r->IntAttrs(), r->IntAttrs() ? (size_t)r->Size() * r->IntAttrNum() : 0);
     });
     m.def((p + "_float_attributes").c_str(), [](OpResponse* res) {
-      LookupResponse* r = static_cast<LookupResponse*>(res);
+      LookupResponse* r = As<LookupResponse>(res, "LookupResponse");
       return ViewOf<float>(r, kFloatAttrKey, r->FloatAttrs() ? (size_t)r->Size() * r->FloatAttrNum() : 0);
     });
     m.def((p + "_string_attributes").c_str(), [](OpResponse* res) {
-      LookupResponse* r = static_cast<LookupResponse*>(res);
+      LookupResponse* r = As<LookupResponse>(res, "LookupResponse");
       py::list out;
       for (const std::string& s : r->StringAttrs()) out.append(py::str(s));
       return py::array(py::module_::import("numpy").attr("array")(out, py::arg("dtype") = "object"));
@@ -315,12 +324,12 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
         [](const std::string& edge_type, int32_t /*node_from*/) -> OpRequest* { return new GetDegreeRequest(edge_type); },
         py::return_value_policy::reference);
   m.def("set_degree_request", [](OpRequest* req, I64Array node_ids) {
-    static_cast<GetDegreeRequest*>(req)->Set(node_ids.data(), (int32_t)node_ids.size());
+    As<GetDegreeRequest>(req, "GetDegreeRequest")->Set(node_ids.data(), (int32_t)node_ids.size());
   });
   m.def("new_get_degree_response", []() -> OpResponse* { return new GetDegreeResponse(); },
         py::return_value_policy::reference);
   m.def("get_degree", [](OpResponse* res) {
-    GetDegreeResponse* r = static_cast<GetDegreeResponse*>(res);
+    GetDegreeResponse* r = As<GetDegreeResponse>(res, "GetDegreeResponse");
     return CopyOut(r->GetDegrees(), (size_t)r->batch_size_);
   });
 
