@@ -159,6 +159,9 @@ struct glx_graph {
   GlxAlias* alias;   // [E] or nullptr
   GlxAlias* alias_indeg;  // [E] alias tables over the neighbours' in-degrees, or nullptr
   int64_t* nbr_sorted;    // [E] every row's neighbour ids ascending (strict negative sampling), or nullptr
+  GlxIdMapStorage dst_map;  // destination id -> index into dst_count (with alias_indeg), for in-degree lookups
+  int64_t* dst_count;     // [num_dst] in-degree of every distinct destination id
+  int64_t num_dst;
   GlxEwRec* ew;           // [E] packed EdgeWeight records, or nullptr (edge ids beyond int32)
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }

@@ -139,13 +139,71 @@ extern "C" int glx_graph_enable_in_degree(glx_graph* g, void* stream) {
       rc = glx_alias_build_launch(g->row_ptr, w.as<float>(), V, E, table, s);
     }
     hipError_t e2 = hipStreamSynchronize(s);
-    glx_idmap_free(&um);
+    if (e != hipSuccess || e2 != hipSuccess || rc != GLX_OK) glx_idmap_free(&um);
     GLX_HIP(e);
     GLX_HIP(e2);
     if (rc != GLX_OK) return rc;
+    // keep destination id -> in-degree for glx_graph_in_degrees (GetInDegree, topo_statics.cc:62-69)
+    int64_t* keep = nullptr;
+    hipError_t e3 = hipMalloc(&keep, (size_t)(U > 0 ? U : 1) * 8);
+    if (e3 == hipSuccess) e3 = hipMemcpyAsync(keep, counts.p, (size_t)U * 8, hipMemcpyDeviceToDevice, s);
+    if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
+    if (e3 != hipSuccess) {
+      if (keep) (void)hipFree(keep);
+      glx_idmap_free(&um);
+      GLX_HIP(e3);
+    }
+    g->dst_map = um;
+    g->dst_count = keep;
+    g->num_dst = U;
   }
   own.p = nullptr;
   g->alias_indeg = table;
+  return GLX_OK;
+}
+
+namespace {
+__global__ void glx_in_degrees_kernel(GlxIdMap map, const int64_t* __restrict__ count, const int64_t* __restrict__ ids,
+                                      int64_t n, int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t at = glx_row_of(map, ids[i]);
+  out[i] = at < 0 ? 0 : count[at];
+}
+}  // namespace
+
+extern "C" int glx_graph_in_degrees(const glx_graph* g, const int64_t* ids, int64_t n, int64_t* deg_out, int ptr_kind,
+                                    void* stream) {
+  GLX_REQUIRE(g && (n == 0 || (ids && deg_out)), "NULL argument");
+  GLX_REQUIRE(n >= 0, "negative n");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  GLX_REQUIRE(g->alias_indeg != nullptr, "call glx_graph_enable_in_degree(graph) first");
+  if (n == 0) return GLX_OK;
+  GlxDeviceGuard guard(g->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
+  const bool host = ptr_kind == GLX_PTR_HOST;
+  hipStream_t s = host ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
+  const int64_t* d_ids = ids;
+  int64_t* d_out = deg_out;
+  int64_t* scratch = nullptr;
+  if (host) {
+    int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), (size_t)n * 16, s, 0);
+    if (rc != GLX_OK) return rc;
+    GLX_HIP(hipMemcpyAsync(scratch, ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    d_ids = scratch;
+    d_out = scratch + n;
+  }
+  if (g->num_dst == 0) {
+    GLX_HIP(hipMemsetAsync(d_out, 0, (size_t)n * 8, s));
+  } else {
+    const GlxIdMap map{g->dst_map.keys, g->dst_map.vals, g->dst_map.cap - 1, g->num_dst};
+    glx_in_degrees_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(map, g->dst_count, d_ids, n, d_out);
+  }
+  hipError_t e = hipGetLastError();
+  if (host && e == hipSuccess) e = hipMemcpyAsync(deg_out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s);
+  if (host && e == hipSuccess) e = hipStreamSynchronize(s);
+  if (scratch) glx_scratch_free(scratch, s);
+  GLX_HIP(e);
   return GLX_OK;
 }
 

@@ -373,6 +373,8 @@ void glx_graph_free(glx_graph* g) {
   if (g->alias) (void)hipFree(g->alias);
   if (g->alias_indeg) (void)hipFree(g->alias_indeg);
   if (g->nbr_sorted) (void)hipFree(g->nbr_sorted);
+  if (g->dst_count) (void)hipFree(g->dst_count);
+  glx_idmap_free(&g->dst_map);
   if (g->ew) (void)hipFree(g->ew);
   glx_idmap_free(&g->idmap);
   delete g;

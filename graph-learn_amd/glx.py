@@ -39,7 +39,7 @@ AGGREGATOR_IDS = {
 EXPORTS = [
     "glx_abi_version", "glx_device_count", "glx_last_error",
     "glx_graph_create", "glx_graph_build", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
-    "glx_graph_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
+    "glx_graph_degrees", "glx_graph_in_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
     "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
@@ -85,6 +85,7 @@ def lib():
                                      ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.glx_graph_export_alias.argtypes = [vp, vp, vp, ci, vp]
         L.glx_graph_degrees.argtypes = [vp, vp, i64, vp, ci, vp]
+        L.glx_graph_in_degrees.argtypes = [vp, vp, i64, vp, ci, vp]
         L.glx_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_sample_ex.argtypes = [vp, ci, vp, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_sample_hops.argtypes = [vp, i32, ci, vp, i32, vp, ci, i64, u64, u64, vp, vp, ci, vp]
@@ -264,6 +265,17 @@ class Graph:
             out = np.empty(src.shape[0], np.int64)
         (ps, k1), (po, _) = _ptr(src), _ptr(out)
         _check(lib().glx_graph_degrees(self._h, ps, src.shape[0], po, k1, _stream(k1)))
+        return out
+
+    def in_degrees(self, ids):
+        """In-degrees of raw destination ids (needs enable_in_degree())."""
+        if _is_torch(ids):
+            import torch
+            out = torch.empty(ids.shape[0], dtype=torch.int64, device=ids.device)
+        else:
+            out = np.empty(ids.shape[0], np.int64)
+        (ps, k1), (po, _) = _ptr(ids), _ptr(out)
+        _check(lib().glx_graph_in_degrees(self._h, ps, ids.shape[0], po, k1, _stream(k1)))
         return out
 
     def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR,

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "graphlearn/config.h"
 #include "graphlearn/graph_store.h"
 #include "graphlearn/op_request.h"
 
@@ -92,7 +93,9 @@ typedef LookupResponse LookupEdgesResponse;
 class GetDegreeRequest : public OpRequest {
 public:
   GetDegreeRequest();
-  explicit GetDegreeRequest(const std::string& edge_type);
+  // node_from: kEdgeSrc = out-degrees of source ids, kEdgeDst = in-degrees of destination ids
+  explicit GetDegreeRequest(const std::string& edge_type, NodeFrom node_from = kEdgeSrc);
+  NodeFrom GetNodeFrom() const;
   OpRequest* Clone() const override;
   void Set(const int64_t* node_ids, int32_t batch_size);
   const std::string& EdgeType() const;

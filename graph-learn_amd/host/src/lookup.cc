@@ -138,15 +138,21 @@ REGISTER_REQUEST(LookupEdges, LookupEdgesRequest, LookupResponse)
 // -------------------------------------------------------------- GetDegree --
 GetDegreeRequest::GetDegreeRequest() : OpRequest(kNodeIds) {}
 
-GetDegreeRequest::GetDegreeRequest(const std::string& edge_type) : OpRequest(kNodeIds) {
+GetDegreeRequest::GetDegreeRequest(const std::string& edge_type, NodeFrom node_from) : OpRequest(kNodeIds) {
   ADD_TENSOR(params_, kOpName, kString, 1);
   params_[kOpName].AddString("GetDegree");
+  ADD_TENSOR(params_, "node_from", kInt32, 1);
+  params_["node_from"].AddInt32((int32_t)node_from);
   ADD_TENSOR(params_, kEdgeType, kString, 1);
   params_[kEdgeType].AddString(edge_type);
   ADD_TENSOR(tensors_, kNodeIds, kInt64, 64);
 }
 
-OpRequest* GetDegreeRequest::Clone() const { return new GetDegreeRequest(EdgeType()); }
+OpRequest* GetDegreeRequest::Clone() const { return new GetDegreeRequest(EdgeType(), GetNodeFrom()); }
+NodeFrom GetDegreeRequest::GetNodeFrom() const {
+  auto it = params_.find("node_from");
+  return it == params_.end() ? kEdgeSrc : (NodeFrom)it->second.GetInt32(0);
+}
 void GetDegreeRequest::Set(const int64_t* node_ids, int32_t batch_size) {
   tensors_[kNodeIds].AddInt64(node_ids, node_ids + batch_size);
 }
@@ -237,7 +243,14 @@ public:
     response->InitDegrees(n);
     if (!graph->Device()) return error::InvalidArgument("edge type '" + request->EdgeType() + "' is not built on the device");
     std::vector<int64_t> deg((size_t)n);
-    int rc = glx_graph_degrees(graph->Device(), request->NodeIds(), n, deg.data(), GLX_PTR_HOST, nullptr);
+    int rc;
+    if (request->GetNodeFrom() == kEdgeDst) {
+      Status s = graph->EnsureInDegree();
+      if (!s.ok()) return s;
+      rc = glx_graph_in_degrees(graph->Device(), request->NodeIds(), n, deg.data(), GLX_PTR_HOST, nullptr);
+    } else {
+      rc = glx_graph_degrees(graph->Device(), request->NodeIds(), n, deg.data(), GLX_PTR_HOST, nullptr);
+    }
     if (rc != GLX_OK) return error::FromGlx(rc);
     int32_t* out = response->MutableDegrees();
     for (int32_t i = 0; i < n; ++i) out[i] = (int32_t)deg[i];

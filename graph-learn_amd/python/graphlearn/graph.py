@@ -218,9 +218,9 @@ class Graph(object):
     return self._run_lookup("edge", edge_type, self.get_edge_decoder(edge_type),
                             lambda req: pywrap.set_lookup_edges_request(req, src_ids, edge_ids))
 
-  def out_degrees(self, ids, edge_type):
+  def _degrees(self, ids, edge_type, node_from):
     ids = np.array(ids)
-    req = pywrap.new_get_degree_request(edge_type, 0)
+    req = pywrap.new_get_degree_request(edge_type, node_from)
     pywrap.set_degree_request(req, np.ascontiguousarray(ids.reshape(-1), dtype=np.int64))
     res = pywrap.new_get_degree_response()
     status = self._client.get_degree(req, res)
@@ -230,8 +230,13 @@ class Graph(object):
     errors.raise_exception_on_not_ok_status(status)
     return out
 
+  def out_degrees(self, ids, edge_type):
+    """Out-degrees of source ids of `edge_type` (0 for unknown ids)."""
+    return self._degrees(ids, edge_type, pywrap.NodeFrom.EDGE_SRC)
+
   def in_degrees(self, ids, edge_type):
-    raise NotImplementedError("in-degree lookup is not served by the device engine")
+    """In-degrees of destination ids of `edge_type` (0 for ids no edge points to)."""
+    return self._degrees(ids, edge_type, pywrap.NodeFrom.EDGE_DST)
 
   # -- samplers -------------------------------------------------------------------
   def neighbor_sampler(self, meta_path, expand_factor, strategy="random"):

@@ -321,7 +321,9 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
 
   // ---- degrees (py_client.cc:468-491) ----
   m.def("new_get_degree_request",
-        [](const std::string& edge_type, int32_t /*node_from*/) -> OpRequest* { return new GetDegreeRequest(edge_type); },
+        [](const std::string& edge_type, NodeFrom node_from) -> OpRequest* {
+          return new GetDegreeRequest(edge_type, node_from);
+        },
         py::return_value_policy::reference);
   m.def("set_degree_request", [](OpRequest* req, I64Array node_ids) {
     As<GetDegreeRequest>(req, "GetDegreeRequest")->Set(node_ids.data(), (int32_t)node_ids.size());

@@ -125,6 +125,10 @@ GLX_API int glx_graph_export_alias(const glx_graph* g, float* prob, int32_t* ali
 /* Degrees of a batch of raw ids (0 for unknown ids), as GetNeighbors().Size(). */
 GLX_API int glx_graph_degrees(const glx_graph* g, const int64_t* src, int64_t n, int64_t* deg_out,
                       int ptr_kind, void* stream);
+/* In-degrees of a batch of raw destination ids (0 for ids no edge points to), as
+ * GraphStorage::GetInDegree (topo_statics.cc:62-69).  Needs glx_graph_enable_in_degree(g). */
+GLX_API int glx_graph_in_degrees(const glx_graph* g, const int64_t* ids, int64_t n, int64_t* deg_out,
+                         int ptr_kind, void* stream);
 
 /* ---- neighbour sampling: replaces Sampler::Sample of the four samplers
  * (random_sampler.cc:33-76, random_without_replacement_sampler.cc:31-75,

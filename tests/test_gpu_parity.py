@@ -602,3 +602,17 @@ def test_negative_sampling_exhausted_candidates_and_empty_list():
     assert np.array_equal(got, orc.negative_sample(ids, (prob, alias), 1, og, src, 5, seed=2, call_counter=5))
     empty = glx.Negative(np.zeros(0, np.int64))
     assert (empty.sample(src, 3, default_neighbor_id=-4) == -4).all()
+
+
+def test_in_degree_lookup_equals_bincount():
+    rng = np.random.default_rng(5)
+    V, E = 3000, 40000
+    rp, col, eid, w = synth.small_graph(V, E, seed=31, weighted=True, hub_degree=900)
+    g = glx.Graph(rp, col, eid, w).enable_in_degree()
+    want = np.bincount(col, minlength=V + 10)
+    q = np.concatenate([rng.integers(0, V + 10, 5000), [-1, 10 ** 12]]).astype(np.int64)
+    got = g.in_degrees(q)
+    ok = (q >= 0) & (q < V + 10)
+    assert np.array_equal(got[ok], want[q[ok]]) and (got[~ok] == 0).all()
+    import torch
+    assert np.array_equal(g.in_degrees(torch.from_numpy(q).cuda()).cpu().numpy(), got)

@@ -480,3 +480,18 @@ def test_python_stack_equals_live_reference_on_the_same_records(gl, g):
         np.testing.assert_equal(g.out_degrees(ids, EDGE2), deg)
     finally:
         ref.close()
+
+
+def test_in_and_out_degree_lookups(gl, g):
+    """Graph.out_degrees / in_degrees (GetDegree with NodeFrom EDGE_SRC / EDGE_DST) against the generator."""
+    ids = np.array([102, 105, 107, 199, 5000])
+    np.testing.assert_equal(g.out_degrees(ids, EDGE2), [2, 0, 2, 4, 0])
+    dsts = np.arange(0, 100)
+    want = np.zeros(100, np.int64)
+    for s in range(*RANGE2):
+        for d_ in fx.fixed_dst_ids(s, RANGE1):
+            want[d_] += 1
+    np.testing.assert_equal(g.in_degrees(dsts, EDGE2), want)
+    np.testing.assert_equal(g.in_degrees(np.array([100, -7, 10 ** 9]), EDGE2), [0, 0, 0])
+    nodes = g.get_nodes(NODE1, dsts)
+    np.testing.assert_equal(nodes.get_in_degrees(EDGE2), want)
