@@ -1,6 +1,9 @@
 // Local-mode Client / Server (see client.h).
 #include "graphlearn/client.h"
 
+#include <mutex>
+#include <vector>
+
 #include "graphlearn/operator.h"
 
 namespace graphlearn {
@@ -32,6 +35,14 @@ Status Client::Stop() { return Status::OK(); }
 
 Client* NewInMemoryClient() { return new Client(); }
 
+namespace {
+// The operators serve ONE store per process (OpFactory::Set, like the reference).  With
+// several Server objects alive, the most recently initialised one is served; stopping it
+// hands the operators back to the previous one instead of leaving them unbound.
+std::mutex g_bound_mtx;
+std::vector<Server*> g_bound;
+}  // namespace
+
 Server::Server() : store_(nullptr), bound_(false) {}
 
 Server::~Server() { Stop(); }
@@ -56,7 +67,9 @@ void Server::Init(const std::vector<io::EdgeSource>& edges, const std::vector<io
   }
   if (status_.ok()) status_ = store_->Build(option);
   if (status_.ok()) {
-    op::OpFactory::GetInstance()->Set(store_);  // one store per process, like the reference
+    std::lock_guard<std::mutex> g(g_bound_mtx);
+    op::OpFactory::GetInstance()->Set(store_);
+    if (!bound_) g_bound.push_back(this);
     bound_ = true;
   }
 }
@@ -71,7 +84,13 @@ uintptr_t Server::DeviceFeatures(const std::string& node_type) {
 
 void Server::Stop() {
   if (store_) {
-    if (bound_) op::OpFactory::GetInstance()->Set(nullptr);
+    if (bound_) {
+      std::lock_guard<std::mutex> g(g_bound_mtx);
+      for (size_t i = 0; i < g_bound.size(); ++i) {
+        if (g_bound[i] == this) g_bound.erase(g_bound.begin() + i);
+      }
+      op::OpFactory::GetInstance()->Set(g_bound.empty() ? nullptr : g_bound.back()->store_);
+    }
     bound_ = false;
     delete store_;
     store_ = nullptr;

@@ -495,3 +495,46 @@ def test_in_and_out_degree_lookups(gl, g):
     np.testing.assert_equal(g.in_degrees(np.array([100, -7, 10 ** 9]), EDGE2), [0, 0, 0])
     nodes = g.get_nodes(NODE1, dsts)
     np.testing.assert_equal(nodes.get_in_degrees(EDGE2), want)
+
+
+def test_empty_and_degenerate_sources(gl, g, tmp_path):
+    """Header-only files, CRLF line endings, blank lines, a missing trailing newline, duplicate node ids
+    and malformed records (skipped with ignore_invalid, fatal without)."""
+    d = str(tmp_path)
+    open(os.path.join(d, "e0"), "w").write("src_id:int64\tdst_id:int64\tweight:float\n")
+    open(os.path.join(d, "n0"), "w").write("id:int64\tfeature:string\n")
+    open(os.path.join(d, "e1"), "w").write("src_id:int64\tdst_id:int64\tweight:float\r\n1\t2\t0.5\r\n\r\n1\t3\t0.25\r\nbad\tline\there\r\n2\t3\t1.0")
+    open(os.path.join(d, "n1"), "w").write("id:int64\tfeature:string\n1\t0.5:1.5\n2\t2.5:3.5\n1\t9.0:9.0\n3\tnot:a_number\n")
+    g = gl.Graph().edge(os.path.join(d, "e0"), ("a", "a", "empty"), gl.Decoder(weighted=True)) \
+        .node(os.path.join(d, "n0"), "a", gl.Decoder(attr_types=["float", "float"])) \
+        .edge(os.path.join(d, "e1"), ("b", "b", "some"), gl.Decoder(weighted=True)) \
+        .node(os.path.join(d, "n1"), "b", gl.Decoder(attr_types=["float", "float"]))
+    g.init()
+    try:
+        gl.set_padding_mode(gl.CIRCULAR)
+        ids = np.array([1, 2, 3])
+        nb = g.neighbor_sampler("empty", 2, strategy="random").get(ids)
+        assert (nb.layer_nodes(1).ids == -1).all()  # default neighbour id set by the module fixture
+        top = g.neighbor_sampler("some", 2, strategy="topk").get(ids)
+        np.testing.assert_equal(top.layer_nodes(1).ids, [[2, 3], [3, 3], [-1, -1]])
+        np.testing.assert_equal(top.layer_edges(1).edge_ids, [[0, 1], [2, 2], [-1, -1]])  # the bad record took no id
+        vals = g.lookup_nodes("b", np.array([1, 2, 3]))
+        np.testing.assert_allclose(vals.float_attrs, [[0.5, 1.5], [2.5, 3.5], [999.9, 999.9]], rtol=1e-6)
+        assert g.get_nodes("a", np.array([7])).float_attrs.tolist() == [[pytest.approx(999.9), pytest.approx(999.9)]]
+    finally:
+        gl.set_padding_mode(gl.REPLICATE)
+        g.close()
+    gl.set_ignore_invalid(False)
+    try:
+        strict = gl.Graph().edge(os.path.join(d, "e1"), ("b", "b", "some"), gl.Decoder(weighted=True))
+        with pytest.raises(gl.InvalidArgumentError):
+            strict.init()
+        strict.close()
+    finally:
+        gl.set_ignore_invalid(True)
+
+
+def test_module_graph_still_served_after_other_graphs_closed(gl, g):
+    """Other Graph objects came and went in this process; the operators are bound to this one again."""
+    nbrs = g.neighbor_sampler(EDGE1, 3, strategy="random").get(SEEDS1)
+    fx.expect_edges_follow_generator(nbrs.layer_edges(1), RANGE2, SEEDS1, DEFAULT_ID)
