@@ -173,6 +173,57 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
   }
 }
 
+// k <= 16: the same permutation without the k dependent cross-lane steps.  Every lane of the
+// W-lane group fetches all W draws (W independent shuffles), replays the sparse Fisher-Yates
+// bookkeeping in registers -- w_t = "value found at position t when step t ran" -- with fully
+// unrolled compares, and reads off its own entry: perm_l = value at position r_l before
+// step l.  ~W^2 VALU compares instead of 3k serialised ds_bpermute round trips.
+template <int W>
+__global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int l = lane & (W - 1);
+  const int base = lane - l;
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / W;
+  const bool active = i < a.batch;
+  int64_t start = 0, deg = 0;
+  if (active) {
+    const int64_t row = glx_row_of(a.map, a.src[i]);
+    if (row >= 0) {
+      start = a.row_ptr[row];
+      deg = a.row_ptr[row + 1] - start;
+    }
+  }
+  const int32_t m = (int32_t)(deg < a.k ? deg : a.k);
+  int32_t r = l;
+  if (l < m) {
+    const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
+    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, (uint32_t)l), (uint64_t)(deg - l));
+  }
+  int32_t rs[W], ws[W];
+#pragma unroll
+  for (int t = 0; t < W; ++t) rs[t] = __shfl(r, base + t);
+#pragma unroll
+  for (int t = 0; t < W; ++t) {
+    int32_t v = t;
+#pragma unroll
+    for (int u = 0; u < t; ++u) v = (rs[u] == t) ? ws[u] : v;  // ascending u: the latest step wins
+    ws[t] = v;
+  }
+  int32_t perm = r;
+#pragma unroll
+  for (int u = 0; u < W; ++u) perm = (u < l && rs[u] == r) ? ws[u] : perm;
+  // Slot l of the row: circular_padder.h:46-63 with indices_ = the permutation.
+  const bool has_slot = l < a.k;
+  const int32_t c = (has_slot && m > 0) ? l % m : 0;
+  const int32_t pc = __shfl(perm, base + c);
+  if (active && has_slot) {
+    GlxAdj rec = GlxAdj{a.default_nbr, -1};
+    if (m > 0) rec = a.adj[start + pc];
+    a.nbr_out[i * a.k + l] = rec.nbr;
+    a.eid_out[i * a.k + l] = rec.eid;
+  }
+}
+
 // Same algorithm for 64 < k <= 8192: one wave per row, r/w/perm in LDS, the
 // "latest t < j" lookup is a strided scan + wave max.
 __device__ __forceinline__ int32_t glx_wave_max_i32(int32_t v) {
@@ -238,7 +289,8 @@ void launch_slots(const SampleArgs& a, hipStream_t s) {
 template <int W>
 void launch_rwor(const SampleArgs& a, hipStream_t s) {
   const int64_t threads = (int64_t)a.batch * W;
-  glx_rwor_kernel<W><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+  if (W <= 16) glx_rwor_small_kernel<(W <= 16 ? W : 16)><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+  else glx_rwor_kernel<W><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
 }
 
 int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padding_mode,
