@@ -538,3 +538,11 @@ def test_module_graph_still_served_after_other_graphs_closed(gl, g):
     """Other Graph objects came and went in this process; the operators are bound to this one again."""
     nbrs = g.neighbor_sampler(EDGE1, 3, strategy="random").get(SEEDS1)
     fx.expect_edges_follow_generator(nbrs.layer_edges(1), RANGE2, SEEDS1, DEFAULT_ID)
+
+
+def test_quickstart_example_runs():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "quickstart.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "one epoch: 4 batches" in r.stdout
