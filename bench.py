@@ -756,6 +756,11 @@ def main():
             legs = "failed: %r" % (ex,)
         dog.cancel()
         emit({"ablations": legs})
+        if isinstance(legs, str):
+            # a leg failed on this rank: the other ranks may be waiting in a collective, and tearing
+            # the process group down would wait for them -- the result is out, leave now
+            sys.stderr.flush()
+            os._exit(0)
     else:
         emit({})
     if sharded:
