@@ -3,6 +3,10 @@
 // storage in file order -- so edge ids (= load order, memory_edge_storage.cc:53-57)
 // are deterministic, which the reference's thread-interleaved loaders
 // (graph_store.cc:76-93) do not guarantee.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -380,9 +384,40 @@ inline bool FieldFloat(const Fields& f, int c, float* v) {
 }
 }  // namespace
 
+namespace {
+// A source path may be a directory: every regular file in it is one piece of the source
+// (the reference's file system lists them, edge_loader_unittest.cpp:334-390); names are
+// taken in sorted order so that load order -- hence edge ids -- is reproducible.
+bool ListDirectory(const std::string& path, std::vector<std::string>* files) {
+  struct stat st;
+  if (::stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  DIR* dir = ::opendir(path.c_str());
+  if (!dir) return false;
+  while (struct dirent* e = ::readdir(dir)) {
+    const std::string name = e->d_name;
+    if (name == "." || name == "..") continue;
+    const std::string full = path + (path.empty() || path.back() == '/' ? "" : "/") + name;
+    if (::stat(full.c_str(), &st) == 0 && S_ISREG(st.st_mode)) files->push_back(full);
+  }
+  ::closedir(dir);
+  std::sort(files->begin(), files->end());
+  return true;
+}
+}  // namespace
+
 Status LoadEdges(const EdgeSource& source, GraphStore* store) {
   if (source.src_id_type.empty() || source.dst_id_type.empty() || source.edge_type.empty()) {
     return error::InvalidArgument("Node and edge types must be assigned.");
+  }
+  std::vector<std::string> pieces;
+  if (ListDirectory(source.path, &pieces)) {
+    for (const std::string& piece : pieces) {
+      EdgeSource one = source;
+      one.path = piece;
+      Status st = LoadEdges(one, store);
+      if (!st.ok()) return st;
+    }
+    return Status::OK();
   }
   File f;
   Status s = ReadFile(source.path, &f);
@@ -439,6 +474,16 @@ Status LoadEdges(const EdgeSource& source, GraphStore* store) {
 
 Status LoadNodes(const NodeSource& source, GraphStore* store) {
   if (source.id_type.empty()) return error::InvalidArgument("Node type must be assigned.");
+  std::vector<std::string> pieces;
+  if (ListDirectory(source.path, &pieces)) {
+    for (const std::string& piece : pieces) {
+      NodeSource one = source;
+      one.path = piece;
+      Status st = LoadNodes(one, store);
+      if (!st.ok()) return st;
+    }
+    return Status::OK();
+  }
   File f;
   Status s = ReadFile(source.path, &f);
   if (!s.ok()) return s;

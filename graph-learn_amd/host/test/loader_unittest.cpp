@@ -1,0 +1,215 @@
+// Restates graphlearn/src/core/io/test/edge_loader_unittest.cpp and
+// node_loader_unittest.cpp against the glx loader (host/src/loader.cc): every combination of
+// the optional columns, several files of one type, directory sources, and what the
+// reference's loaders reject.  Loading is host work: this test needs no GPU (the stores are
+// never built).
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "graphlearn/graphlearn.h"
+#include "test_util.h"
+
+using namespace graphlearn;      // NOLINT
+using namespace graphlearn::io;  // NOLINT
+
+namespace {
+
+std::string Title(bool edge, int32_t format) {
+  std::string t = edge ? "src_id:int64\tdst_id:int64" : "node_id:int64";
+  if (format & kWeighted) t += edge ? "\tedge_weight:float" : "\tnode_weight:float";
+  if (format & kLabeled) t += "\tlabel:int32";
+  if (format & kAttributed) t += "\tattribute:string";
+  return t + "\n";
+}
+
+// record i: ids = i, weight = float(i), label = i, attributes "i:float(i):<letter>"
+void GenFile(const std::string& path, bool edge, int32_t format, int32_t offset = 0, int32_t count = 100) {
+  std::ofstream out(path);
+  out << Title(edge, format);
+  char buf[128];
+  for (int32_t i = offset; i < offset + count; ++i) {
+    std::string line = edge ? std::to_string(i) + "\t" + std::to_string(i) : std::to_string(i);
+    if (format & kWeighted) {
+      std::snprintf(buf, sizeof(buf), "\t%f", (float)i);
+      line += buf;
+    }
+    if (format & kLabeled) line += "\t" + std::to_string(i);
+    if (format & kAttributed) {
+      std::snprintf(buf, sizeof(buf), "\t%d:%f:%c", i, (float)i, (char)(i % 26 + 'A'));
+      line += buf;
+    }
+    out << line << "\n";
+  }
+}
+
+void FillAttrInfo(AttributeInfo* info, int32_t format) {
+  info->ignore_invalid = false;
+  if (format & kAttributed) {
+    info->delimiter = ":";
+    info->types = {kInt32, kFloat, kString};
+    info->hash_buckets = {0, 0, 0};
+  }
+}
+
+EdgeSource EdgeSrc(const std::string& path, int32_t format, const char* type, const char* src, const char* dst) {
+  EdgeSource s;
+  s.path = path;
+  s.format = format;
+  s.edge_type = type;
+  s.src_id_type = src;
+  s.dst_id_type = dst;
+  FillAttrInfo(&s.attr_info, format);
+  return s;
+}
+
+NodeSource NodeSrc(const std::string& path, int32_t format, const char* type) {
+  NodeSource s;
+  s.path = path;
+  s.format = format;
+  s.id_type = type;
+  FillAttrInfo(&s.attr_info, format);
+  return s;
+}
+
+void CheckEdges(Graph* g, int32_t format, int64_t from, int64_t to, int64_t first_edge_id = 0) {
+  const SideInfo* info = g->GetSideInfo();
+  EXPECT_EQ(info->format, format);
+  for (int64_t i = from; i < to; ++i) {
+    const int64_t e = first_edge_id + (i - from);
+    EXPECT_EQ(g->GetSrcId(e), i);
+    EXPECT_EQ(g->GetDstId(e), i);
+    if (format & kWeighted) EXPECT_TRUE(g->GetEdgeWeight(e) == (float)i);
+    if (format & kLabeled) EXPECT_EQ(g->GetEdgeLabel(e), (int32_t)i);
+    if (format & kAttributed) {
+      EXPECT_EQ(g->GetEdgeIntAttrs(e)[0], i);
+      EXPECT_TRUE(g->GetEdgeFloatAttrs(e)[0] == (float)i);
+      EXPECT_EQ(g->GetEdgeStringAttrs(e)[0], std::string(1, (char)('A' + i % 26)));
+    }
+  }
+}
+
+void CheckNodes(Noder* n, int32_t format, int64_t from, int64_t to) {
+  for (int64_t i = from; i < to; ++i) {
+    const int32_t row = n->RowOf(i);
+    EXPECT_TRUE(row >= 0);
+    if (format & kWeighted) EXPECT_TRUE(n->GetWeight(i) == (float)i);
+    if (format & kLabeled) EXPECT_EQ(n->GetLabel(i), (int32_t)i);
+    if (format & kAttributed) {
+      EXPECT_EQ(n->GetIntAttrs(row)[0], i);
+      EXPECT_TRUE(n->GetFloatAttrs(row)[0] == (float)i);
+      EXPECT_EQ(n->GetStringAttrs(row)[0], std::string(1, (char)('A' + i % 26)));
+    }
+  }
+}
+
+const int32_t kFormats[] = {kWeighted, kLabeled, kAttributed, kWeighted | kLabeled, kWeighted | kAttributed,
+                            kLabeled | kAttributed, kWeighted | kLabeled | kAttributed};
+}  // namespace
+
+TEST(EdgeLoaderTest, EveryColumnCombination) {
+  // edge_loader_unittest.cpp: ReadWeightedLabeled / ReadWeightedAttributed / ReadLabeledAttributed /
+  // ReadWeightedLabeledAttributed (+ the single-column files of ReadMultiFiles)
+  for (int32_t format : kFormats) {
+    const std::string file = "glx_efile_" + std::to_string(format);
+    GenFile(file, true, format);
+    GraphStore store;
+    EXPECT_TRUE(LoadEdges(EdgeSrc(file, format, "click", "user", "item"), &store).ok());
+    Graph* g = store.GetGraph("click");
+    EXPECT_EQ(g->GetEdgeCount(), (int64_t)100);
+    EXPECT_EQ(g->GetSideInfo()->type, std::string("click"));
+    EXPECT_EQ(g->GetSideInfo()->src_type, std::string("user"));
+    EXPECT_EQ(g->GetSideInfo()->dst_type, std::string("item"));
+    CheckEdges(g, format, 0, 100);
+    std::remove(file.c_str());
+  }
+}
+
+TEST(EdgeLoaderTest, MultiFilesAndDirectories) {
+  // ReadMultiFiles + ReadDirectories: files of one type append in the order given / in sorted
+  // name order, edge ids keep counting
+  ::mkdir("glx_weighted_efiles", 0755);
+  for (int i = 0; i < 3; ++i) GenFile("glx_weighted_efiles/" + std::to_string(i) + "_#100", true, kWeighted, 100 * i);
+  GenFile("glx_extra_efile", true, kWeighted, 300);
+  GraphStore store;
+  EXPECT_TRUE(LoadEdges(EdgeSrc("glx_weighted_efiles/", kWeighted, "click", "user", "item"), &store).ok());
+  EXPECT_TRUE(LoadEdges(EdgeSrc("glx_extra_efile", kWeighted, "click", "user", "item"), &store).ok());
+  Graph* g = store.GetGraph("click");
+  EXPECT_EQ(g->GetEdgeCount(), (int64_t)400);
+  CheckEdges(g, kWeighted, 0, 400);
+  // a reversed source swaps the end points (edge_loader.cc:66-68)
+  EdgeSource rev = EdgeSrc("glx_extra_efile", kWeighted, "click_reverse", "item", "user");
+  rev.direction = kReversed;
+  GenFile("glx_asym_efile", true, kWeighted, 0, 1);
+  {
+    std::ofstream out("glx_asym_efile");
+    out << Title(true, kWeighted) << "7\t9\t0.5\n";
+  }
+  rev.path = "glx_asym_efile";
+  EXPECT_TRUE(LoadEdges(rev, &store).ok());
+  EXPECT_EQ(store.GetGraph("click_reverse")->GetSrcId(0), (int64_t)9);
+  EXPECT_EQ(store.GetGraph("click_reverse")->GetDstId(0), (int64_t)7);
+  for (int i = 0; i < 3; ++i) std::remove(("glx_weighted_efiles/" + std::to_string(i) + "_#100").c_str());
+  ::rmdir("glx_weighted_efiles");
+  std::remove("glx_extra_efile");
+  std::remove("glx_asym_efile");
+}
+
+TEST(NodeLoaderTest, EveryColumnCombinationAndDirectories) {
+  for (int32_t format : kFormats) {
+    const std::string file = "glx_nfile_" + std::to_string(format);
+    GenFile(file, false, format);
+    GraphStore store;
+    EXPECT_TRUE(LoadNodes(NodeSrc(file, format, "user"), &store).ok());
+    Noder* n = store.GetNoder("user");
+    EXPECT_EQ(n->GetNodeCount(), (int64_t)100);
+    EXPECT_EQ(n->GetSideInfo()->format, format);
+    CheckNodes(n, format, 0, 100);
+    std::remove(file.c_str());
+  }
+  ::mkdir("glx_labeled_nfiles", 0755);
+  for (int i = 0; i < 2; ++i) GenFile("glx_labeled_nfiles/" + std::to_string(i) + "_#100", false, kLabeled, 100 * i);
+  GraphStore store;
+  EXPECT_TRUE(LoadNodes(NodeSrc("glx_labeled_nfiles", kLabeled, "item"), &store).ok());
+  EXPECT_EQ(store.GetNoder("item")->GetNodeCount(), (int64_t)200);
+  CheckNodes(store.GetNoder("item"), kLabeled, 0, 200);
+  for (int i = 0; i < 2; ++i) std::remove(("glx_labeled_nfiles/" + std::to_string(i) + "_#100").c_str());
+  ::rmdir("glx_labeled_nfiles");
+}
+
+TEST(LoaderTest, RejectsWhatTheReferenceRejects) {
+  GenFile("glx_bad_schema", true, kWeighted);
+  GraphStore store;
+  // decoder says labeled, the file says weighted (edge_loader.cc:110-160)
+  Status s = LoadEdges(EdgeSrc("glx_bad_schema", kLabeled, "e", "a", "b"), &store);
+  EXPECT_TRUE(error::IsInvalidArgument(s));
+  // missing types (edge_loader.cc:94-104)
+  EdgeSource untyped = EdgeSrc("glx_bad_schema", kWeighted, "", "a", "b");
+  EXPECT_TRUE(error::IsInvalidArgument(LoadEdges(untyped, &store)));
+  EXPECT_EQ((int)LoadEdges(EdgeSrc("glx_no_such_file", kWeighted, "e", "a", "b"), &store).code(), (int)error::NOT_FOUND);
+  // wrong attribute count / a non-numeric attribute: fatal unless ignore_invalid
+  {
+    std::ofstream out("glx_bad_attr");
+    out << Title(true, kAttributed) << "1\t2\t1:1.0:A\n3\t4\t1:oops:B\n5\t6\t2:2.0\n7\t8\t3:3.0:C\n";
+  }
+  EdgeSource strict = EdgeSrc("glx_bad_attr", kAttributed, "strict", "a", "b");
+  EXPECT_TRUE(error::IsInvalidArgument(LoadEdges(strict, &store)));
+  EdgeSource lenient = EdgeSrc("glx_bad_attr", kAttributed, "lenient", "a", "b");
+  lenient.attr_info.ignore_invalid = true;
+  EXPECT_TRUE(LoadEdges(lenient, &store).ok());
+  Graph* g = store.GetGraph("lenient");
+  EXPECT_EQ(g->GetEdgeCount(), (int64_t)2);  // the two malformed records took no edge id
+  EXPECT_EQ(g->GetSrcId(1), (int64_t)7);
+  EXPECT_EQ(g->GetEdgeStringAttrs(1)[0], std::string("C"));
+  // out-of-range edge ids answer with the defaults (memory_edge_storage.cc:90-125)
+  EXPECT_EQ(g->GetSrcId(5), (int64_t)-1);
+  EXPECT_TRUE(g->GetEdgeIntAttrs(-1) == nullptr);
+  std::remove("glx_bad_schema");
+  std::remove("glx_bad_attr");
+}
+
+int main() { return RunAllTests(); }

@@ -41,6 +41,15 @@ def test_host_layer_fails_loudly_without_gpu(name):
     assert "no usable HIP device" in r.stdout and "no CPU fallback" in r.stdout
 
 
+def test_loader_unittest_on_cpu(tmp_path):
+    """edge_loader_unittest.cpp / node_loader_unittest.cpp restated: parsing and staging are host
+    work, so this one runs everywhere."""
+    r = subprocess.run([os.path.join(LIB, "loader_unittest")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout
+    assert "4 test(s), 0 failure(s)" in r.stdout, r.stdout
+
+
 def test_host_library_exports_registry():
     import subprocess as sp
     out = sp.run(["nm", "-DC", os.path.join(LIB, "libglx_host.so")], stdout=sp.PIPE, text=True).stdout
