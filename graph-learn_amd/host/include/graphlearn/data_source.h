@@ -93,5 +93,22 @@ Status LoadEdges(const EdgeSource& source, GraphStore* store);
 Status LoadNodes(const NodeSource& source, GraphStore* store);
 
 }  // namespace io
+
+template <class EdgeSources, class NodeSources>
+Status GraphStore::Load(const EdgeSources& edges, const NodeSources& nodes) {
+  IndexOption option;
+  option.name = "sort";
+  for (const auto& e : edges) {
+    Status s = io::LoadEdges(e, this);
+    if (!s.ok()) return s;
+    option = e.option.name.empty() ? option : e.option;
+  }
+  for (const auto& n : nodes) {
+    Status s = io::LoadNodes(n, this);
+    if (!s.ok()) return s;
+  }
+  return Build(option);
+}
+
 }  // namespace graphlearn
 #endif  // GLX_HOST_DATA_SOURCE_H_

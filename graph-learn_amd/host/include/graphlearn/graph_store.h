@@ -215,6 +215,10 @@ public:
   Noder* GetNoder(const std::string& node_type);
   // Build every storage added so far (GraphStore::Build, graph_store.cc:252-276).
   Status Build(const IndexOption& option);
+  // Load every source, then Build (GraphStore::Load, graph_store.cc:60-120): declared in
+  // data_source.h's terms, defined in loader.cc.
+  template <class EdgeSources, class NodeSources>
+  Status Load(const EdgeSources& edges, const NodeSources& nodes);
 
 private:
   std::mutex mtx_;

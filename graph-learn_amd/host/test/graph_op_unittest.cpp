@@ -1,0 +1,199 @@
+// Restates the lookup / degree parts of graphlearn/src/core/operator/graph/test/
+// graph_op_unittest.cpp (EdgeLookuper :500-601, NodeLookuper :603-703, DegreeGetter :787-826)
+// against the glx host mirror: TSV sources -> GraphStore::Load (host parse, device build) ->
+// OpFactory::Create(name)->Process.
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "graphlearn/graphlearn.h"
+#include "test_util.h"
+
+using namespace graphlearn;      // NOLINT
+using namespace graphlearn::io;  // NOLINT
+using namespace graphlearn::op;  // NOLINT
+
+namespace {
+
+void GenFile(const std::string& path, bool edge, int32_t format) {
+  std::ofstream out(path);
+  std::string title = edge ? "src_id:int64\tdst_id:int64" : "node_id:int64";
+  if (format & kWeighted) title += "\tweight:float";
+  if (format & kLabeled) title += "\tlabel:int32";
+  if (format & kAttributed) title += "\tattribute:string";
+  out << title << "\n";
+  char buf[96];
+  for (int32_t i = 0; i < 100; ++i) {
+    std::string line = edge ? std::to_string(i) + "\t" + std::to_string(i) : std::to_string(i);
+    if (format & kWeighted) {
+      std::snprintf(buf, sizeof(buf), "\t%f", (float)i);
+      line += buf;
+    }
+    if (format & kLabeled) line += "\t" + std::to_string(i);
+    if (format & kAttributed) {
+      std::snprintf(buf, sizeof(buf), "\t%d:%f:%c", i, (float)i, (char)(i % 26 + 'A'));
+      line += buf;
+    }
+    out << line << "\n";
+  }
+}
+
+void Attr(AttributeInfo* info, int32_t format) {
+  if (format & kAttributed) {
+    info->delimiter = ":";
+    info->types = {kInt32, kFloat, kString};
+    info->hash_buckets = {0, 0, 0};
+  }
+}
+
+GraphStore* g_store = nullptr;
+
+void SetUpStore() {
+  if (g_store) return;
+  GenFile("glx_w_edge_file", true, kWeighted);
+  GenFile("glx_l_edge_file", true, kLabeled);
+  GenFile("glx_a_edge_file", true, kAttributed);
+  GenFile("glx_w_node_file", false, kWeighted);
+  GenFile("glx_l_node_file", false, kLabeled);
+  GenFile("glx_a_node_file", false, kAttributed);
+  std::vector<EdgeSource> edges(3);
+  const char* efiles[3] = {"glx_w_edge_file", "glx_l_edge_file", "glx_a_edge_file"};
+  const char* etypes[3] = {"click", "buy", "watch"};
+  const int32_t formats[3] = {kWeighted, kLabeled, kAttributed};
+  for (int i = 0; i < 3; ++i) {
+    edges[i].path = efiles[i];
+    edges[i].edge_type = etypes[i];
+    edges[i].src_id_type = "user";
+    edges[i].dst_id_type = i == 2 ? "movie" : "item";
+    edges[i].format = formats[i];
+    Attr(&edges[i].attr_info, formats[i]);
+  }
+  std::vector<NodeSource> nodes(3);
+  const char* nfiles[3] = {"glx_w_node_file", "glx_l_node_file", "glx_a_node_file"};
+  const char* ntypes[3] = {"user", "item", "movie"};
+  for (int i = 0; i < 3; ++i) {
+    nodes[i].path = nfiles[i];
+    nodes[i].id_type = ntypes[i];
+    nodes[i].format = formats[i];
+    Attr(&nodes[i].attr_info, formats[i]);
+  }
+  g_store = new GraphStore();
+  Status s = g_store->Load(edges, nodes);
+  for (const char* f : efiles) std::remove(f);
+  for (const char* f : nfiles) std::remove(f);
+  if (!s.ok()) {
+    std::printf("store load failed: %s\n", s.ToString().c_str());
+    std::exit(2);
+  }
+  OpFactory::GetInstance()->Set(g_store);
+}
+
+std::vector<int64_t> Iota(int32_t n) {
+  std::vector<int64_t> v(n);
+  for (int32_t i = 0; i < n; ++i) v[i] = i;
+  return v;
+}
+}  // namespace
+
+TEST(GraphOpTest, EdgeLookuper) {
+  SetUpStore();
+  const std::vector<int64_t> ids = Iota(100);  // edge ids = load order
+  {
+    LookupEdgesRequest req("click");
+    LookupEdgesResponse res;
+    req.Set(ids.data(), ids.data(), 100);
+    Operator* op = OpFactory::GetInstance()->Create(req.Name());
+    EXPECT_TRUE(op != nullptr);
+    EXPECT_TRUE(op->Process(&req, &res).ok());
+    EXPECT_EQ(res.Size(), 100);
+    EXPECT_EQ(res.Format(), (int)kWeighted);
+    EXPECT_EQ(res.IntAttrNum(), 0);
+    EXPECT_EQ(res.FloatAttrNum(), 0);
+    EXPECT_EQ(res.StringAttrNum(), 0);
+    for (int32_t i = 0; i < 100; ++i) EXPECT_TRUE(res.Weights()[i] == (float)i);
+  }
+  {
+    LookupEdgesRequest req("buy");
+    LookupEdgesResponse res;
+    req.Set(ids.data(), ids.data(), 100);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res).ok());
+    EXPECT_EQ(res.Format(), (int)kLabeled);
+    for (int32_t i = 0; i < 100; ++i) EXPECT_EQ(res.Labels()[i], i);
+  }
+  {
+    LookupEdgesRequest req("watch");
+    LookupEdgesResponse res;
+    req.Set(ids.data(), ids.data(), 100);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res).ok());
+    EXPECT_EQ(res.Format(), (int)kAttributed);
+    EXPECT_EQ(res.IntAttrNum(), 1);
+    EXPECT_EQ(res.FloatAttrNum(), 1);
+    EXPECT_EQ(res.StringAttrNum(), 1);
+    for (int32_t i = 0; i < 100; ++i) {
+      EXPECT_EQ(res.IntAttrs()[i], (int64_t)i);
+      EXPECT_TRUE(res.FloatAttrs()[i] == (float)i);
+      EXPECT_EQ(res.StringAttrs()[i], std::string(1, (char)('A' + i % 26)));
+    }
+  }
+}
+
+TEST(GraphOpTest, NodeLookuper) {
+  SetUpStore();
+  const std::vector<int64_t> ids = Iota(100);
+  {
+    LookupNodesRequest req("user");
+    LookupNodesResponse res;
+    req.Set(ids.data(), 100);
+    Operator* op = OpFactory::GetInstance()->Create(req.Name());
+    EXPECT_TRUE(op != nullptr);
+    EXPECT_TRUE(op->Process(&req, &res).ok());
+    EXPECT_EQ(res.Size(), 100);
+    EXPECT_EQ(res.Format(), (int)kWeighted);
+    for (int32_t i = 0; i < 100; ++i) EXPECT_TRUE(res.Weights()[i] == (float)i);
+  }
+  {
+    LookupNodesRequest req("item");
+    LookupNodesResponse res;
+    req.Set(ids.data(), 100);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res).ok());
+    EXPECT_EQ(res.Format(), (int)kLabeled);
+    for (int32_t i = 0; i < 100; ++i) EXPECT_EQ(res.Labels()[i], i);
+  }
+  {
+    LookupNodesRequest req("movie");  // the float attribute comes back from the device (glx_lookup)
+    LookupNodesResponse res;
+    req.Set(ids.data(), 100);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res).ok());
+    EXPECT_EQ(res.IntAttrNum(), 1);
+    EXPECT_EQ(res.FloatAttrNum(), 1);
+    EXPECT_EQ(res.StringAttrNum(), 1);
+    for (int32_t i = 0; i < 100; ++i) {
+      EXPECT_EQ(res.IntAttrs()[i], (int64_t)i);
+      EXPECT_TRUE(res.FloatAttrs()[i] == (float)i);
+      EXPECT_EQ(res.StringAttrs()[i], std::string(1, (char)('A' + i % 26)));
+    }
+  }
+}
+
+TEST(GraphOpTest, DegreeGetter) {
+  SetUpStore();
+  const std::vector<int64_t> ids = Iota(64);
+  for (NodeFrom from : {kEdgeSrc, kEdgeDst}) {
+    GetDegreeRequest req("click", from);
+    req.Set(ids.data(), 64);
+    GetDegreeResponse res;
+    Operator* op = OpFactory::GetInstance()->Create(req.Name());
+    EXPECT_TRUE(op != nullptr);
+    EXPECT_TRUE(op->Process(&req, &res).ok());
+    for (int32_t i = 0; i < 64; ++i) EXPECT_EQ(res.GetDegrees()[i], 1);  // every i has exactly the edge i -> i
+  }
+  std::vector<int64_t> unknown = {100, 5000, -1};
+  GetDegreeRequest req("click", kEdgeSrc);
+  req.Set(unknown.data(), 3);
+  GetDegreeResponse res;
+  EXPECT_TRUE(OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res).ok());
+  for (int32_t i = 0; i < 3; ++i) EXPECT_EQ(res.GetDegrees()[i], 0);
+}
+
+int main() { return RunAllTests(); }

@@ -11,7 +11,7 @@ import pytest
 import glx
 
 LIB = os.path.join(os.path.dirname(glx.LIB_PATH))
-BINARIES = ["sampler_unittest", "aggregating_op_unittest", "partition_stitch_unittest"]
+BINARIES = ["sampler_unittest", "aggregating_op_unittest", "partition_stitch_unittest", "graph_op_unittest"]
 
 
 def run(name):
