@@ -112,5 +112,57 @@ public:
   int32_t* MutableDegrees();
 };
 
+// GetNodes / GetEdges (graph_request.h:60-260; operators core/operator/graph/node_getter.cc,
+// edge_getter.cc over node_generator.h / edge_generator.h): batch traversal of a type's
+// ids.  strategy "by_order" | "shuffle" | "random".  The cursor lives with the operator,
+// one per (type, node_from): a batch may be short at the end of an epoch, the call after it
+// returns OUT_OF_RANGE and starts the next epoch; a request whose `epoch` is behind the
+// generator's is OUT_OF_RANGE too (its caller has not noticed the epoch change yet).
+class GetNodesRequest : public OpRequest {
+public:
+  GetNodesRequest();
+  GetNodesRequest(const std::string& type, const std::string& strategy, NodeFrom node_from, int32_t batch_size,
+                  int32_t epoch = 0);
+  OpRequest* Clone() const override;
+  const std::string& Type() const;
+  const std::string& Strategy() const;
+  NodeFrom GetNodeFrom() const;
+  int32_t BatchSize() const;
+  int32_t Epoch() const;
+};
+
+class GetNodesResponse : public OpResponse {
+public:
+  GetNodesResponse();
+  OpResponse* New() const override { return new GetNodesResponse; }
+  void Init(int32_t batch_size);
+  void Append(int64_t node_id);
+  int32_t Size() const { return batch_size_; }
+  const int64_t* NodeIds() const;
+};
+
+class GetEdgesRequest : public OpRequest {
+public:
+  GetEdgesRequest();
+  GetEdgesRequest(const std::string& edge_type, const std::string& strategy, int32_t batch_size, int32_t epoch = 0);
+  OpRequest* Clone() const override;
+  const std::string& EdgeType() const;
+  const std::string& Strategy() const;
+  int32_t BatchSize() const;
+  int32_t Epoch() const;
+};
+
+class GetEdgesResponse : public OpResponse {
+public:
+  GetEdgesResponse();
+  OpResponse* New() const override { return new GetEdgesResponse; }
+  void Init(int32_t batch_size);
+  void Append(int64_t src_id, int64_t dst_id, int64_t edge_id);
+  int32_t Size() const { return batch_size_; }
+  const int64_t* SrcIds() const;
+  const int64_t* DstIds() const;
+  const int64_t* EdgeIds() const;
+};
+
 }  // namespace graphlearn
 #endif  // GLX_HOST_GRAPH_REQUEST_H_

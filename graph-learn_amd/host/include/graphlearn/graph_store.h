@@ -213,6 +213,9 @@ public:
   ~GraphStore();
   Graph* GetGraph(const std::string& edge_type);
   Noder* GetNoder(const std::string& node_type);
+  // Distinguishes stores over the process lifetime (an address can be reused): operators that
+  // keep per-store state (traversal cursors) key it by this.
+  uint64_t Uid() const { return uid_; }
   // Build every storage added so far (GraphStore::Build, graph_store.cc:252-276).
   Status Build(const IndexOption& option);
   // Load every source, then Build (GraphStore::Load, graph_store.cc:60-120): declared in
@@ -221,6 +224,7 @@ public:
   Status Load(const EdgeSources& edges, const NodeSources& nodes);
 
 private:
+  uint64_t uid_;
   std::mutex mtx_;
   std::unordered_map<std::string, Graph*> graphs_;
   std::unordered_map<std::string, Noder*> noders_;

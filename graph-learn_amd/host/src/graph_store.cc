@@ -1,6 +1,7 @@
 // GraphStore / Graph / Noder: host staging -> CSR -> device (see graph_store.h).
 #include "graphlearn/graph_store.h"
 
+#include <atomic>
 #include <iterator>
 
 #include "glx.h"
@@ -255,7 +256,11 @@ Status Noder::Build(const IndexOption&) {
 }
 
 // ------------------------------------------------------------- GraphStore --
-GraphStore::GraphStore() {}
+namespace {
+std::atomic<uint64_t> g_next_store_uid{1};
+}
+
+GraphStore::GraphStore() : uid_(g_next_store_uid.fetch_add(1)) {}
 
 GraphStore::~GraphStore() {
   for (auto& it : graphs_) delete it.second;

@@ -2,6 +2,7 @@
 // graph_op_unittest.cpp (EdgeLookuper :500-601, NodeLookuper :603-703, DegreeGetter :787-826)
 // against the glx host mirror: TSV sources -> GraphStore::Load (host parse, device build) ->
 // OpFactory::Create(name)->Process.
+#include <algorithm>
 #include <cstdio>
 #include <fstream>
 #include <string>
@@ -194,6 +195,81 @@ TEST(GraphOpTest, DegreeGetter) {
   GetDegreeResponse res;
   EXPECT_TRUE(OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res).ok());
   for (int32_t i = 0; i < 3; ++i) EXPECT_EQ(res.GetDegrees()[i], 0);
+}
+
+TEST(GraphOpTest, EdgeGetter) {
+  // graph_op_unittest.cpp:219-281: batches of 12 over 100 edges: 8 full, one of 4, then OutOfRange
+  SetUpStore();
+  for (const char* type : {"click", "buy", "watch"}) {
+    std::vector<int64_t> seen;
+    for (int index = 0; index < 10; ++index) {
+      GetEdgesRequest req(type, "by_order", 12);
+      GetEdgesResponse res;
+      Operator* op = OpFactory::GetInstance()->Create(req.Name());
+      EXPECT_TRUE(op != nullptr);
+      Status s = op->Process(&req, &res);
+      if (index == 9) {
+        EXPECT_EQ((int)s.code(), (int)error::OUT_OF_RANGE);
+        break;
+      }
+      EXPECT_TRUE(s.ok());
+      EXPECT_EQ(res.Size(), index < 8 ? 12 : 4);
+      for (int32_t i = 0; i < res.Size(); ++i) {
+        EXPECT_EQ(res.SrcIds()[i], res.DstIds()[i]);
+        EXPECT_EQ(res.EdgeIds()[i], res.SrcIds()[i]);  // record i is edge i
+        seen.push_back(res.SrcIds()[i]);
+      }
+    }
+    EXPECT_EQ(seen.size(), (size_t)100);
+    for (size_t i = 0; i < seen.size(); ++i) EXPECT_EQ(seen[i], (int64_t)i);
+    // the next epoch needs a request that knows about it
+    GetEdgesRequest stale(type, "by_order", 12, 0);
+    GetEdgesResponse r0;
+    EXPECT_EQ((int)OpFactory::GetInstance()->Create("GetEdges")->Process(&stale, &r0).code(), (int)error::OUT_OF_RANGE);
+    GetEdgesRequest fresh(type, "by_order", 12, 1);
+    GetEdgesResponse r1;
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("GetEdges")->Process(&fresh, &r1).ok());
+    EXPECT_EQ(r1.Size(), 12);
+  }
+}
+
+TEST(GraphOpTest, NodeGetters) {
+  // NodeGetter :283-341, ShuffledNodeGetter :343-401, NodeGetterFromEdgeSrc :403-498
+  SetUpStore();
+  for (const char* strategy : {"by_order", "shuffle"}) {
+    for (const char* type : {"user", "item", "movie"}) {
+      std::vector<int64_t> seen;
+      for (int index = 0; index < 10; ++index) {
+        GetNodesRequest req(type, strategy, kNode, 12);
+        GetNodesResponse res;
+        Status s = OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res);
+        if (index == 9) {
+          EXPECT_EQ((int)s.code(), (int)error::OUT_OF_RANGE);
+          break;
+        }
+        EXPECT_TRUE(s.ok());
+        EXPECT_EQ(res.Size(), index < 8 ? 12 : 4);
+        for (int32_t i = 0; i < res.Size(); ++i) seen.push_back(res.NodeIds()[i]);
+      }
+      std::vector<int64_t> sorted = seen;
+      std::sort(sorted.begin(), sorted.end());
+      for (size_t i = 0; i < sorted.size(); ++i) EXPECT_EQ(sorted[i], (int64_t)i);  // every id exactly once
+      if (std::string(strategy) == "by_order") EXPECT_TRUE(seen == sorted);
+      else EXPECT_TRUE(seen != sorted);
+    }
+  }
+  for (NodeFrom from : {kEdgeSrc, kEdgeDst}) {
+    GetNodesRequest req("click", "by_order", from, 64);
+    GetNodesResponse res;
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(req.Name())->Process(&req, &res).ok());
+    EXPECT_EQ(res.Size(), 64);
+    for (int32_t i = 0; i < 64; ++i) EXPECT_EQ(res.NodeIds()[i], (int64_t)i);
+  }
+  GetNodesRequest rnd("user", "random", kNode, 500);
+  GetNodesResponse res;
+  EXPECT_TRUE(OpFactory::GetInstance()->Create(rnd.Name())->Process(&rnd, &res).ok());
+  EXPECT_EQ(res.Size(), 500);
+  for (int32_t i = 0; i < 500; ++i) EXPECT_TRUE(res.NodeIds()[i] >= 0 && res.NodeIds()[i] < 100);
 }
 
 int main() { return RunAllTests(); }

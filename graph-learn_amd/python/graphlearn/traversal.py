@@ -1,20 +1,19 @@
 """Batch traversal samplers: g.node_sampler(...) / g.edge_sampler(...)
-(graphlearn/python/sampler/{node,edge}_sampler.py over the GetNodes / GetEdges operators,
+(graphlearn/python/sampler/{node,edge}_sampler.py over the "GetNodes" / "GetEdges" operators,
 core/operator/graph/node_getter.cc:62-91, node_generator.h).
 
-They iterate the store's id lists -- a node type's ids in insertion order, an edge type's
-edges in edge-id order, or an edge type's distinct source / destination ids in
-first-appearance order (GetAllSrcIds / GetAllDstIds) -- in one of three ways:
-  by_order  consecutive batches; the last batch of an epoch may be short; the call after
-            it raises gl.OutOfRangeError and the next epoch starts
+They walk the store's id lists -- a node type's ids in insertion order, an edge type's edges
+in edge-id order, or an edge type's distinct source / destination ids in first-appearance
+order -- in one of three ways:
+  by_order  consecutive batches; the last batch of an epoch may be short; the call after it
+            raises gl.OutOfRangeError and the next epoch starts
   shuffle   the same over a fresh permutation every epoch
   random    independent uniform draws, never out of range
-Samplers over the same (type, node_from) share one cursor, like the reference's server-side
-state map.  This is host-side bookkeeping (seed selection for the device samplers): the id
-lists are fetched from the engine once and kept as numpy arrays.
+The cursor lives with the engine's operator, one per (type, node_from), so samplers over the
+same type share it, like the reference's server-side state; the Graph object remembers the
+epoch it has seen per type (graph.py node_state / edge_state in the reference).  This is
+host-side bookkeeping: seed selection for the device samplers.
 """
-import numpy as np
-
 from graphlearn import pywrap_graphlearn as pywrap
 from graphlearn import errors
 from graphlearn.utils import Mask, get_mask_type
@@ -22,88 +21,55 @@ from graphlearn.utils import Mask, get_mask_type
 __all__ = ["NodeSampler", "RandomNodeSampler", "ByOrderNodeSampler", "ShuffleNodeSampler", "EdgeSampler",
            "RandomEdgeSampler", "ByOrderEdgeSampler", "ShuffleEdgeSampler"]
 
-
-def _first_appearance(ids):
-  _, first = np.unique(ids, return_index=True)
-  return ids[np.sort(first)]
+_STRATEGIES = ("by_order", "random", "shuffle")
 
 
-class _Cursor(object):
-  """Shared epoch state of one id list (node_generator.h State/StateMap)."""
-
-  def __init__(self, size, seed):
-    self.size = size
-    self.at = 0
-    self.epoch = 0
-    self.rng = np.random.default_rng(seed)
-    self.perm = None
-
-  def take(self, batch_size, strategy):
-    """-> positions into the id list"""
-    if strategy == "random":
-      return self.rng.integers(0, self.size, batch_size)
-    if strategy == "shuffle" and self.perm is None:
-      self.perm = self.rng.permutation(self.size)
-    if self.at >= self.size:  # nothing left: begin the next epoch, report the boundary
-      self.at = 0
-      self.epoch += 1
-      self.perm = None
-      raise errors.OutOfRangeError("No more nodes exist.", pywrap.ErrorCode.OUT_OF_RANGE)
-    pos = np.arange(self.at, min(self.at + batch_size, self.size))
-    self.at += pos.size
-    return self.perm[pos] if strategy == "shuffle" else pos
+def _epochs(graph):
+  return graph.__dict__.setdefault("_traversal_epochs", {})
 
 
-class _Traversal(object):
-  _STRATEGIES = ("by_order", "random", "shuffle")
+def _run(graph, key, make_request, new_response, call, read):
+  """One GetNodes / GetEdges call with the caller-side epoch protocol."""
+  epochs = _epochs(graph)
+  req = make_request(epochs.get(key, 0))
+  res = new_response()
+  status = call(req, res)
+  out = read(res) if status.ok() else None
+  if not status.ok() and status.code() == pywrap.ErrorCode.OUT_OF_RANGE:
+    epochs[key] = epochs.get(key, 0) + 1  # the engine has moved on to the next epoch
+  pywrap.del_op_response(res)
+  pywrap.del_op_request(req)
+  errors.raise_exception_on_not_ok_status(status)
+  return out
 
-  def __init__(self, graph, batch_size, strategy):
-    if strategy not in self._STRATEGIES:
-      raise ValueError("strategy must be one of {}".format(self._STRATEGIES))
+
+class NodeSampler(object):
+
+  def __init__(self, graph, t, batch_size, strategy="by_order", node_from=pywrap.NodeFrom.NODE, mask=Mask.NONE):
+    if strategy not in _STRATEGIES:
+      raise ValueError("strategy must be one of {}".format(_STRATEGIES))
     self._graph = graph
     self._batch_size = int(batch_size)
     self._strategy = strategy
-
-  def _cursor(self, key, size):
-    states = self._graph.__dict__.setdefault("_traversal_state", {})
-    full = key + (self._strategy == "shuffle",)
-    if full not in states:
-      from graphlearn import settings
-      states[full] = _Cursor(size, settings._MIRROR["sampling_seed"] + len(states))  # pylint: disable=protected-access
-    return states[full]
-
-
-class NodeSampler(_Traversal):
-
-  def __init__(self, graph, t, batch_size, strategy="by_order", node_from=pywrap.NodeFrom.NODE, mask=Mask.NONE):
-    super(NodeSampler, self).__init__(graph, batch_size, strategy)
     self._node_from = node_from
-    stored = get_mask_type(t, mask)
-    server = graph.get_server()
+    self._stored = get_mask_type(t, mask)
     if node_from == pywrap.NodeFrom.NODE:
-      if stored not in graph.get_node_decoders():
-        raise ValueError("Graph has no node type of {}".format(stored))
+      if self._stored not in graph.get_node_decoders():
+        raise ValueError("Graph has no node type of {}".format(self._stored))
       self._node_type = t
-      self._key = ("node", stored, int(node_from))
-      self._load = lambda: server.node_ids(stored)
     else:
       topo = graph.get_topology()
-      src_type, dst_type = topo.get_src_type(stored), topo.get_dst_type(stored)
-      from_src = node_from == pywrap.NodeFrom.EDGE_SRC
-      self._node_type = src_type if from_src else dst_type
-      self._key = ("edge", stored, int(node_from))
-      self._load = lambda: _first_appearance(server.edge_src_ids(stored) if from_src else server.edge_dst_ids(stored))
-    self._ids = None
+      src_type, dst_type = topo.get_src_type(self._stored), topo.get_dst_type(self._stored)
+      self._node_type = src_type if node_from == pywrap.NodeFrom.EDGE_SRC else dst_type
 
   def get(self):
     """-> Nodes of shape [batch_size] (shorter at the end of an epoch)"""
-    if self._ids is None:
-      cache = self._graph.__dict__.setdefault("_traversal_ids", {})
-      if self._key not in cache:
-        cache[self._key] = self._load()
-      self._ids = cache[self._key]
-    pos = self._cursor(self._key, self._ids.shape[0]).take(self._batch_size, self._strategy)
-    return self._graph.get_nodes(self._node_type, self._ids[pos])
+    client = self._graph.get_client()
+    ids = _run(self._graph, ("nodes", self._stored, int(self._node_from), self._strategy == "shuffle"),
+               lambda epoch: pywrap.new_get_nodes_request(self._stored, self._strategy, self._node_from,
+                                                          self._batch_size, epoch),
+               pywrap.new_get_nodes_response, client.get_nodes, pywrap.get_node_ids)
+    return self._graph.get_nodes(self._node_type, ids)
 
 
 class RandomNodeSampler(NodeSampler):
@@ -118,29 +84,27 @@ class ShuffleNodeSampler(NodeSampler):
   pass
 
 
-class EdgeSampler(_Traversal):
+class EdgeSampler(object):
 
   def __init__(self, graph, edge_type, batch_size, strategy="by_order", mask=Mask.NONE):
-    super(EdgeSampler, self).__init__(graph, batch_size, strategy)
-    self._edge_type = edge_type
+    if strategy not in _STRATEGIES:
+      raise ValueError("strategy must be one of {}".format(_STRATEGIES))
+    self._graph = graph
+    self._batch_size = int(batch_size)
+    self._strategy = strategy
     self._stored = get_mask_type(edge_type, mask)
     if self._stored not in graph.get_edge_decoders():
       raise ValueError("Graph has no edge type of {}".format(self._stored))
-    self._lists = None
 
   def get(self):
     """-> Edges of shape [batch_size]; edge ids are positions in load order"""
-    if self._lists is None:
-      cache = self._graph.__dict__.setdefault("_traversal_ids", {})
-      key = ("edges", self._stored)
-      if key not in cache:
-        server = self._graph.get_server()
-        cache[key] = (server.edge_src_ids(self._stored), server.edge_dst_ids(self._stored))
-      self._lists = cache[key]
-    src, dst = self._lists
-    pos = self._cursor(("edges", self._stored, 0), src.shape[0]).take(self._batch_size, self._strategy)
-    edges = self._graph.get_edges(self._stored, src[pos], dst[pos])
-    edges.edge_ids = np.asarray(pos, dtype=np.int64)
+    client = self._graph.get_client()
+    src, dst, eid = _run(self._graph, ("edges", self._stored, self._strategy == "shuffle"),
+                         lambda epoch: pywrap.new_get_edges_request(self._stored, self._strategy, self._batch_size, epoch),
+                         pywrap.new_get_edges_response, client.get_edges,
+                         lambda res: (pywrap.get_edge_src_id(res), pywrap.get_edge_dst_id(res), pywrap.get_edge_id(res)))
+    edges = self._graph.get_edges(self._stored, src, dst)
+    edges.edge_ids = eid
     return edges
 
 

@@ -223,6 +223,8 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
              return self.GetDegree(As<GetDegreeRequest>(req, "GetDegreeRequest"), As<GetDegreeResponse>(res, "GetDegreeResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
+      .def("get_nodes", [](Client& self, OpRequest* req, OpResponse* res) { return self.RunOp(req, res); })
+      .def("get_edges", [](Client& self, OpRequest* req, OpResponse* res) { return self.RunOp(req, res); })
       .def("run_op", &Client::RunOp, py::call_guard<py::gil_scoped_release>());
   m.def("in_memory_client", &NewInMemoryClient, py::return_value_policy::take_ownership);
 
@@ -318,6 +320,37 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       return py::array(py::module_::import("numpy").attr("array")(out, py::arg("dtype") = "object"));
     });
   }
+
+  // ---- batch traversal (py_client.cc:131-149, 208-239) ----
+  m.def("new_get_nodes_request",
+        [](const std::string& type, const std::string& strategy, NodeFrom node_from, int32_t batch_size,
+           int32_t epoch) -> OpRequest* { return new GetNodesRequest(type, strategy, node_from, batch_size, epoch); },
+        py::return_value_policy::reference);
+  m.def("new_get_nodes_response", []() -> OpResponse* { return new GetNodesResponse(); },
+        py::return_value_policy::reference);
+  m.def("get_node_ids", [](OpResponse* res) {
+    GetNodesResponse* r = As<GetNodesResponse>(res, "GetNodesResponse");
+    return CopyOut(r->NodeIds(), (size_t)r->Size());
+  });
+  m.def("new_get_edges_request",
+        [](const std::string& edge_type, const std::string& strategy, int32_t batch_size, int32_t epoch) -> OpRequest* {
+          return new GetEdgesRequest(edge_type, strategy, batch_size, epoch);
+        },
+        py::return_value_policy::reference);
+  m.def("new_get_edges_response", []() -> OpResponse* { return new GetEdgesResponse(); },
+        py::return_value_policy::reference);
+  m.def("get_edge_src_id", [](OpResponse* res) {
+    GetEdgesResponse* r = As<GetEdgesResponse>(res, "GetEdgesResponse");
+    return CopyOut(r->SrcIds(), (size_t)r->Size());
+  });
+  m.def("get_edge_dst_id", [](OpResponse* res) {
+    GetEdgesResponse* r = As<GetEdgesResponse>(res, "GetEdgesResponse");
+    return CopyOut(r->DstIds(), (size_t)r->Size());
+  });
+  m.def("get_edge_id", [](OpResponse* res) {
+    GetEdgesResponse* r = As<GetEdgesResponse>(res, "GetEdgesResponse");
+    return CopyOut(r->EdgeIds(), (size_t)r->Size());
+  });
 
   // ---- degrees (py_client.cc:468-491) ----
   m.def("new_get_degree_request",
