@@ -216,6 +216,9 @@ public:
   // Distinguishes stores over the process lifetime (an address can be reused): operators that
   // keep per-store state (traversal cursors) key it by this.
   uint64_t Uid() const { return uid_; }
+  // type -> number of nodes / edges held (GetStats: core/operator/graph/stats_getter.cc)
+  std::unordered_map<std::string, int64_t> NodeCounts();
+  std::unordered_map<std::string, int64_t> EdgeCounts();
   // Build every storage added so far (GraphStore::Build, graph_store.cc:252-276).
   Status Build(const IndexOption& option);
   // Load every source, then Build (GraphStore::Load, graph_store.cc:60-120): declared in

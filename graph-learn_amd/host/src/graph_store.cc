@@ -293,6 +293,20 @@ Status GraphStore::Build(const IndexOption& option) {
   return Status::OK();
 }
 
+std::unordered_map<std::string, int64_t> GraphStore::NodeCounts() {
+  std::lock_guard<std::mutex> g(mtx_);
+  std::unordered_map<std::string, int64_t> out;
+  for (auto& it : noders_) out[it.first] = it.second->GetNodeCount();
+  return out;
+}
+
+std::unordered_map<std::string, int64_t> GraphStore::EdgeCounts() {
+  std::lock_guard<std::mutex> g(mtx_);
+  std::unordered_map<std::string, int64_t> out;
+  for (auto& it : graphs_) out[it.first] = it.second->GetEdgeCount();
+  return out;
+}
+
 Noder* GraphStore::GetNoder(const std::string& node_type) {
   std::lock_guard<std::mutex> g(mtx_);
   auto it = noders_.find(node_type);

@@ -218,6 +218,13 @@ class Graph(object):
     return self._run_lookup("edge", edge_type, self.get_edge_decoder(edge_type),
                             lambda req: pywrap.set_lookup_edges_request(req, src_ids, edge_ids))
 
+  def get_stats(self):
+    """Number of nodes / edges held per type (graph.py:1083-1096 in the reference; one store here,
+    so every list has one entry)."""
+    stats = {t: [n] for t, n in self._server.node_counts().items()}
+    stats.update({t: [n] for t, n in self._server.edge_counts().items()})
+    return stats
+
   def _degrees(self, ids, edge_type, node_from):
     ids = np.array(ids)
     req = pywrap.new_get_degree_request(edge_type, node_from)

@@ -172,6 +172,8 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       .def("init", &Server::Init, py::call_guard<py::gil_scoped_release>())
       .def("init_status", &Server::InitStatus)
       .def("device_graph", &Server::DeviceGraph)
+      .def("node_counts", [](Server& self) { return self.Store()->NodeCounts(); })
+      .def("edge_counts", [](Server& self) { return self.Store()->EdgeCounts(); })
       // id lists of the store for the batch-traversal samplers (node_generator.h / edge_generator.h)
       .def("node_ids", [](Server& self, const std::string& node_type) {
         const std::vector<int64_t>& ids = self.Store()->GetNoder(node_type)->Ids();

@@ -482,6 +482,14 @@ def test_python_stack_equals_live_reference_on_the_same_records(gl, g):
         ref.close()
 
 
+def test_get_stats(gl, g):
+    stats = g.get_stats()
+    assert stats[NODE1] == [100] and stats[NODE2] == [100] and stats["entity"] == [120]
+    assert stats[EDGE2] == [len(fx.fixed_dst_ids(range(*RANGE2), RANGE1))]
+    assert stats[EDGE3] == [2 * len(fx.fixed_dst_ids(range(*RANGE2), RANGE2))]  # directed=False on a homogeneous type
+    assert stats["MASK*node1"] == [50]
+
+
 def test_in_and_out_degree_lookups(gl, g):
     """Graph.out_degrees / in_degrees (GetDegree with NodeFrom EDGE_SRC / EDGE_DST) against the generator."""
     ids = np.array([102, 105, 107, 199, 5000])
