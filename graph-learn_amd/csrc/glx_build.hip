@@ -66,7 +66,7 @@ inline unsigned grid_for(int64_t n) {
   } while (0)
 
 int build_impl(glx_graph* g, const int64_t* src, const int64_t* dst, const float* weight,
-               const int64_t* edge_ids, int sort_by_weight, int ptr_kind, hipStream_t s) {
+               const int64_t* edge_ids, const int64_t* timestamp, int order, int ptr_kind, hipStream_t s) {
   const int64_t E = g->num_edges;
   const hipMemcpyKind kind = ptr_kind == GLX_PTR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   if (E == 0) {
@@ -80,7 +80,8 @@ int build_impl(glx_graph* g, const int64_t* src, const int64_t* dst, const float
     return glx_graph_finalize(g, dummy_ids.as<int64_t>(), s);
   }
   // stage the edge list on the device
-  GlxTemp h_src, h_dst, h_w, h_eid;
+  GlxTemp h_src, h_dst, h_w, h_eid, h_ts;
+  const int64_t* d_ts = timestamp;
   const int64_t* d_eid = edge_ids;
   const int64_t* d_src = src;
   const int64_t* d_dst = dst;
@@ -102,6 +103,11 @@ int build_impl(glx_graph* g, const int64_t* src, const int64_t* dst, const float
       GLX_HIP(hipMemcpyAsync(h_w.p, weight, (size_t)E * 4, kind, s));
       d_w = h_w.as<float>();
     }
+    if (timestamp && order == GLX_ORDER_TIMESTAMP_ASC) {
+      GLX_HIP(hipMalloc(&h_ts.p, (size_t)E * 8));
+      GLX_HIP(hipMemcpyAsync(h_ts.p, timestamp, (size_t)E * 8, kind, s));
+      d_ts = h_ts.as<int64_t>();
+    }
   }
   GlxTemp perm_a, perm_b, keys_a, keys_b;
   GLX_HIP(hipMalloc(&perm_a.p, (size_t)E * 8));
@@ -110,7 +116,17 @@ int build_impl(glx_graph* g, const int64_t* src, const int64_t* dst, const float
   int64_t* pb = perm_b.as<int64_t>();
   glx_iota_kernel<<<grid_for(E), 256, 0, s>>>(pa, E);
   const size_t n = (size_t)E;
-  if (weight && sort_by_weight) {
+  if (timestamp && order == GLX_ORDER_TIMESTAMP_ASC) {
+    // pass 1 for timestamped types: timestamp ascending, stable (MemoryAdjMatrix::SortByTimestamp,
+    // memory_adj_matrix.cc:129-148; it takes precedence over the weight order, :60-66)
+    GlxTemp tk;
+    GLX_HIP(hipMalloc(&tk.p, (size_t)E * 8));
+    int64_t* ts_sorted = tk.as<int64_t>();
+#define SORT_T(tmp, bytes) rocprim::radix_sort_pairs(tmp, bytes, d_ts, ts_sorted, pa, pb, n, 0, 64, s)
+    GLX_ROCPRIM(SORT_T);
+#undef SORT_T
+    int64_t* t = pa; pa = pb; pb = t;
+  } else if (weight && order == GLX_ORDER_WEIGHT_DESC) {
     // pass 1: weight descending, stable (ties keep insertion order)
     GlxTemp wk;
     GLX_HIP(hipMalloc(&wk.p, (size_t)E * 4));
@@ -169,7 +185,17 @@ int build_impl(glx_graph* g, const int64_t* src, const int64_t* dst, const float
 extern "C" int glx_graph_build(int device, int64_t num_edges, const int64_t* src, const int64_t* dst,
                                const float* weight, const int64_t* edge_ids, int sort_by_weight,
                                int ptr_kind, void* stream, glx_graph** out) {
+  return glx_graph_build_ordered(device, num_edges, src, dst, weight, edge_ids, nullptr,
+                                 sort_by_weight ? GLX_ORDER_WEIGHT_DESC : GLX_ORDER_INSERTION, ptr_kind, stream, out);
+}
+
+extern "C" int glx_graph_build_ordered(int device, int64_t num_edges, const int64_t* src, const int64_t* dst,
+                                       const float* weight, const int64_t* edge_ids, const int64_t* timestamp,
+                                       int order, int ptr_kind, void* stream, glx_graph** out) {
   GLX_REQUIRE(out != nullptr, "out is NULL");
+  GLX_REQUIRE(order >= GLX_ORDER_INSERTION && order <= GLX_ORDER_TIMESTAMP_ASC, "unknown row order %d", order);
+  GLX_REQUIRE(order != GLX_ORDER_TIMESTAMP_ASC || num_edges == 0 || timestamp != nullptr,
+              "GLX_ORDER_TIMESTAMP_ASC needs timestamps");
   *out = nullptr;
   GLX_REQUIRE(num_edges >= 0, "negative num_edges");
   GLX_REQUIRE(num_edges == 0 || (src && dst), "src/dst must not be NULL");
@@ -183,7 +209,7 @@ extern "C" int glx_graph_build(int device, int64_t num_edges, const int64_t* src
   memset(static_cast<void*>(g), 0, sizeof(*g));
   g->device = device;
   g->num_edges = num_edges;
-  rc = build_impl(g, src, dst, weight, edge_ids, sort_by_weight, ptr_kind, glx_stream(stream));
+  rc = build_impl(g, src, dst, weight, edge_ids, timestamp, order, ptr_kind, glx_stream(stream));
   if (rc != GLX_OK) {
     glx_graph_free(g);
     return rc;

@@ -38,7 +38,7 @@ AGGREGATOR_IDS = {
 
 EXPORTS = [
     "glx_abi_version", "glx_device_count", "glx_last_error",
-    "glx_graph_create", "glx_graph_build", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
+    "glx_graph_create", "glx_graph_build", "glx_graph_build_ordered", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
     "glx_graph_degrees", "glx_graph_in_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
     "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
@@ -84,6 +84,7 @@ def lib():
         L.glx_graph_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ci),
                                      ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.glx_graph_export_alias.argtypes = [vp, vp, vp, ci, vp]
+        L.glx_graph_build_ordered.argtypes = [ci, i64, vp, vp, vp, vp, vp, ci, ci, vp, ctypes.POINTER(vp)]
         L.glx_graph_degrees.argtypes = [vp, vp, i64, vp, ci, vp]
         L.glx_graph_in_degrees.argtypes = [vp, vp, i64, vp, ci, vp]
         L.glx_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
@@ -175,16 +176,18 @@ class Graph:
         self._h = h
 
     @classmethod
-    def from_edges(cls, src, dst, weight=None, edge_ids=None, sort_by_weight=True, device=0):
+    def from_edges(cls, src, dst, weight=None, edge_ids=None, sort_by_weight=True, device=0, timestamp=None):
         """Device-side build from a raw edge list in insertion order (edge id = index,
-        or edge_ids[i] for a shard's subset of a global edge list)."""
+        or edge_ids[i] for a shard's subset of a global edge list).  Rows are ordered by
+        timestamp ascending when timestamps are given (timestamped edge types), else by
+        weight descending (sort_by_weight), else left in insertion order."""
         self = cls.__new__(cls)
-        ptrs = [_ptr(src), _ptr(dst), _ptr(weight), _ptr(edge_ids)]
+        ptrs = [_ptr(src), _ptr(dst), _ptr(weight), _ptr(edge_ids), _ptr(timestamp)]
         kind = _kind(*ptrs)
         h = ctypes.c_void_p()
-        _check(lib().glx_graph_build(device, int(src.shape[0]), ptrs[0][0], ptrs[1][0], ptrs[2][0],
-                                     ptrs[3][0], 1 if sort_by_weight else 0, kind, _stream(kind),
-                                     ctypes.byref(h)))
+        order = 2 if timestamp is not None else (1 if sort_by_weight else 0)
+        _check(lib().glx_graph_build_ordered(device, int(src.shape[0]), ptrs[0][0], ptrs[1][0], ptrs[2][0],
+                                             ptrs[3][0], ptrs[4][0], order, kind, _stream(kind), ctypes.byref(h)))
         self._h = h
         self.device = device
         v, e = ctypes.c_int64(), ctypes.c_int64()

@@ -132,9 +132,16 @@ Status Graph::Build(const IndexOption& option) {
   // memory_adj_matrix.cc:105-125; ties keep insertion order, which the reference's
   // std::sort leaves unspecified).
   const bool weighted = info_.IsWeighted();
-  int rc = glx_graph_build(GLOBAL_FLAG(DeviceId), (int64_t)src_.size(), src_.data(), dst_.data(),
-                           weighted ? weight_.data() : nullptr, nullptr,
-                           (weighted && option.name == "sort") ? 1 : 0, GLX_PTR_HOST, nullptr, &dev_);
+  const bool sorted = option.name == "sort";
+  // Build() orders timestamped types by timestamp, else weighted types by weight
+  // (memory_adj_matrix.cc:60-66)
+  const int order = !sorted ? GLX_ORDER_INSERTION
+                            : info_.IsTimestamped() ? GLX_ORDER_TIMESTAMP_ASC
+                                                    : weighted ? GLX_ORDER_WEIGHT_DESC : GLX_ORDER_INSERTION;
+  int rc = glx_graph_build_ordered(GLOBAL_FLAG(DeviceId), (int64_t)src_.size(), src_.data(), dst_.data(),
+                                   weighted ? weight_.data() : nullptr, nullptr,
+                                   info_.IsTimestamped() ? timestamp_.data() : nullptr, order, GLX_PTR_HOST, nullptr,
+                                   &dev_);
   return error::FromGlx(rc);
 }
 

@@ -116,6 +116,16 @@ GLX_API int glx_graph_create(int device, int64_t num_rows, int64_t num_edges, co
 GLX_API int glx_graph_build(int device, int64_t num_edges, const int64_t* src, const int64_t* dst,
                     const float* weight, const int64_t* edge_ids, int sort_by_weight, int ptr_kind,
                     void* stream, glx_graph** out);
+/* Same, with the row order spelled out.  GLX_ORDER_TIMESTAMP_ASC orders every row by the
+ * edges' timestamps ascending, which is what Build() does for timestamped edge types -- it
+ * takes precedence over the weight order (memory_adj_matrix.cc:60-66,129-148); ties keep
+ * insertion order.  timestamp[num_edges] is only read for that order. */
+#define GLX_ORDER_INSERTION 0
+#define GLX_ORDER_WEIGHT_DESC 1
+#define GLX_ORDER_TIMESTAMP_ASC 2
+GLX_API int glx_graph_build_ordered(int device, int64_t num_edges, const int64_t* src, const int64_t* dst,
+                            const float* weight, const int64_t* edge_ids, const int64_t* timestamp, int order,
+                            int ptr_kind, void* stream, glx_graph** out);
 GLX_API void glx_graph_destroy(glx_graph* g);
 GLX_API int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges, int* weighted,
                    int* has_id_map, int* device);

@@ -599,3 +599,27 @@ int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const
   if (exclude == 1 && g->ids) idmap_free(&m);
   return 0;
 }
+
+void glxo_sort_rows_by_timestamp_asc(const int64_t* row_ptr, int64_t V, int64_t* col, int64_t* eid,
+                                     int64_t* ts_slot, float* weight) {
+  for (int64_t r = 0; r < V; ++r) {
+    const int64_t s = row_ptr[r], e = row_ptr[r + 1];
+    /* stable insertion sort: rows are short in the tests this oracle serves */
+    for (int64_t i = s + 1; i < e; ++i) {
+      const int64_t t = ts_slot[i], c = col[i], d = eid[i];
+      const float w = weight ? weight[i] : 0.0f;
+      int64_t j = i - 1;
+      while (j >= s && ts_slot[j] > t) {
+        ts_slot[j + 1] = ts_slot[j];
+        col[j + 1] = col[j];
+        eid[j + 1] = eid[j];
+        if (weight) weight[j + 1] = weight[j];
+        --j;
+      }
+      ts_slot[j + 1] = t;
+      col[j + 1] = c;
+      eid[j + 1] = d;
+      if (weight) weight[j + 1] = w;
+    }
+  }
+}

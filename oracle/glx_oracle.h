@@ -71,6 +71,12 @@ int64_t glxo_sample_full(const glxo_graph* g, const int64_t* src, int32_t batch,
 void glxo_sort_rows_by_weight_desc(const int64_t* row_ptr, int64_t V, int64_t* col, int64_t* eid,
                                    float* weight);
 
+/* Restates MemoryAdjMatrix::SortByTimestamp (memory_adj_matrix.cc:129-148): each row by the
+ * edges' timestamps ascending (ts_slot[] is per CSR slot); ties keep insertion order.  Sorts
+ * col/eid/ts_slot (and weight when not NULL) in place. */
+void glxo_sort_rows_by_timestamp_asc(const int64_t* row_ptr, int64_t V, int64_t* col, int64_t* eid,
+                                     int64_t* ts_slot, float* weight);
+
 /* The four samplers (random_sampler.cc:33-76,
  * random_without_replacement_sampler.cc:31-75, edge_weight_sampler.cc:31-92 +
  * alias_method.cc:109-124, topk_sampler.cc:29-68) with the padders

@@ -114,6 +114,27 @@ int glref_add_edges(void* h, const char* edge_type, const int64_t* src, const in
   return 0;
 }
 
+// Timestamped edge type: Build() then orders every row by timestamp
+// (memory_adj_matrix.cc:60-66,129-148).  weights may be NULL.
+int glref_add_edges_ts(void* h, const char* edge_type, const int64_t* src, const int64_t* dst,
+                       const float* weights, const int64_t* timestamps, int64_t n) {
+  Ref* r = static_cast<Ref*>(h);
+  io::GraphStorage* st = r->store->GetGraph(edge_type)->GetLocalStorage();
+  io::SideInfo info;
+  info.format = io::kTimestamped | (weights ? io::kWeighted : 0);
+  info.type = edge_type;
+  st->SetSideInfo(&info);
+  io::EdgeValue v;
+  for (int64_t i = 0; i < n; ++i) {
+    v.src_id = src[i];
+    v.dst_id = dst[i];
+    v.weight = weights ? weights[i] : 0.0f;
+    v.timestamp = timestamps[i];
+    st->Add(&v);
+  }
+  return 0;
+}
+
 int glref_build_graph(void* h, const char* edge_type) {
   Ref* r = static_cast<Ref*>(h);
   IndexOption opt;

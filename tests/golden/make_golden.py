@@ -386,6 +386,24 @@ def gen_negative(ref):
     np.savez_compressed(os.path.join(HERE, "negative.npz"), **out)
 
 
+def gen_timestamped(ref):
+    """A timestamped (and weighted) edge type: after Build() every row is in timestamp-ascending order,
+    not weight order (memory_adj_matrix.cc:60-66,129-148).  Timestamps are distinct inside a row."""
+    out = {}
+    rng = np.random.default_rng(91)
+    E = 2500
+    src = rng.integers(0, 120, E).astype(np.int64) * 3
+    dst = rng.integers(0, 500, E).astype(np.int64)
+    ts = rng.permutation(E).astype(np.int64) * 7 + 1_600_000_000
+    w = (rng.random(E) + 0.01).astype(np.float32)
+    ref.add_edges_timestamped("ts", src, dst, ts, w)
+    rows = first_appearance(src)
+    rp, col, eid, ws = ref.export_csr("ts", rows, 4000)
+    tk, te = ref.sample("ts", "TopkSampler", rows, 4)
+    out.update(src=src, dst=dst, ts=ts, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws, topk_nbr=tk, topk_eid=te)
+    np.savez_compressed(os.path.join(HERE, "timestamped.npz"), **out)
+
+
 def main():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -397,6 +415,7 @@ def main():
     gen_agg_stitch(ref)
     gen_loader(ref)
     gen_negative(ref)
+    gen_timestamped(ref)
     # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()
     print("golden fixtures written to", HERE)

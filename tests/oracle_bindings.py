@@ -42,6 +42,7 @@ class Oracle:
         L.glxo_draw64.restype = u64
         L.glxo_alias_build.argtypes = [VP, VP, i64, VP, VP]
         L.glxo_sort_rows_by_weight_desc.argtypes = [VP, i64, VP, VP, VP]
+        L.glxo_sort_rows_by_timestamp_asc.argtypes = [VP, i64, VP, VP, VP, VP]
         L.glxo_sample.argtypes = [ctypes.POINTER(_CGraph), ctypes.c_int, VP, VP, i32, i32, ctypes.c_int, i64, u64,
                                   u64, VP, VP]
         L.glxo_aggregate.argtypes = [VP, i64, i32, VP, ctypes.c_int, VP, VP, i32, i32, ctypes.c_float, VP, VP]
@@ -161,6 +162,13 @@ class Oracle:
         assert rc == 0, rc
         return emb, cnt
 
+    def sort_rows_by_timestamp(self, row_ptr, col, eid, ts_slot, weight=None):
+        """-> (col, eid, ts_slot, weight) with every row in timestamp-ascending order (stable)"""
+        col, eid, ts = col.copy(), eid.copy(), ts_slot.copy()
+        w = None if weight is None else weight.copy()
+        self.L.glxo_sort_rows_by_timestamp_asc(_p(row_ptr), row_ptr.shape[0] - 1, _p(col), _p(eid), _p(ts), _p(w))
+        return col, eid, ts, w
+
     def partition(self, ids, P):
         order = np.zeros(ids.shape[0], np.int64)
         counts = np.zeros(P, np.int64)
@@ -203,6 +211,7 @@ class RefLib:
         L.glref_aggregate.argtypes = [VP, cs, cs, VP, VP, i32, i32, VP, VP, VP]
         L.glref_aggregate_stitch.argtypes = [cs, i32, VP, VP, i32, i32, VP, VP]
         L.glref_add_weighted_nodes.argtypes = [VP, cs, VP, VP, i64]
+        L.glref_add_edges_ts.argtypes = [VP, cs, VP, VP, VP, VP, i64]
         L.glref_dst_statics.argtypes = [VP, cs, VP, VP, i64]
         L.glref_dst_statics.restype = i64
         L.glref_hash64.argtypes = [ctypes.c_char_p, i64]
@@ -234,6 +243,10 @@ class RefLib:
 
     def add_edges(self, etype, src, dst, weight=None):
         self.L.glref_add_edges(self.h, etype.encode(), _p(src), _p(dst), _p(weight), src.shape[0])
+        self.L.glref_build_graph(self.h, etype.encode())
+
+    def add_edges_timestamped(self, etype, src, dst, timestamps, weight=None):
+        self.L.glref_add_edges_ts(self.h, etype.encode(), _p(src), _p(dst), _p(weight), _p(timestamps), src.shape[0])
         self.L.glref_build_graph(self.h, etype.encode())
 
     def add_nodes(self, ntype, ids, feats):

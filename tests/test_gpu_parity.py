@@ -616,3 +616,18 @@ def test_in_degree_lookup_equals_bincount():
     assert np.array_equal(got[ok], want[q[ok]]) and (got[~ok] == 0).all()
     import torch
     assert np.array_equal(g.in_degrees(torch.from_numpy(q).cuda()).cpu().numpy(), got)
+
+
+def test_timestamped_edge_type_rows_in_timestamp_order():
+    """glx_graph_build_ordered(GLX_ORDER_TIMESTAMP_ASC) == the reference's post-Build adjacency of a
+    timestamped + weighted edge type (tests/golden/timestamped.npz), via the Full and Topk samplers."""
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "timestamped.npz")))
+    dev = glx.Graph.from_edges(g["src"], g["dst"], g["w"], timestamp=g["ts"])
+    deg, nbr, eid = dev.sample_full(g["rows"], 0)
+    assert np.array_equal(deg, np.diff(g["row_ptr"])) and np.array_equal(nbr, g["col"]) and np.array_equal(eid, g["eid"])
+    n, e = dev.sample("TopkSampler", g["rows"], 4)
+    assert np.array_equal(n, g["topk_nbr"]) and np.array_equal(e, g["topk_eid"])
+    import torch
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    dev2 = glx.Graph.from_edges(t(g["src"]), t(g["dst"]), t(g["w"]), timestamp=t(g["ts"]))
+    assert np.array_equal(dev2.sample("TopkSampler", g["rows"], 4)[0], g["topk_nbr"])

@@ -554,3 +554,24 @@ def test_quickstart_example_runs():
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "one epoch: 4 batches" in r.stdout
+
+
+def test_timestamped_source_through_the_loader(gl, g, tmp_path):
+    """A timestamped TSV source (`timestamp:int64` column, Decoder(timestamped=True)): rows come out in
+    timestamp order like the reference's Build(), and the edges' timestamps can be looked up."""
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "timestamped.npz")))
+    path = os.path.join(str(tmp_path), "ts_edges")
+    with open(path, "w") as f:
+        f.write("src_id:int64\tdst_id:int64\tweight:float\ttimestamp:int64\n")
+        for s, d_, w, t in zip(gold["src"], gold["dst"], gold["w"], gold["ts"]):
+            f.write("%d\t%d\t%.9g\t%d\n" % (s, d_, w, t))
+    tg = gl.Graph().edge(path, ("a", "a", "ts"), gl.Decoder(weighted=True, timestamped=True)).init()
+    try:
+        full = tg.neighbor_sampler("ts", 0, strategy="full").get(gold["rows"])
+        np.testing.assert_equal(full.layer_nodes(1).ids, gold["col"])
+        edges = full.layer_edges(1)
+        np.testing.assert_equal(edges.edge_ids, gold["eid"])
+        np.testing.assert_equal(edges.timestamps, gold["ts"][gold["eid"]])
+        np.testing.assert_equal(edges.weights.view(np.uint32), gold["w_slot"].view(np.uint32))
+    finally:
+        tg.close()

@@ -510,3 +510,24 @@ def test_node_weight_negative_sampler_matches_reference_distribution(orc):
         assert stats.chi2_contingency(np.stack([hr[keep], ho[keep]]))[1] > 1e-4
     finally:
         ref.close()
+
+
+def test_timestamped_rows_sort_by_timestamp_golden(orc):
+    """Quirk 10: a timestamped edge type is ordered by timestamp ascending at Build(), even when it is
+    weighted too (memory_adj_matrix.cc:60-66,129-148).  tests/golden/timestamped.npz = the reference's
+    post-Build adjacency and its Topk answer."""
+    g = load("timestamped.npz")
+    rows = g["rows"]
+    row_of = {int(v): i for i, v in enumerate(rows)}
+    r = np.array([row_of[int(s)] for s in g["src"]])
+    order = np.argsort(r, kind="stable")
+    rp = np.zeros(rows.shape[0] + 1, np.int64)
+    np.add.at(rp, r + 1, 1)
+    rp = np.cumsum(rp)
+    assert np.array_equal(rp, g["row_ptr"])
+    col, eid, ts, w = orc.sort_rows_by_timestamp(rp, g["dst"][order], order.astype(np.int64), g["ts"][order],
+                                                 g["w"][order])
+    assert np.array_equal(col, g["col"]) and np.array_equal(eid, g["eid"]) and beq(w, g["w_slot"])
+    graph = dict(row_ptr=rp, col=col, eid=eid, weight=w, ids=rows)
+    n, e = orc.sample(graph, "TopkSampler", rows, 4)
+    assert np.array_equal(n, g["topk_nbr"]) and np.array_equal(e, g["topk_eid"])  # "top" = earliest here
