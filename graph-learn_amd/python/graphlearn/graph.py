@@ -170,7 +170,7 @@ class Graph(object):
   def get_nodes(self, node_type, ids, offsets=None, shape=None):
     if offsets is None:
       return data.Nodes(ids, node_type, shape=shape, graph=self)
-    width = shape[1] if shape and shape[1] and shape[1] > 0 else max(offsets)
+    width = shape[1] if shape and shape[1] and shape[1] > 0 else max(offsets, default=0)
     return data.SparseNodes(ids, offsets, (len(offsets), width), node_type, graph=self)
 
   def get_edges(self, edge_type, src_ids, dst_ids, edge_ids=None, offsets=None, shape=None, reverse=False):
@@ -180,7 +180,7 @@ class Graph(object):
     dst_type = self._topology.get_dst_type(edge_type)
     if offsets is None:
       return data.Edges(src_ids, src_type, dst_ids, dst_type, edge_type, edge_ids, shape=shape, graph=self)
-    width = shape[1] if shape and shape[1] and shape[1] > 0 else max(offsets)
+    width = shape[1] if shape and shape[1] and shape[1] > 0 else max(offsets, default=0)
     return data.SparseEdges(src_ids, src_type, dst_ids, dst_type, edge_type, offsets, (len(offsets), width),
                             edge_ids, graph=self)
 

@@ -227,6 +227,10 @@ def test_full_neighbor_sampler(gl, g):
     np.testing.assert_equal(edges.src_ids, np.repeat(SEEDS1, SEEDS1 % 5))
     capped = g.neighbor_sampler(EDGE1, 2, strategy="full").get(SEEDS1).layer_nodes(1)
     assert capped.offsets == [2, 2, 2]
+    # vertices without neighbours: the next hop starts from an empty frontier
+    lonely = g.neighbor_sampler([EDGE1, EDGE2], [0, 0], strategy="full").get(np.array([-3, 10 ** 9]))
+    assert lonely.layer_nodes(1).offsets == [0, 0] and lonely.layer_nodes(1).ids.size == 0
+    assert lonely.layer_nodes(2).offsets == [] and lonely.layer_nodes(2).dense_shape == (0, 0)
 
 
 def test_reverse_edges_of_undirected_types(gl, g):
