@@ -357,6 +357,183 @@ int64_t glxo_sample_full(const glxo_graph* g, const int64_t* src, int32_t batch,
   return total;
 }
 
+/* ---------------------------------------------------------------- filters -- */
+static int64_t filter_field(const glxo_filter* f, const int64_t* row_nbr, const int64_t* row_ts, int32_t idx) {
+  /* Filter::GetFieldFunc, filter.cc:122-150 */
+  if (f->field == GLXO_FIELD_ID) return row_nbr[idx];
+  if (f->field == GLXO_FIELD_TIMESTAMP) return row_ts ? row_ts[idx] : f->default_timestamp;
+  return -1;
+}
+
+static int filter_hit(const glxo_filter* f, int32_t batch_idx, const int64_t* row_nbr, const int64_t* row_ts,
+                      int32_t idx) {
+  /* Filter::Hit + GetFilterFunc, filter.cc:98-107,152-193 */
+  int64_t v = filter_field(f, row_nbr, row_ts, idx);
+  if (f->type == GLXO_FILTER_EQUAL) return v == f->values[batch_idx];
+  if (f->type == GLXO_FILTER_LARGER_THAN) return v > f->values[batch_idx];
+  return 0;
+}
+
+static int32_t filter_find_kth(const glxo_filter* f, const int64_t* row_nbr, const int64_t* row_ts, int32_t n) {
+  /* Filter::FindkthLargest with batch_share_idx = 0, filter.cc:196-229 */
+  int32_t start = 0, end = n - 1, mid = 0;
+  const int64_t filter = f->values[0];
+  if (end == 0) return -1;
+  while (end >= start) {
+    mid = start + (end - start) / 2;
+    int64_t v = filter_field(f, row_nbr, row_ts, mid);
+    if (v == filter) return mid;
+    if (v > filter) end = mid - 1; else start = mid + 1;
+  }
+  if (filter_field(f, row_nbr, row_ts, mid) < filter) mid += 1;
+  return mid;
+}
+
+int32_t glxo_filter_act_on(const glxo_filter* f, int32_t batch_idx, const int64_t* row_nbr,
+                           const int64_t* row_ts, int32_t n, int32_t* indices) {
+  for (int32_t t = 0; t < n; ++t) indices[t] = t;
+  if (f->field == GLXO_FIELD_TIMESTAMP && f->type == GLXO_FILTER_LARGER_THAN) {
+    int32_t k = filter_find_kth(f, row_nbr, row_ts, n);
+    if (k < 0) k = 0;
+    for (int32_t a = 0, b = k - 1; a < b; ++a, --b) { int32_t t = indices[a]; indices[a] = indices[b]; indices[b] = t; }
+    return k;
+  }
+  int32_t l = 0, r = n - 1;
+  while (l <= r) {
+    while (filter_hit(f, batch_idx, row_nbr, row_ts, indices[l]) && (l <= r)) {
+      int32_t t = indices[l]; indices[l] = indices[r]; indices[r] = t;
+      --r;
+    }
+    ++l;
+  }
+  return r + 1;
+}
+
+int glxo_sample_filtered(const glxo_graph* g, int op, const int64_t* src, const int64_t* rng_rows,
+                         int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id,
+                         uint64_t seed, uint64_t call_counter, const glxo_filter* f, int64_t* nbr_out,
+                         int64_t* eid_out) {
+  if (!f || f->type == GLXO_FILTER_NONE)
+    return glxo_sample(g, op, src, rng_rows, batch, k, padding_mode, default_neighbor_id, seed, call_counter,
+                       nbr_out, eid_out);
+  if (op < GLXO_RANDOM || op > GLXO_IN_DEGREE || !f->values) return 3;
+  if (op == GLXO_EDGE_WEIGHT && !g->weight) return 3;
+  if (op == GLXO_IN_DEGREE && !f->indeg_weight) return 3;
+  idmap m;
+  if (g->ids) idmap_build(&m, g->ids, g->V);
+  int64_t maxdeg = 1;
+  for (int64_t r = 0; r < g->V; ++r)
+    if (g->row_ptr[r + 1] - g->row_ptr[r] > maxdeg) maxdeg = g->row_ptr[r + 1] - g->row_ptr[r];
+  int32_t* res = (int32_t*)malloc(sizeof(int32_t) * (size_t)maxdeg);
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(maxdeg > k ? maxdeg : (k > 0 ? k : 1)));
+  float* dist = (float*)malloc(sizeof(float) * (size_t)maxdeg * 2);
+  int32_t* tab = (int32_t*)malloc(sizeof(int32_t) * (size_t)maxdeg * 3);
+  int32_t retry = f->retry_times;
+  for (int32_t i = 0; i < batch; ++i) {
+    int64_t* nbr = nbr_out + (int64_t)i * k;
+    int64_t* eid = eid_out + (int64_t)i * k;
+    const uint32_t rr = rng_rows ? (uint32_t)rng_rows[i] : (uint32_t)i;
+    int64_t row = row_of(g->ids, &m, g->V, src[i]);
+    int64_t start = row < 0 ? 0 : g->row_ptr[row];
+    int32_t deg = row < 0 ? 0 : (int32_t)(g->row_ptr[row + 1] - start);
+    if (deg == 0) { fill_default(nbr, eid, k, default_neighbor_id); continue; }
+    const int64_t* rn = g->col + start;
+    const int64_t* re = g->eid + start;
+    const int64_t* rt = f->ts_slot ? f->ts_slot + start : NULL;
+    if (op == GLXO_RANDOM) {
+      /* random_sampler.cc:58-71: HitAll -> default row; else rejection with the retry budget */
+      int all = 1;
+      for (int32_t t = 0; t < deg && all; ++t) all &= filter_hit(f, i, rn, rt, t);
+      if (all) { fill_default(nbr, eid, k, default_neighbor_id); continue; }
+      for (int32_t j = 0; j < k; ++j) {
+        for (uint32_t a = 0;; ++a) {
+          int32_t d = (int32_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j + a * (uint32_t)k), (uint64_t)deg);
+          if (!filter_hit(f, i, rn, rt, d) || --retry < 0) {
+            nbr[j] = rn[d];
+            eid[j] = re[d];
+            retry = f->retry_times;
+            break;
+          }
+        }
+      }
+      continue;
+    }
+    int32_t cnt = glxo_filter_act_on(f, i, rn, rt, deg, res);
+    if (op == GLXO_TOPK) {
+      for (int32_t t = 0; t < cnt; ++t) idx[t] = res[t];
+      pad_row(rn, re, deg, idx, cnt, k, padding_mode, default_neighbor_id, nbr, eid);
+    } else if (op == GLXO_RANDOM_WITHOUT_REPLACEMENT) {
+      /* shuffle(reserved) under the contract's forward Fisher-Yates, then Pad */
+      for (int32_t t = 0; t < cnt; ++t) idx[t] = res[t];
+      if (padding_mode == GLXO_PAD_CIRCULAR) {
+        int32_t steps = cnt < k ? cnt : k;
+        for (int32_t j = 0; j < steps; ++j) {
+          int64_t r = j + (int64_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j), (uint64_t)(cnt - j));
+          int64_t t = idx[j]; idx[j] = idx[r]; idx[r] = t;
+        }
+      }
+      pad_row(rn, re, deg, idx, cnt, k, padding_mode, default_neighbor_id, nbr, eid);
+    } else {
+      /* SampleFromIndices: alias table over the reserved neighbours' weights, k draws,
+       * mapped back through the reserved list; an empty list stays empty */
+      if (cnt == 0) {
+        pad_row(rn, re, deg, idx, 0, k, padding_mode, default_neighbor_id, nbr, eid);
+        continue;
+      }
+      const float* w = op == GLXO_EDGE_WEIGHT ? g->weight + start : f->indeg_weight + start;
+      for (int32_t t = 0; t < cnt; ++t) dist[t] = w[res[t]];
+      float* probs = dist + maxdeg;
+      alias_build_row(dist, cnt, probs, tab, tab + maxdeg, tab + 2 * maxdeg);
+      for (int32_t j = 0; j < k; ++j) {
+        uint64_t u = glxo_draw64(seed, call_counter, rr, (uint32_t)j);
+        double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(cnt - 1);
+        float rnd = (float)rd;
+        int32_t ix = (int32_t)rnd;
+        idx[j] = res[(probs[ix] <= (rnd - ix)) ? tab[ix] : ix];
+      }
+      pad_row(rn, re, deg, idx, k, k, padding_mode, default_neighbor_id, nbr, eid);
+    }
+  }
+  free(res); free(idx); free(dist); free(tab);
+  if (g->ids) idmap_free(&m);
+  return 0;
+}
+
+int64_t glxo_sample_full_filtered(const glxo_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                                  int padding_mode, int64_t default_neighbor_id, const glxo_filter* f,
+                                  int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out, int64_t cap) {
+  if (!f || f->type == GLXO_FILTER_NONE)
+    return glxo_sample_full(g, src, batch, max_limit, degrees_out, nbr_out, eid_out, cap);
+  idmap m;
+  if (g->ids) idmap_build(&m, g->ids, g->V);
+  int64_t maxdeg = 1;
+  for (int64_t r = 0; r < g->V; ++r)
+    if (g->row_ptr[r + 1] - g->row_ptr[r] > maxdeg) maxdeg = g->row_ptr[r + 1] - g->row_ptr[r];
+  int32_t* res = (int32_t*)malloc(sizeof(int32_t) * (size_t)maxdeg);
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)maxdeg);
+  int64_t* tn = (int64_t*)malloc(sizeof(int64_t) * (size_t)maxdeg * 2);
+  int64_t total = 0;
+  for (int32_t i = 0; i < batch; ++i) {
+    int64_t row = row_of(g->ids, &m, g->V, src[i]);
+    int64_t start = row < 0 ? 0 : g->row_ptr[row];
+    int32_t deg = row < 0 ? 0 : (int32_t)(g->row_ptr[row + 1] - start);
+    int32_t take = (max_limit > 0 && max_limit < deg) ? max_limit : deg;
+    degrees_out[i] = take;
+    if (deg == 0) continue;
+    const int64_t* rt = f->ts_slot ? f->ts_slot + start : NULL;
+    int32_t cnt = glxo_filter_act_on(f, i, g->col + start, rt, deg, res);
+    for (int32_t t = 0; t < cnt; ++t) idx[t] = res[t];
+    pad_row(g->col + start, g->eid + start, deg, idx, cnt, take, padding_mode, default_neighbor_id, tn, tn + maxdeg);
+    for (int32_t j = 0; j < take; ++j) {
+      if (total < cap) { nbr_out[total] = tn[j]; eid_out[total] = tn[maxdeg + j]; }
+      ++total;
+    }
+  }
+  free(res); free(idx); free(tn);
+  if (g->ids) idmap_free(&m);
+  return total;
+}
+
 /* ------------------------------------------------------------ aggregators -- */
 int glxo_aggregate(const float* feats, int64_t V, int32_t dim, const int64_t* ids, int op,
                    const int64_t* node_ids, const int32_t* segment_ids, int32_t num_ids,

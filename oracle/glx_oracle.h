@@ -65,6 +65,47 @@ void glxo_in_degree_weights(const int64_t* col, int64_t E, float* w_out);
 int64_t glxo_sample_full(const glxo_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
                          int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out, int64_t cap);
 
+/* ---- sampling filters (core/operator/sampler/filter.{h,cc}) -----------------------
+ * type / field use the reference's enum values (include/constants.h:135-145).  values[]
+ * is the request's filter tensor AFTER Filter::FillValues (filter.cc:53-67): one value per
+ * request row.  ts_slot = GetEdgeTimestamp of every CSR slot (NULL: default_timestamp
+ * everywhere); indeg_weight = glxo_in_degree_weights (InDegreeSampler only). */
+enum { GLXO_FILTER_NONE = 0, GLXO_FILTER_EQUAL = 1, GLXO_FILTER_LARGER_THAN = 2 };
+enum { GLXO_FIELD_NONE = 0, GLXO_FIELD_ID = 1, GLXO_FIELD_TIMESTAMP = 2 };
+typedef struct {
+  int type, field;
+  const int64_t* values;
+  int32_t retry_times;       /* GLOBAL_FLAG(SamplingRetryTimes), RandomSampler only */
+  const int64_t* ts_slot;
+  int64_t default_timestamp;
+  const float* indeg_weight;
+} glxo_filter;
+
+/* Restates Filter::ActOn (filter.cc:69-96) for request row `batch_idx` over a row of n
+ * neighbours: indices[] (capacity n) receives the reserved positions in the reference's
+ * order; returns their number.  Timestamp + LARGER_THAN takes the binary-search path
+ * (FindkthLargest, filter.cc:196-229), which reads values[0] for EVERY row (the default
+ * batch_share_idx = 0, filter.h:107-111) and returns the positions descending. */
+int32_t glxo_filter_act_on(const glxo_filter* f, int32_t batch_idx, const int64_t* row_nbr,
+                           const int64_t* row_ts, int32_t n, int32_t* indices);
+
+/* The samplers with a filter set (random_sampler.cc:52-71, topk_sampler.cc:52-61,
+ * random_without_replacement_sampler.cc:56-68, edge_weight_sampler.cc:55-66,94-112,
+ * in_degree_sampler.cc:54-65,94-113).  Same seeding contract as glxo_sample; RandomSampler's
+ * retry a of slot j uses draw j + a * k.  EdgeWeight / InDegree build the alias table of
+ * the reserved neighbours' weights per row, as the reference does. */
+int glxo_sample_filtered(const glxo_graph* g, int op, const int64_t* src, const int64_t* rng_rows,
+                         int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id,
+                         uint64_t seed, uint64_t call_counter, const glxo_filter* f, int64_t* nbr_out,
+                         int64_t* eid_out);
+/* FullSampler with a filter (full_sampler.cc:66-84): the row sizes stay the UNFILTERED
+ * min(limit, deg) and the reserved neighbours are padded up to that size.  A row whose
+ * neighbours are all filtered out yields that many default ids (the reference's
+ * FillWith(dim2) breaks the ragged layout there: SURVEY 8(a) quirk 12). */
+int64_t glxo_sample_full_filtered(const glxo_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                                  int padding_mode, int64_t default_neighbor_id, const glxo_filter* f,
+                                  int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out, int64_t cap);
+
 /* Restates MemoryAdjMatrix::Sort (memory_adj_matrix.cc:105-125): each row by
  * weight descending.  Ties keep insertion order (the reference's std::sort
  * leaves tie order unspecified).  Sorts col/eid/weight in place. */

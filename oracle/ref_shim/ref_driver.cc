@@ -350,6 +350,51 @@ int64_t glref_sample_full(void* h, const char* edge_type, const int64_t* src, in
   return total;
 }
 
+// The samplers with a Filter (core/operator/sampler/filter.{h,cc}): the filter values reach
+// the request the way the DAG runner hands them over -- SamplingRequest::Set(tensors), which
+// runs Filter::FillValues (sampling_request.cc:127-136).  strategy "FullSampler" answers
+// with segments (degrees_out != NULL, capacity `cap` values); the others with [batch, k].
+// Returns the number of values, or -(error code) - 1.
+int64_t glref_sample_filtered(void* h, const char* edge_type, const char* strategy, const int64_t* src,
+                              int32_t batch, int32_t k, int filter_type, int filter_field,
+                              const int64_t* values, int32_t num_values, int32_t retry_times,
+                              int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out, int64_t cap,
+                              int fresh_thread) {
+  (void)h;
+  int64_t rc = 0;
+  SetGlobalFlagSamplingRetryTimes(retry_times);
+  RunMaybeFresh(fresh_thread, [&]() {
+    SamplingRequest req(edge_type, strategy, k, static_cast<FilterType>(filter_type),
+                        static_cast<FilterField>(filter_field));
+    SamplingResponse res;
+    Tensor::Map tensors;
+    ADD_TENSOR(tensors, kSrcIds, kInt64, batch);
+    tensors[kSrcIds].AddInt64(src, src + batch);
+    ADD_TENSOR(tensors, kFilterValues, kInt64, num_values);
+    tensors[kFilterValues].AddInt64(values, values + num_values);
+    req.Set(tensors);
+    op::Operator* op = op::OpFactory::GetInstance()->Create(req.Name());
+    if (!op) { rc = -2; return; }
+    Status s = op->Process(&req, &res);
+    if (!s.ok()) { rc = -static_cast<int64_t>(s.code()) - 1; return; }
+    int64_t total = static_cast<int64_t>(batch) * k;
+    if (degrees_out) {
+      const Shape shape = res.GetShape();
+      total = 0;
+      for (int32_t i = 0; i < batch; ++i) {
+        degrees_out[i] = shape.segments[i];
+        total += shape.segments[i];
+      }
+    }
+    for (int64_t i = 0; i < total && i < cap; ++i) {
+      nbr_out[i] = res.GetNeighborIds()[i];
+      eid_out[i] = res.GetEdgeIds()[i];
+    }
+    rc = total;
+  });
+  return rc;
+}
+
 // GraphStorage::GetInDegree (memory_topo_storage.cc:103-109, topo_statics.cc:62-69).
 int32_t glref_in_degree(void* h, const char* edge_type, int64_t dst_id) {
   Ref* r = static_cast<Ref*>(h);

@@ -404,6 +404,131 @@ def gen_timestamped(ref):
     np.savez_compressed(os.path.join(HERE, "timestamped.npz"), **out)
 
 
+def gen_filtered(ref):
+    """Sampling with a Filter (core/operator/sampler/filter.{h,cc}).
+    Deterministic part: TopkSampler / FullSampler answers of the reference for ID and TIMESTAMP
+    filters of both types under both padding modes, on a timestamped multigraph whose rows have
+    1..40 neighbours with repeated destination ids.  Random part: per (row, slot) histograms
+    of RandomSampler / RandomWithoutReplacementSampler / EdgeWeightSampler / InDegreeSampler
+    with an ID == value filter."""
+    from oracle_bindings import FILTER_EQUAL, FILTER_LARGER_THAN, FIELD_ID, FIELD_TIMESTAMP, Oracle
+    orc = Oracle()
+    out = {}
+    rng = np.random.default_rng(123)
+    degs = np.concatenate([[1, 1, 2, 2, 3], rng.integers(1, 41, 55)])
+    src = np.repeat(np.arange(degs.shape[0], dtype=np.int64) * 5 - 20, degs)
+    dst = rng.integers(0, 12, src.shape[0]).astype(np.int64) + 900
+    ts = rng.permutation(src.shape[0]).astype(np.int64) * 3 + 1000
+    w = (rng.random(src.shape[0]) + 0.05).astype(np.float32)
+    ref.add_edges_timestamped("flt", src, dst, ts, w)
+    rows = first_appearance(src)
+    rp, col, eid, ws = ref.export_csr("flt", rows, 64)
+    ts_slot = ts[eid]
+    out.update(src=src, dst=dst, ts=ts, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws, ts_slot=ts_slot)
+    q = np.concatenate([rows, [77777, rows[3]]]).astype(np.int64)  # + an unknown id and a repeat
+    pos = {int(v): i for i, v in enumerate(rows)}
+
+    def row_of(v):
+        i = pos.get(int(v))
+        return (col[rp[i]:rp[i + 1]], ts_slot[rp[i]:rp[i + 1]]) if i is not None else (np.zeros(0, np.int64),) * 2
+
+    def values_for(kind):
+        vals = []
+        for n, v in enumerate(q):
+            nb, t = row_of(v)
+            if nb.shape[0] == 0:
+                vals.append(5)
+            elif kind == "id_eq":
+                vals.append(int(nb[n % nb.shape[0]]) if n % 3 else 899)
+            elif kind == "id_gt":
+                vals.append(int(np.sort(nb)[nb.shape[0] // 2]))
+            elif kind == "ts_eq":
+                vals.append(int(t[n % t.shape[0]]))
+            else:  # ts_gt: per-row thresholds; the ActOn path only ever reads values[0]
+                vals.append(int(np.sort(t)[t.shape[0] // 2]) + (n % 2))
+        return np.array(vals, np.int64)
+
+    filters = {"id_eq": (FILTER_EQUAL, FIELD_ID), "id_gt": (FILTER_LARGER_THAN, FIELD_ID),
+               "ts_eq": (FILTER_EQUAL, FIELD_TIMESTAMP), "ts_gt": (FILTER_LARGER_THAN, FIELD_TIMESTAMP)}
+    cases = []
+    for kind, (ft, ff) in filters.items():
+        vals = values_for(kind)
+        if kind == "ts_gt":
+            vals[0] = int(np.median(ts))  # the shared threshold: about half of every row survives
+        out["values_" + kind] = vals
+        flt = dict(type=ft, field=ff, values=vals)
+        for pad in (1, 0):
+            ref.set_flags(pad, -7, 0.0)
+            for strategy, k in (("TopkSampler", 6), ("TopkSampler", 1), ("FullSampler", 0), ("FullSampler", 3)):
+                ids = q
+                if strategy == "FullSampler" and pad == 1:
+                    # a row filtered to nothing breaks the reference's ragged layout (FillWith(dim2)): leave those out
+                    keep = []
+                    for n, v in enumerate(q):
+                        nb, t = row_of(v)
+                        one = dict(flt, values=vals if kind == "ts_gt" else vals[n:n + 1])
+                        keep.append(nb.shape[0] == 0 or orc.filter_act_on(one, 0, nb, t).shape[0] > 0)
+                    ids = q[np.array(keep)]
+                    flt_case = dict(flt, values=vals[np.array(keep)] if kind != "ts_gt" else np.concatenate(
+                        [vals[:1], vals[np.array(keep)][1:]]))
+                else:
+                    flt_case = flt
+                got = ref.sample_filtered("flt", strategy, ids, k, flt_case)
+                name = "%s_%s_k%d_pad%d" % (kind, strategy, k, pad)
+                out[name + "_ids"] = ids
+                out[name + "_values"] = np.ascontiguousarray(flt_case["values"], np.int64)
+                if strategy == "FullSampler":
+                    out[name + "_deg"], out[name + "_nbr"], out[name + "_eid"] = got
+                else:
+                    out[name + "_nbr"], out[name + "_eid"] = got
+                cases.append(name)
+    # Filter::FillValues: values shorter than the batch repeat batch / len(values) times
+    ref.set_flags(1, -7, 0.0)
+    two = np.array([rows[10], rows[11], rows[12], rows[13]], np.int64)
+    short = np.array([int(row_of(rows[10])[0][0]), int(row_of(rows[12])[0][0])], np.int64)
+    out["fill_ids"], out["fill_values"] = two, short
+    out["fill_nbr"], out["fill_eid"] = ref.sample_filtered("flt", "TopkSampler", two, 5,
+                                                          dict(type=FILTER_EQUAL, field=FIELD_ID, values=short))
+    out["cases"] = np.array(cases)
+
+    # ---- distributions --------------------------------------------------------------
+    rng = np.random.default_rng(124)
+    ddegs = [2, 3, 5, 8, 12]
+    pool = np.arange(700, 716, dtype=np.int64)
+    dsrc, ddst = [], []
+    for r, d in enumerate(ddegs):
+        dsrc += [r] * d
+        ddst += rng.choice(pool, d, replace=False).tolist()
+    extra = rng.choice(pool, 80, p=np.arange(1, 17) / 136.0)
+    dsrc += list(range(100, 180))
+    ddst += extra.tolist()
+    dsrc, ddst = np.array(dsrc, np.int64), np.array(ddst, np.int64)
+    dw = (rng.random(dsrc.shape[0]) * 0.95 + 0.05).astype(np.float32)
+    ref.add_edges("fdist", dsrc, ddst, dw)
+    drows = first_appearance(dsrc)
+    drp, dcol, deid, dws = ref.export_csr("fdist", drows, max(ddegs))
+    out.update(d_src=dsrc, d_dst=ddst, d_w=dw, d_rows=drows, d_row_ptr=drp, d_col=dcol, d_eid=deid, d_w_slot=dws,
+               d_degs=np.array(ddegs, np.int64), d_indeg_w=ref.in_degree("fdist", dcol).astype(np.float32))
+    T, k = 20000, 4
+    dvals = np.array([int(dcol[drp[r] + (r % d)]) for r, d in enumerate(ddegs)], np.int64)  # one neighbour of each row
+    out["d_values"] = dvals
+    flt = dict(type=FILTER_EQUAL, field=FIELD_ID, values=np.tile(dvals, T), retry_times=1)
+    ref.set_flags(1, 0, 0.0)
+    ref.set_seed(4242)
+    for name in ("RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "InDegreeSampler"):
+        _, e = ref.sample_filtered("fdist", name, np.tile(drows[:len(ddegs)], T), k, flt, fresh_thread=True)
+        e = e.reshape(T, len(ddegs), k)
+        hist = np.zeros((len(ddegs), k, max(ddegs)), np.int64)
+        for r, d in enumerate(ddegs):
+            pos_of = {int(x): i for i, x in enumerate(deid[drp[r]:drp[r + 1]])}
+            p = np.vectorize(pos_of.get)(e[:, r, :])
+            for j in range(k):
+                hist[r, j, :d] = np.bincount(p[:, j], minlength=d)
+        out["d_%s_hist" % name] = hist
+    out["d_T"] = np.array(T)
+    np.savez_compressed(os.path.join(HERE, "filtered.npz"), **out)
+
+
 def main():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -416,6 +541,7 @@ def main():
     gen_loader(ref)
     gen_negative(ref)
     gen_timestamped(ref)
+    gen_filtered(ref)
     # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()
     print("golden fixtures written to", HERE)

@@ -33,6 +33,15 @@ class _CGraph(ctypes.Structure):
                 ("indeg_alias", VP)]
 
 
+class _CFilter(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int), ("field", ctypes.c_int), ("values", VP), ("retry_times", ctypes.c_int32),
+                ("ts_slot", VP), ("default_timestamp", ctypes.c_int64), ("indeg_weight", VP)]
+
+
+FILTER_EQUAL, FILTER_LARGER_THAN = 1, 2  # include/constants.h:135-139
+FIELD_ID, FIELD_TIMESTAMP = 1, 2         # include/constants.h:141-145
+
+
 class Oracle:
     def __init__(self):
         L = ctypes.CDLL(ORACLE_SO)
@@ -57,6 +66,13 @@ class Oracle:
         L.glxo_aggregate_stitch.argtypes = [ctypes.c_int, i32, VP, VP, i32, i32, ctypes.c_float, ctypes.c_int, VP, VP]
         L.glxo_stitch_i64.argtypes = [VP, VP, i64, i32, VP]
         L.glxo_set_reference_cost_model.argtypes = [ctypes.c_int]
+        L.glxo_filter_act_on.argtypes = [ctypes.POINTER(_CFilter), i32, VP, VP, i32, VP]
+        L.glxo_filter_act_on.restype = i32
+        L.glxo_sample_filtered.argtypes = [ctypes.POINTER(_CGraph), ctypes.c_int, VP, VP, i32, i32, ctypes.c_int, i64,
+                                           u64, u64, ctypes.POINTER(_CFilter), VP, VP]
+        L.glxo_sample_full_filtered.argtypes = [ctypes.POINTER(_CGraph), VP, i32, i32, ctypes.c_int, i64,
+                                                ctypes.POINTER(_CFilter), VP, VP, VP, i64]
+        L.glxo_sample_full_filtered.restype = i64
         self.L = L
 
     def philox(self, ctr, key):
@@ -93,6 +109,47 @@ class Oracle:
                                 seed, call_counter, _p(nbr), _p(eid))
         assert rc == 0, rc
         return nbr, eid
+
+    @staticmethod
+    def _cfilter(g, flt):
+        """flt: dict(type, field, values[batch], retry_times=5, default_timestamp=-1); the graph dict supplies
+        ts_slot (per CSR slot) and indeg_weight."""
+        keep = [np.ascontiguousarray(flt["values"], np.int64)]
+        return _CFilter(flt["type"], flt["field"], _p(keep[0]), flt.get("retry_times", 5), _p(g.get("ts_slot")),
+                        flt.get("default_timestamp", -1), _p(g.get("indeg_weight"))), keep
+
+    def filter_act_on(self, flt, batch_idx, row_nbr, row_ts=None):
+        cf, keep = self._cfilter({"ts_slot": row_ts}, flt)
+        out = np.zeros(max(1, row_nbr.shape[0]), np.int32)
+        n = self.L.glxo_filter_act_on(ctypes.byref(cf), batch_idx, _p(row_nbr), _p(row_ts), row_nbr.shape[0], _p(out))
+        return out[:n].copy()
+
+    def sample_filtered(self, g, sampler, src, k, flt, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0,
+                        rng_rows=None):
+        if isinstance(sampler, str):
+            sampler = ALL_SAMPLERS.index(sampler)
+        cg = self._cgraph(g)
+        cf, keep = self._cfilter(g, flt)
+        batch = src.shape[0]
+        nbr = np.zeros((batch, k), np.int64)
+        eid = np.zeros((batch, k), np.int64)
+        rc = self.L.glxo_sample_filtered(ctypes.byref(cg), sampler, _p(src), _p(rng_rows), batch, k, padding_mode,
+                                         default_neighbor_id, seed, call_counter, ctypes.byref(cf), _p(nbr), _p(eid))
+        assert rc == 0, rc
+        return nbr, eid
+
+    def sample_full_filtered(self, g, src, max_limit, flt, padding_mode=1, default_neighbor_id=0):
+        cg = self._cgraph(g)
+        cf, keep = self._cfilter(g, flt)
+        batch = src.shape[0]
+        deg = np.zeros(batch, np.int32)
+        total = self.L.glxo_sample_full_filtered(ctypes.byref(cg), _p(src), batch, max_limit, padding_mode,
+                                                 default_neighbor_id, ctypes.byref(cf), _p(deg), None, None, 0)
+        nbr = np.zeros(total, np.int64)
+        eid = np.zeros(total, np.int64)
+        self.L.glxo_sample_full_filtered(ctypes.byref(cg), _p(src), batch, max_limit, padding_mode, default_neighbor_id,
+                                         ctypes.byref(cf), _p(deg), _p(nbr), _p(eid), total)
+        return deg, nbr, eid
 
     def _cgraph(self, g):
         alias = g.get("alias")
@@ -222,6 +279,9 @@ class RefLib:
         L.glref_sample_full.restype = i64
         L.glref_in_degree.argtypes = [VP, cs, i64]
         L.glref_in_degree.restype = i32
+        L.glref_sample_filtered.argtypes = [VP, cs, cs, VP, i32, i32, ctypes.c_int, ctypes.c_int, VP, i32, i32, VP, VP,
+                                            VP, i64, ctypes.c_int]
+        L.glref_sample_filtered.restype = i64
         L.glref_alias_build.argtypes = [VP, i32, VP, VP]
         L.glref_time_sample_2hop.argtypes = [VP, cs, cs, VP, i32, i32, i32, i32, i32, VP]
         L.glref_time_sample_2hop.restype = ctypes.c_double
@@ -287,6 +347,28 @@ class RefLib:
                                          _p(eid), cap)
         assert 0 <= total <= cap, total
         return deg, nbr[:total].copy(), eid[:total].copy()
+
+    def sample_filtered(self, etype, strategy, src, k, flt, fresh_thread=True):
+        """flt: dict(type, field, values, retry_times=5); values may be shorter than the batch
+        (Filter::FillValues repeats each value batch / len(values) times)."""
+        values = np.ascontiguousarray(flt["values"], np.int64)
+        batch = src.shape[0]
+        if strategy == "FullSampler":
+            cap = 1 << 22
+            deg = np.zeros(batch, np.int32)
+            nbr, eid = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+            total = self.L.glref_sample_filtered(self.h, etype.encode(), strategy.encode(), _p(src), batch, k,
+                                                 flt["type"], flt["field"], _p(values), values.shape[0],
+                                                 flt.get("retry_times", 5), _p(deg), _p(nbr), _p(eid), cap, 0)
+            assert 0 <= total <= cap, total
+            return deg, nbr[:total].copy(), eid[:total].copy()
+        nbr = np.zeros((batch, k), np.int64)
+        eid = np.zeros((batch, k), np.int64)
+        total = self.L.glref_sample_filtered(self.h, etype.encode(), strategy.encode(), _p(src), batch, k, flt["type"],
+                                             flt["field"], _p(values), values.shape[0], flt.get("retry_times", 5),
+                                             None, _p(nbr), _p(eid), batch * k, 1 if fresh_thread else 0)
+        assert total == batch * k, total
+        return nbr, eid
 
     def in_degree(self, etype, ids):
         return np.array([self.L.glref_in_degree(self.h, etype.encode(), int(v)) for v in ids], np.int32)

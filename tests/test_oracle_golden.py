@@ -531,3 +531,113 @@ def test_timestamped_rows_sort_by_timestamp_golden(orc):
     graph = dict(row_ptr=rp, col=col, eid=eid, weight=w, ids=rows)
     n, e = orc.sample(graph, "TopkSampler", rows, 4)
     assert np.array_equal(n, g["topk_nbr"]) and np.array_equal(e, g["topk_eid"])  # "top" = earliest here
+
+
+# ------------------------------------------------------------ sampling filters ---
+FILTERS = {"id_eq": (1, 1), "id_gt": (2, 1), "ts_eq": (1, 2), "ts_gt": (2, 2)}  # (FilterType, FilterField)
+
+
+def filtered_graph(g, orc=None):
+    d = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"], ts_slot=g["ts_slot"])
+    return d
+
+
+def test_filtered_topk_and_full_match_reference(orc):
+    """a6: Filter::ActOn's reserved order (the in-place partition of filter.cc:83-94, the descending
+    binary-search prefix of :74-82 that reads values[0] for every row) and the padders behind
+    it, for TopkSampler / FullSampler: bit-identical to the reference on all 32 golden cases."""
+    g = load("filtered.npz")
+    og = filtered_graph(g)
+    for name in g["cases"]:
+        kind, strategy, k, pad = str(name).rsplit("_", 3)[0], str(name).split("_")[2], int(str(name).split("_k")[1][0]), \
+            int(str(name)[-1])
+        ft, ff = FILTERS[kind]
+        ids, vals = g[name + "_ids"], g[name + "_values"]
+        flt = dict(type=ft, field=ff, values=vals)
+        if strategy == "FullSampler":
+            deg, nbr, eid = orc.sample_full_filtered(og, ids, k, flt, padding_mode=pad, default_neighbor_id=-7)
+            assert np.array_equal(deg, g[name + "_deg"]), name
+        else:
+            nbr, eid = orc.sample_filtered(og, "TopkSampler", ids, k, flt, padding_mode=pad, default_neighbor_id=-7)
+        assert np.array_equal(nbr, g[name + "_nbr"]), name
+        assert np.array_equal(eid, g[name + "_eid"]), name
+
+
+def test_filter_values_expand_like_fill_values(orc):
+    """Filter::FillValues (filter.cc:53-67): each value covers batch / len(values) request rows."""
+    g = load("filtered.npz")
+    vals = np.repeat(g["fill_values"], g["fill_ids"].shape[0] // g["fill_values"].shape[0])
+    nbr, eid = orc.sample_filtered(filtered_graph(g), "TopkSampler", g["fill_ids"], 5, dict(type=1, field=1, values=vals),
+                                   default_neighbor_id=-7)
+    assert np.array_equal(nbr, g["fill_nbr"]) and np.array_equal(eid, g["fill_eid"])
+
+
+def test_filter_quirks_are_kept(orc):
+    g = load("filtered.npz")
+    nb = np.array([5, 7, 5, 9, 5, 3], np.int64)
+    # the partition pulls survivors from the right end into the holes, rightmost first
+    assert orc.filter_act_on(dict(type=1, field=1, values=[5]), 0, nb).tolist() == [5, 1, 3]
+    assert orc.filter_act_on(dict(type=2, field=1, values=[5]), 0, nb).tolist() == [0, 5, 2, 4]
+    ts = np.array([1, 2, 2, 4, 8, 9], np.int64)
+    # timestamp > v: a descending prefix; a single-neighbour row always comes back empty (filter.cc:208-210)
+    assert orc.filter_act_on(dict(type=2, field=2, values=[3]), 0, nb, ts).tolist() == [2, 1, 0]
+    assert orc.filter_act_on(dict(type=2, field=2, values=[100]), 0, nb[:1], ts[:1]).tolist() == []
+    # ... and reads values[0] whatever the request row
+    assert orc.filter_act_on(dict(type=2, field=2, values=[3, 100]), 1, nb, ts).tolist() == [2, 1, 0]
+
+
+@pytest.mark.parametrize("name", ["RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler",
+                                  "InDegreeSampler"])
+def test_filtered_random_samplers_match_reference_distribution(orc, name):
+    """ID == value filter, retry budget 1: per (row, slot) histograms vs 20000 reference requests."""
+    g = load("filtered.npz")
+    og = dict(row_ptr=g["d_row_ptr"], col=g["d_col"], eid=g["d_eid"], weight=g["d_w_slot"], ids=g["d_rows"],
+              indeg_weight=g["d_indeg_w"])
+    T, degs, k = int(g["d_T"]), g["d_degs"], 4
+    flt = dict(type=1, field=1, values=np.tile(g["d_values"], T), retry_times=1)
+    _, eid = orc.sample_filtered(og, name, np.tile(g["d_rows"][:len(degs)], T), k, flt, seed=77, call_counter=2)
+    eid = eid.reshape(T, len(degs), k)
+    ref_hist = g["d_%s_hist" % name]
+    rp = g["d_row_ptr"]
+    for r, d in enumerate(degs):
+        pos_of = {int(x): i for i, x in enumerate(g["d_eid"][rp[r]:rp[r + 1]])}
+        pos = np.vectorize(pos_of.get)(eid[:, r, :])
+        for j in range(k):
+            h = np.bincount(pos[:, j], minlength=d)
+            assert _two_sample_p(h, ref_hist[r, j, :d]) > 1e-4, (name, r, j, h, ref_hist[r, j, :d])
+        hit = int(np.flatnonzero(g["d_col"][rp[r]:rp[r + 1]] == g["d_values"][r])[0])
+        if name != "RandomSampler":  # ActOn removes the neighbour for good; RandomSampler leaks it (1/d)^2 of the time
+            assert ref_hist[r, :, hit].sum() == 0 and (pos == hit).sum() == 0
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_filtered_samplers_live_against_reference(orc):
+    """Fresh random requests (every filter, both paddings, Topk + Full) against the live reference."""
+    g = load("filtered.npz")
+    og = filtered_graph(g)
+    ref = RefLib()
+    try:
+        ref.add_edges_timestamped("flt", g["src"], g["dst"], g["ts"], g["w"])
+        rng = np.random.default_rng(8)
+        rows, rp = g["rows"], g["row_ptr"]
+        for trial in range(40):
+            ids = rng.choice(rows, 24)
+            kind = list(FILTERS)[trial % 4]
+            ft, ff = FILTERS[kind]
+            if ff == 1:
+                vals = rng.integers(898, 913, ids.shape[0])
+            else:
+                vals = rng.choice(g["ts"], ids.shape[0]) + rng.integers(-1, 2, ids.shape[0])
+            pad = (trial // 4) % 2
+            ref.set_flags(pad, -3, 0.0)
+            flt = dict(type=ft, field=ff, values=vals.astype(np.int64))
+            k = int(rng.integers(1, 9))
+            a = orc.sample_filtered(og, "TopkSampler", ids, k, flt, padding_mode=pad, default_neighbor_id=-3)
+            b = ref.sample_filtered("flt", "TopkSampler", ids, k, flt)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (trial, kind, pad)
+            if pad == 0:  # replicate: no FillWith(dim2) on emptied rows
+                a = orc.sample_full_filtered(og, ids, k - 1, flt, padding_mode=pad, default_neighbor_id=-3)
+                b = ref.sample_filtered("flt", "FullSampler", ids, k - 1, flt)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (trial, kind)
+    finally:
+        ref.close()
