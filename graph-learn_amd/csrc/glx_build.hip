@@ -103,7 +103,7 @@ int build_impl(glx_graph* g, const int64_t* src, const int64_t* dst, const float
       GLX_HIP(hipMemcpyAsync(h_w.p, weight, (size_t)E * 4, kind, s));
       d_w = h_w.as<float>();
     }
-    if (timestamp && order == GLX_ORDER_TIMESTAMP_ASC) {
+    if (timestamp) {
       GLX_HIP(hipMalloc(&h_ts.p, (size_t)E * 8));
       GLX_HIP(hipMemcpyAsync(h_ts.p, timestamp, (size_t)E * 8, kind, s));
       d_ts = h_ts.as<int64_t>();
@@ -175,6 +175,11 @@ int build_impl(glx_graph* g, const int64_t* src, const int64_t* dst, const float
   if (weight) {
     GLX_HIP(hipMalloc(&g->weight, (size_t)E * 4));
     glx_gather_kernel<float><<<grid_for(E), 256, 0, s>>>(d_w, perm, E, g->weight);
+  }
+  if (timestamp) {
+    // GetEdgeTimestamp(edge id) of every slot, for timestamp filters (filter.cc:136-141)
+    GLX_HIP(hipMalloc(&g->ts, (size_t)E * 8));
+    glx_gather_kernel<int64_t><<<grid_for(E), 256, 0, s>>>(d_ts, perm, E, g->ts);
   }
   GLX_HIP(hipGetLastError());
   return glx_graph_finalize(g, uniq.as<int64_t>(), s);

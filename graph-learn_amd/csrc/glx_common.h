@@ -163,6 +163,7 @@ struct glx_graph {
   int64_t* dst_count;     // [num_dst] in-degree of every distinct destination id
   int64_t num_dst;
   GlxEwRec* ew;           // [E] packed EdgeWeight records, or nullptr (edge ids beyond int32)
+  int64_t* ts;            // [E] GetEdgeTimestamp of every slot (timestamp filters), or nullptr
   GlxIdMapStorage idmap;
   GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
 };

@@ -1,0 +1,554 @@
+// glx: neighbour sampling with a Filter.
+// Replaces op::Filter (core/operator/sampler/filter.h:30-125, filter.cc:69-229) as the
+// samplers call it: RandomSampler's HitAll / Hit rejection loop (random_sampler.cc:52-71)
+// and ActOn in front of Topk / RandomWithoutReplacement / EdgeWeight / InDegree / Full
+// (topk_sampler.cc:52-61, random_without_replacement_sampler.cc:56-68,
+// edge_weight_sampler.cc:55-66,94-112, in_degree_sampler.cc:54-65,94-113,
+// full_sampler.cc:66-84).
+//
+// A filtered request is served in stages that all stay on the device:
+//   rows      request row -> (first slot, degree); exclusive scan of the degrees gives every
+//             row a private span of a scratch array
+//   reserve   one wave per row writes ActOn's reserved positions, in the reference's order,
+//             into the row's span (closed form of the in-place partition, see the kernel)
+//   draw      per strategy: nothing (Topk/Full), a Fisher-Yates over the span (RWoR), or a
+//             per-row alias build over the reserved weights (EdgeWeight/InDegree)
+//   pad       slots are filled through the span with the padders' rules
+// RandomSampler never materialises the reserved set: a count kernel answers HitAll and the
+// slot kernel redraws hits from the row's random stream.
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "glx_common.h"
+
+namespace {
+
+struct FilterDev {
+  int32_t type, field;
+  const int64_t* values;
+  const int64_t* ts;  // per slot, or nullptr
+  int64_t default_ts;
+  int32_t retry;
+};
+
+// Filter::GetFieldFunc, filter.cc:122-150
+__device__ __forceinline__ int64_t field_of(const FilterDev& f, const GlxAdj* __restrict__ adj, int64_t slot) {
+  if (f.field == GLX_FILTER_FIELD_ID) return adj[slot].nbr;
+  if (f.field == GLX_FILTER_FIELD_TIMESTAMP) return f.ts ? f.ts[slot] : f.default_ts;
+  return -1;
+}
+
+// Filter::GetFilterFunc, filter.cc:152-193
+__device__ __forceinline__ bool hit_of(const FilterDev& f, int64_t v, int64_t value) {
+  if (f.type == GLX_FILTER_EQUAL) return v == value;
+  if (f.type == GLX_FILTER_LARGER_THAN) return v > value;
+  return false;
+}
+
+struct RowArgs {
+  GlxIdMap map;
+  const int64_t* row_ptr;
+  const GlxAdj* adj;
+  const int64_t* src;
+  const int64_t* rng_rows;
+  int32_t batch;
+};
+
+__global__ void glx_filter_rows_kernel(RowArgs a, int64_t* __restrict__ start, int32_t* __restrict__ deg,
+                                       int64_t* __restrict__ deg64) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.batch) return;
+  const int64_t row = glx_row_of(a.map, a.src[i]);
+  int64_t s = 0, d = 0;
+  if (row >= 0) {
+    s = a.row_ptr[row];
+    d = a.row_ptr[row + 1] - s;
+  }
+  start[i] = s;
+  deg[i] = (int32_t)d;
+  if (deg64) deg64[i] = d;
+}
+
+__global__ void glx_filter_zero_kernel(int64_t* p) { *p = 0; }
+
+// Number of neighbours of every request row that do NOT hit (0 <=> Filter::HitAll).
+__global__ __launch_bounds__(64) void glx_filter_count_kernel(FilterDev f, const GlxAdj* __restrict__ adj,
+                                                              const int64_t* __restrict__ start,
+                                                              const int32_t* __restrict__ deg,
+                                                              int32_t* __restrict__ nonhit) {
+  const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int32_t n = deg[i];
+  const int64_t s = start[i];
+  const int64_t val = f.values[i];
+  int32_t cnt = 0;
+  for (int32_t base = 0; base < n; base += 64) {
+    const int32_t p = base + lane;
+    const bool nh = p < n && !hit_of(f, field_of(f, adj, s + p), val);
+    cnt += __popcll(__ballot(nh));
+  }
+  if (lane == 0) nonhit[i] = cnt;
+}
+
+// Filter::ActOn for one request row per wave.
+//
+// General path (filter.cc:83-94): the reference walks l upwards and, while indices[l] hits,
+// swaps it with indices[r] and shrinks r.  Net effect on the kept prefix [0, m), m = number
+// of survivors: a surviving position keeps its place; the holes (hit positions below m), taken
+// in ascending order, receive the survivors at positions >= m in DESCENDING order.  So three
+// passes with ballots: count m; write survivors below m in place and list the ones at or above m
+// (ascending) in the unused tail [m, n) of the row's span; fill hole h from tail entry
+// F - 1 - h (F = number of holes = number of tail survivors).
+//
+// Timestamp + LARGER_THAN (filter.cc:74-82, FindkthLargest :196-229): binary search for
+// values[0] -- request row 0's value, whatever the row -- over the timestamp-ascending row; the
+// reserved set is the prefix below the found position, listed descending; a row with a single
+// neighbour keeps nothing.
+__global__ __launch_bounds__(64) void glx_filter_reserve_kernel(FilterDev f, const GlxAdj* __restrict__ adj,
+                                                                const int64_t* __restrict__ start,
+                                                                const int32_t* __restrict__ deg,
+                                                                const int64_t* __restrict__ soff,
+                                                                int32_t* __restrict__ res,
+                                                                int32_t* __restrict__ res_cnt) {
+  const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int32_t n = deg[i];
+  if (n == 0) {
+    if (lane == 0) res_cnt[i] = 0;
+    return;
+  }
+  const int64_t s = start[i];
+  int32_t* R = res + soff[i];
+  if (f.field == GLX_FILTER_FIELD_TIMESTAMP && f.type == GLX_FILTER_LARGER_THAN) {
+    int32_t k = 0;
+    if (lane == 0) {
+      const int64_t filter = f.values[0];
+      int32_t lo = 0, hi = n - 1, mid = 0;
+      if (hi == 0) {
+        k = -1;
+      } else {
+        bool found = false;
+        while (hi >= lo) {
+          mid = lo + (hi - lo) / 2;
+          const int64_t v = field_of(f, adj, s + mid);
+          if (v == filter) {
+            found = true;
+            break;
+          }
+          if (v > filter) hi = mid - 1;
+          else lo = mid + 1;
+        }
+        if (!found && field_of(f, adj, s + mid) < filter) mid += 1;
+        k = mid;
+      }
+      if (k < 0) k = 0;
+    }
+    k = __shfl(k, 0);
+    for (int32_t t = lane; t < k; t += 64) R[t] = k - 1 - t;
+    if (lane == 0) res_cnt[i] = k;
+    return;
+  }
+  const int64_t val = f.values[i];
+  const uint64_t lt = (1ull << lane) - 1ull;
+  int32_t m = 0;
+  for (int32_t base = 0; base < n; base += 64) {
+    const int32_t p = base + lane;
+    const bool nh = p < n && !hit_of(f, field_of(f, adj, s + p), val);
+    m += __popcll(__ballot(nh));
+  }
+  int32_t tail = 0;  // survivors at positions >= m seen so far
+  for (int32_t base = 0; base < n; base += 64) {
+    const int32_t p = base + lane;
+    const bool nh = p < n && !hit_of(f, field_of(f, adj, s + p), val);
+    const bool up = nh && p >= m;
+    const uint64_t b = __ballot(up);
+    if (nh && p < m) R[p] = p;
+    if (up) R[m + tail + __popcll(b & lt)] = p;
+    tail += __popcll(b);
+  }
+  __syncthreads();  // one wave per block: orders the tail list before the hole fill
+  int32_t holes = 0;
+  for (int32_t base = 0; base < m; base += 64) {
+    const int32_t p = base + lane;
+    const bool h = p < m && hit_of(f, field_of(f, adj, s + p), val);
+    const uint64_t b = __ballot(h);
+    if (h) {
+      const int32_t rank = holes + __popcll(b & lt);
+      R[p] = R[m + tail - 1 - rank];
+    }
+    holes += __popcll(b);
+  }
+  if (lane == 0) res_cnt[i] = m;
+}
+
+struct DrawArgs {
+  const GlxAdj* adj;
+  const int64_t* start;
+  const int32_t* deg;
+  const int64_t* soff;
+  const int32_t* res;
+  const int32_t* res_cnt;
+  const int64_t* rng_rows;
+  uint64_t seed, cc;
+  int64_t default_nbr;
+  int32_t batch, k;
+};
+
+// RandomWithoutReplacement: std::shuffle(reserved) under the contract's forward Fisher-Yates
+// (step j swaps entry j with entry j + bounded(draw_j, m - j)); only the first min(k, m) steps
+// can reach the padded output.  One thread per request row, in place on the row's span.
+__global__ void glx_filter_shuffle_kernel(DrawArgs a, int32_t* __restrict__ res) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.batch || a.deg[i] == 0) return;
+  const int32_t m = a.res_cnt[i];
+  int32_t* R = res + a.soff[i];
+  const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
+  const int32_t steps = m < a.k ? m : a.k;
+  for (int32_t j = 0; j < steps; ++j) {
+    const int32_t r = j + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, (uint32_t)j), (uint64_t)(m - j));
+    const int32_t t = R[j];
+    R[j] = R[r];
+    R[r] = t;
+  }
+}
+
+// SampleFromIndices (edge_weight_sampler.cc:94-112, in_degree_sampler.cc:94-113): the alias
+// table of the reserved neighbours' weights, rebuilt per request row like the reference does.
+// One thread per row; dist / tab / stk are spans parallel to the reserved list.
+__global__ void glx_filter_alias_build_kernel(DrawArgs a, const float* __restrict__ weight, GlxIdMap dst_map,
+                                              const int64_t* __restrict__ dst_count, float* __restrict__ dist,
+                                              GlxAlias* __restrict__ tab, int32_t* __restrict__ stk) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.batch || a.deg[i] == 0) return;
+  const int32_t m = a.res_cnt[i];
+  if (m == 0) return;
+  const int64_t off = a.soff[i], s = a.start[i];
+  for (int32_t t = 0; t < m; ++t) {
+    const int64_t slot = s + a.res[off + t];
+    float w;
+    if (weight) {
+      w = weight[slot];
+    } else {
+      const int64_t r = glx_row_of(dst_map, a.adj[slot].nbr);
+      w = r < 0 ? 0.0f : (float)(int32_t)dst_count[r];  // static_cast<float>(GetInDegree(id))
+    }
+    dist[off + t] = w;
+  }
+  glx_alias_build_row(dist + off, m, tab + off, stk + off, stk + off + m - 1);
+}
+
+// EdgeWeight / InDegree slots under circular padding: k alias draws mapped back through the
+// reserved list (indices.size() == k, so the padder is the identity over them).
+__global__ __launch_bounds__(256) void glx_filter_alias_slots_kernel(DrawArgs a, const GlxAlias* __restrict__ tab,
+                                                                     int64_t* __restrict__ nbr_out,
+                                                                     int64_t* __restrict__ eid_out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)a.batch * a.k) return;
+  const int32_t i = (int32_t)(t / a.k);
+  const int32_t j = (int32_t)(t - (int64_t)i * a.k);
+  GlxAdj rec = GlxAdj{a.default_nbr, -1};
+  const int32_t m = a.deg[i] > 0 ? a.res_cnt[i] : 0;
+  if (m > 0) {
+    const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
+    const int64_t off = a.soff[i];
+    const int32_t pick = glx_alias_pick(glx_draw64(a.seed, a.cc, rr, (uint32_t)j), m, tab + off);
+    rec = a.adj[a.start[i] + a.res[off + pick]];
+  }
+  nbr_out[t] = rec.nbr;
+  eid_out[t] = rec.eid;
+}
+
+// The padders over a reserved list (circular_padder.h:36-66, replicate_padder.h:37-56); one
+// wave per request row, target = k (dense) or the row's segment (FullSampler).
+//   kPadCircular        m == 0: default ids; else slot j = reserved[j % m]
+//   kPadReplicate       the first min(target, m) neighbours IN ROW ORDER (the padder ignores the
+//                       index values), then default ids
+//   kPadReplicateDrawn  EdgeWeight / InDegree: the index list has k entries unless nothing was
+//                       reserved, so min(target, deg) row-order neighbours (clamped to the row
+//                       instead of the reference's out-of-bounds read), or all default
+enum { kPadCircular = 0, kPadReplicate = 1, kPadReplicateDrawn = 2 };
+__global__ __launch_bounds__(256) void glx_filter_pad_kernel(DrawArgs a, const int64_t* __restrict__ offsets, int mode,
+                                                             int64_t* __restrict__ nbr_out,
+                                                             int64_t* __restrict__ eid_out) {
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= a.batch) return;
+  const int32_t n = a.deg[i];
+  const int32_t m = n > 0 ? a.res_cnt[i] : 0;
+  const int64_t s = a.start[i];
+  const int64_t o0 = offsets ? offsets[i] : i * (int64_t)a.k;
+  const int64_t target = offsets ? offsets[i + 1] - o0 : a.k;
+  const int32_t* R = a.res + a.soff[i];
+  for (int64_t j = lane; j < target; j += 64) {
+    GlxAdj rec = GlxAdj{a.default_nbr, -1};
+    if (mode == kPadCircular) {
+      if (m > 0) rec = a.adj[s + R[j % m]];
+    } else if (mode == kPadReplicate) {
+      if (j < m) rec = a.adj[s + j];
+    } else {
+      if (m > 0 && j < n) rec = a.adj[s + j];
+    }
+    nbr_out[o0 + j] = rec.nbr;
+    eid_out[o0 + j] = rec.eid;
+  }
+}
+
+// RandomSampler (random_sampler.cc:58-71): HitAll rows are default-filled; every other slot
+// redraws a hit `retry` times and keeps the next draw whatever it is.
+__global__ __launch_bounds__(256) void glx_filter_random_kernel(DrawArgs a, FilterDev f,
+                                                                const int32_t* __restrict__ nonhit,
+                                                                int64_t* __restrict__ nbr_out,
+                                                                int64_t* __restrict__ eid_out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)a.batch * a.k) return;
+  const int32_t i = (int32_t)(t / a.k);
+  const int32_t j = (int32_t)(t - (int64_t)i * a.k);
+  GlxAdj rec = GlxAdj{a.default_nbr, -1};
+  const int32_t n = a.deg[i];
+  if (n > 0 && nonhit[i] > 0) {
+    const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
+    const int64_t s = a.start[i];
+    const int64_t val = f.values[i];
+    for (int32_t at = 0;; ++at) {
+      const uint32_t draw = (uint32_t)j + (uint32_t)at * (uint32_t)a.k;
+      const int64_t d = (int64_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, draw), (uint64_t)n);
+      if (at >= f.retry || !hit_of(f, field_of(f, a.adj, s + d), val)) {
+        rec = a.adj[s + d];
+        break;
+      }
+    }
+  }
+  nbr_out[t] = rec.nbr;
+  eid_out[t] = rec.eid;
+}
+
+constexpr int kFullSampler = -1;
+
+// All pointers are device pointers.  `sampler` is a GLX_SAMPLER_* id or kFullSampler (then
+// d_offsets[batch + 1] gives the segments and k is unused).
+int filtered_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng, int32_t batch,
+                    int32_t k, const int64_t* d_offsets, int padding_mode, int64_t default_nbr, uint64_t seed,
+                    uint64_t cc, FilterDev f, int64_t* d_nbr, int64_t* d_eid, hipStream_t s) {
+  const bool circular = padding_mode == GLX_PAD_CIRCULAR;
+  const size_t nb = (size_t)batch;
+  // row info: start[batch] i64 | soff[batch + 1] i64 | deg[batch] i32 | cnt[batch] i32
+  char* info = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&info), (nb * 2 + 1) * 8 + nb * 2 * 4, s, 1);
+  if (rc != GLX_OK) return rc;
+  int64_t* start = reinterpret_cast<int64_t*>(info);
+  int64_t* soff = start + nb;
+  int32_t* deg = reinterpret_cast<int32_t*>(soff + nb + 1);
+  int32_t* cnt = deg + nb;
+  RowArgs ra{g->map(), g->row_ptr, g->adj, d_src, d_rng, batch};
+  DrawArgs da{g->adj, start, deg, soff, nullptr, cnt, d_rng, seed, cc, default_nbr, batch, k};
+  const unsigned row_blocks = (unsigned)((nb + 255) / 256);
+  GlxKernelTimer timer(GLX_KERNEL_SAMPLE, s);
+  if (sampler == GLX_SAMPLER_RANDOM) {
+    glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, nullptr);
+    glx_filter_count_kernel<<<(unsigned)batch, 64, 0, s>>>(f, g->adj, start, deg, cnt);
+    const int64_t total = (int64_t)batch * k;
+    glx_filter_random_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(da, f, cnt, d_nbr, d_eid);
+    timer.stop();
+    GLX_HIP(hipGetLastError());
+    return GLX_OK;
+  }
+  glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, soff + 1);
+  glx_filter_zero_kernel<<<1, 1, 0, s>>>(soff);
+  {
+    size_t bytes = 0;
+    GLX_HIP(rocprim::inclusive_scan(nullptr, bytes, soff + 1, soff + 1, nb, rocprim::plus<int64_t>(), s));
+    void* tmp = nullptr;
+    rc = glx_scratch_alloc(&tmp, bytes, s, 3);
+    if (rc != GLX_OK) return rc;
+    GLX_HIP(rocprim::inclusive_scan(tmp, bytes, soff + 1, soff + 1, nb, rocprim::plus<int64_t>(), s));
+  }
+  int64_t total_deg = 0;
+  GLX_HIP(hipMemcpyAsync(&total_deg, soff + nb, 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  const bool alias_draw = circular && (sampler == GLX_SAMPLER_EDGE_WEIGHT || sampler == GLX_SAMPLER_IN_DEGREE);
+  // reserved positions i32 [| alias table 8 B | weights f32 | stacks i32], each total_deg long
+  const size_t span = ((size_t)total_deg + 1) & ~(size_t)1;  // keeps the 8-byte table aligned
+  char* work = nullptr;
+  rc = glx_scratch_alloc(reinterpret_cast<void**>(&work), span * (alias_draw ? 20 : 4) + 16, s, 2);
+  if (rc != GLX_OK) return rc;
+  GlxAlias* tab = reinterpret_cast<GlxAlias*>(work);
+  int32_t* res = alias_draw ? reinterpret_cast<int32_t*>(work + span * 8) : reinterpret_cast<int32_t*>(work);
+  float* dist = reinterpret_cast<float*>(work + span * 12);
+  int32_t* stk = reinterpret_cast<int32_t*>(work + span * 16);
+  da.res = res;
+  glx_filter_reserve_kernel<<<(unsigned)batch, 64, 0, s>>>(f, g->adj, start, deg, soff, res, cnt);
+  const unsigned wave_blocks = (unsigned)((nb * 64 + 255) / 256);
+  if (sampler == kFullSampler) {
+    glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, d_offsets, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
+  } else if (sampler == GLX_SAMPLER_TOPK) {
+    glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, nullptr, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
+  } else if (sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT) {
+    if (circular) glx_filter_shuffle_kernel<<<row_blocks, 256, 0, s>>>(da, res);
+    glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, nullptr, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
+  } else {  // EdgeWeight / InDegree
+    if (!circular) {
+      glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, nullptr, kPadReplicateDrawn, d_nbr, d_eid);
+    } else {
+      const bool by_weight = sampler == GLX_SAMPLER_EDGE_WEIGHT;
+      const GlxIdMap dm = GlxIdMap{g->dst_map.keys, g->dst_map.vals, g->dst_map.cap - 1, g->num_dst};
+      glx_filter_alias_build_kernel<<<row_blocks, 256, 0, s>>>(da, by_weight ? g->weight : nullptr, dm, g->dst_count,
+                                                              dist, tab, stk);
+      const int64_t total = (int64_t)batch * k;
+      glx_filter_alias_slots_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(da, tab, d_nbr, d_eid);
+    }
+  }
+  timer.stop();
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+int check_filter(const glx_graph* g, const glx_filter* filter) {
+  GLX_REQUIRE(filter->type == GLX_FILTER_EQUAL || filter->type == GLX_FILTER_LARGER_THAN, "unknown filter type %d",
+              filter->type);
+  GLX_REQUIRE(filter->field >= GLX_FILTER_FIELD_NONE && filter->field <= GLX_FILTER_FIELD_TIMESTAMP,
+              "unknown filter field %d", filter->field);
+  GLX_REQUIRE(filter->values != nullptr, "filter values are NULL");
+  (void)g;
+  return GLX_OK;
+}
+
+// Stages host arrays next to each other in one slot-0 workspace; entries with a NULL source
+// are outputs (or absent).
+struct Staged {
+  int64_t* d = nullptr;
+  size_t used = 0;
+  int64_t* take(size_t n) {
+    int64_t* p = d + used;
+    used += n;
+    return p;
+  }
+};
+
+}  // namespace
+
+extern "C" int glx_graph_set_timestamps(glx_graph* g, const int64_t* ts_slot, int ptr_kind, void* stream) {
+  GLX_REQUIRE(g != nullptr, "graph is NULL");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  GLX_REQUIRE(ts_slot != nullptr || g->num_edges == 0, "timestamps are NULL");
+  GlxDeviceGuard guard(g->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
+  hipStream_t s = glx_stream(stream);
+  if (!g->ts) GLX_HIP(hipMalloc(&g->ts, (size_t)(g->num_edges > 0 ? g->num_edges : 1) * 8));
+  if (g->num_edges > 0) {
+    GLX_HIP(hipMemcpyAsync(g->ts, ts_slot, (size_t)g->num_edges * 8,
+                           ptr_kind == GLX_PTR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+  }
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
+}
+
+extern "C" int glx_sample_filtered(const glx_graph* g, int sampler, const int64_t* src, const int64_t* rng_rows,
+                                   int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id,
+                                   uint64_t seed, uint64_t call_counter, const glx_filter* filter,
+                                   int64_t* nbr_out, int64_t* eid_out, int ptr_kind, void* stream) {
+  if (filter == nullptr || filter->type == GLX_FILTER_NONE) {
+    return glx_sample_ex(g, sampler, src, rng_rows, batch, k, padding_mode, default_neighbor_id, seed, call_counter,
+                         nbr_out, eid_out, ptr_kind, stream);
+  }
+  GLX_REQUIRE(g != nullptr, "graph is NULL");
+  GLX_REQUIRE(batch >= 0 && k >= 0, "negative batch / neighbor_count");
+  GLX_REQUIRE(padding_mode == GLX_PAD_CIRCULAR || padding_mode == GLX_PAD_REPLICATE, "bad padding_mode %d",
+              padding_mode);
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  GLX_REQUIRE(sampler >= GLX_SAMPLER_RANDOM && sampler <= GLX_SAMPLER_IN_DEGREE, "unknown sampler id %d", sampler);
+  GLX_REQUIRE((int64_t)batch * k <= INT32_MAX, "batch * neighbor_count exceeds int32 (tensor.h:47)");
+  if (batch == 0 || k == 0) return GLX_OK;
+  GLX_REQUIRE(src && nbr_out && eid_out, "NULL data pointer");
+  int rc = check_filter(g, filter);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(sampler != GLX_SAMPLER_EDGE_WEIGHT || g->weight != nullptr, "EdgeWeightSampler needs a weighted graph");
+  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || g->dst_count != nullptr,
+              "InDegreeSampler needs glx_graph_enable_in_degree()");
+  GlxDeviceGuard guard(g->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
+  FilterDev f{filter->type, filter->field, filter->values, g->ts, filter->default_timestamp, filter->retry_times};
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    return filtered_device(g, sampler, src, rng_rows, batch, k, nullptr, padding_mode, default_neighbor_id, seed,
+                           call_counter, f, nbr_out, eid_out, s);
+  }
+  const size_t nb = (size_t)batch, n_out = nb * (size_t)k;
+  Staged st;
+  rc = glx_scratch_alloc(reinterpret_cast<void**>(&st.d), (nb * 3 + n_out * 2) * 8, s, 0);
+  if (rc != GLX_OK) return rc;
+  int64_t* d_src = st.take(nb);
+  int64_t* d_val = st.take(nb);
+  int64_t* d_rng = rng_rows ? st.take(nb) : nullptr;
+  int64_t* d_nbr = st.take(n_out);
+  int64_t* d_eid = st.take(n_out);
+  GLX_HIP(hipMemcpyAsync(d_src, src, nb * 8, hipMemcpyHostToDevice, s));
+  GLX_HIP(hipMemcpyAsync(d_val, filter->values, nb * 8, hipMemcpyHostToDevice, s));
+  if (rng_rows) GLX_HIP(hipMemcpyAsync(d_rng, rng_rows, nb * 8, hipMemcpyHostToDevice, s));
+  f.values = d_val;
+  rc = filtered_device(g, sampler, d_src, d_rng, batch, k, nullptr, padding_mode, default_neighbor_id, seed,
+                       call_counter, f, d_nbr, d_eid, s);
+  if (rc != GLX_OK) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
+  GLX_HIP(hipMemcpyAsync(nbr_out, d_nbr, n_out * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipMemcpyAsync(eid_out, d_eid, n_out * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
+}
+
+extern "C" int glx_sample_full_filtered(const glx_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                                        const int64_t* offsets, int padding_mode, int64_t default_neighbor_id,
+                                        const glx_filter* filter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+                                        void* stream) {
+  if (filter == nullptr || filter->type == GLX_FILTER_NONE) {
+    return glx_sample_full(g, src, batch, max_limit, offsets, nbr_out, eid_out, ptr_kind, stream);
+  }
+  GLX_REQUIRE(g != nullptr, "graph is NULL");
+  GLX_REQUIRE(batch >= 0, "negative batch");
+  GLX_REQUIRE(padding_mode == GLX_PAD_CIRCULAR || padding_mode == GLX_PAD_REPLICATE, "bad padding_mode %d",
+              padding_mode);
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  if (batch == 0) return GLX_OK;
+  GLX_REQUIRE(src && offsets, "NULL data pointer");
+  int rc = check_filter(g, filter);
+  if (rc != GLX_OK) return rc;
+  (void)max_limit;  // the segments in `offsets` already carry the truncation
+  GlxDeviceGuard guard(g->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
+  FilterDev f{filter->type, filter->field, filter->values, g->ts, filter->default_timestamp, filter->retry_times};
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    GLX_REQUIRE(nbr_out && eid_out, "NULL output pointer");
+    return filtered_device(g, kFullSampler, src, nullptr, batch, 0, offsets, padding_mode, default_neighbor_id, 0, 0,
+                           f, nbr_out, eid_out, s);
+  }
+  const size_t nb = (size_t)batch;
+  const int64_t total = offsets[batch];
+  GLX_REQUIRE(total >= 0, "bad offsets");
+  if (total == 0) return GLX_OK;
+  GLX_REQUIRE(nbr_out && eid_out, "NULL output pointer");
+  Staged st;
+  rc = glx_scratch_alloc(reinterpret_cast<void**>(&st.d), (nb * 3 + 1 + (size_t)total * 2) * 8, s, 0);
+  if (rc != GLX_OK) return rc;
+  int64_t* d_src = st.take(nb);
+  int64_t* d_val = st.take(nb);
+  int64_t* d_off = st.take(nb + 1);
+  int64_t* d_nbr = st.take((size_t)total);
+  int64_t* d_eid = st.take((size_t)total);
+  GLX_HIP(hipMemcpyAsync(d_src, src, nb * 8, hipMemcpyHostToDevice, s));
+  GLX_HIP(hipMemcpyAsync(d_val, filter->values, nb * 8, hipMemcpyHostToDevice, s));
+  GLX_HIP(hipMemcpyAsync(d_off, offsets, (nb + 1) * 8, hipMemcpyHostToDevice, s));
+  f.values = d_val;
+  rc = filtered_device(g, kFullSampler, d_src, nullptr, batch, 0, d_off, padding_mode, default_neighbor_id, 0, 0, f,
+                       d_nbr, d_eid, s);
+  if (rc != GLX_OK) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
+  GLX_HIP(hipMemcpyAsync(nbr_out, d_nbr, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipMemcpyAsync(eid_out, d_eid, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
+}

@@ -376,6 +376,7 @@ void glx_graph_free(glx_graph* g) {
   if (g->dst_count) (void)hipFree(g->dst_count);
   glx_idmap_free(&g->dst_map);
   if (g->ew) (void)hipFree(g->ew);
+  if (g->ts) (void)hipFree(g->ts);
   glx_idmap_free(&g->idmap);
   delete g;
 }

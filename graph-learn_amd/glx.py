@@ -41,6 +41,7 @@ EXPORTS = [
     "glx_graph_create", "glx_graph_build", "glx_graph_build_ordered", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
     "glx_graph_degrees", "glx_graph_in_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
     "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
+    "glx_graph_set_timestamps", "glx_sample_filtered", "glx_sample_full_filtered",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
     "glx_partition", "glx_stitch_i64", "glx_stitch_f32", "glx_aggregate_stitch",
@@ -48,6 +49,16 @@ EXPORTS = [
     "glx_negative_export", "glx_graph_enable_negative", "glx_negative_sample",
     "glx_profile_enable", "glx_profile_collect",
 ]
+
+
+FILTER_NONE, FILTER_EQUAL, FILTER_LARGER_THAN = 0, 1, 2
+FILTER_FIELD_NONE, FILTER_FIELD_ID, FILTER_FIELD_TIMESTAMP = 0, 1, 2
+
+
+class Filter(ctypes.Structure):
+    """glx_filter (include/glx.h): type, field, values[batch], retry_times, default_timestamp."""
+    _fields_ = [("type", ctypes.c_int32), ("field", ctypes.c_int32), ("values", ctypes.c_void_p),
+                ("retry_times", ctypes.c_int32), ("default_timestamp", ctypes.c_int64)]
 
 
 class GlxError(RuntimeError):
@@ -93,6 +104,10 @@ def lib():
         L.glx_graph_enable_in_degree.argtypes = [vp, vp]
         L.glx_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
         L.glx_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, ci, vp]
+        L.glx_graph_set_timestamps.argtypes = [vp, vp, ci, vp]
+        L.glx_sample_filtered.argtypes = [vp, ci, vp, vp, i32, i32, ci, i64, u64, u64, ctypes.POINTER(Filter), vp, vp, ci,
+                                          vp]
+        L.glx_sample_full_filtered.argtypes = [vp, vp, i32, i32, vp, ci, i64, ctypes.POINTER(Filter), vp, vp, ci, vp]
         L.glx_features_view.argtypes = [ci, i64, i32, vp, ctypes.POINTER(vp)]
         L.glx_features_create.argtypes = [ci, i64, i32, vp, vp, ci, vp, ctypes.POINTER(vp)]
         L.glx_features_destroy.argtypes = [vp]
@@ -252,6 +267,60 @@ class Graph:
         eid = np.empty(total, np.int64)
         _check(lib().glx_sample_full(self._h, _ptr(src)[0], batch, max_limit, _ptr(off)[0], _ptr(nbr)[0],
                                      _ptr(eid)[0], PTR_HOST, None))
+        return deg, nbr, eid
+
+    def set_timestamps(self, ts_slot):
+        """Per-slot edge timestamps (CSR order) for a handle made from a CSR; mutates the handle."""
+        p, kind = _ptr(ts_slot)
+        _check(lib().glx_graph_set_timestamps(self._h, p, kind, _stream(kind)))
+
+    def sample_filtered(self, sampler, src, k, filter_type, filter_field, values, seed=0, call_counter=0,
+                        padding_mode=PAD_CIRCULAR, default_neighbor_id=0, retry_times=5, default_timestamp=-1,
+                        rng_rows=None):
+        """Sampling with a Filter: values[batch] is the expanded filter tensor (same kind as src)."""
+        if isinstance(sampler, str):
+            sampler = SAMPLER_IDS[sampler] if sampler in SAMPLER_IDS else EXTRA_SAMPLER_IDS[sampler]
+        batch = int(src.shape[0])
+        if _is_torch(src):
+            import torch
+            nbr = torch.empty((batch, k), dtype=torch.int64, device=src.device)
+            eid = torch.empty((batch, k), dtype=torch.int64, device=src.device)
+        else:
+            nbr = np.empty((batch, k), np.int64)
+            eid = np.empty((batch, k), np.int64)
+        ps, pn, pe, pr, pv = _ptr(src), _ptr(nbr), _ptr(eid), _ptr(rng_rows), _ptr(values)
+        kind = _kind(ps, pn, pe, pr, pv)
+        flt = Filter(filter_type, filter_field, pv[0], retry_times, default_timestamp)
+        _check(lib().glx_sample_filtered(self._h, sampler, ps[0], pr[0], batch, k, padding_mode, default_neighbor_id,
+                                         seed, call_counter, ctypes.byref(flt), pn[0], pe[0], kind, _stream(kind)))
+        return nbr, eid
+
+    def sample_full_filtered(self, src, max_limit, filter_type, filter_field, values, padding_mode=PAD_CIRCULAR,
+                             default_neighbor_id=0, default_timestamp=-1):
+        """FullSampler with a Filter: -> (degrees, nbr, eid); the segments are the unfiltered ones."""
+        batch = int(src.shape[0])
+        torch_in = _is_torch(src)
+        if torch_in:
+            import torch
+            deg = torch.empty(batch, dtype=torch.int32, device=src.device)
+            off = torch.empty(batch + 1, dtype=torch.int64, device=src.device)
+        else:
+            deg = np.empty(batch, np.int32)
+            off = np.empty(batch + 1, np.int64)
+        kind = PTR_DEVICE if torch_in else PTR_HOST
+        _check(lib().glx_sample_full_sizes(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0], kind,
+                                           _stream(kind)))
+        total = int(off[-1].item()) if torch_in else int(off[-1])
+        if torch_in:
+            nbr = torch.empty(total, dtype=torch.int64, device=src.device)
+            eid = torch.empty(total, dtype=torch.int64, device=src.device)
+        else:
+            nbr = np.empty(total, np.int64)
+            eid = np.empty(total, np.int64)
+        flt = Filter(filter_type, filter_field, _ptr(values)[0], 0, default_timestamp)
+        _check(lib().glx_sample_full_filtered(self._h, _ptr(src)[0], batch, max_limit, _ptr(off)[0], padding_mode,
+                                              default_neighbor_id, ctypes.byref(flt), _ptr(nbr)[0], _ptr(eid)[0], kind,
+                                              _stream(kind)))
         return deg, nbr, eid
 
     def export_alias(self):

@@ -119,7 +119,8 @@ GLX_API int glx_graph_build(int device, int64_t num_edges, const int64_t* src, c
 /* Same, with the row order spelled out.  GLX_ORDER_TIMESTAMP_ASC orders every row by the
  * edges' timestamps ascending, which is what Build() does for timestamped edge types -- it
  * takes precedence over the weight order (memory_adj_matrix.cc:60-66,129-148); ties keep
- * insertion order.  timestamp[num_edges] is only read for that order. */
+ * insertion order.  timestamp (may be NULL for the other orders) is also kept per slot
+ * for timestamp filters (glx_sample_filtered). */
 #define GLX_ORDER_INSERTION 0
 #define GLX_ORDER_WEIGHT_DESC 1
 #define GLX_ORDER_TIMESTAMP_ASC 2
@@ -151,8 +152,8 @@ GLX_API int glx_graph_in_degrees(const glx_graph* g, const int64_t* ids, int64_t
  * `padding_mode` and `default_neighbor_id` are the reference's global flags,
  * passed explicitly.  (`seed`, `call_counter`) select the random stream (the
  * seeding contract in DESIGN.md): the same pair gives the same output,
- * bit-for-bit, on every run and every GPU count.  Filters are not supported
- * on this path.
+ * bit-for-bit, on every run and every GPU count.  Requests with a Filter go through
+ * glx_sample_filtered.
  */
 GLX_API int glx_sample(const glx_graph* g, int sampler, const int64_t* src, int32_t batch, int32_t k,
                int padding_mode, int64_t default_neighbor_id, uint64_t seed,
@@ -206,6 +207,56 @@ GLX_API int glx_sample_hops(const glx_graph* const* graphs, int32_t num_hops, in
                     const int64_t* seeds, int32_t batch, const int32_t* fanouts, int padding_mode,
                     int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
                     int64_t* const* nbr_out, int64_t* const* eid_out, int ptr_kind, void* stream);
+
+/* ---- sampling filters: replaces op::Filter (core/operator/sampler/filter.h:30-125,
+ * filter.cc:69-229) as the samplers use it (random_sampler.cc:52-71, topk_sampler.cc:52-61,
+ * random_without_replacement_sampler.cc:56-68, edge_weight_sampler.cc:55-66,94-112,
+ * in_degree_sampler.cc:54-65,94-113, full_sampler.cc:66-84). ----------------------------
+ * type / field carry the reference's enum values (include/constants.h:135-145).  values[batch]
+ * is the filter tensor AFTER Filter::FillValues: one value per request row, in the same
+ * memory kind as src.  A neighbour "hits" when its field (ID = the neighbour id, TIMESTAMP =
+ * the edge's timestamp, default_timestamp when the graph has none) == / > the row's value,
+ * and hits are what sampling avoids:
+ *   RandomSampler   a row whose neighbours all hit is default-filled; otherwise every slot
+ *                   redraws a hit up to retry_times times and then keeps it (attempt a of
+ *                   slot j is draw j + a * k of the row's stream);
+ *   the others      sample from the reserved positions Filter::ActOn leaves, in ITS order:
+ *                   survivors keep their place, holes left by hits are refilled from the
+ *                   right end, rightmost survivor first (filter.cc:83-94); TIMESTAMP +
+ *                   LARGER_THAN instead keeps the prefix below values[0] -- the value of
+ *                   request row 0, for every row (filter.h:107-111) -- in descending order,
+ *                   and keeps nothing of a single-neighbour row (filter.cc:208-210).
+ *                   EdgeWeight / InDegree rebuild the alias table over the reserved
+ *                   neighbours' weights per row, like the reference; padding as before.
+ * glx_sample_full_filtered: the row sizes stay those of glx_sample_full_sizes (the
+ *   UNFILTERED min(limit, deg), full_sampler.cc:55-62) and the reserved neighbours are padded
+ *   up to that size; a row whose neighbours all hit yields default ids (the reference's
+ *   FillWith(dim2) breaks the ragged layout there).
+ * filter == NULL or type == GLX_FILTER_NONE: identical to the unfiltered entry points. */
+#define GLX_FILTER_NONE 0
+#define GLX_FILTER_EQUAL 1
+#define GLX_FILTER_LARGER_THAN 2
+#define GLX_FILTER_FIELD_NONE 0
+#define GLX_FILTER_FIELD_ID 1
+#define GLX_FILTER_FIELD_TIMESTAMP 2
+typedef struct glx_filter {
+  int32_t type;
+  int32_t field;
+  const int64_t* values;
+  int32_t retry_times;       /* GLOBAL_FLAG(SamplingRetryTimes), config.cc:108; RandomSampler only */
+  int64_t default_timestamp; /* GLOBAL_FLAG(DefaultTimestamp), memory_edge_storage.cc:113-119 */
+} glx_filter;
+/* Per-slot timestamps for a handle made by glx_graph_create: ts_slot[num_edges] in the
+ * order of `col`.  MUTATES the handle, like glx_graph_enable_in_degree. */
+GLX_API int glx_graph_set_timestamps(glx_graph* g, const int64_t* ts_slot, int ptr_kind, void* stream);
+GLX_API int glx_sample_filtered(const glx_graph* g, int sampler, const int64_t* src, const int64_t* rng_rows,
+                                int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id,
+                                uint64_t seed, uint64_t call_counter, const glx_filter* filter,
+                                int64_t* nbr_out, int64_t* eid_out, int ptr_kind, void* stream);
+GLX_API int glx_sample_full_filtered(const glx_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
+                                     const int64_t* offsets, int padding_mode, int64_t default_neighbor_id,
+                                     const glx_filter* filter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+                                     void* stream);
 
 /* ---- node features: replaces NodeStorage::GetAttribute()->GetFloats()
  * (node_storage.h:51-54, compressed_memory_node_storage.cc:149-176). -------
