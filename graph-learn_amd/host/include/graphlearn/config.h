@@ -19,7 +19,7 @@ extern std::string gDefaultStringAttribute;  // config.cc:101 ("")
 extern int64_t gDefaultLabel;           // config.cc:103 (-1)
 extern int64_t gDefaultTimestamp;       // config.cc:104 (-1)
 extern int32_t gIgnoreInvalid;          // config.cc:109 (1: skip records that fail to parse)
-extern int32_t gSamplingRetryTimes;     // config.cc:108 (5; filters only, unused on device)
+extern int32_t gSamplingRetryTimes;     // config.cc:108 (5; RandomSampler's redraws of filtered neighbours)
 // New (the reference has no seed flag, include/config.h:77-118): the seed of the
 // glx seeding contract, and the GPU this process' GraphStore lives on.
 extern int64_t gSamplingSeed;

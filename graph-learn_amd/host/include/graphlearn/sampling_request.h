@@ -10,7 +10,7 @@
 
 namespace graphlearn {
 
-enum FilterType { kOperatorUnspecified = 0, kLargerThan = 1, kEqual = 2 };
+enum FilterType { kOperatorUnspecified = 0, kEqual = 1, kLargerThan = 2 };  // include/constants.h:135-139
 enum FilterField { kFieldUnspecified = 0, kId = 1, kTimestamp = 2 };
 
 struct Shape {
@@ -52,9 +52,17 @@ public:
   void SetCallCounter(int64_t call_counter);
   bool HasCallCounter() const;
   int64_t CallCounter() const;
-  // true when a filter was requested (sampler/filter.h:73-75); the device path
-  // rejects such requests with Unimplemented.
-  bool HasFilter() const { return filter_type_ != kOperatorUnspecified && filter_field_ != kFieldUnspecified; }
+  // true when a filter was requested: Filter::operator bool, sampler/filter.h:73-75
+  bool HasFilter() const { return filter_type_ != kOperatorUnspecified; }
+  FilterType GetFilterType() const { return filter_type_; }
+  FilterField GetFilterField() const { return filter_field_; }
+  // The filter values, one per src id.  Set(tensors) fills them from tensors[kFilterValues]
+  // the way Filter::FillValues does (filter.cc:53-67: each value covers
+  // batch / values.Size() consecutive src ids); SetFilterValues appends values as they are
+  // (a direct caller's shortcut past the tensor map).  nullptr unless there is exactly one
+  // value per src id.
+  void SetFilterValues(const int64_t* values, int32_t count);
+  const int64_t* GetFilterValues() const;
 
 private:
   void InitParams(const std::string& type, const std::string& strategy);

@@ -76,9 +76,9 @@ const char* kSideInfo = "side_info";
 const char* kSegmentIds = "segment_ids";
 const char* kNumSegments = "num_segments";
 const char* kSegments = "segments";
-const char* kFilterType = "filter_type";
-const char* kFilterField = "filter_field";
-const char* kFilterValues = "filter_values";
+const char* kFilterType = "ftype";    // service/constants.cc:60-62
+const char* kFilterField = "field";
+const char* kFilterValues = "filt";
 
 // ----------------------------------------------------------------- tensor --
 // Storage of the numeric tensors.  A response of the device path is one large block

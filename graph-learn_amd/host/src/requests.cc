@@ -72,6 +72,7 @@ void SamplingRequest::InitParams(const std::string& type, const std::string& str
   ADD_TENSOR(params_, kFilterField, kInt32, 1);
   params_[kFilterField].AddInt32(filter_field_);
   ADD_TENSOR(tensors_, kSrcIds, kInt64, 64);
+  if (HasFilter()) ADD_TENSOR(tensors_, kFilterValues, kInt64, 64);
 }
 
 OpRequest* SamplingRequest::Clone() const {
@@ -101,6 +102,27 @@ void SamplingRequest::Init(const Tensor::Map& params) {
 void SamplingRequest::Set(const Tensor::Map& tensors) {
   const Tensor& ids = tensors.at(kSrcIds);
   Set(ids.GetInt64(), ids.Size());
+  if (HasFilter()) {
+    // Filter::FillValues, filter.cc:53-67
+    const Tensor& values = tensors.at(kFilterValues);
+    const int32_t filter_size = values.Size();
+    if (filter_size != 0) {
+      const int32_t fanout = ids.Size() / filter_size;
+      Tensor& mine = tensors_[kFilterValues];
+      for (int32_t i = 0; i < filter_size; ++i) {
+        for (int32_t j = 0; j < fanout; ++j) mine.AddInt64(values.GetInt64(i));
+      }
+    }
+  }
+}
+
+void SamplingRequest::SetFilterValues(const int64_t* values, int32_t count) {
+  if (HasFilter()) tensors_[kFilterValues].AddInt64(values, values + count);
+}
+
+const int64_t* SamplingRequest::GetFilterValues() const {
+  auto it = tensors_.find(kFilterValues);
+  return (it == tensors_.end() || it->second.Size() != BatchSize()) ? nullptr : it->second.GetInt64();
 }
 
 void SamplingRequest::Set(const int64_t* src_ids, int32_t batch_size) {

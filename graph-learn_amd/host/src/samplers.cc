@@ -16,6 +16,21 @@
 namespace graphlearn {
 namespace op {
 
+namespace {
+// The request's op::Filter as the C-ABI wants it (sampler/filter.h:30-125); the enum
+// values are shared with include/glx.h.
+glx_filter FilterOf(const SamplingRequest* req) {
+  glx_filter f;
+  f.type = req->HasFilter() ? (int32_t)req->GetFilterType() : GLX_FILTER_NONE;
+  f.field = (int32_t)req->GetFilterField();
+  f.values = req->GetFilterValues();
+  f.retry_times = GLOBAL_FLAG(SamplingRetryTimes);
+  f.default_timestamp = GLOBAL_FLAG(DefaultTimestamp);
+  if (f.values == nullptr) f.type = GLX_FILTER_NONE;  // empty batch
+  return f;
+}
+}  // namespace
+
 class Sampler : public Operator {
 public:
   Status Process(const OpRequest* req, OpResponse* res) override {
@@ -31,8 +46,8 @@ protected:
     res->SetShape(batch_size, count);
     res->InitNeighborIds();
     res->InitEdgeIds();
-    if (req->HasFilter()) {
-      return error::Unimplemented("sampling filters are not supported on the device path");
+    if (req->HasFilter() && batch_size > 0 && !req->GetFilterValues()) {
+      return error::InvalidArgument("the request has a filter but not one filter value per src id");
     }
     if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
     Graph* graph = graph_store_->GetGraph(req->Type());
@@ -58,10 +73,11 @@ protected:
     const uint64_t cc = req->HasCallCounter() ? (uint64_t)req->CallCounter()
                                                : call_counter_.fetch_add(1, std::memory_order_relaxed);
     // A part of a partitioned request draws from its rows' ORIGINAL random streams.
-    int rc = glx_sample_ex(g, SamplerId(), req->GetSrcIds(), req->GetRngRows(), batch_size, count,
-                           GLOBAL_FLAG(PaddingMode), GLOBAL_FLAG(DefaultNeighborId),
-                           (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, res->GetNeighborIds(), res->GetEdgeIds(),
-                           GLX_PTR_HOST, nullptr);
+    const glx_filter filter = FilterOf(req);
+    int rc = glx_sample_filtered(g, SamplerId(), req->GetSrcIds(), req->GetRngRows(), batch_size, count,
+                                 GLOBAL_FLAG(PaddingMode), GLOBAL_FLAG(DefaultNeighborId),
+                                 (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, &filter, res->GetNeighborIds(),
+                                 res->GetEdgeIds(), GLX_PTR_HOST, nullptr);
     return error::FromGlx(rc);
   }
 
@@ -93,7 +109,9 @@ public:
     SamplingResponse* response = static_cast<SamplingResponse*>(res);
     const int32_t batch_size = request->BatchSize();
     const int32_t max_limit = request->NeighborCount();
-    if (request->HasFilter()) return error::Unimplemented("sampling filters are not supported on the device path");
+    if (request->HasFilter() && batch_size > 0 && !request->GetFilterValues()) {
+      return error::InvalidArgument("the request has a filter but not one filter value per src id");
+    }
     if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
     const glx_graph* g = graph_store_->GetGraph(request->Type())->Device();
     std::vector<int32_t> degrees(batch_size, 0);
@@ -108,8 +126,10 @@ public:
     response->InitEdgeIds();
     response->ResizeDense();  // sizes both tensors to shape.size (the sum of the counts)
     if (g && offsets[batch_size] > 0) {
-      int rc = glx_sample_full(g, request->GetSrcIds(), batch_size, max_limit, offsets.data(),
-                               response->GetNeighborIds(), response->GetEdgeIds(), GLX_PTR_HOST, nullptr);
+      const glx_filter filter = FilterOf(request);
+      int rc = glx_sample_full_filtered(g, request->GetSrcIds(), batch_size, max_limit, offsets.data(),
+                                        GLOBAL_FLAG(PaddingMode), GLOBAL_FLAG(DefaultNeighborId), &filter,
+                                        response->GetNeighborIds(), response->GetEdgeIds(), GLX_PTR_HOST, nullptr);
       if (rc != GLX_OK) return error::FromGlx(rc);
     }
     return Status::OK();

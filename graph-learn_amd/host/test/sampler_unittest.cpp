@@ -276,13 +276,13 @@ TEST(SamplerTest, ErrorConventions) {
   EXPECT_TRUE(rq != nullptr && rs != nullptr);
   delete rq;
   delete rs;
-  // filters are not served by the device path: explicit Unimplemented, no silent CPU path
+  int64_t ids[1] = {0};
+  // a filter without one value per src id is an InvalidArgument, not a silent no-filter run
   SamplingRequest req("u-i", "RandomSampler", 2, kEqual, kId);
   SamplingResponse res;
-  int64_t ids[1] = {0};
   req.Set(ids, 1);
   Status s = OpFactory::GetInstance()->Create("RandomSampler")->Process(&req, &res);
-  EXPECT_TRUE(error::IsUnimplemented(s));
+  EXPECT_TRUE(error::IsInvalidArgument(s));
   // an edge type that was never loaded: all rows unknown -> default fill
   SamplingRequest req2("nobody", "TopkSampler", 3);
   SamplingResponse res2;
@@ -291,6 +291,68 @@ TEST(SamplerTest, ErrorConventions) {
   for (int i = 0; i < 3; ++i) {
     EXPECT_EQ(res2.GetNeighborIds()[i], 0);
     EXPECT_EQ(res2.GetEdgeIds()[i], -1);
+  }
+}
+
+// op::Filter (sampler/filter.h:30-125) on the 5-edge fixture; rows after Build: 0 -> {20, 10, 30}, 1 -> {21, 11}.
+TEST(SamplerTest, Filters) {
+  SetUpStore();
+  {  // Topk, id == value: ActOn refills the hole from the right end (filter.cc:83-94)
+    SamplingRequest req("u-i", "TopkSampler", 3, kEqual, kId);
+    SamplingResponse res;
+    int64_t ids[2] = {0, 1}, values[2] = {20, 11};
+    req.Set(ids, 2);
+    req.SetFilterValues(values, 2);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("TopkSampler")->Process(&req, &res).ok());
+    const int64_t want[6] = {30, 10, 30, 21, 21, 21};
+    for (int i = 0; i < 6; ++i) EXPECT_EQ(res.GetNeighborIds()[i], want[i]);
+  }
+  {  // values through the tensor map expand like Filter::FillValues (filter.cc:53-67)
+    SamplingRequest req("u-i", "TopkSampler", 2, kEqual, kId);
+    SamplingResponse res;
+    Tensor::Map tensors;
+    ADD_TENSOR(tensors, kSrcIds, kInt64, 4);
+    ADD_TENSOR(tensors, kFilterValues, kInt64, 2);
+    int64_t ids[4] = {0, 0, 1, 1}, values[2] = {10, 21};
+    tensors[kSrcIds].AddInt64(ids, ids + 4);
+    tensors[kFilterValues].AddInt64(values, values + 2);
+    req.Set(tensors);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("TopkSampler")->Process(&req, &res).ok());
+    const int64_t want[8] = {20, 30, 20, 30, 11, 11, 11, 11};
+    for (int i = 0; i < 8; ++i) EXPECT_EQ(res.GetNeighborIds()[i], want[i]);
+  }
+  {  // RandomSampler: hits are redrawn; a row whose neighbours all hit is default-filled
+    SetGlobalFlagSamplingRetryTimes(60);
+    SamplingRequest req("u-i", "RandomSampler", 16, kLargerThan, kId);
+    SamplingResponse res;
+    int64_t ids[2] = {0, 1}, values[2] = {15, 5};
+    req.Set(ids, 2);
+    req.SetFilterValues(values, 2);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("RandomSampler")->Process(&req, &res).ok());
+    for (int i = 0; i < 16; ++i) EXPECT_EQ(res.GetNeighborIds()[i], 10);
+    for (int i = 16; i < 32; ++i) EXPECT_EQ(res.GetNeighborIds()[i], 0);
+    SetGlobalFlagSamplingRetryTimes(5);
+  }
+  for (const char* name : {"RandomWithoutReplacementSampler", "EdgeWeightSampler", "InDegreeSampler"}) {
+    SamplingRequest req("u-i", name, 4, kEqual, kId);
+    SamplingResponse res;
+    int64_t ids[1] = {0}, values[1] = {10};
+    req.Set(ids, 1);
+    req.SetFilterValues(values, 1);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(name)->Process(&req, &res).ok());
+    for (int i = 0; i < 4; ++i) EXPECT_TRUE(res.GetNeighborIds()[i] == 20 || res.GetNeighborIds()[i] == 30);
+  }
+  {  // FullSampler keeps the unfiltered segment sizes and pads the survivors (full_sampler.cc:55-84)
+    SamplingRequest req("u-i", "FullSampler", 0, kEqual, kId);
+    SamplingResponse res;
+    int64_t ids[2] = {0, 9}, values[2] = {10, 10};
+    req.Set(ids, 2);
+    req.SetFilterValues(values, 2);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("FullSampler")->Process(&req, &res).ok());
+    EXPECT_EQ(res.GetShape().segments[0], 3);
+    EXPECT_EQ(res.GetShape().segments[1], 0);
+    const int64_t want[3] = {20, 30, 20};
+    for (int i = 0; i < 3; ++i) EXPECT_EQ(res.GetNeighborIds()[i], want[i]);
   }
 }
 

@@ -40,6 +40,38 @@ class NeighborSampler(object):
     topo = graph.get_topology()
     self._dst_types = [topo.get_dst_type(e) for e in self._meta_path]
     self._call_counter = None
+    self._filter = (pywrap.FilterType.OPERATOR_UNSPECIFIED, pywrap.FilterField.FIELD_UNSPECIFIED)
+
+  def set_filter(self, filter_type, filter_field):
+    """Sample around neighbours whose field hits the filter value of their seed (the
+    reference's op::Filter, core/operator/sampler/filter.h, which its Python API only reaches
+    through GSL's .filter() / timestamped traversals): filter_type "equal" | "larger_than" |
+    None, filter_field "id" | "timestamp".  get(ids, filter_values=...) then takes one int64
+    value per seed id; every hop reuses a seed's value for all of its descendants, like
+    Filter::FillValues (filter.cc:53-67)."""
+    types = {None: pywrap.FilterType.OPERATOR_UNSPECIFIED, "equal": pywrap.FilterType.EQUAL,
+             "larger_than": pywrap.FilterType.LARGER_THAN}
+    fields = {None: pywrap.FilterField.FIELD_UNSPECIFIED, "id": pywrap.FilterField.ID,
+              "timestamp": pywrap.FilterField.TIMESTAMP}
+    if filter_type not in types or filter_field not in fields:
+      raise ValueError("unknown filter ({!r}, {!r})".format(filter_type, filter_field))
+    self._filter = (types[filter_type], fields[filter_field])
+    return self
+
+  def _filtered(self):
+    return self._filter[0] != pywrap.FilterType.OPERATOR_UNSPECIFIED
+
+  def _filter_values(self, ids, filter_values):
+    if not self._filtered():
+      if filter_values is not None:
+        raise ValueError("filter_values given but no filter set: call set_filter() first")
+      return None
+    if filter_values is None:
+      raise ValueError("the sampler has a filter: pass filter_values (one per id)")
+    values = np.ascontiguousarray(np.array(filter_values).reshape(-1), dtype=np.int64)
+    if values.size != np.array(ids).size:
+      raise ValueError("filter_values must hold one value per id")
+    return values
 
   def set_call_counter(self, value):
     """Pin the random stream of the next get(): hop h uses counter value + h.  Unset,
@@ -50,11 +82,13 @@ class NeighborSampler(object):
     if len(self._meta_path) != len(self._expand_factor):
       raise ValueError("The length of meta_path must be same with hop count.")
 
-  def _sample(self, hop, src_ids):
+  def _sample(self, hop, src_ids, filter_values=None):
     """-> (neighbor ids, edge ids, per-row counts) of one hop, flat."""
     req = pywrap.new_sampling_request(self._meta_path[hop], self._op, int(self._expand_factor[hop]),
-                                      pywrap.FilterType.OPERATOR_UNSPECIFIED, pywrap.FilterField.FIELD_UNSPECIFIED)
+                                      self._filter[0], self._filter[1])
     pywrap.set_sampling_request(req, np.ascontiguousarray(src_ids.reshape(-1), dtype=np.int64))
+    if filter_values is not None:
+      pywrap.set_sampling_filter_values(req, filter_values)
     if self._call_counter is not None:
       pywrap.set_sampling_call_counter(req, int(self._call_counter) + hop)
     res = pywrap.new_sampling_response()
@@ -68,14 +102,16 @@ class NeighborSampler(object):
     errors.raise_exception_on_not_ok_status(status)
     return out
 
-  def get(self, ids):
+  def get(self, ids, filter_values=None):
     """ids: 1-D int64 array.  -> Layers; layer h holds [len(previous layer), expand_factor[h]] nodes/edges."""
     self._check()
     src = np.array(ids)
+    values = self._filter_values(src, filter_values)
     layers = Layers()
     for hop, edge_type in enumerate(self._meta_path):
       k = self._expand_factor[hop]
-      nbr, eid, _ = self._sample(hop, src)
+      nbr, eid, _ = self._sample(hop, src, values)
+      values = None if values is None else np.repeat(values, k)
       shape = (src.size, k)
       nodes = self._graph.get_nodes(self._dst_types[hop], nbr, shape=shape)
       edges = self._graph.get_edges(edge_type, np.repeat(src.reshape(-1), k), nbr, shape=shape)
@@ -94,6 +130,8 @@ class NeighborSampler(object):
     self._check()
     if self._strategy == "full":
       raise ValueError("the full sampler returns ragged rows; use get()")
+    if self._filtered():
+      raise ValueError("filtered sampling goes hop by hop; use get(ids, filter_values=...)")
     graphs = [self._graph.device_graph(e) for e in self._meta_path]
     seed = _flag("sampling_seed") if seed is None else seed
     return glx.sample_hops(graphs, self._op, ids, [int(k) for k in self._expand_factor], seed=seed,
@@ -130,13 +168,15 @@ class FullNeighborSampler(NeighborSampler):
   """All neighbours (at most expand_factor per vertex when it is > 0): ragged results,
   returned as SparseNodes / SparseEdges."""
 
-  def get(self, ids):
+  def get(self, ids, filter_values=None):
     self._check()
     src = np.array(ids).reshape(-1)
+    values = self._filter_values(src, filter_values)
     layers = Layers()
     for hop, edge_type in enumerate(self._meta_path):
-      nbr, eid, counts = self._sample(hop, src)
+      nbr, eid, counts = self._sample(hop, src, values)
       counts = [int(c) for c in counts]
+      values = None if values is None else np.repeat(values, counts)
       dense = (src.size, max(counts) if counts else 0)
       nodes = self._graph.get_nodes(self._dst_types[hop], nbr, offsets=counts, shape=dense)
       edges = self._graph.get_edges(edge_type, np.repeat(src, counts), nbr, offsets=counts, shape=dense)

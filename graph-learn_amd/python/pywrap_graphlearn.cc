@@ -242,6 +242,11 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("set_sampling_request", [](OpRequest* req, I64Array src_ids) {
     As<SamplingRequest>(req, "SamplingRequest")->Set(src_ids.data(), (int32_t)src_ids.size());
   });
+  // glx addition: the reference hands filter values over only inside a DAG's tensor map
+  // (SamplingRequest::Set(tensors) -> Filter::FillValues); this sets one value per src id.
+  m.def("set_sampling_filter_values", [](OpRequest* req, I64Array values) {
+    As<SamplingRequest>(req, "SamplingRequest")->SetFilterValues(values.data(), (int32_t)values.size());
+  });
   m.def("set_sampling_call_counter", [](OpRequest* req, int64_t call_counter) {
     As<SamplingRequest>(req, "SamplingRequest")->SetCallCounter(call_counter);
   });

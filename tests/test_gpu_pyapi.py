@@ -579,3 +579,48 @@ def test_timestamped_source_through_the_loader(gl, g, tmp_path):
         np.testing.assert_equal(edges.weights.view(np.uint32), gold["w_slot"].view(np.uint32))
     finally:
         tg.close()
+
+
+def test_filtered_sampling_through_the_python_api(gl, g, tmp_path):
+    """op::Filter end to end (TSV -> loader -> GraphStore -> SamplingRequest with filter values -> HIP): the
+    reference's own Topk / Full answers of tests/golden/filtered.npz, plus the seed's value reaching hop 2."""
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "filtered.npz")))
+    path = os.path.join(str(tmp_path), "flt_edges")
+    with open(path, "w") as f:
+        f.write("src_id:int64\tdst_id:int64\tweight:float\ttimestamp:int64\n")
+        for s, d_, w, t in zip(gold["src"], gold["dst"], gold["w"], gold["ts"]):
+            f.write("%d\t%d\t%.9g\t%d\n" % (s, d_, w, t))
+    names = {"id_eq": ("equal", "id"), "id_gt": ("larger_than", "id"), "ts_eq": ("equal", "timestamp"),
+             "ts_gt": ("larger_than", "timestamp")}
+    gl.set_default_neighbor_id(-7)
+    tg = gl.Graph().edge(path, ("a", "a", "flt"), gl.Decoder(weighted=True, timestamped=True)).init()
+    try:
+        for case in gold["cases"]:
+            case = str(case)
+            kind, strategy = case.rsplit("_", 3)[0], case.split("_")[2]
+            k, pad = int(case.split("_k")[1][0]), int(case[-1])
+            gl.set_padding_mode(gl.CIRCULAR if pad else gl.REPLICATE)
+            sampler = tg.neighbor_sampler("flt", k, strategy="topk" if strategy == "TopkSampler" else "full")
+            layer = sampler.set_filter(*names[kind]).get(gold[case + "_ids"], filter_values=gold[case + "_values"])
+            np.testing.assert_equal(layer.layer_nodes(1).ids.reshape(-1), gold[case + "_nbr"].reshape(-1), err_msg=case)
+            np.testing.assert_equal(layer.layer_edges(1).edge_ids.reshape(-1), gold[case + "_eid"].reshape(-1))
+        gl.set_padding_mode(gl.CIRCULAR)
+        # two hops: every descendant of a seed is filtered with the seed's value
+        gl.set_sampler_retry_times(80)
+        seeds = gold["rows"][5:25]
+        values = np.full(seeds.shape[0], 905, np.int64)
+        two = tg.neighbor_sampler(["flt", "flt"], [3, 4], strategy="random").set_filter("equal", "id")
+        layers = two.get(seeds, filter_values=values)
+        for hop in (1, 2):
+            ids = layers.layer_nodes(hop).ids
+            assert ids.shape == (seeds.size * (1 if hop == 1 else 3), 3 if hop == 1 else 4)
+            assert not (ids == 905).any()
+        with pytest.raises(ValueError):
+            two.get(seeds)
+        with pytest.raises(ValueError):
+            tg.neighbor_sampler("flt", 2).get(seeds, filter_values=values)
+    finally:
+        gl.set_sampler_retry_times(5)
+        gl.set_default_neighbor_id(DEFAULT_ID)
+        gl.set_padding_mode(gl.REPLICATE)
+        tg.close()
