@@ -51,6 +51,7 @@ struct GlxDeviceGuard {
 int glx_init_device(int device);
 int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot);
 void glx_scratch_free(void* p, hipStream_t s);
+void glx_scratch_trim(hipStream_t s, int slot, size_t keep_bytes);
 
 // Temporary device allocation released on every exit path.
 struct GlxTemp {
@@ -219,6 +220,59 @@ __host__ __device__ inline void glx_alias_build_row(const float* dist, int32_t c
   while (high_num > 0) tab[high[-(--high_num)]].prob = 1.0f;
 }
 
+// The same build for the device's one-lane-per-row kernels, restructured around memory
+// latency; every float operation and every stack decision is the one above, so the tables are
+// bit-identical.  The stacks hold {prob, index} pairs (one 8-byte load per pop instead of an
+// index load and a dependent table load), and the tops of both stacks live in registers: the
+// high entry that was just reduced is the next one popped (LIFO), and a high entry that drops
+// below 1 is pushed onto -- hence immediately popped from -- the low stack.  `stk` holds
+// `count` pairs: low grows up from stk, high grows down from stk + count - 1.
+__device__ inline void glx_alias_build_row_dev(const float* __restrict__ dist, int32_t count,
+                                               GlxAlias* __restrict__ tab, GlxAlias* __restrict__ stk) {
+  const float avg_prob = (float)(1.0 / (double)count);
+  double acc = 0.0;
+  for (int32_t i = 0; i < count; ++i) acc += (double)dist[i];
+  const float sum = (float)acc;
+  GlxAlias* low = stk;
+  GlxAlias* high = stk + count - 1;
+  int32_t low_num = 0, high_num = 0;
+  for (int32_t i = 0; i < count; ++i) {
+    const float prob = dist[i] / sum;
+    const GlxAlias e = GlxAlias{prob * (float)count, i};
+    tab[i] = e;
+    if (prob < avg_prob) {
+      low[low_num++] = e;
+    } else if (prob > avg_prob) {
+      high[-(high_num++)] = e;
+    }
+  }
+  bool have_lo = false, have_hi = false;
+  GlxAlias lo = GlxAlias{0.0f, 0}, hi = GlxAlias{0.0f, 0};  // .alias carries the entry's own index here
+  while (low_num + (have_lo ? 1 : 0) > 0 && high_num + (have_hi ? 1 : 0) > 0) {
+    if (!have_lo) lo = low[--low_num];
+    if (!have_hi) hi = high[-(--high_num)];
+    have_lo = false;
+    const float p = hi.prob - 1.0f + lo.prob;
+    tab[lo.alias].alias = hi.alias;
+    hi.prob = p;
+    if (p < 1.0f) {
+      tab[hi.alias].prob = p;
+      lo = hi;
+      have_lo = true;
+      have_hi = false;
+    } else if (p > 1.0f) {
+      have_hi = true;  // back on top of the high stack; its final prob is written when it leaves
+    } else {
+      tab[hi.alias].prob = p;
+      have_hi = false;
+    }
+  }
+  if (have_lo) tab[lo.alias].prob = 1.0f;
+  while (low_num > 0) tab[low[--low_num].alias].prob = 1.0f;
+  if (have_hi) tab[hi.alias].prob = 1.0f;
+  while (high_num > 0) tab[high[-(--high_num)].alias].prob = 1.0f;
+}
+
 // ------------------------------------------------------------- contract RNG -
 // Philox4x32-10; key = (seed lo, seed hi); counter = (j >> 1, row, cc lo, cc hi).
 // Draw j of a row is words {2(j&1), 2(j&1)+1} of block j >> 1.
@@ -272,6 +326,13 @@ int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s);
 int glx_alias_build_launch(const int64_t* row_ptr, const float* weight, int64_t V, int64_t E,
                            GlxAlias* out, hipStream_t s);
 void glx_graph_free(glx_graph* g);
+
+// glx_sample.hip: TopkSampler / RandomWithoutReplacementSampler restricted to the first
+// d_prefix[i] slots of request row i (listed descending under circular padding).
+int glx_sample_prefix_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng,
+                             const int32_t* d_prefix, int32_t batch, int32_t k, int padding_mode,
+                             int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter, int64_t* d_nbr,
+                             int64_t* d_eid, hipStream_t s);
 
 static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

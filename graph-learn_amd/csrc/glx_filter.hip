@@ -16,7 +16,10 @@
 //   pad       slots are filled through the span with the padders' rules
 // RandomSampler never materialises the reserved set: a count kernel answers HitAll and the
 // slot kernel redraws hits from the row's random stream.
+#include <stdlib.h>
 #include <string.h>
+
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -72,7 +75,9 @@ __global__ void glx_filter_rows_kernel(RowArgs a, int64_t* __restrict__ start, i
 
 __global__ void glx_filter_zero_kernel(int64_t* p) { *p = 0; }
 
-// Number of neighbours of every request row that do NOT hit (0 <=> Filter::HitAll).
+// Filter::HitAll (filter.cc:109-120): nonhit[i] > 0 as soon as one neighbour of request row i
+// does not hit -- the scan stops at the first 64-slot chunk that holds a survivor, so it only
+// walks a whole row when (nearly) everything in it hits.
 __global__ __launch_bounds__(64) void glx_filter_count_kernel(FilterDev f, const GlxAdj* __restrict__ adj,
                                                               const int64_t* __restrict__ start,
                                                               const int32_t* __restrict__ deg,
@@ -87,8 +92,42 @@ __global__ __launch_bounds__(64) void glx_filter_count_kernel(FilterDev f, const
     const int32_t p = base + lane;
     const bool nh = p < n && !hit_of(f, field_of(f, adj, s + p), val);
     cnt += __popcll(__ballot(nh));
+    if (cnt > 0) break;
   }
   if (lane == 0) nonhit[i] = cnt;
+}
+
+// Timestamp + LARGER_THAN (filter.cc:74-82, FindkthLargest :196-229): binary search for
+// values[0] -- request row 0's value, whatever the row -- over the timestamp-ascending row.  The
+// reserved set is the prefix below the found position, listed descending; a row with a single
+// neighbour keeps nothing.  Returns the prefix length.
+__device__ __forceinline__ int32_t ts_prefix_of(const FilterDev& f, const GlxAdj* __restrict__ adj, int64_t s,
+                                                int32_t n) {
+  const int64_t filter = f.values[0];
+  int32_t lo = 0, hi = n - 1, mid = 0;
+  if (hi <= 0) return 0;  // n == 1: FindkthLargest returns -1, ActOn clamps to 0
+  while (hi >= lo) {
+    mid = lo + (hi - lo) / 2;
+    const int64_t v = field_of(f, adj, s + mid);
+    if (v == filter) return mid;
+    if (v > filter) hi = mid - 1;
+    else lo = mid + 1;
+  }
+  if (field_of(f, adj, s + mid) < filter) mid += 1;
+  return mid;
+}
+
+// One thread per request row: prefix[i] for the samplers that can work on a prefix directly.
+__global__ void glx_filter_tsprefix_kernel(RowArgs a, FilterDev f, int32_t* __restrict__ prefix) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.batch) return;
+  const int64_t row = glx_row_of(a.map, a.src[i]);
+  int32_t m = 0;
+  if (row >= 0) {
+    const int64_t s = a.row_ptr[row];
+    m = ts_prefix_of(f, a.adj, s, (int32_t)(a.row_ptr[row + 1] - s));
+  }
+  prefix[i] = m;
 }
 
 // Filter::ActOn for one request row per wave.
@@ -101,17 +140,17 @@ __global__ __launch_bounds__(64) void glx_filter_count_kernel(FilterDev f, const
 // (ascending) in the unused tail [m, n) of the row's span; fill hole h from tail entry
 // F - 1 - h (F = number of holes = number of tail survivors).
 //
-// Timestamp + LARGER_THAN (filter.cc:74-82, FindkthLargest :196-229): binary search for
-// values[0] -- request row 0's value, whatever the row -- over the timestamp-ascending row; the
-// reserved set is the prefix below the found position, listed descending; a row with a single
-// neighbour keeps nothing.
+// Timestamp + LARGER_THAN: the descending prefix of ts_prefix_of.
+//
+// Rows [row0, row0 + gridDim.x) of the request are served per launch; their spans start at
+// soff[i] - base of the scratch array (the request is cut into chunks of bounded total degree).
 __global__ __launch_bounds__(64) void glx_filter_reserve_kernel(FilterDev f, const GlxAdj* __restrict__ adj,
                                                                 const int64_t* __restrict__ start,
                                                                 const int32_t* __restrict__ deg,
-                                                                const int64_t* __restrict__ soff,
-                                                                int32_t* __restrict__ res,
+                                                                const int64_t* __restrict__ soff, int32_t row0,
+                                                                int64_t base, int32_t* __restrict__ res,
                                                                 int32_t* __restrict__ res_cnt) {
-  const int64_t i = blockIdx.x;
+  const int64_t i = row0 + (int64_t)blockIdx.x;
   const int lane = threadIdx.x;
   const int32_t n = deg[i];
   if (n == 0) {
@@ -119,31 +158,10 @@ __global__ __launch_bounds__(64) void glx_filter_reserve_kernel(FilterDev f, con
     return;
   }
   const int64_t s = start[i];
-  int32_t* R = res + soff[i];
+  int32_t* R = res + (soff[i] - base);
   if (f.field == GLX_FILTER_FIELD_TIMESTAMP && f.type == GLX_FILTER_LARGER_THAN) {
     int32_t k = 0;
-    if (lane == 0) {
-      const int64_t filter = f.values[0];
-      int32_t lo = 0, hi = n - 1, mid = 0;
-      if (hi == 0) {
-        k = -1;
-      } else {
-        bool found = false;
-        while (hi >= lo) {
-          mid = lo + (hi - lo) / 2;
-          const int64_t v = field_of(f, adj, s + mid);
-          if (v == filter) {
-            found = true;
-            break;
-          }
-          if (v > filter) hi = mid - 1;
-          else lo = mid + 1;
-        }
-        if (!found && field_of(f, adj, s + mid) < filter) mid += 1;
-        k = mid;
-      }
-      if (k < 0) k = 0;
-    }
+    if (lane == 0) k = ts_prefix_of(f, adj, s, n);
     k = __shfl(k, 0);
     for (int32_t t = lane; t < k; t += 64) R[t] = k - 1 - t;
     if (lane == 0) res_cnt[i] = k;
@@ -193,16 +211,19 @@ struct DrawArgs {
   uint64_t seed, cc;
   int64_t default_nbr;
   int32_t batch, k;
+  int32_t row0, nrows;  // the rows of the request this launch serves
+  int64_t base;         // soff[row0]: spans are relative to it
 };
 
 // RandomWithoutReplacement: std::shuffle(reserved) under the contract's forward Fisher-Yates
 // (step j swaps entry j with entry j + bounded(draw_j, m - j)); only the first min(k, m) steps
 // can reach the padded output.  One thread per request row, in place on the row's span.
 __global__ void glx_filter_shuffle_kernel(DrawArgs a, int32_t* __restrict__ res) {
-  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.batch || a.deg[i] == 0) return;
+  const int32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t i = a.row0 + li;
+  if (li >= a.nrows || a.deg[i] == 0) return;
   const int32_t m = a.res_cnt[i];
-  int32_t* R = res + a.soff[i];
+  int32_t* R = res + (a.soff[i] - a.base);
   const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
   const int32_t steps = m < a.k ? m : a.k;
   for (int32_t j = 0; j < steps; ++j) {
@@ -218,12 +239,13 @@ __global__ void glx_filter_shuffle_kernel(DrawArgs a, int32_t* __restrict__ res)
 // One thread per row; dist / tab / stk are spans parallel to the reserved list.
 __global__ void glx_filter_alias_build_kernel(DrawArgs a, const float* __restrict__ weight, GlxIdMap dst_map,
                                               const int64_t* __restrict__ dst_count, float* __restrict__ dist,
-                                              GlxAlias* __restrict__ tab, int32_t* __restrict__ stk) {
-  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.batch || a.deg[i] == 0) return;
+                                              GlxAlias* __restrict__ tab, GlxAlias* __restrict__ stk) {
+  const int32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t i = a.row0 + li;
+  if (li >= a.nrows || a.deg[i] == 0) return;
   const int32_t m = a.res_cnt[i];
   if (m == 0) return;
-  const int64_t off = a.soff[i], s = a.start[i];
+  const int64_t off = a.soff[i] - a.base, s = a.start[i];
   for (int32_t t = 0; t < m; ++t) {
     const int64_t slot = s + a.res[off + t];
     float w;
@@ -235,7 +257,7 @@ __global__ void glx_filter_alias_build_kernel(DrawArgs a, const float* __restric
     }
     dist[off + t] = w;
   }
-  glx_alias_build_row(dist + off, m, tab + off, stk + off, stk + off + m - 1);
+  glx_alias_build_row_dev(dist + off, m, tab + off, stk + off);
 }
 
 // EdgeWeight / InDegree slots under circular padding: k alias draws mapped back through the
@@ -243,15 +265,16 @@ __global__ void glx_filter_alias_build_kernel(DrawArgs a, const float* __restric
 __global__ __launch_bounds__(256) void glx_filter_alias_slots_kernel(DrawArgs a, const GlxAlias* __restrict__ tab,
                                                                      int64_t* __restrict__ nbr_out,
                                                                      int64_t* __restrict__ eid_out) {
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= (int64_t)a.batch * a.k) return;
-  const int32_t i = (int32_t)(t / a.k);
-  const int32_t j = (int32_t)(t - (int64_t)i * a.k);
+  const int64_t lt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (lt >= (int64_t)a.nrows * a.k) return;
+  const int32_t i = a.row0 + (int32_t)(lt / a.k);
+  const int32_t j = (int32_t)(lt % a.k);
+  const int64_t t = (int64_t)i * a.k + j;
   GlxAdj rec = GlxAdj{a.default_nbr, -1};
   const int32_t m = a.deg[i] > 0 ? a.res_cnt[i] : 0;
   if (m > 0) {
     const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
-    const int64_t off = a.soff[i];
+    const int64_t off = a.soff[i] - a.base;
     const int32_t pick = glx_alias_pick(glx_draw64(a.seed, a.cc, rr, (uint32_t)j), m, tab + off);
     rec = a.adj[a.start[i] + a.res[off + pick]];
   }
@@ -271,19 +294,21 @@ enum { kPadCircular = 0, kPadReplicate = 1, kPadReplicateDrawn = 2 };
 __global__ __launch_bounds__(256) void glx_filter_pad_kernel(DrawArgs a, const int64_t* __restrict__ offsets, int mode,
                                                              int64_t* __restrict__ nbr_out,
                                                              int64_t* __restrict__ eid_out) {
-  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t li = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (i >= a.batch) return;
+  if (li >= a.nrows) return;
+  const int64_t i = a.row0 + li;
   const int32_t n = a.deg[i];
   const int32_t m = n > 0 ? a.res_cnt[i] : 0;
   const int64_t s = a.start[i];
   const int64_t o0 = offsets ? offsets[i] : i * (int64_t)a.k;
   const int64_t target = offsets ? offsets[i + 1] - o0 : a.k;
-  const int32_t* R = a.res + a.soff[i];
+  // res == nullptr: the reserved list is the descending prefix (timestamp > value), not stored
+  const int32_t* R = a.res ? a.res + (a.soff[i] - a.base) : nullptr;
   for (int64_t j = lane; j < target; j += 64) {
     GlxAdj rec = GlxAdj{a.default_nbr, -1};
     if (mode == kPadCircular) {
-      if (m > 0) rec = a.adj[s + R[j % m]];
+      if (m > 0) rec = a.adj[s + (R ? R[j % m] : m - 1 - (int32_t)(j % m))];
     } else if (mode == kPadReplicate) {
       if (j < m) rec = a.adj[s + j];
     } else {
@@ -324,6 +349,26 @@ __global__ __launch_bounds__(256) void glx_filter_random_kernel(DrawArgs a, Filt
 }
 
 constexpr int kFullSampler = -1;
+// Upper bound on the reserved positions held in scratch at once.  A request whose rows'
+// degrees add up to more is served in chunks of consecutive rows (a single larger row is a
+// chunk of its own), one after the other.  1 Gi positions keep the workspace at 4 GiB (24 GiB
+// with alias tables), small enough to stay cached per (thread, stream): allocating and
+// freeing tens of GB per call costs seconds, far more than the kernels.  When HBM is short the
+// bound shrinks to what half of the free memory holds; a workspace beyond 32 GiB (one huge
+// row) is returned to the device after the call.
+constexpr int64_t kSpanCap = (int64_t)1 << 30;
+int64_t span_cap(size_t bytes_per_position) {
+  const char* e = getenv("GLX_FILTER_SPAN_CAP");  // test knob: force many small chunks
+  const int64_t v = e ? atoll(e) : 0;
+  if (v > 0) return v;
+  size_t free_b = 0, total_b = 0;
+  int64_t cap = kSpanCap;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const int64_t fit = (int64_t)(free_b / 2 / bytes_per_position);
+    if (fit < cap) cap = fit;
+  }
+  return cap > ((int64_t)1 << 20) ? cap : ((int64_t)1 << 20);
+}
 
 // All pointers are device pointers.  `sampler` is a GLX_SAMPLER_* id or kFullSampler (then
 // d_offsets[batch + 1] gives the segments and k is unused).
@@ -341,14 +386,32 @@ int filtered_device(const glx_graph* g, int sampler, const int64_t* d_src, const
   int32_t* deg = reinterpret_cast<int32_t*>(soff + nb + 1);
   int32_t* cnt = deg + nb;
   RowArgs ra{g->map(), g->row_ptr, g->adj, d_src, d_rng, batch};
-  DrawArgs da{g->adj, start, deg, soff, nullptr, cnt, d_rng, seed, cc, default_nbr, batch, k};
+  DrawArgs da{g->adj, start, deg, soff, nullptr, cnt, d_rng, seed, cc, default_nbr, batch, k, 0, batch, 0};
   const unsigned row_blocks = (unsigned)((nb + 255) / 256);
+  const unsigned wave_blocks = (unsigned)((nb * 64 + 255) / 256);
   GlxKernelTimer timer(GLX_KERNEL_SAMPLE, s);
   if (sampler == GLX_SAMPLER_RANDOM) {
     glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, nullptr);
     glx_filter_count_kernel<<<(unsigned)batch, 64, 0, s>>>(f, g->adj, start, deg, cnt);
     const int64_t total = (int64_t)batch * k;
     glx_filter_random_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(da, f, cnt, d_nbr, d_eid);
+    timer.stop();
+    GLX_HIP(hipGetLastError());
+    return GLX_OK;
+  }
+  const bool ts_prefix = f.field == GLX_FILTER_FIELD_TIMESTAMP && f.type == GLX_FILTER_LARGER_THAN;
+  if (ts_prefix && (sampler == GLX_SAMPLER_TOPK || sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT)) {
+    // the reserved set is a row prefix: the plain kernels sample from it directly
+    glx_filter_tsprefix_kernel<<<row_blocks, 256, 0, s>>>(ra, f, cnt);
+    rc = glx_sample_prefix_device(g, sampler, d_src, d_rng, cnt, batch, k, padding_mode, default_nbr, seed, cc, d_nbr,
+                                  d_eid, s);
+    timer.stop();
+    return rc;
+  }
+  if (ts_prefix && sampler == kFullSampler) {
+    glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, nullptr);
+    glx_filter_tsprefix_kernel<<<row_blocks, 256, 0, s>>>(ra, f, cnt);
+    glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, d_offsets, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
     timer.stop();
     GLX_HIP(hipGetLastError());
     return GLX_OK;
@@ -363,43 +426,59 @@ int filtered_device(const glx_graph* g, int sampler, const int64_t* d_src, const
     if (rc != GLX_OK) return rc;
     GLX_HIP(rocprim::inclusive_scan(tmp, bytes, soff + 1, soff + 1, nb, rocprim::plus<int64_t>(), s));
   }
-  int64_t total_deg = 0;
-  GLX_HIP(hipMemcpyAsync(&total_deg, soff + nb, 8, hipMemcpyDeviceToHost, s));
+  std::vector<int64_t> h_soff(nb + 1);
+  GLX_HIP(hipMemcpyAsync(h_soff.data(), soff, (nb + 1) * 8, hipMemcpyDeviceToHost, s));
   GLX_HIP(hipStreamSynchronize(s));
+  // chunks of consecutive rows with at most kSpanCap reserved positions
   const bool alias_draw = circular && (sampler == GLX_SAMPLER_EDGE_WEIGHT || sampler == GLX_SAMPLER_IN_DEGREE);
-  // reserved positions i32 [| alias table 8 B | weights f32 | stacks i32], each total_deg long
-  const size_t span = ((size_t)total_deg + 1) & ~(size_t)1;  // keeps the 8-byte table aligned
+  const int64_t cap = span_cap(alias_draw ? 24 : 4);
+  std::vector<int32_t> cuts{0};
+  int64_t widest = 0;
+  for (int32_t a = 0; a < batch;) {
+    int32_t b = a + 1;
+    while (b < batch && h_soff[b + 1] - h_soff[a] <= cap) ++b;
+    if (h_soff[b] - h_soff[a] > widest) widest = h_soff[b] - h_soff[a];
+    cuts.push_back(b);
+    a = b;
+  }
+  // [alias table 8 B | stack pairs 8 B |] reserved positions i32 [| weights f32], each `span` long
+  const size_t span = ((size_t)widest + 1) & ~(size_t)1;  // keeps the 8-byte table aligned
   char* work = nullptr;
-  rc = glx_scratch_alloc(reinterpret_cast<void**>(&work), span * (alias_draw ? 20 : 4) + 16, s, 2);
+  rc = glx_scratch_alloc(reinterpret_cast<void**>(&work), span * (alias_draw ? 24 : 4) + 16, s, 2);
   if (rc != GLX_OK) return rc;
   GlxAlias* tab = reinterpret_cast<GlxAlias*>(work);
-  int32_t* res = alias_draw ? reinterpret_cast<int32_t*>(work + span * 8) : reinterpret_cast<int32_t*>(work);
-  float* dist = reinterpret_cast<float*>(work + span * 12);
-  int32_t* stk = reinterpret_cast<int32_t*>(work + span * 16);
+  GlxAlias* stk = reinterpret_cast<GlxAlias*>(work + span * 8);
+  int32_t* res = alias_draw ? reinterpret_cast<int32_t*>(work + span * 16) : reinterpret_cast<int32_t*>(work);
+  float* dist = reinterpret_cast<float*>(work + span * 20);
   da.res = res;
-  glx_filter_reserve_kernel<<<(unsigned)batch, 64, 0, s>>>(f, g->adj, start, deg, soff, res, cnt);
-  const unsigned wave_blocks = (unsigned)((nb * 64 + 255) / 256);
-  if (sampler == kFullSampler) {
-    glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, d_offsets, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
-  } else if (sampler == GLX_SAMPLER_TOPK) {
-    glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, nullptr, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
-  } else if (sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT) {
-    if (circular) glx_filter_shuffle_kernel<<<row_blocks, 256, 0, s>>>(da, res);
-    glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, nullptr, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
-  } else {  // EdgeWeight / InDegree
-    if (!circular) {
-      glx_filter_pad_kernel<<<wave_blocks, 256, 0, s>>>(da, nullptr, kPadReplicateDrawn, d_nbr, d_eid);
+  const GlxIdMap dm = GlxIdMap{g->dst_map.keys, g->dst_map.vals, g->dst_map.cap - 1, g->num_dst};
+  for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+    da.row0 = cuts[c];
+    da.nrows = cuts[c + 1] - cuts[c];
+    da.base = h_soff[da.row0];
+    const size_t nr = (size_t)da.nrows;
+    const unsigned rb = (unsigned)((nr + 255) / 256), wb = (unsigned)((nr * 64 + 255) / 256);
+    glx_filter_reserve_kernel<<<(unsigned)nr, 64, 0, s>>>(f, g->adj, start, deg, soff, da.row0, da.base, res, cnt);
+    if (sampler == kFullSampler) {
+      glx_filter_pad_kernel<<<wb, 256, 0, s>>>(da, d_offsets, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
+    } else if (sampler == GLX_SAMPLER_TOPK) {
+      glx_filter_pad_kernel<<<wb, 256, 0, s>>>(da, nullptr, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
+    } else if (sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT) {
+      if (circular) glx_filter_shuffle_kernel<<<rb, 256, 0, s>>>(da, res);
+      glx_filter_pad_kernel<<<wb, 256, 0, s>>>(da, nullptr, circular ? kPadCircular : kPadReplicate, d_nbr, d_eid);
+    } else if (!circular) {  // EdgeWeight / InDegree, replicate padding
+      glx_filter_pad_kernel<<<wb, 256, 0, s>>>(da, nullptr, kPadReplicateDrawn, d_nbr, d_eid);
     } else {
       const bool by_weight = sampler == GLX_SAMPLER_EDGE_WEIGHT;
-      const GlxIdMap dm = GlxIdMap{g->dst_map.keys, g->dst_map.vals, g->dst_map.cap - 1, g->num_dst};
-      glx_filter_alias_build_kernel<<<row_blocks, 256, 0, s>>>(da, by_weight ? g->weight : nullptr, dm, g->dst_count,
-                                                              dist, tab, stk);
-      const int64_t total = (int64_t)batch * k;
+      glx_filter_alias_build_kernel<<<rb, 256, 0, s>>>(da, by_weight ? g->weight : nullptr, dm, g->dst_count, dist, tab,
+                                                      stk);
+      const int64_t total = (int64_t)nr * k;
       glx_filter_alias_slots_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(da, tab, d_nbr, d_eid);
     }
   }
   timer.stop();
   GLX_HIP(hipGetLastError());
+  glx_scratch_trim(s, 2, (size_t)32 << 30);
   return GLX_OK;
 }
 

@@ -123,6 +123,22 @@ int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot) {
   return GLX_OK;
 }
 
+// Gives a slot's cached workspace back to the device when it has grown beyond `keep_bytes`
+// (a rare huge request must not pin tens of GB per calling thread).  Synchronises `s` first.
+void glx_scratch_trim(hipStream_t s, int slot, size_t keep_bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  WsKey key{dev, s, slot};
+  for (auto& b : g_ws.bufs) {
+    if (b.key == key && b.cap > keep_bytes) {
+      (void)hipStreamSynchronize(s);
+      (void)hipFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+    }
+  }
+}
+
 void glx_scratch_free(void* p, hipStream_t s) {
   (void)p;
   (void)s;  // workspaces are cached per thread/stream; nothing to release per call
@@ -304,19 +320,19 @@ __global__ void glx_pack_adj_kernel(const int64_t* __restrict__ col, const int64
 }
 
 // AliasMethod::Build (alias_method.cc:57-107), one lane per row, bit-identical
-// to the serial reference: LIFO low/high stacks (kept in `stk`: low grows up
-// from the row's first slot, high grows down from its last; |low|+|high| <= deg
-// always), sum accumulated in double then narrowed to float (:73), float
-// arithmetic without contraction (-ffp-contract=off).
+// to the serial reference: LIFO low/high stacks (kept in `stk` as {prob, index}
+// pairs: low grows up from the row's first slot, high grows down from its last;
+// |low|+|high| <= deg always), sum accumulated in double then narrowed to float
+// (:73), float arithmetic without contraction (-ffp-contract=off).
 __global__ void glx_alias_build_kernel(const int64_t* __restrict__ row_ptr,
                                        const float* __restrict__ weight, int64_t V,
-                                       GlxAlias* __restrict__ out, int32_t* __restrict__ stk) {
+                                       GlxAlias* __restrict__ out, GlxAlias* __restrict__ stk) {
   int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (row >= V) return;
   const int64_t s = row_ptr[row];
   const int32_t count = (int32_t)(row_ptr[row + 1] - s);
   if (count == 0) return;
-  glx_alias_build_row(weight + s, count, out + s, stk + s, stk + s + count - 1);
+  glx_alias_build_row_dev(weight + s, count, out + s, stk + s);
 }
 
 // Packs {prob, (nbr, eid) of the slot, (nbr, eid) of its alias} per slot; *bad is set
@@ -436,9 +452,9 @@ int glx_alias_build_launch(const int64_t* row_ptr, const float* weight, int64_t 
                            GlxAlias* out, hipStream_t s) {
   if (E <= 0 || V <= 0) return GLX_OK;
   GlxTemp stk_buf;
-  GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(int32_t)));
+  GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(GlxAlias)));
   glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(row_ptr, weight, V, out,
-                                                                  stk_buf.as<int32_t>());
+                                                                  stk_buf.as<GlxAlias>());
   GLX_HIP(hipStreamSynchronize(s));  // stk_buf is released on return
   GLX_HIP(hipGetLastError());
   return GLX_OK;

@@ -21,6 +21,11 @@ struct SampleArgs {
   const GlxEwRec* ew;
   const int64_t* src;
   const int64_t* rng_rows;  // nullptr: request row i uses stream i
+  // Filtered requests whose reserved set is a row PREFIX (timestamp > value, filter.cc:74-82):
+  // row i samples from its first prefix[i] slots only, listed in descending order
+  // (reserved[x] = prefix[i] - 1 - x) when `reversed`.  nullptr: the whole row, as is.
+  const int32_t* prefix;
+  int32_t reversed;
   int64_t* nbr_out;
   int64_t* eid_out;
   int64_t default_nbr;
@@ -49,6 +54,7 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
     start = a.row_ptr[row];
     deg = a.row_ptr[row + 1] - start;
   }
+  if (a.prefix && row >= 0) deg = a.prefix[i];
   const int64_t obase = (int64_t)i * a.k;
   GlxPhilox blk;
   if (OP == kSlotRandom || OP == kSlotEdgeWeight || OP == kSlotEdgeWeightPacked) {
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
       } else if (OP == kSlotCircular) {
         // circular_padder.h:46-63 over iota(deg) (TopkSampler).
         pick = j % deg;
+        if (a.reversed) pick = deg - 1 - pick;
       } else {
         // replicate_padder.h:37-56: first min(k, deg) slots, then default fill.
         pick = j < deg ? j : -1;
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
       deg = a.row_ptr[row + 1] - start;
     }
   }
+  if (a.prefix && active) deg = deg > 0 ? a.prefix[i] : 0;
   const int32_t m = (int32_t)(deg < a.k ? deg : a.k);
   int32_t r = -1;
   if (l < m) {
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
   const int32_t pc = __shfl(perm, base + c);
   if (active && has_slot) {
     GlxAdj rec = GlxAdj{a.default_nbr, -1};
-    if (m > 0) rec = a.adj[start + pc];
+    if (m > 0) rec = a.adj[start + (a.reversed ? (int32_t)deg - 1 - pc : pc)];
     a.nbr_out[i * a.k + l] = rec.nbr;
     a.eid_out[i * a.k + l] = rec.eid;
   }
@@ -193,6 +201,7 @@ __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
       deg = a.row_ptr[row + 1] - start;
     }
   }
+  if (a.prefix && active) deg = deg > 0 ? a.prefix[i] : 0;
   const int32_t m = (int32_t)(deg < a.k ? deg : a.k);
   int32_t r = l;
   if (l < m) {
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
   const int32_t pc = __shfl(perm, base + c);
   if (active && has_slot) {
     GlxAdj rec = GlxAdj{a.default_nbr, -1};
-    if (m > 0) rec = a.adj[start + pc];
+    if (m > 0) rec = a.adj[start + (a.reversed ? (int32_t)deg - 1 - pc : pc)];
     a.nbr_out[i * a.k + l] = rec.nbr;
     a.eid_out[i * a.k + l] = rec.eid;
   }
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(64) void glx_rwor_lds_kernel(SampleArgs a) {
     start = a.row_ptr[row];
     deg = a.row_ptr[row + 1] - start;
   }
+  if (a.prefix) deg = deg > 0 ? a.prefix[i] : 0;
   const int32_t m = (int32_t)(deg < k ? deg : k);
   const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
   for (int32_t t = lane; t < m; t += 64) {
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(64) void glx_rwor_lds_kernel(SampleArgs a) {
   }
   for (int32_t j = lane; j < k; j += 64) {
     GlxAdj rec = GlxAdj{a.default_nbr, -1};
-    if (m > 0) rec = a.adj[start + perm[j % m]];
+    if (m > 0) rec = a.adj[start + (a.reversed ? (int32_t)deg - 1 - perm[j % m] : perm[j % m])];
     a.nbr_out[i * k + j] = rec.nbr;
     a.eid_out[i * k + j] = rec.eid;
   }
@@ -353,6 +363,31 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
 
 }  // namespace
 
+// glx_filter.hip: Topk / RandomWithoutReplacement over a per-row prefix (device pointers).
+int glx_sample_prefix_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng,
+                             const int32_t* d_prefix, int32_t batch, int32_t k, int padding_mode,
+                             int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter, int64_t* d_nbr,
+                             int64_t* d_eid, hipStream_t s) {
+  SampleArgs a;
+  a.map = g->map();
+  a.row_ptr = g->row_ptr;
+  a.adj = g->adj;
+  a.alias = nullptr;
+  a.ew = nullptr;
+  a.src = d_src;
+  a.rng_rows = d_rng;
+  a.prefix = d_prefix;
+  a.reversed = padding_mode == GLX_PAD_CIRCULAR ? 1 : 0;  // ReplicatePadder ignores the index values
+  a.nbr_out = d_nbr;
+  a.eid_out = d_eid;
+  a.default_nbr = default_neighbor_id;
+  a.seed = seed;
+  a.cc = call_counter;
+  a.batch = batch;
+  a.k = k;
+  return sample_device(g, sampler, a, padding_mode, s);
+}
+
 extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src,
                              const int64_t* rng_rows, int32_t batch, int32_t k, int padding_mode,
                              int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
@@ -381,6 +416,8 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
   a.cc = call_counter;
   a.batch = batch;
   a.k = k;
+  a.prefix = nullptr;
+  a.reversed = 0;
   if (ptr_kind == GLX_PTR_DEVICE) {
     a.src = src;
     a.rng_rows = rng_rows;

@@ -117,6 +117,31 @@ def test_filtered_samplers_bit_exact_with_oracle(orc, kind, pad):
     dev.close()
 
 
+def test_chunked_requests_match_unchunked(orc, monkeypatch):
+    """Large requests are served in chunks of bounded total degree (GLX_FILTER_SPAN_CAP forces tiny ones)."""
+    rng = np.random.default_rng(77)
+    src, dst, ts, w = random_graph(rng)
+    dev = glx.Graph.from_edges(src, dst, w, timestamp=ts)
+    dev.enable_in_degree()
+    og, rows = oracle_graph(orc, dev, src, ts, w)
+    ids = rng.choice(rows, 500).astype(np.int64)
+    for kind in ("id_eq", "id_gt", "ts_eq"):
+        ft, ff = FILTERS[kind]
+        vals = make_values(rng, og, rows, ids, kind)
+        for name in ALL_SAMPLERS[1:]:
+            monkeypatch.delenv("GLX_FILTER_SPAN_CAP", raising=False)
+            whole = dev.sample_filtered(name, ids, 7, ft, ff, vals, seed=3, call_counter=9)
+            monkeypatch.setenv("GLX_FILTER_SPAN_CAP", "90")
+            cut = dev.sample_filtered(name, ids, 7, ft, ff, vals, seed=3, call_counter=9)
+            want = orc.sample_filtered(og, name, ids, 7, dict(type=ft, field=ff, values=vals), seed=3, call_counter=9)
+            assert np.array_equal(cut[0], whole[0]) and np.array_equal(cut[1], whole[1]), (kind, name)
+            assert np.array_equal(cut[0], want[0]) and np.array_equal(cut[1], want[1]), (kind, name)
+        full = dev.sample_full_filtered(ids, 0, ft, ff, vals)
+        monkeypatch.delenv("GLX_FILTER_SPAN_CAP", raising=False)
+        assert all(np.array_equal(a, b) for a, b in zip(full, dev.sample_full_filtered(ids, 0, ft, ff, vals)))
+    dev.close()
+
+
 def test_filter_without_timestamps_uses_the_default_timestamp(orc):
     """GetEdgeTimestamp on a type without timestamps is GLOBAL_FLAG(DefaultTimestamp)
     (memory_edge_storage.cc:113-119): timestamp == default hits every neighbour."""
