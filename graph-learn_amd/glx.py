@@ -41,7 +41,7 @@ EXPORTS = [
     "glx_graph_create", "glx_graph_build", "glx_graph_build_ordered", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
     "glx_graph_degrees", "glx_graph_in_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
     "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
-    "glx_graph_set_timestamps", "glx_sample_filtered", "glx_sample_full_filtered",
+    "glx_graph_set_timestamps", "glx_sample_filtered", "glx_sample_full_filtered", "glx_random_walk",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
     "glx_partition", "glx_stitch_i64", "glx_stitch_f32", "glx_aggregate_stitch",
@@ -105,6 +105,7 @@ def lib():
         L.glx_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
         L.glx_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, ci, vp]
         L.glx_graph_set_timestamps.argtypes = [vp, vp, ci, vp]
+        L.glx_random_walk.argtypes = [vp, vp, i32, i32, f32, f32, i32, f32, i64, u64, u64, vp, ci, vp]
         L.glx_sample_filtered.argtypes = [vp, ci, vp, vp, i32, i32, ci, i64, u64, u64, ctypes.POINTER(Filter), vp, vp, ci,
                                           vp]
         L.glx_sample_full_filtered.argtypes = [vp, vp, i32, i32, vp, ci, i64, ctypes.POINTER(Filter), vp, vp, ci, vp]
@@ -322,6 +323,21 @@ class Graph:
                                               default_neighbor_id, ctypes.byref(flt), _ptr(nbr)[0], _ptr(eid)[0], kind,
                                               _stream(kind)))
         return deg, nbr, eid
+
+    def random_walk(self, seeds, walk_len, p=1.0, q=1.0, full_nbr_num=100, default_weight=0.0, default_neighbor_id=0,
+                    seed=0, call_counter=0):
+        """RandomWalk operator: -> walks[batch, walk_len] (DeepWalk when p = q = 1, node2vec otherwise)."""
+        batch = int(seeds.shape[0])
+        if _is_torch(seeds):
+            import torch
+            walks = torch.empty((batch, walk_len), dtype=torch.int64, device=seeds.device)
+        else:
+            walks = np.empty((batch, walk_len), np.int64)
+        ps, pw = _ptr(seeds), _ptr(walks)
+        kind = _kind(ps, pw)
+        _check(lib().glx_random_walk(self._h, ps[0], batch, walk_len, p, q, full_nbr_num, default_weight,
+                                     default_neighbor_id, seed, call_counter, pw[0], kind, _stream(kind)))
+        return walks
 
     def export_alias(self):
         prob = np.empty(self.num_edges, np.float32)

@@ -112,6 +112,42 @@ public:
   int32_t* MutableDegrees();
 };
 
+// RandomWalk (include/random_walk_request.h, service/request/random_walk_request.cc;
+// operator core/operator/random_walk/random_walk.cc): walk_len steps from every src id over
+// one edge type.  p = q = 1 is DeepWalk, anything else node2vec.  The reference's operator
+// feeds itself one sub-request per step with the parents and their neighbour lists
+// (random_walk.cc:95-130); here all steps run in one device call (glx_random_walk).
+class RandomWalkRequest : public OpRequest {
+public:
+  RandomWalkRequest();
+  RandomWalkRequest(const std::string& type, float p, float q, int32_t walk_len = 1);
+  OpRequest* Clone() const override;
+  void Set(const int64_t* src_ids, int32_t batch_size);
+  const std::string& Type() const;
+  float P() const;
+  float Q() const;
+  int32_t WalkLen() const;
+  bool IsDeepWalk() const;  // random_walk_request.cc:152-160
+  int32_t BatchSize() const;
+  const int64_t* GetSrcIds() const;
+  void SetCallCounter(int64_t call_counter);  // pins the random stream, as on SamplingRequest
+  bool HasCallCounter() const;
+  int64_t CallCounter() const;
+};
+
+class RandomWalkResponse : public OpResponse {
+public:
+  RandomWalkResponse();
+  OpResponse* New() const override { return new RandomWalkResponse; }
+  void InitWalks(int32_t batch_size, int32_t walk_len);
+  const int64_t* GetWalks() const;  // [batch, walk_len] row-major
+  int64_t* MutableWalks();
+  int32_t WalkLen() const { return walk_len_; }
+
+private:
+  int32_t walk_len_ = 0;
+};
+
 // GetNodes / GetEdges (graph_request.h:60-260; operators core/operator/graph/node_getter.cc,
 // edge_getter.cc over node_generator.h / edge_generator.h): batch traversal of a type's
 // ids.  strategy "by_order" | "shuffle" | "random".  The cursor lives with the operator,

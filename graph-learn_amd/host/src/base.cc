@@ -37,6 +37,7 @@ int64_t gDefaultLabel = -1;
 int64_t gDefaultTimestamp = -1;
 int32_t gIgnoreInvalid = 1;
 int32_t gSamplingRetryTimes = 5;
+int32_t gDefaultFullNbrNum = 100;
 int64_t gSamplingSeed = 0;
 int32_t gDeviceId = 0;
 
@@ -50,6 +51,7 @@ void SetGlobalFlagDefaultLabel(int64_t v) { gDefaultLabel = v; }
 void SetGlobalFlagDefaultTimestamp(int64_t v) { gDefaultTimestamp = v; }
 void SetGlobalFlagIgnoreInvalid(int32_t v) { gIgnoreInvalid = v; }
 void SetGlobalFlagSamplingRetryTimes(int32_t v) { gSamplingRetryTimes = v; }
+void SetGlobalFlagDefaultFullNbrNum(int32_t v) { gDefaultFullNbrNum = v; }
 void SetGlobalFlagSamplingSeed(int64_t v) { gSamplingSeed = v; }
 void SetGlobalFlagDeviceId(int32_t v) { gDeviceId = v; }
 

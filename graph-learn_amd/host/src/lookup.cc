@@ -1,6 +1,10 @@
 // "LookupNodes" / "LookupEdges" / "GetDegree" operators (see graph_request.h).
 // Unknown node ids and out-of-range edge ids (the -1 of a default-filled sample)
 // yield the Default* flags, like AttributeValue::Default (core/io/element_value.cc:26-50).
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+
 #include "glx.h"
 #include "graphlearn/config.h"
 #include "graphlearn/graph_request.h"
@@ -172,6 +176,61 @@ int32_t* GetDegreeResponse::MutableDegrees() { return tensors_[kDegreeKey].Mutab
 
 REGISTER_REQUEST(GetDegree, GetDegreeRequest, GetDegreeResponse)
 
+// -------------------------------------------------------------- RandomWalk --
+RandomWalkRequest::RandomWalkRequest() : OpRequest(kSrcIds) {}
+
+RandomWalkRequest::RandomWalkRequest(const std::string& type, float p, float q, int32_t walk_len)
+    : OpRequest(kSrcIds) {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("RandomWalk");
+  ADD_TENSOR(params_, kEdgeType, kString, 1);
+  params_[kEdgeType].AddString(type);
+  ADD_TENSOR(params_, kSideInfo, kFloat, 2);
+  params_[kSideInfo].AddFloat(p);
+  params_[kSideInfo].AddFloat(q);
+  ADD_TENSOR(params_, "walk_len", kInt32, 1);
+  params_["walk_len"].AddInt32(walk_len);
+  ADD_TENSOR(tensors_, kSrcIds, kInt64, 64);
+}
+
+OpRequest* RandomWalkRequest::Clone() const {
+  RandomWalkRequest* r = new RandomWalkRequest(Type(), P(), Q(), WalkLen());
+  if (HasCallCounter()) r->SetCallCounter(CallCounter());
+  return r;
+}
+void RandomWalkRequest::Set(const int64_t* src_ids, int32_t batch_size) {
+  tensors_[kSrcIds].AddInt64(src_ids, src_ids + batch_size);
+}
+const std::string& RandomWalkRequest::Type() const { return params_.at(kEdgeType).GetString(0); }
+float RandomWalkRequest::P() const { return params_.at(kSideInfo).GetFloat(0); }
+float RandomWalkRequest::Q() const { return params_.at(kSideInfo).GetFloat(1); }
+int32_t RandomWalkRequest::WalkLen() const { return params_.at("walk_len").GetInt32(0); }
+bool RandomWalkRequest::IsDeepWalk() const {
+  return std::fabs(P() - 1.0f) < 32 * FLT_EPSILON && std::fabs(Q() - 1.0f) < 32 * FLT_EPSILON;
+}
+int32_t RandomWalkRequest::BatchSize() const { return tensors_.at(kSrcIds).Size(); }
+const int64_t* RandomWalkRequest::GetSrcIds() const { return tensors_.at(kSrcIds).GetInt64(); }
+void RandomWalkRequest::SetCallCounter(int64_t call_counter) {
+  params_.erase("call_counter");
+  ADD_TENSOR(params_, "call_counter", kInt64, 1);
+  params_["call_counter"].AddInt64(call_counter);
+}
+bool RandomWalkRequest::HasCallCounter() const { return params_.count("call_counter") != 0; }
+int64_t RandomWalkRequest::CallCounter() const { return params_.at("call_counter").GetInt64(0); }
+
+RandomWalkResponse::RandomWalkResponse() : OpResponse() {}
+void RandomWalkResponse::InitWalks(int32_t batch_size, int32_t walk_len) {
+  batch_size_ = batch_size;
+  walk_len_ = walk_len;
+  tensors_.erase(kNodeIds);
+  ADD_TENSOR(tensors_, kNodeIds, kInt64, batch_size * walk_len);
+  tensors_[kNodeIds].Resize(batch_size * walk_len);
+}
+const int64_t* RandomWalkResponse::GetWalks() const { return tensors_.at(kNodeIds).GetInt64(); }
+int64_t* RandomWalkResponse::MutableWalks() { return tensors_[kNodeIds].MutableInt64(); }
+
+REGISTER_REQUEST(RandomWalk, RandomWalkRequest, RandomWalkResponse)
+
 namespace op {
 
 class NodeLookuper : public Operator {
@@ -258,9 +317,40 @@ public:
   }
 };
 
+// RandomWalk (core/operator/random_walk/random_walk.cc:30-276): all steps in one device call.
+class RandomWalk : public Operator {
+public:
+  Status Process(const OpRequest* req, OpResponse* res) override {
+    const RandomWalkRequest* request = static_cast<const RandomWalkRequest*>(req);
+    RandomWalkResponse* response = static_cast<RandomWalkResponse*>(res);
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    const int32_t n = request->BatchSize(), len = request->WalkLen();
+    response->InitWalks(n, len);
+    int64_t* walks = response->MutableWalks();
+    const glx_graph* g = graph_store_->GetGraph(request->Type())->Device();
+    if (!g) {  // an edge type nobody loaded: every walker is stuck at once
+      for (int64_t i = 0; i < (int64_t)n * len; ++i) walks[i] = GLOBAL_FLAG(DefaultNeighborId);
+      return Status::OK();
+    }
+    // every step consumes one call counter value, like one sub-request of the reference
+    const uint64_t cc = request->HasCallCounter()
+                            ? (uint64_t)request->CallCounter()
+                            : call_counter_.fetch_add((uint64_t)(len > 0 ? len : 1), std::memory_order_relaxed);
+    int rc = glx_random_walk(g, request->GetSrcIds(), n, len, request->P(), request->Q(),
+                             GLOBAL_FLAG(DefaultFullNbrNum), GLOBAL_FLAG(DefaultWeight),
+                             GLOBAL_FLAG(DefaultNeighborId), (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, walks,
+                             GLX_PTR_HOST, nullptr);
+    return error::FromGlx(rc);
+  }
+
+private:
+  std::atomic<uint64_t> call_counter_{0};
+};
+
 REGISTER_OPERATOR("LookupNodes", NodeLookuper)
 REGISTER_OPERATOR("LookupEdges", EdgeLookuper)
 REGISTER_OPERATOR("GetDegree", DegreeGetter)
+REGISTER_OPERATOR("RandomWalk", RandomWalk)
 
 }  // namespace op
 }  // namespace graphlearn

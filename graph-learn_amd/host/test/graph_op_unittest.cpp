@@ -197,6 +197,35 @@ TEST(GraphOpTest, DegreeGetter) {
   for (int32_t i = 0; i < 3; ++i) EXPECT_EQ(res.GetDegrees()[i], 0);
 }
 
+// RandomWalk (core/operator/random_walk/random_walk.cc) on the self-loop fixture: a walker stays where it is, an
+// unknown id yields the default id and walks on from it; DeepWalk and node2vec requests share the operator.
+TEST(GraphOpTest, RandomWalk) {
+  SetUpStore();
+  for (float p : {1.0f, 0.5f}) {
+    RandomWalkRequest req("click", p, 2.0f * p, 4);
+    RandomWalkResponse res;
+    int64_t ids[3] = {5, 42, 200};
+    req.Set(ids, 3);
+    EXPECT_TRUE(req.IsDeepWalk() == (p == 1.0f));
+    Operator* op = OpFactory::GetInstance()->Create(req.Name());
+    EXPECT_TRUE(op != nullptr);
+    EXPECT_TRUE(op->Process(&req, &res).ok());
+    EXPECT_EQ(res.WalkLen(), 4);
+    for (int t = 0; t < 4; ++t) {
+      EXPECT_EQ(res.GetWalks()[t], 5);
+      EXPECT_EQ(res.GetWalks()[4 + t], 42);
+      EXPECT_EQ(res.GetWalks()[8 + t], 0);  // default id, then vertex 0's self loop
+    }
+  }
+  RandomWalkRequest nobody("no-such-type", 1.0f, 1.0f, 2);
+  RandomWalkResponse res;
+  int64_t id = 3;
+  nobody.Set(&id, 1);
+  EXPECT_TRUE(OpFactory::GetInstance()->Create("RandomWalk")->Process(&nobody, &res).ok());
+  EXPECT_EQ(res.GetWalks()[0], 0);
+  EXPECT_EQ(res.GetWalks()[1], 0);
+}
+
 TEST(GraphOpTest, EdgeGetter) {
   // graph_op_unittest.cpp:219-281: batches of 12 over 100 edges: 8 full, one of 4, then OutOfRange
   SetUpStore();

@@ -271,27 +271,36 @@ class Graph(object):
       raise ValueError("node type {} has no float attributes on the device".format(node_type))
     return glx.Features.from_handle(h)
 
-  def random_walk(self, edge_type, ids, walk_len, p=1.0, q=1.0, call_counter=0):
-    """DeepWalk-style uniform random walks (the p = q = 1 case of the reference's "RandomWalk"
-    operator, core/operator/random_walk/random_walk.cc:168-190): `walk_len` steps from every id, each
-    step = one uniform neighbour draw, the default neighbour id where a vertex has no out-edges.
-    All steps run in one glx_sample_hops call.  ids: numpy array or torch CUDA tensor
-    -> walks [len(ids), walk_len] of the same kind.  node2vec biases (p, q != 1) are not served."""
-    if p != 1.0 or q != 1.0:
-      self._off_path("node2vec-biased random walk (p, q != 1)")
-    import glx
+  def random_walk(self, edge_type, ids, walk_len, p=1.0, q=1.0, call_counter=None):
+    """Random walks over one edge type -- the reference's "RandomWalk" operator
+    (core/operator/random_walk/random_walk.cc), which its own Python API reaches through GSL's
+    .random_walk() only: `walk_len` steps from every id.  p = q = 1: DeepWalk, every step one uniform
+    neighbour draw.  Otherwise node2vec: a step weighs the first `default_full_nbr_num` edges of the
+    current vertex by 1/p (back to the parent), 1 (to a neighbour of the parent) or 1/q and draws
+    from their alias table.  A vertex without out-edges yields the default neighbour id.
+    ids: numpy array -> numpy walks [len(ids), walk_len] through the operator; torch CUDA tensor ->
+    CUDA walks straight from the device graph (call_counter defaults to 0 there)."""
     import torch
     from graphlearn import settings
-    as_numpy = not isinstance(ids, torch.Tensor)
-    dev = torch.device("cuda", settings._MIRROR.get("device_id", 0))  # pylint: disable=protected-access
-    seeds = torch.as_tensor(np.ascontiguousarray(np.array(ids).reshape(-1), dtype=np.int64)).to(dev) if as_numpy else ids
-    graph = self.device_graph(edge_type)
-    hops = glx.sample_hops([graph] * int(walk_len), "RandomSampler", seeds, [1] * int(walk_len),
-                           seed=settings._MIRROR["sampling_seed"], call_counter=call_counter,  # pylint: disable=protected-access
-                           padding_mode=settings._MIRROR["padding_mode"],  # pylint: disable=protected-access
-                           default_neighbor_id=settings._MIRROR["default_neighbor_id"])  # pylint: disable=protected-access
-    walks = torch.cat([h[0] for h in hops], dim=1)
-    return walks.cpu().numpy() if as_numpy else walks
+    if isinstance(ids, torch.Tensor):
+      flags = settings._MIRROR  # pylint: disable=protected-access
+      return self.device_graph(edge_type).random_walk(
+          ids, int(walk_len), p=float(p), q=float(q), full_nbr_num=flags["default_full_nbr_num"],
+          default_weight=flags["default_weight"], default_neighbor_id=flags["default_neighbor_id"],
+          seed=flags["sampling_seed"], call_counter=call_counter or 0)
+    self.get_edge_decoder(edge_type)
+    src = np.ascontiguousarray(np.array(ids).reshape(-1), dtype=np.int64)
+    req = pywrap.new_random_walk_request(edge_type, float(p), float(q), int(walk_len))
+    pywrap.set_random_walk_request(req, src)
+    if call_counter is not None:
+      pywrap.set_random_walk_call_counter(req, int(call_counter))
+    res = pywrap.new_random_walk_response()
+    status = self._client.run_op(req, res)
+    walks = pywrap.get_random_walks(res).reshape(src.size, int(walk_len)) if status.ok() else None
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
+    return walks
 
   def _off_path(self, what):
     raise NotImplementedError("%s is outside the sampling/aggregation path this engine replaces" % what)

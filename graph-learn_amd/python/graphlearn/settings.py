@@ -8,6 +8,7 @@ __all__ = [
     "set_default_neighbor_id", "set_padding_mode", "set_default_int_attribute",
     "set_default_float_attribute", "set_default_string_attribute", "set_default_weight",
     "set_default_label", "set_default_timestamp", "set_ignore_invalid", "set_sampler_retry_times",
+    "set_default_full_nbr_num",
     "set_inter_threadnum", "set_intra_threadnum", "set_inner_threadnum", "set_datainit_batchsize",
     "set_inmemory_queuesize", "set_shuffle_buffer_size", "set_tracker_mode", "set_storage_mode",
     "set_retry_times", "set_timeout", "set_sampling_seed", "set_device_id",
@@ -15,7 +16,8 @@ __all__ = [
 
 
 # flags the device-tensor path (NeighborSampler.get_device) passes to the C-ABI itself
-_MIRROR = {"padding_mode": 1, "default_neighbor_id": 0, "sampling_seed": 0, "default_float_attr": 0.0, "device_id": 0}
+_MIRROR = {"padding_mode": 1, "default_neighbor_id": 0, "sampling_seed": 0, "default_float_attr": 0.0, "device_id": 0,
+           "default_full_nbr_num": 100, "default_weight": 0.0}
 
 
 def set_default_neighbor_id(nbr_id):
@@ -44,6 +46,13 @@ def set_default_string_attribute(value=""):
 
 def set_default_weight(value=0.0):
   pywrap.set_default_weight(float(value))
+  _MIRROR["default_weight"] = float(value)
+
+
+def set_default_full_nbr_num(num):
+  """Neighbours a node2vec step looks at (GLOBAL_FLAG(DefaultFullNbrNum), 100)."""
+  pywrap.set_default_full_nbr_num(int(num))
+  _MIRROR["default_full_nbr_num"] = int(num)
 
 
 def set_default_label(value=-1):

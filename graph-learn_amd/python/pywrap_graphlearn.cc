@@ -71,6 +71,7 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("set_default_timestamp", &SetGlobalFlagDefaultTimestamp);
   m.def("set_ignore_invalid", &SetGlobalFlagIgnoreInvalid);
   m.def("set_sampler_retry_times", &SetGlobalFlagSamplingRetryTimes);
+  m.def("set_default_full_nbr_num", &SetGlobalFlagDefaultFullNbrNum);
   m.def("set_sampling_seed", &SetGlobalFlagSamplingSeed);
   m.def("set_device_id", &SetGlobalFlagDeviceId);
   // thread-pool / queue sizing of the reference's service layer: accepted, no effect
@@ -262,6 +263,25 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
     SamplingResponse* r = As<SamplingResponse>(res, "SamplingResponse");
     const Shape& shape = r->GetShape();
     return CopyOut(shape.segments.data(), shape.segments.size());
+  });
+
+  // ---- random walks (the reference reaches its RandomWalk operator through GSL only) ----
+  m.def("new_random_walk_request",
+        [](const std::string& type, float p, float q, int32_t walk_len) -> OpRequest* {
+          return new RandomWalkRequest(type, p, q, walk_len);
+        },
+        py::return_value_policy::reference);
+  m.def("new_random_walk_response", []() -> OpResponse* { return new RandomWalkResponse(); },
+        py::return_value_policy::reference);
+  m.def("set_random_walk_request", [](OpRequest* req, I64Array src_ids) {
+    As<RandomWalkRequest>(req, "RandomWalkRequest")->Set(src_ids.data(), (int32_t)src_ids.size());
+  });
+  m.def("set_random_walk_call_counter", [](OpRequest* req, int64_t call_counter) {
+    As<RandomWalkRequest>(req, "RandomWalkRequest")->SetCallCounter(call_counter);
+  });
+  m.def("get_random_walks", [](OpResponse* res) {
+    RandomWalkResponse* r = As<RandomWalkResponse>(res, "RandomWalkResponse");
+    return ViewOf<int64_t>(r, kNodeIds, (size_t)r->batch_size_ * (size_t)r->WalkLen());
   });
 
   // ---- aggregation (py_client.cc:365-391) ----

@@ -258,6 +258,26 @@ GLX_API int glx_sample_full_filtered(const glx_graph* g, const int64_t* src, int
                                      const glx_filter* filter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
                                      void* stream);
 
+/* ---- random walks: replaces the "RandomWalk" operator (core/operator/random_walk/
+ * random_walk.cc:30-276) -- DeepWalk (:168-190) when p = q = 1 within 32 FLT_EPSILON
+ * (RandomWalkRequest::IsDeepWalk, random_walk_request.cc:152-160), node2vec otherwise
+ * (WeightedRandomWalk / WeightedRandomWalkKernel, :192-272). ----------------------------
+ * walks_out[batch * walk_len], row i = the walk_len vertices visited from seeds[i] (the
+ * response layout, :121-127).  A vertex without out-edges yields default_neighbor_id, and
+ * the walk goes on from THAT id, like the reference.  node2vec looks at the first
+ * min(deg, full_nbr_num) neighbours only (GLOBAL_FLAG(DefaultFullNbrNum), <= 4096 here),
+ * weighs an edge by 1/(p + 1e-6) when it returns to the parent, by 1 when it leads to one of
+ * the parent's first full_nbr_num neighbours, by 1/(q + 1e-6) otherwise, and draws once from
+ * the alias table of those weights; the first step's parent is the seed itself, without
+ * neighbours (random_walk_request.cc:120-131).  default_weight stands in for the edge
+ * weights of an unweighted graph (GLOBAL_FLAG(DefaultWeight)).  Step t of walker i uses draw 0
+ * of the stream (seed, call_counter + t, i).  The reference does not advance its cursor
+ * into the parents' neighbour lists past a walker that is stuck (:214-226), which shifts the
+ * lists of all later walkers of the batch; glx keeps every walker on its own parent. */
+GLX_API int glx_random_walk(const glx_graph* g, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
+                            float q, int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id,
+                            uint64_t seed, uint64_t call_counter, int64_t* walks_out, int ptr_kind, void* stream);
+
 /* ---- node features: replaces NodeStorage::GetAttribute()->GetFloats()
  * (node_storage.h:51-54, compressed_memory_node_storage.cc:149-176). -------
  * X is [num_rows, dim] row-major float32 (SideInfo.f_num == dim). */

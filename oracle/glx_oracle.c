@@ -8,6 +8,7 @@
 #include "glx_oracle.h"
 
 #include <float.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -355,6 +356,89 @@ int64_t glxo_sample_full(const glxo_graph* g, const int64_t* src, int32_t batch,
   }
   if (g->ids) idmap_free(&m);
   return total;
+}
+
+/* ------------------------------------------------------------ random walk -- */
+static int32_t node2vec_weights(const glxo_graph* g, const idmap* m, int64_t cur, int64_t parent, int has_parent_nbrs,
+                                float p, float q, int32_t F, float default_weight, float* w_out, int64_t* start_out) {
+  int64_t row = row_of(g->ids, m, g->V, cur);
+  if (row < 0) return 0;
+  int64_t s = g->row_ptr[row], d = g->row_ptr[row + 1] - s;
+  int32_t n = (int32_t)(d < F ? d : F);
+  *start_out = s;
+  int64_t ps = 0;
+  int32_t pn = 0;
+  if (has_parent_nbrs) {
+    int64_t prow = row_of(g->ids, m, g->V, parent);
+    if (prow >= 0) {
+      ps = g->row_ptr[prow];
+      int64_t pd = g->row_ptr[prow + 1] - ps;
+      pn = (int32_t)(pd < F ? pd : F);
+    }
+  }
+  for (int32_t x = 0; x < n; ++x) {
+    float ew = g->weight ? g->weight[s + x] : default_weight;
+    if (g->col[s + x] == parent) {
+      w_out[x] = ew * 1.0 / (p + 1e-6);  /* random_walk.cc:247-248 */
+    } else {
+      int32_t y = 0;
+      for (; y < pn; ++y) {
+        if (g->col[ps + y] == g->col[s + x]) { w_out[x] = ew; break; }
+      }
+      if (y == pn) w_out[x] = ew * 1.0 / (q + 1e-6);
+    }
+  }
+  return n;
+}
+
+void glxo_node2vec_weights(const glxo_graph* g, int64_t cur, int64_t parent, int has_parent_nbrs, float p, float q,
+                           int32_t full_nbr_num, float default_weight, float* w_out, int32_t* n_out) {
+  idmap m;
+  if (g->ids) idmap_build(&m, g->ids, g->V);
+  int64_t s = 0;
+  *n_out = node2vec_weights(g, &m, cur, parent, has_parent_nbrs, p, q, full_nbr_num, default_weight, w_out, &s);
+  if (g->ids) idmap_free(&m);
+}
+
+int glxo_random_walk(const glxo_graph* g, const int64_t* seeds, int32_t batch, int32_t walk_len, float p, float q,
+                     int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id, uint64_t seed,
+                     uint64_t call_counter, int64_t* walks_out) {
+  /* RandomWalkRequest::IsDeepWalk, random_walk_request.cc:152-160 */
+  const int deep = fabsf(p - 1.0f) < 32 * FLT_EPSILON && fabsf(q - 1.0f) < 32 * FLT_EPSILON;
+  if (!deep && full_nbr_num < 1) return 3;
+  idmap m;
+  if (g->ids) idmap_build(&m, g->ids, g->V);
+  const int32_t F = full_nbr_num > 0 ? full_nbr_num : 1;
+  float* w = (float*)malloc(sizeof(float) * (size_t)F * 2);
+  int32_t* tab = (int32_t*)malloc(sizeof(int32_t) * (size_t)F * 3);
+  for (int32_t t = 0; t < walk_len; ++t) {
+    for (int32_t i = 0; i < batch; ++i) {
+      int64_t* walk = walks_out + (int64_t)i * walk_len;
+      const int64_t cur = t == 0 ? seeds[i] : walk[t - 1];
+      const int64_t parent = t <= 1 ? seeds[i] : walk[t - 2];
+      const uint64_t u = glxo_draw64(seed, call_counter + (uint64_t)t, (uint32_t)i, 0);
+      if (deep) {
+        int64_t row = row_of(g->ids, &m, g->V, cur);
+        int64_t s = row < 0 ? 0 : g->row_ptr[row];
+        int64_t d = row < 0 ? 0 : g->row_ptr[row + 1] - s;
+        walk[t] = d == 0 ? default_neighbor_id : g->col[s + (int64_t)bounded(u, (uint64_t)d)];
+        continue;
+      }
+      int64_t s = 0;
+      int32_t n = node2vec_weights(g, &m, cur, parent, t > 0, p, q, F, default_weight, w, &s);
+      if (n == 0) { walk[t] = default_neighbor_id; continue; }
+      float* probs = w + F;
+      alias_build_row(w, n, probs, tab, tab + F, tab + 2 * F);
+      double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(n - 1);
+      float rnd = (float)rd;
+      int32_t ix = (int32_t)rnd;
+      walk[t] = g->col[s + ((probs[ix] <= (rnd - ix)) ? tab[ix] : ix)];
+    }
+  }
+  free(w);
+  free(tab);
+  if (g->ids) idmap_free(&m);
+  return 0;
 }
 
 /* ---------------------------------------------------------------- filters -- */

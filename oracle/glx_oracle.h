@@ -106,6 +106,19 @@ int64_t glxo_sample_full_filtered(const glxo_graph* g, const int64_t* src, int32
                                   int padding_mode, int64_t default_neighbor_id, const glxo_filter* f,
                                   int32_t* degrees_out, int64_t* nbr_out, int64_t* eid_out, int64_t cap);
 
+/* Restates the "RandomWalk" operator (core/operator/random_walk/random_walk.cc:30-276):
+ * DeepWalk (:168-190) when p = q = 1 within 32 FLT_EPSILON, node2vec otherwise
+ * (WeightedRandomWalkKernel :228-272: biased weights over the first min(deg, full_nbr_num)
+ * neighbours, AliasMethod over them, one draw).  walks_out[batch * walk_len] row-major.
+ * Step t of walker i uses draw 0 of stream (seed, call_counter + t, i).  Every walker reads
+ * its own parent's neighbour list (the reference's cursor slips past stuck walkers). */
+int glxo_random_walk(const glxo_graph* g, const int64_t* seeds, int32_t batch, int32_t walk_len, float p, float q,
+                     int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id, uint64_t seed,
+                     uint64_t call_counter, int64_t* walks_out);
+/* The biased weights of one node2vec step (exposed for the distribution tests). */
+void glxo_node2vec_weights(const glxo_graph* g, int64_t cur, int64_t parent, int has_parent_nbrs, float p, float q,
+                           int32_t full_nbr_num, float default_weight, float* w_out, int32_t* n_out);
+
 /* Restates MemoryAdjMatrix::Sort (memory_adj_matrix.cc:105-125): each row by
  * weight descending.  Ties keep insertion order (the reference's std::sort
  * leaves tie order unspecified).  Sorts col/eid/weight in place. */

@@ -66,6 +66,10 @@ class Oracle:
         L.glxo_aggregate_stitch.argtypes = [ctypes.c_int, i32, VP, VP, i32, i32, ctypes.c_float, ctypes.c_int, VP, VP]
         L.glxo_stitch_i64.argtypes = [VP, VP, i64, i32, VP]
         L.glxo_set_reference_cost_model.argtypes = [ctypes.c_int]
+        L.glxo_random_walk.argtypes = [ctypes.POINTER(_CGraph), VP, i32, i32, ctypes.c_float, ctypes.c_float, i32,
+                                       ctypes.c_float, i64, u64, u64, VP]
+        L.glxo_node2vec_weights.argtypes = [ctypes.POINTER(_CGraph), i64, i64, ctypes.c_int, ctypes.c_float,
+                                            ctypes.c_float, i32, ctypes.c_float, VP, VP]
         L.glxo_filter_act_on.argtypes = [ctypes.POINTER(_CFilter), i32, VP, VP, i32, VP]
         L.glxo_filter_act_on.restype = i32
         L.glxo_sample_filtered.argtypes = [ctypes.POINTER(_CGraph), ctypes.c_int, VP, VP, i32, i32, ctypes.c_int, i64,
@@ -150,6 +154,23 @@ class Oracle:
         self.L.glxo_sample_full_filtered(ctypes.byref(cg), _p(src), batch, max_limit, padding_mode, default_neighbor_id,
                                          ctypes.byref(cf), _p(deg), _p(nbr), _p(eid), total)
         return deg, nbr, eid
+
+    def random_walk(self, g, seeds, walk_len, p=1.0, q=1.0, full_nbr_num=100, default_weight=0.0, default_neighbor_id=0,
+                    seed=0, call_counter=0):
+        cg = self._cgraph(g)
+        walks = np.zeros((seeds.shape[0], walk_len), np.int64)
+        rc = self.L.glxo_random_walk(ctypes.byref(cg), _p(seeds), seeds.shape[0], walk_len, p, q, full_nbr_num,
+                                     default_weight, default_neighbor_id, seed, call_counter, _p(walks))
+        assert rc == 0, rc
+        return walks
+
+    def node2vec_weights(self, g, cur, parent, has_parent_nbrs, p, q, full_nbr_num=100, default_weight=0.0):
+        cg = self._cgraph(g)
+        w = np.zeros(full_nbr_num, np.float32)
+        n = ctypes.c_int32()
+        self.L.glxo_node2vec_weights(ctypes.byref(cg), cur, parent, 1 if has_parent_nbrs else 0, p, q, full_nbr_num,
+                                     default_weight, _p(w), ctypes.byref(n))
+        return w[:n.value].copy()
 
     def _cgraph(self, g):
         alias = g.get("alias")

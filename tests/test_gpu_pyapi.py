@@ -436,7 +436,7 @@ def test_random_walk_deepwalk(gl, g):
     step follows an edge of the type; a vertex without out-edges yields the default id."""
     import torch
     seeds = np.array([102, 107, 108, 111])
-    walks = g.random_walk(EDGE3, seeds, 10)
+    walks = g.random_walk(EDGE3, seeds, 10, call_counter=0)
     assert walks.shape == (4, 10)
     prev = seeds
     for step in range(10):
@@ -450,8 +450,6 @@ def test_random_walk_deepwalk(gl, g):
         prev = cur
     dev = g.random_walk(EDGE3, torch.from_numpy(seeds).cuda(), 10)
     assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), walks)  # same pinned stream
-    with pytest.raises(NotImplementedError):
-        g.random_walk(EDGE3, seeds, 5, p=0.5)
 
 
 def test_python_stack_equals_live_reference_on_the_same_records(gl, g):
@@ -624,3 +622,21 @@ def test_filtered_sampling_through_the_python_api(gl, g, tmp_path):
         gl.set_default_neighbor_id(DEFAULT_ID)
         gl.set_padding_mode(gl.REPLICATE)
         tg.close()
+
+
+def test_random_walk_through_the_python_api(gl, g):
+    """RandomWalk operator (random_walk.cc) behind Graph.random_walk: numpy ids go through the registered operator,
+    CUDA ids straight to the device graph; the same pinned stream gives the same walks; node2vec biases are served."""
+    import torch
+    seeds = np.arange(100, 160, dtype=np.int64)
+    for p, q in ((1.0, 1.0), (0.25, 4.0)):
+        a = g.random_walk(EDGE3, seeds, 5, p=p, q=q, call_counter=7)
+        b = g.random_walk(EDGE3, torch.from_numpy(seeds).cuda(), 5, p=p, q=q, call_counter=7).cpu().numpy()
+        assert a.shape == (60, 5) and np.array_equal(a, b)
+        for row, s in zip(a, seeds):  # every step follows an (undirected) edge3 edge, or is the default id at a dead end
+            cur = int(s)
+            for v in row:
+                out = set(fx.fixed_dst_ids(cur, RANGE2)) | {x for x in range(*RANGE2) if cur in fx.fixed_dst_ids(x, RANGE2)}
+                assert (int(v) in out) if (out and cur != DEFAULT_ID) else (v == DEFAULT_ID), (cur, v)
+                cur = int(v)
+    assert not np.array_equal(g.random_walk(EDGE3, seeds, 5), g.random_walk(EDGE3, seeds, 5))  # fresh streams per call
