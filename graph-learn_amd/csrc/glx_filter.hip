@@ -542,7 +542,7 @@ extern "C" int glx_sample_filtered(const glx_graph* g, int sampler, const int64_
   int rc = check_filter(g, filter);
   if (rc != GLX_OK) return rc;
   GLX_REQUIRE(sampler != GLX_SAMPLER_EDGE_WEIGHT || g->weight != nullptr, "EdgeWeightSampler needs a weighted graph");
-  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || g->dst_count != nullptr,
+  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || g->alias_indeg != nullptr,
               "InDegreeSampler needs glx_graph_enable_in_degree()");
   GlxDeviceGuard guard(g->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);

@@ -202,7 +202,7 @@ TEST(GraphOpTest, DegreeGetter) {
 TEST(GraphOpTest, RandomWalk) {
   SetUpStore();
   for (float p : {1.0f, 0.5f}) {
-    RandomWalkRequest req("click", p, 2.0f * p, 4);
+    RandomWalkRequest req("click", p, p == 1.0f ? 1.0f : 2.0f, 4);
     RandomWalkResponse res;
     int64_t ids[3] = {5, 42, 200};
     req.Set(ids, 3);

@@ -147,6 +147,44 @@ TEST(PartitionStitchTest, SamplersOnTwoDeviceStoresEqualOneStore) {
     for (size_t i = 0; i < ids.size() * 6; ++i) same &= stitched.GetNeighborIds()[i] == single.GetNeighborIds()[i];
     EXPECT_TRUE(same);  // edge ids are server-local in the reference too, so only neighbours are compared
   }
+  // the same with a filter: the values travel with their src ids (HashPartitioner copies every tensor of the
+  // request, hash_partitioner.h:69-74), so every part filters its rows with the right value
+  for (int n = 0; n < 4; ++n) {
+    Operator* op = OpFactory::GetInstance()->Create(names[n]);
+    SamplingRequest req("e", names[n], 6, kLargerThan, kId);
+    std::vector<int64_t> values;
+    for (size_t i = 0; i < ids.size(); ++i) values.push_back(100 + (int64_t)(i % 150));
+    req.Set(ids.data(), (int32_t)ids.size());
+    req.SetFilterValues(values.data(), (int32_t)values.size());
+    req.SetCallCounter(2000 + n);
+    SamplingResponse single;
+    OpFactory::GetInstance()->Set(&c->whole);
+    EXPECT_TRUE(op->Process(&req, &single).ok());
+    ShardsPtr<OpRequest> parts = partitioner.Partition(&req);
+    ShardsPtr<OpResponse> answers(new Shards<OpResponse>(2));
+    for (int s = 0; s < 2; ++s) {
+      const SamplingRequest* part = static_cast<const SamplingRequest*>(parts->Get(s));
+      EXPECT_TRUE(part->HasFilter() && part->GetFilterValues() != nullptr);
+      for (int32_t i = 0; i < part->BatchSize(); ++i) {
+        EXPECT_EQ(part->GetFilterValues()[i], values[(size_t)parts->StickerPtr()->At(s)[i]]);
+      }
+      OpFactory::GetInstance()->Set(&c->shard[s]);
+      SamplingResponse* r = new SamplingResponse;
+      EXPECT_TRUE(op->Process(parts->Get(s), r).ok());
+      answers->Add(s, r, true);
+      for (int32_t st : parts->StickerPtr()->At(s)) answers->StickerPtr()->Add(s, st);
+    }
+    SamplingResponse stitched;
+    stitched.Stitch(answers);
+    bool same = true, filtered = true;
+    for (size_t i = 0; i < ids.size() * 6; ++i) {
+      same &= stitched.GetNeighborIds()[i] == single.GetNeighborIds()[i];
+      // ids above the row's value only appear through RandomSampler's exhausted retries
+      if (n != 0) filtered &= stitched.GetNeighborIds()[i] <= values[i / 6];
+    }
+    EXPECT_TRUE(same);
+    EXPECT_TRUE(filtered);
+  }
   OpFactory::GetInstance()->Set(&c->whole);
 }
 

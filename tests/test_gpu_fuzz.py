@@ -54,6 +54,47 @@ def test_fuzz_samplers(seed, V, maxdeg, k, pad, hashed, nq, rng_seed, cc):
     assert np.array_equal(d, od) and np.array_equal(n, on) and np.array_equal(e, oe)
 
 
+@settings(**dict(COMMON, max_examples=120))
+@given(seed=st.integers(0, 2 ** 31 - 1), V=st.integers(1, 30), maxdeg=st.integers(0, 150), k=st.integers(1, 40),
+       pad=st.integers(0, 1), ftype=st.integers(1, 2), ffield=st.integers(0, 2), retry=st.integers(0, 6),
+       sorted_ts=st.booleans(), rng_seed=st.integers(0, 2 ** 63 - 1))
+def test_fuzz_filtered_samplers(seed, V, maxdeg, k, pad, ftype, ffield, retry, sorted_ts, rng_seed):
+    """op::Filter on arbitrary rows: repeated neighbour ids, tied and (optionally) unsorted timestamps -- the binary
+    search of the timestamp path is then run on data it was not made for, and must still match the restatement."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, maxdeg + 1, V)
+    deg[rng.random(V) < 0.2] = 0
+    deg[rng.random(V) < 0.2] = 1
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    E = int(rp[-1])
+    col = rng.integers(0, 12, E).astype(np.int64)
+    eid = rng.permutation(E).astype(np.int64)
+    w = (rng.integers(1, 50, E) / 50.0).astype(np.float32)
+    ts = rng.integers(0, 25, E).astype(np.int64)
+    if sorted_ts:
+        for r in range(V):
+            ts[rp[r]:rp[r + 1]] = np.sort(ts[rp[r]:rp[r + 1]])
+    og = dict(row_ptr=rp, col=col, eid=eid, weight=w, ts_slot=ts)
+    og["indeg_weight"] = ORC.in_degree_alias(og)[1]
+    dev = glx.Graph(rp, col, eid, w).enable_in_degree()
+    dev.set_timestamps(ts)
+    q = np.concatenate([rng.integers(0, V, 40), [V + 3, -2]]).astype(np.int64)
+    vals = rng.integers(-1, 26 if ffield == 2 else 13, q.shape[0]).astype(np.int64)
+    flt = dict(type=ftype, field=ffield, values=vals, retry_times=retry, default_timestamp=7)
+    for name in SAMPLERS + ["InDegreeSampler"]:
+        n, e = dev.sample_filtered(name, q, k, ftype, ffield, vals, seed=rng_seed, call_counter=3, padding_mode=pad,
+                                   default_neighbor_id=-11, retry_times=retry, default_timestamp=7)
+        on, oe = ORC.sample_filtered(og, name, q, k, flt, seed=rng_seed, call_counter=3, padding_mode=pad,
+                                     default_neighbor_id=-11)
+        assert np.array_equal(n, on) and np.array_equal(e, oe), (name, k, pad, ftype, ffield)
+    lim = int(seed % 4)
+    got = dev.sample_full_filtered(q, lim, ftype, ffield, vals, padding_mode=pad, default_neighbor_id=-11,
+                                   default_timestamp=7)
+    want = ORC.sample_full_filtered(og, q, lim, flt, padding_mode=pad, default_neighbor_id=-11)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want)), (lim, pad, ftype, ffield)
+    dev.close()
+
+
 @settings(**COMMON)
 @given(seed=st.integers(0, 2 ** 31 - 1), V=st.integers(1, 50), D=st.integers(1, 70), Sg=st.integers(0, 40),
        maxlen=st.integers(0, 30), hashed=st.booleans(), corrupt=st.booleans(),
