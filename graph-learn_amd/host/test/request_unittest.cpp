@@ -1,0 +1,143 @@
+// Host-only behaviour of the request classes (no device): what the reference's
+// service/request/*.cc do before an operator ever runs -- filter parameters and
+// Filter::FillValues (sampling_request.cc:33-136, filter.cc:53-67), partitioning of a
+// request's tensors (hash_partitioner.h:33-92), RandomWalkRequest::IsDeepWalk
+// (random_walk_request.cc:152-160), Clone() of every request kind.
+#include <cstdlib>
+#include <vector>
+
+#include "glx.h"
+#include "graphlearn/graphlearn.h"
+#include "test_util.h"
+
+using namespace graphlearn;  // NOLINT
+
+TEST(RequestTest, FilterParametersAndValues) {
+  SamplingRequest plain("e", "RandomSampler", 3);
+  EXPECT_TRUE(!plain.HasFilter());
+  EXPECT_TRUE(plain.GetFilterValues() == nullptr);
+  int64_t ids[4] = {7, 8, 9, 10};
+  plain.Set(ids, 4);
+  int64_t v[4] = {1, 2, 3, 4};
+  plain.SetFilterValues(v, 4);  // no filter: ignored, like Filter::FillValues on an unspecified type
+  EXPECT_TRUE(plain.GetFilterValues() == nullptr);
+
+  // the reference's enum values (include/constants.h:135-145) are the C-ABI's
+  EXPECT_EQ((int)kEqual, GLX_FILTER_EQUAL);
+  EXPECT_EQ((int)kLargerThan, GLX_FILTER_LARGER_THAN);
+  EXPECT_EQ((int)kId, GLX_FILTER_FIELD_ID);
+  EXPECT_EQ((int)kTimestamp, GLX_FILTER_FIELD_TIMESTAMP);
+
+  SamplingRequest req("e", "TopkSampler", 2, kLargerThan, kTimestamp);
+  EXPECT_TRUE(req.HasFilter());
+  EXPECT_EQ(req.GetFilterType(), kLargerThan);
+  EXPECT_EQ(req.GetFilterField(), kTimestamp);
+  req.Set(ids, 4);
+  EXPECT_TRUE(req.GetFilterValues() == nullptr);  // not one value per src id yet
+  req.SetFilterValues(v, 2);
+  EXPECT_TRUE(req.GetFilterValues() == nullptr);
+  req.SetFilterValues(v + 2, 2);
+  EXPECT_TRUE(req.GetFilterValues() != nullptr);
+  for (int i = 0; i < 4; ++i) EXPECT_EQ(req.GetFilterValues()[i], v[i]);
+
+  // Clone keeps the filter kind (sampling_request.cc:68-72), not the data
+  OpRequest* c = req.Clone();
+  SamplingRequest* cs = static_cast<SamplingRequest*>(c);
+  EXPECT_TRUE(cs->HasFilter() && cs->GetFilterType() == kLargerThan && cs->GetFilterField() == kTimestamp);
+  EXPECT_EQ(cs->BatchSize(), 0);
+  delete c;
+}
+
+TEST(RequestTest, FillValuesExpandsByFanout) {
+  // DAG hand-over: 6 src ids that descend from 2 upstream ids -> every value covers 3 rows
+  SamplingRequest req("e", "RandomSampler", 2, kEqual, kId);
+  Tensor::Map tensors;
+  ADD_TENSOR(tensors, kSrcIds, kInt64, 6);
+  ADD_TENSOR(tensors, kFilterValues, kInt64, 2);
+  int64_t ids[6] = {1, 2, 3, 4, 5, 6}, values[2] = {100, 200};
+  tensors[kSrcIds].AddInt64(ids, ids + 6);
+  tensors[kFilterValues].AddInt64(values, values + 2);
+  req.Set(tensors);
+  EXPECT_EQ(req.BatchSize(), 6);
+  EXPECT_TRUE(req.GetFilterValues() != nullptr);
+  for (int i = 0; i < 6; ++i) EXPECT_EQ(req.GetFilterValues()[i], i < 3 ? 100 : 200);
+
+  // Init from a parameter map (DagNodeRunner path, sampling_request.cc:87-124)
+  Tensor::Map params;
+  ADD_TENSOR(params, kEdgeType, kString, 1);
+  params[kEdgeType].AddString("e");
+  ADD_TENSOR(params, kStrategy, kString, 1);
+  params[kStrategy].AddString("TopkSampler");
+  ADD_TENSOR(params, kNeighborCount, kInt32, 1);
+  params[kNeighborCount].AddInt32(5);
+  ADD_TENSOR(params, kFilterType, kInt32, 1);
+  params[kFilterType].AddInt32(kEqual);
+  ADD_TENSOR(params, kFilterField, kInt32, 1);
+  params[kFilterField].AddInt32(kId);
+  SamplingRequest from_params;
+  from_params.Init(params);
+  EXPECT_TRUE(from_params.HasFilter());
+  EXPECT_EQ(from_params.NeighborCount(), 5);
+  EXPECT_TRUE(from_params.Strategy() == "TopkSampler");
+  from_params.Set(tensors);
+  EXPECT_EQ(from_params.GetFilterValues()[5], 200);
+}
+
+TEST(RequestTest, PartitionCarriesFilterValues) {
+  SamplingRequest req("e", "EdgeWeightSampler", 4, kEqual, kId);
+  std::vector<int64_t> ids, values;
+  for (int i = 0; i < 50; ++i) {
+    ids.push_back(i * 3 - 20);
+    values.push_back(1000 + i);
+  }
+  req.Set(ids.data(), 50);
+  req.SetFilterValues(values.data(), 50);
+  req.SetCallCounter(77);
+  HashPartitioner partitioner(3);
+  ShardsPtr<OpRequest> parts = partitioner.Partition(&req);
+  int seen = 0;
+  for (int s = 0; s < 3; ++s) {
+    const SamplingRequest* p = static_cast<const SamplingRequest*>(parts->Get(s));
+    if (!p) continue;
+    EXPECT_TRUE(p->HasFilter() && p->HasCallCounter() && p->CallCounter() == 77);
+    EXPECT_TRUE(p->GetFilterValues() != nullptr && p->GetRngRows() != nullptr);
+    for (int32_t i = 0; i < p->BatchSize(); ++i) {
+      const int64_t row = p->GetRngRows()[i];
+      EXPECT_EQ(p->GetSrcIds()[i], ids[(size_t)row]);
+      EXPECT_EQ(p->GetFilterValues()[i], values[(size_t)row]);
+      EXPECT_EQ((int)(std::llabs(p->GetSrcIds()[i]) % 3), s);
+      ++seen;
+    }
+  }
+  EXPECT_EQ(seen, 50);
+}
+
+TEST(RequestTest, RandomWalkRequest) {
+  RandomWalkRequest deep("e", 1.0f, 1.0f, 5);
+  EXPECT_TRUE(deep.IsDeepWalk());
+  EXPECT_EQ(deep.WalkLen(), 5);
+  RandomWalkRequest nearly("e", 1.0f + 16 * 1.1920929e-07f, 1.0f, 5);
+  EXPECT_TRUE(nearly.IsDeepWalk());  // within 32 FLT_EPSILON
+  RandomWalkRequest biased("e", 0.5f, 1.0f, 5);
+  EXPECT_TRUE(!biased.IsDeepWalk());
+  RandomWalkRequest biased_q("e", 1.0f, 2.0f);
+  EXPECT_TRUE(!biased_q.IsDeepWalk());
+  EXPECT_EQ(biased_q.WalkLen(), 1);
+  int64_t ids[2] = {4, 5};
+  biased.Set(ids, 2);
+  biased.SetCallCounter(9);
+  OpRequest* c = biased.Clone();
+  RandomWalkRequest* cw = static_cast<RandomWalkRequest*>(c);
+  EXPECT_TRUE(cw->P() == 0.5f && cw->Q() == 1.0f && cw->WalkLen() == 5 && cw->CallCounter() == 9);
+  EXPECT_TRUE(cw->Type() == "e" && cw->Name() == "RandomWalk");
+  delete c;
+  // registered under the operator's name (op_request.h:138-152)
+  OpRequest* rq = RequestFactory::GetInstance()->NewRequest("RandomWalk");
+  OpResponse* rs = RequestFactory::GetInstance()->NewResponse("RandomWalk");
+  EXPECT_TRUE(rq != nullptr && rs != nullptr);
+  delete rq;
+  delete rs;
+  EXPECT_TRUE(op::OpFactory::GetInstance()->Create("RandomWalk") != nullptr);
+}
+
+int main() { return RunAllTests(); }

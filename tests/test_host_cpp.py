@@ -50,6 +50,13 @@ def test_loader_unittest_on_cpu(tmp_path):
     assert "4 test(s), 0 failure(s)" in r.stdout, r.stdout
 
 
+def test_request_unittest_on_cpu():
+    """Request classes, Filter::FillValues, partitioning of filter values, RandomWalkRequest: no device involved."""
+    r = run("request_unittest")
+    assert r.returncode == 0, r.stdout
+    assert "4 test(s), 0 failure(s)" in r.stdout, r.stdout
+
+
 def test_host_library_exports_registry():
     import subprocess as sp
     out = sp.run(["nm", "-DC", os.path.join(LIB, "libglx_host.so")], stdout=sp.PIPE, text=True).stdout
