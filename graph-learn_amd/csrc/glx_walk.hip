@@ -28,7 +28,7 @@ struct WalkArgs {
 };
 
 // One wave per walker.  LDS: parent's neighbour ids [F] i64 | weights [F] f32 | table [F] 8 B |
-// stack pairs [F] 8 B.
+// stack pairs [F] 8 B = 28 F bytes (F <= 2048 keeps it under the 64 KiB a launch may ask for).
 __global__ __launch_bounds__(64) void glx_node2vec_step_kernel(WalkArgs a) {
   extern __shared__ int64_t lds64[];
   const int32_t F = a.full_nbr_num;
@@ -118,7 +118,7 @@ extern "C" int glx_random_walk(const glx_graph* g, const int64_t* seeds, int32_t
   GLX_REQUIRE(seeds && walks_out, "NULL data pointer");
   // RandomWalkRequest::IsDeepWalk, random_walk_request.cc:152-160
   const bool deep = fabsf(p - 1.0f) < 32 * 1.1920929e-07f && fabsf(q - 1.0f) < 32 * 1.1920929e-07f;
-  GLX_REQUIRE(deep || (full_nbr_num >= 1 && full_nbr_num <= 4096), "DefaultFullNbrNum must be in [1, 4096], got %d",
+  GLX_REQUIRE(deep || (full_nbr_num >= 1 && full_nbr_num <= 2048), "DefaultFullNbrNum must be in [1, 2048], got %d",
               full_nbr_num);
   GlxDeviceGuard guard(g->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);

@@ -265,7 +265,7 @@ GLX_API int glx_sample_full_filtered(const glx_graph* g, const int64_t* src, int
  * walks_out[batch * walk_len], row i = the walk_len vertices visited from seeds[i] (the
  * response layout, :121-127).  A vertex without out-edges yields default_neighbor_id, and
  * the walk goes on from THAT id, like the reference.  node2vec looks at the first
- * min(deg, full_nbr_num) neighbours only (GLOBAL_FLAG(DefaultFullNbrNum), <= 4096 here),
+ * min(deg, full_nbr_num) neighbours only (GLOBAL_FLAG(DefaultFullNbrNum), <= 2048 here),
  * weighs an edge by 1/(p + 1e-6) when it returns to the parent, by 1 when it leads to one of
  * the parent's first full_nbr_num neighbours, by 1/(q + 1e-6) otherwise, and draws once from
  * the alias table of those weights; the first step's parent is the seed itself, without
