@@ -174,3 +174,53 @@ def test_negative_sampling_properties_full_size(c3):
     spos = torch.searchsorted(edge_keys, skeys).clamp(max=E - 1)
     soft_leaks = int((edge_keys[spos] == skeys).sum())
     assert leaks * 20 < max(soft_leaks, 1), (leaks, soft_leaks)  # strict removes (almost) all of them
+
+
+def test_filtered_sampling_properties_full_size(c3):
+    """op::Filter at full size (id == value with the value = the seed's first neighbour, i.e. GSL's .filter()):
+    the filtered id never comes back (RandomSampler: only through exhausted retries, none with a budget of 60),
+    every answer is still a real out-edge, rows whose neighbours all hit are default-filled, without-replacement
+    rows stay duplicate-free, and Topk is the unfiltered row with the hits taken out in ActOn's order (checked on
+    the rows that have no hit among their first K1 + 1 slots, where that order is the identity)."""
+    c = c3
+    seeds = c["seeds"]
+    g = c["g"]
+    first, _ = g.sample("TopkSampler", seeds, 1)
+    values = first.view(-1).contiguous()
+    deg = c["deg"][seeds]
+    start = c["row_ptr"][seeds]
+    for name in ("RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"):
+        nbr, eid = g.sample_filtered(name, seeds, K1, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, values, seed=5, call_counter=2,
+                                     retry_times=60)
+        torch.cuda.synchronize()
+        real = eid >= 0
+        slot = c["slot_of_eid"][eid.clamp(min=0)]
+        srcx = seeds.view(-1, 1).expand(-1, K1)
+        assert bool(((slot >= c["row_ptr"][srcx]) & (slot < c["row_ptr"][srcx + 1]))[real].all()), name
+        assert bool((c["col"][slot] == nbr)[real].all()), name
+        assert bool((nbr[real] != values.view(-1, 1).expand(-1, K1)[real]).all()), name  # the filtered id is gone
+        assert bool((nbr[~real] == 0).all())
+        # a row is default-filled exactly when it has no neighbour other than the filtered id
+        survivors = torch.zeros_like(deg)
+        has = deg > 0
+        # count neighbours != value over the rows (segment sum over each row's slots)
+        rows_idx = torch.repeat_interleave(torch.arange(seeds.shape[0], device=c["dev"])[has], deg[has])
+        offs = torch.arange(int(deg[has].sum()), device=c["dev"]) - torch.repeat_interleave(
+            torch.cumsum(deg[has], 0) - deg[has], deg[has])
+        col = c["col"][torch.repeat_interleave(start[has], deg[has]) + offs]
+        survivors.index_add_(0, rows_idx, (col != values[rows_idx]).to(survivors.dtype))
+        assert bool((real.all(dim=1) == (survivors > 0)).all()), name
+        assert bool((real.any(dim=1) == real.all(dim=1)).all()), name
+        if name == "RandomWithoutReplacementSampler":
+            m = torch.minimum(survivors, torch.full_like(survivors, K1))
+            srt, _ = torch.sort(torch.where(real, eid, -1 - torch.arange(K1, device=c["dev"]).view(1, -1).expand_as(eid)), dim=1)
+            distinct = (srt[:, 1:] != srt[:, :-1]).sum(dim=1) + 1
+            assert bool((distinct[survivors > 0] == m[survivors > 0]).all())
+        if name == "TopkSampler":
+            plain, _ = g.sample("TopkSampler", seeds, K1 + 1)
+            hit_free_tail = (plain[:, 1:] != values.view(-1, 1)).all(dim=1) & (deg > K1 + 1) & (survivors == deg - 1)
+            # one hit, at slot 0: the hole is refilled with the row's LAST neighbour (filter.cc:83-94)
+            last = c["col"][start + deg - 1]
+            sel = hit_free_tail
+            assert bool((nbr[sel][:, 0] == last[sel]).all()) and bool((nbr[sel][:, 1:] == plain[sel][:, 1:K1]).all())
+            assert int(sel.sum()) > 100
