@@ -224,3 +224,37 @@ def test_filtered_sampling_properties_full_size(c3):
             sel = hit_free_tail
             assert bool((nbr[sel][:, 0] == last[sel]).all()) and bool((nbr[sel][:, 1:] == plain[sel][:, 1:K1]).all())
             assert int(sel.sum()) > 100
+
+
+def test_random_walk_properties_full_size(c3):
+    """RandomWalk at full size: a DeepWalk is the chain of neighbor_count-1 RandomSampler draws; every node2vec step
+    lands on one of the first DefaultFullNbrNum neighbours of where it stood (or on the default id at a dead end).
+    (The RMAT graph is directed and has hardly any reciprocal edges, so the return bias of p is checked on the small
+    graphs of test_gpu_walk.py instead.)"""
+    c = c3
+    g, seeds, dev = c["g"], c["seeds"], c["dev"]
+    L, F = 5, 100
+    deep = g.random_walk(seeds, L, seed=9, call_counter=4, default_neighbor_id=0)
+    cur = seeds
+    for t in range(L):
+        nbr, _ = g.sample("RandomSampler", cur, 1, seed=9, call_counter=4 + t)
+        assert bool((deep[:, t] == nbr[:, 0]).all())
+        cur = nbr[:, 0].contiguous()
+
+    def walk(p, q):
+        w = g.random_walk(seeds, L, p=p, q=q, full_nbr_num=F, seed=9, call_counter=4, default_neighbor_id=0)
+        torch.cuda.synchronize()
+        prev = seeds
+        for t in range(L):
+            nxt = w[:, t]
+            d = torch.clamp(c["deg"][prev], max=F)
+            j = torch.arange(F, device=dev).view(1, -1)
+            slot = (c["row_ptr"][prev].view(-1, 1) + j).clamp(max=E - 1)
+            among = ((c["col"][slot] == nxt.view(-1, 1)) & (j < d.view(-1, 1))).any(dim=1)
+            assert bool((among | ((d == 0) & (nxt == 0))).all()), (p, q, t)
+            prev = nxt
+        return w
+    for p, q in ((0.05, 1.0), (20.0, 0.25)):
+        w = walk(p, q)
+        assert w.shape == (B0, L)
+    assert not bool((walk(0.05, 1.0) == walk(20.0, 0.25)).all())
