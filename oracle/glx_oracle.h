@@ -11,7 +11,9 @@
  * reference's own sources) and against the reference's known-answer tests
  * (tests/golden/); the random samplers are checked distributionally against
  * the reference because the reference itself is unseeded
- * (random_sampler.cc:46-47).
+ * (random_sampler.cc:46-47); so are the filtered samplers and the RandomWalk
+ * operator (tests/golden/filtered.npz, walk.npz: the reference's own filter.cc /
+ * random_walk.cc built into oracle/_ref).
  */
 #ifndef GLX_ORACLE_H_
 #define GLX_ORACLE_H_

@@ -34,6 +34,7 @@
 #include "include/aggregating_request.h"
 #include "include/config.h"
 #include "include/index_option.h"
+#include "include/random_walk_request.h"
 #include "include/sampling_request.h"
 
 namespace std {
@@ -391,6 +392,32 @@ int64_t glref_sample_filtered(void* h, const char* edge_type, const char* strate
       eid_out[i] = res.GetEdgeIds()[i];
     }
     rc = total;
+  });
+  return rc;
+}
+
+// The reference's RandomWalk operator (core/operator/random_walk/random_walk.cc) on a request
+// built the way the DAG runner builds it -- RandomWalkRequest::Set(tensors), which makes every
+// src id its own parent without neighbours (random_walk_request.cc:120-131).  core/runner's
+// OpRunner is stubbed to Operator::Process (ref_shim/stubs/core/runner/op_runner.h).
+// walks_out[batch * walk_len]; returns 0 or the reference's error code (-1: unknown op).
+int glref_random_walk(void* h, const char* edge_type, const int64_t* src, int32_t batch, int32_t walk_len,
+                      float p, float q, int32_t full_nbr_num, int64_t* walks_out, int fresh_thread) {
+  (void)h;
+  int rc = 0;
+  SetGlobalFlagDefaultFullNbrNum(full_nbr_num);
+  RunMaybeFresh(fresh_thread, [&]() {
+    RandomWalkRequest req(edge_type, p, q, walk_len);
+    RandomWalkResponse res;
+    Tensor::Map tensors;
+    ADD_TENSOR(tensors, kSrcIds, kInt64, batch);
+    tensors[kSrcIds].AddInt64(src, src + batch);
+    req.Set(tensors);
+    op::Operator* op = op::OpFactory::GetInstance()->Create("RandomWalk");
+    if (!op) { rc = -1; return; }
+    Status s = op->Process(&req, &res);
+    if (!s.ok()) { rc = static_cast<int>(s.code()); return; }
+    memcpy(walks_out, res.GetWalks(), sizeof(int64_t) * static_cast<size_t>(batch) * walk_len);
   });
   return rc;
 }

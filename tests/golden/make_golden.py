@@ -529,6 +529,42 @@ def gen_filtered(ref):
     np.savez_compressed(os.path.join(HERE, "filtered.npz"), **out)
 
 
+def gen_walk(ref):
+    """The reference's RandomWalk operator (random_walk.cc) on a weighted graph without dead ends: node2vec
+    walks of length 3 from one seed, 40000 walkers per (p, q): histograms of the first step and of the
+    (step 1, step 2) and (step 2, step 3) pairs.  Also a run with DefaultFullNbrNum = 3."""
+    rng = np.random.default_rng(77)
+    V = 14
+    src, dst = [], []
+    for v in range(V):
+        for d in rng.choice(V, int(rng.integers(3, 9)), replace=False):
+            src.append(v)
+            dst.append(int(d))
+    src, dst = np.array(src, np.int64), np.array(dst, np.int64)
+    w = (rng.random(src.shape[0]) + 0.05).astype(np.float32)
+    ref.add_edges("walk", src, dst, w)
+    rows = first_appearance(src)
+    rp, col, eid, ws = ref.export_csr("walk", rows, 16)
+    out = dict(src=src, dst=dst, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws)
+    T = 40000
+    ref.set_flags(1, 0, 0.0)
+    ref.set_seed(2024)
+    cases = []
+    for p, q, F in ((0.5, 2.0, 100), (4.0, 0.25, 100), (0.5, 2.0, 3), (1.0, 1.0, 100)):
+        walks = ref.random_walk("walk", np.full(T, 5, np.int64), 3, p, q, F)
+        name = "p%g_q%g_F%d" % (p, q, F)
+        h1 = np.bincount(walks[:, 0], minlength=V)
+        h12 = np.zeros((V, V), np.int64)
+        h23 = np.zeros((V, V), np.int64)
+        np.add.at(h12, (walks[:, 0], walks[:, 1]), 1)
+        np.add.at(h23, (walks[:, 1], walks[:, 2]), 1)
+        out[name + "_h1"], out[name + "_h12"], out[name + "_h23"] = h1, h12, h23
+        cases.append(name)
+    out["cases"] = np.array(cases)
+    out["T"] = np.array(T)
+    np.savez_compressed(os.path.join(HERE, "walk.npz"), **out)
+
+
 def main():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -542,6 +578,7 @@ def main():
     gen_negative(ref)
     gen_timestamped(ref)
     gen_filtered(ref)
+    gen_walk(ref)
     # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()
     print("golden fixtures written to", HERE)

@@ -300,6 +300,7 @@ class RefLib:
         L.glref_sample_full.restype = i64
         L.glref_in_degree.argtypes = [VP, cs, i64]
         L.glref_in_degree.restype = i32
+        L.glref_random_walk.argtypes = [VP, cs, VP, i32, i32, ctypes.c_float, ctypes.c_float, i32, VP, ctypes.c_int]
         L.glref_sample_filtered.argtypes = [VP, cs, cs, VP, i32, i32, ctypes.c_int, ctypes.c_int, VP, i32, i32, VP, VP,
                                             VP, i64, ctypes.c_int]
         L.glref_sample_filtered.restype = i64
@@ -390,6 +391,13 @@ class RefLib:
                                              None, _p(nbr), _p(eid), batch * k, 1 if fresh_thread else 0)
         assert total == batch * k, total
         return nbr, eid
+
+    def random_walk(self, etype, src, walk_len, p, q, full_nbr_num=100, fresh_thread=True):
+        walks = np.zeros((src.shape[0], walk_len), np.int64)
+        rc = self.L.glref_random_walk(self.h, etype.encode(), _p(src), src.shape[0], walk_len, p, q, full_nbr_num,
+                                      _p(walks), 1 if fresh_thread else 0)
+        assert rc == 0, rc
+        return walks
 
     def in_degree(self, etype, ids):
         return np.array([self.L.glref_in_degree(self.h, etype.encode(), int(v)) for v in ids], np.int32)

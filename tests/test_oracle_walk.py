@@ -109,3 +109,67 @@ def test_deepwalk_and_dead_ends():
     # node2vec from a stuck vertex: default id as well
     w2 = orc.random_walk(g, np.array([5], np.int64), 2, np.float32(2.0), np.float32(0.5), default_neighbor_id=-1, seed=2)
     assert w2.tolist() == [[-1, -1]]
+
+
+# ------------------------------------------------- against the reference's own operator ---
+import os  # noqa: E402
+
+import pytest  # noqa: E402
+
+from oracle_bindings import RefLib, have_ref  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "walk.npz")
+
+
+def _two_sample_p(a, b):
+    a = np.asarray(a, np.float64).reshape(-1)
+    b = np.asarray(b, np.float64).reshape(-1)
+    keep = (a + b) > 0
+    return 1.0 if keep.sum() < 2 else stats.chi2_contingency(np.stack([a[keep], b[keep]]))[1]
+
+
+def _walk_stats(walks, V):
+    h1 = np.bincount(walks[:, 0], minlength=V)
+    h12 = np.zeros((V, V), np.int64)
+    h23 = np.zeros((V, V), np.int64)
+    np.add.at(h12, (walks[:, 0], walks[:, 1]), 1)
+    np.add.at(h23, (walks[:, 1], walks[:, 2]), 1)
+    return h1, h12, h23
+
+
+def test_walks_match_the_reference_operator_distribution():
+    """tests/golden/walk.npz holds 40000 three-step walks per (p, q, DefaultFullNbrNum) of the reference's OWN
+    RandomWalk operator (oracle/_ref: random_walk.cc + random_walk_request.cc compiled where they lie).  The
+    restatement must produce the same first-step, (step 1, step 2) and (step 2, step 3) frequencies: that pins the
+    1/p, 1, 1/q weighting, the self-parent first step, the neighbour cap and the single alias draw end to end."""
+    g = dict(np.load(GOLD))
+    og = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"])
+    T, V = int(g["T"]), 14
+    for name in g["cases"]:
+        name = str(name)
+        p, q, F = float(name.split("_")[0][1:]), float(name.split("_")[1][1:]), int(name.split("_F")[1])
+        walks = orc.random_walk(og, np.full(T, 5, np.int64), 3, np.float32(p), np.float32(q), full_nbr_num=F, seed=31,
+                                call_counter=6)
+        for got, want, what in zip(_walk_stats(walks, V), (g[name + "_h1"], g[name + "_h12"], g[name + "_h23"]),
+                                   ("step 1", "steps 1-2", "steps 2-3")):
+            assert ((got > 0) == (want > 0)).all() or _two_sample_p(got, want) > 1e-4, (name, what)  # same support ...
+            assert _two_sample_p(got, want) > 1e-4, (name, what, got, want)                          # ... same law
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_walks_live_against_the_reference_operator():
+    g = dict(np.load(GOLD))
+    og = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"])
+    ref = RefLib()
+    try:
+        ref.add_edges("walk", g["src"], g["dst"], g["w"])
+        ref.set_seed(99)
+        T = 30000
+        for start, p, q, F in ((2, 0.25, 1.0, 100), (9, 1.0, 3.0, 4)):
+            seeds = np.full(T, start, np.int64)
+            a = _walk_stats(ref.random_walk("walk", seeds, 3, p, q, F), 14)
+            b = _walk_stats(orc.random_walk(og, seeds, 3, np.float32(p), np.float32(q), full_nbr_num=F, seed=1), 14)
+            for x, y in zip(a, b):
+                assert _two_sample_p(x, y) > 1e-4, (start, p, q, F)
+    finally:
+        ref.close()
