@@ -55,12 +55,15 @@ public:
 private:
   Server();
   friend Server* NewServer(int32_t, int32_t, const std::string&, const std::string&);
+  int32_t shard_index_ = 0, shard_count_ = 1;
   GraphStore* store_;
   Status status_;
   bool bound_;  // the process-wide OpFactory currently serves THIS server's store
 };
 
-// Only (server_id 0, server_count 1) exists in local mode; host/tracker are ignored.
+// server_count > 1: this process holds shard server_id of server_count (GraphStore::SetShard): one
+// process per GPU, all reading the same sources; requests are routed between the processes by
+// the RCCL layer (graph-learn_amd/dist.py), not by this class.  host/tracker are ignored.
 Server* NewServer(int32_t server_id, int32_t server_count, const std::string& server_host,
                   const std::string& tracker);
 

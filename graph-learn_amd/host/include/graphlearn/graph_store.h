@@ -225,8 +225,22 @@ public:
   // data_source.h's terms, defined in loader.cc.
   template <class EdgeSources, class NodeSources>
   Status Load(const EdgeSources& edges, const NodeSources& nodes);
+  // One process per GPU, every process reads the same sources: shard `index` of `count` keeps
+  // the edges whose source id -- and the nodes whose id -- hash to it, llabs(id) % count, the
+  // rule HashPartitioner routes requests by (hash_partitioner.h:88-90); this is where the
+  // reference's servers end up after Initializer has exchanged the records they read.  Edge
+  // ids are positions in the shard's own load order, i.e. server-local like the reference's.
+  // Set before loading; the default (0, 1) keeps everything.
+  void SetShard(int32_t index, int32_t count);
+  int32_t ShardIndex() const { return shard_index_; }
+  int32_t ShardCount() const { return shard_count_; }
+  bool Owns(int64_t id) const {
+    return shard_count_ <= 1 || (int32_t)((id < 0 ? -(uint64_t)id : (uint64_t)id) % (uint64_t)shard_count_) == shard_index_;
+  }
 
 private:
+  int32_t shard_index_ = 0;
+  int32_t shard_count_ = 1;
   uint64_t uid_;
   std::mutex mtx_;
   std::unordered_map<std::string, Graph*> graphs_;

@@ -48,7 +48,10 @@ Server::Server() : store_(nullptr), bound_(false) {}
 Server::~Server() { Stop(); }
 
 void Server::Start() {
-  if (!store_) store_ = new GraphStore();
+  if (!store_) {
+    store_ = new GraphStore();
+    store_->SetShard(shard_index_, shard_count_);
+  }
 }
 
 void Server::Init(const std::vector<io::EdgeSource>& edges, const std::vector<io::NodeSource>& nodes) {
@@ -97,6 +100,11 @@ void Server::Stop() {
   }
 }
 
-Server* NewServer(int32_t, int32_t, const std::string&, const std::string&) { return new Server(); }
+Server* NewServer(int32_t server_id, int32_t server_count, const std::string&, const std::string&) {
+  Server* s = new Server();
+  s->shard_index_ = server_id;
+  s->shard_count_ = server_count;
+  return s;
+}
 
 }  // namespace graphlearn

@@ -269,6 +269,11 @@ std::atomic<uint64_t> g_next_store_uid{1};
 
 GraphStore::GraphStore() : uid_(g_next_store_uid.fetch_add(1)) {}
 
+void GraphStore::SetShard(int32_t index, int32_t count) {
+  shard_count_ = count < 1 ? 1 : count;
+  shard_index_ = (index < 0 || index >= shard_count_) ? 0 : index;
+}
+
 GraphStore::~GraphStore() {
   for (auto& it : graphs_) delete it.second;
   for (auto& it : noders_) delete it.second;

@@ -448,6 +448,7 @@ Status LoadEdges(const EdgeSource& source, GraphStore* store) {
     if (ok && source.IsTimestamped()) ok = FieldInt64(fld, c++, &ts);
     Status bad;
     if (!ok) bad = error::InvalidArgument("Invalid edge record in " + source.path);
+    else if (!store->Owns(reversed ? dst : src)) return error::OUT_OF_RANGE;  // another shard's edge: read on
     else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
     if (!bad.ok()) {
       if (skip_bad) return error::OUT_OF_RANGE;  // edge_loader.cc:70-78: ignore the record, read on
@@ -510,6 +511,7 @@ Status LoadNodes(const NodeSource& source, GraphStore* store) {
     if (ok && source.IsTimestamped()) ok = FieldInt64(fld, c++, &ts);
     Status bad;
     if (!ok) bad = error::InvalidArgument("Invalid node record in " + source.path);
+    else if (!store->Owns(id)) return error::OUT_OF_RANGE;  // another shard's node: read on
     else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
     if (!bad.ok()) {
       if (skip_bad) return error::OUT_OF_RANGE;

@@ -181,6 +181,55 @@ TEST(NodeLoaderTest, EveryColumnCombinationAndDirectories) {
   ::rmdir("glx_labeled_nfiles");
 }
 
+TEST(LoaderTest, ShardsKeepWhatHashesToThem) {
+  // One process per GPU, all reading the same files: shard r of P keeps the edges whose source id and the nodes
+  // whose id satisfy llabs(id) % P == r (HashPartitioner's rule, hash_partitioner.h:88-90); edge ids are the
+  // shard's own load order.  The shards are disjoint and together hold every record.
+  const int32_t format = kWeighted | kLabeled | kAttributed;
+  GenFile("glx_shard_efile", true, format);
+  GenFile("glx_shard_nfile", false, format);
+  {  // a negative id lands on llabs(id) % P
+    std::ofstream extra("glx_shard_efile", std::ios::app);
+    extra << "-7\t3\t1.500000\t9\t9:9.000000:J\n";
+  }
+  int64_t edges_seen = 0, nodes_seen = 0;
+  for (int32_t r = 0; r < 3; ++r) {
+    GraphStore store;
+    store.SetShard(r, 3);
+    EXPECT_EQ(store.ShardIndex(), r);
+    EXPECT_EQ(store.ShardCount(), 3);
+    EXPECT_TRUE(LoadEdges(EdgeSrc("glx_shard_efile", format, "click", "user", "item"), &store).ok());
+    EXPECT_TRUE(LoadNodes(NodeSrc("glx_shard_nfile", format, "user"), &store).ok());
+    Graph* g = store.GetGraph("click");
+    Noder* n = store.GetNoder("user");
+    int64_t e = 0;
+    for (int64_t i = 0; i < 100; ++i) {
+      if (i % 3 != r) {
+        EXPECT_TRUE(n->RowOf(i) < 0);
+        continue;
+      }
+      CheckNodes(n, format, i, i + 1);
+      CheckEdges(g, format, i, i + 1, e);  // the shard's e-th edge is record i
+      ++e;
+    }
+    if (r == 7 % 3) {
+      EXPECT_EQ(g->GetSrcId(e), (int64_t)-7);
+      EXPECT_EQ(g->GetDstId(e), (int64_t)3);
+      ++e;
+    }
+    EXPECT_EQ(g->GetEdgeCount(), e);
+    edges_seen += g->GetEdgeCount();
+    nodes_seen += n->GetNodeCount();
+  }
+  EXPECT_EQ(edges_seen, (int64_t)101);
+  EXPECT_EQ(nodes_seen, (int64_t)100);
+  GraphStore whole;  // the default keeps everything
+  EXPECT_TRUE(LoadEdges(EdgeSrc("glx_shard_efile", format, "click", "user", "item"), &whole).ok());
+  EXPECT_EQ(whole.GetGraph("click")->GetEdgeCount(), (int64_t)101);
+  std::remove("glx_shard_efile");
+  std::remove("glx_shard_nfile");
+}
+
 TEST(LoaderTest, RejectsWhatTheReferenceRejects) {
   GenFile("glx_bad_schema", true, kWeighted);
   GraphStore store;

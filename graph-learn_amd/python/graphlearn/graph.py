@@ -110,17 +110,50 @@ class Graph(object):
     return self
 
   def init(self, task_index=0, task_count=1, cluster="", job_name="", **kwargs):
-    """Load + build on this process' GPU.  `tracker=` is accepted and ignored."""
-    if cluster or task_count != 1 or kwargs.get("hosts") is not None:
+    """Load + build on this process' GPU.  `tracker=` is accepted and ignored.
+
+    task_count > 1 is the SPMD mode of this engine: one process per GPU (torchrun), every process
+    reads the same sources and keeps shard `task_index` -- the edges whose source id, and the nodes
+    whose id, satisfy llabs(id) % task_count == task_index, the rule the reference routes requests by
+    (hash_partitioner.h:88-90).  Samplers of this object then see the shard only; `sharded_store()`
+    gives the view over ALL shards (requests exchanged between the GPUs over RCCL)."""
+    if cluster or kwargs.get("hosts") is not None:
       raise NotImplementedError(
-          "only the local deploy mode is served by this engine; multi-GPU execution is one process per GPU "
-          "over RCCL (graph-learn_amd/dist.py), not the reference's client/server RPC")
+          "the reference's client/server RPC deploy mode is not served by this engine; multi-GPU execution is one "
+          "process per GPU: init(task_index=rank, task_count=world_size) + sharded_store()")
+    task_index, task_count = int(task_index), int(task_count)
+    if task_count < 1 or not 0 <= task_index < task_count:
+      raise ValueError("task_index {} is not in [0, task_count {})".format(task_index, task_count))
+    self._shard = (task_index, task_count)
     self._client = pywrap.in_memory_client()
-    self._server = pywrap.server(0, 1, "", "")
+    self._server = pywrap.server(task_index, task_count, "", "")
     self._server.start()
     self._server.init(self._edge_sources, self._node_sources)
     errors.raise_exception_on_not_ok_status(self._server.init_status())
     return self
+
+  def sharded_store(self, edge_type, node_type=None, group=None, replicate_features=False):
+    """The edge type (and optionally a node type's float attributes) across all shards of an
+    init(task_index, task_count) job, as a dist.ShardedStore: `store.sample(sampler, cuda_ids, k, ...)`
+    and `store.aggregate(op, node_ids, segment_ids, num_segments)` are collective calls -- every rank
+    passes its own batch, rows are routed to their owners by llabs(id) % world over RCCL all-to-all
+    (HashPartitioner / Stitcher on the device) and the answers equal a single store's, draw for draw.
+    Needs an initialised torch.distributed process group whose size is task_count.
+    replicate_features=True all-gathers the feature shards once so that aggregation needs no exchange."""
+    import torch.distributed as torch_dist
+    import dist as glx_dist
+    if not torch_dist.is_initialized():
+      raise RuntimeError("sharded_store needs torch.distributed.init_process_group (backend 'nccl' = RCCL)")
+    world = torch_dist.get_world_size(group)
+    shard = getattr(self, "_shard", (0, 1))
+    if (torch_dist.get_rank(group), world) != shard:
+      raise ValueError("the process group says rank {} of {}, the graph was initialised as shard {} of {}".format(
+          torch_dist.get_rank(group), world, shard[0], shard[1]))
+    feats = self.device_features(node_type) if node_type is not None else None
+    replica = None
+    if feats is not None and replicate_features:
+      raise NotImplementedError("replicate_features needs dense node ids; use graph-learn_amd/dist.py directly")
+    return glx_dist.ShardedStore(glx_dist.DeviceOps(), self.device_graph(edge_type), feats, group, replica)
 
   def close(self):
     if self._client is not None:

@@ -1,0 +1,85 @@
+"""SPMD mode of the Python API, run under torch.distributed.run: every rank loads ITS shard of the same TSV
+sources (Graph.init(task_index, task_count)), the ranks answer each other's sampling / aggregation requests
+through Graph.sharded_store(), and every rank checks its answers against an unsharded load of the same files.
+Prints one line `spmd ok rank R` per rank.
+
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 scripts/spmd_pyapi_check.py DIR [--share-device]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as td  # noqa: E402
+import graphlearn as gl  # noqa: E402
+
+data_dir = sys.argv[1]
+share = "--share-device" in sys.argv
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+local = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
+td.init_process_group(backend="gloo" if share else "nccl")
+torch.cuda.set_device(local)
+gl.set_device_id(local)
+gl.set_padding_mode(gl.CIRCULAR)
+gl.set_default_neighbor_id(-1)
+gl.set_sampling_seed(77)
+
+edges, nodes = os.path.join(data_dir, "edges"), os.path.join(data_dir, "nodes")
+if rank == 0:
+    rng = np.random.default_rng(3)
+    V, E = 400, 6000
+    src = rng.integers(0, V, E) * 3 - 200  # sparse ids, some negative
+    dst = rng.integers(0, V, E) * 3 - 200
+    with open(edges, "w") as f:
+        f.write("src_id:int64\tdst_id:int64\tweight:float\n")
+        for s, d, w in zip(src, dst, rng.random(E) + 0.01):
+            f.write("%d\t%d\t%.6f\n" % (s, d, w))
+    with open(nodes, "w") as f:
+        f.write("id:int64\tattribute:string\n")
+        for v in range(V):
+            f.write("%d\t%s\n" % (v * 3 - 200, ":".join("%.3f" % x for x in rng.standard_normal(8))))
+td.barrier()
+
+
+def build(**kw):
+    return gl.Graph().node(nodes, "n", gl.Decoder(attr_types=["float"] * 8)) \
+        .edge(edges, ("n", "n", "e"), gl.Decoder(weighted=True)).init(**kw)
+
+
+whole = build()
+whole_graph, whole_feats = whole.device_graph("e"), whole.device_features("n")
+shard = build(task_index=rank, task_count=world)
+store = shard.sharded_store("e", "n")
+dev = torch.device("cuda", local)
+
+# every rank holds its part, and the parts add up
+mine = torch.tensor([shard.device_graph("e").num_edges], dtype=torch.int64)
+td.all_reduce(mine)
+assert int(mine) == whole_graph.num_edges, (int(mine), whole_graph.num_edges)
+assert shard.device_graph("e").num_edges < whole_graph.num_edges
+
+gen = np.random.default_rng(100 + rank)  # every rank asks for its own batch
+for trial, name in enumerate(["TopkSampler", "EdgeWeightSampler", "RandomSampler", "RandomWithoutReplacementSampler"]):
+    ids = torch.from_numpy(np.concatenate([gen.integers(0, 400, 300) * 3 - 200, [5, 10 ** 6]])).to(dev)
+    nbr, _ = store.sample(name, ids, 6, seed=77, call_counter=10 + trial, default_neighbor_id=-1)
+    want, _ = whole_graph.sample(name, ids, 6, seed=77, call_counter=10 + trial, default_neighbor_id=-1)
+    assert torch.equal(nbr, want), (rank, name)
+    seg = torch.arange(ids.shape[0], device=dev, dtype=torch.int32).repeat_interleave(6)
+    for op in ("MaxAggregator", "SumAggregator"):
+        emb, cnt = store.aggregate(op, nbr.reshape(-1), seg, ids.shape[0])
+        wemb, wcnt = whole_feats.aggregate(op, nbr.reshape(-1).contiguous(), seg, ids.shape[0])
+        assert torch.equal(cnt, wcnt), (rank, name, op)
+        if op == "MaxAggregator":
+            assert torch.equal(emb, wemb), (rank, name, op)
+        else:
+            assert torch.allclose(emb, wemb, rtol=1e-5, atol=1e-5), (rank, name, op)
+torch.cuda.synchronize()
+td.barrier()
+shard.close()
+whole.close()
+print("spmd ok rank %d" % rank, flush=True)
+td.destroy_process_group()

@@ -65,3 +65,14 @@ def test_bench_c5_hetero_two_ranks_on_one_gpu():
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["verified_sharded_equals_unpartitioned"] is True and res["value"] > 0
+
+
+def test_python_api_spmd_mode_two_ranks_on_one_gpu(tmp_path):
+    """Graph.init(task_index, task_count) + Graph.sharded_store(): two ranks load their shards of the same TSV
+    files and serve each other's requests; every rank's answers equal an unsharded load's (scripts/spmd_pyapi_check.py)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "scripts", "spmd_pyapi_check.py"),
+           str(tmp_path), "--share-device"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "spmd ok rank 0" in r.stdout and "spmd ok rank 1" in r.stdout, r.stdout
