@@ -144,8 +144,16 @@ def test_python_api_fails_loudly_without_gpu(tmp_path):
     g.close()
 
 
-def test_distributed_modes_are_not_served():
-    with pytest.raises(NotImplementedError):
-        gl.Graph().init(task_count=2)
+def test_deploy_modes():
+    """The reference's client/server RPC deploy mode is not served; init(task_index, task_count) is the SPMD mode
+    (one process per GPU, every process keeps its shard of the sources)."""
     with pytest.raises(NotImplementedError):
         gl.Graph().init(cluster={"server_count": 1, "client_count": 1})
+    with pytest.raises(NotImplementedError):
+        gl.Graph().init(hosts="127.0.0.1:8888")
+    with pytest.raises(ValueError):
+        gl.Graph().init(task_index=2, task_count=2)
+    g = gl.Graph().init(task_index=1, task_count=2)  # nothing to load: no device needed
+    with pytest.raises(RuntimeError):
+        g.sharded_store("e")  # no torch.distributed process group
+    g.close()
