@@ -50,6 +50,12 @@ class DeviceOps:
         return graph.sample(sampler, ids, k, seed=seed, call_counter=cc, padding_mode=pad,
                             default_neighbor_id=dflt, rng_rows=rng_rows)
 
+    def sample_filtered(self, graph, sampler, ids, rng_rows, k, seed, cc, pad, dflt, ftype, ffield, values, retry,
+                        default_ts):
+        return graph.sample_filtered(sampler, ids, k, ftype, ffield, values, seed=seed, call_counter=cc,
+                                     padding_mode=pad, default_neighbor_id=dflt, retry_times=retry,
+                                     default_timestamp=default_ts, rng_rows=rng_rows)
+
     def lookup(self, feats, ids, default_attr):
         return feats.lookup(ids, default_attr)
 
@@ -155,6 +161,24 @@ class ShardedStore:
         rows_in = _a2a(order, send, recv, self.group, most)  # original row index = random stream
         nbr, eid = self.ops.sample(self.graph, sampler, ids_in, rows_in, k, seed, call_counter,
                                    padding_mode, default_neighbor_id)
+        nbr = _a2a(nbr, recv, send, self.group, most)
+        eid = _a2a(eid, recv, send, self.group, most)
+        return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
+
+    def sample_filtered(self, sampler, src, k, filter_type, filter_field, values, seed=0, call_counter=0,
+                        padding_mode=1, default_neighbor_id=0, retry_times=5, default_timestamp=-1):
+        """sample() for a request with an op::Filter: every row's filter value travels with its id (as
+        HashPartitioner copies every tensor of a request, hash_partitioner.h:69-74).  Id filters and
+        timestamp == value give the single-store answer draw for draw.  timestamp > value does not: the
+        reference's ActOn reads the value of the FIRST row of whatever request a server sees
+        (filter.h:107-111), so each shard uses its own part's first value -- as the reference's servers do."""
+        bucketed, order, send, recv, most = self._route(src)
+        ids_in = _a2a(bucketed, send, recv, self.group, most)
+        rows_in = _a2a(order, send, recv, self.group, most)
+        vals_in = _a2a(values[order].contiguous(), send, recv, self.group, most)
+        nbr, eid = self.ops.sample_filtered(self.graph, sampler, ids_in, rows_in, k, seed, call_counter, padding_mode,
+                                            default_neighbor_id, filter_type, filter_field, vals_in, retry_times,
+                                            default_timestamp)
         nbr = _a2a(nbr, recv, send, self.group, most)
         eid = _a2a(eid, recv, send, self.group, most)
         return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)

@@ -45,6 +45,13 @@ class OracleOps:
                              default_neighbor_id=dflt, rng_rows=rng_rows.numpy())
         return torch.from_numpy(n), torch.from_numpy(e)
 
+    def sample_filtered(self, graph, sampler, ids, rng_rows, k, seed, cc, pad, dflt, ftype, ffield, values, retry,
+                        default_ts):
+        flt = dict(type=ftype, field=ffield, values=values.numpy(), retry_times=retry, default_timestamp=default_ts)
+        n, e = self.o.sample_filtered(graph, sampler, ids.numpy(), k, flt, seed=seed, call_counter=cc, padding_mode=pad,
+                                      default_neighbor_id=dflt, rng_rows=rng_rows.numpy())
+        return torch.from_numpy(n), torch.from_numpy(e)
+
     def lookup(self, feats, ids, default_attr):
         X, raw = feats
         row_of = {int(v): i for i, v in enumerate(raw)}
@@ -119,6 +126,21 @@ def _worker(rank, world, port, q, message_limit=None):
                 on2, _ = orc.sample(whole, name, on.reshape(-1), 3, seed=77, call_counter=cc, padding_mode=pad,
                                     default_neighbor_id=-2)
                 ok &= np.array_equal(n2.numpy(), on2)
+        # requests with an op::Filter: the values travel with their rows; id filters give the single-store answer
+        ts_whole = (np.arange(col.shape[0], dtype=np.int64) * 7919) % 1009  # "timestamps": any per-edge field
+        whole_f = dict(whole, ts_slot=ts_whole[eid])
+        shard_f = dict(shard, ts_slot=ts_whole[shard["eid"]])
+        shard_f["indeg_weight"] = whole_f["indeg_weight"] = None
+        store_f = gdist.ShardedStore(ops, shard_f, feats)
+        for (ftype, ffield) in ((1, 1), (2, 1), (1, 2)):
+            vals = rng.integers(0, 600, src.shape[0]).astype(np.int64) if ffield == 1 else rng.integers(0, 1009, src.shape[0]).astype(np.int64)
+            for name in ("RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"):
+                cc += 1
+                n1, e1 = store_f.sample_filtered(name, t(src), 5, ftype, ffield, t(vals), seed=77, call_counter=cc,
+                                                 default_neighbor_id=-2, retry_times=2)
+                on, oe = orc.sample_filtered(whole_f, name, src, 5, dict(type=ftype, field=ffield, values=vals, retry_times=2),
+                                             seed=77, call_counter=cc, default_neighbor_id=-2)
+                ok &= np.array_equal(n1.numpy(), on) and np.array_equal(e1.numpy(), oe)
         ids = n2.reshape(-1).numpy().copy()
         seg = (np.arange(ids.shape[0]) // 3).astype(np.int32)
         Sg = ids.shape[0] // 3
