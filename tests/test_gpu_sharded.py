@@ -156,6 +156,12 @@ def test_sharded_store_over_rccl_world1(world):
             n, e = store.sample(name, src, 10, seed=3, call_counter=1)
             rn, re = whole.sample(name, src, 10, seed=3, call_counter=1)
             assert torch.equal(n, rn) and torch.equal(e, re)
+        # a filtered request through the exchange: the values travel with their rows
+        vals = whole.sample("TopkSampler", src, 1)[0].view(-1).contiguous()  # every row's first neighbour
+        for name in glx.SAMPLER_IDS:
+            fn, fe = store.sample_filtered(name, src, 10, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, seed=3, call_counter=2)
+            rn2, re2 = whole.sample_filtered(name, src, 10, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, seed=3, call_counter=2)
+            assert torch.equal(fn, rn2) and torch.equal(fe, re2)
         seg = (torch.arange(40000, device=dev) // 10).to(torch.int32)
         emb, cnt = store.aggregate("MeanAggregator", n.view(-1), seg, 4000)
         remb, rcnt = feats.aggregate("MeanAggregator", n.view(-1), seg, 4000)
