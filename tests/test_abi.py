@@ -71,3 +71,25 @@ def test_argument_validation_needs_no_gpu():
     assert L.glx_sample(None, 0, None, 1, 1, 1, 0, 0, 0, None, None, 0, None) == 3
     assert L.glx_aggregate(None, 0, None, None, 0, 0, 0.0, None, None, 0, None) == 3
     assert b"NULL" in L.glx_last_error()
+
+
+def test_every_entry_point_cites_the_reference_interface_it_replaces():
+    """include/glx.h is the drop-in boundary: each block of entry points must say which reference file:line it
+    stands in for (or that it is an addition of this engine)."""
+    text = open(os.path.join(ROOT, "include", "glx.h")).read()
+    # sections start at the "/* ---- title ..." comments; a citation anywhere in a section's comments covers the
+    # entry points declared in that section
+    starts = [m.start() for m in re.finditer(r"/\* ----", text)] + [len(text)]
+    cited = set()
+    for a, b in zip(starts[:-1], starts[1:]):
+        section = text[a:b]
+        comments = " ".join(re.findall(r"/\*.*?\*/", section, flags=re.S))
+        names = re.findall(r"\b(glx_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", section, flags=re.S))
+        if re.search(r"\w+\.(?:cc|h|py):\d+", comments):
+            cited.update(names)
+    uncited = [s for s in declared_symbols() if s not in cited]
+    # housekeeping entry points that have no counterpart in the reference
+    allowed = {"glx_abi_version", "glx_device_count", "glx_last_error", "glx_graph_destroy", "glx_graph_info",
+               "glx_features_destroy", "glx_features_info", "glx_negative_destroy", "glx_negative_info",
+               "glx_profile_collect"}
+    assert set(uncited) <= allowed, sorted(set(uncited) - allowed)
