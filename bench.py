@@ -133,7 +133,8 @@ def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
     value = 1.0 / (1.0 / r_sample + 1.0 / r_agg)
     return {
         "thread_sweep": sweep or None,
-        "value": value, "unit": "edges/s", "cores": threads, "kind": "reference",
+        "value": value, "unit": "edges/s", "cores": threads, "threads": threads, "nproc": os.cpu_count(),
+        "kind": "reference",
         "sampling_edges_per_s": r_sample, "aggregation_vertices_per_s": r_agg,
         "sample": ("reference C++ %s [%d,%d] + %s on host threads (one request per thread, "
                    "%d seeds/request, %d requests/thread; %.1fs sampling + %.1fs aggregation timed); "
@@ -182,7 +183,8 @@ def cpu_baseline_port(wl, src, dst, weight, args, seed_pool=None):
         verts += ids.shape[0]
     dta = time.time() - t0
     r_s, r_a = edges / dts, verts / dta
-    return {"value": 1.0 / (1.0 / r_s + 1.0 / r_a), "unit": "edges/s", "cores": 1, "kind": "port",
+    return {"value": 1.0 / (1.0 / r_s + 1.0 / r_a), "unit": "edges/s", "cores": 1, "threads": 1,
+            "nproc": os.cpu_count(), "kind": "port",
             "sampling_edges_per_s": r_s, "aggregation_vertices_per_s": r_a,
             "sample": ("oracle/glx_oracle.c (C restatement, reference cost model: alias table rebuilt per row per "
                        "request) single-threaded; %s [%d,%d] + %s; graph = first %d of %d edges; %d seeds/request; "
@@ -339,8 +341,10 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c5"])
     ap.add_argument("--batch", type=int, default=65536, help="seed vertices per step per GPU (B0)")
     ap.add_argument("--features", default="auto", choices=["auto", "replicated", "sharded"],
-                    help="N>1: replicate the feature table on every GPU (load-time all-gather) or keep it "
-                         "edge-cut sharded with a per-request halo exchange")
+                    help="N>1: which feature placement `value` reports.  auto / sharded = north_star's: the table "
+                         "stays edge-cut, aggregation fetches halo rows per request (auto also times the "
+                         "replicated placement and reports it beside); replicated = the whole table on every "
+                         "GPU (one load-time all-gather) is the headline")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="overlap step i+1's sampling (+ xGMI exchange) with step i's aggregation on two "
                          "HIP streams; auto = on for N>1")
@@ -355,14 +359,11 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="after timing, recompute one step on an unpartitioned copy of the graph held by this "
                          "rank and require bit-identical outputs from the sharded path")
-    ap.add_argument("--ablations", default="auto", choices=["auto", "on", "off"],
-                    help="N>1 with replicated features: after the timed region, also time a few steps with "
-                         "the feature table kept edge-cut sharded -- design H (per-request halo exchange), H "
-                         "with distinct ids only, design R (owners reduce, requester folds partials) -- and "
-                         "report them under \"ablations\" (auto = on for N>1)")
-    ap.add_argument("--ablation-steps", type=int, default=3)
-    ap.add_argument("--ablation-time-limit", type=float, default=240.0,
-                    help="s; if the ablation legs have not finished by then the main result is printed without them")
+    ap.add_argument("--hot-fraction", type=float, default=0.10,
+                    help="N>1: every GPU keeps a replica of this fraction of the feature rows (the top vertices by "
+                         "global in-degree); the rest is fetched per request (halo exchange of the cold tail)")
+    ap.add_argument("--roofline-probes", default="on", choices=["on", "off"],
+                    help="N=1: also time the aggregation kernel on cache-free (uniform) rows and a device copy")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--c5-scale", type=int, default=1, help="divide the c5 node / edge counts (test rig)")
@@ -429,21 +430,16 @@ def main():
     # tables + id map); rows end up weight-descending like the reference's Build().
     t1 = time.time()
     X = synth.features_torch(V, D, gseed + 1, dev)
+    st_smp = st_agg = replica = whole = None
+    hot = None
     if not sharded:
         graph = glx.Graph.from_edges(src, dst, weight, device=local_rank)
         feats = glx.Features(X, device=local_rank)
-        store = None
         placement = "1 GPU"
     else:
         import dist as gdist
-        whole = None
         if args.verify:
             whole = (glx.Graph.from_edges(src, dst, weight, device=local_rank), glx.Features(X, device=local_rank))
-        # ablation leg "everything replicated": the whole topology also fits next to the replica
-        # (C3: 5.6 GB), so requests could be served with no exchange at all
-        whole_graph = None
-        if (args.ablations == "on" or (args.ablations == "auto" and world > 1)) and E * 56 <= 64 * (1 << 30):
-            whole_graph = whole[0] if whole else glx.Graph.from_edges(src, dst, weight, device=local_rank)
         own = (src % world) == rank  # edge-cut: out-edges of v live on shard llabs(v) % P
         eids = torch.nonzero(own).view(-1)
         graph = glx.Graph.from_edges(src[own].contiguous(), dst[own].contiguous(),
@@ -451,27 +447,31 @@ def main():
                                      edge_ids=eids, device=local_rank)
         del own, eids
         x_shard = X[rank::world].contiguous()
-        del X
-        X = None
-        store_h = None
-        want_ablations = args.ablations == "on" or (args.ablations == "auto" and world > 1)
-        if args.features == "replicated" or (args.features == "auto" and V * D * 4 <= 96 * (1 << 30)):
-            # halo exchange done once, at load time: all-gather the shards over RCCL
-            full = gdist.replicate_features(x_shard, V)
-            if want_ablations:  # the same shard, kept edge-cut, for the per-request exchange legs
-                ids = torch.arange(rank, V, world, dtype=torch.int64, device=dev)
-                store_h = gdist.ShardedStore(gdist.DeviceOps(), graph, glx.Features(x_shard, ids=ids, device=local_rank))
-                del ids
-            del x_shard
+        ids = torch.arange(rank, V, world, dtype=torch.int64, device=dev)
+        feats = glx.Features(x_shard, ids=ids, device=local_rank)  # this rank's rows of the edge-cut table
+        del ids
+        # one communicator per stream: sampling (+ its exchanges) of step i+1 overlaps aggregation of step i
+        comm_s = gdist.comm_for_group(None, local_rank)
+        comm_a = gdist.comm_for_group(None, local_rank)
+        st_smp = glx.DistStore(comm_s, graph=graph)
+        st_agg = glx.DistStore(comm_a, features=feats)
+        # hot-row replica: the top vertices by GLOBAL in-degree (computed from the shards), fetched once
+        n_hot = int(V * args.hot_fraction)
+        t_hot = time.time()
+        hot = st_smp.hot_ids(n_hot) if n_hot > 0 else np.empty(0, np.int64)
+        st_agg.set_cache(hot)
+        torch.cuda.synchronize()
+        log("hot-row replica: %d rows (%.2f GB per GPU) selected + fetched in %.1fs"
+            % (hot.shape[0], hot.shape[0] * D * 4 / 1e9, time.time() - t_hot))
+        if args.features != "sharded" and V * D * 4 <= 96 * (1 << 30):
+            # the other end of the placement space: the whole table on every GPU (one load-time all-gather)
+            full = gdist.replicate_features(x_shard, V) if world > 1 else X
             replica = glx.Features(full, device=local_rank)
             del full
-            store = gdist.ShardedStore(gdist.DeviceOps(), graph, None, feature_replica=replica)
-            placement = "graph edge-cut llabs(v)%%%d + RCCL all-to-all per hop; features replicated by one load-time RCCL all-gather" % world
-        else:
-            ids = torch.arange(rank, V, world, dtype=torch.int64, device=dev)
-            feats = glx.Features(x_shard, ids=ids, device=local_rank)
-            store = gdist.ShardedStore(gdist.DeviceOps(), graph, feats)
-            placement = "graph + features edge-cut llabs(v)%%%d; RCCL all-to-all per hop and per-request halo feature exchange" % world
+        del x_shard
+        placement = ("graph + features edge-cut llabs(v)%%%d; per hop: RCCL send/recv exchange of request rows; "
+                     "aggregation: own shard + replica of the top %.0f%% rows by in-degree + per-request halo exchange "
+                     "of the deduplicated cold tail (glx_dist_*)" % (world, 100 * args.hot_fraction))
     del src, dst, weight
     X = None
     torch.cuda.empty_cache()
@@ -485,8 +485,6 @@ def main():
     seeds = seed_pool[torch.randint(0, seed_pool.shape[0], (n_steps, B0), generator=gen, device=dev)]
     del seed_pool
     n1, n2 = B0 * k1, B0 * k1 * k2
-    seg2 = (torch.arange(n2, device=dev) // k2).to(torch.int32)
-    seg1 = (torch.arange(n1, device=dev) // k1).to(torch.int32)
     emb2 = torch.empty((n1, D), dtype=torch.float32, device=dev)
     cnt2 = torch.empty((n1,), dtype=torch.int32, device=dev)
     emb1 = torch.empty((B0, D), dtype=torch.float32, device=dev)
@@ -506,72 +504,104 @@ def main():
 
     def do_sample(i):
         cc = 4 * i
-        if store is None:
-            nb1, ed1, nb2, ed2 = bufs[i % len(bufs)]
+        nb1, ed1, nb2, ed2 = bufs[i % len(bufs)]
+        if st_smp is None:
             graph.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
             graph.sample(sampler, nb1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nb2, ed2))
-            return nb1, nb2
-        a, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=cc)
-        b, _ = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=cc + 1)
-        return a, b
-
-    def do_aggregate(a, b):
-        if store is None:
-            feats.aggregate(agg, b.view(-1), seg2, n1, out=(emb2, cnt2))
-            feats.aggregate(agg, a.view(-1), seg1, B0, out=(emb1, cnt1))
         else:
-            store.aggregate(agg, b.view(-1), seg2, n1)
-            store.aggregate(agg, a.view(-1), seg1, B0)
+            st_smp.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
+            st_smp.sample(sampler, nb1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nb2, ed2))
+        return nb1, nb2
+
+    # A dense sampler response implies its segments (segment i = the neighbours of request row i):
+    # segment_ids = None skips the segment bookkeeping kernels and the read of a segment tensor.
+    def agg_local(table):
+        def run(a, b):
+            table.aggregate(agg, b.view(-1), None, n1, out=(emb2, cnt2))
+            table.aggregate(agg, a.view(-1), None, B0, out=(emb1, cnt1))
+        return run
+
+    def agg_halo(a, b):
+        st_agg.aggregate(agg, b.view(-1), None, n1, out=(emb2, cnt2))
+        st_agg.aggregate(agg, a.view(-1), None, B0, out=(emb1, cnt1))
 
     if pipelined:
         s_smp, s_agg = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        agg_done = []
-
-    def step(i):
-        if not pipelined:
-            a, b = do_sample(i)
-            do_aggregate(a, b)
-            return
-        with torch.cuda.stream(s_smp):
-            if len(agg_done) >= 2:
-                s_smp.wait_event(agg_done[-2])  # the buffers of step i-2 are free again
-            a, b = do_sample(i)
-            a.record_stream(s_agg)
-            b.record_stream(s_agg)
-            sampled = torch.cuda.Event()
-            sampled.record(s_smp)
-        with torch.cuda.stream(s_agg):
-            s_agg.wait_event(sampled)
-            do_aggregate(a, b)
-            done = torch.cuda.Event()
-            done.record(s_agg)
-            agg_done.append(done)
 
     def barrier():
         # Drain the local queue first: an RCCL barrier issued while the GPU still has queued work
         # was seen to take 100+ ms sporadically (world-size-1 probe), which would be charged to
         # the timed region; with an idle GPU it costs ~0.06 ms.
         torch.cuda.synchronize()
-        if sharded:
+        if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    glx.profile_enable(True)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    glx.profile_enable(False)
-    t_agg = glx.profile_collect(glx.KERNEL_AGGREGATE)
-    t_smp = glx.profile_collect(glx.KERNEL_SAMPLE)
-    if world > 1:
-        t = torch.tensor([elapsed], device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_leg(do_aggregate, steps_from, steps_to, warm):
+        """Times steps [steps_from, steps_to) after `warm` untimed ones; -> (seconds, t_agg, t_smp)."""
+        agg_done = []
+
+        def step(i):
+            if not pipelined:
+                a, b = do_sample(i)
+                do_aggregate(a, b)
+                return
+            with torch.cuda.stream(s_smp):
+                if len(agg_done) >= 2:
+                    s_smp.wait_event(agg_done[-2])  # the buffers of step i-2 are free again
+                a, b = do_sample(i)
+                sampled = torch.cuda.Event()
+                sampled.record(s_smp)
+            with torch.cuda.stream(s_agg):
+                s_agg.wait_event(sampled)
+                do_aggregate(a, b)
+                done = torch.cuda.Event()
+                done.record(s_agg)
+                agg_done.append(done)
+        for i in range(warm):
+            step(i)
+        barrier()
+        glx.profile_enable(True)
+        t0 = time.perf_counter()
+        for i in range(steps_from, steps_to):
+            step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        glx.profile_enable(False)
+        t_a = glx.profile_collect(glx.KERNEL_AGGREGATE)
+        t_s = glx.profile_collect(glx.KERNEL_SAMPLE)
+        if world > 1:
+            t = torch.tensor([dt], device=ctl, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, t_a, t_s
+
+    edges_per_step = n1 + n2  # response slots, padding included (SURVEY.md 8(d))
+    ctl = dev if args.backend == "nccl" else torch.device("cpu")  # control-plane tensors (gloo rig: host)
+    legs = {}
+    if not sharded:
+        elapsed, t_agg, t_smp = timed_leg(agg_local(feats), args.warmup, n_steps, args.warmup)
+        headline = "single GPU"
+    else:
+        # north_star's placement: everything edge-cut, halo-vertex feature exchange per request
+        el_h, ta_h, ts_h = timed_leg(agg_halo, args.warmup, n_steps, args.warmup)
+        legs["features_sharded"] = {"ms_per_step": el_h / args.steps * 1e3,
+                                    "value": world * edges_per_step * args.steps / el_h}
+        torch.cuda.synchronize()
+        halo_stats = st_agg.stats()  # the last aggregate call (hop 1); hop 2's are taken below
+        if replica is not None:
+            el_r, ta_r, ts_r = timed_leg(agg_local(replica), args.warmup, n_steps, args.warmup)
+            legs["features_replicated"] = {"ms_per_step": el_r / args.steps * 1e3,
+                                           "value": world * edges_per_step * args.steps / el_r}
+        if args.features == "replicated" and replica is not None:
+            elapsed, t_agg, t_smp, headline = el_r, ta_r, ts_r, "features_replicated"
+        else:
+            elapsed, t_agg, t_smp, headline = el_h, ta_h, ts_h, "features_sharded"
+        # what crossed the links for one hop-2 request (this rank's view)
+        a_last, b_last = do_sample(n_steps - 1)
+        st_agg.aggregate(agg, b_last.view(-1), None, n1, out=(emb2, cnt2))
+        torch.cuda.synchronize()
+        halo_stats = st_agg.stats()
 
     cpu = None
     if host_edges is not None:
@@ -582,7 +612,7 @@ def main():
     # how much of the hop-2 work is the reference's default-fill path (frontier vertices
     # without out-edges)?  Reported so the workload can be judged.
     empty_frac = None
-    if store is None:
+    if st_smp is None:
         a_last, _ = do_sample(n_steps - 1)
         torch.cuda.synchronize()
         empty_frac = float((graph.degrees(a_last.view(-1)) == 0).double().mean().item())
@@ -590,107 +620,30 @@ def main():
     verified = None
     if args.verify and sharded:
         i = n_steps - 1
-        a, ae = store.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
-        b, be = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=4 * i + 1)
-        e2, c2 = store.aggregate(agg, b.view(-1), seg2, n1)
+        a, b = do_sample(i)
+        agg_halo(a, b)
         wa, wae = whole[0].sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
         wb, wbe = whole[0].sample(sampler, wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
-        we2, wc2 = whole[1].aggregate(agg, wb.view(-1), seg2, n1)
+        we2, wc2 = whole[1].aggregate(agg, wb.view(-1), None, n1)
+        we1, wc1 = whole[1].aggregate(agg, wa.view(-1), None, B0)
         torch.cuda.synchronize()
-        verified = bool(torch.equal(a, wa) and torch.equal(ae, wae) and torch.equal(b, wb) and torch.equal(be, wbe)
-                        and torch.equal(c2, wc2) and torch.equal(e2.view(torch.int32), we2.view(torch.int32)))
-        flag = torch.tensor([1 if verified else 0], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN) if args.backend == "gloo" else None
-        if args.backend == "nccl":
-            flag = flag.to(dev)
+        nb1, ed1, nb2, ed2 = bufs[i % len(bufs)]
+        verified = bool(torch.equal(nb1, wa) and torch.equal(ed1, wae) and torch.equal(nb2, wb) and torch.equal(ed2, wbe)
+                        and torch.equal(cnt2, wc2) and torch.equal(emb2.view(torch.int32), we2.view(torch.int32))
+                        and torch.equal(cnt1, wc1) and torch.equal(emb1.view(torch.int32), we1.view(torch.int32)))
+        if replica is not None:
+            re2, rc2 = replica.aggregate(agg, wb.view(-1), None, n1)
+            verified = verified and bool(torch.equal(re2.view(torch.int32), we2.view(torch.int32)))
+        if world > 1:
+            flag = torch.tensor([1 if verified else 0], dtype=torch.int64, device=ctl)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        verified = bool(flag.item())
-        log("verify: sharded == unpartitioned on every rank: %s" % verified)
+            verified = bool(flag.item())
+        log("verify: sharded (halo exchange) == unpartitioned, bit for bit, on every rank: %s" % verified)
 
-    edges_per_step = n1 + n2  # response slots, padding included
     value = world * edges_per_step * args.steps / elapsed
-    res_holder = {}
 
-    def emit(extra):
-        if res_holder.get("done"):
-            return
-        res_holder["done"] = True
-        out = dict(res_holder["res"])
-        out.update(extra)
-        if rank == 0:
-            result_out.write(json.dumps(out) + "\n")
-            result_out.flush()
-
-    def run_ablations():
-        """Per-request feature exchange instead of the load-time replica (north_star's
-        'halo-vertex feature exchange via RCCL all-to-all'), same graph, same requests,
-        un-pipelined; each leg is checked against the replica's answer for one step."""
-        legs = {}
-        exact = agg in ("MaxAggregator", "MinAggregator")
-        K = max(1, args.ablation_steps)
-        if whole_graph is not None:
-            # upper bound of the placement space: topology AND features replicated, no collective on
-            # the data path (requests sharded across ranks, each served locally)
-            def local(i):
-                a, _ = whole_graph.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
-                b, _ = whole_graph.sample(sampler, a.view(-1), k2, seed=42, call_counter=4 * i + 1)
-                e2, c2 = store.aggregate(agg, b.view(-1), seg2, n1)
-                store.aggregate(agg, a.view(-1), seg1, B0)
-                return b, e2
-            local(0)
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                b, e2 = local(args.warmup + i)
-            barrier()
-            dt = time.perf_counter() - t0
-            t = torch.tensor([dt], device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            i = args.warmup + args.steps - 1
-            sa, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
-            sb, _ = store.sample(sampler, sa.view(-1), k2, seed=42, call_counter=4 * i + 1)
-            legs["topology_and_features_replicated_no_exchange"] = {
-                "ms_per_step": float(t.item()) / args.steps * 1e3,
-                "value": world * edges_per_step * args.steps / float(t.item()), "steps": args.steps,
-                "equals_edge_cut_result": bool(torch.equal(sb, b))}
-            log("ablation all-replicated: %.2f ms/step" % legs["topology_and_features_replicated_no_exchange"]["ms_per_step"])
-            del b, e2, sa, sb
-        for key, kw in (("features_sharded_halo_exchange_H", dict(mode="halo")),
-                        ("features_sharded_halo_exchange_H_distinct_ids", dict(mode="halo", dedup=True)),
-                        ("features_sharded_partial_reduce_R", dict(mode="partial"))):
-            def one(i):
-                a, _ = store.sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
-                b, _ = store.sample(sampler, a.view(-1), k2, seed=42, call_counter=4 * i + 1)
-                e2, c2 = store_h.aggregate(agg, b.view(-1), seg2, n1, **kw)
-                e1, c1 = store_h.aggregate(agg, a.view(-1), seg1, B0, **kw)
-                return b, e2, c2
-            one(0)
-            one(1 % n_steps)  # two warm-ups: the multi-GB exchange buffers settle in the caching allocator
-            per_step = []
-            for i in range(K):  # each step timed on its own (these legs are not pipelined); median reported
-                barrier()
-                t0 = time.perf_counter()
-                b, e2, c2 = one(args.warmup + i % max(args.steps, 1))
-                torch.cuda.synchronize()
-                per_step.append(time.perf_counter() - t0)
-            t = torch.tensor(per_step, device=(dev if args.backend == "nccl" else "cpu"), dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # a step takes as long as its slowest rank
-            per_step = sorted(t.tolist())
-            med = per_step[len(per_step) // 2]
-            we2, wc2 = store.aggregate(agg, b.view(-1), seg2, n1)  # the replica's (single-shard) answer
-            if exact or kw["mode"] == "halo":
-                same = torch.equal(e2.view(torch.int32), we2.view(torch.int32))
-            else:
-                same = torch.allclose(e2, we2, rtol=1e-5, atol=1e-4)
-            same = bool(same and torch.equal(c2, wc2))
-            del e2, c2, we2, wc2, b
-            torch.cuda.empty_cache()
-            legs[key] = {"ms_per_step": med * 1e3, "value": world * edges_per_step / med, "steps": K,
-                         "ms_per_step_all": [round(x * 1e3, 3) for x in per_step], "equals_replica_result": same}
-            log("ablation %s: %.2f ms/step (%s)" % (key, legs[key]["ms_per_step"], "ok" if same else "MISMATCH"))
-        return legs
-    # dominant kernel: the hop-2 segmented reduce (first aggregate launch of each step)
-    agg2 = t_agg[0::2] if store is None else t_agg[0::2]
+    # ---- roofline of the dominant kernel: the hop-2 segmented reduce (first aggregate launch of each step)
+    agg2 = t_agg[0::2]
     agg1 = t_agg[1::2]
     bytes_agg2 = n2 * (4 * D + 12) + n1 * (4 * D + 4)  # SURVEY.md 8(d): algorithmic bytes
     avg_agg2_ms = float(np.mean(agg2)) if len(agg2) else float("nan")
@@ -704,6 +657,51 @@ def main():
             traffic = rec.get(key, {}).get("aggregate_hop2_bytes_per_launch")
         except Exception:
             traffic = None
+    roof = {"kernel": "glx_aggregate_kernel (hop-2 %s, dim=%d%s)" % (agg, D, ", 3 row sources" if headline == "features_sharded" else ""),
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "avg_launch_ms": avg_agg2_ms, "algorithmic_bytes_per_launch": bytes_agg2, "launches_timed": int(len(agg2)),
+            "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBS,
+            "note_algorithmic": "SURVEY 8(d) bytes / live launch time; counts every row read once per occurrence, so hub "
+                                "rows re-read from L2 / Infinity Cache push it past what HBM delivers (cache-assisted)",
+            "traffic": traffic,
+            "traffic_source": ("profiles/pmc_traffic.json: offline rocprofv3 --pmc passes of this command (FETCH_SIZE x2 + "
+                               "WRITE_SIZE per launch), not measured in this run") if traffic else None}
+    if traffic and not sharded:
+        roof["achieved"] = traffic / (avg_agg2_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["frac_basis"] = "PMC-measured HBM traffic per launch / live launch time / 8 TB/s"
+    else:
+        roof["achieved"] = min(achieved, HBM_PEAK_GBS)
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["frac_basis"] = "algorithmic bytes (no PMC traffic recorded for this configuration), capped at the peak"
+    if args.roofline_probes == "on" and not sharded:
+        # (a) the same kernel on uniformly random rows of the whole table: no reuse a cache could serve
+        # (b) what a plain device-to-device copy reaches on this box (read + write)
+        fake = torch.randint(0, V, (n2,), generator=gen, device=dev)
+        for _ in range(2):
+            feats.aggregate(agg, fake, None, n1, out=(emb2, cnt2))
+        torch.cuda.synchronize()
+        glx.profile_enable(True)
+        for _ in range(5):
+            feats.aggregate(agg, fake, None, n1, out=(emb2, cnt2))
+        torch.cuda.synchronize()
+        glx.profile_enable(False)
+        ms = float(np.mean(glx.profile_collect(glx.KERNEL_AGGREGATE)))
+        roof["cache_free"] = {"rows": "uniform over all %d rows" % V, "avg_launch_ms": ms,
+                              "achieved": bytes_agg2 / (ms * 1e-3) / 1e9, "frac": bytes_agg2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del fake
+        x = torch.empty(1 << 29, dtype=torch.float32, device=dev)  # 2 GiB
+        y = torch.empty_like(x)
+        for _ in range(2):
+            y.copy_(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        roof["peak_measured_copy"] = 2 * x.numel() * 4 / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
+        del x, y
     smp_ms = float(np.sum(t_smp)) / max(args.steps, 1)
     agg_ms = float(np.sum(t_agg)) / max(args.steps, 1)
     res = {
@@ -712,7 +710,9 @@ def main():
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s" % (args.workload, desc), "seeds_per_step_per_gpu": B0,
+        "config": {"workload": "%s: %s%s" % (args.workload, desc,
+                                             "" if not sharded else " -- value = %s placement" % headline),
+                   "seeds_per_step_per_gpu": B0,
                    "seeds": "uniform over the vertices that have out-edges, fresh batch every step",
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
                    "arithmetic": "int64 ids / edge ids (bit-exact), f32 features and aggregates",
@@ -727,43 +727,28 @@ def main():
             "aggregated_vertices_per_s_aggregation_only": world * edges_per_step / (agg_ms * 1e-3) if agg_ms > 0 else None,
             "aggregate_hop1_avg_ms": float(np.mean(agg1)) if len(agg1) else None,
         },
-        "roofline": {"kernel": "glx_aggregate_kernel (hop-2 %s, dim=%d)" % (agg, D), "bound": "hbm",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "avg_launch_ms": avg_agg2_ms, "algorithmic_bytes_per_launch": bytes_agg2,
-                     "launches_timed": int(len(agg2))},
+        "roofline": roof,
         "cpu_baseline": cpu,
     }
+    if sharded:
+        res["value_features_sharded"] = legs["features_sharded"]["value"]
+        res["value_features_replicated"] = legs.get("features_replicated", {}).get("value")
+        res["placements"] = legs
+        res["halo_exchange_hop2"] = dict(halo_stats, hot_rows=int(hot.shape[0]), hot_fraction=args.hot_fraction,
+                                         note="one rank's last hop-2 request: ids by source, distinct halo rows, "
+                                              "bytes over the transport")
     if verified is not None:
         res["verified_sharded_equals_unpartitioned"] = verified
     if cpu:
         res["gpu_over_cpu"] = value / cpu["value"]
-    res_holder["res"] = res
-    if sharded and store is not None and store_h is not None:
-        # The headline number is already final.  The ablation legs exchange feature rows
-        # per request; a watchdog prints the result without them should they stall.
-        import threading
-
-        def give_up():
-            emit({"ablations": "not finished within %.0f s" % args.ablation_time_limit})
-            os._exit(3 if verified is False else 0)
-        dog = threading.Timer(args.ablation_time_limit, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            legs = run_ablations()
-        except Exception as ex:  # noqa: BLE001 -- never lose the headline line
-            legs = "failed: %r" % (ex,)
-        dog.cancel()
-        emit({"ablations": legs})
-        if isinstance(legs, str):
-            # a leg failed on this rank: the other ranks may be waiting in a collective, and tearing
-            # the process group down would wait for them -- the result is out, leave now
-            sys.stderr.flush()
-            os._exit(0)
-    else:
-        emit({})
+    if rank == 0:
+        result_out.write(json.dumps(res) + "\n")
+        result_out.flush()
     if sharded:
+        st_smp.close()
+        st_agg.close()
+        comm_s.close()
+        comm_a.close()
         dist.destroy_process_group()
     if verified is False:
         sys.exit(3)

@@ -76,8 +76,8 @@ __device__ __forceinline__ float agg_combine(float l, float r) {
 struct AggArgs {
   const float* X;
   const int64_t* node_ids;   // raw ids (dense map) ...
-  const int32_t* rows;       // ... or pre-translated rows (hashed map); one is null
-  const int32_t* seg_start;  // [num_segments + 1]
+  const int32_t* rows;       // ... or pre-translated rows (hashed map / multi-source); one is null
+  const int32_t* seg_start;  // [num_segments + 1], or null: uniform segments of `fanout` ids
   float* emb_out;
   int32_t* cnt_out;
   int64_t num_rows;
@@ -85,28 +85,50 @@ struct AggArgs {
   int64_t swizzle_rows;
   int32_t dim;
   int32_t num_segments;
+  int32_t fanout;
   float default_attr;
+  // further row sources of the distributed store (glx_dist.hip): virtual row r lives in
+  // source 0 when r < base1, in source 1 (the hot-row replica) when r < base2, else in
+  // source 2 (the halo rows of this request, plain row-major, no swizzle).
+  const float* X1;
+  const float* X2;
+  int64_t stride1, swizzle1, stride2;
+  int32_t base1, base2;
 };
 
 // Feature rows are < 2^31 (checked at creation), so a row index fits an int32 --
-// half the registers of the raw int64 id, which keeps the kernel at 8 waves/SIMD.
+// half the registers of the raw int64 id.
 __device__ __forceinline__ int32_t agg_row_at(const AggArgs& a, int32_t pos) {
   if (a.rows) return a.rows[pos];
   const int64_t id = a.node_ids[pos];
   return (id >= 0 && id < a.num_rows) ? (int32_t)id : -1;
 }
 
+template <int NSRC>
+__device__ __forceinline__ const float* agg_row_ptr(const AggArgs& a, int32_t row) {
+  if (NSRC == 1 || row < a.base1) return a.X + glx_swizzle_row(row, a.swizzle_rows) * a.stride;
+  if (row < a.base2) return a.X1 + glx_swizzle_row(row - a.base1, a.swizzle1) * a.stride1;
+  return a.X2 + (int64_t)(row - a.base2) * a.stride2;
+}
+
 // G lanes per segment, VEC floats per lane per pass (VEC = 4: one dwordx4 per
 // row per lane; VEC = 1 for dims that are not a multiple of 4).  U rows are
-// issued back-to-back before the first is consumed.
-template <int OP, int G, int VEC, int U>
+// issued back-to-back before the first is consumed.  NSRC = 3: rows come from the
+// three sources of a distributed store.
+template <int OP, int G, int VEC, int U, int NSRC>
 __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
   const int c = threadIdx.x & (G - 1);
   if (gid >= a.num_segments) return;
-  const int32_t s0 = a.seg_start[gid];
-  const int32_t s1 = a.seg_start[gid + 1];
+  int32_t s0, s1;
+  if (a.seg_start) {
+    s0 = a.seg_start[gid];
+    s1 = a.seg_start[gid + 1];
+  } else {  // a dense sampler response: segment gid = ids [gid * fanout, (gid + 1) * fanout)
+    s0 = (int32_t)gid * a.fanout;
+    s1 = s0 + a.fanout;
+  }
   const int32_t n = s1 - s0;
   if (c == 0) a.cnt_out[gid] = n;
   const int32_t dim = a.dim;
@@ -123,7 +145,7 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (row[u] >= 0) {
-          val[u] = *reinterpret_cast<const vec_t*>(a.X + glx_swizzle_row(row[u], a.swizzle_rows) * a.stride + col);
+          val[u] = *reinterpret_cast<const vec_t*>(agg_row_ptr<NSRC>(a, row[u]) + col);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) val[u][v] = a.default_attr;
@@ -150,32 +172,60 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
   }
 }
 
-template <int OP, int G, int VEC>
+// Rows in flight per lane.  8 is the default; GLX_AGG_UNROLL=10|12 selects the other
+// instantiations of the wide float4 shapes for A/B runs (a fanout-10 segment is then one
+// batch of loads instead of 8 + 2).
+int agg_unroll() {
+  static const int u = [] {
+    const char* e = getenv("GLX_AGG_UNROLL");
+    const int v = e ? atoi(e) : 8;
+    return (v == 10 || v == 12) ? v : 8;
+  }();
+  return u;
+}
+
+template <int OP, int G, int VEC, int NSRC>
 void launch_agg_g(const AggArgs& a, hipStream_t s) {
   const int64_t threads = (int64_t)a.num_segments * G;
-  glx_aggregate_kernel<OP, G, VEC, 8><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  if (VEC == 4 && G >= 32 && NSRC == 1 && agg_unroll() != 8) {
+    if (agg_unroll() == 10) glx_aggregate_kernel<OP, G, VEC, (VEC == 4 && G >= 32 && NSRC == 1) ? 10 : 8, NSRC><<<grid, 256, 0, s>>>(a);
+    else glx_aggregate_kernel<OP, G, VEC, (VEC == 4 && G >= 32 && NSRC == 1) ? 12 : 8, NSRC><<<grid, 256, 0, s>>>(a);
+    return;
+  }
+  glx_aggregate_kernel<OP, G, VEC, 8, NSRC><<<grid, 256, 0, s>>>(a);
+}
+
+template <int OP, int NSRC>
+void launch_agg_n(const AggArgs& a, hipStream_t s) {
+  bool vec4 = a.dim % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0 &&
+              (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && (a.stride % 4) == 0;
+  if (NSRC > 1) {
+    vec4 = vec4 && (reinterpret_cast<uintptr_t>(a.X1) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.X2) & 15) == 0 &&
+           (a.stride1 % 4) == 0 && (a.stride2 % 4) == 0;
+  }
+  if (vec4) {
+    const int lanes = a.dim / 4;
+    if (lanes >= 64) launch_agg_g<OP, 64, 4, NSRC>(a, s);
+    else if (lanes >= 32) launch_agg_g<OP, 32, 4, NSRC>(a, s);
+    else if (lanes >= 16) launch_agg_g<OP, 16, 4, NSRC>(a, s);
+    else if (lanes >= 8) launch_agg_g<OP, 8, 4, NSRC>(a, s);
+    else if (lanes >= 4) launch_agg_g<OP, 4, 4, NSRC>(a, s);
+    else if (lanes >= 2) launch_agg_g<OP, 2, 4, NSRC>(a, s);
+    else launch_agg_g<OP, 1, 4, NSRC>(a, s);
+  } else {
+    const int lanes = a.dim;
+    if (lanes >= 64) launch_agg_g<OP, 64, 1, NSRC>(a, s);
+    else if (lanes >= 16) launch_agg_g<OP, 16, 1, NSRC>(a, s);
+    else if (lanes >= 4) launch_agg_g<OP, 4, 1, NSRC>(a, s);
+    else launch_agg_g<OP, 1, 1, NSRC>(a, s);
+  }
 }
 
 template <int OP>
 void launch_agg(const AggArgs& a, hipStream_t s) {
-  const bool vec4 = a.dim % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
-  if (vec4) {
-    const int lanes = a.dim / 4;
-    if (lanes >= 64) launch_agg_g<OP, 64, 4>(a, s);
-    else if (lanes >= 32) launch_agg_g<OP, 32, 4>(a, s);
-    else if (lanes >= 16) launch_agg_g<OP, 16, 4>(a, s);
-    else if (lanes >= 8) launch_agg_g<OP, 8, 4>(a, s);
-    else if (lanes >= 4) launch_agg_g<OP, 4, 4>(a, s);
-    else if (lanes >= 2) launch_agg_g<OP, 2, 4>(a, s);
-    else launch_agg_g<OP, 1, 4>(a, s);
-  } else {
-    const int lanes = a.dim;
-    if (lanes >= 64) launch_agg_g<OP, 64, 1>(a, s);
-    else if (lanes >= 16) launch_agg_g<OP, 16, 1>(a, s);
-    else if (lanes >= 4) launch_agg_g<OP, 4, 1>(a, s);
-    else launch_agg_g<OP, 1, 1>(a, s);
-  }
+  if (a.X1 || a.X2) launch_agg_n<OP, 3>(a, s);
+  else launch_agg_n<OP, 1>(a, s);
 }
 
 // Upload: row r of the caller's dense [V, D] matrix -> its (swizzled, pitched) slot.
@@ -212,42 +262,7 @@ __global__ __launch_bounds__(256) void glx_lookup_kernel(GlxIdMap map, const flo
   }
 }
 
-int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const int32_t* d_seg,
-                     int32_t num_ids, int32_t num_segments, float default_attr, float* d_emb,
-                     int32_t* d_cnt, hipStream_t s) {
-  // scratch: valid_len (1) + seg_start (Sg+1) [+ rows (N) for hashed ids]
-  const bool hashed = f->idmap.keys != nullptr;
-  const size_t n_i32 = 1 + (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
-  int32_t* scratch = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s, 1);
-  if (rc != GLX_OK) return rc;
-  int32_t* valid_len = scratch;
-  int32_t* seg_start = scratch + 1;
-  int32_t* rows = hashed ? seg_start + num_segments + 1 : nullptr;
-  glx_set_i32_kernel<<<1, 1, 0, s>>>(valid_len, num_ids);
-  if (num_ids > 0) {
-    glx_seg_valid_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(d_seg, num_ids,
-                                                                          num_segments, valid_len);
-    if (hashed) {
-      glx_rows_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(f->map(), d_ids, num_ids, rows);
-    }
-  }
-  glx_seg_start_kernel<<<(unsigned)((num_segments + 1 + 255) / 256), 256, 0, s>>>(
-      d_seg, valid_len, num_segments, seg_start);
-
-  AggArgs a;
-  a.X = f->X;
-  a.node_ids = hashed ? nullptr : d_ids;
-  a.rows = rows;
-  a.seg_start = seg_start;
-  a.emb_out = d_emb;
-  a.cnt_out = d_cnt;
-  a.num_rows = f->num_rows;
-  a.stride = f->stride;
-  a.swizzle_rows = f->swizzle_rows;
-  a.dim = f->dim;
-  a.num_segments = num_segments;
-  a.default_attr = default_attr;
+int run_aggregate(AggArgs& a, int op, const int32_t* d_seg, int32_t num_ids, hipStream_t s) {
   GlxKernelTimer timer(GLX_KERNEL_AGGREGATE, s);
   switch (op) {
     case GLX_AGG_SUM: launch_agg<GLX_AGG_SUM>(a, s); break;
@@ -258,6 +273,59 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
     default: break;
   }
   timer.stop();
+  return GLX_OK;
+}
+
+// Segment bookkeeping shared by the single-table and the multi-source entry: fills
+// a.seg_start (or a.fanout for uniform segments) from scratch laid out by the caller.
+// scratch = valid_len (1) + seg_start (Sg + 1).
+void prepare_segments(AggArgs& a, const int32_t* d_seg, int32_t num_ids, int32_t num_segments, int32_t* scratch,
+                      hipStream_t s) {
+  if (d_seg == nullptr) {  // uniform segments: nothing to derive, nothing to read
+    a.seg_start = nullptr;
+    a.fanout = num_segments > 0 ? num_ids / num_segments : 0;
+    return;
+  }
+  int32_t* valid_len = scratch;
+  int32_t* seg_start = scratch + 1;
+  glx_set_i32_kernel<<<1, 1, 0, s>>>(valid_len, num_ids);
+  if (num_ids > 0) {
+    glx_seg_valid_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(d_seg, num_ids, num_segments, valid_len);
+  }
+  glx_seg_start_kernel<<<(unsigned)((num_segments + 1 + 255) / 256), 256, 0, s>>>(d_seg, valid_len, num_segments,
+                                                                                   seg_start);
+  a.seg_start = seg_start;
+  a.fanout = 0;
+}
+
+int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const int32_t* d_seg,
+                     int32_t num_ids, int32_t num_segments, float default_attr, float* d_emb,
+                     int32_t* d_cnt, hipStream_t s) {
+  // scratch: valid_len (1) + seg_start (Sg+1) [+ rows (N) for hashed ids]
+  const bool hashed = f->idmap.keys != nullptr;
+  const size_t n_i32 = 1 + (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
+  int32_t* scratch = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s, 1);
+  if (rc != GLX_OK) return rc;
+  int32_t* rows = hashed ? scratch + 1 + num_segments + 1 : nullptr;
+  AggArgs a;
+  memset(&a, 0, sizeof(a));
+  prepare_segments(a, d_seg, num_ids, num_segments, scratch, s);
+  if (hashed && num_ids > 0) {
+    glx_rows_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(f->map(), d_ids, num_ids, rows);
+  }
+  a.X = f->X;
+  a.node_ids = hashed ? nullptr : d_ids;
+  a.rows = rows;
+  a.emb_out = d_emb;
+  a.cnt_out = d_cnt;
+  a.num_rows = f->num_rows;
+  a.stride = f->stride;
+  a.swizzle_rows = f->swizzle_rows;
+  a.dim = f->dim;
+  a.num_segments = num_segments;
+  a.default_attr = default_attr;
+  run_aggregate(a, op, d_seg, num_ids, s);
   hipError_t le = hipGetLastError();
   glx_scratch_free(scratch, s);
   GLX_HIP(le);
@@ -323,6 +391,48 @@ void launch_agg_stitch(bool vec4, const float* parts, const int32_t* cnts, int32
 }
 
 }  // namespace
+
+// glx_dist.hip: segmented reduce over pre-resolved virtual rows of up to three sources
+// (own shard, hot-row replica, halo rows); vrows[i] = -1 is the default row.
+int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, int op, const int32_t* vrows,
+                               const int32_t* d_seg, int32_t num_ids, int32_t num_segments, float default_attr,
+                               float* d_emb, int32_t* d_cnt, hipStream_t s) {
+  int32_t* scratch = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), ((size_t)num_segments + 2) * sizeof(int32_t), s, 1);
+  if (rc != GLX_OK) return rc;
+  AggArgs a;
+  memset(&a, 0, sizeof(a));
+  prepare_segments(a, d_seg, num_ids, num_segments, scratch, s);
+  const GlxRowSource none{nullptr, dim, 0, 0};
+  const GlxRowSource& s0 = nsrc > 0 ? src[0] : none;
+  const GlxRowSource& s1 = nsrc > 1 ? src[1] : none;
+  const GlxRowSource& s2 = nsrc > 2 ? src[2] : none;
+  a.X = s0.X;
+  a.stride = s0.stride;
+  a.swizzle_rows = s0.swizzle_rows;
+  a.num_rows = s0.rows;
+  a.X1 = s1.X;
+  a.stride1 = s1.stride;
+  a.swizzle1 = s1.swizzle_rows;
+  a.X2 = s2.X;
+  a.stride2 = s2.stride;
+  a.base1 = (int32_t)s0.rows;
+  a.base2 = (int32_t)(s0.rows + s1.rows);
+  // the multi-source kernel is selected by a non-null X1 / X2; with neither (no replica, no
+  // halo) the single-table kernel reads the same rows
+  a.node_ids = nullptr;
+  a.rows = vrows;
+  a.emb_out = d_emb;
+  a.cnt_out = d_cnt;
+  a.dim = dim;
+  a.num_segments = num_segments;
+  a.default_attr = default_attr;
+  run_aggregate(a, op, d_seg, num_ids, s);
+  hipError_t le = hipGetLastError();
+  glx_scratch_free(scratch, s);
+  GLX_HIP(le);
+  return GLX_OK;
+}
 
 extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
                                    const int64_t* ids, int ptr_kind, void* stream,
@@ -450,7 +560,9 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
   GLX_REQUIRE((int64_t)num_segments * f->dim <= INT32_MAX,
               "num_segments * dim exceeds int32 (tensor.h:47)");
   if (num_segments == 0) return GLX_OK;
-  GLX_REQUIRE(emb_out && cnt_out && (num_ids == 0 || (node_ids && segment_ids)), "NULL data pointer");
+  GLX_REQUIRE(emb_out && cnt_out && (num_ids == 0 || node_ids), "NULL data pointer");
+  GLX_REQUIRE(segment_ids != nullptr || num_ids % num_segments == 0,
+              "segment_ids == NULL means equal segments: num_ids must be a multiple of num_segments");
   GlxDeviceGuard guard(f->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", f->device);
   hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, f->device) : glx_stream(stream);
@@ -470,10 +582,10 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
   hipError_t e = hipSuccess;
   if (num_ids > 0) {
     e = hipMemcpyAsync(d_ids, node_ids, (size_t)num_ids * 8, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_seg, segment_ids, (size_t)num_ids * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && segment_ids) e = hipMemcpyAsync(d_seg, segment_ids, (size_t)num_ids * 4, hipMemcpyHostToDevice, s);
   }
   if (e == hipSuccess) {
-    rc = aggregate_device(f, op, d_ids, d_seg, num_ids, num_segments, default_attr, d_emb, d_cnt, s);
+    rc = aggregate_device(f, op, d_ids, segment_ids ? d_seg : nullptr, num_ids, num_segments, default_attr, d_emb, d_cnt, s);
     if (rc == GLX_OK) {
       e = hipMemcpyAsync(emb_out, d_emb, emb_n * 4, hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipMemcpyAsync(cnt_out, d_cnt, (size_t)num_segments * 4, hipMemcpyDeviceToHost, s);

@@ -334,6 +334,17 @@ int glx_sample_prefix_device(const glx_graph* g, int sampler, const int64_t* d_s
                              int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter, int64_t* d_nbr,
                              int64_t* d_eid, hipStream_t s);
 
+// glx_aggregate.hip: one row source of the multi-source segmented reduce (glx_dist.hip).
+struct GlxRowSource {
+  const float* X;
+  int64_t stride;        // floats between rows
+  int64_t swizzle_rows;  // glx_swizzle_row bound (0 = rows stored in order)
+  int64_t rows;
+};
+int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, int op, const int32_t* vrows,
+                               const int32_t* d_seg, int32_t num_ids, int32_t num_segments, float default_attr,
+                               float* d_emb, int32_t* d_cnt, hipStream_t s);
+
 static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Host-pointer calls are synchronous.  When the caller passes no stream they run on

@@ -1,0 +1,1063 @@
+// glx distributed store: the edge-cut multi-GPU path of the hot operators.
+// Replaces DistributeRunner<Req, Res>::Run (graphlearn/src/core/runner/op_runner.h:60-152):
+//   Partition (core/partition/hash_partitioner.h:33-92: shard = llabs(id) % P, stable)
+//   -> one sub-request per shard -> Process on the owner -> Stitch
+//   (core/partition/stitcher.h:67-107; service/request/aggregating_request.cc:117-213)
+// with device kernels on both sides of two transport exchanges (glx_comm.hip: RCCL
+// send/recv groups over xGMI).  Requests and responses never leave HBM.
+//
+// Sampling: request rows are bucketed by owner (glx_partition), each row travels with its
+// index in the original request (the Sticker value) so the owner draws from THAT row's
+// random stream, results travel back and are scattered by the Sticker: bit-identical to the
+// unpartitioned sampler for every shard count.
+//
+// Aggregation (design H of SURVEY.md 8(e), north_star's halo-vertex feature exchange): the
+// reduce runs on the requester in request order over rows that come from three places --
+// its own shard, the replica of hot rows every GPU keeps (power-law graphs: a few percent of
+// the rows take most accesses), and the halo: the remaining remote ids, DEDUPLICATED on the
+// device (open-addressing set + per-owner compaction, no sort), fetched from their owners.
+// Only the cold tail crosses the links, once per distinct id.  One host synchronisation per
+// call (the P x P count matrix).
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "glx_comm.h"
+
+namespace {
+
+constexpr int kMaxWorld = 64;
+constexpr int kMaxProbe = 512;
+
+// ---------------------------------------------------------------- memory -----
+// Grow-only device arena; growth synchronises the device (hipFree), which also makes it safe
+// to drop a buffer earlier work of this store may still read.
+struct Arena {
+  char* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return GLX_OK;
+    if (p) GLX_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4;
+    if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+    want = (want + 255) & ~(size_t)255;
+    GLX_HIP(hipMalloc(reinterpret_cast<void**>(&p), want));
+    cap = want;
+    return GLX_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// Carves 256-byte aligned pieces out of one arena allocation.
+struct Carver {
+  size_t at = 0;
+  size_t take(size_t bytes) {
+    const size_t off = at;
+    at += (bytes + 255) & ~(size_t)255;
+    return off;
+  }
+};
+
+__device__ __forceinline__ int32_t dist_owner(int64_t id, int32_t P) {
+  const uint64_t a = id < 0 ? (uint64_t)0 - (uint64_t)id : (uint64_t)id;  // llabs (hash_partitioner.h:90-92)
+  return (int32_t)(a % (uint64_t)P);
+}
+
+// ------------------------------------------------------------- sampling ------
+__global__ void glx_dist_gather_i64_kernel(const int64_t* __restrict__ in, const int64_t* __restrict__ order,
+                                           int64_t n, int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[order[i]];
+}
+
+// A request's scalar parameters travel with it: the owner serves requester q's rows with q's
+// seed / call counter / flags, not its own (every rank drives its own request).
+struct ReqParams {
+  int64_t v[12];
+};
+__global__ void glx_dist_set_params_kernel(int64_t* dst, ReqParams p, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+
+// Stitcher::DoStitch for both response tensors at once: row i of the bucketed answer goes to
+// request row order[i].
+__global__ __launch_bounds__(256) void glx_dist_stitch2_kernel(const int64_t* __restrict__ nbr_in,
+                                                               const int64_t* __restrict__ eid_in,
+                                                               const int64_t* __restrict__ order, int64_t n, int32_t k,
+                                                               int64_t* __restrict__ nbr_out,
+                                                               int64_t* __restrict__ eid_out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n * k) return;
+  const int64_t i = t / k;
+  const int32_t c = (int32_t)(t - i * k);
+  const int64_t o = order[i] * k + c;
+  nbr_out[o] = nbr_in[t];
+  eid_out[o] = eid_in[t];
+}
+
+// ----------------------------------------------------------- aggregation -----
+// Counter block (int32, zeroed before every resolve):
+//   [0, P)     distinct halo ids per owner         [P, 2P)   compaction cursors
+//   [2P]       overflow flag (set table too small)  [2P+1..3] ids served by replica / own shard /
+//   [2P+4 ..]  exclusive offsets per owner (P + 1)            remote (with repeats)
+struct ResolveArgs {
+  GlxIdMap cache_map;
+  GlxIdMap own_map;
+  const int64_t* ids;
+  int64_t n;
+  int32_t* loc;
+  int64_t* tkeys;
+  uint64_t tmask;
+  int32_t* ctr;
+  int32_t P, me;
+  int32_t cache_base;
+  int32_t has_cache;
+};
+
+// Pass 1: every id -> a virtual row (own shard / replica), -1 (default row), or -(h + 2) when
+// it is remote and cold: h = its slot in the open-addressing set of distinct halo ids.
+__global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
+  __shared__ int32_t s_stat[3];
+  if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  int32_t n_hit = 0, n_own = 0, n_cold = 0;
+  for (int64_t base = blockIdx.x * 256ll; base < a.n; base += gridDim.x * 256ll) {
+    const int64_t i = base + threadIdx.x;
+    bool winner = false;
+    int32_t owner = 0;
+    if (i < a.n) {
+      const int64_t id = a.ids[i];
+      int32_t out = -1;
+      int64_t r = a.has_cache ? glx_row_of(a.cache_map, id) : -1;
+      if (r >= 0) {
+        out = a.cache_base + (int32_t)r;
+        ++n_hit;
+      } else {
+        owner = dist_owner(id, a.P);
+        if (owner == a.me || id == GLX_EMPTY_KEY) {
+          r = glx_row_of(a.own_map, id);
+          out = r >= 0 ? (int32_t)r : -1;
+          ++n_own;
+        } else {
+          ++n_cold;
+          uint64_t h = glx_mix64((uint64_t)id) & a.tmask;
+          int probes = 0;
+          while (true) {
+            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&a.tkeys[h]),
+                                                      (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)id);
+            if ((int64_t)prev == GLX_EMPTY_KEY) {
+              winner = true;
+              out = -(int32_t)h - 2;
+              break;
+            }
+            if ((int64_t)prev == id) {
+              out = -(int32_t)h - 2;
+              break;
+            }
+            h = (h + 1) & a.tmask;
+            if (++probes > kMaxProbe) {  // the set is too small: the host retries with a larger one
+              a.ctr[2 * a.P] = 1;
+              out = -1;
+              break;
+            }
+          }
+        }
+      }
+      a.loc[i] = out;
+    }
+    // one atomic per (wave, owner) for the new distinct ids
+    uint64_t pending = __ballot(winner);
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      const int32_t o = __shfl(owner, leader);
+      const uint64_t same = __ballot(winner && owner == o);
+      if (lane == leader) atomicAdd(&a.ctr[o], __popcll(same));
+      pending &= ~same;
+    }
+  }
+  atomicAdd(&s_stat[0], n_hit);
+  atomicAdd(&s_stat[1], n_own);
+  atomicAdd(&s_stat[2], n_cold);
+  __syncthreads();
+  if (threadIdx.x < 3 && s_stat[threadIdx.x]) atomicAdd(&a.ctr[2 * a.P + 1 + threadIdx.x], s_stat[threadIdx.x]);
+}
+
+// Pass 2 (one wave): per-owner offsets, and the values every rank shares:
+// vals[0..P) = ids requested from each owner, [P] overflow, [P+1] distinct total,
+// [P+2..4] replica / own / remote id counts.
+__global__ void glx_dist_offsets_kernel(int32_t* ctr, int32_t P, uint64_t tcap, int64_t* vals) {
+  if (threadIdx.x != 0) return;
+  int32_t* off = ctr + 2 * P + 4;
+  int32_t total = 0;
+  for (int32_t p = 0; p < P; ++p) {
+    off[p] = total;
+    vals[p] = ctr[p];
+    total += ctr[p];
+    ctr[P + p] = 0;
+  }
+  off[P] = total;
+  vals[P] = ctr[2 * P];
+  vals[P + 1] = total;
+  vals[P + 2] = ctr[2 * P + 1];
+  vals[P + 3] = ctr[2 * P + 2];
+  vals[P + 4] = ctr[2 * P + 3];
+  (void)tcap;
+}
+
+// Pass 3: compact the set into per-owner buckets (the ids each owner is asked for) and give
+// every member its halo row = position in that concatenation.
+__global__ __launch_bounds__(256) void glx_dist_assign_kernel(const int64_t* __restrict__ tkeys, uint64_t tcap,
+                                                              int32_t* __restrict__ tvals, int32_t* ctr, int32_t P,
+                                                              int64_t* __restrict__ cold_ids) {
+  const int lane = threadIdx.x & 63;
+  int32_t* cursor = ctr + P;
+  const int32_t* off = ctr + 2 * P + 4;
+  for (uint64_t base = blockIdx.x * 256ull; base < tcap; base += gridDim.x * 256ull) {
+    const uint64_t h = base + threadIdx.x;
+    const int64_t key = h < tcap ? tkeys[h] : GLX_EMPTY_KEY;
+    const bool live = key != GLX_EMPTY_KEY;
+    const int32_t owner = live ? dist_owner(key, P) : 0;
+    uint64_t pending = __ballot(live);
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      const int32_t o = __shfl(owner, leader);
+      const uint64_t same = __ballot(live && owner == o);
+      int32_t start = 0;
+      if (lane == leader) start = atomicAdd(&cursor[o], __popcll(same));
+      start = __shfl(start, leader);
+      if (live && owner == o) {
+        const int32_t pos = off[o] + start + __popcll(same & ((1ull << lane) - 1ull));
+        tvals[h] = pos;
+        cold_ids[pos] = key;
+      }
+      pending &= ~same;
+    }
+  }
+}
+
+// Pass 4: pending entries -> halo virtual rows.
+__global__ void glx_dist_finalize_kernel(int32_t* __restrict__ loc, int64_t n, const int32_t* __restrict__ tvals,
+                                         int32_t halo_base) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = loc[i];
+  if (v <= -2) loc[i] = halo_base + tvals[-(v + 2)];
+}
+
+__global__ void glx_dist_fill_keys_kernel(int64_t* keys, uint64_t cap) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) keys[i] = GLX_EMPTY_KEY;
+}
+
+// LookupNodes over resolved virtual rows: G lanes per output row.
+struct GatherArgs {
+  GlxRowSource src[3];
+  int32_t base1, base2;
+  const int32_t* vrows;
+  int64_t n;
+  int32_t dim;
+  float default_attr;
+  float* out;
+};
+__global__ __launch_bounds__(256) void glx_dist_gather_rows_kernel(GatherArgs a, int G) {
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int c = threadIdx.x % G;
+  if (gid >= a.n) return;
+  const int32_t row = a.vrows[gid];
+  const float* src = nullptr;
+  if (row >= 0) {
+    if (row < a.base1) src = a.src[0].X + glx_swizzle_row(row, a.src[0].swizzle_rows) * a.src[0].stride;
+    else if (row < a.base2) src = a.src[1].X + glx_swizzle_row(row - a.base1, a.src[1].swizzle_rows) * a.src[1].stride;
+    else src = a.src[2].X + (int64_t)(row - a.base2) * a.src[2].stride;
+  }
+  float* o = a.out + gid * (int64_t)a.dim;
+  for (int32_t col = c; col < a.dim; col += G) o[col] = src ? src[col] : a.default_attr;
+}
+
+// Replica build: an id its owner does not know must stay unknown (a request's own
+// default_attr applies to it), so it is withheld from the replica's id map.
+__global__ void glx_dist_known_kernel(GlxIdMap map, const int64_t* __restrict__ ids, int64_t n,
+                                      int64_t* __restrict__ known) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) known[i] = glx_row_of(map, ids[i]) >= 0 ? 1 : 0;
+}
+__global__ void glx_dist_mask_ids_kernel(int64_t* __restrict__ ids, const int64_t* __restrict__ known, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && !known[i]) ids[i] = GLX_EMPTY_KEY;
+}
+
+inline unsigned grid_for(int64_t n, int64_t cap = 4096) {
+  int64_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b < cap ? b : cap);
+}
+
+inline uint64_t pow2_at_least(uint64_t x) {
+  uint64_t c = 1;
+  while (c < x) c <<= 1;
+  return c;
+}
+
+#define GLX_ROCPRIM(call)                                             \
+  do {                                                                \
+    size_t bytes__ = 0;                                               \
+    GLX_HIP(call(nullptr, bytes__));                                  \
+    GlxTemp tmp__;                                                    \
+    GLX_HIP(hipMalloc(&tmp__.p, bytes__ ? bytes__ : 16));             \
+    GLX_HIP(call(tmp__.p, bytes__));                                  \
+    GLX_HIP(hipStreamSynchronize(s)); /* tmp__ is freed right after */ \
+  } while (0)
+
+__global__ void glx_dist_extract_nbr_kernel(const GlxAdj* __restrict__ adj, int64_t n, int64_t* __restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = adj[i].nbr;
+}
+
+}  // namespace
+
+struct glx_dist_store {
+  glx_comm* comm = nullptr;
+  const glx_graph* graph = nullptr;
+  const glx_features* feats = nullptr;
+  glx_features* cache = nullptr;
+  int device = 0, rank = 0, world = 1;
+  bool shortcut = true;  // world == 1: call the local operator directly
+  Arena req, recv, tab, halo;
+  int64_t* d_vals = nullptr;  // [world + 8] values shared by the count exchange
+  int32_t* d_ctr = nullptr;   // [3 * world + 8] counter block of the resolve passes
+  int64_t last_distinct = 0;
+  glx_dist_stats stats;
+  std::vector<int64_t> h_mat;
+};
+
+namespace {
+
+struct Routing {
+  std::vector<int64_t> send_counts, send_offs, recv_counts, recv_offs;
+  int64_t n_send = 0, n_recv = 0;
+};
+
+// h_mat[q * nvals + p] (p < P) = elements rank q sends to rank p.
+void routing_from_matrix(const glx_dist_store* st, int nvals, Routing* r) {
+  const int P = st->world, me = st->rank;
+  r->send_counts.assign(P, 0);
+  r->recv_counts.assign(P, 0);
+  r->send_offs.assign(P + 1, 0);
+  r->recv_offs.assign(P + 1, 0);
+  for (int p = 0; p < P; ++p) {
+    r->send_counts[p] = st->h_mat[(size_t)me * nvals + p];
+    r->recv_counts[p] = st->h_mat[(size_t)p * nvals + me];
+    r->send_offs[p + 1] = r->send_offs[p] + r->send_counts[p];
+    r->recv_offs[p + 1] = r->recv_offs[p] + r->recv_counts[p];
+  }
+  r->n_send = r->send_offs[P];
+  r->n_recv = r->recv_offs[P];
+}
+
+// Result of routing a request's ids to their rows: loc[n] virtual rows + the row sources.
+struct Resolved {
+  const int32_t* loc = nullptr;
+  GlxRowSource src[3];
+};
+
+// Shared front half of glx_dist_aggregate / glx_dist_lookup: resolve ids, dedup the cold
+// remote ones, fetch their rows from the owners.  d_ids is a device pointer.
+int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float default_attr, hipStream_t s,
+                      Resolved* out) {
+  const glx_features* f = st->feats;
+  const int P = st->world, me = st->rank;
+  const int32_t dim = f->dim;
+  const int64_t n_own = f->num_rows, n_cache = st->cache ? st->cache->num_rows : 0;
+  GLX_REQUIRE(n_own + n_cache + n < (int64_t)INT32_MAX, "virtual row space exceeds int32");
+  GLX_REQUIRE(n < ((int64_t)1 << 29), "a partitioned request is limited to 2^29 ids");
+  glx_dist_stats& stat = st->stats;
+  memset(&stat, 0, sizeof(stat));
+  stat.ids = n;
+
+  const int nvals = P + 6;  // + the requester's default_attr (what its unknown ids look like)
+  // request-sized buffers: loc[n] (int32) + cold_ids[n] (int64; at most n distinct)
+  Carver cv;
+  const size_t o_loc = cv.take((size_t)(n > 0 ? n : 1) * 4);
+  const size_t o_cold = cv.take((size_t)(n > 0 ? n : 1) * 8);
+  int rc = st->req.ensure(cv.at);
+  if (rc != GLX_OK) return rc;
+  int32_t* loc = reinterpret_cast<int32_t*>(st->req.p + o_loc);
+  int64_t* cold_ids = reinterpret_cast<int64_t*>(st->req.p + o_cold);
+
+  // Set of distinct halo ids: sized from the previous request (the cold tail is a small
+  // fraction of a power-law request), grown to the safe bound 2n when it overflows.
+  const uint64_t safe_cap = pow2_at_least((uint64_t)(n > 0 ? n : 1) * 2);
+  uint64_t tcap = P == 1 ? 64 : pow2_at_least((uint64_t)(st->last_distinct > 4096 ? st->last_distinct : 4096) * 4);
+  if (tcap > safe_cap) tcap = safe_cap;
+  bool first = true, mine_overflow = false;
+  int64_t* tkeys = nullptr;
+  int32_t* tvals = nullptr;
+  while (true) {
+    if (first || mine_overflow) {
+      if (mine_overflow) tcap = safe_cap;
+      rc = st->tab.ensure((size_t)tcap * 12 + 256);
+      if (rc != GLX_OK) return rc;
+      tkeys = reinterpret_cast<int64_t*>(st->tab.p);
+      tvals = reinterpret_cast<int32_t*>(st->tab.p + (((size_t)tcap * 8 + 255) & ~(size_t)255));
+      glx_dist_fill_keys_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap);
+      GLX_HIP(hipMemsetAsync(st->d_ctr, 0, (size_t)(3 * P + 8) * 4, s));
+      ResolveArgs a;
+      a.cache_map = st->cache ? st->cache->map() : GlxIdMap{nullptr, nullptr, 0, 0};
+      a.own_map = f->map();
+      a.ids = d_ids;
+      a.n = n;
+      a.loc = loc;
+      a.tkeys = tkeys;
+      a.tmask = tcap - 1;
+      a.ctr = st->d_ctr;
+      a.P = P;
+      a.me = me;
+      a.cache_base = (int32_t)n_own;
+      a.has_cache = st->cache != nullptr;
+      if (n > 0) glx_dist_resolve_kernel<<<grid_for(n), 256, 0, s>>>(a);
+      glx_dist_offsets_kernel<<<1, 64, 0, s>>>(st->d_ctr, P, tcap, st->d_vals);
+      ReqParams prm;
+      memset(&prm, 0, sizeof(prm));
+      memcpy(&prm.v[0], &default_attr, sizeof(float));
+      glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P + 5, prm, 1);
+      if (P > 1 && n > 0) {
+        glx_dist_assign_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap, tvals, st->d_ctr, P, cold_ids);
+        glx_dist_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(loc, n, tvals,
+                                                                              (int32_t)(n_own + n_cache));
+      }
+      GLX_HIP(hipGetLastError());
+    }
+    first = false;
+    st->h_mat.resize((size_t)P * nvals);
+    rc = st->comm->allgather_i64(st->d_vals, nvals, st->h_mat.data(), s);  // the one host sync
+    if (rc != GLX_OK) return rc;
+    bool any = false;
+    for (int q = 0; q < P; ++q) any = any || st->h_mat[(size_t)q * nvals + P] != 0;
+    mine_overflow = st->h_mat[(size_t)me * nvals + P] != 0;
+    if (!any) break;
+    GLX_REQUIRE(!(mine_overflow && tcap >= safe_cap), "halo id set overflowed at its safe size (internal error)");
+  }
+  const int64_t* mine = &st->h_mat[(size_t)me * nvals];
+  const int64_t U = mine[P + 1];
+  st->last_distinct = U;
+  stat.remote_distinct = U;
+  stat.from_replica = mine[P + 2];
+  stat.from_own_shard = mine[P + 3];
+  stat.remote = mine[P + 4];
+
+  Routing rt;
+  routing_from_matrix(st, nvals, &rt);
+  const int64_t m = rt.n_recv;  // rows this rank serves to its peers
+  stat.served_rows = m;
+  float* halo = nullptr;
+  if (P > 1) {
+    // receive-sized: ids_in[m] + rows_loc[m, dim]; halo[U, dim] lives in its own arena
+    Carver cr;
+    const size_t o_ids = cr.take((size_t)(m > 0 ? m : 1) * 8);
+    const size_t o_rows = cr.take((size_t)(m > 0 ? m : 1) * dim * 4);
+    rc = st->recv.ensure(cr.at);
+    if (rc == GLX_OK) rc = st->halo.ensure((size_t)(U > 0 ? U : 1) * dim * 4);
+    if (rc != GLX_OK) return rc;
+    int64_t* ids_in = reinterpret_cast<int64_t*>(st->recv.p + o_ids);
+    float* rows_loc = reinterpret_cast<float*>(st->recv.p + o_rows);
+    halo = reinterpret_cast<float*>(st->halo.p);
+    GlxSeg seg_ids{cold_ids, ids_in, 8};
+    rc = st->comm->alltoallv(&seg_ids, 1, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
+                             rt.recv_offs.data(), s);
+    if (rc != GLX_OK) return rc;
+    // gather for every requester with ITS default row for unknown ids
+    bool same_default = true;
+    for (int q = 0; q < P; ++q) same_default = same_default && st->h_mat[(size_t)q * nvals + P + 5] == mine[P + 5];
+    for (int q = 0; q < (same_default ? 1 : P); ++q) {
+      const int64_t begin = same_default ? 0 : rt.recv_offs[q];
+      const int64_t cnt = same_default ? m : rt.recv_counts[q];
+      float dq = default_attr;
+      if (!same_default) memcpy(&dq, &st->h_mat[(size_t)q * nvals + P + 5], sizeof(float));
+      if (cnt > 0) {
+        rc = glx_lookup(f, ids_in + begin, cnt, dq, rows_loc + begin * dim, GLX_PTR_DEVICE, s);
+        if (rc != GLX_OK) return rc;
+      }
+    }
+    GlxSeg seg_rows{rows_loc, halo, (size_t)dim * 4};
+    rc = st->comm->alltoallv(&seg_rows, 1, rt.recv_counts.data(), rt.recv_offs.data(), rt.send_counts.data(),
+                             rt.send_offs.data(), s);
+    if (rc != GLX_OK) return rc;
+    stat.exchange_rounds = st->comm->last_rounds;
+    const int64_t self_ids = rt.send_counts[me];  // always 0: own ids never enter the halo set
+    stat.bytes_sent = (rt.n_send - self_ids) * 8 + (m - rt.recv_counts[me]) * (int64_t)dim * 4;
+    stat.bytes_received = (m - rt.recv_counts[me]) * 8 + (rt.n_send - self_ids) * (int64_t)dim * 4;
+  }
+  out->loc = loc;
+  out->src[0] = GlxRowSource{f->X, f->stride, f->swizzle_rows, n_own};
+  out->src[1] = st->cache ? GlxRowSource{st->cache->X, st->cache->stride, st->cache->swizzle_rows, n_cache}
+                          : GlxRowSource{nullptr, dim, 0, 0};
+  out->src[2] = GlxRowSource{U > 0 ? halo : nullptr, dim, 0, U};
+  return GLX_OK;
+}
+
+int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int32_t batch, int32_t k,
+                       int padding_mode, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                       const glx_filter* filter, int64_t* nbr_out, int64_t* eid_out, hipStream_t s) {
+  const int P = st->world;
+  const bool filtered = filter != nullptr && filter->type != GLX_FILTER_NONE;
+  if (P == 1 && st->shortcut) {
+    return glx_sample_filtered(st->graph, sampler, src, nullptr, batch, k, padding_mode, default_neighbor_id, seed,
+                               call_counter, filter, nbr_out, eid_out, GLX_PTR_DEVICE, s);
+  }
+  const int64_t n = batch;
+  Carver cv;
+  const size_t o_buck = cv.take((size_t)(n > 0 ? n : 1) * 8);
+  const size_t o_ord = cv.take((size_t)(n > 0 ? n : 1) * 8);
+  const size_t o_val = cv.take(filtered ? (size_t)(n > 0 ? n : 1) * 8 : 0);
+  const size_t o_nb = cv.take((size_t)(n > 0 ? n : 1) * k * 8);
+  const size_t o_eb = cv.take((size_t)(n > 0 ? n : 1) * k * 8);
+  int rc = st->req.ensure(cv.at);
+  if (rc != GLX_OK) return rc;
+  int64_t* bucketed = reinterpret_cast<int64_t*>(st->req.p + o_buck);
+  int64_t* order = reinterpret_cast<int64_t*>(st->req.p + o_ord);
+  int64_t* vals_b = filtered ? reinterpret_cast<int64_t*>(st->req.p + o_val) : nullptr;
+  int64_t* nbr_back = reinterpret_cast<int64_t*>(st->req.p + o_nb);
+  int64_t* eid_back = reinterpret_cast<int64_t*>(st->req.p + o_eb);
+
+  rc = glx_partition(st->device, src, n, P, bucketed, order, st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  if (filtered && n > 0) {
+    // every row's filter value travels with its id (HashPartitioner copies every tensor of a
+    // request: hash_partitioner.h:69-74)
+    glx_dist_gather_i64_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(filter->values, order, n, vals_b);
+  }
+  constexpr int kParams = 10;
+  ReqParams mine;
+  memset(&mine, 0, sizeof(mine));
+  mine.v[0] = (int64_t)seed;
+  mine.v[1] = (int64_t)call_counter;
+  mine.v[2] = k;
+  mine.v[3] = sampler;
+  mine.v[4] = padding_mode;
+  mine.v[5] = default_neighbor_id;
+  mine.v[6] = filtered ? filter->type : GLX_FILTER_NONE;
+  mine.v[7] = filtered ? filter->field : GLX_FILTER_FIELD_NONE;
+  mine.v[8] = filtered ? filter->retry_times : 0;
+  mine.v[9] = filtered ? filter->default_timestamp : 0;
+  glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P, mine, kParams);
+  const int nvals = P + kParams;
+  st->h_mat.resize((size_t)P * nvals);
+  rc = st->comm->allgather_i64(st->d_vals, nvals, st->h_mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  Routing rt;
+  routing_from_matrix(st, nvals, &rt);
+  const int64_t m = rt.n_recv;
+  GLX_REQUIRE(m <= INT32_MAX, "more than 2^31 request rows arrived at one shard");
+  bool uniform = true;
+  for (int q = 0; q < P; ++q) {
+    const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
+    // the response width and the set of tensors that travel are part of the exchange's shape
+    GLX_REQUIRE(pq[2] == k, "rank %d asks for neighbor_count %lld, this rank for %d: one collective, one count", q,
+                (long long)pq[2], k);
+    GLX_REQUIRE((pq[6] != GLX_FILTER_NONE) == filtered, "rank %d and this rank disagree on whether the request has a filter",
+                q);
+    for (int j = 0; j < kParams; ++j) uniform = uniform && pq[j] == mine.v[j];
+  }
+
+  Carver cr;
+  const size_t o_ids = cr.take((size_t)(m > 0 ? m : 1) * 8);
+  const size_t o_rows = cr.take((size_t)(m > 0 ? m : 1) * 8);
+  const size_t o_vin = cr.take(filtered ? (size_t)(m > 0 ? m : 1) * 8 : 0);
+  const size_t o_nl = cr.take((size_t)(m > 0 ? m : 1) * k * 8);
+  const size_t o_el = cr.take((size_t)(m > 0 ? m : 1) * k * 8);
+  rc = st->recv.ensure(cr.at);
+  if (rc != GLX_OK) return rc;
+  int64_t* ids_in = reinterpret_cast<int64_t*>(st->recv.p + o_ids);
+  int64_t* rows_in = reinterpret_cast<int64_t*>(st->recv.p + o_rows);
+  int64_t* vals_in = filtered ? reinterpret_cast<int64_t*>(st->recv.p + o_vin) : nullptr;
+  int64_t* nbr_loc = reinterpret_cast<int64_t*>(st->recv.p + o_nl);
+  int64_t* eid_loc = reinterpret_cast<int64_t*>(st->recv.p + o_el);
+
+  GlxSeg out_segs[3] = {{bucketed, ids_in, 8}, {order, rows_in, 8}, {vals_b, vals_in, 8}};
+  rc = st->comm->alltoallv(out_segs, filtered ? 3 : 2, rt.send_counts.data(), rt.send_offs.data(),
+                           rt.recv_counts.data(), rt.recv_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+
+  // Process on the owner: rows draw from the random stream of their ORIGINAL index, with their
+  // requester's seed / call counter / flags.  One launch when every rank sent the same
+  // parameters (SPMD lockstep), else one per requester.
+  const int64_t chunk = k > 0 ? (int64_t)INT32_MAX / k : (m > 0 ? m : 1);
+  for (int q = 0; q < (uniform ? 1 : P); ++q) {
+    const int64_t begin = uniform ? 0 : rt.recv_offs[q];
+    const int64_t end = uniform ? m : rt.recv_offs[q + 1];
+    const int64_t* pq = &st->h_mat[(size_t)(uniform ? st->rank : q) * nvals + P];
+    for (int64_t lo = begin; lo < end; lo += chunk) {
+      const int64_t cnt = end - lo < chunk ? end - lo : chunk;
+      glx_filter part;
+      const glx_filter* fp = nullptr;
+      if (filtered) {
+        part.type = (int32_t)pq[6];
+        part.field = (int32_t)pq[7];
+        part.retry_times = (int32_t)pq[8];
+        part.default_timestamp = pq[9];
+        part.values = vals_in + lo;
+        fp = &part;
+      }
+      rc = glx_sample_filtered(st->graph, (int)pq[3], ids_in + lo, rows_in + lo, (int32_t)cnt, k, (int)pq[4], pq[5],
+                               (uint64_t)pq[0], (uint64_t)pq[1], fp, nbr_loc + lo * k, eid_loc + lo * k,
+                               GLX_PTR_DEVICE, s);
+      if (rc != GLX_OK) return rc;
+    }
+  }
+  GlxSeg back_segs[2] = {{nbr_loc, nbr_back, (size_t)k * 8}, {eid_loc, eid_back, (size_t)k * 8}};
+  rc = st->comm->alltoallv(back_segs, 2, rt.recv_counts.data(), rt.recv_offs.data(), rt.send_counts.data(),
+                           rt.send_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  if (n > 0 && k > 0) {
+    const int64_t total = n * k;
+    glx_dist_stitch2_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(nbr_back, eid_back, order, n, k,
+                                                                            nbr_out, eid_out);
+    GLX_HIP(hipGetLastError());
+  }
+  return GLX_OK;
+}
+
+int check_store(const glx_dist_store* st, int ptr_kind) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
+  return GLX_OK;
+}
+
+}  // namespace
+
+extern "C" int glx_dist_store_create(glx_comm* comm, const glx_graph* graph, const glx_features* features,
+                                     glx_dist_store** out) {
+  GLX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  GLX_REQUIRE(comm != nullptr, "comm is NULL");
+  GLX_REQUIRE(graph != nullptr || features != nullptr, "a store needs a graph shard, a feature shard or both");
+  GLX_REQUIRE(!graph || graph->device == comm->device, "the graph shard lives on device %d, the communicator on %d",
+              graph ? graph->device : -1, comm->device);
+  GLX_REQUIRE(!features || features->device == comm->device,
+              "the feature shard lives on device %d, the communicator on %d", features ? features->device : -1,
+              comm->device);
+  GLX_REQUIRE(comm->world <= kMaxWorld, "world size above %d", kMaxWorld);
+  GlxDeviceGuard guard(comm->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", comm->device);
+  glx_dist_store* st = new (std::nothrow) glx_dist_store();
+  GLX_REQUIRE(st != nullptr, "out of host memory");
+  st->comm = comm;
+  st->graph = graph;
+  st->feats = features;
+  st->device = comm->device;
+  st->rank = comm->rank;
+  st->world = comm->world;
+  if (const char* e = getenv("GLX_DIST_NO_SHORTCUT")) st->shortcut = atoi(e) == 0;
+  memset(&st->stats, 0, sizeof(st->stats));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&st->d_vals), (size_t)(st->world + 16) * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->d_ctr), (size_t)(3 * st->world + 8) * 4);
+  if (e != hipSuccess) {
+    glx_dist_store_destroy(st);
+    GLX_HIP(e);
+  }
+  *out = st;
+  return GLX_OK;
+}
+
+extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
+  if (!st) return;
+  GlxDeviceGuard guard(st->device);
+  (void)hipDeviceSynchronize();
+  st->req.release();
+  st->recv.release();
+  st->tab.release();
+  st->halo.release();
+  if (st->d_vals) (void)hipFree(st->d_vals);
+  if (st->d_ctr) (void)hipFree(st->d_ctr);
+  if (st->cache) glx_features_destroy(st->cache);
+  delete st;
+}
+
+extern "C" int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out) {
+  GLX_REQUIRE(st != nullptr && out != nullptr, "NULL argument");
+  *out = st->stats;
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* src, int32_t batch, int32_t k,
+                               int padding_mode, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                               const glx_filter* filter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+                               void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(batch >= 0 && k >= 0, "negative batch / neighbor_count");
+  GLX_REQUIRE(padding_mode == GLX_PAD_CIRCULAR || padding_mode == GLX_PAD_REPLICATE, "bad padding_mode %d",
+              padding_mode);
+  GLX_REQUIRE((int64_t)batch * k <= INT32_MAX, "batch * neighbor_count exceeds int32 (tensor.h:47)");
+  GLX_REQUIRE(batch == 0 || k == 0 || (src && nbr_out && eid_out), "NULL data pointer");
+  const bool filtered = filter != nullptr && filter->type != GLX_FILTER_NONE;
+  GLX_REQUIRE(!filtered || batch == 0 || filter->values != nullptr, "filter without values");
+  // InDegreeSampler weighs a neighbour by its in-degree over ALL shards; a shard's tables
+  // (glx_graph_enable_in_degree) only count the edges it owns.
+  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || st->world == 1,
+              "InDegreeSampler is not served by a partitioned store: a shard's in-degree tables cover its own "
+              "edges only");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    return dist_sample_device(st, sampler, src, batch, k, padding_mode, default_neighbor_id, seed, call_counter,
+                              filter, nbr_out, eid_out, glx_stream(stream));
+  }
+  hipStream_t s = glx_host_call_stream(stream, st->device);
+  const size_t n_out = (size_t)batch * k;
+  GlxTemp d;
+  GLX_HIP(hipMalloc(&d.p, ((size_t)batch * 2 + 2 * n_out + 4) * 8));
+  int64_t* d_src = d.as<int64_t>();
+  int64_t* d_val = d_src + batch;
+  int64_t* d_nbr = d_val + batch;
+  int64_t* d_eid = d_nbr + n_out;
+  if (batch) GLX_HIP(hipMemcpyAsync(d_src, src, (size_t)batch * 8, hipMemcpyHostToDevice, s));
+  glx_filter dev_filter;
+  const glx_filter* fp = nullptr;
+  if (filtered) {
+    if (batch) GLX_HIP(hipMemcpyAsync(d_val, filter->values, (size_t)batch * 8, hipMemcpyHostToDevice, s));
+    dev_filter = *filter;
+    dev_filter.values = d_val;
+    fp = &dev_filter;
+  }
+  rc = dist_sample_device(st, sampler, d_src, batch, k, padding_mode, default_neighbor_id, seed, call_counter, fp,
+                          d_nbr, d_eid, s);
+  hipError_t e = hipSuccess;
+  if (rc == GLX_OK && n_out) {
+    e = hipMemcpyAsync(nbr_out, d_nbr, n_out * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(eid_out, d_eid, n_out * 8, hipMemcpyDeviceToHost, s);
+  }
+  hipError_t e2 = hipStreamSynchronize(s);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(e);
+  GLX_HIP(e2);
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,
+                                  int32_t num_ids, int32_t num_segments, float default_attr, float* emb_out,
+                                  int32_t* cnt_out, int ptr_kind, void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->feats != nullptr, "this store has no feature shard");
+  GLX_REQUIRE(op >= GLX_AGG_SUM && op <= GLX_AGG_PROD, "unknown aggregator id %d", op);
+  GLX_REQUIRE(num_ids >= 0 && num_segments >= 0, "negative sizes");
+  GLX_REQUIRE((int64_t)num_segments * st->feats->dim <= INT32_MAX, "num_segments * dim exceeds int32 (tensor.h:47)");
+  GLX_REQUIRE(num_segments == 0 || (emb_out && cnt_out), "NULL output pointer");
+  GLX_REQUIRE(num_ids == 0 || node_ids, "NULL data pointer");
+  GLX_REQUIRE(segment_ids != nullptr || num_segments == 0 || num_ids % num_segments == 0,
+              "segment_ids == NULL means equal segments: num_ids must be a multiple of num_segments");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  const glx_features* f = st->feats;
+  if (st->world == 1 && st->shortcut && st->cache == nullptr) {
+    return glx_aggregate(f, op, node_ids, segment_ids, num_ids, num_segments, default_attr, emb_out, cnt_out,
+                         ptr_kind, stream);
+  }
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  const int64_t* d_ids = node_ids;
+  const int32_t* d_seg = segment_ids;
+  float* d_emb = emb_out;
+  int32_t* d_cnt = cnt_out;
+  GlxTemp stage;
+  const size_t emb_n = (size_t)num_segments * f->dim;
+  if (ptr_kind == GLX_PTR_HOST) {
+    const size_t emb_b = (emb_n * 4 + 255) & ~(size_t)255;
+    const size_t ids_b = ((size_t)num_ids * 8 + 255) & ~(size_t)255;
+    const size_t seg_b = ((size_t)num_ids * 4 + 255) & ~(size_t)255;
+    GLX_HIP(hipMalloc(&stage.p, emb_b + ids_b + seg_b + (size_t)num_segments * 4 + 256));
+    char* b = stage.as<char>();
+    d_emb = reinterpret_cast<float*>(b);
+    int64_t* ids_w = reinterpret_cast<int64_t*>(b + emb_b);
+    int32_t* seg_w = reinterpret_cast<int32_t*>(b + emb_b + ids_b);
+    d_cnt = reinterpret_cast<int32_t*>(b + emb_b + ids_b + seg_b);
+    if (num_ids) GLX_HIP(hipMemcpyAsync(ids_w, node_ids, (size_t)num_ids * 8, hipMemcpyHostToDevice, s));
+    if (num_ids && segment_ids) {
+      GLX_HIP(hipMemcpyAsync(seg_w, segment_ids, (size_t)num_ids * 4, hipMemcpyHostToDevice, s));
+    }
+    d_ids = ids_w;
+    d_seg = segment_ids ? seg_w : nullptr;
+  }
+  Resolved rs;
+  rc = resolve_and_fetch(st, d_ids, num_ids, default_attr, s, &rs);
+  if (rc == GLX_OK && num_segments > 0) {
+    rc = glx_aggregate_vrows_device(rs.src, 3, f->dim, op, rs.loc, d_seg, num_ids, num_segments, default_attr, d_emb,
+                                    d_cnt, s);
+  }
+  if (ptr_kind == GLX_PTR_HOST) {
+    hipError_t e = hipSuccess;
+    if (rc == GLX_OK && num_segments > 0) {
+      e = hipMemcpyAsync(emb_out, d_emb, emb_n * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(cnt_out, d_cnt, (size_t)num_segments * 4, hipMemcpyDeviceToHost, s);
+    }
+    hipError_t e2 = hipStreamSynchronize(s);
+    if (rc != GLX_OK) return rc;
+    GLX_HIP(e);
+    GLX_HIP(e2);
+  }
+  return rc;
+}
+
+extern "C" int glx_dist_lookup(glx_dist_store* st, const int64_t* node_ids, int64_t n, float default_attr,
+                               float* out, int ptr_kind, void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->feats != nullptr, "this store has no feature shard");
+  GLX_REQUIRE(n >= 0 && n < INT32_MAX, "bad n");
+  GLX_REQUIRE(n == 0 || (node_ids && out), "NULL data pointer");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  const glx_features* f = st->feats;
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  const int64_t* d_ids = node_ids;
+  float* d_out = out;
+  GlxTemp stage;
+  const size_t out_b = (size_t)n * f->dim * 4;
+  if (ptr_kind == GLX_PTR_HOST) {
+    GLX_HIP(hipMalloc(&stage.p, ((out_b + 255) & ~(size_t)255) + (size_t)n * 8 + 256));
+    d_out = stage.as<float>();
+    int64_t* ids_w = reinterpret_cast<int64_t*>(stage.as<char>() + ((out_b + 255) & ~(size_t)255));
+    if (n) GLX_HIP(hipMemcpyAsync(ids_w, node_ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    d_ids = ids_w;
+  }
+  Resolved rs;
+  rc = resolve_and_fetch(st, d_ids, n, default_attr, s, &rs);
+  if (rc == GLX_OK && n > 0) {
+    GatherArgs g;
+    for (int j = 0; j < 3; ++j) g.src[j] = rs.src[j];
+    g.base1 = (int32_t)rs.src[0].rows;
+    g.base2 = (int32_t)(rs.src[0].rows + rs.src[1].rows);
+    g.vrows = rs.loc;
+    g.n = n;
+    g.dim = f->dim;
+    g.default_attr = default_attr;
+    g.out = d_out;
+    int G = 1;
+    while (G < 64 && G < f->dim) G <<= 1;
+    const int64_t threads = n * G;
+    glx_dist_gather_rows_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(g, G);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+      glx_set_error("gather launch failed: %s", hipGetErrorString(le));
+      rc = GLX_INTERNAL;
+    }
+  }
+  if (ptr_kind == GLX_PTR_HOST) {
+    hipError_t e = hipSuccess;
+    if (rc == GLX_OK && n > 0) e = hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    if (rc != GLX_OK) return rc;
+    GLX_HIP(e);
+    GLX_HIP(e2);
+  }
+  return rc;
+}
+
+// Collective: every rank holds the same hot id list; each fetches its owned rows once and
+// all ranks end up with the same [n, dim] replica (+ id map), in owner-major order.
+extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_ids, int64_t n, float default_attr,
+                                        int ptr_kind, void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->feats != nullptr, "this store has no feature shard");
+  GLX_REQUIRE(n >= 0 && n < INT32_MAX, "bad n");
+  GLX_REQUIRE(n == 0 || hot_ids, "NULL data pointer");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  GLX_HIP(hipStreamSynchronize(s));
+  if (st->cache) {
+    glx_features_destroy(st->cache);
+    st->cache = nullptr;
+  }
+  if (n == 0) return GLX_OK;
+  const glx_features* f = st->feats;
+  const int P = st->world, me = st->rank;
+  const int32_t dim = f->dim;
+  GlxTemp ids_d, bucketed, order, rows_mine, table, known_mine, known_all;
+  const int64_t* d_hot = hot_ids;
+  if (ptr_kind == GLX_PTR_HOST) {
+    GLX_HIP(hipMalloc(&ids_d.p, (size_t)n * 8));
+    GLX_HIP(hipMemcpyAsync(ids_d.p, hot_ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    d_hot = ids_d.as<int64_t>();
+  }
+  GLX_HIP(hipMalloc(&bucketed.p, (size_t)n * 8));
+  GLX_HIP(hipMalloc(&order.p, (size_t)n * 8));
+  rc = glx_partition(st->device, d_hot, n, P, bucketed.as<int64_t>(), order.as<int64_t>(), st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  std::vector<int64_t> counts((size_t)P);
+  GLX_HIP(hipMemcpyAsync(counts.data(), st->d_vals, (size_t)P * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  std::vector<int64_t> offs((size_t)P + 1, 0), same((size_t)P), zero((size_t)P, 0);
+  for (int p = 0; p < P; ++p) offs[p + 1] = offs[p] + counts[p];
+  for (int p = 0; p < P; ++p) same[p] = counts[me];
+  const int64_t c_me = counts[me];
+  GLX_HIP(hipMalloc(&rows_mine.p, (size_t)(c_me > 0 ? c_me : 1) * dim * 4));
+  GLX_HIP(hipMalloc(&table.p, (size_t)n * dim * 4));
+  GLX_HIP(hipMalloc(&known_mine.p, (size_t)(c_me > 0 ? c_me : 1) * 8));
+  GLX_HIP(hipMalloc(&known_all.p, (size_t)n * 8));
+  if (c_me > 0) {
+    rc = glx_lookup(f, bucketed.as<int64_t>() + offs[me], c_me, default_attr, rows_mine.as<float>(), GLX_PTR_DEVICE,
+                    s);
+    if (rc != GLX_OK) return rc;
+    glx_dist_known_kernel<<<(unsigned)((c_me + 255) / 256), 256, 0, s>>>(f->map(), bucketed.as<int64_t>() + offs[me],
+                                                                         c_me, known_mine.as<int64_t>());
+  }
+  // all-gather(v) as an all-to-all whose every outgoing message is the same buffer
+  GlxSeg segs[2] = {{rows_mine.p, table.p, (size_t)dim * 4}, {known_mine.p, known_all.p, 8}};
+  rc = st->comm->alltoallv(segs, 2, same.data(), zero.data(), counts.data(), offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  glx_dist_mask_ids_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(bucketed.as<int64_t>(), known_all.as<int64_t>(),
+                                                                       n);
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipStreamSynchronize(s));
+  rc = glx_features_create(st->device, n, dim, table.as<float>(), bucketed.as<int64_t>(), GLX_PTR_DEVICE, s,
+                           &st->cache);
+  return rc;
+}
+
+// Collective: global in-degree top-`want` of the store's edge type.
+extern "C" int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_out, int64_t* n_out, void* stream) {
+  GLX_REQUIRE(st != nullptr && ids_out != nullptr && n_out != nullptr, "NULL argument");
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(want >= 0 && want < INT32_MAX, "bad want");
+  *n_out = 0;
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = glx_stream(stream);
+  const glx_graph* g = st->graph;
+  const int P = st->world, me = st->rank;
+  const size_t E = (size_t)g->num_edges;
+
+  // 1. this shard's (destination id, count) pairs: sort + run-length encode
+  GlxTemp keys, sorted, uniq, cnt, nruns;
+  GLX_HIP(hipMalloc(&keys.p, (E ? E : 1) * 8));
+  GLX_HIP(hipMalloc(&sorted.p, (E ? E : 1) * 8));
+  GLX_HIP(hipMalloc(&uniq.p, (E ? E : 1) * 8));
+  GLX_HIP(hipMalloc(&cnt.p, (E ? E : 1) * 8));
+  GLX_HIP(hipMalloc(&nruns.p, 8));
+  int64_t Ul = 0;
+  if (E > 0) {
+    glx_dist_extract_nbr_kernel<<<grid_for((int64_t)E, 8192), 256, 0, s>>>(g->adj, (int64_t)E, keys.as<int64_t>());
+#define SORT(tmp, bytes) rocprim::radix_sort_keys(tmp, bytes, keys.as<int64_t>(), sorted.as<int64_t>(), E, 0, 64, s)
+    GLX_ROCPRIM(SORT);
+#undef SORT
+#define RLE(tmp, bytes)                                                                                        \
+  rocprim::run_length_encode(tmp, bytes, sorted.as<int64_t>(), E, uniq.as<int64_t>(), cnt.as<int64_t>(), \
+                             nruns.as<int64_t>(), s)
+    GLX_ROCPRIM(RLE);
+#undef RLE
+    GLX_HIP(hipMemcpyAsync(&Ul, nruns.p, 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+  }
+  // 2. route every pair to the owner of the destination id
+  GlxTemp buck, ord, cnt_b;
+  GLX_HIP(hipMalloc(&buck.p, (size_t)(Ul ? Ul : 1) * 8));
+  GLX_HIP(hipMalloc(&ord.p, (size_t)(Ul ? Ul : 1) * 8));
+  GLX_HIP(hipMalloc(&cnt_b.p, (size_t)(Ul ? Ul : 1) * 8));
+  int rc = glx_partition(st->device, uniq.as<int64_t>(), Ul, P, buck.as<int64_t>(), ord.as<int64_t>(), st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  if (Ul > 0) {
+    glx_dist_gather_i64_kernel<<<(unsigned)((Ul + 255) / 256), 256, 0, s>>>(cnt.as<int64_t>(), ord.as<int64_t>(), Ul,
+                                                                            cnt_b.as<int64_t>());
+  }
+  st->h_mat.resize((size_t)P * P);
+  rc = st->comm->allgather_i64(st->d_vals, P, st->h_mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  Routing rt;
+  routing_from_matrix(st, P, &rt);
+  const size_t m = (size_t)rt.n_recv;
+  GlxTemp ids_in, cnt_in, ids_s, cnt_s, own_id, own_cnt, nown;
+  GLX_HIP(hipMalloc(&ids_in.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&cnt_in.p, (m ? m : 1) * 8));
+  GlxSeg segs[2] = {{buck.p, ids_in.p, 8}, {cnt_b.p, cnt_in.p, 8}};
+  rc = st->comm->alltoallv(segs, 2, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
+                           rt.recv_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  // 3. owner: total in-degree per owned destination id
+  GLX_HIP(hipMalloc(&ids_s.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&cnt_s.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&own_id.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&own_cnt.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&nown.p, 8));
+  int64_t M = 0;
+  if (m > 0) {
+#define SORTP(tmp, bytes)                                                                                    \
+  rocprim::radix_sort_pairs(tmp, bytes, ids_in.as<int64_t>(), ids_s.as<int64_t>(), cnt_in.as<int64_t>(), \
+                            cnt_s.as<int64_t>(), m, 0, 64, s)
+    GLX_ROCPRIM(SORTP);
+#undef SORTP
+#define REDUCE(tmp, bytes)                                                                                     \
+  rocprim::reduce_by_key(tmp, bytes, ids_s.as<int64_t>(), cnt_s.as<int64_t>(), m, own_id.as<int64_t>(),   \
+                         own_cnt.as<int64_t>(), nown.as<int64_t>(), rocprim::plus<int64_t>(),                \
+                         rocprim::equal_to<int64_t>(), s)
+    GLX_ROCPRIM(REDUCE);
+#undef REDUCE
+    GLX_HIP(hipMemcpyAsync(&M, nown.p, 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+  }
+  // 4. this owner's best `want` (count descending; ids ascending among equals: the input is
+  //    id-sorted and the radix sort is stable)
+  GlxTemp top_cnt, top_id;
+  GLX_HIP(hipMalloc(&top_cnt.p, (size_t)(M ? M : 1) * 8));
+  GLX_HIP(hipMalloc(&top_id.p, (size_t)(M ? M : 1) * 8));
+  if (M > 0) {
+    const size_t Ms = (size_t)M;
+#define SORTD(tmp, bytes)                                                                                         \
+  rocprim::radix_sort_pairs_desc(tmp, bytes, own_cnt.as<int64_t>(), top_cnt.as<int64_t>(), own_id.as<int64_t>(), \
+                                 top_id.as<int64_t>(), Ms, 0, 64, s)
+    GLX_ROCPRIM(SORTD);
+#undef SORTD
+  }
+  const int64_t c_me = M < want ? M : want;
+  // 5. share the candidates: everyone gets every owner's list (rank-major), merges the same way
+  int64_t c_me_copy = c_me;
+  GLX_HIP(hipMemcpyAsync(st->d_vals, &c_me_copy, 8, hipMemcpyHostToDevice, s));
+  std::vector<int64_t> cand((size_t)P);
+  rc = st->comm->allgather_i64(st->d_vals, 1, cand.data(), s);
+  if (rc != GLX_OK) return rc;
+  std::vector<int64_t> offs((size_t)P + 1, 0), same((size_t)P, c_me), zero((size_t)P, 0);
+  for (int p = 0; p < P; ++p) offs[p + 1] = offs[p] + cand[p];
+  const size_t T = (size_t)offs[P];
+  GlxTemp all_cnt, all_id, by_id_cnt, by_id_id, fin_cnt, fin_id;
+  GLX_HIP(hipMalloc(&all_cnt.p, (T ? T : 1) * 8));
+  GLX_HIP(hipMalloc(&all_id.p, (T ? T : 1) * 8));
+  GlxSeg csegs[2] = {{top_cnt.p, all_cnt.p, 8}, {top_id.p, all_id.p, 8}};
+  rc = st->comm->alltoallv(csegs, 2, same.data(), zero.data(), cand.data(), offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  (void)me;
+  if (T == 0) return GLX_OK;
+  GLX_HIP(hipMalloc(&by_id_cnt.p, T * 8));
+  GLX_HIP(hipMalloc(&by_id_id.p, T * 8));
+  GLX_HIP(hipMalloc(&fin_cnt.p, T * 8));
+  GLX_HIP(hipMalloc(&fin_id.p, T * 8));
+#define SORT1(tmp, bytes)                                                                                     \
+  rocprim::radix_sort_pairs(tmp, bytes, all_id.as<int64_t>(), by_id_id.as<int64_t>(), all_cnt.as<int64_t>(), \
+                            by_id_cnt.as<int64_t>(), T, 0, 64, s)
+  GLX_ROCPRIM(SORT1);
+#undef SORT1
+#define SORT2(tmp, bytes)                                                                                            \
+  rocprim::radix_sort_pairs_desc(tmp, bytes, by_id_cnt.as<int64_t>(), fin_cnt.as<int64_t>(), by_id_id.as<int64_t>(), \
+                                 fin_id.as<int64_t>(), T, 0, 64, s)
+  GLX_ROCPRIM(SORT2);
+#undef SORT2
+  const int64_t take = (int64_t)T < want ? (int64_t)T : want;
+  GLX_HIP(hipMemcpyAsync(ids_out, fin_id.p, (size_t)take * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  *n_out = take;
+  return GLX_OK;
+}

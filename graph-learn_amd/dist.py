@@ -26,8 +26,14 @@ Results are bit-identical to the unpartitioned operator for every shard count:
     Prod are re-associated across shards (within 1e-5 relative).  Cheaper than H on
     the wire when the mean segment length exceeds the shard count.
 
-`ops` abstracts the local compute: DeviceOps (HIP, the product) or, in the CPU
-tests only, an oracle-backed stand-in.  Tensors are torch tensors throughout.
+Where things run.  On GPUs (`ops` = DeviceOps) sampling, design H and LookupNodes are ONE
+call into the C distributed store (include/glx.h glx_dist_*, csrc/glx_dist.hip): partition,
+RCCL send/recv groups (csrc/glx_comm.hip), the owner's kernel and the stitch all happen
+behind the C-ABI, and this class is a thin binding.  Design H there also keeps a replica of
+hot rows on every GPU (`hot_ids`) and exchanges only the deduplicated cold tail.  The Python
+orchestration below is the same protocol spelled out over torch.distributed: it is what the
+CPU tests run (world size 2/3 over gloo with an oracle-backed `ops`), and it still carries
+design R on GPUs.  Tensors are torch tensors throughout.
 """
 import torch
 import torch.distributed as dist
@@ -35,6 +41,8 @@ import torch.distributed as dist
 
 class DeviceOps:
     """Local compute on this rank's GPU through the glx C-ABI."""
+
+    native = True  # ShardedStore hands sampling / design H / lookup to the C distributed store
 
     def __init__(self):
         import glx
@@ -129,21 +137,88 @@ def _a2a(x, send_counts, recv_counts, group, bound):
     return out
 
 
+def comm_for_group(group=None, device=0):
+    """A glx communicator with the ranks of a torch.distributed group: RCCL (unique id made by
+    rank 0, handed out through the group) when the group's backend is nccl; for gloo -- ranks
+    that cannot run RCCL together, e.g. several ranks sharing one GPU in the test rig -- the
+    host-staged transport with the group's own all-to-all / all-gather behind it."""
+    import glx
+    import numpy as np
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) != "gloo":
+        box = [glx.Comm.unique_id() if rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group, device=torch.device("cuda", device))
+        return glx.Comm.rccl(device, rank, world, box[0])
+
+    def a2a(send, send_counts, recv, recv_counts, eb):
+        out = torch.from_numpy(recv)
+        dist.all_to_all_single(out, torch.from_numpy(send), output_split_sizes=[int(c) * eb for c in recv_counts],
+                               input_split_sizes=[int(c) * eb for c in send_counts], group=group)
+
+    def gather(send, recv):
+        parts = list(torch.from_numpy(recv).view(world, -1).unbind(0))
+        dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(send)), group=group)
+    return glx.Comm.callbacks(device, rank, world, a2a, gather)
+
+
 class ShardedStore:
     """One rank's view of an edge-cut partitioned graph + feature store."""
 
-    def __init__(self, ops, graph_shard, feature_shard=None, group=None, feature_replica=None):
+    def __init__(self, ops, graph_shard, feature_shard=None, group=None, feature_replica=None, comm=None,
+                 hot_ids=None):
         """feature_shard: this rank's rows (halo exchange per request, design H);
         feature_replica: a full copy of the feature table on this GPU (built once by
-        `replicate_features`, i.e. the halo exchange done at load time) -- the
-        MI355X-first placement whenever V*D*4 bytes fit next to the graph in 288 GB."""
+        `replicate_features`, i.e. the halo exchange done at load time);
+        hot_ids: ids (the same list on every rank) whose rows every rank keeps a copy of; design H
+        then exchanges only the deduplicated cold tail.  None / empty: no hot-row replica.
+        comm: a glx.Comm to use instead of one derived from `group` (device ops only)."""
         self.ops = ops
         self.graph = graph_shard
         self.feats = feature_shard
         self.replica = feature_replica
         self.group = group
+        self.native = None
+        self.cache = None
+        self.last_stats = None
+        if getattr(ops, "native", False):
+            dev = (graph_shard if graph_shard is not None else feature_shard).device
+            self.comm = comm if comm is not None else comm_for_group(group, dev)
+            self.world, self.rank = self.comm.world, self.comm.rank
+            self.native = ops.glx.DistStore(self.comm, graph=graph_shard, features=feature_shard)
+            if hot_ids is not None and feature_shard is not None:
+                self.native.set_cache(hot_ids)
+            return
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        if hot_ids is not None and len(hot_ids) and feature_shard is not None:
+            self.cache = self._build_cache(torch.as_tensor(hot_ids, dtype=torch.int64))
+
+    def _build_cache(self, hot):
+        """Every rank looks up the hot ids it owns and all-gathers the rows: (sorted ids, rows).  Ids
+        their owner does not know stay out (a request's own default applies to them)."""
+        owner = hot.abs() % self.world
+        mine = hot[owner == self.rank]
+        rows_idx = self.ops.rows_of(self.feats, mine)
+        known = rows_idx >= 0
+        mine = mine[known]
+        rows = self.ops.lookup(self.feats, mine, 0.0)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64), group=self.group)
+        counts = [int(c.item()) for c in counts]
+        most = max(counts + [1])
+        pad_ids = torch.zeros(most, dtype=torch.int64)
+        pad_ids[:mine.shape[0]] = mine
+        pad_rows = torch.zeros((most, rows.shape[1]), dtype=rows.dtype)
+        pad_rows[:mine.shape[0]] = rows
+        all_ids = [torch.empty_like(pad_ids) for _ in range(self.world)]
+        all_rows = [torch.empty_like(pad_rows) for _ in range(self.world)]
+        dist.all_gather(all_ids, pad_ids, group=self.group)
+        dist.all_gather(all_rows, pad_rows, group=self.group)
+        ids = torch.cat([a[:c] for a, c in zip(all_ids, counts)])
+        rows = torch.cat([a[:c] for a, c in zip(all_rows, counts)])
+        srt = torch.argsort(ids)
+        return ids[srt].contiguous(), rows[srt].contiguous()
 
     def _route(self, ids):
         """Bucket ids by owner and share the whole count matrix: -> bucketed, order, rows this
@@ -156,6 +231,9 @@ class ShardedStore:
         return (bucketed, order, matrix[self.rank].tolist(), matrix[:, self.rank].tolist(), int(matrix.max().item()))
 
     def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0):
+        if self.native is not None:
+            return self.native.sample(sampler, src, k, seed=seed, call_counter=call_counter,
+                                      padding_mode=padding_mode, default_neighbor_id=default_neighbor_id)
         bucketed, order, send, recv, most = self._route(src)
         ids_in = _a2a(bucketed, send, recv, self.group, most)
         rows_in = _a2a(order, send, recv, self.group, most)  # original row index = random stream
@@ -172,6 +250,11 @@ class ShardedStore:
         timestamp == value give the single-store answer draw for draw.  timestamp > value does not: the
         reference's ActOn reads the value of the FIRST row of whatever request a server sees
         (filter.h:107-111), so each shard uses its own part's first value -- as the reference's servers do."""
+        if self.native is not None:
+            return self.native.sample(sampler, src, k, seed=seed, call_counter=call_counter,
+                                      padding_mode=padding_mode, default_neighbor_id=default_neighbor_id,
+                                      filter_type=filter_type, filter_field=filter_field, values=values,
+                                      retry_times=retry_times, default_timestamp=default_timestamp)
         bucketed, order, send, recv, most = self._route(src)
         ids_in = _a2a(bucketed, send, recv, self.group, most)
         rows_in = _a2a(order, send, recv, self.group, most)
@@ -183,29 +266,66 @@ class ShardedStore:
         eid = _a2a(eid, recv, send, self.group, most)
         return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
 
-    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, mode="halo", dedup=False):
+    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, mode="halo", dedup=True,
+                  out=None):
         if self.replica is not None:
             return self.ops.aggregate_local(self.replica, op, node_ids, segment_ids, num_segments,
                                             default_attr)
         if mode == "partial":
             return self._aggregate_partial(op, node_ids, segment_ids, num_segments, default_attr)
         assert mode == "halo", mode
+        if self.native is not None:
+            res = self.native.aggregate(op, node_ids, segment_ids, num_segments, default_attr, out=out)
+            return res
+        # ---- the protocol of glx_dist_aggregate, spelled out (CPU tests run this) ----
         n = node_ids.shape[0]
-        inverse = None
+        P, me = self.world, self.rank
+        # 1. where does every id's row come from: hot-row replica, own shard, or the halo
+        slot = torch.full((n,), -1, dtype=torch.int64)
+        if self.cache is not None and self.cache[0].shape[0]:
+            cids = self.cache[0]
+            at = torch.searchsorted(cids, node_ids).clamp(max=cids.shape[0] - 1)
+            slot = torch.where(cids[at] == node_ids, at, slot)
+        hit = slot >= 0
+        mine = (~hit) & ((node_ids.abs() % P) == me)
+        cold = ~(hit | mine)
+        # 2. the cold tail: every distinct remote id crosses the links once
+        cold_ids = node_ids[cold]
         if dedup:
-            # every distinct id crosses the links once; the reduce reads the halo table through `inverse`
-            node_ids, inverse = torch.unique(node_ids, return_inverse=True)
-        bucketed, order, send, recv, most = self._route(node_ids)
+            distinct, inverse = torch.unique(cold_ids, return_inverse=True)
+        else:
+            distinct, inverse = cold_ids, torch.arange(cold_ids.shape[0])
+        bucketed, order, send, recv, most = self._route(distinct)
         ids_in = _a2a(bucketed, send, recv, self.group, most)
-        rows = self.ops.lookup(self.feats, ids_in, default_attr)
-        rows = _a2a(rows, recv, send, self.group, most)  # halo rows, in bucketed order
-        # pos[i] = where (distinct) element i sits in `rows` (inverse of `order`)
-        m = node_ids.shape[0]
-        pos = self.ops.stitch(torch.arange(m, dtype=torch.int64, device=node_ids.device).view(m, 1),
-                              order).view(m)
-        if inverse is not None:
-            pos = pos[inverse]
-        return self.ops.aggregate_rows(rows, pos, segment_ids, num_segments, op, default_attr)
+        rows_out = self.ops.lookup(self.feats, ids_in, default_attr)
+        halo = _a2a(rows_out, recv, send, self.group, most)  # halo rows, in bucketed order
+        m = distinct.shape[0]
+        pos_of_distinct = torch.empty(m, dtype=torch.int64)
+        pos_of_distinct[order] = torch.arange(m, dtype=torch.int64)
+        # 3. one table [halo | replica | own rows of this request | default row], reduced in request order
+        own_rows = self.ops.lookup(self.feats, node_ids[mine], default_attr)
+        parts = [halo]
+        base_cache = halo.shape[0]
+        if self.cache is not None:
+            parts.append(self.cache[1])
+        base_own = base_cache + (self.cache[1].shape[0] if self.cache is not None else 0)
+        parts.append(own_rows)
+        table = torch.cat(parts)
+        pos = torch.empty(n, dtype=torch.int64)
+        pos[hit] = base_cache + slot[hit]
+        pos[mine] = base_own + torch.arange(int(mine.sum()), dtype=torch.int64)
+        pos[cold] = pos_of_distinct[inverse]
+        self.last_stats = dict(ids=n, from_replica=int(hit.sum()), from_own_shard=int(mine.sum()),
+                               remote=int(cold.sum()), remote_distinct=int(m), served_rows=int(ids_in.shape[0]))
+        return self.ops.aggregate_rows(table, pos, segment_ids, num_segments, op, default_attr)
+
+    def lookup(self, node_ids, default_attr=0.0):
+        """LookupNodes in distributed mode (float attributes)."""
+        assert self.native is not None, "device stores only"
+        return self.native.lookup(node_ids, default_attr)
+
+    def stats(self):
+        return self.native.stats() if self.native is not None else self.last_stats
 
     def _aggregate_partial(self, op, node_ids, segment_ids, num_segments, default_attr):
         """Design R: owners reduce, the requester folds the partials (AggregatingRequest::

@@ -48,6 +48,10 @@ EXPORTS = [
     "glx_negative_create", "glx_negative_from_graph", "glx_negative_destroy", "glx_negative_info",
     "glx_negative_export", "glx_graph_enable_negative", "glx_negative_sample",
     "glx_profile_enable", "glx_profile_collect",
+    "glx_comm_unique_id", "glx_comm_init_rccl", "glx_comm_init_local", "glx_comm_init_callbacks", "glx_comm_destroy",
+    "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
+    "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_hot_ids",
+    "glx_dist_sample", "glx_dist_aggregate", "glx_dist_lookup", "glx_dist_last_stats",
 ]
 
 
@@ -59,6 +63,22 @@ class Filter(ctypes.Structure):
     """glx_filter (include/glx.h): type, field, values[batch], retry_times, default_timestamp."""
     _fields_ = [("type", ctypes.c_int32), ("field", ctypes.c_int32), ("values", ctypes.c_void_p),
                 ("retry_times", ctypes.c_int32), ("default_timestamp", ctypes.c_int64)]
+
+
+class DistStats(ctypes.Structure):
+    """glx_dist_stats (include/glx.h): where the ids of a store's last aggregate / lookup came from."""
+    _fields_ = [(n, ctypes.c_int64) for n in ("ids", "from_replica", "from_own_shard", "remote", "remote_distinct",
+                                                "served_rows", "bytes_sent", "bytes_received", "exchange_rounds")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# int (*)(void* user, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts, int64_t eb)
+HOST_ALLTOALLV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_int64)
+# int (*)(void* user, const void* send, void* recv, int64_t bytes_per_rank)
+HOST_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 
 
 class GlxError(RuntimeError):
@@ -131,6 +151,27 @@ def lib():
         L.glx_negative_sample.argtypes = [vp, ci, vp, vp, i32, i32, i64, u64, u64, vp, ci, vp]
         L.glx_profile_enable.argtypes = [ci]
         L.glx_profile_collect.argtypes = [ci, vp, i32, ctypes.POINTER(i32)]
+        L.glx_comm_unique_id.argtypes = [vp]
+        L.glx_comm_init_rccl.argtypes = [ci, ci, ci, vp, ctypes.POINTER(vp)]
+        L.glx_comm_init_local.argtypes = [i64, ci, ci, ci, ctypes.POINTER(vp)]
+        L.glx_comm_init_callbacks.argtypes = [ci, ci, ci, HOST_ALLTOALLV_FN, HOST_ALLGATHER_FN, vp, ctypes.POINTER(vp)]
+        L.glx_comm_destroy.argtypes = [vp]
+        L.glx_comm_destroy.restype = None
+        L.glx_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.glx_comm_set_max_message_bytes.argtypes = [vp, i64]
+        L.glx_comm_set_max_message_bytes.restype = i64
+        L.glx_exchange_v.argtypes = [vp, vp, vp, vp, vp, i64, ci, vp]
+        L.glx_comm_allgather_i64.argtypes = [vp, vp, i32, vp, ci, vp]
+        L.glx_comm_barrier.argtypes = [vp, vp]
+        L.glx_dist_store_create.argtypes = [vp, vp, vp, ctypes.POINTER(vp)]
+        L.glx_dist_store_destroy.argtypes = [vp]
+        L.glx_dist_store_destroy.restype = None
+        L.glx_dist_store_set_cache.argtypes = [vp, vp, i64, f32, ci, vp]
+        L.glx_dist_hot_ids.argtypes = [vp, i64, vp, ctypes.POINTER(i64), vp]
+        L.glx_dist_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, ctypes.POINTER(Filter), vp, vp, ci, vp]
+        L.glx_dist_aggregate.argtypes = [vp, ci, vp, vp, i32, i32, f32, vp, vp, ci, vp]
+        L.glx_dist_lookup.argtypes = [vp, vp, i64, f32, vp, ci, vp]
+        L.glx_dist_last_stats.argtypes = [vp, ctypes.POINTER(DistStats)]
         _lib = L
     return _lib
 
@@ -450,6 +491,7 @@ class Features:
         else:
             emb = np.empty((num_segments, self.dim), np.float32)
             cnt = np.empty((num_segments,), np.int32)
+        # segment_ids=None: num_segments equal segments of n / num_segments ids (a dense sampler response)
         pi, pg, pe, pc = _ptr(node_ids), _ptr(segment_ids), _ptr(emb), _ptr(cnt)
         kind = _kind(pi, pg, pe, pc)
         _check(lib().glx_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0],
@@ -606,6 +648,221 @@ def aggregate_stitch(op, parts, cnts, default_attr=0.0):
     _check(lib().glx_aggregate_stitch(dev, op, P, _ptr(parts)[0], _ptr(cnts)[0], sg, dim, default_attr,
                                       _ptr(emb)[0], _ptr(cnt)[0], _stream(PTR_DEVICE)))
     return emb, cnt
+
+
+COMM_RCCL, COMM_LOCAL, COMM_CALLBACKS = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+
+
+class Comm:
+    """Shard communicator (glx_comm): RCCL over xGMI, in-process threads, or host-staged callbacks."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep  # ctypes callback objects must outlive the handle
+        r, w, d, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib().glx_comm_info(handle, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d), ctypes.byref(t)))
+        self.rank, self.world, self.device, self.transport = r.value, w.value, d.value, t.value
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+        _check(lib().glx_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, device, rank, world, unique_id):
+        h = ctypes.c_void_p()
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        _check(lib().glx_comm_init_rccl(device, rank, world, ctypes.c_char_p(unique_id), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def local(cls, fabric_key, device, rank, world):
+        """Ranks = threads of this process (ctypes releases the GIL inside the collectives)."""
+        h = ctypes.c_void_p()
+        _check(lib().glx_comm_init_local(fabric_key, device, rank, world, ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def callbacks(cls, device, rank, world, alltoallv, allgather):
+        """Host-staged transport.  alltoallv(send_u8, send_counts, recv_u8, recv_counts, elem_bytes) and
+        allgather(send_u8, recv_u8) get numpy views of the pinned staging buffers."""
+        def _a2a(_user, send, send_counts, recv, recv_counts, eb):
+            try:
+                sc = np.ctypeslib.as_array((ctypes.c_int64 * world).from_address(send_counts)).copy()
+                rc = np.ctypeslib.as_array((ctypes.c_int64 * world).from_address(recv_counts)).copy()
+                ns, nr = int(sc.sum()) * eb, int(rc.sum()) * eb
+                sb = np.ctypeslib.as_array((ctypes.c_uint8 * max(ns, 1)).from_address(send))[:ns] if send else np.empty(0, np.uint8)
+                rb = np.ctypeslib.as_array((ctypes.c_uint8 * max(nr, 1)).from_address(recv))[:nr] if recv else np.empty(0, np.uint8)
+                alltoallv(sb, sc, rb, rc, int(eb))
+                return 0
+            except Exception:  # noqa: BLE001 -- an exception must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _ag(_user, send, recv, nbytes):
+            try:
+                sb = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(send))
+                rb = np.ctypeslib.as_array((ctypes.c_uint8 * (nbytes * world)).from_address(recv))
+                allgather(sb, rb)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+        c1, c2 = HOST_ALLTOALLV_FN(_a2a), HOST_ALLGATHER_FN(_ag)
+        h = ctypes.c_void_p()
+        _check(lib().glx_comm_init_callbacks(device, rank, world, c1, c2, None, ctypes.byref(h)))
+        return cls(h, keep=(c1, c2))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().glx_comm_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def set_max_message_bytes(self, nbytes):
+        return int(lib().glx_comm_set_max_message_bytes(self._h, int(nbytes)))
+
+    def exchange_v(self, send, send_counts, recv_counts):
+        """all-to-all(v) of the rows of `send` (numpy or torch CUDA, packed peer-major) -> received rows."""
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        n = int(rc.sum())
+        width = 1
+        for d in send.shape[1:]:
+            width *= int(d)
+        if _is_torch(send):
+            import torch
+            out = torch.empty((n,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            eb = send.element_size() * width
+        else:
+            out = np.empty((n,) + tuple(send.shape[1:]), send.dtype)
+            eb = send.dtype.itemsize * width
+        ps, po = _ptr(send), _ptr(out)
+        kind = _kind(ps, po)
+        _check(lib().glx_exchange_v(self._h, ps[0], _ptr(sc)[0], po[0], _ptr(rc)[0], eb, kind, _stream(kind)))
+        return out
+
+    def allgather_i64(self, vals):
+        """vals[nvals] int64 (numpy or torch CUDA) of every rank -> [world, nvals] of the same kind."""
+        n = int(vals.shape[0])
+        if _is_torch(vals):
+            import torch
+            out = torch.empty((self.world, n), dtype=torch.int64, device=vals.device)
+        else:
+            out = np.empty((self.world, n), np.int64)
+        pv, po = _ptr(vals), _ptr(out)
+        kind = _kind(pv, po)
+        _check(lib().glx_comm_allgather_i64(self._h, pv[0], n, po[0], kind, _stream(kind)))
+        return out
+
+    def barrier(self):
+        _check(lib().glx_comm_barrier(self._h, _stream(PTR_DEVICE)))
+
+
+class DistStore:
+    """One rank's shard of an edge-cut partitioned graph + feature table behind a communicator
+    (glx_dist_store): the device-resident DistributeRunner.  Every method except stats() is
+    COLLECTIVE: all ranks of the communicator call it together, each with its own request."""
+
+    def __init__(self, comm, graph=None, features=None):
+        h = ctypes.c_void_p()
+        _check(lib().glx_dist_store_create(comm._h, graph._h if graph is not None else None,
+                                           features._h if features is not None else None, ctypes.byref(h)))
+        self._h = h
+        self.comm, self.graph, self.features = comm, graph, features
+        self.dim = features.dim if features is not None else None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().glx_dist_store_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def set_cache(self, hot_ids, default_attr=0.0):
+        """Replicate the rows of hot_ids (same list on every rank) on this GPU; empty list drops the replica."""
+        n = int(hot_ids.shape[0])
+        p, kind = _ptr(hot_ids) if n else (None, PTR_HOST)
+        _check(lib().glx_dist_store_set_cache(self._h, p, n, default_attr, kind, _stream(kind)))
+
+    def hot_ids(self, want):
+        """The `want` destination ids with the largest global in-degree (numpy int64, same on every rank)."""
+        out = np.empty(max(int(want), 1), np.int64)
+        n = ctypes.c_int64(0)
+        _check(lib().glx_dist_hot_ids(self._h, int(want), _ptr(out)[0], ctypes.byref(n), _stream(PTR_DEVICE)))
+        return out[:n.value].copy()
+
+    def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR, default_neighbor_id=0,
+               out=None, filter_type=FILTER_NONE, filter_field=FILTER_FIELD_NONE, values=None, retry_times=5,
+               default_timestamp=-1):
+        if isinstance(sampler, str):
+            sampler = SAMPLER_IDS[sampler] if sampler in SAMPLER_IDS else EXTRA_SAMPLER_IDS[sampler]
+        batch = int(src.shape[0])
+        if out is not None:
+            nbr, eid = out
+        elif _is_torch(src):
+            import torch
+            nbr = torch.empty((batch, k), dtype=torch.int64, device=src.device)
+            eid = torch.empty((batch, k), dtype=torch.int64, device=src.device)
+        else:
+            nbr = np.empty((batch, k), np.int64)
+            eid = np.empty((batch, k), np.int64)
+        ps, pn, pe, pv = _ptr(src), _ptr(nbr), _ptr(eid), _ptr(values)
+        kind = _kind(ps, pn, pe, pv)
+        flt = None
+        if values is not None and filter_type != FILTER_NONE:
+            flt = ctypes.byref(Filter(filter_type, filter_field, pv[0], retry_times, default_timestamp))
+        _check(lib().glx_dist_sample(self._h, sampler, ps[0], batch, k, padding_mode, default_neighbor_id, seed,
+                                     call_counter, flt, pn[0], pe[0], kind, _stream(kind)))
+        return nbr, eid
+
+    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, out=None):
+        """segment_ids=None: num_segments equal segments (a dense sampler response)."""
+        if isinstance(op, str):
+            op = AGGREGATOR_IDS[op]
+        n = int(node_ids.shape[0])
+        if out is not None:
+            emb, cnt = out
+        elif _is_torch(node_ids):
+            import torch
+            emb = torch.empty((num_segments, self.dim), dtype=torch.float32, device=node_ids.device)
+            cnt = torch.empty((num_segments,), dtype=torch.int32, device=node_ids.device)
+        else:
+            emb = np.empty((num_segments, self.dim), np.float32)
+            cnt = np.empty((num_segments,), np.int32)
+        pi, pg, pe, pc = _ptr(node_ids), _ptr(segment_ids), _ptr(emb), _ptr(cnt)
+        kind = _kind(pi, pg, pe, pc)
+        _check(lib().glx_dist_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0], pc[0], kind,
+                                        _stream(kind)))
+        return emb, cnt
+
+    def lookup(self, node_ids, default_attr=0.0):
+        n = int(node_ids.shape[0])
+        if _is_torch(node_ids):
+            import torch
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=node_ids.device)
+        else:
+            out = np.empty((n, self.dim), np.float32)
+        pi, po = _ptr(node_ids), _ptr(out)
+        kind = _kind(pi, po)
+        _check(lib().glx_dist_lookup(self._h, pi[0], n, default_attr, po[0], kind, _stream(kind)))
+        return out
+
+    def stats(self):
+        st = DistStats()
+        _check(lib().glx_dist_last_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
 
 
 KERNEL_SAMPLE, KERNEL_AGGREGATE, KERNEL_LOOKUP = 0, 1, 2

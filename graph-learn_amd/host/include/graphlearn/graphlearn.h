@@ -9,6 +9,7 @@
 #include "graphlearn/graph_store.h"
 #include "graphlearn/op_request.h"
 #include "graphlearn/operator.h"
+#include "graphlearn/op_runner.h"
 #include "graphlearn/partition.h"
 #include "graphlearn/sampling_request.h"
 #include "graphlearn/status.h"

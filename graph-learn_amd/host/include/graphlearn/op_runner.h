@@ -1,0 +1,113 @@
+// Operator runners.  Mirrors graphlearn/src/core/runner/op_runner.h:33-159:
+//   Runner<Req, Res>::Run             -- local: op->Process(req, res)            (:33-48)
+//   DistributeRunner<Req, Res>::Run   -- Partition -> one sub-request per shard, shipped to
+//                                        its server -> Process there -> Stitch    (:50-152)
+//   GetOpRunner(env, op)              -- the distributed runner when the deployment has
+//                                        more than one server                     (:156)
+// The reference ships the parts with one gRPC call per remote shard from a thread pool
+// (RunInParallel, :86-117).  Here the servers are the GPUs of one node, one process (or
+// host thread) each, and `Env` carries the shard communicator (include/glx.h glx_comm: RCCL
+// send/recv groups over xGMI) instead of channels and pools.  Run() is one call into the
+// device-resident distributed store (glx_dist_sample / glx_dist_aggregate): partition,
+// exchange, the owner's kernels, exchange back and stitch all happen on the GPUs; the
+// request and response objects are only copied in and out.
+//
+// SPMD, as the reference's worker loop is not: every rank calls Run() for the same operator
+// at the same time, each with its OWN request (a rank with nothing to ask passes an empty
+// one).  Results equal the single-store operator's, draw for draw.
+#ifndef GLX_HOST_OP_RUNNER_H_
+#define GLX_HOST_OP_RUNNER_H_
+#include <atomic>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "graphlearn/graph_store.h"
+#include "graphlearn/op_request.h"
+#include "graphlearn/operator.h"
+#include "graphlearn/status.h"
+
+struct glx_comm;
+struct glx_dist_store;
+
+namespace graphlearn {
+
+// What a runner needs from the deployment (the role of platform/env.h + the naming engine):
+// this server's id, the server count, the way to the other servers, and the local shard.
+class Env {
+public:
+  // `comm` stays owned by the caller and must outlive the Env; `store` is this rank's shard
+  // (GraphStore::SetShard(comm rank, comm world) before loading).
+  Env(glx_comm* comm, GraphStore* store);
+  ~Env();
+  Env(const Env&) = delete;
+  Env& operator=(const Env&) = delete;
+
+  int32_t ServerId() const { return server_id_; }
+  int32_t ServerCount() const { return server_count_; }
+  glx_comm* Comm() const { return comm_; }
+  GraphStore* Store() const { return store_; }
+
+  // Collective.  Every GPU keeps a copy of these nodes' float attributes (the same id list on
+  // every rank); aggregation then fetches only the remaining remote rows per request.
+  Status ReplicateHotNodes(const std::string& node_type, const int64_t* ids, int64_t count);
+  // Collective.  The `want` vertices with the largest in-degree over all shards of `edge_type`.
+  Status HotNodes(const std::string& edge_type, int64_t want, std::vector<int64_t>* ids);
+
+  // Device-resident distributed stores of one edge / node type, created on first use.
+  Status EdgeStore(const std::string& edge_type, glx_dist_store** out);
+  Status NodeStore(const std::string& node_type, glx_dist_store** out);
+  uint64_t NextCallCounter() { return call_counter_.fetch_add(1, std::memory_order_relaxed); }
+
+private:
+  glx_comm* comm_;
+  GraphStore* store_;
+  int32_t server_id_, server_count_;
+  std::mutex mtx_;
+  std::unordered_map<std::string, glx_dist_store*> edge_stores_, node_stores_;
+  std::atomic<uint64_t> call_counter_{0};
+};
+
+// op_runner.h:33-48
+template <class Request, class Response>
+class Runner {
+public:
+  Runner(Env* env, op::Operator* op) : env_(env), op_(op) {}
+  virtual ~Runner() = default;
+  virtual Status Run(const Request* req, Response* res) { return op_->Process(req, res); }
+
+protected:
+  Env* env_;
+  op::Operator* op_;
+};
+
+// The body of DistributeRunner::Run for the requests this engine serves across shards:
+// SamplingRequest (dense samplers) and AggregatingRequest.  Anything else that is shardable
+// is refused with Unimplemented rather than silently answered from the local shard.
+Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpResponse* res);
+
+// op_runner.h:50-152
+template <class Request, class Response>
+class DistributeRunner : public Runner<Request, Response> {
+public:
+  DistributeRunner(Env* env, int32_t local_id, op::Operator* op)
+      : Runner<Request, Response>(env, op), local_id_(local_id) {}
+  Status Run(const Request* req, Response* res) override {
+    if (!req->IsShardable()) return Runner<Request, Response>::Run(req, res);  // op_runner.h:61-62
+    return RunDistributed(this->env_, this->op_, req, res);
+  }
+
+private:
+  int32_t local_id_;
+};
+
+typedef Runner<OpRequest, OpResponse> OpRunner;
+typedef DistributeRunner<OpRequest, OpResponse> DistOpRunner;
+
+// op_runner.h:156 / op_runner.cc: distributed when there is more than one server.
+std::unique_ptr<OpRunner> GetOpRunner(Env* env, op::Operator* op);
+
+}  // namespace graphlearn
+#endif  // GLX_HOST_OP_RUNNER_H_

@@ -1,0 +1,171 @@
+// DistributeRunner over the device-resident distributed store.  Replaces
+// graphlearn/src/core/runner/op_runner.h:60-152 (Partition -> RunInParallel -> Stitch) and
+// op_runner.cc (GetOpRunner): the sub-requests never exist as host objects -- the C-ABI
+// call buckets the request rows by owner on the GPU, exchanges them over the shard
+// communicator, runs the owner's kernels, exchanges the results back and stitches.
+#include "graphlearn/op_runner.h"
+
+#include <vector>
+
+#include "glx.h"
+#include "graphlearn/aggregating_request.h"
+#include "graphlearn/config.h"
+#include "graphlearn/sampling_request.h"
+
+namespace graphlearn {
+
+Env::Env(glx_comm* comm, GraphStore* store) : comm_(comm), store_(store), server_id_(0), server_count_(1) {
+  int rank = 0, world = 1;
+  if (comm && glx_comm_info(comm, &rank, &world, nullptr, nullptr) == GLX_OK) {
+    server_id_ = rank;
+    server_count_ = world;
+  }
+}
+
+Env::~Env() {
+  for (auto& kv : edge_stores_) glx_dist_store_destroy(kv.second);
+  for (auto& kv : node_stores_) glx_dist_store_destroy(kv.second);
+}
+
+Status Env::EdgeStore(const std::string& edge_type, glx_dist_store** out) {
+  std::lock_guard<std::mutex> lock(mtx_);
+  auto it = edge_stores_.find(edge_type);
+  if (it == edge_stores_.end()) {
+    const glx_graph* g = store_->GetGraph(edge_type)->Device();
+    if (!g) return error::InvalidArgument("edge type '" + edge_type + "' is not built on server " + std::to_string(server_id_));
+    glx_dist_store* st = nullptr;
+    int rc = glx_dist_store_create(comm_, g, nullptr, &st);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    it = edge_stores_.emplace(edge_type, st).first;
+  }
+  *out = it->second;
+  return Status::OK();
+}
+
+Status Env::NodeStore(const std::string& node_type, glx_dist_store** out) {
+  std::lock_guard<std::mutex> lock(mtx_);
+  auto it = node_stores_.find(node_type);
+  if (it == node_stores_.end()) {
+    const glx_features* f = store_->GetNoder(node_type)->Device();
+    if (!f) return error::InvalidArgument("node type '" + node_type + "' has no float attributes on server " + std::to_string(server_id_));
+    glx_dist_store* st = nullptr;
+    int rc = glx_dist_store_create(comm_, nullptr, f, &st);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    it = node_stores_.emplace(node_type, st).first;
+  }
+  *out = it->second;
+  return Status::OK();
+}
+
+Status Env::ReplicateHotNodes(const std::string& node_type, const int64_t* ids, int64_t count) {
+  glx_dist_store* st = nullptr;
+  Status s = NodeStore(node_type, &st);
+  if (!s.ok()) return s;
+  return error::FromGlx(glx_dist_store_set_cache(st, ids, count, GLOBAL_FLAG(DefaultFloatAttribute), GLX_PTR_HOST, nullptr));
+}
+
+Status Env::HotNodes(const std::string& edge_type, int64_t want, std::vector<int64_t>* ids) {
+  glx_dist_store* st = nullptr;
+  Status s = EdgeStore(edge_type, &st);
+  if (!s.ok()) return s;
+  ids->assign((size_t)(want > 0 ? want : 1), 0);
+  int64_t n = 0;
+  int rc = glx_dist_hot_ids(st, want, ids->data(), &n, nullptr);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  ids->resize((size_t)n);
+  return Status::OK();
+}
+
+namespace {
+
+int SamplerIdOf(const std::string& name) {
+  if (name == "RandomSampler") return GLX_SAMPLER_RANDOM;
+  if (name == "RandomWithoutReplacementSampler") return GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT;
+  if (name == "EdgeWeightSampler") return GLX_SAMPLER_EDGE_WEIGHT;
+  if (name == "TopkSampler") return GLX_SAMPLER_TOPK;
+  if (name == "InDegreeSampler") return GLX_SAMPLER_IN_DEGREE;
+  return -1;
+}
+
+int AggregatorIdOf(const std::string& name) {
+  if (name == "SumAggregator") return GLX_AGG_SUM;
+  if (name == "MeanAggregator") return GLX_AGG_MEAN;
+  if (name == "MaxAggregator") return GLX_AGG_MAX;
+  if (name == "MinAggregator") return GLX_AGG_MIN;
+  if (name == "ProdAggregator") return GLX_AGG_PROD;
+  return -1;
+}
+
+Status RunSampling(Env* env, const SamplingRequest* req, SamplingResponse* res) {
+  const int sampler = SamplerIdOf(req->Strategy());
+  if (sampler < 0) {
+    return error::Unimplemented("'" + req->Strategy() + "' is not served across shards (dense neighbour samplers are)");
+  }
+  const int32_t count = req->NeighborCount();
+  const int32_t batch_size = req->BatchSize();
+  res->SetShape(batch_size, count);
+  res->InitNeighborIds();
+  res->InitEdgeIds();
+  if (req->HasFilter() && batch_size > 0 && !req->GetFilterValues()) {
+    return error::InvalidArgument("the request has a filter but not one filter value per src id");
+  }
+  glx_dist_store* st = nullptr;
+  Status s = env->EdgeStore(req->Type(), &st);
+  if (!s.ok()) return s;
+  res->ResizeDense();
+  glx_filter filter;
+  filter.type = req->HasFilter() && req->GetFilterValues() ? (int32_t)req->GetFilterType() : GLX_FILTER_NONE;
+  filter.field = (int32_t)req->GetFilterField();
+  filter.values = req->GetFilterValues();
+  filter.retry_times = GLOBAL_FLAG(SamplingRetryTimes);
+  filter.default_timestamp = GLOBAL_FLAG(DefaultTimestamp);
+  // the reference's RNG state advances from call to call; here: a per-deployment call counter
+  const uint64_t cc = req->HasCallCounter() ? (uint64_t)req->CallCounter() : env->NextCallCounter();
+  int rc = glx_dist_sample(st, sampler, req->GetSrcIds(), batch_size, count, GLOBAL_FLAG(PaddingMode),
+                           GLOBAL_FLAG(DefaultNeighborId), (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, &filter,
+                           res->GetNeighborIds(), res->GetEdgeIds(), GLX_PTR_HOST, nullptr);
+  return error::FromGlx(rc);
+}
+
+Status RunAggregating(Env* env, const AggregatingRequest* req, AggregatingResponse* res) {
+  const int op = AggregatorIdOf(req->Strategy());
+  if (op < 0) return error::Unimplemented("'" + req->Strategy() + "' is not an aggregator this engine serves");
+  Noder* noder = env->Store()->GetNoder(req->Type());
+  res->SetEmbeddingDim(noder->GetSideInfo()->f_num);
+  res->SetNumSegments(req->NumSegments());
+  res->SetName(req->Name());
+  glx_dist_store* st = nullptr;
+  Status s = env->NodeStore(req->Type(), &st);
+  if (!s.ok()) return s;
+  int rc = glx_dist_aggregate(st, op, req->NodeIds(), req->SegmentIds(), req->NumIds(), req->NumSegments(),
+                              GLOBAL_FLAG(DefaultFloatAttribute), res->MutableEmbeddings(), res->MutableSegments(),
+                              GLX_PTR_HOST, nullptr);
+  return error::FromGlx(rc);
+}
+
+}  // namespace
+
+Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpResponse* res) {
+  (void)op;  // the owner's Process() is the kernel behind the distributed store
+  if (!env || !env->Comm() || !env->Store()) return error::InvalidArgument("the runner has no communicator / store");
+  if (auto* sreq = dynamic_cast<const SamplingRequest*>(req)) {
+    auto* sres = dynamic_cast<SamplingResponse*>(res);
+    if (!sres) return error::InvalidArgument("a SamplingRequest needs a SamplingResponse");
+    return RunSampling(env, sreq, sres);
+  }
+  if (auto* areq = dynamic_cast<const AggregatingRequest*>(req)) {
+    auto* ares = dynamic_cast<AggregatingResponse*>(res);
+    if (!ares) return error::InvalidArgument("an AggregatingRequest needs an AggregatingResponse");
+    return RunAggregating(env, areq, ares);
+  }
+  return error::Unimplemented("request '" + req->Name() + "' is shardable but not served across shards");
+}
+
+std::unique_ptr<OpRunner> GetOpRunner(Env* env, op::Operator* op) {
+  if (env && env->ServerCount() > 1) {
+    return std::unique_ptr<OpRunner>(new DistOpRunner(env, env->ServerId(), op));
+  }
+  return std::unique_ptr<OpRunner>(new OpRunner(env, op));
+}
+
+}  // namespace graphlearn

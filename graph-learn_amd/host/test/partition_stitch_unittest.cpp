@@ -3,8 +3,12 @@
 // really PROCESSED on two device-resident GraphStores (one per "server") and the
 // stitched answer must equal the answer of a single store holding everything.
 #include <cmath>
+#include <cstring>
 #include <random>
+#include <thread>
 #include <vector>
+
+#include "glx.h"
 
 #include "graphlearn/graphlearn.h"
 #include "test_util.h"
@@ -237,6 +241,131 @@ TEST(PartitionStitchTest, AggregatorsOnTwoDeviceStoresEqualOneStore) {
     EXPECT_TRUE(ok);
   }
   OpFactory::GetInstance()->Set(&c->whole);
+}
+
+// The distributed runner itself (op_runner.h:50-152): two "servers" = two host threads, each
+// with its own shard store on the GPU and a rank of one shard communicator; every server
+// drives its OWN requests through GetOpRunner(env, op)->Run(), and must get exactly what a
+// single store holding everything answers.
+TEST(PartitionStitchTest, DistributeRunnerOnTwoServersEqualsOneStore) {
+  Cluster* c = BuildCluster();
+  const char* samplers[4] = {"RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"};
+  const char* aggs[5] = {"SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"};
+  // per-server requests, and the single-store answers
+  std::vector<int64_t> ids[2], agg_ids[2];
+  std::vector<int32_t> seg[2];
+  for (int r = 0; r < 2; ++r) {
+    for (int i = 0; i < 300 + 40 * r; ++i) ids[r].push_back((i * (7 + 4 * r)) % 320);
+    std::mt19937 rng(30 + r);
+    for (int32_t s = 0; s < 90; ++s) {
+      const int n = s % 9 == 0 ? 0 : 1 + rng() % 5;
+      for (int j = 0; j < n; ++j) {
+        agg_ids[r].push_back((int64_t)(rng() % 310));  // a few ids nobody knows
+        seg[r].push_back(s);
+      }
+    }
+  }
+  OpFactory::GetInstance()->Set(&c->whole);
+  std::vector<std::vector<int64_t>> want_nbr[2];
+  std::vector<std::vector<float>> want_emb[2];
+  std::vector<std::vector<int32_t>> want_cnt[2];
+  for (int r = 0; r < 2; ++r) {
+    for (int n = 0; n < 4; ++n) {
+      SamplingRequest req("e", samplers[n], 5);
+      req.Set(ids[r].data(), (int32_t)ids[r].size());
+      req.SetCallCounter(500 + 10 * r + n);
+      SamplingResponse res;
+      EXPECT_TRUE(OpFactory::GetInstance()->Create(samplers[n])->Process(&req, &res).ok());
+      want_nbr[r].emplace_back(res.GetNeighborIds(), res.GetNeighborIds() + ids[r].size() * 5);
+    }
+    for (int n = 0; n < 5; ++n) {
+      AggregatingRequest req("n", aggs[n]);
+      req.Set(agg_ids[r].data(), seg[r].data(), (int32_t)agg_ids[r].size(), 90);
+      AggregatingResponse res;
+      EXPECT_TRUE(OpFactory::GetInstance()->Create(aggs[n])->Process(&req, &res).ok());
+      want_emb[r].emplace_back(res.Embeddings(), res.Embeddings() + 90 * 8);
+      want_cnt[r].emplace_back(res.Segments(), res.Segments() + 90);
+    }
+  }
+  bool ok[2] = {true, true};
+  std::string why[2];
+  auto server = [&](int r, bool with_replica) {
+    glx_comm* comm = nullptr;
+    if (glx_comm_init_local(77001 + (with_replica ? 1 : 0), 0, r, 2, &comm) != GLX_OK) {
+      ok[r] = false;
+      why[r] = glx_last_error();
+      return;
+    }
+    {
+      Env env(comm, &c->shard[r]);
+      if (with_replica) {
+        std::vector<int64_t> hot;
+        Status s = env.HotNodes("e", 40, &hot);
+        if (s.ok()) s = env.ReplicateHotNodes("n", hot.data(), (int64_t)hot.size());
+        if (!s.ok() || hot.size() != 40) {
+          ok[r] = false;
+          why[r] = "hot nodes: " + s.ToString();
+        }
+      }
+      for (int n = 0; n < 4 && ok[r]; ++n) {
+        Operator* op = OpFactory::GetInstance()->Create(samplers[n]);
+        std::unique_ptr<OpRunner> runner = GetOpRunner(&env, op);
+        SamplingRequest req("e", samplers[n], 5);
+        req.Set(ids[r].data(), (int32_t)ids[r].size());
+        req.SetCallCounter(500 + 10 * r + n);  // each server has its own random stream
+        SamplingResponse res;
+        Status s = runner->Run(&req, &res);
+        if (!s.ok()) {
+          ok[r] = false;
+          why[r] = s.ToString();
+          break;
+        }
+        for (size_t i = 0; i < ids[r].size() * 5; ++i) {
+          if (res.GetNeighborIds()[i] != want_nbr[r][n][i]) {
+            ok[r] = false;
+            why[r] = std::string(samplers[n]) + ": neighbour mismatch";
+            break;
+          }
+        }
+      }
+      for (int n = 0; n < 5 && ok[r]; ++n) {
+        Operator* op = OpFactory::GetInstance()->Create(aggs[n]);
+        std::unique_ptr<OpRunner> runner = GetOpRunner(&env, op);
+        AggregatingRequest req("n", aggs[n]);
+        req.Set(agg_ids[r].data(), seg[r].data(), (int32_t)agg_ids[r].size(), 90);
+        AggregatingResponse res;
+        Status s = runner->Run(&req, &res);
+        if (!s.ok()) {
+          ok[r] = false;
+          why[r] = s.ToString();
+          break;
+        }
+        for (int i = 0; i < 90 && ok[r]; ++i) {
+          if (res.Segments()[i] != want_cnt[r][n][i]) {
+            ok[r] = false;
+            why[r] = std::string(aggs[n]) + ": count mismatch";
+          }
+          for (int d = 0; d < 8; ++d) {
+            // the halo design reduces on the requester in request order: bit-identical for every aggregator
+            if (memcmp(&res.Embeddings()[i * 8 + d], &want_emb[r][n][i * 8 + d], 4) != 0) {
+              ok[r] = false;
+              why[r] = std::string(aggs[n]) + ": embedding mismatch";
+            }
+          }
+        }
+      }
+    }
+    glx_comm_destroy(comm);
+  };
+  for (int with_replica = 0; with_replica < 2; ++with_replica) {
+    std::thread t0(server, 0, with_replica != 0), t1(server, 1, with_replica != 0);
+    t0.join();
+    t1.join();
+    for (int r = 0; r < 2; ++r) {
+      if (!ok[r]) std::printf("  server %d (replica %d): %s\n", r, with_replica, why[r].c_str());
+      EXPECT_TRUE(ok[r]);
+    }
+  }
 }
 
 int main() { return RunAllTests(); }

@@ -301,7 +301,10 @@ GLX_API int glx_features_info(const glx_features* f, int64_t* num_rows, int32_t*
  * cnt_out[num_segments].  Unknown ids contribute a row of `default_attr`;
  * empty segments are `default_attr` (GLOBAL_FLAG(DefaultFloatAttribute)).
  * Each output element is accumulated in the reference's left-to-right order,
- * so results are bit-identical to the reference for every op.  Device-pointer
+ * so results are bit-identical to the reference for every op.  segment_ids == NULL
+ * means num_segments equal segments of num_ids / num_segments consecutive ids -- the
+ * layout of a dense sampler response (segment i = the neighbours of request row i):
+ * the segment bookkeeping kernels and the read of the segment ids are skipped.  Device-pointer
  * callers get the float4 path when dim % 4 == 0 and emb_out (and a view's X) are
  * 16-byte aligned; any other alignment silently takes the scalar path. */
 GLX_API int glx_aggregate(const glx_features* f, int op, const int64_t* node_ids,
@@ -380,6 +383,122 @@ GLX_API int glx_stitch_f32(int device, const float* in, const int64_t* order, in
 GLX_API int glx_aggregate_stitch(int device, int op, int32_t num_parts, const float* parts,
                                  const int32_t* cnts, int32_t num_segments, int32_t dim, float default_attr,
                                  float* emb_out, int32_t* cnt_out, void* stream);
+
+/* ---- shard communicator: replaces the RPC layer under DistributeRunner
+ * (core/runner/op_runner.h:86-152 RunInParallel: one gRPC call per remote shard,
+ * service/client_impl.cc + rpc/) with RCCL point-to-point groups over xGMI. -----------
+ * One glx_comm per process (= per GPU) and per concurrently used stream; `rank` plays the
+ * role of the reference's server id and `world` of its server count (hash_partitioner.h:33-92
+ * routes id v to shard llabs(v) % world).  Three transports, one interface:
+ *   glx_comm_init_rccl       ncclCommInitRank from a unique id that rank 0 made with
+ *                            glx_comm_unique_id and handed to the others out of band (the
+ *                            role of the reference's coordinator / naming engine);
+ *                            exchanges are ncclGroupStart + ncclSend/ncclRecv + ncclGroupEnd
+ *                            on the caller's stream (librccl is loaded with dlopen, so the
+ *                            library loads without it);
+ *   glx_comm_init_local      `world` ranks that are threads of ONE process (each may use its
+ *                            own GPU or all the same one): peers copy device-to-device out of
+ *                            each other's send buffers between two host barriers.  Ranks that
+ *                            pass the same `fabric_key` form one communicator.  This is the
+ *                            one-GPU test rig and the single-process multi-GPU mode;
+ *   glx_comm_init_callbacks  host-staged: buffers are copied to pinned host memory and handed
+ *                            to the caller's all-to-all / all-gather (e.g. torch.distributed
+ *                            gloo, MPI) -- for ranks that cannot run RCCL together. */
+#define GLX_UNIQUE_ID_BYTES 128
+#define GLX_COMM_RCCL 0
+#define GLX_COMM_LOCAL 1
+#define GLX_COMM_CALLBACKS 2
+typedef struct glx_comm glx_comm;
+/* send/recv are packed host buffers (peer-major); counts are in elements of elem_bytes. */
+typedef int (*glx_host_alltoallv_fn)(void* user, const void* send, const int64_t* send_counts, void* recv,
+                                     const int64_t* recv_counts, int64_t elem_bytes);
+typedef int (*glx_host_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
+GLX_API int glx_comm_unique_id(void* id_out /* GLX_UNIQUE_ID_BYTES */);
+GLX_API int glx_comm_init_rccl(int device, int rank, int world, const void* unique_id, glx_comm** out);
+GLX_API int glx_comm_init_local(int64_t fabric_key, int device, int rank, int world, glx_comm** out);
+GLX_API int glx_comm_init_callbacks(int device, int rank, int world, glx_host_alltoallv_fn alltoallv,
+                                    glx_host_allgather_fn allgather, void* user, glx_comm** out);
+GLX_API void glx_comm_destroy(glx_comm* c);
+GLX_API int glx_comm_info(const glx_comm* c, int* rank, int* world, int* device, int* transport);
+/* No peer message of one exchange round exceeds this many bytes (default 512 MiB; RCCL 2.26
+ * was seen to deliver only half of an all-to-all message above 1 GiB); larger exchanges are
+ * cut into rounds of pointer offsets -- no staging copies.  Returns the previous value. */
+GLX_API int64_t glx_comm_set_max_message_bytes(glx_comm* c, int64_t bytes);
+/* all-to-all(v): send_counts[p] consecutive elements of `send` (peer-major, packed) go to rank
+ * p; recv_counts[q] elements arrive from rank q into `recv` (packed in rank order).  Counts are
+ * HOST arrays of `world` entries; data pointers are host or device per ptr_kind.  Collective:
+ * every rank of the communicator must call it.  Device pointers: enqueued on `stream`. */
+GLX_API int glx_exchange_v(glx_comm* c, const void* send, const int64_t* send_counts, void* recv,
+                           const int64_t* recv_counts, int64_t elem_bytes, int ptr_kind, void* stream);
+/* vals[nvals] int64 of every rank -> out[world * nvals] on every rank (rank-major), host or
+ * device pointers.  The call returns when `out` is valid (it synchronises `stream`). */
+GLX_API int glx_comm_allgather_i64(glx_comm* c, const int64_t* vals, int32_t nvals, int64_t* out, int ptr_kind,
+                                   void* stream);
+GLX_API int glx_comm_barrier(glx_comm* c, void* stream);
+
+/* ---- distributed store: replaces DistributeRunner<Req, Res>::Run (op_runner.h:60-84) for
+ * the sampling and aggregating requests: Partition (hash_partitioner.h:33-92) -> ship the
+ * parts -> Process on the owning shard -> ship the results back -> Stitch
+ * (stitcher.h:67-107; aggregating_request.cc:117-213) -- all on the device, between the
+ * caller's request and response buffers.  SPMD: every rank calls the same entry point at the
+ * same time with ITS OWN request (a rank with nothing to ask passes batch / num_ids = 0).
+ * `graph` is this rank's shard of one edge type (out-edges of the vertices it owns, GLOBAL
+ * destination ids, global edge ids); `features` its shard of one node type's rows, with the
+ * raw ids as id map.  Either may be NULL when only the other operator family is used.
+ * Results are bit-identical to the unpartitioned operator for every world size: a sampled
+ * row draws from the random stream of its index in the ORIGINAL request (glx_sample_ex), and
+ * aggregation reduces on the requester, in request order, over rows fetched from
+ *   (1) this rank's own shard,
+ *   (2) the HOT-ROW REPLICA: a copy, on every GPU, of the rows of a caller-chosen id set
+ *       (glx_dist_store_set_cache; glx_dist_hot_ids picks the top-K vertices by global
+ *       in-degree) -- in power-law graphs a few percent of the rows take most accesses, and
+ *   (3) the HALO: the remaining remote ids, deduplicated on the device, requested from their
+ *       owners (ids out, rows back: the halo-vertex feature exchange).
+ * One store must not be used from two host threads at once; use one store (and one
+ * communicator) per concurrently used stream. */
+typedef struct glx_dist_store glx_dist_store;
+GLX_API int glx_dist_store_create(glx_comm* comm, const glx_graph* graph, const glx_features* features,
+                                  glx_dist_store** out);
+GLX_API void glx_dist_store_destroy(glx_dist_store* st);
+/* Collective.  hot_ids[n] (identical on every rank; host or device) -> every rank fetches the
+ * rows from their owners once and keeps them.  n = 0 drops the replica. */
+GLX_API int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_ids, int64_t n, float default_attr,
+                                     int ptr_kind, void* stream);
+/* Collective.  The `want` destination ids with the largest in-degree summed over all shards
+ * of the store's graph (ties: smaller id first), the same list on every rank, in descending
+ * order of in-degree; *n_out <= want.  ids_out is a HOST array of `want` entries. */
+GLX_API int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_out, int64_t* n_out, void* stream);
+/* Collective.  DistributeRunner<SamplingRequest, SamplingResponse>::Run: glx_sample_filtered's
+ * arguments (filter may be NULL), request rows routed to their owners and back. */
+GLX_API int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* src, int32_t batch, int32_t k,
+                            int padding_mode, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                            const glx_filter* filter, int64_t* nbr_out, int64_t* eid_out, int ptr_kind,
+                            void* stream);
+/* Collective.  DistributeRunner<AggregatingRequest, AggregatingResponse>::Run with
+ * glx_aggregate's arguments; segment_ids == NULL means num_segments equal segments of
+ * num_ids / num_segments consecutive ids (a dense sampler response). */
+GLX_API int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,
+                               int32_t num_ids, int32_t num_segments, float default_attr, float* emb_out,
+                               int32_t* cnt_out, int ptr_kind, void* stream);
+/* Collective.  LookupNodes in distributed mode (node_lookuper.cc:24-52 behind
+ * DistributeRunner): out[n * dim] rows of ids owned by any shard. */
+GLX_API int glx_dist_lookup(glx_dist_store* st, const int64_t* node_ids, int64_t n, float default_attr,
+                            float* out, int ptr_kind, void* stream);
+/* Where the ids of this store's LAST glx_dist_aggregate / glx_dist_lookup came from, and what
+ * crossed the links because of it (this rank's view).  The call synchronises nothing: read it
+ * after the stream has drained. */
+typedef struct glx_dist_stats {
+  int64_t ids;             /* request size */
+  int64_t from_replica;    /* served by the hot-row replica */
+  int64_t from_own_shard;  /* owned by this rank (or unknown everywhere: default row) */
+  int64_t remote;          /* remote and not replicated (with repeats) */
+  int64_t remote_distinct; /* ... distinct: the ids sent, = halo rows received */
+  int64_t served_rows;     /* halo rows this rank gathered for its peers */
+  int64_t bytes_sent;      /* ids out + rows out over the transport, self-copies excluded */
+  int64_t bytes_received;
+  int64_t exchange_rounds; /* transport rounds of the last row exchange (message-size limit) */
+} glx_dist_stats;
+GLX_API int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out);
 
 /* ---- kernel timing: the device-side counterpart of the reference's
  * PROFILING(key) scope timers (common/base/profiling.h:24-71). ------------

@@ -62,6 +62,11 @@ class OracleOps:
                 out[i] = X[r]
         return torch.from_numpy(out)
 
+    def rows_of(self, feats, ids):
+        X, raw = feats
+        row_of = {int(v): i for i, v in enumerate(raw)}
+        return torch.tensor([row_of.get(int(v), -1) for v in ids.numpy()], dtype=torch.int64)
+
     def aggregate_rows(self, rows, pos, seg, num_segments, op, default_attr):
         e, c = self.o.aggregate(rows.numpy(), op, pos.numpy(), seg.numpy(), num_segments, default_attr)
         return torch.from_numpy(e), torch.from_numpy(c)
@@ -149,8 +154,8 @@ def _worker(rank, world, port, q, message_limit=None):
             oemb, ocnt = orc.aggregate(X, name, ids, seg, Sg, 1.25)
             ok &= np.array_equal(cnt.numpy(), ocnt)
             ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
-            # the same with every distinct halo id shipped once
-            emb, cnt = store.aggregate(name, t(ids), t(seg), Sg, default_attr=1.25, dedup=True)
+            # the same with every halo id shipped as often as it occurs
+            emb, cnt = store.aggregate(name, t(ids), t(seg), Sg, default_attr=1.25, dedup=False)
             ok &= np.array_equal(cnt.numpy(), ocnt)
             ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
             # design R: owners reduce, the requester folds the partials.  Max/Min exact,
@@ -161,6 +166,23 @@ def _worker(rank, world, port, q, message_limit=None):
                 ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
             else:
                 ok &= bool(np.allclose(emb.numpy(), oemb, rtol=1e-5, atol=1e-5))
+        # hot-row replica + cold-tail halo exchange (the protocol of glx_dist_aggregate): replica sizes
+        # none / partial (top in-degree ids, plus ids nobody knows) / everything
+        indeg = np.bincount(col, minlength=600)
+        top = np.lexsort((np.arange(600), -indeg))[:60].astype(np.int64)
+        for hot in (np.empty(0, np.int64), np.concatenate([top, [700, -7]]), np.arange(600, dtype=np.int64)):
+            store_c = gdist.ShardedStore(ops, shard, feats, hot_ids=hot)
+            for name in ("SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"):
+                emb, cnt = store_c.aggregate(name, t(ids), t(seg), Sg, default_attr=1.25)
+                oemb, ocnt = orc.aggregate(X, name, ids, seg, Sg, 1.25)
+                ok &= np.array_equal(cnt.numpy(), ocnt)
+                ok &= np.array_equal(emb.numpy().view(np.uint32), oemb.view(np.uint32))
+            st = store_c.stats()
+            ok &= st["from_replica"] + st["from_own_shard"] + st["remote"] == ids.shape[0]
+            if hot.shape[0] == 600:
+                ok &= st["remote"] == 0 or bool(((ids < 0) | (ids >= 600)).any())
+            if hot.shape[0] == 0:
+                ok &= st["from_replica"] == 0
         # load-time halo exchange: all-gather the feature shards, then aggregate locally
         full = gdist.replicate_features(t(X[rank::world].copy()), X.shape[0])
         ok &= np.array_equal(full.numpy(), X)

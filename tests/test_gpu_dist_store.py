@@ -1,0 +1,382 @@
+"""GPU tests of the C distributed store (include/glx.h "distributed store", csrc/glx_dist.hip +
+csrc/glx_comm.hip): the device-resident replacement of DistributeRunner<Req, Res>::Run
+(graphlearn/src/core/runner/op_runner.h:60-152) -- Partition -> exchange -> Process on the
+owner -> exchange -> Stitch -- with the hot-row replica + deduplicated cold-tail halo exchange
+for aggregation.
+
+One GPU is enough: the P ranks of a communicator are threads of this process
+(glx_comm_init_local: peers copy out of each other's send buffers), or host-staged callbacks,
+or RCCL with world size 1 -- the store code above the transport is the same.  Claim under test
+(SURVEY.md 8(e)): for every shard count, every replica size and every transport the result of
+each rank's OWN request is bit-identical to the unpartitioned operator's.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import glx
+import synth
+
+pytestmark = pytest.mark.gpu
+
+V, D = 5000, 64
+_KEY = [1000]
+
+
+def _fabric_key():
+    _KEY[0] += 1
+    return _KEY[0]
+
+
+@pytest.fixture(scope="module")
+def world():
+    import dist as gdist
+    rp, col, eid, w = synth.small_graph(V, 80000, seed=21, weighted=True, hub_degree=3000)
+    X = np.random.default_rng(4).standard_normal((V, D)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    whole = glx.Graph(t(rp), t(col), t(eid), t(w))
+    feats = glx.Features(t(X))
+    shards = {}
+    for P in (1, 2, 3, 8):
+        gs, fs = [], []
+        for r in range(P):
+            srp, scol, seid, sw, sids = gdist.shard_graph(t(rp), t(col), t(eid), t(w), r, P)
+            gs.append(glx.Graph(srp, scol, seid, sw, ids=sids))
+            fs.append(glx.Features(t(X[r::P].copy()), ids=sids))
+        shards[P] = (gs, fs)
+    indeg = np.bincount(col, minlength=V)
+    return dict(whole=whole, feats=feats, shards=shards, dev=dev, indeg=indeg, col=col, X=X)
+
+
+def _run_ranks(P, body, make_comm=None):
+    """Runs body(rank, comm) on P threads (one per rank); re-raises the first failure."""
+    key = _fabric_key()
+    errors = [None] * P
+
+    def main(r):
+        try:
+            comm = make_comm(r) if make_comm else glx.Comm.local(key, 0, r, P)
+            with torch.cuda.stream(torch.cuda.Stream(device=0)):
+                body(r, comm)
+                torch.cuda.current_stream().synchronize()
+        except BaseException as ex:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            errors[r] = ex
+    ts = [threading.Thread(target=main, args=(r,)) for r in range(P)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join(300)
+    for e in errors:
+        if e is not None:
+            raise e
+    assert not any(th.is_alive() for th in ts), "a rank hung"
+
+
+def _requests(rank, dev, n=3000):
+    rng = np.random.default_rng(100 + rank)
+    src = np.concatenate([rng.integers(0, V, n + 37 * rank), [0, 0, -1, -4, V, 10 ** 9]]).astype(np.int64)
+    return torch.from_numpy(src).to(dev)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_dist_sample_equals_unpartitioned(world, P):
+    whole, dev = world["whole"], world["dev"]
+    gs, _ = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        src = _requests(r, dev)
+        cc = 0
+        for name in glx.SAMPLER_IDS:
+            for k, pad in ((10, 1), (25, 1), (7, 0), (70, 1)):
+                cc += 1
+                n1, e1 = st.sample(name, src, k, seed=9, call_counter=cc, padding_mode=pad, default_neighbor_id=-5)
+                rn, re = whole.sample(name, src, k, seed=9, call_counter=cc, padding_mode=pad, default_neighbor_id=-5)
+                assert torch.equal(n1, rn) and torch.equal(e1, re), (name, k, pad, r)
+        # hop 2 on hop 1's output, as NeighborSampler.get chains them (neighbor_sampler.py:93-127)
+        n2, e2 = st.sample("EdgeWeightSampler", n1.view(-1), 5, seed=9, call_counter=99)
+        rn2, re2 = whole.sample("EdgeWeightSampler", rn.view(-1), 5, seed=9, call_counter=99)
+        assert torch.equal(n2, rn2) and torch.equal(e2, re2)
+        # host pointers (the C++ operators' boundary)
+        hn, he = st.sample("TopkSampler", src.cpu().numpy(), 6, seed=1, call_counter=3)
+        rn3, re3 = whole.sample("TopkSampler", src, 6, seed=1, call_counter=3)
+        assert np.array_equal(hn, rn3.cpu().numpy()) and np.array_equal(he, re3.cpu().numpy())
+        # an empty request still takes part in the collectives
+        en, ee = st.sample("RandomSampler", src[:0], 4, seed=1, call_counter=4)
+        assert en.shape == (0, 4)
+    _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_every_rank_may_use_its_own_seed_and_flags(world, P):
+    """A request's seed / call counter / sampler / padding / default id (and an aggregation's default
+    attribute) travel with it: the owner serves each requester's rows with THAT requester's values."""
+    whole, feats, dev = world["whole"], world["feats"], world["dev"]
+    gs, fs = world["shards"][P]
+    names = list(glx.SAMPLER_IDS)
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r], features=fs[r])
+        src = _requests(r, dev, 700)
+        kw = dict(seed=100 + r, call_counter=7 * r + 1, padding_mode=r % 2, default_neighbor_id=-10 - r)
+        n1, e1 = st.sample(names[r % 4], src, 9, **kw)
+        rn, re = whole.sample(names[r % 4], src, 9, **kw)
+        assert torch.equal(n1, rn) and torch.equal(e1, re), r
+        ids = torch.cat([n1.view(-1)[: 9 * 700 - 3], torch.tensor([-1, V + 7, 10 ** 9], device=dev)])
+        e, c = st.aggregate("SumAggregator", ids, None, 700, default_attr=1.5 + r)
+        ref_e, ref_c = feats.aggregate("SumAggregator", ids, None, 700, default_attr=1.5 + r)
+        assert torch.equal(c, ref_c) and torch.equal(e.view(torch.int32), ref_e.view(torch.int32)), r
+    _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_dist_sample_filtered_equals_unpartitioned(world, P):
+    whole, dev = world["whole"], world["dev"]
+    gs, _ = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        src = _requests(r, dev, 800)
+        rng = np.random.default_rng(7 + r)
+        vals = torch.from_numpy(rng.integers(0, V, src.shape[0]).astype(np.int64)).to(dev)
+        cc = 40
+        for name in glx.SAMPLER_IDS:
+            for ftype in (glx.FILTER_EQUAL, glx.FILTER_LARGER_THAN):
+                cc += 1
+                n1, e1 = st.sample(name, src, 6, seed=5, call_counter=cc, default_neighbor_id=-2, filter_type=ftype,
+                                   filter_field=glx.FILTER_FIELD_ID, values=vals, retry_times=2)
+                rn, re = whole.sample_filtered(name, src, 6, ftype, glx.FILTER_FIELD_ID, vals, seed=5,
+                                               call_counter=cc, default_neighbor_id=-2, retry_times=2)
+                assert torch.equal(n1, rn) and torch.equal(e1, re), (name, ftype, r)
+    _run_ranks(P, body)
+
+
+def _hot(world, count):
+    """Top-`count` ids by in-degree, ties by smaller id (what glx_dist_hot_ids returns)."""
+    indeg = world["indeg"]
+    order = np.lexsort((np.arange(V), -indeg))
+    order = order[indeg[order] > 0]
+    return order[:count].astype(np.int64)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+@pytest.mark.parametrize("cache", ["none", "partial", "all"])
+def test_dist_aggregate_equals_unpartitioned(world, P, cache):
+    feats, dev = world["feats"], world["dev"]
+    _, fs = world["shards"][P]
+    hot = {"none": np.empty(0, np.int64), "partial": _hot(world, 400),
+           "all": np.concatenate([np.arange(V, dtype=np.int64), [V + 5, -9]])}[cache]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, features=fs[r])
+        st.set_cache(torch.from_numpy(hot).to(dev) if r % 2 == 0 else hot, default_attr=123.0)
+        rng = np.random.default_rng(50 + r)
+        n, f = 20000 + 100 * r, 10
+        # power-law-ish ids (hub-heavy), a few unknown / negative ones
+        ids = np.where(rng.random(n) < 0.6, _hot(world, 2000)[rng.integers(0, 2000, n)], rng.integers(-3, V + 3, n))
+        ids = torch.from_numpy(ids.astype(np.int64)).to(dev)
+        seg = torch.from_numpy((np.arange(n) // f).astype(np.int32)).to(dev)
+        for name in glx.AGGREGATOR_IDS:
+            ref_e, ref_c = feats.aggregate(name, ids, seg, n // f, default_attr=0.5)
+            e, c = st.aggregate(name, ids, seg, n // f, default_attr=0.5)
+            assert torch.equal(c, ref_c), (name, r)
+            assert torch.equal(e.view(torch.int32), ref_e.view(torch.int32)), (name, r)
+            s = st.stats()
+            if P > 1 or cache != "none":
+                assert s["ids"] == n and s["from_replica"] + s["from_own_shard"] + s["remote"] == n, s
+                assert s["remote_distinct"] <= s["remote"]
+                if cache == "all":
+                    assert s["remote"] == 0, s
+                if cache == "none" and P > 1:
+                    assert s["from_replica"] == 0 and s["remote"] > 0, s
+        # equal segments without a segment tensor (a dense sampler response), and ragged + stalled ones
+        e, c = st.aggregate("MeanAggregator", ids, None, n // f, default_attr=0.5)
+        ref_e, ref_c = feats.aggregate("MeanAggregator", ids, seg, n // f, default_attr=0.5)
+        assert torch.equal(c, ref_c) and torch.equal(e.view(torch.int32), ref_e.view(torch.int32))
+        rag = torch.from_numpy(np.sort(rng.integers(0, 500, n)).astype(np.int32)).to(dev)
+        rag[n // 2] = 3  # out of order: the cursor stalls here (aggregating_request.cc:86-105)
+        e, c = st.aggregate("SumAggregator", ids, rag, 500, default_attr=-1.0)
+        ref_e, ref_c = feats.aggregate("SumAggregator", ids, rag, 500, default_attr=-1.0)
+        assert torch.equal(c, ref_c) and torch.equal(e.view(torch.int32), ref_e.view(torch.int32))
+        # host pointers
+        he, hc = st.aggregate("MaxAggregator", ids.cpu().numpy(), seg.cpu().numpy(), n // f, default_attr=0.5)
+        ref_e, ref_c = feats.aggregate("MaxAggregator", ids, seg, n // f, default_attr=0.5)
+        assert np.array_equal(hc, ref_c.cpu().numpy())
+        assert np.array_equal(he.view(np.uint32), ref_e.cpu().numpy().view(np.uint32))
+        # LookupNodes in distributed mode
+        rows = st.lookup(ids[:5000], default_attr=7.0)
+        assert torch.equal(rows.view(torch.int32), feats.lookup(ids[:5000], 7.0).view(torch.int32))
+        # an empty request
+        e, c = st.aggregate("SumAggregator", ids[:0], seg[:0], 0)
+        assert e.shape[0] == 0
+    _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [2, 8])
+def test_halo_set_grows_when_it_overflows(world, P):
+    """The set of distinct halo ids is sized from the previous request; a much larger cold tail must
+    trigger the retry with the safe size on the ranks that overflow, in lockstep with the others."""
+    feats, dev = world["feats"], world["dev"]
+    _, fs = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, features=fs[r])
+        rng = np.random.default_rng(r)
+        for n in (64, 120000, 300, 120000):
+            # half of the ids are unknown everywhere (default rows) so that the distinct remote ids
+            # outnumber the 16 Ki slots the set starts with
+            mixed = np.where(rng.random(n) < 0.5, rng.integers(0, V, n), rng.integers(V, 10 ** 7, n))
+            ids = torch.from_numpy(mixed.astype(np.int64)).to(dev) if (r > 0 or n > 64) else \
+                torch.zeros(n, dtype=torch.int64, device=dev)
+            e, c = st.aggregate("SumAggregator", ids, None, n // 4, default_attr=0.0)
+            ref_e, ref_c = feats.aggregate("SumAggregator", ids, None, n // 4, default_attr=0.0)
+            assert torch.equal(c, ref_c) and torch.equal(e.view(torch.int32), ref_e.view(torch.int32)), (n, r)
+    _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [1, 3, 8])
+def test_dist_hot_ids_is_the_global_in_degree_top_k(world, P):
+    gs, _ = world["shards"][P]
+    want = 300
+    expect = _hot(world, want)
+    got = [None] * P
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        got[r] = st.hot_ids(want)
+    _run_ranks(P, body)
+    for r in range(P):
+        assert np.array_equal(got[r], expect), r
+
+
+def test_callback_transport_matches(world):
+    """Host-staged transport (the interface torch.distributed gloo / MPI plug into): three ranks
+    whose all-to-all / all-gather callbacks meet on an in-memory board."""
+    P = 3
+    feats, whole, dev = world["feats"], world["whole"], world["dev"]
+    gs, fs = world["shards"][P]
+    bar = threading.Barrier(P)
+    board = [None] * P
+
+    def make_comm(r):
+        def a2a(send, send_counts, recv, recv_counts, eb):
+            offs = np.concatenate([[0], np.cumsum(send_counts)]) * eb
+            board[r] = (send, offs)
+            bar.wait(60)
+            at = 0
+            for q in range(P):
+                s, o = board[q]
+                piece = s[int(o[r]):int(o[r + 1])]
+                assert piece.shape[0] == int(recv_counts[q]) * eb
+                recv[at:at + piece.shape[0]] = piece
+                at += piece.shape[0]
+            bar.wait(60)
+
+        def gather(send, recv):
+            board[r] = send
+            bar.wait(60)
+            n = send.shape[0]
+            for q in range(P):
+                recv[q * n:(q + 1) * n] = board[q]
+            bar.wait(60)
+        return glx.Comm.callbacks(0, r, P, a2a, gather)
+
+    def body(r, comm):
+        assert comm.transport == glx.COMM_CALLBACKS
+        st = glx.DistStore(comm, graph=gs[r], features=fs[r])
+        st.set_cache(_hot(world, 100))
+        src = _requests(r, dev, 500)
+        n1, e1 = st.sample("RandomWithoutReplacementSampler", src, 8, seed=3, call_counter=1)
+        rn, re = whole.sample("RandomWithoutReplacementSampler", src, 8, seed=3, call_counter=1)
+        assert torch.equal(n1, rn) and torch.equal(e1, re)
+        e, c = st.aggregate("MeanAggregator", n1.view(-1), None, src.shape[0], default_attr=0.25)
+        ref_e, ref_c = feats.aggregate("MeanAggregator", rn.view(-1), None, src.shape[0], default_attr=0.25)
+        assert torch.equal(c, ref_c) and torch.equal(e.view(torch.int32), ref_e.view(torch.int32))
+    _run_ranks(P, body, make_comm)
+
+
+def test_exchange_primitives_local(world):
+    """glx_exchange_v / glx_comm_allgather_i64 with device and host buffers."""
+    P = 4
+    dev = world["dev"]
+
+    def body(r, comm):
+        send_counts = np.array([(r + p) % 3 + 1 for p in range(P)], np.int64)
+        recv_counts = np.array([(q + r) % 3 + 1 for q in range(P)], np.int64)
+        rows = np.concatenate([np.full((int(send_counts[p]), 3), 100 * r + p, np.int64) for p in range(P)])
+        expect = np.concatenate([np.full((int(recv_counts[q]), 3), 100 * q + r, np.int64) for q in range(P)])
+        got = comm.exchange_v(torch.from_numpy(rows).to(dev), send_counts, recv_counts)
+        assert np.array_equal(got.cpu().numpy(), expect)
+        got_h = comm.exchange_v(rows, send_counts, recv_counts)
+        assert np.array_equal(got_h, expect)
+        m = comm.allgather_i64(torch.tensor([r, 10 * r], dtype=torch.int64, device=dev))
+        assert m.cpu().tolist() == [[q, 10 * q] for q in range(P)]
+        mh = comm.allgather_i64(np.array([r + 1], np.int64))
+        assert mh.reshape(-1).tolist() == [q + 1 for q in range(P)]
+        comm.barrier()
+    _run_ranks(P, body)
+
+
+def test_rccl_world_size_one(world):
+    """The RCCL transport itself (ncclCommInitRank, send/recv groups, self copies, message rounds) with
+    one rank, and the store's generic path with the world-size-1 shortcut switched off."""
+    feats, whole, dev = world["feats"], world["whole"], world["dev"]
+    gs, fs = world["shards"][1]
+    comm = glx.Comm.rccl(0, 0, 1, glx.Comm.unique_id())
+    assert comm.transport == glx.COMM_RCCL and comm.world == 1
+    comm.set_max_message_bytes(4096)  # force several rounds
+    x = torch.arange(50000, dtype=torch.int64, device=dev).view(-1, 2)
+    y = comm.exchange_v(x, np.array([25000], np.int64), np.array([25000], np.int64))
+    assert torch.equal(x, y)
+    assert comm.allgather_i64(torch.tensor([5, 6], dtype=torch.int64, device=dev)).cpu().tolist() == [[5, 6]]
+    comm.barrier()
+    os.environ["GLX_DIST_NO_SHORTCUT"] = "1"
+    try:
+        st = glx.DistStore(comm, graph=gs[0], features=fs[0])
+    finally:
+        del os.environ["GLX_DIST_NO_SHORTCUT"]
+    st.set_cache(_hot(world, 200))
+    src = _requests(0, dev)
+    n1, e1 = st.sample("EdgeWeightSampler", src, 10, seed=2, call_counter=8)
+    rn, re = whole.sample("EdgeWeightSampler", src, 10, seed=2, call_counter=8)
+    assert torch.equal(n1, rn) and torch.equal(e1, re)
+    e, c = st.aggregate("MaxAggregator", n1.view(-1), None, src.shape[0])
+    ref_e, ref_c = feats.aggregate("MaxAggregator", rn.view(-1), None, src.shape[0])
+    assert torch.equal(c, ref_c) and torch.equal(e.view(torch.int32), ref_e.view(torch.int32))
+    s = st.stats()
+    assert s["remote"] == 0 and s["from_replica"] > 0
+
+
+def test_in_degree_sampler_is_refused_on_a_partitioned_store(world):
+    gs, _ = world["shards"][2]
+    dev = world["dev"]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        with pytest.raises(glx.GlxError, match="InDegreeSampler"):
+            st.sample("InDegreeSampler", _requests(r, dev, 10), 3)
+    _run_ranks(2, body)
+
+
+def test_uniform_segments_single_gpu(world):
+    """glx_aggregate with segment_ids == NULL equals the explicit arange // k segment tensor."""
+    feats, dev = world["feats"], world["dev"]
+    rng = np.random.default_rng(0)
+    for k, sg in ((10, 1000), (1, 50), (25, 64), (7, 1)):
+        ids = torch.from_numpy(rng.integers(-2, V + 2, k * sg).astype(np.int64)).to(dev)
+        seg = (torch.arange(k * sg, device=dev) // k).to(torch.int32)
+        for name in glx.AGGREGATOR_IDS:
+            e, c = feats.aggregate(name, ids, None, sg, default_attr=0.5)
+            re_, rc = feats.aggregate(name, ids, seg, sg, default_attr=0.5)
+            assert torch.equal(c, rc) and torch.equal(e.view(torch.int32), re_.view(torch.int32)), (name, k)
+    # host pointers
+    ids = rng.integers(0, V, 60).astype(np.int64)
+    e, c = feats.aggregate("SumAggregator", ids, None, 6)
+    re_, rc = feats.aggregate("SumAggregator", ids, (np.arange(60) // 10).astype(np.int32), 6)
+    assert np.array_equal(c, rc) and np.array_equal(e.view(np.uint32), re_.view(np.uint32))
