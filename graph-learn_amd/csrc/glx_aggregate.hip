@@ -175,13 +175,10 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
 // Rows in flight per lane.  8 is the default; GLX_AGG_UNROLL=10|12 selects the other
 // instantiations of the wide float4 shapes for A/B runs (a fanout-10 segment is then one
 // batch of loads instead of 8 + 2).
-int agg_unroll() {
-  static const int u = [] {
-    const char* e = getenv("GLX_AGG_UNROLL");
-    const int v = e ? atoi(e) : 8;
-    return (v == 10 || v == 12) ? v : 8;
-  }();
-  return u;
+int agg_unroll() {  // read per launch so that one process can A/B
+  const char* e = getenv("GLX_AGG_UNROLL");
+  const int v = e ? atoi(e) : 8;
+  return (v == 10 || v == 12) ? v : 8;
 }
 
 template <int OP, int G, int VEC, int NSRC>

@@ -508,11 +508,13 @@ extern "C" int glx_sample_hops(const glx_graph* const* graphs, int32_t num_hops,
   int64_t* d = nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), total * 8, s, 0);
   if (rc != GLX_OK) return rc;
-  GLX_HIP(hipMemcpyAsync(d, seeds, (size_t)batch * 8, hipMemcpyHostToDevice, s));
+  // Errors are collected, not returned on the spot: copies already queued into the caller's
+  // buffers must drain (and the shared staging buffer must be idle) before this call returns.
+  hipError_t e = hipMemcpyAsync(d, seeds, (size_t)batch * 8, hipMemcpyHostToDevice, s);
   const int64_t* frontier = d;
   int64_t* cursor = d + batch;
   int64_t n = batch;
-  for (int32_t h = 0; h < num_hops; ++h) {
+  for (int32_t h = 0; h < num_hops && e == hipSuccess && rc == GLX_OK; ++h) {
     const int64_t slots = n * fanouts[h];
     int64_t* dn = cursor;
     int64_t* de = cursor + slots;
@@ -521,14 +523,18 @@ extern "C" int glx_sample_hops(const glx_graph* const* graphs, int32_t num_hops,
       rc = glx_sample(graphs[h], sampler, frontier, (int32_t)n, fanouts[h], padding_mode,
                       default_neighbor_id, seed, call_counter + (uint64_t)h, dn, de, GLX_PTR_DEVICE, s);
       if (rc != GLX_OK) break;
-      GLX_HIP(hipMemcpyAsync(nbr_out[h], dn, (size_t)slots * 8, hipMemcpyDeviceToHost, s));
-      if (eid_out && eid_out[h]) GLX_HIP(hipMemcpyAsync(eid_out[h], de, (size_t)slots * 8, hipMemcpyDeviceToHost, s));
+      e = hipMemcpyAsync(nbr_out[h], dn, (size_t)slots * 8, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess && eid_out && eid_out[h]) {
+        e = hipMemcpyAsync(eid_out[h], de, (size_t)slots * 8, hipMemcpyDeviceToHost, s);
+      }
     }
     frontier = dn;
     n = slots;
   }
   hipError_t e2 = hipStreamSynchronize(s);
+  glx_scratch_free(d, s);
   if (rc != GLX_OK) return rc;
+  GLX_HIP(e);
   GLX_HIP(e2);
   return GLX_OK;
 }

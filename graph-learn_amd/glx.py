@@ -210,10 +210,13 @@ def _kind(*xs):
     return kinds.pop()
 
 
-def _stream(kind):
+def _stream(kind, device=None):
+    """torch's current stream ON THE DEVICE THE HANDLE LIVES ON (not on torch's current device: a process
+    that drives several GPUs, or set_device_id() without torch.cuda.set_device(), would otherwise pass a
+    stream of another device)."""
     if kind == PTR_DEVICE:
         import torch
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     return None
 
 
@@ -228,7 +231,7 @@ class Graph:
         self.device = device
         h = ctypes.c_void_p()
         _check(lib().glx_graph_create(device, self.num_rows, self.num_edges, ptrs[0][0], ptrs[1][0],
-                                      ptrs[2][0], ptrs[3][0], ptrs[4][0], kind, _stream(kind),
+                                      ptrs[2][0], ptrs[3][0], ptrs[4][0], kind, _stream(kind, self.device),
                                       ctypes.byref(h)))
         self._h = h
 
@@ -244,7 +247,7 @@ class Graph:
         h = ctypes.c_void_p()
         order = 2 if timestamp is not None else (1 if sort_by_weight else 0)
         _check(lib().glx_graph_build_ordered(device, int(src.shape[0]), ptrs[0][0], ptrs[1][0], ptrs[2][0],
-                                             ptrs[3][0], ptrs[4][0], order, kind, _stream(kind), ctypes.byref(h)))
+                                             ptrs[3][0], ptrs[4][0], order, kind, _stream(kind, device), ctypes.byref(h)))
         self._h = h
         self.device = device
         v, e = ctypes.c_int64(), ctypes.c_int64()
@@ -258,10 +261,10 @@ class Graph:
         self = cls.__new__(cls)
         self._h = ctypes.c_void_p(int(handle))
         self._borrowed = True
-        self.device = device
-        v, e = ctypes.c_int64(), ctypes.c_int64()
-        _check(lib().glx_graph_info(self._h, ctypes.byref(v), ctypes.byref(e), None, None, None))
+        v, e, d = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _check(lib().glx_graph_info(self._h, ctypes.byref(v), ctypes.byref(e), None, None, ctypes.byref(d)))
         self.num_rows, self.num_edges = v.value, e.value
+        self.device = d.value  # the device the handle lives on, whatever the caller passed
         return self
 
     def close(self):
@@ -293,12 +296,12 @@ class Graph:
             deg = torch.empty(batch, dtype=torch.int32, device=src.device)
             off = torch.empty(batch + 1, dtype=torch.int64, device=src.device)
             _check(lib().glx_sample_full_sizes(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0],
-                                               PTR_DEVICE, _stream(PTR_DEVICE)))
+                                               PTR_DEVICE, _stream(PTR_DEVICE, self.device)))
             total = int(off[-1].item())
             nbr = torch.empty(total, dtype=torch.int64, device=src.device)
             eid = torch.empty(total, dtype=torch.int64, device=src.device)
             _check(lib().glx_sample_full(self._h, _ptr(src)[0], batch, max_limit, _ptr(off)[0], _ptr(nbr)[0],
-                                         _ptr(eid)[0], PTR_DEVICE, _stream(PTR_DEVICE)))
+                                         _ptr(eid)[0], PTR_DEVICE, _stream(PTR_DEVICE, self.device)))
             return deg, nbr, eid
         deg = np.empty(batch, np.int32)
         off = np.empty(batch + 1, np.int64)
@@ -314,7 +317,7 @@ class Graph:
     def set_timestamps(self, ts_slot):
         """Per-slot edge timestamps (CSR order) for a handle made from a CSR; mutates the handle."""
         p, kind = _ptr(ts_slot)
-        _check(lib().glx_graph_set_timestamps(self._h, p, kind, _stream(kind)))
+        _check(lib().glx_graph_set_timestamps(self._h, p, kind, _stream(kind, self.device)))
 
     def sample_filtered(self, sampler, src, k, filter_type, filter_field, values, seed=0, call_counter=0,
                         padding_mode=PAD_CIRCULAR, default_neighbor_id=0, retry_times=5, default_timestamp=-1,
@@ -334,7 +337,7 @@ class Graph:
         kind = _kind(ps, pn, pe, pr, pv)
         flt = Filter(filter_type, filter_field, pv[0], retry_times, default_timestamp)
         _check(lib().glx_sample_filtered(self._h, sampler, ps[0], pr[0], batch, k, padding_mode, default_neighbor_id,
-                                         seed, call_counter, ctypes.byref(flt), pn[0], pe[0], kind, _stream(kind)))
+                                         seed, call_counter, ctypes.byref(flt), pn[0], pe[0], kind, _stream(kind, self.device)))
         return nbr, eid
 
     def sample_full_filtered(self, src, max_limit, filter_type, filter_field, values, padding_mode=PAD_CIRCULAR,
@@ -351,7 +354,7 @@ class Graph:
             off = np.empty(batch + 1, np.int64)
         kind = PTR_DEVICE if torch_in else PTR_HOST
         _check(lib().glx_sample_full_sizes(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0], kind,
-                                           _stream(kind)))
+                                           _stream(kind, self.device)))
         total = int(off[-1].item()) if torch_in else int(off[-1])
         if torch_in:
             nbr = torch.empty(total, dtype=torch.int64, device=src.device)
@@ -362,7 +365,7 @@ class Graph:
         flt = Filter(filter_type, filter_field, _ptr(values)[0], 0, default_timestamp)
         _check(lib().glx_sample_full_filtered(self._h, _ptr(src)[0], batch, max_limit, _ptr(off)[0], padding_mode,
                                               default_neighbor_id, ctypes.byref(flt), _ptr(nbr)[0], _ptr(eid)[0], kind,
-                                              _stream(kind)))
+                                              _stream(kind, self.device)))
         return deg, nbr, eid
 
     def random_walk(self, seeds, walk_len, p=1.0, q=1.0, full_nbr_num=100, default_weight=0.0, default_neighbor_id=0,
@@ -377,7 +380,7 @@ class Graph:
         ps, pw = _ptr(seeds), _ptr(walks)
         kind = _kind(ps, pw)
         _check(lib().glx_random_walk(self._h, ps[0], batch, walk_len, p, q, full_nbr_num, default_weight,
-                                     default_neighbor_id, seed, call_counter, pw[0], kind, _stream(kind)))
+                                     default_neighbor_id, seed, call_counter, pw[0], kind, _stream(kind, self.device)))
         return walks
 
     def export_alias(self):
@@ -393,7 +396,7 @@ class Graph:
         else:
             out = np.empty(src.shape[0], np.int64)
         (ps, k1), (po, _) = _ptr(src), _ptr(out)
-        _check(lib().glx_graph_degrees(self._h, ps, src.shape[0], po, k1, _stream(k1)))
+        _check(lib().glx_graph_degrees(self._h, ps, src.shape[0], po, k1, _stream(k1, self.device)))
         return out
 
     def in_degrees(self, ids):
@@ -404,7 +407,7 @@ class Graph:
         else:
             out = np.empty(ids.shape[0], np.int64)
         (ps, k1), (po, _) = _ptr(ids), _ptr(out)
-        _check(lib().glx_graph_in_degrees(self._h, ps, ids.shape[0], po, k1, _stream(k1)))
+        _check(lib().glx_graph_in_degrees(self._h, ps, ids.shape[0], po, k1, _stream(k1, self.device)))
         return out
 
     def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR,
@@ -426,7 +429,7 @@ class Graph:
         kind = _kind(ps, pn, pe, pr)
         _check(lib().glx_sample_ex(self._h, sampler, ps[0], pr[0], batch, k, padding_mode,
                                    default_neighbor_id, seed, call_counter, pn[0], pe[0], kind,
-                                   _stream(kind)))
+                                   _stream(kind, self.device)))
         return nbr, eid
 
 
@@ -450,7 +453,7 @@ class Features:
         self.device = device
         h = ctypes.c_void_p()
         _check(lib().glx_features_create(device, self.num_rows, self.dim, ptrs[0][0], ptrs[1][0], kind,
-                                         _stream(kind), ctypes.byref(h)))
+                                         _stream(kind, self.device), ctypes.byref(h)))
         self._h = h
 
     @classmethod
@@ -459,10 +462,10 @@ class Features:
         self = cls.__new__(cls)
         self._h = ctypes.c_void_p(int(handle))
         self._borrowed = True
-        self.device = device
-        v, d = ctypes.c_int64(), ctypes.c_int32()
-        _check(lib().glx_features_info(self._h, ctypes.byref(v), ctypes.byref(d), None, None))
+        v, d, dv = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int()
+        _check(lib().glx_features_info(self._h, ctypes.byref(v), ctypes.byref(d), None, ctypes.byref(dv)))
         self.num_rows, self.dim = v.value, d.value
+        self.device = dv.value  # the device the handle lives on, whatever the caller passed
         return self
 
     def close(self):
@@ -495,7 +498,7 @@ class Features:
         pi, pg, pe, pc = _ptr(node_ids), _ptr(segment_ids), _ptr(emb), _ptr(cnt)
         kind = _kind(pi, pg, pe, pc)
         _check(lib().glx_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0],
-                                   pc[0], kind, _stream(kind)))
+                                   pc[0], kind, _stream(kind, self.device)))
         return emb, cnt
 
     def lookup(self, node_ids, default_attr=0.0):
@@ -507,7 +510,7 @@ class Features:
             out = np.empty((n, self.dim), np.float32)
         pi, po = _ptr(node_ids), _ptr(out)
         kind = _kind(pi, po)
-        _check(lib().glx_lookup(self._h, pi[0], n, default_attr, po[0], kind, _stream(kind)))
+        _check(lib().glx_lookup(self._h, pi[0], n, default_attr, po[0], kind, _stream(kind, self.device)))
         return out
 
 
@@ -538,7 +541,7 @@ def sample_hops(graphs, sampler, seeds, fanouts, seed=0, call_counter=0, padding
     pn = (ctypes.c_void_p * L)(*[_ptr(o[0])[0] for o in outs])
     pe = (ctypes.c_void_p * L)(*[_ptr(o[1])[0] for o in outs])
     _check(lib().glx_sample_hops(gh, L, sampler, _ptr(seeds)[0], int(seeds.shape[0]), fo, padding_mode,
-                                 default_neighbor_id, seed, call_counter, pn, pe, kind, _stream(kind)))
+                                 default_neighbor_id, seed, call_counter, pn, pe, kind, _stream(kind, graphs[0].device)))
     return outs
 
 
@@ -551,7 +554,7 @@ def partition(ids, num_shards):
     counts = torch.empty(num_shards, dtype=torch.int64, device=ids.device)
     dev = ids.device.index or 0
     _check(lib().glx_partition(dev, _ptr(ids)[0], n, num_shards, _ptr(bucketed)[0], _ptr(order)[0],
-                               _ptr(counts)[0], _stream(PTR_DEVICE)))
+                               _ptr(counts)[0], _stream(PTR_DEVICE, dev)))
     return bucketed, order, counts
 
 
@@ -564,7 +567,7 @@ def stitch(rows, order):
     dev = rows.device.index or 0
     fn = lib().glx_stitch_i64 if rows.dtype == torch.int64 else lib().glx_stitch_f32
     assert rows.dtype in (torch.int64, torch.float32)
-    _check(fn(dev, _ptr(rows)[0], _ptr(order)[0], n, width, _ptr(out)[0], _stream(PTR_DEVICE)))
+    _check(fn(dev, _ptr(rows)[0], _ptr(order)[0], n, width, _ptr(out)[0], _stream(PTR_DEVICE, dev)))
     return out
 
 
@@ -578,9 +581,10 @@ class Negative:
         ptrs = [_ptr(ids), _ptr(weights)]
         kind = _kind(*ptrs)
         h = ctypes.c_void_p()
-        _check(lib().glx_negative_create(device, int(ids.shape[0]), ptrs[0][0], ptrs[1][0], kind, _stream(kind),
+        _check(lib().glx_negative_create(device, int(ids.shape[0]), ptrs[0][0], ptrs[1][0], kind, _stream(kind, device),
                                          ctypes.byref(h)))
         self._h = h
+        self.device = device
         self._info()
 
     @classmethod
@@ -591,6 +595,7 @@ class Negative:
         h = ctypes.c_void_p()
         _check(lib().glx_negative_from_graph(graph._h, 1 if by_in_degree else 0, None, ctypes.byref(h)))
         self._h = h
+        self.device = graph.device
         self._info()
         return self
 
@@ -629,7 +634,7 @@ class Negative:
         ps, po = _ptr(src), _ptr(out)
         kind = _kind(ps, po)
         _check(lib().glx_negative_sample(self._h, exclude, graph._h if graph is not None else None, ps[0], batch,
-                                         count, default_neighbor_id, seed, call_counter, po[0], kind, _stream(kind)))
+                                         count, default_neighbor_id, seed, call_counter, po[0], kind, _stream(kind, self.device)))
         return out
 
 
@@ -646,7 +651,7 @@ def aggregate_stitch(op, parts, cnts, default_attr=0.0):
     cnt = torch.empty((sg,), dtype=torch.int32, device=parts.device)
     dev = parts.device.index or 0
     _check(lib().glx_aggregate_stitch(dev, op, P, _ptr(parts)[0], _ptr(cnts)[0], sg, dim, default_attr,
-                                      _ptr(emb)[0], _ptr(cnt)[0], _stream(PTR_DEVICE)))
+                                      _ptr(emb)[0], _ptr(cnt)[0], _stream(PTR_DEVICE, dev)))
     return emb, cnt
 
 
@@ -747,7 +752,7 @@ class Comm:
             eb = send.dtype.itemsize * width
         ps, po = _ptr(send), _ptr(out)
         kind = _kind(ps, po)
-        _check(lib().glx_exchange_v(self._h, ps[0], _ptr(sc)[0], po[0], _ptr(rc)[0], eb, kind, _stream(kind)))
+        _check(lib().glx_exchange_v(self._h, ps[0], _ptr(sc)[0], po[0], _ptr(rc)[0], eb, kind, _stream(kind, self.device)))
         return out
 
     def allgather_i64(self, vals):
@@ -760,11 +765,11 @@ class Comm:
             out = np.empty((self.world, n), np.int64)
         pv, po = _ptr(vals), _ptr(out)
         kind = _kind(pv, po)
-        _check(lib().glx_comm_allgather_i64(self._h, pv[0], n, po[0], kind, _stream(kind)))
+        _check(lib().glx_comm_allgather_i64(self._h, pv[0], n, po[0], kind, _stream(kind, self.device)))
         return out
 
     def barrier(self):
-        _check(lib().glx_comm_barrier(self._h, _stream(PTR_DEVICE)))
+        _check(lib().glx_comm_barrier(self._h, _stream(PTR_DEVICE, self.device)))
 
 
 class DistStore:
@@ -794,13 +799,13 @@ class DistStore:
         """Replicate the rows of hot_ids (same list on every rank) on this GPU; empty list drops the replica."""
         n = int(hot_ids.shape[0])
         p, kind = _ptr(hot_ids) if n else (None, PTR_HOST)
-        _check(lib().glx_dist_store_set_cache(self._h, p, n, default_attr, kind, _stream(kind)))
+        _check(lib().glx_dist_store_set_cache(self._h, p, n, default_attr, kind, _stream(kind, self.comm.device)))
 
     def hot_ids(self, want):
         """The `want` destination ids with the largest global in-degree (numpy int64, same on every rank)."""
         out = np.empty(max(int(want), 1), np.int64)
         n = ctypes.c_int64(0)
-        _check(lib().glx_dist_hot_ids(self._h, int(want), _ptr(out)[0], ctypes.byref(n), _stream(PTR_DEVICE)))
+        _check(lib().glx_dist_hot_ids(self._h, int(want), _ptr(out)[0], ctypes.byref(n), _stream(PTR_DEVICE, self.comm.device)))
         return out[:n.value].copy()
 
     def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR, default_neighbor_id=0,
@@ -824,7 +829,7 @@ class DistStore:
         if values is not None and filter_type != FILTER_NONE:
             flt = ctypes.byref(Filter(filter_type, filter_field, pv[0], retry_times, default_timestamp))
         _check(lib().glx_dist_sample(self._h, sampler, ps[0], batch, k, padding_mode, default_neighbor_id, seed,
-                                     call_counter, flt, pn[0], pe[0], kind, _stream(kind)))
+                                     call_counter, flt, pn[0], pe[0], kind, _stream(kind, self.comm.device)))
         return nbr, eid
 
     def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, out=None):
@@ -844,7 +849,7 @@ class DistStore:
         pi, pg, pe, pc = _ptr(node_ids), _ptr(segment_ids), _ptr(emb), _ptr(cnt)
         kind = _kind(pi, pg, pe, pc)
         _check(lib().glx_dist_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0], pc[0], kind,
-                                        _stream(kind)))
+                                        _stream(kind, self.comm.device)))
         return emb, cnt
 
     def lookup(self, node_ids, default_attr=0.0):
@@ -856,7 +861,7 @@ class DistStore:
             out = np.empty((n, self.dim), np.float32)
         pi, po = _ptr(node_ids), _ptr(out)
         kind = _kind(pi, po)
-        _check(lib().glx_dist_lookup(self._h, pi[0], n, default_attr, po[0], kind, _stream(kind)))
+        _check(lib().glx_dist_lookup(self._h, pi[0], n, default_attr, po[0], kind, _stream(kind, self.comm.device)))
         return out
 
     def stats(self):

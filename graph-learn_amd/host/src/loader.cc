@@ -448,8 +448,22 @@ Status LoadEdges(const EdgeSource& source, GraphStore* store) {
     if (ok && source.IsTimestamped()) ok = FieldInt64(fld, c++, &ts);
     Status bad;
     if (!ok) bad = error::InvalidArgument("Invalid edge record in " + source.path);
-    else if (!store->Owns(reversed ? dst : src)) return error::OUT_OF_RANGE;  // another shard's edge: read on
-    else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
+    else if (!store->Owns(reversed ? dst : src)) {
+      // Another shard's edge: read on.  With ignore_invalid off a malformed record is fatal, and it must
+      // be fatal on EVERY rank (all ranks read the same files and meet in collectives afterwards): the
+      // non-owners validate the attributes too, into a scratch they throw away.
+      if (!skip_bad && source.IsAttributed()) {
+        std::vector<int64_t> ti;
+        std::vector<float> tf;
+        std::vector<std::string> ts_;
+        bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &ti, &tf, &ts_);
+        if (!bad.ok()) {
+          *why = bad;
+          return bad.code();
+        }
+      }
+      return error::OUT_OF_RANGE;
+    } else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
     if (!bad.ok()) {
       if (skip_bad) return error::OUT_OF_RANGE;  // edge_loader.cc:70-78: ignore the record, read on
       *why = bad;
@@ -511,8 +525,20 @@ Status LoadNodes(const NodeSource& source, GraphStore* store) {
     if (ok && source.IsTimestamped()) ok = FieldInt64(fld, c++, &ts);
     Status bad;
     if (!ok) bad = error::InvalidArgument("Invalid node record in " + source.path);
-    else if (!store->Owns(id)) return error::OUT_OF_RANGE;  // another shard's node: read on
-    else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
+    else if (!store->Owns(id)) {
+      // another shard's node: read on -- after the same validation its owner performs (see LoadEdges)
+      if (!skip_bad && source.IsAttributed()) {
+        std::vector<int64_t> ti;
+        std::vector<float> tf;
+        std::vector<std::string> ts_;
+        bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &ti, &tf, &ts_);
+        if (!bad.ok()) {
+          *why = bad;
+          return bad.code();
+        }
+      }
+      return error::OUT_OF_RANGE;
+    } else if (source.IsAttributed()) bad = ParseAttribute(fld.ptr[c], fld.len[c], source.attr_info, &out->i_attrs, &out->f_attrs, &out->s_attrs);
     if (!bad.ok()) {
       if (skip_bad) return error::OUT_OF_RANGE;
       *why = bad;

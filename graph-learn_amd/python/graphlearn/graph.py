@@ -5,10 +5,12 @@ Same construction protocol as graphlearn/python/graph.py:
     g.neighbor_sampler(["buy"], expand_factor=[10]).get(ids)
 `init()` parses the sources on the host (C++), builds CSR / alias tables / the feature
 matrix on the GPU and keeps them resident there; every sampler / aggregator call then
-goes Python -> pywrap -> Operator::Process -> HIP.  Distributed deploy modes
-(init(cluster=...), task_count > 1), GSL (`V()/E()`), subgraph / conditional-negative samplers
-and the vineyard backend are outside the path this engine replaces and raise
-NotImplementedError.
+goes Python -> pywrap -> Operator::Process -> HIP.  Multi-GPU is the SPMD mode:
+init(task_index=r, task_count=P) in each of P processes (one per GPU) keeps the records that
+hash to shard r, and sharded_store() serves sampling / aggregation across the shards over RCCL.
+The reference's client/server deploy modes (init(cluster=...)), GSL (`V()/E()`), subgraph /
+conditional-negative samplers and the vineyard backend are outside the path this engine
+replaces and raise NotImplementedError.
 """
 import os
 import sys
@@ -132,16 +134,21 @@ class Graph(object):
     errors.raise_exception_on_not_ok_status(self._server.init_status())
     return self
 
-  def sharded_store(self, edge_type, node_type=None, group=None, replicate_features=False):
+  def sharded_store(self, edge_type, node_type=None, group=None, replicate_features=False, hot_nodes=0):
     """The edge type (and optionally a node type's float attributes) across all shards of an
     init(task_index, task_count) job, as a dist.ShardedStore: `store.sample(sampler, cuda_ids, k, ...)`
     and `store.aggregate(op, node_ids, segment_ids, num_segments)` are collective calls -- every rank
-    passes its own batch, rows are routed to their owners by llabs(id) % world over RCCL all-to-all
-    (HashPartitioner / Stitcher on the device) and the answers equal a single store's, draw for draw.
-    Needs an initialised torch.distributed process group whose size is task_count.
-    replicate_features=True all-gathers the feature shards once so that aggregation needs no exchange."""
+    passes its own batch, rows are routed to their owners by llabs(id) % world over RCCL
+    (HashPartitioner / Stitcher on the device, glx_dist_*) and the answers equal a single store's, draw
+    for draw.  Needs an initialised torch.distributed process group whose size is task_count.
+    hot_nodes=K keeps a replica of the K vertices with the largest in-degree (over all shards of
+    `edge_type`) on every GPU; aggregation then fetches only the remaining remote rows per request.
+    replicate_features (a full copy of the table on every GPU) is not offered here: use hot_nodes."""
     import torch.distributed as torch_dist
     import dist as glx_dist
+    if replicate_features:
+      raise NotImplementedError("replicate_features is not offered by sharded_store(); hot_nodes=K replicates the "
+                                "K hottest rows (K = the node count replicates everything that has in-edges)")
     if not torch_dist.is_initialized():
       raise RuntimeError("sharded_store needs torch.distributed.init_process_group (backend 'nccl' = RCCL)")
     world = torch_dist.get_world_size(group)
@@ -150,10 +157,10 @@ class Graph(object):
       raise ValueError("the process group says rank {} of {}, the graph was initialised as shard {} of {}".format(
           torch_dist.get_rank(group), world, shard[0], shard[1]))
     feats = self.device_features(node_type) if node_type is not None else None
-    replica = None
-    if feats is not None and replicate_features:
-      raise NotImplementedError("replicate_features needs dense node ids; use graph-learn_amd/dist.py directly")
-    return glx_dist.ShardedStore(glx_dist.DeviceOps(), self.device_graph(edge_type), feats, group, replica)
+    store = glx_dist.ShardedStore(glx_dist.DeviceOps(), self.device_graph(edge_type), feats, group)
+    if hot_nodes and feats is not None:
+      store.native.set_cache(store.native.hot_ids(int(hot_nodes)))
+    return store
 
   def close(self):
     if self._client is not None:

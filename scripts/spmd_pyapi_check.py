@@ -73,10 +73,25 @@ for trial, name in enumerate(["TopkSampler", "EdgeWeightSampler", "RandomSampler
         emb, cnt = store.aggregate(op, nbr.reshape(-1), seg, ids.shape[0])
         wemb, wcnt = whole_feats.aggregate(op, nbr.reshape(-1).contiguous(), seg, ids.shape[0])
         assert torch.equal(cnt, wcnt), (rank, name, op)
-        if op == "MaxAggregator":
-            assert torch.equal(emb, wemb), (rank, name, op)
-        else:
-            assert torch.allclose(emb, wemb, rtol=1e-5, atol=1e-5), (rank, name, op)
+        # the halo design reduces on the requester in request order: bit-identical for every aggregator
+        assert torch.equal(emb.view(torch.int32), wemb.view(torch.int32)), (rank, name, op)
+
+# a replica of the hottest rows on every GPU changes where rows come from, never the answer
+hot_store = shard.sharded_store("e", "n", hot_nodes=50)
+emb, cnt = hot_store.aggregate("MeanAggregator", nbr.reshape(-1), seg, ids.shape[0])
+wemb, wcnt = whole_feats.aggregate("MeanAggregator", nbr.reshape(-1).contiguous(), seg, ids.shape[0])
+assert torch.equal(cnt, wcnt) and torch.equal(emb.view(torch.int32), wemb.view(torch.int32)), rank
+st = hot_store.stats()
+assert st["from_replica"] > 0 and st["from_replica"] + st["from_own_shard"] + st["remote"] == st["ids"], st
+
+# InDegreeSampler weighs neighbours by their in-degree over ALL shards; a shard's tables only count its own
+# edges, so a partitioned store refuses it instead of drawing from a different distribution
+if world > 1:
+    try:
+        store.sample("InDegreeSampler", ids, 3)
+        raise AssertionError("InDegreeSampler must be refused on a partitioned store")
+    except Exception as ex:  # noqa: BLE001
+        assert "InDegreeSampler" in str(ex), ex
 torch.cuda.synchronize()
 td.barrier()
 shard.close()

@@ -1,0 +1,246 @@
+"""GPU tests at the FULL sizes of the other BASELINE.json configs (test_gpu_fullsize.py covers
+configs[2]), through size-independent properties checked with torch -- no CPU reference needed:
+
+  C2  configs[1]  RMAT 2.4M nodes / 62M edges, RandomWithoutReplacement [15,10], Sum/Mean, dim 128
+  C4  configs[3]  RMAT 111M nodes / 1.6B edges, RandomSampler [20,15], Mean, dim 128 -- on ONE GPU
+                  (the 288 GB hold it); and the same shape with 2.3B edges, i.e. MORE THAN 2^31 CSR
+                  slots and edge ids: the size at which the reference's int32 offsets break
+                  (core/graph/storage/types.h:28) and where any 32-bit narrowing here would show
+  C5  configs[4]  3 edge types (user-item 300M, item-shop 100M, user-shop 100M edges over
+                  40M / 9M / 1M nodes), per-type TopkSampler k = 10 / 10 / 5 + type-wise Sum, dim 256
+
+Properties: every sampled (src, nbr, eid) is a real edge (edge id = insertion index, so
+src[eid] / dst[eid] of the generated edge list are the witnesses), default fill exactly on
+rows without out-edges, without-replacement rows are duplicate-free and circularly padded,
+Topk equals the first k of the row in the reference's order (weight descending, ties by
+insertion), rows whose CSR slots lie beyond 2^31 are checked explicitly, Sum matches torch
+within 1e-5 relative, Mean == Sum / count bit for bit, counts == segment sizes.
+"""
+import pytest
+import torch
+
+import glx
+import synth
+
+pytestmark = pytest.mark.gpu
+B0 = 65536
+
+
+def _edge_witness(src_all, dst_all, src, nbr, eid, deg, default=0):
+    """eid is the insertion index of the sampled edge: it must leave `src` and arrive at `nbr`."""
+    k = nbr.shape[1]
+    real = eid >= 0
+    e = eid.clamp(min=0)
+    assert bool((src_all[e] == src.view(-1, 1).expand(-1, k))[real].all()), "edge id is not an out-edge of its source"
+    assert bool((dst_all[e] == nbr)[real].all()), "neighbour id does not match the edge id"
+    empty = (deg[src.clamp(min=0)] == 0).view(-1, 1).expand(-1, k)
+    assert bool((real == ~empty).all()), "default fill must happen exactly for rows without neighbours"
+    assert bool((nbr[~real] == default).all())
+
+
+def _sum_mean_check(f, X, ids, k, sg, dev, dim):
+    """Sum within 1e-5 relative of torch (only the summation order differs), Mean == Sum / count bit for
+    bit, counts == k; uniform segments (segment_ids = None) == explicit segment ids on a sample."""
+    emb_sum, cnt = f.aggregate("SumAggregator", ids, None, sg)
+    emb_mean, cnt_m = f.aggregate("MeanAggregator", ids, None, sg)
+    torch.cuda.synchronize()
+    assert bool((cnt == k).all()) and torch.equal(cnt, cnt_m)
+    assert torch.equal(emb_mean, emb_sum / cnt.view(-1, 1).to(torch.float32))
+    chunk = 1 << 15
+    for lo in range(0, sg, chunk * 16):  # 1/16 of the segments, evenly spread
+        hi = min(lo + chunk, sg)
+        rows = X[ids[lo * k:hi * k]].view(hi - lo, k, dim)
+        ref = rows.sum(1)
+        err = (emb_sum[lo:hi] - ref).abs()
+        tol = 1e-5 * rows.abs().sum(1) + 1e-30
+        assert bool((err <= tol).all()), float((err / tol).max())
+    part = min(sg, 1 << 16)
+    seg = (torch.arange(part * k, device=dev) // k).to(torch.int32)
+    e2, c2 = f.aggregate("SumAggregator", ids[:part * k].contiguous(), seg, part)
+    assert torch.equal(c2, cnt[:part]) and torch.equal(e2.view(torch.int32), emb_sum[:part].view(torch.int32))
+    return emb_sum
+
+
+def test_c2_products_shape_full_size():
+    V, E, D, K1, K2 = 2_400_000, 62_000_000, 128, 15, 10
+    dev = torch.device("cuda", 0)
+    src, dst, _ = synth.rmat_edges_torch(V, E, 2, dev, weighted=False)
+    g = glx.Graph.from_edges(src, dst, None)
+    deg = torch.bincount(src, minlength=V)
+    assert g.num_edges == E and g.num_rows == int((deg > 0).sum())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    seeds = torch.randint(0, V, (B0,), generator=gen, device=dev)
+    name = "RandomWithoutReplacementSampler"
+    n1, e1 = g.sample(name, seeds, K1, seed=11, call_counter=1)
+    n2, e2 = g.sample(name, n1.view(-1), K2, seed=11, call_counter=2)
+    torch.cuda.synchronize()
+    for s, nbr, eid, k in ((seeds, n1, e1, K1), (n1.view(-1), n2, e2, K2)):
+        _edge_witness(src, dst, s, nbr, eid, deg)
+        d = deg[s].view(-1, 1)
+        m = d.clamp(max=k)
+        j = torch.arange(k, device=dev).view(1, -1)
+        # circular padding: slot j repeats slot j % min(k, deg)
+        rep = torch.gather(eid, 1, (j % m.clamp(min=1)).expand_as(eid))
+        assert bool(((eid == rep) | (d == 0)).all())
+        # the first min(k, deg) picks are distinct edges
+        big = torch.where(j < m, eid, torch.full_like(eid, -1) - j)
+        srt = torch.sort(big, dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())
+        # (a row with deg <= k therefore returns ALL its edges: deg distinct out-edges of a deg-edge row)
+    m1, f1 = g.sample(name, seeds, K1, seed=11, call_counter=1)
+    assert torch.equal(m1, n1) and torch.equal(f1, e1)
+    X = synth.features_torch(V, D, 3, dev)
+    f = glx.Features(X)
+    _sum_mean_check(f, X, n2.view(-1), K2, B0 * K1, dev, D)
+    _sum_mean_check(f, X, n1.view(-1), K1, B0, dev, D)
+
+
+def _edges_leaving(pick, src, dev):
+    """Edge ids (ascending = insertion order) of the edges whose source is in the sorted id list `pick`,
+    and for each the index of its source in `pick`.  Chunked: torch.nonzero is limited to 2^31 elements."""
+    ids, owners = [], []
+    step = 1 << 30
+    for lo in range(0, src.shape[0], step):
+        part = src[lo:lo + step]
+        pos = torch.searchsorted(pick, part)
+        hit = pick[pos.clamp(max=pick.shape[0] - 1)] == part
+        e = torch.nonzero(hit).view(-1)
+        ids.append(e + lo)
+        owners.append(pos[e])
+        del pos, hit, e
+    return torch.cat(ids), torch.cat(owners)
+
+
+@pytest.mark.parametrize("E,with_features", [(1_600_000_000, True), (2_300_000_000, False)])
+def test_c4_papers100m_shape_full_size(E, with_features):
+    V, D, K1, K2 = 111_000_000, 128, 20, 15
+    far = 2 ** 31 if E > 2 ** 31 else 2 ** 30  # "far" slots / edge ids: beyond int32 when the graph has them
+    dev = torch.device("cuda", 0)
+    src, dst, _ = synth.rmat_edges_torch(V, E, 6, dev, weighted=False)
+    torch.cuda.synchronize()
+    g = glx.Graph.from_edges(src, dst, None)
+    torch.cuda.empty_cache()
+    deg = torch.bincount(src, minlength=V)
+    assert g.num_edges == E and g.num_rows == int((deg > 0).sum())
+    row_start = torch.cumsum(deg, 0) - deg  # rows are stored in ascending id order: first slot of every row
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    seeds = torch.randint(0, V, (B0,), generator=gen, device=dev)
+    assert int((row_start[seeds] >= far).sum()) > B0 // 64  # plenty of request rows live in the far slots
+    q = seeds[:4096].contiguous()
+    assert torch.equal(g.degrees(q), deg[q])
+    n1, e1 = g.sample("RandomSampler", seeds, K1, seed=11, call_counter=1)
+    n2, e2 = g.sample("RandomSampler", n1.view(-1), K2, seed=11, call_counter=2)
+    torch.cuda.synchronize()
+    assert int(e2.max()) >= far  # far edge ids come back intact
+    _edge_witness(src, dst, seeds, n1, e1, deg)
+    _edge_witness(src, dst, n1.view(-1), n2, e2, deg)
+    m1, f1 = g.sample("RandomSampler", seeds, K1, seed=11, call_counter=1)
+    assert torch.equal(m1, n1) and torch.equal(f1, e1)
+    m2, _ = g.sample("RandomSampler", seeds, K1, seed=11, call_counter=3)
+    assert not torch.equal(m2, n1)
+
+    # Exact row contents for rows in the far slots: Topk (circular) on an unweighted type returns the row
+    # in insertion order, slot j = the (j % deg)-th out-edge of the source by edge id.
+    high = torch.nonzero(((row_start >= far) & (deg > 0) & (deg <= 64))[: 2 ** 31 - 1]).view(-1)
+    pick = torch.unique(high[torch.randint(0, high.shape[0], (512,), generator=gen, device=dev)])
+    tn, te = g.sample("TopkSampler", pick, 8, seed=0, call_counter=0)
+    rn, re = g.sample("RandomWithoutReplacementSampler", pick, 64, seed=4, call_counter=5)
+    torch.cuda.synchronize()
+    e_of, owner = _edges_leaving(pick, src, dev)
+    order = torch.sort(owner, stable=True)
+    e_sorted, owner_sorted = e_of[order.indices], order.values
+    first = torch.searchsorted(owner_sorted, torch.arange(pick.shape[0], device=dev))
+    d = deg[pick]
+    j = torch.arange(8, device=dev).view(1, -1)
+    want_e = e_sorted[(first.view(-1, 1) + j % d.view(-1, 1))]
+    assert torch.equal(te, want_e) and torch.equal(tn, dst[want_e])
+    # and a without-replacement request for 64 >= deg neighbours is a permutation of the whole row
+    jj = torch.arange(64, device=dev).view(1, -1)
+    got = torch.sort(torch.where(jj < d.view(-1, 1), re, torch.full_like(re, -1)), dim=1).values
+    exp = torch.sort(torch.where(jj < d.view(-1, 1), e_sorted[(first.view(-1, 1) + jj % d.view(-1, 1))],
+                                 torch.full_like(re, -1)), dim=1).values
+    assert torch.equal(got, exp)
+    del e_of, owner, order, e_sorted, owner_sorted, src, dst, row_start
+    torch.cuda.empty_cache()
+    if not with_features:
+        return
+    X = synth.features_torch(V, D, 9, dev)  # 57 GB
+    f = glx.Features(X)
+    _sum_mean_check(f, X, n2.view(-1), K2, B0 * K1, dev, D)
+    _sum_mean_check(f, X, n1.view(-1), K1, B0, dev, D)
+
+
+def test_c5_hetero_three_edge_types_full_size():
+    D = 256
+    dev = torch.device("cuda", 0)
+    n_user, n_item, n_shop = 40_000_000, 9_000_000, 1_000_000
+    spec = {"u-i": (n_user, n_item, 300_000_000, 10), "i-s": (n_item, n_shop, 100_000_000, 10),
+            "u-s": (n_user, n_shop, 100_000_000, 5)}
+    graphs, raw = {}, {}
+    for i, (t, (ns, nd, ne, k)) in enumerate(spec.items()):
+        src, dst, w = synth.rmat_edges_torch(1 << 26, ne, 20 + i, dev, weighted=True)
+        src %= ns
+        dst %= nd
+        graphs[t] = glx.Graph.from_edges(src, dst, w)
+        raw[t] = (src, dst, w, torch.bincount(src, minlength=ns))
+        assert graphs[t].num_edges == ne
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    seeds = torch.randint(0, n_user, (B0,), generator=gen, device=dev)
+
+    def topk_checked(t, s, k):
+        src, dst, w, deg = raw[t]
+        nbr, eid = graphs[t].sample("TopkSampler", s, k)
+        torch.cuda.synchronize()
+        _edge_witness(src, dst, s, nbr, eid, deg)
+        d = deg[s].view(-1, 1)
+        real = eid >= 0
+        we = torch.where(real, w[eid.clamp(min=0)], torch.zeros((), device=dev))
+        j = torch.arange(k, device=dev).view(1, -1)
+        # weight-descending (memory_adj_matrix.cc:105-125), ties by insertion order (edge id ascending)
+        inside = (j[:, 1:] < d) & real[:, 1:]
+        prev_w, cur_w = we[:, :-1], we[:, 1:]
+        ok = (prev_w > cur_w) | ((prev_w == cur_w) & (eid[:, :-1] < eid[:, 1:]))
+        assert bool((ok | ~inside).all()), t
+        # circular padding repeats the row prefix
+        rep = torch.gather(eid, 1, (j % d.clamp(min=1, max=k)).expand_as(eid))
+        assert bool(((eid == rep) | (d == 0)).all()), t
+        # the first slot is the row's heaviest edge: no out-edge of the source is heavier
+        top_w = torch.zeros(deg.shape[0], device=dev).scatter_reduce(0, src, w, "amax")
+        has = (d.view(-1) > 0)
+        assert bool((we[:, 0][has] == top_w[s][has]).all()), t
+        # distinct edges inside the un-padded prefix
+        big = torch.where(j < d.clamp(max=k), eid, torch.full_like(eid, -1) - j)
+        srt = torch.sort(big, dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all()), t
+        return nbr
+
+    a1 = topk_checked("u-i", seeds, 10)
+    a2 = topk_checked("i-s", a1.view(-1), 10)
+    a3 = topk_checked("u-s", seeds, 5)
+    # exact row prefix on a sample of rows: the k heaviest out-edges by (weight desc, edge id asc)
+    src, dst, w, deg = raw["u-s"]
+    pick = torch.unique(seeds[:512])
+    e_of, owner = _edges_leaving(pick, src, dev)
+    o1 = torch.sort(w[e_of], descending=True, stable=True).indices
+    e_w = e_of[o1]
+    o2 = torch.sort(owner[o1], stable=True)
+    e_sorted, owner_sorted = e_w[o2.indices], o2.values
+    first = torch.searchsorted(owner_sorted, torch.arange(pick.shape[0], device=dev))
+    d = deg[pick].view(-1, 1)
+    tn, te = graphs["u-s"].sample("TopkSampler", pick, 5)
+    j = torch.arange(5, device=dev).view(1, -1)
+    want = e_sorted[(first.view(-1, 1) + j % d.clamp(min=1)).clamp(max=e_sorted.shape[0] - 1)]
+    has = d.view(-1) > 0
+    assert torch.equal(te[has], want[has]) and torch.equal(tn[has], dst[want[has]])
+    del raw, src, dst, w
+    torch.cuda.empty_cache()
+
+    x_item = synth.features_torch(n_item, D, 31, dev)
+    x_shop = synth.features_torch(n_shop, D, 32, dev)
+    f_item, f_shop = glx.Features(x_item), glx.Features(x_shop)
+    _sum_mean_check(f_shop, x_shop, a2.view(-1), 10, B0 * 10, dev, D)
+    _sum_mean_check(f_item, x_item, a1.view(-1), 10, B0, dev, D)
+    _sum_mean_check(f_shop, x_shop, a3.view(-1), 5, B0, dev, D)
