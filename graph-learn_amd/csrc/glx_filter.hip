@@ -348,6 +348,228 @@ __global__ __launch_bounds__(256) void glx_filter_random_kernel(DrawArgs a, Filt
   eid_out[t] = rec.eid;
 }
 
+// ---------------------------------------------------------------------------------------
+// id == value filters (GSL's .filter(): "not back to where the path came from").  A row has few
+// hits -- none at all in most rows -- so ActOn's result is the identity with a handful of
+// corrections.  The hit positions are found with ONE look at the row (a binary search in the
+// row's id-sorted index when glx_graph_enable_id_filter() built it, else one ballot scan), the
+// reserved list is never materialised: with hits h_0 < ... < h_{H-1} and m = n - H survivors,
+//   R(p) = p                                   when p is not a hit,
+//   R(h_r) = the r-th survivor of [m, n), descending   for the hits below m (the holes),
+// which is the closed form of filter.cc:83-94 used by glx_filter_reserve_kernel.  Rows with more
+// than kMaxHits hits (parallel edges to the filtered id) take the general path.
+constexpr int kMaxHits = 8;
+constexpr int kFastMaxK = 32;
+
+struct HitArgs {
+  const GlxAdj* adj;
+  const int64_t* start;
+  const int32_t* deg;
+  const int64_t* values;
+  const int64_t* nbr_sorted;  // per row ascending ids + their row-local positions, or nullptr
+  const int32_t* pos_sorted;
+  int32_t* nhits;             // [batch]
+  int32_t* hits;              // [batch * kMaxHits] ascending positions
+  int32_t batch;
+};
+
+// With the index: one thread per row.
+__global__ void glx_filter_idhits_index_kernel(HitArgs a) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.batch) return;
+  const int32_t n = a.deg[i];
+  const int64_t s = a.start[i], val = a.values[i];
+  int32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int32_t mid = lo + ((hi - lo) >> 1);
+    if (a.nbr_sorted[s + mid] < val) lo = mid + 1; else hi = mid;
+  }
+  int32_t H = 0;
+  int32_t pos[kMaxHits];
+  while (lo + H < n && a.nbr_sorted[s + lo + H] == val) {
+    if (H < kMaxHits) {  // insertion sort: positions ascending
+      int32_t p = a.pos_sorted[s + lo + H], t = H;
+      while (t > 0 && pos[t - 1] > p) {
+        pos[t] = pos[t - 1];
+        --t;
+      }
+      pos[t] = p;
+    }
+    ++H;
+  }
+  a.nhits[i] = H;
+  for (int32_t t = 0; t < H && t < kMaxHits; ++t) a.hits[(int64_t)i * kMaxHits + t] = pos[t];
+}
+
+// Without it: one wave per row, one pass.
+__global__ __launch_bounds__(64) void glx_filter_idhits_scan_kernel(HitArgs a) {
+  const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int32_t n = a.deg[i];
+  const int64_t s = a.start[i], val = a.values[i];
+  const uint64_t lt = (1ull << lane) - 1ull;
+  int32_t H = 0;
+  for (int32_t base = 0; base < n; base += 64) {
+    const int32_t p = base + lane;
+    const bool h = p < n && a.adj[s + p].nbr == val;
+    const uint64_t b = __ballot(h);
+    if (h) {
+      const int32_t at = H + __popcll(b & lt);
+      if (at < kMaxHits) a.hits[i * kMaxHits + at] = p;
+    }
+    H += __popcll(b);
+  }
+  if (lane == 0) a.nhits[i] = H;
+}
+
+// R(p) for p in [0, m) from the ascending hit list.
+__device__ __forceinline__ int32_t reserved_at(int32_t p, const int32_t* __restrict__ hits, int32_t H, int32_t n) {
+  const int32_t m = n - H;
+  int32_t rank = -1;
+  for (int32_t t = 0; t < H; ++t) {
+    if (hits[t] == p) rank = t;  // hits below m are the first ones: t is the hole's rank
+  }
+  if (rank < 0) return p;
+  // the rank-th survivor of [m, n), walking down from n - 1 and skipping hits
+  int32_t q = n - 1, left = rank, t = H - 1;
+  while (true) {
+    while (t >= 0 && hits[t] > q) --t;
+    if (t >= 0 && hits[t] == q) {
+      --q;
+      continue;
+    }
+    if (left == 0) return q;
+    --left;
+    --q;
+  }
+  (void)m;
+}
+
+struct FastArgs {
+  DrawArgs d;
+  const int32_t* nhits;
+  const int32_t* hits;
+  int32_t* general;   // [batch] 1 = this row takes the general path
+  int32_t sampler;
+  int32_t circular;
+};
+
+// Which rows the closed form does not serve: too many hits; without-replacement beyond the register
+// budget; and the alias samplers as soon as a single neighbour is filtered out (their table must be
+// rebuilt over the reserved weights -- rows WITHOUT a hit keep the table built at load, which is what
+// the reference's per-request build over the unchanged row yields).
+__global__ void glx_filter_classify_kernel(FastArgs a) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.d.batch) return;
+  const int32_t H = a.nhits[i];
+  const bool alias = a.sampler == GLX_SAMPLER_EDGE_WEIGHT || a.sampler == GLX_SAMPLER_IN_DEGREE;
+  bool gen = H > kMaxHits;
+  if (alias) gen = H > 0;
+  if (a.sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT && a.circular && a.d.k > kFastMaxK) gen = H > 0;
+  a.general[i] = gen ? 1 : 0;
+}
+
+// Topk (and every sampler's replicate padding): one thread per output slot.
+__global__ __launch_bounds__(256) void glx_filter_fast_topk_kernel(FastArgs a, int64_t* __restrict__ nbr_out,
+                                                                   int64_t* __restrict__ eid_out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)a.d.batch * a.d.k) return;
+  const int32_t i = (int32_t)(t / a.d.k);
+  const int32_t j = (int32_t)(t - (int64_t)i * a.d.k);
+  if (a.general[i]) return;
+  const int32_t n = a.d.deg[i];
+  const int32_t H = a.nhits[i];
+  const int32_t m = n - H;
+  GlxAdj rec = GlxAdj{a.d.default_nbr, -1};
+  if (a.circular) {
+    if (m > 0) rec = a.d.adj[a.d.start[i] + reserved_at(j % m, a.hits + (int64_t)i * kMaxHits, H, n)];
+  } else if (j < m) {
+    rec = a.d.adj[a.d.start[i] + j];  // ReplicatePadder ignores the index values
+  }
+  nbr_out[t] = rec.nbr;
+  eid_out[t] = rec.eid;
+}
+
+// RandomWithoutReplacement, circular padding, k <= kFastMaxK: one thread per row runs the contract's
+// forward Fisher-Yates over the implicit reserved list with a sparse record of the swapped entries.
+__global__ void glx_filter_fast_rwor_kernel(FastArgs a, int64_t* __restrict__ nbr_out, int64_t* __restrict__ eid_out) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.d.batch || a.general[i]) return;
+  const int32_t n = a.d.deg[i];
+  const int32_t H = a.nhits[i];
+  const int32_t m = n - H;
+  const int32_t k = a.d.k;
+  const int64_t o = (int64_t)i * k;
+  if (m <= 0) {
+    for (int32_t j = 0; j < k; ++j) {
+      nbr_out[o + j] = a.d.default_nbr;
+      eid_out[o + j] = -1;
+    }
+    return;
+  }
+  const int32_t* hits = a.hits + (int64_t)i * kMaxHits;
+  const uint32_t rr = a.d.rng_rows ? (uint32_t)a.d.rng_rows[i] : (uint32_t)i;
+  const int32_t steps = m < k ? m : k;
+  int32_t okey[kFastMaxK], oval[kFastMaxK], outv[kFastMaxK];
+  int32_t no = 0;
+  for (int32_t j = 0; j < steps; ++j) {
+    const int32_t r = j + (int32_t)glx_bounded(glx_draw64(a.d.seed, a.d.cc, rr, (uint32_t)j), (uint64_t)(m - j));
+    int32_t aj = -1, ar = -1, at_r = -1;
+    for (int32_t t = 0; t < no; ++t) {
+      if (okey[t] == j) aj = oval[t];
+      if (okey[t] == r) {
+        ar = oval[t];
+        at_r = t;
+      }
+    }
+    if (aj < 0) aj = reserved_at(j, hits, H, n);
+    if (ar < 0) ar = r == j ? aj : reserved_at(r, hits, H, n);
+    outv[j] = ar;  // entry j is final after this step
+    if (r != j) {
+      if (at_r >= 0) oval[at_r] = aj;
+      else {
+        okey[no] = r;
+        oval[no] = aj;
+        ++no;
+      }
+    }
+  }
+  const int64_t s = a.d.start[i];
+  for (int32_t j = 0; j < k; ++j) {
+    const GlxAdj rec = a.d.adj[s + outv[j % m]];  // j % m < steps
+    nbr_out[o + j] = rec.nbr;
+    eid_out[o + j] = rec.eid;
+  }
+}
+
+// The rows left to the general path, packed into a request of their own (src, random stream row,
+// filter value) + where their answers go.
+__global__ void glx_filter_pack_general_kernel(const int32_t* __restrict__ general, const int64_t* __restrict__ src,
+                                               const int64_t* __restrict__ rng, const int64_t* __restrict__ values,
+                                               int32_t batch, int32_t* __restrict__ count, int32_t* __restrict__ gidx,
+                                               int64_t* __restrict__ sub_src, int64_t* __restrict__ sub_rng,
+                                               int64_t* __restrict__ sub_val) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch || !general[i]) return;
+  const int32_t at = atomicAdd(count, 1);
+  gidx[at] = i;
+  sub_src[at] = src[i];
+  sub_rng[at] = rng ? rng[i] : (int64_t)i;
+  sub_val[at] = values[i];
+}
+
+__global__ void glx_filter_unpack_general_kernel(const int32_t* __restrict__ gidx, int32_t G, int32_t k,
+                                                 const int64_t* __restrict__ sub_nbr, const int64_t* __restrict__ sub_eid,
+                                                 int64_t* __restrict__ nbr_out, int64_t* __restrict__ eid_out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)G * k) return;
+  const int32_t r = (int32_t)(t / k);
+  const int32_t j = (int32_t)(t - (int64_t)r * k);
+  const int64_t o = (int64_t)gidx[r] * k + j;
+  nbr_out[o] = sub_nbr[t];
+  eid_out[o] = sub_eid[t];
+}
+
 constexpr int kFullSampler = -1;
 // Upper bound on the reserved positions held in scratch at once.  A request whose rows'
 // degrees add up to more is served in chunks of consecutive rows (a single larger row is a
@@ -372,9 +594,9 @@ int64_t span_cap(size_t bytes_per_position) {
 
 // All pointers are device pointers.  `sampler` is a GLX_SAMPLER_* id or kFullSampler (then
 // d_offsets[batch + 1] gives the segments and k is unused).
-int filtered_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng, int32_t batch,
-                    int32_t k, const int64_t* d_offsets, int padding_mode, int64_t default_nbr, uint64_t seed,
-                    uint64_t cc, FilterDev f, int64_t* d_nbr, int64_t* d_eid, hipStream_t s) {
+int filtered_general(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng, int32_t batch,
+                     int32_t k, const int64_t* d_offsets, int padding_mode, int64_t default_nbr, uint64_t seed,
+                     uint64_t cc, FilterDev f, int64_t* d_nbr, int64_t* d_eid, hipStream_t s, int ws_base) {
   const bool circular = padding_mode == GLX_PAD_CIRCULAR;
   const size_t nb = (size_t)batch;
   // row info: start[batch] i64 | soff[batch + 1] i64 | deg[batch] i32 | cnt[batch] i32

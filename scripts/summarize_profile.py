@@ -15,8 +15,8 @@ def short(n):
     return (m.group(1) + (m.group(2) or "")) if m else n
 b = json.load(open(os.path.join(dst, "bench_under_rocprof_trace.json")))
 rows = [r for r in csv.DictReader(open(os.path.join(dst, "kernel_stats_trace.csv"))) if "glx" in r["Name"]]
-out = ["# %s rocprofv3 summary (one MI355X; `python bench.py --steps 20 --warmup 3 --cpu-baseline off`, workload c3, B0=65536)" % tag, "",
-       "Commands (scripts/profile_r01.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...`; PMC: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run with `--kernel-trace` only (5 steps + 1 warm-up).", "",
+out = ["# %s rocprofv3 summary (one MI355X; `python bench.py --steps 20 --warmup 5 --cpu-baseline off --roofline-probes off`, workload c3, B0=65536)" % tag, "",
+       "Commands (scripts/profile_r01.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...`; PMC: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run with `--kernel-trace` only (5 steps + 1 warm-up); script: scripts/profile_bench.sh.", "",
        "## glx kernels (kernel-trace stats; torch's synthetic-data generator kernels omitted)", "",
        "| kernel | calls | total ms | avg us | % of all GPU time |", "|---|---|---|---|---|"]
 for r in rows:
@@ -26,16 +26,25 @@ tr = [r for r in csv.DictReader(open(os.path.join(dst, "kernel_trace_glx_only.cs
 dur = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr)
 hop2 = [d for d in dur if d > 1.0]
 hop1 = [d for d in dur if d <= 1.0]
-out += ["", "`glx_aggregate_kernel<2, 64, 4, 8>` = MaxAggregator, 64 lanes/segment, float4, 8 loads in flight. It is dispatched twice per step; "
+out += ["", "`glx_aggregate_kernel<2, 64, 4, 8, 1>` = MaxAggregator, 64 lanes/segment, float4, 8 loads in flight, one row source. It is dispatched twice per step; "
         "from the per-dispatch rows (`kernel_trace_glx_only.csv`): %d hop-2 dispatches (16,384,000 ids -> 1,638,400 segments) average **%.3f ms**, "
         "%d hop-1 dispatches (1,638,400 -> 65,536) average %.3f ms. bench.py's live HIP-event measurement of the hop-2 launches in the same run: "
         "**%.3f ms** (`roofline.avg_launch_ms`)." % (len(hop2), sum(hop2) / len(hop2), len(hop1), sum(hop1) / max(len(hop1), 1), b["roofline"]["avg_launch_ms"])]
+PMC_STEPS = 6  # the PMC passes run --steps 5 --warmup 1; later hop-2-sized launches are bench.py's cache-free probe
 def agg(name):
     d = collections.OrderedDict()
+    probe = []
+    big = collections.Counter()
     for r in csv.DictReader(open(os.path.join(dst, "pmc_%s_glx_only.csv" % name))):
-        d.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    return d
-f, w = agg("FETCH_SIZE"), agg("WRITE_SIZE")
+        k = r["Kernel_Name"]
+        if "glx_aggregate_kernel" in k and int(r["Grid_Size"]) >= 100_000_000:
+            big[k] += 1
+            if big[k] > PMC_STEPS:  # uniform-row probe launches (roofline.cache_free), not the workload
+                probe.append(float(r["Counter_Value"]))
+                continue
+        d.setdefault(k, []).append(float(r["Counter_Value"]))
+    return d, probe
+(f, f_probe), (w, w_probe) = agg("FETCH_SIZE"), agg("WRITE_SIZE")
 out += ["", "## HBM-side traffic (PMC, KB per dispatch)", "",
         "FETCH_SIZE on gfx950 reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section). Calibration inside this run: "
         "`glx_gather_adj_kernel` / `glx_pack_adj_kernel`-class streaming kernels and rocPRIM's sort passes confirm it (see round-1 note below); "
@@ -54,6 +63,11 @@ out += ["", "Hop-2 aggregate launch (max over dispatches): read %.2f GB + write 
         "At %.3f ms per launch that is %.2f TB/s of real traffic (copy ceiling of the part ~6.3 TB/s) and %.2f TB/s algorithmic = %.1f%% of the 8 TB/s peak."
         % (rd / 1e9, wr / 1e9, (rd + wr) / 1e9, alg / 1e9, ms, (rd + wr) / ms / 1e9, alg / ms / 1e9, alg / ms / 8e9 * 100),
         ""]
+if f_probe:
+    prd, pwr = max(f_probe) * 2 * 1024, max(w_probe) * 1024 if w_probe else 0.0
+    out += ["The same kernel on uniformly random rows of the whole table (bench.py's `roofline.cache_free` probe, %d launches in the PMC pass): "
+            "read %.2f GB + write %.2f GB = %.2f GB per launch, i.e. the algorithmic bytes -- without reuse every row comes over the fabric once, "
+            "which also validates the x2 correction on this access pattern." % (len(f_probe), prd / 1e9, pwr / 1e9, (prd + pwr) / 1e9), ""]
 cal = [x for x in f if "glx_place_rows_kernel" in x]
 if cal:
     known = 10_000_000 * 256 * 4  # the C3 feature upload streams exactly V*D*4 bytes in and out
