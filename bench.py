@@ -362,6 +362,9 @@ def main():
     ap.add_argument("--hot-fraction", type=float, default=0.10,
                     help="N>1: every GPU keeps a replica of this fraction of the feature rows (the top vertices by "
                          "global in-degree); the rest is fetched per request (halo exchange of the cold tail)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
+                         "auto = on for launch-bound batches (B0 <= 8192)")
     ap.add_argument("--roofline-probes", default="on", choices=["on", "off"],
                     help="N=1: also time the aggregation kernel on cache-free (uniform) rows and a device copy")
     ap.add_argument("--force-sharded", action="store_true",
@@ -577,9 +580,28 @@ def main():
         return dt, t_a, t_s
 
     edges_per_step = n1 + n2  # response slots, padding included
+    kernel_steps = args.steps  # steps the per-kernel timers covered
     ctl = dev if args.backend == "nccl" else torch.device("cpu")  # control-plane tensors (gloo rig: host)
     legs = {}
-    if not sharded:
+    use_graph = not sharded and (args.graph == "on" or (args.graph == "auto" and B0 <= 8192))
+    if use_graph:
+        # launch-bound batch sizes: the whole step (2 sample + 2 aggregate kernels) is ONE hipGraph launch
+        # (glx_plan); seeds and call counter enter through the graph's stage node
+        plan = glx.Plan([graph, graph], sampler, [k1, k2], B0, features=[feats, feats], agg=agg, seed=42)
+        for i in range(args.warmup):
+            plan.run(seeds[i], call_counter=4 * i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_steps):
+            plan.run(seeds[i], call_counter=4 * i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # kernel durations for the roofline line: a few steps issued kernel by kernel, outside the timed region
+        kernel_steps = min(args.steps, 10)
+        _, t_agg, t_smp = timed_leg(agg_local(feats), 0, kernel_steps, 2)
+        headline = "single GPU, one hipGraph launch per step"
+        placement = "1 GPU; step = one hipGraph launch (glx_plan)"
+    elif not sharded:
         elapsed, t_agg, t_smp = timed_leg(agg_local(feats), args.warmup, n_steps, args.warmup)
         headline = "single GPU"
     else:
@@ -702,8 +724,8 @@ def main():
         torch.cuda.synchronize()
         roof["peak_measured_copy"] = 2 * x.numel() * 4 / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
         del x, y
-    smp_ms = float(np.sum(t_smp)) / max(args.steps, 1)
-    agg_ms = float(np.sum(t_agg)) / max(args.steps, 1)
+    smp_ms = float(np.sum(t_smp)) / max(kernel_steps, 1)
+    agg_ms = float(np.sum(t_agg)) / max(kernel_steps, 1)
     res = {
         "metric": "sampled-edges/sec + aggregated-vertices/sec (2-hop sample + aggregate per step; every "
                   "sampled vertex is aggregated once, so the step rate counts both)",
@@ -719,7 +741,7 @@ def main():
                    "nodes": V, "edges": E, "hop2_rows_without_out_edges_fraction": empty_frac,
                    "vertex_labels": "raw RMAT ids" if args.no_scramble else "RMAT ids relabeled by a fixed random permutation (Graph500-style)",
                    "parallelism": placement,
-                   "pipelined_two_streams": bool(pipelined)},
+                   "pipelined_two_streams": bool(pipelined) and not use_graph, "hipgraph_step": bool(use_graph)},
         "phases": {
             "sampling_kernels_ms_per_step": smp_ms,
             "aggregation_kernels_ms_per_step": agg_ms,

@@ -53,6 +53,17 @@ int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot);
 void glx_scratch_free(void* p, hipStream_t s);
 void glx_scratch_trim(hipStream_t s, int slot, size_t keep_bytes);
 
+// Request plans (glx_plan.hip) capture a sequence of entry points into a hipGraph.  While a plan is
+// being built on this thread: (1) workspaces must not be allocated inside the capture, and must belong to
+// the plan, not to the per-thread cache -- glx_scratch_alloc first RECORDS the sizes of a dry run, then
+// REPLAYS them out of the plan's arena; (2) the samplers read the run's call counter from device memory.
+enum { GLX_SCRATCH_NORMAL = 0, GLX_SCRATCH_RECORD = 1, GLX_SCRATCH_REPLAY = 2 };
+void glx_scratch_mode(int mode, char* arena, size_t arena_bytes);  // RECORD clears the recorded sizes
+size_t glx_scratch_recorded_bytes();
+void glx_capture_set_cc_dev(const uint64_t* p);
+const uint64_t* glx_capture_cc_dev();
+bool glx_profile_suspend(bool suspend);  // returns the previous "enabled" state when suspending
+
 // Temporary device allocation released on every exit path.
 struct GlxTemp {
   void* p = nullptr;
@@ -159,7 +170,8 @@ struct glx_graph {
   float* weight;     // [E] or nullptr
   GlxAlias* alias;   // [E] or nullptr
   GlxAlias* alias_indeg;  // [E] alias tables over the neighbours' in-degrees, or nullptr
-  int64_t* nbr_sorted;    // [E] every row's neighbour ids ascending (strict negative sampling), or nullptr
+  int64_t* nbr_sorted;    // [E] every row's neighbour ids ascending (strict negative sampling, id filters), or nullptr
+  uint32_t* slot_sorted;  // [E] the CSR slot each entry of nbr_sorted came from (built together with it)
   GlxIdMapStorage dst_map;  // destination id -> index into dst_count (with alias_indeg), for in-degree lookups
   int64_t* dst_count;     // [num_dst] in-degree of every distinct destination id
   int64_t num_dst;

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void glx_filter_random_kernel(DrawArgs a, Filt
 // id == value filters (GSL's .filter(): "not back to where the path came from").  A row has few
 // hits -- none at all in most rows -- so ActOn's result is the identity with a handful of
 // corrections.  The hit positions are found with ONE look at the row (a binary search in the
-// row's id-sorted index when glx_graph_enable_id_filter() built it, else one ballot scan), the
+// row's id-sorted index when glx_graph_enable_negative() built it, else one ballot scan), the
 // reserved list is never materialised: with hits h_0 < ... < h_{H-1} and m = n - H survivors,
 //   R(p) = p                                   when p is not a hit,
 //   R(h_r) = the r-th survivor of [m, n), descending   for the hits below m (the holes),
@@ -367,7 +367,7 @@ struct HitArgs {
   const int32_t* deg;
   const int64_t* values;
   const int64_t* nbr_sorted;  // per row ascending ids + their row-local positions, or nullptr
-  const int32_t* pos_sorted;
+  const uint32_t* slot_sorted;
   int32_t* nhits;             // [batch]
   int32_t* hits;              // [batch * kMaxHits] ascending positions
   int32_t batch;
@@ -388,7 +388,7 @@ __global__ void glx_filter_idhits_index_kernel(HitArgs a) {
   int32_t pos[kMaxHits];
   while (lo + H < n && a.nbr_sorted[s + lo + H] == val) {
     if (H < kMaxHits) {  // insertion sort: positions ascending
-      int32_t p = a.pos_sorted[s + lo + H], t = H;
+      int32_t p = (int32_t)((int64_t)a.slot_sorted[s + lo + H] - s), t = H;
       while (t > 0 && pos[t - 1] > p) {
         pos[t] = pos[t - 1];
         --t;
@@ -596,7 +596,7 @@ int64_t span_cap(size_t bytes_per_position) {
 // d_offsets[batch + 1] gives the segments and k is unused).
 int filtered_general(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng, int32_t batch,
                      int32_t k, const int64_t* d_offsets, int padding_mode, int64_t default_nbr, uint64_t seed,
-                     uint64_t cc, FilterDev f, int64_t* d_nbr, int64_t* d_eid, hipStream_t s, int ws_base) {
+                     uint64_t cc, FilterDev f, int64_t* d_nbr, int64_t* d_eid, hipStream_t s) {
   const bool circular = padding_mode == GLX_PAD_CIRCULAR;
   const size_t nb = (size_t)batch;
   // row info: start[batch] i64 | soff[batch + 1] i64 | deg[batch] i32 | cnt[batch] i32
@@ -701,6 +701,88 @@ int filtered_general(const glx_graph* g, int sampler, const int64_t* d_src, cons
   timer.stop();
   GLX_HIP(hipGetLastError());
   glx_scratch_trim(s, 2, (size_t)32 << 30);
+  return GLX_OK;
+}
+
+// Entry of every filtered request.  id == value filters in front of Topk / RandomWithoutReplacement /
+// EdgeWeight / InDegree take the closed-form path above; the few rows it does not serve (and every other
+// filter) go through filtered_general.
+int filtered_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng, int32_t batch,
+                    int32_t k, const int64_t* d_offsets, int padding_mode, int64_t default_nbr, uint64_t seed,
+                    uint64_t cc, FilterDev f, int64_t* d_nbr, int64_t* d_eid, hipStream_t s) {
+  const bool id_equal = f.type == GLX_FILTER_EQUAL && f.field == GLX_FILTER_FIELD_ID;
+  const bool served = sampler == GLX_SAMPLER_TOPK || sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT ||
+                      sampler == GLX_SAMPLER_EDGE_WEIGHT || sampler == GLX_SAMPLER_IN_DEGREE;
+  static const bool disabled = getenv("GLX_FILTER_NO_FAST_PATH") != nullptr;  // A/B and test knob
+  if (!id_equal || !served || batch == 0 || k == 0 || disabled) {
+    return filtered_general(g, sampler, d_src, d_rng, batch, k, d_offsets, padding_mode, default_nbr, seed, cc, f, d_nbr,
+                            d_eid, s);
+  }
+  const bool circular = padding_mode == GLX_PAD_CIRCULAR;
+  const size_t nb = (size_t)batch;
+  // start | sub_src | sub_rng | sub_val (i64) ; deg | nhits | general | gidx (i32) ; hits (i32 x kMaxHits) ; count
+  char* buf = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&buf), nb * 4 * 8 + nb * 4 * 4 + nb * kMaxHits * 4 + 64, s, 4);
+  if (rc != GLX_OK) return rc;
+  int64_t* start = reinterpret_cast<int64_t*>(buf);
+  int64_t* sub_src = start + nb;
+  int64_t* sub_rng = sub_src + nb;
+  int64_t* sub_val = sub_rng + nb;
+  int32_t* deg = reinterpret_cast<int32_t*>(sub_val + nb);
+  int32_t* nhits = deg + nb;
+  int32_t* general = nhits + nb;
+  int32_t* gidx = general + nb;
+  int32_t* hits = gidx + nb;
+  int32_t* count = hits + nb * kMaxHits;
+  const unsigned row_blocks = (unsigned)((nb + 255) / 256);
+  RowArgs ra{g->map(), g->row_ptr, g->adj, d_src, d_rng, batch};
+  glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, nullptr);
+  HitArgs ha{g->adj, start, deg, f.values, g->nbr_sorted, g->slot_sorted, nhits, hits, batch};
+  if (g->nbr_sorted && g->slot_sorted) glx_filter_idhits_index_kernel<<<row_blocks, 256, 0, s>>>(ha);
+  else glx_filter_idhits_scan_kernel<<<(unsigned)batch, 64, 0, s>>>(ha);
+  FastArgs fa;
+  fa.d = DrawArgs{g->adj, start, deg, nullptr, nullptr, nullptr, d_rng, seed, cc, default_nbr, batch, k, 0, batch, 0};
+  fa.nhits = nhits;
+  fa.hits = hits;
+  fa.general = general;
+  fa.sampler = sampler;
+  fa.circular = circular ? 1 : 0;
+  glx_filter_classify_kernel<<<row_blocks, 256, 0, s>>>(fa);
+  GLX_HIP(hipMemsetAsync(count, 0, 4, s));
+  glx_filter_pack_general_kernel<<<row_blocks, 256, 0, s>>>(general, d_src, d_rng, f.values, batch, count, gidx, sub_src,
+                                                            sub_rng, sub_val);
+  int32_t G = 0;
+  GLX_HIP(hipMemcpyAsync(&G, count, 4, hipMemcpyDeviceToHost, s));
+  const bool alias = sampler == GLX_SAMPLER_EDGE_WEIGHT || sampler == GLX_SAMPLER_IN_DEGREE;
+  const bool wide_rwor = sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT && circular && k > kFastMaxK;
+  if (alias || wide_rwor) {
+    // rows without a hit: the unfiltered sampler IS the answer (same reserved list, same weights, hence the
+    // table built at load); rows with a hit are overwritten by the general path below
+    rc = glx_sample_ex(g, sampler, d_src, d_rng, batch, k, padding_mode, default_nbr, seed, cc, d_nbr, d_eid,
+                       GLX_PTR_DEVICE, s);
+    if (rc != GLX_OK) return rc;
+  } else if (sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT && circular) {
+    glx_filter_fast_rwor_kernel<<<row_blocks, 256, 0, s>>>(fa, d_nbr, d_eid);
+  } else {
+    const int64_t total = (int64_t)batch * k;
+    glx_filter_fast_topk_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(fa, d_nbr, d_eid);
+  }
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipStreamSynchronize(s));
+  if (G > 0) {
+    int64_t* sub_out = nullptr;
+    rc = glx_scratch_alloc(reinterpret_cast<void**>(&sub_out), (size_t)G * k * 2 * 8, s, 5);
+    if (rc != GLX_OK) return rc;
+    FilterDev fs = f;
+    fs.values = sub_val;
+    rc = filtered_general(g, sampler, sub_src, sub_rng, G, k, nullptr, padding_mode, default_nbr, seed, cc, fs, sub_out,
+                          sub_out + (size_t)G * k, s);
+    if (rc != GLX_OK) return rc;
+    const int64_t total = (int64_t)G * k;
+    glx_filter_unpack_general_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(gidx, G, k, sub_out,
+                                                                                    sub_out + (size_t)G * k, d_nbr, d_eid);
+    GLX_HIP(hipGetLastError());
+  }
   return GLX_OK;
 }
 

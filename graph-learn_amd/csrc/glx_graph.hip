@@ -93,10 +93,52 @@ struct WsCache {
 thread_local WsCache g_ws;
 }  // namespace
 
+namespace {
+struct ScratchPlan {
+  int mode = GLX_SCRATCH_NORMAL;
+  std::vector<size_t> sizes;  // aligned sizes of the dry run, in call order
+  size_t cursor = 0, offset = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+};
+thread_local ScratchPlan g_scratch_plan;
+thread_local const uint64_t* g_cc_dev = nullptr;
+}  // namespace
+
+void glx_scratch_mode(int mode, char* arena, size_t arena_bytes) {
+  ScratchPlan& sp = g_scratch_plan;
+  sp.mode = mode;
+  sp.cursor = 0;
+  sp.offset = 0;
+  sp.arena = arena;
+  sp.arena_bytes = arena_bytes;
+  if (mode == GLX_SCRATCH_RECORD) sp.sizes.clear();
+}
+
+size_t glx_scratch_recorded_bytes() {
+  size_t total = 0;
+  for (size_t b : g_scratch_plan.sizes) total += b;
+  return total;
+}
+
+void glx_capture_set_cc_dev(const uint64_t* p) { g_cc_dev = p; }
+const uint64_t* glx_capture_cc_dev() { return g_cc_dev; }
+
 int glx_scratch_alloc(void** p, size_t bytes, hipStream_t s, int slot) {
   int dev = 0;
   GLX_HIP(hipGetDevice(&dev));
   if (bytes == 0) bytes = 256;
+  ScratchPlan& sp = g_scratch_plan;
+  if (sp.mode == GLX_SCRATCH_REPLAY) {
+    // the same call sequence as the recorded dry run, served out of the plan's own arena
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    GLX_REQUIRE(sp.cursor < sp.sizes.size() && want <= sp.sizes[sp.cursor] && sp.offset + sp.sizes[sp.cursor] <= sp.arena_bytes,
+                "request plan: workspace request %zu does not match the recorded dry run", sp.cursor);
+    *p = sp.arena + sp.offset;
+    sp.offset += sp.sizes[sp.cursor++];
+    return GLX_OK;
+  }
+  if (sp.mode == GLX_SCRATCH_RECORD) sp.sizes.push_back((bytes + 255) & ~(size_t)255);
   WsKey key{dev, s, slot};
   WsBuf* hit = nullptr;
   for (auto& b : g_ws.bufs) {
@@ -208,6 +250,17 @@ GlxKernelTimer::GlxKernelTimer(int kind, hipStream_t stream) : s(stream) {
 
 void GlxKernelTimer::stop() {
   if (slot >= 0) (void)hipEventRecord(g_prof.launches[slot].stop, s);
+}
+
+bool glx_profile_suspend(bool suspend) {
+  static thread_local bool saved = false;
+  if (suspend) {
+    saved = g_prof.on;
+    g_prof.on = false;
+    return saved;
+  }
+  g_prof.on = saved;
+  return saved;
 }
 
 extern "C" int glx_profile_enable(int on) {
@@ -389,6 +442,7 @@ void glx_graph_free(glx_graph* g) {
   if (g->alias) (void)hipFree(g->alias);
   if (g->alias_indeg) (void)hipFree(g->alias_indeg);
   if (g->nbr_sorted) (void)hipFree(g->nbr_sorted);
+  if (g->slot_sorted) (void)hipFree(g->slot_sorted);
   if (g->dst_count) (void)hipFree(g->dst_count);
   glx_idmap_free(&g->dst_map);
   if (g->ew) (void)hipFree(g->ew);

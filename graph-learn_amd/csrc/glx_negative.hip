@@ -326,6 +326,12 @@ extern "C" int glx_negative_export(const glx_negative* t, int64_t* ids, float* p
   return GLX_OK;
 }
 
+__global__ void glx_neg_iota_u32_kernel(uint32_t* p, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = (uint32_t)i;
+}
+
 extern "C" int glx_graph_enable_negative(glx_graph* g, void* stream) {
   GLX_REQUIRE(g != nullptr, "graph is NULL");
   if (g->nbr_sorted) return GLX_OK;
@@ -334,22 +340,30 @@ extern "C" int glx_graph_enable_negative(glx_graph* g, void* stream) {
   hipStream_t s = glx_stream(stream);
   const int64_t E = g->num_edges, V = g->num_rows;
   int64_t* sorted = nullptr;
+  uint32_t* slots = nullptr;
   GLX_HIP(hipMalloc(&sorted, (size_t)(E > 0 ? E : 1) * 8));
-  GlxTemp own;
+  GlxTemp own, own2;
   own.p = sorted;
+  GLX_HIP(hipMalloc(&slots, (size_t)(E > 0 ? E : 1) * 4));
+  own2.p = slots;
   if (E > 0) {
-    GlxTemp nbr, eid;
+    GlxTemp nbr, eid, iota;
+    GLX_REQUIRE(E < (int64_t)UINT32_MAX, "the id-sorted row index supports up to 2^32 - 1 edges per GPU");
     GLX_HIP(hipMalloc(&nbr.p, (size_t)E * 8));
     GLX_HIP(hipMalloc(&eid.p, (size_t)E * 8));
+    GLX_HIP(hipMalloc(&iota.p, (size_t)E * 4));
     glx_neg_split_adj_kernel<<<grid_for(E), 256, 0, s>>>(g->adj, E, nbr.as<int64_t>(), eid.as<int64_t>());
-    // every row's neighbour ids in ascending order: the membership test is a binary search
-#define SEGSORT(tmp, bytes)                                                                             \
-  rocprim::segmented_radix_sort_keys(tmp, bytes, nbr.as<int64_t>(), sorted, (unsigned int)E, (unsigned int)V, \
-                                     g->row_ptr, g->row_ptr + 1, 0, 64, s)
-    GLX_REQUIRE(E < (int64_t)UINT32_MAX, "strict negative sampling supports up to 2^32 - 1 edges per GPU");
+    glx_neg_iota_u32_kernel<<<grid_for(E), 256, 0, s>>>(iota.as<uint32_t>(), E);
+    // every row's neighbour ids in ascending order, each with the CSR slot it sits in: the membership test of
+    // strict negative sampling is a binary search, an id == value filter finds its hits the same way
+#define SEGSORT(tmp, bytes)                                                                                    \
+  rocprim::segmented_radix_sort_pairs(tmp, bytes, nbr.as<int64_t>(), sorted, iota.as<uint32_t>(), slots,    \
+                                      (unsigned int)E, (unsigned int)V, g->row_ptr, g->row_ptr + 1, 0, 64, s)
     GLX_ROCPRIM(SEGSORT);
 #undef SEGSORT
   }
+  own2.p = nullptr;
+  g->slot_sorted = slots;
   own.p = nullptr;
   g->nbr_sorted = sorted;
   return GLX_OK;

@@ -31,9 +31,14 @@ struct SampleArgs {
   int64_t default_nbr;
   uint64_t seed;
   uint64_t cc;
+  // Inside a captured request plan (glx_plan.hip) the call counter of a run lives in device memory:
+  // the effective counter is cc + *cc_dev.  nullptr everywhere else.
+  const uint64_t* cc_dev;
   int32_t batch;
   int32_t k;
 };
+
+__device__ __forceinline__ uint64_t sample_cc(const SampleArgs& a) { return a.cc_dev ? a.cc + *a.cc_dev : a.cc; }
 
 enum SlotOp { kSlotRandom = 0, kSlotEdgeWeight = 1, kSlotCircular = 2, kSlotReplicate = 3, kSlotEdgeWeightPacked = 4 };
 
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
   if (OP == kSlotRandom || OP == kSlotEdgeWeight || OP == kSlotEdgeWeightPacked) {
     if (deg > 0) {
       const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
-      blk = glx_philox_block((uint32_t)q, rr, a.seed, a.cc);
+      blk = glx_philox_block((uint32_t)q, rr, a.seed, sample_cc(a));
     }
   }
   GlxAdj got[2];
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
   int32_t r = -1;
   if (l < m) {
     const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
-    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, (uint32_t)l), (uint64_t)(deg - l));
+    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, sample_cc(a), rr, (uint32_t)l), (uint64_t)(deg - l));
   }
   int32_t w = 0, perm = 0;
   for (int32_t j = 0; j < a.k; ++j) {
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
   int32_t r = l;
   if (l < m) {
     const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
-    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, (uint32_t)l), (uint64_t)(deg - l));
+    r = l + (int32_t)glx_bounded(glx_draw64(a.seed, sample_cc(a), rr, (uint32_t)l), (uint64_t)(deg - l));
   }
   int32_t rs[W], ws[W];
 #pragma unroll
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(64) void glx_rwor_lds_kernel(SampleArgs a) {
   const int32_t m = (int32_t)(deg < k ? deg : k);
   const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
   for (int32_t t = lane; t < m; t += 64) {
-    r[t] = t + (int32_t)glx_bounded(glx_draw64(a.seed, a.cc, rr, (uint32_t)t), (uint64_t)(deg - t));
+    r[t] = t + (int32_t)glx_bounded(glx_draw64(a.seed, sample_cc(a), rr, (uint32_t)t), (uint64_t)(deg - t));
   }
   __syncthreads();
   for (int32_t j = 0; j < m; ++j) {
@@ -383,6 +388,7 @@ int glx_sample_prefix_device(const glx_graph* g, int sampler, const int64_t* d_s
   a.default_nbr = default_neighbor_id;
   a.seed = seed;
   a.cc = call_counter;
+  a.cc_dev = glx_capture_cc_dev();
   a.batch = batch;
   a.k = k;
   return sample_device(g, sampler, a, padding_mode, s);
@@ -414,6 +420,7 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
   a.default_nbr = default_neighbor_id;
   a.seed = seed;
   a.cc = call_counter;
+  a.cc_dev = glx_capture_cc_dev();
   a.batch = batch;
   a.k = k;
   a.prefix = nullptr;

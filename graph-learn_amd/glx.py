@@ -52,6 +52,7 @@ EXPORTS = [
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_hot_ids",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_lookup", "glx_dist_last_stats",
+    "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
 ]
 
 
@@ -172,6 +173,12 @@ def lib():
         L.glx_dist_aggregate.argtypes = [vp, ci, vp, vp, i32, i32, f32, vp, vp, ci, vp]
         L.glx_dist_lookup.argtypes = [vp, vp, i64, f32, vp, ci, vp]
         L.glx_dist_last_stats.argtypes = [vp, ctypes.POINTER(DistStats)]
+        L.glx_plan_create.argtypes = [vp, i32, ci, vp, i32, ci, i64, u64, vp, ci, f32, ctypes.POINTER(vp)]
+        L.glx_plan_run.argtypes = [vp, vp, u64, vp]
+        L.glx_plan_output.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                      ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32)]
+        L.glx_plan_destroy.argtypes = [vp]
+        L.glx_plan_destroy.restype = None
         _lib = L
     return _lib
 
@@ -282,6 +289,8 @@ class Graph:
     def enable_negative(self):
         """Sort every row's neighbour ids (the exclusion test of strict negative sampling)."""
         _check(lib().glx_graph_enable_negative(self._h, None))
+
+    enable_id_index = enable_negative  # the same per-row id-sorted index serves id == value filters
 
     def enable_in_degree(self):
         """Build the in-degree alias tables InDegreeSampler needs (once, on the device)."""
@@ -868,6 +877,69 @@ class DistStore:
         st = DistStats()
         _check(lib().glx_dist_last_stats(self._h, ctypes.byref(st)))
         return st.as_dict()
+
+
+class _DevArray:
+    """A device buffer owned by a C handle, exposed to torch without a copy (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner  # keeps the plan alive while a tensor view exists
+
+
+class Plan:
+    """A fixed-shape multi-hop sample (+ aggregate) request captured into one hipGraph (glx_plan): the
+    launch-bound small-batch path.  run(seeds, call_counter) replays it on torch's current stream; the outputs
+    are views of plan-owned device buffers, overwritten by the next run."""
+
+    def __init__(self, graphs, sampler, fanouts, batch, features=None, agg=None, seed=0, padding_mode=PAD_CIRCULAR,
+                 default_neighbor_id=0, default_attr=0.0):
+        import torch
+        if isinstance(sampler, str):
+            sampler = SAMPLER_IDS[sampler] if sampler in SAMPLER_IDS else EXTRA_SAMPLER_IDS[sampler]
+        L = len(fanouts)
+        assert len(graphs) == L and (features is None or len(features) == L)
+        self.device = graphs[0].device
+        self._keep = (list(graphs), list(features) if features is not None else None)
+        gh = (ctypes.c_void_p * L)(*[g._h for g in graphs])
+        fo = (ctypes.c_int32 * L)(*[int(f) for f in fanouts])
+        fh = (ctypes.c_void_p * L)(*[f._h for f in features]) if features is not None else None
+        op = AGGREGATOR_IDS[agg] if isinstance(agg, str) else (agg if agg is not None else 0)
+        h = ctypes.c_void_p()
+        _check(lib().glx_plan_create(gh, L, sampler, fo, int(batch), padding_mode, default_neighbor_id, seed, fh, op,
+                                     default_attr, ctypes.byref(h)))
+        self._h = h
+        self.batch, self.num_hops = int(batch), L
+        self.hops = []
+        dev = torch.device("cuda", self.device)
+        for hop in range(L):
+            pn, pe, pm, pc = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            rows, fan = ctypes.c_int64(), ctypes.c_int32()
+            _check(lib().glx_plan_output(h, hop, ctypes.byref(pn), ctypes.byref(pe), ctypes.byref(pm), ctypes.byref(pc),
+                                         ctypes.byref(rows), ctypes.byref(fan)))
+            r, k = rows.value, fan.value
+            out = {"nbr": torch.as_tensor(_DevArray(pn.value, (r, k), "<i8", self), device=dev),
+                   "eid": torch.as_tensor(_DevArray(pe.value, (r, k), "<i8", self), device=dev)}
+            if features is not None:
+                out["emb"] = torch.as_tensor(_DevArray(pm.value, (r, features[hop].dim), "<f4", self), device=dev)
+                out["cnt"] = torch.as_tensor(_DevArray(pc.value, (r,), "<i4", self), device=dev)
+            self.hops.append(out)
+
+    def run(self, seeds, call_counter=0):
+        assert _is_torch(seeds) and seeds.is_cuda and seeds.is_contiguous() and int(seeds.shape[0]) == self.batch
+        _check(lib().glx_plan_run(self._h, _ptr(seeds)[0], call_counter, _stream(PTR_DEVICE, self.device)))
+        return self.hops
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().glx_plan_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    __del__ = close
 
 
 KERNEL_SAMPLE, KERNEL_AGGREGATE, KERNEL_LOOKUP = 0, 1, 2

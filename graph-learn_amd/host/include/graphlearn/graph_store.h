@@ -132,6 +132,8 @@ public:
   Status Negative(bool by_in_degree, bool strict, const glx_negative** out);
   // In-degree alias tables for InDegreeSampler, built on first use.
   Status EnsureInDegree();
+  // Per-row id-sorted index for id == value filters (and strict negative sampling), built on first use.
+  Status EnsureIdIndex();
 
   // Per-edge properties by edge id, host resident (they are not read by the samplers):
   // EdgeStorage::GetWeight/GetLabel/GetTimestamp/GetAttribute

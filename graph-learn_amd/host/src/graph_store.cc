@@ -158,6 +158,18 @@ Status Graph::EnsureInDegree() {
   return Status::OK();
 }
 
+Status Graph::EnsureIdIndex() {
+  // Per-row id-sorted index (shared with strict negative sampling): an id == value filter then finds its
+  // hits with a binary search instead of scanning the row.  Built the first time such a request arrives.
+  std::lock_guard<std::mutex> g(mtx_);
+  if (neg_strict_ready_) return Status::OK();
+  if (!dev_) return error::InvalidArgument("edge type '" + type_ + "' is not built on the device");
+  int rc = glx_graph_enable_negative(dev_, nullptr);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  neg_strict_ready_ = true;
+  return Status::OK();
+}
+
 // ------------------------------------------------------------------ Noder --
 Noder::Noder(const std::string& type) : type_(type), dev_(nullptr), neg_(nullptr) {}
 

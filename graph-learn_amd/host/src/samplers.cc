@@ -56,6 +56,11 @@ protected:
       Status s = graph->EnsureInDegree();
       if (!s.ok()) return s;
     }
+    if (g && req->HasFilter() && (int32_t)req->GetFilterType() == GLX_FILTER_EQUAL &&
+        (int32_t)req->GetFilterField() == GLX_FILTER_FIELD_ID && SamplerId() != GLX_SAMPLER_RANDOM) {
+      Status s = graph->EnsureIdIndex();  // hits by binary search instead of a row scan
+      if (!s.ok()) return s;
+    }
     res->ResizeDense();
     if (!g) {
       // An edge type nobody loaded behaves like a storage without any row:

@@ -346,7 +346,9 @@ GLX_API void glx_negative_destroy(glx_negative* t);
 GLX_API int glx_negative_info(const glx_negative* t, int64_t* num_ids, int* weighted);
 /* Copies the candidate ids and the alias table to HOST arrays (parity checks). */
 GLX_API int glx_negative_export(const glx_negative* t, int64_t* ids, float* prob, int32_t* alias, void* stream);
-/* Builds every row's neighbour ids in ascending order (the exclusion test is a binary search). */
+/* Builds every row's neighbour ids in ascending order, each with the CSR slot it came from: the exclusion
+ * test of strict negative sampling is a binary search in it, and an id == value filter
+ * (glx_sample_filtered) finds its hits the same way instead of scanning the row.  MUTATES the handle. */
 GLX_API int glx_graph_enable_negative(glx_graph* g, void* stream);
 GLX_API int glx_negative_sample(const glx_negative* t, int exclude, const glx_graph* g, const int64_t* src,
                                 int32_t batch, int32_t count, int64_t default_neighbor_id, uint64_t seed,
@@ -499,6 +501,31 @@ typedef struct glx_dist_stats {
   int64_t exchange_rounds; /* transport rounds of the last row exchange (message-size limit) */
 } glx_dist_stats;
 GLX_API int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out);
+
+/* ---- request plans: a multi-hop sample (+ aggregate) request as ONE graph launch.  Replaces the
+ * per-batch walk over a chain of DAG nodes (core/runner/dag_node_runner.cc:32-109: each node builds a
+ * request, runs its operator, feeds the next) and the hop loop of NeighborSampler.get
+ * (python/sampler/neighbor_sampler.py:93-127) for fixed-shape requests. -------------------------
+ * glx_plan_create captures, for `batch` seeds: hop h = glx_sample(graphs[h], sampler, hop h-1's
+ * neighbours, fanouts[h], ...) with random stream (seed, call_counter + h) -- exactly glx_sample_hops --
+ * and, when `features` is given, for every hop h (deepest first) glx_aggregate(features[h], agg_op) of hop
+ * h's neighbours into the fanouts[h]-sized segments of hop h-1's rows (features[h] = the node type hop h
+ * reaches).  The kernels are recorded once into a hipGraph; glx_plan_run(seeds, call_counter) replays it on
+ * `stream`: one launch instead of 2 * num_hops, which is what a small batch (B0 <= 8192) needs -- its kernels
+ * take microseconds, launching them one by one takes longer.  Outputs live in plan-owned device buffers
+ * (glx_plan_output) valid until the next run; results are bit-identical to the separate calls.  A plan is
+ * bound to one device and must not run concurrently with itself. */
+typedef struct glx_plan glx_plan;
+GLX_API int glx_plan_create(const glx_graph* const* graphs, int32_t num_hops, int sampler, const int32_t* fanouts,
+                            int32_t batch, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+                            const glx_features* const* features, int agg_op, float default_attr, glx_plan** out);
+/* seeds[batch]: DEVICE pointer, read when the graph executes. */
+GLX_API int glx_plan_run(glx_plan* p, const int64_t* seeds, uint64_t call_counter, void* stream);
+/* Device buffers of hop `hop`: nbr / eid [rows * fanout], emb [rows * dim] and cnt [rows] (NULL without
+ * aggregation); rows = request rows of the hop.  Any out pointer may be NULL. */
+GLX_API int glx_plan_output(const glx_plan* p, int32_t hop, int64_t** nbr, int64_t** eid, float** emb, int32_t** cnt,
+                            int64_t* rows, int32_t* fanout);
+GLX_API void glx_plan_destroy(glx_plan* p);
 
 /* ---- kernel timing: the device-side counterpart of the reference's
  * PROFILING(key) scope timers (common/base/profiling.h:24-71). ------------

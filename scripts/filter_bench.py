@@ -45,6 +45,9 @@ def timed(fn, reps=5):
 slots = rows.shape[0] * K
 print(json.dumps({"graph": "rmat V=2^20 E=2^25", "rows": int(rows.shape[0]), "k": K,
                   "sum_of_row_degrees": int(g.degrees(rows).sum()), "max_row_degree": int(g.degrees(rows).max())}))
+if "--index" in sys.argv:
+    g.enable_id_index()  # per-row id-sorted index: id == value filters find their hits by binary search
+print(json.dumps({"id_sorted_row_index": "--index" in sys.argv}))
 for name in list(glx.SAMPLER_IDS) + ["InDegreeSampler"]:
     base = timed(lambda: g.sample(name, rows, K, seed=1, call_counter=3))
     by_id = timed(lambda: g.sample_filtered(name, rows, K, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, back, seed=1, call_counter=3))

@@ -170,3 +170,43 @@ def test_filter_without_timestamps_uses_the_default_timestamp(orc):
     assert np.array_equal(a[0], b[0])
     dev.close()
     csr.close()
+
+
+@pytest.mark.parametrize("indexed", [False, True])
+@pytest.mark.parametrize("pad", [glx.PAD_CIRCULAR, glx.PAD_REPLICATE])
+def test_id_equal_fast_path_bit_exact_with_oracle(orc, indexed, pad):
+    """id == value filters take the closed-form path (hit positions from one look at the row -- a binary
+    search in the id-sorted index when it is built, one ballot scan otherwise -- and an implicit reserved
+    list); rows it does not serve fall back to the general path.  Hit patterns exercised: none, one, several,
+    more than kMaxHits = 8 parallel edges (hub rows over 60 distinct destinations), hits at the first / last
+    positions, single-neighbour rows (everything filtered), k beyond the register budget of the
+    without-replacement path (k > 32)."""
+    rng = np.random.default_rng(321 + pad)
+    src, dst, ts, w = random_graph(rng, n_dst=60)
+    dst[::3] = rng.integers(1000, 5000, dst[::3].shape[0])  # a third of the edges go to (mostly) unique ids
+    dev = glx.Graph.from_edges(src, dst, w, timestamp=ts)
+    dev.enable_in_degree()
+    if indexed:
+        dev.enable_id_index()
+    og, rows = oracle_graph(orc, dev, src, ts, w)
+    pos = {int(v): i for i, v in enumerate(rows)}
+    ids = np.concatenate([rng.choice(rows, 900), [999999, -1]]).astype(np.int64)
+    vals = rng.integers(-5, 5000, ids.shape[0]).astype(np.int64)
+    for n, v in enumerate(ids):
+        i = pos.get(int(v))
+        if i is None:
+            continue
+        a, b = og["row_ptr"][i], og["row_ptr"][i + 1]
+        if b > a and n % 5:
+            vals[n] = og["col"][[a, b - 1, rng.integers(a, b), rng.integers(a, b)][n % 4]]
+    flt = dict(type=glx.FILTER_EQUAL, field=glx.FILTER_FIELD_ID, values=vals)
+    rev = np.arange(ids.shape[0], dtype=np.int64)[::-1].copy()  # a shard's slice: streams by original row
+    for name in ("TopkSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "InDegreeSampler"):
+        for k in (1, 5, 12, 40):
+            for rr in (None, rev):
+                want = orc.sample_filtered(og, name, ids, k, flt, seed=23, call_counter=k, padding_mode=pad,
+                                           default_neighbor_id=-3, rng_rows=rr)
+                got = dev.sample_filtered(name, ids, k, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, seed=23,
+                                          call_counter=k, padding_mode=pad, default_neighbor_id=-3, rng_rows=rr)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, k, pad, indexed)
+    dev.close()

@@ -631,3 +631,44 @@ def test_timestamped_edge_type_rows_in_timestamp_order():
     t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
     dev2 = glx.Graph.from_edges(t(g["src"]), t(g["dst"]), t(g["w"]), timestamp=t(g["ts"]))
     assert np.array_equal(dev2.sample("TopkSampler", g["rows"], 4)[0], g["topk_nbr"])
+
+
+def test_request_plan_equals_separate_calls():
+    """glx_plan (one hipGraph launch per batch: the small-batch path) == glx_sample_hops + glx_aggregate
+    called one by one, bit for bit, for every sampler, with dense and hashed ids, over several runs with
+    changing seeds and call counters."""
+    import torch
+    rng = np.random.default_rng(8)
+    rp, col, eid, w = synth.small_graph(3000, 60000, seed=5, weighted=True, hub_degree=500)
+    X = rng.standard_normal((3000, 32)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    for hashed in (False, True):
+        ids = (np.arange(3000, dtype=np.int64) * 3 - 500) if hashed else None
+        mapped = (lambda a: a * 3 - 500) if hashed else (lambda a: a)
+        g = glx.Graph(t(rp), t(mapped(col)), t(eid), t(w), ids=t(ids) if hashed else None)
+        f = glx.Features(t(X), ids=t(ids) if hashed else None)
+        for name in glx.SAMPLER_IDS:
+            for agg in ("MaxAggregator", "MeanAggregator"):
+                plan = glx.Plan([g, g], name, [7, 4], 512, features=[f, f], agg=agg, seed=31, default_neighbor_id=-4,
+                                default_attr=0.5)
+                for run in range(3):
+                    seeds = t(mapped(rng.integers(0, 3005, 512)).astype(np.int64))
+                    hops = plan.run(seeds, call_counter=10 * run)
+                    ref = glx.sample_hops([g, g], name, seeds, [7, 4], seed=31, call_counter=10 * run,
+                                          default_neighbor_id=-4)
+                    torch.cuda.synchronize()
+                    for h in range(2):
+                        assert torch.equal(hops[h]["nbr"], ref[h][0]) and torch.equal(hops[h]["eid"], ref[h][1]), (name, h)
+                        k = (7, 4)[h]
+                        e, c = f.aggregate(agg, ref[h][0].view(-1), None, ref[h][0].shape[0], default_attr=0.5)
+                        assert torch.equal(hops[h]["cnt"], c), (name, agg, h)
+                        assert torch.equal(hops[h]["emb"].view(torch.int32), e.view(torch.int32)), (name, agg, h, k)
+                plan.close()
+        # sampling only
+        plan = glx.Plan([g], "TopkSampler", [5], 64)
+        seeds = t(mapped(rng.integers(0, 3000, 64)).astype(np.int64))
+        out = plan.run(seeds)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0]["nbr"], g.sample("TopkSampler", seeds, 5)[0])
+        plan.close()
