@@ -365,6 +365,7 @@ def main():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
                          "auto = on for launch-bound batches (B0 <= 8192)")
+    ap.add_argument("--graph-streams", type=int, default=2, help="--graph: plans / streams the steps alternate over")
     ap.add_argument("--roofline-probes", default="on", choices=["on", "off"],
                     help="N=1: also time the aggregation kernel on cache-free (uniform) rows and a device copy")
     ap.add_argument("--force-sharded", action="store_true",
@@ -587,20 +588,28 @@ def main():
     if use_graph:
         # launch-bound batch sizes: the whole step (2 sample + 2 aggregate kernels) is ONE hipGraph launch
         # (glx_plan); seeds and call counter enter through the graph's stage node
-        plan = glx.Plan([graph, graph], sampler, [k1, k2], B0, features=[feats, feats], agg=agg, seed=42)
+        # two plans on two streams, steps alternate: a step's small kernels (hop 1 is 100 workgroups) leave most
+        # of the GPU idle, and the gaps between the nodes of one graph are filled by the other stream's step
+        plans = [glx.Plan([graph, graph], sampler, [k1, k2], B0, features=[feats, feats], agg=agg, seed=42)
+                 for _ in range(args.graph_streams)]
+        streams = [torch.cuda.Stream(device=dev) for _ in plans]
+
+        def graph_step(i):
+            with torch.cuda.stream(streams[i % len(plans)]):
+                plans[i % len(plans)].run(seeds[i], call_counter=4 * i)
         for i in range(args.warmup):
-            plan.run(seeds[i], call_counter=4 * i)
+            graph_step(i)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.warmup, n_steps):
-            plan.run(seeds[i], call_counter=4 * i)
+            graph_step(i)
         barrier()
         elapsed = time.perf_counter() - t0
         # kernel durations for the roofline line: a few steps issued kernel by kernel, outside the timed region
         kernel_steps = min(args.steps, 10)
         _, t_agg, t_smp = timed_leg(agg_local(feats), 0, kernel_steps, 2)
         headline = "single GPU, one hipGraph launch per step"
-        placement = "1 GPU; step = one hipGraph launch (glx_plan)"
+        placement = "1 GPU; step = one hipGraph launch (glx_plan), %d plan(s) alternating on as many streams" % len(plans)
     elif not sharded:
         elapsed, t_agg, t_smp = timed_leg(agg_local(feats), args.warmup, n_steps, args.warmup)
         headline = "single GPU"

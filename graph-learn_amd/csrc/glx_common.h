@@ -285,6 +285,148 @@ __device__ inline void glx_alias_build_row_dev(const float* __restrict__ dist, i
   while (high_num > 0) tab[high[-(--high_num)].alias].prob = 1.0f;
 }
 
+// The same build once more, for a whole WAVE per distribution (long rows: the per-lane version walks
+// a 100 K-entry hub row alone while 63 lanes of its wave wait).  Bit-identical again:
+//   sum       every lane adds a strided share in double and the wave combines them.  That is only
+//             allowed when no addition rounds: the addends are floats, i.e. integers times 2^elow; with
+//             emax the largest exponent every partial sum is an integer multiple of 2^elow_min below
+//             count * 2^(emax+1), so it is exact in double -- in ANY order -- as long as
+//             emax + 1 + ceil(log2 count) - elow_min <= 52.  (Weights in [0.01, 1] span 30 bits, in-degrees
+//             are integers: both qualify up to 2^20-entry rows.)  Otherwise lane 0 adds sequentially.
+//   classify  prob / table entry per position in parallel; the low and high stacks are filled by ballot
+//             compaction, which keeps the push order of the serial loop (ascending position).
+//   pairing   inherently serial (each step's float result decides the next): lane 0 runs the loop of
+//             glx_alias_build_row_dev, but never waits for global memory -- the other lanes refill two LDS
+//             windows with the next kAliasWindow entries of each stack (coalesced), lane 0 pops from LDS,
+//             and its table updates are fire-and-forget stores.
+// All 64 lanes of the wave call it with the same arguments; `lds` = 2 * kAliasWindow entries private to the wave.
+constexpr int kAliasWindow = 256;
+constexpr int kAliasLaneRowMax = 96;  // rows up to this length are built by one lane (64 rows per wave)
+__device__ inline void glx_alias_build_row_wave(const float* __restrict__ dist, int32_t count,
+                                                GlxAlias* __restrict__ tab, GlxAlias* __restrict__ stk,
+                                                GlxAlias* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  // ---- sum
+  double acc = 0.0;
+  int32_t emax = -1000, elow = 1000;
+  bool odd = false;  // inf / nan / denormal: take the sequential sum
+  for (int32_t i = lane; i < count; i += 64) {
+    const float x = dist[i];
+    acc += (double)x;
+    const uint32_t b = __float_as_uint(x);
+    const int32_t ef = (int32_t)((b >> 23) & 0xff);
+    const uint32_t man = b & 0x7fffffu;
+    if (ef == 0xff || (ef == 0 && man != 0)) odd = true;
+    if (ef != 0 && ef != 0xff) {
+      const int32_t e = ef - 127;
+      const uint32_t m24 = man | 0x800000u;
+      const int32_t lo = e - 23 + (__ffs((int)m24) - 1);
+      emax = e > emax ? e : emax;
+      elow = lo < elow ? lo : elow;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_xor(acc, off);
+    const int32_t em = __shfl_xor(emax, off), el = __shfl_xor(elow, off);
+    emax = em > emax ? em : emax;
+    elow = el < elow ? el : elow;
+  }
+  int32_t log2n = 0;
+  while ((1 << log2n) < count) ++log2n;
+  const bool exact = !__any(odd) && (emax < -999 || emax + 1 + log2n - elow <= 52);
+  if (!exact) {
+    acc = 0.0;
+    if (lane == 0) {
+      for (int32_t i = 0; i < count; ++i) acc += (double)dist[i];
+    }
+    acc = __shfl(acc, 0);
+  }
+  const float sum = (float)acc;
+  const float avg_prob = (float)(1.0 / (double)count);
+  // ---- classify: low stack grows up from stk[0], high stack down from stk[count - 1]
+  int32_t low_num = 0, high_num = 0;
+  for (int32_t base = 0; base < count; base += 64) {
+    const int32_t i = base + lane;
+    bool is_low = false, is_high = false;
+    GlxAlias e = GlxAlias{0.0f, 0};
+    if (i < count) {
+      const float prob = dist[i] / sum;
+      e = GlxAlias{prob * (float)count, i};
+      tab[i] = e;
+      is_low = prob < avg_prob;
+      is_high = prob > avg_prob;
+    }
+    const uint64_t bl = __ballot(is_low), bh = __ballot(is_high);
+    if (is_low) stk[low_num + __popcll(bl & lt)] = e;
+    if (is_high) stk[count - 1 - (high_num + __popcll(bh & lt))] = e;
+    low_num += __popcll(bl);
+    high_num += __popcll(bh);
+  }
+  __threadfence_block();
+  // ---- pairing
+  GlxAlias* wl = lds;
+  GlxAlias* wh = lds + kAliasWindow;
+  int32_t l_n = 0, l_at = 0, h_n = 0, h_at = 0;  // windows: entries [at, n) are still to be popped, in pop order
+  bool have_lo = false, have_hi = false;
+  GlxAlias lo = GlxAlias{0.0f, 0}, hi = GlxAlias{0.0f, 0};  // .alias carries the entry's own index here
+  while (true) {
+    if (l_at == l_n && low_num > 0) {  // next window of the low stack: pop order = descending address
+      const int32_t n = low_num < kAliasWindow ? low_num : kAliasWindow;
+      for (int32_t j = lane; j < n; j += 64) wl[j] = stk[low_num - 1 - j];
+      low_num -= n;
+      l_n = n;
+      l_at = 0;
+    }
+    if (h_at == h_n && high_num > 0) {  // high stack: pop order = ascending address from its top
+      const int32_t n = high_num < kAliasWindow ? high_num : kAliasWindow;
+      for (int32_t j = lane; j < n; j += 64) wh[j] = stk[count - high_num + j];
+      high_num -= n;
+      h_n = n;
+      h_at = 0;
+    }
+    __threadfence_block();
+    if (lane == 0) {
+      while ((have_lo || l_at < l_n) && (have_hi || h_at < h_n)) {
+        if (!have_lo) lo = wl[l_at++];
+        if (!have_hi) hi = wh[h_at++];
+        have_lo = false;
+        const float p = hi.prob - 1.0f + lo.prob;
+        tab[lo.alias].alias = hi.alias;
+        hi.prob = p;
+        if (p < 1.0f) {
+          tab[hi.alias].prob = p;
+          lo = hi;
+          have_lo = true;
+          have_hi = false;
+        } else if (p > 1.0f) {
+          have_hi = true;  // still the top of the high stack; its final prob is written when it leaves
+        } else {
+          tab[hi.alias].prob = p;
+          have_hi = false;
+        }
+      }
+    }
+    l_at = __shfl(l_at, 0);
+    h_at = __shfl(h_at, 0);
+    have_lo = __shfl((int)have_lo, 0) != 0;
+    have_hi = __shfl((int)have_hi, 0) != 0;
+    const int32_t lows_left = low_num + (l_n - l_at) + (have_lo ? 1 : 0);
+    const int32_t highs_left = high_num + (h_n - h_at) + (have_hi ? 1 : 0);
+    if (lows_left == 0 || highs_left == 0) break;
+  }
+  // ---- whatever is left on either stack has probability 1
+  if (lane == 0) {
+    if (have_lo) tab[lo.alias].prob = 1.0f;
+    if (have_hi) tab[hi.alias].prob = 1.0f;
+  }
+  for (int32_t j = l_at + lane; j < l_n; j += 64) tab[wl[j].alias].prob = 1.0f;
+  for (int32_t j = h_at + lane; j < h_n; j += 64) tab[wh[j].alias].prob = 1.0f;
+  for (int32_t j = lane; j < low_num; j += 64) tab[stk[j].alias].prob = 1.0f;
+  for (int32_t j = lane; j < high_num; j += 64) tab[stk[count - 1 - j].alias].prob = 1.0f;
+}
+
 // ------------------------------------------------------------- contract RNG -
 // Philox4x32-10; key = (seed lo, seed hi); counter = (j >> 1, row, cc lo, cc hi).
 // Draw j of a row is words {2(j&1), 2(j&1)+1} of block j >> 1.

@@ -244,7 +244,7 @@ __global__ void glx_filter_alias_build_kernel(DrawArgs a, const float* __restric
   const int32_t i = a.row0 + li;
   if (li >= a.nrows || a.deg[i] == 0) return;
   const int32_t m = a.res_cnt[i];
-  if (m == 0) return;
+  if (m == 0 || m > kAliasLaneRowMax) return;  // longer reserved lists: glx_filter_alias_build_wave_kernel
   const int64_t off = a.soff[i] - a.base, s = a.start[i];
   for (int32_t t = 0; t < m; ++t) {
     const int64_t slot = s + a.res[off + t];
@@ -258,6 +258,36 @@ __global__ void glx_filter_alias_build_kernel(DrawArgs a, const float* __restric
     dist[off + t] = w;
   }
   glx_alias_build_row_dev(dist + off, m, tab + off, stk + off);
+}
+
+// The same for reserved lists longer than kAliasLaneRowMax: one wave per request row gathers the weights
+// (coalesced over the reserved list) and runs glx_alias_build_row_wave.
+__global__ __launch_bounds__(256) void glx_filter_alias_build_wave_kernel(DrawArgs a, const float* __restrict__ weight,
+                                                                          GlxIdMap dst_map,
+                                                                          const int64_t* __restrict__ dst_count,
+                                                                          float* __restrict__ dist, GlxAlias* __restrict__ tab,
+                                                                          GlxAlias* __restrict__ stk) {
+  __shared__ GlxAlias windows[4][2 * kAliasWindow];
+  const int32_t li = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  const int32_t i = a.row0 + li;
+  if (li >= a.nrows || a.deg[i] == 0) return;
+  const int32_t m = a.res_cnt[i];
+  if (m <= kAliasLaneRowMax) return;
+  const int64_t off = a.soff[i] - a.base, s = a.start[i];
+  for (int32_t t = lane; t < m; t += 64) {
+    const int64_t slot = s + a.res[off + t];
+    float w;
+    if (weight) {
+      w = weight[slot];
+    } else {
+      const int64_t r = glx_row_of(dst_map, a.adj[slot].nbr);
+      w = r < 0 ? 0.0f : (float)(int32_t)dst_count[r];
+    }
+    dist[off + t] = w;
+  }
+  __threadfence_block();
+  glx_alias_build_row_wave(dist + off, m, tab + off, stk + off, windows[threadIdx.x >> 6]);
 }
 
 // EdgeWeight / InDegree slots under circular padding: k alias draws mapped back through the
@@ -694,6 +724,8 @@ int filtered_general(const glx_graph* g, int sampler, const int64_t* d_src, cons
       const bool by_weight = sampler == GLX_SAMPLER_EDGE_WEIGHT;
       glx_filter_alias_build_kernel<<<rb, 256, 0, s>>>(da, by_weight ? g->weight : nullptr, dm, g->dst_count, dist, tab,
                                                       stk);
+      glx_filter_alias_build_wave_kernel<<<wb, 256, 0, s>>>(da, by_weight ? g->weight : nullptr, dm, g->dst_count, dist,
+                                                           tab, stk);
       const int64_t total = (int64_t)nr * k;
       glx_filter_alias_slots_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(da, tab, d_nbr, d_eid);
     }

@@ -40,6 +40,31 @@ extern "C" int glx_device_count(int* count) {
   return GLX_OK;
 }
 
+extern "C" int glx_host_register(void* p, uint64_t bytes) {
+  GLX_REQUIRE(p != nullptr && bytes > 0, "bad buffer");
+  int n = 0;
+  int rc = glx_device_count(&n);
+  if (rc != GLX_OK) return rc;
+  hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    glx_set_error("hipHostRegister(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? GLX_RESOURCE_EXHAUSTED : GLX_UNAVAILABLE;
+  }
+  return GLX_OK;
+}
+
+extern "C" int glx_host_unregister(void* p) {
+  GLX_REQUIRE(p != nullptr, "bad buffer");
+  hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    glx_set_error("hipHostUnregister failed: %s", hipGetErrorString(e));
+    return GLX_UNAVAILABLE;
+  }
+  return GLX_OK;
+}
+
 int glx_init_device(int device) {
   static std::mutex mtx;
   static bool done[64] = {false};
@@ -384,8 +409,22 @@ __global__ void glx_alias_build_kernel(const int64_t* __restrict__ row_ptr,
   if (row >= V) return;
   const int64_t s = row_ptr[row];
   const int32_t count = (int32_t)(row_ptr[row + 1] - s);
-  if (count == 0) return;
+  if (count == 0 || count > kAliasLaneRowMax) return;  // longer rows: glx_alias_build_wave_kernel
   glx_alias_build_row_dev(weight + s, count, out + s, stk + s);
+}
+
+// Rows longer than kAliasLaneRowMax: one wave per row (glx_alias_build_row_wave).
+__global__ __launch_bounds__(256) void glx_alias_build_wave_kernel(const int64_t* __restrict__ row_ptr,
+                                                                   const float* __restrict__ weight, int64_t V,
+                                                                   GlxAlias* __restrict__ out,
+                                                                   GlxAlias* __restrict__ stk) {
+  __shared__ GlxAlias windows[4][2 * kAliasWindow];
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= V) return;
+  const int64_t s = row_ptr[row];
+  const int32_t count = (int32_t)(row_ptr[row + 1] - s);
+  if (count <= kAliasLaneRowMax) return;
+  glx_alias_build_row_wave(weight + s, count, out + s, stk + s, windows[threadIdx.x >> 6]);
 }
 
 // Packs {prob, (nbr, eid) of the slot, (nbr, eid) of its alias} per slot; *bad is set
@@ -509,6 +548,8 @@ int glx_alias_build_launch(const int64_t* row_ptr, const float* weight, int64_t 
   GLX_HIP(hipMalloc(&stk_buf.p, (size_t)E * sizeof(GlxAlias)));
   glx_alias_build_kernel<<<(unsigned)((V + 63) / 64), 64, 0, s>>>(row_ptr, weight, V, out,
                                                                   stk_buf.as<GlxAlias>());
+  glx_alias_build_wave_kernel<<<(unsigned)((V * 64 + 255) / 256), 256, 0, s>>>(row_ptr, weight, V, out,
+                                                                               stk_buf.as<GlxAlias>());
   GLX_HIP(hipStreamSynchronize(s));  // stk_buf is released on return
   GLX_HIP(hipGetLastError());
   return GLX_OK;

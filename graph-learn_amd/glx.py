@@ -37,7 +37,7 @@ AGGREGATOR_IDS = {
 }
 
 EXPORTS = [
-    "glx_abi_version", "glx_device_count", "glx_last_error",
+    "glx_abi_version", "glx_device_count", "glx_last_error", "glx_host_register", "glx_host_unregister",
     "glx_graph_create", "glx_graph_build", "glx_graph_build_ordered", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
     "glx_graph_degrees", "glx_graph_in_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
     "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
@@ -109,6 +109,8 @@ def lib():
         ci = ctypes.c_int
         L.glx_last_error.restype = ctypes.c_char_p
         L.glx_device_count.argtypes = [ctypes.POINTER(ci)]
+        L.glx_host_register.argtypes = [vp, u64]
+        L.glx_host_unregister.argtypes = [vp]
         L.glx_graph_create.argtypes = [ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ctypes.POINTER(vp)]
         L.glx_graph_build.argtypes = [ci, i64, vp, vp, vp, vp, ci, ci, vp, ctypes.POINTER(vp)]
         L.glx_graph_destroy.argtypes = [vp]

@@ -86,9 +86,15 @@ const char* kFilterValues = "filt";
 // Storage of the numeric tensors.  A response of the device path is one large block
 // written by a single device->host copy, so two things matter on the host side:
 // (1) no value-initialisation of memory that is about to be overwritten, and
-// (2) no fresh mmap + page faults per request.  BlockPool recycles large blocks
-// (>= 256 KiB, power-of-two classes, at most kPoolCap bytes parked) across requests;
-// small tensors use the ordinary heap.
+// (2) no fresh mmap + page faults per request, and (3) the block should be PINNED: a
+// device->host copy into pageable memory bounces through the runtime's staging buffers (one
+// extra pass over every response byte, serialised between the pool threads), a copy into
+// registered memory is a single DMA straight into the response.  BlockPool recycles large
+// blocks (>= 64 KiB, power-of-two classes, at most kPoolCap bytes parked) across requests and
+// registers each block with the GPU runtime ONCE, when it is first obtained
+// (glx_host_register; pinning costs milliseconds, recycling a pinned block nothing);
+// small tensors use the ordinary heap.  Without a GPU runtime registration fails and the
+// block simply stays pageable.
 namespace {
 class BlockPool {
 public:
@@ -96,7 +102,7 @@ public:
     static BlockPool* pool = new BlockPool;  // never destroyed: tensors may outlive static teardown
     return *pool;
   }
-  static constexpr size_t kMinBytes = 256u << 10;
+  static constexpr size_t kMinBytes = 64u << 10;
   static constexpr size_t kPoolCap = 4ull << 30;
   static int ClassOf(size_t bytes) {
     int c = 18;
@@ -116,6 +122,7 @@ public:
     }
     void* p = nullptr;
     if (posix_memalign(&p, 4096, 1ull << c) != 0) throw std::bad_alloc();
+    if (pin_) (void)glx_host_register(p, 1ull << c);  // best effort: an unregistered block is only slower
     return p;
   }
   void Give(void* p, size_t bytes) {
@@ -128,6 +135,7 @@ public:
         return;
       }
     }
+    if (pin_) (void)glx_host_unregister(p);
     std::free(p);
   }
 
@@ -135,6 +143,8 @@ private:
   std::mutex mtx_;
   std::vector<void*> free_[48];
   size_t parked_ = 0;
+  // GLX_HOST_PINNED_RESPONSES=0 keeps response blocks pageable (A/B knob)
+  const bool pin_ = !(std::getenv("GLX_HOST_PINNED_RESPONSES") && std::atoi(std::getenv("GLX_HOST_PINNED_RESPONSES")) == 0);
 };
 
 template <class T>

@@ -7,6 +7,7 @@
 //
 //   host_path_bench [threads=8] [seeds_per_request=1024] [requests_per_thread=20]
 //                   [log2_nodes=21] [edges=20000000] [dim=256]
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -109,16 +110,27 @@ int main(int argc, char** argv) {
       *edges += (int64_t)B * k1 + (int64_t)B * k1 * k2;
     }
   };
-  {  // warm-up (workspaces, streams)
-    int64_t e = 0; int ok = 1;
-    worker(0, 2, &e, &ok);
-    if (!ok) { std::printf("warm-up failed\n"); return 2; }
-  }
+  // A persistent pool, like the reference's (common/threading/runner/threadpool.h): every thread first
+  // serves two warm-up requests (its device workspaces and streams are per thread; the response blocks are
+  // pinned once, when BlockPool first obtains them, and recycled afterwards), then all start the timed
+  // requests together.
   std::vector<std::thread> pool;
-  std::vector<int64_t> edges(threads, 0);
+  std::vector<int64_t> edges(threads, 0), warm_edges(threads, 0);
   std::vector<int> oks(threads, 1);
-  auto t0 = std::chrono::steady_clock::now();
-  for (int t = 0; t < threads; ++t) pool.emplace_back(worker, t, reps, &edges[t], &oks[t]);
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  std::chrono::steady_clock::time_point t0;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t] {
+      worker(t, 2, &warm_edges[t], &oks[t]);
+      ready.fetch_add(1);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      if (oks[t]) worker(t, reps, &edges[t], &oks[t]);
+    });
+  }
+  while (ready.load() < threads) std::this_thread::yield();
+  t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
   for (auto& th : pool) th.join();
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int64_t tot = 0;

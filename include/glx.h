@@ -83,6 +83,14 @@ GLX_API int glx_abi_version(void);
 GLX_API int glx_device_count(int* count);
 GLX_API const char* glx_last_error(void);
 
+/* Pins (page-locks and maps) a caller-owned host buffer so that the copies of host-pointer calls into / out
+ * of it are single DMA transfers instead of bouncing through the runtime's pageable staging -- what the
+ * response tensors of the C++ layer are backed by (the role of the reference's RepeatedField storage,
+ * service/tensor_impl.h:72-75,196-200, on this path).  Both return GLX_UNAVAILABLE without a GPU runtime;
+ * an unregistered buffer works everywhere, only slower. */
+GLX_API int glx_host_register(void* p, uint64_t bytes);
+GLX_API int glx_host_unregister(void* p);
+
 /* ---- graph storage: replaces GraphStorage::GetNeighbors / GetOutEdges /
  * GetEdgeWeight (graph_storage.h:40-57) + CompressedMemoryAdjMatrix
  * (memory_adj_matrix.cc:159-225) + AutoIndex (auto_indexing.cc:21-33). -----

@@ -672,3 +672,43 @@ def test_request_plan_equals_separate_calls():
         torch.cuda.synchronize()
         assert torch.equal(out[0]["nbr"], g.sample("TopkSampler", seeds, 5)[0])
         plan.close()
+
+
+def test_alias_tables_of_long_and_odd_rows_bit_exact():
+    """The wave-per-row alias build (rows longer than 96 slots): bit-identical to the oracle's restatement of
+    AliasMethod::Build (alias_method.cc:57-107) for long rows of every kind -- weights in (0.01, 1] (parallel
+    double sum is exact), integer weights (in-degrees), all-equal weights (no low / high entries at all), one
+    dominating weight, zeros mixed in, and a dynamic range beyond 52 bits, denormals, a huge value (the
+    sequential-sum fallback) -- at lengths around the window size of the pairing loop (256) and far above."""
+    orc = Oracle()
+    rng = np.random.default_rng(99)
+    rows = []
+    for n in (97, 255, 256, 257, 513, 4000, 70000):
+        rows.append((rng.random(n) * 0.99 + 0.01).astype(np.float32))
+        rows.append(rng.integers(1, 100000, n).astype(np.float32))
+        rows.append(np.full(n, 0.25, np.float32))
+        one = (rng.random(n) * 0.01).astype(np.float32)
+        one[n // 3] = 1000.0
+        rows.append(one)
+        z = (rng.random(n)).astype(np.float32)
+        z[::3] = 0.0
+        rows.append(z)
+        wide = (10.0 ** rng.uniform(-30, 30, n)).astype(np.float32)
+        rows.append(wide)
+        den = (rng.random(n) * 0.5).astype(np.float32)
+        den[1] = np.float32(1e-42)  # denormal
+        den[2] = np.float32(3e38)
+        rows.append(den)
+    deg = np.array([r.shape[0] for r in rows], np.int64)
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    w = np.concatenate(rows).astype(np.float32)
+    E = int(rp[-1])
+    col = (np.arange(E, dtype=np.int64) * 7) % 1000
+    eid = np.arange(E, dtype=np.int64)
+    dev = glx.Graph(rp, col, eid, w)
+    prob, alias = dev.export_alias()
+    oprob, oalias = orc.alias_build(rp, w)
+    for r in range(len(rows)):
+        a, b = rp[r], rp[r + 1]
+        assert np.array_equal(alias[a:b], oalias[a:b]), ("alias", r, deg[r])
+        assert np.array_equal(prob[a:b].view(np.uint32), oprob[a:b].view(np.uint32)), ("prob", r, deg[r])
