@@ -193,6 +193,31 @@ def cpu_baseline_port(wl, src, dst, weight, args, seed_pool=None):
             "wall_s": time.time() - t_all}
 
 
+def host_boundary_rate(args):
+    """What a graph-learn caller gets THROUGH the drop-in boundary: host_path_bench issues the same 2-hop
+    EdgeWeightSampler [25,10] + MaxAggregator (dim 256) requests from T host threads through the C++ operator
+    API (OpFactory::Create(name)->Process(req, res)) with host buffers -- one request per pool thread, the
+    reference's concurrency model (in_memory_service.cc:64-71) -- so every id and every embedding crosses PCIe.
+    `value` above is the device-resident rate; this is the PCIe-inclusive one."""
+    import subprocess
+    exe = os.path.join(ROOT, "graph-learn_amd", "lib", "host_path_bench")
+    if not os.path.exists(exe):
+        return None
+    threads, B, reps = args.host_boundary_threads, 1024, 10
+    try:
+        r = subprocess.run([exe, str(threads), str(B), str(reps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        rec = json.loads(line)
+    except Exception as ex:  # noqa: BLE001 -- never lose the headline line
+        return {"error": repr(ex)}
+    return {"edges_per_s": rec["sampled_edges_per_s_host_pointer_path"], "threads": threads, "seeds_per_request": B,
+            "requests_per_thread": reps, "graph": "RMAT 2M nodes / 20M edges, dim 256 (host_path_bench defaults)",
+            "response_bytes_per_request": B * 25 * 16 + B * 250 * 16 + (B * 25 + B) * (256 * 4 + 4),
+            "note": "PCIe-inclusive: requests and responses are host tensors of the C++ operator API; response blocks "
+                    "are pinned (glx_host_register) so the device->host copies are single DMA transfers"}
+
+
 def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
     """BASELINE configs[4] shape: heterogeneous user-item-shop graph, three
     weighted edge types (u-i 300M, i-s 100M, u-s 100M edges over 40M / 9M / 1M nodes),
@@ -362,6 +387,10 @@ def main():
     ap.add_argument("--hot-fraction", type=float, default=0.10,
                     help="N>1: every GPU keeps a replica of this fraction of the feature rows (the top vertices by "
                          "global in-degree); the rest is fetched per request (halo exchange of the cold tail)")
+    ap.add_argument("--host-boundary", default="on", choices=["on", "off"],
+                    help="N=1: also run graph-learn_amd/lib/host_path_bench (requests through the C++ operator API "
+                         "with host buffers) and report its PCIe-inclusive rate under \"host_boundary\"")
+    ap.add_argument("--host-boundary-threads", type=int, default=32)
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
                          "auto = on for launch-bound batches (B0 <= 8192)")
@@ -772,6 +801,8 @@ def main():
         res["verified_sharded_equals_unpartitioned"] = verified
     if cpu:
         res["gpu_over_cpu"] = value / cpu["value"]
+    if args.host_boundary == "on" and not sharded and rank == 0:
+        res["host_boundary"] = host_boundary_rate(args)
     if rank == 0:
         result_out.write(json.dumps(res) + "\n")
         result_out.flush()

@@ -568,14 +568,21 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
                             emb_out, cnt_out, s);
   }
   const size_t emb_n = (size_t)num_segments * f->dim;
-  const size_t bytes = (size_t)num_ids * 8 + (size_t)num_ids * 4 + emb_n * 4 + (size_t)num_segments * 4 + 64;
+  // outputs go straight into the caller's buffers when those are pinned (glx_mapped_ptr): the embeddings are
+  // by far the largest part of a response (4 * dim bytes per segment)
+  float* m_emb = static_cast<float*>(glx_mapped_ptr(emb_out));
+  int32_t* m_cnt = static_cast<int32_t*>(glx_mapped_ptr(cnt_out));
+  const bool direct = m_emb != nullptr && m_cnt != nullptr;
+  const size_t out_b = direct ? 0 : ((emb_n * 4 + 15) & ~(size_t)15) + (size_t)num_segments * 4;
+  const size_t bytes = (size_t)num_ids * 8 + (size_t)num_ids * 4 + out_b + 64;
   char* d = nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), bytes, s, 0);
   if (rc != GLX_OK) return rc;
-  float* d_emb = reinterpret_cast<float*>(d);
-  int64_t* d_ids = reinterpret_cast<int64_t*>(d + ((emb_n * 4 + 15) & ~(size_t)15));
-  int32_t* d_seg = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(d_ids) + (size_t)num_ids * 8);
-  int32_t* d_cnt = d_seg + num_ids;
+  int64_t* d_ids = reinterpret_cast<int64_t*>(d);
+  int32_t* d_seg = reinterpret_cast<int32_t*>(d + (size_t)num_ids * 8);
+  char* d_out = d + (((size_t)num_ids * 12 + 15) & ~(size_t)15);
+  float* d_emb = direct ? m_emb : reinterpret_cast<float*>(d_out);
+  int32_t* d_cnt = direct ? m_cnt : reinterpret_cast<int32_t*>(d_out + ((emb_n * 4 + 15) & ~(size_t)15));
   hipError_t e = hipSuccess;
   if (num_ids > 0) {
     e = hipMemcpyAsync(d_ids, node_ids, (size_t)num_ids * 8, hipMemcpyHostToDevice, s);
@@ -583,7 +590,7 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
   }
   if (e == hipSuccess) {
     rc = aggregate_device(f, op, d_ids, segment_ids ? d_seg : nullptr, num_ids, num_segments, default_attr, d_emb, d_cnt, s);
-    if (rc == GLX_OK) {
+    if (rc == GLX_OK && !direct) {
       e = hipMemcpyAsync(emb_out, d_emb, emb_n * 4, hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipMemcpyAsync(cnt_out, d_cnt, (size_t)num_segments * 4, hipMemcpyDeviceToHost, s);
     }
@@ -619,16 +626,18 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
     return GLX_OK;
   }
   const size_t out_bytes = (size_t)n * f->dim * 4;
+  float* m_out = static_cast<float*>(glx_mapped_ptr(out));  // pinned caller buffer: the kernel writes it directly
+  const size_t ids_b = ((size_t)n * 8 + 15) & ~(size_t)15;  // ids first, 16-byte aligned rows after them
   char* d = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), out_bytes + (size_t)n * 8, s, 0);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ids_b + (m_out ? 0 : out_bytes), s, 0);
   if (rc != GLX_OK) return rc;
-  float* d_out = reinterpret_cast<float*>(d);
-  int64_t* d_ids = reinterpret_cast<int64_t*>(d + out_bytes);
+  int64_t* d_ids = reinterpret_cast<int64_t*>(d);
+  float* d_out = m_out ? m_out : reinterpret_cast<float*>(d + ids_b);
   hipError_t e = hipMemcpyAsync(d_ids, node_ids, (size_t)n * 8, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     glx_lookup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(f->map(), f->X, f->stride, f->swizzle_rows, f->dim, d_ids, n,
                                                                        default_attr, d_out, G);
-    e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s);
+    if (!m_out) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s);
   }
   hipError_t e2 = hipStreamSynchronize(s);
   glx_scratch_free(d, s);

@@ -499,6 +499,12 @@ int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, i
                                const int32_t* d_seg, int32_t num_ids, int32_t num_segments, float default_attr,
                                float* d_emb, int32_t* d_cnt, hipStream_t s);
 
+// Device-visible alias of a host buffer the caller pinned with glx_host_register (or allocated with
+// hipHostMalloc), nullptr for ordinary pageable memory.  Host-pointer calls let their kernels write results
+// straight into such a buffer -- the response crosses PCIe once, as the kernel's own coalesced stores, with no
+// staging copy and no copy engine in between; pageable buffers are served through a device workspace + copy.
+void* glx_mapped_ptr(const void* host_ptr);
+
 static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Host-pointer calls are synchronous.  When the caller passes no stream they run on

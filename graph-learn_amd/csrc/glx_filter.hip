@@ -889,14 +889,17 @@ extern "C" int glx_sample_filtered(const glx_graph* g, int sampler, const int64_
                            call_counter, f, nbr_out, eid_out, s);
   }
   const size_t nb = (size_t)batch, n_out = nb * (size_t)k;
+  int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out));  // pinned caller buffers are written directly
+  int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out));
+  const bool direct = m_nbr != nullptr && m_eid != nullptr;
   Staged st;
-  rc = glx_scratch_alloc(reinterpret_cast<void**>(&st.d), (nb * 3 + n_out * 2) * 8, s, 0);
+  rc = glx_scratch_alloc(reinterpret_cast<void**>(&st.d), (nb * 3 + (direct ? 0 : n_out * 2)) * 8, s, 0);
   if (rc != GLX_OK) return rc;
   int64_t* d_src = st.take(nb);
   int64_t* d_val = st.take(nb);
   int64_t* d_rng = rng_rows ? st.take(nb) : nullptr;
-  int64_t* d_nbr = st.take(n_out);
-  int64_t* d_eid = st.take(n_out);
+  int64_t* d_nbr = direct ? m_nbr : st.take(n_out);
+  int64_t* d_eid = direct ? m_eid : st.take(n_out);
   GLX_HIP(hipMemcpyAsync(d_src, src, nb * 8, hipMemcpyHostToDevice, s));
   GLX_HIP(hipMemcpyAsync(d_val, filter->values, nb * 8, hipMemcpyHostToDevice, s));
   if (rng_rows) GLX_HIP(hipMemcpyAsync(d_rng, rng_rows, nb * 8, hipMemcpyHostToDevice, s));
@@ -907,8 +910,10 @@ extern "C" int glx_sample_filtered(const glx_graph* g, int sampler, const int64_
     (void)hipStreamSynchronize(s);
     return rc;
   }
-  GLX_HIP(hipMemcpyAsync(nbr_out, d_nbr, n_out * 8, hipMemcpyDeviceToHost, s));
-  GLX_HIP(hipMemcpyAsync(eid_out, d_eid, n_out * 8, hipMemcpyDeviceToHost, s));
+  if (!direct) {
+    GLX_HIP(hipMemcpyAsync(nbr_out, d_nbr, n_out * 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipMemcpyAsync(eid_out, d_eid, n_out * 8, hipMemcpyDeviceToHost, s));
+  }
   GLX_HIP(hipStreamSynchronize(s));
   return GLX_OK;
 }

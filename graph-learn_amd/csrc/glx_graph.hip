@@ -65,6 +65,22 @@ extern "C" int glx_host_unregister(void* p) {
   return GLX_OK;
 }
 
+void* glx_mapped_ptr(const void* host_ptr) {
+  static const bool off = [] {
+    const char* e = getenv("GLX_HOST_ZERO_COPY");  // "0": always stage through a copy (A/B knob)
+    return e && atoi(e) == 0;
+  }();
+  if (off || host_ptr == nullptr) return nullptr;
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  if (hipPointerGetAttributes(&attr, host_ptr) != hipSuccess) {
+    (void)hipGetLastError();  // an unregistered pointer is not an error here
+    return nullptr;
+  }
+  if (attr.type != hipMemoryTypeHost || attr.devicePointer == nullptr) return nullptr;
+  return attr.devicePointer;
+}
+
 int glx_init_device(int device) {
   static std::mutex mtx;
   static bool done[64] = {false};

@@ -432,20 +432,24 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
     a.eid_out = eid_out;
     return sample_device(g, sampler, a, padding_mode, s);
   }
-  // Host pointers: stage through stream-ordered scratch; synchronous.
+  // Host pointers: inputs are staged through a device workspace; outputs are written by the kernel straight
+  // into the caller's buffers when those are pinned (glx_mapped_ptr), else staged and copied.  Synchronous.
   const size_t n_out = (size_t)batch * k;
+  int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out));
+  int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out));
+  const bool direct = m_nbr != nullptr && m_eid != nullptr;
   int64_t* d = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch * 2 + 2 * n_out) * 8, s, 0);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch * 2 + (direct ? 0 : 2 * n_out)) * 8, s, 0);
   if (rc != GLX_OK) return rc;
   a.src = d;
   a.rng_rows = rng_rows ? d + batch : nullptr;
-  a.nbr_out = d + 2 * (size_t)batch;
-  a.eid_out = d + 2 * (size_t)batch + n_out;
+  a.nbr_out = direct ? m_nbr : d + 2 * (size_t)batch;
+  a.eid_out = direct ? m_eid : d + 2 * (size_t)batch + n_out;
   hipError_t e = hipMemcpyAsync(d, src, (size_t)batch * 8, hipMemcpyHostToDevice, s);
   if (e == hipSuccess && rng_rows) e = hipMemcpyAsync(d + batch, rng_rows, (size_t)batch * 8, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     rc = sample_device(g, sampler, a, padding_mode, s);
-    if (rc == GLX_OK) {
+    if (rc == GLX_OK && !direct) {
       e = hipMemcpyAsync(nbr_out, a.nbr_out, n_out * 8, hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipMemcpyAsync(eid_out, a.eid_out, n_out * 8, hipMemcpyDeviceToHost, s);
     }

@@ -712,3 +712,43 @@ def test_alias_tables_of_long_and_odd_rows_bit_exact():
         a, b = rp[r], rp[r + 1]
         assert np.array_equal(alias[a:b], oalias[a:b]), ("alias", r, deg[r])
         assert np.array_equal(prob[a:b].view(np.uint32), oprob[a:b].view(np.uint32)), ("prob", r, deg[r])
+
+
+def test_pinned_host_buffers_are_written_directly():
+    """Host-pointer calls write their results straight into caller buffers pinned with glx_host_register (no
+    staging copy); the answers equal those of pageable buffers, for sampling (plain and filtered), aggregation
+    and lookup, and registration can be undone."""
+    import ctypes
+    rng = np.random.default_rng(12)
+    rp, col, eid, w = synth.small_graph(2000, 40000, seed=9, weighted=True, hub_degree=400)
+    X = rng.standard_normal((2000, 48)).astype(np.float32)
+    g, f = glx.Graph(rp, col, eid, w), glx.Features(X)
+    L = glx.lib()
+    ids = rng.integers(-2, 2003, 3000).astype(np.int64)
+    vals = rng.integers(0, 2000, 3000).astype(np.int64)
+
+    def pinned(shape, dtype):
+        a = np.empty(shape, dtype)
+        assert L.glx_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) == 0, L.glx_last_error()
+        a.fill(0)
+        return a
+    bufs = []
+    try:
+        for name in glx.SAMPLER_IDS:
+            want = g.sample(name, ids, 7, seed=3, call_counter=5)
+            n, e = pinned((3000, 7), np.int64), pinned((3000, 7), np.int64)
+            bufs += [n, e]
+            g.sample(name, ids, 7, seed=3, call_counter=5, out=(n, e))
+            assert np.array_equal(n, want[0]) and np.array_equal(e, want[1]), name
+        want = g.sample_filtered("TopkSampler", ids, 5, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals)
+        nbr = want[0]
+        seg = (np.arange(nbr.size) // 5).astype(np.int32)
+        for name in glx.AGGREGATOR_IDS:
+            we, wc = f.aggregate(name, nbr.reshape(-1), seg, 3000, default_attr=0.5)
+            emb, cnt = pinned((3000, 48), np.float32), pinned((3000,), np.int32)
+            bufs += [emb, cnt]
+            f.aggregate(name, nbr.reshape(-1), seg, 3000, default_attr=0.5, out=(emb, cnt))
+            assert np.array_equal(cnt, wc) and np.array_equal(emb.view(np.uint32), we.view(np.uint32)), name
+    finally:
+        for a in bufs:
+            assert L.glx_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0
