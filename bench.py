@@ -394,7 +394,7 @@ def main():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
                          "auto = on for launch-bound batches (B0 <= 8192)")
-    ap.add_argument("--graph-streams", type=int, default=2, help="--graph: plans / streams the steps alternate over")
+    ap.add_argument("--graph-streams", type=int, default=3, help="--graph: plans / streams the steps alternate over")
     ap.add_argument("--roofline-probes", default="on", choices=["on", "off"],
                     help="N=1: also time the aggregation kernel on cache-free (uniform) rows and a device copy")
     ap.add_argument("--force-sharded", action="store_true",

@@ -567,6 +567,7 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
     return aggregate_device(f, op, node_ids, segment_ids, num_ids, num_segments, default_attr,
                             emb_out, cnt_out, s);
   }
+  GlxHostCallSlot admitted(f->device);
   const size_t emb_n = (size_t)num_segments * f->dim;
   // outputs go straight into the caller's buffers when those are pinned (glx_mapped_ptr): the embeddings are
   // by far the largest part of a response (4 * dim bytes per segment)
@@ -625,6 +626,7 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
     GLX_HIP(hipGetLastError());
     return GLX_OK;
   }
+  GlxHostCallSlot admitted(f->device);
   const size_t out_bytes = (size_t)n * f->dim * 4;
   float* m_out = static_cast<float*>(glx_mapped_ptr(out));  // pinned caller buffer: the kernel writes it directly
   const size_t ids_b = ((size_t)n * 8 + 15) & ~(size_t)15;  // ids first, 16-byte aligned rows after them

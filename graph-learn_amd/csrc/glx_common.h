@@ -499,6 +499,18 @@ int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, i
                                const int32_t* d_seg, int32_t num_ids, int32_t num_segments, float default_attr,
                                float* d_emb, int32_t* d_cnt, hipStream_t s);
 
+// Admission control for host-pointer calls.  The reference's servers run up to 32 pool threads on one
+// operator (in_memory_service.cc:64-71); on one GPU more than ~16 host-pointer calls in flight only contend
+// (runtime locks, copy queues: 32 threads measured 2.2e8 edges/s against 3.5e8 with 16), so the surplus
+// waits here.  GLX_HOST_CALL_CONCURRENCY overrides the limit (0 = unlimited).
+struct GlxHostCallSlot {
+  int device;
+  explicit GlxHostCallSlot(int device);
+  ~GlxHostCallSlot();
+  GlxHostCallSlot(const GlxHostCallSlot&) = delete;
+  GlxHostCallSlot& operator=(const GlxHostCallSlot&) = delete;
+};
+
 // Device-visible alias of a host buffer the caller pinned with glx_host_register (or allocated with
 // hipHostMalloc), nullptr for ordinary pageable memory.  Host-pointer calls let their kernels write results
 // straight into such a buffer -- the response crosses PCIe once, as the kernel's own coalesced stores, with no

@@ -888,6 +888,7 @@ extern "C" int glx_sample_filtered(const glx_graph* g, int sampler, const int64_
     return filtered_device(g, sampler, src, rng_rows, batch, k, nullptr, padding_mode, default_neighbor_id, seed,
                            call_counter, f, nbr_out, eid_out, s);
   }
+  GlxHostCallSlot admitted(g->device);
   const size_t nb = (size_t)batch, n_out = nb * (size_t)k;
   int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out));  // pinned caller buffers are written directly
   int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out));

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -63,6 +64,44 @@ extern "C" int glx_host_unregister(void* p) {
     return GLX_UNAVAILABLE;
   }
   return GLX_OK;
+}
+
+namespace {
+struct HostGate {
+  std::mutex m;
+  std::condition_variable cv;
+  int in_flight = 0;
+};
+HostGate g_host_gate[64];
+int host_call_limit() {
+  static const int limit = [] {
+    const char* e = getenv("GLX_HOST_CALL_CONCURRENCY");
+    return e ? atoi(e) : 16;
+  }();
+  return limit;
+}
+}  // namespace
+
+GlxHostCallSlot::GlxHostCallSlot(int dev) : device(dev) {
+  const int limit = host_call_limit();
+  if (limit <= 0 || device < 0 || device >= 64) {
+    device = -1;
+    return;
+  }
+  HostGate& g = g_host_gate[device];
+  std::unique_lock<std::mutex> lk(g.m);
+  g.cv.wait(lk, [&] { return g.in_flight < limit; });
+  ++g.in_flight;
+}
+
+GlxHostCallSlot::~GlxHostCallSlot() {
+  if (device < 0) return;
+  HostGate& g = g_host_gate[device];
+  {
+    std::lock_guard<std::mutex> lk(g.m);
+    --g.in_flight;
+  }
+  g.cv.notify_one();
 }
 
 void* glx_mapped_ptr(const void* host_ptr) {

@@ -434,6 +434,7 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
   }
   // Host pointers: inputs are staged through a device workspace; outputs are written by the kernel straight
   // into the caller's buffers when those are pinned (glx_mapped_ptr), else staged and copied.  Synchronous.
+  GlxHostCallSlot admitted(g->device);
   const size_t n_out = (size_t)batch * k;
   int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out));
   int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out));
