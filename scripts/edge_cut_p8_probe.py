@@ -1,0 +1,102 @@
+"""The edge-cut path at its real shape on ONE GPU: P ranks = P threads of this process (in-process transport,
+device-to-device copies instead of xGMI), full C3 (RMAT 10M / 100M, EdgeWeight [25,10] + Max, dim 256), every
+rank driving its own 65,536-seed batch like bench.py --gpus P.  All ranks share the GPU, so wall time per step
+/ P is a rank's device work WITHOUT link time: partition, exchanges as copies, the owner's sampling, resolve +
+dedup of the cold tail, halo lookups, the 3-source reduce.  Also checks every rank's answer against the
+unpartitioned operators, bit for bit, and prints where the ids came from (replica / own shard / halo).
+
+  python scripts/edge_cut_p8_probe.py [P=8] [hot_fraction=0.10] [steps=6]
+"""
+import os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd"))
+import numpy as np, torch, glx, synth
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+hot_fraction = float(sys.argv[2]) if len(sys.argv) > 2 else 0.10
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+dev = torch.device("cuda", 0)
+V, E, D, B0, k1, k2 = 10_000_000, 100_000_000, 256, 65536, 25, 10
+src, dst, w = synth.rmat_edges_torch(V, E, 4, dev)
+pool = torch.unique(src)
+whole = glx.Graph.from_edges(src, dst, w)
+X = synth.features_torch(V, D, 5, dev)
+feats = glx.Features(X)
+graphs, fshards = [], []
+for r in range(P):
+    own = (src % P) == r
+    graphs.append(glx.Graph.from_edges(src[own].contiguous(), dst[own].contiguous(), w[own].contiguous(),
+                                       edge_ids=torch.nonzero(own).view(-1)))
+    ids = torch.arange(r, V, P, dtype=torch.int64, device=dev)
+    fshards.append(glx.Features(X[r::P].contiguous(), ids=ids))
+    del own, ids
+del src, dst, w, X
+torch.cuda.empty_cache()
+n1, n2 = B0 * k1, B0 * k1 * k2
+bar = threading.Barrier(P)
+times, stats, ok = [None] * P, [None] * P, [True] * P
+
+
+def rank_main(r):
+    try:
+        comm = glx.Comm.local(4242, 0, r, P)
+        with torch.cuda.stream(torch.cuda.Stream(device=0)):
+            st_s = glx.DistStore(comm, graph=graphs[r])
+            st_a = glx.DistStore(comm, features=fshards[r])
+            hot = st_s.hot_ids(int(V * hot_fraction))
+            st_a.set_cache(hot)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1000 + r)
+            seeds = pool[torch.randint(0, pool.shape[0], (steps + 2, B0), generator=gen, device=dev)]
+            nb1 = torch.empty((B0, k1), dtype=torch.int64, device=dev); ed1 = torch.empty_like(nb1)
+            nb2 = torch.empty((n1, k2), dtype=torch.int64, device=dev); ed2 = torch.empty_like(nb2)
+            emb2 = torch.empty((n1, D), dtype=torch.float32, device=dev); cnt2 = torch.empty(n1, dtype=torch.int32, device=dev)
+            emb1 = torch.empty((B0, D), dtype=torch.float32, device=dev); cnt1 = torch.empty(B0, dtype=torch.int32, device=dev)
+
+            def step(i):
+                st_s.sample("EdgeWeightSampler", seeds[i], k1, seed=42, call_counter=4 * i, out=(nb1, ed1))
+                st_s.sample("EdgeWeightSampler", nb1.view(-1), k2, seed=42, call_counter=4 * i + 1, out=(nb2, ed2))
+                st_a.aggregate("MaxAggregator", nb2.view(-1), None, n1, out=(emb2, cnt2))
+                s2 = st_a.stats()
+                st_a.aggregate("MaxAggregator", nb1.view(-1), None, B0, out=(emb1, cnt1))
+                return s2
+            for i in range(2):
+                step(i)
+            torch.cuda.current_stream().synchronize()
+            bar.wait()
+            t0 = time.perf_counter()
+            for i in range(2, steps + 2):
+                s2 = step(i)
+            torch.cuda.current_stream().synchronize()
+            bar.wait()
+            times[r] = (time.perf_counter() - t0) / steps
+            stats[r] = s2
+            # bit-identical to the unpartitioned operators (last step)
+            i = steps + 1
+            wa, wae = whole.sample("EdgeWeightSampler", seeds[i], k1, seed=42, call_counter=4 * i)
+            wb, wbe = whole.sample("EdgeWeightSampler", wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
+            we2, wc2 = feats.aggregate("MaxAggregator", wb.view(-1), None, n1)
+            torch.cuda.current_stream().synchronize()
+            ok[r] = bool(torch.equal(nb1, wa) and torch.equal(ed1, wae) and torch.equal(nb2, wb) and torch.equal(ed2, wbe)
+                         and torch.equal(cnt2, wc2) and torch.equal(emb2.view(torch.int32), we2.view(torch.int32)))
+            st_s.close(); st_a.close()
+        comm.close()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        ok[r] = False
+        try:
+            bar.abort()
+        except Exception:
+            pass
+
+
+ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+for t in ts: t.start()
+for t in ts: t.join(600)
+print("P = %d ranks on one GPU, hot fraction %.2f: %.2f ms per step with all ranks running (%.2f ms of device work per rank-step); "
+      "all answers equal the unpartitioned operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3,
+                                                              max(x or 0 for x in times) * 1e3 / P, all(ok)))
+for r in (0, P - 1):
+    print("rank %d hop-2 request:" % r, stats[r])
+sys.exit(0 if all(ok) else 1)
