@@ -500,9 +500,9 @@ int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, i
                                float* d_emb, int32_t* d_cnt, hipStream_t s);
 
 // Admission control for host-pointer calls.  The reference's servers run up to 32 pool threads on one
-// operator (in_memory_service.cc:64-71); on one GPU more than ~16 host-pointer calls in flight only contend
-// (runtime locks, copy queues: 32 threads measured 2.2e8 edges/s against 3.5e8 with 16), so the surplus
-// waits here.  GLX_HOST_CALL_CONCURRENCY overrides the limit (0 = unlimited).
+// operator (in_memory_service.cc:64-71); on one GPU more than a dozen host-pointer calls in flight only contend
+// (runtime locks, copy queues: 32 unlimited threads measured 2.2e8 edges/s, 3.7e8 with 12 admitted), so the
+// surplus waits here.  GLX_HOST_CALL_CONCURRENCY overrides the limit (0 = unlimited).
 struct GlxHostCallSlot {
   int device;
   explicit GlxHostCallSlot(int device);

@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int kMaxWorld = 64;
-constexpr int kMaxProbe = 512;
+constexpr int kMaxProbe = 128;
 
 // ---------------------------------------------------------------- memory -----
 // Grow-only device arena; growth synchronises the device (hipFree), which also makes it safe
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void glx_dist_stitch2_kernel(const int64_t* __
 //   [0, P)     distinct halo ids per owner         [P, 2P)   compaction cursors
 //   [2P]       overflow flag (set table too small)  [2P+1..3] ids served by replica / own shard /
 //   [2P+4 ..]  exclusive offsets per owner (P + 1)            remote (with repeats)
+//   [3P+5]     distinct halo ids inserted so far (all owners)
 struct ResolveArgs {
   GlxIdMap cache_map;
   GlxIdMap own_map;
@@ -122,6 +123,7 @@ struct ResolveArgs {
   int32_t P, me;
   int32_t cache_base;
   int32_t has_cache;
+  int32_t insert_limit;  // distinct ids the set takes before it counts as too small (60 % of its slots)
 };
 
 // Pass 1: every id -> a virtual row (own shard / replica), -1 (default row), or -(h + 2) when
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
           r = glx_row_of(a.own_map, id);
           out = r >= 0 ? (int32_t)r : -1;
           ++n_own;
+        } else if (__atomic_load_n(&a.ctr[2 * a.P], __ATOMIC_RELAXED) != 0) {
+          ++n_cold;  // the set already overflowed: this pass is void, the host retries with a larger one
         } else {
           ++n_cold;
           uint64_t h = glx_mix64((uint64_t)id) & a.tmask;
@@ -176,8 +180,13 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
       }
       a.loc[i] = out;
     }
-    // one atomic per (wave, owner) for the new distinct ids
+    // one atomic per (wave, owner) for the new distinct ids, one for their total: a set that fills beyond
+    // its limit is declared too small at once, before probe sequences grow long
     uint64_t pending = __ballot(winner);
+    if (pending && lane == (int)(__ffsll((long long)pending) - 1)) {
+      const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], __popcll(pending));
+      if (before + __popcll(pending) > a.insert_limit) a.ctr[2 * a.P] = 1;
+    }
     while (pending) {
       const int leader = __ffsll((long long)pending) - 1;
       const int32_t o = __shfl(owner, leader);
@@ -338,7 +347,7 @@ struct glx_dist_store {
   Arena req, recv, tab, halo;
   int64_t* d_vals = nullptr;  // [world + 8] values shared by the count exchange
   int32_t* d_ctr = nullptr;   // [3 * world + 8] counter block of the resolve passes
-  int64_t last_distinct = 0;
+  double halo_share = 0.0;  // largest (distinct halo ids / request ids) seen so far
   glx_dist_stats stats;
   std::vector<int64_t> h_mat;
 };
@@ -397,10 +406,14 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
   int32_t* loc = reinterpret_cast<int32_t*>(st->req.p + o_loc);
   int64_t* cold_ids = reinterpret_cast<int64_t*>(st->req.p + o_cold);
 
-  // Set of distinct halo ids: sized from the previous request (the cold tail is a small
-  // fraction of a power-law request), grown to the safe bound 2n when it overflows.
+  // Set of distinct halo ids.  Sized for the request at hand: a quarter of its ids, or 2.5x the largest share
+  // of distinct halo ids this store has seen (a hop-2 and a hop-1 request alternate: sizing from the PREVIOUS
+  // request's absolute count made every other call overflow), and regrown to the safe bound 2n -- on the ranks
+  // that overflowed, in lockstep with the others -- when that is not enough.
   const uint64_t safe_cap = pow2_at_least((uint64_t)(n > 0 ? n : 1) * 2);
-  uint64_t tcap = P == 1 ? 64 : pow2_at_least((uint64_t)(st->last_distinct > 4096 ? st->last_distinct : 4096) * 4);
+  double share = 2.5 * st->halo_share;
+  if (share < 0.25) share = 0.25;
+  uint64_t tcap = P == 1 ? 64 : pow2_at_least((uint64_t)((double)(n > 0 ? n : 1) * share) + 65536);
   if (tcap > safe_cap) tcap = safe_cap;
   bool first = true, mine_overflow = false;
   int64_t* tkeys = nullptr;
@@ -427,6 +440,7 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
       a.me = me;
       a.cache_base = (int32_t)n_own;
       a.has_cache = st->cache != nullptr;
+      a.insert_limit = tcap >= safe_cap ? INT32_MAX : (int32_t)(tcap / 10 * 6);
       if (n > 0) glx_dist_resolve_kernel<<<grid_for(n), 256, 0, s>>>(a);
       glx_dist_offsets_kernel<<<1, 64, 0, s>>>(st->d_ctr, P, tcap, st->d_vals);
       ReqParams prm;
@@ -452,7 +466,7 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
   }
   const int64_t* mine = &st->h_mat[(size_t)me * nvals];
   const int64_t U = mine[P + 1];
-  st->last_distinct = U;
+  if (n > 0 && (double)U / (double)n > st->halo_share) st->halo_share = (double)U / (double)n;
   stat.remote_distinct = U;
   stat.from_replica = mine[P + 2];
   stat.from_own_shard = mine[P + 3];

@@ -76,7 +76,7 @@ HostGate g_host_gate[64];
 int host_call_limit() {
   static const int limit = [] {
     const char* e = getenv("GLX_HOST_CALL_CONCURRENCY");
-    return e ? atoi(e) : 16;
+    return e ? atoi(e) : 12;
   }();
   return limit;
 }

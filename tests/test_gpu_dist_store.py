@@ -220,18 +220,19 @@ def test_dist_aggregate_equals_unpartitioned(world, P, cache):
 
 @pytest.mark.parametrize("P", [2, 8])
 def test_halo_set_grows_when_it_overflows(world, P):
-    """The set of distinct halo ids is sized from the previous request; a much larger cold tail must
-    trigger the retry with the safe size on the ranks that overflow, in lockstep with the others."""
+    """The set of distinct halo ids is sized for a quarter of the request (or 2.5x the largest share of
+    distinct halo ids seen so far); a request whose ids are nearly all distinct and remote must trigger the
+    retry with the safe size on the ranks that overflow, in lockstep with the others."""
     feats, dev = world["feats"], world["dev"]
     _, fs = world["shards"][P]
 
     def body(r, comm):
         st = glx.DistStore(comm, features=fs[r])
         rng = np.random.default_rng(r)
-        for n in (64, 120000, 300, 120000):
-            # half of the ids are unknown everywhere (default rows) so that the distinct remote ids
-            # outnumber the 16 Ki slots the set starts with
-            mixed = np.where(rng.random(n) < 0.5, rng.integers(0, V, n), rng.integers(V, 10 ** 7, n))
+        for n in (64, 1000000, 300, 1000000):
+            # nine ids in ten are unknown everywhere (default rows) and distinct, so that the distinct remote
+            # ids outnumber 60 % of the n / 4 slots the set starts with
+            mixed = np.where(rng.random(n) < 0.1, rng.integers(0, V, n), rng.integers(V, 10 ** 9, n))
             ids = torch.from_numpy(mixed.astype(np.int64)).to(dev) if (r > 0 or n > 64) else \
                 torch.zeros(n, dtype=torch.int64, device=dev)
             e, c = st.aggregate("SumAggregator", ids, None, n // 4, default_attr=0.0)
