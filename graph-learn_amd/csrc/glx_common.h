@@ -481,6 +481,11 @@ int glx_alias_build_launch(const int64_t* row_ptr, const float* weight, int64_t 
                            GlxAlias* out, hipStream_t s);
 void glx_graph_free(glx_graph* g);
 
+// glx_full.hip: the in-degree machinery shared with the distributed store (glx_dist_enable_in_degree).
+int glx_graph_dst_counts(const glx_graph* g, GlxTemp* uniq, GlxTemp* counts, int64_t* U, hipStream_t s);
+int glx_graph_install_in_degree(glx_graph* g, const int64_t* d_uniq, const int64_t* d_counts, int64_t U,
+                                hipStream_t s);
+
 // glx_sample.hip: TopkSampler / RandomWithoutReplacementSampler restricted to the first
 // d_prefix[i] slots of request row i (listed descending under circular padding).
 int glx_sample_prefix_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng,

@@ -128,13 +128,21 @@ struct ResolveArgs {
 
 // Pass 1: every id -> a virtual row (own shard / replica), -1 (default row), or -(h + 2) when
 // it is remote and cold: h = its slot in the open-addressing set of distinct halo ids.
+// New distinct ids are counted per owner in LDS and flushed to the global counters every few
+// iterations: per-wave atomics on P global addresses (a quarter of a million waves on eight
+// counters) serialised the whole kernel -- 10 ms for a 16 M-id request.
+constexpr int kFlushEvery = 8;
 __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   __shared__ int32_t s_stat[3];
+  __shared__ int32_t s_cnt[kMaxWorld];
+  __shared__ int32_t s_sum;
   if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+  if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   int32_t n_hit = 0, n_own = 0, n_cold = 0;
-  for (int64_t base = blockIdx.x * 256ll; base < a.n; base += gridDim.x * 256ll) {
+  int it = 0;
+  for (int64_t base = blockIdx.x * 256ll; base < a.n; base += gridDim.x * 256ll, ++it) {
     const int64_t i = base + threadIdx.x;
     bool winner = false;
     int32_t owner = 0;
@@ -180,19 +188,33 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
       }
       a.loc[i] = out;
     }
-    // one atomic per (wave, owner) for the new distinct ids, one for their total: a set that fills beyond
-    // its limit is declared too small at once, before probe sequences grow long
+    // new distinct ids: one LDS atomic per (wave, owner)
     uint64_t pending = __ballot(winner);
-    if (pending && lane == (int)(__ffsll((long long)pending) - 1)) {
-      const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], __popcll(pending));
-      if (before + __popcll(pending) > a.insert_limit) a.ctr[2 * a.P] = 1;
-    }
     while (pending) {
       const int leader = __ffsll((long long)pending) - 1;
       const int32_t o = __shfl(owner, leader);
       const uint64_t same = __ballot(winner && owner == o);
-      if (lane == leader) atomicAdd(&a.ctr[o], __popcll(same));
+      if (lane == leader) atomicAdd(&s_cnt[o], __popcll(same));
       pending &= ~same;
+    }
+    if ((it % kFlushEvery) == kFlushEvery - 1) {
+      // flush: P global atomics per block, and the running total decides early whether the set is too small
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int32_t sum = 0;
+        for (int32_t p = 0; p < a.P; ++p) sum += s_cnt[p];
+        s_sum = sum;
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < a.P && s_cnt[threadIdx.x]) {
+        atomicAdd(&a.ctr[threadIdx.x], s_cnt[threadIdx.x]);
+        s_cnt[threadIdx.x] = 0;
+      }
+      if (threadIdx.x == 0 && s_sum) {
+        const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], s_sum);
+        if (before + s_sum > a.insert_limit) a.ctr[2 * a.P] = 1;
+      }
+      __syncthreads();
     }
   }
   atomicAdd(&s_stat[0], n_hit);
@@ -200,6 +222,15 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   atomicAdd(&s_stat[2], n_cold);
   __syncthreads();
   if (threadIdx.x < 3 && s_stat[threadIdx.x]) atomicAdd(&a.ctr[2 * a.P + 1 + threadIdx.x], s_stat[threadIdx.x]);
+  if ((int)threadIdx.x < a.P && s_cnt[threadIdx.x]) atomicAdd(&a.ctr[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x == 0) {
+    int32_t sum = 0;
+    for (int32_t p = 0; p < a.P; ++p) sum += s_cnt[p];
+    if (sum) {
+      const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], sum);
+      if (before + sum > a.insert_limit) a.ctr[2 * a.P] = 1;
+    }
+  }
 }
 
 // Pass 2 (one wave): per-owner offsets, and the values every rank shares:
@@ -225,33 +256,69 @@ __global__ void glx_dist_offsets_kernel(int32_t* ctr, int32_t P, uint64_t tcap, 
 }
 
 // Pass 3: compact the set into per-owner buckets (the ids each owner is asked for) and give
-// every member its halo row = position in that concatenation.
+// every member its halo row = position in that concatenation.  A block takes a tile of kAssignTile
+// slots at a time: count its members per owner in LDS, reserve the block's ranges with P global
+// atomics, then place the members (order inside a bucket is arbitrary; results do not depend on it).
+constexpr int kAssignTile = 4096;
 __global__ __launch_bounds__(256) void glx_dist_assign_kernel(const int64_t* __restrict__ tkeys, uint64_t tcap,
                                                               int32_t* __restrict__ tvals, int32_t* ctr, int32_t P,
                                                               int64_t* __restrict__ cold_ids) {
+  __shared__ int32_t s_cnt[kMaxWorld];
+  __shared__ int32_t s_base[kMaxWorld];
   const int lane = threadIdx.x & 63;
+  const uint64_t lt = (1ull << lane) - 1ull;
   int32_t* cursor = ctr + P;
   const int32_t* off = ctr + 2 * P + 4;
-  for (uint64_t base = blockIdx.x * 256ull; base < tcap; base += gridDim.x * 256ull) {
-    const uint64_t h = base + threadIdx.x;
-    const int64_t key = h < tcap ? tkeys[h] : GLX_EMPTY_KEY;
-    const bool live = key != GLX_EMPTY_KEY;
-    const int32_t owner = live ? dist_owner(key, P) : 0;
-    uint64_t pending = __ballot(live);
-    while (pending) {
-      const int leader = __ffsll((long long)pending) - 1;
-      const int32_t o = __shfl(owner, leader);
-      const uint64_t same = __ballot(live && owner == o);
-      int32_t start = 0;
-      if (lane == leader) start = atomicAdd(&cursor[o], __popcll(same));
-      start = __shfl(start, leader);
-      if (live && owner == o) {
-        const int32_t pos = off[o] + start + __popcll(same & ((1ull << lane) - 1ull));
-        tvals[h] = pos;
-        cold_ids[pos] = key;
+  if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t tile = blockIdx.x * (uint64_t)kAssignTile; tile < tcap; tile += gridDim.x * (uint64_t)kAssignTile) {
+    // count
+    for (int j = 0; j < kAssignTile / 256; ++j) {
+      const uint64_t h = tile + j * 256 + threadIdx.x;
+      const int64_t key = h < tcap ? tkeys[h] : GLX_EMPTY_KEY;
+      const bool live = key != GLX_EMPTY_KEY;
+      const int32_t owner = live ? dist_owner(key, P) : 0;
+      uint64_t pending = __ballot(live);
+      while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int32_t o = __shfl(owner, leader);
+        const uint64_t same = __ballot(live && owner == o);
+        if (lane == leader) atomicAdd(&s_cnt[o], __popcll(same));
+        pending &= ~same;
       }
-      pending &= ~same;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < P) {
+      const int32_t c = s_cnt[threadIdx.x];
+      s_base[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0;
+      s_cnt[threadIdx.x] = 0;  // becomes the running offset inside the block's range
+    }
+    __syncthreads();
+    // place
+    for (int j = 0; j < kAssignTile / 256; ++j) {
+      const uint64_t h = tile + j * 256 + threadIdx.x;
+      const int64_t key = h < tcap ? tkeys[h] : GLX_EMPTY_KEY;
+      const bool live = key != GLX_EMPTY_KEY;
+      const int32_t owner = live ? dist_owner(key, P) : 0;
+      uint64_t pending = __ballot(live);
+      while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int32_t o = __shfl(owner, leader);
+        const uint64_t same = __ballot(live && owner == o);
+        int32_t start = 0;
+        if (lane == leader) start = atomicAdd(&s_cnt[o], __popcll(same));
+        start = __shfl(start, leader);
+        if (live && owner == o) {
+          const int32_t pos = off[o] + s_base[o] + start + __popcll(same & lt);
+          tvals[h] = pos;
+          cold_ids[pos] = key;
+        }
+        pending &= ~same;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
   }
 }
 
@@ -329,12 +396,6 @@ inline uint64_t pow2_at_least(uint64_t x) {
     GLX_HIP(hipStreamSynchronize(s)); /* tmp__ is freed right after */ \
   } while (0)
 
-__global__ void glx_dist_extract_nbr_kernel(const GlxAdj* __restrict__ adj, int64_t n, int64_t* __restrict__ out) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = adj[i].nbr;
-}
-
 }  // namespace
 
 struct glx_dist_store {
@@ -348,6 +409,7 @@ struct glx_dist_store {
   int64_t* d_vals = nullptr;  // [world + 8] values shared by the count exchange
   int32_t* d_ctr = nullptr;   // [3 * world + 8] counter block of the resolve passes
   double halo_share = 0.0;  // largest (distinct halo ids / request ids) seen so far
+  bool global_in_degree = false;  // glx_dist_enable_in_degree built the shard's tables from global counts
   glx_dist_stats stats;
   std::vector<int64_t> h_mat;
 };
@@ -448,7 +510,7 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
       memcpy(&prm.v[0], &default_attr, sizeof(float));
       glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P + 5, prm, 1);
       if (P > 1 && n > 0) {
-        glx_dist_assign_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap, tvals, st->d_ctr, P, cold_ids);
+        glx_dist_assign_kernel<<<grid_for((int64_t)(tcap / 16 + 1)), 256, 0, s>>>(tkeys, tcap, tvals, st->d_ctr, P, cold_ids);
         glx_dist_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(loc, n, tvals,
                                                                               (int32_t)(n_own + n_cache));
       }
@@ -722,9 +784,9 @@ extern "C" int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* s
   GLX_REQUIRE(!filtered || batch == 0 || filter->values != nullptr, "filter without values");
   // InDegreeSampler weighs a neighbour by its in-degree over ALL shards; a shard's tables
   // (glx_graph_enable_in_degree) only count the edges it owns.
-  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || st->world == 1,
-              "InDegreeSampler is not served by a partitioned store: a shard's in-degree tables cover its own "
-              "edges only");
+  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || st->world == 1 || st->global_in_degree,
+              "InDegreeSampler on a partitioned store needs glx_dist_enable_in_degree(): a shard's own in-degree "
+              "tables cover its own edges only");
   GlxDeviceGuard guard(st->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
   if (ptr_kind == GLX_PTR_DEVICE) {
@@ -944,6 +1006,96 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
   return rc;
 }
 
+namespace {
+
+// Every destination id of the edge type with its in-degree summed over ALL shards, at the id's owner
+// (llabs(id) % P): each shard run-length-encodes its own destinations, the (id, count) pairs travel to the
+// owners, the owners reduce by key.  Collective.
+struct DstTotals {
+  GlxTemp uniq, cnt;       // this shard's distinct destination ids (ascending) + its own counts
+  int64_t Ul = 0;
+  GlxTemp buck, ord;       // the same ids bucketed by owner + their index in `uniq`
+  Routing rt;              // uniq ids out / in
+  GlxTemp ids_in;          // ids the other shards asked about (requester-major), rt.n_recv of them
+  GlxTemp own_id, own_cnt; // owned ids ascending + global in-degree
+  int64_t M = 0;
+};
+
+int dst_totals(glx_dist_store* st, hipStream_t s, DstTotals* t) {
+  const glx_graph* g = st->graph;
+  const int P = st->world;
+  int rc = glx_graph_dst_counts(g, &t->uniq, &t->cnt, &t->Ul, s);
+  if (rc != GLX_OK) return rc;
+  const int64_t Ul = t->Ul;
+  GlxTemp cnt_b;
+  GLX_HIP(hipMalloc(&t->buck.p, (size_t)(Ul ? Ul : 1) * 8));
+  GLX_HIP(hipMalloc(&t->ord.p, (size_t)(Ul ? Ul : 1) * 8));
+  GLX_HIP(hipMalloc(&cnt_b.p, (size_t)(Ul ? Ul : 1) * 8));
+  rc = glx_partition(st->device, t->uniq.as<int64_t>(), Ul, P, t->buck.as<int64_t>(), t->ord.as<int64_t>(), st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  if (Ul > 0) {
+    glx_dist_gather_i64_kernel<<<(unsigned)((Ul + 255) / 256), 256, 0, s>>>(t->cnt.as<int64_t>(), t->ord.as<int64_t>(), Ul,
+                                                                            cnt_b.as<int64_t>());
+  }
+  st->h_mat.resize((size_t)P * P);
+  rc = st->comm->allgather_i64(st->d_vals, P, st->h_mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  routing_from_matrix(st, P, &t->rt);
+  const size_t m = (size_t)t->rt.n_recv;
+  GlxTemp cnt_in, ids_s, cnt_s, nown;
+  GLX_HIP(hipMalloc(&t->ids_in.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&cnt_in.p, (m ? m : 1) * 8));
+  GlxSeg segs[2] = {{t->buck.p, t->ids_in.p, 8}, {cnt_b.p, cnt_in.p, 8}};
+  rc = st->comm->alltoallv(segs, 2, t->rt.send_counts.data(), t->rt.send_offs.data(), t->rt.recv_counts.data(),
+                           t->rt.recv_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(hipMalloc(&ids_s.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&cnt_s.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&t->own_id.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&t->own_cnt.p, (m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&nown.p, 8));
+  t->M = 0;
+  if (m > 0) {
+#define SORTP(tmp, bytes)                                                                                       \
+  rocprim::radix_sort_pairs(tmp, bytes, t->ids_in.as<int64_t>(), ids_s.as<int64_t>(), cnt_in.as<int64_t>(), \
+                            cnt_s.as<int64_t>(), m, 0, 64, s)
+    GLX_ROCPRIM(SORTP);
+#undef SORTP
+#define REDUCE(tmp, bytes)                                                                                        \
+  rocprim::reduce_by_key(tmp, bytes, ids_s.as<int64_t>(), cnt_s.as<int64_t>(), m, t->own_id.as<int64_t>(),    \
+                         t->own_cnt.as<int64_t>(), nown.as<int64_t>(), rocprim::plus<int64_t>(),                \
+                         rocprim::equal_to<int64_t>(), s)
+    GLX_ROCPRIM(REDUCE);
+#undef REDUCE
+    GLX_HIP(hipMemcpyAsync(&t->M, nown.p, 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+  }
+  return GLX_OK;
+}
+
+// out[i] = total of ids[i] in the owner's ascending (own_id, own_cnt) table; every id asked about is there.
+__global__ void glx_dist_total_of_kernel(const int64_t* __restrict__ own_id, const int64_t* __restrict__ own_cnt,
+                                         int64_t M, const int64_t* __restrict__ ids, int64_t n,
+                                         int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  int64_t lo = 0, hi = M;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (own_id[mid] < id) lo = mid + 1; else hi = mid;
+  }
+  out[i] = (lo < M && own_id[lo] == id) ? own_cnt[lo] : 0;
+}
+
+__global__ void glx_dist_scatter_i64_kernel(const int64_t* __restrict__ in, const int64_t* __restrict__ order, int64_t n,
+                                            int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[order[i]] = in[i];
+}
+
+}  // namespace
+
 // Collective: global in-degree top-`want` of the store's edge type.
 extern "C" int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_out, int64_t* n_out, void* stream) {
   GLX_REQUIRE(st != nullptr && ids_out != nullptr && n_out != nullptr, "NULL argument");
@@ -953,92 +1105,26 @@ extern "C" int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_o
   GlxDeviceGuard guard(st->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
   hipStream_t s = glx_stream(stream);
-  const glx_graph* g = st->graph;
-  const int P = st->world, me = st->rank;
-  const size_t E = (size_t)g->num_edges;
-
-  // 1. this shard's (destination id, count) pairs: sort + run-length encode
-  GlxTemp keys, sorted, uniq, cnt, nruns;
-  GLX_HIP(hipMalloc(&keys.p, (E ? E : 1) * 8));
-  GLX_HIP(hipMalloc(&sorted.p, (E ? E : 1) * 8));
-  GLX_HIP(hipMalloc(&uniq.p, (E ? E : 1) * 8));
-  GLX_HIP(hipMalloc(&cnt.p, (E ? E : 1) * 8));
-  GLX_HIP(hipMalloc(&nruns.p, 8));
-  int64_t Ul = 0;
-  if (E > 0) {
-    glx_dist_extract_nbr_kernel<<<grid_for((int64_t)E, 8192), 256, 0, s>>>(g->adj, (int64_t)E, keys.as<int64_t>());
-#define SORT(tmp, bytes) rocprim::radix_sort_keys(tmp, bytes, keys.as<int64_t>(), sorted.as<int64_t>(), E, 0, 64, s)
-    GLX_ROCPRIM(SORT);
-#undef SORT
-#define RLE(tmp, bytes)                                                                                        \
-  rocprim::run_length_encode(tmp, bytes, sorted.as<int64_t>(), E, uniq.as<int64_t>(), cnt.as<int64_t>(), \
-                             nruns.as<int64_t>(), s)
-    GLX_ROCPRIM(RLE);
-#undef RLE
-    GLX_HIP(hipMemcpyAsync(&Ul, nruns.p, 8, hipMemcpyDeviceToHost, s));
-    GLX_HIP(hipStreamSynchronize(s));
-  }
-  // 2. route every pair to the owner of the destination id
-  GlxTemp buck, ord, cnt_b;
-  GLX_HIP(hipMalloc(&buck.p, (size_t)(Ul ? Ul : 1) * 8));
-  GLX_HIP(hipMalloc(&ord.p, (size_t)(Ul ? Ul : 1) * 8));
-  GLX_HIP(hipMalloc(&cnt_b.p, (size_t)(Ul ? Ul : 1) * 8));
-  int rc = glx_partition(st->device, uniq.as<int64_t>(), Ul, P, buck.as<int64_t>(), ord.as<int64_t>(), st->d_vals, s);
+  const int P = st->world;
+  DstTotals t;
+  int rc = dst_totals(st, s, &t);
   if (rc != GLX_OK) return rc;
-  if (Ul > 0) {
-    glx_dist_gather_i64_kernel<<<(unsigned)((Ul + 255) / 256), 256, 0, s>>>(cnt.as<int64_t>(), ord.as<int64_t>(), Ul,
-                                                                            cnt_b.as<int64_t>());
-  }
-  st->h_mat.resize((size_t)P * P);
-  rc = st->comm->allgather_i64(st->d_vals, P, st->h_mat.data(), s);
-  if (rc != GLX_OK) return rc;
-  Routing rt;
-  routing_from_matrix(st, P, &rt);
-  const size_t m = (size_t)rt.n_recv;
-  GlxTemp ids_in, cnt_in, ids_s, cnt_s, own_id, own_cnt, nown;
-  GLX_HIP(hipMalloc(&ids_in.p, (m ? m : 1) * 8));
-  GLX_HIP(hipMalloc(&cnt_in.p, (m ? m : 1) * 8));
-  GlxSeg segs[2] = {{buck.p, ids_in.p, 8}, {cnt_b.p, cnt_in.p, 8}};
-  rc = st->comm->alltoallv(segs, 2, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
-                           rt.recv_offs.data(), s);
-  if (rc != GLX_OK) return rc;
-  // 3. owner: total in-degree per owned destination id
-  GLX_HIP(hipMalloc(&ids_s.p, (m ? m : 1) * 8));
-  GLX_HIP(hipMalloc(&cnt_s.p, (m ? m : 1) * 8));
-  GLX_HIP(hipMalloc(&own_id.p, (m ? m : 1) * 8));
-  GLX_HIP(hipMalloc(&own_cnt.p, (m ? m : 1) * 8));
-  GLX_HIP(hipMalloc(&nown.p, 8));
-  int64_t M = 0;
-  if (m > 0) {
-#define SORTP(tmp, bytes)                                                                                    \
-  rocprim::radix_sort_pairs(tmp, bytes, ids_in.as<int64_t>(), ids_s.as<int64_t>(), cnt_in.as<int64_t>(), \
-                            cnt_s.as<int64_t>(), m, 0, 64, s)
-    GLX_ROCPRIM(SORTP);
-#undef SORTP
-#define REDUCE(tmp, bytes)                                                                                     \
-  rocprim::reduce_by_key(tmp, bytes, ids_s.as<int64_t>(), cnt_s.as<int64_t>(), m, own_id.as<int64_t>(),   \
-                         own_cnt.as<int64_t>(), nown.as<int64_t>(), rocprim::plus<int64_t>(),                \
-                         rocprim::equal_to<int64_t>(), s)
-    GLX_ROCPRIM(REDUCE);
-#undef REDUCE
-    GLX_HIP(hipMemcpyAsync(&M, nown.p, 8, hipMemcpyDeviceToHost, s));
-    GLX_HIP(hipStreamSynchronize(s));
-  }
-  // 4. this owner's best `want` (count descending; ids ascending among equals: the input is
-  //    id-sorted and the radix sort is stable)
+  const int64_t M = t.M;
+  // this owner's best `want` (count descending; ids ascending among equals: the input is id-sorted and the
+  // radix sort is stable)
   GlxTemp top_cnt, top_id;
   GLX_HIP(hipMalloc(&top_cnt.p, (size_t)(M ? M : 1) * 8));
   GLX_HIP(hipMalloc(&top_id.p, (size_t)(M ? M : 1) * 8));
   if (M > 0) {
     const size_t Ms = (size_t)M;
-#define SORTD(tmp, bytes)                                                                                         \
-  rocprim::radix_sort_pairs_desc(tmp, bytes, own_cnt.as<int64_t>(), top_cnt.as<int64_t>(), own_id.as<int64_t>(), \
+#define SORTD(tmp, bytes)                                                                                             \
+  rocprim::radix_sort_pairs_desc(tmp, bytes, t.own_cnt.as<int64_t>(), top_cnt.as<int64_t>(), t.own_id.as<int64_t>(), \
                                  top_id.as<int64_t>(), Ms, 0, 64, s)
     GLX_ROCPRIM(SORTD);
 #undef SORTD
   }
   const int64_t c_me = M < want ? M : want;
-  // 5. share the candidates: everyone gets every owner's list (rank-major), merges the same way
+  // share the candidates: everyone gets every owner's list (rank-major) and merges the same way
   int64_t c_me_copy = c_me;
   GLX_HIP(hipMemcpyAsync(st->d_vals, &c_me_copy, 8, hipMemcpyHostToDevice, s));
   std::vector<int64_t> cand((size_t)P);
@@ -1053,7 +1139,6 @@ extern "C" int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_o
   GlxSeg csegs[2] = {{top_cnt.p, all_cnt.p, 8}, {top_id.p, all_id.p, 8}};
   rc = st->comm->alltoallv(csegs, 2, same.data(), zero.data(), cand.data(), offs.data(), s);
   if (rc != GLX_OK) return rc;
-  (void)me;
   if (T == 0) return GLX_OK;
   GLX_HIP(hipMalloc(&by_id_cnt.p, T * 8));
   GLX_HIP(hipMalloc(&by_id_id.p, T * 8));
@@ -1073,5 +1158,43 @@ extern "C" int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_o
   GLX_HIP(hipMemcpyAsync(ids_out, fin_id.p, (size_t)take * 8, hipMemcpyDeviceToHost, s));
   GLX_HIP(hipStreamSynchronize(s));
   *n_out = take;
+  return GLX_OK;
+}
+
+// Collective: InDegreeSampler on a partitioned edge type.  A neighbour's weight is its in-degree over ALL
+// shards (GraphStorage::GetInDegree of the unpartitioned storage, topo_statics.cc:62-69; the sampler:
+// in_degree_sampler.cc:33-114), so every shard asks the owners for the totals of the destinations it holds
+// and builds its per-row alias tables from those.
+extern "C" int glx_dist_enable_in_degree(glx_dist_store* st, glx_graph* shard, void* stream) {
+  GLX_REQUIRE(st != nullptr && shard != nullptr, "NULL argument");
+  GLX_REQUIRE(st->graph == shard, "`shard` must be the graph this store was created with");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = glx_stream(stream);
+  DstTotals t;
+  int rc = dst_totals(st, s, &t);
+  if (rc != GLX_OK) return rc;
+  const int64_t m = t.rt.n_recv, Ul = t.Ul;
+  GlxTemp tot_in, tot_b, total;
+  GLX_HIP(hipMalloc(&tot_in.p, (size_t)(m ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&tot_b.p, (size_t)(Ul ? Ul : 1) * 8));
+  GLX_HIP(hipMalloc(&total.p, (size_t)(Ul ? Ul : 1) * 8));
+  if (m > 0) {
+    glx_dist_total_of_kernel<<<(unsigned)((m + 255) / 256), 256, 0, s>>>(t.own_id.as<int64_t>(), t.own_cnt.as<int64_t>(),
+                                                                         t.M, t.ids_in.as<int64_t>(), m,
+                                                                         tot_in.as<int64_t>());
+  }
+  GlxSeg seg{tot_in.p, tot_b.p, 8};
+  rc = st->comm->alltoallv(&seg, 1, t.rt.recv_counts.data(), t.rt.recv_offs.data(), t.rt.send_counts.data(),
+                           t.rt.send_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  if (Ul > 0) {
+    glx_dist_scatter_i64_kernel<<<(unsigned)((Ul + 255) / 256), 256, 0, s>>>(tot_b.as<int64_t>(), t.ord.as<int64_t>(), Ul,
+                                                                             total.as<int64_t>());
+  }
+  GLX_HIP(hipGetLastError());
+  rc = glx_graph_install_in_degree(shard, t.uniq.as<int64_t>(), total.as<int64_t>(), Ul, s);
+  if (rc != GLX_OK) return rc;
+  st->global_in_degree = true;
   return GLX_OK;
 }

@@ -580,8 +580,17 @@ __global__ void glx_filter_pack_general_kernel(const int32_t* __restrict__ gener
                                                int64_t* __restrict__ sub_src, int64_t* __restrict__ sub_rng,
                                                int64_t* __restrict__ sub_val) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= batch || !general[i]) return;
-  const int32_t at = atomicAdd(count, 1);
+  const bool take = i < batch && general[i];
+  // one atomic per wave, not per row: a request can leave hundreds of thousands of rows to the general path
+  const uint64_t b = __ballot(take);
+  if (!b) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)b) - 1;
+  int32_t start = 0;
+  if (lane == leader) start = atomicAdd(count, __popcll(b));
+  start = __shfl(start, leader);
+  if (!take) return;
+  const int32_t at = start + __popcll(b & ((1ull << lane) - 1ull));
   gidx[at] = i;
   sub_src[at] = src[i];
   sub_rng[at] = rng ? rng[i] : (int64_t)i;

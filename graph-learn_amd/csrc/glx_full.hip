@@ -97,45 +97,27 @@ int full_sizes_device(const glx_graph* g, const int64_t* d_src, int32_t batch, i
 
 }  // namespace
 
-extern "C" int glx_graph_enable_in_degree(glx_graph* g, void* stream) {
-  GLX_REQUIRE(g != nullptr, "graph is NULL");
-  if (g->alias_indeg) return GLX_OK;
-  GlxDeviceGuard guard(g->device);
-  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
-  hipStream_t s = glx_stream(stream);
+// Installs the InDegreeSampler tables from (destination id, in-degree) pairs: uniq[U] distinct ids
+// (device), counts[U] their in-degrees -- this shard's own (glx_graph_enable_in_degree) or summed over
+// all shards (glx_dist_enable_in_degree).  Replaces tables installed earlier.
+int glx_graph_install_in_degree(glx_graph* g, const int64_t* d_uniq, const int64_t* d_counts, int64_t U,
+                                hipStream_t s) {
   const int64_t V = g->num_rows, E = g->num_edges;
+  GLX_REQUIRE(U < INT32_MAX, "more than 2^31 distinct neighbour ids");
   GlxAlias* table = nullptr;
   GLX_HIP(hipMalloc(&table, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
   GlxTemp own;  // frees the table on early returns
   own.p = table;
+  GlxIdMapStorage um;
+  int64_t* keep = nullptr;
   if (E > 0) {
-    const size_t n = (size_t)E;
-    GlxTemp keys, sorted, uniq, counts, nruns, w;
-    GLX_HIP(hipMalloc(&keys.p, n * 8));
-    GLX_HIP(hipMalloc(&sorted.p, n * 8));
-    glx_extract_nbr_kernel<<<grid_for(E), 256, 0, s>>>(g->adj, E, keys.as<int64_t>());
-#define SORT(tmp, bytes) rocprim::radix_sort_keys(tmp, bytes, keys.as<int64_t>(), sorted.as<int64_t>(), n, 0, 64, s)
-    GLX_ROCPRIM(SORT);
-#undef SORT
-    GLX_HIP(hipMalloc(&uniq.p, n * 8));
-    GLX_HIP(hipMalloc(&counts.p, n * 8));
-    GLX_HIP(hipMalloc(&nruns.p, 8));
-#define RLE(tmp, bytes)                                                                             \
-  rocprim::run_length_encode(tmp, bytes, sorted.as<int64_t>(), n, uniq.as<int64_t>(), counts.as<int64_t>(), \
-                             nruns.as<int64_t>(), s)
-    GLX_ROCPRIM(RLE);
-#undef RLE
-    int64_t U = 0;
-    GLX_HIP(hipMemcpyAsync(&U, nruns.p, 8, hipMemcpyDeviceToHost, s));
-    GLX_HIP(hipStreamSynchronize(s));
-    GLX_REQUIRE(U < INT32_MAX, "more than 2^31 distinct neighbour ids");
-    GlxIdMapStorage um;
-    int rc = glx_idmap_build(uniq.as<int64_t>(), U, &um, s);
+    GlxTemp w;
+    int rc = glx_idmap_build(d_uniq, U, &um, s);
     if (rc != GLX_OK) return rc;
-    hipError_t e = hipMalloc(&w.p, n * 4);
+    hipError_t e = hipMalloc(&w.p, (size_t)E * 4);
     if (e == hipSuccess) {
-      glx_indeg_weight_kernel<<<grid_for(E), 256, 0, s>>>(g->adj, E, GlxIdMap{um.keys, um.vals, um.cap - 1, U},
-                                                         counts.as<int64_t>(), w.as<float>());
+      glx_indeg_weight_kernel<<<grid_for(E), 256, 0, s>>>(g->adj, E, GlxIdMap{um.keys, um.vals, um.cap - 1, U}, d_counts,
+                                                         w.as<float>());
       rc = glx_alias_build_launch(g->row_ptr, w.as<float>(), V, E, table, s);
     }
     hipError_t e2 = hipStreamSynchronize(s);
@@ -144,22 +126,64 @@ extern "C" int glx_graph_enable_in_degree(glx_graph* g, void* stream) {
     GLX_HIP(e2);
     if (rc != GLX_OK) return rc;
     // keep destination id -> in-degree for glx_graph_in_degrees (GetInDegree, topo_statics.cc:62-69)
-    int64_t* keep = nullptr;
     hipError_t e3 = hipMalloc(&keep, (size_t)(U > 0 ? U : 1) * 8);
-    if (e3 == hipSuccess) e3 = hipMemcpyAsync(keep, counts.p, (size_t)U * 8, hipMemcpyDeviceToDevice, s);
+    if (e3 == hipSuccess) e3 = hipMemcpyAsync(keep, d_counts, (size_t)U * 8, hipMemcpyDeviceToDevice, s);
     if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
     if (e3 != hipSuccess) {
       if (keep) (void)hipFree(keep);
       glx_idmap_free(&um);
       GLX_HIP(e3);
     }
-    g->dst_map = um;
-    g->dst_count = keep;
-    g->num_dst = U;
   }
+  // swap in (a handle is immutable while it is shared; this runs right after creation)
+  if (g->alias_indeg) (void)hipFree(g->alias_indeg);
+  if (g->dst_count) (void)hipFree(g->dst_count);
+  glx_idmap_free(&g->dst_map);
   own.p = nullptr;
   g->alias_indeg = table;
+  g->dst_map = um;
+  g->dst_count = keep;
+  g->num_dst = E > 0 ? U : 0;
   return GLX_OK;
+}
+
+// This shard's distinct destination ids (ascending) and how often each occurs.
+int glx_graph_dst_counts(const glx_graph* g, GlxTemp* uniq, GlxTemp* counts, int64_t* U, hipStream_t s) {
+  const int64_t E = g->num_edges;
+  *U = 0;
+  const size_t n = (size_t)(E > 0 ? E : 1);
+  GlxTemp keys, sorted, nruns;
+  GLX_HIP(hipMalloc(&keys.p, n * 8));
+  GLX_HIP(hipMalloc(&sorted.p, n * 8));
+  GLX_HIP(hipMalloc(&uniq->p, n * 8));
+  GLX_HIP(hipMalloc(&counts->p, n * 8));
+  GLX_HIP(hipMalloc(&nruns.p, 8));
+  if (E == 0) return GLX_OK;
+  glx_extract_nbr_kernel<<<grid_for(E), 256, 0, s>>>(g->adj, E, keys.as<int64_t>());
+#define SORT(tmp, bytes) rocprim::radix_sort_keys(tmp, bytes, keys.as<int64_t>(), sorted.as<int64_t>(), n, 0, 64, s)
+  GLX_ROCPRIM(SORT);
+#undef SORT
+#define RLE(tmp, bytes)                                                                                    \
+  rocprim::run_length_encode(tmp, bytes, sorted.as<int64_t>(), n, uniq->as<int64_t>(), counts->as<int64_t>(), \
+                             nruns.as<int64_t>(), s)
+  GLX_ROCPRIM(RLE);
+#undef RLE
+  GLX_HIP(hipMemcpyAsync(U, nruns.p, 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
+}
+
+extern "C" int glx_graph_enable_in_degree(glx_graph* g, void* stream) {
+  GLX_REQUIRE(g != nullptr, "graph is NULL");
+  if (g->alias_indeg) return GLX_OK;
+  GlxDeviceGuard guard(g->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
+  hipStream_t s = glx_stream(stream);
+  GlxTemp uniq, counts;
+  int64_t U = 0;
+  int rc = glx_graph_dst_counts(g, &uniq, &counts, &U, s);
+  if (rc != GLX_OK) return rc;
+  return glx_graph_install_in_degree(g, uniq.as<int64_t>(), counts.as<int64_t>(), U, s);
 }
 
 namespace {

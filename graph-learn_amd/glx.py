@@ -51,6 +51,7 @@ EXPORTS = [
     "glx_comm_unique_id", "glx_comm_init_rccl", "glx_comm_init_local", "glx_comm_init_callbacks", "glx_comm_destroy",
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_hot_ids",
+    "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_lookup", "glx_dist_last_stats",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
 ]
@@ -171,6 +172,7 @@ def lib():
         L.glx_dist_store_destroy.restype = None
         L.glx_dist_store_set_cache.argtypes = [vp, vp, i64, f32, ci, vp]
         L.glx_dist_hot_ids.argtypes = [vp, i64, vp, ctypes.POINTER(i64), vp]
+        L.glx_dist_enable_in_degree.argtypes = [vp, vp, vp]
         L.glx_dist_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, ctypes.POINTER(Filter), vp, vp, ci, vp]
         L.glx_dist_aggregate.argtypes = [vp, ci, vp, vp, i32, i32, f32, vp, vp, ci, vp]
         L.glx_dist_lookup.argtypes = [vp, vp, i64, f32, vp, ci, vp]
@@ -818,6 +820,10 @@ class DistStore:
         n = ctypes.c_int64(0)
         _check(lib().glx_dist_hot_ids(self._h, int(want), _ptr(out)[0], ctypes.byref(n), _stream(PTR_DEVICE, self.comm.device)))
         return out[:n.value].copy()
+
+    def enable_in_degree(self):
+        """Collective: build the shard's InDegreeSampler tables from in-degrees summed over all shards."""
+        _check(lib().glx_dist_enable_in_degree(self._h, self.graph._h, _stream(PTR_DEVICE, self.comm.device)))
 
     def sample(self, sampler, src, k, seed=0, call_counter=0, padding_mode=PAD_CIRCULAR, default_neighbor_id=0,
                out=None, filter_type=FILTER_NONE, filter_field=FILTER_FIELD_NONE, values=None, retry_times=5,

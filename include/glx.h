@@ -478,6 +478,13 @@ GLX_API int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_ids,
  * of the store's graph (ties: smaller id first), the same list on every rank, in descending
  * order of in-degree; *n_out <= want.  ids_out is a HOST array of `want` entries. */
 GLX_API int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_out, int64_t* n_out, void* stream);
+/* Collective.  InDegreeSampler (in_degree_sampler.cc:33-114) weighs a neighbour by its in-degree in the WHOLE
+ * edge type (GraphStorage::GetInDegree, topo_statics.cc:62-69); a shard only sees the edges it owns.  This
+ * sums the per-destination counts over all shards (pairs routed to the destination's owner, reduced there,
+ * answers routed back) and builds `shard`'s per-row alias tables -- and glx_graph_in_degrees -- from the
+ * totals.  `shard` must be the graph the store was created with; MUTATES it like glx_graph_enable_in_degree.
+ * Until it has run, glx_dist_sample refuses GLX_SAMPLER_IN_DEGREE on a store with more than one shard. */
+GLX_API int glx_dist_enable_in_degree(glx_dist_store* st, glx_graph* shard, void* stream);
 /* Collective.  DistributeRunner<SamplingRequest, SamplingResponse>::Run: glx_sample_filtered's
  * arguments (filter may be NULL), request rows routed to their owners and back. */
 GLX_API int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* src, int32_t batch, int32_t k,

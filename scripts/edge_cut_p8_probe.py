@@ -5,7 +5,11 @@ rank driving its own 65,536-seed batch like bench.py --gpus P.  All ranks share 
 dedup of the cold tail, halo lookups, the 3-source reduce.  Also checks every rank's answer against the
 unpartitioned operators, bit for bit, and prints where the ids came from (replica / own shard / halo).
 
-  python scripts/edge_cut_p8_probe.py [P=8] [hot_fraction=0.10] [steps=6]
+  python scripts/edge_cut_p8_probe.py [P=8] [hot_fraction=0.10] [steps=6] [solo]
+
+solo: only rank 0 asks; the other ranks take part in every collective with empty requests and serve rank 0's.
+The wall time per step is then rank 0's own work plus the service work all owners do for it -- in the symmetric
+real case exactly one GPU's share -- with no kernels of other ranks' requests running beside it.
 """
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +19,7 @@ import numpy as np, torch, glx, synth
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 hot_fraction = float(sys.argv[2]) if len(sys.argv) > 2 else 0.10
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+solo = len(sys.argv) > 4 and sys.argv[4] == "solo"
 dev = torch.device("cuda", 0)
 V, E, D, B0, k1, k2 = 10_000_000, 100_000_000, 256, 65536, 25, 10
 src, dst, w = synth.rmat_edges_torch(V, E, 4, dev)
@@ -47,18 +52,20 @@ def rank_main(r):
             st_a.set_cache(hot)
             gen = torch.Generator(device=dev)
             gen.manual_seed(1000 + r)
-            seeds = pool[torch.randint(0, pool.shape[0], (steps + 2, B0), generator=gen, device=dev)]
-            nb1 = torch.empty((B0, k1), dtype=torch.int64, device=dev); ed1 = torch.empty_like(nb1)
-            nb2 = torch.empty((n1, k2), dtype=torch.int64, device=dev); ed2 = torch.empty_like(nb2)
-            emb2 = torch.empty((n1, D), dtype=torch.float32, device=dev); cnt2 = torch.empty(n1, dtype=torch.int32, device=dev)
-            emb1 = torch.empty((B0, D), dtype=torch.float32, device=dev); cnt1 = torch.empty(B0, dtype=torch.int32, device=dev)
+            b0 = B0 if (r == 0 or not solo) else 0
+            m1, m2 = b0 * k1, b0 * k1 * k2
+            seeds = pool[torch.randint(0, pool.shape[0], (steps + 2, b0), generator=gen, device=dev)]
+            nb1 = torch.empty((b0, k1), dtype=torch.int64, device=dev); ed1 = torch.empty_like(nb1)
+            nb2 = torch.empty((m1, k2), dtype=torch.int64, device=dev); ed2 = torch.empty_like(nb2)
+            emb2 = torch.empty((m1, D), dtype=torch.float32, device=dev); cnt2 = torch.empty(m1, dtype=torch.int32, device=dev)
+            emb1 = torch.empty((b0, D), dtype=torch.float32, device=dev); cnt1 = torch.empty(b0, dtype=torch.int32, device=dev)
 
             def step(i):
                 st_s.sample("EdgeWeightSampler", seeds[i], k1, seed=42, call_counter=4 * i, out=(nb1, ed1))
                 st_s.sample("EdgeWeightSampler", nb1.view(-1), k2, seed=42, call_counter=4 * i + 1, out=(nb2, ed2))
-                st_a.aggregate("MaxAggregator", nb2.view(-1), None, n1, out=(emb2, cnt2))
+                st_a.aggregate("MaxAggregator", nb2.view(-1), None, m1, out=(emb2, cnt2))
                 s2 = st_a.stats()
-                st_a.aggregate("MaxAggregator", nb1.view(-1), None, B0, out=(emb1, cnt1))
+                st_a.aggregate("MaxAggregator", nb1.view(-1), None, b0, out=(emb1, cnt1))
                 return s2
             for i in range(2):
                 step(i)
@@ -75,7 +82,7 @@ def rank_main(r):
             i = steps + 1
             wa, wae = whole.sample("EdgeWeightSampler", seeds[i], k1, seed=42, call_counter=4 * i)
             wb, wbe = whole.sample("EdgeWeightSampler", wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
-            we2, wc2 = feats.aggregate("MaxAggregator", wb.view(-1), None, n1)
+            we2, wc2 = feats.aggregate("MaxAggregator", wb.view(-1), None, m1)
             torch.cuda.current_stream().synchronize()
             ok[r] = bool(torch.equal(nb1, wa) and torch.equal(ed1, wae) and torch.equal(nb2, wb) and torch.equal(ed2, wbe)
                          and torch.equal(cnt2, wc2) and torch.equal(emb2.view(torch.int32), we2.view(torch.int32)))
@@ -94,9 +101,14 @@ def rank_main(r):
 ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
 for t in ts: t.start()
 for t in ts: t.join(600)
-print("P = %d ranks on one GPU, hot fraction %.2f: %.2f ms per step with all ranks running (%.2f ms of device work per rank-step); "
-      "all answers equal the unpartitioned operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3,
-                                                              max(x or 0 for x in times) * 1e3 / P, all(ok)))
+if solo:
+    print("P = %d ranks on one GPU, hot fraction %.2f, ONLY rank 0 asks: %.2f ms per step = one rank's own work + the service "
+          "work of all owners for it (= one GPU's share in the symmetric case), no link time; answers equal the unpartitioned "
+          "operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3, all(ok)))
+else:
+    print("P = %d ranks on one GPU, hot fraction %.2f: %.2f ms per step with all ranks running (%.2f ms of device work per rank-step); "
+          "all answers equal the unpartitioned operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3,
+                                                                  max(x or 0 for x in times) * 1e3 / P, all(ok)))
 for r in (0, P - 1):
     print("rank %d hop-2 request:" % r, stats[r])
 sys.exit(0 if all(ok) else 1)

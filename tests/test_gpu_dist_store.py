@@ -354,7 +354,7 @@ def test_rccl_world_size_one(world):
     assert s["remote"] == 0 and s["from_replica"] > 0
 
 
-def test_in_degree_sampler_is_refused_on_a_partitioned_store(world):
+def test_in_degree_sampler_is_refused_until_global_in_degrees_are_built(world):
     gs, _ = world["shards"][2]
     dev = world["dev"]
 
@@ -363,6 +363,37 @@ def test_in_degree_sampler_is_refused_on_a_partitioned_store(world):
         with pytest.raises(glx.GlxError, match="InDegreeSampler"):
             st.sample("InDegreeSampler", _requests(r, dev, 10), 3)
     _run_ranks(2, body)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_in_degree_sampler_with_global_in_degrees(world, P):
+    """glx_dist_enable_in_degree: a shard's InDegreeSampler tables are built from in-degrees summed over ALL
+    shards, so a partitioned request draws exactly what the single store draws (in_degree_sampler.cc:33-114),
+    and glx_graph_in_degrees on a shard answers with the global counts."""
+    import dist as gdist
+    whole, dev = world["whole"], world["dev"]
+    whole.enable_in_degree()
+    # private shard handles: enabling mutates them
+    rp, col, eid, w = synth.small_graph(V, 80000, seed=21, weighted=True, hub_degree=3000)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    gs = []
+    for r in range(P):
+        srp, scol, seid, sw, sids = gdist.shard_graph(t(rp), t(col), t(eid), t(w), r, P)
+        gs.append(glx.Graph(srp, scol, seid, sw, ids=sids))
+    probe = torch.arange(0, V, 7, dtype=torch.int64, device=dev)
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        st.enable_in_degree()
+        assert torch.equal(gs[r].in_degrees(probe), whole.in_degrees(probe)), r
+        src = _requests(r, dev, 1500)
+        for k, pad in ((6, 1), (30, 1), (4, 0)):
+            n1, e1 = st.sample("InDegreeSampler", src, k, seed=13 + r, call_counter=k, padding_mode=pad,
+                               default_neighbor_id=-6)
+            rn, re = whole.sample("InDegreeSampler", src, k, seed=13 + r, call_counter=k, padding_mode=pad,
+                                  default_neighbor_id=-6)
+            assert torch.equal(n1, rn) and torch.equal(e1, re), (k, pad, r)
+    _run_ranks(P, body)
 
 
 def test_uniform_segments_single_gpu(world):
