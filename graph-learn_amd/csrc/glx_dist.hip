@@ -111,8 +111,36 @@ __global__ __launch_bounds__(256) void glx_dist_stitch2_kernel(const int64_t* __
 //   [2P]       overflow flag (set table too small)  [2P+1..3] ids served by replica / own shard /
 //   [2P+4 ..]  exclusive offsets per owner (P + 1)            remote (with repeats)
 //   [3P+5]     distinct halo ids inserted so far (all owners)
+// The replica's id map with key and row in ONE 16-byte slot: a probe is a single load (the generic GlxIdMap
+// keeps keys and rows in two arrays = two dependent random loads per hit, and every id of a request probes it).
+struct PackedSlot {
+  int64_t key;
+  int32_t row;
+  int32_t pad_;
+};
+struct PackedMap {
+  const PackedSlot* slots;
+  uint64_t mask;
+};
+__device__ __forceinline__ int32_t packed_row_of(const PackedMap& m, int64_t id) {
+  if (id == GLX_EMPTY_KEY) return -1;
+  uint64_t h = glx_mix64((uint64_t)id) & m.mask;
+  while (true) {
+    const PackedSlot sl = m.slots[h];
+    if (sl.key == id) return sl.row;
+    if (sl.key == GLX_EMPTY_KEY) return -1;
+    h = (h + 1) & m.mask;
+  }
+}
+__global__ void glx_dist_pack_map_kernel(const int64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                         uint64_t cap, PackedSlot* __restrict__ out) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) out[i] = PackedSlot{keys[i], vals[i], 0};
+}
+
 struct ResolveArgs {
-  GlxIdMap cache_map;
+  PackedMap cache_map;
   GlxIdMap own_map;
   const int64_t* ids;
   int64_t n;
@@ -136,6 +164,9 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   __shared__ int32_t s_stat[3];
   __shared__ int32_t s_cnt[kMaxWorld];
   __shared__ int32_t s_sum;
+  __shared__ int32_t s_void;  // the overflow flag as of the last flush (reading the global flag per id made one
+                              // L2 address the hot spot of the kernel)
+  if (threadIdx.x == 0) s_void = 0;
   if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
   if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -149,7 +180,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
     if (i < a.n) {
       const int64_t id = a.ids[i];
       int32_t out = -1;
-      int64_t r = a.has_cache ? glx_row_of(a.cache_map, id) : -1;
+      int64_t r = a.has_cache ? packed_row_of(a.cache_map, id) : -1;
       if (r >= 0) {
         out = a.cache_base + (int32_t)r;
         ++n_hit;
@@ -159,7 +190,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
           r = glx_row_of(a.own_map, id);
           out = r >= 0 ? (int32_t)r : -1;
           ++n_own;
-        } else if (__atomic_load_n(&a.ctr[2 * a.P], __ATOMIC_RELAXED) != 0) {
+        } else if (s_void != 0) {
           ++n_cold;  // the set already overflowed: this pass is void, the host retries with a larger one
         } else {
           ++n_cold;
@@ -210,9 +241,12 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
         atomicAdd(&a.ctr[threadIdx.x], s_cnt[threadIdx.x]);
         s_cnt[threadIdx.x] = 0;
       }
-      if (threadIdx.x == 0 && s_sum) {
-        const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], s_sum);
-        if (before + s_sum > a.insert_limit) a.ctr[2 * a.P] = 1;
+      if (threadIdx.x == 0) {
+        if (s_sum) {
+          const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], s_sum);
+          if (before + s_sum > a.insert_limit) a.ctr[2 * a.P] = 1;
+        }
+        s_void = __atomic_load_n(&a.ctr[2 * a.P], __ATOMIC_RELAXED);
       }
       __syncthreads();
     }
@@ -403,6 +437,7 @@ struct glx_dist_store {
   const glx_graph* graph = nullptr;
   const glx_features* feats = nullptr;
   glx_features* cache = nullptr;
+  PackedSlot* cache_slots = nullptr;  // the replica's id map, packed (glx_dist_pack_map_kernel)
   int device = 0, rank = 0, world = 1;
   bool shortcut = true;  // world == 1: call the local operator directly
   Arena req, recv, tab, halo;
@@ -490,7 +525,7 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
       glx_dist_fill_keys_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap);
       GLX_HIP(hipMemsetAsync(st->d_ctr, 0, (size_t)(3 * P + 8) * 4, s));
       ResolveArgs a;
-      a.cache_map = st->cache ? st->cache->map() : GlxIdMap{nullptr, nullptr, 0, 0};
+      a.cache_map = PackedMap{st->cache_slots, st->cache ? st->cache->idmap.cap - 1 : 0};
       a.own_map = f->map();
       a.ids = d_ids;
       a.n = n;
@@ -759,6 +794,7 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
   if (st->d_vals) (void)hipFree(st->d_vals);
   if (st->d_ctr) (void)hipFree(st->d_ctr);
   if (st->cache) glx_features_destroy(st->cache);
+  if (st->cache_slots) (void)hipFree(st->cache_slots);
   delete st;
 }
 
@@ -960,6 +996,10 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
     glx_features_destroy(st->cache);
     st->cache = nullptr;
   }
+  if (st->cache_slots) {
+    GLX_HIP(hipFree(st->cache_slots));
+    st->cache_slots = nullptr;
+  }
   if (n == 0) return GLX_OK;
   const glx_features* f = st->feats;
   const int P = st->world, me = st->rank;
@@ -1003,7 +1043,14 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
   GLX_HIP(hipStreamSynchronize(s));
   rc = glx_features_create(st->device, n, dim, table.as<float>(), bucketed.as<int64_t>(), GLX_PTR_DEVICE, s,
                            &st->cache);
-  return rc;
+  if (rc != GLX_OK) return rc;
+  const uint64_t cap = st->cache->idmap.cap;
+  GLX_HIP(hipMalloc(reinterpret_cast<void**>(&st->cache_slots), (size_t)cap * sizeof(PackedSlot)));
+  glx_dist_pack_map_kernel<<<grid_for((int64_t)cap), 256, 0, s>>>(st->cache->idmap.keys, st->cache->idmap.vals, cap,
+                                                                 st->cache_slots);
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
 }
 
 namespace {

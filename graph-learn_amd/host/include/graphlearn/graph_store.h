@@ -20,6 +20,7 @@
 struct glx_graph;
 struct glx_features;
 struct glx_negative;
+struct glx_dist_store;
 
 namespace graphlearn {
 namespace io {
@@ -132,6 +133,8 @@ public:
   Status Negative(bool by_in_degree, bool strict, const glx_negative** out);
   // In-degree alias tables for InDegreeSampler, built on first use.
   Status EnsureInDegree();
+  // The same for a shard of a partitioned edge type: in-degrees summed over all shards (collective).
+  Status EnsureGlobalInDegree(glx_dist_store* store);
   // Per-row id-sorted index for id == value filters (and strict negative sampling), built on first use.
   Status EnsureIdIndex();
 
@@ -163,6 +166,7 @@ private:
   glx_negative* neg_in_degree_;
   bool neg_strict_ready_;
   bool in_degree_ready_;
+  bool global_in_degree_ready_;
   std::mutex mtx_;
 };
 

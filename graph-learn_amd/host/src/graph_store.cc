@@ -21,7 +21,7 @@ void UpdateNodesRequest::Append(const io::NodeValue* value) { values_.push_back(
 // ------------------------------------------------------------------ Graph --
 Graph::Graph(const std::string& type)
     : type_(type), dev_(nullptr), neg_uniform_(nullptr), neg_in_degree_(nullptr), neg_strict_ready_(false),
-      in_degree_ready_(false) {}
+      in_degree_ready_(false), global_in_degree_ready_(false) {}
 
 Graph::~Graph() {
   glx_negative_destroy(neg_uniform_);
@@ -154,6 +154,19 @@ Status Graph::EnsureInDegree() {
   if (!dev_) return error::InvalidArgument("edge type '" + type_ + "' is not built on the device");
   int rc = glx_graph_enable_in_degree(dev_, nullptr);
   if (rc != GLX_OK) return error::FromGlx(rc);
+  in_degree_ready_ = true;
+  return Status::OK();
+}
+
+Status Graph::EnsureGlobalInDegree(glx_dist_store* store) {
+  // A shard of a partitioned edge type: InDegreeSampler's weights are in-degrees over ALL shards
+  // (glx_dist_enable_in_degree: collective, every server gets here in the same Run()).
+  std::lock_guard<std::mutex> g(mtx_);
+  if (global_in_degree_ready_) return Status::OK();
+  if (!dev_) return error::InvalidArgument("edge type '" + type_ + "' is not built on the device");
+  int rc = glx_dist_enable_in_degree(store, dev_, nullptr);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  global_in_degree_ready_ = true;
   in_degree_ready_ = true;
   return Status::OK();
 }

@@ -112,6 +112,10 @@ Status RunSampling(Env* env, const SamplingRequest* req, SamplingResponse* res) 
   glx_dist_store* st = nullptr;
   Status s = env->EdgeStore(req->Type(), &st);
   if (!s.ok()) return s;
+  if (sampler == GLX_SAMPLER_IN_DEGREE && env->ServerCount() > 1) {
+    s = env->Store()->GetGraph(req->Type())->EnsureGlobalInDegree(st);
+    if (!s.ok()) return s;
+  }
   res->ResizeDense();
   glx_filter filter;
   filter.type = req->HasFilter() && req->GetFilterValues() ? (int32_t)req->GetFilterType() : GLX_FILTER_NONE;

@@ -249,7 +249,10 @@ TEST(PartitionStitchTest, AggregatorsOnTwoDeviceStoresEqualOneStore) {
 // single store holding everything answers.
 TEST(PartitionStitchTest, DistributeRunnerOnTwoServersEqualsOneStore) {
   Cluster* c = BuildCluster();
-  const char* samplers[4] = {"RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"};
+  // InDegreeSampler: the servers' tables come from in-degrees summed over both shards (glx_dist_enable_in_degree)
+  const int kSamplers = 5;
+  const char* samplers[kSamplers] = {"RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler",
+                                     "InDegreeSampler"};
   const char* aggs[5] = {"SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"};
   // per-server requests, and the single-store answers
   std::vector<int64_t> ids[2], agg_ids[2];
@@ -270,7 +273,7 @@ TEST(PartitionStitchTest, DistributeRunnerOnTwoServersEqualsOneStore) {
   std::vector<std::vector<float>> want_emb[2];
   std::vector<std::vector<int32_t>> want_cnt[2];
   for (int r = 0; r < 2; ++r) {
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < kSamplers; ++n) {
       SamplingRequest req("e", samplers[n], 5);
       req.Set(ids[r].data(), (int32_t)ids[r].size());
       req.SetCallCounter(500 + 10 * r + n);
@@ -307,7 +310,7 @@ TEST(PartitionStitchTest, DistributeRunnerOnTwoServersEqualsOneStore) {
           why[r] = "hot nodes: " + s.ToString();
         }
       }
-      for (int n = 0; n < 4 && ok[r]; ++n) {
+      for (int n = 0; n < kSamplers && ok[r]; ++n) {
         Operator* op = OpFactory::GetInstance()->Create(samplers[n]);
         std::unique_ptr<OpRunner> runner = GetOpRunner(&env, op);
         SamplingRequest req("e", samplers[n], 5);

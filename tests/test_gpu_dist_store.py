@@ -369,23 +369,27 @@ def test_in_degree_sampler_is_refused_until_global_in_degrees_are_built(world):
 def test_in_degree_sampler_with_global_in_degrees(world, P):
     """glx_dist_enable_in_degree: a shard's InDegreeSampler tables are built from in-degrees summed over ALL
     shards, so a partitioned request draws exactly what the single store draws (in_degree_sampler.cc:33-114),
-    and glx_graph_in_degrees on a shard answers with the global counts."""
+    and glx_graph_in_degrees on a shard answers with the global counts of the destinations it holds."""
     import dist as gdist
     whole, dev = world["whole"], world["dev"]
     whole.enable_in_degree()
     # private shard handles: enabling mutates them
     rp, col, eid, w = synth.small_graph(V, 80000, seed=21, weighted=True, hub_degree=3000)
     t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
-    gs = []
+    gs, cols = [], []
     for r in range(P):
         srp, scol, seid, sw, sids = gdist.shard_graph(t(rp), t(col), t(eid), t(w), r, P)
         gs.append(glx.Graph(srp, scol, seid, sw, ids=sids))
+        cols.append(scol)
     probe = torch.arange(0, V, 7, dtype=torch.int64, device=dev)
 
     def body(r, comm):
         st = glx.DistStore(comm, graph=gs[r])
         st.enable_in_degree()
-        assert torch.equal(gs[r].in_degrees(probe), whole.in_degrees(probe)), r
+        # a shard knows the destinations its own edges point to -- with their GLOBAL in-degree
+        mine = torch.isin(probe, cols[r])
+        got, want = gs[r].in_degrees(probe), whole.in_degrees(probe)
+        assert torch.equal(got[mine], want[mine]) and bool((got[~mine] == 0).all()), r
         src = _requests(r, dev, 1500)
         for k, pad in ((6, 1), (30, 1), (4, 0)):
             n1, e1 = st.sample("InDegreeSampler", src, k, seed=13 + r, call_counter=k, padding_mode=pad,
