@@ -544,19 +544,27 @@ def main():
         else:
             st_smp.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
             st_smp.sample(sampler, nb1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nb2, ed2))
+            if prefetch_halo[0]:
+                # the collective half of the two aggregations, on the SAMPLING stream: ids are resolved and the
+                # halo rows fetched while the previous step's reduce still runs on the other stream
+                st_agg.aggregate_begin(2 * (i % 2), nb2.view(-1))
+                st_agg.aggregate_begin(2 * (i % 2) + 1, nb1.view(-1))
         return nb1, nb2
 
     # A dense sampler response implies its segments (segment i = the neighbours of request row i):
     # segment_ids = None skips the segment bookkeeping kernels and the read of a segment tensor.
+    prefetch_halo = [False]  # set for the sharded leg: do_sample also begins the step's two aggregations
+
     def agg_local(table):
-        def run(a, b):
+        def run(a, b, i):
             table.aggregate(agg, b.view(-1), None, n1, out=(emb2, cnt2))
             table.aggregate(agg, a.view(-1), None, B0, out=(emb1, cnt1))
         return run
 
-    def agg_halo(a, b):
-        st_agg.aggregate(agg, b.view(-1), None, n1, out=(emb2, cnt2))
-        st_agg.aggregate(agg, a.view(-1), None, B0, out=(emb1, cnt1))
+    def agg_halo(a, b, i):
+        # the local half: the segmented reduce over own shard + hot-row replica + the halo rows begun above
+        st_agg.aggregate_end(2 * (i % 2), agg, None, n1, out=(emb2, cnt2))
+        st_agg.aggregate_end(2 * (i % 2) + 1, agg, None, B0, out=(emb1, cnt1))
 
     if pipelined:
         s_smp, s_agg = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
@@ -577,7 +585,7 @@ def main():
         def step(i):
             if not pipelined:
                 a, b = do_sample(i)
-                do_aggregate(a, b)
+                do_aggregate(a, b, i)
                 return
             with torch.cuda.stream(s_smp):
                 if len(agg_done) >= 2:
@@ -587,7 +595,7 @@ def main():
                 sampled.record(s_smp)
             with torch.cuda.stream(s_agg):
                 s_agg.wait_event(sampled)
-                do_aggregate(a, b)
+                do_aggregate(a, b, i)
                 done = torch.cuda.Event()
                 done.record(s_agg)
                 agg_done.append(done)
@@ -644,7 +652,9 @@ def main():
         headline = "single GPU"
     else:
         # north_star's placement: everything edge-cut, halo-vertex feature exchange per request
+        prefetch_halo[0] = True
         el_h, ta_h, ts_h = timed_leg(agg_halo, args.warmup, n_steps, args.warmup)
+        prefetch_halo[0] = False
         legs["features_sharded"] = {"ms_per_step": el_h / args.steps * 1e3,
                                     "value": world * edges_per_step * args.steps / el_h}
         torch.cuda.synchronize()
@@ -680,8 +690,10 @@ def main():
     verified = None
     if args.verify and sharded:
         i = n_steps - 1
+        prefetch_halo[0] = True
         a, b = do_sample(i)
-        agg_halo(a, b)
+        agg_halo(a, b, i)
+        prefetch_halo[0] = False
         wa, wae = whole[0].sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
         wb, wbe = whole[0].sample(sampler, wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
         we2, wc2 = whole[1].aggregate(agg, wb.view(-1), None, n1)

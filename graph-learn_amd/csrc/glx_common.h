@@ -172,6 +172,7 @@ struct glx_graph {
   GlxAlias* alias_indeg;  // [E] alias tables over the neighbours' in-degrees, or nullptr
   int64_t* nbr_sorted;    // [E] every row's neighbour ids ascending (strict negative sampling, id filters), or nullptr
   uint32_t* slot_sorted;  // [E] the CSR slot each entry of nbr_sorted came from (built together with it)
+  bool indeg_global;      // alias_indeg / dst_count hold in-degrees summed over all shards (glx_dist_enable_in_degree)
   GlxIdMapStorage dst_map;  // destination id -> index into dst_count (with alias_indeg), for in-degree lookups
   int64_t* dst_count;     // [num_dst] in-degree of every distinct destination id
   int64_t num_dst;

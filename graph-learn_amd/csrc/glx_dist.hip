@@ -440,11 +440,21 @@ struct glx_dist_store {
   PackedSlot* cache_slots = nullptr;  // the replica's id map, packed (glx_dist_pack_map_kernel)
   int device = 0, rank = 0, world = 1;
   bool shortcut = true;  // world == 1: call the local operator directly
-  Arena req, recv, tab, halo;
+  Arena req, recv;  // sampling: request-sized and receive-sized buffers
+  // aggregation / lookup: one buffer set per request in flight (glx_dist_aggregate_begin .. _end)
+  struct Slot {
+    Arena req, recv, tab, halo;
+    const int32_t* loc = nullptr;
+    GlxRowSource src[3];
+    int32_t num_ids = -1;  // -1: nothing begun
+    float default_attr = 0.0f;
+    glx_dist_stats stats;
+  };
+  Slot slots[GLX_DIST_SLOTS];
+  int last_slot = 0;
   int64_t* d_vals = nullptr;  // [world + 8] values shared by the count exchange
   int32_t* d_ctr = nullptr;   // [3 * world + 8] counter block of the resolve passes
   double halo_share = 0.0;  // largest (distinct halo ids / request ids) seen so far
-  bool global_in_degree = false;  // glx_dist_enable_in_degree built the shard's tables from global counts
   glx_dist_stats stats;
   std::vector<int64_t> h_mat;
 };
@@ -481,15 +491,17 @@ struct Resolved {
 
 // Shared front half of glx_dist_aggregate / glx_dist_lookup: resolve ids, dedup the cold
 // remote ones, fetch their rows from the owners.  d_ids is a device pointer.
-int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float default_attr, hipStream_t s,
+int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_t n, float default_attr, hipStream_t s,
                       Resolved* out) {
+  glx_dist_store::Slot& sl = st->slots[slot];
+  st->last_slot = slot;
   const glx_features* f = st->feats;
   const int P = st->world, me = st->rank;
   const int32_t dim = f->dim;
   const int64_t n_own = f->num_rows, n_cache = st->cache ? st->cache->num_rows : 0;
   GLX_REQUIRE(n_own + n_cache + n < (int64_t)INT32_MAX, "virtual row space exceeds int32");
   GLX_REQUIRE(n < ((int64_t)1 << 29), "a partitioned request is limited to 2^29 ids");
-  glx_dist_stats& stat = st->stats;
+  glx_dist_stats& stat = sl.stats;
   memset(&stat, 0, sizeof(stat));
   stat.ids = n;
 
@@ -498,10 +510,10 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
   Carver cv;
   const size_t o_loc = cv.take((size_t)(n > 0 ? n : 1) * 4);
   const size_t o_cold = cv.take((size_t)(n > 0 ? n : 1) * 8);
-  int rc = st->req.ensure(cv.at);
+  int rc = sl.req.ensure(cv.at);
   if (rc != GLX_OK) return rc;
-  int32_t* loc = reinterpret_cast<int32_t*>(st->req.p + o_loc);
-  int64_t* cold_ids = reinterpret_cast<int64_t*>(st->req.p + o_cold);
+  int32_t* loc = reinterpret_cast<int32_t*>(sl.req.p + o_loc);
+  int64_t* cold_ids = reinterpret_cast<int64_t*>(sl.req.p + o_cold);
 
   // Set of distinct halo ids.  Sized for the request at hand: a quarter of its ids, or 2.5x the largest share
   // of distinct halo ids this store has seen (a hop-2 and a hop-1 request alternate: sizing from the PREVIOUS
@@ -518,10 +530,10 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
   while (true) {
     if (first || mine_overflow) {
       if (mine_overflow) tcap = safe_cap;
-      rc = st->tab.ensure((size_t)tcap * 12 + 256);
+      rc = sl.tab.ensure((size_t)tcap * 12 + 256);
       if (rc != GLX_OK) return rc;
-      tkeys = reinterpret_cast<int64_t*>(st->tab.p);
-      tvals = reinterpret_cast<int32_t*>(st->tab.p + (((size_t)tcap * 8 + 255) & ~(size_t)255));
+      tkeys = reinterpret_cast<int64_t*>(sl.tab.p);
+      tvals = reinterpret_cast<int32_t*>(sl.tab.p + (((size_t)tcap * 8 + 255) & ~(size_t)255));
       glx_dist_fill_keys_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap);
       GLX_HIP(hipMemsetAsync(st->d_ctr, 0, (size_t)(3 * P + 8) * 4, s));
       ResolveArgs a;
@@ -579,12 +591,12 @@ int resolve_and_fetch(glx_dist_store* st, const int64_t* d_ids, int64_t n, float
     Carver cr;
     const size_t o_ids = cr.take((size_t)(m > 0 ? m : 1) * 8);
     const size_t o_rows = cr.take((size_t)(m > 0 ? m : 1) * dim * 4);
-    rc = st->recv.ensure(cr.at);
-    if (rc == GLX_OK) rc = st->halo.ensure((size_t)(U > 0 ? U : 1) * dim * 4);
+    rc = sl.recv.ensure(cr.at);
+    if (rc == GLX_OK) rc = sl.halo.ensure((size_t)(U > 0 ? U : 1) * dim * 4);
     if (rc != GLX_OK) return rc;
-    int64_t* ids_in = reinterpret_cast<int64_t*>(st->recv.p + o_ids);
-    float* rows_loc = reinterpret_cast<float*>(st->recv.p + o_rows);
-    halo = reinterpret_cast<float*>(st->halo.p);
+    int64_t* ids_in = reinterpret_cast<int64_t*>(sl.recv.p + o_ids);
+    float* rows_loc = reinterpret_cast<float*>(sl.recv.p + o_rows);
+    halo = reinterpret_cast<float*>(sl.halo.p);
     GlxSeg seg_ids{cold_ids, ids_in, 8};
     rc = st->comm->alltoallv(&seg_ids, 1, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
                              rt.recv_offs.data(), s);
@@ -772,7 +784,7 @@ extern "C" int glx_dist_store_create(glx_comm* comm, const glx_graph* graph, con
   st->rank = comm->rank;
   st->world = comm->world;
   if (const char* e = getenv("GLX_DIST_NO_SHORTCUT")) st->shortcut = atoi(e) == 0;
-  memset(&st->stats, 0, sizeof(st->stats));
+  for (auto& sl : st->slots) memset(&sl.stats, 0, sizeof(sl.stats));
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&st->d_vals), (size_t)(st->world + 16) * 8);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->d_ctr), (size_t)(3 * st->world + 8) * 4);
   if (e != hipSuccess) {
@@ -789,8 +801,12 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
   (void)hipDeviceSynchronize();
   st->req.release();
   st->recv.release();
-  st->tab.release();
-  st->halo.release();
+  for (auto& sl : st->slots) {
+    sl.req.release();
+    sl.recv.release();
+    sl.tab.release();
+    sl.halo.release();
+  }
   if (st->d_vals) (void)hipFree(st->d_vals);
   if (st->d_ctr) (void)hipFree(st->d_ctr);
   if (st->cache) glx_features_destroy(st->cache);
@@ -800,7 +816,7 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
 
 extern "C" int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out) {
   GLX_REQUIRE(st != nullptr && out != nullptr, "NULL argument");
-  *out = st->stats;
+  *out = st->slots[st->last_slot].stats;
   return GLX_OK;
 }
 
@@ -820,7 +836,7 @@ extern "C" int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* s
   GLX_REQUIRE(!filtered || batch == 0 || filter->values != nullptr, "filter without values");
   // InDegreeSampler weighs a neighbour by its in-degree over ALL shards; a shard's tables
   // (glx_graph_enable_in_degree) only count the edges it owns.
-  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || st->world == 1 || st->global_in_degree,
+  GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || st->world == 1 || st->graph->indeg_global,
               "InDegreeSampler on a partitioned store needs glx_dist_enable_in_degree(): a shard's own in-degree "
               "tables cover its own edges only");
   GlxDeviceGuard guard(st->device);
@@ -905,7 +921,8 @@ extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* nod
     d_seg = segment_ids ? seg_w : nullptr;
   }
   Resolved rs;
-  rc = resolve_and_fetch(st, d_ids, num_ids, default_attr, s, &rs);
+  rc = resolve_and_fetch(st, 0, d_ids, num_ids, default_attr, s, &rs);
+  st->slots[0].num_ids = -1;  // a whole call: nothing left pending in the slot
   if (rc == GLX_OK && num_segments > 0) {
     rc = glx_aggregate_vrows_device(rs.src, 3, f->dim, op, rs.loc, d_seg, num_ids, num_segments, default_attr, d_emb,
                                     d_cnt, s);
@@ -922,6 +939,49 @@ extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* nod
     GLX_HIP(e2);
   }
   return rc;
+}
+
+// The two halves of glx_dist_aggregate for software pipelining (device pointers only).
+extern "C" int glx_dist_aggregate_begin(glx_dist_store* st, int32_t slot, const int64_t* node_ids, int32_t num_ids,
+                                        float default_attr, void* stream) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  GLX_REQUIRE(st->feats != nullptr, "this store has no feature shard");
+  GLX_REQUIRE(slot >= 0 && slot < GLX_DIST_SLOTS, "slot %d outside [0, %d)", slot, GLX_DIST_SLOTS);
+  GLX_REQUIRE(num_ids >= 0 && (num_ids == 0 || node_ids), "bad request");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  glx_dist_store::Slot& sl = st->slots[slot];
+  Resolved rs;
+  int rc = resolve_and_fetch(st, slot, node_ids, num_ids, default_attr, glx_stream(stream), &rs);
+  if (rc != GLX_OK) {
+    sl.num_ids = -1;
+    return rc;
+  }
+  sl.loc = rs.loc;
+  for (int j = 0; j < 3; ++j) sl.src[j] = rs.src[j];
+  sl.num_ids = num_ids;
+  sl.default_attr = default_attr;
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_aggregate_end(glx_dist_store* st, int32_t slot, int op, const int32_t* segment_ids,
+                                      int32_t num_segments, float* emb_out, int32_t* cnt_out, void* stream) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  GLX_REQUIRE(slot >= 0 && slot < GLX_DIST_SLOTS, "slot %d outside [0, %d)", slot, GLX_DIST_SLOTS);
+  GLX_REQUIRE(op >= GLX_AGG_SUM && op <= GLX_AGG_PROD, "unknown aggregator id %d", op);
+  glx_dist_store::Slot& sl = st->slots[slot];
+  GLX_REQUIRE(sl.num_ids >= 0, "slot %d holds no begun request", slot);
+  GLX_REQUIRE(num_segments >= 0 && (int64_t)num_segments * st->feats->dim <= INT32_MAX, "bad num_segments");
+  GLX_REQUIRE(num_segments == 0 || (emb_out && cnt_out), "NULL output pointer");
+  GLX_REQUIRE(segment_ids != nullptr || num_segments == 0 || sl.num_ids % num_segments == 0,
+              "segment_ids == NULL means equal segments: num_ids must be a multiple of num_segments");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  const int32_t n = sl.num_ids;
+  sl.num_ids = -1;
+  if (num_segments == 0) return GLX_OK;
+  return glx_aggregate_vrows_device(sl.src, 3, st->feats->dim, op, sl.loc, segment_ids, n, num_segments, sl.default_attr,
+                                    emb_out, cnt_out, glx_stream(stream));
 }
 
 extern "C" int glx_dist_lookup(glx_dist_store* st, const int64_t* node_ids, int64_t n, float default_attr,
@@ -947,7 +1007,8 @@ extern "C" int glx_dist_lookup(glx_dist_store* st, const int64_t* node_ids, int6
     d_ids = ids_w;
   }
   Resolved rs;
-  rc = resolve_and_fetch(st, d_ids, n, default_attr, s, &rs);
+  rc = resolve_and_fetch(st, 0, d_ids, n, default_attr, s, &rs);
+  st->slots[0].num_ids = -1;
   if (rc == GLX_OK && n > 0) {
     GatherArgs g;
     for (int j = 0; j < 3; ++j) g.src[j] = rs.src[j];
@@ -1242,6 +1303,6 @@ extern "C" int glx_dist_enable_in_degree(glx_dist_store* st, glx_graph* shard, v
   GLX_HIP(hipGetLastError());
   rc = glx_graph_install_in_degree(shard, t.uniq.as<int64_t>(), total.as<int64_t>(), Ul, s);
   if (rc != GLX_OK) return rc;
-  st->global_in_degree = true;
+  shard->indeg_global = true;
   return GLX_OK;
 }

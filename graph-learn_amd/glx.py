@@ -52,7 +52,8 @@ EXPORTS = [
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
-    "glx_dist_sample", "glx_dist_aggregate", "glx_dist_lookup", "glx_dist_last_stats",
+    "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
+    "glx_dist_last_stats",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
 ]
 
@@ -176,6 +177,8 @@ def lib():
         L.glx_dist_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, ctypes.POINTER(Filter), vp, vp, ci, vp]
         L.glx_dist_aggregate.argtypes = [vp, ci, vp, vp, i32, i32, f32, vp, vp, ci, vp]
         L.glx_dist_lookup.argtypes = [vp, vp, i64, f32, vp, ci, vp]
+        L.glx_dist_aggregate_begin.argtypes = [vp, i32, vp, i32, f32, vp]
+        L.glx_dist_aggregate_end.argtypes = [vp, i32, ci, vp, i32, vp, vp, vp]
         L.glx_dist_last_stats.argtypes = [vp, ctypes.POINTER(DistStats)]
         L.glx_plan_create.argtypes = [vp, i32, ci, vp, i32, ci, i64, u64, vp, ci, f32, ctypes.POINTER(vp)]
         L.glx_plan_run.argtypes = [vp, vp, u64, vp]
@@ -867,6 +870,22 @@ class DistStore:
         kind = _kind(pi, pg, pe, pc)
         _check(lib().glx_dist_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0], pc[0], kind,
                                         _stream(kind, self.comm.device)))
+        return emb, cnt
+
+    def aggregate_begin(self, slot, node_ids, default_attr=0.0):
+        """Collective half of aggregate(): resolve the ids and fetch the halo rows into buffer set `slot`
+        (torch CUDA ids, on the current stream) -- may run ahead of aggregate_end, beside an earlier reduce."""
+        assert _is_torch(node_ids) and node_ids.is_cuda and node_ids.is_contiguous()
+        _check(lib().glx_dist_aggregate_begin(self._h, slot, _ptr(node_ids)[0], int(node_ids.shape[0]), default_attr,
+                                              _stream(PTR_DEVICE, self.comm.device)))
+
+    def aggregate_end(self, slot, op, segment_ids, num_segments, out):
+        """Local half: the segmented reduce over the rows aggregate_begin(slot, ...) prepared."""
+        if isinstance(op, str):
+            op = AGGREGATOR_IDS[op]
+        emb, cnt = out
+        _check(lib().glx_dist_aggregate_end(self._h, slot, op, _ptr(segment_ids)[0], num_segments, _ptr(emb)[0],
+                                            _ptr(cnt)[0], _stream(PTR_DEVICE, self.comm.device)))
         return emb, cnt
 
     def lookup(self, node_ids, default_attr=0.0):

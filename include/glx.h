@@ -497,6 +497,18 @@ GLX_API int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* src,
 GLX_API int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,
                                int32_t num_ids, int32_t num_segments, float default_attr, float* emb_out,
                                int32_t* cnt_out, int ptr_kind, void* stream);
+/* The same in two halves, for software pipelining (device pointers only).  _begin is the collective part:
+ * it resolves the ids and fetches the halo rows into buffer set `slot` (0 <= slot < GLX_DIST_SLOTS); it may run
+ * on the stream that PRODUCED the ids, one or more requests ahead of the reduce.  _end is local: the segmented
+ * reduce over the slot's rows, on any stream ordered after _begin's.  The caller keeps a slot untouched between
+ * its _begin and the completion of its _end.  glx_dist_aggregate == _begin + _end on slot 0.  Why: with the
+ * halo exchange of request i+1 running beside the HBM-bound reduce of request i, link time and the probe passes
+ * leave the critical path. */
+#define GLX_DIST_SLOTS 4
+GLX_API int glx_dist_aggregate_begin(glx_dist_store* st, int32_t slot, const int64_t* node_ids, int32_t num_ids,
+                                     float default_attr, void* stream);
+GLX_API int glx_dist_aggregate_end(glx_dist_store* st, int32_t slot, int op, const int32_t* segment_ids,
+                                   int32_t num_segments, float* emb_out, int32_t* cnt_out, void* stream);
 /* Collective.  LookupNodes in distributed mode (node_lookuper.cc:24-52 behind
  * DistributeRunner): out[n * dim] rows of ids owned by any shard. */
 GLX_API int glx_dist_lookup(glx_dist_store* st, const int64_t* node_ids, int64_t n, float default_attr,

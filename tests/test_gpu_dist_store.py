@@ -195,6 +195,20 @@ def test_dist_aggregate_equals_unpartitioned(world, P, cache):
                     assert s["remote"] <= int(((ids < 0) | (ids >= V)).sum()), s
                 if cache == "none" and P > 1:
                     assert s["from_replica"] == 0 and s["remote"] > 0, s
+        # the two halves separately, two requests in flight in different slots (software pipelining)
+        ids_b = torch.flip(ids, [0]).contiguous()
+        st.aggregate_begin(2, ids, default_attr=0.5)
+        st.aggregate_begin(3, ids_b, default_attr=0.25)
+        out3 = (torch.empty((n // f, D), dtype=torch.float32, device=dev), torch.empty(n // f, dtype=torch.int32, device=dev))
+        out2 = (torch.empty((n // f, D), dtype=torch.float32, device=dev), torch.empty(n // f, dtype=torch.int32, device=dev))
+        st.aggregate_end(3, "SumAggregator", seg, n // f, out3)
+        st.aggregate_end(2, "MaxAggregator", None, n // f, out2)
+        r3, _ = feats.aggregate("SumAggregator", ids_b, seg, n // f, default_attr=0.25)
+        r2, _ = feats.aggregate("MaxAggregator", ids, seg, n // f, default_attr=0.5)
+        assert torch.equal(out3[0].view(torch.int32), r3.view(torch.int32)), r
+        assert torch.equal(out2[0].view(torch.int32), r2.view(torch.int32)), r
+        with pytest.raises(glx.GlxError, match="no begun request"):
+            st.aggregate_end(2, "MaxAggregator", None, n // f, out2)
         # equal segments without a segment tensor (a dense sampler response), and ragged + stalled ones
         e, c = st.aggregate("MeanAggregator", ids, None, n // f, default_attr=0.5)
         ref_e, ref_c = feats.aggregate("MeanAggregator", ids, seg, n // f, default_attr=0.5)
@@ -355,7 +369,7 @@ def test_rccl_world_size_one(world):
 
 
 def test_in_degree_sampler_is_refused_until_global_in_degrees_are_built(world):
-    gs, _ = world["shards"][2]
+    gs, _ = world["shards"][2]  # shared fixture handles: nobody has built global in-degrees on them
     dev = world["dev"]
 
     def body(r, comm):
