@@ -39,6 +39,10 @@ del src, dst, w, X
 torch.cuda.empty_cache()
 n1, n2 = B0 * k1, B0 * k1 * k2
 bar = threading.Barrier(P)
+hot_by = os.environ.get("HOT_BY", "indegree")
+acc_all = torch.zeros(V, dtype=torch.int32, device=dev)
+acc_lock = threading.Lock()
+hot_shared = [None]
 times, stats, ok = [None] * P, [None] * P, [True] * P
 
 
@@ -48,7 +52,26 @@ def rank_main(r):
         with torch.cuda.stream(torch.cuda.Stream(device=0)):
             st_s = glx.DistStore(comm, graph=graphs[r])
             st_a = glx.DistStore(comm, features=fshards[r])
-            hot = st_s.hot_ids(int(V * hot_fraction))
+            if hot_by == "access" and hot_fraction > 0:
+                # rows ranked by how often profiling requests touch them (bench.py --hot-by access)
+                pg = torch.Generator(device=dev)
+                pg.manual_seed(77 + r)
+                for j in range(4):
+                    ps = pool[torch.randint(0, pool.shape[0], (B0,), generator=pg, device=dev)]
+                    p1, _ = st_s.sample("EdgeWeightSampler", ps, k1, seed=4242, call_counter=2 * j)
+                    p2, _ = st_s.sample("EdgeWeightSampler", p1.view(-1), k2, seed=4242, call_counter=2 * j + 1)
+                    c = torch.bincount(p2.view(-1), minlength=V) + torch.bincount(p1.view(-1), minlength=V)
+                    torch.cuda.current_stream().synchronize()
+                    with acc_lock:
+                        acc_all.add_(c.to(torch.int32))
+                        torch.cuda.current_stream().synchronize()
+                bar.wait()
+                if r == 0:
+                    hot_shared[0] = torch.topk(acc_all, int(V * hot_fraction)).indices.to(torch.int64).cpu().numpy()
+                bar.wait()
+                hot = hot_shared[0]
+            else:
+                hot = st_s.hot_ids(int(V * hot_fraction))
             st_a.set_cache(hot)
             gen = torch.Generator(device=dev)
             gen.manual_seed(1000 + r)
@@ -106,6 +129,7 @@ if solo:
           "work of all owners for it (= one GPU's share in the symmetric case), no link time; answers equal the unpartitioned "
           "operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3, all(ok)))
 else:
+    print("hot rows chosen by", hot_by)
     print("P = %d ranks on one GPU, hot fraction %.2f: %.2f ms per step with all ranks running (%.2f ms of device work per rank-step); "
           "all answers equal the unpartitioned operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3,
                                                                   max(x or 0 for x in times) * 1e3 / P, all(ok)))
