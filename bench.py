@@ -384,7 +384,7 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="after timing, recompute one step on an unpartitioned copy of the graph held by this "
                          "rank and require bit-identical outputs from the sharded path")
-    ap.add_argument("--hot-fraction", type=float, default=0.10,
+    ap.add_argument("--hot-fraction", type=float, default=0.25,
                     help="N>1: every GPU keeps a replica of this fraction of the feature rows (the top vertices by "
                          "global in-degree); the rest is fetched per request (halo exchange of the cold tail)")
     ap.add_argument("--host-boundary", default="on", choices=["on", "off"],
@@ -395,7 +395,7 @@ def main():
                     help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
                          "auto = on for launch-bound batches (B0 <= 8192)")
     ap.add_argument("--graph-streams", type=int, default=3, help="--graph: plans / streams the steps alternate over")
-    ap.add_argument("--hot-by", default="access", choices=["access", "indegree"],
+    ap.add_argument("--hot-by", default="indegree", choices=["access", "indegree"],
                     help="N>1: how the replicated rows are chosen: by access count over a few profiling requests, or by "
                          "global in-degree (glx_dist_hot_ids: needs no request profile)")
     ap.add_argument("--hot-profile-steps", type=int, default=4)
@@ -489,7 +489,7 @@ def main():
         del ids
         # one communicator per stream: sampling (+ its exchanges) of step i+1 overlaps aggregation of step i
         comm_s = gdist.comm_for_group(None, local_rank)
-        comm_a = gdist.comm_for_group(None, local_rank)
+        comm_a = gdist.comm_for_group(None, local_rank)  # the halo prefetch stage's collectives
         st_smp = glx.DistStore(comm_s, graph=graph)
         st_agg = glx.DistStore(comm_a, features=feats)
         # hot-row replica: the top vertices by GLOBAL in-degree (computed from the shards), fetched once
@@ -561,7 +561,7 @@ def main():
     # at most one step ahead.
     pipelined = args.pipeline == "on" or (args.pipeline == "auto" and sharded)
     bufs = []
-    for _ in range(2 if pipelined else 1):
+    for _ in range((3 if sharded else 2) if pipelined else 1):
         b1 = torch.empty((B0, k1), dtype=torch.int64, device=dev)
         b2 = torch.empty((n1, k2), dtype=torch.int64, device=dev)
         bufs.append((b1, torch.empty_like(b1), b2, torch.empty_like(b2)))
@@ -575,17 +575,17 @@ def main():
         else:
             st_smp.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
             st_smp.sample(sampler, nb1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nb2, ed2))
-            if prefetch_halo[0]:
-                # the collective half of the two aggregations, on the SAMPLING stream: ids are resolved and the
-                # halo rows fetched while the previous step's reduce still runs on the other stream
-                st_agg.aggregate_begin(2 * (i % 2), nb2.view(-1))
-                st_agg.aggregate_begin(2 * (i % 2) + 1, nb1.view(-1))
         return nb1, nb2
+
+    def halo_begin(a, b, i):
+        # the collective half of the two aggregations: ids are resolved (replica / own shard / halo) and the halo
+        # rows fetched from their owners -- on its own stream, beside the previous step's reduce and the next
+        # step's sampling
+        st_agg.aggregate_begin(2 * (i % 3), b.view(-1))
+        st_agg.aggregate_begin(2 * (i % 3) + 1, a.view(-1))
 
     # A dense sampler response implies its segments (segment i = the neighbours of request row i):
     # segment_ids = None skips the segment bookkeeping kernels and the read of a segment tensor.
-    prefetch_halo = [False]  # set for the sharded leg: do_sample also begins the step's two aggregations
-
     def agg_local(table):
         def run(a, b, i):
             table.aggregate(agg, b.view(-1), None, n1, out=(emb2, cnt2))
@@ -594,11 +594,12 @@ def main():
 
     def agg_halo(a, b, i):
         # the local half: the segmented reduce over own shard + hot-row replica + the halo rows begun above
-        st_agg.aggregate_end(2 * (i % 2), agg, None, n1, out=(emb2, cnt2))
-        st_agg.aggregate_end(2 * (i % 2) + 1, agg, None, B0, out=(emb1, cnt1))
+        st_agg.aggregate_end(2 * (i % 3), agg, None, n1, out=(emb2, cnt2))
+        st_agg.aggregate_end(2 * (i % 3) + 1, agg, None, B0, out=(emb1, cnt1))
 
     if pipelined:
         s_smp, s_agg = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        s_pre = torch.cuda.Stream(device=dev)  # sharded leg: the halo prefetch stage
 
     def barrier():
         # Drain the local queue first: an RCCL barrier issued while the GPU still has queued work
@@ -648,6 +649,68 @@ def main():
             dt = float(t.item())
         return dt, t_a, t_s
 
+    def timed_leg_halo(steps_from, steps_to, warm):
+        """The edge-cut placement as a three-stage software pipeline over three streams (one communicator per
+        collective stage): S = 2-hop sampling of step i+1 (request rows exchanged over the links), P = halo
+        prefetch of step i (resolve + dedup + ids out + owners gather + rows back), R = the segmented reduce of
+        step i.  Every step's work completes inside the timed region."""
+        if not pipelined:
+            def flat(a, b, i):
+                halo_begin(a, b, i)
+                agg_halo(a, b, i)
+            return timed_leg(flat, steps_from, steps_to, warm)
+        ev_r = {}
+        pending = {}
+
+        def stage_s(i):
+            with torch.cuda.stream(s_smp):
+                if i - 3 in ev_r:
+                    s_smp.wait_event(ev_r[i - 3])  # buffers and slots of step i-3 are free again
+                a, b = do_sample(i)
+                e = torch.cuda.Event()
+                e.record(s_smp)
+            pending[i] = (a, b, e)
+
+        def stage_pr(i):
+            a, b, e = pending.pop(i)
+            with torch.cuda.stream(s_pre):
+                s_pre.wait_event(e)
+                halo_begin(a, b, i)
+                p = torch.cuda.Event()
+                p.record(s_pre)
+            with torch.cuda.stream(s_agg):
+                s_agg.wait_event(p)
+                agg_halo(a, b, i)
+                r = torch.cuda.Event()
+                r.record(s_agg)
+            ev_r[i] = r
+            ev_r.pop(i - 6, None)
+
+        def run(first, last):
+            if first >= last:
+                return
+            stage_s(first)
+            for i in range(first, last):
+                if i + 1 < last:
+                    stage_s(i + 1)  # issued BEFORE this step's prefetch: the host then waits in begin(i)
+                stage_pr(i)
+        run(0, warm)
+        barrier()
+        ev_r.clear()
+        glx.profile_enable(True)
+        t0 = time.perf_counter()
+        run(steps_from, steps_to)
+        barrier()
+        dt = time.perf_counter() - t0
+        glx.profile_enable(False)
+        t_a = glx.profile_collect(glx.KERNEL_AGGREGATE)
+        t_s = glx.profile_collect(glx.KERNEL_SAMPLE)
+        if world > 1:
+            t = torch.tensor([dt], device=ctl, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, t_a, t_s
+
     edges_per_step = n1 + n2  # response slots, padding included (SURVEY.md 8(d))
     kernel_steps = args.steps  # steps the per-kernel timers covered
     ctl = dev if args.backend == "nccl" else torch.device("cpu")  # control-plane tensors (gloo rig: host)
@@ -683,9 +746,7 @@ def main():
         headline = "single GPU"
     else:
         # north_star's placement: everything edge-cut, halo-vertex feature exchange per request
-        prefetch_halo[0] = True
-        el_h, ta_h, ts_h = timed_leg(agg_halo, args.warmup, n_steps, args.warmup)
-        prefetch_halo[0] = False
+        el_h, ta_h, ts_h = timed_leg_halo(args.warmup, n_steps, args.warmup)
         legs["features_sharded"] = {"ms_per_step": el_h / args.steps * 1e3,
                                     "value": world * edges_per_step * args.steps / el_h}
         torch.cuda.synchronize()
@@ -721,10 +782,9 @@ def main():
     verified = None
     if args.verify and sharded:
         i = n_steps - 1
-        prefetch_halo[0] = True
         a, b = do_sample(i)
+        halo_begin(a, b, i)
         agg_halo(a, b, i)
-        prefetch_halo[0] = False
         wa, wae = whole[0].sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
         wb, wbe = whole[0].sample(sampler, wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
         we2, wc2 = whole[1].aggregate(agg, wb.view(-1), None, n1)

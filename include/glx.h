@@ -504,7 +504,7 @@ GLX_API int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_i
  * its _begin and the completion of its _end.  glx_dist_aggregate == _begin + _end on slot 0.  Why: with the
  * halo exchange of request i+1 running beside the HBM-bound reduce of request i, link time and the probe passes
  * leave the critical path. */
-#define GLX_DIST_SLOTS 4
+#define GLX_DIST_SLOTS 8
 GLX_API int glx_dist_aggregate_begin(glx_dist_store* st, int32_t slot, const int64_t* node_ids, int32_t num_ids,
                                      float default_attr, void* stream);
 GLX_API int glx_dist_aggregate_end(glx_dist_store* st, int32_t slot, int op, const int32_t* segment_ids,
