@@ -172,25 +172,35 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
   }
 }
 
-// Rows in flight per lane.  8 is the default; GLX_AGG_UNROLL=10|12 selects the other
-// instantiations of the wide float4 shapes for A/B runs (a fanout-10 segment is then one
-// batch of loads instead of 8 + 2).
-int agg_unroll() {  // read per launch so that one process can A/B
+// Rows in flight per lane.  A/B in one process on the C3 hop-2 request (scripts/agg_unroll_probe.py,
+// profiles/r02/agg_unroll_probe.txt): 3 / 4 / 5 / 6 / 8 / 10 / 12 rows -> 2.26 / 2.19 / 2.11 / 2.10 / 2.21 / 2.49 /
+// 2.48 ms: fewer rows per lane cost fewer registers and let more waves hide the latency, down to 6; a
+// fanout-10 segment is then 6 + 4 loads.  The wide float4 shapes (dim >= 128) use 6, the narrow ones keep 8
+// (not measured).  GLX_AGG_UNROLL = 3|4|5|6|8|10|12 overrides it for the wide shapes, read per launch.
+int agg_unroll() {
   const char* e = getenv("GLX_AGG_UNROLL");
-  const int v = e ? atoi(e) : 8;
-  return (v == 10 || v == 12) ? v : 8;
+  const int v = e ? atoi(e) : 6;
+  return (v == 3 || v == 4 || v == 5 || v == 8 || v == 10 || v == 12) ? v : 6;
 }
 
 template <int OP, int G, int VEC, int NSRC>
 void launch_agg_g(const AggArgs& a, hipStream_t s) {
   const int64_t threads = (int64_t)a.num_segments * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
-  if (VEC == 4 && G >= 32 && NSRC == 1 && agg_unroll() != 8) {
-    if (agg_unroll() == 10) glx_aggregate_kernel<OP, G, VEC, (VEC == 4 && G >= 32 && NSRC == 1) ? 10 : 8, NSRC><<<grid, 256, 0, s>>>(a);
-    else glx_aggregate_kernel<OP, G, VEC, (VEC == 4 && G >= 32 && NSRC == 1) ? 12 : 8, NSRC><<<grid, 256, 0, s>>>(a);
+  constexpr bool kWide = VEC == 4 && G >= 32;
+  if (!kWide) {
+    glx_aggregate_kernel<OP, G, VEC, 8, NSRC><<<grid, 256, 0, s>>>(a);
     return;
   }
-  glx_aggregate_kernel<OP, G, VEC, 8, NSRC><<<grid, 256, 0, s>>>(a);
+  switch (agg_unroll()) {
+    case 3: glx_aggregate_kernel<OP, G, VEC, kWide ? 3 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
+    case 4: glx_aggregate_kernel<OP, G, VEC, kWide ? 4 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
+    case 5: glx_aggregate_kernel<OP, G, VEC, kWide ? 5 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
+    case 8: glx_aggregate_kernel<OP, G, VEC, 8, NSRC><<<grid, 256, 0, s>>>(a); break;
+    case 10: glx_aggregate_kernel<OP, G, VEC, kWide ? 10 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
+    case 12: glx_aggregate_kernel<OP, G, VEC, kWide ? 12 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
+    default: glx_aggregate_kernel<OP, G, VEC, kWide ? 6 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
+  }
 }
 
 template <int OP, int NSRC>
