@@ -26,7 +26,7 @@ tr = [r for r in csv.DictReader(open(os.path.join(dst, "kernel_trace_glx_only.cs
 dur = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr)
 hop2 = [d for d in dur if d > 1.0]
 hop1 = [d for d in dur if d <= 1.0]
-out += ["", "`glx_aggregate_kernel<2, 64, 4, 8, 1>` = MaxAggregator, 64 lanes/segment, float4, 8 loads in flight, one row source. It is dispatched twice per step; "
+out += ["", "`glx_aggregate_kernel<2, 64, 4, 6, 1>` = MaxAggregator, 64 lanes/segment, float4, 6 loads in flight, one row source. It is dispatched twice per step; "
         "from the per-dispatch rows (`kernel_trace_glx_only.csv`): %d hop-2 dispatches (16,384,000 ids -> 1,638,400 segments) average **%.3f ms**, "
         "%d hop-1 dispatches (1,638,400 -> 65,536) average %.3f ms. bench.py's live HIP-event measurement of the hop-2 launches in the same run: "
         "**%.3f ms** (`roofline.avg_launch_ms`)." % (len(hop2), sum(hop2) / len(hop2), len(hop1), sum(hop1) / max(len(hop1), 1), b["roofline"]["avg_launch_ms"])]
