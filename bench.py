@@ -395,6 +395,9 @@ def main():
                     help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
                          "auto = on for launch-bound batches (B0 <= 8192)")
     ap.add_argument("--graph-streams", type=int, default=3, help="--graph: plans / streams the steps alternate over")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="N>1: seconds the timed legs may take before rank 0 prints a result without a value and all "
+                         "ranks exit (a hung collective must not hang the node)")
     ap.add_argument("--hot-by", default="indegree", choices=["access", "indegree"],
                     help="N>1: how the replicated rows are chosen: by access count over a few profiling requests, or by "
                          "global in-degree (glx_dist_hot_ids: needs no request profile)")
@@ -745,6 +748,25 @@ def main():
         elapsed, t_agg, t_smp = timed_leg(agg_local(feats), args.warmup, n_steps, args.warmup)
         headline = "single GPU"
     else:
+        # A collective that never completes (a rank died, a link fault) would hang every rank forever: after
+        # --watchdog seconds rank 0 prints what has been measured so far and every rank leaves.
+        import threading
+        progress = {"stage": "features_sharded leg"}
+
+        def give_up():
+            if rank == 0:
+                result_out.write(json.dumps({
+                    "metric": "sampled-edges/sec + aggregated-vertices/sec", "value": None, "unit": "edges/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "%s: %s" % (args.workload, desc)},
+                    "error": "watchdog: no progress for %.0f s in the %s" % (args.watchdog, progress["stage"]),
+                    "placements": legs}) + "\n")
+                result_out.flush()
+            os._exit(4)
+        dog = threading.Timer(args.watchdog, give_up)
+        dog.daemon = True
+        dog.start()
         # north_star's placement: everything edge-cut, halo-vertex feature exchange per request
         el_h, ta_h, ts_h = timed_leg_halo(args.warmup, n_steps, args.warmup)
         legs["features_sharded"] = {"ms_per_step": el_h / args.steps * 1e3,
@@ -752,6 +774,7 @@ def main():
         torch.cuda.synchronize()
         halo_stats = st_agg.stats()  # the last aggregate call (hop 1); hop 2's are taken below
         if replica is not None:
+            progress["stage"] = "features_replicated leg"
             el_r, ta_r, ts_r = timed_leg(agg_local(replica), args.warmup, n_steps, args.warmup)
             legs["features_replicated"] = {"ms_per_step": el_r / args.steps * 1e3,
                                            "value": world * edges_per_step * args.steps / el_r}
@@ -764,6 +787,7 @@ def main():
         st_agg.aggregate(agg, b_last.view(-1), None, n1, out=(emb2, cnt2))
         torch.cuda.synchronize()
         halo_stats = st_agg.stats()
+        dog.cancel()
 
     cpu = None
     if host_edges is not None:

@@ -64,6 +64,24 @@ def test_fails_loudly_without_gpu():
         glx.Features(np.zeros((2, 4), np.float32))
 
 
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is visible")
+def test_distributed_entry_points_fail_loudly_without_gpu():
+    """The communicator / distributed store / request plan are part of the same library: without a GPU they
+    report UNAVAILABLE like everything else (librccl itself loads: a unique id can be made on any box)."""
+    L = glx.lib()
+    h = ctypes.c_void_p()
+    assert L.glx_comm_init_local(7, 0, 0, 1, ctypes.byref(h)) == 14 and not h.value
+    uid = ctypes.create_string_buffer(128)
+    rc = L.glx_comm_unique_id(uid)
+    assert rc in (0, 14)
+    if rc == 0:
+        assert L.glx_comm_init_rccl(0, 0, 1, uid, ctypes.byref(h)) == 14 and not h.value
+    assert L.glx_dist_store_create(None, None, None, ctypes.byref(h)) == 3  # INVALID_ARGUMENT: no communicator
+    assert L.glx_plan_create(None, 1, 0, None, 1, 1, 0, 0, None, 0, 0.0, ctypes.byref(h)) == 3
+    a = np.zeros(16, np.int64)
+    assert L.glx_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) == 14
+
+
 def test_argument_validation_needs_no_gpu():
     L = glx.lib()
     assert L.glx_graph_info(None, None, None, None, None, None) == 3  # INVALID_ARGUMENT
