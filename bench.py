@@ -756,8 +756,10 @@ def main():
         def give_up():
             if rank == 0:
                 result_out.write(json.dumps({
-                    "metric": "sampled-edges/sec + aggregated-vertices/sec", "value": None, "unit": "edges/s",
-                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                    "metric": "sampled-edges/sec + aggregated-vertices/sec",
+                    "value": legs.get("features_sharded", {}).get("value"), "unit": "edges/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": legs.get("features_sharded", {}).get("ms_per_step"),
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                     "config": {"workload": "%s: %s" % (args.workload, desc)},
                     "error": "watchdog: no progress for %.0f s in the %s" % (args.watchdog, progress["stage"]),
