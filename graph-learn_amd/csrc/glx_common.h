@@ -389,25 +389,35 @@ __device__ inline void glx_alias_build_row_wave(const float* __restrict__ dist, 
     }
     __threadfence_block();
     if (lane == 0) {
-      while ((have_lo || l_at < l_n) && (have_hi || h_at < h_n)) {
-        if (!have_lo) lo = wl[l_at++];
-        if (!have_hi) hi = wh[h_at++];
-        have_lo = false;
-        const float p = hi.prob - 1.0f + lo.prob;
-        tab[lo.alias].alias = hi.alias;
-        hi.prob = p;
-        if (p < 1.0f) {
-          tab[hi.alias].prob = p;
-          lo = hi;
-          have_lo = true;
-          have_hi = false;
-        } else if (p > 1.0f) {
-          have_hi = true;  // still the top of the high stack; its final prob is written when it leaves
-        } else {
-          tab[hi.alias].prob = p;
-          have_hi = false;
-        }
+      // The serial machine of glx_alias_build_row_dev, written without branches in the body: which entries a
+      // step takes (the carried low / high or the next window entry) and what it leaves behind are selects on
+      // the previous step's two comparisons; the window entries of the NEXT step are loaded as soon as their
+      // addresses are known, i.e. before this step's float chain, so LDS latency is off the critical path.
+      // Per step: select, subtract, add, compare, select -- and two fire-and-forget stores.
+      int32_t la = l_at, ha = h_at;
+      bool hl = have_lo, hh = have_hi;
+      GlxAlias nl = wl[la < kAliasWindow ? la : kAliasWindow - 1];
+      GlxAlias nh = wh[ha < kAliasWindow ? ha : kAliasWindow - 1];
+      while ((hl || la < l_n) && (hh || ha < h_n)) {
+        const GlxAlias cl = hl ? lo : nl;
+        const GlxAlias ch = hh ? hi : nh;
+        la += hl ? 0 : 1;
+        ha += hh ? 0 : 1;
+        nl = wl[la < kAliasWindow ? la : kAliasWindow - 1];
+        nh = wh[ha < kAliasWindow ? ha : kAliasWindow - 1];
+        const float p = ch.prob - 1.0f + cl.prob;
+        tab[cl.alias].alias = ch.alias;
+        const bool lt = p < 1.0f, gt = p > 1.0f;
+        if (!gt) tab[ch.alias].prob = p;  // leaves the high stack: below 1 it becomes the next low, at 1 it is done
+        hi = GlxAlias{p, ch.alias};       // p > 1: still the top of the high stack (final prob written when it leaves)
+        lo = hi;                          // meaningful when p < 1 only
+        hl = lt;
+        hh = gt;
       }
+      l_at = la;
+      h_at = ha;
+      have_lo = hl;
+      have_hi = hh;
     }
     l_at = __shfl(l_at, 0);
     h_at = __shfl(h_at, 0);

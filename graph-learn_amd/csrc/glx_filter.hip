@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void glx_filter_random_kernel(DrawArgs a, Filt
 //   R(p) = p                                   when p is not a hit,
 //   R(h_r) = the r-th survivor of [m, n), descending   for the hits below m (the holes),
 // which is the closed form of filter.cc:83-94 used by glx_filter_reserve_kernel.  Rows with more
-// than kMaxHits hits (parallel edges to the filtered id) take the general path.
+// than kMaxHits hits (parallel edges to the filtered id: hub rows of a multigraph) take the general path.
 constexpr int kMaxHits = 8;
 constexpr int kFastMaxK = 32;
 
