@@ -34,6 +34,20 @@ struct glx_dist_store;
 
 namespace graphlearn {
 
+// Bootstrap of the shard communicator through a shared directory, the way the reference's servers find each
+// other (service/dist/fs_naming_engine.cc:30-106: every server writes `<tracker>/endpoints/<id>`, the others
+// poll the directory): server 0 makes the RCCL unique id and publishes it as `<tracker>/glx_comm/<session>`
+// (written to a temporary name, then renamed: readers never see a partial file); the others poll for it.
+// `session` names this run of the deployment (a job id, a start time): a file left behind by an earlier run
+// under another session is never picked up.  Returns the 128 id bytes in `id`; when server 0 passes an `id`
+// that already holds 128 bytes, those are published instead of a fresh RCCL id (tests, other transports).
+Status ExchangeUniqueId(const std::string& tracker, const std::string& session, int32_t server_id,
+                        double timeout_seconds, std::string* id);
+// ExchangeUniqueId + glx_comm_init_rccl(device, server_id, server_count): every server calls it once (twice,
+// with two session names, for two communicators).  The caller owns *comm (glx_comm_destroy).
+Status ConnectServers(const std::string& tracker, const std::string& session, int device, int32_t server_id,
+                      int32_t server_count, glx_comm** comm);
+
 // What a runner needs from the deployment (the role of platform/env.h + the naming engine):
 // this server's id, the server count, the way to the other servers, and the local shard.
 class Env {

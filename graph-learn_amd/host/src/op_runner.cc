@@ -5,6 +5,12 @@
 // communicator, runs the owner's kernels, exchanges the results back and stitches.
 #include "graphlearn/op_runner.h"
 
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <thread>
 #include <vector>
 
 #include "glx.h"
@@ -13,6 +19,57 @@
 #include "graphlearn/sampling_request.h"
 
 namespace graphlearn {
+
+Status ExchangeUniqueId(const std::string& tracker, const std::string& session, int32_t server_id,
+                        double timeout_seconds, std::string* id) {
+  if (tracker.empty() || session.empty() || session.find('/') != std::string::npos) {
+    return error::InvalidArgument("ExchangeUniqueId needs a tracker directory and a session name without '/'");
+  }
+  const std::string dir = tracker + (tracker.back() == '/' ? "" : "/") + "glx_comm";
+  const std::string path = dir + "/" + session;
+  const bool preset = server_id == 0 && id->size() == (size_t)GLX_UNIQUE_ID_BYTES;
+  if (!preset) id->assign((size_t)GLX_UNIQUE_ID_BYTES, '\0');
+  if (server_id == 0) {
+    if (!preset) {
+      int rc = glx_comm_unique_id(&(*id)[0]);
+      if (rc != GLX_OK) return error::FromGlx(rc);
+    }
+    if (mkdir(dir.c_str(), 0777) != 0 && errno != EEXIST) {
+      return error::InvalidArgument("cannot create " + dir + " (tracker path)");
+    }
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return error::InvalidArgument("cannot write " + tmp);
+    const bool ok = fwrite(id->data(), 1, id->size(), f) == id->size();
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) {
+      (void)remove(tmp.c_str());
+      return error::Internal("cannot publish " + path);
+    }
+    return Status::OK();
+  }
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_seconds);
+  while (true) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (f) {
+      const size_t n = fread(&(*id)[0], 1, id->size(), f);
+      fclose(f);
+      if (n == id->size()) return Status::OK();
+    }
+    if (std::chrono::steady_clock::now() > deadline) {
+      return error::Unavailable("server 0 did not publish " + path + " within the timeout");
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
+}
+
+Status ConnectServers(const std::string& tracker, const std::string& session, int device, int32_t server_id,
+                      int32_t server_count, glx_comm** comm) {
+  *comm = nullptr;
+  std::string id;
+  Status s = ExchangeUniqueId(tracker, session, server_id, 300.0, &id);
+  if (!s.ok()) return s;
+  return error::FromGlx(glx_comm_init_rccl(device, server_id, server_count, id.data(), comm));
+}
 
 Env::Env(glx_comm* comm, GraphStore* store) : comm_(comm), store_(store), server_id_(0), server_count_(1) {
   int rank = 0, world = 1;

@@ -3,7 +3,9 @@
 // Filter::FillValues (sampling_request.cc:33-136, filter.cc:53-67), partitioning of a
 // request's tensors (hash_partitioner.h:33-92), RandomWalkRequest::IsDeepWalk
 // (random_walk_request.cc:152-160), Clone() of every request kind.
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "glx.h"
@@ -138,6 +140,33 @@ TEST(RequestTest, RandomWalkRequest) {
   delete rq;
   delete rs;
   EXPECT_TRUE(op::OpFactory::GetInstance()->Create("RandomWalk") != nullptr);
+}
+
+// Bootstrap of the shard communicator through the tracker directory (no device involved): what server 0
+// publishes is what the other servers read, whichever starts first; a session nobody published times out.
+TEST(RequestTest, UniqueIdTravelsThroughTheTrackerDirectory) {
+  char tmpl[] = "/tmp/glx_tracker_XXXXXX";
+  const char* dir = mkdtemp(tmpl);
+  EXPECT_TRUE(dir != nullptr);
+  std::string got0(GLX_UNIQUE_ID_BYTES, '\0'), got1;  // server 0 publishes these bytes (no RCCL on a CPU box)
+  for (size_t i = 0; i < got0.size(); ++i) got0[i] = (char)(i * 7 + 3);
+  Status s1;
+  std::thread reader([&] { s1 = ExchangeUniqueId(dir, "job42", 1, 20.0, &got1); });  // starts polling first
+  std::this_thread::sleep_for(std::chrono::milliseconds(100));
+  Status s0 = ExchangeUniqueId(dir, "job42", 0, 20.0, &got0);
+  reader.join();
+  EXPECT_TRUE(s0.ok() && s1.ok());
+  EXPECT_EQ(got0.size(), (size_t)GLX_UNIQUE_ID_BYTES);
+  EXPECT_TRUE(got0 == got1);
+  bool nonzero = false;
+  for (char c : got0) nonzero |= c != 0;
+  EXPECT_TRUE(nonzero);
+  std::string late;
+  EXPECT_TRUE(ExchangeUniqueId(dir, "job42", 3, 1.0, &late).ok() && late == got0);  // a late joiner
+  std::string other;
+  Status missing = ExchangeUniqueId(dir, "another-session", 1, 0.2, &other);
+  EXPECT_TRUE(error::IsUnavailable(missing));
+  EXPECT_TRUE(error::IsInvalidArgument(ExchangeUniqueId(dir, "a/b", 0, 1.0, &other)));
 }
 
 int main() { return RunAllTests(); }
