@@ -395,9 +395,12 @@ def main():
                     help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
                          "auto = on for launch-bound batches (B0 <= 8192)")
     ap.add_argument("--graph-streams", type=int, default=3, help="--graph: plans / streams the steps alternate over")
-    ap.add_argument("--watchdog", type=float, default=900.0,
+    ap.add_argument("--watchdog", type=float, default=300.0,
                     help="N>1: seconds the timed legs may take before rank 0 prints a result without a value and all "
                          "ranks exit (a hung collective must not hang the node)")
+    ap.add_argument("--setup-watchdog", type=float, default=900.0,
+                    help="N>1: seconds everything before the timed legs may take (process group, communicators, "
+                         "store build, replica fetch)")
     ap.add_argument("--hot-by", default="indegree", choices=["access", "indegree"],
                     help="N>1: how the replicated rows are chosen: by access count over a few profiling requests, or by "
                          "global in-degree (glx_dist_hot_ids: needs no request profile)")
@@ -433,6 +436,26 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
+    setup_dog = None
+    if world > 1:
+        # a rank that never arrives (or a communicator that never forms) must not hang the node: the timed legs
+        # have their own watchdog, this one covers everything before them
+        import threading
+
+        def setup_give_up():
+            if rank == 0:
+                result_out.write(json.dumps({
+                    "metric": "sampled-edges/sec + aggregated-vertices/sec", "value": None, "unit": "edges/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                    "data": "synthetic", "config": {"workload": args.workload},
+                    "error": "setup watchdog: communicator / store set-up did not finish in %.0f s" % args.setup_watchdog,
+                }) + "\n")
+                result_out.flush()
+            os._exit(5)
+        setup_dog = threading.Timer(args.setup_watchdog, setup_give_up)
+        setup_dog.daemon = True
+        setup_dog.start()
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -442,6 +465,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if args.workload == "c5":
+        if setup_dog is not None:
+            setup_dog.cancel()
         bench_c5(args, dev, result_out, world=world, rank=rank, sharded=sharded)
         return
     wl = WORKLOADS[args.workload]
@@ -751,35 +776,64 @@ def main():
         # A collective that never completes (a rank died, a link fault) would hang every rank forever: after
         # --watchdog seconds rank 0 prints what has been measured so far and every rank leaves.
         import threading
-        progress = {"stage": "features_sharded leg"}
+        if setup_dog is not None:
+            setup_dog.cancel()
+        progress = {"stage": "first leg"}
 
-        def give_up():
+        def give_up(reason=None):
+            # the headline placement if it finished; otherwise the other placement, named as such
+            for name in ("features_sharded", "features_replicated"):
+                if name in legs:
+                    best = name
+                    break
+            else:
+                best = None
             if rank == 0:
                 result_out.write(json.dumps({
                     "metric": "sampled-edges/sec + aggregated-vertices/sec",
-                    "value": legs.get("features_sharded", {}).get("value"), "unit": "edges/s",
+                    "value": legs[best]["value"] if best else None, "unit": "edges/s",
                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                    "ms_per_step": legs.get("features_sharded", {}).get("ms_per_step"),
+                    "ms_per_step": legs[best]["ms_per_step"] if best else None,
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                    "config": {"workload": "%s: %s" % (args.workload, desc)},
-                    "error": "watchdog: no progress for %.0f s in the %s" % (args.watchdog, progress["stage"]),
+                    "config": {"workload": "%s: %s -- value = %s placement (the only leg that finished)"
+                                           % (args.workload, desc, best)},
+                    "error": reason or ("watchdog: no progress for %.0f s in the %s" % (args.watchdog, progress["stage"])),
                     "placements": legs}) + "\n")
                 result_out.flush()
             os._exit(4)
         dog = threading.Timer(args.watchdog, give_up)
         dog.daemon = True
         dog.start()
+
+        def guarded(name, fn):
+            """A leg that raises on one rank leaves its peers inside a collective: rank 0 reports what it has at
+            once; another rank keeps its process alive (so the launcher does not tear rank 0 down) until rank
+            0's watchdog has spoken."""
+            progress["stage"] = name + " leg"
+            try:
+                return fn()
+            except Exception as ex:  # noqa: BLE001
+                log("rank %d: %s leg failed: %r" % (rank, name, ex))
+                if rank == 0:
+                    give_up("%s leg failed on rank 0: %r" % (name, ex))
+                time.sleep(args.watchdog + 30)
+                os._exit(4)
+        # the other end of the placement space first (it shares the sampling exchanges but has no halo step):
+        # a fault in the halo leg then still leaves a measured, labelled number
+        if replica is not None:
+            el_r, ta_r, ts_r = guarded("features_replicated",
+                                       lambda: timed_leg(agg_local(replica), args.warmup, n_steps, args.warmup))
+            legs["features_replicated"] = {"ms_per_step": el_r / args.steps * 1e3,
+                                           "value": world * edges_per_step * args.steps / el_r}
+            dog.cancel()
+            dog = threading.Timer(args.watchdog, give_up)
+            dog.daemon = True
+            dog.start()
         # north_star's placement: everything edge-cut, halo-vertex feature exchange per request
-        el_h, ta_h, ts_h = timed_leg_halo(args.warmup, n_steps, args.warmup)
+        el_h, ta_h, ts_h = guarded("features_sharded", lambda: timed_leg_halo(args.warmup, n_steps, args.warmup))
         legs["features_sharded"] = {"ms_per_step": el_h / args.steps * 1e3,
                                     "value": world * edges_per_step * args.steps / el_h}
         torch.cuda.synchronize()
-        halo_stats = st_agg.stats()  # the last aggregate call (hop 1); hop 2's are taken below
-        if replica is not None:
-            progress["stage"] = "features_replicated leg"
-            el_r, ta_r, ts_r = timed_leg(agg_local(replica), args.warmup, n_steps, args.warmup)
-            legs["features_replicated"] = {"ms_per_step": el_r / args.steps * 1e3,
-                                           "value": world * edges_per_step * args.steps / el_r}
         if args.features == "replicated" and replica is not None:
             elapsed, t_agg, t_smp, headline = el_r, ta_r, ts_r, "features_replicated"
         else:
