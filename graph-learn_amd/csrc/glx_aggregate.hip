@@ -87,6 +87,7 @@ struct AggArgs {
   int32_t num_segments;
   int32_t fanout;
   float default_attr;
+  int32_t col0, ncols;       // the columns [col0, col0 + ncols) this launch reduces (a column slice, or all)
   // further row sources of the distributed store (glx_dist.hip): virtual row r lives in
   // source 0 when r < base1, in source 1 (the hot-row replica) when r < base2, else in
   // source 2 (the halo rows of this request, plain row-major, no swizzle).
@@ -130,10 +131,10 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
     s1 = s0 + a.fanout;
   }
   const int32_t n = s1 - s0;
-  if (c == 0) a.cnt_out[gid] = n;
-  const int32_t dim = a.dim;
-  float* out = a.emb_out + gid * (int64_t)dim;
-  for (int32_t col = c * VEC; col < dim; col += G * VEC) {
+  if (c == 0 && a.col0 == 0) a.cnt_out[gid] = n;
+  float* out = a.emb_out + gid * (int64_t)a.dim;
+  const int32_t col_end = a.col0 + a.ncols;
+  for (int32_t col = a.col0 + c * VEC; col < col_end; col += G * VEC) {
     vec_t acc;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = agg_init<OP>();
@@ -203,16 +204,29 @@ void launch_agg_g(const AggArgs& a, hipStream_t s) {
   }
 }
 
+// Column slices.  A hop-2 request of a power-law graph re-reads its hub rows from thousands of segments; whether
+// those re-reads are served by L2 / Infinity Cache or by HBM depends on how many distinct hot BYTES sit between two
+// uses.  Reducing the columns in S slices, one after the other (slice-major block order inside one launch order),
+// divides the hot working set of each phase by S at the price of reading the ids S times.
+// GLX_AGG_SLICES = 1|2|4|8 (read per launch).
+int agg_slices(const AggArgs& a) {
+  const char* e = getenv("GLX_AGG_SLICES");
+  const int v = e ? atoi(e) : 1;
+  if (v != 2 && v != 4 && v != 8) return 1;
+  if (a.dim % (4 * v) != 0) return 1;
+  return v;
+}
+
 template <int OP, int NSRC>
-void launch_agg_n(const AggArgs& a, hipStream_t s) {
-  bool vec4 = a.dim % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0 &&
+void launch_agg_cols(const AggArgs& a, hipStream_t s) {
+  bool vec4 = a.dim % 4 == 0 && a.ncols % 4 == 0 && a.col0 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0 &&
               (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && (a.stride % 4) == 0;
   if (NSRC > 1) {
     vec4 = vec4 && (reinterpret_cast<uintptr_t>(a.X1) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.X2) & 15) == 0 &&
            (a.stride1 % 4) == 0 && (a.stride2 % 4) == 0;
   }
   if (vec4) {
-    const int lanes = a.dim / 4;
+    const int lanes = a.ncols / 4;
     if (lanes >= 64) launch_agg_g<OP, 64, 4, NSRC>(a, s);
     else if (lanes >= 32) launch_agg_g<OP, 32, 4, NSRC>(a, s);
     else if (lanes >= 16) launch_agg_g<OP, 16, 4, NSRC>(a, s);
@@ -221,11 +235,22 @@ void launch_agg_n(const AggArgs& a, hipStream_t s) {
     else if (lanes >= 2) launch_agg_g<OP, 2, 4, NSRC>(a, s);
     else launch_agg_g<OP, 1, 4, NSRC>(a, s);
   } else {
-    const int lanes = a.dim;
+    const int lanes = a.ncols;
     if (lanes >= 64) launch_agg_g<OP, 64, 1, NSRC>(a, s);
     else if (lanes >= 16) launch_agg_g<OP, 16, 1, NSRC>(a, s);
     else if (lanes >= 4) launch_agg_g<OP, 4, 1, NSRC>(a, s);
     else launch_agg_g<OP, 1, 1, NSRC>(a, s);
+  }
+}
+
+template <int OP, int NSRC>
+void launch_agg_n(const AggArgs& a0, hipStream_t s) {
+  AggArgs a = a0;
+  const int slices = agg_slices(a);
+  for (int c = 0; c < slices; ++c) {
+    a.ncols = a.dim / slices;
+    a.col0 = c * a.ncols;
+    launch_agg_cols<OP, NSRC>(a, s);
   }
 }
 

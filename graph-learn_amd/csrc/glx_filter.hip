@@ -378,16 +378,16 @@ __global__ __launch_bounds__(256) void glx_filter_random_kernel(DrawArgs a, Filt
   eid_out[t] = rec.eid;
 }
 
-// ---------------------------------------------------------------------------------------
-// id == value filters (GSL's .filter(): "not back to where the path came from").  A row has few
-// hits -- none at all in most rows -- so ActOn's result is the identity with a handful of
-// corrections.  The hit positions are found with ONE look at the row (a binary search in the
-// row's id-sorted index when glx_graph_enable_negative() built it, else one ballot scan), the
-// reserved list is never materialised: with hits h_0 < ... < h_{H-1} and m = n - H survivors,
-//   R(p) = p                                   when p is not a hit,
-//   R(h_r) = the r-th survivor of [m, n), descending   for the hits below m (the holes),
-// which is the closed form of filter.cc:83-94 used by glx_filter_reserve_kernel.  Rows with more
-// than kMaxHits hits (parallel edges to the filtered id: hub rows of a multigraph) take the general path.
+// id == value filters (GSL's .filter()): the closed form of Filter::ActOn (filter.cc:83-94, the one
+// glx_filter_reserve_kernel materialises) evaluated lazily.  With H hit positions in a row of n neighbours and
+// m = n - H survivors, the reserved list is
+//   R(p) = p                                                 when position p is not a hit,
+//   R(h) = the r-th survivor of [m, n), counted downwards    when h < m is the r-th hit (ascending) -- a hole.
+// Whether p is a hit is one look at adj[p]; r = the number of hits below h; the r-th survivor from the top is the
+// fixed point of q = n - 1 - r - #(hits >= q).  Both counts run over the row's hit list in ANY order, so the list
+// is never sorted or copied: with the id-sorted row index it is the run slot_sorted[lo, lo + H) the binary
+// search lands on (any H); without the index one ballot scan lists up to kMaxHits positions and rows with more
+// take the general path.
 constexpr int kMaxHits = 8;
 constexpr int kFastMaxK = 32;
 
@@ -396,14 +396,15 @@ struct HitArgs {
   const int64_t* start;
   const int32_t* deg;
   const int64_t* values;
-  const int64_t* nbr_sorted;  // per row ascending ids + their row-local positions, or nullptr
+  const int64_t* nbr_sorted;  // per row ascending ids + the CSR slots they came from, or nullptr
   const uint32_t* slot_sorted;
   int32_t* nhits;             // [batch]
-  int32_t* hits;              // [batch * kMaxHits] ascending positions
+  int32_t* hit_lo;            // [batch] with the index: where the run of hits starts in the row's sorted ids
+  int32_t* hits;              // [batch * kMaxHits] without the index: the first hit positions
   int32_t batch;
 };
 
-// With the index: one thread per row.
+// With the index: one thread per row, a binary search and a count.
 __global__ void glx_filter_idhits_index_kernel(HitArgs a) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.batch) return;
@@ -415,20 +416,16 @@ __global__ void glx_filter_idhits_index_kernel(HitArgs a) {
     if (a.nbr_sorted[s + mid] < val) lo = mid + 1; else hi = mid;
   }
   int32_t H = 0;
-  int32_t pos[kMaxHits];
-  while (lo + H < n && a.nbr_sorted[s + lo + H] == val) {
-    if (H < kMaxHits) {  // insertion sort: positions ascending
-      int32_t p = (int32_t)((int64_t)a.slot_sorted[s + lo + H] - s), t = H;
-      while (t > 0 && pos[t - 1] > p) {
-        pos[t] = pos[t - 1];
-        --t;
-      }
-      pos[t] = p;
+  if (lo < n && a.nbr_sorted[s + lo] == val) {  // the run's end: a second search (a hub can hold thousands of hits)
+    int32_t l2 = lo + 1, h2 = n;
+    while (l2 < h2) {
+      const int32_t mid = l2 + ((h2 - l2) >> 1);
+      if (a.nbr_sorted[s + mid] <= val) l2 = mid + 1; else h2 = mid;
     }
-    ++H;
+    H = l2 - lo;
   }
   a.nhits[i] = H;
-  for (int32_t t = 0; t < H && t < kMaxHits; ++t) a.hits[(int64_t)i * kMaxHits + t] = pos[t];
+  a.hit_lo[i] = lo;
 }
 
 // Without it: one wave per row, one pass.
@@ -452,48 +449,58 @@ __global__ __launch_bounds__(64) void glx_filter_idhits_scan_kernel(HitArgs a) {
   if (lane == 0) a.nhits[i] = H;
 }
 
-// R(p) for p in [0, m) from the ascending hit list.
-__device__ __forceinline__ int32_t reserved_at(int32_t p, const int32_t* __restrict__ hits, int32_t H, int32_t n) {
-  const int32_t m = n - H;
-  int32_t rank = -1;
-  for (int32_t t = 0; t < H; ++t) {
-    if (hits[t] == p) rank = t;  // hits below m are the first ones: t is the hole's rank
-  }
-  if (rank < 0) return p;
-  // the rank-th survivor of [m, n), walking down from n - 1 and skipping hits
-  int32_t q = n - 1, left = rank, t = H - 1;
-  while (true) {
-    while (t >= 0 && hits[t] > q) --t;
-    if (t >= 0 && hits[t] == q) {
-      --q;
-      continue;
-    }
-    if (left == 0) return q;
-    --left;
-    --q;
-  }
-  (void)m;
-}
+// One row's hit positions, in no particular order.
+struct HitList {
+  const uint32_t* run;  // slot_sorted + start + lo (CSR slots), or nullptr
+  const int32_t* arr;   // row-local positions
+  int64_t s;
+  int32_t H;
+  __device__ __forceinline__ int32_t pos(int32_t t) const { return run ? (int32_t)((int64_t)run[t] - s) : arr[t]; }
+};
 
 struct FastArgs {
   DrawArgs d;
   const int32_t* nhits;
+  const int32_t* hit_lo;
   const int32_t* hits;
+  const uint32_t* slot_sorted;  // nullptr: the lists are in `hits`
+  const int64_t* values;
   int32_t* general;   // [batch] 1 = this row takes the general path
   int32_t sampler;
   int32_t circular;
 };
 
-// Which rows the closed form does not serve: too many hits; without-replacement beyond the register
-// budget; and the alias samplers as soon as a single neighbour is filtered out (their table must be
-// rebuilt over the reserved weights -- rows WITHOUT a hit keep the table built at load, which is what
+__device__ __forceinline__ HitList hit_list(const FastArgs& a, int32_t i, int64_t s, int32_t H) {
+  if (a.slot_sorted) return HitList{a.slot_sorted + s + a.hit_lo[i], nullptr, s, H};
+  return HitList{nullptr, a.hits + (int64_t)i * kMaxHits, s, H};
+}
+
+// R(p) for p in [0, m), m = n - H > 0.
+__device__ __forceinline__ int32_t reserved_at(int32_t p, const HitList& h, int32_t n, const GlxAdj* __restrict__ row,
+                                               int64_t val) {
+  if (h.H == 0 || row[p].nbr != val) return p;
+  int32_t r = 0;
+  for (int32_t t = 0; t < h.H; ++t) r += h.pos(t) < p ? 1 : 0;
+  int32_t q = n - 1 - r;
+  while (true) {
+    int32_t c = 0;
+    for (int32_t t = 0; t < h.H; ++t) c += h.pos(t) >= q ? 1 : 0;
+    const int32_t q2 = n - 1 - r - c;
+    if (q2 == q) return q;
+    q = q2;
+  }
+}
+
+// Which rows the closed form does not serve: more hits than the scan lists (no index); without-replacement
+// beyond the register budget; and the alias samplers as soon as a single neighbour is filtered out (their table
+// must be rebuilt over the reserved weights -- rows WITHOUT a hit keep the table built at load, which is what
 // the reference's per-request build over the unchanged row yields).
 __global__ void glx_filter_classify_kernel(FastArgs a) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.d.batch) return;
   const int32_t H = a.nhits[i];
   const bool alias = a.sampler == GLX_SAMPLER_EDGE_WEIGHT || a.sampler == GLX_SAMPLER_IN_DEGREE;
-  bool gen = H > kMaxHits;
+  bool gen = a.slot_sorted == nullptr && H > kMaxHits;
   if (alias) gen = H > 0;
   if (a.sampler == GLX_SAMPLER_RANDOM_WITHOUT_REPLACEMENT && a.circular && a.d.k > kFastMaxK) gen = H > 0;
   a.general[i] = gen ? 1 : 0;
@@ -511,10 +518,15 @@ __global__ __launch_bounds__(256) void glx_filter_fast_topk_kernel(FastArgs a, i
   const int32_t H = a.nhits[i];
   const int32_t m = n - H;
   GlxAdj rec = GlxAdj{a.d.default_nbr, -1};
+  const int64_t s = a.d.start[i];
   if (a.circular) {
-    if (m > 0) rec = a.d.adj[a.d.start[i] + reserved_at(j % m, a.hits + (int64_t)i * kMaxHits, H, n)];
+    if (m > 0) {
+      const int32_t p = j % m;
+      rec = a.d.adj[s + p];
+      if (H > 0 && rec.nbr == a.values[i]) rec = a.d.adj[s + reserved_at(p, hit_list(a, i, s, H), n, a.d.adj + s, a.values[i])];
+    }
   } else if (j < m) {
-    rec = a.d.adj[a.d.start[i] + j];  // ReplicatePadder ignores the index values
+    rec = a.d.adj[s + j];  // ReplicatePadder ignores the index values
   }
   nbr_out[t] = rec.nbr;
   eid_out[t] = rec.eid;
@@ -537,7 +549,10 @@ __global__ void glx_filter_fast_rwor_kernel(FastArgs a, int64_t* __restrict__ nb
     }
     return;
   }
-  const int32_t* hits = a.hits + (int64_t)i * kMaxHits;
+  const int64_t s = a.d.start[i];
+  const HitList hl = hit_list(a, i, s, H);
+  const int64_t val = a.values[i];
+  const GlxAdj* __restrict__ row = a.d.adj + s;
   const uint32_t rr = a.d.rng_rows ? (uint32_t)a.d.rng_rows[i] : (uint32_t)i;
   const int32_t steps = m < k ? m : k;
   int32_t okey[kFastMaxK], oval[kFastMaxK], outv[kFastMaxK];
@@ -552,8 +567,8 @@ __global__ void glx_filter_fast_rwor_kernel(FastArgs a, int64_t* __restrict__ nb
         at_r = t;
       }
     }
-    if (aj < 0) aj = reserved_at(j, hits, H, n);
-    if (ar < 0) ar = r == j ? aj : reserved_at(r, hits, H, n);
+    if (aj < 0) aj = reserved_at(j, hl, n, row, val);
+    if (ar < 0) ar = r == j ? aj : reserved_at(r, hl, n, row, val);
     outv[j] = ar;  // entry j is final after this step
     if (r != j) {
       if (at_r >= 0) oval[at_r] = aj;
@@ -564,9 +579,8 @@ __global__ void glx_filter_fast_rwor_kernel(FastArgs a, int64_t* __restrict__ nb
       }
     }
   }
-  const int64_t s = a.d.start[i];
   for (int32_t j = 0; j < k; ++j) {
-    const GlxAdj rec = a.d.adj[s + outv[j % m]];  // j % m < steps
+    const GlxAdj rec = row[outv[j % m]];  // j % m < steps
     nbr_out[o + j] = rec.nbr;
     eid_out[o + j] = rec.eid;
   }
@@ -631,6 +645,203 @@ int64_t span_cap(size_t bytes_per_position) {
   return cap > ((int64_t)1 << 20) ? cap : ((int64_t)1 << 20);
 }
 
+// ---- one alias table per DISTINCT (vertex, filter value) pair of a request -----------------------------------
+// The reference rebuilds the table for every request row (edge_weight_sampler.cc:94-112).  The table is a function
+// of the row's reserved list and weights only, i.e. of (vertex, filter value) -- and timestamp > value filters use
+// request row 0's value for every row (filter.cc:74-82), so there the vertex alone decides.  Hop-2 frontiers of a
+// power-law graph name the same hubs thousands of times: the request rows are sorted by that pair, every distinct
+// pair gets ONE span / reserved list / table, and each request row draws from its pair's table with its own
+// random stream.  Bit-identical to the per-row build (same list, same weights, same serial algorithm).
+__global__ void glx_filter_dedup_keys_kernel(const int64_t* __restrict__ start, const int32_t* __restrict__ deg,
+                                             const int64_t* __restrict__ values, int same_value, int32_t batch,
+                                             int64_t* __restrict__ key1, int64_t* __restrict__ key2,
+                                             int32_t* __restrict__ iota) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  key1[i] = deg[i] > 0 ? start[i] : -1;
+  key2[i] = same_value ? 0 : values[i];
+  iota[i] = i;
+}
+
+__global__ void glx_filter_dedup_gather_kernel(const int64_t* __restrict__ key, const int32_t* __restrict__ perm,
+                                               int32_t batch, int64_t* __restrict__ out) {
+  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < batch) out[t] = key[perm[t]];
+}
+
+__global__ void glx_filter_dedup_flag_kernel(const int64_t* __restrict__ k1, const int64_t* __restrict__ k2,
+                                             int32_t batch, int32_t* __restrict__ flag) {
+  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch) return;
+  flag[t] = (t == 0 || k1[t] != k1[t - 1] || k2[t] != k2[t - 1]) ? 1 : 0;
+}
+
+// uid1[t] = 1 + the pair index of sorted position t (inclusive scan of the head flags).
+__global__ void glx_filter_dedup_sub_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ uid1,
+                                            const int32_t* __restrict__ perm, const int64_t* __restrict__ start,
+                                            const int32_t* __restrict__ deg, const int64_t* __restrict__ values,
+                                            int same_value, int32_t batch, int64_t* __restrict__ sub_start,
+                                            int32_t* __restrict__ sub_deg, int64_t* __restrict__ sub_deg64,
+                                            int64_t* __restrict__ sub_val, int32_t* __restrict__ run_begin) {
+  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch) return;
+  if (t == batch - 1) run_begin[uid1[t]] = batch;
+  if (!flag[t]) return;
+  const int32_t u = uid1[t] - 1, i = perm[t];
+  sub_start[u] = start[i];
+  sub_deg[u] = deg[i];
+  sub_deg64[u] = deg[i];
+  sub_val[u] = same_value ? values[0] : values[i];
+  run_begin[u] = t;
+}
+
+// k alias draws per request row from its pair's table; sorted positions [t0, t1) of the request.
+__global__ __launch_bounds__(256) void glx_filter_alias_slots_dedup_kernel(DrawArgs a, const GlxAlias* __restrict__ tab,
+                                                                           const int32_t* __restrict__ perm,
+                                                                           const int32_t* __restrict__ uid1, int32_t t0,
+                                                                           int32_t t1, const int64_t* __restrict__ rng_rows,
+                                                                           int64_t* __restrict__ nbr_out,
+                                                                           int64_t* __restrict__ eid_out) {
+  const int64_t lt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (lt >= (int64_t)(t1 - t0) * a.k) return;
+  const int32_t t = t0 + (int32_t)(lt / a.k);
+  const int32_t j = (int32_t)(lt % a.k);
+  const int32_t i = perm[t], u = uid1[t] - 1;
+  GlxAdj rec = GlxAdj{a.default_nbr, -1};
+  const int32_t m = a.deg[u] > 0 ? a.res_cnt[u] : 0;
+  if (m > 0) {
+    const uint32_t rr = rng_rows ? (uint32_t)rng_rows[i] : (uint32_t)i;
+    const int64_t off = a.soff[u] - a.base;
+    const int32_t pick = glx_alias_pick(glx_draw64(a.seed, a.cc, rr, (uint32_t)j), m, tab + off);
+    rec = a.adj[a.start[u] + a.res[off + pick]];
+  }
+  const int64_t o = (int64_t)i * a.k + j;
+  nbr_out[o] = rec.nbr;
+  eid_out[o] = rec.eid;
+}
+
+int dedup_min_rows() {
+  const char* e = getenv("GLX_FILTER_DEDUP_MIN_ROWS");  // test knob; 0 disables
+  return e ? atoi(e) : 1024;
+}
+
+#define GLX_FILTER_PRIM(call_with)                                             \
+  do {                                                                         \
+    size_t bytes__ = 0;                                                        \
+    void* tmp__ = nullptr;                                                     \
+    GLX_HIP(call_with(tmp__, bytes__));                                        \
+    int rc__ = glx_scratch_alloc(&tmp__, bytes__ ? bytes__ : 8, s, 3);         \
+    if (rc__ != GLX_OK) return rc__;                                           \
+    GLX_HIP(call_with(tmp__, bytes__));                                        \
+  } while (0)
+
+// EdgeWeight / InDegree under circular padding, any filter: start / deg are the request rows' (filled by the caller).
+int filtered_alias_dedup(const glx_graph* g, int sampler, const int64_t* d_rng, int32_t batch, int32_t k,
+                         int64_t default_nbr, uint64_t seed, uint64_t cc, FilterDev f, const int64_t* start,
+                         const int32_t* deg, int64_t* d_nbr, int64_t* d_eid, hipStream_t s) {
+  const size_t nb = (size_t)batch;
+  const bool same_value = f.field == GLX_FILTER_FIELD_TIMESTAMP && f.type == GLX_FILTER_LARGER_THAN;
+  // i64: key1 key2 k1s k2s sub_start sub_val soff_u[nb + 1] ; i32: iota permA perm flag uid1 sub_deg cnt_u run_begin[nb + 1]
+  char* buf = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&buf), (nb * 7 + 1) * 8 + (nb * 8 + 1) * 4 + 16, s, 6);
+  if (rc != GLX_OK) return rc;
+  int64_t* key1 = reinterpret_cast<int64_t*>(buf);
+  int64_t* key2 = key1 + nb;
+  int64_t* k1s = key2 + nb;
+  int64_t* k2s = k1s + nb;
+  int64_t* sub_start = k2s + nb;
+  int64_t* sub_val = sub_start + nb;
+  int64_t* soff = sub_val + nb;
+  int32_t* iota = reinterpret_cast<int32_t*>(soff + nb + 1);
+  int32_t* permA = iota + nb;
+  int32_t* perm = permA + nb;
+  int32_t* flag = perm + nb;
+  int32_t* uid1 = flag + nb;
+  int32_t* sub_deg = uid1 + nb;
+  int32_t* cnt = sub_deg + nb;
+  int32_t* run_begin = cnt + nb;
+  const unsigned row_blocks = (unsigned)((nb + 255) / 256);
+  glx_filter_dedup_keys_kernel<<<row_blocks, 256, 0, s>>>(start, deg, f.values, same_value ? 1 : 0, batch, key1, key2, iota);
+  if (same_value) {
+#define SORT1(tmp, bytes) rocprim::radix_sort_pairs(tmp, bytes, key1, k1s, iota, perm, nb, 0, 64, s)
+    GLX_FILTER_PRIM(SORT1);
+#undef SORT1
+    GLX_HIP(hipMemsetAsync(k2s, 0, nb * 8, s));
+  } else {
+    // by value first, then (stable) by vertex: rows of one (vertex, value) pair end up adjacent
+#define SORTA(tmp, bytes) rocprim::radix_sort_pairs(tmp, bytes, key2, k2s, iota, permA, nb, 0, 64, s)
+    GLX_FILTER_PRIM(SORTA);
+#undef SORTA
+    glx_filter_dedup_gather_kernel<<<row_blocks, 256, 0, s>>>(key1, permA, batch, k2s);  // k2s reused: key1 in A order
+#define SORTB(tmp, bytes) rocprim::radix_sort_pairs(tmp, bytes, k2s, k1s, permA, perm, nb, 0, 64, s)
+    GLX_FILTER_PRIM(SORTB);
+#undef SORTB
+    glx_filter_dedup_gather_kernel<<<row_blocks, 256, 0, s>>>(key2, perm, batch, k2s);
+  }
+  glx_filter_dedup_flag_kernel<<<row_blocks, 256, 0, s>>>(k1s, k2s, batch, flag);
+#define SCANF(tmp, bytes) rocprim::inclusive_scan(tmp, bytes, flag, uid1, nb, rocprim::plus<int32_t>(), s)
+  GLX_FILTER_PRIM(SCANF);
+#undef SCANF
+  glx_filter_zero_kernel<<<1, 1, 0, s>>>(soff);
+  glx_filter_dedup_sub_kernel<<<row_blocks, 256, 0, s>>>(flag, uid1, perm, start, deg, f.values, same_value ? 1 : 0, batch,
+                                                         sub_start, sub_deg, soff + 1, sub_val, run_begin);
+  int32_t U = 0;
+  GLX_HIP(hipMemcpyAsync(&U, uid1 + nb - 1, 4, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  const size_t nu = (size_t)U;
+#define SCANS(tmp, bytes) rocprim::inclusive_scan(tmp, bytes, soff + 1, soff + 1, nu, rocprim::plus<int64_t>(), s)
+  GLX_FILTER_PRIM(SCANS);
+#undef SCANS
+  std::vector<int64_t> h_soff(nu + 1);
+  std::vector<int32_t> h_run(nu + 1);
+  GLX_HIP(hipMemcpyAsync(h_soff.data(), soff, (nu + 1) * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipMemcpyAsync(h_run.data(), run_begin, (nu + 1) * 4, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  const int64_t cap = span_cap(24);
+  std::vector<int32_t> cuts{0};
+  int64_t widest = 0;
+  for (int32_t a = 0; a < U;) {
+    int32_t b = a + 1;
+    while (b < U && h_soff[b + 1] - h_soff[a] <= cap) ++b;
+    if (h_soff[b] - h_soff[a] > widest) widest = h_soff[b] - h_soff[a];
+    cuts.push_back(b);
+    a = b;
+  }
+  const size_t span = ((size_t)widest + 1) & ~(size_t)1;
+  char* work = nullptr;
+  rc = glx_scratch_alloc(reinterpret_cast<void**>(&work), span * 24 + 16, s, 2);
+  if (rc != GLX_OK) return rc;
+  GlxAlias* tab = reinterpret_cast<GlxAlias*>(work);
+  GlxAlias* stk = reinterpret_cast<GlxAlias*>(work + span * 8);
+  int32_t* res = reinterpret_cast<int32_t*>(work + span * 16);
+  float* dist = reinterpret_cast<float*>(work + span * 20);
+  FilterDev fu = f;
+  fu.values = sub_val;
+  DrawArgs da{g->adj, sub_start, sub_deg, soff, res, cnt, nullptr, seed, cc, default_nbr, U, k, 0, U, 0};
+  const GlxIdMap dm = GlxIdMap{g->dst_map.keys, g->dst_map.vals, g->dst_map.cap - 1, g->num_dst};
+  const bool by_weight = sampler == GLX_SAMPLER_EDGE_WEIGHT;
+  for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+    da.row0 = cuts[c];
+    da.nrows = cuts[c + 1] - cuts[c];
+    da.base = h_soff[da.row0];
+    const size_t nr = (size_t)da.nrows;
+    const unsigned rb = (unsigned)((nr + 255) / 256), wb = (unsigned)((nr * 64 + 255) / 256);
+    glx_filter_reserve_kernel<<<(unsigned)nr, 64, 0, s>>>(fu, g->adj, sub_start, sub_deg, soff, da.row0, da.base, res, cnt);
+    glx_filter_alias_build_kernel<<<rb, 256, 0, s>>>(da, by_weight ? g->weight : nullptr, dm, g->dst_count, dist, tab, stk);
+    glx_filter_alias_build_wave_kernel<<<wb, 256, 0, s>>>(da, by_weight ? g->weight : nullptr, dm, g->dst_count, dist, tab,
+                                                         stk);
+    const int32_t t0 = h_run[cuts[c]], t1 = h_run[cuts[c + 1]];
+    const int64_t total = (int64_t)(t1 - t0) * k;
+    if (total > 0) {
+      glx_filter_alias_slots_dedup_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(da, tab, perm, uid1, t0, t1, d_rng,
+                                                                                         d_nbr, d_eid);
+    }
+  }
+  GLX_HIP(hipGetLastError());
+  glx_scratch_trim(s, 2, (size_t)32 << 30);
+  return GLX_OK;
+}
+
 // All pointers are device pointers.  `sampler` is a GLX_SAMPLER_* id or kFullSampler (then
 // d_offsets[batch + 1] gives the segments and k is unused).
 int filtered_general(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rng, int32_t batch,
@@ -676,6 +887,13 @@ int filtered_general(const glx_graph* g, int sampler, const int64_t* d_src, cons
     timer.stop();
     GLX_HIP(hipGetLastError());
     return GLX_OK;
+  }
+  if (circular && (sampler == GLX_SAMPLER_EDGE_WEIGHT || sampler == GLX_SAMPLER_IN_DEGREE) && dedup_min_rows() > 0 &&
+      batch >= dedup_min_rows()) {
+    glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, nullptr);
+    rc = filtered_alias_dedup(g, sampler, d_rng, batch, k, default_nbr, seed, cc, f, start, deg, d_nbr, d_eid, s);
+    timer.stop();
+    return rc;
   }
   glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, soff + 1);
   glx_filter_zero_kernel<<<1, 1, 0, s>>>(soff);
@@ -761,9 +979,12 @@ int filtered_device(const glx_graph* g, int sampler, const int64_t* d_src, const
   }
   const bool circular = padding_mode == GLX_PAD_CIRCULAR;
   const size_t nb = (size_t)batch;
-  // start | sub_src | sub_rng | sub_val (i64) ; deg | nhits | general | gidx (i32) ; hits (i32 x kMaxHits) ; count
+  // start | sub_src | sub_rng | sub_val (i64) ; deg | nhits | general | gidx | hit_lo (i32) ; hits (i32 x kMaxHits,
+  // only without the index) ; count
+  const bool indexed = g->nbr_sorted && g->slot_sorted;
   char* buf = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&buf), nb * 4 * 8 + nb * 4 * 4 + nb * kMaxHits * 4 + 64, s, 4);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&buf),
+                             nb * 4 * 8 + nb * 5 * 4 + (indexed ? 0 : nb * kMaxHits * 4) + 64, s, 4);
   if (rc != GLX_OK) return rc;
   int64_t* start = reinterpret_cast<int64_t*>(buf);
   int64_t* sub_src = start + nb;
@@ -773,18 +994,22 @@ int filtered_device(const glx_graph* g, int sampler, const int64_t* d_src, const
   int32_t* nhits = deg + nb;
   int32_t* general = nhits + nb;
   int32_t* gidx = general + nb;
-  int32_t* hits = gidx + nb;
-  int32_t* count = hits + nb * kMaxHits;
+  int32_t* hit_lo = gidx + nb;
+  int32_t* hits = hit_lo + nb;
+  int32_t* count = hits + (indexed ? 0 : nb * kMaxHits);
   const unsigned row_blocks = (unsigned)((nb + 255) / 256);
   RowArgs ra{g->map(), g->row_ptr, g->adj, d_src, d_rng, batch};
   glx_filter_rows_kernel<<<row_blocks, 256, 0, s>>>(ra, start, deg, nullptr);
-  HitArgs ha{g->adj, start, deg, f.values, g->nbr_sorted, g->slot_sorted, nhits, hits, batch};
-  if (g->nbr_sorted && g->slot_sorted) glx_filter_idhits_index_kernel<<<row_blocks, 256, 0, s>>>(ha);
+  HitArgs ha{g->adj, start, deg, f.values, g->nbr_sorted, g->slot_sorted, nhits, hit_lo, hits, batch};
+  if (indexed) glx_filter_idhits_index_kernel<<<row_blocks, 256, 0, s>>>(ha);
   else glx_filter_idhits_scan_kernel<<<(unsigned)batch, 64, 0, s>>>(ha);
   FastArgs fa;
   fa.d = DrawArgs{g->adj, start, deg, nullptr, nullptr, nullptr, d_rng, seed, cc, default_nbr, batch, k, 0, batch, 0};
   fa.nhits = nhits;
+  fa.hit_lo = hit_lo;
   fa.hits = hits;
+  fa.slot_sorted = indexed ? g->slot_sorted : nullptr;
+  fa.values = f.values;
   fa.general = general;
   fa.sampler = sampler;
   fa.circular = circular ? 1 : 0;

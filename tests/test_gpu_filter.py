@@ -210,3 +210,81 @@ def test_id_equal_fast_path_bit_exact_with_oracle(orc, indexed, pad):
                                           call_counter=k, padding_mode=pad, default_neighbor_id=-3, rng_rows=rr)
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, k, pad, indexed)
     dev.close()
+
+
+@pytest.mark.parametrize("indexed", [False, True])
+def test_id_equal_rows_with_long_runs_of_parallel_edges(orc, indexed):
+    """Hub rows of a multigraph: hundreds of parallel edges to the filtered id (the run of hits is read in place
+    from the id-sorted index, in whatever order the segmented sort left it), every neighbour filtered, all hits
+    in the last positions, all in the first ones."""
+    rng = np.random.default_rng(99)
+    rows = []
+    for v, (same, others) in enumerate([(150, 50), (30, 0), (300, 3), (9, 500), (1, 1), (64, 64), (1000, 7)]):
+        d = np.concatenate([np.full(same, 7, np.int64), rng.integers(100, 10**6, others)])
+        rows.append((np.full(d.shape[0], v * 11 + 5, np.int64), d))
+    src = np.concatenate([r[0] for r in rows])
+    dst = np.concatenate([r[1] for r in rows])
+    perm = rng.permutation(src.shape[0])
+    src, dst = src[perm], dst[perm]
+    # weights place the parallel edges first (heaviest), last (lightest) or anywhere, row by row
+    w = rng.random(src.shape[0]).astype(np.float32) + 0.01
+    hit = dst == 7
+    w[hit & (src == 5)] += 10.0        # row 0: hits first
+    w[hit & (src == 27)] *= 1e-3       # row 2: hits last
+    w[hit & (src == 71)] += 10.0       # row 6: 1000 hits first
+    ts = rng.permutation(src.shape[0]).astype(np.int64)
+    dev = glx.Graph.from_edges(src, dst, w, timestamp=ts)
+    dev.enable_in_degree()
+    if indexed:
+        dev.enable_id_index()
+    og, ids = oracle_graph(orc, dev, src, ts, w)
+    ids = np.concatenate([ids, ids]).astype(np.int64)
+    vals = np.full(ids.shape[0], 7, np.int64)
+    vals[ids.shape[0] // 2:] = og["col"][og["row_ptr"][:-1]]  # second half: filter each row's first neighbour
+    flt = dict(type=glx.FILTER_EQUAL, field=glx.FILTER_FIELD_ID, values=vals)
+    for name in ("TopkSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "InDegreeSampler"):
+        for k in (1, 4, 10, 32, 40):
+            for pad in (glx.PAD_CIRCULAR, glx.PAD_REPLICATE):
+                want = orc.sample_filtered(og, name, ids, k, flt, seed=5, call_counter=k, padding_mode=pad,
+                                           default_neighbor_id=-3)
+                got = dev.sample_filtered(name, ids, k, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, seed=5,
+                                          call_counter=k, padding_mode=pad, default_neighbor_id=-3)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, k, pad, indexed)
+    dev.close()
+
+
+@pytest.mark.parametrize("kind", list(FILTERS))
+def test_alias_samplers_share_one_table_per_vertex_and_value(orc, kind, monkeypatch):
+    """EdgeWeight / InDegree with a filter: request rows naming the same (vertex, filter value) pair draw from ONE
+    table built for the pair (large requests only by default; GLX_FILTER_DEDUP_MIN_ROWS = 1 forces it here) --
+    same answers as the per-row build, also when the pairs are served in several chunks and for a shard's slice."""
+    rng = np.random.default_rng(400 + list(FILTERS).index(kind))
+    src, dst, ts, w = random_graph(rng)
+    dev = glx.Graph.from_edges(src, dst, w, timestamp=ts)
+    dev.enable_in_degree()
+    dev.enable_id_index()
+    og, rows = oracle_graph(orc, dev, src, ts, w)
+    ft, ff = FILTERS[kind]
+    ids = np.concatenate([rng.choice(rows[:60], 1500), [999999, -1, 999999]]).astype(np.int64)
+    vals = make_values(rng, og, rows, ids, kind)
+    vals[::2] = vals[0]  # many rows share their value as well
+    rev = rng.permutation(ids.shape[0]).astype(np.int64)
+    for cap in (None, "500"):
+        for name in ("EdgeWeightSampler", "InDegreeSampler"):
+            for rr in (None, rev):
+                flt = dict(type=ft, field=ff, values=vals)
+                want = orc.sample_filtered(og, name, ids, 6, flt, seed=31, call_counter=2, default_neighbor_id=-4,
+                                           rng_rows=rr)
+                monkeypatch.setenv("GLX_FILTER_DEDUP_MIN_ROWS", "0")
+                per_row = dev.sample_filtered(name, ids, 6, ft, ff, vals, seed=31, call_counter=2,
+                                              default_neighbor_id=-4, rng_rows=rr)
+                monkeypatch.setenv("GLX_FILTER_DEDUP_MIN_ROWS", "1")
+                if cap:
+                    monkeypatch.setenv("GLX_FILTER_SPAN_CAP", cap)
+                shared = dev.sample_filtered(name, ids, 6, ft, ff, vals, seed=31, call_counter=2,
+                                             default_neighbor_id=-4, rng_rows=rr)
+                monkeypatch.delenv("GLX_FILTER_SPAN_CAP", raising=False)
+                monkeypatch.delenv("GLX_FILTER_DEDUP_MIN_ROWS", raising=False)
+                assert np.array_equal(per_row[0], want[0]) and np.array_equal(per_row[1], want[1]), (name, kind)
+                assert np.array_equal(shared[0], want[0]) and np.array_equal(shared[1], want[1]), (name, kind, cap)
+    dev.close()
