@@ -286,6 +286,211 @@ __device__ inline void glx_alias_build_row_dev(const float* __restrict__ dist, i
   while (high_num > 0) tab[high[-(--high_num)].alias].prob = 1.0f;
 }
 
+// scripts/probes/alias_row_probe.hip: cycle stamps of the phases of one row
+#ifdef GLX_ALIAS_PROFILE
+__device__ unsigned long long glx_alias_prof[8];
+#define GLX_ALIAS_STAMP(i) do { if ((threadIdx.x & 63) == 0) glx_alias_prof[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GLX_ALIAS_STAMP(i) do { } while (0)
+#endif
+// The pairing loop of the wave build (see glx_alias_build_row_wave).  stk holds the low stack in [0, low_num)
+// (top = highest address) and the high stack in [count - high_num, count) (top = lowest address).
+// kNan: some probability is not finite -- compare the way IEEE does (every comparison with a NaN is false).
+template <bool kNan>
+__device__ inline void glx_alias_pair_wave(GlxAlias* __restrict__ tab, const GlxAlias* __restrict__ stk, int32_t count_v,
+                                           int32_t low_num_v, int32_t high_num_v) {
+  const int lane = threadIdx.x & 63;
+  const int32_t count = __builtin_amdgcn_readfirstlane(count_v);
+  const uint64_t tab_bits = reinterpret_cast<uint64_t>(tab);  // the same in every lane: make that known
+  GlxAlias* const tab_u = reinterpret_cast<GlxAlias*>(
+      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(tab_bits >> 32)) << 32) |
+      (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)tab_bits));
+  int32_t lows = __builtin_amdgcn_readfirstlane(low_num_v);    // entries of the low stack not yet in the current window
+  int32_t highs = __builtin_amdgcn_readfirstlane(high_num_v);
+  // windows: lane j holds the j-th next pop; `n*` = the prefetched following window
+  int32_t wl_p = 0, wl_i = 0, wh_p = 0, wh_i = 0, nl_p = 0, nl_i = 0, nh_p = 0, nh_i = 0;
+  int32_t l_n = 0, la = 0, h_n = 0, ha = 0;
+  auto fetch_low = [&](int32_t& pp, int32_t& ii) {  // the next 64 pops of what is left in memory
+    const int32_t j = lows - 1 - lane;
+    GlxAlias e = GlxAlias{0.0f, 0};
+    if (j >= 0) e = stk[j];
+    pp = __float_as_int(e.prob);
+    ii = e.alias;
+  };
+  auto fetch_high = [&](int32_t& pp, int32_t& ii) {
+    const int32_t j = highs - 1 - lane;
+    GlxAlias e = GlxAlias{0.0f, 0};
+    if (j >= 0) e = stk[count - 1 - j];
+    pp = __float_as_int(e.prob);
+    ii = e.alias;
+  };
+  fetch_low(nl_p, nl_i);
+  fetch_high(nh_p, nh_i);
+  int32_t c_p = 0, c_i = 0;  // the entry the last step left on top of a stack
+  int state = 0;             // 0: nothing carried, 1: a high is carried, 2: a low is carried
+  while (true) {
+    // ---- outer: a window ran out
+    if (state != 2 && la == l_n) {
+      if (lows == 0) break;
+      wl_p = nl_p;
+      wl_i = nl_i;
+      l_n = lows < 64 ? lows : 64;
+      lows -= l_n;
+      la = 0;
+      fetch_low(nl_p, nl_i);
+    }
+    if (state != 1 && ha == h_n) {
+      if (highs == 0) break;
+      wh_p = nh_p;
+      wh_i = nh_i;
+      h_n = highs < 64 ? highs : 64;
+      highs -= h_n;
+      ha = 0;
+      fetch_high(nh_p, nh_i);
+    }
+    // ---- inner: steps until a window runs out; touches no prefetch register, waits for no memory.
+    // A step: p = high - 1 + low; low's alias = high; p > 1: `high` stays on top of the high stack (carried);
+    // else it leaves with probability p and, below 1, is the next low (carried).
+    int32_t xa = __builtin_amdgcn_readfirstlane(la), ya = __builtin_amdgcn_readfirstlane(ha);
+    const int32_t xn = __builtin_amdgcn_readfirstlane(l_n), yn = __builtin_amdgcn_readfirstlane(h_n);
+    int st = __builtin_amdgcn_readfirstlane(state);
+    int32_t kp = __builtin_amdgcn_readfirstlane(c_p), ki = __builtin_amdgcn_readfirstlane(c_i);
+    if constexpr (!kNan) {
+      // Hand-scheduled: the compiler turns the three-state machine into mask-valued booleans and dispatch codes
+      // (45-55 instructions per step).  Written out: the entry a step leaves on top of a stack is carried in two
+      // VGPRs (probability, index; every lane holds the same value), a pop is two v_readlane, the decision is a
+      // v_cmp + s_cbranch_vccnz -- 12 instructions while a high stays carried, ~16 otherwise.
+      // gfx950 wait states respected by construction: an SGPR written by v_readlane is read by a VALU
+      // instruction no sooner than the third instruction after it; lane selects are written by SALU.
+      int32_t s_p, s_i, v_t, v_off;
+      int32_t v_kp = kp, v_ki = ki;
+      asm volatile(
+          "s_mov_b64 exec, 1\n\t"  // lane 0 alone: a 64-lane store to one address is 64 conflicting writes
+          "s_cmp_eq_u32 %[st], 1\n\t"
+          "s_cbranch_scc1 .Lglx_high%=\n\t"
+          "s_cmp_eq_u32 %[st], 2\n\t"
+          "s_cbranch_scc1 .Lglx_low%=\n"
+          ".Lglx_none%=:\n\t"  // nothing carried: pop a low and a high
+          "s_mov_b32 %[st], 0\n\t"
+          "s_cmp_ge_i32 %[xa], %[xn]\n\t"
+          "s_cbranch_scc1 .Lglx_out%=\n\t"
+          "s_cmp_ge_i32 %[ya], %[yn]\n\t"
+          "s_cbranch_scc1 .Lglx_out%=\n\t"
+          "v_readlane_b32 %[sp], %[whp], %[ya]\n\t"
+          "v_readlane_b32 %[si], %[whi], %[ya]\n\t"
+          "s_add_i32 %[ya], %[ya], 1\n\t"
+          "s_nop 0\n\t"
+          "v_mov_b32 %[vkp], %[sp]\n\t"
+          "v_mov_b32 %[vki], %[si]\n"
+          ".Lglx_high%=:\n\t"  // (vkp, vki) is the top of the high stack: pop a low
+          "s_mov_b32 %[st], 1\n\t"
+          "s_cmp_ge_i32 %[xa], %[xn]\n\t"
+          "s_cbranch_scc1 .Lglx_out%=\n"
+          ".Lglx_high_go%=:\n\t"
+          "v_readlane_b32 %[sp], %[wlp], %[xa]\n\t"
+          "v_readlane_b32 %[si], %[wli], %[xa]\n\t"
+          "v_add_f32 %[vkp], -1.0, %[vkp]\n\t"
+          "s_add_i32 %[xa], %[xa], 1\n\t"
+          "v_lshlrev_b32 %[voff], 3, %[si]\n\t"
+          "v_add_f32 %[vkp], %[sp], %[vkp]\n\t"
+          "global_store_dword %[voff], %[vki], %[tab] offset:4\n\t"
+          "v_cmp_lt_f32 vcc, 1.0, %[vkp]\n\t"
+          "s_cbranch_vccz .Lglx_leave%=\n\t"
+          "s_cmp_lt_i32 %[xa], %[xn]\n\t"  // still above 1: the same high takes the next low
+          "s_cbranch_scc1 .Lglx_high_go%=\n\t"
+          "s_branch .Lglx_out%=\n"
+          ".Lglx_leave%=:\n\t"  // (vkp, vki) leaves the high stack with probability vkp <= 1
+          "v_lshlrev_b32 %[voff], 3, %[vki]\n\t"
+          "v_cmp_eq_f32 vcc, 1.0, %[vkp]\n\t"
+          "global_store_dword %[voff], %[vkp], %[tab]\n\t"
+          "s_cbranch_vccnz .Lglx_none%=\n"
+          ".Lglx_low%=:\n\t"  // (vkp, vki) is the top of the low stack: pop a high
+          "s_mov_b32 %[st], 2\n\t"
+          "s_cmp_ge_i32 %[ya], %[yn]\n\t"
+          "s_cbranch_scc1 .Lglx_out%=\n\t"
+          "v_readlane_b32 %[sp], %[whp], %[ya]\n\t"
+          "v_readlane_b32 %[si], %[whi], %[ya]\n\t"
+          "v_lshlrev_b32 %[voff], 3, %[vki]\n\t"
+          "s_add_i32 %[ya], %[ya], 1\n\t"
+          "v_add_f32 %[vt], -1.0, %[sp]\n\t"
+          "v_mov_b32 %[vki], %[si]\n\t"
+          "v_add_f32 %[vkp], %[vkp], %[vt]\n\t"
+          "global_store_dword %[voff], %[vki], %[tab] offset:4\n\t"
+          "v_cmp_lt_f32 vcc, 1.0, %[vkp]\n\t"
+          "s_cbranch_vccz .Lglx_leave%=\n\t"
+          "s_branch .Lglx_high%=\n"
+          ".Lglx_out%=:\n\t"
+          "s_mov_b64 exec, -1\n\t"
+          : [st] "+s"(st), [xa] "+s"(xa), [ya] "+s"(ya), [vkp] "+v"(v_kp), [vki] "+v"(v_ki), [sp] "=&s"(s_p),
+            [si] "=&s"(s_i), [vt] "=&v"(v_t), [voff] "=&v"(v_off)
+          : [xn] "s"(xn), [yn] "s"(yn), [wlp] "v"(wl_p), [wli] "v"(wl_i), [whp] "v"(wh_p), [whi] "v"(wh_i),
+            [tab] "s"(tab_u)
+          : "memory", "scc", "vcc");
+      kp = __builtin_amdgcn_readfirstlane(v_kp);
+      ki = __builtin_amdgcn_readfirstlane(v_ki);
+    } else {
+      char* const tab_b = reinterpret_cast<char*>(tab);
+      while (true) {
+        if (st == 1) {
+          // a high is carried: it takes low after low while it stays above 1
+          bool out = false;
+          float p;
+          do {
+            if (xa >= xn) {
+              out = true;
+              break;
+            }
+            const int32_t lp = __builtin_amdgcn_readlane(wl_p, xa), li = __builtin_amdgcn_readlane(wl_i, xa);
+            ++xa;
+            p = __int_as_float(kp) - 1.0f + __int_as_float(lp);
+            kp = __builtin_amdgcn_readfirstlane(__float_as_int(p));
+            *reinterpret_cast<int32_t*>(tab_b + ((uint32_t)li << 3) + 4) = ki;
+          } while (kNan ? ((kp & 0x7fffffff) <= 0x7f800000 && kp > 0x3f800000) : kp > 0x3f800000);
+          if (out) break;
+          *reinterpret_cast<float*>(tab_b + ((uint32_t)ki << 3)) = p;
+          st = (kNan && (kp & 0x7fffffff) > 0x7f800000) ? 0 : (kp < 0x3f800000 ? 2 : 0);
+          continue;
+        }
+        int32_t lp, li;
+        if (st == 2) {
+          if (ya >= yn) break;
+          lp = kp;
+          li = ki;
+        } else {
+          if (xa >= xn || ya >= yn) break;
+          lp = __builtin_amdgcn_readlane(wl_p, xa);
+          li = __builtin_amdgcn_readlane(wl_i, xa);
+          ++xa;
+        }
+        const int32_t hp = __builtin_amdgcn_readlane(wh_p, ya);
+        ki = __builtin_amdgcn_readlane(wh_i, ya);
+        ++ya;
+        const float p = __int_as_float(hp) - 1.0f + __int_as_float(lp);
+        kp = __builtin_amdgcn_readfirstlane(__float_as_int(p));
+        *reinterpret_cast<int32_t*>(tab_b + ((uint32_t)li << 3) + 4) = ki;
+        if (!(kNan && (kp & 0x7fffffff) > 0x7f800000) && kp > 0x3f800000) {
+          st = 1;
+          continue;
+        }
+        *reinterpret_cast<float*>(tab_b + ((uint32_t)ki << 3)) = p;
+        st = (kNan && (kp & 0x7fffffff) > 0x7f800000) ? 0 : (kp < 0x3f800000 ? 2 : 0);
+      }
+    }
+    la = xa;
+    ha = ya;
+    state = st;
+    c_p = kp;
+    c_i = ki;
+  }
+  GLX_ALIAS_STAMP(3);
+  // ---- whatever is left on either stack has probability 1
+  if (state != 0 && lane == 0) tab[c_i].prob = 1.0f;
+  if (lane >= la && lane < l_n) tab[wl_i].prob = 1.0f;
+  if (lane >= ha && lane < h_n) tab[wh_i].prob = 1.0f;
+  for (int32_t j = lane; j < lows; j += 64) tab[stk[j].alias].prob = 1.0f;
+  for (int32_t j = lane; j < highs; j += 64) tab[stk[count - 1 - j].alias].prob = 1.0f;
+}
+
 // The same build once more, for a whole WAVE per distribution (long rows: the per-lane version walks
 // a 100 K-entry hub row alone while 63 lanes of its wave wait).  Bit-identical again:
 //   sum       every lane adds a strided share in double and the wave combines them.  That is only
@@ -296,17 +501,20 @@ __device__ inline void glx_alias_build_row_dev(const float* __restrict__ dist, i
 //             are integers: both qualify up to 2^20-entry rows.)  Otherwise lane 0 adds sequentially.
 //   classify  prob / table entry per position in parallel; the low and high stacks are filled by ballot
 //             compaction, which keeps the push order of the serial loop (ascending position).
-//   pairing   inherently serial (each step's float result decides the next): lane 0 runs the loop of
-//             glx_alias_build_row_dev, but never waits for global memory -- the other lanes refill two LDS
-//             windows with the next kAliasWindow entries of each stack (coalesced), lane 0 pops from LDS,
-//             and its table updates are fire-and-forget stores.
-// All 64 lanes of the wave call it with the same arguments; `lds` = 2 * kAliasWindow entries private to the wave.
-constexpr int kAliasWindow = 256;
+//   pairing   inherently serial (each step's float result decides the next), so the cost is instructions per step
+//             of ONE wave (a wave issues one instruction every few cycles whatever its width).  The machine of
+//             glx_alias_build_row_dev runs on wave-uniform state: the next 64 pops of each stack sit one per
+//             lane in a register (window), a pop is a v_readlane with a scalar lane index, the entry a step
+//             leaves on top of a stack is carried in scalar registers, the step's float result goes to a scalar
+//             register and the three-way decision (p < 1 / == 1 / > 1) is an integer compare and a scalar
+//             branch between three straight-line states -- no exec masking, no LDS, no selects.  The following
+//             window of each stack is prefetched (coalesced) while the current one is consumed.
+// All 64 lanes of the wave call it with the same arguments.
 constexpr int kAliasLaneRowMax = 96;  // rows up to this length are built by one lane (64 rows per wave)
 __device__ inline void glx_alias_build_row_wave(const float* __restrict__ dist, int32_t count,
-                                                GlxAlias* __restrict__ tab, GlxAlias* __restrict__ stk,
-                                                GlxAlias* __restrict__ lds) {
+                                                GlxAlias* __restrict__ tab, GlxAlias* __restrict__ stk) {
   const int lane = threadIdx.x & 63;
+  GLX_ALIAS_STAMP(0);
   const uint64_t lt = (1ull << lane) - 1ull;
   // ---- sum
   double acc = 0.0;
@@ -346,8 +554,10 @@ __device__ inline void glx_alias_build_row_wave(const float* __restrict__ dist, 
   }
   const float sum = (float)acc;
   const float avg_prob = (float)(1.0 / (double)count);
+  GLX_ALIAS_STAMP(1);
   // ---- classify: low stack grows up from stk[0], high stack down from stk[count - 1]
   int32_t low_num = 0, high_num = 0;
+  bool bad = false;  // a probability that is not finite: the pairing loop must compare like IEEE (NaN is unordered)
   for (int32_t base = 0; base < count; base += 64) {
     const int32_t i = base + lane;
     bool is_low = false, is_high = false;
@@ -355,6 +565,7 @@ __device__ inline void glx_alias_build_row_wave(const float* __restrict__ dist, 
     if (i < count) {
       const float prob = dist[i] / sum;
       e = GlxAlias{prob * (float)count, i};
+      bad = bad || (__float_as_uint(e.prob) & 0x7f800000u) == 0x7f800000u;
       tab[i] = e;
       is_low = prob < avg_prob;
       is_high = prob > avg_prob;
@@ -366,76 +577,13 @@ __device__ inline void glx_alias_build_row_wave(const float* __restrict__ dist, 
     high_num += __popcll(bh);
   }
   __threadfence_block();
-  // ---- pairing
-  GlxAlias* wl = lds;
-  GlxAlias* wh = lds + kAliasWindow;
-  int32_t l_n = 0, l_at = 0, h_n = 0, h_at = 0;  // windows: entries [at, n) are still to be popped, in pop order
-  bool have_lo = false, have_hi = false;
-  GlxAlias lo = GlxAlias{0.0f, 0}, hi = GlxAlias{0.0f, 0};  // .alias carries the entry's own index here
-  while (true) {
-    if (l_at == l_n && low_num > 0) {  // next window of the low stack: pop order = descending address
-      const int32_t n = low_num < kAliasWindow ? low_num : kAliasWindow;
-      for (int32_t j = lane; j < n; j += 64) wl[j] = stk[low_num - 1 - j];
-      low_num -= n;
-      l_n = n;
-      l_at = 0;
-    }
-    if (h_at == h_n && high_num > 0) {  // high stack: pop order = ascending address from its top
-      const int32_t n = high_num < kAliasWindow ? high_num : kAliasWindow;
-      for (int32_t j = lane; j < n; j += 64) wh[j] = stk[count - high_num + j];
-      high_num -= n;
-      h_n = n;
-      h_at = 0;
-    }
-    __threadfence_block();
-    if (lane == 0) {
-      // The serial machine of glx_alias_build_row_dev, written without branches in the body: which entries a
-      // step takes (the carried low / high or the next window entry) and what it leaves behind are selects on
-      // the previous step's two comparisons; the window entries of the NEXT step are loaded as soon as their
-      // addresses are known, i.e. before this step's float chain, so LDS latency is off the critical path.
-      // Per step: select, subtract, add, compare, select -- and two fire-and-forget stores.
-      int32_t la = l_at, ha = h_at;
-      bool hl = have_lo, hh = have_hi;
-      GlxAlias nl = wl[la < kAliasWindow ? la : kAliasWindow - 1];
-      GlxAlias nh = wh[ha < kAliasWindow ? ha : kAliasWindow - 1];
-      while ((hl || la < l_n) && (hh || ha < h_n)) {
-        const GlxAlias cl = hl ? lo : nl;
-        const GlxAlias ch = hh ? hi : nh;
-        la += hl ? 0 : 1;
-        ha += hh ? 0 : 1;
-        nl = wl[la < kAliasWindow ? la : kAliasWindow - 1];
-        nh = wh[ha < kAliasWindow ? ha : kAliasWindow - 1];
-        const float p = ch.prob - 1.0f + cl.prob;
-        tab[cl.alias].alias = ch.alias;
-        const bool lt = p < 1.0f, gt = p > 1.0f;
-        if (!gt) tab[ch.alias].prob = p;  // leaves the high stack: below 1 it becomes the next low, at 1 it is done
-        hi = GlxAlias{p, ch.alias};       // p > 1: still the top of the high stack (final prob written when it leaves)
-        lo = hi;                          // meaningful when p < 1 only
-        hl = lt;
-        hh = gt;
-      }
-      l_at = la;
-      h_at = ha;
-      have_lo = hl;
-      have_hi = hh;
-    }
-    l_at = __shfl(l_at, 0);
-    h_at = __shfl(h_at, 0);
-    have_lo = __shfl((int)have_lo, 0) != 0;
-    have_hi = __shfl((int)have_hi, 0) != 0;
-    const int32_t lows_left = low_num + (l_n - l_at) + (have_lo ? 1 : 0);
-    const int32_t highs_left = high_num + (h_n - h_at) + (have_hi ? 1 : 0);
-    if (lows_left == 0 || highs_left == 0) break;
+  GLX_ALIAS_STAMP(2);
+  if (__any(bad)) {
+    glx_alias_pair_wave<true>(tab, stk, count, low_num, high_num);
+  } else {
+    glx_alias_pair_wave<false>(tab, stk, count, low_num, high_num);
   }
-  // ---- whatever is left on either stack has probability 1
-  if (lane == 0) {
-    if (have_lo) tab[lo.alias].prob = 1.0f;
-    if (have_hi) tab[hi.alias].prob = 1.0f;
-  }
-  for (int32_t j = l_at + lane; j < l_n; j += 64) tab[wl[j].alias].prob = 1.0f;
-  for (int32_t j = h_at + lane; j < h_n; j += 64) tab[wh[j].alias].prob = 1.0f;
-  for (int32_t j = lane; j < low_num; j += 64) tab[stk[j].alias].prob = 1.0f;
-  for (int32_t j = lane; j < high_num; j += 64) tab[stk[count - 1 - j].alias].prob = 1.0f;
+  GLX_ALIAS_STAMP(4);
 }
 
 // ------------------------------------------------------------- contract RNG -

@@ -267,7 +267,6 @@ __global__ __launch_bounds__(256) void glx_filter_alias_build_wave_kernel(DrawAr
                                                                           const int64_t* __restrict__ dst_count,
                                                                           float* __restrict__ dist, GlxAlias* __restrict__ tab,
                                                                           GlxAlias* __restrict__ stk) {
-  __shared__ GlxAlias windows[4][2 * kAliasWindow];
   const int32_t li = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   const int lane = threadIdx.x & 63;
   const int32_t i = a.row0 + li;
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(256) void glx_filter_alias_build_wave_kernel(DrawAr
     dist[off + t] = w;
   }
   __threadfence_block();
-  glx_alias_build_row_wave(dist + off, m, tab + off, stk + off, windows[threadIdx.x >> 6]);
+  glx_alias_build_row_wave(dist + off, m, tab + off, stk + off);
 }
 
 // EdgeWeight / InDegree slots under circular padding: k alias draws mapped back through the

@@ -473,13 +473,12 @@ __global__ __launch_bounds__(256) void glx_alias_build_wave_kernel(const int64_t
                                                                    const float* __restrict__ weight, int64_t V,
                                                                    GlxAlias* __restrict__ out,
                                                                    GlxAlias* __restrict__ stk) {
-  __shared__ GlxAlias windows[4][2 * kAliasWindow];
   const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (row >= V) return;
   const int64_t s = row_ptr[row];
   const int32_t count = (int32_t)(row_ptr[row + 1] - s);
   if (count <= kAliasLaneRowMax) return;
-  glx_alias_build_row_wave(weight + s, count, out + s, stk + s, windows[threadIdx.x >> 6]);
+  glx_alias_build_row_wave(weight + s, count, out + s, stk + s);
 }
 
 // Packs {prob, (nbr, eid) of the slot, (nbr, eid) of its alias} per slot; *bad is set
