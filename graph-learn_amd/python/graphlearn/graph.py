@@ -134,6 +134,15 @@ class Graph(object):
     errors.raise_exception_on_not_ok_status(self._server.init_status())
     return self
 
+  def sharded_store_cached(self, edge_type, node_type=None):
+    """sharded_store(edge_type, node_type) on the default process group, created once per (edge type, node
+    type): a store owns a communicator, so the samplers of the Python API share it."""
+    stores = self.__dict__.setdefault("_sharded_stores", {})
+    key = (edge_type, node_type)
+    if key not in stores:
+      stores[key] = self.sharded_store(edge_type, node_type)
+    return stores[key]
+
   def sharded_store(self, edge_type, node_type=None, group=None, replicate_features=False, hot_nodes=0):
     """The edge type (and optionally a node type's float attributes) across all shards of an
     init(task_index, task_count) job, as a dist.ShardedStore: `store.sample(sampler, cuda_ids, k, ...)`

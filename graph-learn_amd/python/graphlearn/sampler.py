@@ -125,15 +125,28 @@ class NeighborSampler(object):
     """All hops in one engine call on torch CUDA tensors (glx_sample_hops): the hop-h frontier is
     hop h-1's output and never leaves HBM.  ids: int64 CUDA tensor [B].
     -> [(neighbor ids [rows_h, k_h], edge ids [rows_h, k_h]) per hop], CUDA tensors.
-    Same draws as get() with set_call_counter(call_counter) under the same seed."""
+    Same draws as get() with set_call_counter(call_counter) under the same seed.  In SPMD mode the call is
+    collective: every rank passes its own batch (torch.distributed must be initialised)."""
     import glx
     self._check()
     if self._strategy == "full":
       raise ValueError("the full sampler returns ragged rows; use get()")
     if self._filtered():
       raise ValueError("filtered sampling goes hop by hop; use get(ids, filter_values=...)")
-    graphs = [self._graph.device_graph(e) for e in self._meta_path]
     seed = _flag("sampling_seed") if seed is None else seed
+    if getattr(self._graph, "_shard", (0, 1))[1] > 1:
+      # SPMD mode (Graph.init(task_index, task_count)): every hop is a collective request to the partitioned store
+      # (rows travel to their owners over RCCL, glx_dist_sample); same draws as one store, for any shard count
+      out, frontier = [], ids
+      for hop, edge_type in enumerate(self._meta_path):
+        store = self._graph.sharded_store_cached(edge_type)
+        nbr, eid = store.sample(self._op, frontier.reshape(-1), int(self._expand_factor[hop]), seed=seed,
+                                call_counter=call_counter + hop, padding_mode=_flag("padding_mode"),
+                                default_neighbor_id=_flag("default_neighbor_id"))
+        out.append((nbr, eid))
+        frontier = nbr
+      return out
+    graphs = [self._graph.device_graph(e) for e in self._meta_path]
     return glx.sample_hops(graphs, self._op, ids, [int(k) for k in self._expand_factor], seed=seed,
                            call_counter=call_counter, padding_mode=_flag("padding_mode"),
                            default_neighbor_id=_flag("default_neighbor_id"))
