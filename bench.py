@@ -401,6 +401,11 @@ def main():
     ap.add_argument("--setup-watchdog", type=float, default=900.0,
                     help="N>1: seconds everything before the timed legs may take (process group, communicators, "
                          "store build, replica fetch)")
+    ap.add_argument("--graph-replica", default="on", choices=["on", "off"],
+                    help="N>1: also replicate the hot vertices' adjacency rows (their sampling requests stay local)")
+    ap.add_argument("--graph-hot-fraction", type=float, default=None,
+                    help="N>1: fraction of the vertices (hottest first) whose adjacency rows are replicated; "
+                         "default: --hot-fraction")
     ap.add_argument("--hot-by", default="indegree", choices=["access", "indegree"],
                     help="N>1: how the replicated rows are chosen: by access count over a few profiling requests, or by "
                          "global in-degree (glx_dist_hot_ids: needs no request profile)")
@@ -554,16 +559,38 @@ def main():
         torch.cuda.synchronize()
         log("hot-row replica (%s): %d rows (%.2f GB per GPU) selected + fetched in %.1fs"
             % (args.hot_by, hot.shape[0], hot.shape[0] * D * 4 / 1e9, time.time() - t_hot))
+        graph_replica = None
+        if args.graph_replica == "on" and hot.shape[0] > 0:
+            # the same vertices' adjacency rows on every GPU: hop-2 request rows are hop-1 samples, i.e. mostly hubs,
+            # and those are then sampled here instead of travelling to their owner and back.  Every rank holds the
+            # synthetic edge list, so the rows are cut from it directly (a loader would read the hot rows' edges
+            # on every rank); same edge order as the owner's shard => same rows, same alias tables.
+            t_rep = time.time()
+            g_hot = hot if args.graph_hot_fraction is None else hot[:int(V * args.graph_hot_fraction)]
+            is_hot = torch.zeros(V, dtype=torch.bool, device=dev)
+            is_hot[torch.from_numpy(g_hot).to(dev)] = True
+            keep = is_hot[src]
+            r_eids = torch.nonzero(keep).view(-1)
+            graph_replica = glx.Graph.from_edges(src[keep].contiguous(), dst[keep].contiguous(),
+                                                 weight[keep].contiguous() if weight is not None else None,
+                                                 edge_ids=r_eids, device=local_rank)
+            st_smp.set_graph_replica(graph_replica)
+            del is_hot, keep, r_eids
+            torch.cuda.synchronize()
+            log("graph replica: the out-edges of the hottest %d vertices, %d of %d edges, built in %.1fs"
+                % (g_hot.shape[0], graph_replica.num_edges, E, time.time() - t_rep))
         if args.features != "sharded" and V * D * 4 <= 96 * (1 << 30):
             # the other end of the placement space: the whole table on every GPU (one load-time all-gather)
             full = gdist.replicate_features(x_shard, V) if world > 1 else X
             replica = glx.Features(full, device=local_rank)
             del full
         del x_shard
-        placement = ("graph + features edge-cut llabs(v)%%%d; per hop: RCCL send/recv exchange of request rows; "
+        placement = ("graph + features edge-cut llabs(v)%%%d%s; per hop: RCCL send/recv exchange of the request rows the "
+                     "replica does not hold; "
                      "aggregation: own shard + replica of the top %.0f%% rows by %s + per-request halo exchange "
                      "of the deduplicated cold tail, prefetched beside the previous step's reduce (glx_dist_*)"
-                     % (world, 100 * args.hot_fraction, "access count" if args.hot_by == "access" else "in-degree"))
+                     % (world, " + adjacency rows of the hot vertices on every GPU" if graph_replica is not None else "",
+                        100 * args.hot_fraction, "access count" if args.hot_by == "access" else "in-degree"))
     del src, dst, weight
     X = None
     torch.cuda.empty_cache()
@@ -840,6 +867,7 @@ def main():
             elapsed, t_agg, t_smp, headline = el_h, ta_h, ts_h, "features_sharded"
         # what crossed the links for one hop-2 request (this rank's view)
         a_last, b_last = do_sample(n_steps - 1)
+        sample_rows = st_smp.last_sample_rows()  # the hop-2 request
         st_agg.aggregate(agg, b_last.view(-1), None, n1, out=(emb2, cnt2))
         torch.cuda.synchronize()
         halo_stats = st_agg.stats()
@@ -981,6 +1009,14 @@ def main():
                                          hot_rows_chosen_by=args.hot_by,
                                          note="one rank's last hop-2 request: ids by source, distinct halo rows, "
                                               "bytes over the transport")
+        res["sampling_exchange_hop2"] = dict(sample_rows, graph_replica_edges=(graph_replica.num_edges if graph_replica
+                                                                               is not None else 0), graph_edges=E,
+                                             note="one rank's last hop-2 request: rows served by the local graph "
+                                                  "replica / sent to another rank")
+        res["sampling_exchange_hop2"] = dict(sample_rows, graph_replica_edges=(graph_replica.num_edges if graph_replica
+                                                                               is not None else 0), graph_edges=E,
+                                             note="one rank's last hop-2 request: rows served by the local graph "
+                                                  "replica / sent to another rank")
     if verified is not None:
         res["verified_sharded_equals_unpartitioned"] = verified
     if cpu:

@@ -136,6 +136,9 @@ struct GlxIdMapStorage {
 };
 // Builds the table for ids[num_rows] (device pointer) on `s`.
 int glx_idmap_build(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out, hipStream_t s);
+// glx_partition with one more bucket (the last) for the ids `divert` knows; counts has num_shards + 1 entries.
+int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert,
+                         int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s);
 void glx_idmap_free(GlxIdMapStorage* m);
 
 // ---------------------------------------------------------------- handles ---

@@ -435,6 +435,8 @@ inline uint64_t pow2_at_least(uint64_t x) {
 struct glx_dist_store {
   glx_comm* comm = nullptr;
   const glx_graph* graph = nullptr;
+  const glx_graph* graph_replica = nullptr;  // complete rows of the hot vertices, borrowed (glx_dist_store_set_graph_replica)
+  int64_t sample_rows = 0, sample_rows_replica = 0, sample_rows_remote = 0;  // the last glx_dist_sample
   const glx_features* feats = nullptr;
   glx_features* cache = nullptr;
   PackedSlot* cache_slots = nullptr;  // the replica's id map, packed (glx_dist_pack_map_kernel)
@@ -655,7 +657,16 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   int64_t* nbr_back = reinterpret_cast<int64_t*>(st->req.p + o_nb);
   int64_t* eid_back = reinterpret_cast<int64_t*>(st->req.p + o_eb);
 
-  rc = glx_partition(st->device, src, n, P, bucketed, order, st->d_vals, s);
+  // Rows of vertices the graph replica holds are served here, from the same adjacency (and alias tables) their
+  // owner holds and with the same random stream (their index in the request): they form one more bucket, last.
+  const glx_graph* rg = st->graph_replica;
+  const bool divert = rg != nullptr && !filtered && sampler != GLX_SAMPLER_IN_DEGREE &&
+                      (sampler != GLX_SAMPLER_EDGE_WEIGHT || rg->weight != nullptr);
+  if (divert) {
+    rc = glx_partition_divert(st->device, src, n, P, rg->map(), bucketed, order, st->d_vals, s);
+  } else {
+    rc = glx_partition(st->device, src, n, P, bucketed, order, st->d_vals, s);
+  }
   if (rc != GLX_OK) return rc;
   if (filtered && n > 0) {
     // every row's filter value travels with its id (HashPartitioner copies every tensor of a
@@ -713,6 +724,21 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   rc = st->comm->alltoallv(out_segs, filtered ? 3 : 2, rt.send_counts.data(), rt.send_offs.data(),
                            rt.recv_counts.data(), rt.recv_offs.data(), s);
   if (rc != GLX_OK) return rc;
+  int64_t sent = 0;
+  for (int q = 0; q < P; ++q) sent += rt.send_counts[q];
+  st->sample_rows = n;
+  st->sample_rows_replica = n - sent;
+  st->sample_rows_remote = sent - rt.send_counts[st->rank];
+  if (divert && n > sent) {
+    // the replica's bucket: straight into the tail of the response buffers the stitch reads
+    const int64_t chunk_r = k > 0 ? (int64_t)INT32_MAX / k : n;
+    for (int64_t lo = sent; lo < n; lo += chunk_r) {
+      const int64_t cnt = n - lo < chunk_r ? n - lo : chunk_r;
+      rc = glx_sample_ex(rg, sampler, bucketed + lo, order + lo, (int32_t)cnt, k, padding_mode, default_neighbor_id, seed,
+                         call_counter, nbr_back + lo * k, eid_back + lo * k, GLX_PTR_DEVICE, s);
+      if (rc != GLX_OK) return rc;
+    }
+  }
 
   // Process on the owner: rows draw from the random stream of their ORIGINAL index, with their
   // requester's seed / call counter / flags.  One launch when every rank sent the same
@@ -792,6 +818,29 @@ extern "C" int glx_dist_store_create(glx_comm* comm, const glx_graph* graph, con
     GLX_HIP(e);
   }
   *out = st;
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_graph* replica) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  if (replica != nullptr) {
+    GLX_REQUIRE(replica->device == st->device, "the replica lives on device %d, the store on %d", replica->device,
+                st->device);
+    GLX_REQUIRE(replica->idmap.keys != nullptr, "a graph replica needs its vertex ids (glx_graph_build with ids)");
+    GLX_REQUIRE((replica->weight != nullptr) == (st->graph->weight != nullptr),
+                "the replica and the shard must both be weighted or both unweighted");
+  }
+  st->graph_replica = replica;
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_last_sample_rows(const glx_dist_store* st, int64_t* rows, int64_t* from_replica,
+                                         int64_t* remote) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  if (rows) *rows = st->sample_rows;
+  if (from_replica) *from_replica = st->sample_rows_replica;
+  if (remote) *remote = st->sample_rows_remote;
   return GLX_OK;
 }
 

@@ -17,9 +17,16 @@ __device__ __forceinline__ int32_t shard_of(int64_t id, int32_t P) {
   return (int32_t)(a % (uint64_t)P);
 }
 
+// With a divert map the request has one bucket more: ids the map knows go to bucket P - 1 (rows a local replica
+// serves, glx_dist.hip), everything else to llabs(id) % (P - 1).
+__device__ __forceinline__ int32_t bucket_of(int64_t id, int32_t P, const GlxIdMap& divert) {
+  if (divert.keys == nullptr) return shard_of(id, P);
+  return glx_row_of(divert, id) >= 0 ? P - 1 : shard_of(id, P - 1);
+}
+
 // block_counts is shard-major: [P][nblocks].
 __global__ __launch_bounds__(256) void glx_part_count_kernel(const int64_t* __restrict__ ids, int64_t n,
-                                                             int32_t P, int64_t nblocks,
+                                                             int32_t P, int64_t nblocks, GlxIdMap divert,
                                                              int64_t* __restrict__ block_counts) {
   __shared__ int32_t cnt[kMaxShards];
   if (threadIdx.x < kMaxShards) cnt[threadIdx.x] = 0;
@@ -27,7 +34,7 @@ __global__ __launch_bounds__(256) void glx_part_count_kernel(const int64_t* __re
   const int64_t base = blockIdx.x * (int64_t)kTile;
   for (int it = 0; it < kTile / 256; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[shard_of(ids[i], P)], 1);
+    if (i < n) atomicAdd(&cnt[bucket_of(ids[i], P, divert)], 1);
   }
   __syncthreads();
   if (threadIdx.x < P) block_counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = cnt[threadIdx.x];
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(1024) void glx_part_scan_kernel(int64_t* __restrict
 }
 
 __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __restrict__ ids, int64_t n,
-                                                               int32_t P, int64_t nblocks,
+                                                               int32_t P, int64_t nblocks, GlxIdMap divert,
                                                                const int64_t* __restrict__ block_off,
                                                                int64_t* __restrict__ bucketed,
                                                                int64_t* __restrict__ order) {
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __
     const int64_t i = base + it * 256 + threadIdx.x;
     const bool valid = i < n;
     const int64_t id = valid ? ids[i] : 0;
-    const int32_t sh = valid ? shard_of(id, P) : -1;
+    const int32_t sh = valid ? bucket_of(id, P, divert) : -1;
     int32_t my_rank = 0;
     for (int32_t p = 0; p < P; ++p) {
       const uint64_t b = __ballot(sh == p);
@@ -124,6 +131,27 @@ __global__ __launch_bounds__(256) void glx_stitch_kernel(const T* __restrict__ i
 
 }  // namespace
 
+static int partition_impl(int device, const int64_t* ids, int64_t n, int32_t num_buckets, GlxIdMap divert,
+                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s) {
+  if (n == 0) {
+    GLX_HIP(hipMemsetAsync(counts, 0, (size_t)num_buckets * sizeof(int64_t), s));
+    return GLX_OK;
+  }
+  const int64_t nblocks = (n + kTile - 1) / kTile;
+  int64_t* block_counts = nullptr;
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&block_counts),
+                             (size_t)num_buckets * nblocks * sizeof(int64_t), s, 1);
+  if (rc != GLX_OK) return rc;
+  glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts);
+  glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_buckets, counts);
+  glx_part_scatter_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
+                                                           bucketed, order);
+  hipError_t e = hipGetLastError();
+  glx_scratch_free(block_counts, s);
+  GLX_HIP(e);
+  return GLX_OK;
+}
+
 extern "C" int glx_partition(int device, const int64_t* ids, int64_t n, int32_t num_shards,
                              int64_t* bucketed, int64_t* order, int64_t* counts, void* stream) {
   GLX_REQUIRE(num_shards >= 1 && num_shards <= kMaxShards, "num_shards must be in [1, %d]", kMaxShards);
@@ -133,24 +161,17 @@ extern "C" int glx_partition(int device, const int64_t* ids, int64_t n, int32_t 
   if (rc != GLX_OK) return rc;
   GlxDeviceGuard guard(device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", device);
-  hipStream_t s = glx_stream(stream);
-  if (n == 0) {
-    GLX_HIP(hipMemsetAsync(counts, 0, (size_t)num_shards * sizeof(int64_t), s));
-    return GLX_OK;
-  }
-  const int64_t nblocks = (n + kTile - 1) / kTile;
-  int64_t* block_counts = nullptr;
-  rc = glx_scratch_alloc(reinterpret_cast<void**>(&block_counts),
-                         (size_t)num_shards * nblocks * sizeof(int64_t), s, 1);
-  if (rc != GLX_OK) return rc;
-  glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_shards, nblocks, block_counts);
-  glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_shards, counts);
-  glx_part_scatter_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_shards, nblocks, block_counts,
-                                                           bucketed, order);
-  hipError_t e = hipGetLastError();
-  glx_scratch_free(block_counts, s);
-  GLX_HIP(e);
-  return GLX_OK;
+  return partition_impl(device, ids, n, num_shards, GlxIdMap{nullptr, nullptr, 0, 0}, bucketed, order, counts,
+                        glx_stream(stream));
+}
+
+// The partition of a request that a local replica serves in part: buckets 0 .. num_shards - 1 as glx_partition,
+// bucket num_shards = the ids `divert` knows (counts has num_shards + 1 entries).  Device already selected.
+int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert,
+                         int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s) {
+  GLX_REQUIRE(num_shards >= 1 && num_shards + 1 <= kMaxShards, "num_shards must be in [1, %d)", kMaxShards);
+  GLX_REQUIRE(divert.keys != nullptr, "no divert map");
+  return partition_impl(device, ids, n, num_shards + 1, divert, bucketed, order, counts, s);
 }
 
 template <typename T>

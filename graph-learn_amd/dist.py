@@ -355,11 +355,9 @@ class ShardedStore:
                                          pcnt.view(self.world, num_segments), default_attr)
 
 
-def shard_graph(row_ptr, col, eid, weight, rank, world):
-    """Rows of the (dense-id, torch) CSR owned by `rank`: v % world == rank.
-    -> (row_ptr, col, eid, weight, ids) of the shard; col keeps GLOBAL ids."""
-    V = row_ptr.shape[0] - 1
-    ids = torch.arange(rank, V, world, dtype=torch.int64, device=row_ptr.device)
+def rows_of_graph(row_ptr, col, eid, weight, ids):
+    """The rows `ids` (int64 tensor of dense vertex ids) of a (dense-id, torch) CSR, complete and in storage order.
+    -> (row_ptr, col, eid, weight, ids) of the sub-graph; col keeps GLOBAL ids."""
     deg = row_ptr[ids + 1] - row_ptr[ids]
     rp = torch.zeros(ids.shape[0] + 1, dtype=torch.int64, device=row_ptr.device)
     rp[1:] = torch.cumsum(deg, 0)
@@ -370,6 +368,13 @@ def shard_graph(row_ptr, col, eid, weight, rank, world):
     slot = row_ptr[ids][row_of_slot] + (torch.arange(total, device=row_ptr.device) - rp[row_of_slot])
     w = weight[slot].contiguous() if weight is not None else None
     return rp, col[slot].contiguous(), eid[slot].contiguous(), w, ids
+
+
+def shard_graph(row_ptr, col, eid, weight, rank, world):
+    """Rows of the (dense-id, torch) CSR owned by `rank`: v % world == rank."""
+    V = row_ptr.shape[0] - 1
+    ids = torch.arange(rank, V, world, dtype=torch.int64, device=row_ptr.device)
+    return rows_of_graph(row_ptr, col, eid, weight, ids)
 
 
 def replicate_features(x_shard, num_nodes, group=None):

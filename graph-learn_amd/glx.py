@@ -50,7 +50,8 @@ EXPORTS = [
     "glx_profile_enable", "glx_profile_collect",
     "glx_comm_unique_id", "glx_comm_init_rccl", "glx_comm_init_local", "glx_comm_init_callbacks", "glx_comm_destroy",
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
-    "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_hot_ids",
+    "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_store_set_graph_replica",
+    "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
     "glx_dist_last_stats",
@@ -172,6 +173,8 @@ def lib():
         L.glx_dist_store_destroy.argtypes = [vp]
         L.glx_dist_store_destroy.restype = None
         L.glx_dist_store_set_cache.argtypes = [vp, vp, i64, f32, ci, vp]
+        L.glx_dist_store_set_graph_replica.argtypes = [vp, vp]
+        L.glx_dist_last_sample_rows.argtypes = [vp, vp, vp, vp]
         L.glx_dist_hot_ids.argtypes = [vp, i64, vp, ctypes.POINTER(i64), vp]
         L.glx_dist_enable_in_degree.argtypes = [vp, vp, vp]
         L.glx_dist_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, ctypes.POINTER(Filter), vp, vp, ci, vp]
@@ -816,6 +819,19 @@ class DistStore:
         n = int(hot_ids.shape[0])
         p, kind = _ptr(hot_ids) if n else (None, PTR_HOST)
         _check(lib().glx_dist_store_set_cache(self._h, p, n, default_attr, kind, _stream(kind, self.comm.device)))
+
+    def set_graph_replica(self, replica):
+        """Serve request rows of the vertices `replica` (a glx.Graph built with explicit ids, holding their complete
+        adjacency rows) on this GPU instead of sending them to their owners; None detaches it.  The store keeps a
+        reference so the replica outlives its use."""
+        _check(lib().glx_dist_store_set_graph_replica(self._h, replica._h if replica is not None else None))
+        self._graph_replica = replica
+
+    def last_sample_rows(self):
+        """{'rows', 'from_graph_replica', 'remote'} of the last sample() on this rank."""
+        a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(lib().glx_dist_last_sample_rows(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"rows": a.value, "from_graph_replica": b.value, "remote": c.value}
 
     def hot_ids(self, want):
         """The `want` destination ids with the largest global in-degree (numpy int64, same on every rank)."""

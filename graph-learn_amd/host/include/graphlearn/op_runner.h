@@ -67,6 +67,11 @@ public:
   // Collective.  Every GPU keeps a copy of these nodes' float attributes (the same id list on
   // every rank); aggregation then fetches only the remaining remote rows per request.
   Status ReplicateHotNodes(const std::string& node_type, const int64_t* ids, int64_t count);
+  // Not collective.  `replica` holds the complete adjacency rows of a (hot) vertex set, built like any Graph
+  // (the hot rows' edges loaded on every server); sampling requests for those vertices are then served here
+  // instead of travelling to their owner (glx_dist_store_set_graph_replica).  nullptr detaches it; the caller
+  // keeps `replica` alive.
+  Status AttachGraphReplica(const std::string& edge_type, const Graph* replica);
   // Collective.  The `want` vertices with the largest in-degree over all shards of `edge_type`.
   Status HotNodes(const std::string& edge_type, int64_t want, std::vector<int64_t>* ids);
 

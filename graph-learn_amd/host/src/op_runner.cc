@@ -121,6 +121,14 @@ Status Env::ReplicateHotNodes(const std::string& node_type, const int64_t* ids, 
   return error::FromGlx(glx_dist_store_set_cache(st, ids, count, GLOBAL_FLAG(DefaultFloatAttribute), GLX_PTR_HOST, nullptr));
 }
 
+Status Env::AttachGraphReplica(const std::string& edge_type, const Graph* replica) {
+  glx_dist_store* st = nullptr;
+  Status s = EdgeStore(edge_type, &st);
+  if (!s.ok()) return s;
+  if (replica != nullptr && replica->Device() == nullptr) return error::InvalidArgument("the replica graph is not built");
+  return error::FromGlx(glx_dist_store_set_graph_replica(st, replica ? replica->Device() : nullptr));
+}
+
 Status Env::HotNodes(const std::string& edge_type, int64_t want, std::vector<int64_t>* ids) {
   glx_dist_store* st = nullptr;
   Status s = EdgeStore(edge_type, &st);

@@ -474,6 +474,16 @@ GLX_API void glx_dist_store_destroy(glx_dist_store* st);
  * rows from their owners once and keeps them.  n = 0 drops the replica. */
 GLX_API int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_ids, int64_t n, float default_attr,
                                      int ptr_kind, void* stream);
+/* Graph replica: complete adjacency rows of a set of (hot) vertices on this GPU, as a glx_graph the caller built with
+ * explicit vertex ids -- every row with exactly the edges, weights and edge ids its owner holds (hub vertices of a
+ * power-law graph are both the rows requests ask for most and cheap to hold everywhere: the hybrid-cut idea on top of
+ * the hash partition of graphlearn/src/core/partition/hash_partitioner.h:33-92).  glx_dist_sample then serves the
+ * request rows the replica knows locally -- same draws, the random stream is the row's index in the request -- and
+ * only the rest travels to its owner.  Requests with a filter and InDegreeSampler keep the full exchange.  The store
+ * borrows `replica` (NULL detaches it); the caller keeps it alive and destroys it.  Not collective. */
+GLX_API int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_graph* replica);
+/* Rows of the last glx_dist_sample on this rank: all, served by the graph replica, sent to another rank. */
+GLX_API int glx_dist_last_sample_rows(const glx_dist_store* st, int64_t* rows, int64_t* from_replica, int64_t* remote);
 /* Collective.  The `want` destination ids with the largest in-degree summed over all shards
  * of the store's graph (ties: smaller id first), the same list on every rank, in descending
  * order of in-degree; *n_out <= want.  ids_out is a HOST array of `want` entries. */

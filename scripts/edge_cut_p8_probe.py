@@ -35,8 +35,12 @@ for r in range(P):
     ids = torch.arange(r, V, P, dtype=torch.int64, device=dev)
     fshards.append(glx.Features(X[r::P].contiguous(), ids=ids))
     del own, ids
-del src, dst, w, X
+graph_replica_on = os.environ.get("GRAPH_REPLICA", "0") == "1"  # also replicate the hot vertices' adjacency rows
+if not graph_replica_on:
+    del src, dst, w
+del X
 torch.cuda.empty_cache()
+replica_shared = [None]
 n1, n2 = B0 * k1, B0 * k1 * k2
 bar = threading.Barrier(P)
 hot_by = os.environ.get("HOT_BY", "indegree")
@@ -73,6 +77,17 @@ def rank_main(r):
             else:
                 hot = st_s.hot_ids(int(V * hot_fraction))
             st_a.set_cache(hot)
+            if graph_replica_on:
+                if r == 0:
+                    is_hot = torch.zeros(V, dtype=torch.bool, device=dev)
+                    is_hot[torch.from_numpy(hot).to(dev)] = True
+                    keep = is_hot[src]
+                    replica_shared[0] = glx.Graph.from_edges(src[keep].contiguous(), dst[keep].contiguous(),
+                                                             w[keep].contiguous(), edge_ids=torch.nonzero(keep).view(-1))
+                    torch.cuda.current_stream().synchronize()
+                    print("graph replica: %d of %d edges" % (replica_shared[0].num_edges, E), flush=True)
+                bar.wait()
+                st_s.set_graph_replica(replica_shared[0])  # one GPU: the ranks share one copy
             gen = torch.Generator(device=dev)
             gen.manual_seed(1000 + r)
             b0 = B0 if (r == 0 or not solo) else 0
@@ -100,7 +115,7 @@ def rank_main(r):
             torch.cuda.current_stream().synchronize()
             bar.wait()
             times[r] = (time.perf_counter() - t0) / steps
-            stats[r] = s2
+            stats[r] = dict(s2, sampling_hop2=st_s.last_sample_rows())
             # bit-identical to the unpartitioned operators (last step)
             i = steps + 1
             wa, wae = whole.sample("EdgeWeightSampler", seeds[i], k1, seed=42, call_counter=4 * i)

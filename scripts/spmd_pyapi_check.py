@@ -81,8 +81,8 @@ for strategy in ("edge_weight", "topk", "random_without_replacement"):
     ids = torch.from_numpy(gen.integers(0, 400, 200) * 3 - 200).to(dev)
     got = shard.neighbor_sampler(["e", "e"], [4, 3], strategy=strategy).get_device(ids, call_counter=60)
     want = whole.neighbor_sampler(["e", "e"], [4, 3], strategy=strategy).get_device(ids, call_counter=60)
-    for (gn, ge), (wn, we) in zip(got, want):
-        assert torch.equal(gn.reshape(-1), wn.reshape(-1)) and torch.equal(ge.reshape(-1), we.reshape(-1)), (rank, strategy)
+    for (gn, _), (wn, _) in zip(got, want):  # edge ids are per-shard insertion indices, as on the reference's servers
+        assert torch.equal(gn.reshape(-1), wn.reshape(-1)), (rank, strategy)
 
 # a replica of the hottest rows on every GPU changes where rows come from, never the answer
 hot_store = shard.sharded_store("e", "n", hot_nodes=50)

@@ -430,3 +430,52 @@ def test_uniform_segments_single_gpu(world):
     e, c = feats.aggregate("SumAggregator", ids, None, 6)
     re_, rc = feats.aggregate("SumAggregator", ids, (np.arange(60) // 10).astype(np.int32), 6)
     assert np.array_equal(c, rc) and np.array_equal(e.view(np.uint32), re_.view(np.uint32))
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_graph_replica_serves_hot_rows_locally_with_the_same_draws(world, P):
+    """glx_dist_store_set_graph_replica: the complete adjacency rows of the hottest vertices on every GPU.  Request
+    rows the replica knows never leave the rank -- and the answers stay those of the unpartitioned graph, draw
+    for draw (the random stream is the row's index in the request, the rows and alias tables are the owner's)."""
+    import dist as gdist
+    whole, dev = world["whole"], world["dev"]
+    gs, _ = world["shards"][P]
+    rp, col, eid, w = (torch.from_numpy(a).to(dev) for a in synth.small_graph(V, 80000, seed=21, weighted=True,
+                                                                                hub_degree=3000))
+    hot = torch.from_numpy(np.argsort(-world["indeg"], kind="stable")[:600].astype(np.int64)).to(dev)
+    rrp, rcol, reid, rw, rids = gdist.rows_of_graph(rp, col, eid, w, hot)
+    replica = glx.Graph(rrp, rcol, reid, rw, ids=rids)
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        st.set_graph_replica(replica)
+        src = _requests(r, dev)
+        # hop-2-like request: ids drawn from a hop-1 response are mostly hot
+        h1, _ = whole.sample("RandomSampler", src, 8, seed=3, call_counter=1, default_neighbor_id=0)
+        for ids in (src, h1.view(-1).contiguous()):
+            cc = 10
+            for name in glx.SAMPLER_IDS:
+                for k, pad in ((10, 1), (3, 0), (40, 1)):
+                    cc += 1
+                    got = st.sample(name, ids, k, seed=5, call_counter=cc, padding_mode=pad, default_neighbor_id=-5)
+                    want = whole.sample(name, ids, k, seed=5, call_counter=cc, padding_mode=pad, default_neighbor_id=-5)
+                    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (name, k, pad, r)
+            rows = st.last_sample_rows()
+            in_replica = int(torch.isin(ids, rids).sum())
+            assert rows["rows"] == ids.shape[0] and rows["from_graph_replica"] == in_replica, rows
+            assert rows["remote"] <= ids.shape[0] - in_replica
+        assert rows["from_graph_replica"] > ids.shape[0] // 3  # hop-2 ids: hubs dominate
+        # a filtered request keeps the full exchange (and its answers)
+        vals = torch.full_like(src, 7)
+        got = st.sample("TopkSampler", src, 4, seed=1, call_counter=2, filter_type=glx.FILTER_EQUAL,
+                        filter_field=glx.FILTER_FIELD_ID, values=vals)
+        want = whole.sample_filtered("TopkSampler", src, 4, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, seed=1,
+                                     call_counter=2)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        assert st.last_sample_rows()["from_graph_replica"] == 0
+        st.set_graph_replica(None)
+        got = st.sample("EdgeWeightSampler", src, 5, seed=5, call_counter=77)
+        want = whole.sample("EdgeWeightSampler", src, 5, seed=5, call_counter=77)
+        assert torch.equal(got[0], want[0]) and st.last_sample_rows()["from_graph_replica"] == 0
+    _run_ranks(P, body)
+    replica.close()
