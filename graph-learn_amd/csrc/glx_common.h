@@ -136,6 +136,10 @@ struct GlxIdMapStorage {
 };
 // Builds the table for ids[num_rows] (device pointer) on `s`.
 int glx_idmap_build(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out, hipStream_t s);
+// glx_sample_ex on device pointers where request row i draws from stream d_rows[i] AND answers into output row d_rows[i].
+int glx_sample_scatter_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rows,
+                              int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+                              uint64_t call_counter, int64_t* d_nbr, int64_t* d_eid, hipStream_t s);
 // glx_partition with one more bucket (the last) for the ids `divert` knows; counts has num_shards + 1 entries.
 int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert,
                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s);

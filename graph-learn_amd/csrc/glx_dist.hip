@@ -730,12 +730,13 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   st->sample_rows_replica = n - sent;
   st->sample_rows_remote = sent - rt.send_counts[st->rank];
   if (divert && n > sent) {
-    // the replica's bucket: straight into the tail of the response buffers the stitch reads
+    // the replica's bucket: every row answers straight into ITS row of the caller's response (its index in the
+    // request is both its random stream and its output row), so these rows need no stitch
     const int64_t chunk_r = k > 0 ? (int64_t)INT32_MAX / k : n;
     for (int64_t lo = sent; lo < n; lo += chunk_r) {
       const int64_t cnt = n - lo < chunk_r ? n - lo : chunk_r;
-      rc = glx_sample_ex(rg, sampler, bucketed + lo, order + lo, (int32_t)cnt, k, padding_mode, default_neighbor_id, seed,
-                         call_counter, nbr_back + lo * k, eid_back + lo * k, GLX_PTR_DEVICE, s);
+      rc = glx_sample_scatter_device(rg, sampler, bucketed + lo, order + lo, (int32_t)cnt, k, padding_mode,
+                                     default_neighbor_id, seed, call_counter, nbr_out, eid_out, s);
       if (rc != GLX_OK) return rc;
     }
   }
@@ -770,9 +771,9 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   rc = st->comm->alltoallv(back_segs, 2, rt.recv_counts.data(), rt.recv_offs.data(), rt.send_counts.data(),
                            rt.send_offs.data(), s);
   if (rc != GLX_OK) return rc;
-  if (n > 0 && k > 0) {
-    const int64_t total = n * k;
-    glx_dist_stitch2_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(nbr_back, eid_back, order, n, k,
+  if (sent > 0 && k > 0) {  // the rows that travelled (or were served by this rank's own shard)
+    const int64_t total = sent * k;
+    glx_dist_stitch2_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(nbr_back, eid_back, order, sent, k,
                                                                             nbr_out, eid_out);
     GLX_HIP(hipGetLastError());
   }

@@ -21,6 +21,7 @@ struct SampleArgs {
   const GlxEwRec* ew;
   const int64_t* src;
   const int64_t* rng_rows;  // nullptr: request row i uses stream i
+  const int64_t* out_rows;  // nullptr: request row i answers into output row i (else into output row out_rows[i])
   // Filtered requests whose reserved set is a row PREFIX (timestamp > value, filter.cc:74-82):
   // row i samples from its first prefix[i] slots only, listed in descending order
   // (reserved[x] = prefix[i] - 1 - x) when `reversed`.  nullptr: the whole row, as is.
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void glx_sample_slots_kernel(SampleArgs a, int
     deg = a.row_ptr[row + 1] - start;
   }
   if (a.prefix && row >= 0) deg = a.prefix[i];
-  const int64_t obase = (int64_t)i * a.k;
+  const int64_t obase = (a.out_rows ? a.out_rows[i] : (int64_t)i) * a.k;
   GlxPhilox blk;
   if (OP == kSlotRandom || OP == kSlotEdgeWeight || OP == kSlotEdgeWeightPacked) {
     if (deg > 0) {
@@ -181,8 +182,9 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
   if (active && has_slot) {
     GlxAdj rec = GlxAdj{a.default_nbr, -1};
     if (m > 0) rec = a.adj[start + (a.reversed ? (int32_t)deg - 1 - pc : pc)];
-    a.nbr_out[i * a.k + l] = rec.nbr;
-    a.eid_out[i * a.k + l] = rec.eid;
+    const int64_t o = (a.out_rows ? a.out_rows[i] : (int64_t)i) * a.k + l;
+    a.nbr_out[o] = rec.nbr;
+    a.eid_out[o] = rec.eid;
   }
 }
 
@@ -233,8 +235,9 @@ __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
   if (active && has_slot) {
     GlxAdj rec = GlxAdj{a.default_nbr, -1};
     if (m > 0) rec = a.adj[start + (a.reversed ? (int32_t)deg - 1 - pc : pc)];
-    a.nbr_out[i * a.k + l] = rec.nbr;
-    a.eid_out[i * a.k + l] = rec.eid;
+    const int64_t o = (a.out_rows ? a.out_rows[i] : (int64_t)i) * a.k + l;
+    a.nbr_out[o] = rec.nbr;
+    a.eid_out[o] = rec.eid;
   }
 }
 
@@ -289,8 +292,9 @@ __global__ __launch_bounds__(64) void glx_rwor_lds_kernel(SampleArgs a) {
   for (int32_t j = lane; j < k; j += 64) {
     GlxAdj rec = GlxAdj{a.default_nbr, -1};
     if (m > 0) rec = a.adj[start + (a.reversed ? (int32_t)deg - 1 - perm[j % m] : perm[j % m])];
-    a.nbr_out[i * k + j] = rec.nbr;
-    a.eid_out[i * k + j] = rec.eid;
+    const int64_t o = (a.out_rows ? a.out_rows[i] : i) * k + j;
+    a.nbr_out[o] = rec.nbr;
+    a.eid_out[o] = rec.eid;
   }
 }
 
@@ -381,8 +385,37 @@ int glx_sample_prefix_device(const glx_graph* g, int sampler, const int64_t* d_s
   a.ew = nullptr;
   a.src = d_src;
   a.rng_rows = d_rng;
+  a.out_rows = nullptr;
   a.prefix = d_prefix;
   a.reversed = padding_mode == GLX_PAD_CIRCULAR ? 1 : 0;  // ReplicatePadder ignores the index values
+  a.nbr_out = d_nbr;
+  a.eid_out = d_eid;
+  a.default_nbr = default_neighbor_id;
+  a.seed = seed;
+  a.cc = call_counter;
+  a.cc_dev = glx_capture_cc_dev();
+  a.batch = batch;
+  a.k = k;
+  return sample_device(g, sampler, a, padding_mode, s);
+}
+
+// glx_dist.hip: request rows served by a graph replica answer straight into their rows of the caller's response
+// (output row = random-stream row = the row's index in the original request).  Device pointers, device selected.
+int glx_sample_scatter_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rows,
+                              int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
+                              uint64_t call_counter, int64_t* d_nbr, int64_t* d_eid, hipStream_t s) {
+  if (batch == 0 || k == 0) return GLX_OK;
+  SampleArgs a;
+  a.map = g->map();
+  a.row_ptr = g->row_ptr;
+  a.adj = g->adj;
+  a.alias = g->alias;
+  a.ew = g->ew;
+  a.src = d_src;
+  a.rng_rows = d_rows;
+  a.out_rows = d_rows;
+  a.prefix = nullptr;
+  a.reversed = 0;
   a.nbr_out = d_nbr;
   a.eid_out = d_eid;
   a.default_nbr = default_neighbor_id;
@@ -425,6 +458,7 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
   a.k = k;
   a.prefix = nullptr;
   a.reversed = 0;
+  a.out_rows = nullptr;
   if (ptr_kind == GLX_PTR_DEVICE) {
     a.src = src;
     a.rng_rows = rng_rows;
