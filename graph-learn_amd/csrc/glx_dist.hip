@@ -139,6 +139,12 @@ __global__ void glx_dist_pack_map_kernel(const int64_t* __restrict__ keys, const
   for (; i < cap; i += stride) out[i] = PackedSlot{keys[i], vals[i], 0};
 }
 
+struct RankWord {
+  uint64_t bits;
+  uint32_t rank;  // set bits in all words before this one
+  uint32_t pad_;
+};
+
 struct ResolveArgs {
   PackedMap cache_map;
   GlxIdMap own_map;
@@ -151,6 +157,12 @@ struct ResolveArgs {
   int32_t P, me;
   int32_t cache_base;
   int32_t has_cache;
+  // replica membership by rank-select when the hot ids are small non-negative numbers (else nullptr: the packed hash
+  // map): bit `id % 64` of bm_member[id / 64].bits = id is replicated, its row = .rank + the set bits below it
+  // (the replica's rows are in ascending id order); bm_valid clears the ids their owner does not know.
+  const RankWord* bm_member;  // one 16-byte record per 64 ids: ONE sector per lookup
+  const uint64_t* bm_valid;   // nullptr when every hot id is known to its owner (the usual case)
+  int64_t bm_max;
   int32_t insert_limit;  // distinct ids the set takes before it counts as too small (60 % of its slots)
 };
 
@@ -159,7 +171,8 @@ struct ResolveArgs {
 // New distinct ids are counted per owner in LDS and flushed to the global counters every few
 // iterations: per-wave atomics on P global addresses (a quarter of a million waves on eight
 // counters) serialised the whole kernel -- 10 ms for a 16 M-id request.
-constexpr int kFlushEvery = 8;
+constexpr int kFlushIds = 2048;  // ids a block resolves between two flushes of its counters
+template <int kIds>
 __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   __shared__ int32_t s_stat[3];
   __shared__ int32_t s_cnt[kMaxWorld];
@@ -173,62 +186,108 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   const int lane = threadIdx.x & 63;
   int32_t n_hit = 0, n_own = 0, n_cold = 0;
   int it = 0;
-  for (int64_t base = blockIdx.x * 256ll; base < a.n; base += gridDim.x * 256ll, ++it) {
-    const int64_t i = base + threadIdx.x;
-    bool winner = false;
-    int32_t owner = 0;
-    if (i < a.n) {
-      const int64_t id = a.ids[i];
-      int32_t out = -1;
-      int64_t r = a.has_cache ? packed_row_of(a.cache_map, id) : -1;
-      if (r >= 0) {
-        out = a.cache_base + (int32_t)r;
-        ++n_hit;
-      } else {
-        owner = dist_owner(id, a.P);
-        if (owner == a.me || id == GLX_EMPTY_KEY) {
-          r = glx_row_of(a.own_map, id);
-          out = r >= 0 ? (int32_t)r : -1;
-          ++n_own;
-        } else if (s_void != 0) {
-          ++n_cold;  // the set already overflowed: this pass is void, the host retries with a larger one
+  // kIds ids per thread per iteration: the loads of the replica lookup (the common case: a hop-2 request finds
+  // ~96 % of its ids there) are independent and issued back to back; the rare rest is handled id by id.
+  for (int64_t base = blockIdx.x * (256ll * kIds); base < a.n; base += gridDim.x * (256ll * kIds), ++it) {
+    int64_t id[kIds];
+    int64_t r[kIds];
+#pragma unroll
+    for (int j = 0; j < kIds; ++j) {
+      const int64_t i = base + j * 256 + threadIdx.x;
+      id[j] = i < a.n ? a.ids[i] : GLX_EMPTY_KEY;
+      r[j] = -1;
+    }
+    if (a.bm_member) {
+      RankWord w[kIds];
+#pragma unroll
+      for (int j = 0; j < kIds; ++j) {
+        const bool in = id[j] >= 0 && id[j] <= a.bm_max;
+        w[j] = a.bm_member[in ? (id[j] >> 6) : 0];
+        if (!in) w[j].bits = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < kIds; ++j) {
+        const uint64_t bit = 1ull << (id[j] & 63);
+        if (w[j].bits & bit) {
+          if (a.bm_valid == nullptr || (a.bm_valid[id[j] >> 6] & bit)) r[j] = (int64_t)w[j].rank + __popcll(w[j].bits & (bit - 1));
+        }
+      }
+    } else if (a.has_cache) {
+      PackedSlot first[kIds];
+      uint64_t h[kIds];
+#pragma unroll
+      for (int j = 0; j < kIds; ++j) {
+        h[j] = glx_mix64((uint64_t)id[j]) & a.cache_map.mask;
+        first[j] = a.cache_map.slots[h[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < kIds; ++j) {
+        if (id[j] == GLX_EMPTY_KEY) continue;
+        PackedSlot sl = first[j];
+        uint64_t hh = h[j];
+        while (sl.key != id[j] && sl.key != GLX_EMPTY_KEY) {
+          hh = (hh + 1) & a.cache_map.mask;
+          sl = a.cache_map.slots[hh];
+        }
+        if (sl.key == id[j]) r[j] = sl.row;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kIds; ++j) {
+      const int64_t i = base + j * 256 + threadIdx.x;
+      bool winner = false;
+      int32_t owner = 0;
+      if (i < a.n) {
+        int32_t out = -1;
+        if (r[j] >= 0) {
+          out = a.cache_base + (int32_t)r[j];
+          ++n_hit;
         } else {
-          ++n_cold;
-          uint64_t h = glx_mix64((uint64_t)id) & a.tmask;
-          int probes = 0;
-          while (true) {
-            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&a.tkeys[h]),
-                                                      (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)id);
-            if ((int64_t)prev == GLX_EMPTY_KEY) {
-              winner = true;
-              out = -(int32_t)h - 2;
-              break;
-            }
-            if ((int64_t)prev == id) {
-              out = -(int32_t)h - 2;
-              break;
-            }
-            h = (h + 1) & a.tmask;
-            if (++probes > kMaxProbe) {  // the set is too small: the host retries with a larger one
-              a.ctr[2 * a.P] = 1;
-              out = -1;
-              break;
+          owner = dist_owner(id[j], a.P);
+          if (owner == a.me || id[j] == GLX_EMPTY_KEY) {
+            const int64_t rr = glx_row_of(a.own_map, id[j]);
+            out = rr >= 0 ? (int32_t)rr : -1;
+            ++n_own;
+          } else if (s_void != 0) {
+            ++n_cold;  // the set already overflowed: this pass is void, the host retries with a larger one
+          } else {
+            ++n_cold;
+            uint64_t h = glx_mix64((uint64_t)id[j]) & a.tmask;
+            int probes = 0;
+            while (true) {
+              const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&a.tkeys[h]),
+                                                        (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)id[j]);
+              if ((int64_t)prev == GLX_EMPTY_KEY) {
+                winner = true;
+                out = -(int32_t)h - 2;
+                break;
+              }
+              if ((int64_t)prev == id[j]) {
+                out = -(int32_t)h - 2;
+                break;
+              }
+              h = (h + 1) & a.tmask;
+              if (++probes > kMaxProbe) {  // the set is too small: the host retries with a larger one
+                a.ctr[2 * a.P] = 1;
+                out = -1;
+                break;
+              }
             }
           }
         }
+        a.loc[i] = out;
       }
-      a.loc[i] = out;
+      // new distinct ids: one LDS atomic per (wave, owner)
+      uint64_t pending = __ballot(winner);
+      while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int32_t o = __shfl(owner, leader);
+        const uint64_t same = __ballot(winner && owner == o);
+        if (lane == leader) atomicAdd(&s_cnt[o], __popcll(same));
+        pending &= ~same;
+      }
     }
-    // new distinct ids: one LDS atomic per (wave, owner)
-    uint64_t pending = __ballot(winner);
-    while (pending) {
-      const int leader = __ffsll((long long)pending) - 1;
-      const int32_t o = __shfl(owner, leader);
-      const uint64_t same = __ballot(winner && owner == o);
-      if (lane == leader) atomicAdd(&s_cnt[o], __popcll(same));
-      pending &= ~same;
-    }
-    if ((it % kFlushEvery) == kFlushEvery - 1) {
+    if ((it % (kFlushIds / (256 * kIds))) == kFlushIds / (256 * kIds) - 1) {
       // flush: P global atomics per block, and the running total decides early whether the set is too small
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -408,6 +467,30 @@ __global__ void glx_dist_mask_ids_kernel(int64_t* __restrict__ ids, const int64_
   if (i < n && !known[i]) ids[i] = GLX_EMPTY_KEY;
 }
 
+// sorted[n] ascending (masked[i] = sorted[i], or GLX_EMPTY_KEY when the owner does not know the id):
+// member / valid bits; *dup is set when two equal ids are adjacent (the rank of an id would not be its row).
+__global__ void glx_dist_bitmap_set_kernel(const int64_t* __restrict__ sorted, const int64_t* __restrict__ masked,
+                                           int64_t n, unsigned long long* __restrict__ member,
+                                           unsigned long long* __restrict__ valid, int* __restrict__ flags) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = sorted[i];
+  if (i > 0 && sorted[i - 1] == id) flags[0] = 1;  // listed twice
+  const unsigned long long bit = 1ull << (id & 63);
+  atomicOr(&member[id >> 6], bit);
+  if (masked[i] != GLX_EMPTY_KEY) atomicOr(&valid[id >> 6], bit);
+  else flags[1] = 1;  // an id its owner does not know
+}
+__global__ void glx_dist_bitmap_popc_kernel(const uint64_t* __restrict__ member, int64_t words, uint32_t* __restrict__ cnt) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < words) cnt[i] = (uint32_t)__popcll(member[i]);
+}
+__global__ void glx_dist_bitmap_pack_kernel(const uint64_t* __restrict__ member, const uint32_t* __restrict__ rank,
+                                            int64_t words, RankWord* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < words) out[i] = RankWord{member[i], rank[i], 0};
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 4096) {
   int64_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -440,6 +523,9 @@ struct glx_dist_store {
   const glx_features* feats = nullptr;
   glx_features* cache = nullptr;
   PackedSlot* cache_slots = nullptr;  // the replica's id map, packed (glx_dist_pack_map_kernel)
+  RankWord* bm_member = nullptr;      // ... or, for small non-negative ids, a bitmap with per-word ranks
+  uint64_t* bm_valid = nullptr;       // (same allocation) the known ids, only when some hot id is unknown to its owner
+  int64_t bm_max = -1;
   int device = 0, rank = 0, world = 1;
   bool shortcut = true;  // world == 1: call the local operator directly
   Arena req, recv;  // sampling: request-sized and receive-sized buffers
@@ -551,8 +637,18 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
       a.me = me;
       a.cache_base = (int32_t)n_own;
       a.has_cache = st->cache != nullptr;
+      a.bm_member = st->cache ? st->bm_member : nullptr;
+      a.bm_valid = st->bm_valid;
+      a.bm_max = st->bm_max;
       a.insert_limit = tcap >= safe_cap ? INT32_MAX : (int32_t)(tcap / 10 * 6);
-      if (n > 0) glx_dist_resolve_kernel<<<grid_for(n), 256, 0, s>>>(a);
+      // Few, long-lived blocks: every block pays global atomics at its flushes and exit (a 16 M-id request: 0.27 ms
+      // with 4096 blocks, 0.16 ms with 1024, 0.8 ms with 65536).  Two ids per thread-iteration with the rank
+      // records (0.10 ms; one: 0.12, four: 0.12), one with the hash map (0.30; two: 0.32, four: 0.34) --
+      // scripts/resolve_probe.py.
+      if (n > 0) {
+        if (a.bm_member) glx_dist_resolve_kernel<2><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
+        else glx_dist_resolve_kernel<1><<<grid_for(n, 1024), 256, 0, s>>>(a);
+      }
       glx_dist_offsets_kernel<<<1, 64, 0, s>>>(st->d_ctr, P, tcap, st->d_vals);
       ReqParams prm;
       memset(&prm, 0, sizeof(prm));
@@ -861,6 +957,7 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
   if (st->d_ctr) (void)hipFree(st->d_ctr);
   if (st->cache) glx_features_destroy(st->cache);
   if (st->cache_slots) (void)hipFree(st->cache_slots);
+  if (st->bm_member) (void)hipFree(st->bm_member);
   delete st;
 }
 
@@ -1111,6 +1208,12 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
     GLX_HIP(hipFree(st->cache_slots));
     st->cache_slots = nullptr;
   }
+  if (st->bm_member) {
+    GLX_HIP(hipFree(st->bm_member));
+    st->bm_member = nullptr;
+    st->bm_valid = nullptr;
+    st->bm_max = -1;
+  }
   if (n == 0) return GLX_OK;
   const glx_features* f = st->feats;
   const int P = st->world, me = st->rank;
@@ -1122,6 +1225,13 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
     GLX_HIP(hipMemcpyAsync(ids_d.p, hot_ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
     d_hot = ids_d.as<int64_t>();
   }
+  // the replica's rows are kept in ascending id order (an id's row is then its rank among the hot ids)
+  GlxTemp sorted, sorted_masked, table_sorted;
+  GLX_HIP(hipMalloc(&sorted.p, (size_t)n * 8));
+#define SORTK(tmp, bytes) rocprim::radix_sort_keys(tmp, bytes, d_hot, sorted.as<int64_t>(), (size_t)n, 0, 64, s)
+  GLX_ROCPRIM(SORTK);
+#undef SORTK
+  d_hot = sorted.as<int64_t>();
   GLX_HIP(hipMalloc(&bucketed.p, (size_t)n * 8));
   GLX_HIP(hipMalloc(&order.p, (size_t)n * 8));
   rc = glx_partition(st->device, d_hot, n, P, bucketed.as<int64_t>(), order.as<int64_t>(), st->d_vals, s);
@@ -1151,10 +1261,61 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
   glx_dist_mask_ids_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(bucketed.as<int64_t>(), known_all.as<int64_t>(),
                                                                        n);
   GLX_HIP(hipGetLastError());
+  // owner-major (the all-gather's layout) -> ascending ids: bucketed position pos came from sorted position order[pos]
+  GLX_HIP(hipMalloc(&table_sorted.p, (size_t)n * dim * 4));
+  GLX_HIP(hipMalloc(&sorted_masked.p, (size_t)n * 8));
+  rc = glx_stitch_f32(st->device, table.as<float>(), order.as<int64_t>(), n, dim, table_sorted.as<float>(), s);
+  if (rc == GLX_OK) {
+    rc = glx_stitch_i64(st->device, bucketed.as<int64_t>(), order.as<int64_t>(), n, 1, sorted_masked.as<int64_t>(), s);
+  }
+  if (rc != GLX_OK) return rc;
   GLX_HIP(hipStreamSynchronize(s));
-  rc = glx_features_create(st->device, n, dim, table.as<float>(), bucketed.as<int64_t>(), GLX_PTR_DEVICE, s,
+  (void)hipFree(table.p);
+  table.p = nullptr;
+  rc = glx_features_create(st->device, n, dim, table_sorted.as<float>(), sorted_masked.as<int64_t>(), GLX_PTR_DEVICE, s,
                            &st->cache);
   if (rc != GLX_OK) return rc;
+  // rank-select membership when the ids allow it
+  st->bm_max = -1;
+  int64_t lo_hi[2] = {0, 0};
+  GLX_HIP(hipMemcpyAsync(&lo_hi[0], sorted.as<int64_t>(), 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipMemcpyAsync(&lo_hi[1], sorted.as<int64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  const bool no_bitmap = getenv("GLX_DIST_NO_BITMAP") != nullptr;  // A/B and test knob, read per call
+  if (!no_bitmap && lo_hi[0] >= 0 && lo_hi[1] < ((int64_t)1 << 31)) {
+    const int64_t words = (lo_hi[1] >> 6) + 1;
+    const size_t wb = ((size_t)words * 8 + 255) & ~(size_t)255;
+    // kept: RankWord[words] | valid[words]; scratch: member[words] | rank[words] | flags
+    char* bm = nullptr;
+    GlxTemp tmp_bm;
+    GLX_HIP(hipMalloc(reinterpret_cast<void**>(&bm), (size_t)words * sizeof(RankWord) + wb + 256));
+    GLX_HIP(hipMalloc(&tmp_bm.p, wb + (size_t)words * 4 + 256));
+    GLX_HIP(hipMemsetAsync(bm, 0, (size_t)words * sizeof(RankWord) + wb + 256, s));
+    GLX_HIP(hipMemsetAsync(tmp_bm.p, 0, wb + (size_t)words * 4 + 256, s));
+    RankWord* packed = reinterpret_cast<RankWord*>(bm);
+    uint64_t* valid = reinterpret_cast<uint64_t*>(bm + (size_t)words * sizeof(RankWord));
+    uint64_t* member = reinterpret_cast<uint64_t*>(tmp_bm.as<char>());
+    uint32_t* rank = reinterpret_cast<uint32_t*>(tmp_bm.as<char>() + wb);
+    int* flags = reinterpret_cast<int*>(tmp_bm.as<char>() + wb + (size_t)words * 4);
+    glx_dist_bitmap_set_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        sorted.as<int64_t>(), sorted_masked.as<int64_t>(), n, reinterpret_cast<unsigned long long*>(member),
+        reinterpret_cast<unsigned long long*>(valid), flags);
+    glx_dist_bitmap_popc_kernel<<<(unsigned)((words + 255) / 256), 256, 0, s>>>(member, words, rank);
+#define SCANP(tmp, bytes) rocprim::exclusive_scan(tmp, bytes, rank, rank, 0u, (size_t)words, rocprim::plus<uint32_t>(), s)
+    GLX_ROCPRIM(SCANP);
+#undef SCANP
+    glx_dist_bitmap_pack_kernel<<<(unsigned)((words + 255) / 256), 256, 0, s>>>(member, rank, words, packed);
+    int h_flags[2] = {0, 0};
+    GLX_HIP(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+    if (h_flags[0]) {
+      (void)hipFree(bm);  // an id listed twice: ranks are not rows, keep the hash map
+    } else {
+      st->bm_member = packed;
+      st->bm_valid = h_flags[1] ? valid : nullptr;
+      st->bm_max = lo_hi[1];
+    }
+  }
   const uint64_t cap = st->cache->idmap.cap;
   GLX_HIP(hipMalloc(reinterpret_cast<void**>(&st->cache_slots), (size_t)cap * sizeof(PackedSlot)));
   glx_dist_pack_map_kernel<<<grid_for((int64_t)cap), 256, 0, s>>>(st->cache->idmap.keys, st->cache->idmap.vals, cap,

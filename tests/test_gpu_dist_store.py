@@ -166,12 +166,18 @@ def _hot(world, count):
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 8])
-@pytest.mark.parametrize("cache", ["none", "partial", "all"])
-def test_dist_aggregate_equals_unpartitioned(world, P, cache):
+@pytest.mark.parametrize("cache", ["none", "partial", "partial_hashed", "all", "all_ranked"])
+def test_dist_aggregate_equals_unpartitioned(world, P, cache, monkeypatch):
+    """The replica's membership test has two forms: rank-select over two bitmaps when the hot ids are small
+    non-negative numbers ("partial", "all_ranked": with an id its owner does not know), the packed hash map otherwise
+    ("all": a negative id in the list; "partial_hashed": forced by GLX_DIST_NO_BITMAP)."""
     feats, dev = world["feats"], world["dev"]
     _, fs = world["shards"][P]
-    hot = {"none": np.empty(0, np.int64), "partial": _hot(world, 400),
-           "all": np.concatenate([np.arange(V, dtype=np.int64), [V + 5, -9]])}[cache]
+    if cache == "partial_hashed":
+        monkeypatch.setenv("GLX_DIST_NO_BITMAP", "1")
+    hot = {"none": np.empty(0, np.int64), "partial": _hot(world, 400)[::-1].copy(), "partial_hashed": _hot(world, 400),
+           "all": np.concatenate([np.arange(V, dtype=np.int64), [V + 5, -9]]),
+           "all_ranked": np.concatenate([[V + 5], np.arange(V, dtype=np.int64)[::-1]])}[cache]
 
     def body(r, comm):
         st = glx.DistStore(comm, features=fs[r])
@@ -191,7 +197,7 @@ def test_dist_aggregate_equals_unpartitioned(world, P, cache):
             if P > 1 or cache != "none":
                 assert s["ids"] == n and s["from_replica"] + s["from_own_shard"] + s["remote"] == n, s
                 assert s["remote_distinct"] <= s["remote"]
-                if cache == "all":  # only ids nobody knows (outside [0, V)) can still be remote
+                if cache in ("all", "all_ranked"):  # only ids nobody knows (outside [0, V)) can still be remote
                     assert s["remote"] <= int(((ids < 0) | (ids >= V)).sum()), s
                 if cache == "none" and P > 1:
                     assert s["from_replica"] == 0 and s["remote"] > 0, s
