@@ -10,6 +10,7 @@ namespace {
 
 constexpr int kTile = 2048;  // ids per workgroup (8 passes of 256)
 constexpr int kMaxShards = 64;
+constexpr int64_t kOwnScanBlocks = 2048;  // requests up to 4 M ids: the scatter kernel scans the block counts itself
 
 __device__ __forceinline__ int32_t shard_of(int64_t id, int32_t P) {
   // llabs(id) % P (hash_partitioner.h:90-92)
@@ -79,15 +80,50 @@ __global__ __launch_bounds__(1024) void glx_part_scan_kernel(int64_t* __restrict
   }
 }
 
+// kOwnScan: block_off holds the raw per-block counts of glx_part_count_kernel and every block derives its own
+// offsets from them (sum of the whole buckets before its bucket + its bucket's counts in the blocks before it) --
+// O(P * nblocks) L2 reads per block, which for requests of a few million ids is cheaper than a third kernel in the
+// chain: a one-workgroup scan between two launches waits for a CU behind whatever else runs (0.7 ms instead of
+// 15 us beside a segmented reduce).  Block 0 also writes the bucket totals.  Otherwise block_off is the scanned table.
+template <bool kOwnScan>
 __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __restrict__ ids, int64_t n,
                                                                int32_t P, int64_t nblocks, GlxIdMap divert,
                                                                const int64_t* __restrict__ block_off,
                                                                int64_t* __restrict__ bucketed,
-                                                               int64_t* __restrict__ order) {
+                                                               int64_t* __restrict__ order,
+                                                               int64_t* __restrict__ counts) {
   __shared__ int64_t run[kMaxShards];       // next output position per shard for this block
   __shared__ int32_t wave_cnt[4][kMaxShards];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x < P) run[threadIdx.x] = block_off[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+  if (kOwnScan) {
+    __shared__ int64_t before[kMaxShards], total[kMaxShards];
+    for (int32_t p = wid; p < P; p += 4) {  // one wave per bucket at a time
+      int64_t b = 0, t = 0;
+      for (int64_t j = lane; j < nblocks; j += 64) {
+        const int64_t c = block_off[(int64_t)p * nblocks + j];
+        t += c;
+        if (j < (int64_t)blockIdx.x) b += c;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        b += __shfl_xor(b, off);
+        t += __shfl_xor(t, off);
+      }
+      if (lane == 0) {
+        before[p] = b;
+        total[p] = t;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < P) {
+      int64_t base = 0;
+      for (int32_t q = 0; q < (int32_t)threadIdx.x; ++q) base += total[q];
+      run[threadIdx.x] = base + before[threadIdx.x];
+      if (blockIdx.x == 0) counts[threadIdx.x] = total[threadIdx.x];
+    }
+  } else if (threadIdx.x < P) {
+    run[threadIdx.x] = block_off[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+  }
   __syncthreads();
   const int64_t base = blockIdx.x * (int64_t)kTile;
   for (int it = 0; it < kTile / 256; ++it) {
@@ -143,9 +179,14 @@ static int partition_impl(int device, const int64_t* ids, int64_t n, int32_t num
                              (size_t)num_buckets * nblocks * sizeof(int64_t), s, 1);
   if (rc != GLX_OK) return rc;
   glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts);
-  glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_buckets, counts);
-  glx_part_scatter_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
-                                                           bucketed, order);
+  if (nblocks <= kOwnScanBlocks) {
+    glx_part_scatter_kernel<true><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
+                                                                   bucketed, order, counts);
+  } else {
+    glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_buckets, counts);
+    glx_part_scatter_kernel<false><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
+                                                                    bucketed, order, counts);
+  }
   hipError_t e = hipGetLastError();
   glx_scratch_free(block_counts, s);
   GLX_HIP(e);

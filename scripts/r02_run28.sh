@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 2, GPU run 28: partition without the one-workgroup scan in the chain.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R=$PWD
+export TMPDIR=/tmp
+O=$R/gpurun_out/r02_run28
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_dist_store.py tests/test_gpu_sharded.py tests/test_gpu_two_ranks.py -q -m gpu --timeout 900 > $O/pytest.log 2>&1
+echo "pytest rc=$?" | tee -a $O/status.txt
+grep -n "passed\|failed" $O/pytest.log | tail -2
+for i in 1 2; do
+  GLX_DIST_NO_SHORTCUT=1 timeout 600 python bench.py --gpus 1 --force-sharded --steps 20 --warmup 5 --cpu-baseline off --verify > $O/bench_w1_$i.json 2> $O/bench_w1_$i.log
+  python -c "import json; r=json.load(open('$O/bench_w1_$i.json')); print(r['placements'], r['verified_sharded_equals_unpartitioned'])"
+done
