@@ -203,7 +203,7 @@ def host_boundary_rate(args):
     exe = os.path.join(ROOT, "graph-learn_amd", "lib", "host_path_bench")
     if not os.path.exists(exe):
         return None
-    threads, B, reps = args.host_boundary_threads, 1024, 10
+    threads, B, reps = args.host_boundary_threads, 1024, 40  # 10 per thread: start / tail skew of the pool costs 20 %
     try:
         r = subprocess.run([exe, str(threads), str(B), str(reps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            text=True, timeout=300)
