@@ -10,7 +10,7 @@ namespace {
 
 constexpr int kTile = 2048;  // ids per workgroup (8 passes of 256)
 constexpr int kMaxShards = 64;
-constexpr int64_t kOwnScanBlocks = 2048;  // requests up to 4 M ids: the scatter kernel scans the block counts itself
+constexpr int64_t kOwnScanCells = 32768;  // tile histogram cells (buckets x tiles) up to which the scatter kernel scans them itself
 
 __device__ __forceinline__ int32_t shard_of(int64_t id, int32_t P) {
   // llabs(id) % P (hash_partitioner.h:90-92)
@@ -179,7 +179,7 @@ static int partition_impl(int device, const int64_t* ids, int64_t n, int32_t num
                              (size_t)num_buckets * nblocks * sizeof(int64_t), s, 1);
   if (rc != GLX_OK) return rc;
   glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts);
-  if (nblocks <= kOwnScanBlocks) {
+  if ((int64_t)num_buckets * nblocks <= kOwnScanCells) {
     glx_part_scatter_kernel<true><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
                                                                    bucketed, order, counts);
   } else {

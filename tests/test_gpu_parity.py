@@ -264,8 +264,9 @@ def test_aggregate_device_pointers_and_lookup(orc):
 def test_partition_and_stitch(orc, P):
     import torch
     rng = np.random.default_rng(P)
-    # up to 2048 tiles the scatter kernel scans the tile counts itself; beyond that a scan kernel runs in between
-    for n in (0, 1, 255, 2048, 2049, 100003) + ((4_300_000,) if P in (3, 64) else ()):
+    # up to 32768 histogram cells (buckets x 2048-id tiles) the scatter kernel scans them itself; beyond that a scan
+    # kernel runs in between (P = 64 at n = 2.2 M, P = 3 at n = 23 M)
+    for n in (0, 1, 255, 2048, 2049, 100003) + ((2_200_000,) if P == 64 else (23_000_000,) if P == 3 else ()):
         ids = rng.integers(-10 ** 9, 10 ** 9, n).astype(np.int64)
         t = torch.from_numpy(ids).cuda()
         bucketed, order, counts = glx.partition(t, P)
