@@ -701,6 +701,27 @@ def test_alias_tables_of_long_and_odd_rows_bit_exact():
         den[1] = np.float32(1e-42)  # denormal
         den[2] = np.float32(3e38)
         rows.append(den)
+    # the pairing loop pops 64-entry register windows: stacks of exactly / just over / just under a window, steps whose
+    # result is exactly 1 (0.5 + 1.5: nothing is carried), negative weights (negative probabilities are lows), and rows
+    # with an infinite or NaN weight (the IEEE-comparison variant of the loop)
+    for nl, nh in ((64, 64), (65, 63), (63, 65), (128, 64), (64, 128), (129, 127), (1, 200), (200, 1)):
+        rows.append(np.concatenate([np.full(nl, 0.5, np.float32), np.full(nh, 1.5, np.float32)]))
+        mixed = np.concatenate([rng.random(nl) * 0.9, 1.1 + rng.random(nh)]).astype(np.float32)
+        rows.append(rng.permutation(mixed))
+    for n in (127, 128, 129, 191, 192, 193, 1000):
+        neg = (rng.random(n) + 0.05).astype(np.float32)
+        neg[::7] = -0.01
+        rows.append(neg)
+        inf = (rng.random(n) + 0.05).astype(np.float32)
+        inf[n // 2] = np.inf
+        rows.append(inf)
+        nan = (rng.random(n) + 0.05).astype(np.float32)
+        nan[n // 5] = np.nan
+        rows.append(nan)
+        # weights that sum to exactly zero: probabilities +inf (highs) and -inf (lows), every step yields NaN
+        pm = np.where(np.arange(n + (n & 1)) % 2 == 0, 1.0, -1.0).astype(np.float32)
+        rows.append(pm)
+        rows.append(np.zeros(n, np.float32))
     deg = np.array([r.shape[0] for r in rows], np.int64)
     rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
     w = np.concatenate(rows).astype(np.float32)
