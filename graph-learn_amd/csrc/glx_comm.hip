@@ -46,8 +46,10 @@ RcclApi* rccl_api() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // GLX_RCCL_LIBRARY names another build of the library (the tests load an in-process stand-in through it)
+    const char* names[] = {getenv("GLX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
+      if (n == nullptr || *n == 0) continue;
       api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (api.handle) break;
     }

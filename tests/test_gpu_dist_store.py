@@ -485,3 +485,20 @@ def test_graph_replica_serves_hot_rows_locally_with_the_same_draws(world, P):
         assert torch.equal(got[0], want[0]) and st.last_sample_rows()["from_graph_replica"] == 0
     _run_ranks(P, body)
     replica.close()
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_rccl_transport_call_pattern_with_several_ranks(P):
+    """Real RCCL refuses several ranks on one GPU, so the RCCL transport's own code -- send / recv groups with per-peer
+    offsets, message rounds, several segments per group, the count all-gather -- runs here against an in-process
+    stand-in for librccl (tests/fake_rccl, loaded through GLX_RCCL_LIBRARY in a process of its own): P ranks, the full
+    store on top, every answer equal to the unpartitioned operators'."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
+    assert os.path.exists(lib), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    env = dict(os.environ, GLX_RCCL_LIBRARY=lib)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "fake_rccl_check.py"), str(P)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and ("fake-rccl ok: world size %d" % P) in r.stdout, r.stdout[-4000:]
