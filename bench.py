@@ -564,20 +564,12 @@ def main():
         graph_replica = None
         if args.graph_replica == "on" and hot.shape[0] > 0:
             # the same vertices' adjacency rows on every GPU: hop-2 request rows are hop-1 samples, i.e. mostly hubs,
-            # and those are then sampled here instead of travelling to their owner and back.  Every rank holds the
-            # synthetic edge list, so the rows are cut from it directly (a loader would read the hot rows' edges
-            # on every rank); same edge order as the owner's shard => same rows, same alias tables.
+            # and those are then sampled here instead of travelling to their owner and back.  Built from the shards:
+            # every owner cuts its hot vertices' rows (its edge ids, its row order) and the pieces are all-gathered
+            # once, at load time (glx_dist_build_graph_replica).
             t_rep = time.time()
             g_hot = hot if args.graph_hot_fraction is None else hot[:int(V * args.graph_hot_fraction)]
-            is_hot = torch.zeros(V, dtype=torch.bool, device=dev)
-            is_hot[torch.from_numpy(g_hot).to(dev)] = True
-            keep = is_hot[src]
-            r_eids = torch.nonzero(keep).view(-1)
-            graph_replica = glx.Graph.from_edges(src[keep].contiguous(), dst[keep].contiguous(),
-                                                 weight[keep].contiguous() if weight is not None else None,
-                                                 edge_ids=r_eids, device=local_rank)
-            st_smp.set_graph_replica(graph_replica)
-            del is_hot, keep, r_eids
+            graph_replica = st_smp.build_graph_replica(g_hot)
             torch.cuda.synchronize()
             log("graph replica: the out-edges of the hottest %d vertices, %d of %d edges, built in %.1fs"
                 % (g_hot.shape[0], graph_replica.num_edges, E, time.time() - t_rep))

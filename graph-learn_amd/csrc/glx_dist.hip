@@ -491,6 +491,36 @@ __global__ void glx_dist_bitmap_pack_kernel(const uint64_t* __restrict__ member,
   if (i < words) out[i] = RankWord{member[i], rank[i], 0};
 }
 
+// ---- graph replica built from the shards (glx_dist_build_graph_replica) ----
+// degree of each of this owner's hot vertices (0 when the shard has no such row)
+__global__ void glx_dist_rep_deg_kernel(GlxIdMap map, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ ids,
+                                        int64_t n, int64_t* __restrict__ deg) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = glx_row_of(map, ids[i]);
+  deg[i] = row >= 0 ? row_ptr[row + 1] - row_ptr[row] : 0;
+}
+// one wave per hot vertex: its slots, in storage order, into the piece this owner ships
+__global__ __launch_bounds__(256) void glx_dist_rep_rows_kernel(GlxIdMap map, const int64_t* __restrict__ row_ptr,
+                                                                const GlxAdj* __restrict__ adj,
+                                                                const float* __restrict__ weight,
+                                                                const int64_t* __restrict__ ids, int64_t n,
+                                                                const int64_t* __restrict__ off, int64_t* __restrict__ col,
+                                                                int64_t* __restrict__ eid, float* __restrict__ w) {
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const int64_t row = glx_row_of(map, ids[i]);
+  if (row < 0) return;
+  const int64_t s = row_ptr[row], d = row_ptr[row + 1] - s, o = off[i];
+  for (int64_t j = lane; j < d; j += 64) {
+    const GlxAdj a = adj[s + j];
+    col[o + j] = a.nbr;
+    eid[o + j] = a.eid;
+    if (w) w[o + j] = weight[s + j];
+  }
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 4096) {
   int64_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -916,6 +946,115 @@ extern "C" int glx_dist_store_create(glx_comm* comm, const glx_graph* graph, con
   }
   *out = st;
   return GLX_OK;
+}
+
+extern "C" int glx_dist_build_graph_replica(glx_dist_store* st, const int64_t* hot_ids, int64_t n, int ptr_kind,
+                                            void* stream, glx_graph** out) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(n > 0 && n < INT32_MAX, "the hot list must hold between 1 and 2^31 - 1 ids");
+  GLX_REQUIRE(hot_ids != nullptr, "NULL data pointer");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  GLX_HIP(hipStreamSynchronize(s));
+  const glx_graph* g = st->graph;
+  const int P = st->world, me = st->rank;
+  const bool weighted = g->weight != nullptr;
+  const int64_t n1 = n > 0 ? n : 1;
+  GlxTemp ids_d, sorted, bucketed, order, deg_mine, off_mine;
+  const int64_t* d_hot = hot_ids;
+  if (ptr_kind == GLX_PTR_HOST && n > 0) {
+    GLX_HIP(hipMalloc(&ids_d.p, (size_t)n * 8));
+    GLX_HIP(hipMemcpyAsync(ids_d.p, hot_ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    d_hot = ids_d.as<int64_t>();
+  }
+  // ascending ids: every rank then lists every owner's rows in the same order
+  GLX_HIP(hipMalloc(&sorted.p, (size_t)n1 * 8));
+  if (n > 0) {
+#define SORTK(tmp, bytes) rocprim::radix_sort_keys(tmp, bytes, d_hot, sorted.as<int64_t>(), (size_t)n, 0, 64, s)
+    GLX_ROCPRIM(SORTK);
+#undef SORTK
+  }
+  GLX_HIP(hipMalloc(&bucketed.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&order.p, (size_t)n1 * 8));
+  rc = glx_partition(st->device, sorted.as<int64_t>(), n, P, bucketed.as<int64_t>(), order.as<int64_t>(), st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  std::vector<int64_t> counts((size_t)P);
+  GLX_HIP(hipMemcpyAsync(counts.data(), st->d_vals, (size_t)P * 8, hipMemcpyDeviceToHost, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  std::vector<int64_t> offs((size_t)P + 1, 0);
+  for (int p = 0; p < P; ++p) offs[p + 1] = offs[p] + counts[p];
+  const int64_t c_me = counts[me];
+  const int64_t* my_ids = bucketed.as<int64_t>() + offs[me];
+  // this owner's piece: degrees, then the slots
+  GLX_HIP(hipMalloc(&deg_mine.p, (size_t)(c_me + 1) * 8));
+  GLX_HIP(hipMalloc(&off_mine.p, (size_t)(c_me + 1) * 8));
+  int64_t e_me = 0;
+  if (c_me > 0) {
+    glx_dist_rep_deg_kernel<<<(unsigned)((c_me + 255) / 256), 256, 0, s>>>(g->map(), g->row_ptr, my_ids, c_me,
+                                                                          deg_mine.as<int64_t>());
+#define SCANO(tmp, bytes)                                                                                      \
+  rocprim::exclusive_scan(tmp, bytes, deg_mine.as<int64_t>(), off_mine.as<int64_t>(), (int64_t)0, (size_t)c_me, \
+                          rocprim::plus<int64_t>(), s)
+    GLX_ROCPRIM(SCANO);
+#undef SCANO
+    int64_t last[2] = {0, 0};
+    GLX_HIP(hipMemcpyAsync(&last[0], off_mine.as<int64_t>() + (c_me - 1), 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipMemcpyAsync(&last[1], deg_mine.as<int64_t>() + (c_me - 1), 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+    e_me = last[0] + last[1];
+  }
+  GlxTemp col_mine, eid_mine, w_mine;
+  GLX_HIP(hipMalloc(&col_mine.p, (size_t)(e_me + 1) * 8));
+  GLX_HIP(hipMalloc(&eid_mine.p, (size_t)(e_me + 1) * 8));
+  GLX_HIP(hipMalloc(&w_mine.p, (size_t)(e_me + 1) * 4));
+  if (c_me > 0) {
+    glx_dist_rep_rows_kernel<<<(unsigned)((c_me * 64 + 255) / 256), 256, 0, s>>>(
+        g->map(), g->row_ptr, g->adj, weighted ? g->weight : nullptr, my_ids, c_me, off_mine.as<int64_t>(),
+        col_mine.as<int64_t>(), eid_mine.as<int64_t>(), weighted ? w_mine.as<float>() : nullptr);
+    GLX_HIP(hipGetLastError());
+  }
+  // every owner's edge total
+  GlxTemp d_e;
+  GLX_HIP(hipMalloc(&d_e.p, 8));
+  GLX_HIP(hipMemcpyAsync(d_e.p, &e_me, 8, hipMemcpyHostToDevice, s));
+  std::vector<int64_t> e_all((size_t)P);
+  rc = st->comm->allgather_i64(d_e.as<int64_t>(), 1, e_all.data(), s);
+  if (rc != GLX_OK) return rc;
+  std::vector<int64_t> eoffs((size_t)P + 1, 0);
+  for (int p = 0; p < P; ++p) eoffs[p + 1] = eoffs[p] + e_all[p];
+  const int64_t E = eoffs[P];
+  GLX_REQUIRE(E < ((int64_t)1 << 40), "replica too large");
+  // all-gather(v) of the pieces (an all-to-all whose every outgoing message is the same buffer), owner-major
+  GlxTemp deg_all, col_all, eid_all, w_all, row_ptr;
+  GLX_HIP(hipMalloc(&deg_all.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&col_all.p, (size_t)(E + 1) * 8));
+  GLX_HIP(hipMalloc(&eid_all.p, (size_t)(E + 1) * 8));
+  GLX_HIP(hipMalloc(&w_all.p, (size_t)(E + 1) * 4));
+  std::vector<int64_t> same_rows((size_t)P, c_me), same_edges((size_t)P, e_me), zero((size_t)P, 0);
+  GlxSeg seg_rows{deg_mine.p, deg_all.p, 8};
+  rc = st->comm->alltoallv(&seg_rows, 1, same_rows.data(), zero.data(), counts.data(), offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  GlxSeg seg_edges[3] = {{col_mine.p, col_all.p, 8}, {eid_mine.p, eid_all.p, 8}, {w_mine.p, w_all.p, 4}};
+  rc = st->comm->alltoallv(seg_edges, weighted ? 3 : 2, same_edges.data(), zero.data(), e_all.data(), eoffs.data(), s);
+  if (rc != GLX_OK) return rc;
+  // rows in owner-major order = `bucketed`; row_ptr = exclusive scan of the degrees (+ the total)
+  GLX_HIP(hipMalloc(&row_ptr.p, (size_t)(n + 1) * 8));
+  if (n > 0) {
+#define SCANR(tmp, bytes)                                                                                    \
+  rocprim::exclusive_scan(tmp, bytes, deg_all.as<int64_t>(), row_ptr.as<int64_t>(), (int64_t)0, (size_t)n,   \
+                          rocprim::plus<int64_t>(), s)
+    GLX_ROCPRIM(SCANR);
+#undef SCANR
+  }
+  GLX_HIP(hipMemcpyAsync(row_ptr.as<int64_t>() + n, &E, 8, hipMemcpyHostToDevice, s));
+  GLX_HIP(hipStreamSynchronize(s));
+  return glx_graph_create(st->device, n, E, row_ptr.as<int64_t>(), col_all.as<int64_t>(), eid_all.as<int64_t>(),
+                          weighted ? w_all.as<float>() : nullptr, bucketed.as<int64_t>(), GLX_PTR_DEVICE, s, out);
 }
 
 extern "C" int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_graph* replica) {

@@ -51,6 +51,7 @@ EXPORTS = [
     "glx_comm_unique_id", "glx_comm_init_rccl", "glx_comm_init_local", "glx_comm_init_callbacks", "glx_comm_destroy",
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_store_set_graph_replica",
+    "glx_dist_build_graph_replica",
     "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
@@ -174,6 +175,7 @@ def lib():
         L.glx_dist_store_destroy.restype = None
         L.glx_dist_store_set_cache.argtypes = [vp, vp, i64, f32, ci, vp]
         L.glx_dist_store_set_graph_replica.argtypes = [vp, vp]
+        L.glx_dist_build_graph_replica.argtypes = [vp, vp, i64, ci, vp, vp]
         L.glx_dist_last_sample_rows.argtypes = [vp, vp, vp, vp]
         L.glx_dist_hot_ids.argtypes = [vp, i64, vp, ctypes.POINTER(i64), vp]
         L.glx_dist_enable_in_degree.argtypes = [vp, vp, vp]
@@ -826,6 +828,20 @@ class DistStore:
         reference so the replica outlives its use."""
         _check(lib().glx_dist_store_set_graph_replica(self._h, replica._h if replica is not None else None))
         self._graph_replica = replica
+
+    def build_graph_replica(self, hot_ids, attach=True):
+        """Collective: the complete adjacency rows of hot_ids (same list on every rank; unique ids), cut out of the
+        shards by their owners and all-gathered -> a glx.Graph on this GPU (owned by the caller).  attach=True also
+        makes the store serve those vertices' sampling requests from it (set_graph_replica)."""
+        n = int(hot_ids.shape[0])
+        p, kind = _ptr(hot_ids)
+        h = ctypes.c_void_p()
+        _check(lib().glx_dist_build_graph_replica(self._h, p, n, kind, _stream(kind, self.comm.device), ctypes.byref(h)))
+        g = Graph.from_handle(h.value)
+        g._borrowed = False  # ours to destroy
+        if attach:
+            self.set_graph_replica(g)
+        return g
 
     def last_sample_rows(self):
         """{'rows', 'from_graph_replica', 'remote'} of the last sample() on this rank."""

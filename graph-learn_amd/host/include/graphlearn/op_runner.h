@@ -67,6 +67,11 @@ public:
   // Collective.  Every GPU keeps a copy of these nodes' float attributes (the same id list on
   // every rank); aggregation then fetches only the remaining remote rows per request.
   Status ReplicateHotNodes(const std::string& node_type, const int64_t* ids, int64_t count);
+  // Collective.  Every GPU keeps the complete adjacency rows of these vertices of `edge_type` (the same id list
+  // on every rank): the owners cut them out of their shards -- neighbours, their edge ids, weights, in storage
+  // order -- and the pieces are all-gathered once (glx_dist_build_graph_replica); sampling requests for those
+  // vertices are then served locally, with the same draws.  The Env owns the replica.
+  Status ReplicateHotRows(const std::string& edge_type, const int64_t* ids, int64_t count);
   // Not collective.  `replica` holds the complete adjacency rows of a (hot) vertex set, built like any Graph
   // (the hot rows' edges loaded on every server); sampling requests for those vertices are then served here
   // instead of travelling to their owner (glx_dist_store_set_graph_replica).  nullptr detaches it; the caller
@@ -86,6 +91,7 @@ private:
   int32_t server_id_, server_count_;
   std::mutex mtx_;
   std::unordered_map<std::string, glx_dist_store*> edge_stores_, node_stores_;
+  std::unordered_map<std::string, glx_graph*> graph_replicas_;  // built by ReplicateHotRows
   std::atomic<uint64_t> call_counter_{0};
 };
 

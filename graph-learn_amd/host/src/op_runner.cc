@@ -82,6 +82,7 @@ Env::Env(glx_comm* comm, GraphStore* store) : comm_(comm), store_(store), server
 Env::~Env() {
   for (auto& kv : edge_stores_) glx_dist_store_destroy(kv.second);
   for (auto& kv : node_stores_) glx_dist_store_destroy(kv.second);
+  for (auto& kv : graph_replicas_) glx_graph_destroy(kv.second);  // after the stores that borrowed them
 }
 
 Status Env::EdgeStore(const std::string& edge_type, glx_dist_store** out) {
@@ -119,6 +120,25 @@ Status Env::ReplicateHotNodes(const std::string& node_type, const int64_t* ids, 
   Status s = NodeStore(node_type, &st);
   if (!s.ok()) return s;
   return error::FromGlx(glx_dist_store_set_cache(st, ids, count, GLOBAL_FLAG(DefaultFloatAttribute), GLX_PTR_HOST, nullptr));
+}
+
+Status Env::ReplicateHotRows(const std::string& edge_type, const int64_t* ids, int64_t count) {
+  glx_dist_store* st = nullptr;
+  Status s = EdgeStore(edge_type, &st);
+  if (!s.ok()) return s;
+  glx_graph* built = nullptr;
+  int rc = glx_dist_build_graph_replica(st, ids, count, GLX_PTR_HOST, nullptr, &built);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  rc = glx_dist_store_set_graph_replica(st, built);
+  if (rc != GLX_OK) {
+    glx_graph_destroy(built);
+    return error::FromGlx(rc);
+  }
+  std::lock_guard<std::mutex> g(mtx_);
+  glx_graph*& slot = graph_replicas_[edge_type];
+  if (slot) glx_graph_destroy(slot);
+  slot = built;
+  return Status::OK();
 }
 
 Status Env::AttachGraphReplica(const std::string& edge_type, const Graph* replica) {

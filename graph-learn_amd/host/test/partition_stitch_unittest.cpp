@@ -305,8 +305,8 @@ TEST(PartitionStitchTest, DistributeRunnerOnTwoServersEqualsOneStore) {
         std::vector<int64_t> hot;
         Status s = env.HotNodes("e", 40, &hot);
         if (s.ok()) s = env.ReplicateHotNodes("n", hot.data(), (int64_t)hot.size());
-        // ... and a graph replica: here the adjacency rows of every vertex, so no sampling row leaves the server
-        if (s.ok()) s = env.AttachGraphReplica("e", c->whole.GetGraph("e"));
+        // ... and the adjacency rows of the same vertices, cut out of the shards and all-gathered
+        if (s.ok()) s = env.ReplicateHotRows("e", hot.data(), (int64_t)hot.size());
         if (!s.ok() || hot.size() != 40) {
           ok[r] = false;
           why[r] = "hot nodes: " + s.ToString();

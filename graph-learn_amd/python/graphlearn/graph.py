@@ -151,7 +151,8 @@ class Graph(object):
     (HashPartitioner / Stitcher on the device, glx_dist_*) and the answers equal a single store's, draw
     for draw.  Needs an initialised torch.distributed process group whose size is task_count.
     hot_nodes=K keeps a replica of the K vertices with the largest in-degree (over all shards of
-    `edge_type`) on every GPU; aggregation then fetches only the remaining remote rows per request.
+    `edge_type`) on every GPU -- their float attributes and their adjacency rows; aggregation then fetches only
+    the remaining remote rows per request and sampling requests for those vertices stay local.
     replicate_features (a full copy of the table on every GPU) is not offered here: use hot_nodes."""
     import torch.distributed as torch_dist
     import dist as glx_dist
@@ -167,8 +168,14 @@ class Graph(object):
           torch_dist.get_rank(group), world, shard[0], shard[1]))
     feats = self.device_features(node_type) if node_type is not None else None
     store = glx_dist.ShardedStore(glx_dist.DeviceOps(), self.device_graph(edge_type), feats, group)
-    if hot_nodes and feats is not None:
-      store.native.set_cache(store.native.hot_ids(int(hot_nodes)))
+    if hot_nodes:
+      hot = store.native.hot_ids(int(hot_nodes))
+      if feats is not None:
+        store.native.set_cache(hot)
+      if hot.shape[0] > 0:
+        # the same vertices' adjacency rows on every GPU (cut out of the shards, all-gathered once): their sampling
+        # requests are then served locally, with the same draws
+        store.graph_replica = store.native.build_graph_replica(hot)
     return store
 
   def close(self):

@@ -482,6 +482,14 @@ GLX_API int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_ids,
  * only the rest travels to its owner.  Requests with a filter and InDegreeSampler keep the full exchange.  The store
  * borrows `replica` (NULL detaches it); the caller keeps it alive and destroys it.  Not collective. */
 GLX_API int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_graph* replica);
+/* Collective.  Builds such a replica from the shards themselves: every owner cuts the rows of its vertices in
+ * hot_ids[n] (the same list on every rank; host or device) out of its shard -- neighbours, ITS edge ids and weights, in
+ * storage order -- and the pieces are all-gathered; *out is a new glx_graph over the hot vertices (ids unknown to their
+ * owner become empty rows), with its own alias tables, identical on every rank.  The caller owns it
+ * (glx_graph_destroy) and attaches it with glx_dist_store_set_graph_replica.  The load-time counterpart of the
+ * per-request exchange, as glx_dist_store_set_cache is for features. */
+GLX_API int glx_dist_build_graph_replica(glx_dist_store* st, const int64_t* hot_ids, int64_t n, int ptr_kind,
+                                         void* stream, glx_graph** out);
 /* Rows of the last glx_dist_sample on this rank: all, served by the graph replica, sent to another rank. */
 GLX_API int glx_dist_last_sample_rows(const glx_dist_store* st, int64_t* rows, int64_t* from_replica, int64_t* remote);
 /* Collective.  The `want` destination ids with the largest in-degree summed over all shards

@@ -91,6 +91,14 @@ wemb, wcnt = whole_feats.aggregate("MeanAggregator", nbr.reshape(-1).contiguous(
 assert torch.equal(cnt, wcnt) and torch.equal(emb.view(torch.int32), wemb.view(torch.int32)), rank
 st = hot_store.stats()
 assert st["from_replica"] > 0 and st["from_replica"] + st["from_own_shard"] + st["remote"] == st["ids"], st
+# ... and the same vertices' adjacency rows are on every GPU too: their sampling requests stay local, same draws
+ids = torch.from_numpy(gen.integers(0, 400, 300) * 3 - 200).to(dev)
+h1, _ = whole_graph.sample("RandomSampler", ids, 5, seed=77, call_counter=70, default_neighbor_id=-1)
+for name in ("EdgeWeightSampler", "TopkSampler", "RandomWithoutReplacementSampler"):
+    nbr2, _ = hot_store.sample(name, h1.reshape(-1), 4, seed=77, call_counter=71, default_neighbor_id=-1)
+    want2, _ = whole_graph.sample(name, h1.reshape(-1), 4, seed=77, call_counter=71, default_neighbor_id=-1)
+    assert torch.equal(nbr2, want2), (rank, name)
+assert hot_store.native.last_sample_rows()["from_graph_replica"] > 0
 
 # InDegreeSampler weighs neighbours by their in-degree over ALL shards; a shard's tables only count its own
 # edges, so a partitioned store refuses it instead of drawing from a different distribution

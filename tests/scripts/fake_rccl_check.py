@@ -54,7 +54,8 @@ def run(P, max_message_bytes):
                         got_hot = st.hot_ids(400)
                         assert got_hot.shape[0] == 400
                         st.set_cache(got_hot)
-                        st.set_graph_replica(replica)
+                        built = st.build_graph_replica(hot)  # collective: rows cut out of the shards, all-gathered
+                        assert built.num_edges == replica.num_edges
                     cc = 0
                     for name in glx.SAMPLER_IDS:
                         for k, pad in ((10, 1), (7, 0)):

@@ -483,6 +483,24 @@ def test_graph_replica_serves_hot_rows_locally_with_the_same_draws(world, P):
         got = st.sample("EdgeWeightSampler", src, 5, seed=5, call_counter=77)
         want = whole.sample("EdgeWeightSampler", src, 5, seed=5, call_counter=77)
         assert torch.equal(got[0], want[0]) and st.last_sample_rows()["from_graph_replica"] == 0
+        # the same replica built FROM THE SHARDS (every owner ships the rows of its hot vertices): same rows, same
+        # owner edge ids, same alias tables -- and ids nobody knows become empty rows
+        listed = torch.cat([hot.flip(0), torch.tensor([V + 7, 10 ** 12], device=dev)]) if r % 2 else \
+            torch.cat([hot.flip(0), torch.tensor([V + 7, 10 ** 12], device=dev)]).cpu().numpy()
+        built = st.build_graph_replica(listed)
+        assert built.num_rows == hot.shape[0] + 2 and built.num_edges == replica.num_edges
+        probe = torch.cat([hot, torch.tensor([V + 7], device=dev)])
+        for a, b in zip(built.sample_full(probe, 0), replica.sample_full(probe, 0)):
+            assert torch.equal(a, b)
+        pa, aa = built.export_alias()
+        assert pa.shape[0] == replica.num_edges
+        for name in glx.SAMPLER_IDS:
+            got = st.sample(name, h1.view(-1).contiguous(), 6, seed=8, call_counter=3)
+            want = whole.sample(name, h1.view(-1).contiguous(), 6, seed=8, call_counter=3)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (name, r)
+        assert st.last_sample_rows()["from_graph_replica"] > 0
+        st.set_graph_replica(None)
+        built.close()
     _run_ranks(P, body)
     replica.close()
 
