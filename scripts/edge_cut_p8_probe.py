@@ -1,8 +1,8 @@
 """The edge-cut path at its real shape on ONE GPU: P ranks = P threads of this process (in-process transport,
 device-to-device copies instead of xGMI), full C3 (RMAT 10M / 100M, EdgeWeight [25,10] + Max, dim 256), every
 rank driving its own 65,536-seed batch like bench.py --gpus P.  All ranks share the GPU, so wall time per step
-/ P is a rank's device work WITHOUT link time: partition, exchanges as copies, the owner's sampling, resolve +
-dedup of the cold tail, halo lookups, the 3-source reduce.  Also checks every rank's answer against the
+/ P is an UPPER BOUND on a rank's cost without link time (the in-process transport synchronises the stream and
+meets the other threads at two host barriers per exchange, and the eight threads share one Python interpreter).  Also checks every rank's answer against the
 unpartitioned operators, bit for bit, and prints where the ids came from (replica / own shard / halo).
 
   python scripts/edge_cut_p8_probe.py [P=8] [hot_fraction=0.10] [steps=6] [solo]
@@ -36,11 +36,9 @@ for r in range(P):
     fshards.append(glx.Features(X[r::P].contiguous(), ids=ids))
     del own, ids
 graph_replica_on = os.environ.get("GRAPH_REPLICA", "0") == "1"  # also replicate the hot vertices' adjacency rows
-if not graph_replica_on:
-    del src, dst, w
+del src, dst, w
 del X
 torch.cuda.empty_cache()
-replica_shared = [None]
 n1, n2 = B0 * k1, B0 * k1 * k2
 bar = threading.Barrier(P)
 hot_by = os.environ.get("HOT_BY", "indegree")
@@ -78,16 +76,10 @@ def rank_main(r):
                 hot = st_s.hot_ids(int(V * hot_fraction))
             st_a.set_cache(hot)
             if graph_replica_on:
+                # collective: every owner cuts its hot vertices' rows out of its shard, the pieces are all-gathered
+                mine = st_s.build_graph_replica(hot)
                 if r == 0:
-                    is_hot = torch.zeros(V, dtype=torch.bool, device=dev)
-                    is_hot[torch.from_numpy(hot).to(dev)] = True
-                    keep = is_hot[src]
-                    replica_shared[0] = glx.Graph.from_edges(src[keep].contiguous(), dst[keep].contiguous(),
-                                                             w[keep].contiguous(), edge_ids=torch.nonzero(keep).view(-1))
-                    torch.cuda.current_stream().synchronize()
-                    print("graph replica: %d of %d edges" % (replica_shared[0].num_edges, E), flush=True)
-                bar.wait()
-                st_s.set_graph_replica(replica_shared[0])  # one GPU: the ranks share one copy
+                    print("graph replica built from the shards: %d of %d edges" % (mine.num_edges, E), flush=True)
             gen = torch.Generator(device=dev)
             gen.manual_seed(1000 + r)
             b0 = B0 if (r == 0 or not solo) else 0
@@ -145,7 +137,7 @@ if solo:
           "operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3, all(ok)))
 else:
     print("hot rows chosen by", hot_by)
-    print("P = %d ranks on one GPU, hot fraction %.2f: %.2f ms per step with all ranks running (%.2f ms of device work per rank-step); "
+    print("P = %d ranks on one GPU, hot fraction %.2f: %.2f ms per step with all ranks running (%.2f ms of wall time per rank-step: host barriers and one GPU shared by all ranks included); "
           "all answers equal the unpartitioned operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3,
                                                                   max(x or 0 for x in times) * 1e3 / P, all(ok)))
 for r in (0, P - 1):
