@@ -122,16 +122,6 @@ struct PackedMap {
   const PackedSlot* slots;
   uint64_t mask;
 };
-__device__ __forceinline__ int32_t packed_row_of(const PackedMap& m, int64_t id) {
-  if (id == GLX_EMPTY_KEY) return -1;
-  uint64_t h = glx_mix64((uint64_t)id) & m.mask;
-  while (true) {
-    const PackedSlot sl = m.slots[h];
-    if (sl.key == id) return sl.row;
-    if (sl.key == GLX_EMPTY_KEY) return -1;
-    h = (h + 1) & m.mask;
-  }
-}
 __global__ void glx_dist_pack_map_kernel(const int64_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                          uint64_t cap, PackedSlot* __restrict__ out) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
