@@ -218,6 +218,26 @@ def host_boundary_rate(args):
                     "are pinned (glx_host_register) so the device->host copies are single DMA transfers"}
 
 
+def edge_cut_world1(args):
+    """The N > 1 code path with one rank, in a process of its own (this one keeps its store resident): same workload,
+    same step count, both feature placements, answers verified bit for bit against the unpartitioned operators."""
+    import subprocess
+    env = dict(os.environ, GLX_DIST_NO_SHORTCUT="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--cpu-baseline", "off", "--host-boundary", "off", "--roofline-probes", "off",
+           "--edge-cut-probe", "off", "--verify"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as ex:  # noqa: BLE001 -- never lose the headline line
+        return {"error": repr(ex)}
+    return {"placements": rec.get("placements"), "verified_equals_unpartitioned": rec.get("verified_sharded_equals_unpartitioned"),
+            "hot_fraction": args.hot_fraction, "halo_exchange_hop2": rec.get("halo_exchange_hop2"),
+            "sampling_exchange_hop2": rec.get("sampling_exchange_hop2"),
+            "note": "world size 1 over RCCL, generic path (GLX_DIST_NO_SHORTCUT=1): partition, self-exchange, resolve + "
+                    "dedup, halo slots, 3-source reduce, 3-stage pipeline -- no link time; compare with ms_per_step above"}
+
+
 def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
     """BASELINE configs[4] shape: heterogeneous user-item-shop graph, three
     weighted edge types (u-i 300M, i-s 100M, u-s 100M edges over 40M / 9M / 1M nodes),
@@ -391,6 +411,11 @@ def main():
                     help="N=1: also run graph-learn_amd/lib/host_path_bench (requests through the C++ operator API "
                          "with host buffers) and report its PCIe-inclusive rate under \"host_boundary\"")
     ap.add_argument("--host-boundary-threads", type=int, default=32)
+    ap.add_argument("--edge-cut-probe", default="on", choices=["on", "off"],
+                    help="N=1, C3: after the headline, time the same steps once more through the multi-GPU machinery with "
+                         "ONE rank over RCCL (partition, exchanges, resolve, halo slots, 3-source reduce: the generic "
+                         "path, GLX_DIST_NO_SHORTCUT=1), verified against the plain operators, and report it under "
+                         "\"edge_cut_world1\" -- what the edge-cut path costs before any link time")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="N=1: replay the step as one captured hipGraph (glx_plan) instead of 4 kernel launches; "
                          "auto = on for launch-bound batches (B0 <= 8192)")
@@ -1017,6 +1042,8 @@ def main():
         res["gpu_over_cpu"] = value / cpu["value"]
     if args.host_boundary == "on" and not sharded and rank == 0:
         res["host_boundary"] = host_boundary_rate(args)
+    if args.edge_cut_probe == "on" and not sharded and world == 1 and args.workload == "c3" and B0 == 65536:
+        res["edge_cut_world1"] = edge_cut_world1(args)
     if rank == 0:
         result_out.write(json.dumps(res) + "\n")
         result_out.flush()
