@@ -225,7 +225,7 @@ def edge_cut_world1(args):
     env = dict(os.environ, GLX_DIST_NO_SHORTCUT="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--cpu-baseline", "off", "--host-boundary", "off", "--roofline-probes", "off",
-           "--edge-cut-probe", "off", "--verify"]
+           "--edge-cut-probe", "off", "--small-batches", "off", "--verify"]
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -411,6 +411,8 @@ def main():
                     help="N=1: also run graph-learn_amd/lib/host_path_bench (requests through the C++ operator API "
                          "with host buffers) and report its PCIe-inclusive rate under \"host_boundary\"")
     ap.add_argument("--host-boundary-threads", type=int, default=32)
+    ap.add_argument("--small-batches", default="on", choices=["on", "off"],
+                    help="N=1 at the default batch: also time B0 = 1024 and 8192 on the same store (\"small_batches\")")
     ap.add_argument("--edge-cut-probe", default="on", choices=["on", "off"],
                     help="N=1, C3: after the headline, time the same steps once more through the multi-GPU machinery with "
                          "ONE rank over RCCL (partition, exchanges, resolve, halo slots, 3-source reduce: the generic "
@@ -1042,6 +1044,31 @@ def main():
         res["gpu_over_cpu"] = value / cpu["value"]
     if args.host_boundary == "on" and not sharded and rank == 0:
         res["host_boundary"] = host_boundary_rate(args)
+    if args.small_batches == "on" and not sharded and world == 1 and B0 == 65536:
+        # SURVEY 8(a) fixes B0 in {1024, 8192, 65536}: the launch-bound sizes on the same resident store, each step ONE
+        # hipGraph launch (glx_plan), plans alternating over --graph-streams streams
+        small = {}
+        for b in (1024, 8192):
+            plans = [glx.Plan([graph, graph], sampler, [k1, k2], b, features=[feats, feats], agg=agg, seed=42)
+                     for _ in range(args.graph_streams)]
+            streams = [torch.cuda.Stream(device=dev) for _ in plans]
+            reps = 400
+
+            def run(i):
+                with torch.cuda.stream(streams[i % len(plans)]):
+                    plans[i % len(plans)].run(seeds[i % n_steps, :b].contiguous(), call_counter=4 * i)
+            for i in range(40):
+                run(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(40, 40 + reps):
+                run(i)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            small[str(b)] = {"ms_per_step": dt / reps * 1e3, "value": (b * k1 + b * k1 * k2) * reps / dt, "steps": reps}
+            del plans, streams
+        res["small_batches"] = dict(small, note="same store, B0 seeds per step, step = one hipGraph launch (glx_plan), %d plans "
+                                                "alternating on as many streams; value in edges/s" % args.graph_streams)
     if args.edge_cut_probe == "on" and not sharded and world == 1 and args.workload == "c3" and B0 == 65536:
         res["edge_cut_world1"] = edge_cut_world1(args)
     if rank == 0:
