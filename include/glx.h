@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define GLX_ABI_VERSION 1
+/* 1: graph / features / samplers / aggregators / partition helpers.  2 (additions only): host registration, shard
+ * communicator, distributed store (+ replicas), request plans. */
+#define GLX_ABI_VERSION 2
 
 /* Exported symbols: libglx.so is built with -fvisibility=hidden. */
 #if defined(__GNUC__)
