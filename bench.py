@@ -863,6 +863,8 @@ def main():
             0's watchdog has spoken."""
             progress["stage"] = name + " leg"
             try:
+                if os.environ.get("GLX_BENCH_FAULT") == "%d:%s" % (rank, name):  # test knob: this rank fails this leg
+                    raise RuntimeError("injected fault (GLX_BENCH_FAULT)")
                 return fn()
             except Exception as ex:  # noqa: BLE001
                 log("rank %d: %s leg failed: %r" % (rank, name, ex))

@@ -53,6 +53,24 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
         assert "features_sharded placement" in res["config"]["workload"]
 
 
+def test_bench_reports_what_it_measured_when_a_rank_fails_in_a_leg():
+    """A rank that fails inside the halo leg leaves its peer in a collective: rank 0's watchdog must still print ONE
+    result line -- the placement that did finish, named as such, with the error -- and every process must leave."""
+    env = dict(os.environ, GLX_BENCH_FAULT="1:features_sharded")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--backend", "gloo", "--share-device", "--workload", "tiny", "--batch", "2048",
+           "--steps", "3", "--warmup", "1", "--cpu-baseline", "off", "--watchdog", "15"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    res = json.loads(lines[0])
+    assert "error" in res and "features_sharded" in res["error"]
+    assert res["value"] == res["placements"]["features_replicated"]["value"] > 0
+    assert "features_replicated placement (the only leg that finished)" in res["config"]["workload"]
+
+
 def test_bench_c5_hetero_two_ranks_on_one_gpu():
     """BASELINE configs[4] (3 edge types, per-type Topk + Sum) through the N > 1 path: one ShardedStore
     per edge type, verified against unpartitioned copies of the three graphs on every rank."""
