@@ -589,7 +589,12 @@ def main():
         log("hot-row replica (%s): %d rows (%.2f GB per GPU) selected + fetched in %.1fs"
             % (args.hot_by, hot.shape[0], hot.shape[0] * D * 4 / 1e9, time.time() - t_hot))
         graph_replica = None
-        if args.graph_replica == "on" and hot.shape[0] > 0:
+        # room: the replica can hold nearly every edge (RMAT hubs own most of them) at ~56 B per edge, plus the build's
+        # temporaries; skipped (with a note) when that is not there
+        room = torch.cuda.mem_get_info(dev)[0] > 3 * E * 56
+        if args.graph_replica == "on" and hot.shape[0] > 0 and not room:
+            log("graph replica skipped: not enough free HBM for a replica of up to %d edges" % E)
+        if args.graph_replica == "on" and hot.shape[0] > 0 and room:
             # the same vertices' adjacency rows on every GPU: hop-2 request rows are hop-1 samples, i.e. mostly hubs,
             # and those are then sampled here instead of travelling to their owner and back.  Built from the shards:
             # every owner cuts its hot vertices' rows (its edge ids, its row order) and the pieces are all-gathered
