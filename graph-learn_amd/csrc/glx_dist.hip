@@ -953,7 +953,7 @@ extern "C" int glx_dist_build_graph_replica(glx_dist_store* st, const int64_t* h
   GLX_HIP(hipStreamSynchronize(s));
   const glx_graph* g = st->graph;
   const int P = st->world, me = st->rank;
-  const bool weighted = g->weight != nullptr;
+  bool weighted = g->weight != nullptr;  // agreed on below: a shard without edges cannot tell
   const int64_t n1 = n > 0 ? n : 1;
   GlxTemp ids_d, sorted, bucketed, order, deg_mine, off_mine;
   const int64_t* d_hot = hot_ids;
@@ -1008,15 +1008,20 @@ extern "C" int glx_dist_build_graph_replica(glx_dist_store* st, const int64_t* h
         col_mine.as<int64_t>(), eid_mine.as<int64_t>(), weighted ? w_mine.as<float>() : nullptr);
     GLX_HIP(hipGetLastError());
   }
-  // every owner's edge total
+  // every owner's edge total, and whether the edge type is weighted (a shard without edges holds no weight array)
   GlxTemp d_e;
-  GLX_HIP(hipMalloc(&d_e.p, 8));
-  GLX_HIP(hipMemcpyAsync(d_e.p, &e_me, 8, hipMemcpyHostToDevice, s));
-  std::vector<int64_t> e_all((size_t)P);
-  rc = st->comm->allgather_i64(d_e.as<int64_t>(), 1, e_all.data(), s);
+  GLX_HIP(hipMalloc(&d_e.p, 16));
+  const int64_t mine2[2] = {e_me, weighted ? 1 : 0};
+  GLX_HIP(hipMemcpyAsync(d_e.p, mine2, 16, hipMemcpyHostToDevice, s));
+  std::vector<int64_t> all2((size_t)P * 2), e_all((size_t)P);
+  rc = st->comm->allgather_i64(d_e.as<int64_t>(), 2, all2.data(), s);
   if (rc != GLX_OK) return rc;
   std::vector<int64_t> eoffs((size_t)P + 1, 0);
-  for (int p = 0; p < P; ++p) eoffs[p + 1] = eoffs[p] + e_all[p];
+  for (int p = 0; p < P; ++p) {
+    e_all[p] = all2[(size_t)p * 2];
+    weighted = weighted || all2[(size_t)p * 2 + 1] != 0;
+    eoffs[p + 1] = eoffs[p] + e_all[p];
+  }
   const int64_t E = eoffs[P];
   GLX_REQUIRE(E < ((int64_t)1 << 40), "replica too large");
   // all-gather(v) of the pieces (an all-to-all whose every outgoing message is the same buffer), owner-major
@@ -1054,7 +1059,8 @@ extern "C" int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_gr
     GLX_REQUIRE(replica->device == st->device, "the replica lives on device %d, the store on %d", replica->device,
                 st->device);
     GLX_REQUIRE(replica->idmap.keys != nullptr, "a graph replica needs its vertex ids (glx_graph_build with ids)");
-    GLX_REQUIRE((replica->weight != nullptr) == (st->graph->weight != nullptr),
+    GLX_REQUIRE(st->graph->num_edges == 0 || replica->num_edges == 0 ||
+                    (replica->weight != nullptr) == (st->graph->weight != nullptr),
                 "the replica and the shard must both be weighted or both unweighted");
   }
   st->graph_replica = replica;

@@ -1110,6 +1110,12 @@ extern "C" int glx_sample_filtered(const glx_graph* g, int sampler, const int64_
   GLX_REQUIRE(src && nbr_out && eid_out, "NULL data pointer");
   int rc = check_filter(g, filter);
   if (rc != GLX_OK) return rc;
+  if (g->num_edges == 0) {
+    // no row has a neighbour, filtered or not: the plain samplers write the default ids (and an empty shard of a
+    // weighted type has no weight array to be recognised by)
+    return glx_sample_ex(g, sampler, src, rng_rows, batch, k, padding_mode, default_neighbor_id, seed, call_counter, nbr_out,
+                         eid_out, ptr_kind, stream);
+  }
   GLX_REQUIRE(sampler != GLX_SAMPLER_EDGE_WEIGHT || g->weight != nullptr, "EdgeWeightSampler needs a weighted graph");
   GLX_REQUIRE(sampler != GLX_SAMPLER_IN_DEGREE || g->alias_indeg != nullptr,
               "InDegreeSampler needs glx_graph_enable_in_degree()");

@@ -321,6 +321,12 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
       launch_slots<kSlotRandom>(a, s);
       break;
     case GLX_SAMPLER_EDGE_WEIGHT:
+      if (g->alias == nullptr && g->num_edges == 0) {
+        // a shard that holds no edge of a weighted type has no weight array to tell it is weighted: every row is
+        // empty, every slot is the default neighbour -- whichever kernel writes it
+        launch_slots<kSlotRandom>(a, s);
+        break;
+      }
       GLX_REQUIRE(g->alias != nullptr, "EdgeWeightSampler needs a weighted graph");
       // Replicate mode: ReplicatePadder ignores the drawn indices and (in the
       // reference) reads neighbors_[0..k) -- out of bounds when deg < k.  glx
@@ -332,6 +338,10 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
     case GLX_SAMPLER_IN_DEGREE: {
       // in_degree_sampler.cc:79-92: the alias draw of EdgeWeightSampler over the
       // neighbours' in-degrees (tables built once by glx_graph_enable_in_degree).
+      if (g->alias_indeg == nullptr && g->num_edges == 0) {
+        launch_slots<kSlotRandom>(a, s);  // an empty shard: default ids only
+        break;
+      }
       GLX_REQUIRE(g->alias_indeg != nullptr, "InDegreeSampler needs glx_graph_enable_in_degree()");
       SampleArgs b = a;
       b.alias = g->alias_indeg;

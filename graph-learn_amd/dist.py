@@ -373,7 +373,8 @@ def rows_of_graph(row_ptr, col, eid, weight, ids):
 def shard_graph(row_ptr, col, eid, weight, rank, world):
     """Rows of the (dense-id, torch) CSR owned by `rank`: v % world == rank."""
     V = row_ptr.shape[0] - 1
-    ids = torch.arange(rank, V, world, dtype=torch.int64, device=row_ptr.device)
+    ids = (torch.arange(rank, V, world, dtype=torch.int64, device=row_ptr.device) if rank < V
+           else torch.empty(0, dtype=torch.int64, device=row_ptr.device))  # more shards than vertices: an empty shard
     return rows_of_graph(row_ptr, col, eid, weight, ids)
 
 

@@ -523,3 +523,70 @@ def test_rccl_transport_call_pattern_with_several_ranks(P):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "fake_rccl_check.py"), str(P)], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and ("fake-rccl ok: world size %d" % P) in r.stdout, r.stdout[-4000:]
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_dist_store_fuzz(case):
+    """Random shapes the fixed cases do not reach: tiny graphs with more ranks than vertices, empty shards, empty
+    requests on some ranks, hot sets from nothing to everything (with ids nobody knows), replicas on or off,
+    ragged / stalled segments, every sampler and aggregator -- always against the unpartitioned operators."""
+    import dist as gdist
+    rng = np.random.default_rng(9000 + case)
+    dev = torch.device("cuda", 0)
+    Vf = int(rng.choice([3, 17, 200, 1500]))
+    Ef = int(rng.integers(1, 12 * Vf))
+    P = int(rng.choice([1, 2, 3, 5, 8]))
+    Df = int(rng.choice([1, 4, 20, 64]))
+    src = rng.integers(0, Vf, Ef)
+    dst = rng.integers(0, Vf, Ef)
+    order = np.lexsort((np.arange(Ef), src))
+    wgt = (rng.random(Ef) + 0.01).astype(np.float32)
+    # rows weight-descending like the reference's Build(), ties by insertion order
+    order = np.lexsort((np.arange(Ef), -wgt, src))
+    rp = np.zeros(Vf + 1, np.int64)
+    np.add.at(rp, src + 1, 1)
+    rp = np.cumsum(rp)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    trp, tcol, teid, tw = t(rp), t(dst[order].astype(np.int64)), t(order.astype(np.int64)), t(wgt[order])
+    X = rng.standard_normal((Vf, Df)).astype(np.float32)
+    whole, feats = glx.Graph(trp, tcol, teid, tw), glx.Features(t(X))
+    shards = []
+    for r in range(P):
+        srp, scol, seid, sw, sids = gdist.shard_graph(trp, tcol, teid, tw, r, P)
+        rows = X[r::P].copy() if r < Vf else np.zeros((0, Df), np.float32)
+        shards.append((glx.Graph(srp, scol, seid, sw, ids=sids), glx.Features(t(rows), ids=sids)))
+    n_hot = int(rng.choice([0, 1, Vf // 3, Vf]))
+    hot = np.concatenate([rng.permutation(Vf)[:n_hot], [Vf + 3] if case % 2 else []]).astype(np.int64)
+    use_graph_replica = bool(case % 3) and hot.shape[0] > 0
+    k = int(rng.choice([1, 2, 7, 33]))
+    pad = int(rng.integers(0, 2))
+
+    def body(r, comm):
+        g, f = shards[r]
+        st = glx.DistStore(comm, graph=g, features=f)
+        st.set_cache(hot if r % 2 else t(hot), default_attr=9.0)
+        if use_graph_replica:
+            st.build_graph_replica(t(hot) if r % 2 else hot)
+        rr = np.random.default_rng(500 * case + r)
+        n = 0 if (r == 1 and case % 4 == 0) else int(rr.integers(1, 400))
+        ids = t(rr.integers(-2, Vf + 2, n).astype(np.int64))
+        for name in glx.SAMPLER_IDS:
+            got = st.sample(name, ids, k, seed=case, call_counter=r + 3, padding_mode=pad, default_neighbor_id=-7)
+            want = whole.sample(name, ids, k, seed=case, call_counter=r + 3, padding_mode=pad, default_neighbor_id=-7)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (name, r, case)
+        nbrs = got[0].reshape(-1).contiguous()
+        m = int(nbrs.shape[0])
+        nseg = max(1, m // 3)
+        seg = np.sort(rr.integers(0, nseg + 1, m)).astype(np.int32)  # ragged; ids of segment `nseg` stall the cursor
+        for op in glx.AGGREGATOR_IDS:
+            e, c = st.aggregate(op, nbrs, t(seg), nseg, default_attr=0.25)
+            we, wc = feats.aggregate(op, nbrs, t(seg), nseg, default_attr=0.25)
+            assert torch.equal(c, wc) and torch.equal(e.view(torch.int32), we.view(torch.int32)), (op, r, case)
+        # (collective: a rank with an empty request takes part all the same)
+        e, c = st.aggregate("MeanAggregator", nbrs, None, n, default_attr=-1.0)
+        if n > 0:
+            we, wc = feats.aggregate("MeanAggregator", nbrs, None, n, default_attr=-1.0)
+            assert torch.equal(c, wc) and torch.equal(e.view(torch.int32), we.view(torch.int32)), (r, case)
+        rows = st.lookup(ids, default_attr=2.0)
+        assert torch.equal(rows.view(torch.int32), feats.lookup(ids, 2.0).view(torch.int32)), (r, case)
+    _run_ranks(P, body)
