@@ -590,3 +590,64 @@ def test_dist_store_fuzz(case):
         rows = st.lookup(ids, default_attr=2.0)
         assert torch.equal(rows.view(torch.int32), feats.lookup(ids, 2.0).view(torch.int32)), (r, case)
     _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_dist_store_fuzz_sparse_ids_filters_in_degree(case):
+    """The same idea on graphs with sparse, partly negative vertex ids (hashed id maps, owner = llabs(id) % P, the
+    replica's hash-map form), built on the device from edge lists; requests with id == value filters;
+    InDegreeSampler over in-degrees summed across the shards."""
+    rng = np.random.default_rng(7000 + case)
+    dev = torch.device("cuda", 0)
+    Vf = int(rng.choice([5, 60, 900]))
+    Ef = int(rng.integers(2, 15 * Vf))
+    P = int(rng.choice([2, 3, 4, 8]))
+    Df = int(rng.choice([3, 16]))
+    names = rng.permutation(np.arange(-Vf, 3 * Vf))[:Vf].astype(np.int64) * 5 + 1  # sparse, negative and positive
+    src = names[rng.integers(0, Vf, Ef)]
+    dst = names[rng.integers(0, Vf, Ef)]
+    wgt = (rng.random(Ef) + 0.01).astype(np.float32)
+    ts = rng.permutation(Ef).astype(np.int64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    whole = glx.Graph.from_edges(t(src), t(dst), t(wgt), timestamp=t(ts))
+    whole.enable_in_degree()
+    X = rng.standard_normal((Vf, Df)).astype(np.float32)
+    feats = glx.Features(t(X), ids=t(names))
+    shards = []
+    for r in range(P):
+        own = (np.abs(src) % P) == r
+        g = glx.Graph.from_edges(t(src[own]), t(dst[own]), t(wgt[own]), edge_ids=t(np.nonzero(own)[0].astype(np.int64)),
+                                 timestamp=t(ts[own]))
+        fown = (np.abs(names) % P) == r
+        shards.append((g, glx.Features(t(X[fown]), ids=t(names[fown]))))
+    n_hot = int(rng.choice([0, 2, Vf // 2, Vf]))
+    hot = rng.permutation(names)[:n_hot].astype(np.int64)
+    k = int(rng.choice([1, 3, 12]))
+
+    def body(r, comm):
+        g, f = shards[r]
+        st = glx.DistStore(comm, graph=g, features=f)
+        st.set_cache(t(hot))
+        if n_hot:
+            st.build_graph_replica(hot)
+        st.enable_in_degree()
+        rr = np.random.default_rng(300 * case + r)
+        n = int(rr.integers(0, 300))
+        ids = t(np.concatenate([names[rr.integers(0, Vf, n)], [0, 7]]).astype(np.int64))
+        for name in list(glx.SAMPLER_IDS) + ["InDegreeSampler"]:
+            got = st.sample(name, ids, k, seed=case, call_counter=5, default_neighbor_id=-7)
+            want = whole.sample(name, ids, k, seed=case, call_counter=5, default_neighbor_id=-7)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (name, r, case)
+        # filter: never step to a given vertex (id == value); the value travels with its row
+        vals = t(names[rr.integers(0, Vf, ids.shape[0])])
+        for name in ("TopkSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler"):
+            got = st.sample(name, ids, k, seed=case, call_counter=6, filter_type=glx.FILTER_EQUAL,
+                            filter_field=glx.FILTER_FIELD_ID, values=vals)
+            want = whole.sample_filtered(name, ids, k, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, seed=case, call_counter=6)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (name, r, case, "id filter")
+        nbrs = got[0].reshape(-1).contiguous()
+        for op in ("SumAggregator", "MaxAggregator"):
+            e, c = st.aggregate(op, nbrs, None, ids.shape[0], default_attr=0.5)
+            we, wc = feats.aggregate(op, nbrs, None, ids.shape[0], default_attr=0.5)
+            assert torch.equal(c, wc) and torch.equal(e.view(torch.int32), we.view(torch.int32)), (op, r, case)
+    _run_ranks(P, body)
