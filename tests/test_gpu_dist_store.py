@@ -651,3 +651,30 @@ def test_dist_store_fuzz_sparse_ids_filters_in_degree(case):
             we, wc = feats.aggregate(op, nbrs, None, ids.shape[0], default_attr=0.5)
             assert torch.equal(c, wc) and torch.equal(e.view(torch.int32), we.view(torch.int32)), (op, r, case)
     _run_ranks(P, body)
+
+
+def test_large_request_with_graph_replica_takes_the_scan_kernel_path(world):
+    """A 7.6 M-row request over 8 shards + the replica bucket is more than 32768 histogram cells: the partition runs
+    its scan kernel between count and scatter (smaller requests let the scatter kernel scan the tile counts itself)."""
+    import dist as gdist
+    P = 8
+    whole, dev = world["whole"], world["dev"]
+    gs, _ = world["shards"][P]
+    rp, col, eid, w = (torch.from_numpy(a).to(dev) for a in synth.small_graph(V, 80000, seed=21, weighted=True,
+                                                                                hub_degree=3000))
+    hot = torch.from_numpy(np.argsort(-world["indeg"], kind="stable")[:300].astype(np.int64)).to(dev)
+    replica = glx.Graph(*gdist.rows_of_graph(rp, col, eid, w, hot)[:4], ids=hot)
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        st.set_graph_replica(replica)
+        n = 7_600_000 if r == 0 else 1000
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(40 + r)
+        ids = torch.randint(-3, V + 3, (n,), generator=gen, device=dev)
+        got = st.sample("TopkSampler", ids, 1, seed=1, call_counter=2, default_neighbor_id=-9)
+        want = whole.sample("TopkSampler", ids, 1, seed=1, call_counter=2, default_neighbor_id=-9)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), r
+        assert st.last_sample_rows()["from_graph_replica"] > 0
+    _run_ranks(P, body)
+    replica.close()
