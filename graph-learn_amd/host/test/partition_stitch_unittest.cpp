@@ -373,4 +373,83 @@ TEST(PartitionStitchTest, DistributeRunnerOnTwoServersEqualsOneStore) {
   }
 }
 
+// A server that holds NO edge of a weighted edge type (every source id happens to live elsewhere -- small edge types
+// of a heterogeneous graph) still takes part: it serves the rows of the vertices it owns (all empty: default ids)
+// and its own requests are answered by the other server.
+TEST(PartitionStitchTest, AServerWithoutEdgesOfATypeStillServes) {
+  GraphStore whole, shard[2];
+  io::SideInfo einfo;
+  einfo.format = io::kWeighted;
+  einfo.type = "e";
+  GraphStore* all[3] = {&whole, &shard[0], &shard[1]};
+  for (GraphStore* s : all) s->GetGraph("e")->SetSideInfo(&einfo);
+  std::mt19937_64 rng(5);
+  for (int e = 0; e < 600; ++e) {
+    io::EdgeValue v;
+    v.src_id = (int64_t)(rng() % 40) * 2;  // even ids only: server 1 owns none of the sources
+    v.dst_id = (int64_t)(rng() % 80);
+    v.weight = 0.01f + (float)(rng() % 1000) / 1000.0f + e * 1e-6f;
+    whole.GetGraph("e")->Add(&v);
+    shard[0].GetGraph("e")->Add(&v);
+  }
+  IndexOption opt;
+  opt.name = "sort";
+  for (GraphStore* s : all) EXPECT_TRUE(s->GetGraph("e")->Build(opt).ok());
+  std::vector<int64_t> ids;
+  for (int i = 0; i < 120; ++i) ids.push_back((i * 5) % 90);  // even and odd ids, some unknown
+  const char* samplers[3] = {"EdgeWeightSampler", "TopkSampler", "RandomWithoutReplacementSampler"};
+  std::vector<std::vector<int64_t>> want;
+  OpFactory::GetInstance()->Set(&whole);
+  for (int n = 0; n < 3; ++n) {
+    SamplingRequest req("e", samplers[n], 4);
+    req.Set(ids.data(), (int32_t)ids.size());
+    req.SetCallCounter(40 + n);
+    SamplingResponse res;
+    EXPECT_TRUE(OpFactory::GetInstance()->Create(samplers[n])->Process(&req, &res).ok());
+    want.emplace_back(res.GetNeighborIds(), res.GetNeighborIds() + ids.size() * 4);
+  }
+  bool ok[2] = {true, true};
+  std::string why[2];
+  auto server = [&](int r) {
+    glx_comm* comm = nullptr;
+    if (glx_comm_init_local(77100, 0, r, 2, &comm) != GLX_OK) {
+      ok[r] = false;
+      why[r] = glx_last_error();
+      return;
+    }
+    {
+      Env env(comm, &shard[r]);
+      for (int n = 0; n < 3 && ok[r]; ++n) {
+        Operator* op = OpFactory::GetInstance()->Create(samplers[n]);
+        std::unique_ptr<OpRunner> runner = GetOpRunner(&env, op);
+        SamplingRequest req("e", samplers[n], 4);
+        req.Set(ids.data(), (int32_t)ids.size());
+        req.SetCallCounter(40 + n);
+        SamplingResponse res;
+        Status s = runner->Run(&req, &res);
+        if (!s.ok()) {
+          ok[r] = false;
+          why[r] = std::string(samplers[n]) + ": " + s.ToString();
+          break;
+        }
+        for (size_t i = 0; i < ids.size() * 4; ++i) {
+          if (res.GetNeighborIds()[i] != want[n][i]) {
+            ok[r] = false;
+            why[r] = std::string(samplers[n]) + ": neighbour mismatch";
+            break;
+          }
+        }
+      }
+    }
+    glx_comm_destroy(comm);
+  };
+  std::thread t0(server, 0), t1(server, 1);
+  t0.join();
+  t1.join();
+  for (int r = 0; r < 2; ++r) {
+    if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
+    EXPECT_TRUE(ok[r]);
+  }
+}
+
 int main() { return RunAllTests(); }
