@@ -57,10 +57,14 @@ def test_fuzz_samplers(seed, V, maxdeg, k, pad, hashed, nq, rng_seed, cc):
 @settings(**dict(COMMON, max_examples=120))
 @given(seed=st.integers(0, 2 ** 31 - 1), V=st.integers(1, 30), maxdeg=st.integers(0, 150), k=st.integers(1, 40),
        pad=st.integers(0, 1), ftype=st.integers(1, 2), ffield=st.integers(0, 2), retry=st.integers(0, 6),
-       sorted_ts=st.booleans(), rng_seed=st.integers(0, 2 ** 63 - 1))
-def test_fuzz_filtered_samplers(seed, V, maxdeg, k, pad, ftype, ffield, retry, sorted_ts, rng_seed):
+       sorted_ts=st.booleans(), rng_seed=st.integers(0, 2 ** 63 - 1), indexed=st.booleans(), shared=st.booleans())
+def test_fuzz_filtered_samplers(seed, V, maxdeg, k, pad, ftype, ffield, retry, sorted_ts, rng_seed, indexed, shared):
     """op::Filter on arbitrary rows: repeated neighbour ids, tied and (optionally) unsorted timestamps -- the binary
-    search of the timestamp path is then run on data it was not made for, and must still match the restatement."""
+    search of the timestamp path is then run on data it was not made for, and must still match the restatement.
+    indexed: with the id-sorted row index (id == value hit runs are read from it); shared: the alias samplers build one
+    table per distinct (vertex, value) pair of the request instead of one per row."""
+    import os
+    os.environ["GLX_FILTER_DEDUP_MIN_ROWS"] = "1" if shared else "0"
     rng = np.random.default_rng(seed)
     deg = rng.integers(0, maxdeg + 1, V)
     deg[rng.random(V) < 0.2] = 0
@@ -78,6 +82,8 @@ def test_fuzz_filtered_samplers(seed, V, maxdeg, k, pad, ftype, ffield, retry, s
     og["indeg_weight"] = ORC.in_degree_alias(og)[1]
     dev = glx.Graph(rp, col, eid, w).enable_in_degree()
     dev.set_timestamps(ts)
+    if indexed:
+        dev.enable_id_index()
     q = np.concatenate([rng.integers(0, V, 40), [V + 3, -2]]).astype(np.int64)
     vals = rng.integers(-1, 26 if ffield == 2 else 13, q.shape[0]).astype(np.int64)
     flt = dict(type=ftype, field=ffield, values=vals, retry_times=retry, default_timestamp=7)
@@ -93,6 +99,7 @@ def test_fuzz_filtered_samplers(seed, V, maxdeg, k, pad, ftype, ffield, retry, s
     want = ORC.sample_full_filtered(og, q, lim, flt, padding_mode=pad, default_neighbor_id=-11)
     assert all(np.array_equal(a, b) for a, b in zip(got, want)), (lim, pad, ftype, ffield)
     dev.close()
+    os.environ.pop("GLX_FILTER_DEDUP_MIN_ROWS", None)
 
 
 @settings(**COMMON)
