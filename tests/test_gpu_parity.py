@@ -808,3 +808,38 @@ def test_alias_tables_fuzz_bit_exact():
     oprob, oalias = orc.alias_build(rp, w)
     bad = np.nonzero((alias != oalias) | (prob.view(np.uint32) != oprob.view(np.uint32)))[0]
     assert bad.size == 0, ("first mismatch in row", int(np.searchsorted(rp, bad[0], side="right") - 1), int(bad.size))
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_request_plan_fuzz(case):
+    """Plans of random shape -- 1 to 3 hops, odd fanouts and batches (1 seed included), feature widths that are not a
+    multiple of 4, either padding, with and without the aggregation -- replayed several times, against separate calls."""
+    import torch
+    rng = np.random.default_rng(600 + case)
+    Vp = int(rng.choice([50, 800]))
+    rp, col, eid, w = synth.small_graph(Vp, 12 * Vp, seed=case, weighted=True, hub_degree=int(rng.choice([0, 200])))
+    Dp = int(rng.choice([1, 5, 8, 33]))
+    X = rng.standard_normal((Vp, Dp)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    g, f = glx.Graph(t(rp), t(col), t(eid), t(w)), glx.Features(t(X))
+    hops = int(rng.integers(1, 4))
+    fan = [int(x) for x in rng.choice([1, 2, 3, 5, 17], hops)]
+    batch = int(rng.choice([1, 3, 100]))
+    pad = int(rng.integers(0, 2))
+    name = list(glx.SAMPLER_IDS)[case % len(glx.SAMPLER_IDS)]
+    agg = [None, "SumAggregator", "MaxAggregator", "MeanAggregator"][case % 4]
+    plan = glx.Plan([g] * hops, name, fan, batch, features=[f] * hops if agg else None, agg=agg, seed=77, padding_mode=pad,
+                    default_neighbor_id=-6, default_attr=1.5)
+    for run in range(3):
+        seeds = t(rng.integers(-1, Vp + 2, batch).astype(np.int64))
+        out = plan.run(seeds, call_counter=100 * run)
+        ref = glx.sample_hops([g] * hops, name, seeds, fan, seed=77, call_counter=100 * run, padding_mode=pad,
+                              default_neighbor_id=-6)
+        torch.cuda.synchronize()
+        for h in range(hops):
+            assert torch.equal(out[h]["nbr"], ref[h][0]) and torch.equal(out[h]["eid"], ref[h][1]), (name, h, run)
+            if agg:
+                e, c = f.aggregate(agg, ref[h][0].reshape(-1), None, ref[h][0].shape[0], default_attr=1.5)
+                assert torch.equal(out[h]["cnt"], c) and torch.equal(out[h]["emb"].view(torch.int32), e.view(torch.int32)), (agg, h)
+    plan.close()
