@@ -638,6 +638,11 @@ def test_dist_store_fuzz_sparse_ids_filters_in_degree(case):
         if n_hot:
             st.build_graph_replica(hot)
         st.enable_in_degree()
+        # the hottest vertices by in-degree summed over the shards: ties go to the smaller id, the same list everywhere
+        uniq, cnt = np.unique(dst, return_counts=True)
+        by = np.lexsort((uniq, -cnt))
+        want_hot = uniq[by][: max(1, Vf // 3)]
+        assert np.array_equal(st.hot_ids(max(1, Vf // 3)), want_hot[: min(want_hot.shape[0], max(1, Vf // 3))]), (r, case)
         rr = np.random.default_rng(300 * case + r)
         n = int(rr.integers(0, 300))
         ids = t(np.concatenate([names[rr.integers(0, Vf, n)], [0, 7]]).astype(np.int64))
