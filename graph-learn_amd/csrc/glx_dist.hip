@@ -511,6 +511,38 @@ __global__ __launch_bounds__(256) void glx_dist_rep_rows_kernel(GlxIdMap map, co
   }
 }
 
+// ---- partitioned FullSampler (glx_dist_sample_full_*) ----
+// row `order[pos]` of the request takes the `deg[pos]` values that arrived at `src_off[pos]` (rows arrive in bucketed
+// order, owner by owner) to its place `dst_off[order[pos]]`; one wave per row
+__global__ __launch_bounds__(256) void glx_dist_ragged_stitch_kernel(const int64_t* __restrict__ order,
+                                                                     const int64_t* __restrict__ src_off,
+                                                                     const int64_t* __restrict__ deg_b,
+                                                                     const int64_t* __restrict__ dst_off, int64_t n,
+                                                                     const int64_t* __restrict__ nbr_in,
+                                                                     const int64_t* __restrict__ eid_in,
+                                                                     int64_t* __restrict__ nbr_out,
+                                                                     int64_t* __restrict__ eid_out) {
+  const int64_t pos = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (pos >= n) return;
+  const int64_t s = src_off[pos], d = deg_b[pos], o = dst_off[order[pos]];
+  for (int64_t j = lane; j < d; j += 64) {
+    nbr_out[o + j] = nbr_in[s + j];
+    eid_out[o + j] = eid_in[s + j];
+  }
+}
+__global__ void glx_dist_widen_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void glx_dist_stitch_deg_kernel(const int64_t* __restrict__ deg_b, const int64_t* __restrict__ order, int64_t n,
+                                           int32_t* __restrict__ deg_out, int64_t* __restrict__ deg64_out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  deg_out[order[i]] = (int32_t)deg_b[i];
+  deg64_out[order[i]] = deg_b[i];
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 4096) {
   int64_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -896,6 +928,121 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   return GLX_OK;
 }
 
+// Partitioned FullSampler.  Phase 1 (always): request rows to their owners, the owners' row sizes back, offsets.
+// Phase 2 (fill): the owners' values back, every row to its place.  Device pointers.
+int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit, int32_t* deg_out,
+                            int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out, int64_t capacity, bool fill,
+                            int64_t* total_out, hipStream_t s) {
+  const int P = st->world;
+  const int64_t n = batch, n1 = n > 0 ? n : 1;
+  Carver cv;
+  const size_t o_buck = cv.take((size_t)n1 * 8);
+  const size_t o_ord = cv.take((size_t)n1 * 8);
+  const size_t o_degb = cv.take((size_t)n1 * 8);
+  const size_t o_soff = cv.take((size_t)(n1 + 1) * 8);
+  const size_t o_d64 = cv.take((size_t)(n1 + 1) * 8);
+  int rc = st->req.ensure(cv.at);
+  if (rc != GLX_OK) return rc;
+  int64_t* bucketed = reinterpret_cast<int64_t*>(st->req.p + o_buck);
+  int64_t* order = reinterpret_cast<int64_t*>(st->req.p + o_ord);
+  int64_t* deg_b = reinterpret_cast<int64_t*>(st->req.p + o_degb);
+  int64_t* src_off = reinterpret_cast<int64_t*>(st->req.p + o_soff);
+  int64_t* deg64 = reinterpret_cast<int64_t*>(st->req.p + o_d64);
+  rc = glx_partition(st->device, src, n, P, bucketed, order, st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  st->h_mat.resize((size_t)P * P);
+  rc = st->comm->allgather_i64(st->d_vals, P, st->h_mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  Routing rt;
+  routing_from_matrix(st, P, &rt);
+  const int64_t m = rt.n_recv, m1 = m > 0 ? m : 1;
+  GLX_REQUIRE(m <= INT32_MAX, "more than 2^31 request rows arrived at one shard");
+  GlxTemp ids_in, deg_loc, off_loc, deg_loc64;
+  GLX_HIP(hipMalloc(&ids_in.p, (size_t)m1 * 8));
+  GLX_HIP(hipMalloc(&deg_loc.p, (size_t)m1 * 4));
+  GLX_HIP(hipMalloc(&off_loc.p, (size_t)(m1 + 1) * 8));
+  GLX_HIP(hipMalloc(&deg_loc64.p, (size_t)m1 * 8));
+  GlxSeg seg_ids{bucketed, ids_in.p, 8};
+  rc = st->comm->alltoallv(&seg_ids, 1, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
+                           rt.recv_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(hipMemsetAsync(off_loc.p, 0, (size_t)(m1 + 1) * 8, s));
+  if (m > 0) {
+    rc = glx_sample_full_sizes(st->graph, ids_in.as<int64_t>(), (int32_t)m, max_limit, deg_loc.as<int32_t>(),
+                               off_loc.as<int64_t>(), GLX_PTR_DEVICE, s);
+    if (rc != GLX_OK) return rc;
+    glx_dist_widen_i32_kernel<<<(unsigned)((m + 255) / 256), 256, 0, s>>>(deg_loc.as<int32_t>(), m, deg_loc64.as<int64_t>());
+  }
+  GlxSeg seg_deg{deg_loc64.p, deg_b, 8};
+  rc = st->comm->alltoallv(&seg_deg, 1, rt.recv_counts.data(), rt.recv_offs.data(), rt.send_counts.data(),
+                           rt.send_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  int64_t total = 0;
+  if (n > 0) {
+    glx_dist_stitch_deg_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(deg_b, order, n, deg_out, deg64);
+#define SCAN_O(tmp, bytes) rocprim::exclusive_scan(tmp, bytes, deg64, offsets_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)
+    GLX_ROCPRIM(SCAN_O);
+#undef SCAN_O
+#define SCAN_S(tmp, bytes) rocprim::exclusive_scan(tmp, bytes, deg_b, src_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)
+    GLX_ROCPRIM(SCAN_S);
+#undef SCAN_S
+    int64_t last[2] = {0, 0};
+    GLX_HIP(hipMemcpyAsync(&last[0], offsets_out + (n - 1), 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipMemcpyAsync(&last[1], deg64 + (n - 1), 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+    total = last[0] + last[1];
+  }
+  GLX_HIP(hipMemcpyAsync(offsets_out + n, &total, 8, hipMemcpyHostToDevice, s));
+  GLX_HIP(hipStreamSynchronize(s));  // `total` lives on this frame
+  if (total_out) *total_out = total;
+  if (!fill) return GLX_OK;
+  GLX_REQUIRE(total <= capacity, "the response holds %lld values, the buffers %lld", (long long)total, (long long)capacity);
+  // the owners' values: how many each requester gets = the span of its rows in off_loc
+  std::vector<int64_t> h_cut((size_t)P + 1, 0);
+  for (int q = 0; q <= P; ++q) {
+    GLX_HIP(hipMemcpyAsync(&h_cut[(size_t)q], off_loc.as<int64_t>() + rt.recv_offs[q], 8, hipMemcpyDeviceToHost, s));
+  }
+  GLX_HIP(hipStreamSynchronize(s));
+  std::vector<int64_t> send_vals((size_t)P), send_voffs((size_t)P);
+  for (int q = 0; q < P; ++q) {
+    send_vals[(size_t)q] = h_cut[(size_t)q + 1] - h_cut[(size_t)q];
+    send_voffs[(size_t)q] = h_cut[(size_t)q];
+  }
+  GlxTemp d_cnt, nbr_loc, eid_loc, nbr_in, eid_in;
+  GLX_HIP(hipMalloc(&d_cnt.p, (size_t)P * 8));
+  GLX_HIP(hipMemcpyAsync(d_cnt.p, send_vals.data(), (size_t)P * 8, hipMemcpyHostToDevice, s));
+  std::vector<int64_t> mat((size_t)P * P);
+  rc = st->comm->allgather_i64(d_cnt.as<int64_t>(), P, mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  std::vector<int64_t> recv_vals((size_t)P), recv_voffs((size_t)P + 1, 0);
+  for (int q = 0; q < P; ++q) {
+    recv_vals[(size_t)q] = mat[(size_t)q * P + st->rank];  // what owner q sends to me
+    recv_voffs[(size_t)q + 1] = recv_voffs[(size_t)q] + recv_vals[(size_t)q];
+  }
+  GLX_REQUIRE(recv_voffs[(size_t)P] == total, "the owners announce %lld values, the row sizes add up to %lld",
+              (long long)recv_voffs[(size_t)P], (long long)total);
+  const int64_t loc_total = h_cut[(size_t)P];
+  GLX_HIP(hipMalloc(&nbr_loc.p, (size_t)(loc_total + 1) * 8));
+  GLX_HIP(hipMalloc(&eid_loc.p, (size_t)(loc_total + 1) * 8));
+  GLX_HIP(hipMalloc(&nbr_in.p, (size_t)(total + 1) * 8));
+  GLX_HIP(hipMalloc(&eid_in.p, (size_t)(total + 1) * 8));
+  if (m > 0 && loc_total > 0) {
+    rc = glx_sample_full(st->graph, ids_in.as<int64_t>(), (int32_t)m, max_limit, off_loc.as<int64_t>(),
+                         nbr_loc.as<int64_t>(), eid_loc.as<int64_t>(), GLX_PTR_DEVICE, s);
+    if (rc != GLX_OK) return rc;
+  }
+  GlxSeg seg_vals[2] = {{nbr_loc.p, nbr_in.p, 8}, {eid_loc.p, eid_in.p, 8}};
+  rc = st->comm->alltoallv(seg_vals, 2, send_vals.data(), send_voffs.data(), recv_vals.data(), recv_voffs.data(), s);
+  if (rc != GLX_OK) return rc;
+  if (n > 0 && total > 0) {
+    glx_dist_ragged_stitch_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, s>>>(
+        order, src_off, deg_b, offsets_out, n, nbr_in.as<int64_t>(), eid_in.as<int64_t>(), nbr_out, eid_out);
+    GLX_HIP(hipGetLastError());
+  }
+  GLX_HIP(hipStreamSynchronize(s));  // the temporaries above are released on return
+  return GLX_OK;
+}
+
 int check_store(const glx_dist_store* st, int ptr_kind) {
   GLX_REQUIRE(st != nullptr, "store is NULL");
   GLX_REQUIRE(ptr_kind == GLX_PTR_HOST || ptr_kind == GLX_PTR_DEVICE, "bad ptr_kind");
@@ -1156,6 +1303,44 @@ extern "C" int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* s
   GLX_HIP(e);
   GLX_HIP(e2);
   return GLX_OK;
+}
+
+extern "C" int glx_dist_sample_full_sizes(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
+                                          int32_t* degrees_out, int64_t* offsets_out, void* stream) {
+  int rc = check_store(st, GLX_PTR_DEVICE);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(batch >= 0 && offsets_out != nullptr && (batch == 0 || (src && degrees_out)), "bad request");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  if (st->world == 1 && st->shortcut) {
+    return glx_sample_full_sizes(st->graph, src, batch, max_limit, degrees_out, offsets_out, GLX_PTR_DEVICE, stream);
+  }
+  return dist_sample_full_device(st, src, batch, max_limit, degrees_out, offsets_out, nullptr, nullptr, 0, false, nullptr,
+                                 glx_stream(stream));
+}
+
+extern "C" int glx_dist_sample_full(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
+                                    int32_t* degrees_out, int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out,
+                                    int64_t capacity, void* stream) {
+  int rc = check_store(st, GLX_PTR_DEVICE);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(batch >= 0 && offsets_out != nullptr && (batch == 0 || (src && degrees_out)), "bad request");
+  GLX_REQUIRE(capacity >= 0 && (capacity == 0 || (nbr_out && eid_out)), "bad response buffers");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  if (st->world == 1 && st->shortcut) {
+    rc = glx_sample_full_sizes(st->graph, src, batch, max_limit, degrees_out, offsets_out, GLX_PTR_DEVICE, stream);
+    if (rc != GLX_OK) return rc;
+    int64_t total = 0;
+    GLX_HIP(hipMemcpyAsync(&total, offsets_out + batch, 8, hipMemcpyDeviceToHost, glx_stream(stream)));
+    GLX_HIP(hipStreamSynchronize(glx_stream(stream)));
+    GLX_REQUIRE(total <= capacity, "the response holds %lld values, the buffers %lld", (long long)total, (long long)capacity);
+    return glx_sample_full(st->graph, src, batch, max_limit, offsets_out, nbr_out, eid_out, GLX_PTR_DEVICE, stream);
+  }
+  return dist_sample_full_device(st, src, batch, max_limit, degrees_out, offsets_out, nbr_out, eid_out, capacity, true,
+                                 nullptr, glx_stream(stream));
 }
 
 extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,

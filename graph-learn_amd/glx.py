@@ -51,7 +51,7 @@ EXPORTS = [
     "glx_comm_unique_id", "glx_comm_init_rccl", "glx_comm_init_local", "glx_comm_init_callbacks", "glx_comm_destroy",
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_store_set_graph_replica",
-    "glx_dist_build_graph_replica",
+    "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full",
     "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
@@ -176,6 +176,8 @@ def lib():
         L.glx_dist_store_set_cache.argtypes = [vp, vp, i64, f32, ci, vp]
         L.glx_dist_store_set_graph_replica.argtypes = [vp, vp]
         L.glx_dist_build_graph_replica.argtypes = [vp, vp, i64, ci, vp, vp]
+        L.glx_dist_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.glx_dist_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]
         L.glx_dist_last_sample_rows.argtypes = [vp, vp, vp, vp]
         L.glx_dist_hot_ids.argtypes = [vp, i64, vp, ctypes.POINTER(i64), vp]
         L.glx_dist_enable_in_degree.argtypes = [vp, vp, vp]
@@ -842,6 +844,23 @@ class DistStore:
         if attach:
             self.set_graph_replica(g)
         return g
+
+    def sample_full(self, src, max_limit=0):
+        """Collective FullSampler over the shards: -> (degrees[batch] int32, nbr[total], eid[total]) for this rank's
+        rows, as Graph.sample_full answers on one store.  torch CUDA ids."""
+        import torch
+        assert _is_torch(src) and src.is_cuda
+        batch = int(src.shape[0])
+        deg = torch.empty(batch, dtype=torch.int32, device=src.device)
+        off = torch.empty(batch + 1, dtype=torch.int64, device=src.device)
+        stream = _stream(PTR_DEVICE, self.comm.device)
+        _check(lib().glx_dist_sample_full_sizes(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0], stream))
+        total = int(off[-1].item())
+        nbr = torch.empty(total, dtype=torch.int64, device=src.device)
+        eid = torch.empty(total, dtype=torch.int64, device=src.device)
+        _check(lib().glx_dist_sample_full(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0],
+                                          _ptr(nbr)[0] if total else None, _ptr(eid)[0] if total else None, total, stream))
+        return deg, nbr, eid
 
     def last_sample_rows(self):
         """{'rows', 'from_graph_replica', 'remote'} of the last sample() on this rank."""

@@ -2,6 +2,6 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=$PWD/gpurun_out/r02_run42
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_dist_store.py -x -q -m gpu --timeout 600 -k "fuzz" > $O/pytest.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_dist_store.py -x -q -m gpu --timeout 600 -k "fuzz or full_sampler" > $O/pytest.log 2>&1
 echo "rc=$?"
 tail -30 $O/pytest.log | cut -c1-250

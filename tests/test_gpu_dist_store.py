@@ -596,6 +596,8 @@ def test_dist_store_fuzz(case):
             assert torch.equal(c, wc) and torch.equal(e.view(torch.int32), we.view(torch.int32)), (r, case)
         rows = st.lookup(ids, default_attr=2.0)
         assert torch.equal(rows.view(torch.int32), feats.lookup(ids, 2.0).view(torch.int32)), (r, case)
+        for a, b in zip(st.sample_full(ids, case % 4), whole.sample_full(ids, case % 4)):
+            assert torch.equal(a, b), (r, case, "full")
     _run_ranks(P, body)
 
 
@@ -690,3 +692,20 @@ def test_large_request_with_graph_replica_takes_the_scan_kernel_path(world):
         assert st.last_sample_rows()["from_graph_replica"] > 0
     _run_ranks(P, body)
     replica.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_dist_full_sampler_equals_unpartitioned(world, P):
+    """FullSampler's sparse response through the shards: sizes first, then the values, every row at its place."""
+    whole, dev = world["whole"], world["dev"]
+    gs, _ = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        src = _requests(r, dev, n=0 if (P > 1 and r == 1) else 1500)[: (0 if (P > 1 and r == 1) else None)]
+        for limit in (0, 3, 5000):
+            got = st.sample_full(src, limit)
+            want = whole.sample_full(src, limit)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (limit, r)
+    _run_ranks(P, body)
