@@ -1305,42 +1305,75 @@ extern "C" int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* s
   return GLX_OK;
 }
 
-extern "C" int glx_dist_sample_full_sizes(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
-                                          int32_t* degrees_out, int64_t* offsets_out, void* stream) {
-  int rc = check_store(st, GLX_PTR_DEVICE);
+namespace {
+// Both entry points: host pointers are staged (ids in; sizes, offsets and values out), device pointers are used as given.
+int dist_sample_full_any(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit, int32_t* degrees_out,
+                         int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out, int64_t capacity, bool fill, int ptr_kind,
+                         void* stream) {
+  int rc = check_store(st, ptr_kind);
   if (rc != GLX_OK) return rc;
   GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
   GLX_REQUIRE(batch >= 0 && offsets_out != nullptr && (batch == 0 || (src && degrees_out)), "bad request");
+  GLX_REQUIRE(!fill || (capacity >= 0 && (capacity == 0 || (nbr_out && eid_out))), "bad response buffers");
   GlxDeviceGuard guard(st->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
-  if (st->world == 1 && st->shortcut) {
-    return glx_sample_full_sizes(st->graph, src, batch, max_limit, degrees_out, offsets_out, GLX_PTR_DEVICE, stream);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  const size_t nb = (size_t)batch;
+  GlxTemp stage;
+  const int64_t* d_src = src;
+  int32_t* d_deg = degrees_out;
+  int64_t* d_off = offsets_out;
+  int64_t* d_nbr = nbr_out;
+  int64_t* d_eid = eid_out;
+  if (ptr_kind == GLX_PTR_HOST) {
+    const size_t cap = fill ? (size_t)capacity : 0;
+    GLX_HIP(hipMalloc(&stage.p, (nb + (nb + 1) + 2 * cap + 2) * 8 + (nb + 2) * 4));
+    int64_t* b = stage.as<int64_t>();
+    if (nb) GLX_HIP(hipMemcpyAsync(b, src, nb * 8, hipMemcpyHostToDevice, s));
+    d_src = b;
+    d_off = b + nb;
+    d_nbr = d_off + nb + 1;
+    d_eid = d_nbr + cap;
+    d_deg = reinterpret_cast<int32_t*>(d_eid + cap);
   }
-  return dist_sample_full_device(st, src, batch, max_limit, degrees_out, offsets_out, nullptr, nullptr, 0, false, nullptr,
-                                 glx_stream(stream));
+  int64_t total = 0;
+  if (st->world == 1 && st->shortcut) {
+    rc = glx_sample_full_sizes(st->graph, d_src, batch, max_limit, d_deg, d_off, GLX_PTR_DEVICE, s);
+    if (rc != GLX_OK) return rc;
+    GLX_HIP(hipMemcpyAsync(&total, d_off + batch, 8, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+    if (fill) {
+      GLX_REQUIRE(total <= capacity, "the response holds %lld values, the buffers %lld", (long long)total, (long long)capacity);
+      rc = glx_sample_full(st->graph, d_src, batch, max_limit, d_off, d_nbr, d_eid, GLX_PTR_DEVICE, s);
+      if (rc != GLX_OK) return rc;
+    }
+  } else {
+    rc = dist_sample_full_device(st, d_src, batch, max_limit, d_deg, d_off, d_nbr, d_eid, capacity, fill, &total, s);
+    if (rc != GLX_OK) return rc;
+  }
+  if (ptr_kind == GLX_PTR_HOST) {
+    if (nb) GLX_HIP(hipMemcpyAsync(degrees_out, d_deg, nb * 4, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipMemcpyAsync(offsets_out, d_off, (nb + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (fill && total > 0) {
+      GLX_HIP(hipMemcpyAsync(nbr_out, d_nbr, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+      GLX_HIP(hipMemcpyAsync(eid_out, d_eid, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    }
+  }
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
+}
+}  // namespace
+
+extern "C" int glx_dist_sample_full_sizes(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
+                                          int32_t* degrees_out, int64_t* offsets_out, int ptr_kind, void* stream) {
+  return dist_sample_full_any(st, src, batch, max_limit, degrees_out, offsets_out, nullptr, nullptr, 0, false, ptr_kind, stream);
 }
 
 extern "C" int glx_dist_sample_full(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
                                     int32_t* degrees_out, int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out,
-                                    int64_t capacity, void* stream) {
-  int rc = check_store(st, GLX_PTR_DEVICE);
-  if (rc != GLX_OK) return rc;
-  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
-  GLX_REQUIRE(batch >= 0 && offsets_out != nullptr && (batch == 0 || (src && degrees_out)), "bad request");
-  GLX_REQUIRE(capacity >= 0 && (capacity == 0 || (nbr_out && eid_out)), "bad response buffers");
-  GlxDeviceGuard guard(st->device);
-  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
-  if (st->world == 1 && st->shortcut) {
-    rc = glx_sample_full_sizes(st->graph, src, batch, max_limit, degrees_out, offsets_out, GLX_PTR_DEVICE, stream);
-    if (rc != GLX_OK) return rc;
-    int64_t total = 0;
-    GLX_HIP(hipMemcpyAsync(&total, offsets_out + batch, 8, hipMemcpyDeviceToHost, glx_stream(stream)));
-    GLX_HIP(hipStreamSynchronize(glx_stream(stream)));
-    GLX_REQUIRE(total <= capacity, "the response holds %lld values, the buffers %lld", (long long)total, (long long)capacity);
-    return glx_sample_full(st->graph, src, batch, max_limit, offsets_out, nbr_out, eid_out, GLX_PTR_DEVICE, stream);
-  }
-  return dist_sample_full_device(st, src, batch, max_limit, degrees_out, offsets_out, nbr_out, eid_out, capacity, true,
-                                 nullptr, glx_stream(stream));
+                                    int64_t capacity, int ptr_kind, void* stream) {
+  return dist_sample_full_any(st, src, batch, max_limit, degrees_out, offsets_out, nbr_out, eid_out, capacity, true, ptr_kind,
+                              stream);
 }
 
 extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,

@@ -176,8 +176,8 @@ def lib():
         L.glx_dist_store_set_cache.argtypes = [vp, vp, i64, f32, ci, vp]
         L.glx_dist_store_set_graph_replica.argtypes = [vp, vp]
         L.glx_dist_build_graph_replica.argtypes = [vp, vp, i64, ci, vp, vp]
-        L.glx_dist_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, vp]
-        L.glx_dist_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]
+        L.glx_dist_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
+        L.glx_dist_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i64, ci, vp]
         L.glx_dist_last_sample_rows.argtypes = [vp, vp, vp, vp]
         L.glx_dist_hot_ids.argtypes = [vp, i64, vp, ctypes.POINTER(i64), vp]
         L.glx_dist_enable_in_degree.argtypes = [vp, vp, vp]
@@ -847,19 +847,23 @@ class DistStore:
 
     def sample_full(self, src, max_limit=0):
         """Collective FullSampler over the shards: -> (degrees[batch] int32, nbr[total], eid[total]) for this rank's
-        rows, as Graph.sample_full answers on one store.  torch CUDA ids."""
-        import torch
-        assert _is_torch(src) and src.is_cuda
+        rows, as Graph.sample_full answers on one store (numpy in -> numpy out, torch CUDA in -> torch CUDA out)."""
         batch = int(src.shape[0])
-        deg = torch.empty(batch, dtype=torch.int32, device=src.device)
-        off = torch.empty(batch + 1, dtype=torch.int64, device=src.device)
-        stream = _stream(PTR_DEVICE, self.comm.device)
-        _check(lib().glx_dist_sample_full_sizes(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0], stream))
-        total = int(off[-1].item())
-        nbr = torch.empty(total, dtype=torch.int64, device=src.device)
-        eid = torch.empty(total, dtype=torch.int64, device=src.device)
-        _check(lib().glx_dist_sample_full(self._h, _ptr(src)[0], batch, max_limit, _ptr(deg)[0], _ptr(off)[0],
-                                          _ptr(nbr)[0] if total else None, _ptr(eid)[0] if total else None, total, stream))
+        if _is_torch(src):
+            import torch
+            mk = lambda n, dt: torch.empty(n, dtype=dt, device=src.device)  # noqa: E731
+            deg, off, i64t = mk(batch, torch.int32), mk(batch + 1, torch.int64), torch.int64
+        else:
+            mk = lambda n, dt: np.empty(n, dt)  # noqa: E731
+            deg, off, i64t = mk(batch, np.int32), mk(batch + 1, np.int64), np.int64
+        ps, kind = _ptr(src) if batch else (None, PTR_DEVICE if _is_torch(src) else PTR_HOST)
+        stream = _stream(kind, self.comm.device)
+        _check(lib().glx_dist_sample_full_sizes(self._h, ps, batch, max_limit, _ptr(deg)[0] if batch else None, _ptr(off)[0],
+                                                kind, stream))
+        total = int(off[-1])
+        nbr, eid = mk(total, i64t), mk(total, i64t)
+        _check(lib().glx_dist_sample_full(self._h, ps, batch, max_limit, _ptr(deg)[0] if batch else None, _ptr(off)[0],
+                                          _ptr(nbr)[0] if total else None, _ptr(eid)[0] if total else None, total, kind, stream))
         return deg, nbr, eid
 
     def last_sample_rows(self):

@@ -181,7 +181,31 @@ int AggregatorIdOf(const std::string& name) {
   return -1;
 }
 
+// FullSampler's sparse response across shards (full_sampler.cc:28-97 behind DistributeRunner): sizes, then values.
+Status RunFullSampling(Env* env, const SamplingRequest* req, SamplingResponse* res) {
+  if (req->HasFilter()) return error::Unimplemented("FullSampler with a filter is not served across shards");
+  const int32_t batch_size = req->BatchSize();
+  const int32_t max_limit = req->NeighborCount();
+  glx_dist_store* st = nullptr;
+  Status s = env->EdgeStore(req->Type(), &st);
+  if (!s.ok()) return s;
+  std::vector<int32_t> degrees((size_t)batch_size, 0);
+  std::vector<int64_t> offsets((size_t)batch_size + 1, 0);
+  int rc = glx_dist_sample_full_sizes(st, req->GetSrcIds(), batch_size, max_limit, degrees.data(), offsets.data(),
+                                      GLX_PTR_HOST, nullptr);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  res->SetShape(batch_size, max_limit, degrees);
+  res->InitNeighborIds();
+  res->InitEdgeIds();
+  res->ResizeDense();  // sizes both tensors to the sum of the counts
+  // collective even when this server's rows are all empty: its peers may have values to fetch from it
+  rc = glx_dist_sample_full(st, req->GetSrcIds(), batch_size, max_limit, degrees.data(), offsets.data(),
+                            res->GetNeighborIds(), res->GetEdgeIds(), offsets[(size_t)batch_size], GLX_PTR_HOST, nullptr);
+  return error::FromGlx(rc);
+}
+
 Status RunSampling(Env* env, const SamplingRequest* req, SamplingResponse* res) {
+  if (req->Strategy() == "FullSampler") return RunFullSampling(env, req, res);
   const int sampler = SamplerIdOf(req->Strategy());
   if (sampler < 0) {
     return error::Unimplemented("'" + req->Strategy() + "' is not served across shards (dense neighbour samplers are)");

@@ -450,6 +450,51 @@ TEST(PartitionStitchTest, AServerWithoutEdgesOfATypeStillServes) {
     if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
     EXPECT_TRUE(ok[r]);
   }
+  // FullSampler's sparse response through the runner: row sizes and values equal the single store's
+  SamplingRequest freq("e", "FullSampler", 3);
+  freq.Set(ids.data(), (int32_t)ids.size());
+  SamplingResponse fwant;
+  OpFactory::GetInstance()->Set(&whole);
+  EXPECT_TRUE(OpFactory::GetInstance()->Create("FullSampler")->Process(&freq, &fwant).ok());
+  auto full_server = [&](int r) {
+    glx_comm* comm = nullptr;
+    if (glx_comm_init_local(77101, 0, r, 2, &comm) != GLX_OK) {
+      ok[r] = false;
+      why[r] = glx_last_error();
+      return;
+    }
+    {
+      Env env(comm, &shard[r]);
+      std::unique_ptr<OpRunner> runner = GetOpRunner(&env, OpFactory::GetInstance()->Create("FullSampler"));
+      SamplingRequest req("e", "FullSampler", 3);
+      req.Set(ids.data(), (int32_t)ids.size());
+      SamplingResponse res;
+      Status s = runner->Run(&req, &res);
+      if (!s.ok()) {
+        ok[r] = false;
+        why[r] = "FullSampler: " + s.ToString();
+      } else if (res.GetShape().size != fwant.GetShape().size || res.GetShape().segments != fwant.GetShape().segments) {
+        ok[r] = false;
+        why[r] = "FullSampler: shape mismatch";
+      } else {
+        for (size_t i = 0; i < res.GetShape().size; ++i) {
+          if (res.GetNeighborIds()[i] != fwant.GetNeighborIds()[i]) {
+            ok[r] = false;
+            why[r] = "FullSampler: neighbour mismatch";
+            break;
+          }
+        }
+      }
+    }
+    glx_comm_destroy(comm);
+  };
+  std::thread f0(full_server, 0), f1(full_server, 1);
+  f0.join();
+  f1.join();
+  for (int r = 0; r < 2; ++r) {
+    if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
+    EXPECT_TRUE(ok[r]);
+  }
 }
 
 int main() { return RunAllTests(); }

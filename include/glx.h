@@ -515,13 +515,13 @@ GLX_API int glx_dist_sample(glx_dist_store* st, int sampler, const int64_t* src,
  * sampling_request.cc:198-224, stitched row by row as SamplingResponse::Stitch does for the sparse case): request rows
  * to their owners, the owners' row sizes back -> degrees_out[batch], offsets_out[batch + 1] (last entry = the total);
  * glx_dist_sample_full additionally brings the values back, row i at offsets_out[i] of nbr_out / eid_out, which hold
- * `capacity` entries (InvalidArgument when the response is larger: ask _sizes first).  Device pointers; both return
- * when their outputs are valid. */
+ * `capacity` entries (InvalidArgument when the response is larger: ask _sizes first).  Host or device pointers; both
+ * return when their outputs are valid. */
 GLX_API int glx_dist_sample_full_sizes(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
-                                       int32_t* degrees_out, int64_t* offsets_out, void* stream);
+                                       int32_t* degrees_out, int64_t* offsets_out, int ptr_kind, void* stream);
 GLX_API int glx_dist_sample_full(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
                                  int32_t* degrees_out, int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out,
-                                 int64_t capacity, void* stream);
+                                 int64_t capacity, int ptr_kind, void* stream);
 /* Collective.  DistributeRunner<AggregatingRequest, AggregatingResponse>::Run with
  * glx_aggregate's arguments; segment_ids == NULL means num_segments equal segments of
  * num_ids / num_segments consecutive ids (a dense sampler response). */

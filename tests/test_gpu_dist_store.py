@@ -708,4 +708,8 @@ def test_dist_full_sampler_equals_unpartitioned(world, P):
             want = whole.sample_full(src, limit)
             for a, b in zip(got, want):
                 assert torch.equal(a, b), (limit, r)
+            if limit == 3:  # host pointers (the C++ runner's boundary)
+                hg = st.sample_full(src.cpu().numpy(), limit)
+                for a, b in zip(hg, want):
+                    assert np.array_equal(a, b.cpu().numpy()), (limit, r, "host")
     _run_ranks(P, body)
