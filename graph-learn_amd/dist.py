@@ -243,6 +243,12 @@ class ShardedStore:
         eid = _a2a(eid, recv, send, self.group, most)
         return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
 
+    def sample_full(self, src, max_limit=0):
+        """FullSampler over the shards (sparse response): -> (degrees, nbr, eid) of this rank's rows."""
+        if self.native is None:
+            raise NotImplementedError("the partitioned FullSampler runs in the C distributed store (device ops)")
+        return self.native.sample_full(src, max_limit)
+
     def sample_filtered(self, sampler, src, k, filter_type, filter_field, values, seed=0, call_counter=0,
                         padding_mode=1, default_neighbor_id=0, retry_times=5, default_timestamp=-1):
         """sample() for a request with an op::Filter: every row's filter value travels with its id (as
