@@ -68,6 +68,8 @@ def run(P, max_message_bytes):
                         e, c = st.aggregate(op, ids, None, src.shape[0], default_attr=0.5)
                         re_, rc_ = feats.aggregate(op, ids, None, src.shape[0], default_attr=0.5)
                         assert torch.equal(c, rc_) and torch.equal(e.view(torch.int32), re_.view(torch.int32)), (op, r)
+                    for a, b in zip(st.sample_full(src, 4), whole.sample_full(src, 4)):  # ragged values back
+                        assert torch.equal(a, b), ("full", r)
                     rows = st.lookup(src, default_attr=-1.0)
                     assert torch.equal(rows.view(torch.int32), feats.lookup(src, -1.0).view(torch.int32)), r
                     # a request only SOME ranks have rows for: the others take part with nothing to send
