@@ -543,6 +543,12 @@ __global__ void glx_dist_stitch_deg_kernel(const int64_t* __restrict__ deg_b, co
   deg64_out[order[i]] = deg_b[i];
 }
 
+__global__ void glx_dist_walk_column_kernel(const int64_t* __restrict__ step, int64_t n, int32_t walk_len, int32_t t,
+                                            int64_t* __restrict__ walks) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) walks[i * walk_len + t] = step[i];
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 4096) {
   int64_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -1374,6 +1380,55 @@ extern "C" int glx_dist_sample_full(glx_dist_store* st, const int64_t* src, int3
                                     int64_t capacity, int ptr_kind, void* stream) {
   return dist_sample_full_any(st, src, batch, max_limit, degrees_out, offsets_out, nbr_out, eid_out, capacity, true, ptr_kind,
                               stream);
+}
+
+extern "C" int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
+                                    float q, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                                    int64_t* walks_out, int ptr_kind, void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(batch >= 0 && walk_len >= 0, "negative batch / walk_len");
+  GLX_REQUIRE((int64_t)batch * walk_len <= INT32_MAX, "batch * walk_len exceeds int32 (tensor.h:47)");
+  GLX_REQUIRE(batch == 0 || walk_len == 0 || (seeds && walks_out), "NULL data pointer");
+  const bool deep = fabsf(p - 1.0f) < 32 * 1.1920929e-07f && fabsf(q - 1.0f) < 32 * 1.1920929e-07f;
+  if (!deep) {
+    glx_set_error("node2vec walks (p, q != 1) are not served across shards: a step needs the previous vertex's neighbours");
+    return GLX_UNIMPLEMENTED;
+  }
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  const size_t nb = (size_t)(batch > 0 ? batch : 1), total = (size_t)batch * (size_t)walk_len;
+  GlxTemp buf;
+  GLX_HIP(hipMalloc(&buf.p, (nb * 3 + (ptr_kind == GLX_PTR_HOST ? total : 0) + 2) * 8));
+  int64_t* cur = buf.as<int64_t>();
+  int64_t* nxt = cur + nb;
+  int64_t* eid = nxt + nb;
+  int64_t* d_walks = ptr_kind == GLX_PTR_HOST ? eid + nb : walks_out;
+  if (batch > 0) {
+    GLX_HIP(hipMemcpyAsync(cur, seeds, (size_t)batch * 8, ptr_kind == GLX_PTR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+  }
+  // DeepWalk (random_walk.cc:168-190): step t of walker i = RandomSampler's draw 0 of the stream (seed, call_counter + t,
+  // i) on the vertex it stands on -- one partitioned request with neighbor_count 1 per step, every walker a row; a
+  // walker on a vertex without out-edges continues from the default id, like the single-store walk
+  for (int32_t t = 0; t < walk_len; ++t) {
+    rc = dist_sample_device(st, GLX_SAMPLER_RANDOM, cur, batch, 1, GLX_PAD_CIRCULAR, default_neighbor_id, seed,
+                            call_counter + (uint64_t)t, nullptr, nxt, eid, s);
+    if (rc != GLX_OK) return rc;
+    if (batch > 0) {
+      glx_dist_walk_column_kernel<<<(unsigned)((batch + 255) / 256), 256, 0, s>>>(nxt, batch, walk_len, t, d_walks);
+    }
+    int64_t* tmp = cur;
+    cur = nxt;
+    nxt = tmp;
+  }
+  GLX_HIP(hipGetLastError());
+  if (ptr_kind == GLX_PTR_HOST && total > 0) {
+    GLX_HIP(hipMemcpyAsync(walks_out, d_walks, total * 8, hipMemcpyDeviceToHost, s));
+  }
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
 }
 
 extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,

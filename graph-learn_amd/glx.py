@@ -51,7 +51,7 @@ EXPORTS = [
     "glx_comm_unique_id", "glx_comm_init_rccl", "glx_comm_init_local", "glx_comm_init_callbacks", "glx_comm_destroy",
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_store_set_graph_replica",
-    "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full",
+    "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full", "glx_dist_random_walk",
     "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
@@ -176,6 +176,7 @@ def lib():
         L.glx_dist_store_set_cache.argtypes = [vp, vp, i64, f32, ci, vp]
         L.glx_dist_store_set_graph_replica.argtypes = [vp, vp]
         L.glx_dist_build_graph_replica.argtypes = [vp, vp, i64, ci, vp, vp]
+        L.glx_dist_random_walk.argtypes = [vp, vp, i32, i32, f32, f32, i64, u64, u64, vp, ci, vp]
         L.glx_dist_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
         L.glx_dist_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i64, ci, vp]
         L.glx_dist_last_sample_rows.argtypes = [vp, vp, vp, vp]
@@ -865,6 +866,22 @@ class DistStore:
         _check(lib().glx_dist_sample_full(self._h, ps, batch, max_limit, _ptr(deg)[0] if batch else None, _ptr(off)[0],
                                           _ptr(nbr)[0] if total else None, _ptr(eid)[0] if total else None, total, kind, stream))
         return deg, nbr, eid
+
+    def random_walk(self, seeds, walk_len, p=1.0, q=1.0, default_neighbor_id=0, seed=0, call_counter=0):
+        """Collective DeepWalk over the shards: -> walks[batch, walk_len], Graph.random_walk's draws (p = q = 1 only)."""
+        batch = int(seeds.shape[0])
+        if _is_torch(seeds):
+            import torch
+            walks = torch.empty((batch, walk_len), dtype=torch.int64, device=seeds.device)
+            kind = PTR_DEVICE
+        else:
+            walks = np.empty((batch, walk_len), np.int64)
+            kind = PTR_HOST
+        _check(lib().glx_dist_random_walk(self._h, _ptr(seeds)[0] if batch else None, batch, walk_len, p, q,
+                                          default_neighbor_id, seed, call_counter,
+                                          _ptr(walks)[0] if batch * walk_len else None, kind,
+                                          _stream(kind, self.comm.device)))
+        return walks
 
     def last_sample_rows(self):
         """{'rows', 'from_graph_replica', 'remote'} of the last sample() on this rank."""

@@ -522,6 +522,13 @@ GLX_API int glx_dist_sample_full_sizes(glx_dist_store* st, const int64_t* src, i
 GLX_API int glx_dist_sample_full(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
                                  int32_t* degrees_out, int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out,
                                  int64_t capacity, int ptr_kind, void* stream);
+/* Collective.  DeepWalk (random_walk.cc:168-190; p = q = 1 as RandomWalkRequest::IsDeepWalk decides) across the shards,
+ * glx_random_walk's layout and draws: step t is one partitioned RandomSampler request with neighbor_count 1 and call
+ * counter call_counter + t, walker i drawing from stream i.  node2vec (p, q != 1) needs the previous vertex's
+ * neighbour list at every step and returns GLX_UNIMPLEMENTED here. */
+GLX_API int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p, float q,
+                                 int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter, int64_t* walks_out,
+                                 int ptr_kind, void* stream);
 /* Collective.  DistributeRunner<AggregatingRequest, AggregatingResponse>::Run with
  * glx_aggregate's arguments; segment_ids == NULL means num_segments equal segments of
  * num_ids / num_segments consecutive ids (a dense sampler response). */

@@ -713,3 +713,24 @@ def test_dist_full_sampler_equals_unpartitioned(world, P):
                 for a, b in zip(hg, want):
                     assert np.array_equal(a, b.cpu().numpy()), (limit, r, "host")
     _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_dist_deepwalk_equals_unpartitioned(world, P):
+    """DeepWalk across the shards = one partitioned RandomSampler request per step: the single store's walks, vertex
+    for vertex (dead ends continue from the default id, as there); node2vec is refused, on every rank alike."""
+    whole, dev = world["whole"], world["dev"]
+    gs, _ = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        seeds = _requests(r, dev, n=800)
+        for walk_len, dflt in ((1, 0), (6, 0), (5, -1)):
+            got = st.random_walk(seeds, walk_len, default_neighbor_id=dflt, seed=11, call_counter=20)
+            want = whole.random_walk(seeds, walk_len, default_neighbor_id=dflt, seed=11, call_counter=20)
+            assert torch.equal(got, want), (walk_len, dflt, r)
+        host = st.random_walk(seeds.cpu().numpy(), 4, seed=11, call_counter=7)
+        assert np.array_equal(host, whole.random_walk(seeds, 4, seed=11, call_counter=7).cpu().numpy())
+        with pytest.raises(glx.GlxError, match="node2vec"):
+            st.random_walk(seeds, 3, p=0.5, q=2.0)
+    _run_ranks(P, body)
