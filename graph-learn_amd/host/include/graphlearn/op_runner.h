@@ -84,6 +84,8 @@ public:
   Status EdgeStore(const std::string& edge_type, glx_dist_store** out);
   Status NodeStore(const std::string& node_type, glx_dist_store** out);
   uint64_t NextCallCounter() { return call_counter_.fetch_add(1, std::memory_order_relaxed); }
+  // `count` consecutive values at once (a walk consumes one per step); returns the first
+  uint64_t NextCallCounters(uint64_t count) { return call_counter_.fetch_add(count ? count : 1, std::memory_order_relaxed); }
 
 private:
   glx_comm* comm_;

@@ -15,6 +15,7 @@
 
 #include "glx.h"
 #include "graphlearn/aggregating_request.h"
+#include "graphlearn/graph_request.h"
 #include "graphlearn/config.h"
 #include "graphlearn/sampling_request.h"
 
@@ -270,6 +271,22 @@ Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpRespon
     auto* ares = dynamic_cast<AggregatingResponse*>(res);
     if (!ares) return error::InvalidArgument("an AggregatingRequest needs an AggregatingResponse");
     return RunAggregating(env, areq, ares);
+  }
+  if (auto* wreq = dynamic_cast<const RandomWalkRequest*>(req)) {
+    auto* wres = dynamic_cast<RandomWalkResponse*>(res);
+    if (!wres) return error::InvalidArgument("a RandomWalkRequest needs a RandomWalkResponse");
+    // DeepWalk across the shards: one partitioned RandomSampler request per step (glx_dist_random_walk); every step
+    // consumes one call counter value
+    const int32_t n = wreq->BatchSize(), len = wreq->WalkLen();
+    wres->InitWalks(n, len);
+    glx_dist_store* st = nullptr;
+    Status s = env->EdgeStore(wreq->Type(), &st);
+    if (!s.ok()) return s;
+    const uint64_t cc = wreq->HasCallCounter() ? (uint64_t)wreq->CallCounter()
+                                               : env->NextCallCounters((uint64_t)(len > 0 ? len : 1));
+    int rc = glx_dist_random_walk(st, wreq->GetSrcIds(), n, len, wreq->P(), wreq->Q(), GLOBAL_FLAG(DefaultNeighborId),
+                                  (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, wres->MutableWalks(), GLX_PTR_HOST, nullptr);
+    return error::FromGlx(rc);
   }
   return error::Unimplemented("request '" + req->Name() + "' is shardable but not served across shards");
 }

@@ -450,6 +450,52 @@ TEST(PartitionStitchTest, AServerWithoutEdgesOfATypeStillServes) {
     if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
     EXPECT_TRUE(ok[r]);
   }
+  // DeepWalk through the runner: the single store's walks
+  {
+    RandomWalkRequest wq("e", 1.0f, 1.0f, 5);
+    wq.Set(ids.data(), (int32_t)ids.size());
+    wq.SetCallCounter(900);
+    RandomWalkResponse wwant;
+    OpFactory::GetInstance()->Set(&whole);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("RandomWalk")->Process(&wq, &wwant).ok());
+    auto walk_server = [&](int r) {
+      glx_comm* comm = nullptr;
+      if (glx_comm_init_local(77102, 0, r, 2, &comm) != GLX_OK) {
+        ok[r] = false;
+        why[r] = glx_last_error();
+        return;
+      }
+      {
+        Env env(comm, &shard[r]);
+        std::unique_ptr<OpRunner> runner = GetOpRunner(&env, OpFactory::GetInstance()->Create("RandomWalk"));
+        RandomWalkRequest req("e", 1.0f, 1.0f, 5);
+        req.Set(ids.data(), (int32_t)ids.size());
+        req.SetCallCounter(900);
+        RandomWalkResponse res;
+        Status s = runner->Run(&req, &res);
+        if (!s.ok()) {
+          ok[r] = false;
+          why[r] = "RandomWalk: " + s.ToString();
+        } else {
+          for (size_t i = 0; i < ids.size() * 5; ++i) {
+            if (res.GetWalks()[i] != wwant.GetWalks()[i]) {
+              ok[r] = false;
+              why[r] = "RandomWalk: walk mismatch";
+              break;
+            }
+          }
+        }
+      }
+      glx_comm_destroy(comm);
+    };
+    std::thread w0(walk_server, 0), w1(walk_server, 1);
+    w0.join();
+    w1.join();
+    for (int r = 0; r < 2; ++r) {
+      if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
+      EXPECT_TRUE(ok[r]);
+    }
+  }
   // FullSampler's sparse response through the runner: row sizes and values equal the single store's
   SamplingRequest freq("e", "FullSampler", 3);
   freq.Set(ids.data(), (int32_t)ids.size());
