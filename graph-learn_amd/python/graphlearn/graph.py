@@ -338,6 +338,12 @@ class Graph(object):
     CUDA walks straight from the device graph (call_counter defaults to 0 there)."""
     import torch
     from graphlearn import settings
+    if isinstance(ids, torch.Tensor) and getattr(self, "_shard", (0, 1))[1] > 1:
+      # SPMD mode: a collective walk over the shards (DeepWalk; glx_dist_random_walk), the single store's draws
+      flags = settings._MIRROR  # pylint: disable=protected-access
+      return self.sharded_store_cached(edge_type).native.random_walk(
+          ids, int(walk_len), p=float(p), q=float(q), default_neighbor_id=flags["default_neighbor_id"],
+          seed=flags["sampling_seed"], call_counter=call_counter or 0)
     if isinstance(ids, torch.Tensor):
       flags = settings._MIRROR  # pylint: disable=protected-access
       return self.device_graph(edge_type).random_walk(

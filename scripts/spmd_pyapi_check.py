@@ -84,6 +84,10 @@ for strategy in ("edge_weight", "topk", "random_without_replacement"):
     for (gn, _), (wn, _) in zip(got, want):  # edge ids are per-shard insertion indices, as on the reference's servers
         assert torch.equal(gn.reshape(-1), wn.reshape(-1)), (rank, strategy)
 
+# walks: collective DeepWalk over the shards
+ids = torch.from_numpy(gen.integers(0, 400, 150) * 3 - 200).to(dev)
+assert torch.equal(shard.random_walk("e", ids, 5, call_counter=80), whole.random_walk("e", ids, 5, call_counter=80)), rank
+
 # a replica of the hottest rows on every GPU changes where rows come from, never the answer
 hot_store = shard.sharded_store("e", "n", hot_nodes=50)
 emb, cnt = hot_store.aggregate("MeanAggregator", nbr.reshape(-1), seg, ids.shape[0])
