@@ -117,8 +117,10 @@ class Graph(object):
     task_count > 1 is the SPMD mode of this engine: one process per GPU (torchrun), every process
     reads the same sources and keeps shard `task_index` -- the edges whose source id, and the nodes
     whose id, satisfy llabs(id) % task_count == task_index, the rule the reference routes requests by
-    (hash_partitioner.h:88-90).  Samplers of this object then see the shard only; `sharded_store()`
-    gives the view over ALL shards (requests exchanged between the GPUs over RCCL)."""
+    (hash_partitioner.h:88-90).  The numpy request path of this object (sampler.get(), lookups) then sees the
+    shard only; the view over ALL shards -- requests exchanged between the GPUs over RCCL, every rank calling at
+    the same time with its own batch -- is `sharded_store()`, and on CUDA tensors `neighbor_sampler(...).get_device()`
+    and `random_walk()` go through it by themselves."""
     if cluster or kwargs.get("hosts") is not None:
       raise NotImplementedError(
           "the reference's client/server RPC deploy mode is not served by this engine; multi-GPU execution is one "
