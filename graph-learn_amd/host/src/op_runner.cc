@@ -288,6 +288,22 @@ Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpRespon
                                   (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, wres->MutableWalks(), GLX_PTR_HOST, nullptr);
     return error::FromGlx(rc);
   }
+  if (auto* dreq = dynamic_cast<const GetDegreeRequest*>(req)) {
+    auto* dres = dynamic_cast<GetDegreeResponse*>(res);
+    if (!dres) return error::InvalidArgument("a GetDegreeRequest needs a GetDegreeResponse");
+    if (dreq->GetNodeFrom() != kEdgeSrc) {
+      return error::Unimplemented("in-degrees of destination ids are not served across shards (out-degrees are)");
+    }
+    // out-degrees live with the rows: the sizes half of the partitioned FullSampler, without a limit
+    const int32_t n = dreq->Size();
+    dres->InitDegrees(n);
+    glx_dist_store* st = nullptr;
+    Status s = env->EdgeStore(dreq->EdgeType(), &st);
+    if (!s.ok()) return s;
+    std::vector<int64_t> offsets((size_t)n + 1, 0);
+    int rc = glx_dist_sample_full_sizes(st, dreq->NodeIds(), n, 0, dres->MutableDegrees(), offsets.data(), GLX_PTR_HOST, nullptr);
+    return error::FromGlx(rc);
+  }
   return error::Unimplemented("request '" + req->Name() + "' is shardable but not served across shards");
 }
 

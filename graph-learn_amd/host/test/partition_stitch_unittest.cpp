@@ -473,6 +473,24 @@ TEST(PartitionStitchTest, AServerWithoutEdgesOfATypeStillServes) {
         req.SetCallCounter(900);
         RandomWalkResponse res;
         Status s = runner->Run(&req, &res);
+        // out-degrees of the same ids through the runner
+        GetDegreeRequest dq("e", kEdgeSrc);
+        dq.Set(ids.data(), (int32_t)ids.size());
+        GetDegreeResponse dr, dw;
+        Status ds = GetOpRunner(&env, OpFactory::GetInstance()->Create("GetDegree"))->Run(&dq, &dr);
+        OpFactory::GetInstance()->Set(&whole);
+        if (ds.ok()) ds = OpFactory::GetInstance()->Create("GetDegree")->Process(&dq, &dw);
+        if (!ds.ok()) {
+          ok[r] = false;
+          why[r] = "GetDegree: " + ds.ToString();
+        } else {
+          for (size_t i = 0; i < ids.size(); ++i) {
+            if (dr.GetDegrees()[i] != dw.GetDegrees()[i]) {
+              ok[r] = false;
+              why[r] = "GetDegree: mismatch";
+            }
+          }
+        }
         if (!s.ok()) {
           ok[r] = false;
           why[r] = "RandomWalk: " + s.ToString();
