@@ -449,7 +449,8 @@ GLX_API int glx_comm_allgather_i64(glx_comm* c, const int64_t* vals, int32_t nva
 GLX_API int glx_comm_barrier(glx_comm* c, void* stream);
 
 /* ---- distributed store: replaces DistributeRunner<Req, Res>::Run (op_runner.h:60-84) for
- * the sampling and aggregating requests: Partition (hash_partitioner.h:33-92) -> ship the
+ * the sampling (dense samplers, FullSampler, DeepWalk), aggregating and node-lookup requests:
+ * Partition (hash_partitioner.h:33-92) -> ship the
  * parts -> Process on the owning shard -> ship the results back -> Stitch
  * (stitcher.h:67-107; aggregating_request.cc:117-213) -- all on the device, between the
  * caller's request and response buffers.  SPMD: every rank calls the same entry point at the
