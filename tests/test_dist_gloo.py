@@ -236,3 +236,21 @@ def test_shard_graph_partitions_every_row_once():
             assert np.array_equal(seid[a:b].numpy(), eid[rp[v]:rp[v + 1]])
             seen[rp[v]:rp[v + 1]] += 1
     assert (seen == 1).all()
+
+
+def test_shard_and_row_helpers_on_edge_shapes():
+    """More shards than vertices leave empty shards; rows_of_graph cuts any id subset (the shape of a graph replica)."""
+    sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd"))
+    import dist as gdist
+    rp, col, eid, w, _ = _world_graph()
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    V = rp.shape[0] - 1
+    srp, scol, seid, sw, sids = gdist.shard_graph(t(rp), t(col), t(eid), t(w), V + 2, V + 5)  # owns nothing
+    assert sids.shape[0] == 0 and srp.tolist() == [0] and scol.shape[0] == 0 and sw.shape[0] == 0
+    pick = torch.tensor([V - 1, 0, 3], dtype=torch.int64)
+    qrp, qcol, qeid, qw, qids = gdist.rows_of_graph(t(rp), t(col), t(eid), t(w), pick)
+    assert torch.equal(qids, pick)
+    for i, v in enumerate(pick.tolist()):
+        a, b = qrp[i].item(), qrp[i + 1].item()
+        assert np.array_equal(qcol[a:b].numpy(), col[rp[v]:rp[v + 1]]) and np.array_equal(qeid[a:b].numpy(), eid[rp[v]:rp[v + 1]])
+        assert np.array_equal(qw[a:b].numpy(), w[rp[v]:rp[v + 1]])
