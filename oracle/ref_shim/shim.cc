@@ -263,6 +263,9 @@ Status Client::Sampling(const SamplingRequest*, SamplingResponse*) {
 Status Client::Aggregating(const AggregatingRequest*, AggregatingResponse*) {
   return error::Unimplemented("oracle shim: no RPC");
 }
+Status Client::RandomWalk(const RandomWalkRequest*, RandomWalkResponse*) {
+  return error::Unimplemented("oracle shim: no RPC");
+}
 void Log(const char*) {}
 void Log(const std::string&) {}
 

@@ -17,6 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle_bindings import RefLib, VP, SAMPLERS, AGGREGATORS  # noqa: E402
 
+OUT_DIR = HERE  # --check regenerates into a scratch directory instead
+
 
 def ref_alias(ref, w):
     ref.L.glref_alias_build.argtypes = [VP, ctypes.c_int32, VP, VP]
@@ -50,7 +52,7 @@ def gen_kat(ref):
                 n, e = ref.sample("kat", "TopkSampler", q, k)
                 out["topk_p%d_d%d_k%d_nbr" % (pad, dflt + 1, k)] = n
                 out["topk_p%d_d%d_k%d_eid" % (pad, dflt + 1, k)] = e
-    np.savez_compressed(os.path.join(HERE, "kat_sampler.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "kat_sampler.npz"), **out)
 
 
 def gen_pyfixture(ref):
@@ -83,7 +85,7 @@ def gen_pyfixture(ref):
             n, e = ref.sample("edge2", "RandomWithoutReplacementSampler", q, 6)
             out["rwor_p0_nbr"] = n
             out["rwor_p0_eid"] = e
-    np.savez_compressed(os.path.join(HERE, "pyfixture_topk.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "pyfixture_topk.npz"), **out)
 
 
 def gen_rand_graph(ref):
@@ -137,7 +139,7 @@ def gen_rand_graph(ref):
     out["indeg_w"] = indeg
     out["indeg_alias_prob"] = ip
     out["indeg_alias_idx"] = ia
-    np.savez_compressed(os.path.join(HERE, "rand_graph.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "rand_graph.npz"), **out)
 
 
 def gen_dist(ref):
@@ -179,7 +181,7 @@ def gen_dist(ref):
             out["%s_k%d_hist" % (name, k)] = hist
             out["%s_k%d_pair" % (name, k)] = pair
     out["T"] = np.array(T)
-    np.savez_compressed(os.path.join(HERE, "dist.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "dist.npz"), **out)
 
 
 def gen_dist_indegree(ref):
@@ -217,7 +219,7 @@ def gen_dist_indegree(ref):
             hist[r, j, :d] = np.bincount(pos[:, j], minlength=d)
     out["hist"] = hist
     out["T"] = np.array(T)
-    np.savez_compressed(os.path.join(HERE, "dist_indegree.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "dist_indegree.npz"), **out)
 
 
 def gen_agg(ref):
@@ -269,7 +271,7 @@ def gen_agg(ref):
                 out["c%d_%s_cnt" % (case, name)] = cnt
             case += 1
     out["num_cases"] = np.array(case)
-    np.savez_compressed(os.path.join(HERE, "agg.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "agg.npz"), **out)
 
 
 def gen_agg_stitch(ref):
@@ -318,7 +320,7 @@ def gen_agg_stitch(ref):
                 out["c%d_%s_cnt" % (case, name)] = cnt
             case += 1
     out["num_cases"] = np.array(case)
-    np.savez_compressed(os.path.join(HERE, "agg_stitch.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "agg_stitch.npz"), **out)
 
 
 def gen_loader(ref):
@@ -357,7 +359,7 @@ def gen_loader(ref):
         cases.append(dict(data=data.hex(), delimiter=delim, types=types, hash_buckets=buckets, code=int(rc),
                           ints=[int(x) for x in ints], floats_bits=[int(x) for x in floats.view(np.uint32)],
                           strings=[x.hex() for x in strings]))
-    with open(os.path.join(HERE, "loader.json"), "w") as f:
+    with open(os.path.join(OUT_DIR, "loader.json"), "w") as f:
         json.dump(dict(hash64=hashes, parse_attribute=cases), f, indent=1)
 
 
@@ -383,7 +385,7 @@ def gen_negative(ref):
     nw = (rng.random(400) + 0.02).astype(np.float32)
     np_, na = ref.alias_build(nw)
     out.update(node_ids=nid, node_weights=nw, node_prob=np_, node_alias=na)
-    np.savez_compressed(os.path.join(HERE, "negative.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "negative.npz"), **out)
 
 
 def gen_timestamped(ref):
@@ -401,7 +403,7 @@ def gen_timestamped(ref):
     rp, col, eid, ws = ref.export_csr("ts", rows, 4000)
     tk, te = ref.sample("ts", "TopkSampler", rows, 4)
     out.update(src=src, dst=dst, ts=ts, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws, topk_nbr=tk, topk_eid=te)
-    np.savez_compressed(os.path.join(HERE, "timestamped.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "timestamped.npz"), **out)
 
 
 def gen_filtered(ref):
@@ -526,7 +528,7 @@ def gen_filtered(ref):
                 hist[r, j, :d] = np.bincount(p[:, j], minlength=d)
         out["d_%s_hist" % name] = hist
     out["d_T"] = np.array(T)
-    np.savez_compressed(os.path.join(HERE, "filtered.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "filtered.npz"), **out)
 
 
 def gen_walk(ref):
@@ -562,10 +564,10 @@ def gen_walk(ref):
         cases.append(name)
     out["cases"] = np.array(cases)
     out["T"] = np.array(T)
-    np.savez_compressed(os.path.join(HERE, "walk.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "walk.npz"), **out)
 
 
-def main():
+def generate():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
     gen_pyfixture(ref)
@@ -579,8 +581,54 @@ def main():
     gen_timestamped(ref)
     gen_filtered(ref)
     gen_walk(ref)
-    # The CSR ("compressed") storage mode must expose the same adjacency.
     ref.close()
+
+
+def check():
+    """Regenerate every fixture from the reference library as built NOW and compare
+    with the committed files: same keys, dtypes, shapes and bytes for each .npz
+    (array contents, not the zip container), same text for loader.json.  Returns the
+    list of differences (empty = the committed goldens are what the recipe makes)."""
+    import tempfile
+    global OUT_DIR
+    diffs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT_DIR = tmp
+        try:
+            generate()
+        finally:
+            OUT_DIR = HERE
+        made = sorted(f for f in os.listdir(tmp))
+        have = sorted(f for f in os.listdir(HERE) if f.endswith(".npz") or f.endswith(".json"))
+        if made != have:
+            diffs.append("file sets differ: made %s, committed %s" % (made, have))
+        for f in made:
+            a, b = os.path.join(tmp, f), os.path.join(HERE, f)
+            if not os.path.exists(b):
+                continue
+            if f.endswith(".json"):
+                if open(a).read() != open(b).read():
+                    diffs.append(f + ": text differs")
+                continue
+            za, zb = np.load(a), np.load(b)
+            if sorted(za.files) != sorted(zb.files):
+                diffs.append("%s: keys differ (%s)" % (f, sorted(set(za.files) ^ set(zb.files))))
+                continue
+            for k in za.files:
+                x, y = za[k], zb[k]
+                if x.dtype != y.dtype or x.shape != y.shape or x.tobytes() != y.tobytes():
+                    diffs.append("%s[%s]" % (f, k))
+    return diffs
+
+
+def main():
+    if "--check" in sys.argv[1:]:
+        diffs = check()
+        for d in diffs:
+            print("DIFF", d)
+        print("golden check:", "FAILED (%d)" % len(diffs) if diffs else "OK -- every committed fixture regenerates identically")
+        sys.exit(1 if diffs else 0)
+    generate()
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libglx_oracle.so")
-REF_SO = os.path.join(ROOT, "oracle", "_ref", "libglref.so")
+REF_SO = os.environ.get("GLX_REF_LIB") or os.path.join(ROOT, "oracle", "_ref", "libglref.so")
 
 VP = ctypes.c_void_p
 SAMPLERS = ["RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler"]
