@@ -203,16 +203,19 @@ def host_boundary_rate(args):
     exe = os.path.join(ROOT, "graph-learn_amd", "lib", "host_path_bench")
     if not os.path.exists(exe):
         return None
+    t_hb = time.time()
     threads, B, reps = args.host_boundary_threads, 1024, 40  # 10 per thread: start / tail skew of the pool costs 20 %
     try:
-        r = subprocess.run([exe, str(threads), str(B), str(reps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                           text=True, timeout=300)
+        # the headline graph's shape: RMAT scale 24 folded onto 10 M nodes, 100 M edges, dim 256
+        r = subprocess.run([exe, str(threads), str(B), str(reps), "24", "100000000", "256", "10000000"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         rec = json.loads(line)
     except Exception as ex:  # noqa: BLE001 -- never lose the headline line
         return {"error": repr(ex)}
     return {"edges_per_s": rec["sampled_edges_per_s_host_pointer_path"], "threads": threads, "seeds_per_request": B,
-            "requests_per_thread": reps, "graph": "RMAT 2M nodes / 20M edges, dim 256 (host_path_bench defaults)",
+            "requests_per_thread": reps, "wall_s_incl_build": time.time() - t_hb,
+            "graph": "RMAT %d nodes / %d edges, dim %d: the headline workload's shape, built through the C++ store API" % (rec["nodes"], rec["edges"], rec["dim"]),
             "response_bytes_per_request": B * 25 * 16 + B * 250 * 16 + (B * 25 + B) * (256 * 4 + 4),
             "note": "PCIe-inclusive: requests and responses are host tensors of the C++ operator API; response blocks "
                     "are pinned (glx_host_register) so the device->host copies are single DMA transfers"}
@@ -225,7 +228,7 @@ def edge_cut_world1(args):
     env = dict(os.environ, GLX_DIST_NO_SHORTCUT="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--cpu-baseline", "off", "--host-boundary", "off", "--roofline-probes", "off",
-           "--edge-cut-probe", "off", "--small-batches", "off", "--verify"]
+           "--edge-cut-probe", "off", "--small-batches", "off", "--other-configs", "", "--verify"]
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -378,6 +381,109 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
         sys.exit(3)
 
 
+def roofline_aggregate(agg, D, n_segments, n_ids, avg_ms, launches, ids_last, workload, B0, sources=1, offline_ok=True):
+    """Roofline entry of the hop-2 segmented reduce.  Everything named frac* is computed from THIS run:
+      algorithmic bytes (SURVEY 8(d)): n_ids * (4D + 12) + n_segments * (4D + 4) -- every row occurrence counted;
+      compulsory bytes: the DISTINCT rows of the launch's ids once + ids + outputs -- what HBM must deliver even
+        with perfect caches; achieved / frac use these (<= the real traffic <= peak * t, so frac <= 1);
+      offline PMC traffic (profiles/pmc_traffic.json) is reported beside, labelled as not of this run."""
+    bytes_alg = n_ids * (4 * D + 12) + n_segments * (4 * D + 4)
+    distinct = int(torch.unique(ids_last.reshape(-1)).numel())
+    bytes_comp = distinct * 4 * D + n_ids * 12 + n_segments * (4 * D + 4)
+    t = avg_ms * 1e-3
+    roof = {"kernel": "glx_aggregate_kernel (hop-2 %s, dim=%d%s)" % (agg, D, ", 3 row sources" if sources == 3 else ""),
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": avg_ms, "launches_timed": launches,
+            "algorithmic_bytes_per_launch": bytes_alg, "achieved_algorithmic": bytes_alg / t / 1e9,
+            "algorithmic_over_peak": bytes_alg / t / 1e9 / HBM_PEAK_GBS, "cache_assisted": True,
+            "note_algorithmic": "SURVEY 8(d) bytes / live launch time; every row occurrence counted, so re-reads of hub rows "
+                                "served by L2 / Infinity Cache are in it: a rate the kernel delivers, not HBM traffic",
+            "distinct_rows_last_launch": distinct, "compulsory_bytes_per_launch": bytes_comp,
+            "achieved": bytes_comp / t / 1e9, "frac": bytes_comp / t / 1e9 / HBM_PEAK_GBS, "frac_compulsory": bytes_comp / t / 1e9 / HBM_PEAK_GBS,
+            "frac_basis": "compulsory bytes of this run's last timed hop-2 launch (distinct rows x 4D + ids + outputs) / live "
+                          "average launch time / 8 TB/s",
+            "traffic": None}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if offline_ok and os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("%s_b%d" % (workload, B0), {}).get("aggregate_hop2_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+        if traffic:
+            roof["traffic"] = traffic
+            roof["traffic_source"] = ("OFFLINE: profiles/pmc_traffic.json, rocprofv3 --pmc passes of this command on another "
+                                      "box (FETCH_SIZE x2 + WRITE_SIZE per launch); not measured in this run")
+            roof["frac_traffic_offline"] = min(1.0, traffic / t / 1e9 / HBM_PEAK_GBS)
+    return roof
+
+
+def roofline_sampler(sampler, k, rows, slots, avg_ms, launches, workload, B0):
+    """Roofline entry of the hop-2 sampler launch.  SURVEY 8(d): 32 B per output slot (8 col + 8 edge id read, 16
+    written), EdgeWeight + 8 B per draw (alias prob + index), + 24 B per request row (src id + two row_ptr)."""
+    per_slot = 40 if sampler in ("EdgeWeightSampler", "InDegreeSampler") else 32
+    bytes_alg = slots * per_slot + rows * 24
+    t = avg_ms * 1e-3
+    r = {"kernel": "hop-2 %s launch (k=%d, %d request rows)" % (sampler, k, rows), "bound": "hbm", "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "avg_launch_ms": avg_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": bytes_alg,
+         "achieved": bytes_alg / t / 1e9, "frac": bytes_alg / t / 1e9 / HBM_PEAK_GBS, "draws_per_s": slots / t, "traffic": None}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc)).get("%s_b%d" % (workload, B0), {})
+        except Exception:  # noqa: BLE001
+            rec = {}
+        if rec.get("sample_hop2_bytes_per_launch"):
+            r["traffic"] = rec["sample_hop2_bytes_per_launch"]
+            r["traffic_source"] = "OFFLINE: profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per launch); not of this run"
+            r["traffic_over_algorithmic_offline"] = rec["sample_hop2_bytes_per_launch"] / bytes_alg
+    return r
+
+
+def verify_vs_oracle(args, wl, dev, seeds_last, out, call_counters):
+    """--verify-oracle: the outputs of the last TIMED step against the oracle, on row subsets cut from the raw edge
+    list (tests/headline_check.py).  Outside the timed region; the oracle is the checker, never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from headline_check import check_step
+    V, E, sampler, fan, agg, D, gseed, _ = wl
+    weighted = sampler in ("EdgeWeightSampler", "TopkSampler")
+    t0 = time.time()
+    src, dst, weight = synth.rmat_edges_torch(V, E, gseed, dev, weighted=weighted, scramble=not args.no_scramble)
+    X = synth.features_torch(V, D, gseed + 1, dev)
+    hubs = torch.topk(torch.bincount(src, minlength=V), 100).indices.cpu().numpy()
+    r = check_step((src, dst, weight), lambda ids: X[ids], sampler, fan, agg, seeds_last, out, seed=42,
+                   call_counters=call_counters, rows_hop1=4096, rows_hop2=8192, segments=16384, hub_ids=hubs)
+    del src, dst, weight, X
+    torch.cuda.empty_cache()
+    r["wall_s"] = time.time() - t0
+    r["what"] = ("last timed step: sampled (neighbour, edge id) rows and aggregated segments re-computed by oracle/glx_oracle.c "
+                 "on sub-graphs cut from the raw edge list; bit-for-bit equality")
+    log("verify vs oracle: %s" % r)
+    return r
+
+
+def other_configs(args):
+    """BASELINE configs[1] (c2) and configs[4] (c5) on this GPU, each in a process of its own (this one keeps the
+    headline's store resident until it exits), same --steps / --warmup: driver-timed numbers for the configs that
+    are not the headline."""
+    import subprocess
+    out = {}
+    for name in [x for x in args.other_configs.split(",") if x.strip()]:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", name, "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--cpu-baseline", "off", "--host-boundary", "off", "--edge-cut-probe", "off",
+               "--small-batches", "off", "--other-configs", ""]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out[name] = {"workload": rec["config"]["workload"], "ms_per_step": rec["ms_per_step"], "value": rec["value"],
+                         "unit": rec["unit"], "steps": rec["steps"], "phases": rec.get("phases"), "roofline": rec.get("roofline"),
+                         "roofline_sampler": rec.get("roofline_sampler"), "verified_vs_oracle": rec.get("verified_vs_oracle"),
+                         "wall_s": time.time() - t0}
+        except Exception as ex:  # noqa: BLE001 -- never lose the headline line
+            out[name] = {"error": repr(ex)}
+        log("other config %s: %s" % (name, {k: out[name].get(k) for k in ("ms_per_step", "value", "error")}))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,11 +547,17 @@ def main():
     ap.add_argument("--hot-profile-steps", type=int, default=4)
     ap.add_argument("--roofline-probes", default="on", choices=["on", "off"],
                     help="N=1: also time the aggregation kernel on cache-free (uniform) rows and a device copy")
+    ap.add_argument("--verify-oracle", default="on", choices=["on", "off"],
+                    help="N=1: after timing, re-check the last timed step's outputs on row subsets against the oracle "
+                         "(tests/headline_check.py) and emit \"verified_vs_oracle\"")
+    ap.add_argument("--other-configs", default="c2,c5",
+                    help="N=1, headline workload at the default batch: also time these workloads (comma separated), each in a "
+                         "process of its own, and report them under \"other_configs\"")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--c5-scale", type=int, default=1, help="divide the c5 node / edge counts (test rig)")
     ap.add_argument("--cpu-baseline", default="on", choices=["on", "off"])
-    ap.add_argument("--cpu-build-budget", type=float, default=85.0, help="s of reference graph build")
+    ap.add_argument("--cpu-build-budget", type=float, default=45.0, help="s of reference graph build")
     ap.add_argument("--cpu-time-budget", type=float, default=10.0, help="s per timed CPU leg")
     ap.add_argument("--cpu-seeds-per-request", type=int, default=128)
     ap.add_argument("--cpu-storage-mode", type=int, default=3, choices=[2, 3],
@@ -905,6 +1017,19 @@ def main():
         halo_stats = st_agg.stats()
         dog.cancel()
 
+    # the last timed step's outputs against the oracle, before anything else touches the buffers
+    oracle_check = None
+    if args.verify_oracle == "on" and not sharded and world == 1:
+        last_i = (kernel_steps - 1) if use_graph else (n_steps - 1)
+        nb1, ed1, nb2, ed2 = bufs[last_i % len(bufs)]
+        torch.cuda.synchronize()
+        try:
+            oracle_check = verify_vs_oracle(args, wl, dev, seeds[last_i],
+                                            dict(n1=nb1, e1=ed1, n2=nb2, e2=ed2, emb2=emb2, cnt2=cnt2, emb1=emb1, cnt1=cnt1),
+                                            (4 * last_i, 4 * last_i + 1))
+        except Exception as ex:  # noqa: BLE001 -- a checker that cannot run is reported, not fatal to the line
+            oracle_check = {"ok": None, "error": repr(ex)}
+
     cpu = None
     if host_edges is not None:
         t1 = time.time()
@@ -948,38 +1073,30 @@ def main():
     # ---- roofline of the dominant kernel: the hop-2 segmented reduce (first aggregate launch of each step)
     agg2 = t_agg[0::2]
     agg1 = t_agg[1::2]
-    bytes_agg2 = n2 * (4 * D + 12) + n1 * (4 * D + 4)  # algorithmic bytes
+    smp2 = t_smp[1::2]  # hop-2 sampler launches (second sample launch of each step)
     avg_agg2_ms = float(np.mean(agg2)) if len(agg2) else float("nan")
-    achieved = bytes_agg2 / (avg_agg2_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            rec = json.load(open(pmc))
-            key = "%s_b%d" % (args.workload, B0)
-            traffic = rec.get(key, {}).get("aggregate_hop2_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roof = {"kernel": "glx_aggregate_kernel (hop-2 %s, dim=%d%s)" % (agg, D, ", 3 row sources" if headline == "features_sharded" else ""),
-            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "avg_launch_ms": avg_agg2_ms, "algorithmic_bytes_per_launch": bytes_agg2, "launches_timed": int(len(agg2)),
-            "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBS,
-            "note_algorithmic": "SURVEY 8(d) bytes / live launch time; counts every row read once per occurrence, so hub "
-                                "rows re-read from L2 / Infinity Cache push it past what HBM delivers (cache-assisted)",
-            "traffic": traffic,
-            "traffic_source": ("profiles/pmc_traffic.json: offline rocprofv3 --pmc passes of this command (FETCH_SIZE x2 + "
-                               "WRITE_SIZE per launch), not measured in this run") if traffic else None}
-    if traffic and not sharded:
-        roof["achieved"] = traffic / (avg_agg2_ms * 1e-3) / 1e9
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        roof["frac_basis"] = "PMC-measured HBM traffic per launch / live launch time / 8 TB/s"
+    if sharded:
+        last_ids2 = b_last
     else:
-        roof["achieved"] = min(achieved, HBM_PEAK_GBS)
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        roof["frac_basis"] = "algorithmic bytes (no PMC traffic recorded for this configuration), capped at the peak"
+        last_ids2 = bufs[(n_steps - 1) % len(bufs)][2]  # hop-2 neighbour ids of the last TIMED step
+    roof = roofline_aggregate(agg, D, n1, n2, avg_agg2_ms, int(len(agg2)), last_ids2, args.workload, B0,
+                              sources=3 if headline == "features_sharded" else 1, offline_ok=not sharded)
+    roof_smp = None
+    if len(smp2) and not sharded:
+        roof_smp = roofline_sampler(sampler, k2, n1, n2, float(np.mean(smp2)), int(len(smp2)), args.workload, B0)
     if args.roofline_probes == "on" and not sharded:
-        # (a) the same kernel on uniformly random rows of the whole table: no reuse a cache could serve
-        # (b) what a plain device-to-device copy reaches on this box (read + write)
+        # what the memory system of THIS box delivers to hand-written kernels with known byte counts (glx_probe.hip),
+        # and the reduce itself on uniformly random rows of the whole table (no reuse a cache could serve)
+        peaks = {k: glx.probe_bandwidth(k, 2 << 30, reps=10, device=local_rank)["gbps"] for k in ("stream_read", "copy", "triad")}
+        row_b = 4 * D
+        table_b = (min(V * row_b, 8 << 30) // (4096 * row_b)) * (4096 * row_b)
+        peaks["gather_rows_%dB_uniform" % row_b] = glx.probe_bandwidth("gather_rows", table_b, units=n2, unit_bytes=row_b,
+                                                                         reps=5, device=local_rank)["gbps"]
+        roof["peak_measured"] = dict(peaks, unit="GB/s", note="glx_probe_bandwidth in this run: 2 GiB streaming read / copy / "
+                                     "STREAM triad kernels (16 B per lane, non-temporal), and the reduce's row gather on "
+                                     "uniformly random rows without the reduce")
+        best = max(peaks["stream_read"], peaks["copy"], peaks["triad"])
+        roof["frac_of_measured_stream_peak"] = min(1.0, roof["achieved"] / best)
         fake = torch.randint(0, V, (n2,), generator=gen, device=dev)
         for _ in range(2):
             feats.aggregate(agg, fake, None, n1, out=(emb2, cnt2))
@@ -990,21 +1107,20 @@ def main():
         torch.cuda.synchronize()
         glx.profile_enable(False)
         ms = float(np.mean(glx.profile_collect(glx.KERNEL_AGGREGATE)))
-        roof["cache_free"] = {"rows": "uniform over all %d rows" % V, "avg_launch_ms": ms,
-                              "achieved": bytes_agg2 / (ms * 1e-3) / 1e9, "frac": bytes_agg2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        bytes_alg = roof["algorithmic_bytes_per_launch"]
+        roof["cache_free"] = {"rows": "uniform over all %d rows (every row read is an HBM read)" % V, "avg_launch_ms": ms,
+                              "achieved": bytes_alg / (ms * 1e-3) / 1e9, "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "frac_of_gather_rows_probe": min(1.0, bytes_alg / (ms * 1e-3) / 1e9 / peaks["gather_rows_%dB_uniform" % row_b])}
         del fake
-        x = torch.empty(1 << 29, dtype=torch.float32, device=dev)  # 2 GiB
-        y = torch.empty_like(x)
-        for _ in range(2):
-            y.copy_(x)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            y.copy_(x)
-        e1.record()
-        torch.cuda.synchronize()
-        roof["peak_measured_copy"] = 2 * x.numel() * 4 / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
-        del x, y
+        if roof_smp is not None:
+            g32 = glx.probe_bandwidth("gather32", (E * 32 // 4096) * 4096, units=n2, reps=5, device=local_rank)
+            rate = n2 / (g32["ms"] * 1e-3)
+            roof_smp["gather32_uniform"] = {"records_per_s": rate, "ms": g32["ms"], "table_bytes": (E * 32 // 4096) * 4096,
+                                            "note": "glx_probe_bandwidth GATHER32 in this run: as many aligned 32-byte records as the "
+                                                    "hop-2 launch draws, from uniformly random positions of a table the size of the "
+                                                    "packed alias records, 16 B written per record"}
+            roof_smp["draws_over_uniform_gather_rate"] = roof_smp["draws_per_s"] / rate
+            roof_smp["frac_of_gather_ceiling"] = min(1.0, roof_smp["draws_per_s"] / rate)
     smp_ms = float(np.sum(t_smp)) / max(kernel_steps, 1)
     agg_ms = float(np.sum(t_agg)) / max(kernel_steps, 1)
     res = {
@@ -1033,6 +1149,11 @@ def main():
         "roofline": roof,
         "cpu_baseline": cpu,
     }
+    if roof_smp is not None:
+        res["roofline_sampler"] = roof_smp
+    if oracle_check is not None:
+        res["verified_vs_oracle"] = oracle_check["ok"]
+        res["oracle_check"] = oracle_check
     if sharded:
         res["value_features_sharded"] = legs["features_sharded"]["value"]
         res["value_features_replicated"] = legs.get("features_replicated", {}).get("value")
@@ -1078,6 +1199,11 @@ def main():
                                                 "alternating on as many streams; value in edges/s" % args.graph_streams)
     if args.edge_cut_probe == "on" and not sharded and world == 1 and args.workload == "c3" and B0 == 65536:
         res["edge_cut_world1"] = edge_cut_world1(args)
+    if args.other_configs and not sharded and world == 1 and args.workload == "c3" and B0 == 65536:
+        # free this process's store first: c5 needs most of the HBM for its build
+        del graph, feats
+        torch.cuda.empty_cache()
+        res["other_configs"] = other_configs(args)
     if rank == 0:
         result_out.write(json.dumps(res) + "\n")
         result_out.flush()

@@ -173,6 +173,110 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
   }
 }
 
+// ---- north_star's "dense feature tile staged in LDS, MFMA on the tile" formulation of Sum / Mean, kept as a
+// measured ABLATION (GLX_AGG_MFMA=1; profiles/r03/mfma_ablation.txt) ----------------------------
+// A segmented sum is the SpMM  Out[Sg, D] = S[Sg, N] * Xg[N, D]  with S the 0/1 segment-indicator matrix.  For a
+// dense sampler response (uniform fanout f) a workgroup owns 16 consecutive segments = 16 f consecutive ids:
+//   * the 4 waves gather KC rows at a time into LDS with 16-byte loads (row pitch D + 16 floats: the four rows
+//     of one MFMA step then sit in four disjoint groups of 16 banks);
+//   * wave w owns the columns [w D/4, (w+1) D/4) as NB = D/64 blocks of 16 and issues, per 4 rows,
+//     v_mfma_f32_16x16x4_f32 with A[m][k] = (row k belongs to segment m) and B[k][n] = the staged row;
+//   * f32 MFMA is an exact fmaf chain over k in order and the indicator is 0 or 1, so every output element
+//     is still accumulated in the reference's left-to-right order (sum_aggregator.cc:25-33): bit-identical.
+// 15/16 of the multiply-adds multiply by zero, f32 MFMA runs at the vector rate (157 TF), and the reduce is
+// 0.25 flop/byte: the matrix core cannot make it faster than the HBM stream -- the ablation measures what the
+// LDS round trip and the workgroup barriers cost instead.
+template <int OP, int NB>
+__global__ __launch_bounds__(256) void glx_aggregate_mfma_kernel(AggArgs a) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int KC = 32;  // rows staged per round
+  extern __shared__ float tile[];  // [KC][pitch]
+  constexpr int32_t D = 64 * NB;
+  constexpr int32_t pitch = D + 16;
+  const int32_t f = a.fanout;
+  const int64_t seg0 = (int64_t)blockIdx.x * 16;
+  const int32_t nseg = (int32_t)((a.num_segments - seg0) < 16 ? (a.num_segments - seg0) : 16);
+  const int64_t id0 = seg0 * f;
+  const int32_t nrows = nseg * f;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m = lane & 15;   // A: segment row of this lane / B, C: column inside the block
+  const int kq = lane >> 4;  // A, B: which of the step's 4 rows / C: row group
+  f4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int32_t row_f4 = D / 4;
+  constexpr int32_t PT = KC * row_f4 / 256;  // 16-byte pieces per thread per round (2 NB)
+  for (int32_t base = 0; base < nrows; base += KC) {
+    // stage rows [base, base + KC): thread t moves pieces t, t + 256, ...; all loads issued before the first store
+    f4 v[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int32_t p = threadIdx.x + i * 256;
+      const int32_t r = p / row_f4;
+      const int32_t c4 = p - r * row_f4;
+      v[i] = f4{0.f, 0.f, 0.f, 0.f};
+      if (base + r < nrows) {
+        const int32_t row = agg_row_at(a, (int32_t)(id0 + base + r));
+        if (row >= 0) v[i] = *reinterpret_cast<const f4*>(agg_row_ptr<1>(a, row) + c4 * 4);
+        else v[i] = f4{a.default_attr, a.default_attr, a.default_attr, a.default_attr};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int32_t p = threadIdx.x + i * 256;
+      const int32_t r = p / row_f4;
+      const int32_t c4 = p - r * row_f4;
+      *reinterpret_cast<f4*>(tile + r * pitch + c4 * 4) = v[i];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int32_t k4 = 0; k4 < KC; k4 += 4) {
+      const int32_t krow = base + k4 + kq;
+      const float ind = (krow < nrows && krow / f == m) ? 1.0f : 0.0f;
+      const float* brow = tile + (k4 + kq) * pitch + wave * (D / 4) + m;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ind, brow[b * 16], acc[b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int32_t srow = kq * 4 + reg;
+    if (srow < nseg) {
+      float* out = a.emb_out + (seg0 + srow) * (int64_t)D + wave * (D / 4) + m;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float v = acc[b][reg];
+        if (f == 0) v = a.default_attr;
+        else if (OP == GLX_AGG_MEAN) v = v / (float)f;
+        out[b * 16] = v;
+      }
+    }
+  }
+  if (threadIdx.x < nseg) a.cnt_out[seg0 + threadIdx.x] = f;
+}
+
+bool agg_use_mfma(const AggArgs& a, int op) {
+  const char* e = getenv("GLX_AGG_MFMA");
+  if (!e || atoi(e) == 0) return false;
+  return (op == GLX_AGG_SUM || op == GLX_AGG_MEAN) && a.seg_start == nullptr && a.fanout > 0 && a.X1 == nullptr &&
+         a.X2 == nullptr && (a.dim == 64 || a.dim == 128 || a.dim == 256) && (a.stride % 4) == 0 &&
+         (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+}
+
+template <int OP>
+void launch_agg_mfma(const AggArgs& a, hipStream_t s) {
+  const unsigned grid = (unsigned)((a.num_segments + 15) / 16);
+  const size_t lds = (size_t)32 * (a.dim + 16) * sizeof(float);
+  if (a.dim == 64) glx_aggregate_mfma_kernel<OP, 1><<<grid, 256, lds, s>>>(a);
+  else if (a.dim == 128) glx_aggregate_mfma_kernel<OP, 2><<<grid, 256, lds, s>>>(a);
+  else glx_aggregate_mfma_kernel<OP, 4><<<grid, 256, lds, s>>>(a);
+}
+
 // Rows in flight per lane.  A/B in one process on the C3 hop-2 request (scripts/agg_unroll_probe.py,
 // profiles/r02/agg_unroll_probe.txt): 3 / 4 / 5 / 6 / 8 / 10 / 12 rows -> 2.26 / 2.19 / 2.11 / 2.10 / 2.21 / 2.49 /
 // 2.48 ms: fewer rows per lane cost fewer registers and let more waves hide the latency, down to 6; a
@@ -296,6 +400,12 @@ __global__ __launch_bounds__(256) void glx_lookup_kernel(GlxIdMap map, const flo
 
 int run_aggregate(AggArgs& a, int op, const int32_t* d_seg, int32_t num_ids, hipStream_t s) {
   GlxKernelTimer timer(GLX_KERNEL_AGGREGATE, s);
+  if (agg_use_mfma(a, op)) {  // ablation knob (GLX_AGG_MFMA=1): the LDS-staged MFMA formulation of Sum / Mean
+    if (op == GLX_AGG_SUM) launch_agg_mfma<GLX_AGG_SUM>(a, s);
+    else launch_agg_mfma<GLX_AGG_MEAN>(a, s);
+    timer.stop();
+    return GLX_OK;
+  }
   switch (op) {
     case GLX_AGG_SUM: launch_agg<GLX_AGG_SUM>(a, s); break;
     case GLX_AGG_MEAN: launch_agg<GLX_AGG_MEAN>(a, s); break;

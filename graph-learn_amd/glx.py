@@ -57,6 +57,7 @@ EXPORTS = [
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
     "glx_dist_last_stats",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
+    "glx_probe_bandwidth",
 ]
 
 
@@ -193,6 +194,8 @@ def lib():
         L.glx_plan_output.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                       ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32)]
         L.glx_plan_destroy.argtypes = [vp]
+        L.glx_probe_bandwidth.argtypes = [ci, ci, i64, i64, i32, i32, ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(ctypes.c_double), vp]
         L.glx_plan_destroy.restype = None
         _lib = L
     return _lib
@@ -1042,6 +1045,18 @@ class Plan:
 
 
 KERNEL_SAMPLE, KERNEL_AGGREGATE, KERNEL_LOOKUP = 0, 1, 2
+
+
+PROBES = {"stream_read": 0, "copy": 1, "triad": 2, "gather32": 3, "gather_rows": 4}
+
+
+def probe_bandwidth(kind, nbytes, units=0, unit_bytes=0, reps=10, device=0):
+    """glx_probe_bandwidth: -> dict(gbps, ms, moved_bytes) of one hand-written streaming / gather kernel."""
+    moved, ms = ctypes.c_double(), ctypes.c_double()
+    _check(lib().glx_probe_bandwidth(device, PROBES[kind] if isinstance(kind, str) else kind, int(nbytes), int(units),
+                                     int(unit_bytes), int(reps), ctypes.byref(moved), ctypes.byref(ms),
+                                     _stream(PTR_DEVICE, device)))
+    return {"gbps": moved.value / (ms.value * 1e-3) / 1e9, "ms": ms.value, "moved_bytes": moved.value}
 
 
 def profile_enable(on=True):

@@ -6,7 +6,9 @@
 // is the PCIe-inclusive rate of the drop-in boundary, not the device-resident rate.
 //
 //   host_path_bench [threads=8] [seeds_per_request=1024] [requests_per_thread=20]
-//                   [log2_nodes=21] [edges=20000000] [dim=256]
+//                   [log2_nodes=21] [edges=20000000] [dim=256] [nodes=2^log2_nodes]
+// bench.py runs it on the headline graph's shape: log2_nodes 24, edges 100000000, dim 256, nodes 10000000
+// (RMAT ids folded onto [0, nodes) like synth.rmat_edges_torch does).
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -27,12 +29,17 @@ int main(int argc, char** argv) {
   const int scale = argc > 4 ? atoi(argv[4]) : 21;
   const int64_t E = argc > 5 ? atoll(argv[5]) : 20000000;
   const int D = argc > 6 ? atoi(argv[6]) : 256;
-  const int64_t V = 1LL << scale;
+  const int64_t V = argc > 7 && atoll(argv[7]) > 0 ? atoll(argv[7]) : 1LL << scale;
   const int k1 = 25, k2 = 10;
 
-  // RMAT (0.57, 0.19, 0.19, 0.05) edge stream with U(0.01, 1) weights
-  std::mt19937_64 rng(4);
-  std::uniform_real_distribution<double> uni(0.0, 1.0);
+  // RMAT (0.57, 0.19, 0.19, 0.05) edge stream with U(0.01, 1) weights; splitmix64, 16 random bits per level
+  uint64_t sm = 4;
+  auto next64 = [&sm]() {
+    uint64_t z = (sm += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
   GraphStore store;
   {
     io::SideInfo info;
@@ -43,14 +50,17 @@ int main(int argc, char** argv) {
     io::EdgeValue v;
     for (int64_t e = 0; e < E; ++e) {
       int64_t s = 0, d = 0;
+      uint64_t bits = 0;
       for (int l = 0; l < scale; ++l) {
-        const double r = uni(rng);
-        s = (s << 1) | (r >= 0.76);
-        d = (d << 1) | ((r >= 0.57 && r < 0.76) || r >= 0.95);
+        if ((l & 3) == 0) bits = next64();
+        const uint32_t r = (uint32_t)(bits & 0xFFFF);  // U[0, 65536): thresholds 0.57 / 0.76 / 0.95
+        bits >>= 16;
+        s = (s << 1) | (r >= 49807);
+        d = (d << 1) | ((r >= 37356 && r < 49807) || r >= 62259);
       }
-      v.src_id = s;
-      v.dst_id = d;
-      v.weight = static_cast<float>(0.01 + 0.99 * uni(rng));
+      v.src_id = s % V;
+      v.dst_id = d % V;
+      v.weight = 0.01f + 0.99f * (float)((next64() >> 40) * (1.0 / 16777216.0));
       graph->Add(&v);
     }
     IndexOption opt;
@@ -67,11 +77,15 @@ int main(int argc, char** argv) {
     noder->SetSideInfo(&info);
     io::NodeValue nv;
     nv.attrs.resize(D);
-    std::mt19937 frng(5);
-    std::uniform_real_distribution<float> fu(-1.f, 1.f);
+    sm = 5;
     for (int64_t i = 0; i < V; ++i) {
       nv.id = i;
-      for (int j = 0; j < D; ++j) nv.attrs[j] = fu(frng);
+      for (int j = 0; j + 1 < D; j += 2) {
+        const uint64_t z = next64();
+        nv.attrs[j] = (float)(uint32_t)(z >> 40) * (2.0f / 16777216.0f) - 1.0f;
+        nv.attrs[j + 1] = (float)(uint32_t)((z >> 8) & 0xFFFFFF) * (2.0f / 16777216.0f) - 1.0f;
+      }
+      if (D & 1) nv.attrs[D - 1] = (float)(uint32_t)(next64() >> 40) * (2.0f / 16777216.0f) - 1.0f;
       noder->Add(&nv);
     }
     IndexOption opt;

@@ -31,8 +31,8 @@ extern "C" {
 #endif
 
 /* 1: graph / features / samplers / aggregators / partition helpers.  2 (additions only): host registration, shard
- * communicator, distributed store (+ replicas), request plans. */
-#define GLX_ABI_VERSION 2
+ * communicator, distributed store (+ replicas), request plans.  3 (additions only): memory-system probes. */
+#define GLX_ABI_VERSION 3
 
 /* Exported symbols: libglx.so is built with -fvisibility=hidden. */
 #if defined(__GNUC__)
@@ -605,6 +605,27 @@ GLX_API void glx_plan_destroy(glx_plan* p);
 #define GLX_KERNEL_LOOKUP 2
 GLX_API int glx_profile_enable(int on);
 GLX_API int glx_profile_collect(int kind, float* ms_out, int32_t cap, int32_t* count);
+
+/* ---- memory-system probes: the measured ceilings the kernels above are priced against -- an addition of this
+ * engine with no counterpart in the reference (its PROFILING timers, common/base/profiling.h:24-71, time scopes; they
+ * do not measure the machine).  Each probe allocates its own buffers on `device`, runs 2 untimed + `reps` timed
+ * launches between two HIP events on `stream` and reports the bytes one launch moves and its average duration.
+ *   GLX_PROBE_STREAM_READ  reads a `bytes` buffer once (16 B per lane, grid-strided)          moved = bytes
+ *   GLX_PROBE_COPY         b = a                                                             moved = 2 * bytes
+ *   GLX_PROBE_TRIAD        a = b + s * c  (STREAM triad)                                     moved = 3 * bytes
+ *   GLX_PROBE_GATHER32     `units` aligned 32-byte records from uniformly random positions of a `bytes` table, 16 B
+ *                          written per record: EdgeWeightSampler's access per output slot (alias_method.cc:117-121 on
+ *                          one packed record)                                                moved = 48 * units
+ *   GLX_PROBE_GATHER_ROWS  `units` rows of `unit_bytes` from uniformly random rows of a `bytes` table, reduced ten to
+ *                          one in registers: the gather of Aggregator::Aggregate (aggregator.cc:25-59) without cache
+ *                          reuse                                                             moved = 1.1 * units * unit_bytes */
+#define GLX_PROBE_STREAM_READ 0
+#define GLX_PROBE_COPY 1
+#define GLX_PROBE_TRIAD 2
+#define GLX_PROBE_GATHER32 3
+#define GLX_PROBE_GATHER_ROWS 4
+GLX_API int glx_probe_bandwidth(int device, int kind, int64_t bytes, int64_t units, int32_t unit_bytes, int32_t reps,
+                                double* moved_bytes_out, double* avg_ms_out, void* stream);
 
 #ifdef __cplusplus
 }
