@@ -36,15 +36,33 @@ __global__ __launch_bounds__(256) void glx_probe_read_kernel(const f4* __restric
 
 __global__ __launch_bounds__(256) void glx_probe_copy_kernel(const f4* __restrict__ a, f4* __restrict__ b, int64_t n4) {
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += step) {
-    __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), b + i);
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * step < n4; i += 4 * step) {  // four loads in flight before the first store
+    const f4 v0 = __builtin_nontemporal_load(a + i);
+    const f4 v1 = __builtin_nontemporal_load(a + i + step);
+    const f4 v2 = __builtin_nontemporal_load(a + i + 2 * step);
+    const f4 v3 = __builtin_nontemporal_load(a + i + 3 * step);
+    __builtin_nontemporal_store(v0, b + i);
+    __builtin_nontemporal_store(v1, b + i + step);
+    __builtin_nontemporal_store(v2, b + i + 2 * step);
+    __builtin_nontemporal_store(v3, b + i + 3 * step);
   }
+  for (; i < n4; i += step) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), b + i);
 }
 
 __global__ __launch_bounds__(256) void glx_probe_triad_kernel(f4* __restrict__ a, const f4* __restrict__ b,
                                                               const f4* __restrict__ c, float s, int64_t n4) {
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += step) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i + step < n4; i += 2 * step) {
+    const f4 x0 = __builtin_nontemporal_load(b + i);
+    const f4 y0 = __builtin_nontemporal_load(c + i);
+    const f4 x1 = __builtin_nontemporal_load(b + i + step);
+    const f4 y1 = __builtin_nontemporal_load(c + i + step);
+    __builtin_nontemporal_store(x0 + s * y0, a + i);
+    __builtin_nontemporal_store(x1 + s * y1, a + i + step);
+  }
+  for (; i < n4; i += step) {
     const f4 x = __builtin_nontemporal_load(b + i);
     const f4 y = __builtin_nontemporal_load(c + i);
     __builtin_nontemporal_store(x + s * y, a + i);

@@ -59,10 +59,41 @@ def _pick(n, want, gen):
     return np.sort(gen.choice(n, want, replace=False)).astype(np.int64)
 
 
+def check_sample(orc, edges, sampler, k, request, nbr, eid, seed, call_counter, rows, padding_mode=1,
+                 default_neighbor_id=0):
+    """Request rows `rows` (sorted int64 numpy indices into `request`, a device tensor of source ids) of one sampler
+    call against the oracle on the sub-graph of their source ids, cut from the raw edge list.
+    -> (equal, edges in the sub-graph)"""
+    src, dst, weight = edges
+    t = torch.from_numpy(rows).to(request.device)
+    ids = np.ascontiguousarray(request.reshape(-1)[t].cpu().numpy())
+    g = sub_csr(orc, src, dst, weight, np.unique(ids), with_alias=sampler == "EdgeWeightSampler")
+    o, oe = orc.sample(g, sampler, ids, k, seed=seed, call_counter=call_counter, rng_rows=rows,
+                       padding_mode=padding_mode, default_neighbor_id=default_neighbor_id)
+    ok = np.array_equal(o, nbr.reshape(-1, k)[t].cpu().numpy()) and np.array_equal(oe, eid.reshape(-1, k)[t].cpu().numpy())
+    return ok, int(g["col"].shape[0])
+
+
+def check_aggregate(orc, features_of, aggregator, ids_2d, emb, cnt, segs, default_attr=0.0):
+    """Segments `segs` (sorted int64 numpy indices) of one aggregate call whose segment i reduces ids_2d[i, :]
+    (a dense sampler response) against the oracle on the feature rows those segments touch."""
+    f = ids_2d.shape[1]
+    t = torch.from_numpy(segs).to(ids_2d.device)
+    ids = ids_2d[t].reshape(-1)  # the segments' ids, in request order
+    uniq = torch.unique(ids)
+    X = features_of(uniq).cpu().numpy()
+    ids_h = ids.cpu().numpy()
+    seg = (np.arange(ids_h.shape[0]) // f).astype(np.int32)
+    oemb, ocnt = orc.aggregate(X, aggregator, ids_h, seg, segs.shape[0], default_attr=default_attr,
+                               ids=np.ascontiguousarray(uniq.cpu().numpy()))
+    return bool(np.array_equal(ocnt, cnt[t].cpu().numpy())
+                and np.array_equal(oemb.view(np.uint32), emb[t].cpu().numpy().view(np.uint32)))
+
+
 def check_step(edges, features_of, sampler, fanout, aggregator, seeds, out, seed, call_counters,
                rows_hop1=4096, rows_hop2=8192, segments=16384, hub_ids=None, hub_rows=2048, rng_seed=99,
                padding_mode=1, default_neighbor_id=0, default_attr=0.0):
-    """One real step against the oracle on a row subset.
+    """One real 2-hop step against the oracle on a row subset.
 
     edges        (src, dst, weight|None) device tensors of the raw edge list (edge id = index)
     features_of  callable(ids: int64 device tensor) -> [len, D] float32 device tensor of the raw rows
@@ -74,7 +105,6 @@ def check_step(edges, features_of, sampler, fanout, aggregator, seeds, out, seed
     orc = Oracle()
     k1, k2 = fanout
     gen = np.random.default_rng(rng_seed)
-    src, dst, weight = edges
     B0 = seeds.shape[0]
     n1, e1, n2, e2 = out["n1"], out["e1"], out["n2"], out["e2"]
     req2 = n1.reshape(-1)
@@ -87,40 +117,21 @@ def check_step(edges, features_of, sampler, fanout, aggregator, seeds, out, seed
         if pos.shape[0] > hub_rows:
             pos = pos[gen.choice(pos.shape[0], hub_rows, replace=False)]
         r2 = np.unique(np.concatenate([r2, pos.astype(np.int64)]))
-    seeds_h = seeds.cpu().numpy()
-    src1 = np.ascontiguousarray(seeds_h[r1])
-    src2 = np.ascontiguousarray(req2[torch.from_numpy(r2).to(req2.device)].cpu().numpy())
-    need = np.unique(np.concatenate([src1, src2]))
-    g = sub_csr(orc, src, dst, weight, need, with_alias=sampler == "EdgeWeightSampler")
     bad = []
-    o1, oe1 = orc.sample(g, sampler, src1, k1, seed=seed, call_counter=call_counters[0], rng_rows=r1,
-                         padding_mode=padding_mode, default_neighbor_id=default_neighbor_id)
-    t1 = torch.from_numpy(r1).to(n1.device)
-    if not (np.array_equal(o1, n1[t1].cpu().numpy()) and np.array_equal(oe1, e1[t1].cpu().numpy())):
+    kw = dict(padding_mode=padding_mode, default_neighbor_id=default_neighbor_id)
+    ok1, ne1 = check_sample(orc, edges, sampler, k1, seeds, n1, e1, seed, call_counters[0], r1, **kw)
+    if not ok1:
         bad.append("hop-1 sample")
-    o2, oe2 = orc.sample(g, sampler, src2, k2, seed=seed, call_counter=call_counters[1], rng_rows=r2,
-                         padding_mode=padding_mode, default_neighbor_id=default_neighbor_id)
-    t2 = torch.from_numpy(r2).to(n2.device)
-    if not (np.array_equal(o2, n2[t2].cpu().numpy()) and np.array_equal(oe2, e2[t2].cpu().numpy())):
+    ok2, ne2 = check_sample(orc, edges, sampler, k2, req2, n2, e2, seed, call_counters[1], r2, **kw)
+    if not ok2:
         bad.append("hop-2 sample")
-    res = dict(rows_hop1=int(r1.shape[0]), rows_hop2=int(r2.shape[0]), edges_in_subgraph=int(g["col"].shape[0]),
+    res = dict(rows_hop1=int(r1.shape[0]), rows_hop2=int(r2.shape[0]), edges_in_subgraph=ne1 + ne2,
                segments_hop2=0, segments_hop1=0)
     if aggregator is not None and "emb2" in out:
-        for name, ids_t, f, emb, cnt, want in (("hop-2", n2, k2, out["emb2"], out["cnt2"], segments),
-                                               ("hop-1", n1, k1, out["emb1"], out["cnt1"], max(1, segments // 8))):
-            nseg = ids_t.shape[0]
-            sg = _pick(nseg, want, gen)
-            tsg = torch.from_numpy(sg).to(ids_t.device)
-            ids = ids_t[tsg].reshape(-1)  # the segments' ids, in request order
-            uniq = torch.unique(ids)
-            X = features_of(uniq).cpu().numpy()
-            ids_h = ids.cpu().numpy()
-            seg = (np.arange(ids_h.shape[0]) // f).astype(np.int32)
-            oemb, ocnt = orc.aggregate(X, aggregator, ids_h, seg, sg.shape[0], default_attr=default_attr,
-                                       ids=np.ascontiguousarray(uniq.cpu().numpy()))
-            gemb = emb[tsg].cpu().numpy()
-            gcnt = cnt[tsg].cpu().numpy()
-            if not (np.array_equal(ocnt, gcnt) and np.array_equal(oemb.view(np.uint32), gemb.view(np.uint32))):
+        for name, ids_t, emb, cnt, want in (("hop-2", n2, out["emb2"], out["cnt2"], segments),
+                                            ("hop-1", n1, out["emb1"], out["cnt1"], max(1, segments // 8))):
+            sg = _pick(ids_t.shape[0], want, gen)
+            if not check_aggregate(orc, features_of, aggregator, ids_t, emb, cnt, sg, default_attr=default_attr):
                 bad.append(name + " aggregate")
             res["segments_" + name.replace("-", "")] = int(sg.shape[0])
     res["mismatches"] = bad
