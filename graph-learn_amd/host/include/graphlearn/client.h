@@ -26,6 +26,8 @@ public:
   Status LookupNodes(const LookupNodesRequest* request, LookupNodesResponse* response);
   Status LookupEdges(const LookupEdgesRequest* request, LookupEdgesResponse* response);
   Status GetDegree(const GetDegreeRequest* request, GetDegreeResponse* response);
+  Status GetCount(const GetCountRequest* request, GetCountResponse* response);
+  Status GetStats(const GetStatsRequest* request, GetStatsResponse* response);
   Status RunOp(const OpRequest* request, OpResponse* response);
   Status Stop();
 

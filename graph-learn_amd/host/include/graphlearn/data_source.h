@@ -98,6 +98,8 @@ template <class EdgeSources, class NodeSources>
 Status GraphStore::Load(const EdgeSources& edges, const NodeSources& nodes) {
   IndexOption option;
   option.name = "sort";
+  for (const auto& e : edges) DeclareEdgeType(e.edge_type);  // GraphStore::Init, graph_store.cc:185-208
+  for (const auto& n : nodes) DeclareNodeType(n.id_type);
   for (const auto& e : edges) {
     Status s = io::LoadEdges(e, this);
     if (!s.ok()) return s;

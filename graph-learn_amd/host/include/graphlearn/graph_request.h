@@ -112,6 +112,40 @@ public:
   int32_t* MutableDegrees();
 };
 
+// GetCountRequest / GetCountResponse (graph_request.h:324-349; operator core/operator/graph/
+// local_count_getter.cc:25-49): the number of edges / nodes THIS server holds, one int32 per declared
+// edge type then per declared node type, each group in type-name order (GraphStore::GetLocalCount).
+class GetCountRequest : public OpRequest {
+public:
+  GetCountRequest();
+};
+
+class GetCountResponse : public OpResponse {
+public:
+  GetCountResponse();
+  OpResponse* New() const override { return new GetCountResponse; }
+  void Init(int32_t type_num);
+  void Append(int32_t count);
+  const int32_t* Count() const;
+  int32_t Size() const;
+};
+
+// GetStatsRequest / GetStatsResponse (graph_request.h:401-417; operator core/operator/graph/
+// stats_getter.cc:25-48): per type, the counts of every server -- one int32 tensor per type name
+// (GetStatsResponse::SetCounts, graph_lookup_request.cc:742-749).
+class GetStatsRequest : public OpRequest {
+public:
+  GetStatsRequest();
+};
+
+class GetStatsResponse : public OpResponse {
+public:
+  GetStatsResponse();
+  OpResponse* New() const override { return new GetStatsResponse; }
+  void SetCounts(const Counts& counts);
+  Counts GetCounts() const;  // the tensors read back as a map (what the Python client does, python/client.py get_stats)
+};
+
 // RandomWalk (include/random_walk_request.h, service/request/random_walk_request.cc;
 // operator core/operator/random_walk/random_walk.cc): walk_len steps from every src id over
 // one edge type.  p = q = 1 is DeepWalk, anything else node2vec.  The reference's operator

@@ -11,6 +11,8 @@
 #define GLX_HOST_GRAPH_STORE_H_
 #include <cstdint>
 #include <mutex>
+#include <functional>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -213,6 +215,17 @@ private:
   std::mutex mtx_;
 };
 
+// include/graph_statistics.h:26-39: type -> one count per server, edge types and node types alike.
+using Counts = std::unordered_map<std::string, std::vector<int32_t>>;
+class GraphStatistics {
+public:
+  const Counts& GetCounts() const { return counts_; }
+  void AppendCount(const std::string& type, int32_t count) { counts_[type].push_back(count); }
+
+private:
+  Counts counts_;
+};
+
 class GraphStore {
 public:
   GraphStore();
@@ -225,6 +238,21 @@ public:
   // type -> number of nodes / edges held (GetStats: core/operator/graph/stats_getter.cc)
   std::unordered_map<std::string, int64_t> NodeCounts();
   std::unordered_map<std::string, int64_t> EdgeCounts();
+  // GraphStore::Init's bookkeeping (graph_store.cc:185-208): an edge type declared by two sources (the
+  // reverse pass of an undirected homogeneous edge file) counts double; Load() declares every source.  A
+  // store filled directly through GetGraph() / GetNoder() counts every type it holds once.
+  void DeclareEdgeType(const std::string& edge_type);
+  void DeclareNodeType(const std::string& node_type);
+  // Edges / nodes held here, one entry per declared edge type then per declared node type, each group in
+  // type-name order (BuildLocalCount, graph_store.cc:305-317); what "GetCount" answers with.
+  std::vector<int32_t> GetLocalCount();
+  // "GetStats": the local counts of every server, per type (BuildStatistics / FillCounts, graph_store.cc:
+  // 278-303).  One server: this store's counts.  Several: the gatherer an Env installs collects every
+  // server's GetLocalCount() (COLLECTIVE: every server asks for the statistics at the same time).
+  typedef std::function<Status(const std::vector<int32_t>& local, std::vector<std::vector<int32_t>>* all)> CountGatherer;
+  void SetCountGatherer(CountGatherer gather);
+  Status BuildStatistics();
+  const GraphStatistics& GetStatistics() const { return stats_; }
   // Build every storage added so far (GraphStore::Build, graph_store.cc:252-276).
   Status Build(const IndexOption& option);
   // Load every source, then Build (GraphStore::Load, graph_store.cc:60-120): declared in
@@ -251,6 +279,9 @@ private:
   std::mutex mtx_;
   std::unordered_map<std::string, Graph*> graphs_;
   std::unordered_map<std::string, Noder*> noders_;
+  std::map<std::string, int32_t> e_types_, n_types_;  // declared types -> multiplier, in name order
+  CountGatherer gather_;
+  GraphStatistics stats_;
 };
 
 }  // namespace graphlearn

@@ -31,6 +31,8 @@ Status Client::LookupEdges(const LookupEdgesRequest* request, LookupEdgesRespons
 Status Client::GetDegree(const GetDegreeRequest* request, GetDegreeResponse* response) {
   return RunOp(request, response);
 }
+Status Client::GetCount(const GetCountRequest* request, GetCountResponse* response) { return RunOp(request, response); }
+Status Client::GetStats(const GetStatsRequest* request, GetStatsResponse* response) { return RunOp(request, response); }
 Status Client::Stop() { return Status::OK(); }
 
 Client* NewInMemoryClient() { return new Client(); }

@@ -344,6 +344,69 @@ std::unordered_map<std::string, int64_t> GraphStore::EdgeCounts() {
   return out;
 }
 
+void GraphStore::DeclareEdgeType(const std::string& edge_type) {
+  std::lock_guard<std::mutex> g(mtx_);
+  auto it = e_types_.find(edge_type);
+  if (it == e_types_.end()) e_types_.insert({edge_type, 1});
+  else it->second = 2;  // graph_store.cc:196-201: undirected homogeneous edges
+}
+
+void GraphStore::DeclareNodeType(const std::string& node_type) {
+  std::lock_guard<std::mutex> g(mtx_);
+  n_types_.insert({node_type, 1});
+}
+
+std::vector<int32_t> GraphStore::GetLocalCount() {
+  std::lock_guard<std::mutex> g(mtx_);
+  // types that were never declared by a source (a store filled through GetGraph() / GetNoder()) count once
+  for (auto& it : graphs_) e_types_.insert({it.first, 1});
+  for (auto& it : noders_) n_types_.insert({it.first, 1});
+  std::vector<int32_t> out;
+  out.reserve(e_types_.size() + n_types_.size());
+  for (auto& it : e_types_) {
+    auto f = graphs_.find(it.first);
+    out.push_back((int32_t)((f == graphs_.end() ? 0 : f->second->GetEdgeCount()) * it.second));
+  }
+  for (auto& it : n_types_) {
+    auto f = noders_.find(it.first);
+    out.push_back((int32_t)((f == noders_.end() ? 0 : f->second->GetNodeCount()) * it.second));
+  }
+  return out;
+}
+
+void GraphStore::SetCountGatherer(CountGatherer gather) {
+  std::lock_guard<std::mutex> g(mtx_);
+  gather_ = std::move(gather);
+}
+
+Status GraphStore::BuildStatistics() {
+  const std::vector<int32_t> local = GetLocalCount();
+  std::vector<std::vector<int32_t>> all;
+  CountGatherer gather;
+  {
+    std::lock_guard<std::mutex> g(mtx_);
+    gather = gather_;
+  }
+  if (gather) {
+    Status s = gather(local, &all);
+    if (!s.ok()) return s;
+  } else {
+    all.push_back(local);
+  }
+  std::lock_guard<std::mutex> g(mtx_);
+  stats_ = GraphStatistics();
+  for (const auto& counts : all) {  // FillCounts, graph_store.cc:295-303
+    if (counts.size() != e_types_.size() + n_types_.size()) {
+      return error::Internal("GetStats: a server reported " + std::to_string(counts.size()) + " counts, " +
+                             std::to_string(e_types_.size() + n_types_.size()) + " types are declared here");
+    }
+    size_t j = 0;
+    for (auto& it : e_types_) stats_.AppendCount(it.first, counts[j++]);
+    for (auto& it : n_types_) stats_.AppendCount(it.first, counts[j++]);
+  }
+  return Status::OK();
+}
+
 Noder* GraphStore::GetNoder(const std::string& node_type) {
   std::lock_guard<std::mutex> g(mtx_);
   auto it = noders_.find(node_type);

@@ -176,6 +176,51 @@ int32_t* GetDegreeResponse::MutableDegrees() { return tensors_[kDegreeKey].Mutab
 
 REGISTER_REQUEST(GetDegree, GetDegreeRequest, GetDegreeResponse)
 
+// ------------------------------------------------------ GetCount / GetStats --
+namespace {
+const char* kCountKey = "cnt";  // service/constants.cc:51
+}
+
+GetCountRequest::GetCountRequest() : OpRequest() {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("GetCount");
+}
+GetCountResponse::GetCountResponse() : OpResponse() {}
+void GetCountResponse::Init(int32_t type_num) {
+  tensors_.erase(kCountKey);
+  ADD_TENSOR(tensors_, kCountKey, kInt32, type_num);
+}
+void GetCountResponse::Append(int32_t count) { tensors_[kCountKey].AddInt32(count); }
+const int32_t* GetCountResponse::Count() const { return tensors_.at(kCountKey).GetInt32(); }
+int32_t GetCountResponse::Size() const {
+  auto it = tensors_.find(kCountKey);
+  return it == tensors_.end() ? 0 : it->second.Size();
+}
+
+GetStatsRequest::GetStatsRequest() : OpRequest() {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("GetStats");
+}
+GetStatsResponse::GetStatsResponse() : OpResponse() {}
+void GetStatsResponse::SetCounts(const Counts& counts) {
+  for (const auto& it : counts) {
+    tensors_.erase(it.first);
+    ADD_TENSOR(tensors_, it.first, kInt32, (int32_t)it.second.size());
+    for (int32_t c : it.second) tensors_[it.first].AddInt32(c);
+  }
+}
+Counts GetStatsResponse::GetCounts() const {
+  Counts out;
+  for (const auto& it : tensors_) {
+    const int32_t* p = it.second.GetInt32();
+    out[it.first] = std::vector<int32_t>(p, p + it.second.Size());
+  }
+  return out;
+}
+
+REGISTER_REQUEST(GetCount, GetCountRequest, GetCountResponse)
+REGISTER_REQUEST(GetStats, GetStatsRequest, GetStatsResponse)
+
 // -------------------------------------------------------------- RandomWalk --
 RandomWalkRequest::RandomWalkRequest() : OpRequest(kSrcIds) {}
 
@@ -317,6 +362,34 @@ public:
   }
 };
 
+// local_count_getter.cc:25-49
+class CountGetter : public Operator {
+public:
+  Status Process(const OpRequest*, OpResponse* res) override {
+    GetCountResponse* response = static_cast<GetCountResponse*>(res);
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    const std::vector<int32_t> local = graph_store_->GetLocalCount();
+    response->Init((int32_t)local.size());
+    for (int32_t c : local) response->Append(c);
+    return Status::OK();
+  }
+};
+
+// stats_getter.cc:25-48
+class StatsGetter : public Operator {
+public:
+  Status Process(const OpRequest*, OpResponse* res) override {
+    GetStatsResponse* response = static_cast<GetStatsResponse*>(res);
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    if (graph_store_->GetStatistics().GetCounts().empty()) {
+      Status s = graph_store_->BuildStatistics();
+      if (!s.ok()) return s;
+    }
+    response->SetCounts(graph_store_->GetStatistics().GetCounts());
+    return Status::OK();
+  }
+};
+
 // RandomWalk (core/operator/random_walk/random_walk.cc:30-276): all steps in one device call.
 class RandomWalk : public Operator {
 public:
@@ -350,6 +423,8 @@ private:
 REGISTER_OPERATOR("LookupNodes", NodeLookuper)
 REGISTER_OPERATOR("LookupEdges", EdgeLookuper)
 REGISTER_OPERATOR("GetDegree", DegreeGetter)
+REGISTER_OPERATOR("GetCount", CountGetter)
+REGISTER_OPERATOR("GetStats", StatsGetter)
 REGISTER_OPERATOR("RandomWalk", RandomWalk)
 
 }  // namespace op

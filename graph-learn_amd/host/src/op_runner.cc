@@ -78,9 +78,36 @@ Env::Env(glx_comm* comm, GraphStore* store) : comm_(comm), store_(store), server
     server_id_ = rank;
     server_count_ = world;
   }
+  if (comm_ && store_ && server_count_ > 1) {
+    // GraphStore::BuildStatistics (graph_store.cc:278-293) asks every other server for its local counts with one
+    // GetCount RPC each; here all servers contribute theirs to one all-gather over the shard communicator.
+    glx_comm* c = comm_;
+    const int32_t world_n = server_count_;
+    store_->SetCountGatherer([c, world_n](const std::vector<int32_t>& local, std::vector<std::vector<int32_t>>* all) {
+      std::vector<int64_t> mine(local.begin(), local.end());
+      int64_t n = (int64_t)mine.size();
+      std::vector<int64_t> sizes((size_t)world_n);
+      int rc = glx_comm_allgather_i64(c, &n, 1, sizes.data(), GLX_PTR_HOST, nullptr);
+      if (rc != GLX_OK) return error::FromGlx(rc);
+      for (int64_t s : sizes) {
+        if (s != n) return error::Internal("GetStats: the servers declare different numbers of types");
+      }
+      std::vector<int64_t> got((size_t)world_n * (size_t)n);
+      if (n > 0) {
+        rc = glx_comm_allgather_i64(c, mine.data(), (int32_t)n, got.data(), GLX_PTR_HOST, nullptr);
+        if (rc != GLX_OK) return error::FromGlx(rc);
+      }
+      all->clear();
+      for (int32_t r = 0; r < world_n; ++r) {
+        all->emplace_back(got.begin() + (size_t)r * n, got.begin() + (size_t)(r + 1) * n);
+      }
+      return Status::OK();
+    });
+  }
 }
 
 Env::~Env() {
+  if (store_ && server_count_ > 1) store_->SetCountGatherer(nullptr);
   for (auto& kv : edge_stores_) glx_dist_store_destroy(kv.second);
   for (auto& kv : node_stores_) glx_dist_store_destroy(kv.second);
   for (auto& kv : graph_replicas_) glx_graph_destroy(kv.second);  // after the stores that borrowed them

@@ -199,6 +199,55 @@ TEST(GraphOpTest, DegreeGetter) {
 
 // RandomWalk (core/operator/random_walk/random_walk.cc) on the self-loop fixture: a walker stays where it is, an
 // unknown id yields the default id and walks on from it; DeepWalk and node2vec requests share the operator.
+// graph_op_unittest.cpp:705-789 (NodeCountGetter / EdgeCountGetter): 100 records per type, one count per
+// declared type -- edge types first, then node types, each group in type-name order.
+TEST(GraphOpTest, CountGetter) {
+  SetUpStore();
+  for (int32_t i = 0; i < 3; ++i) {
+    GetCountRequest req;
+    GetCountResponse res;
+    Operator* op = OpFactory::GetInstance()->Create(req.Name());
+    EXPECT_TRUE(op != nullptr);
+    EXPECT_TRUE(op->Process(&req, &res).ok());
+    EXPECT_EQ(res.Size(), 6);
+    for (int32_t j = 0; j < res.Size(); ++j) EXPECT_EQ(res.Count()[j], 100);
+  }
+}
+
+// stats_getter.cc:25-48 over GraphStore::BuildStatistics: on one server every type maps to one count.
+TEST(GraphOpTest, StatsGetter) {
+  SetUpStore();
+  GetStatsRequest req;
+  GetStatsResponse res;
+  Operator* op = OpFactory::GetInstance()->Create(req.Name());
+  EXPECT_TRUE(op != nullptr);
+  EXPECT_TRUE(op->Process(&req, &res).ok());
+  Counts c = res.GetCounts();
+  EXPECT_EQ(c.size(), (size_t)6);
+  for (const char* t : {"click", "buy", "watch", "user", "item", "movie"}) {
+    EXPECT_EQ(c[t].size(), (size_t)1);
+    EXPECT_EQ(c[t][0], 100);
+  }
+}
+
+// GraphStore::Init (graph_store.cc:196-201): an edge type declared by two sources counts double.
+TEST(GraphOpTest, UndirectedEdgeTypeCountsTwice) {
+  GraphStore store;
+  store.DeclareEdgeType("e");
+  store.DeclareEdgeType("e");
+  store.DeclareNodeType("n");
+  io::EdgeValue v;
+  v.src_id = 1;
+  v.dst_id = 2;
+  store.GetGraph("e")->Add(&v);
+  store.GetGraph("e")->Add(&v);
+  store.GetGraph("e")->Add(&v);
+  std::vector<int32_t> c = store.GetLocalCount();
+  EXPECT_EQ(c.size(), (size_t)2);
+  EXPECT_EQ(c[0], 6);
+  EXPECT_EQ(c[1], 0);
+}
+
 TEST(GraphOpTest, RandomWalk) {
   SetUpStore();
   for (float p : {1.0f, 0.5f}) {

@@ -376,6 +376,60 @@ TEST(PartitionStitchTest, DistributeRunnerOnTwoServersEqualsOneStore) {
 // A server that holds NO edge of a weighted edge type (every source id happens to live elsewhere -- small edge types
 // of a heterogeneous graph) still takes part: it serves the rows of the vertices it owns (all empty: default ids)
 // and its own requests are answered by the other server.
+// GraphStore::BuildStatistics across servers (graph_store.cc:278-303): every server ends up with every server's
+// local counts, per type, in server order -- gathered over the shard communicator instead of GetCount RPCs.
+TEST(PartitionStitchTest, StatisticsAcrossTwoServers) {
+  GraphStore shard[2];
+  const int n_edges[2] = {600, 0}, n_nodes[2] = {10, 7};
+  for (int r = 0; r < 2; ++r) {
+    shard[r].DeclareEdgeType("e");
+    shard[r].DeclareNodeType("n");
+    io::EdgeValue v;
+    for (int e = 0; e < n_edges[r]; ++e) {
+      v.src_id = e % 40;
+      v.dst_id = e % 7;
+      shard[r].GetGraph("e")->Add(&v);
+    }
+    io::NodeValue nv;
+    for (int i = 0; i < n_nodes[r]; ++i) {
+      nv.id = i * 2 + r;
+      shard[r].GetNoder("n")->Add(&nv);
+    }
+  }
+  bool ok[2] = {true, true};
+  std::string why[2];
+  auto server = [&](int r) {
+    glx_comm* comm = nullptr;
+    if (glx_comm_init_local(77110, 0, r, 2, &comm) != GLX_OK) {
+      ok[r] = false;
+      why[r] = glx_last_error();
+      return;
+    }
+    {
+      Env env(comm, &shard[r]);
+      Status s = shard[r].BuildStatistics();
+      if (!s.ok()) {
+        ok[r] = false;
+        why[r] = s.ToString();
+      } else {
+        Counts c = shard[r].GetStatistics().GetCounts();
+        if (c["e"] != std::vector<int32_t>({600, 0}) || c["n"] != std::vector<int32_t>({10, 7}) || c.size() != 2) {
+          ok[r] = false;
+          why[r] = "wrong counts";
+        }
+      }
+    }
+    glx_comm_destroy(comm);
+  };
+  std::thread t0(server, 0), t1(server, 1);
+  t0.join();
+  t1.join();
+  for (int r = 0; r < 2; ++r) {
+    if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
+    EXPECT_TRUE(ok[r]);
+  }
+}
+
 TEST(PartitionStitchTest, AServerWithoutEdgesOfATypeStillServes) {
   GraphStore whole, shard[2];
   io::SideInfo einfo;

@@ -277,10 +277,15 @@ class Graph(object):
                             lambda req: pywrap.set_lookup_edges_request(req, src_ids, edge_ids))
 
   def get_stats(self):
-    """Number of nodes / edges held per type (graph.py:1083-1096 in the reference; one store here,
-    so every list has one entry)."""
-    stats = {t: [n] for t, n in self._server.node_counts().items()}
-    stats.update({t: [n] for t, n in self._server.edge_counts().items()})
+    """Number of nodes / edges held per type, one entry per server (graph.py:1083-1093 in the reference):
+    the "GetStats" operator through the client."""
+    req = pywrap.new_get_stats_request()
+    res = pywrap.new_get_stats_response()
+    status = self._client.get_stats(req, res)
+    stats = pywrap.get_stats(res) if status.ok() else None
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
     return stats
 
   def _degrees(self, ids, edge_type, node_from):

@@ -226,6 +226,16 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
              return self.GetDegree(As<GetDegreeRequest>(req, "GetDegreeRequest"), As<GetDegreeResponse>(res, "GetDegreeResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
+      .def("get_stats",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.GetStats(As<GetStatsRequest>(req, "GetStatsRequest"), As<GetStatsResponse>(res, "GetStatsResponse"));
+           },
+           py::call_guard<py::gil_scoped_release>())
+      .def("get_count",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.GetCount(As<GetCountRequest>(req, "GetCountRequest"), As<GetCountResponse>(res, "GetCountResponse"));
+           },
+           py::call_guard<py::gil_scoped_release>())
       .def("get_nodes", [](Client& self, OpRequest* req, OpResponse* res) { return self.RunOp(req, res); })
       .def("get_edges", [](Client& self, OpRequest* req, OpResponse* res) { return self.RunOp(req, res); })
       .def("run_op", &Client::RunOp, py::call_guard<py::gil_scoped_release>());
@@ -393,6 +403,17 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("get_degree", [](OpResponse* res) {
     GetDegreeResponse* r = As<GetDegreeResponse>(res, "GetDegreeResponse");
     return CopyOut(r->GetDegrees(), (size_t)r->batch_size_);
+  });
+
+  // ---- statistics (py_client.cc:452-465; py_wrapper.h get_stats) ----
+  m.def("new_get_stats_request", []() -> OpRequest* { return new GetStatsRequest(); }, py::return_value_policy::reference);
+  m.def("new_get_stats_response", []() -> OpResponse* { return new GetStatsResponse(); }, py::return_value_policy::reference);
+  m.def("get_stats", [](OpResponse* res) { return As<GetStatsResponse>(res, "GetStatsResponse")->GetCounts(); });
+  m.def("new_get_count_request", []() -> OpRequest* { return new GetCountRequest(); }, py::return_value_policy::reference);
+  m.def("new_get_count_response", []() -> OpResponse* { return new GetCountResponse(); }, py::return_value_policy::reference);
+  m.def("get_count", [](OpResponse* res) {
+    GetCountResponse* r = As<GetCountResponse>(res, "GetCountResponse");
+    return CopyOut(r->Count(), (size_t)r->Size());
   });
 
   // ---- loader primitives exposed for the parity tests ----
