@@ -57,7 +57,7 @@ EXPORTS = [
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
     "glx_dist_last_stats",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
-    "glx_probe_bandwidth",
+    "glx_probe_bandwidth", "glx_subgraph_induce",
 ]
 
 
@@ -194,6 +194,7 @@ def lib():
         L.glx_plan_output.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                       ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32)]
         L.glx_plan_destroy.argtypes = [vp]
+        L.glx_subgraph_induce.argtypes = [ci, vp, i32, vp, vp, vp, vp, vp, vp, i64, ctypes.POINTER(i64), ci, vp]
         L.glx_probe_bandwidth.argtypes = [ci, ci, i64, i64, i32, i32, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), vp]
         L.glx_plan_destroy.restype = None
@@ -1045,6 +1046,32 @@ class Plan:
 
 
 KERNEL_SAMPLE, KERNEL_AGGREGATE, KERNEL_LOOKUP = 0, 1, 2
+
+
+i64_t = ctypes.c_int64
+
+
+def subgraph_induce(nodes, offsets, nbr, eid, device=0):
+    """glx_subgraph_induce on FullSampler's response rows of `nodes` -> (row[m] int32, col[m] int32, eid[m] int64);
+    numpy in -> numpy out, torch (device) in -> torch out."""
+    n = int(nodes.shape[0])
+    pn, po, pb, pe = _ptr(nodes), _ptr(offsets), _ptr(nbr), _ptr(eid)
+    kind = _kind(pn, po, pb, pe)
+    total = i64_t()
+    _check(lib().glx_subgraph_induce(device, pn[0], n, po[0], pb[0], pe[0], None, None, None, 0, ctypes.byref(total), kind,
+                                     _stream(kind, device)))
+    m = int(total.value)
+    if _is_torch(nodes):
+        import torch
+        row = torch.empty(m, dtype=torch.int32, device=nodes.device)
+        col = torch.empty(m, dtype=torch.int32, device=nodes.device)
+        out = torch.empty(m, dtype=torch.int64, device=nodes.device)
+    else:
+        row, col, out = np.empty(m, np.int32), np.empty(m, np.int32), np.empty(m, np.int64)
+    if m:
+        _check(lib().glx_subgraph_induce(device, pn[0], n, po[0], pb[0], pe[0], _ptr(row)[0], _ptr(col)[0], _ptr(out)[0], m,
+                                         ctypes.byref(total), kind, _stream(kind, device)))
+    return row, col, out
 
 
 PROBES = {"stream_read": 0, "copy": 1, "triad": 2, "gather32": 3, "gather_rows": 4}

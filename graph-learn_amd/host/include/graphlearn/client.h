@@ -13,6 +13,7 @@
 #include "graphlearn/aggregating_request.h"
 #include "graphlearn/data_source.h"
 #include "graphlearn/graph_request.h"
+#include "graphlearn/subgraph_request.h"
 #include "graphlearn/sampling_request.h"
 #include "graphlearn/status.h"
 
@@ -27,6 +28,7 @@ public:
   Status LookupEdges(const LookupEdgesRequest* request, LookupEdgesResponse* response);
   Status GetDegree(const GetDegreeRequest* request, GetDegreeResponse* response);
   Status GetCount(const GetCountRequest* request, GetCountResponse* response);
+  Status SubGraph(const SubGraphRequest* request, SubGraphResponse* response);
   Status GetStats(const GetStatsRequest* request, GetStatsResponse* response);
   Status RunOp(const OpRequest* request, OpResponse* response);
   Status Stop();

@@ -13,5 +13,6 @@
 #include "graphlearn/partition.h"
 #include "graphlearn/sampling_request.h"
 #include "graphlearn/status.h"
+#include "graphlearn/subgraph_request.h"
 #include "graphlearn/tensor.h"
 #endif

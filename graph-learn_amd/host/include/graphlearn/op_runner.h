@@ -115,6 +115,10 @@ protected:
 // is refused with Unimplemented rather than silently answered from the local shard.
 Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpResponse* res);
 
+// Unshardable requests whose operator fans out sub-requests (SubGraphSampler): served with the sub-requests going
+// through the distributed store.  Returns false when `req` is not of that kind (the caller runs the local operator).
+bool RunWithSubRequests(Env* env, const OpRequest* req, OpResponse* res, Status* status);
+
 // op_runner.h:50-152
 template <class Request, class Response>
 class DistributeRunner : public Runner<Request, Response> {
@@ -122,7 +126,13 @@ public:
   DistributeRunner(Env* env, int32_t local_id, op::Operator* op)
       : Runner<Request, Response>(env, op), local_id_(local_id) {}
   Status Run(const Request* req, Response* res) override {
-    if (!req->IsShardable()) return Runner<Request, Response>::Run(req, res);  // op_runner.h:61-62
+    if (!req->IsShardable()) {  // op_runner.h:61-62: the operator itself runs, here
+      // ... but an operator that issues sub-requests through GetOpRunner(Env::Default(), op) (SubGraphSampler's
+      // FullSampler calls, subgraph_sampler.cc:27-32) must get THIS deployment's runner for them
+      Status s;
+      if (RunWithSubRequests(this->env_, req, res, &s)) return s;
+      return Runner<Request, Response>::Run(req, res);
+    }
     return RunDistributed(this->env_, this->op_, req, res);
   }
 

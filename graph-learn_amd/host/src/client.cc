@@ -33,6 +33,7 @@ Status Client::GetDegree(const GetDegreeRequest* request, GetDegreeResponse* res
 }
 Status Client::GetCount(const GetCountRequest* request, GetCountResponse* response) { return RunOp(request, response); }
 Status Client::GetStats(const GetStatsRequest* request, GetStatsResponse* response) { return RunOp(request, response); }
+Status Client::SubGraph(const SubGraphRequest* request, SubGraphResponse* response) { return RunOp(request, response); }
 Status Client::Stop() { return Status::OK(); }
 
 Client* NewInMemoryClient() { return new Client(); }
@@ -61,6 +62,8 @@ void Server::Init(const std::vector<io::EdgeSource>& edges, const std::vector<io
   status_ = Status::OK();
   IndexOption option;
   option.name = "sort";
+  for (const io::EdgeSource& e : edges) store_->DeclareEdgeType(e.edge_type);  // GraphStore::Init, graph_store.cc:185-208
+  for (const io::NodeSource& n : nodes) store_->DeclareNodeType(n.id_type);
   for (const io::EdgeSource& e : edges) {
     if (!status_.ok()) break;
     status_ = io::LoadEdges(e, store_);

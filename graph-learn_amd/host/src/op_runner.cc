@@ -3,7 +3,10 @@
 // op_runner.cc (GetOpRunner): the sub-requests never exist as host objects -- the C-ABI
 // call buckets the request rows by owner on the GPU, exchanges them over the shard
 // communicator, runs the owner's kernels, exchanges the results back and stitches.
+#include <functional>
+
 #include "graphlearn/op_runner.h"
+#include "graphlearn/subgraph_request.h"
 
 #include <sys/stat.h>
 #include <unistd.h>
@@ -332,6 +335,27 @@ Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpRespon
     return error::FromGlx(rc);
   }
   return error::Unimplemented("request '" + req->Name() + "' is shardable but not served across shards");
+}
+
+// subgraph.cc
+Status RunSubGraph(const SubGraphRequest* request, SubGraphResponse* response, int device,
+                   const std::function<Status(const SamplingRequest*, SamplingResponse*)>& full_sampler);
+
+bool RunWithSubRequests(Env* env, const OpRequest* req, OpResponse* res, Status* status) {
+  auto* sub = dynamic_cast<const SubGraphRequest*>(req);
+  if (!sub) return false;
+  auto* sres = dynamic_cast<SubGraphResponse*>(res);
+  if (!sres || !env || !env->Comm()) {
+    *status = error::InvalidArgument("a SubGraphRequest needs a SubGraphResponse and a communicator");
+    return true;
+  }
+  int device = 0;
+  glx_comm_info(env->Comm(), nullptr, nullptr, &device, nullptr);
+  // COLLECTIVE like every partitioned request: each FullSampler sub-request is one glx_dist_sample_full, so every
+  // server must be serving a sub-graph request with the same number of hops at the same time
+  *status = RunSubGraph(sub, sres, device,
+                        [env](const SamplingRequest* q, SamplingResponse* r) { return RunFullSampling(env, q, r); });
+  return true;
 }
 
 std::unique_ptr<OpRunner> GetOpRunner(Env* env, op::Operator* op) {

@@ -401,5 +401,7 @@ class Graph(object):
       raise ValueError("unknown negative sampling strategy {!r}".format(strategy))
     return cls(self, object_type, expand_factor, strategy=strategy)
 
-  def subgraph_sampler(self, *args, **kwargs):
-    self._off_path("subgraph_sampler")
+  def subgraph_sampler(self, nbr_type, num_nbrs=(0,), need_dist=False):
+    """graph.py:1060-1081 in the reference (without its unused seed_type): a sampler of induced sub-graphs."""
+    from graphlearn import sampler
+    return sampler.SubGraphSampler(self, nbr_type, num_nbrs=num_nbrs, need_dist=need_dist)

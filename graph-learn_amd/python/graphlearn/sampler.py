@@ -199,6 +199,70 @@ class FullNeighborSampler(NeighborSampler):
     return layers
 
 
+class SubGraph(object):
+  """python/data/values.py:819-843: edge_index [2, m] (positions in `nodes`), nodes, edges + free attributes."""
+
+  def __init__(self, edge_index, nodes, edges=None, **kwargs):
+    self._nodes = nodes
+    self._edge_index = edge_index
+    self._edges = edges
+    for key, item in kwargs.items():
+      setattr(self, key, item)
+
+  @property
+  def nodes(self):
+    return self._nodes
+
+  @property
+  def edge_index(self):
+    return self._edge_index
+
+  @property
+  def edges(self):
+    return self._edges
+
+  def __getitem__(self, key):
+    return getattr(self, key, None)
+
+  def __setitem__(self, key, value):
+    setattr(self, key, value)
+
+
+class SubGraphSampler(object):
+  """python/sampler/subgraph_sampler.py:26-104: the seeds' `num_nbrs`-hop neighbourhood (FullSampler with a limit per
+  hop) and the edges of `nbr_type` it induces; need_dist adds every node's distance to the first two nodes."""
+
+  def __init__(self, graph, nbr_type, num_nbrs=(0,), need_dist=False):
+    self._graph = graph
+    self._nbr_type = nbr_type
+    self._num_nbrs = [int(x) for x in num_nbrs]
+    self._need_dist = bool(need_dist)
+    self._node_type = graph.get_topology().get_src_type(nbr_type)
+
+  def get(self, ids, dst_ids=None):
+    ids = np.ascontiguousarray(np.array(ids).reshape(-1), dtype=np.int64)
+    if dst_ids is not None:
+      dst_ids = np.ascontiguousarray(np.array(dst_ids).reshape(-1), dtype=np.int64)
+    req = pywrap.new_subgraph_request(self._nbr_type, self._num_nbrs, self._need_dist)
+    pywrap.set_subgraph_request(req, ids, dst_ids)
+    res = pywrap.new_subgraph_response()
+    status = self._graph.get_client().sample_subgraph(req, res)
+    out = None
+    if status.ok():
+      out = (pywrap.get_node_set(res), pywrap.get_row_idx(res), pywrap.get_col_idx(res), pywrap.get_edge_set(res),
+             pywrap.get_dist_to_src(res) if self._need_dist else None,
+             pywrap.get_dist_to_dst(res) if self._need_dist else None)
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
+    node_ids, row_idx, col_idx, edge_ids, to_src, to_dst = out
+    nodes = self._graph.get_nodes(self._node_type, node_ids)
+    sub = SubGraph(np.stack([row_idx, col_idx], axis=0), nodes, edge_ids)
+    sub.dist_to_src = to_src
+    sub.dist_to_dst = to_dst
+    return sub
+
+
 class NegativeSampler(object):
   """Negative sampling (graphlearn/python/sampler/negative_sampler.py): for every given id,
   `expand_factor` candidate destination ids.  object_type is an edge type ("random",

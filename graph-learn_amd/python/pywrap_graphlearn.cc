@@ -226,6 +226,11 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
              return self.GetDegree(As<GetDegreeRequest>(req, "GetDegreeRequest"), As<GetDegreeResponse>(res, "GetDegreeResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
+      .def("sample_subgraph",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             return self.SubGraph(As<SubGraphRequest>(req, "SubGraphRequest"), As<SubGraphResponse>(res, "SubGraphResponse"));
+           },
+           py::call_guard<py::gil_scoped_release>())
       .def("get_stats",
            [](Client& self, OpRequest* req, OpResponse* res) {
              return self.GetStats(As<GetStatsRequest>(req, "GetStatsRequest"), As<GetStatsResponse>(res, "GetStatsResponse"));
@@ -403,6 +408,48 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("get_degree", [](OpResponse* res) {
     GetDegreeResponse* r = As<GetDegreeResponse>(res, "GetDegreeResponse");
     return CopyOut(r->GetDegrees(), (size_t)r->batch_size_);
+  });
+
+  // ---- sub-graph sampling (py_client.cc:393-449; py_wrapper.h:497-580) ----
+  m.def("new_subgraph_request",
+        [](const std::string& nbr_type, const std::vector<int32_t>& num_nbrs, bool need_dist) -> OpRequest* {
+          return new SubGraphRequest(nbr_type, num_nbrs, need_dist);
+        },
+        py::return_value_policy::reference);
+  m.def("new_subgraph_response", []() -> OpResponse* { return new SubGraphResponse(); }, py::return_value_policy::reference);
+  m.def("set_subgraph_request", [](OpRequest* req, I64Array src_ids, py::object dst_ids) {
+    SubGraphRequest* r = As<SubGraphRequest>(req, "SubGraphRequest");
+    if (dst_ids.is_none()) {
+      r->Set(src_ids.data(), (int32_t)src_ids.size());
+    } else {
+      I64Array dst = dst_ids.cast<I64Array>();
+      if (dst.size() != src_ids.size()) throw std::invalid_argument("src_ids and dst_ids must have the same size");
+      r->Set(src_ids.data(), dst.data(), (int32_t)src_ids.size());
+    }
+  });
+  m.def("get_node_set", [](OpResponse* res) {
+    SubGraphResponse* r = As<SubGraphResponse>(res, "SubGraphResponse");
+    return CopyOut(r->NodeIds(), (size_t)r->NodeCount());
+  });
+  m.def("get_row_idx", [](OpResponse* res) {
+    SubGraphResponse* r = As<SubGraphResponse>(res, "SubGraphResponse");
+    return CopyOut(r->RowIndices(), (size_t)r->EdgeCount());
+  });
+  m.def("get_col_idx", [](OpResponse* res) {
+    SubGraphResponse* r = As<SubGraphResponse>(res, "SubGraphResponse");
+    return CopyOut(r->ColIndices(), (size_t)r->EdgeCount());
+  });
+  m.def("get_edge_set", [](OpResponse* res) {
+    SubGraphResponse* r = As<SubGraphResponse>(res, "SubGraphResponse");
+    return CopyOut(r->EdgeIds(), (size_t)r->EdgeCount());
+  });
+  m.def("get_dist_to_src", [](OpResponse* res) {
+    SubGraphResponse* r = As<SubGraphResponse>(res, "SubGraphResponse");
+    return CopyOut(r->DistToSrc(), (size_t)r->NodeCount());
+  });
+  m.def("get_dist_to_dst", [](OpResponse* res) {
+    SubGraphResponse* r = As<SubGraphResponse>(res, "SubGraphResponse");
+    return CopyOut(r->DistToDst(), (size_t)r->NodeCount());
   });
 
   // ---- statistics (py_client.cc:452-465; py_wrapper.h get_stats) ----

@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 /* 1: graph / features / samplers / aggregators / partition helpers.  2 (additions only): host registration, shard
- * communicator, distributed store (+ replicas), request plans.  3 (additions only): memory-system probes. */
+ * communicator, distributed store (+ replicas), request plans.  3 (additions only): memory-system probes,
+ * induced sub-graph, conditional negative sampling. */
 #define GLX_ABI_VERSION 3
 
 /* Exported symbols: libglx.so is built with -fvisibility=hidden. */
@@ -605,6 +606,18 @@ GLX_API void glx_plan_destroy(glx_plan* p);
 #define GLX_KERNEL_LOOKUP 2
 GLX_API int glx_profile_enable(int on);
 GLX_API int glx_profile_collect(int kind, float* ms_out, int32_t cap, int32_t* count);
+
+/* ---- induced sub-graph: replaces SubGraphSampler::InduceSubGraph (core/operator/subgraph/subgraph_sampler.cc:34-95).
+ * nodes[n] is the sub-graph's node list (SubGraphSampler::Process, subgraph_sampler.h:36-78: the seeds, then the sorted set
+ * of every neighbour the hop-wise FullSampler calls returned -- duplicates between the two parts are kept, as in the
+ * reference); offsets[n + 1] / nbr / eid are FullSampler's response for `nodes` with limit GLOBAL_FLAG(DefaultFullNbrNum)
+ * (glx_sample_full, or glx_dist_sample_full across shards).  For every node i, in order, and every j in list order whose
+ * id is among row i's neighbours, the entries (i, j, e) and (j, i, e) are appended, e = the edge id of the LAST slot of row
+ * i holding that neighbour (node2edge[nbrs[k]] = edge_ids[k], :60-64).  *count_out (host) = the number of entries, 2 per
+ * match; at most `capacity` are written (capacity 0: count only).  The call returns when the outputs are valid. */
+GLX_API int glx_subgraph_induce(int device, const int64_t* nodes, int32_t n, const int64_t* offsets, const int64_t* nbr,
+                                const int64_t* eid, int32_t* row_out, int32_t* col_out, int64_t* eid_out, int64_t capacity,
+                                int64_t* count_out, int ptr_kind, void* stream);
 
 /* ---- memory-system probes: the measured ceilings the kernels above are priced against -- an addition of this
  * engine with no counterpart in the reference (its PROFILING timers, common/base/profiling.h:24-71, time scopes; they

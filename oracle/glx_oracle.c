@@ -884,3 +884,65 @@ void glxo_sort_rows_by_timestamp_asc(const int64_t* row_ptr, int64_t V, int64_t*
     }
   }
 }
+
+/* ------------------------------------------------------------- sub-graph -- */
+/* SubGraphSampler::InduceSubGraph (subgraph/subgraph_sampler.cc:34-95) on FullSampler's response rows of `nodes`
+ * (offsets[n + 1], nbr, eid): for node i a map neighbour id -> edge id where a later slot overwrites an earlier one
+ * (:60-64); then for every j in list order with nodes[j] in the map: AppendEdge(i, j, eid), AppendEdge(j, i, eid)
+ * (:66-70).  Returns the number of entries (2 per match); writes the first `cap`. */
+int64_t glxo_subgraph_induce(const int64_t* nodes, int32_t n, const int64_t* offsets, const int64_t* nbr, const int64_t* eid,
+                             int32_t* row_out, int32_t* col_out, int64_t* eid_out, int64_t cap) {
+  int64_t total = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const int64_t o0 = offsets[i], deg = offsets[i + 1] - o0;
+    for (int32_t j = 0; j < n; ++j) {
+      int64_t found = -1;
+      for (int64_t k = 0; k < deg; ++k) {
+        if (nbr[o0 + k] == nodes[j]) found = k; /* the last slot wins, as node2edge[nbrs[k]] = edge_ids[k] does */
+      }
+      if (found < 0) continue;
+      if (total + 1 < cap) {
+        row_out[total] = i; col_out[total] = j; eid_out[total] = eid[o0 + found];
+        row_out[total + 1] = j; col_out[total + 1] = i; eid_out[total + 1] = eid[o0 + found];
+      }
+      total += 2;
+    }
+  }
+  return total;
+}
+
+/* BFSShortestPath (subgraph/subgraph_utils.cc:36-57) over the induced edges with node `skip` removed; unreachable =
+ * INT32_MAX.  dist_out[n]. */
+static void bfs_without(int32_t n, const int32_t* row, const int32_t* col, int64_t m, int32_t skip, int32_t start,
+                        int32_t* dist_out) {
+  int32_t* queue = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  for (int32_t i = 0; i < n; ++i) dist_out[i] = INT32_MAX;
+  int32_t head = 0, tail = 0;
+  dist_out[start] = 0;
+  queue[tail++] = start;
+  while (head < tail) {
+    const int32_t s = queue[head++];
+    for (int64_t e = 0; e < m; ++e) {
+      if (row[e] != s || row[e] == skip || col[e] == skip) continue;
+      if (dist_out[col[e]] == INT32_MAX && col[e] != start) {
+        dist_out[col[e]] = dist_out[s] + 1;
+        queue[tail++] = col[e];
+      }
+    }
+  }
+  free(queue);
+}
+
+/* The need_dist half of InduceSubGraph (:71-93): src = node 0, dst = node 1; dist_to_dst = BFS from dst in the
+ * graph without src (then dist_to_dst[src] = 0), dist_to_src = BFS from src without dst (dist_to_src[dst] = 0). */
+void glxo_subgraph_dist(int32_t n, const int32_t* row, const int32_t* col, int64_t m, int32_t* dist_to_src,
+                        int32_t* dist_to_dst) {
+  if (n < 2) {
+    for (int32_t i = 0; i < n; ++i) { dist_to_src[i] = 0; dist_to_dst[i] = 0; }
+    return;
+  }
+  bfs_without(n, row, col, m, /*skip=*/0, /*start=*/1, dist_to_dst);
+  bfs_without(n, row, col, m, /*skip=*/1, /*start=*/0, dist_to_src);
+  dist_to_dst[0] = 0;
+  dist_to_src[1] = 0;
+}

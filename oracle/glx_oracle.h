@@ -200,6 +200,13 @@ int glxo_aggregate_stitch(int op, int32_t P, const float* parts, const int32_t* 
 void glxo_stitch_i64(const int64_t* shard_major, const int64_t* order, int64_t n, int32_t width,
                      int64_t* out);
 
+/* Restates SubGraphSampler::InduceSubGraph (subgraph/subgraph_sampler.cc:34-95) on FullSampler's response rows and
+ * its need_dist labelling (:71-93, subgraph_utils.cc:36-57). */
+int64_t glxo_subgraph_induce(const int64_t* nodes, int32_t n, const int64_t* offsets, const int64_t* nbr, const int64_t* eid,
+                             int32_t* row_out, int32_t* col_out, int64_t* eid_out, int64_t cap);
+void glxo_subgraph_dist(int32_t n, const int32_t* row, const int32_t* col, int64_t m, int32_t* dist_to_src,
+                        int32_t* dist_to_dst);
+
 #ifdef __cplusplus
 }
 #endif

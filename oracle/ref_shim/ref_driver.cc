@@ -35,6 +35,7 @@
 #include "include/config.h"
 #include "include/index_option.h"
 #include "include/random_walk_request.h"
+#include "include/subgraph_request.h"
 #include "include/sampling_request.h"
 
 namespace std {
@@ -420,6 +421,40 @@ int glref_random_walk(void* h, const char* edge_type, const int64_t* src, int32_
     memcpy(walks_out, res.GetWalks(), sizeof(int64_t) * static_cast<size_t>(batch) * walk_len);
   });
   return rc;
+}
+
+// The reference's SubGraphSampler (core/operator/subgraph/subgraph_sampler.{h,cc}): seeds -> per hop FullSampler with
+// limit num_nbrs[h] -> nodes = seeds + sorted set of all sampled neighbours -> InduceSubGraph with limit
+// DefaultFullNbrNum.  Outputs: nodes_out[cap_nodes], row/col/eid_out[cap_edges], dist_*_out[cap_nodes] (need_dist).
+// sizes_out = {node count, edge count}; returns 0, -1 (unknown op) or the reference's error code.
+int glref_subgraph(void* h, const char* nbr_type, const int64_t* src, int32_t batch, const int32_t* num_nbrs, int32_t hops,
+                   int need_dist, int32_t full_nbr_num, int64_t* nodes_out, int64_t cap_nodes, int32_t* row_out,
+                   int32_t* col_out, int64_t* eid_out, int64_t cap_edges, int32_t* dist_src_out, int32_t* dist_dst_out,
+                   int64_t* sizes_out) {
+  (void)h;
+  SetGlobalFlagDefaultFullNbrNum(full_nbr_num);
+  SubGraphRequest req(nbr_type, std::vector<int32_t>(num_nbrs, num_nbrs + hops), need_dist != 0);
+  req.Set(src, batch);
+  SubGraphResponse res;
+  op::Operator* op = op::OpFactory::GetInstance()->Create("SubGraphSampler");
+  if (!op) return -1;
+  Status s = op->Process(&req, &res);
+  if (!s.ok()) return static_cast<int>(s.code());
+  sizes_out[0] = res.NodeCount();
+  sizes_out[1] = res.EdgeCount();
+  for (int64_t i = 0; i < res.NodeCount() && i < cap_nodes; ++i) {
+    nodes_out[i] = res.NodeIds()[i];
+    if (need_dist) {
+      dist_src_out[i] = res.DistToSrc()[i];
+      dist_dst_out[i] = res.DistToDst()[i];
+    }
+  }
+  for (int64_t i = 0; i < res.EdgeCount() && i < cap_edges; ++i) {
+    row_out[i] = res.RowIndices()[i];
+    col_out[i] = res.ColIndices()[i];
+    eid_out[i] = res.EdgeIds()[i];
+  }
+  return 0;
 }
 
 // GraphStorage::GetInDegree (memory_topo_storage.cc:103-109, topo_statics.cc:62-69).

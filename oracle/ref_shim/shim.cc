@@ -231,8 +231,24 @@ public:
     return error::Unimplemented("oracle shim");                                    \
   }
   UNSUPPORTED(UpdateNodes)
-  UNSUPPORTED(LookupNodes)
 #undef UNSUPPORTED
+  // LocalNoder::LookupNodes (core/graph/local_noder.cc:85-97), which ConditionalNegativeSampler reaches through
+  // GetNodeAttributesWrapper -> "LookupNodes" (get_node_attributes_wrapper.cc:45-63).
+  Status LookupNodes(const LookupNodesRequest* req, LookupNodesResponse* res) override {
+    int64_t node_id = 0;
+    LookupNodesRequest* request = const_cast<LookupNodesRequest*>(req);
+    res->SetSideInfo(storage_->GetSideInfo(), req->Size());
+    while (request->Next(&node_id)) {
+      res->AppendWeight(storage_->GetWeight(node_id));
+      res->AppendLabel(storage_->GetLabel(node_id));
+      res->AppendTimestamp(storage_->GetTimestamp(node_id));
+      res->AppendAttribute(storage_->GetAttribute(node_id).get());
+    }
+    return Status::OK();
+  }
+  Status LookupNodes(int32_t, const LookupNodesRequest*, LookupNodesResponse*) override {
+    return error::Unimplemented("oracle shim");
+  }
 private:
   io::NodeStorage* storage_;
 };

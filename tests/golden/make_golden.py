@@ -567,6 +567,45 @@ def gen_walk(ref):
     np.savez_compressed(os.path.join(OUT_DIR, "walk.npz"), **out)
 
 
+def gen_subgraph(ref):
+    """The reference's SubGraphSampler (core/operator/subgraph/subgraph_sampler.{h,cc}) on a small weighted graph with
+    multi-edges (the later slot's edge id wins, :60-64) and duplicate seeds.  One-hop and zero-hop requests only: with
+    two or more hops the reference feeds hop h+1 from the already destroyed response of hop h (subgraph_sampler.h:52-68:
+    `nodes = res.GetNeighborIds()` outlives `res`), i.e. its output is undefined there."""
+    rng = np.random.default_rng(77)
+    V = 60
+    src, dst = [], []
+    for v in range(V):
+        for d in rng.choice(V, int(rng.integers(0, 12)), replace=True):  # replace=True: multi-edges
+            src.append(v)
+            dst.append(int(d))
+    src, dst = np.array(src, np.int64), np.array(dst, np.int64)
+    w = (rng.random(src.shape[0]) + 0.05).astype(np.float32)
+    ref.add_edges("sub", src, dst, w)
+    rows = first_appearance(src)
+    rp, col, eid, ws = ref.export_csr("sub", rows, 16)
+    out = dict(src=src, dst=dst, w=w, rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws)
+    ref.set_flags(1, 0, 0.0)
+    cases = []
+    for name, seeds, nn, full, dist in (
+            ("hop1", [3, 17, 40, 41], [4], 100, False),
+            ("hop1_limit3", [3, 17, 40, 41], [4], 3, False),
+            ("hop0", [5, 6, 7, 8, 9, 10], [0], 100, False),
+            ("dup_seeds", [3, 3, 17], [2], 100, False),
+            ("pair_dist", [3, 17], [5], 100, True),
+            ("pair_dist_far", [0, 59], [3], 100, True),
+            ("unknown_seed", [3, 1000], [4], 100, False)):
+        r = ref.subgraph("sub", np.array(seeds, np.int64), nn, full_nbr_num=full, need_dist=dist)
+        out[name + "_seeds"] = np.array(seeds, np.int64)
+        out[name + "_num_nbrs"] = np.array(nn, np.int32)
+        out[name + "_full"] = np.array(full)
+        for k, v in r.items():
+            out[name + "_" + k] = v
+        cases.append(name)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT_DIR, "subgraph.npz"), **out)
+
+
 def generate():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -581,6 +620,7 @@ def generate():
     gen_timestamped(ref)
     gen_filtered(ref)
     gen_walk(ref)
+    gen_subgraph(ref)
     ref.close()
 
 

@@ -77,7 +77,39 @@ class Oracle:
         L.glxo_sample_full_filtered.argtypes = [ctypes.POINTER(_CGraph), VP, i32, i32, ctypes.c_int, i64,
                                                 ctypes.POINTER(_CFilter), VP, VP, VP, i64]
         L.glxo_sample_full_filtered.restype = i64
+        L.glxo_subgraph_induce.argtypes = [VP, i32, VP, VP, VP, VP, VP, VP, i64]
+        L.glxo_subgraph_induce.restype = i64
+        L.glxo_subgraph_dist.argtypes = [i32, VP, VP, i64, VP, VP]
         self.L = L
+
+    def subgraph_induce(self, nodes, offsets, nbr, eid):
+        """InduceSubGraph on FullSampler's rows of `nodes` -> (row[m], col[m], eid[m])."""
+        n = nodes.shape[0]
+        m = self.L.glxo_subgraph_induce(_p(nodes), n, _p(offsets), _p(nbr), _p(eid), None, None, None, 0)
+        row, col, e = np.zeros(m, np.int32), np.zeros(m, np.int32), np.zeros(m, np.int64)
+        self.L.glxo_subgraph_induce(_p(nodes), n, _p(offsets), _p(nbr), _p(eid), _p(row), _p(col), _p(e), m)
+        return row, col, e
+
+    def subgraph(self, g, seeds, num_nbrs, full_nbr_num=100, need_dist=False):
+        """SubGraphSampler::Process (subgraph_sampler.h:36-78) -> dict(nodes, row, col, eid[, dist_src, dist_dst])."""
+        nodes = np.ascontiguousarray(seeds, np.int64)
+        cur, found = nodes, set()
+        for k in num_nbrs:
+            if k > 0:
+                _, nb, _ = self.sample_full(g, np.ascontiguousarray(cur), k)
+                cur = nb
+                found.update(int(x) for x in nb)
+        nodes = np.concatenate([nodes, np.array(sorted(found), np.int64)]) if found else nodes
+        deg, nb, ed = self.sample_full(g, nodes, full_nbr_num)
+        off = np.zeros(nodes.shape[0] + 1, np.int64)
+        off[1:] = np.cumsum(deg)
+        row, col, e = self.subgraph_induce(nodes, off, nb, ed)
+        out = dict(nodes=nodes, row=row, col=col, eid=e)
+        if need_dist:
+            ds, dd = np.zeros(nodes.shape[0], np.int32), np.zeros(nodes.shape[0], np.int32)
+            self.L.glxo_subgraph_dist(nodes.shape[0], _p(row), _p(col), row.shape[0], _p(ds), _p(dd))
+            out.update(dist_src=ds, dist_dst=dd)
+        return out
 
     def philox(self, ctr, key):
         c = np.asarray(ctr, np.uint32)
@@ -296,6 +328,7 @@ class RefLib:
         L.glref_hash64.restype = ctypes.c_uint64
         L.glref_parse_attribute.argtypes = [ctypes.c_char_p, i64, cs, VP, VP, i32, i32, VP, VP, VP, VP, ctypes.c_char_p,
                                             i64, VP]
+        L.glref_subgraph.argtypes = [VP, cs, VP, i32, VP, i32, ctypes.c_int, i32, VP, i64, VP, VP, VP, i64, VP, VP, VP]
         L.glref_sample_full.argtypes = [VP, cs, VP, i32, i32, VP, VP, VP, i64]
         L.glref_sample_full.restype = i64
         L.glref_in_degree.argtypes = [VP, cs, i64]
@@ -369,6 +402,25 @@ class RefLib:
                                          _p(eid), cap)
         assert 0 <= total <= cap, total
         return deg, nbr[:total].copy(), eid[:total].copy()
+
+    def subgraph(self, nbr_type, seeds, num_nbrs, full_nbr_num=100, need_dist=False, cap_nodes=1 << 14, cap_edges=1 << 20):
+        """The reference's SubGraphSampler operator -> dict(nodes, row, col, eid[, dist_src, dist_dst])."""
+        seeds = np.ascontiguousarray(seeds, np.int64)
+        nn = np.ascontiguousarray(num_nbrs, np.int32)
+        nodes = np.zeros(cap_nodes, np.int64)
+        row, col, eid = np.zeros(cap_edges, np.int32), np.zeros(cap_edges, np.int32), np.zeros(cap_edges, np.int64)
+        ds, dd = np.zeros(cap_nodes, np.int32), np.zeros(cap_nodes, np.int32)
+        sizes = np.zeros(2, np.int64)
+        rc = self.L.glref_subgraph(self.h, nbr_type.encode(), _p(seeds), seeds.shape[0], _p(nn), nn.shape[0],
+                                   1 if need_dist else 0, full_nbr_num, _p(nodes), cap_nodes, _p(row), _p(col), _p(eid),
+                                   cap_edges, _p(ds), _p(dd), _p(sizes))
+        assert rc == 0, rc
+        n, m = int(sizes[0]), int(sizes[1])
+        assert n <= cap_nodes and m <= cap_edges
+        out = dict(nodes=nodes[:n].copy(), row=row[:m].copy(), col=col[:m].copy(), eid=eid[:m].copy())
+        if need_dist:
+            out.update(dist_src=ds[:n].copy(), dist_dst=dd[:n].copy())
+        return out
 
     def sample_filtered(self, etype, strategy, src, k, flt, fresh_thread=True):
         """flt: dict(type, field, values, retry_times=5); values may be shorter than the batch

@@ -488,8 +488,44 @@ def test_get_stats(gl, g):
     stats = g.get_stats()
     assert stats[NODE1] == [100] and stats[NODE2] == [100] and stats["entity"] == [120]
     assert stats[EDGE2] == [len(fx.fixed_dst_ids(range(*RANGE2), RANGE1))]
-    assert stats[EDGE3] == [2 * len(fx.fixed_dst_ids(range(*RANGE2), RANGE2))]  # directed=False on a homogeneous type
+    # directed=False on a homogeneous type: both directions live in ONE storage (2 E records) AND the type is declared by
+    # two sources, which BuildLocalCount multiplies in once more (graph_store.cc:196-201, 305-311): 4 E, as the reference
+    assert stats[EDGE3] == [4 * len(fx.fixed_dst_ids(range(*RANGE2), RANGE2))]
+    assert stats[EDGE1] == stats[EDGE1 + "_reverse"] == [len(fx.fixed_dst_ids(range(*RANGE1), RANGE2))]
     assert stats["MASK*node1"] == [50]
+
+
+def test_subgraph_sampler_through_the_python_api(gl, g):
+    """Graph.subgraph_sampler -> "SubGraphSampler" (subgraph_sampler.{h,cc}) on the relation edges i -> i+2, i+3, i+5
+    (both directions in one storage: directed=False): node set = seeds + sorted neighbour set, edges = every ordered
+    pair of listed nodes joined by a relation edge, reported in both directions; distances as the SEAL labelling."""
+    gl.set_default_full_nbr_num(100)
+    seeds = np.array([10, 13])
+    sub = g.subgraph_sampler("relation", num_nbrs=[6], need_dist=True).get(seeds)
+    nbrs_of = lambda v: [x for d in (2, 3, 5) for x in (v + d, v - d) if 0 <= x < 120]  # noqa: E731
+    want_nodes = list(seeds) + sorted(set(x for v in seeds for x in nbrs_of(v)))
+    np.testing.assert_equal(sub.nodes.ids, want_nodes)
+    idx = sub.edge_index
+    assert idx.shape[0] == 2 and idx.shape[1] % 2 == 0
+    pairs = set()
+    for i, u in enumerate(want_nodes):
+        for j, v in enumerate(want_nodes):
+            if abs(int(u) - int(v)) in (2, 3, 5):
+                pairs.add((i, j))
+    got = set(zip(idx[0].tolist(), idx[1].tolist()))
+    assert got == pairs
+    # entries come in (i, j), (j, i) pairs sharing the edge id
+    assert np.array_equal(idx[0][0::2], idx[1][1::2]) and np.array_equal(idx[1][0::2], idx[0][1::2])
+    assert np.array_equal(sub.edges[0::2], sub.edges[1::2])
+    assert sub.dist_to_src[0] == 0 and sub.dist_to_dst[1] == 0 and sub.dist_to_src[1] == 0 and sub.dist_to_dst[0] == 0
+    # 10 and 13 are joined directly (|d| = 3); every listed neighbour of 13 is one step from it
+    for j, v in enumerate(want_nodes[2:], start=2):
+        if abs(int(v) - 13) in (2, 3, 5):
+            assert sub.dist_to_dst[j] == 1
+    # zero hops: the seeds and the edges among them
+    sub0 = g.subgraph_sampler("relation").get(np.array([20, 22, 40]))
+    np.testing.assert_equal(sub0.nodes.ids, [20, 22, 40])
+    assert set(zip(sub0.edge_index[0].tolist(), sub0.edge_index[1].tolist())) == {(0, 1), (1, 0)}
 
 
 def test_in_and_out_degree_lookups(gl, g):

@@ -58,3 +58,65 @@ def test_probes_report_plausible_bandwidth():
     assert 100 < w["gbps"] < 8000
     with pytest.raises(glx.GlxError):
         glx.probe_bandwidth("gather_rows", 1 << 30, units=1 << 20, unit_bytes=1000)
+
+
+# ---- SubGraphSampler::InduceSubGraph on the device (glx_subgraph_induce, subgraph_sampler.cc:34-95) ------------------
+import os as _os  # noqa: E402
+
+SUB = dict(np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "subgraph.npz")))
+
+
+def _gold_graph():
+    return glx.Graph(SUB["row_ptr"], SUB["col"], SUB["eid"], SUB["w_slot"], ids=SUB["rows"])
+
+
+@pytest.mark.parametrize("case", [str(c) for c in SUB["cases"]])
+@pytest.mark.parametrize("kind", ["host", "device"])
+def test_subgraph_pipeline_equals_the_reference_golden(case, kind):
+    """FullSampler per hop + sorted set + FullSampler(DefaultFullNbrNum) + glx_subgraph_induce == the reference's own
+    SubGraphSampler output (tests/golden/subgraph.npz), entry for entry."""
+    g = _gold_graph()
+    seeds = SUB[case + "_seeds"]
+    frontier, found = seeds, set()
+    for k in SUB[case + "_num_nbrs"]:
+        if k > 0:
+            _, nb, _ = g.sample_full(np.ascontiguousarray(frontier), int(k))
+            frontier = nb
+            found.update(int(x) for x in nb)
+    nodes = np.concatenate([seeds, np.array(sorted(found), np.int64)]) if found else seeds
+    assert np.array_equal(nodes, SUB[case + "_nodes"])
+    deg, nb, ed = g.sample_full(nodes, int(SUB[case + "_full"]))
+    off = np.zeros(nodes.shape[0] + 1, np.int64)
+    off[1:] = np.cumsum(deg)
+    if kind == "device":
+        row, col, eid = glx.subgraph_induce(*(torch.from_numpy(x).cuda() for x in (nodes, off, nb, ed)))
+        row, col, eid = row.cpu().numpy(), col.cpu().numpy(), eid.cpu().numpy()
+    else:
+        row, col, eid = glx.subgraph_induce(nodes, off, nb, ed)
+    assert np.array_equal(row, SUB[case + "_row"]) and np.array_equal(col, SUB[case + "_col"])
+    assert np.array_equal(eid, SUB[case + "_eid"])
+
+
+def test_subgraph_induce_fuzz_equals_oracle():
+    rng = np.random.default_rng(11)
+    orc = Oracle()
+    for trial in range(30):
+        n = int(rng.integers(1, 400))
+        ids_hi = int(rng.choice([n // 2 + 1, n * 4]))  # dense (many matches, duplicate nodes) or sparse
+        nodes = rng.integers(-3, ids_hi, n).astype(np.int64)
+        deg = rng.integers(0, 40, n)
+        if trial % 5 == 0:
+            deg[:] = 0
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum(deg)
+        nbr = rng.integers(-3, ids_hi, int(off[-1])).astype(np.int64)  # multi-edges: repeated neighbour ids
+        eid = rng.integers(0, 1 << 40, int(off[-1])).astype(np.int64)
+        want = orc.subgraph_induce(nodes, off, nbr, eid)
+        got = glx.subgraph_induce(nodes, off, nbr, eid)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), trial
+        gd = glx.subgraph_induce(*(torch.from_numpy(x).cuda() for x in (nodes, off, nbr, eid)))
+        for a, b in zip(want, gd):
+            assert np.array_equal(a, b.cpu().numpy()), trial
+    r, c, e = glx.subgraph_induce(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64))
+    assert r.size == 0 and c.size == 0 and e.size == 0
