@@ -946,3 +946,195 @@ void glxo_subgraph_dist(int32_t n, const int32_t* row, const int32_t* col, int64
   dist_to_dst[0] = 0;
   dist_to_src[1] = 0;
 }
+
+/* ------------------------------------------- ConditionalNegativeSampler -- */
+/* core/operator/sampler/conditional_negative_sampler.cc:37-161 over condition_table.cc:65-148 and
+ * attribute_nodes_map.h:74-127, under the glx seeding contract.
+ *
+ * Candidates ids[U] with weights[U] (NULL = 1.0f each: the "random" strategy's ConditionTable has no weights and its
+ * default AliasMethod(ids.Size()) is built over ones, alias_method.cc:36-39).  Column c of the condition table groups
+ * the candidates by cand_keys[c * U + u] (the attribute value as an int64 key: an int attribute, a float's bits, a
+ * string's dictionary id); every group has its own alias table over the members' weights (CreateAM).  Request row i
+ * carries dst_keys[i * ncols + c] (GLXO_NO_KEY matches no group: "when there is no this attr at all, just skip").
+ *
+ * The exclusion set lives ACROSS the rows of a request (nbr_set is declared before the row loop and never cleared,
+ * conditional_negative_sampler.cc:105-123): batch_share = all dst ids up front; otherwise row i adds src i's neighbours
+ * and dst i before it samples.  unique also adds every accepted id.
+ *
+ * Per row, per column c: num_c = (int32)(count * props[c]); AttributeNodesMap::Sample draws blocks of num_c alias
+ * indices, at most `retry` blocks, walks a block in order and accepts what is not in the set -- but its loop condition
+ * re-tests retry_times > 0 after the LAST block has been drawn, so of block `retry` only the first entry is looked at
+ * (attribute_nodes_map.h:109-125).  Draw d of row i is word d of the stream (seed, call_counter, i); column c, block b,
+ * position j is draw retry * (num_0 + .. + num_{c-1}) + b * num_c + j.
+ *
+ * The reference then means to fill the row up to `count` from the default alias table (:128-152), but computes how many
+ * it has from the STATIC response shape (res->GetShape().size - idx * num = (batch - idx) * num >= num), so that loop
+ * never runs and a row that came up short leaves the response tensor short and misaligned.  Like the out-of-bounds read
+ * of SURVEY 8(a).3 this is not reproduced: the fill loop runs as written -- blocks of `count` default draws starting at
+ * draw retry * (num_0 + ..); retry + 1 blocks against the set, then the set is dropped for good (nbr_set.clear(), :140)
+ * and up to two more blocks are taken; whatever is still missing is default_neighbor_id.  Where the reference's response
+ * is complete (every column found its num_c and they add up to count) the two agree in distribution. */
+typedef struct { int64_t* keys; uint8_t* used; uint64_t mask; } i64set;
+static void i64set_init(i64set* s, uint64_t cap_hint) {
+  uint64_t cap = 16;
+  while (cap < 2 * cap_hint + 2) cap <<= 1;
+  s->keys = (int64_t*)malloc(sizeof(int64_t) * cap);
+  s->used = (uint8_t*)calloc(cap, 1);
+  s->mask = cap - 1;
+}
+static void i64set_clear(i64set* s) { memset(s->used, 0, (size_t)(s->mask + 1)); }
+static void i64set_free(i64set* s) { free(s->keys); free(s->used); }
+static int i64set_has(const i64set* s, int64_t v) {
+  uint64_t h = mix64((uint64_t)v) & s->mask;
+  while (s->used[h]) {
+    if (s->keys[h] == v) return 1;
+    h = (h + 1) & s->mask;
+  }
+  return 0;
+}
+static void i64set_add(i64set* s, int64_t v) {
+  uint64_t h = mix64((uint64_t)v) & s->mask;
+  while (s->used[h]) {
+    if (s->keys[h] == v) return;
+    h = (h + 1) & s->mask;
+  }
+  s->used[h] = 1;
+  s->keys[h] = v;
+}
+
+typedef struct { int64_t key; int64_t pos; } keypos;
+static int cmp_keypos(const void* a, const void* b) {
+  const keypos* x = (const keypos*)a; const keypos* y = (const keypos*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);
+}
+
+static int32_t alias_draw(uint64_t u, int64_t n, const float* prob, const int32_t* alias) {
+  /* AliasMethod::Sample (alias_method.cc:117-121) */
+  double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(n - 1);
+  float rnd = (float)rd;
+  int32_t k = (int32_t)rnd;
+  return (prob[k] <= (rnd - k)) ? alias[k] : k;
+}
+
+int glxo_cond_negative_sample(const int64_t* ids, const float* weights, int64_t U, int32_t ncols, const int64_t* cand_keys,
+                              const float* props, const glxo_graph* g, const int64_t* src, const int64_t* dst,
+                              const int64_t* dst_keys, int32_t batch, int32_t count, int batch_share, int unique,
+                              int32_t retry, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                              int64_t* out, int32_t* filled_by_columns_out) {
+  if (batch <= 0 || count <= 0) return 0;
+  int32_t* stack = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(U > 0 ? U : 1)); /* low / high stacks of Build */
+  /* condition table: per column, members sorted by (key, candidate position); groups = runs of equal keys */
+  keypos** order = (keypos**)malloc(sizeof(keypos*) * (size_t)(ncols > 0 ? ncols : 1));
+  float** gprob = (float**)malloc(sizeof(float*) * (size_t)(ncols > 0 ? ncols : 1));
+  int32_t** galias = (int32_t**)malloc(sizeof(int32_t*) * (size_t)(ncols > 0 ? ncols : 1));
+  for (int32_t c = 0; c < ncols; ++c) {
+    order[c] = (keypos*)malloc(sizeof(keypos) * (size_t)(U > 0 ? U : 1));
+    gprob[c] = (float*)malloc(sizeof(float) * (size_t)(U > 0 ? U : 1));
+    galias[c] = (int32_t*)malloc(sizeof(int32_t) * (size_t)(U > 0 ? U : 1));
+    for (int64_t u = 0; u < U; ++u) { order[c][u].key = cand_keys[(int64_t)c * U + u]; order[c][u].pos = u; }
+    qsort(order[c], (size_t)U, sizeof(keypos), cmp_keypos);
+    float* w = (float*)malloc(sizeof(float) * (size_t)(U > 0 ? U : 1));
+    for (int64_t a = 0; a < U;) {
+      int64_t b = a;
+      while (b < U && order[c][b].key == order[c][a].key) ++b;
+      for (int64_t t = a; t < b; ++t) w[t - a] = weights ? weights[order[c][t].pos] : 1.0f;
+      alias_build_row(w, (int32_t)(b - a), gprob[c] + a, galias[c] + a, stack, stack + U);
+      a = b;
+    }
+    free(w);
+  }
+  /* default alias table over all candidates */
+  float* dprob = (float*)malloc(sizeof(float) * (size_t)(U > 0 ? U : 1));
+  int32_t* dalias = (int32_t*)malloc(sizeof(int32_t) * (size_t)(U > 0 ? U : 1));
+  {
+    float* w = (float*)malloc(sizeof(float) * (size_t)(U > 0 ? U : 1));
+    for (int64_t u = 0; u < U; ++u) w[u] = weights ? weights[u] : 1.0f;
+    if (U > 0) alias_build_row(w, (int32_t)U, dprob, dalias, stack, stack + U);
+    free(w);
+  }
+  idmap m;
+  if (g && g->ids) idmap_build(&m, g->ids, g->V);
+  uint64_t cap = (uint64_t)batch * (uint64_t)(count + 1);
+  if (g) {
+    for (int32_t i = 0; i < batch; ++i) {
+      int64_t row = row_of(g->ids, &m, g->V, src[i]);
+      if (row >= 0) cap += (uint64_t)(g->row_ptr[row + 1] - g->row_ptr[row]);
+    }
+  }
+  i64set S;
+  i64set_init(&S, cap);
+  if (batch_share) for (int32_t i = 0; i < batch; ++i) i64set_add(&S, dst[i]);
+  int32_t* num_c = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ncols > 0 ? ncols : 1));
+  for (int32_t i = 0; i < batch; ++i) {
+    if (!batch_share) {
+      if (g) {
+        int64_t row = row_of(g->ids, &m, g->V, src[i]);
+        if (row >= 0) for (int64_t e = g->row_ptr[row]; e < g->row_ptr[row + 1]; ++e) i64set_add(&S, g->col[e]);
+      }
+      i64set_add(&S, dst[i]);
+    }
+    int64_t* orow = out + (int64_t)i * count;
+    int32_t taken = 0;
+    uint32_t base = 0;
+    for (int32_t c = 0; c < ncols; ++c) {
+      const int32_t n = (int32_t)((float)count * props[c]);
+      num_c[c] = n;
+      if (n <= 0) continue;
+      /* the group of this row's key */
+      const int64_t key = dst_keys[(int64_t)i * ncols + c];
+      int64_t a = -1, b = -1;
+      if (key != GLXO_NO_KEY) {
+        int64_t lo = 0, hi = U;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (order[c][mid].key < key) lo = mid + 1; else hi = mid; }
+        if (lo < U && order[c][lo].key == key) { a = lo; b = lo; while (b < U && order[c][b].key == key) ++b; }
+      }
+      if (a >= 0) {
+        int32_t got = 0;
+        for (int32_t blk = 0; blk < retry && got < n; ++blk) {
+          const int32_t look = (blk == retry - 1) ? 1 : n; /* the last block: its first entry only */
+          for (int32_t j = 0; j < look && got < n; ++j) {
+            uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, base + (uint32_t)(blk * n + j));
+            int32_t ix = alias_draw(u, b - a, gprob[c] + a, galias[c] + a);
+            int64_t item = ids[order[c][a + ix].pos];
+            if (!i64set_has(&S, item)) {
+              if (taken < count) orow[taken] = item;
+              ++taken; ++got;
+              if (unique) i64set_add(&S, item);
+            }
+          }
+        }
+      }
+      base += (uint32_t)retry * (uint32_t)n;
+    }
+    if (taken > count) taken = count; /* props adding up to more than 1: the row is cut at count */
+    if (filled_by_columns_out) filled_by_columns_out[i] = taken; /* == count: the reference's response row is complete too */
+    /* default sampling (:128-152, as written) */
+    if (U > 0) {
+      int32_t retry_times = retry + 1, blk = 0;
+      int last = 0;
+      while (taken < count && !last) {
+        if (--retry_times <= 0) i64set_clear(&S);
+        if (retry_times < 0) last = 1; /* the loop condition fails after the first entry of this block */
+        const int32_t look = last ? 1 : count;
+        for (int32_t j = 0; j < look && taken < count; ++j) {
+          uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, base + (uint32_t)(blk * count + j));
+          int64_t item = ids[alias_draw(u, U, dprob, dalias)];
+          if (!i64set_has(&S, item)) {
+            orow[taken++] = item;
+            if (unique) i64set_add(&S, item);
+          }
+        }
+        ++blk;
+      }
+    }
+    for (; taken < count; ++taken) orow[taken] = default_neighbor_id;
+  }
+  free(num_c);
+  i64set_free(&S);
+  if (g && g->ids) idmap_free(&m);
+  free(dprob); free(dalias); free(stack);
+  for (int32_t c = 0; c < ncols; ++c) { free(order[c]); free(gprob[c]); free(galias[c]); }
+  free(order); free(gprob); free(galias);
+  return 0;
+}

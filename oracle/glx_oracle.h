@@ -200,6 +200,16 @@ int glxo_aggregate_stitch(int op, int32_t P, const float* parts, const int32_t* 
 void glxo_stitch_i64(const int64_t* shard_major, const int64_t* order, int64_t n, int32_t width,
                      int64_t* out);
 
+/* Restates ConditionalNegativeSampler (conditional_negative_sampler.cc:37-161, condition_table.cc:65-148,
+ * attribute_nodes_map.h:74-127) under the seeding contract; see the comment above its definition for the layout of the
+ * keys, the draw numbering and the one deliberate divergence (the reference's dead fill loop runs here).  out[batch * count]. */
+#define GLXO_NO_KEY INT64_MIN
+int glxo_cond_negative_sample(const int64_t* ids, const float* weights, int64_t U, int32_t ncols, const int64_t* cand_keys,
+                              const float* props, const glxo_graph* g, const int64_t* src, const int64_t* dst,
+                              const int64_t* dst_keys, int32_t batch, int32_t count, int batch_share, int unique,
+                              int32_t retry, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                              int64_t* out, int32_t* filled_by_columns_out /* [batch] or NULL: ids the condition columns gave */);
+
 /* Restates SubGraphSampler::InduceSubGraph (subgraph/subgraph_sampler.cc:34-95) on FullSampler's response rows and
  * its need_dist labelling (:71-93, subgraph_utils.cc:36-57). */
 int64_t glxo_subgraph_induce(const int64_t* nodes, int32_t n, const int64_t* offsets, const int64_t* nbr, const int64_t* eid,

@@ -423,6 +423,68 @@ int glref_random_walk(void* h, const char* edge_type, const int64_t* src, int32_
   return rc;
 }
 
+// Nodes with a weight and int / float / string attributes (the node type ConditionalNegativeSampler looks its conditions
+// up in).  int_attrs[n * I], float_attrs[n * F]; the strings of all nodes back to back in `strs` with lengths str_len[n * S].
+int glref_add_attr_nodes(void* h, const char* node_type, const int64_t* ids, const float* weights, const int64_t* int_attrs,
+                         int32_t I, const float* float_attrs, int32_t F, const char* strs, const int32_t* str_len, int32_t S,
+                         int64_t n) {
+  Ref* r = static_cast<Ref*>(h);
+  io::NodeStorage* st = r->store->GetNoder(node_type)->GetLocalStorage();
+  io::SideInfo info;
+  info.format = io::kAttributed | (weights ? io::kWeighted : 0);
+  info.i_num = I;
+  info.f_num = F;
+  info.s_num = S;
+  info.type = node_type;
+  st->SetSideInfo(&info);
+  io::NodeValue v;
+  const char* cur = strs;
+  for (int64_t i = 0; i < n; ++i) {
+    v.id = ids[i];
+    v.weight = weights ? weights[i] : 0.0f;
+    v.attrs->Clear();
+    if (I > 0) v.attrs->Add(int_attrs + i * I, I);
+    if (F > 0) v.attrs->Add(float_attrs + i * F, F);
+    for (int32_t k = 0; k < S; ++k) {
+      v.attrs->Add(cur, str_len[i * S + k]);
+      cur += str_len[i * S + k];
+    }
+    st->Add(&v);
+  }
+  return 0;
+}
+
+// The reference's ConditionalNegativeSampler (conditional_negative_sampler.cc) on a ConditionalSamplingRequest built with
+// its own constructor + SetIds + SetSelectedCols.  The condition tables and default alias tables are cached per `type`
+// by the reference's factories: use a fresh type name per configuration.  out[cap]; *n_out = ids in the response (the
+// reference's fill loop never runs, so this may be less than batch * count).  Returns 0 or the error code.
+int glref_cond_neg_sample(void* h, const char* type, const char* strategy, const char* dst_node_type, const int64_t* src,
+                          const int64_t* dst, int32_t batch, int32_t count, int batch_share, int unique,
+                          const int32_t* int_cols, const float* int_props, int32_t n_int, const int32_t* float_cols,
+                          const float* float_props, int32_t n_float, const int32_t* str_cols, const float* str_props,
+                          int32_t n_str, int32_t retry_times, int64_t* out, int64_t cap, int64_t* n_out, int fresh_thread) {
+  (void)h;
+  int rc = 0;
+  SetGlobalFlagSamplingRetryTimes(retry_times);
+  RunMaybeFresh(fresh_thread, [&]() {
+    ConditionalSamplingRequest req(type, strategy, count, dst_node_type, batch_share != 0, unique != 0);
+    req.SetIds(src, dst, batch);
+    req.SetSelectedCols(std::vector<int32_t>(int_cols, int_cols + n_int), std::vector<float>(int_props, int_props + n_int),
+                        std::vector<int32_t>(float_cols, float_cols + n_float),
+                        std::vector<float>(float_props, float_props + n_float),
+                        std::vector<int32_t>(str_cols, str_cols + n_str), std::vector<float>(str_props, str_props + n_str));
+    SamplingResponse res;
+    op::Operator* op = op::OpFactory::GetInstance()->Create("ConditionalNegativeSampler");
+    if (!op) { rc = -1; return; }
+    Status s = op->Process(&req, &res);
+    if (!s.ok()) { rc = static_cast<int>(s.code()); return; }
+    const int64_t n = res.tensors_[kNodeIds].Size();
+    *n_out = n;
+    for (int64_t i = 0; i < n && i < cap; ++i) out[i] = res.GetNeighborIds()[i];
+  });
+  return rc;
+}
+
 // The reference's SubGraphSampler (core/operator/subgraph/subgraph_sampler.{h,cc}): seeds -> per hop FullSampler with
 // limit num_nbrs[h] -> nodes = seeds + sorted set of all sampled neighbours -> InduceSubGraph with limit
 // DefaultFullNbrNum.  Outputs: nodes_out[cap_nodes], row/col/eid_out[cap_edges], dist_*_out[cap_nodes] (need_dist).

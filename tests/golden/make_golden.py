@@ -606,6 +606,72 @@ def gen_subgraph(ref):
     np.savez_compressed(os.path.join(OUT_DIR, "subgraph.npz"), **out)
 
 
+COND_CASES = (  # name, strategy, batch_share, unique
+    ("random", "random", False, False), ("random_unique", "random", False, True), ("random_share", "random", True, False),
+    ("in_degree", "in_degree", False, False), ("node_weight", "node_weight", False, True))
+
+
+def cond_fixture():
+    """The graph the conditional negative sampling fixtures share: 120 item nodes (int attribute id % 4, float attribute
+    (id % 3) / 2, string attribute "A" / "B" by id parity, node weights), 80 users buying 4 items each (the candidates
+    of the edge-type strategies are the items somebody bought, in first-appearance order: GetAllDstIds)."""
+    rng = np.random.default_rng(2024)
+    U = 120
+    items = np.arange(100, 100 + U, dtype=np.int64)
+    w = (rng.random(U) + 0.1).astype(np.float32)
+    src, dst = [], []
+    for u in range(80):
+        for d in rng.choice(items, 4, replace=False):
+            src.append(u)
+            dst.append(int(d))
+    src, dst = np.array(src, np.int64), np.array(dst, np.int64)
+    req_src = np.arange(4, dtype=np.int64)
+    req_dst = np.array([dst[4 * u] for u in range(4)], np.int64)
+    return dict(items=items, item_w=w, int_attr=(items % 4).astype(np.int64), float_attr=((items % 3) * 0.5).astype(np.float32),
+                str_attr=np.array([b"A" if i % 2 == 0 else b"B" for i in items]), src=src, dst=dst, req_src=req_src,
+                req_dst=req_dst, count=np.array(8), int_props=np.array([0.5], np.float32),
+                float_props=np.array([0.25], np.float32), str_props=np.array([0.25], np.float32))
+
+
+def gen_cond_negative(ref):
+    """The reference's ConditionalNegativeSampler (conditional_negative_sampler.cc, condition_table.cc,
+    attribute_nodes_map.h): per case T requests with fresh pinned seeds; counts[row, slot, candidate] of the ids its
+    response holds.  Groups are large and exclusions few, so every response is complete (asserted): the reference's dead
+    fill loop is not exercised."""
+    fx = cond_fixture()
+    ref.add_attr_nodes("item", fx["items"], weights=fx["item_w"], int_attrs=fx["int_attr"].reshape(-1, 1),
+                       float_attrs=fx["float_attr"].reshape(-1, 1), str_attrs=[[bytes(x)] for x in fx["str_attr"]])
+    out = dict(fx)
+    T = 3000
+    ref.set_flags(1, 0, 0.0)
+    count = int(fx["count"])
+    for name, strategy, share, unique in COND_CASES:
+        etype = "buy_" + name  # the reference caches its condition tables per type name
+        if strategy != "node_weight":
+            ref.add_edges(etype, fx["src"], fx["dst"], None)
+        else:
+            etype = "item"
+        counts = np.zeros((fx["req_src"].shape[0], count, fx["items"].shape[0]), np.int32)
+        skipped = 0
+        for t in range(T):
+            ref.set_seed(1000 + t)
+            ids = ref.cond_neg_sample(etype, strategy, "item", fx["req_src"], fx["req_dst"], count, int_cols=[0],
+                                      int_props=fx["int_props"], float_cols=[0], float_props=fx["float_props"], str_cols=[0],
+                                      str_props=fx["str_props"], batch_share=share, unique=unique)
+            if ids.shape[0] != fx["req_src"].shape[0] * count:
+                skipped += 1  # a column came up short: the reference's response is misaligned (its fill loop is dead code)
+                continue
+            ix = ids.reshape(-1, count) - 100
+            for r in range(ix.shape[0]):
+                counts[r, np.arange(count), ix[r]] += 1
+        assert skipped <= T // 20, (name, skipped)
+        out[name + "_counts"] = counts
+        out[name + "_trials"] = np.array(T - skipped)
+    out["T"] = np.array(T)
+    ref.set_seed(0)
+    np.savez_compressed(os.path.join(OUT_DIR, "cond_negative.npz"), **out)
+
+
 def generate():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -621,6 +687,7 @@ def generate():
     gen_filtered(ref)
     gen_walk(ref)
     gen_subgraph(ref)
+    gen_cond_negative(ref)
     ref.close()
 
 

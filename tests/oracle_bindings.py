@@ -77,10 +77,34 @@ class Oracle:
         L.glxo_sample_full_filtered.argtypes = [ctypes.POINTER(_CGraph), VP, i32, i32, ctypes.c_int, i64,
                                                 ctypes.POINTER(_CFilter), VP, VP, VP, i64]
         L.glxo_sample_full_filtered.restype = i64
+        L.glxo_cond_negative_sample.argtypes = [VP, VP, i64, i32, VP, VP, ctypes.POINTER(_CGraph), VP, VP, VP, i32, i32,
+                                                ctypes.c_int, ctypes.c_int, i32, i64, u64, u64, VP, VP]
         L.glxo_subgraph_induce.argtypes = [VP, i32, VP, VP, VP, VP, VP, VP, i64]
         L.glxo_subgraph_induce.restype = i64
         L.glxo_subgraph_dist.argtypes = [i32, VP, VP, i64, VP, VP]
         self.L = L
+
+    def cond_negative_sample(self, ids, weights, cand_keys, props, g, src, dst, dst_keys, count, batch_share=False,
+                             unique=False, retry=5, default_neighbor_id=0, seed=0, call_counter=0, with_filled=False):
+        """ConditionalNegativeSampler under the contract.  cand_keys [ncols, U] int64, dst_keys [batch, ncols] int64
+        (NO_KEY = matches nothing), props [ncols] float32 -> out [batch, count]."""
+        ids = np.ascontiguousarray(ids, np.int64)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        ck = np.ascontiguousarray(cand_keys, np.int64).reshape(-1, ids.shape[0])
+        ncols = ck.shape[0]
+        pr = np.ascontiguousarray(props, np.float32)
+        src = np.ascontiguousarray(src, np.int64)
+        dst = np.ascontiguousarray(dst, np.int64)
+        dk = np.ascontiguousarray(dst_keys, np.int64).reshape(src.shape[0], ncols)
+        out = np.zeros((src.shape[0], count), np.int64)
+        filled = np.zeros(src.shape[0], np.int32)
+        cg = self._cgraph(g) if g is not None else None
+        rc = self.L.glxo_cond_negative_sample(_p(ids), _p(w), ids.shape[0], ncols, _p(ck), _p(pr),
+                                              ctypes.byref(cg) if cg is not None else None, _p(src), _p(dst), _p(dk),
+                                              src.shape[0], count, int(batch_share), int(unique), retry, default_neighbor_id,
+                                              seed, call_counter, _p(out), _p(filled))
+        assert rc == 0, rc
+        return (out, filled) if with_filled else out
 
     def subgraph_induce(self, nodes, offsets, nbr, eid):
         """InduceSubGraph on FullSampler's rows of `nodes` -> (row[m], col[m], eid[m])."""
@@ -328,6 +352,9 @@ class RefLib:
         L.glref_hash64.restype = ctypes.c_uint64
         L.glref_parse_attribute.argtypes = [ctypes.c_char_p, i64, cs, VP, VP, i32, i32, VP, VP, VP, VP, ctypes.c_char_p,
                                             i64, VP]
+        L.glref_add_attr_nodes.argtypes = [VP, cs, VP, VP, VP, i32, VP, i32, ctypes.c_char_p, VP, i32, i64]
+        L.glref_cond_neg_sample.argtypes = [VP, cs, cs, cs, VP, VP, i32, i32, ctypes.c_int, ctypes.c_int, VP, VP, i32, VP, VP,
+                                            i32, VP, VP, i32, i32, VP, i64, VP, ctypes.c_int]
         L.glref_subgraph.argtypes = [VP, cs, VP, i32, VP, i32, ctypes.c_int, i32, VP, i64, VP, VP, VP, i64, VP, VP, VP]
         L.glref_sample_full.argtypes = [VP, cs, VP, i32, i32, VP, VP, VP, i64]
         L.glref_sample_full.restype = i64
@@ -402,6 +429,40 @@ class RefLib:
                                          _p(eid), cap)
         assert 0 <= total <= cap, total
         return deg, nbr[:total].copy(), eid[:total].copy()
+
+    def add_attr_nodes(self, ntype, ids, weights=None, int_attrs=None, float_attrs=None, str_attrs=None):
+        """int_attrs [n, I] int64, float_attrs [n, F] float32, str_attrs: list of n lists of S byte strings."""
+        ids = np.ascontiguousarray(ids, np.int64)
+        n = ids.shape[0]
+        ia = None if int_attrs is None else np.ascontiguousarray(int_attrs, np.int64).reshape(n, -1)
+        fa = None if float_attrs is None else np.ascontiguousarray(float_attrs, np.float32).reshape(n, -1)
+        S = len(str_attrs[0]) if str_attrs else 0
+        blob = b"".join(x for row in (str_attrs or []) for x in row)
+        lens = np.array([len(x) for row in (str_attrs or []) for x in row], np.int32)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        self.L.glref_add_attr_nodes(self.h, ntype.encode(), _p(ids), _p(w), _p(ia), 0 if ia is None else ia.shape[1], _p(fa),
+                                    0 if fa is None else fa.shape[1], blob, _p(lens), S, n)
+        self.L.glref_build_nodes(self.h, ntype.encode())
+
+    def cond_neg_sample(self, etype, strategy, dst_node_type, src, dst, count, int_cols=(), int_props=(), float_cols=(),
+                        float_props=(), str_cols=(), str_props=(), batch_share=False, unique=False, retry=5,
+                        fresh_thread=True):
+        """The reference's ConditionalNegativeSampler -> flat array of the ids its response holds (may be shorter
+        than batch * count: its fill loop never runs)."""
+        src = np.ascontiguousarray(src, np.int64)
+        dst = np.ascontiguousarray(dst, np.int64)
+        cap = src.shape[0] * count + 16
+        out = np.zeros(cap, np.int64)
+        n = ctypes.c_int64()
+        a = lambda x, t: np.ascontiguousarray(x, t)  # noqa: E731
+        ic, ip, fc, fp, sc, sp = (a(int_cols, np.int32), a(int_props, np.float32), a(float_cols, np.int32),
+                                  a(float_props, np.float32), a(str_cols, np.int32), a(str_props, np.float32))
+        rc = self.L.glref_cond_neg_sample(self.h, etype.encode(), strategy.encode(), dst_node_type.encode(), _p(src), _p(dst),
+                                          src.shape[0], count, int(batch_share), int(unique), _p(ic), _p(ip), ic.shape[0],
+                                          _p(fc), _p(fp), fc.shape[0], _p(sc), _p(sp), sc.shape[0], retry, _p(out), cap,
+                                          ctypes.byref(n), 1 if fresh_thread else 0)
+        assert rc == 0, rc
+        return out[:n.value].copy()
 
     def subgraph(self, nbr_type, seeds, num_nbrs, full_nbr_num=100, need_dist=False, cap_nodes=1 << 14, cap_edges=1 << 20):
         """The reference's SubGraphSampler operator -> dict(nodes, row, col, eid[, dist_src, dist_dst])."""
