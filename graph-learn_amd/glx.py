@@ -58,6 +58,7 @@ EXPORTS = [
     "glx_dist_last_stats",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
     "glx_probe_bandwidth", "glx_subgraph_induce",
+    "glx_cond_table_create", "glx_cond_table_destroy", "glx_cond_negative_sample",
 ]
 
 
@@ -194,6 +195,10 @@ def lib():
         L.glx_plan_output.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                       ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32)]
         L.glx_plan_destroy.argtypes = [vp]
+        L.glx_cond_table_create.argtypes = [ci, i64, vp, vp, i32, vp, ci, vp, ctypes.POINTER(vp)]
+        L.glx_cond_table_destroy.argtypes = [vp]
+        L.glx_cond_table_destroy.restype = None
+        L.glx_cond_negative_sample.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, ci, ci, i32, i64, u64, u64, vp, ci, vp]
         L.glx_subgraph_induce.argtypes = [ci, vp, i32, vp, vp, vp, vp, vp, vp, i64, ctypes.POINTER(i64), ci, vp]
         L.glx_probe_bandwidth.argtypes = [ci, ci, i64, i64, i32, i32, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), vp]
@@ -1049,6 +1054,47 @@ KERNEL_SAMPLE, KERNEL_AGGREGATE, KERNEL_LOOKUP = 0, 1, 2
 
 
 i64_t = ctypes.c_int64
+NO_KEY = -(1 << 63)  # a dst key that matches no group
+
+
+class CondTable:
+    """glx_cond_table: ids [U], weights [U] | None, cand_keys [ncols, U] int64 (numpy or torch-on-device)."""
+
+    def __init__(self, ids, weights, cand_keys, device=0):
+        self.device = device
+        self.num_ids = int(ids.shape[0])
+        self.num_cols = 0 if cand_keys is None else int(cand_keys.reshape(-1, max(self.num_ids, 1)).shape[0]) if self.num_ids else 0
+        pi, pw, pk = _ptr(ids), _ptr(weights), _ptr(cand_keys)
+        kind = _kind(pi, pw, pk)
+        h = ctypes.c_void_p()
+        _check(lib().glx_cond_table_create(device, self.num_ids, pi[0], pw[0], self.num_cols, pk[0], kind, _stream(kind, device),
+                                           ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().glx_cond_table_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def sample(self, graph, src, dst, dst_keys, props, count, batch_share=False, unique=False, retry=5,
+               default_neighbor_id=0, seed=0, call_counter=0):
+        """-> out [batch, count] int64 (numpy in -> numpy out, torch in -> torch out)."""
+        batch = int(src.shape[0])
+        if _is_torch(src):
+            import torch
+            out = torch.empty((batch, count), dtype=torch.int64, device=src.device)
+        else:
+            out = np.empty((batch, count), np.int64)
+        props = np.ascontiguousarray(props, np.float32)
+        ps, pd, pk, po = _ptr(src), _ptr(dst), _ptr(dst_keys), _ptr(out)
+        kind = _kind(ps, pd, pk, po)
+        _check(lib().glx_cond_negative_sample(self._h, graph._h if graph is not None else None, ps[0], pd[0], pk[0],
+                                              ctypes.c_void_p(props.ctypes.data), batch, count, int(batch_share), int(unique),
+                                              retry, default_neighbor_id, seed, call_counter, po[0], kind,
+                                              _stream(kind, self.device)))
+        return out
 
 
 def subgraph_induce(nodes, offsets, nbr, eid, device=0):

@@ -607,6 +607,33 @@ GLX_API void glx_plan_destroy(glx_plan* p);
 GLX_API int glx_profile_enable(int on);
 GLX_API int glx_profile_collect(int kind, float* ms_out, int32_t cap, int32_t* count);
 
+/* ---- conditional negative sampling: replaces ConditionalNegativeSampler (core/operator/sampler/
+ * conditional_negative_sampler.cc:37-161) with its ConditionTable (condition_table.cc:65-148) and AttributeNodesMap
+ * (attribute_nodes_map.h:74-127). ----------------------------------------------------------------------------
+ * glx_cond_table_create: the candidates ids[num_ids] (the edge type's destination ids in first-appearance order, or a
+ *   node type's ids: StorageWrapper::GetIds) with weights[num_ids] (in-degrees / node weights; NULL = 1 each, the
+ *   "random" strategy) and, per selected attribute column c, the candidates' attribute values as int64 keys
+ *   cand_keys[c * num_ids + u] (an int attribute itself, a float's bit pattern with -0 folded onto +0, a string's
+ *   dictionary index: equal keys <=> equal attribute values).  Groups candidates by key per column and builds one alias
+ *   table per group plus the default table over all candidates -- the reference's lazily built, per-type cached
+ *   ConditionTable + AliasMethod pair -- on the device.
+ * glx_cond_negative_sample: out[batch * count].  Row i is sampled AFTER rows 0..i-1: the exclusion set grows through the
+ *   request (all dst ids up front when batch_share; else the neighbours of src i in `g` -- may be NULL -- and dst i are
+ *   added before row i samples; `unique` also adds every accepted id) exactly as the reference's nbr_set does.  Per
+ *   column c the row takes (int32)(count * props[c]) ids from the group whose key is dst_keys[i * num_cols + c]
+ *   (INT64_MIN: no such group) with AttributeNodesMap::Sample's retry schedule (retry_times = GLOBAL_FLAG(
+ *   SamplingRetryTimes)); the rest of the row comes from the default table, then default_neighbor_id.  props is a HOST
+ *   array of num_cols floats; the other pointers follow ptr_kind.  Draws: stream (seed, call_counter, i); the layout is
+ *   spelled out in DESIGN.md section 5.  The call returns when `out` is valid. */
+typedef struct glx_cond_table glx_cond_table;
+GLX_API int glx_cond_table_create(int device, int64_t num_ids, const int64_t* ids, const float* weights, int32_t num_cols,
+                                  const int64_t* cand_keys, int ptr_kind, void* stream, glx_cond_table** out);
+GLX_API void glx_cond_table_destroy(glx_cond_table* t);
+GLX_API int glx_cond_negative_sample(const glx_cond_table* t, const glx_graph* g, const int64_t* src, const int64_t* dst,
+                                     const int64_t* dst_keys, const float* props, int32_t batch, int32_t count,
+                                     int batch_share, int unique, int32_t retry_times, int64_t default_neighbor_id,
+                                     uint64_t seed, uint64_t call_counter, int64_t* out, int ptr_kind, void* stream);
+
 /* ---- induced sub-graph: replaces SubGraphSampler::InduceSubGraph (core/operator/subgraph/subgraph_sampler.cc:34-95).
  * nodes[n] is the sub-graph's node list (SubGraphSampler::Process, subgraph_sampler.h:36-78: the seeds, then the sorted set
  * of every neighbour the hop-wise FullSampler calls returned -- duplicates between the two parts are kept, as in the

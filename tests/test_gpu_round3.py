@@ -120,3 +120,78 @@ def test_subgraph_induce_fuzz_equals_oracle():
             assert np.array_equal(a, b.cpu().numpy()), trial
     r, c, e = glx.subgraph_induce(np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64))
     assert r.size == 0 and c.size == 0 and e.size == 0
+
+
+# ---- ConditionalNegativeSampler on the device (glx_cond_*; conditional_negative_sampler.cc:37-161) ------------------
+def _cond_case(rng, U, ncols, n_users, deg, batch, hashed_ids):
+    items = (rng.permutation(U * 3)[:U] + 1000).astype(np.int64) if hashed_ids else np.arange(U, dtype=np.int64)
+    weights = (rng.random(U) + 0.05).astype(np.float32)
+    keys = np.stack([rng.integers(0, int(rng.integers(1, 6)), U) for _ in range(ncols)]).astype(np.int64) if ncols else \
+        np.zeros((0, U), np.int64)
+    src, dst = [], []
+    for u in range(n_users):
+        for d in rng.choice(items, deg, replace=True):
+            src.append(u)
+            dst.append(int(d))
+    src, dst = np.array(src, np.int64), np.array(dst, np.int64)
+    rp = np.zeros(n_users + 1, np.int64)
+    np.add.at(rp, src + 1, 1)
+    rp = np.cumsum(rp)
+    req_src = rng.integers(-1, n_users + 2, batch).astype(np.int64)  # some unknown sources
+    req_dst = rng.choice(items, batch).astype(np.int64)
+    dk = np.zeros((batch, ncols), np.int64)
+    pos = {int(v): i for i, v in enumerate(items)}
+    for i, d in enumerate(req_dst):
+        for c in range(ncols):
+            dk[i, c] = keys[c, pos[int(d)]] if rng.random() > 0.1 else glx.NO_KEY  # some rows without a matching group
+    return items, weights, keys, dict(row_ptr=rp, col=dst, eid=np.arange(dst.shape[0], dtype=np.int64)), req_src, req_dst, dk
+
+
+@pytest.mark.parametrize("trial", range(12))
+def test_conditional_negative_sampler_is_bit_identical_to_the_oracle(trial):
+    rng = np.random.default_rng(100 + trial)
+    U = int(rng.choice([1, 2, 7, 60, 300]))
+    ncols = int(rng.integers(0, 4))
+    batch = int(rng.choice([1, 5, 40, 130]))
+    count = int(rng.choice([1, 4, 9, 70]))
+    items, w, keys, og, req_src, req_dst, dk = _cond_case(rng, U, ncols, 12, int(rng.integers(0, 9)), batch, trial % 2 == 1)
+    props = (rng.dirichlet(np.ones(ncols + 1))[:ncols] if ncols else np.zeros(0)).astype(np.float32)
+    weights = None if trial % 3 == 0 else w
+    share, unique, retry = bool(trial & 1), bool(trial & 2), int(rng.choice([1, 2, 5]))
+    orc = Oracle()
+    want = orc.cond_negative_sample(items, weights, keys, props, og, req_src, req_dst, dk, count, batch_share=share,
+                                    unique=unique, retry=retry, default_neighbor_id=-7, seed=5, call_counter=trial)
+    g = glx.Graph(og["row_ptr"], og["col"], og["eid"])
+    tab = glx.CondTable(items, weights, keys if ncols else None)
+    got = tab.sample(g, req_src, req_dst, dk if ncols else None, props, count, batch_share=share, unique=unique, retry=retry,
+                     default_neighbor_id=-7, seed=5, call_counter=trial)
+    assert np.array_equal(got, want), trial
+    # device pointers
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    tab_d = glx.CondTable(T(items), None if weights is None else T(weights), T(keys) if ncols else None)
+    got_d = tab_d.sample(g, T(req_src), T(req_dst), T(dk) if ncols else None, props, count, batch_share=share, unique=unique,
+                         retry=retry, default_neighbor_id=-7, seed=5, call_counter=trial)
+    assert np.array_equal(got_d.cpu().numpy(), want), trial
+    # without a graph (node_weight strategy: no neighbour exclusion)
+    want_n = orc.cond_negative_sample(items, weights, keys, props, None, req_src, req_dst, dk, count, batch_share=share,
+                                      unique=unique, retry=retry, seed=6, call_counter=trial)
+    got_n = tab.sample(None, req_src, req_dst, dk if ncols else None, props, count, batch_share=share, unique=unique,
+                       retry=retry, seed=6, call_counter=trial)
+    assert np.array_equal(got_n, want_n), trial
+
+
+def test_conditional_negative_sampler_on_the_reference_fixture_matches_oracle():
+    """The fixture the oracle is pinned to the reference on (tests/golden/cond_negative.npz): device == oracle there too."""
+    G = dict(np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "cond_negative.npz")))
+    from test_oracle_cond_negative import setup
+    for strategy, share, unique in (("random", False, False), ("in_degree", False, True), ("node_weight", True, True)):
+        cand, w, keys, dk, og, _ = setup(strategy)
+        props = np.concatenate([G["int_props"], G["float_props"], G["str_props"]])
+        g = glx.Graph(og["row_ptr"], og["col"], og["eid"]) if og is not None else None
+        tab = glx.CondTable(cand, w, keys)
+        for cc in range(20):
+            want = Oracle().cond_negative_sample(cand, w, keys, props, og, G["req_src"], G["req_dst"], dk, int(G["count"]),
+                                                 batch_share=share, unique=unique, seed=9, call_counter=cc)
+            got = tab.sample(g, G["req_src"], G["req_dst"], dk, props, int(G["count"]), batch_share=share, unique=unique,
+                             seed=9, call_counter=cc)
+            assert np.array_equal(got, want), (strategy, cc)
