@@ -83,6 +83,12 @@ public:
   // Device-resident distributed stores of one edge / node type, created on first use.
   Status EdgeStore(const std::string& edge_type, glx_dist_store** out);
   Status NodeStore(const std::string& node_type, glx_dist_store** out);
+  // A distributed store keeps per-call state (request / receive arenas, exchange counters, halo slots) and every
+  // partitioned request is a sequence of collectives: two requests of one server must not interleave, and all
+  // servers must issue their requests in the same order.  The runners hold this lock for the whole request, so the
+  // pool threads of one server (the reference runs operators from up to 32, in_memory_service.cc:64-71) take turns;
+  // the order across servers is the caller's contract (SPMD: INTEGRATION.md).
+  std::mutex& RunMutex() { return run_mtx_; }
   uint64_t NextCallCounter() { return call_counter_.fetch_add(1, std::memory_order_relaxed); }
   // `count` consecutive values at once (a walk consumes one per step); returns the first
   uint64_t NextCallCounters(uint64_t count) { return call_counter_.fetch_add(count ? count : 1, std::memory_order_relaxed); }
@@ -92,6 +98,7 @@ private:
   GraphStore* store_;
   int32_t server_id_, server_count_;
   std::mutex mtx_;
+  std::mutex run_mtx_;
   std::unordered_map<std::string, glx_dist_store*> edge_stores_, node_stores_;
   std::unordered_map<std::string, glx_graph*> graph_replicas_;  // built by ReplicateHotRows
   std::atomic<uint64_t> call_counter_{0};

@@ -71,6 +71,35 @@ private:
   FilterField filter_field_;
 };
 
+// ConditionalSamplingRequest (include/sampling_request.h:152-202, service/request/conditional_sampling_request.cc) for
+// "ConditionalNegativeSampler": negatives for (src, dst) pairs that share selected attributes with the dst
+// (conditional_negative_sampler.cc:37-161).  `type` is an edge type (strategies "random", "in_degree") or a node type
+// ("node_weight"); dst_node_type is the node type the condition attributes are looked up in.
+class ConditionalSamplingRequest : public SamplingRequest {
+public:
+  ConditionalSamplingRequest();
+  ConditionalSamplingRequest(const std::string& type, const std::string& strategy, int32_t neighbor_count,
+                             const std::string& dst_node_type, bool batch_share, bool unique);
+  OpRequest* Clone() const override;
+  void SetIds(const int64_t* src_ids, const int64_t* dst_ids, int32_t batch_size);
+  void SetSelectedCols(const std::vector<int32_t>& int_cols, const std::vector<float>& int_props,
+                       const std::vector<int32_t>& float_cols, const std::vector<float>& float_props,
+                       const std::vector<int32_t>& str_cols, const std::vector<float>& str_props);
+  // The sampling strategy of the DEFAULT table ("random" / "in_degree" / "node_weight"); the operator's registry
+  // name ("ConditionalNegativeSampler") is what OpRequest::Name() returns.
+  const std::string& Strategy() const;
+  const std::string& DstNodeType() const;
+  bool BatchShare() const;
+  bool Unique() const;
+  const int64_t* GetDstIds() const;
+  std::vector<int32_t> IntCols() const;
+  std::vector<float> IntProps() const;
+  std::vector<int32_t> FloatCols() const;
+  std::vector<float> FloatProps() const;
+  std::vector<int32_t> StrCols() const;
+  std::vector<float> StrProps() const;
+};
+
 class SamplingResponse : public OpResponse {
 public:
   SamplingResponse();

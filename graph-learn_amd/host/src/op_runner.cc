@@ -292,6 +292,7 @@ Status RunAggregating(Env* env, const AggregatingRequest* req, AggregatingRespon
 Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpResponse* res) {
   (void)op;  // the owner's Process() is the kernel behind the distributed store
   if (!env || !env->Comm() || !env->Store()) return error::InvalidArgument("the runner has no communicator / store");
+  std::lock_guard<std::mutex> one_request_at_a_time(env->RunMutex());
   if (auto* sreq = dynamic_cast<const SamplingRequest*>(req)) {
     auto* sres = dynamic_cast<SamplingResponse*>(res);
     if (!sres) return error::InvalidArgument("a SamplingRequest needs a SamplingResponse");
@@ -351,6 +352,7 @@ bool RunWithSubRequests(Env* env, const OpRequest* req, OpResponse* res, Status*
   }
   int device = 0;
   glx_comm_info(env->Comm(), nullptr, nullptr, &device, nullptr);
+  std::lock_guard<std::mutex> one_request_at_a_time(env->RunMutex());
   // COLLECTIVE like every partitioned request: each FullSampler sub-request is one glx_dist_sample_full, so every
   // server must be serving a sub-graph request with the same number of hops at the same time
   *status = RunSubGraph(sub, sres, device,

@@ -393,9 +393,9 @@ class Graph(object):
   def negative_sampler(self, object_type, expand_factor, strategy="random", conditional=False, **kwargs):
     """strategy: "random", "in_degree", "soft_in_degree" (object_type = an edge type) or
     "node_weight" (object_type = a node type)."""
-    if conditional:
-      self._off_path("conditional negative sampling")
     from graphlearn import sampler
+    if conditional:
+      return sampler.ConditionalNegativeSampler(self, object_type, expand_factor, strategy=strategy, **kwargs)
     cls = getattr(sampler, "".join(w.capitalize() for w in strategy.split("_")) + "NegativeSampler", None)
     if cls is None:
       raise ValueError("unknown negative sampling strategy {!r}".format(strategy))

@@ -306,6 +306,52 @@ class NegativeSampler(object):
     return self._graph.get_nodes(self._dst_type, out, shape=(ids.shape[0], self._expand_factor))
 
 
+class ConditionalNegativeSampler(NegativeSampler):
+  """python/sampler/negative_sampler.py:119-229: negatives for (src, dst) pairs that share the selected attribute
+  columns with the dst.  kwargs: batch_share, unique, int_cols / int_props, float_cols / float_props, str_cols /
+  str_props (column indices into the dst node type's int / float / string attributes and the share of the
+  `expand_factor` slots each column fills; the rest comes from the unconditioned `strategy`)."""
+
+  _needs = None  # an edge type ("random", "in_degree") or a node type ("node_weight")
+
+  def __init__(self, graph, object_type, expand_factor, strategy="random", **kwargs):
+    self._needs = "node" if strategy == "node_weight" else "edge"
+    super(ConditionalNegativeSampler, self).__init__(graph, object_type, expand_factor, strategy=strategy)
+    self._strategy = strategy
+    self._batch_share = bool(kwargs.get("batch_share", False))
+    self._unique = bool(kwargs.get("unique", False))
+    self._cols = [[int(c) for c in (kwargs.get(k + "_cols") or [])] for k in ("int", "float", "str")]
+    self._props = [[float(p) for p in (kwargs.get(k + "_props") or [])] for k in ("int", "float", "str")]
+    for cols, props in zip(self._cols, self._props):
+      if len(cols) != len(props):
+        raise ValueError("Condition columns and props must be the same size.")
+    decoder = graph.get_node_decoder(self._dst_type)
+    for cols, n in zip(self._cols, (decoder.int_attr_num, decoder.float_attr_num, decoder.string_attr_num)):
+      if any(not (0 <= c < n) for c in cols):
+        raise ValueError("Condition columns index out of range.")
+    if sum(sum(p) for p in self._props) > 1:
+      raise ValueError("Condition props sum is greater than 1.")
+
+  def get(self, src_ids, dst_ids):
+    """-> Nodes of shape [len(src_ids), expand_factor]"""
+    src_ids = np.ascontiguousarray(np.array(src_ids).reshape(-1), dtype=np.int64)
+    dst_ids = np.ascontiguousarray(np.array(dst_ids).reshape(-1), dtype=np.int64)
+    req = pywrap.new_conditional_sampling_request(self._object_type, self._strategy, self._expand_factor, self._dst_type,
+                                                  self._batch_share, self._unique)
+    pywrap.set_conditional_sampling_request_ids(req, src_ids, dst_ids)
+    pywrap.set_conditional_sampling_request_cols(req, self._cols[0], self._props[0], self._cols[1], self._props[1],
+                                                 self._cols[2], self._props[2])
+    if self._call_counter is not None:
+      pywrap.set_sampling_call_counter(req, int(self._call_counter))
+    res = pywrap.new_sampling_response()
+    status = self._graph.get_client().cond_neg_sample(req, res)
+    out = pywrap.get_sampling_node_ids(res) if status.ok() else None
+    pywrap.del_op_response(res)
+    pywrap.del_op_request(req)
+    errors.raise_exception_on_not_ok_status(status)
+    return self._graph.get_nodes(self._dst_type, out, shape=(dst_ids.shape[0], self._expand_factor))
+
+
 class RandomNegativeSampler(NegativeSampler):
   pass
 

@@ -226,6 +226,12 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
              return self.GetDegree(As<GetDegreeRequest>(req, "GetDegreeRequest"), As<GetDegreeResponse>(res, "GetDegreeResponse"));
            },
            py::call_guard<py::gil_scoped_release>())
+      .def("cond_neg_sample",
+           [](Client& self, OpRequest* req, OpResponse* res) {
+             As<ConditionalSamplingRequest>(req, "ConditionalSamplingRequest");
+             return self.RunOp(req, As<SamplingResponse>(res, "SamplingResponse"));
+           },
+           py::call_guard<py::gil_scoped_release>())
       .def("sample_subgraph",
            [](Client& self, OpRequest* req, OpResponse* res) {
              return self.SubGraph(As<SubGraphRequest>(req, "SubGraphRequest"), As<SubGraphResponse>(res, "SubGraphResponse"));
@@ -255,6 +261,24 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
         py::return_value_policy::reference);
   m.def("new_sampling_response", []() -> OpResponse* { return new SamplingResponse(); },
         py::return_value_policy::reference);
+  // conditional negative sampling (py_client.cc:301-341; py_wrapper.h:376-419)
+  m.def("new_conditional_sampling_request",
+        [](const std::string& type, const std::string& strategy, int32_t neighbor_count, const std::string& dst_node_type,
+           bool batch_share, bool unique) -> OpRequest* {
+          return new ConditionalSamplingRequest(type, strategy, neighbor_count, dst_node_type, batch_share, unique);
+        },
+        py::return_value_policy::reference);
+  m.def("set_conditional_sampling_request_ids", [](OpRequest* req, I64Array src_ids, I64Array dst_ids) {
+    if (src_ids.size() != dst_ids.size()) throw std::invalid_argument("src_ids and dst_ids must have the same size");
+    As<ConditionalSamplingRequest>(req, "ConditionalSamplingRequest")->SetIds(src_ids.data(), dst_ids.data(), (int32_t)src_ids.size());
+  });
+  m.def("set_conditional_sampling_request_cols",
+        [](OpRequest* req, const std::vector<int32_t>& int_cols, const std::vector<float>& int_props,
+           const std::vector<int32_t>& float_cols, const std::vector<float>& float_props,
+           const std::vector<int32_t>& str_cols, const std::vector<float>& str_props) {
+          As<ConditionalSamplingRequest>(req, "ConditionalSamplingRequest")
+              ->SetSelectedCols(int_cols, int_props, float_cols, float_props, str_cols, str_props);
+        });
   m.def("set_sampling_request", [](OpRequest* req, I64Array src_ids) {
     As<SamplingRequest>(req, "SamplingRequest")->Set(src_ids.data(), (int32_t)src_ids.size());
   });

@@ -528,6 +528,40 @@ def test_subgraph_sampler_through_the_python_api(gl, g):
     assert set(zip(sub0.edge_index[0].tolist(), sub0.edge_index[1].tolist())) == {(0, 1), (1, 0)}
 
 
+def test_conditional_negative_sampler_through_the_python_api(gl, g):
+    """Graph.negative_sampler(conditional=True) -> "ConditionalNegativeSampler" (conditional_negative_sampler.cc).  EDGE2
+    runs node2 -> node1; node1 carries ints [v, Hash64("hehe") % 10], floats [float(v)], strings [str(v)]: int column 1
+    is one group holding every candidate, int column 0 / the float / the string column put every node in a group of its
+    own -- whose only member, the dst, is excluded, so those slots fall through to the default sampler."""
+    src = np.array([102, 107, 108, 111])
+    dst = np.array([fx.fixed_dst_ids(int(s_), RANGE1)[0] for s_ in src])
+    cands = set(fx.fixed_dst_ids(range(*RANGE2), RANGE1))
+    for strategy in ("random", "in_degree"):
+        ns = g.negative_sampler(EDGE2, 6, strategy, conditional=True, unique=True, int_cols=[1, 0], int_props=[0.5, 0.25],
+                                str_cols=[0], str_props=[0.25])
+        ns.set_call_counter(5)
+        nodes = ns.get(src, dst)
+        assert nodes.ids.shape == (4, 6) and nodes.type == NODE1
+        seen = set()
+        for r in range(4):
+            seen |= set(fx.fixed_dst_ids(int(src[r]), RANGE1)) | {int(dst[r])}
+            row = nodes.ids[r].tolist()
+            assert set(row) <= cands and not (set(row) & seen), (strategy, r, row)
+            seen |= set(row)  # unique: accepted ids join the exclusion set
+        assert len(set(nodes.ids.reshape(-1).tolist())) == 24
+        again = g.negative_sampler(EDGE2, 6, strategy, conditional=True, unique=True, int_cols=[1, 0], int_props=[0.5, 0.25],
+                                   str_cols=[0], str_props=[0.25])
+        again.set_call_counter(5)
+        np.testing.assert_equal(again.get(src, dst).ids, nodes.ids)  # the call counter pins the stream
+    nw = g.negative_sampler(NODE2, 4, "node_weight", conditional=True)  # node2 has no attributes: default table only
+    out = nw.get(np.array([1, 2]), np.array([150, 151]))
+    assert out.ids.shape == (2, 4) and set(out.ids.reshape(-1).tolist()) <= set(range(*RANGE2)) - {150, 151}
+    with pytest.raises(ValueError):
+        g.negative_sampler(EDGE2, 6, "random", conditional=True, int_cols=[7], int_props=[0.5])
+    with pytest.raises(ValueError):
+        g.negative_sampler(EDGE2, 6, "random", conditional=True, int_cols=[0, 1], int_props=[0.7, 0.7])
+
+
 def test_in_and_out_degree_lookups(gl, g):
     """Graph.out_degrees / in_degrees (GetDegree with NodeFrom EDGE_SRC / EDGE_DST) against the generator."""
     ids = np.array([102, 105, 107, 199, 5000])
