@@ -474,25 +474,31 @@ extern "C" int glx_comm_init_local(int64_t fabric_key, int device, int rank, int
   c->rank = rank;
   c->world = world;
   c->kind = GLX_COMM_LOCAL;
-  std::lock_guard<std::mutex> g(g_fabric_mtx);
-  LocalFabric*& f = g_fabrics[fabric_key];
-  if (!f) {
-    f = new LocalFabric();
-    f->key = fabric_key;
-    f->world = world;
-  }
-  if (f->world != world) {
-    glx_set_error("fabric %lld was created with world size %d, not %d", (long long)fabric_key, f->world, world);
-    if (f->refs == 0) {
-      delete f;
-      g_fabrics.erase(fabric_key);
+  bool mismatch = false;
+  {
+    std::lock_guard<std::mutex> g(g_fabric_mtx);
+    auto it = g_fabrics.find(fabric_key);
+    if (it == g_fabrics.end()) {
+      LocalFabric* f = new LocalFabric();
+      f->key = fabric_key;
+      f->world = world;
+      it = g_fabrics.emplace(fabric_key, f).first;
     }
-    c->fab = nullptr;
+    LocalFabric* f = it->second;
+    if (f->world != world) {
+      glx_set_error("fabric %lld was created with world size %d, not %d", (long long)fabric_key, f->world, world);
+      mismatch = true;
+    } else {
+      ++f->refs;
+      c->fab = f;
+    }
+  }
+  if (mismatch) {
+    // outside the lock: ~LocalComm takes g_fabric_mtx itself (it is not recursive); c->fab is still null, so the
+    // fabric the OTHER ranks share is left alone
     delete c;
     return GLX_INVALID_ARGUMENT;
   }
-  ++f->refs;
-  c->fab = f;
   *out = c;
   return GLX_OK;
 }

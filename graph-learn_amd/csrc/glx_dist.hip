@@ -587,6 +587,13 @@ struct glx_dist_store {
   int device = 0, rank = 0, world = 1;
   bool shortcut = true;  // world == 1: call the local operator directly
   Arena req, recv;  // sampling: request-sized and receive-sized buffers
+  // The last kernels of a sampling call (the stitch into the caller's response) still READ these arenas when the call
+  // returns; the next call re-carves them at once.  On the same stream that is ordered; a caller that alternates
+  // streams is ordered through this event (recorded when a call has enqueued its last kernel, waited on by the next
+  // call's stream before it touches the arenas).
+  hipEvent_t arena_free = nullptr;
+  hipStream_t arena_stream = nullptr;
+  bool arena_used = false;
   // aggregation / lookup: one buffer set per request in flight (glx_dist_aggregate_begin .. _end)
   struct Slot {
     Arena req, recv, tab, halo;
@@ -628,6 +635,24 @@ void routing_from_matrix(const glx_dist_store* st, int nvals, Routing* r) {
   r->n_send = r->send_offs[P];
   r->n_recv = r->recv_offs[P];
 }
+
+struct ArenaOrder {
+  glx_dist_store* st;
+  hipStream_t s;
+  ArenaOrder(glx_dist_store* st_, hipStream_t s_) : st(st_), s(s_) {
+    if (st->arena_used && st->arena_free && st->arena_stream != s) (void)hipStreamWaitEvent(s, st->arena_free, 0);
+  }
+  ~ArenaOrder() {
+    if (!st->arena_free && hipEventCreateWithFlags(&st->arena_free, hipEventDisableTiming) != hipSuccess) {
+      st->arena_free = nullptr;
+      (void)hipStreamSynchronize(s);  // no event to order the next call by: drain instead
+      return;
+    }
+    (void)hipEventRecord(st->arena_free, s);
+    st->arena_stream = s;
+    st->arena_used = true;
+  }
+};
 
 // Result of routing a request's ids to their rows: loc[n] virtual rows + the row sources.
 struct Resolved {
@@ -797,6 +822,7 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
                                call_counter, filter, nbr_out, eid_out, GLX_PTR_DEVICE, s);
   }
   const int64_t n = batch;
+  ArenaOrder arena_order(st, s);
   Carver cv;
   const size_t o_buck = cv.take((size_t)(n > 0 ? n : 1) * 8);
   const size_t o_ord = cv.take((size_t)(n > 0 ? n : 1) * 8);
@@ -941,6 +967,7 @@ int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batc
                             int64_t* total_out, hipStream_t s) {
   const int P = st->world;
   const int64_t n = batch, n1 = n > 0 ? n : 1;
+  ArenaOrder arena_order(st, s);
   Carver cv;
   const size_t o_buck = cv.take((size_t)n1 * 8);
   const size_t o_ord = cv.take((size_t)n1 * 8);
@@ -1233,6 +1260,7 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
   if (!st) return;
   GlxDeviceGuard guard(st->device);
   (void)hipDeviceSynchronize();
+  if (st->arena_free) (void)hipEventDestroy(st->arena_free);
   st->req.release();
   st->recv.release();
   for (auto& sl : st->slots) {
@@ -1683,6 +1711,23 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
   rc = glx_features_create(st->device, n, dim, table_sorted.as<float>(), sorted_masked.as<int64_t>(), GLX_PTR_DEVICE, s,
                            &st->cache);
   if (rc != GLX_OK) return rc;
+  // from here on a failure must not leave a half-installed replica behind: st->cache set while cache_slots (or the
+  // bitmap) is missing would have the next resolve kernel dereference null slots
+  struct Rollback {
+    glx_dist_store* st;
+    bool armed = true;
+    ~Rollback() {
+      if (!armed) return;
+      if (st->cache) glx_features_destroy(st->cache);
+      st->cache = nullptr;
+      if (st->bm_member) (void)hipFree(st->bm_member);
+      st->bm_member = nullptr;
+      st->bm_valid = nullptr;
+      st->bm_max = -1;
+      if (st->cache_slots) (void)hipFree(st->cache_slots);
+      st->cache_slots = nullptr;
+    }
+  } rollback{st};
   // rank-select membership when the ids allow it
   st->bm_max = -1;
   int64_t lo_hi[2] = {0, 0};
@@ -1690,13 +1735,18 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
   GLX_HIP(hipMemcpyAsync(&lo_hi[1], sorted.as<int64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, s));
   GLX_HIP(hipStreamSynchronize(s));
   const bool no_bitmap = getenv("GLX_DIST_NO_BITMAP") != nullptr;  // A/B and test knob, read per call
-  if (!no_bitmap && lo_hi[0] >= 0 && lo_hi[1] < ((int64_t)1 << 31)) {
-    const int64_t words = (lo_hi[1] >> 6) + 1;
+  // ... and are dense enough: the bitmap costs 24 bytes per 64 ids of the RANGE, persistent, plus scratch -- one stray
+  // id near 2^31 in a short hot list would pin ~800 MB per GPU.  Within 4 words per listed id (+ a floor) it never
+  // exceeds ~100 bytes per hot row, a tenth of the row itself at dim 256; sparser lists keep the hash map.
+  const int64_t words_needed = lo_hi[1] >= 0 ? (lo_hi[1] >> 6) + 1 : 0;
+  if (!no_bitmap && lo_hi[0] >= 0 && lo_hi[1] < ((int64_t)1 << 31) && words_needed <= 4 * n + 4096) {
+    const int64_t words = words_needed;
     const size_t wb = ((size_t)words * 8 + 255) & ~(size_t)255;
     // kept: RankWord[words] | valid[words]; scratch: member[words] | rank[words] | flags
-    char* bm = nullptr;
+    GlxTemp bm_owner;  // released on every early return; handed to the store only when complete
     GlxTemp tmp_bm;
-    GLX_HIP(hipMalloc(reinterpret_cast<void**>(&bm), (size_t)words * sizeof(RankWord) + wb + 256));
+    GLX_HIP(hipMalloc(&bm_owner.p, (size_t)words * sizeof(RankWord) + wb + 256));
+    char* bm = bm_owner.as<char>();
     GLX_HIP(hipMalloc(&tmp_bm.p, wb + (size_t)words * 4 + 256));
     GLX_HIP(hipMemsetAsync(bm, 0, (size_t)words * sizeof(RankWord) + wb + 256, s));
     GLX_HIP(hipMemsetAsync(tmp_bm.p, 0, wb + (size_t)words * 4 + 256, s));
@@ -1717,8 +1767,9 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
     GLX_HIP(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, s));
     GLX_HIP(hipStreamSynchronize(s));
     if (h_flags[0]) {
-      (void)hipFree(bm);  // an id listed twice: ranks are not rows, keep the hash map
+      // an id listed twice: ranks are not rows, keep the hash map (bm_owner frees the bitmap)
     } else {
+      bm_owner.p = nullptr;
       st->bm_member = packed;
       st->bm_valid = h_flags[1] ? valid : nullptr;
       st->bm_max = lo_hi[1];
@@ -1730,6 +1781,7 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
                                                                  st->cache_slots);
   GLX_HIP(hipGetLastError());
   GLX_HIP(hipStreamSynchronize(s));
+  rollback.armed = false;
   return GLX_OK;
 }
 
