@@ -235,6 +235,7 @@ def edge_cut_world1(args):
     except Exception as ex:  # noqa: BLE001 -- never lose the headline line
         return {"error": repr(ex)}
     return {"placements": rec.get("placements"), "verified_equals_unpartitioned": rec.get("verified_sharded_equals_unpartitioned"),
+            "verified_legs": rec.get("verified_legs"), "replicated_per_gpu": rec.get("config", {}).get("replicated_per_gpu"),
             "hot_fraction": args.hot_fraction, "halo_exchange_hop2": rec.get("halo_exchange_hop2"),
             "sampling_exchange_hop2": rec.get("sampling_exchange_hop2"),
             "note": "world size 1 over RCCL, generic path (GLX_DIST_NO_SHORTCUT=1): partition, self-exchange, resolve + "
@@ -606,8 +607,14 @@ def main():
                          "store build, replica fetch)")
     ap.add_argument("--stage-priority", default="normal", choices=["high", "normal"],
                     help="pipelined legs: HIP stream priority of the sampling / halo-prefetch stages")
-    ap.add_argument("--graph-replica", default="on", choices=["on", "off"],
-                    help="N>1: also replicate the hot vertices' adjacency rows (their sampling requests stay local)")
+    ap.add_argument("--graph-replica", default="auto", choices=["auto", "on", "off"],
+                    help="N>1: also replicate the hot vertices' adjacency rows (their sampling requests stay local).  auto = "
+                         "when the replica fits the free HBM, and config.workload says which it was; on = refuse to run when "
+                         "it does not fit")
+    ap.add_argument("--pure-leg", default="on", choices=["on", "off"],
+                    help="N>1: after the placements with replicas, time the same steps once more with NO replica at all "
+                         "(hot fraction 0, no graph replica): every remote request row and every remote feature row "
+                         "crosses the links -- north_star's exchange itself; reported as placements.edge_cut_pure")
     ap.add_argument("--graph-hot-fraction", type=float, default=None,
                     help="N>1: fraction of the vertices (hottest first) whose adjacency rows are replicated; "
                          "default: --hot-fraction")
@@ -775,8 +782,10 @@ def main():
         # temporaries; skipped (with a note) when that is not there
         room = torch.cuda.mem_get_info(dev)[0] > 3 * E * 56
         if args.graph_replica == "on" and hot.shape[0] > 0 and not room:
-            log("graph replica skipped: not enough free HBM for a replica of up to %d edges" % E)
-        if args.graph_replica == "on" and hot.shape[0] > 0 and room:
+            raise SystemExit("--graph-replica on: not enough free HBM for a replica of up to %d edges (use auto / off)" % E)
+        if args.graph_replica == "auto" and hot.shape[0] > 0 and not room:
+            log("graph replica: off (auto: not enough free HBM for a replica of up to %d edges)" % E)
+        if args.graph_replica in ("on", "auto") and hot.shape[0] > 0 and room:
             # the same vertices' adjacency rows on every GPU: hop-2 request rows are hop-1 samples, i.e. mostly hubs,
             # and those are then sampled here instead of travelling to their owner and back.  Built from the shards:
             # every owner cuts its hot vertices' rows (its edge ids, its row order) and the pieces are all-gathered
@@ -978,6 +987,32 @@ def main():
             dt = float(t.item())
         return dt, t_a, t_s
 
+    verified_legs = {}
+
+    def verify_sharded():
+        """One step through the partitioned stores as they are NOW against unpartitioned copies held by this rank."""
+        i = n_steps - 1
+        a, b = do_sample(i)
+        halo_begin(a, b, i)
+        agg_halo(a, b, i)
+        wa, wae = whole[0].sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
+        wb, wbe = whole[0].sample(sampler, wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
+        we2, wc2 = whole[1].aggregate(agg, wb.view(-1), None, n1)
+        we1, wc1 = whole[1].aggregate(agg, wa.view(-1), None, B0)
+        torch.cuda.synchronize()
+        nb1, ed1, nb2, ed2 = bufs[i % len(bufs)]
+        ok = bool(torch.equal(nb1, wa) and torch.equal(ed1, wae) and torch.equal(nb2, wb) and torch.equal(ed2, wbe)
+                  and torch.equal(cnt2, wc2) and torch.equal(emb2.view(torch.int32), we2.view(torch.int32))
+                  and torch.equal(cnt1, wc1) and torch.equal(emb1.view(torch.int32), we1.view(torch.int32)))
+        if replica is not None:
+            re2, _ = replica.aggregate(agg, wb.view(-1), None, n1)
+            ok = ok and bool(torch.equal(re2.view(torch.int32), we2.view(torch.int32)))
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=ctl)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+        return ok
+
     edges_per_step = n1 + n2  # response slots, padding included (SURVEY.md 8(d))
     kernel_steps = args.steps  # steps the per-kernel timers covered
     ctl = dev if args.backend == "nccl" else torch.device("cpu")  # control-plane tensors (gloo rig: host)
@@ -1085,6 +1120,27 @@ def main():
         st_agg.aggregate(agg, b_last.view(-1), None, n1, out=(emb2, cnt2))
         torch.cuda.synchronize()
         halo_stats = st_agg.stats()
+        if args.verify:
+            verified_legs["features_sharded"] = guarded("verify", verify_sharded)
+        if args.pure_leg == "on":
+            # north_star's path without any cache: drop the hot-row replica and detach the graph replica, then the same steps
+            dog.cancel()
+            dog = threading.Timer(args.watchdog, give_up)
+            dog.daemon = True
+            dog.start()
+            st_agg.set_cache(np.empty(0, np.int64))
+            st_smp.set_graph_replica(None)
+            torch.cuda.synchronize()
+            el_p, _, _ = guarded("edge_cut_pure", lambda: timed_leg_halo(args.warmup, n_steps, args.warmup))
+            legs["edge_cut_pure"] = {"ms_per_step": el_p / args.steps * 1e3, "value": world * edges_per_step * args.steps / el_p}
+            a_p, b_p = do_sample(n_steps - 1)
+            pure_rows = st_smp.last_sample_rows()
+            st_agg.aggregate(agg, b_p.view(-1), None, n1, out=(emb2, cnt2))
+            torch.cuda.synchronize()
+            legs["edge_cut_pure"]["halo_exchange_hop2"] = st_agg.stats()
+            legs["edge_cut_pure"]["sampling_exchange_hop2"] = pure_rows
+            if args.verify:
+                verified_legs["edge_cut_pure"] = guarded("verify", verify_sharded)
         dog.cancel()
 
     # the last timed step's outputs against the oracle, before anything else touches the buffers
@@ -1115,28 +1171,9 @@ def main():
         empty_frac = float((graph.degrees(a_last.view(-1)) == 0).double().mean().item())
 
     verified = None
-    if args.verify and sharded:
-        i = n_steps - 1
-        a, b = do_sample(i)
-        halo_begin(a, b, i)
-        agg_halo(a, b, i)
-        wa, wae = whole[0].sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
-        wb, wbe = whole[0].sample(sampler, wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
-        we2, wc2 = whole[1].aggregate(agg, wb.view(-1), None, n1)
-        we1, wc1 = whole[1].aggregate(agg, wa.view(-1), None, B0)
-        torch.cuda.synchronize()
-        nb1, ed1, nb2, ed2 = bufs[i % len(bufs)]
-        verified = bool(torch.equal(nb1, wa) and torch.equal(ed1, wae) and torch.equal(nb2, wb) and torch.equal(ed2, wbe)
-                        and torch.equal(cnt2, wc2) and torch.equal(emb2.view(torch.int32), we2.view(torch.int32))
-                        and torch.equal(cnt1, wc1) and torch.equal(emb1.view(torch.int32), we1.view(torch.int32)))
-        if replica is not None:
-            re2, rc2 = replica.aggregate(agg, wb.view(-1), None, n1)
-            verified = verified and bool(torch.equal(re2.view(torch.int32), we2.view(torch.int32)))
-        if world > 1:
-            flag = torch.tensor([1 if verified else 0], dtype=torch.int64, device=ctl)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            verified = bool(flag.item())
-        log("verify: sharded (halo exchange) == unpartitioned, bit for bit, on every rank: %s" % verified)
+    if verified_legs:
+        verified = all(bool(v) for v in verified_legs.values())
+        log("verify: sharded (halo exchange) == unpartitioned, bit for bit, on every rank: %s" % verified_legs)
 
     value = world * edges_per_step * args.steps / elapsed
 
@@ -1234,7 +1271,16 @@ def main():
         res["verified_vs_oracle"] = oracle_check["ok"]
         res["oracle_check"] = oracle_check
     if sharded:
+        # what the leg `value` reports keeps on EVERY GPU besides its own shard (placements.edge_cut_pure keeps nothing)
+        res["config"]["replicated_per_gpu"] = {
+            "feature_rows": int(hot.shape[0]) if headline == "features_sharded" else V,
+            "feature_row_fraction": (float(hot.shape[0]) / V) if headline == "features_sharded" else 1.0,
+            "feature_bytes": (int(hot.shape[0]) if headline == "features_sharded" else V) * D * 4,
+            "graph_edges": int(graph_replica.num_edges) if graph_replica is not None else 0,
+            "graph_edge_fraction": (float(graph_replica.num_edges) / E) if graph_replica is not None else 0.0,
+            "graph_replica": ("on" if graph_replica is not None else "off") + " (--graph-replica %s)" % args.graph_replica}
         res["value_features_sharded"] = legs["features_sharded"]["value"]
+        res["value_edge_cut_pure"] = legs.get("edge_cut_pure", {}).get("value")
         res["value_features_replicated"] = legs.get("features_replicated", {}).get("value")
         res["placements"] = legs
         res["halo_exchange_hop2"] = dict(halo_stats, hot_rows=int(hot.shape[0]), hot_fraction=args.hot_fraction,
@@ -1247,6 +1293,7 @@ def main():
                                                   "replica / sent to another rank")
     if verified is not None:
         res["verified_sharded_equals_unpartitioned"] = verified
+        res["verified_legs"] = verified_legs
     if cpu:
         res["gpu_over_cpu"] = value / cpu["value"]
     if args.host_boundary == "on" and not sharded and rank == 0:

@@ -154,6 +154,7 @@ struct ResolveArgs {
   const uint64_t* bm_valid;   // nullptr when every hot id is known to its owner (the usual case)
   int64_t bm_max;
   int32_t insert_limit;  // distinct ids the set takes before it counts as too small (60 % of its slots)
+  int32_t max_probe;     // probes before a lookup gives up on a set that is too small; unbounded at the safe size
 };
 
 // Pass 1: every id -> a virtual row (own shard / replica), -1 (default row), or -(h + 2) when
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
                 break;
               }
               h = (h + 1) & a.tmask;
-              if (++probes > kMaxProbe) {  // the set is too small: the host retries with a larger one
+              if (++probes > a.max_probe) {  // the set is too small: the host retries with a larger one
                 a.ctr[2 * a.P] = 1;
                 out = -1;
                 break;
@@ -724,6 +725,10 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
       a.bm_valid = st->bm_valid;
       a.bm_max = st->bm_max;
       a.insert_limit = tcap >= safe_cap ? INT32_MAX : (int32_t)(tcap / 10 * 6);
+      // at the safe size (>= 2 slots per id of the request) the load stays <= 50 %: every probe sequence ends, and a
+      // capped one could only fail this rank AFTER its peers passed the count exchange -- leaving them in the
+      // row exchange waiting for it
+      a.max_probe = tcap >= safe_cap ? INT32_MAX : kMaxProbe;
       // Few, long-lived blocks: every block pays global atomics at its flushes and exit (a 16 M-id request: 0.27 ms
       // with 4096 blocks, 0.16 ms with 1024, 0.8 ms with 65536).  Two ids per thread-iteration with the rank
       // records (0.10 ms; one: 0.12, four: 0.12), one with the hash map (0.30; two: 0.32, four: 0.34) --
@@ -1239,6 +1244,10 @@ extern "C" int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_gr
     GLX_REQUIRE(replica->device == st->device, "the replica lives on device %d, the store on %d", replica->device,
                 st->device);
     GLX_REQUIRE(replica->idmap.keys != nullptr, "a graph replica needs its vertex ids (glx_graph_build with ids)");
+    // the request partition gets one more bucket for the replica (glx_partition_divert: at most 64 buckets); refuse
+    // here, where it is a configuration error, not inside a collective sample call
+    GLX_REQUIRE(st->world + 1 <= 64, "a graph replica needs world size <= 63 (the request partition has 64 buckets), got %d",
+                st->world);
     GLX_REQUIRE(st->graph->num_edges == 0 || replica->num_edges == 0 ||
                     (replica->weight != nullptr) == (st->graph->weight != nullptr),
                 "the replica and the shard must both be weighted or both unweighted");
@@ -1522,6 +1531,149 @@ extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* nod
     GLX_HIP(e2);
   }
   return rc;
+}
+
+namespace {
+
+__global__ void glx_dist_seg_of_kernel(const int32_t* __restrict__ seg, const int64_t* __restrict__ order, int64_t n,
+                                       int32_t fanout, int32_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t at = order[i];
+  out[i] = seg ? seg[at] : (int32_t)(at / fanout);  // a dense sampler response: segment = request row
+}
+
+// Design R: the reference's own distributed aggregation -- AggregatingRequest::Partition sends every
+// (id, segment id) to the id's owner, the owner reduces what it received per segment, AggregatingResponse::Stitch
+// folds the P partial [Sg, D] results on the requester (aggregating_request.cc:117-213).  Device pointers.
+int dist_aggregate_partial_device(glx_dist_store* st, int op, const int64_t* d_ids, const int32_t* d_seg, int32_t num_ids,
+                                  int32_t num_segments, float default_attr, float* d_emb, int32_t* d_cnt, hipStream_t s) {
+  const int P = st->world, me = st->rank;
+  const glx_features* f = st->feats;
+  const int32_t D = f->dim;
+  const int64_t n = num_ids, n1 = n > 0 ? n : 1;
+  const int32_t fanout = (d_seg == nullptr && num_segments > 0) ? num_ids / num_segments : 1;
+  GlxTemp buck, ord, seg_b;
+  GLX_HIP(hipMalloc(&buck.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&ord.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&seg_b.p, (size_t)n1 * 4));
+  int rc = glx_partition(st->device, d_ids, n, P, buck.as<int64_t>(), ord.as<int64_t>(), st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  if (n > 0) {
+    // stable inside a shard: a requester's segment ids stay non-decreasing on their way to every owner
+    glx_dist_seg_of_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d_seg, ord.as<int64_t>(), n, fanout > 0 ? fanout : 1,
+                                                                     seg_b.as<int32_t>());
+  }
+  // counts + this requester's segment count and default value (requests differ per rank)
+  ReqParams mine;
+  memset(&mine, 0, sizeof(mine));
+  mine.v[0] = num_segments;
+  mine.v[1] = op;
+  memcpy(&mine.v[2], &default_attr, sizeof(float));
+  constexpr int kParams = 3;
+  glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P, mine, kParams);
+  const int nvals = P + kParams;
+  st->h_mat.resize((size_t)P * nvals);
+  rc = st->comm->allgather_i64(st->d_vals, nvals, st->h_mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  Routing rt;
+  routing_from_matrix(st, nvals, &rt);
+  const int64_t m = rt.n_recv;
+  GLX_REQUIRE(m <= INT32_MAX, "more than 2^31 ids arrived at one shard");
+  std::vector<int64_t> sg_of((size_t)P), sg_off((size_t)P + 1, 0), back_counts((size_t)P), back_offs((size_t)P + 1, 0);
+  for (int q = 0; q < P; ++q) {
+    const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
+    GLX_REQUIRE(pq[1] == op, "rank %d asks for aggregator %lld, this rank for %d: one collective, one operator", q,
+                (long long)pq[1], op);
+    sg_of[(size_t)q] = pq[0];
+    sg_off[(size_t)q + 1] = sg_off[(size_t)q] + pq[0];
+    back_counts[(size_t)q] = num_segments;  // every owner answers with one partial row per segment of MINE
+    back_offs[(size_t)q + 1] = back_offs[(size_t)q] + num_segments;
+  }
+  const int64_t served = sg_off[(size_t)P];  // partial rows this owner produces, requester-major
+  GlxTemp ids_in, seg_in, part_out, cnt_part, part_in, cnt_in;
+  GLX_HIP(hipMalloc(&ids_in.p, (size_t)(m > 0 ? m : 1) * 8));
+  GLX_HIP(hipMalloc(&seg_in.p, (size_t)(m > 0 ? m : 1) * 4));
+  GLX_HIP(hipMalloc(&part_out.p, (size_t)(served > 0 ? served : 1) * D * 4));
+  GLX_HIP(hipMalloc(&cnt_part.p, (size_t)(served > 0 ? served : 1) * 4));
+  GLX_HIP(hipMalloc(&part_in.p, (size_t)P * (size_t)(num_segments > 0 ? num_segments : 1) * D * 4));
+  GLX_HIP(hipMalloc(&cnt_in.p, (size_t)P * (size_t)(num_segments > 0 ? num_segments : 1) * 4));
+  GlxSeg out_segs[2] = {{buck.p, ids_in.p, 8}, {seg_b.p, seg_in.p, 4}};
+  rc = st->comm->alltoallv(out_segs, 2, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
+                           rt.recv_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  // Process on the owner: one local segmented reduce per requester (Aggregator::Aggregate on the ids it owns)
+  for (int q = 0; q < P; ++q) {
+    const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
+    float dq;
+    memcpy(&dq, &pq[2], sizeof(float));
+    if (sg_of[(size_t)q] == 0) continue;
+    rc = glx_aggregate(f, op, ids_in.as<int64_t>() + rt.recv_offs[(size_t)q], seg_in.as<int32_t>() + rt.recv_offs[(size_t)q],
+                       (int32_t)rt.recv_counts[(size_t)q], (int32_t)sg_of[(size_t)q], dq,
+                       part_out.as<float>() + sg_off[(size_t)q] * D, cnt_part.as<int32_t>() + sg_off[(size_t)q],
+                       GLX_PTR_DEVICE, s);
+    if (rc != GLX_OK) return rc;
+  }
+  // partial rows back: to requester q its sg_of[q] rows, from every owner my num_segments rows (shard-major)
+  GlxSeg back_segs[2] = {{part_out.p, part_in.p, (size_t)D * 4}, {cnt_part.p, cnt_in.p, 4}};
+  rc = st->comm->alltoallv(back_segs, 2, sg_of.data(), sg_off.data(), back_counts.data(), back_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  st->stats = glx_dist_stats{};
+  st->stats.ids = n;
+  st->stats.from_own_shard = rt.send_counts[(size_t)me];
+  st->stats.remote = n - rt.send_counts[(size_t)me];
+  st->stats.bytes_sent = (n - rt.send_counts[(size_t)me]) * 12 + (served - sg_of[(size_t)me]) * ((int64_t)D * 4 + 4);
+  st->stats.bytes_received = (m - rt.recv_counts[(size_t)me]) * 12 + (int64_t)(P - 1) * num_segments * ((int64_t)D * 4 + 4);
+  st->stats.exchange_rounds = st->comm->last_rounds;
+  if (num_segments > 0) {
+    rc = glx_aggregate_stitch(st->device, op, P, part_in.as<float>(), cnt_in.as<int32_t>(), num_segments, D, default_attr, d_emb,
+                              d_cnt, s);
+    if (rc != GLX_OK) return rc;
+  }
+  GLX_HIP(hipStreamSynchronize(s));  // the temporaries are released on return
+  return GLX_OK;
+}
+
+}  // namespace
+
+extern "C" int glx_dist_aggregate_partial(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,
+                                          int32_t num_ids, int32_t num_segments, float default_attr, float* emb_out,
+                                          int32_t* cnt_out, int ptr_kind, void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->feats != nullptr, "this store has no feature shard");
+  GLX_REQUIRE(op >= GLX_AGG_SUM && op <= GLX_AGG_PROD, "unknown aggregator id %d", op);
+  GLX_REQUIRE(num_ids >= 0 && num_segments >= 0, "negative sizes");
+  GLX_REQUIRE((int64_t)num_segments * st->feats->dim <= INT32_MAX, "num_segments * dim exceeds int32 (tensor.h:47)");
+  GLX_REQUIRE(num_segments == 0 || (emb_out && cnt_out), "NULL output pointer");
+  GLX_REQUIRE(num_ids == 0 || node_ids, "NULL data pointer");
+  GLX_REQUIRE(segment_ids != nullptr || num_segments == 0 || num_ids % num_segments == 0,
+              "segment_ids == NULL means equal segments: num_ids must be a multiple of num_segments");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  if (ptr_kind == GLX_PTR_DEVICE) {
+    return dist_aggregate_partial_device(st, op, node_ids, segment_ids, num_ids, num_segments, default_attr, emb_out,
+                                         cnt_out, s);
+  }
+  const glx_features* f = st->feats;
+  const size_t emb_n = (size_t)num_segments * f->dim;
+  GlxTemp d_ids, d_seg, d_emb, d_cnt;
+  GLX_HIP(hipMalloc(&d_ids.p, (size_t)(num_ids > 0 ? num_ids : 1) * 8));
+  GLX_HIP(hipMalloc(&d_seg.p, (size_t)(num_ids > 0 ? num_ids : 1) * 4));
+  GLX_HIP(hipMalloc(&d_emb.p, (emb_n > 0 ? emb_n : 1) * 4));
+  GLX_HIP(hipMalloc(&d_cnt.p, (size_t)(num_segments > 0 ? num_segments : 1) * 4));
+  if (num_ids) GLX_HIP(hipMemcpyAsync(d_ids.p, node_ids, (size_t)num_ids * 8, hipMemcpyHostToDevice, s));
+  if (num_ids && segment_ids) GLX_HIP(hipMemcpyAsync(d_seg.p, segment_ids, (size_t)num_ids * 4, hipMemcpyHostToDevice, s));
+  rc = dist_aggregate_partial_device(st, op, d_ids.as<int64_t>(), segment_ids ? d_seg.as<int32_t>() : nullptr, num_ids,
+                                     num_segments, default_attr, d_emb.as<float>(), d_cnt.as<int32_t>(), s);
+  if (rc != GLX_OK) return rc;
+  if (num_segments > 0) {
+    GLX_HIP(hipMemcpyAsync(emb_out, d_emb.p, emb_n * 4, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipMemcpyAsync(cnt_out, d_cnt.p, (size_t)num_segments * 4, hipMemcpyDeviceToHost, s));
+  }
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
 }
 
 // The two halves of glx_dist_aggregate for software pipelining (device pointers only).

@@ -54,7 +54,7 @@ EXPORTS = [
     "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full", "glx_dist_random_walk",
     "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
-    "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
+    "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_partial", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
     "glx_dist_last_stats",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
     "glx_probe_bandwidth", "glx_subgraph_induce",
@@ -186,6 +186,7 @@ def lib():
         L.glx_dist_enable_in_degree.argtypes = [vp, vp, vp]
         L.glx_dist_sample.argtypes = [vp, ci, vp, i32, i32, ci, i64, u64, u64, ctypes.POINTER(Filter), vp, vp, ci, vp]
         L.glx_dist_aggregate.argtypes = [vp, ci, vp, vp, i32, i32, f32, vp, vp, ci, vp]
+        L.glx_dist_aggregate_partial.argtypes = [vp, ci, vp, vp, i32, i32, f32, vp, vp, ci, vp]
         L.glx_dist_lookup.argtypes = [vp, vp, i64, f32, vp, ci, vp]
         L.glx_dist_aggregate_begin.argtypes = [vp, i32, vp, i32, f32, vp]
         L.glx_dist_aggregate_end.argtypes = [vp, i32, ci, vp, i32, vp, vp, vp]
@@ -933,8 +934,9 @@ class DistStore:
                                      call_counter, flt, pn[0], pe[0], kind, _stream(kind, self.comm.device)))
         return nbr, eid
 
-    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, out=None):
-        """segment_ids=None: num_segments equal segments (a dense sampler response)."""
+    def aggregate(self, op, node_ids, segment_ids, num_segments, default_attr=0.0, out=None, partial=False):
+        """segment_ids=None: num_segments equal segments (a dense sampler response).  partial=True: design R -- owners
+        reduce, the requester folds the partial results (glx_dist_aggregate_partial) instead of the halo-row exchange."""
         if isinstance(op, str):
             op = AGGREGATOR_IDS[op]
         n = int(node_ids.shape[0])
@@ -949,8 +951,8 @@ class DistStore:
             cnt = np.empty((num_segments,), np.int32)
         pi, pg, pe, pc = _ptr(node_ids), _ptr(segment_ids), _ptr(emb), _ptr(cnt)
         kind = _kind(pi, pg, pe, pc)
-        _check(lib().glx_dist_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0], pc[0], kind,
-                                        _stream(kind, self.comm.device)))
+        fn = lib().glx_dist_aggregate_partial if partial else lib().glx_dist_aggregate
+        _check(fn(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0], pc[0], kind, _stream(kind, self.comm.device)))
         return emb, cnt
 
     def aggregate_begin(self, slot, node_ids, default_attr=0.0):

@@ -537,6 +537,19 @@ GLX_API int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32
 GLX_API int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,
                                int32_t num_ids, int32_t num_segments, float default_attr, float* emb_out,
                                int32_t* cnt_out, int ptr_kind, void* stream);
+/* Collective.  The same request served the way the reference's servers serve it (SURVEY 8(e) design R, kept as the
+ * ablation of the halo exchange above): AggregatingRequest::Partition routes every (id, segment id) to the id's owner
+ * (aggregating_request.cc:117-170), each owner runs Aggregator::Aggregate over what it received, and
+ * AggregatingResponse::Stitch folds the world-size partial [num_segments, dim] results and counts on the requester
+ * (:172-213; glx_aggregate_stitch).  Per request it moves 12 B per remote id out and world * num_segments * (4 dim + 4) B
+ * back instead of 4 dim B per distinct remote id: cheaper when segments are long (fan-out >> world).  Max / Min / counts
+ * equal the single-store operator exactly; Sum / Mean / Prod fold per-shard partial results, so they differ from it by
+ * the floating-point reassociation the reference's distributed mode has as well (<= 1e-5 relative at the fan-outs of
+ * BASELINE's configs).  A segment none of whose ids a shard owns contributes nothing from that shard (SURVEY 8(a)
+ * quirk 8: the reference folds a default row in there).  Replicas (hot rows, graph) are not consulted. */
+GLX_API int glx_dist_aggregate_partial(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,
+                                       int32_t num_ids, int32_t num_segments, float default_attr, float* emb_out,
+                                       int32_t* cnt_out, int ptr_kind, void* stream);
 /* The same in two halves, for software pipelining (device pointers only).  _begin is the collective part:
  * it resolves the ids and fetches the halo rows into buffer set `slot` (0 <= slot < GLX_DIST_SLOTS); it may run
  * on the stream that PRODUCED the ids, one or more requests ahead of the reduce.  _end is local: the segmented

@@ -238,6 +238,46 @@ def test_dist_aggregate_equals_unpartitioned(world, P, cache, monkeypatch):
     _run_ranks(P, body)
 
 
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_dist_aggregate_partial_design_r(world, P):
+    """glx_dist_aggregate_partial: the reference's own distributed aggregation (owners reduce, the requester folds the
+    partial results: aggregating_request.cc:117-213).  Counts, Max and Min equal the single store exactly; Sum / Mean /
+    Prod within the north-star tolerance (1e-5 relative: per-shard partial results are folded, as in the reference)."""
+    feats, dev = world["feats"], world["dev"]
+    _, fs = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, features=fs[r])
+        rng = np.random.default_rng(70 + r)
+        n, f = 12000 + 40 * r, 10
+        ids = np.where(rng.random(n) < 0.5, _hot(world, 500)[rng.integers(0, 500, n)], rng.integers(-3, V + 3, n))
+        ids = torch.from_numpy(ids.astype(np.int64)).to(dev)
+        seg = torch.from_numpy((np.arange(n) // f).astype(np.int32)).to(dev)
+        rag = torch.from_numpy(np.sort(rng.integers(0, 700, n)).astype(np.int32)).to(dev)  # ragged, some segments empty
+        for name in glx.AGGREGATOR_IDS:
+            for sg, nseg in ((seg, n // f), (None, n // f), (rag, 700)):
+                ref_e, ref_c = feats.aggregate(name, ids, sg if sg is not None else seg, nseg, default_attr=0.5 + r)
+                e, c = st.aggregate(name, ids, sg, nseg, default_attr=0.5 + r, partial=True)
+                assert torch.equal(c, ref_c), (name, r)
+                if name in ("MaxAggregator", "MinAggregator") or P == 1:
+                    assert torch.equal(e.view(torch.int32), ref_e.view(torch.int32)), (name, r)
+                else:
+                    scale = ref_e.abs().clamp(min=1.0)
+                    assert bool(((e - ref_e).abs() / scale).max() <= 1e-5), (name, r, float(((e - ref_e).abs() / scale).max()))
+        s = st.stats()
+        assert s["ids"] == n and s["from_own_shard"] + s["remote"] == n
+        if P > 1:
+            assert s["remote"] > 0 and s["bytes_sent"] > 0
+        # host pointers, and an empty request beside busy peers
+        he, hc = st.aggregate("MaxAggregator", ids.cpu().numpy(), seg.cpu().numpy(), n // f, default_attr=0.5, partial=True)
+        ref_e, ref_c = feats.aggregate("MaxAggregator", ids, seg, n // f, default_attr=0.5)
+        assert np.array_equal(hc, ref_c.cpu().numpy()) and np.array_equal(he.view(np.uint32), ref_e.cpu().numpy().view(np.uint32))
+        k = 0 if r == 0 else 50
+        e, c = st.aggregate("SumAggregator", ids[:k], seg[:k], k // f, partial=True)
+        assert e.shape[0] == k // f
+    _run_ranks(P, body)
+
+
 @pytest.mark.parametrize("P", [2, 8])
 def test_halo_set_grows_when_it_overflows(world, P):
     """The set of distinct halo ids is sized for a quarter of the request (or 2.5x the largest share of

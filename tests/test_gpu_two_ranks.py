@@ -45,6 +45,16 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
     halo = res["halo_exchange_hop2"]
     assert halo["from_replica"] + halo["from_own_shard"] + halo["remote"] == halo["ids"]
     assert halo["remote_distinct"] <= halo["remote"] and halo["hot_rows"] > 0
+    # the third placement: no replica of anything -- every remote request row and feature row crosses the transport --
+    # timed, verified and described like the others
+    pure = res["placements"]["edge_cut_pure"]
+    assert pure["value"] > 0 and res["value_edge_cut_pure"] == pure["value"]
+    assert res["verified_legs"] == {"features_sharded": True, "edge_cut_pure": True}
+    ph, ps = pure["halo_exchange_hop2"], pure["sampling_exchange_hop2"]
+    assert ph["from_replica"] == 0 and ph["remote"] > 0 and ph["bytes_sent"] > 0
+    assert ps["from_graph_replica"] == 0 and ps["remote"] > 0
+    rep = res["config"]["replicated_per_gpu"]
+    assert rep["feature_rows"] > 0 and 0 < rep["feature_row_fraction"] <= 1.0
     if features == "replicated":
         assert res["value_features_replicated"] == res["value"]
         assert "features_replicated placement" in res["config"]["workload"]
