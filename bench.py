@@ -973,12 +973,19 @@ def main():
         run(0, warm)
         barrier()
         ev_r.clear()
+        sync0 = [st.stats() for st in (st_smp, st_agg)]
         glx.profile_enable(True)
         t0 = time.perf_counter()
         run(steps_from, steps_to)
         barrier()
         dt = time.perf_counter() - t0
         glx.profile_enable(False)
+        sync1 = [st.stats() for st in (st_smp, st_agg)]
+        nst = max(steps_to - steps_from, 1)
+        # count exchanges of the timed steps: each blocks the issuing host thread until every rank's counts are in
+        last_host_syncs.update(
+            host_syncs_per_step=sum(b["host_syncs"] - a["host_syncs"] for a, b in zip(sync0, sync1)) / nst,
+            host_stall_ms_per_step=sum(b["host_stall_us"] - a["host_stall_us"] for a, b in zip(sync0, sync1)) / nst / 1e3)
         t_a = glx.profile_collect(glx.KERNEL_AGGREGATE)
         t_s = glx.profile_collect(glx.KERNEL_SAMPLE)
         if world > 1:
@@ -988,6 +995,7 @@ def main():
         return dt, t_a, t_s
 
     verified_legs = {}
+    last_host_syncs = {}
 
     def verify_sharded():
         """One step through the partitioned stores as they are NOW against unpartitioned copies held by this rank."""
@@ -1107,8 +1115,8 @@ def main():
             dog.start()
         # north_star's placement: everything edge-cut, halo-vertex feature exchange per request
         el_h, ta_h, ts_h = guarded("features_sharded", lambda: timed_leg_halo(args.warmup, n_steps, args.warmup))
-        legs["features_sharded"] = {"ms_per_step": el_h / args.steps * 1e3,
-                                    "value": world * edges_per_step * args.steps / el_h}
+        legs["features_sharded"] = dict({"ms_per_step": el_h / args.steps * 1e3,
+                                         "value": world * edges_per_step * args.steps / el_h}, **last_host_syncs)
         torch.cuda.synchronize()
         if args.features == "replicated" and replica is not None:
             elapsed, t_agg, t_smp, headline = el_r, ta_r, ts_r, "features_replicated"
@@ -1132,7 +1140,8 @@ def main():
             st_smp.set_graph_replica(None)
             torch.cuda.synchronize()
             el_p, _, _ = guarded("edge_cut_pure", lambda: timed_leg_halo(args.warmup, n_steps, args.warmup))
-            legs["edge_cut_pure"] = {"ms_per_step": el_p / args.steps * 1e3, "value": world * edges_per_step * args.steps / el_p}
+            legs["edge_cut_pure"] = dict({"ms_per_step": el_p / args.steps * 1e3,
+                                          "value": world * edges_per_step * args.steps / el_p}, **last_host_syncs)
             a_p, b_p = do_sample(n_steps - 1)
             pure_rows = st_smp.last_sample_rows()
             st_agg.aggregate(agg, b_p.view(-1), None, n1, out=(emb2, cnt2))

@@ -24,6 +24,8 @@
 #include <new>
 #include <vector>
 
+#include <chrono>
+
 #include <rocprim/rocprim.hpp>
 
 #include "glx_comm.h"
@@ -609,6 +611,9 @@ struct glx_dist_store {
   int64_t* d_vals = nullptr;  // [world + 8] values shared by the count exchange
   int32_t* d_ctr = nullptr;   // [3 * world + 8] counter block of the resolve passes
   double halo_share = 0.0;  // largest (distinct halo ids / request ids) seen so far
+  // every count exchange blocks the calling host thread until the slowest rank's counts have arrived: how often, and
+  // for how long, since the store was created (glx_dist_stats.host_syncs / host_stall_us)
+  int64_t host_syncs = 0, host_stall_us = 0;
   glx_dist_stats stats;
   std::vector<int64_t> h_mat;
 };
@@ -635,6 +640,15 @@ void routing_from_matrix(const glx_dist_store* st, int nvals, Routing* r) {
   }
   r->n_send = r->send_offs[P];
   r->n_recv = r->recv_offs[P];
+}
+
+// The count exchange of a partitioned request: the one place its host thread waits for the other ranks.
+int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_t* h_out, hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = st->comm->allgather_i64(d_vals, nvals, h_out, s);
+  st->host_stall_us += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  ++st->host_syncs;
+  return rc;
 }
 
 struct ArenaOrder {
@@ -751,7 +765,7 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
     }
     first = false;
     st->h_mat.resize((size_t)P * nvals);
-    rc = st->comm->allgather_i64(st->d_vals, nvals, st->h_mat.data(), s);  // the one host sync
+    rc = exchange_counts(st, st->d_vals, nvals, st->h_mat.data(), s);  // the one host sync
     if (rc != GLX_OK) return rc;
     bool any = false;
     for (int q = 0; q < P; ++q) any = any || st->h_mat[(size_t)q * nvals + P] != 0;
@@ -874,7 +888,7 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P, mine, kParams);
   const int nvals = P + kParams;
   st->h_mat.resize((size_t)P * nvals);
-  rc = st->comm->allgather_i64(st->d_vals, nvals, st->h_mat.data(), s);
+  rc = exchange_counts(st, st->d_vals, nvals, st->h_mat.data(), s);
   if (rc != GLX_OK) return rc;
   Routing rt;
   routing_from_matrix(st, nvals, &rt);
@@ -989,7 +1003,7 @@ int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batc
   rc = glx_partition(st->device, src, n, P, bucketed, order, st->d_vals, s);
   if (rc != GLX_OK) return rc;
   st->h_mat.resize((size_t)P * P);
-  rc = st->comm->allgather_i64(st->d_vals, P, st->h_mat.data(), s);
+  rc = exchange_counts(st, st->d_vals, P, st->h_mat.data(), s);
   if (rc != GLX_OK) return rc;
   Routing rt;
   routing_from_matrix(st, P, &rt);
@@ -1050,7 +1064,7 @@ int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batc
   GLX_HIP(hipMalloc(&d_cnt.p, (size_t)P * 8));
   GLX_HIP(hipMemcpyAsync(d_cnt.p, send_vals.data(), (size_t)P * 8, hipMemcpyHostToDevice, s));
   std::vector<int64_t> mat((size_t)P * P);
-  rc = st->comm->allgather_i64(d_cnt.as<int64_t>(), P, mat.data(), s);
+  rc = exchange_counts(st, d_cnt.as<int64_t>(), P, mat.data(), s);
   if (rc != GLX_OK) return rc;
   std::vector<int64_t> recv_vals((size_t)P), recv_voffs((size_t)P + 1, 0);
   for (int q = 0; q < P; ++q) {
@@ -1199,7 +1213,7 @@ extern "C" int glx_dist_build_graph_replica(glx_dist_store* st, const int64_t* h
   const int64_t mine2[2] = {e_me, weighted ? 1 : 0};
   GLX_HIP(hipMemcpyAsync(d_e.p, mine2, 16, hipMemcpyHostToDevice, s));
   std::vector<int64_t> all2((size_t)P * 2), e_all((size_t)P);
-  rc = st->comm->allgather_i64(d_e.as<int64_t>(), 2, all2.data(), s);
+  rc = exchange_counts(st, d_e.as<int64_t>(), 2, all2.data(), s);
   if (rc != GLX_OK) return rc;
   std::vector<int64_t> eoffs((size_t)P + 1, 0);
   for (int p = 0; p < P; ++p) {
@@ -1289,6 +1303,8 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
 extern "C" int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out) {
   GLX_REQUIRE(st != nullptr && out != nullptr, "NULL argument");
   *out = st->slots[st->last_slot].stats;
+  out->host_syncs = st->host_syncs;
+  out->host_stall_us = st->host_stall_us;
   return GLX_OK;
 }
 
@@ -1574,7 +1590,7 @@ int dist_aggregate_partial_device(glx_dist_store* st, int op, const int64_t* d_i
   glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P, mine, kParams);
   const int nvals = P + kParams;
   st->h_mat.resize((size_t)P * nvals);
-  rc = st->comm->allgather_i64(st->d_vals, nvals, st->h_mat.data(), s);
+  rc = exchange_counts(st, st->d_vals, nvals, st->h_mat.data(), s);
   if (rc != GLX_OK) return rc;
   Routing rt;
   routing_from_matrix(st, nvals, &rt);
@@ -1618,13 +1634,16 @@ int dist_aggregate_partial_device(glx_dist_store* st, int op, const int64_t* d_i
   GlxSeg back_segs[2] = {{part_out.p, part_in.p, (size_t)D * 4}, {cnt_part.p, cnt_in.p, 4}};
   rc = st->comm->alltoallv(back_segs, 2, sg_of.data(), sg_off.data(), back_counts.data(), back_offs.data(), s);
   if (rc != GLX_OK) return rc;
-  st->stats = glx_dist_stats{};
-  st->stats.ids = n;
-  st->stats.from_own_shard = rt.send_counts[(size_t)me];
-  st->stats.remote = n - rt.send_counts[(size_t)me];
-  st->stats.bytes_sent = (n - rt.send_counts[(size_t)me]) * 12 + (served - sg_of[(size_t)me]) * ((int64_t)D * 4 + 4);
-  st->stats.bytes_received = (m - rt.recv_counts[(size_t)me]) * 12 + (int64_t)(P - 1) * num_segments * ((int64_t)D * 4 + 4);
-  st->stats.exchange_rounds = st->comm->last_rounds;
+  st->last_slot = 0;
+  glx_dist_stats& stat = st->slots[0].stats;
+  stat = glx_dist_stats{};
+  stat.ids = n;
+  stat.from_own_shard = rt.send_counts[(size_t)me];
+  stat.remote = n - rt.send_counts[(size_t)me];
+  stat.served_rows = served - sg_of[(size_t)me];  // partial rows reduced here for the other requesters
+  stat.bytes_sent = (n - rt.send_counts[(size_t)me]) * 12 + (served - sg_of[(size_t)me]) * ((int64_t)D * 4 + 4);
+  stat.bytes_received = (m - rt.recv_counts[(size_t)me]) * 12 + (int64_t)(P - 1) * num_segments * ((int64_t)D * 4 + 4);
+  stat.exchange_rounds = st->comm->last_rounds;
   if (num_segments > 0) {
     rc = glx_aggregate_stitch(st->device, op, P, part_in.as<float>(), cnt_in.as<int32_t>(), num_segments, D, default_attr, d_emb,
                               d_cnt, s);
@@ -1969,7 +1988,7 @@ int dst_totals(glx_dist_store* st, hipStream_t s, DstTotals* t) {
                                                                             cnt_b.as<int64_t>());
   }
   st->h_mat.resize((size_t)P * P);
-  rc = st->comm->allgather_i64(st->d_vals, P, st->h_mat.data(), s);
+  rc = exchange_counts(st, st->d_vals, P, st->h_mat.data(), s);
   if (rc != GLX_OK) return rc;
   routing_from_matrix(st, P, &t->rt);
   const size_t m = (size_t)t->rt.n_recv;
@@ -2059,7 +2078,7 @@ extern "C" int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_o
   int64_t c_me_copy = c_me;
   GLX_HIP(hipMemcpyAsync(st->d_vals, &c_me_copy, 8, hipMemcpyHostToDevice, s));
   std::vector<int64_t> cand((size_t)P);
-  rc = st->comm->allgather_i64(st->d_vals, 1, cand.data(), s);
+  rc = exchange_counts(st, st->d_vals, 1, cand.data(), s);
   if (rc != GLX_OK) return rc;
   std::vector<int64_t> offs((size_t)P + 1, 0), same((size_t)P, c_me), zero((size_t)P, 0);
   for (int p = 0; p < P; ++p) offs[p + 1] = offs[p] + cand[p];

@@ -75,7 +75,8 @@ class Filter(ctypes.Structure):
 class DistStats(ctypes.Structure):
     """glx_dist_stats (include/glx.h): where the ids of a store's last aggregate / lookup came from."""
     _fields_ = [(n, ctypes.c_int64) for n in ("ids", "from_replica", "from_own_shard", "remote", "remote_distinct",
-                                                "served_rows", "bytes_sent", "bytes_received", "exchange_rounds")]
+                                                "served_rows", "bytes_sent", "bytes_received", "exchange_rounds",
+                                                "host_syncs", "host_stall_us")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -579,6 +579,11 @@ typedef struct glx_dist_stats {
   int64_t bytes_sent;      /* ids out + rows out over the transport, self-copies excluded */
   int64_t bytes_received;
   int64_t exchange_rounds; /* transport rounds of the last row exchange (message-size limit) */
+  /* ABI 3.  Cumulative since the store was created: every partitioned request exchanges its per-shard counts once and the
+   * calling host thread waits there for the slowest rank (the reference's RunInParallel waits for every remote shard's RPC
+   * the same way, op_runner.h:86-117) -- how many such waits, and how long they took in total. */
+  int64_t host_syncs;
+  int64_t host_stall_us;
 } glx_dist_stats;
 GLX_API int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out);
 

@@ -1,0 +1,6 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03_run5; mkdir -p $O
+cd $R
+timeout 1200 python -m pytest tests/test_gpu_dist_store.py tests/test_gpu_two_ranks.py tests/test_gpu_sharded.py -m gpu -q -x > $O/pytest.log 2>&1; tail -30 $O/pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 --cpu-baseline off --other-configs "" > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -8 $O/bench.err
