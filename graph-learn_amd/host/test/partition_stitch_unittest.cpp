@@ -430,6 +430,85 @@ TEST(PartitionStitchTest, StatisticsAcrossTwoServers) {
   }
 }
 
+// SubGraphSampler on a deployment of two servers: the request itself is not shardable, its FullSampler sub-requests are
+// (subgraph_sampler.cc:27-32 runs them through GetOpRunner(Env::Default(), op)); node list and induced COO must equal
+// the single store's (edge ids are server-local in this fixture and not compared).
+TEST(PartitionStitchTest, SubGraphSamplerOnTwoServersEqualsOneStore) {
+  GraphStore whole, shard[2];
+  io::SideInfo einfo;
+  einfo.format = io::kWeighted;
+  einfo.type = "e";
+  GraphStore* all[3] = {&whole, &shard[0], &shard[1]};
+  for (GraphStore* s : all) s->GetGraph("e")->SetSideInfo(&einfo);
+  std::mt19937_64 rng(11);
+  for (int e = 0; e < 900; ++e) {
+    io::EdgeValue v;
+    v.src_id = (int64_t)(rng() % 60);
+    v.dst_id = (int64_t)(rng() % 60);
+    v.weight = 0.01f + (float)(rng() % 1000) / 1000.0f + e * 1e-6f;
+    whole.GetGraph("e")->Add(&v);
+    shard[v.src_id % 2].GetGraph("e")->Add(&v);
+  }
+  IndexOption opt;
+  opt.name = "sort";
+  for (GraphStore* s : all) EXPECT_TRUE(s->GetGraph("e")->Build(opt).ok());
+  const std::vector<int64_t> seeds = {3, 17, 40, 41, 3, 999};
+  OpFactory::GetInstance()->Set(&whole);
+  SubGraphRequest wreq("e", {4, 2}, true);
+  wreq.Set(seeds.data(), (int32_t)seeds.size());
+  SubGraphResponse want;
+  EXPECT_TRUE(OpFactory::GetInstance()->Create("SubGraphSampler")->Process(&wreq, &want).ok());
+  EXPECT_TRUE(want.NodeCount() > (int32_t)seeds.size() && want.EdgeCount() > 0);
+  bool ok[2] = {true, true};
+  std::string why[2];
+  auto server = [&](int r) {
+    glx_comm* comm = nullptr;
+    if (glx_comm_init_local(77120, 0, r, 2, &comm) != GLX_OK) {
+      ok[r] = false;
+      why[r] = glx_last_error();
+      return;
+    }
+    {
+      Env env(comm, &shard[r]);
+      Operator* op = OpFactory::GetInstance()->Create("SubGraphSampler");
+      std::unique_ptr<OpRunner> runner = GetOpRunner(&env, op);
+      SubGraphRequest req("e", {4, 2}, true);
+      req.Set(seeds.data(), (int32_t)seeds.size());
+      SubGraphResponse res;
+      Status s = runner->Run(&req, &res);
+      if (!s.ok()) {
+        ok[r] = false;
+        why[r] = s.ToString();
+      } else if (res.NodeCount() != want.NodeCount() || res.EdgeCount() != want.EdgeCount()) {
+        ok[r] = false;
+        why[r] = "sizes differ";
+      } else {
+        for (int32_t i = 0; i < want.NodeCount() && ok[r]; ++i) {
+          if (res.NodeIds()[i] != want.NodeIds()[i] || res.DistToSrc()[i] != want.DistToSrc()[i] ||
+              res.DistToDst()[i] != want.DistToDst()[i]) {
+            ok[r] = false;
+            why[r] = "node list / distances differ";
+          }
+        }
+        for (int32_t i = 0; i < want.EdgeCount() && ok[r]; ++i) {
+          if (res.RowIndices()[i] != want.RowIndices()[i] || res.ColIndices()[i] != want.ColIndices()[i]) {
+            ok[r] = false;
+            why[r] = "induced edges differ";
+          }
+        }
+      }
+    }
+    glx_comm_destroy(comm);
+  };
+  std::thread t0(server, 0), t1(server, 1);
+  t0.join();
+  t1.join();
+  for (int r = 0; r < 2; ++r) {
+    if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
+    EXPECT_TRUE(ok[r]);
+  }
+}
+
 TEST(PartitionStitchTest, AServerWithoutEdgesOfATypeStillServes) {
   GraphStore whole, shard[2];
   io::SideInfo einfo;

@@ -111,3 +111,28 @@ def test_every_entry_point_cites_the_reference_interface_it_replaces():
                "glx_features_destroy", "glx_features_info", "glx_negative_destroy", "glx_negative_info",
                "glx_profile_collect"}
     assert set(uncited) <= allowed, sorted(set(uncited) - allowed)
+
+
+def test_host_mirror_registers_every_reference_operator_name():
+    """The registry names of the reference (REGISTER_OPERATOR in graphlearn/src/core/operator/**: 27 of them) without
+    UpdateEdges / UpdateNodes (loader plumbing: the mirror's loader fills the stores directly) -- a request by any of
+    these names must find an operator (OpFactory::Create, op_factory.cc:36-66)."""
+    want = {"RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "TopkSampler", "InDegreeSampler",
+            "FullSampler", "RandomNegativeSampler", "InDegreeNegativeSampler", "SoftInDegreeNegativeSampler",
+            "NodeWeightNegativeSampler", "ConditionalNegativeSampler", "SubGraphSampler", "RandomWalk",
+            "SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator",
+            "LookupNodes", "LookupEdges", "GetNodes", "GetEdges", "GetDegree", "GetCount", "GetStats"}
+    have = set()
+    src_dir = os.path.join(ROOT, "graph-learn_amd", "host", "src")
+    for f in os.listdir(src_dir):
+        text = open(os.path.join(src_dir, f)).read()
+        have.update(re.findall(r'REGISTER_OPERATOR\("(\w+)"', text))
+        have.update(re.findall(r"DEFINE_AGGREGATOR\((\w+),", text))
+    assert want <= have, sorted(want - have)
+    if os.path.isdir("/root/reference/graphlearn/src/core/operator"):
+        ref = set()
+        for root, _, files in os.walk("/root/reference/graphlearn/src/core/operator"):
+            for f in files:
+                if f.endswith(".cc"):
+                    ref.update(re.findall(r'REGISTER_OPERATOR\(\s*"(\w+)"', open(os.path.join(root, f)).read()))
+        assert ref - {"UpdateEdges", "UpdateNodes"} == want, sorted(ref ^ want)
