@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
 // bookkeeping in registers -- w_t = "value found at position t when step t ran" -- with fully
 // unrolled compares, and reads off its own entry: perm_l = value at position r_l before
 // step l.  ~W^2 VALU compares instead of 3k serialised ds_bpermute round trips.
-template <int W>
+template <int W, int K>
 __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
   const int lane = threadIdx.x & 63;
   const int l = lane & (W - 1);
@@ -215,11 +215,15 @@ __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
     const uint32_t rr = a.rng_rows ? (uint32_t)a.rng_rows[i] : (uint32_t)i;
     r = l + (int32_t)glx_bounded(glx_draw64(a.seed, sample_cc(a), rr, (uint32_t)l), (uint64_t)(deg - l));
   }
-  int32_t rs[W], ws[W];
+  // Only the first k steps exist (lanes and entries k .. W-1 are never read below): K = k is a template parameter and
+  // the unrolled loops stop there instead of at W -- for k = 10 in the W = 16 shape that is 45 + 10 compare/select pairs and 10
+  // cross-lane reads instead of 120 + 16 and 16, and this kernel is VALU-bound (C2 hop 2: ~500 lane-instructions per
+  // slot group before, 0.234 ms; see profiles/r03/SUMMARY.md).
+  int32_t rs[K], ws[K];
 #pragma unroll
-  for (int t = 0; t < W; ++t) rs[t] = __shfl(r, base + t);
+  for (int t = 0; t < K; ++t) rs[t] = __shfl(r, base + t);
 #pragma unroll
-  for (int t = 0; t < W; ++t) {
+  for (int t = 0; t < K; ++t) {
     int32_t v = t;
 #pragma unroll
     for (int u = 0; u < t; ++u) v = (rs[u] == t) ? ws[u] : v;  // ascending u: the latest step wins
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
   }
   int32_t perm = r;
 #pragma unroll
-  for (int u = 0; u < W; ++u) perm = (u < l && rs[u] == r) ? ws[u] : perm;
+  for (int u = 0; u < K; ++u) perm = (u < l && rs[u] == r) ? ws[u] : perm;
   // Slot l of the row: circular_padder.h:46-63 with indices_ = the permutation.
   const bool has_slot = l < a.k;
   const int32_t c = (has_slot && m > 0) ? l % m : 0;
@@ -308,8 +312,37 @@ void launch_slots(const SampleArgs& a, hipStream_t s) {
 template <int W>
 void launch_rwor(const SampleArgs& a, hipStream_t s) {
   const int64_t threads = (int64_t)a.batch * W;
-  if (W <= 16) glx_rwor_small_kernel<(W <= 16 ? W : 16)><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
-  else glx_rwor_kernel<W><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+  glx_rwor_kernel<W><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+}
+
+// k <= 16: one instantiation per k (the unrolled bookkeeping is k^2 / 2 compares: stopping at k instead of at the lane
+// group's width is the difference between VALU-bound and not)
+template <int K>
+void launch_rwor_small(const SampleArgs& a, hipStream_t s) {
+  constexpr int W = K <= 8 ? 8 : 16;
+  const int64_t threads = (int64_t)a.batch * W;
+  glx_rwor_small_kernel<W, K><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+}
+
+void launch_rwor_small_k(const SampleArgs& a, hipStream_t s) {
+  switch (a.k) {
+    case 1: launch_rwor_small<1>(a, s); break;
+    case 2: launch_rwor_small<2>(a, s); break;
+    case 3: launch_rwor_small<3>(a, s); break;
+    case 4: launch_rwor_small<4>(a, s); break;
+    case 5: launch_rwor_small<5>(a, s); break;
+    case 6: launch_rwor_small<6>(a, s); break;
+    case 7: launch_rwor_small<7>(a, s); break;
+    case 8: launch_rwor_small<8>(a, s); break;
+    case 9: launch_rwor_small<9>(a, s); break;
+    case 10: launch_rwor_small<10>(a, s); break;
+    case 11: launch_rwor_small<11>(a, s); break;
+    case 12: launch_rwor_small<12>(a, s); break;
+    case 13: launch_rwor_small<13>(a, s); break;
+    case 14: launch_rwor_small<14>(a, s); break;
+    case 15: launch_rwor_small<15>(a, s); break;
+    default: launch_rwor_small<16>(a, s); break;
+  }
 }
 
 int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padding_mode,
@@ -358,10 +391,8 @@ int sample_device(const glx_graph* g, int sampler, const SampleArgs& a, int padd
       if (!circular) {
         // ReplicatePadder discards the shuffle: first min(k, deg) in row order.
         launch_slots<kSlotReplicate>(a, s);
-      } else if (a.k <= 8) {
-        launch_rwor<8>(a, s);
       } else if (a.k <= 16) {
-        launch_rwor<16>(a, s);
+        launch_rwor_small_k(a, s);
       } else if (a.k <= 32) {
         launch_rwor<32>(a, s);
       } else if (a.k <= 64) {
