@@ -1231,13 +1231,17 @@ def main():
         cf = bytes_alg / (ms * 1e-3) / 1e9
         roof["cache_free"] = {"rows": "uniform over all %d rows: no reuse a cache could serve, so the algorithmic bytes ARE the "
                                       "HBM traffic (checked with FETCH_SIZE / WRITE_SIZE: profiles/r02/SUMMARY.md)" % V,
+                              "table_gb": V * D * 4 / 1e9,
+                              "infinity_cache_share_upper_bound": min(1.0, 0.256 / (V * D * 4 / 1e9)),
                               "avg_launch_ms": ms, "launches_timed": 5, "achieved": cf, "frac": cf / HBM_PEAK_GBS,
                               "frac_of_measured_stream_peak": min(1.0, cf / best)}
         # the roofline fraction of the kernel: same kernel, same request shape, measured in this run, on the input
         # where bytes moved are known exactly
         roof["frac"] = cf / HBM_PEAK_GBS
         roof["frac_basis"] = ("cache-free leg of this run: the same kernel on the same request shape with ids uniform over the "
-                              "table (algorithmic bytes == HBM traffic) / 8 TB/s; the timed launches themselves run %.2fx "
+                              "table (algorithmic bytes == memory-side traffic; at most the 256 MB Infinity Cache's share of the "
+                              "table -- cache_free.infinity_cache_share_upper_bound -- can be on-die hits) / 8 TB/s; the timed "
+                              "launches themselves run %.2fx "
                               "faster than that because hub rows are re-read from cache (algorithmic_over_peak), and their "
                               "HBM traffic is only bounded in-run (frac_compulsory) or known offline (frac_traffic_offline)"
                               % (ms / avg_agg2_ms))
