@@ -834,9 +834,14 @@ def main():
     # at most one step ahead.
     pipelined = args.pipeline == "on" or (args.pipeline == "auto" and sharded)
     bufs = []
+    both_ids = []  # per buffer set: the hop-2 neighbours followed by the hop-1 neighbours, one allocation
     for _ in range((3 if sharded else 2) if pipelined else 1):
-        b1 = torch.empty((B0, k1), dtype=torch.int64, device=dev)
-        b2 = torch.empty((n1, k2), dtype=torch.int64, device=dev)
+        # hop-2 and hop-1 neighbour ids back to back: the partitioned aggregation resolves and fetches both with ONE
+        # glx_dist_aggregate_begin (one count exchange, one deduplicated halo fetch) and reduces them as two ranges
+        both = torch.empty(n2 + n1, dtype=torch.int64, device=dev)
+        b2 = both[:n2].view(n1, k2)
+        b1 = both[n2:].view(B0, k1)
+        both_ids.append(both)
         bufs.append((b1, torch.empty_like(b1), b2, torch.empty_like(b2)))
 
     def do_sample(i):
@@ -853,9 +858,8 @@ def main():
     def halo_begin(a, b, i):
         # the collective half of the two aggregations: ids are resolved (replica / own shard / halo) and the halo
         # rows fetched from their owners -- on its own stream, beside the previous step's reduce and the next
-        # step's sampling
-        st_agg.aggregate_begin(2 * (i % 3), b.view(-1))
-        st_agg.aggregate_begin(2 * (i % 3) + 1, a.view(-1))
+        # step's sampling.  ONE request for both id sets (they sit back to back: both_ids)
+        st_agg.aggregate_begin(i % 3, both_ids[i % len(both_ids)])
 
     # A dense sampler response implies its segments (segment i = the neighbours of request row i):
     # segment_ids = None skips the segment bookkeeping kernels and the read of a segment tensor.
@@ -867,8 +871,8 @@ def main():
 
     def agg_halo(a, b, i):
         # the local half: the segmented reduce over own shard + hot-row replica + the halo rows begun above
-        st_agg.aggregate_end(2 * (i % 3), agg, None, n1, out=(emb2, cnt2))
-        st_agg.aggregate_end(2 * (i % 3) + 1, agg, None, B0, out=(emb1, cnt1))
+        st_agg.aggregate_end_range(i % 3, 0, n2, agg, None, n1, out=(emb2, cnt2))
+        st_agg.aggregate_end_range(i % 3, n2, n1, agg, None, B0, out=(emb1, cnt1), release=True)
 
     if pipelined:
         # the sampling and halo-prefetch stages are chains of short kernels beside the long reduce; serving their queues
@@ -887,12 +891,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_leg(do_aggregate, steps_from, steps_to, warm):
-        """Times steps [steps_from, steps_to) after `warm` untimed ones; -> (seconds, t_agg, t_smp)."""
+    def timed_leg(do_aggregate, steps_from, steps_to, warm, serial=False):
+        """Times steps [steps_from, steps_to) after `warm` untimed ones; -> (seconds, t_agg, t_smp).  serial: every
+        kernel and every collective of a step on ONE stream, in program order."""
         agg_done = []
 
         def step(i):
-            if not pipelined:
+            if serial or not pipelined:
                 a, b = do_sample(i)
                 do_aggregate(a, b, i)
                 return
@@ -1069,7 +1074,7 @@ def main():
 
         def give_up(reason=None):
             # the headline placement if it finished; otherwise the other placement, named as such
-            for name in ("features_sharded", "features_replicated"):
+            for name in ("features_sharded", "features_replicated", "features_sharded_serial"):
                 if name in legs:
                     best = name
                     break
@@ -1107,7 +1112,24 @@ def main():
                     give_up("%s leg failed on rank 0: %r" % (name, ex))
                 time.sleep(args.watchdog + 30)
                 os._exit(4)
-        # the other end of the placement space first (it shares the sampling exchanges but has no halo step):
+        # First a short SERIAL leg of the headline placement (all kernels and all collectives of a step on one stream, in
+        # program order: the most conservative way to drive two communicators): should the concurrent stages of the
+        # pipelined legs below ever wedge on real links -- RCCL with more than one rank has never run under this code --
+        # the watchdog still has a measured, labelled number of north_star's placement to report.
+        if world > 1 or args.force_sharded:
+            def flat(a, b, i):
+                halo_begin(a, b, i)
+                agg_halo(a, b, i)
+            ns = min(args.steps, 5)
+            el_0, _, _ = guarded("features_sharded_serial",
+                                 lambda: timed_leg(flat, args.warmup, args.warmup + ns, min(args.warmup, 2), serial=True))
+            legs["features_sharded_serial"] = {"ms_per_step": el_0 / ns * 1e3, "value": world * edges_per_step * ns / el_0,
+                                               "steps": ns, "note": "unpipelined: one stream, stages back to back"}
+            dog.cancel()
+            dog = threading.Timer(args.watchdog, give_up)
+            dog.daemon = True
+            dog.start()
+        # the other end of the placement space next (it shares the sampling exchanges but has no halo step):
         # a fault in the halo leg then still leaves a measured, labelled number
         if replica is not None:
             el_r, ta_r, ts_r = guarded("features_replicated",

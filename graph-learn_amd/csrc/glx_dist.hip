@@ -1718,24 +1718,35 @@ extern "C" int glx_dist_aggregate_begin(glx_dist_store* st, int32_t slot, const 
   return GLX_OK;
 }
 
-extern "C" int glx_dist_aggregate_end(glx_dist_store* st, int32_t slot, int op, const int32_t* segment_ids,
-                                      int32_t num_segments, float* emb_out, int32_t* cnt_out, void* stream) {
+extern "C" int glx_dist_aggregate_end_range(glx_dist_store* st, int32_t slot, int32_t first_id, int32_t num_ids, int release,
+                                            int op, const int32_t* segment_ids, int32_t num_segments, float* emb_out,
+                                            int32_t* cnt_out, void* stream) {
   GLX_REQUIRE(st != nullptr, "store is NULL");
   GLX_REQUIRE(slot >= 0 && slot < GLX_DIST_SLOTS, "slot %d outside [0, %d)", slot, GLX_DIST_SLOTS);
   GLX_REQUIRE(op >= GLX_AGG_SUM && op <= GLX_AGG_PROD, "unknown aggregator id %d", op);
   glx_dist_store::Slot& sl = st->slots[slot];
   GLX_REQUIRE(sl.num_ids >= 0, "slot %d holds no begun request", slot);
+  GLX_REQUIRE(first_id >= 0 && num_ids >= 0 && (int64_t)first_id + num_ids <= sl.num_ids,
+              "ids [%d, %d + %d) outside the begun request of %d ids", first_id, first_id, num_ids, sl.num_ids);
   GLX_REQUIRE(num_segments >= 0 && (int64_t)num_segments * st->feats->dim <= INT32_MAX, "bad num_segments");
   GLX_REQUIRE(num_segments == 0 || (emb_out && cnt_out), "NULL output pointer");
-  GLX_REQUIRE(segment_ids != nullptr || num_segments == 0 || sl.num_ids % num_segments == 0,
+  GLX_REQUIRE(segment_ids != nullptr || num_segments == 0 || num_ids % num_segments == 0,
               "segment_ids == NULL means equal segments: num_ids must be a multiple of num_segments");
   GlxDeviceGuard guard(st->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
-  const int32_t n = sl.num_ids;
-  sl.num_ids = -1;
+  if (release) sl.num_ids = -1;
   if (num_segments == 0) return GLX_OK;
-  return glx_aggregate_vrows_device(sl.src, 3, st->feats->dim, op, sl.loc, segment_ids, n, num_segments, sl.default_attr,
-                                    emb_out, cnt_out, glx_stream(stream));
+  return glx_aggregate_vrows_device(sl.src, 3, st->feats->dim, op, sl.loc + first_id, segment_ids, num_ids, num_segments,
+                                    sl.default_attr, emb_out, cnt_out, glx_stream(stream));
+}
+
+extern "C" int glx_dist_aggregate_end(glx_dist_store* st, int32_t slot, int op, const int32_t* segment_ids,
+                                      int32_t num_segments, float* emb_out, int32_t* cnt_out, void* stream) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  GLX_REQUIRE(slot >= 0 && slot < GLX_DIST_SLOTS, "slot %d outside [0, %d)", slot, GLX_DIST_SLOTS);
+  GLX_REQUIRE(st->slots[slot].num_ids >= 0, "slot %d holds no begun request", slot);
+  return glx_dist_aggregate_end_range(st, slot, 0, st->slots[slot].num_ids, 1, op, segment_ids, num_segments, emb_out, cnt_out,
+                                      stream);
 }
 
 extern "C" int glx_dist_lookup(glx_dist_store* st, const int64_t* node_ids, int64_t n, float default_attr,

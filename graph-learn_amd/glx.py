@@ -54,7 +54,7 @@ EXPORTS = [
     "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full", "glx_dist_random_walk",
     "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
-    "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_partial", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_lookup",
+    "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_partial", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_aggregate_end_range", "glx_dist_lookup",
     "glx_dist_last_stats",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
     "glx_probe_bandwidth", "glx_subgraph_induce",
@@ -191,6 +191,7 @@ def lib():
         L.glx_dist_lookup.argtypes = [vp, vp, i64, f32, vp, ci, vp]
         L.glx_dist_aggregate_begin.argtypes = [vp, i32, vp, i32, f32, vp]
         L.glx_dist_aggregate_end.argtypes = [vp, i32, ci, vp, i32, vp, vp, vp]
+        L.glx_dist_aggregate_end_range.argtypes = [vp, i32, i32, i32, ci, ci, vp, i32, vp, vp, vp]
         L.glx_dist_last_stats.argtypes = [vp, ctypes.POINTER(DistStats)]
         L.glx_plan_create.argtypes = [vp, i32, ci, vp, i32, ci, i64, u64, vp, ci, f32, ctypes.POINTER(vp)]
         L.glx_plan_run.argtypes = [vp, vp, u64, vp]
@@ -534,6 +535,17 @@ class Features:
         kind = _kind(pi, pg, pe, pc)
         _check(lib().glx_aggregate(self._h, op, pi[0], pg[0], n, num_segments, default_attr, pe[0],
                                    pc[0], kind, _stream(kind, self.device)))
+        return emb, cnt
+
+    def aggregate_end_range(self, slot, first_id, num_ids, op, segment_ids, num_segments, out, release=False):
+        """The reduce over ids [first_id, first_id + num_ids) of the request begun in `slot` (one begin, several
+        aggregating requests: glx_dist_aggregate_end_range); release=True ends the slot's request."""
+        if isinstance(op, str):
+            op = AGGREGATOR_IDS[op]
+        emb, cnt = out
+        _check(lib().glx_dist_aggregate_end_range(self._h, slot, int(first_id), int(num_ids), 1 if release else 0, op,
+                                                  _ptr(segment_ids)[0], num_segments, _ptr(emb)[0], _ptr(cnt)[0],
+                                                  _stream(PTR_DEVICE, self.comm.device)))
         return emb, cnt
 
     def lookup(self, node_ids, default_attr=0.0):

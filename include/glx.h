@@ -562,6 +562,12 @@ GLX_API int glx_dist_aggregate_begin(glx_dist_store* st, int32_t slot, const int
                                      float default_attr, void* stream);
 GLX_API int glx_dist_aggregate_end(glx_dist_store* st, int32_t slot, int op, const int32_t* segment_ids,
                                    int32_t num_segments, float* emb_out, int32_t* cnt_out, void* stream);
+/* ABI 3.  The reduce over ids [first_id, first_id + num_ids) of the request begun in `slot`: ONE _begin (one count
+ * exchange, one deduplicated halo fetch) can serve several aggregating requests whose ids were handed over back to back
+ * -- the hop-2 and the hop-1 neighbours of one sampling step.  release != 0 ends the slot's request (as _end does). */
+GLX_API int glx_dist_aggregate_end_range(glx_dist_store* st, int32_t slot, int32_t first_id, int32_t num_ids, int release,
+                                         int op, const int32_t* segment_ids, int32_t num_segments, float* emb_out,
+                                         int32_t* cnt_out, void* stream);
 /* Collective.  LookupNodes in distributed mode (node_lookuper.cc:24-52 behind
  * DistributeRunner): out[n * dim] rows of ids owned by any shard. */
 GLX_API int glx_dist_lookup(glx_dist_store* st, const int64_t* node_ids, int64_t n, float default_attr,

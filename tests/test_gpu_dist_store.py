@@ -215,6 +215,24 @@ def test_dist_aggregate_equals_unpartitioned(world, P, cache, monkeypatch):
         assert torch.equal(out2[0].view(torch.int32), r2.view(torch.int32)), r
         with pytest.raises(glx.GlxError, match="no begun request"):
             st.aggregate_end(2, "MaxAggregator", None, n // f, out2)
+        # ONE begin for two aggregating requests whose ids sit back to back (a step's hop-2 and hop-1 neighbours):
+        # one count exchange, one deduplicated halo fetch, two reduces over sub-ranges
+        both = torch.cat([ids, ids_b[: n // 2]])
+        st.aggregate_begin(4, both, default_attr=0.5)
+        oa = (torch.empty((n // f, D), dtype=torch.float32, device=dev), torch.empty(n // f, dtype=torch.int32, device=dev))
+        ob = (torch.empty((n // 2 // 5, D), dtype=torch.float32, device=dev), torch.empty(n // 2 // 5, dtype=torch.int32, device=dev))
+        st.aggregate_end_range(4, 0, n, "MaxAggregator", None, n // f, oa)
+        st.aggregate_end_range(4, n, n // 2, "SumAggregator", None, n // 2 // 5, ob, release=True)
+        ra, rca = feats.aggregate("MaxAggregator", ids, None, n // f, default_attr=0.5)
+        rb, rcb = feats.aggregate("SumAggregator", ids_b[: n // 2].contiguous(), None, n // 2 // 5, default_attr=0.5)
+        assert torch.equal(oa[0].view(torch.int32), ra.view(torch.int32)) and torch.equal(oa[1], rca), r
+        assert torch.equal(ob[0].view(torch.int32), rb.view(torch.int32)) and torch.equal(ob[1], rcb), r
+        with pytest.raises(glx.GlxError, match="no begun request"):
+            st.aggregate_end_range(4, 0, n, "MaxAggregator", None, n // f, oa)
+        st.aggregate_begin(4, ids, default_attr=0.5)
+        with pytest.raises(glx.GlxError, match="outside the begun request"):
+            st.aggregate_end_range(4, n - 5, 10, "MaxAggregator", None, 1, oa)
+        st.aggregate_end(4, "MaxAggregator", None, n // f, oa)
         # equal segments without a segment tensor (a dense sampler response), and ragged + stalled ones
         e, c = st.aggregate("MeanAggregator", ids, None, n // f, default_attr=0.5)
         ref_e, ref_c = feats.aggregate("MeanAggregator", ids, seg, n // f, default_attr=0.5)
