@@ -537,17 +537,6 @@ class Features:
                                    pc[0], kind, _stream(kind, self.device)))
         return emb, cnt
 
-    def aggregate_end_range(self, slot, first_id, num_ids, op, segment_ids, num_segments, out, release=False):
-        """The reduce over ids [first_id, first_id + num_ids) of the request begun in `slot` (one begin, several
-        aggregating requests: glx_dist_aggregate_end_range); release=True ends the slot's request."""
-        if isinstance(op, str):
-            op = AGGREGATOR_IDS[op]
-        emb, cnt = out
-        _check(lib().glx_dist_aggregate_end_range(self._h, slot, int(first_id), int(num_ids), 1 if release else 0, op,
-                                                  _ptr(segment_ids)[0], num_segments, _ptr(emb)[0], _ptr(cnt)[0],
-                                                  _stream(PTR_DEVICE, self.comm.device)))
-        return emb, cnt
-
     def lookup(self, node_ids, default_attr=0.0):
         n = int(node_ids.shape[0])
         if _is_torch(node_ids):
@@ -982,6 +971,17 @@ class DistStore:
         emb, cnt = out
         _check(lib().glx_dist_aggregate_end(self._h, slot, op, _ptr(segment_ids)[0], num_segments, _ptr(emb)[0],
                                             _ptr(cnt)[0], _stream(PTR_DEVICE, self.comm.device)))
+        return emb, cnt
+
+    def aggregate_end_range(self, slot, first_id, num_ids, op, segment_ids, num_segments, out, release=False):
+        """The reduce over ids [first_id, first_id + num_ids) of the request begun in `slot` (one begin, several
+        aggregating requests: glx_dist_aggregate_end_range); release=True ends the slot's request."""
+        if isinstance(op, str):
+            op = AGGREGATOR_IDS[op]
+        emb, cnt = out
+        _check(lib().glx_dist_aggregate_end_range(self._h, slot, int(first_id), int(num_ids), 1 if release else 0, op,
+                                                  _ptr(segment_ids)[0], num_segments, _ptr(emb)[0], _ptr(cnt)[0],
+                                                  _stream(PTR_DEVICE, self.comm.device)))
         return emb, cnt
 
     def lookup(self, node_ids, default_attr=0.0):
