@@ -8,9 +8,13 @@
 // the per-row alias builder of the graph storage (glx_alias_build_launch: bit-identical to alias_method.cc:57-107).
 // The default table is one more alias row over all candidates.
 //
-// Sampling is inherently sequential across the rows of a request: the reference's exclusion set (nbr_set) is declared
-// before the row loop and never cleared, so row i rejects the neighbours and dst ids of rows 0..i (and, with `unique`,
-// everything accepted so far).  One wave therefore walks the rows in order and is parallel inside a row:
+// The reference's exclusion set (nbr_set) is declared before the row loop and never cleared, so row i rejects the
+// neighbours and dst ids of rows 0..i -- and, with `unique`, everything accepted so far.
+//   * Without `unique` the set at row i is known up front: pass 1 records, per id, the FIRST row that inserts it; pass 2
+//     samples one row per wave, "in the set" = "first row <= mine".  Should a row exhaust its default-sampling retries
+//     -- where the reference drops the set for every later row -- the request is replayed sequentially.
+//   * With `unique` the rows depend on each other by definition: one wave walks them in order.
+// Inside a row either way:
 //   * the set is an open-addressing table in HBM sized for everything the request can insert; lanes insert the
 //     neighbours of src i with atomicCAS and probe with device-scope atomic loads (L2-coherent inside the wave);
 //   * the candidates of a block are evaluated one per lane; acceptance in the reference's order is a ballot + prefix
@@ -20,6 +24,7 @@
 //     entry is looked at (attribute_nodes_map.h:109-125).
 // The reference's fill loop is dead code (it derives "how many do I have" from the static response shape); here it runs
 // as written.
+#include <stdlib.h>
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
@@ -110,6 +115,42 @@ __device__ __forceinline__ bool set_has(const int64_t* tab, uint64_t mask, int64
   }
 }
 
+// ---- the exclusion set of a request WITHOUT `unique`, as a function of the row --------------------------------
+// Without `unique` nothing a row samples enters the set, so what row i rejects is known before any row samples: the
+// neighbours and dst ids of rows 0..i (all dst ids when batch_share).  One table maps an id to the FIRST row that
+// inserts it; "in the set at row i" = "first row <= i".  Rows then sample independently, one wave each -- unless a
+// row exhausts its default-sampling retries, where the reference drops the whole set for every later row
+// (nbr_set.clear()): such a request is replayed by the sequential kernel.
+struct FirstEnt {
+  int64_t key;
+  int64_t row;
+};
+
+__device__ __forceinline__ void first_insert(FirstEnt* tab, uint64_t mask, int64_t v, int64_t row) {
+  if (v == GLX_EMPTY_KEY) return;
+  uint64_t h = glx_mix64((uint64_t)v) & mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[h].key),
+                                              (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)v);
+    if ((int64_t)prev == GLX_EMPTY_KEY || (int64_t)prev == v) {
+      atomicMin(reinterpret_cast<long long*>(&tab[h].row), (long long)row);
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ bool first_has(const FirstEnt* tab, uint64_t mask, int64_t v, int64_t row) {
+  if (v == GLX_EMPTY_KEY) return false;
+  uint64_t h = glx_mix64((uint64_t)v) & mask;
+  while (true) {
+    const FirstEnt e = tab[h];  // complete before the sampling kernel starts: plain loads
+    if (e.key == v) return e.row <= row;
+    if (e.key == GLX_EMPTY_KEY) return false;
+    h = (h + 1) & mask;
+  }
+}
+
 struct CondArgs {
   const int64_t* ids;
   const int64_t* member;
@@ -136,11 +177,16 @@ struct CondArgs {
   uint64_t seed, cc;
   int64_t* set;
   uint64_t set_mask;
+  // parallel rows (no `unique`): first-insertion table + "a row wanted to drop the set" flag
+  FirstEnt* first;
+  uint64_t first_mask;
+  int* replay;
   int64_t* out;
 };
 
 // Evaluates up to `look` candidates of one block (draws first_draw + j) from an alias row `tab` of `n` members whose
 // ids are members[0..n) and accepts them in order against the set.  Returns through got/taken.
+template <bool PAR>
 __device__ __forceinline__ void cond_block(const CondArgs& a, int lane, int32_t row, uint32_t first_draw, int32_t look,
                                            const int64_t* members, const GlxAlias* tab, int64_t n, int32_t want,
                                            int64_t* orow, int32_t& got, int32_t& taken) {
@@ -152,9 +198,9 @@ __device__ __forceinline__ void cond_block(const CondArgs& a, int lane, int32_t 
     if (active) {
       const uint64_t u = glx_draw64(a.seed, a.cc, (uint32_t)row, first_draw + (uint32_t)j);
       item = members[glx_alias_pick(u, n, tab)];
-      ok = !set_has(a.set, a.set_mask, item);
+      ok = PAR ? !first_has(a.first, a.first_mask, item, row) : !set_has(a.set, a.set_mask, item);
     }
-    if (a.unique) {
+    if (!PAR && a.unique) {
       // an id equal to an earlier candidate of this chunk: that one was not in the set either, so it was accepted (or
       // the row was already full) and this one is a repeat
       bool dup = false;
@@ -171,7 +217,7 @@ __device__ __forceinline__ void cond_block(const CondArgs& a, int lane, int32_t 
     if (fin) {
       const int32_t pos = taken + rank;
       if (pos < a.count) orow[pos] = item;
-      if (a.unique) set_insert(a.set, a.set_mask, item);
+      if (!PAR && a.unique) set_insert(a.set, a.set_mask, item);
     }
     int32_t acc = (int32_t)__popcll(m);
     if (acc > want - got) acc = want - got;
@@ -180,6 +226,63 @@ __device__ __forceinline__ void cond_block(const CondArgs& a, int lane, int32_t 
   }
 }
 
+// One request row: the condition columns, then the default sampler, then default ids.
+template <bool PAR>
+__device__ __forceinline__ void cond_row(const CondArgs& a, int lane, int32_t i) {
+  int64_t* orow = a.out + (int64_t)i * a.count;
+  int32_t taken = 0;
+  uint32_t base = 0;
+  for (int32_t c = 0; c < a.ncols; ++c) {
+    const int32_t n = a.num_c[c];
+    if (n <= 0) continue;
+    const int64_t key = a.dst_keys[(int64_t)i * a.ncols + c];
+    const int64_t* gk = a.group_key + (int64_t)c * a.U;
+    const int64_t* go = a.group_off + (int64_t)c * (a.U + 1);
+    const int64_t G = a.num_groups[c];
+    int64_t lo = 0, hi = G;
+    while (lo < hi) {  // every lane the same search
+      const int64_t mid = (lo + hi) >> 1;
+      if (gk[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (key != GLX_EMPTY_KEY && lo < G && gk[lo] == key) {
+      const int64_t g0 = go[lo], gn = go[lo + 1] - g0;
+      const int64_t* members = a.member + (int64_t)c * a.U + g0;
+      const GlxAlias* tab = a.member_tab + (int64_t)c * a.U + g0;
+      int32_t got = 0;
+      for (int32_t blk = 0; blk < a.retry && got < n; ++blk) {
+        const int32_t look = (blk == a.retry - 1) ? 1 : n;  // the last block: its first entry only
+        cond_block<PAR>(a, lane, i, base + (uint32_t)(blk * n), look, members, tab, gn, n, orow, got, taken);
+      }
+    }
+    base += (uint32_t)a.retry * (uint32_t)n;
+  }
+  if (taken > a.count) taken = a.count;
+  // default sampling (conditional_negative_sampler.cc:128-152, as written)
+  if (a.U > 0) {
+    int32_t retry_times = a.retry + 1, blk = 0;
+    bool last = false;
+    while (taken < a.count && !last) {
+      if (--retry_times <= 0) {  // nbr_set.clear()
+        if (PAR) {  // the set changes for every later row: this request must be replayed row by row
+          if (lane == 0) *a.replay = 1;
+          return;
+        }
+        for (uint64_t h = lane; h <= a.set_mask; h += 64) {
+          __hip_atomic_store(&a.set[h], (int64_t)GLX_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (retry_times < 0) last = true;
+      int32_t got = taken;
+      cond_block<PAR>(a, lane, i, base + (uint32_t)(blk * a.count), last ? 1 : a.count, a.ids, a.default_tab, a.U, a.count,
+                      orow, got, taken);
+      taken = got;
+      ++blk;
+    }
+  }
+  for (int32_t j = taken + lane; j < a.count; j += 64) orow[j] = a.default_nbr;
+}
+
+// Sequential rows (the set evolves: `unique`, or a replay after a dropped set): ONE wave walks the request.
 __global__ __launch_bounds__(64) void glx_cond_sample_kernel(CondArgs a) {
   const int lane = threadIdx.x;
   if (a.batch_share) {
@@ -196,54 +299,38 @@ __global__ __launch_bounds__(64) void glx_cond_sample_kernel(CondArgs a) {
       }
       if (lane == 0) set_insert(a.set, a.set_mask, a.dst[i]);
     }
-    int64_t* orow = a.out + (int64_t)i * a.count;
-    int32_t taken = 0;
-    uint32_t base = 0;
-    for (int32_t c = 0; c < a.ncols; ++c) {
-      const int32_t n = a.num_c[c];
-      if (n <= 0) continue;
-      const int64_t key = a.dst_keys[(int64_t)i * a.ncols + c];
-      const int64_t* gk = a.group_key + (int64_t)c * a.U;
-      const int64_t* go = a.group_off + (int64_t)c * (a.U + 1);
-      const int64_t G = a.num_groups[c];
-      int64_t lo = 0, hi = G;
-      while (lo < hi) {  // every lane the same search
-        const int64_t mid = (lo + hi) >> 1;
-        if (gk[mid] < key) lo = mid + 1; else hi = mid;
-      }
-      if (key != GLX_EMPTY_KEY && lo < G && gk[lo] == key) {
-        const int64_t g0 = go[lo], gn = go[lo + 1] - g0;
-        const int64_t* members = a.member + (int64_t)c * a.U + g0;
-        const GlxAlias* tab = a.member_tab + (int64_t)c * a.U + g0;
-        int32_t got = 0;
-        for (int32_t blk = 0; blk < a.retry && got < n; ++blk) {
-          const int32_t look = (blk == a.retry - 1) ? 1 : n;  // the last block: its first entry only
-          cond_block(a, lane, i, base + (uint32_t)(blk * n), look, members, tab, gn, n, orow, got, taken);
-        }
-      }
-      base += (uint32_t)a.retry * (uint32_t)n;
-    }
-    if (taken > a.count) taken = a.count;
-    // default sampling (conditional_negative_sampler.cc:128-152, as written)
-    if (a.U > 0) {
-      int32_t retry_times = a.retry + 1, blk = 0;
-      bool last = false;
-      while (taken < a.count && !last) {
-        if (--retry_times <= 0) {  // nbr_set.clear()
-          for (uint64_t h = lane; h <= a.set_mask; h += 64) {
-            __hip_atomic_store(&a.set[h], (int64_t)GLX_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        if (retry_times < 0) last = true;
-        int32_t got = taken;
-        cond_block(a, lane, i, base + (uint32_t)(blk * a.count), last ? 1 : a.count, a.ids, a.default_tab, a.U, a.count,
-                   orow, got, taken);
-        taken = got;
-        ++blk;
-      }
-    }
-    for (int32_t j = taken + lane; j < a.count; j += 64) orow[j] = a.default_nbr;
+    cond_row<false>(a, lane, i);
   }
+}
+
+// Parallel rows (no `unique`): pass 1 records the first row that inserts every id, pass 2 samples one row per wave.
+__global__ __launch_bounds__(256) void glx_cond_first_kernel(CondArgs a) {
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= a.batch) return;
+  if (a.batch_share) {
+    if (lane == 0) first_insert(a.first, a.first_mask, a.dst[i], -1);  // in the set before row 0 samples
+    return;
+  }
+  if (a.has_graph) {
+    const int64_t r = glx_row_of(a.map, a.src[i]);
+    if (r >= 0) {
+      const int64_t s0 = a.row_ptr[r], s1 = a.row_ptr[r + 1];
+      for (int64_t e = s0 + lane; e < s1; e += 64) first_insert(a.first, a.first_mask, a.adj[e].nbr, i);
+    }
+  }
+  if (lane == 0) first_insert(a.first, a.first_mask, a.dst[i], i);
+}
+
+__global__ __launch_bounds__(256) void glx_cond_sample_rows_kernel(CondArgs a) {
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (i >= a.batch) return;
+  cond_row<true>(a, threadIdx.x & 63, (int32_t)i);
+}
+
+__global__ void glx_cond_fill_first_kernel(FirstEnt* p, int64_t n) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += step) p[i] = FirstEnt{GLX_EMPTY_KEY, INT64_MAX};
 }
 
 __global__ void glx_cond_degsum_kernel(GlxIdMap map, const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ src,
@@ -419,12 +506,6 @@ extern "C" int glx_cond_negative_sample(const glx_cond_table* t, const glx_graph
   uint64_t want = (uint64_t)batch * (uint64_t)(count + 1) + deg_total;
   uint64_t cap = 64;
   while (cap < 2 * want + 2) cap <<= 1;
-  GLX_HIP(hipMalloc(&d_set.p, (size_t)cap * 8));
-  {
-    int64_t blocks = ((int64_t)cap + 255) / 256;
-    glx_cond_fill_i64_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, s>>>(d_set.as<int64_t>(), (int64_t)cap,
-                                                                                      GLX_EMPTY_KEY);
-  }
   CondArgs a;
   memset(static_cast<void*>(&a), 0, sizeof(a));
   a.ids = t->ids;
@@ -454,10 +535,41 @@ extern "C" int glx_cond_negative_sample(const glx_cond_table* t, const glx_graph
   a.default_nbr = default_neighbor_id;
   a.seed = seed;
   a.cc = call_counter;
-  a.set = d_set.as<int64_t>();
-  a.set_mask = cap - 1;
   a.out = p_out;
-  glx_cond_sample_kernel<<<1, 64, 0, s>>>(a);
+  const unsigned row_grid = (unsigned)(((int64_t)batch * 64 + 255) / 256);
+  int replay = 1;
+  const bool force_seq = getenv("GLX_COND_SEQUENTIAL") != nullptr;  // A/B and test knob, read per call
+  if (!unique && !force_seq) {
+    // rows are independent given the first-insertion table: one wave per row
+    GlxTemp d_first, d_flag;
+    GLX_HIP(hipMalloc(&d_first.p, (size_t)cap * sizeof(FirstEnt)));
+    GLX_HIP(hipMalloc(&d_flag.p, sizeof(int)));
+    GLX_HIP(hipMemsetAsync(d_flag.p, 0, sizeof(int), s));
+    {
+      int64_t blocks = ((int64_t)cap + 255) / 256;
+      glx_cond_fill_first_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, s>>>(d_first.as<FirstEnt>(), (int64_t)cap);
+    }
+    a.first = d_first.as<FirstEnt>();
+    a.first_mask = cap - 1;
+    a.replay = d_flag.as<int>();
+    glx_cond_first_kernel<<<row_grid, 256, 0, s>>>(a);
+    glx_cond_sample_rows_kernel<<<row_grid, 256, 0, s>>>(a);
+    GLX_HIP(hipGetLastError());
+    GLX_HIP(hipMemcpyAsync(&replay, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+  }
+  if (replay) {
+    // `unique` (every accepted id joins the set), or a row of the parallel pass wanted to drop the set: row by row
+    GLX_HIP(hipMalloc(&d_set.p, (size_t)cap * 8));
+    int64_t blocks = ((int64_t)cap + 255) / 256;
+    glx_cond_fill_i64_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, s>>>(d_set.as<int64_t>(), (int64_t)cap,
+                                                                                      GLX_EMPTY_KEY);
+    a.first = nullptr;
+    a.replay = nullptr;
+    a.set = d_set.as<int64_t>();
+    a.set_mask = cap - 1;
+    glx_cond_sample_kernel<<<1, 64, 0, s>>>(a);
+  }
   GLX_HIP(hipGetLastError());
   if (ptr_kind == GLX_PTR_HOST) {
     GLX_HIP(hipMemcpyAsync(out, p_out, (size_t)batch * count * 8, hipMemcpyDeviceToHost, s));

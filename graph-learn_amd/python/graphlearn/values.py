@@ -16,6 +16,17 @@ _COLUMNS = ("int_attrs", "float_attrs", "string_attrs", "weights", "labels", "ti
 _PER_ELEMENT = ("weights", "labels", "timestamps")  # shape `shape`; attrs get a trailing axis
 
 
+def _ro(attr):
+  """A read-only attribute view (the reference spells these out as @property methods)."""
+  return property(lambda self: getattr(self, attr))
+
+
+def _rw(attr):
+  """A read-write attribute view."""
+  return property(lambda self: getattr(self, attr), lambda self, value: setattr(self, attr, value))
+
+
+
 class Values(object):
   """Columns of a batch of nodes or edges, viewed through `shape`."""
 
@@ -62,21 +73,9 @@ class Values(object):
           self._store(col, getattr(got, col))
     return self._cols.get(name)
 
-  @property
-  def shape(self):
-    return self._shape
+  shape = _rw('_shape')
 
-  @shape.setter
-  def shape(self, shape):
-    self._shape = shape
-
-  @property
-  def graph(self):
-    return self._graph
-
-  @graph.setter
-  def graph(self, graph):
-    self._graph = graph
+  graph = _rw('_graph')
 
 
 def _column_property(name):
@@ -101,13 +100,9 @@ class _Ragged(object):
     self._starts = np.concatenate([[0], np.cumsum(self._offsets)]).astype(np.int64)
     self._row = 0
 
-  @property
-  def offsets(self):
-    return self._offsets
+  offsets = _ro('_offsets')
 
-  @property
-  def dense_shape(self):
-    return self._dense_shape
+  dense_shape = _ro('_dense_shape')
 
   @property
   def indices(self):
@@ -158,17 +153,13 @@ class Nodes(Values):
   def _lookup(self):
     return self._graph.lookup_nodes(self._type, self._ids)
 
-  @property
-  def ids(self):
-    return self._ids
+  ids = _ro('_ids')
 
   @ids.setter
   def ids(self, ids):
     self._ids = self._view(ids)
 
-  @property
-  def type(self):  # pylint: disable=redefined-builtin
-    return self._type
+  type = _ro('_type')
 
   @type.setter
   def type(self, node_type):  # pylint: disable=redefined-builtin
@@ -304,9 +295,7 @@ class Edges(Values):
   dst_type = property(lambda self: self._dst_type)
   edge_type = property(lambda self: self._edge_type)
 
-  @property
-  def edge_ids(self):
-    return self._edge_ids
+  edge_ids = _ro('_edge_ids')
 
   @edge_ids.setter
   def edge_ids(self, edge_ids):

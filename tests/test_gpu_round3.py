@@ -148,7 +148,12 @@ def _cond_case(rng, U, ncols, n_users, deg, batch, hashed_ids):
 
 
 @pytest.mark.parametrize("trial", range(12))
-def test_conditional_negative_sampler_is_bit_identical_to_the_oracle(trial):
+@pytest.mark.parametrize("rows", ["parallel", "sequential"])
+def test_conditional_negative_sampler_is_bit_identical_to_the_oracle(trial, rows, monkeypatch):
+    """rows: without `unique` the rows of a request are sampled one wave each against the first-insertion table
+    (replayed row by row when a row drops the set); GLX_COND_SEQUENTIAL forces the one-wave walk `unique` always takes."""
+    if rows == "sequential":
+        monkeypatch.setenv("GLX_COND_SEQUENTIAL", "1")
     rng = np.random.default_rng(100 + trial)
     U = int(rng.choice([1, 2, 7, 60, 300]))
     ncols = int(rng.integers(0, 4))
