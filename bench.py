@@ -533,9 +533,9 @@ def verify_vs_oracle(args, wl, dev, seeds_last, out, call_counters):
 
 
 def other_configs(args):
-    """BASELINE configs[1] (c2) and configs[4] (c5) on this GPU, each in a process of its own (this one keeps the
-    headline's store resident until it exits), same --steps / --warmup: driver-timed numbers for the configs that
-    are not the headline."""
+    """BASELINE configs[1] (c2), configs[4] (c5) and configs[3] (c4: 111 M nodes / 1.6 B edges, here on ONE GPU) on this
+    GPU, each in a process of its own (the headline's store is released first), same --steps / --warmup: driver-timed
+    numbers for the configs that are not the headline."""
     import subprocess
     out = {}
     for name in [x for x in args.other_configs.split(",") if x.strip()]:
@@ -628,7 +628,7 @@ def main():
     ap.add_argument("--verify-oracle", default="on", choices=["on", "off"],
                     help="N=1: after timing, re-check the last timed step's outputs on row subsets against the oracle "
                          "(tests/headline_check.py) and emit \"verified_vs_oracle\"")
-    ap.add_argument("--other-configs", default="c2,c5",
+    ap.add_argument("--other-configs", default="c2,c5,c4",
                     help="N=1, headline workload at the default batch: also time these workloads (comma separated), each in a "
                          "process of its own, and report them under \"other_configs\"")
     ap.add_argument("--force-sharded", action="store_true",

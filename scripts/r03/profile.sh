@@ -9,7 +9,7 @@ cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 LEAN="--cpu-baseline off --host-boundary off --edge-cut-probe off --small-batches off --other-configs= --verify-oracle off"
-for wl in c3 c2 c5; do
+for wl in c3 c2 c5 c4; do
   B="python $R/bench.py --workload $wl $LEAN"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/${wl}_trace -o t -- $B --steps 20 --warmup 5 --roofline-probes off > $OUT/${wl}_bench_trace.json 2> $OUT/${wl}_trace.err
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/${wl}_fetch -o f -- $B --steps 5 --warmup 1 > $OUT/${wl}_bench_fetch.json 2> $OUT/${wl}_fetch.err

@@ -42,7 +42,7 @@ out = ["# r03 rocprofv3 summary (one MI355X)", "",
        "calibration on `glx_place_rows_kernel` is repeated below).  The driver's full command (`python bench.py --steps 20 "
        "--warmup 5`) ran first: `bench_c3_n1_final.json`.", ""]
 pmc_json = {}
-for wl in ("c3", "c2", "c5"):
+for wl in ("c3", "c2", "c5", "c4"):
     bench_path = os.path.join(SRC, "%s_bench_trace.json" % wl)
     if not os.path.exists(bench_path):
         continue
