@@ -543,6 +543,7 @@ def other_configs(args):
                "--warmup", str(args.warmup), "--cpu-baseline", "off", "--host-boundary", "off", "--edge-cut-probe", "off",
                "--small-batches", "off", "--other-configs", ""]
         t0 = time.time()
+        r = None
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
             rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -551,8 +552,9 @@ def other_configs(args):
                          "roofline_sampler": rec.get("roofline_sampler"), "verified_vs_oracle": rec.get("verified_vs_oracle"),
                          "wall_s": time.time() - t0}
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line
-            out[name] = {"error": repr(ex)}
-        log("other config %s: %s" % (name, {k: out[name].get(k) for k in ("ms_per_step", "value", "error")}))
+            out[name] = {"error": repr(ex), "returncode": getattr(r, "returncode", None),
+                         "stderr_tail": (r.stderr[-1500:] if r is not None and r.stderr else None)}
+        log("other config %s: %s" % (name, {k: out[name].get(k) for k in ("ms_per_step", "value", "error", "stderr_tail")}))
     return out
 
 
@@ -718,14 +720,20 @@ def main():
     # Storage build on the device (glx_graph_build: radix sorts + RLE + scan + alias
     # tables + id map); rows end up weight-descending like the reference's Build().
     t1 = time.time()
-    X = synth.features_torch(V, D, gseed + 1, dev)
     st_smp = st_agg = replica = whole = None
     hot = None
     if not sharded:
+        # the graph first, its edge list released, THEN the feature matrix: C4's build (1.6 B edges: sort temporaries) and
+        # its 57 GB of features + their staging copy would otherwise peak together
         graph = glx.Graph.from_edges(src, dst, weight, device=local_rank)
+        del src, dst, weight
+        src = dst = weight = None
+        torch.cuda.empty_cache()
+        X = synth.features_torch(V, D, gseed + 1, dev)
         feats = glx.Features(X, device=local_rank)
         placement = "1 GPU"
     else:
+        X = synth.features_torch(V, D, gseed + 1, dev)
         import dist as gdist
         if args.verify:
             whole = (glx.Graph.from_edges(src, dst, weight, device=local_rank), glx.Features(X, device=local_rank))
@@ -1360,6 +1368,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             small[str(b)] = {"ms_per_step": dt / reps * 1e3, "value": (b * k1 + b * k1 * k2) * reps / dt, "steps": reps}
+            for pl in plans:
+                pl.close()  # their output tensors would otherwise keep the plans -- and through them the store -- alive
             del plans, streams
         res["small_batches"] = dict(small, note="same store, B0 seeds per step, step = one hipGraph launch (glx_plan), %d plans "
                                                 "alternating on as many streams; value in edges/s" % args.graph_streams)
@@ -1368,7 +1378,11 @@ def main():
     if args.other_configs and not sharded and world == 1 and args.workload == "c3" and B0 == 65536:
         # free this process's store first: c5 needs most of the HBM for its build
         del graph, feats
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        log("before the other configs: %.1f of %.1f GB of HBM free in this process's view" % (free_b / 1e9, total_b / 1e9))
         res["other_configs"] = other_configs(args)
     if rank == 0:
         result_out.write(json.dumps(res) + "\n")

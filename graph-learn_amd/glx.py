@@ -1055,12 +1055,18 @@ class Plan:
         return self.hops
 
     def close(self):
+        """Frees the plan's device buffers and lets go of the stores it was captured over.  The output tensors keep their
+        plan alive through the array interface (a reference cycle that runs through torch's C++ side, which the garbage
+        collector cannot see): a caller that wants the memory back calls close() -- dropping the last Python name is not
+        enough."""
         if getattr(self, "_h", None):
             try:
                 lib().glx_plan_destroy(self._h)
             except Exception:  # interpreter shutdown
                 pass
             self._h = None
+        self.hops = []
+        self._keep = None
 
     __del__ = close
 
