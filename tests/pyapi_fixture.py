@@ -87,6 +87,17 @@ def write_relation_edges(directory, name, count=100):
     return path
 
 
+def write_cond_nodes(directory, name, count=200):
+    """id, weight 0.1 id, attributes "id % 5 : id % 4 : 0.3 id : str(id % 3)" (utils.gen_cond_node; attr types
+    COND_ATTR_TYPES = ['int', 'int', 'float', 'string'])."""
+    path = os.path.join(directory, name)
+    with open(path, "w") as f:
+        f.write("id:int64\tweight:float\tfeature:string\n")
+        for i in range(count):
+            f.write("%d\t%f\t%d:%d:%f:%s\n" % (i, i * 0.1, i % 5, i % 4, i * 0.3, str(i % 3)))
+    return path
+
+
 # ---- expectations -------------------------------------------------------------------
 def expect_edges_follow_generator(edges, dst_range, seed_ids, default_dst_id):
     src = edges.src_ids.reshape(-1)

@@ -47,6 +47,7 @@ def g(gl, tmp_path_factory):
     e3 = fx.write_edges(d, "edge3", RANGE2, RANGE2, [fx.WEIGHTED])
     n3 = fx.write_entity_nodes(d, "entity")
     e4 = fx.write_relation_edges(d, "relation")
+    cond = fx.write_cond_nodes(d, "cond_item")
     train = fx.write_nodes(d, "node1_train", (0, 50), [fx.WEIGHTED])
     graph = gl.Graph() \
         .node(n1, NODE1, gl.Decoder(attr_types=fx.ATTR_TYPES)) \
@@ -56,7 +57,9 @@ def g(gl, tmp_path_factory):
         .edge(e1, (NODE1, NODE2, EDGE1), gl.Decoder(attr_types=fx.ATTR_TYPES, labeled=True), directed=False) \
         .edge(e2, (NODE2, NODE1, EDGE2), gl.Decoder(attr_types=fx.ATTR_TYPES, weighted=True)) \
         .edge(e3, (NODE2, NODE2, EDGE3), gl.Decoder(weighted=True), directed=False) \
-        .edge(e4, ("entity", "entity", "relation"), gl.Decoder(weighted=True), directed=False)
+        .edge(e4, ("entity", "entity", "relation"), gl.Decoder(weighted=True), directed=False) \
+        .node(cond, "cond_item", gl.Decoder(attr_types=["int", "int", "float", "string"], weighted=True)) \
+        .edge(e4, ("cond_item", "cond_item", "cond_sim"), gl.Decoder(weighted=True), directed=True)
     graph.init(tracker=d)
     yield graph
     graph.close()
@@ -560,6 +563,60 @@ def test_conditional_negative_sampler_through_the_python_api(gl, g):
         g.negative_sampler(EDGE2, 6, "random", conditional=True, int_cols=[7], int_props=[0.5])
     with pytest.raises(ValueError):
         g.negative_sampler(EDGE2, 6, "random", conditional=True, int_cols=[0, 1], int_props=[0.7, 0.7])
+
+
+@pytest.mark.parametrize("strategy,share", [("in_degree", False), ("random", False), ("node_weight", True)])
+def test_conditional_negative_sampling_reference_test_case(gl, g, strategy, share):
+    """python/sampler/tests/test_conditional_negative_sampling.py restated: cond_item nodes carry ints [id % 5, id % 4],
+    a float and the string str(id % 3); cond_sim = i -> i + 2, i + 3, i + 5.  Of 4 negatives per pair, slot 0 shares the
+    dst's first int attribute, slot 1 its second, slots 2-3 its string; none is a neighbour of the src (edge-type
+    strategies) / a dst of the batch (batch_share)."""
+    src_ids = np.array([1, 2, 3, 4, 5])
+    dst_ids = np.array([12, 34, 2, 67, 128])
+    object_type = "cond_item" if strategy == "node_weight" else "cond_sim"
+    ns = g.negative_sampler(object_type, expand_factor=4, strategy=strategy, conditional=True, unique=False,
+                            batch_share=share, int_cols=[0, 1], int_props=[0.25, 0.25], str_cols=[0], str_props=[0.5])
+    for cc in range(20):  # the reference draws once; here 20 pinned streams
+        ns.set_call_counter(cc)
+        nodes = ns.get(src_ids, dst_ids)
+        assert nodes.ids.shape == (5, 4)
+        for idx, sid in enumerate(src_ids):
+            neg, pos = nodes.ids[idx], dst_ids[idx]
+            if share:
+                assert set(neg.tolist()).isdisjoint(set(dst_ids.tolist()))
+            else:
+                assert set(neg.tolist()).isdisjoint({sid + 2, sid + 3, sid + 5})
+            assert neg[0] % 5 == pos % 5 and neg[1] % 4 == pos % 4 and neg[2] % 3 == pos % 3 and neg[3] % 3 == pos % 3
+        np.testing.assert_almost_equal(nodes.weights, nodes.ids * 0.1, decimal=4)  # the negatives come back as Nodes
+
+
+def test_subgraph_sampling_reference_test_case(gl, g):
+    """python/sampler/tests/test_subgraph_sampling.py restated: batches of 8 entity nodes in order, the sub-graph the
+    relation edges induce among them; labels, float attributes and -- entry for entry, in order -- the edge index the
+    reference's check_subgraph_edge_indices expects."""
+    node_sampler = g.node_sampler("entity", batch_size=8)
+    subgraph_sampler = g.subgraph_sampler(nbr_type="relation")
+    batches = 0
+    while True:
+        try:
+            nodes = node_sampler.get()
+        except gl.OutOfRangeError:
+            break
+        sub = subgraph_sampler.get(nodes.ids)
+        batches += 1
+        ids = sub.nodes.ids
+        np.testing.assert_equal(sub.nodes.labels, ids)
+        for j in range(4):
+            np.testing.assert_almost_equal(sub.nodes.float_attrs[:, j], ids * 0.1 * (j + 1), decimal=4)
+        rows, cols = [], []
+        for i in range(ids.size):
+            for j in range(ids.size):
+                if (ids[i] < 100 or ids[j] < 100) and abs(int(ids[i]) - int(ids[j])) in (2, 3, 5):
+                    rows += [i, j]
+                    cols += [j, i]
+        np.testing.assert_equal(sub.edge_index[0], np.array(rows, dtype=np.int32))
+        np.testing.assert_equal(sub.edge_index[1], np.array(cols, dtype=np.int32))
+    assert batches == 15  # 120 entity nodes
 
 
 def test_in_and_out_degree_lookups(gl, g):
