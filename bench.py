@@ -618,6 +618,11 @@ def main():
                     help="N>1: after the placements with replicas, time the same steps once more with NO replica at all "
                          "(hot fraction 0, no graph replica): every remote request row and every remote feature row "
                          "crosses the links -- north_star's exchange itself; reported as placements.edge_cut_pure")
+    ap.add_argument("--speculate", default="on", choices=["on", "off"],
+                    help="N>1: time the partitioned placements a second time with a speculation ledger (glx_dist_ledger): "
+                         "sampling requests travel in fixed-capacity messages without a count exchange, the aggregation's "
+                         "count exchange confirms them -- one blocking host wait per step instead of three; reported as "
+                         "placements.*_speculated, verified like the others")
     ap.add_argument("--graph-hot-fraction", type=float, default=None,
                     help="N>1: fraction of the vertices (hottest first) whose adjacency rows are replicated; "
                          "default: --hot-fraction")
@@ -1165,6 +1170,42 @@ def main():
         halo_stats = st_agg.stats()
         if args.verify:
             verified_legs["features_sharded"] = guarded("verify", verify_sharded)
+        def speculated_leg(name):
+            """The same steps with a ledger on both stores: after the first step has recorded the two request shapes no
+            sampling request exchanges counts.  A confirmation that aborts (a message did not fit) voids the leg: the
+            capacities have been raised, the leg starts over -- on every rank, the abort is collective."""
+            ledger = glx.Ledger(local_rank).attach(st_smp, st_agg)
+            aborts = [0]
+
+            def run():
+                while True:
+                    try:
+                        return timed_leg_halo(args.warmup, n_steps, args.warmup)
+                    except glx.GlxError as ex:
+                        if ex.code != glx.ABORTED or aborts[0] >= 3:
+                            raise
+                        aborts[0] += 1
+                        torch.cuda.synchronize()
+                        log("rank %d: %s: confirmation aborted (%s); repeating the leg" % (rank, name, ex))
+            el, ta, ts = guarded(name, run)
+            legs[name] = dict({"ms_per_step": el / args.steps * 1e3, "value": world * edges_per_step * args.steps / el},
+                              **last_host_syncs)
+            legs[name]["ledger"] = dict(ledger.stats(), legs_repeated_after_abort=aborts[0])
+            if args.verify:
+                verified_legs[name] = guarded("verify", verify_sharded)
+            ledger.close()
+            return el, ta, ts
+        exchange_mode = "one count exchange per request"
+        if args.speculate == "on":
+            dog.cancel()
+            dog = threading.Timer(args.watchdog, give_up)
+            dog.daemon = True
+            dog.start()
+            el_s, ta_s, ts_s = speculated_leg("features_sharded_speculated")
+            ok_s = verified_legs.get("features_sharded_speculated", True)
+            if headline == "features_sharded" and ok_s and el_s < elapsed:
+                elapsed, t_agg, t_smp = el_s, ta_s, ts_s
+                exchange_mode = "speculated sampling exchanges (ledger), one count exchange per step"
         if args.pure_leg == "on":
             # north_star's path without any cache: drop the hot-row replica and detach the graph replica, then the same steps
             dog.cancel()
@@ -1185,6 +1226,12 @@ def main():
             legs["edge_cut_pure"]["sampling_exchange_hop2"] = pure_rows
             if args.verify:
                 verified_legs["edge_cut_pure"] = guarded("verify", verify_sharded)
+            if args.speculate == "on":
+                dog.cancel()
+                dog = threading.Timer(args.watchdog, give_up)
+                dog.daemon = True
+                dog.start()
+                speculated_leg("edge_cut_pure_speculated")
         dog.cancel()
 
     # the last timed step's outputs against the oracle, before anything else touches the buffers
@@ -1294,7 +1341,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s%s" % (args.workload, desc,
-                                             "" if not sharded else " -- value = %s placement" % headline),
+                                             "" if not sharded else " -- value = %s placement, %s (the faster of the two "
+                                             "exchange modes timed; both are in placements)" % (headline, exchange_mode)),
                    "seeds_per_step_per_gpu": B0,
                    "seeds": "uniform over the vertices that have out-edges, fresh batch every step",
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
@@ -1328,6 +1376,7 @@ def main():
             "graph_edge_fraction": (float(graph_replica.num_edges) / E) if graph_replica is not None else 0.0,
             "graph_replica": ("on" if graph_replica is not None else "off") + " (--graph-replica %s)" % args.graph_replica}
         res["value_features_sharded"] = legs["features_sharded"]["value"]
+        res["value_features_sharded_speculated"] = legs.get("features_sharded_speculated", {}).get("value")
         res["value_edge_cut_pure"] = legs.get("edge_cut_pure", {}).get("value")
         res["value_features_replicated"] = legs.get("features_replicated", {}).get("value")
         res["placements"] = legs

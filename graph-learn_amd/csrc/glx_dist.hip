@@ -576,7 +576,111 @@ inline uint64_t pow2_at_least(uint64_t x) {
 
 }  // namespace
 
+// ---- speculation ledger (glx.h, ABI 4) ----
+constexpr int kLedgerClasses = 8;
+constexpr int kLedgerTail = 3 + kLedgerClasses;  // words appended to every count exchange of an attached store
+// device words: [0] some bucket did not fit its message  [1 .. 8] per request shape: the largest per-owner share of a
+// request seen since the last exchange, as (rows << 20) / request length, rounded up
+struct glx_dist_ledger {
+  int device = 0;
+  int64_t* d_words = nullptr;  // [1 + kLedgerClasses]
+  int64_t* d_stage = nullptr;  // [kMaxWorld + 32 + kLedgerTail]: a count exchange's values + the tail
+  struct Shape {
+    int64_t n = 0;
+    double share = 0.0;
+  };
+  Shape shapes[kLedgerClasses];
+  int num_shapes = 0;
+  bool hold = false;
+  // speculated calls since the last exchange: how many, and a digest of their parameters (compared across ranks)
+  int64_t pending = 0;
+  uint64_t digest = 0;
+  double slack = 1.25;
+  int64_t pad_rows = 1024;
+  glx_dist_ledger_stats stats;
+  std::vector<int64_t> h_tmp;
+  int shape_of(int64_t n) const {
+    for (int c = 0; c < num_shapes; ++c)
+      if (shapes[c].n == n) return c;
+    return -1;
+  }
+  int64_t capacity(int c) const {
+    const Shape& sh = shapes[c];
+    int64_t cap = (int64_t)((double)sh.n * sh.share * slack) + pad_rows;
+    cap = (cap + 63) & ~(int64_t)63;
+    if (cap < 64) cap = 64;
+    return cap < sh.n ? cap : sh.n;
+  }
+};
+
+namespace {
+
+// vals[nvals] + the ledger's words (taken: a flag raised after this kernel ran travels with the next exchange).
+__global__ void glx_dist_ledger_pack_kernel(const int64_t* __restrict__ vals, int nvals, int64_t* __restrict__ words,
+                                            int64_t pending, int64_t digest, int64_t* __restrict__ out) {
+  const int t = threadIdx.x;
+  for (int i = t; i < nvals; i += blockDim.x) out[i] = vals[i];
+  if (t == 0) {
+    out[nvals + 1] = pending;
+    out[nvals + 2] = digest;
+  }
+  if (t <= kLedgerClasses) {
+    const int64_t w = (int64_t)atomicExch(reinterpret_cast<unsigned long long*>(words + t), 0ull);
+    out[nvals + (t == 0 ? 0 : 2 + t)] = w;
+  }
+}
+
+// Fixed-capacity messages of a speculated request: bucket p's first cap rows, padded with an id no shard knows.
+// blockIdx.y = owner.  cnt_off[0 .. P) <- the bucket sizes, [P .. 2P) <- their offsets in the bucketed request (the
+// stitch reads them after the store's shared counters have moved on).
+__global__ __launch_bounds__(256) void glx_dist_spec_pack_kernel(const int64_t* __restrict__ bucketed,
+                                                                 const int64_t* __restrict__ order,
+                                                                 const int64_t* __restrict__ counts, int32_t P,
+                                                                 int64_t cap, int64_t n, int64_t* __restrict__ ids_out,
+                                                                 int64_t* __restrict__ rows_out,
+                                                                 int64_t* __restrict__ cnt_off,
+                                                                 int64_t* __restrict__ words, int32_t shape) {
+  const int32_t p = blockIdx.y;
+  int64_t off = 0;
+  for (int32_t q = 0; q < p; ++q) off += counts[q];
+  const int64_t c = counts[p];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cnt_off[p] = c;
+    cnt_off[P + p] = off;
+    if (c > cap) atomicExch(reinterpret_cast<unsigned long long*>(words), 1ull);
+    const int64_t share_fp = ((c << 20) + n - 1) / n;
+    atomicMax(reinterpret_cast<unsigned long long*>(words + 1 + shape), (unsigned long long)share_fp);
+  }
+  const int64_t take = c < cap ? c : cap;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+    ids_out[p * cap + i] = i < take ? bucketed[off + i] : GLX_EMPTY_KEY;
+    rows_out[p * cap + i] = i < take ? order[off + i] : 0;
+  }
+}
+
+// Stitcher::DoStitch over the fixed-capacity answers: slot i of owner p's answer is request row order[off_p + i].
+__global__ __launch_bounds__(256) void glx_dist_spec_stitch_kernel(const int64_t* __restrict__ nbr_in,
+                                                                   const int64_t* __restrict__ eid_in,
+                                                                   const int64_t* __restrict__ order,
+                                                                   const int64_t* __restrict__ cnt_off, int32_t P,
+                                                                   int64_t cap, int32_t k, int64_t* __restrict__ nbr_out,
+                                                                   int64_t* __restrict__ eid_out) {
+  const int32_t p = blockIdx.y;
+  const int64_t c = cnt_off[p], off = cnt_off[P + p];
+  const int64_t total = (c < cap ? c : cap) * k;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / k;
+    const int32_t col = (int32_t)(t - i * k);
+    const int64_t o = order[off + i] * k + col;
+    nbr_out[o] = nbr_in[p * cap * k + t];
+    eid_out[o] = eid_in[p * cap * k + t];
+  }
+}
+
+}  // namespace
+
 struct glx_dist_store {
+  glx_dist_ledger* ledger = nullptr;
   glx_comm* comm = nullptr;
   const glx_graph* graph = nullptr;
   const glx_graph* graph_replica = nullptr;  // complete rows of the hot vertices, borrowed (glx_dist_store_set_graph_replica)
@@ -642,10 +746,53 @@ void routing_from_matrix(const glx_dist_store* st, int nvals, Routing* r) {
   r->n_recv = r->recv_offs[P];
 }
 
-// The count exchange of a partitioned request: the one place its host thread waits for the other ranks.
+// The count exchange of a partitioned request: the one place its host thread waits for the other ranks.  With a
+// ledger the exchange is also the confirmation point of the calls that skipped theirs: GLX_ABORTED on every rank when
+// any rank's speculated message overflowed (or the ranks speculated on different requests).
 int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_t* h_out, hipStream_t s) {
+  glx_dist_ledger* lg = st->ledger;
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = st->comm->allgather_i64(d_vals, nvals, h_out, s);
+  int rc;
+  if (lg == nullptr) {
+    rc = st->comm->allgather_i64(d_vals, nvals, h_out, s);
+  } else {
+    const int P = st->world, wide = nvals + kLedgerTail;
+    GLX_REQUIRE(nvals <= kMaxWorld + 32, "count exchange of %d values with a ledger", nvals);
+    glx_dist_ledger_pack_kernel<<<1, 64, 0, s>>>(d_vals, nvals, lg->d_words, lg->pending, (int64_t)lg->digest, lg->d_stage);
+    lg->h_tmp.resize((size_t)P * wide);
+    rc = st->comm->allgather_i64(lg->d_stage, wide, lg->h_tmp.data(), s);
+    if (rc == GLX_OK) {
+      bool overflow = false, disagree = false;
+      int64_t need[kLedgerClasses] = {0};
+      for (int q = 0; q < P; ++q) {
+        const int64_t* row = &lg->h_tmp[(size_t)q * wide];
+        memcpy(h_out + (size_t)q * nvals, row, (size_t)nvals * 8);
+        overflow = overflow || row[nvals] != 0;
+        disagree = disagree || row[nvals + 1] != lg->pending || row[nvals + 2] != (int64_t)lg->digest;
+        for (int c = 0; c < kLedgerClasses; ++c) need[c] = need[c] > row[nvals + 3 + c] ? need[c] : row[nvals + 3 + c];
+      }
+      for (int c = 0; c < lg->num_shapes; ++c) {
+        const double sh = (double)need[c] / (double)(1 << 20);
+        if (sh > lg->shapes[c].share) lg->shapes[c].share = sh;
+        if (lg->shapes[c].share > lg->stats.largest_share) lg->stats.largest_share = lg->shapes[c].share;
+      }
+      lg->pending = 0;
+      lg->digest = 0;
+      if (disagree) {
+        lg->hold = true;
+        lg->stats.holding = 1;
+      }
+      if (overflow || disagree) {
+        ++lg->stats.aborted;
+        glx_set_error(disagree ? "speculated requests differ between the ranks (length, neighbor_count, sampler, padding, "
+                                 "seed or call_counter): their results are void, and this ledger no longer speculates"
+                               : "a speculated request did not fit its fixed-capacity messages: the results of the "
+                                 "glx_dist_sample calls since the last count exchange are void -- repeat them (the "
+                                 "capacities have been raised)");
+        rc = GLX_ABORTED;
+      }
+    }
+  }
   st->host_stall_us += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
   ++st->host_syncs;
   return rc;
@@ -831,6 +978,89 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
   return GLX_OK;
 }
 
+// A request whose shape the ledger knows: fixed-capacity messages, no count leaves the device (glx.h, ABI 4).
+// bucketed / order: the partitioned request (the store's request arena); counts in st->d_vals.
+int dist_sample_speculated(glx_dist_store* st, glx_dist_ledger* lg, int shape, int sampler, int64_t n, int32_t k,
+                           int padding_mode, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                           const glx_graph* rg, const int64_t* bucketed, const int64_t* order, int64_t* nbr_out,
+                           int64_t* eid_out, hipStream_t s) {
+  const int P = st->world;
+  const int64_t cap = lg->capacity(shape), m = cap * P;
+  GLX_REQUIRE(m * k <= (int64_t)INT32_MAX * 8, "speculated request too large");
+  Carver cr;
+  const size_t o_sid = cr.take((size_t)m * 8);
+  const size_t o_srow = cr.take((size_t)m * 8);
+  const size_t o_ids = cr.take((size_t)m * 8);
+  const size_t o_rows = cr.take((size_t)m * 8);
+  const size_t o_nl = cr.take((size_t)m * k * 8);
+  const size_t o_el = cr.take((size_t)m * k * 8);
+  const size_t o_nb = cr.take((size_t)m * k * 8);
+  const size_t o_eb = cr.take((size_t)m * k * 8);
+  const size_t o_co = cr.take((size_t)2 * P * 8);
+  int rc = st->recv.ensure(cr.at);
+  if (rc != GLX_OK) return rc;
+  char* base = st->recv.p;
+  int64_t* send_ids = reinterpret_cast<int64_t*>(base + o_sid);
+  int64_t* send_rows = reinterpret_cast<int64_t*>(base + o_srow);
+  int64_t* ids_in = reinterpret_cast<int64_t*>(base + o_ids);
+  int64_t* rows_in = reinterpret_cast<int64_t*>(base + o_rows);
+  int64_t* nbr_loc = reinterpret_cast<int64_t*>(base + o_nl);
+  int64_t* eid_loc = reinterpret_cast<int64_t*>(base + o_el);
+  int64_t* nbr_back = reinterpret_cast<int64_t*>(base + o_nb);
+  int64_t* eid_back = reinterpret_cast<int64_t*>(base + o_eb);
+  int64_t* cnt_off = reinterpret_cast<int64_t*>(base + o_co);
+
+  const unsigned gx = (unsigned)((cap + 255) / 256 < 1024 ? (cap + 255) / 256 : 1024);
+  glx_dist_spec_pack_kernel<<<dim3(gx > 0 ? gx : 1, (unsigned)P), 256, 0, s>>>(bucketed, order, st->d_vals, P, cap, n, send_ids,
+                                                                              send_rows, cnt_off, lg->d_words, shape);
+  GLX_HIP(hipGetLastError());
+  if (rg != nullptr) {
+    // the replica serves its bucket straight into the caller's response.  Its size stays on the device, so the launch
+    // covers the whole request: rows of the other buckets are ids the replica does not know -- it writes their
+    // default answer, and the stitch below overwrites it with the owner's
+    const int64_t chunk_r = (int64_t)INT32_MAX / k;
+    for (int64_t lo = 0; lo < n; lo += chunk_r) {
+      const int64_t cnt = n - lo < chunk_r ? n - lo : chunk_r;
+      rc = glx_sample_scatter_device(rg, sampler, bucketed + lo, order + lo, (int32_t)cnt, k, padding_mode,
+                                     default_neighbor_id, seed, call_counter, nbr_out, eid_out, s);
+      if (rc != GLX_OK) return rc;
+    }
+  }
+  std::vector<int64_t> cnts((size_t)P, cap), offs((size_t)P + 1, 0);
+  for (int p = 0; p < P; ++p) offs[p + 1] = offs[p] + cap;
+  GlxSeg out_segs[2] = {{send_ids, ids_in, 8}, {send_rows, rows_in, 8}};
+  rc = st->comm->alltoallv(out_segs, 2, cnts.data(), offs.data(), cnts.data(), offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  const int64_t chunk = (int64_t)INT32_MAX / k;
+  for (int64_t lo = 0; lo < m; lo += chunk) {
+    const int64_t cnt = m - lo < chunk ? m - lo : chunk;
+    rc = glx_sample_filtered(st->graph, sampler, ids_in + lo, rows_in + lo, (int32_t)cnt, k, padding_mode,
+                             default_neighbor_id, seed, call_counter, nullptr, nbr_loc + lo * k, eid_loc + lo * k,
+                             GLX_PTR_DEVICE, s);
+    if (rc != GLX_OK) return rc;
+  }
+  GlxSeg back_segs[2] = {{nbr_loc, nbr_back, (size_t)k * 8}, {eid_loc, eid_back, (size_t)k * 8}};
+  rc = st->comm->alltoallv(back_segs, 2, cnts.data(), offs.data(), cnts.data(), offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  const int64_t per = cap * k;
+  const unsigned sx = (unsigned)((per + 255) / 256 < 4096 ? (per + 255) / 256 : 4096);
+  glx_dist_spec_stitch_kernel<<<dim3(sx > 0 ? sx : 1, (unsigned)P), 256, 0, s>>>(nbr_back, eid_back, order, cnt_off, P, cap, k,
+                                                                                nbr_out, eid_out);
+  GLX_HIP(hipGetLastError());
+  // what the ranks must have agreed on for the owners' answers to be the requesters' (compared at the confirmation)
+  const uint64_t words[7] = {seed, call_counter, (uint64_t)k, (uint64_t)sampler, (uint64_t)padding_mode,
+                             (uint64_t)default_neighbor_id, (uint64_t)n};
+  uint64_t d = lg->digest;
+  for (uint64_t w : words) d = glx_mix64(d ^ (w + 0x9e3779b97f4a7c15ull));
+  lg->digest = d;
+  ++lg->pending;
+  ++lg->stats.speculated;
+  st->sample_rows = n;
+  st->sample_rows_replica = -1;  // sizes of a speculated request stay on the device
+  st->sample_rows_remote = -1;
+  return GLX_OK;
+}
+
 int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int32_t batch, int32_t k,
                        int padding_mode, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
                        const glx_filter* filter, int64_t* nbr_out, int64_t* eid_out, hipStream_t s) {
@@ -872,9 +1102,16 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
     // request: hash_partitioner.h:69-74)
     glx_dist_gather_i64_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(filter->values, order, n, vals_b);
   }
-  constexpr int kParams = 10;
+  constexpr int kParams = 11;
   ReqParams mine;
   memset(&mine, 0, sizeof(mine));
+  mine.v[10] = n;
+  glx_dist_ledger* lg = st->ledger;
+  const int shape = lg && !lg->hold && !filtered && n > 0 && k > 0 ? lg->shape_of(n) : -1;
+  if (shape >= 0) {
+    return dist_sample_speculated(st, lg, shape, sampler, n, k, padding_mode, default_neighbor_id, seed, call_counter,
+                                  divert ? rg : nullptr, bucketed, order, nbr_out, eid_out, s);
+  }
   mine.v[0] = (int64_t)seed;
   mine.v[1] = (int64_t)call_counter;
   mine.v[2] = k;
@@ -894,7 +1131,7 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   routing_from_matrix(st, nvals, &rt);
   const int64_t m = rt.n_recv;
   GLX_REQUIRE(m <= INT32_MAX, "more than 2^31 request rows arrived at one shard");
-  bool uniform = true;
+  bool uniform = true, same_length = true;
   for (int q = 0; q < P; ++q) {
     const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
     // the response width and the set of tensors that travel are part of the exchange's shape
@@ -902,7 +1139,28 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
                 (long long)pq[2], k);
     GLX_REQUIRE((pq[6] != GLX_FILTER_NONE) == filtered, "rank %d and this rank disagree on whether the request has a filter",
                 q);
-    for (int j = 0; j < kParams; ++j) uniform = uniform && pq[j] == mine.v[j];
+    for (int j = 0; j < 10; ++j) uniform = uniform && pq[j] == mine.v[j];
+    same_length = same_length && pq[10] == n;
+  }
+  if (lg && !lg->hold && !filtered && uniform && same_length && n > 0 && k > 0) {
+    // a request every rank issued alike: later ones of this length may skip the count exchange.  Its shape = the
+    // largest share of a request that any rank sent to any owner (the same number on every rank: the whole matrix
+    // is here).
+    int c = lg->shape_of(n);
+    if (c < 0 && lg->num_shapes < kLedgerClasses) {
+      c = lg->num_shapes++;
+      lg->shapes[c].n = n;
+      lg->shapes[c].share = 0.0;
+    }
+    if (c >= 0) {
+      int64_t most = 0;
+      for (int q = 0; q < P; ++q)
+        for (int p2 = 0; p2 < P; ++p2) most = most > st->h_mat[(size_t)q * nvals + p2] ? most : st->h_mat[(size_t)q * nvals + p2];
+      const double share = (double)most / (double)n;
+      if (share > lg->shapes[c].share) lg->shapes[c].share = share;
+      if (lg->shapes[c].share > lg->stats.largest_share) lg->stats.largest_share = lg->shapes[c].share;
+      ++lg->stats.learned;
+    }
   }
 
   Carver cr;
@@ -1305,6 +1563,69 @@ extern "C" int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out
   *out = st->slots[st->last_slot].stats;
   out->host_syncs = st->host_syncs;
   out->host_stall_us = st->host_stall_us;
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_ledger_create(int device, glx_dist_ledger** out) {
+  GLX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  int rc = glx_init_device(device);
+  if (rc != GLX_OK) return rc;
+  GlxDeviceGuard guard(device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", device);
+  glx_dist_ledger* l = new (std::nothrow) glx_dist_ledger();
+  GLX_REQUIRE(l != nullptr, "out of host memory");
+  l->device = device;
+  memset(&l->stats, 0, sizeof(l->stats));
+  const size_t words = 1 + kLedgerClasses, stage = kMaxWorld + 32 + kLedgerTail;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&l->d_words), (words + stage) * 8);
+  if (e == hipSuccess) e = hipMemset(l->d_words, 0, (words + stage) * 8);
+  if (e != hipSuccess) {
+    glx_dist_ledger_destroy(l);
+    GLX_HIP(e);
+  }
+  l->d_stage = l->d_words + words;
+  *out = l;
+  return GLX_OK;
+}
+
+extern "C" void glx_dist_ledger_destroy(glx_dist_ledger* l) {
+  if (!l) return;
+  GlxDeviceGuard guard(l->device);
+  (void)hipDeviceSynchronize();
+  if (l->d_words) (void)hipFree(l->d_words);
+  delete l;
+}
+
+extern "C" int glx_dist_store_set_ledger(glx_dist_store* st, glx_dist_ledger* l) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  GLX_REQUIRE(l == nullptr || l->device == st->device, "the ledger lives on device %d, the store on %d", l ? l->device : -1,
+              st->device);
+  st->ledger = l;
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_confirm(glx_dist_store* st, void* stream) {
+  GLX_REQUIRE(st != nullptr, "store is NULL");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  if (st->ledger == nullptr) return GLX_OK;  // nothing speculates: every call confirmed itself
+  std::vector<int64_t> sink((size_t)st->world);
+  // one value so the exchange has a body; the ledger's words ride behind it
+  return exchange_counts(st, st->ledger->d_stage + kMaxWorld + 31, 1, sink.data(), glx_stream(stream));
+}
+
+extern "C" int glx_dist_ledger_get_stats(const glx_dist_ledger* l, glx_dist_ledger_stats* out) {
+  GLX_REQUIRE(l != nullptr && out != nullptr, "NULL argument");
+  *out = l->stats;
+  return GLX_OK;
+}
+
+extern "C" int glx_dist_ledger_set_slack(glx_dist_ledger* l, double slack, int64_t pad_rows) {
+  GLX_REQUIRE(l != nullptr, "ledger is NULL");
+  GLX_REQUIRE(slack > 0.0 && pad_rows >= 0, "slack must be positive, pad_rows non-negative");
+  l->slack = slack;
+  l->pad_rows = pad_rows;
   return GLX_OK;
 }
 

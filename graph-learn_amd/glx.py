@@ -56,6 +56,8 @@ EXPORTS = [
     "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_partial", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_aggregate_end_range", "glx_dist_lookup",
     "glx_dist_last_stats",
+    "glx_dist_ledger_create", "glx_dist_ledger_destroy", "glx_dist_store_set_ledger", "glx_dist_confirm",
+    "glx_dist_ledger_get_stats", "glx_dist_ledger_set_slack",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
     "glx_probe_bandwidth", "glx_subgraph_induce",
     "glx_cond_table_create", "glx_cond_table_destroy", "glx_cond_negative_sample",
@@ -87,6 +89,9 @@ HOST_ALLTOALLV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
                                      ctypes.c_void_p, ctypes.c_int64)
 # int (*)(void* user, const void* send, void* recv, int64_t bytes_per_rank)
 HOST_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+
+
+ABORTED = 10  # GLX_ABORTED: a speculated exchange did not fit (Ledger); repeat the unconfirmed calls
 
 
 class GlxError(RuntimeError):
@@ -193,6 +198,13 @@ def lib():
         L.glx_dist_aggregate_end.argtypes = [vp, i32, ci, vp, i32, vp, vp, vp]
         L.glx_dist_aggregate_end_range.argtypes = [vp, i32, i32, i32, ci, ci, vp, i32, vp, vp, vp]
         L.glx_dist_last_stats.argtypes = [vp, ctypes.POINTER(DistStats)]
+        L.glx_dist_ledger_create.argtypes = [ci, ctypes.POINTER(vp)]
+        L.glx_dist_ledger_destroy.argtypes = [vp]
+        L.glx_dist_ledger_destroy.restype = None
+        L.glx_dist_store_set_ledger.argtypes = [vp, vp]
+        L.glx_dist_confirm.argtypes = [vp, vp]
+        L.glx_dist_ledger_get_stats.argtypes = [vp, ctypes.POINTER(LedgerStats)]
+        L.glx_dist_ledger_set_slack.argtypes = [vp, ctypes.c_double, i64]
         L.glx_plan_create.argtypes = [vp, i32, ci, vp, i32, ci, i64, u64, vp, ci, f32, ctypes.POINTER(vp)]
         L.glx_plan_run.argtypes = [vp, vp, u64, vp]
         L.glx_plan_output.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
@@ -1000,6 +1012,64 @@ class DistStore:
         st = DistStats()
         _check(lib().glx_dist_last_stats(self._h, ctypes.byref(st)))
         return st.as_dict()
+
+    def confirm(self):
+        """A confirmation point for speculated sample calls (Ledger): one count exchange; raises GlxError(ABORTED)
+        on every rank when a speculated message overflowed."""
+        _check(lib().glx_dist_confirm(self._h, _stream(PTR_DEVICE, self.comm.device)))
+
+
+class LedgerStats(ctypes.Structure):
+    _fields_ = [("speculated", ctypes.c_int64), ("learned", ctypes.c_int64), ("aborted", ctypes.c_int64),
+                ("holding", ctypes.c_int64), ("largest_share", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Ledger:
+    """glx_dist_ledger: lets glx_dist_sample skip its count exchange for requests whose shape repeats (fixed-capacity
+    messages; whether they fitted is confirmed by the next count exchange of any store attached to the ledger, which
+    raises GlxError with code ABORTED on every rank when they did not).  One per rank."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        _check(lib().glx_dist_ledger_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self._stores = []
+
+    def attach(self, *stores):
+        for st in stores:
+            _check(lib().glx_dist_store_set_ledger(st._h, self._h))
+            st._ledger = self  # the ledger outlives the stores attached to it
+            self._stores.append(st)
+        return self
+
+    def detach(self, *stores):
+        for st in stores:
+            _check(lib().glx_dist_store_set_ledger(st._h, None))
+            st._ledger = None
+            self._stores = [x for x in self._stores if x is not st]
+
+    def set_slack(self, slack=1.25, pad_rows=1024):
+        _check(lib().glx_dist_ledger_set_slack(self._h, float(slack), int(pad_rows)))
+
+    def stats(self):
+        st = LedgerStats()
+        _check(lib().glx_dist_ledger_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            self.detach(*list(self._stores))
+            lib().glx_dist_ledger_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _DevArray:

@@ -33,7 +33,7 @@ extern "C" {
 /* 1: graph / features / samplers / aggregators / partition helpers.  2 (additions only): host registration, shard
  * communicator, distributed store (+ replicas), request plans.  3 (additions only): memory-system probes,
  * induced sub-graph, conditional negative sampling. */
-#define GLX_ABI_VERSION 3
+#define GLX_ABI_VERSION 4
 
 /* Exported symbols: libglx.so is built with -fvisibility=hidden. */
 #if defined(__GNUC__)
@@ -46,6 +46,7 @@ extern "C" {
 #define GLX_OK 0
 #define GLX_INVALID_ARGUMENT 3
 #define GLX_RESOURCE_EXHAUSTED 8
+#define GLX_ABORTED 10 /* ABI 4: a speculated exchange did not fit (glx_dist_ledger); redo the unconfirmed calls */
 #define GLX_OUT_OF_RANGE 11
 #define GLX_UNIMPLEMENTED 12
 #define GLX_INTERNAL 13
@@ -592,6 +593,42 @@ typedef struct glx_dist_stats {
   int64_t host_stall_us;
 } glx_dist_stats;
 GLX_API int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out);
+
+/* ---- ABI 4: partitioned sampling WITHOUT a count exchange.  DistributeRunner waits for every shard's reply before it
+ * goes on (RunInParallel, core/runner/op_runner.h:86-117); glx_dist_sample does the same once per request, at the count
+ * exchange that tells the ranks how many rows each message carries -- a blocking host wait per hop.  A ledger removes it
+ * for requests whose shape repeats: the first request of a length n goes through the count exchange as before and
+ * records the largest share of it any rank sent to any owner; later requests of that length send FIXED-capacity messages
+ * (that share x 1.25 + 1024 rows, padded with ids no shard knows), the owners answer every slot, and each requester keeps
+ * the answers of its real rows -- no count leaves the device, the host never waits.  Whether every bucket fitted its
+ * message is recorded in a device word and travels with the NEXT count exchange of any store attached to the same
+ * ledger (the aggregation's, glx_dist_aggregate_begin; or glx_dist_confirm): that call returns GLX_ABORTED on every rank
+ * when any bucket of any rank did not fit, and the results of all speculated calls since the previous successful
+ * exchange are void -- redo them (same call counters: same answers); the capacities have been raised to what was
+ * needed, so the repeat fits.  Results of confirmed calls are bit-identical to the count-exchange path.
+ * Contract (SPMD lockstep): every rank issues the same sequence of glx_dist_sample calls with the same request length,
+ * neighbor_count, sampler, padding, seed and call_counter -- the owners serve all requesters with their OWN parameters.
+ * A digest of those parameters travels with the confirmation; ranks that disagree get GLX_ABORTED and the ledger stops
+ * speculating for good.  Filtered requests, glx_dist_sample_full and random walks always take the count exchange.
+ * One ledger per rank, shared by that rank's stores; calls that use it come from one host thread. */
+typedef struct glx_dist_ledger glx_dist_ledger;
+GLX_API int glx_dist_ledger_create(int device, glx_dist_ledger** out);
+GLX_API void glx_dist_ledger_destroy(glx_dist_ledger* l);
+/* NULL detaches.  The ledger must outlive the stores attached to it. */
+GLX_API int glx_dist_store_set_ledger(glx_dist_store* st, glx_dist_ledger* l);
+/* A confirmation point of its own (collective; one count exchange on st's communicator): GLX_OK = every speculated
+ * call enqueued before it, on streams ordered before `stream`, is valid. */
+GLX_API int glx_dist_confirm(glx_dist_store* st, void* stream);
+typedef struct glx_dist_ledger_stats {
+  int64_t speculated;  /* glx_dist_sample calls that skipped their count exchange */
+  int64_t learned;     /* ... that took it and recorded a request shape */
+  int64_t aborted;     /* confirmations that failed */
+  int64_t holding;     /* 1: the ranks' requests disagreed once; no more speculation */
+  double largest_share; /* largest per-owner share of a request recorded so far */
+} glx_dist_ledger_stats;
+GLX_API int glx_dist_ledger_get_stats(const glx_dist_ledger* l, glx_dist_ledger_stats* out);
+/* Test knob: capacity = share x slack + pad rows (defaults 1.25, 1024).  slack < 1 forces the abort path. */
+GLX_API int glx_dist_ledger_set_slack(glx_dist_ledger* l, double slack, int64_t pad_rows);
 
 /* ---- request plans: a multi-hop sample (+ aggregate) request as ONE graph launch.  Replaces the
  * per-batch walk over a chain of DAG nodes (core/runner/dag_node_runner.cc:32-109: each node builds a

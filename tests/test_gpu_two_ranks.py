@@ -49,7 +49,16 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
     # timed, verified and described like the others
     pure = res["placements"]["edge_cut_pure"]
     assert pure["value"] > 0 and res["value_edge_cut_pure"] == pure["value"]
-    assert res["verified_legs"] == {"features_sharded": True, "edge_cut_pure": True}
+    assert res["verified_legs"] == {"features_sharded": True, "features_sharded_speculated": True, "edge_cut_pure": True,
+                                    "edge_cut_pure_speculated": True}
+    # the same placements with a speculation ledger: after the first step only the aggregation exchanges counts
+    for name in ("features_sharded_speculated", "edge_cut_pure_speculated"):
+        leg = res["placements"][name]
+        assert leg["value"] > 0 and leg["ledger"]["holding"] == 0
+        assert leg["ledger"]["speculated"] >= 2 * 3 and leg["ledger"]["learned"] == 2, leg["ledger"]
+        if pipeline == "on":  # (the flat leg does not count its exchanges)
+            assert leg["count_exchanges_per_step"] == 1.0, leg
+            assert res["placements"][name[:-11]]["count_exchanges_per_step"] == 3.0
     ph, ps = pure["halo_exchange_hop2"], pure["sampling_exchange_hop2"]
     assert ph["from_replica"] == 0 and ph["remote"] > 0 and ph["bytes_sent"] > 0
     assert ps["from_graph_replica"] == 0 and ps["remote"] > 0
