@@ -90,7 +90,25 @@ def rank_main(r):
             emb2 = torch.empty((m1, D), dtype=torch.float32, device=dev); cnt2 = torch.empty(m1, dtype=torch.int32, device=dev)
             emb1 = torch.empty((b0, D), dtype=torch.float32, device=dev); cnt1 = torch.empty(b0, dtype=torch.int32, device=dev)
 
+            ledger = glx.Ledger(0).attach(st_s, st_a) if os.environ.get("LEDGER", "0") == "1" else None
+            merged = os.environ.get("MERGED", "0") == "1"  # bench.py's step: ONE aggregate_begin for both id sets
+            both = torch.empty(m2 + m1, dtype=torch.int64, device=dev)
+            if merged:
+                nb2 = both[:m2].view(m1, k2)
+                nb1 = both[m2:].view(b0, k1)
+
+            def step_merged(i):
+                st_s.sample("EdgeWeightSampler", seeds[i], k1, seed=42, call_counter=4 * i, out=(nb1, ed1))
+                st_s.sample("EdgeWeightSampler", nb1.view(-1), k2, seed=42, call_counter=4 * i + 1, out=(nb2, ed2))
+                st_a.aggregate_begin(0, both)
+                s2 = st_a.stats()
+                st_a.aggregate_end_range(0, 0, m2, "MaxAggregator", None, m1, out=(emb2, cnt2))
+                st_a.aggregate_end_range(0, m2, m1, "MaxAggregator", None, b0, out=(emb1, cnt1), release=True)
+                return s2
+
             def step(i):
+                if merged:
+                    return step_merged(i)
                 st_s.sample("EdgeWeightSampler", seeds[i], k1, seed=42, call_counter=4 * i, out=(nb1, ed1))
                 st_s.sample("EdgeWeightSampler", nb1.view(-1), k2, seed=42, call_counter=4 * i + 1, out=(nb2, ed2))
                 st_a.aggregate("MaxAggregator", nb2.view(-1), None, m1, out=(emb2, cnt2))
@@ -101,12 +119,17 @@ def rank_main(r):
                 step(i)
             torch.cuda.current_stream().synchronize()
             bar.wait()
+            sync0 = (st_s.stats()["host_syncs"], st_a.stats()["host_syncs"])
             t0 = time.perf_counter()
             for i in range(2, steps + 2):
                 s2 = step(i)
             torch.cuda.current_stream().synchronize()
             bar.wait()
             times[r] = (time.perf_counter() - t0) / steps
+            if r == 0:
+                print("count exchanges per step: sampling store %.1f, aggregation store %.1f%s" % (
+                    (st_s.stats()["host_syncs"] - sync0[0]) / steps, (st_a.stats()["host_syncs"] - sync0[1]) / steps,
+                    "; ledger: %s" % ledger.stats() if ledger else ""), flush=True)
             stats[r] = dict(s2, sampling_hop2=st_s.last_sample_rows())
             # bit-identical to the unpartitioned operators (last step)
             i = steps + 1
@@ -116,6 +139,8 @@ def rank_main(r):
             torch.cuda.current_stream().synchronize()
             ok[r] = bool(torch.equal(nb1, wa) and torch.equal(ed1, wae) and torch.equal(nb2, wb) and torch.equal(ed2, wbe)
                          and torch.equal(cnt2, wc2) and torch.equal(emb2.view(torch.int32), we2.view(torch.int32)))
+            if ledger:
+                ledger.close()
             st_s.close(); st_a.close()
         comm.close()
     except BaseException:
