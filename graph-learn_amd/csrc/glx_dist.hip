@@ -579,8 +579,9 @@ inline uint64_t pow2_at_least(uint64_t x) {
 // ---- speculation ledger (glx.h, ABI 4) ----
 constexpr int kLedgerClasses = 8;
 constexpr int kLedgerTail = 3 + kLedgerClasses;  // words appended to every count exchange of an attached store
-// device words: [0] some bucket did not fit its message  [1 .. 8] per request shape: the largest per-owner share of a
-// request seen since the last exchange, as (rows << 20) / request length, rounded up
+// device words: [0] epoch + 1 of the newest call one of whose buckets did not fit its message (an abort starts a new epoch:
+// calls of an aborted epoch that are still in flight raise flags nobody heeds)  [1 .. 8] per request shape: the largest
+// per-owner share of a request seen since the last exchange, as (rows << 20) / request length, rounded up
 struct glx_dist_ledger {
   int device = 0;
   int64_t* d_words = nullptr;  // [1 + kLedgerClasses]
@@ -592,6 +593,7 @@ struct glx_dist_ledger {
   Shape shapes[kLedgerClasses];
   int num_shapes = 0;
   bool hold = false;
+  int64_t epoch = 0;
   // speculated calls since the last exchange: how many, and a digest of their parameters (compared across ranks)
   int64_t pending = 0;
   uint64_t digest = 0;
@@ -639,7 +641,8 @@ __global__ __launch_bounds__(256) void glx_dist_spec_pack_kernel(const int64_t* 
                                                                  int64_t cap, int64_t n, int64_t* __restrict__ ids_out,
                                                                  int64_t* __restrict__ rows_out,
                                                                  int64_t* __restrict__ cnt_off,
-                                                                 int64_t* __restrict__ words, int32_t shape) {
+                                                                 int64_t* __restrict__ words, int32_t shape,
+                                                                 int64_t tag) {
   const int32_t p = blockIdx.y;
   int64_t off = 0;
   for (int32_t q = 0; q < p; ++q) off += counts[q];
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(256) void glx_dist_spec_pack_kernel(const int64_t* 
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     cnt_off[p] = c;
     cnt_off[P + p] = off;
-    if (c > cap) atomicExch(reinterpret_cast<unsigned long long*>(words), 1ull);
+    if (c > cap) atomicMax(reinterpret_cast<unsigned long long*>(words), (unsigned long long)tag);
     const int64_t share_fp = ((c << 20) + n - 1) / n;
     atomicMax(reinterpret_cast<unsigned long long*>(words + 1 + shape), (unsigned long long)share_fp);
   }
@@ -767,7 +770,7 @@ int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_
       for (int q = 0; q < P; ++q) {
         const int64_t* row = &lg->h_tmp[(size_t)q * wide];
         memcpy(h_out + (size_t)q * nvals, row, (size_t)nvals * 8);
-        overflow = overflow || row[nvals] != 0;
+        overflow = overflow || row[nvals] == lg->epoch + 1;
         disagree = disagree || row[nvals + 1] != lg->pending || row[nvals + 2] != (int64_t)lg->digest;
         for (int c = 0; c < kLedgerClasses; ++c) need[c] = need[c] > row[nvals + 3 + c] ? need[c] : row[nvals + 3 + c];
       }
@@ -784,6 +787,7 @@ int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_
       }
       if (overflow || disagree) {
         ++lg->stats.aborted;
+        ++lg->epoch;
         glx_set_error(disagree ? "speculated requests differ between the ranks (length, neighbor_count, sampler, padding, "
                                  "seed or call_counter): their results are void, and this ledger no longer speculates"
                                : "a speculated request did not fit its fixed-capacity messages: the results of the "
@@ -1012,7 +1016,8 @@ int dist_sample_speculated(glx_dist_store* st, glx_dist_ledger* lg, int shape, i
 
   const unsigned gx = (unsigned)((cap + 255) / 256 < 1024 ? (cap + 255) / 256 : 1024);
   glx_dist_spec_pack_kernel<<<dim3(gx > 0 ? gx : 1, (unsigned)P), 256, 0, s>>>(bucketed, order, st->d_vals, P, cap, n, send_ids,
-                                                                              send_rows, cnt_off, lg->d_words, shape);
+                                                                              send_rows, cnt_off, lg->d_words, shape,
+                                                                              lg->epoch + 1);
   GLX_HIP(hipGetLastError());
   if (rg != nullptr) {
     // the replica serves its bucket straight into the caller's response.  Its size stays on the device, so the launch

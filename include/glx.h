@@ -605,7 +605,8 @@ GLX_API int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out);
  * ledger (the aggregation's, glx_dist_aggregate_begin; or glx_dist_confirm): that call returns GLX_ABORTED on every rank
  * when any bucket of any rank did not fit, and the results of all speculated calls since the previous successful
  * exchange are void -- redo them (same call counters: same answers); the capacities have been raised to what was
- * needed, so the repeat fits.  Results of confirmed calls are bit-identical to the count-exchange path.
+ * needed, so the repeat fits (voided calls still in flight on other streams need no draining: an abort starts a new
+ * epoch and their flags are not heeded).  Results of confirmed calls are bit-identical to the count-exchange path.
  * Contract (SPMD lockstep): every rank issues the same sequence of glx_dist_sample calls with the same request length,
  * neighbor_count, sampler, padding, seed and call_counter -- the owners serve all requesters with their OWN parameters.
  * A digest of those parameters travels with the confirmation; ranks that disagree get GLX_ABORTED and the ledger stops
