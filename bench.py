@@ -539,7 +539,9 @@ def other_configs(args):
     import subprocess
     out = {}
     for name in [x for x in args.other_configs.split(",") if x.strip()]:
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", name, "--steps", str(args.steps),
+        wl_name, _, variant = name.partition("-")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", wl_name,
+               "--seed-dist", "degree" if variant == "degree-seeds" else "uniform", "--steps", str(args.steps),
                "--warmup", str(args.warmup), "--cpu-baseline", "off", "--host-boundary", "off", "--edge-cut-probe", "off",
                "--small-batches", "off", "--other-configs", ""]
         t0 = time.time()
@@ -547,7 +549,7 @@ def other_configs(args):
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
             rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            out[name] = {"workload": rec["config"]["workload"], "ms_per_step": rec["ms_per_step"], "value": rec["value"],
+            out[name] = {"workload": rec["config"]["workload"], "seeds": rec["config"].get("seeds"), "ms_per_step": rec["ms_per_step"], "value": rec["value"],
                          "unit": rec["unit"], "steps": rec["steps"], "phases": rec.get("phases"), "roofline": rec.get("roofline"),
                          "roofline_sampler": rec.get("roofline_sampler"), "verified_vs_oracle": rec.get("verified_vs_oracle"),
                          "wall_s": time.time() - t0}
@@ -635,7 +637,11 @@ def main():
     ap.add_argument("--verify-oracle", default="on", choices=["on", "off"],
                     help="N=1: after timing, re-check the last timed step's outputs on row subsets against the oracle "
                          "(tests/headline_check.py) and emit \"verified_vs_oracle\"")
-    ap.add_argument("--other-configs", default="c2,c5,c4",
+    ap.add_argument("--seed-dist", default="uniform", choices=["uniform", "degree"],
+                    help="seed vertices of a batch: uniform over the vertices that have out-edges, or degree-biased (the source "
+                         "of a uniformly drawn edge: hubs are asked for in proportion to their out-degree) -- SURVEY 8(d)'s two "
+                         "request mixes")
+    ap.add_argument("--other-configs", default="c2,c5,c4,c3-degree-seeds",
                     help="N=1, headline workload at the default batch: also time these workloads (comma separated), each in a "
                          "process of its own, and report them under \"other_configs\"")
     ap.add_argument("--force-sharded", action="store_true",
@@ -714,6 +720,8 @@ def main():
     # vertices reached by sampling may still have no out-edges: those rows are
     # default-filled exactly as the reference does (random_sampler.cc:58-59).
     seed_pool = torch.unique(src)
+    if args.seed_dist == "degree":
+        seed_pool = src.clone()  # one entry per edge: a uniform draw from it picks a vertex in proportion to its out-degree
 
     # The CPU baseline runs AFTER the timed GPU region (an idle GPU clocks down during
     # 1-2 minutes of host work); keep host copies of the edge list for it.
@@ -1344,7 +1352,8 @@ def main():
                                              "" if not sharded else " -- value = %s placement, %s (the faster of the two "
                                              "exchange modes timed; both are in placements)" % (headline, exchange_mode)),
                    "seeds_per_step_per_gpu": B0,
-                   "seeds": "uniform over the vertices that have out-edges, fresh batch every step",
+                   "seeds": ("uniform over the vertices that have out-edges" if args.seed_dist == "uniform" else
+                             "degree-biased: the sources of uniformly drawn edges") + ", fresh batch every step",
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
                    "arithmetic": "int64 ids / edge ids (bit-exact), f32 features and aggregates",
                    "nodes": V, "edges": E, "hop2_rows_without_out_edges_fraction": empty_frac,
