@@ -655,7 +655,7 @@ def main():
                     help="reference StorageMode for the CPU baseline: 2 = its default (vector-of-vectors adjacency, "
                          "per-node attribute objects), 3 = compressed (CSR + flat attributes): the faster of the "
                          "two on this workload (5.15 M vs 4.5 M edges/s), hence the default here")
-    ap.add_argument("--cpu-thread-sweep", default="",
+    ap.add_argument("--cpu-thread-sweep", default="1,0",
                     help="comma separated extra thread counts for the CPU baseline (0 = nproc), e.g. '1,0'")
     args = ap.parse_args()
 
