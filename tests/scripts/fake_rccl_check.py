@@ -78,6 +78,22 @@ def run(P, max_message_bytes):
                     assert torch.equal(pn, whole.sample("TopkSampler", part, 3, seed=1, call_counter=5)[0])
                     stats = st.stats()
                     assert stats["exchange_rounds"] >= 1
+                # equal-length requests in lockstep with a speculation ledger: fixed-size send / recv groups, no count
+                # all-gather for the sampling calls, the aggregation's confirms them
+                lg = glx.Ledger(0).attach(st)
+                for i in range(4):
+                    eq = torch.from_numpy(np.random.default_rng(7 * i + r).integers(0, V, 2000).astype(np.int64)).to(dev)
+                    before = st.stats()["host_syncs"]
+                    n1, e1 = st.sample("EdgeWeightSampler", eq, 8, seed=3, call_counter=2 * i)
+                    n2, e2 = st.sample("EdgeWeightSampler", n1.view(-1), 4, seed=3, call_counter=2 * i + 1)
+                    e, c = st.aggregate("MaxAggregator", n2.view(-1), None, 16000)
+                    assert st.stats()["host_syncs"] - before == (3 if i == 0 else 1), i
+                    w1, _ = whole.sample("EdgeWeightSampler", eq, 8, seed=3, call_counter=2 * i)
+                    w2, we2 = whole.sample("EdgeWeightSampler", w1.view(-1), 4, seed=3, call_counter=2 * i + 1)
+                    we, wc = feats.aggregate("MaxAggregator", w2.view(-1), None, 16000)
+                    assert torch.equal(n2, w2) and torch.equal(e2, we2) and torch.equal(e.view(torch.int32), we.view(torch.int32)), (r, i)
+                assert lg.stats()["speculated"] == 6 and lg.stats()["aborted"] == 0
+                lg.close()
                 torch.cuda.current_stream().synchronize()
                 st.close()
             comm.close()
