@@ -586,6 +586,10 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="after timing, recompute one step on an unpartitioned copy of the graph held by this "
                          "rank and require bit-identical outputs from the sharded path")
+    ap.add_argument("--verify-sharded", default="auto", choices=["auto", "off"],
+                    help="N>1: auto = --verify whenever an unpartitioned copy of the graph and the feature table fits "
+                         "beside the shards (<= 64 GiB): every partitioned leg of the line is then checked, bit for bit, "
+                         "against the unpartitioned operators on every rank")
     ap.add_argument("--hot-fraction", type=float, default=0.25,
                     help="N>1: every GPU keeps a replica of this fraction of the feature rows (the top vertices by "
                          "global in-degree); the rest is fetched per request (halo exchange of the cold tail)")
@@ -748,6 +752,8 @@ def main():
     else:
         X = synth.features_torch(V, D, gseed + 1, dev)
         import dist as gdist
+        if not args.verify and args.verify_sharded == "auto" and V * D * 4 + E * 56 <= 64 * (1 << 30):
+            args.verify = True
         if args.verify:
             whole = (glx.Graph.from_edges(src, dst, weight, device=local_rank), glx.Features(X, device=local_rank))
         own = (src % world) == rank  # edge-cut: out-edges of v live on shard llabs(v) % P
