@@ -165,20 +165,86 @@ struct ResolveArgs {
 // iterations: per-wave atomics on P global addresses (a quarter of a million waves on eight
 // counters) serialised the whole kernel -- 10 ms for a 16 M-id request.
 constexpr int kFlushIds = 2048;  // ids a block resolves between two flushes of its counters
-template <int kIds>
+// kQueue (a replica is attached, so ids it does not hold are a small share of the request): those ids are queued per
+// wave in LDS and resolved 64 at a time with every lane busy.  Their path -- owner, own-shard probe or insert into the
+// halo set: three or four dependent memory round trips -- otherwise runs with one or two lanes of a wave, and every
+// wave-iteration waits for it: 0.67 ms instead of 0.1 for an 18 M-id request at P = 8 with 4 % of the ids off the replica.
+template <int kIds, bool kQueue>
 __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   __shared__ int32_t s_stat[3];
   __shared__ int32_t s_cnt[kMaxWorld];
   __shared__ int32_t s_sum;
   __shared__ int32_t s_void;  // the overflow flag as of the last flush (reading the global flag per id made one
                               // L2 address the hot spot of the kernel)
-  if (threadIdx.x == 0) s_void = 0;
+  if (threadIdx.x == 0) {
+    s_void = 0;
+    s_sum = 0;
+  }
   if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
   if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   int32_t n_hit = 0, n_own = 0, n_cold = 0;
   int it = 0;
+  __shared__ int64_t s_qid[kQueue ? 4 : 1][kQueue ? 128 : 1];
+  __shared__ int32_t s_qi[kQueue ? 4 : 1][kQueue ? 128 : 1];
+  int64_t* qid = s_qid[kQueue ? (threadIdx.x >> 6) : 0];
+  int32_t* qi = s_qi[kQueue ? (threadIdx.x >> 6) : 0];
+  int qn = 0;  // queued ids of this wave (wave-uniform)
+
+  // One id off the replica: own shard -> its row; remote -> its slot in the halo set (winner: the first to claim it).
+  auto resolve_cold = [&](int64_t id, int32_t& owner, bool& winner, int32_t voided) -> int32_t {
+    int32_t out = -1;
+    owner = dist_owner(id, a.P);
+    if (owner == a.me || id == GLX_EMPTY_KEY) {
+      const int64_t rr = glx_row_of(a.own_map, id);
+      out = rr >= 0 ? (int32_t)rr : -1;
+      ++n_own;
+    } else if (voided != 0) {
+      ++n_cold;  // the set already overflowed: this pass is void, the host retries with a larger one
+    } else {
+      ++n_cold;
+      uint64_t h = glx_mix64((uint64_t)id) & a.tmask;
+      int probes = 0;
+      while (true) {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&a.tkeys[h]),
+                                                  (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)id);
+        if ((int64_t)prev == GLX_EMPTY_KEY || (int64_t)prev == id) {
+          winner = (int64_t)prev == GLX_EMPTY_KEY;
+          out = -(int32_t)h - 2;
+          break;
+        }
+        h = (h + 1) & a.tmask;
+        if (++probes > a.max_probe) {  // the set is too small: the host retries with a larger one
+          a.ctr[2 * a.P] = 1;
+          break;
+        }
+      }
+    }
+    return out;
+  };
+  // new distinct ids: one LDS atomic per (wave, owner)
+  auto count_winners = [&](bool winner, int32_t owner) {
+    uint64_t pending = __ballot(winner);
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      const int32_t o = __shfl(owner, leader);
+      const uint64_t same = __ballot(winner && owner == o);
+      if (lane == leader) atomicAdd(&s_cnt[o], __popcll(same));
+      pending &= ~same;
+    }
+  };
+  auto serve_queue = [&](int count) {  // lanes [0, count) resolve the head of the wave's queue
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // entries other lanes queued
+    __builtin_amdgcn_wave_barrier();
+    bool winner = false;
+    int32_t owner = 0;
+    // the overflow flag once per 64 ids (per id it made one L2 address the hot spot of the kernel); no block-wide
+    // flush in this mode: its barriers made every wave wait for whichever wave was serving its queue (0.51 -> 0.19 ms)
+    const int32_t voided = __shfl(lane == 0 ? __atomic_load_n(&a.ctr[2 * a.P], __ATOMIC_RELAXED) : 0, 0);
+    if (lane < count) a.loc[qi[lane]] = resolve_cold(qid[lane], owner, winner, voided);
+    count_winners(winner, owner);
+  };
   // kIds ids per thread per iteration: the loads of the replica lookup (the common case: a hop-2 request finds
   // ~96 % of its ids there) are independent and issued back to back; the rare rest is handled id by id.
   for (int64_t base = blockIdx.x * (256ll * kIds); base < a.n; base += gridDim.x * (256ll * kIds), ++it) {
@@ -228,81 +294,62 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
 #pragma unroll
     for (int j = 0; j < kIds; ++j) {
       const int64_t i = base + j * 256 + threadIdx.x;
-      bool winner = false;
+      bool winner = false, cold = false;
       int32_t owner = 0;
       if (i < a.n) {
-        int32_t out = -1;
         if (r[j] >= 0) {
-          out = a.cache_base + (int32_t)r[j];
+          a.loc[i] = a.cache_base + (int32_t)r[j];
           ++n_hit;
+        } else if (kQueue) {
+          cold = true;
         } else {
-          owner = dist_owner(id[j], a.P);
-          if (owner == a.me || id[j] == GLX_EMPTY_KEY) {
-            const int64_t rr = glx_row_of(a.own_map, id[j]);
-            out = rr >= 0 ? (int32_t)rr : -1;
-            ++n_own;
-          } else if (s_void != 0) {
-            ++n_cold;  // the set already overflowed: this pass is void, the host retries with a larger one
-          } else {
-            ++n_cold;
-            uint64_t h = glx_mix64((uint64_t)id[j]) & a.tmask;
-            int probes = 0;
-            while (true) {
-              const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&a.tkeys[h]),
-                                                        (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)id[j]);
-              if ((int64_t)prev == GLX_EMPTY_KEY) {
-                winner = true;
-                out = -(int32_t)h - 2;
-                break;
-              }
-              if ((int64_t)prev == id[j]) {
-                out = -(int32_t)h - 2;
-                break;
-              }
-              h = (h + 1) & a.tmask;
-              if (++probes > a.max_probe) {  // the set is too small: the host retries with a larger one
-                a.ctr[2 * a.P] = 1;
-                out = -1;
-                break;
-              }
-            }
+          a.loc[i] = resolve_cold(id[j], owner, winner, s_void);
+        }
+      }
+      if (kQueue) {
+        const uint64_t m = __ballot(cold);
+        if (cold) {
+          const int at = qn + __popcll(m & ((1ull << lane) - 1ull));
+          qid[at] = id[j];
+          qi[at] = (int32_t)i;
+        }
+        qn += __popcll(m);
+        if (qn >= 64) {
+          serve_queue(64);
+          qn -= 64;
+          const int64_t mv_id = lane < qn ? qid[64 + lane] : 0;
+          const int32_t mv_i = lane < qn ? qi[64 + lane] : 0;
+          __builtin_amdgcn_wave_barrier();
+          if (lane < qn) {
+            qid[lane] = mv_id;
+            qi[lane] = mv_i;
           }
         }
-        a.loc[i] = out;
-      }
-      // new distinct ids: one LDS atomic per (wave, owner)
-      uint64_t pending = __ballot(winner);
-      while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int32_t o = __shfl(owner, leader);
-        const uint64_t same = __ballot(winner && owner == o);
-        if (lane == leader) atomicAdd(&s_cnt[o], __popcll(same));
-        pending &= ~same;
+      } else {
+        count_winners(winner, owner);
       }
     }
-    if ((it % (kFlushIds / (256 * kIds))) == kFlushIds / (256 * kIds) - 1) {
+    if (!kQueue && (it % (kFlushIds / (256 * kIds))) == kFlushIds / (256 * kIds) - 1) {
       // flush: P global atomics per block, and the running total decides early whether the set is too small
+      // ONE global atomic per flush (the running total decides early whether the set is too small); the per-owner
+      // counts stay in LDS until the block ends -- flushing them too put 8 same-address atomics per flush and block
+      // on the path of a request with remote ids: 0.67 ms instead of 0.2 for 18 M ids at P = 8
       __syncthreads();
       if (threadIdx.x == 0) {
         int32_t sum = 0;
         for (int32_t p = 0; p < a.P; ++p) sum += s_cnt[p];
+        const int32_t fresh = sum - s_sum;
         s_sum = sum;
-      }
-      __syncthreads();
-      if ((int)threadIdx.x < a.P && s_cnt[threadIdx.x]) {
-        atomicAdd(&a.ctr[threadIdx.x], s_cnt[threadIdx.x]);
-        s_cnt[threadIdx.x] = 0;
-      }
-      if (threadIdx.x == 0) {
-        if (s_sum) {
-          const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], s_sum);
-          if (before + s_sum > a.insert_limit) a.ctr[2 * a.P] = 1;
+        if (fresh) {
+          const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], fresh);
+          if (before + fresh > a.insert_limit) a.ctr[2 * a.P] = 1;
         }
         s_void = __atomic_load_n(&a.ctr[2 * a.P], __ATOMIC_RELAXED);
       }
       __syncthreads();
     }
   }
+  if (kQueue && qn > 0) serve_queue(qn);
   atomicAdd(&s_stat[0], n_hit);
   atomicAdd(&s_stat[1], n_own);
   atomicAdd(&s_stat[2], n_cold);
@@ -312,9 +359,10 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   if (threadIdx.x == 0) {
     int32_t sum = 0;
     for (int32_t p = 0; p < a.P; ++p) sum += s_cnt[p];
-    if (sum) {
-      const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], sum);
-      if (before + sum > a.insert_limit) a.ctr[2 * a.P] = 1;
+    const int32_t fresh = sum - s_sum;
+    if (fresh) {
+      const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], fresh);
+      if (before + fresh > a.insert_limit) a.ctr[2 * a.P] = 1;
     }
   }
 }
@@ -899,8 +947,17 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
       // records (0.10 ms; one: 0.12, four: 0.12), one with the hash map (0.30; two: 0.32, four: 0.34) --
       // scripts/resolve_probe.py.
       if (n > 0) {
-        if (a.bm_member) glx_dist_resolve_kernel<2><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
-        else glx_dist_resolve_kernel<1><<<grid_for(n, 1024), 256, 0, s>>>(a);
+        // with a replica the ids it does not hold are a small share of the request: queued per wave and resolved
+        // 64 at a time (kQueue); without one every id takes that path and a queue would only add work
+        static const bool kNoQueue = getenv("GLX_RESOLVE_NO_QUEUE") != nullptr;  // (ablation)
+        if (a.has_cache && !kNoQueue) {
+          if (a.bm_member) glx_dist_resolve_kernel<2, true><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
+          else glx_dist_resolve_kernel<1, true><<<grid_for(n, 1024), 256, 0, s>>>(a);
+        } else if (a.bm_member) {
+          glx_dist_resolve_kernel<2, false><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
+        } else {
+          glx_dist_resolve_kernel<1, false><<<grid_for(n, 1024), 256, 0, s>>>(a);
+        }
       }
       glx_dist_offsets_kernel<<<1, 64, 0, s>>>(st->d_ctr, P, tcap, st->d_vals);
       ReqParams prm;
