@@ -629,6 +629,9 @@ def main():
                          "sampling requests travel in fixed-capacity messages without a count exchange, the aggregation's "
                          "count exchange confirms them -- one blocking host wait per step instead of three; reported as "
                          "placements.*_speculated, verified like the others")
+    ap.add_argument("--design-r", default="on", choices=["on", "off"],
+                    help="N>1, with --pure-leg on: also time the pure placement with the reference's partial-reduce-and-stitch "
+                         "aggregation (glx_dist_aggregate_partial) instead of the halo-row exchange; placements.edge_cut_pure_design_r")
     ap.add_argument("--graph-hot-fraction", type=float, default=None,
                     help="N>1: fraction of the vertices (hottest first) whose adjacency rows are replicated; "
                          "default: --hot-fraction")
@@ -1246,6 +1249,47 @@ def main():
                 dog.daemon = True
                 dog.start()
                 speculated_leg("edge_cut_pure_speculated")
+            if args.design_r == "on":
+                # SURVEY 8(e)'s ablation: the reference's own shape of a distributed aggregation -- every owner reduces the
+                # ids it holds, the requester folds the P partial results (AggregatingResponse::Stitch,
+                # aggregating_request.cc:172-213) -- instead of the halo-row exchange; same steps, same placement (R keeps
+                # no replica).  Traffic per request: P x segments x (4D + 4) bytes back instead of 4D per distinct remote id.
+                dog.cancel()
+                dog = threading.Timer(args.watchdog, give_up)
+                dog.daemon = True
+                dog.start()
+
+                def agg_r(a, b, i):
+                    st_agg.aggregate(agg, b.view(-1), None, n1, out=(emb2, cnt2), partial=True)
+                    st_agg.aggregate(agg, a.view(-1), None, B0, out=(emb1, cnt1), partial=True)
+                el_d, _, _ = guarded("edge_cut_pure_design_r", lambda: timed_leg(agg_r, args.warmup, n_steps, args.warmup))
+                legs["edge_cut_pure_design_r"] = {
+                    "ms_per_step": el_d / args.steps * 1e3, "value": world * edges_per_step * args.steps / el_d,
+                    "note": "partial reduce on the owners + fold on the requester (glx_dist_aggregate_partial) instead of the "
+                            "halo-row exchange; Max / Min / counts equal the single store exactly, Sum / Mean / Prod within "
+                            "1e-5 relative (per-shard partials are folded: the reference's distributed mode reassociates "
+                            "the same way)"}
+                if args.verify:
+                    def verify_r():
+                        i = n_steps - 1
+                        a, b = do_sample(i)
+                        agg_r(a, b, i)
+                        wa, _ = whole[0].sample(sampler, seeds[i], k1, seed=42, call_counter=4 * i)
+                        wb, _ = whole[0].sample(sampler, wa.view(-1), k2, seed=42, call_counter=4 * i + 1)
+                        we2, wc2 = whole[1].aggregate(agg, wb.view(-1), None, n1)
+                        we1, wc1 = whole[1].aggregate(agg, wa.view(-1), None, B0)
+                        torch.cuda.synchronize()
+                        exact = agg in ("MaxAggregator", "MinAggregator")
+                        same = (lambda x, y: torch.equal(x.view(torch.int32), y.view(torch.int32))) if exact else \
+                               (lambda x, y: bool(((x - y).abs() <= 1e-5 * y.abs() + 1e-6).all()))
+                        ok = bool(torch.equal(b, wb) and torch.equal(cnt2, wc2) and torch.equal(cnt1, wc1)
+                                  and same(emb2, we2) and same(emb1, we1))
+                        if world > 1:
+                            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=ctl)
+                            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                            ok = bool(flag.item())
+                        return ok
+                    verified_legs["edge_cut_pure_design_r"] = guarded("verify", verify_r)
         dog.cancel()
 
     # the last timed step's outputs against the oracle, before anything else touches the buffers
@@ -1393,6 +1437,7 @@ def main():
         res["value_features_sharded"] = legs["features_sharded"]["value"]
         res["value_features_sharded_speculated"] = legs.get("features_sharded_speculated", {}).get("value")
         res["value_edge_cut_pure"] = legs.get("edge_cut_pure", {}).get("value")
+        res["value_edge_cut_pure_design_r"] = legs.get("edge_cut_pure_design_r", {}).get("value")
         res["value_features_replicated"] = legs.get("features_replicated", {}).get("value")
         res["placements"] = legs
         res["halo_exchange_hop2"] = dict(halo_stats, hot_rows=int(hot.shape[0]), hot_fraction=args.hot_fraction,

@@ -50,7 +50,9 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
     pure = res["placements"]["edge_cut_pure"]
     assert pure["value"] > 0 and res["value_edge_cut_pure"] == pure["value"]
     assert res["verified_legs"] == {"features_sharded": True, "features_sharded_speculated": True, "edge_cut_pure": True,
-                                    "edge_cut_pure_speculated": True}
+                                    "edge_cut_pure_speculated": True, "edge_cut_pure_design_r": True}
+    # the reference's own distributed aggregation (owners reduce, requester folds) as an ablation of the halo exchange
+    assert res["placements"]["edge_cut_pure_design_r"]["value"] == res["value_edge_cut_pure_design_r"] > 0
     # the same placements with a speculation ledger: after the first step only the aggregation exchanges counts
     for name in ("features_sharded_speculated", "edge_cut_pure_speculated"):
         leg = res["placements"][name]
