@@ -203,6 +203,7 @@ struct LocalPost {
   const int64_t* send_counts;
   const int64_t* send_offs;
   const int64_t* h_vals;
+  hipEvent_t ready;  // alltoallv: the poster's send buffers are complete when this fires
 };
 
 struct LocalFabric {
@@ -215,6 +216,7 @@ struct LocalFabric {
   uint64_t gen = 0;
   bool broken = false;
   LocalPost post[64];
+  hipEvent_t done[64];  // alltoallv: rank q has read what it needed from its peers' send buffers when done[q] fires
 
   // Generation barrier with a deadline: a rank that failed before the collective must not
   // hang its peers (and the GPU box) forever.
@@ -247,9 +249,13 @@ std::map<int64_t, LocalFabric*> g_fabrics;
 struct LocalComm : glx_comm {
   LocalFabric* fab = nullptr;
   CountStage stage;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   ~LocalComm() override {
     {
       GlxDeviceGuard guard(device);
+      (void)hipDeviceSynchronize();  // peers' streams may still wait on this rank's events
+      if (ev_ready) (void)hipEventDestroy(ev_ready);
+      if (ev_done) (void)hipEventDestroy(ev_done);
       stage.release();
     }
     std::lock_guard<std::mutex> g(g_fabric_mtx);
@@ -259,11 +265,17 @@ struct LocalComm : glx_comm {
     }
   }
 
+  // The ranks meet on the HOST twice (to see each other's posts, and to know every reader has enqueued its copies);
+  // the streams never drain: a rank's copies wait for its peers' `ready` events, and its stream waits for every
+  // peer's `done` event before anything later may touch the send buffers again -- the device-side order of a real
+  // transport, without link time.
   int alltoallv(const GlxSeg* segs, int nseg, const int64_t* send_counts, const int64_t* send_offs,
                 const int64_t* recv_counts, const int64_t* recv_offs, hipStream_t s) override {
     last_rounds = 1;
-    GLX_HIP(hipStreamSynchronize(s));  // my send buffers are complete in memory
-    fab->post[rank] = LocalPost{segs, nseg, send_counts, send_offs, nullptr};
+    if (!ev_ready) GLX_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+    if (!ev_done) GLX_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    GLX_HIP(hipEventRecord(ev_ready, s));
+    fab->post[rank] = LocalPost{segs, nseg, send_counts, send_offs, nullptr, ev_ready};
     int rc = fab->barrier();
     if (rc != GLX_OK) return rc;
     hipError_t e = hipSuccess;
@@ -274,21 +286,33 @@ struct LocalComm : glx_comm {
         mismatch = true;
         break;
       }
+      bool waited = q == rank;
       for (int j = 0; j < nseg && e == hipSuccess; ++j) {
         const size_t eb = segs[j].elem_bytes;
         const size_t bytes = (size_t)recv_counts[q] * eb;
         if (bytes == 0) continue;
+        if (!waited) {
+          e = hipStreamWaitEvent(s, from.ready, 0);
+          waited = true;
+          if (e != hipSuccess) break;
+        }
         e = hipMemcpyAsync(static_cast<char*>(segs[j].recv) + (size_t)recv_offs[q] * eb,
                            static_cast<const char*>(from.segs[j].send) + (size_t)from.send_offs[rank] * eb, bytes,
                            hipMemcpyDefault, s);
       }
     }
-    hipError_t e2 = hipStreamSynchronize(s);  // peers may reuse their send buffers after the barrier
-    rc = fab->barrier();
+    if (e == hipSuccess) e = hipEventRecord(ev_done, s);
+    fab->done[rank] = ev_done;
+    rc = fab->barrier();  // every reader has enqueued its copies (the posts' host arrays may go now)
     GLX_REQUIRE(!mismatch, "local communicator: send / receive counts of two ranks disagree");
     GLX_HIP(e);
-    GLX_HIP(e2);
-    return rc;
+    if (rc != GLX_OK) return rc;
+    for (int q = 0; q < world; ++q) {
+      if (q != rank) GLX_HIP(hipStreamWaitEvent(s, fab->done[q], 0));
+    }
+    // (the events are re-recorded by this rank's NEXT call only after that call's first meeting, which no peer reaches
+    // before it has enqueued the waits above)
+    return GLX_OK;
   }
 
   int allgather_i64(const int64_t* d_vals, int nvals, int64_t* h_out, hipStream_t s) override {
