@@ -32,7 +32,7 @@ case "$what" in
     cd /tmp && export TMPDIR=/tmp
     GRAPH_REPLICA=1 MERGED=1 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_solo -o p8 --output-format csv -- \
       python $R/scripts/edge_cut_p8_probe.py 8 0.25 6 solo 2>&1 | grep "ONLY rank 0"
-    cp $O/prof_solo/*/*kernel_stats.csv $O/p8_solo_kernel_stats.csv 2>/dev/null || cp $O/prof_solo/*kernel_stats.csv $O/p8_solo_kernel_stats.csv
-    rm -rf $O/prof_solo; head -20 $O/p8_solo_kernel_stats.csv | cut -c1-160 ;;
+    python $R/scripts/r03/p8_solo_step.py $(find $O/prof_solo -name '*kernel_trace.csv' | head -1) | tee $O/p8_solo_step.txt
+    rm -rf $O/prof_solo ;;
   *) echo "usage: gpu.sh tests|all|world1|p8|p8-solo"; exit 2 ;;
 esac
