@@ -59,6 +59,14 @@ def main():
     negatives = g.negative_sampler("buy", 4, strategy="in_degree").get(seeds)
     print("4 popularity-weighted negatives per user", negatives.ids.shape)
 
+    # 1b. the same walk as a GSL query: every step is one request of the sampler object it names
+    query = g.V("user").batch(8).shuffle(traverse=True).alias("u") \
+             .outV("buy").sample(5).by("edge_weight").alias("items") \
+             .inV("buy").sample(3).by("random").alias("co_buyers") \
+             .values(lambda r: (r["u"].ids, r["items"].labels, r["co_buyers"].ids))
+    users, labels, co = gl.Dataset(query).next()
+    print("GSL batch: users", users.shape, "item labels", labels.shape, "co-buyers", co.shape)
+
     # 2. device tensors in / out: all hops in one call, nothing leaves the GPU
     import torch
     hops = g.neighbor_sampler(["buy", "buy_reverse"], [5, 3], "edge_weight").get_device(torch.from_numpy(seeds).cuda())

@@ -21,6 +21,7 @@ from graphlearn.sampler import *  # noqa: F401,F403
 from graphlearn.traversal import *  # noqa: F401,F403
 from graphlearn.graph import Graph  # noqa: F401
 from graphlearn.loader import NeighborLoader, NeighborBatch  # noqa: F401
+from graphlearn.gsl import Dataset  # noqa: F401
 
 NODE = pywrap.NodeFrom.NODE
 EDGE_SRC = pywrap.NodeFrom.EDGE_SRC

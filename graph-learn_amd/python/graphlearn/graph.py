@@ -371,14 +371,22 @@ class Graph(object):
     errors.raise_exception_on_not_ok_status(status)
     return walks
 
-  def _off_path(self, what):
-    raise NotImplementedError("%s is outside the sampling/aggregation path this engine replaces" % what)
+  # -- GSL (python/graph.py:645-718 in the reference; steps and Dataset: gsl.py) ------------------
+  def V(self, t, feed=None, node_from=pywrap.NodeFrom.NODE, mask=Mask.NONE):  # pylint: disable=invalid-name
+    """Starts a query at batches of vertices: of node type `t`, or (node_from = EDGE_SRC / EDGE_DST) of the end points
+    of edge type `t`.  -> a step to chain .batch() / .shuffle() / .alias() / .outV() ... on."""
+    from graphlearn import gsl
+    if feed is not None:
+      raise NotImplementedError("feeding a query from a generator is not served: batch the ids through the sampler "
+                                "objects (Graph.neighbor_sampler ...) instead")
+    return gsl.VertexSource(gsl.Query(self), t, node_from=node_from, mask=mask)
 
-  def V(self, *args, **kwargs):  # pylint: disable=invalid-name
-    self._off_path("GSL (Graph.V)")
-
-  def E(self, *args, **kwargs):  # pylint: disable=invalid-name
-    self._off_path("GSL (Graph.E)")
+  def E(self, edge_type, feed=None, reverse=False, mask=Mask.NONE):  # pylint: disable=invalid-name
+    """Starts a query at batches of edges of `edge_type` (reverse=True: of its reversed twin, for undirected types)."""
+    from graphlearn import gsl
+    if feed is not None:
+      raise NotImplementedError("feeding a query from a generator is not served")
+    return gsl.EdgeSource(gsl.Query(self), edge_type + "_reverse" if reverse else edge_type, mask=mask)
 
   def node_sampler(self, t, batch_size=64, strategy="by_order", node_from=pywrap.NodeFrom.NODE, mask=Mask.NONE):
     """Batches of seed vertices: strategy "by_order" | "shuffle" | "random" (see traversal.py)."""
