@@ -19,8 +19,8 @@ ConditionalNegativeSampler / Graph.random_walk), so a GSL step draws exactly wha
 Results are the same Nodes / Edges / SparseNodes values, attributes looked up lazily.
 
 Supported: V / E sources (batch, shuffle, mask, node_from), outV / inV / outE / inE with sample().by(), filter(),
-outNeg / inNeg / Neg with where(), each(), random_walk(), alias(), values(func), Dataset(window, drop_last).  Not
-here: SubGraph() steps (use Graph.subgraph_sampler), feeding a query from a generator.
+outNeg / inNeg / Neg with where(), each(), random_walk(), SubGraph(), alias(), values(func), Dataset(window,
+drop_last).  Not here: feeding a query from a generator.
 """
 import numpy as np
 
@@ -164,6 +164,11 @@ class _VertexTraversals(object):
       raise ValueError("edge type {} is not in the graph".format(edge_type))
     return WalkStep(self._query, self, edge_type, int(walk_len), float(p), float(q))
 
+  def SubGraph(self, nbr_type, num_nbrs=(0,), need_dist=False):  # pylint: disable=invalid-name
+    """The sub-graph `nbr_type` induces among this step's vertices (+ num_nbrs sampled neighbours per hop):
+    dag_node.py:532-556 -> SubGraphSampler.  -> a SubGraph value (nodes, edge_index, edges)."""
+    return SubGraphStep(self._query, self, nbr_type, num_nbrs, need_dist)
+
 
 class VertexSource(Step, _VertexTraversals):
   """g.V(t): batches of vertices of a node type, or of the end points of an edge type (node_from)."""
@@ -229,6 +234,10 @@ class EdgeSource(Step):
 
   def inV(self):  # pylint: disable=invalid-name
     return EndpointStep(self._query, self, "dst")
+
+  def SubGraph(self, nbr_type, num_nbrs=(0,), need_dist=False):  # pylint: disable=invalid-name
+    """The sub-graph around the batch's (src, dst) pairs (dag_node.py:647-674; SEAL-style with need_dist)."""
+    return SubGraphStep(self._query, self, nbr_type, num_nbrs, need_dist, pairs=True)
 
   def _stored_edge_type(self):
     return self._sampler._stored  # pylint: disable=protected-access
@@ -388,6 +397,22 @@ class WalkStep(Step, _VertexTraversals):
     src = np.ascontiguousarray(results[self._upstream].ids.reshape(-1), dtype=np.int64)
     walks = self._query.graph.random_walk(self._edge_type, src, self._walk_len, p=self._p, q=self._q)
     return self._query.graph.get_nodes(self._vertex_type(), walks.reshape(-1), shape=(src.size, self._walk_len))
+
+
+class SubGraphStep(Step):
+  """SubGraph(): one SubGraphSampler request per batch; its value is a sampler.SubGraph, not Nodes, so nothing chains
+  from it (as in the reference, where SubGraphDagNode has no traversals)."""
+
+  def __init__(self, query, upstream, nbr_type, num_nbrs, need_dist, pairs=False):
+    Step.__init__(self, query, upstream)
+    self._pairs = pairs
+    self._sampler = query.graph.subgraph_sampler(nbr_type, num_nbrs=num_nbrs, need_dist=need_dist)
+
+  def _evaluate(self, results):
+    up = results[self._upstream]
+    if self._pairs:
+      return self._sampler.get(up.src_ids.reshape(-1), up.dst_ids.reshape(-1))
+    return self._sampler.get(up.ids.reshape(-1))
 
 
 class Dataset(object):

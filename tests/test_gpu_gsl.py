@@ -198,6 +198,34 @@ def test_shuffle_and_node_from(gl, g):
     assert res['b'].shape == (6, 2) and res['b'].type == NODE1
 
 
+def test_subgraph_step(gl, g):
+    """python/sampler/tests/test_subgraph_sampling.py through a query: batches of 8 entity nodes in order, the
+    sub-graph the relation edges induce among them (the same expectations as the sampler-object test)."""
+    q = g.V("entity").batch(8).alias('seed').SubGraph("relation").alias('sub').values()
+    batches = []
+
+    def check(res):
+        sub, ids = res['sub'], res['sub'].nodes.ids
+        np.testing.assert_equal(np.sort(ids), np.sort(res['seed'].ids))
+        np.testing.assert_equal(sub.nodes.labels, ids)
+        rows, cols = [], []
+        for i in range(ids.size):
+            for j in range(ids.size):
+                if (ids[i] < 100 or ids[j] < 100) and abs(int(ids[i]) - int(ids[j])) in (2, 3, 5):
+                    rows += [i, j]
+                    cols += [j, i]
+        np.testing.assert_equal(sub.edge_index[0], np.array(rows, dtype=np.int32))
+        np.testing.assert_equal(sub.edge_index[1], np.array(cols, dtype=np.int32))
+        batches.append(ids.size)
+    assert _drain(gl, gl.Dataset(q), check) == 15
+    # around the (src, dst) pairs of an edge batch
+    res = gl.Dataset(g.E("relation").batch(1).alias('e').SubGraph("relation", num_nbrs=[2], need_dist=True).alias('s')
+                     .values()).next()
+    sub = res['s']
+    assert {int(res['e'].src_ids[0]), int(res['e'].dst_ids[0])} <= set(sub.nodes.ids.tolist())
+    assert sub.dist_to_src is not None and len(sub.dist_to_src) == sub.nodes.ids.size
+
+
 def test_query_errors(gl, g):
     with pytest.raises(ValueError):
         g.V("no_such_type")
