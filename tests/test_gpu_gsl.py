@@ -226,6 +226,30 @@ def test_subgraph_step(gl, g):
     assert sub.dist_to_src is not None and len(sub.dist_to_src) == sub.nodes.ids.size
 
 
+def test_edge_and_node_iteration_reference_cases(gl, g):
+    """python/tests/test_{node,edge}_{iterate,shuffle}_gsl.py restated on the shared fixture: by_order and
+    shuffle(traverse=True) visit every element exactly once per epoch, shuffle() draws from the whole set for ever."""
+    all_src = sorted(s for s in range(*RANGE2) for _ in fx.fixed_dst_ids(s, RANGE1))
+    for shuffled in (False, True):
+        src = g.E(EDGE2).batch(4)
+        q = (src.shuffle(traverse=True) if shuffled else src).alias('seed').values()
+        got_src, order = [], []
+
+        def check(res):
+            e = res['seed']
+            np.testing.assert_almost_equal(e.weights, (e.src_ids + 0.1 * e.dst_ids) / 10.0, decimal=4)
+            got_src.extend(e.src_ids.tolist())
+            order.extend(e.edge_ids.tolist())
+        _drain(gl, gl.Dataset(q, window=1), check)
+        assert sorted(got_src) == all_src and sorted(order) == list(range(len(all_src)))
+        assert (order != sorted(order)) == shuffled
+    ds = gl.Dataset(g.V(NODE2).batch(4).shuffle().alias('n').values())
+    for _ in range(60):  # more batches than an epoch holds: never out of range
+        nodes = ds.next()['n']
+        assert set(nodes.ids.tolist()) <= set(range(*RANGE2))
+        np.testing.assert_equal(nodes.labels, nodes.ids)
+
+
 def test_query_errors(gl, g):
     with pytest.raises(ValueError):
         g.V("no_such_type")
