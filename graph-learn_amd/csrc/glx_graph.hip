@@ -12,6 +12,8 @@
 #include <new>
 #include <vector>
 
+#include <map>
+
 #include "glx_common.h"
 
 // ------------------------------------------------------------------ errors --
@@ -41,6 +43,14 @@ extern "C" int glx_device_count(int* count) {
   return GLX_OK;
 }
 
+namespace {
+// The ranges pinned through glx_host_register.  Host-pointer calls write straight into a caller buffer only when it
+// lies in one of THESE (glx_mapped_ptr): what the runtime itself reports about an arbitrary pointer also covers
+// ranges other code registered -- and, after unregistrations of ranges that shared pages, was seen to be stale.
+std::mutex g_pinned_mtx;
+std::map<uintptr_t, size_t> g_pinned;
+}  // namespace
+
 extern "C" int glx_host_register(void* p, uint64_t bytes) {
   GLX_REQUIRE(p != nullptr && bytes > 0, "bad buffer");
   int n = 0;
@@ -52,11 +62,17 @@ extern "C" int glx_host_register(void* p, uint64_t bytes) {
     glx_set_error("hipHostRegister(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
     return e == hipErrorOutOfMemory ? GLX_RESOURCE_EXHAUSTED : GLX_UNAVAILABLE;
   }
+  std::lock_guard<std::mutex> g(g_pinned_mtx);
+  g_pinned[reinterpret_cast<uintptr_t>(p)] = (size_t)bytes;
   return GLX_OK;
 }
 
 extern "C" int glx_host_unregister(void* p) {
   GLX_REQUIRE(p != nullptr, "bad buffer");
+  {
+    std::lock_guard<std::mutex> g(g_pinned_mtx);
+    g_pinned.erase(reinterpret_cast<uintptr_t>(p));
+  }
   hipError_t e = hipHostUnregister(p);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -110,14 +126,20 @@ void* glx_mapped_ptr(const void* host_ptr) {
     return e && atoi(e) == 0;
   }();
   if (off || host_ptr == nullptr) return nullptr;
-  hipPointerAttribute_t attr;
-  memset(&attr, 0, sizeof(attr));
-  if (hipPointerGetAttributes(&attr, host_ptr) != hipSuccess) {
-    (void)hipGetLastError();  // an unregistered pointer is not an error here
+  {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(host_ptr);
+    std::lock_guard<std::mutex> g(g_pinned_mtx);
+    auto it = g_pinned.upper_bound(a);
+    if (it == g_pinned.begin()) return nullptr;
+    --it;
+    if (a >= it->first + it->second) return nullptr;  // not in a range glx_host_register pinned
+  }
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, const_cast<void*>(host_ptr), 0) != hipSuccess) {
+    (void)hipGetLastError();
     return nullptr;
   }
-  if (attr.type != hipMemoryTypeHost || attr.devicePointer == nullptr) return nullptr;
-  return attr.devicePointer;
+  return dev;
 }
 
 int glx_init_device(int device) {

@@ -91,7 +91,9 @@ GLX_API const char* glx_last_error(void);
  * of it are single DMA transfers instead of bouncing through the runtime's pageable staging -- what the
  * response tensors of the C++ layer are backed by (the role of the reference's RepeatedField storage,
  * service/tensor_impl.h:72-75,196-200, on this path).  Both return GLX_UNAVAILABLE without a GPU runtime;
- * an unregistered buffer works everywhere, only slower. */
+ * an unregistered buffer works everywhere, only slower.  Register whole pages the buffer owns (page-aligned start, a
+ * multiple of the page size): a range that shares a page with other data or another registration is left to the
+ * runtime's bookkeeping.  Only ranges registered HERE are written directly; memory pinned by other means is staged. */
 GLX_API int glx_host_register(void* p, uint64_t bytes);
 GLX_API int glx_host_unregister(void* p);
 

@@ -750,9 +750,21 @@ def test_pinned_host_buffers_are_written_directly():
     ids = rng.integers(-2, 2003, 3000).astype(np.int64)
     vals = rng.integers(0, 2000, 3000).astype(np.int64)
 
+    owners = []
+
     def pinned(shape, dtype):
-        a = np.empty(shape, dtype)
-        assert L.glx_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) == 0, L.glx_last_error()
+        # whole pages of their own (ordinary private heap memory, the range cut on page boundaries inside a larger
+        # allocation): a registered range that shares a page with other heap data or with another registration --
+        # five 12 KB count arrays sit side by side in the heap -- is at the mercy of the runtime's bookkeeping of
+        # pinned ranges, and a LATER pageable copy from the recycled addresses was seen to hang the GPU
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        span = (nbytes + 4095) // 4096 * 4096
+        raw = np.empty(span + 2 * 4096, np.uint8)
+        owners.append(raw)
+        off = (-raw.ctypes.data) % 4096
+        a = raw[off:off + nbytes].view(dtype).reshape(shape)
+        assert a.ctypes.data % 4096 == 0
+        assert L.glx_host_register(ctypes.c_void_p(a.ctypes.data), span) == 0, L.glx_last_error()
         a.fill(0)
         return a
     bufs = []
@@ -775,6 +787,8 @@ def test_pinned_host_buffers_are_written_directly():
     finally:
         for a in bufs:
             assert L.glx_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0
+        del bufs  # the views go before their pages
+        owners.clear()
 
 
 def test_alias_tables_fuzz_bit_exact():

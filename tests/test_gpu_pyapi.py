@@ -289,7 +289,7 @@ def test_error_surface(gl, g, tmp_path):
     with pytest.raises(ValueError):
         g.neighbor_sampler([EDGE1, EDGE2], expand_factor=[3]).get(SEEDS1)
     with pytest.raises(NotImplementedError):
-        g.V(NODE1, feed=iter(()))  # generator-fed queries are the one GSL source not served (tests/test_gpu_gsl.py)
+        g.V(NODE1, feed=iter(()))  # generator-fed queries are the one GSL source not served (tests/test_gpu_pyapi_gsl.py)
     bad = fx.write_nodes(str(tmp_path), "bad_nodes", (0, 5), [fx.WEIGHTED])
     other = gl.Graph().node(bad, "x", gl.Decoder(labeled=True))  # file has weight:float, decoder says label
     with pytest.raises(gl.InvalidArgumentError):
