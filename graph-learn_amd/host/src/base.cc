@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <unordered_set>
 #include <vector>
 #include <cstring>
 
@@ -90,7 +91,7 @@ const char* kFilterValues = "filt";
 // device->host copy into pageable memory bounces through the runtime's staging buffers (one
 // extra pass over every response byte, serialised between the pool threads), a copy into
 // registered memory is a single DMA straight into the response.  BlockPool recycles large
-// blocks (>= 64 KiB, power-of-two classes, at most kPoolCap bytes parked) across requests and
+// blocks (>= 64 KiB, power-of-two classes, at most kPoolCap bytes pinned in all) across requests and
 // registers each block with the GPU runtime ONCE, when it is first obtained
 // (glx_host_register; pinning costs milliseconds, recycling a pinned block nothing);
 // small tensors use the ordinary heap.  Without a GPU runtime registration fails and the
@@ -111,38 +112,49 @@ public:
   }
   void* Take(size_t bytes) {
     const int c = ClassOf(bytes);
+    bool pin = false;
     {
       std::lock_guard<std::mutex> g(mtx_);
       if (c < 48 && !free_[c].empty()) {
         void* p = free_[c].back();
         free_[c].pop_back();
-        parked_ -= 1ull << c;
         return p;
+      }
+      if (c < 48 && pinned_ + (1ull << c) <= kPoolCap) {
+        pinned_ += 1ull << c;
+        pin = true;
       }
     }
     void* p = nullptr;
     if (posix_memalign(&p, 4096, 1ull << c) != 0) throw std::bad_alloc();
-    if (pin_) (void)glx_host_register(p, 1ull << c);  // best effort: an unregistered block is only slower
+    if (pin) {
+      if (pin_) (void)glx_host_register(p, 1ull << c);  // best effort: an unregistered block is only slower
+      std::lock_guard<std::mutex> g(mtx_);
+      owned_.insert(p);
+    }
     return p;
   }
+  // A pinned block is parked for ever, never unregistered and freed: pageable copies from addresses that WERE
+  // registered once and have been recycled by the heap since were seen to fault in the runtime (ROCm 7.0; the
+  // parity suite hit it through a test that registered and released numpy buffers).  So the pool pins at most
+  // kPoolCap bytes over the life of the process and hands out ordinary heap blocks beyond that.
   void Give(void* p, size_t bytes) {
     const int c = ClassOf(bytes);
     {
       std::lock_guard<std::mutex> g(mtx_);
-      if (c < 48 && parked_ + (1ull << c) <= kPoolCap) {
+      if (owned_.count(p)) {
         free_[c].push_back(p);
-        parked_ += 1ull << c;
         return;
       }
     }
-    if (pin_) (void)glx_host_unregister(p);
     std::free(p);
   }
 
 private:
   std::mutex mtx_;
   std::vector<void*> free_[48];
-  size_t parked_ = 0;
+  std::unordered_set<void*> owned_;  // the pool's blocks (in use or parked; pinned unless pinning is off)
+  size_t pinned_ = 0;                // their bytes
   // GLX_HOST_PINNED_RESPONSES=0 keeps response blocks pageable (A/B knob)
   const bool pin_ = !(std::getenv("GLX_HOST_PINNED_RESPONSES") && std::atoi(std::getenv("GLX_HOST_PINNED_RESPONSES")) == 0);
 };

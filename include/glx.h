@@ -93,7 +93,10 @@ GLX_API const char* glx_last_error(void);
  * service/tensor_impl.h:72-75,196-200, on this path).  Both return GLX_UNAVAILABLE without a GPU runtime;
  * an unregistered buffer works everywhere, only slower.  Register whole pages the buffer owns (page-aligned start, a
  * multiple of the page size): a range that shares a page with other data or another registration is left to the
- * runtime's bookkeeping.  Only ranges registered HERE are written directly; memory pinned by other means is staged. */
+ * runtime's bookkeeping.  Only ranges registered HERE are written directly; memory pinned by other means is staged.
+ * After glx_host_unregister do not hand the pages back to the heap while the process still copies to the GPU from
+ * ordinary heap memory: pageable copies from addresses that were registered once and recycled since were seen to
+ * fault inside the runtime (ROCm 7.0).  Long-lived pools that never unregister (the C++ layer's) are the intended use. */
 GLX_API int glx_host_register(void* p, uint64_t bytes);
 GLX_API int glx_host_unregister(void* p);
 
