@@ -80,8 +80,9 @@ def test_negative_sample(gl, g):
          .values(lambda x: (x['a'].ids, x['b'].weights, x['b'].ids))
     ids, weights, negs = gl.Dataset(q).next()
     assert ids.shape == (2,) and weights.shape == (2, 5)
-    for s, row in zip(ids, negs):
-        assert set(row.tolist()).isdisjoint(fx.fixed_dst_ids(int(s), RANGE2))
+    assert set(negs.reshape(-1).tolist()) <= set(fx.fixed_dst_ids(range(*RANGE1), RANGE2))  # candidates = edge1's dst ids
+    # (a "random" negative may still be a neighbour after SamplingRetryTimes redraws: random_negative_sampler.cc keeps
+    # the last draw; the reference's test checks shapes only)
     np.testing.assert_almost_equal(weights, negs / 10.0, decimal=4)  # node2 weights = id / 10
 
 
