@@ -70,7 +70,8 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
         assert res["value_features_replicated"] == res["value"]
         assert "features_replicated placement" in res["config"]["workload"]
     else:
-        assert res["value_features_sharded"] == res["value"]
+        # `value` = the faster of the placement's two exchange modes; both are reported
+        assert res["value"] == max(res["value_features_sharded"], res["value_features_sharded_speculated"])
         assert "features_sharded placement" in res["config"]["workload"]
 
 
