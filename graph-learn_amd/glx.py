@@ -1047,7 +1047,8 @@ class Ledger:
 
     def detach(self, *stores):
         for st in stores:
-            _check(lib().glx_dist_store_set_ledger(st._h, None))
+            if getattr(st, "_h", None):  # (a store closed before its ledger has nothing left to detach)
+                _check(lib().glx_dist_store_set_ledger(st._h, None))
             st._ledger = None
             self._stores = [x for x in self._stores if x is not st]
 
