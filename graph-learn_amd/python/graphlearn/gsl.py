@@ -20,7 +20,7 @@ Results are the same Nodes / Edges / SparseNodes values, attributes looked up la
 
 Supported: V / E sources (batch, shuffle, mask, node_from), outV / inV / outE / inE with sample().by(), filter(),
 outNeg / inNeg / Neg with where(), each(), random_walk(), SubGraph(), alias(), values(func), Dataset(window,
-drop_last).  Not here: feeding a query from a generator.
+drop_last, fuse_hops).  Not here: feeding a query from a generator.
 """
 import numpy as np
 
@@ -421,17 +421,63 @@ class Dataset(object):
   has nothing to size here: a batch is produced when it is asked for.  drop_last: a final batch shorter than the
   source's batch size is skipped."""
 
-  def __init__(self, query, window=10, drop_last=False):
+  _DENSE = ("random", "random_without_replacement", "topk", "in_degree", "edge_weight")
+
+  def __init__(self, query, window=10, drop_last=False, fuse_hops=False):
+    """fuse_hops (new): a chain .outV(e1).sample(k1).by(s).outV(e2).sample(k2).by(s)... of dense, unfiltered hops with
+    one strategy runs as ONE engine call (glx_sample_hops through NeighborSampler.get_device: the frontiers stay in HBM,
+    one copy back per hop) instead of one request per hop; values, shapes and types are the same, the random streams
+    are the Dataset's own (seed = gl.set_sampling_seed's, a fresh call counter per batch)."""
     if not isinstance(query, Query) or query.values_func is None:
       raise ValueError("Dataset takes a query closed with .values()")
     self._query = query
     self._window = int(window)
     self._drop_last = bool(drop_last)
     self._source = next(s for s in query.steps if isinstance(s, (VertexSource, EdgeSource)))
+    self._chains = self._find_chains() if fuse_hops else {}
+    self._fused_calls = int.from_bytes(__import__("os").urandom(6), "little") << 8
+
+  def _find_chains(self):
+    """first step -> the steps of a fusable chain of two or more hops."""
+    chains, taken = {}, set()
+    for step in self._query.steps:
+      if step in taken or type(step) is not NeighborStep:  # pylint: disable=unidiomatic-typecheck
+        continue
+      chain = [step]
+      while True:
+        nxt = [s for s in self._query.steps if type(s) is NeighborStep and s._upstream is chain[-1]]  # noqa: E721 pylint: disable=unidiomatic-typecheck,protected-access
+        if len(nxt) != 1 or nxt[0]._strategy != step._strategy:  # pylint: disable=protected-access
+          break
+        chain.append(nxt[0])
+      ok = all(s._filter_target is None and s._count is not None and s._count > 0 for s in chain)  # pylint: disable=protected-access
+      if len(chain) >= 2 and ok and step._strategy in self._DENSE:  # pylint: disable=protected-access
+        chains[step] = chain
+        taken.update(chain)
+    return chains
+
+  def _run_chain(self, chain, results):
+    import torch
+    graph = self._query.graph
+    src = results[chain[0]._upstream].ids.reshape(-1)  # pylint: disable=protected-access
+    sampler = graph.neighbor_sampler([s._stored for s in chain], [s._count for s in chain],  # pylint: disable=protected-access
+                                     strategy=chain[0]._strategy)  # pylint: disable=protected-access
+    device = torch.device("cuda", graph.device_graph(chain[0]._stored).device)  # pylint: disable=protected-access
+    ids = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int64)).to(device)
+    self._fused_calls += len(chain)
+    hops = sampler.get_device(ids, call_counter=self._fused_calls)
+    rows = src.size
+    for step, (nbr, _) in zip(chain, hops):
+      results[step] = graph.get_nodes(step._vertex_type(), nbr.cpu().numpy(), shape=(rows, step._count))  # pylint: disable=protected-access
+      rows *= step._count  # pylint: disable=protected-access
 
   def next(self):
     results = {}
     for step in self._query.steps:
+      if step in results:  # a later hop of a fused chain
+        continue
+      if step in self._chains:
+        self._run_chain(self._chains[step], results)
+        continue
       value = step._evaluate(results)  # pylint: disable=protected-access
       if step is self._source and self._drop_last:
         rows = value.src_ids.size if isinstance(step, EdgeSource) else value.ids.size

@@ -251,6 +251,39 @@ def test_edge_and_node_iteration_reference_cases(gl, g):
         np.testing.assert_equal(nodes.labels, nodes.ids)
 
 
+def test_fused_hops_one_engine_call_per_chain(gl, g):
+    """Dataset(fuse_hops=True): the two random hops of a chain run as one glx_sample_hops call (frontier in HBM);
+    shapes, types, generator membership and epochs as hop by hop; a branch or a differing strategy ends the chain."""
+    q = g.V(NODE1).batch(5).alias('a') \
+         .outV(EDGE1).sample(3).by('random').alias('b') \
+         .outV(EDGE2).sample(4).by('random').alias('c') \
+         .outV(EDGE1).sample(2).by('topk').alias('d') \
+         .values()
+    ds = gl.Dataset(q, fuse_hops=True)
+    assert [len(c) for c in ds._chains.values()] == [2]  # b + c fuse; d has another strategy
+
+    def check(res):
+        n = res['a'].shape[0]
+        assert res['b'].shape == (n, 3) and res['c'].shape == (3 * n, 4) and res['d'].shape == (12 * n, 2)
+        assert (res['b'].type, res['c'].type, res['d'].type) == (NODE2, NODE1, NODE2)
+        for s, row in zip(res['a'].ids, res['b'].ids):
+            assert set(row.tolist()) <= set(fx.fixed_dst_ids(int(s), RANGE2)) | {-1}
+        for s, row in zip(res['b'].ids.reshape(-1), res['c'].ids):
+            assert set(row.tolist()) <= (set(fx.fixed_dst_ids(int(s), RANGE1)) if s >= 0 else set()) | {-1}
+        np.testing.assert_equal(res['b'].labels[res['b'].ids >= 0], res['b'].ids[res['b'].ids >= 0])  # attributes resolve
+    assert 1 <= _drain(gl, ds, check) <= 20  # (the by_order cursor of node1 is shared with the tests before)
+    assert _drain(gl, ds, check) == 20       # a whole epoch
+    first = gl.Dataset(g.V(NODE1).batch(5).alias('a').outV(EDGE1).sample(3).by('random').alias('b')
+                       .outV(EDGE2).sample(4).by('random').alias('c').values(), fuse_hops=True)
+    r1, r2 = first.next(), first.next()
+    assert not np.array_equal(r1['c'].ids, r2['c'].ids)  # a fresh stream per batch
+    # a filtered hop or a branch point is not fused
+    q2 = g.V(NODE1).batch(5).alias('a').outV(EDGE1).sample(3).by('random').alias('b')
+    q2.outV(EDGE2).sample(4).by('random').alias('c')
+    q2.outV(EDGE2).sample(2).by('random').alias('c2')
+    assert gl.Dataset(q2.values(), fuse_hops=True)._chains == {}
+
+
 def test_query_errors(gl, g):
     with pytest.raises(ValueError):
         g.V("no_such_type")
