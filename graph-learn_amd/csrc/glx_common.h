@@ -682,8 +682,9 @@ struct GlxHostCallSlot {
   GlxHostCallSlot& operator=(const GlxHostCallSlot&) = delete;
 };
 
-// Device-visible alias of a host buffer the caller pinned with glx_host_register (or allocated with
-// hipHostMalloc), nullptr for ordinary pageable memory.  Host-pointer calls let their kernels write results
+// Device-visible alias of a host buffer the caller pinned with glx_host_register, nullptr for anything else
+// (pageable memory, and memory pinned by other means: glx trusts its own registry only).  Host-pointer calls let
+// their kernels write results
 // straight into such a buffer -- the response crosses PCIe once, as the kernel's own coalesced stores, with no
 // staging copy and no copy engine in between; pageable buffers are served through a device workspace + copy.
 void* glx_mapped_ptr(const void* host_ptr);
