@@ -61,6 +61,189 @@ def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
 
+LINE_LIMIT = 4096  # bytes of the ONE stdout line: the driver keeps ~9 KB of stdout tail and parses the line from it
+
+
+def _short(text, n):
+    text = " ".join(str(text).split())
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def _num(x, digits=6):
+    """Floats rounded to `digits` significant digits (the line is for a parser, the detail file keeps everything)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _pick(d, keys):
+    return {k: _num(d[k]) for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def compact_roofline(r):
+    if not r:
+        return None
+    out = _pick(r, ("bound", "peak", "unit", "achieved", "frac", "algorithmic_over_peak", "frac_compulsory", "traffic",
+                    "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch",
+                    "traffic_over_algorithmic", "frac_of_gather_ceiling", "l2_hit_rate"))
+    out["kernel"] = _short(r.get("kernel", ""), 72)
+    if r.get("frac_basis"):
+        out["frac_basis"] = _short(r["frac_basis"], 80)
+    if r.get("traffic_source"):
+        out["traffic_source"] = _short(r["traffic_source"], 60)
+    if isinstance(r.get("hbm_bytes_bracket"), (list, tuple)):
+        out["hbm_bytes_bracket"] = [_num(float(x)) for x in r["hbm_bytes_bracket"]]
+    cf = r.get("cache_free")
+    if cf:
+        out["cache_free"] = _pick(cf, ("avg_launch_ms", "achieved", "frac", "frac_of_measured_stream_peak"))
+    pk = r.get("peak_measured")
+    if pk:
+        out["peak_measured_gbs"] = {k: _num(v, 4) for k, v in pk.items() if isinstance(v, float)}
+    return out
+
+
+def compact_cpu(c):
+    if not c:
+        return None
+    out = _pick(c, ("value", "unit", "cores", "threads", "nproc", "kind", "sampling_edges_per_s", "aggregation_vertices_per_s",
+                    "storage_mode", "edges_built", "feature_rows"))
+    out["sample"] = _short(c.get("sample", ""), 160)
+    if c.get("thread_sweep"):
+        out["thread_sweep"] = [_pick(t, ("cores", "value")) for t in c["thread_sweep"]]
+    if c.get("modes"):
+        out["modes"] = {m: {t: _num(v, 4) for t, v in tv.items()} for m, tv in c["modes"].items()}
+    return out
+
+
+def compact_line(res, detail_path=None, limit=LINE_LIMIT):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline` + the verification flags, at most `limit`
+    bytes.  Everything else this run measured (probes, per-leg statistics, notes) goes to the detail file and stderr."""
+    cfg = res.get("config") or {}
+    config = {"workload": _short(cfg.get("workload", ""), 200)}
+    for k in ("seeds_per_step_per_gpu", "fanout", "sampler", "aggregator", "dim", "nodes", "edges", "hipgraph_step"):
+        if k in cfg and cfg[k] is not None:
+            config[k] = cfg[k]
+    if cfg.get("parallelism"):
+        config["parallelism"] = _short(cfg["parallelism"], 120)
+    if cfg.get("seeds"):
+        config["seeds"] = _short(cfg["seeds"], 60)
+    line = {"metric": _short(res.get("metric", ""), 90)}
+    for k in ("value", "unit", "n_gpus", "rccl_ranks", "transport", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data"):
+        if k in res:
+            line[k] = _num(res[k], 9)
+    line["config"] = config
+    if "error" in res:
+        line["error"] = _short(res["error"], 200)
+    line["roofline"] = compact_roofline(res.get("roofline"))
+    line["cpu_baseline"] = compact_cpu(res.get("cpu_baseline"))
+    for k in ("gpu_over_cpu", "verified_vs_oracle", "verified_sharded_equals_unpartitioned"):
+        if res.get(k) is not None:
+            line[k] = _num(res[k], 5)
+    optional = []  # dropped from the back if the line would outgrow the limit
+    if res.get("phases"):
+        line["phases"] = _pick(res["phases"], ("sampling_kernels_ms_per_step", "aggregation_kernels_ms_per_step"))
+        optional.append("phases")
+    if res.get("roofline_sampler"):
+        rs = res["roofline_sampler"]
+        line["roofline_sampler"] = dict(_pick(rs, ("achieved", "frac", "traffic", "avg_launch_ms", "frac_of_gather_ceiling")),
+                                        kernel=_short(rs.get("kernel", ""), 60))
+        optional.append("roofline_sampler")
+    if res.get("placements"):
+        line["placements"] = {name: _pick(leg, ("ms_per_step", "value")) for name, leg in res["placements"].items()}
+        optional.append("placements")
+    if res.get("verified_legs"):
+        line["verified_legs"] = res["verified_legs"]
+        optional.append("verified_legs")
+    if res.get("other_configs"):
+        oc = {}
+        for name, rec in res["other_configs"].items():
+            if "error" in rec:
+                oc[name] = {"error": _short(rec["error"], 60)}
+                continue
+            roof = rec.get("roofline") or {}
+            oc[name] = dict(_pick(rec, ("ms_per_step", "value")), frac=_num(roof.get("frac"), 4),
+                            frac_basis=_short(roof.get("frac_basis", ""), 40), traffic=_num(roof.get("traffic"), 4),
+                            verified=rec.get("verified_vs_oracle"))
+        line["other_configs"] = oc
+        optional.append("other_configs")
+    for k in ("host_boundary", "small_batches"):
+        v = res.get(k)
+        if isinstance(v, dict):
+            if k == "host_boundary" and v.get("edges_per_s"):
+                line["host_boundary_edges_per_s"] = _num(v["edges_per_s"], 4)
+                optional.append("host_boundary_edges_per_s")
+            if k == "small_batches":
+                line["small_batches"] = {b: _pick(r, ("ms_per_step", "value")) for b, r in v.items() if isinstance(r, dict)}
+                optional.append("small_batches")
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line, separators=(", ", ": "))
+    trimmed = []
+    for k in ("small_batches", "host_boundary_edges_per_s", "verified_legs", "phases", "roofline_sampler", "placements",
+              "other_configs"):
+        if len(text) <= limit:
+            break
+        if k in optional and k in line:
+            del line[k]
+            trimmed.append(k)
+            line["trimmed"] = trimmed
+            text = json.dumps(line, separators=(", ", ": "))
+    if len(text) > limit:  # last resort: the contract's keys alone
+        for k in list(line):
+            if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                         "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail", "error"):
+                del line[k]
+        line["config"] = {"workload": _short(config["workload"], 100)}
+        text = json.dumps(line, separators=(", ", ": "))
+    return text
+
+
+def emit_result(result_out, res, args):
+    """Rank 0: the full record to the detail file (+ stderr), the compact line to the real stdout."""
+    path = getattr(args, "detail_out", None) or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as fh:
+            json.dump(res, fh, indent=1)
+            fh.write("\n")
+    except OSError as ex:
+        log("could not write %s: %r" % (path, ex))
+        path = None
+    sys.stderr.write("[bench-detail] " + json.dumps(res) + "\n")
+    sys.stderr.flush()
+    result_out.write(compact_line(res, os.path.relpath(path, ROOT) if path and path.startswith(ROOT) else path) + "\n")
+    result_out.flush()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` (one process per GPU, rendezvous on 127.0.0.1) -- the reference's fan-out needs no external
+    launcher either (core/runner/op_runner.h:49-90).  Too few devices: ONE JSON error line, non-zero exit."""
+    import socket
+    have = 0
+    try:
+        have = glx.device_count()
+    except glx.GlxError:
+        have = 0
+    if not args.share_device and have < args.gpus:
+        print(json.dumps({"metric": "sampled-edges/sec + aggregated-vertices/sec", "value": None, "unit": "edges/s",
+                          "n_gpus": have, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": args.workload},
+                          "error": "--gpus %d asked for, %d visible (glx_device_count): nothing measured" % (args.gpus, have)}),
+              flush=True)
+        sys.exit(2)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("no launcher in the environment: re-executing as %s" % " ".join(cmd))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
 
 def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
     """Times the reference's own CPU path (oracle/_ref, built from the reference's
@@ -439,8 +622,7 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
     if verified is not None:
         res["verified_sharded_equals_unpartitioned"] = verified
     if rank == 0:
-        result_out.write(json.dumps(res) + "\n")
-        result_out.flush()
+        emit_result(result_out, res, args)
     if sharded:
         dist.destroy_process_group()
     if verified is False:
@@ -579,8 +761,12 @@ def main():
                     help="keep raw RMAT vertex ids (bit-skewed: 44%% of the edges land on shard 0 of 8 under "
                          "llabs(id)%%P, and hub rows alias onto few HBM channels) instead of the Graph500-style "
                          "random relabeling")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo = test rig only: collectives staged through host memory")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="auto = nccl (RCCL over xGMI), or gloo with --share-device; gloo = test rig only: collectives "
+                         "staged through host memory")
+    ap.add_argument("--detail-out", default=None,
+                    help="where rank 0 writes the full record (default: bench_detail.json beside this file); the stdout "
+                         "line is the compact one (<= 4 KB)")
     ap.add_argument("--share-device", action="store_true",
                     help="test rig: every rank uses cuda:0 (several ranks on a 1-GPU box, with --backend gloo)")
     ap.add_argument("--verify", action="store_true",
@@ -665,6 +851,10 @@ def main():
     ap.add_argument("--cpu-thread-sweep", default="1,0",
                     help="comma separated extra thread counts for the CPU baseline (0 = nproc), e.g. '1,0'")
     args = ap.parse_args()
+    if args.backend == "auto":
+        args.backend = "gloo" if args.share_device else "nccl"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # does not return
 
     # Contract: rank 0 prints exactly ONE JSON line on stdout.  Libraries (RCCL's
     # version banner, rocm warnings) also write to fd 1, so keep a private copy of
@@ -676,7 +866,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
@@ -688,14 +879,13 @@ def main():
 
         def setup_give_up():
             if rank == 0:
-                result_out.write(json.dumps({
+                emit_result(result_out, {
                     "metric": "sampled-edges/sec + aggregated-vertices/sec", "value": None, "unit": "edges/s",
                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                     "data": "synthetic", "config": {"workload": args.workload},
                     "error": "setup watchdog: communicator / store set-up did not finish in %.0f s" % args.setup_watchdog,
-                }) + "\n")
-                result_out.flush()
+                }, args)
             os._exit(5)
         setup_dog = threading.Timer(args.setup_watchdog, setup_give_up)
         setup_dog.daemon = True
@@ -1111,17 +1301,16 @@ def main():
             else:
                 best = None
             if rank == 0:
-                result_out.write(json.dumps({
+                emit_result(result_out, {
                     "metric": "sampled-edges/sec + aggregated-vertices/sec",
                     "value": legs[best]["value"] if best else None, "unit": "edges/s",
                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                     "ms_per_step": legs[best]["ms_per_step"] if best else None,
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                    "config": {"workload": "%s: %s -- value = %s placement (the only leg that finished)"
-                                           % (args.workload, desc, best)},
+                    "config": {"workload": "%s: value = %s placement (the only leg that finished) -- %s"
+                                           % (args.workload, best, desc)},
                     "error": reason or ("watchdog: no progress for %.0f s in the %s" % (args.watchdog, progress["stage"])),
-                    "placements": legs}) + "\n")
-                result_out.flush()
+                    "placements": legs}, args)
             os._exit(4)
         dog = threading.Timer(args.watchdog, give_up)
         dog.daemon = True
@@ -1398,9 +1587,9 @@ def main():
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s%s" % (args.workload, desc,
-                                             "" if not sharded else " -- value = %s placement, %s (the faster of the two "
-                                             "exchange modes timed; both are in placements)" % (headline, exchange_mode)),
+        "config": {"workload": "%s: %s%s" % (args.workload,
+                                             "" if not sharded else "value = %s placement, %s (the faster of the two "
+                                             "exchange modes timed; both are in placements) -- " % (headline, exchange_mode), desc),
                    "seeds_per_step_per_gpu": B0,
                    "seeds": ("uniform over the vertices that have out-edges" if args.seed_dist == "uniform" else
                              "degree-biased: the sources of uniformly drawn edges") + ", fresh batch every step",
@@ -1494,8 +1683,7 @@ def main():
         log("before the other configs: %.1f of %.1f GB of HBM free in this process's view" % (free_b / 1e9, total_b / 1e9))
         res["other_configs"] = other_configs(args)
     if rank == 0:
-        result_out.write(json.dumps(res) + "\n")
-        result_out.flush()
+        emit_result(result_out, res, args)
     if sharded:
         if world > 1:
             # the result line is out; a communicator teardown that waits for a peer must not keep the node busy

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <new>
 
 #include "glx_common.h"
@@ -88,6 +90,8 @@ struct AggArgs {
   int32_t fanout;
   float default_attr;
   int32_t col0, ncols;       // the columns [col0, col0 + ncols) this launch reduces (a column slice, or all)
+  int32_t segs_per_group;    // glx_aggregate_grp_kernel: consecutive segments one lane group reduces
+  int32_t xcd_slices;        // glx_aggregate_grp_kernel: > 1 = workgroup b reduces column slice b % xcd_slices (ncols each)
   // further row sources of the distributed store (glx_dist.hip): virtual row r lives in
   // source 0 when r < base1, in source 1 (the hot-row replica) when r < base2, else in
   // source 2 (the halo rows of this request, plain row-major, no swizzle).
@@ -170,6 +174,167 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
       for (int v = 0; v < VEC; ++v) acc[v] = acc[v] / fn;
     }
     *reinterpret_cast<vec_t*>(out + col) = acc;
+  }
+}
+
+// ---- the wide shapes (16-byte loads, 8..64 lanes per segment): ids fetched ONCE, coalesced ------------------
+// glx_aggregate_kernel above asks for every id with a load of its own in which all lanes of a group read the same
+// address, each followed by a wait: a fanout-10 segment is ten dependent round trips before the first row load
+// issues.  Here a group of G lanes keeps a CHUNK of G * IDR consecutive positions of its id
+// range in registers -- lane c holds positions chunk_base + k G + c, one coalesced load per register -- already
+// translated to feature rows, and hands row `pos` to all its lanes with a cross-lane read: v_readlane for a whole
+// wave (the row index, the swizzle, the multiply by the pitch and the bounds test then run on the scalar unit and
+// the row load takes its base address from SGPRs), ds_bpermute for the narrower groups.  A group reduces S
+// consecutive segments one after the other so a chunk serves several of them (S f <= chunk for the dense sampler
+// responses); up to U row loads are issued back to back before the first is consumed.  Accumulation order is
+// unchanged: lane c owns columns [4c, 4c + 4) of its group's segment and folds the rows left to right
+// (aggregator.cc:45-56), so results stay bit-identical to the reference's serial loop.
+template <int G, int IDR>
+__device__ __forceinline__ void agg_chunk_load(const AggArgs& a, int32_t chunk_base, int32_t pos_end, int c,
+                                               int32_t (&myrow)[IDR]) {
+#pragma unroll
+  for (int k = 0; k < IDR; ++k) {
+    const int32_t pos = chunk_base + k * G + c;
+    myrow[k] = pos < pos_end ? agg_row_at(a, pos) : -1;
+  }
+}
+
+// row held for chunk slot idx in [0, G * IDR) (group-uniform idx)
+template <int G, int IDR>
+__device__ __forceinline__ int32_t agg_chunk_get(const int32_t (&myrow)[IDR], int32_t idx) {
+  if (G == 64) {
+    int32_t r = __builtin_amdgcn_readlane(myrow[0], idx & 63);
+#pragma unroll
+    for (int k = 1; k < IDR; ++k) {
+      const int32_t t = __builtin_amdgcn_readlane(myrow[k], idx & 63);
+      r = (idx >> 6) == k ? t : r;
+    }
+    return r;
+  }
+  int32_t r = __shfl(myrow[0], idx & (G - 1), G);
+#pragma unroll
+  for (int k = 1; k < IDR; ++k) {
+    const int32_t t = __shfl(myrow[k], idx & (G - 1), G);
+    r = (idx / G) == k ? t : r;
+  }
+  return r;
+}
+
+// Row pointer with 32-bit row arithmetic (rows < 2^31, pitch < 2^31 floats): for a wave-uniform row this is a
+// handful of SALU instructions.
+__device__ __forceinline__ uint32_t agg_swizzle32(uint32_t r, uint32_t swizzle_rows) {
+  const uint32_t m = ((r >> GLX_SWIZZLE_BITS) * 0x9E3779B1u) >> (32 - GLX_SWIZZLE_BITS);
+  return r < swizzle_rows ? r ^ m : r;
+}
+
+template <int NSRC>
+__device__ __forceinline__ const float* agg_row_ptr32(const AggArgs& a, int32_t row) {
+  if (NSRC == 1 || row < a.base1) {
+    return a.X + (uint64_t)agg_swizzle32((uint32_t)row, (uint32_t)a.swizzle_rows) * (uint32_t)a.stride;
+  }
+  if (row < a.base2) {
+    return a.X1 + (uint64_t)agg_swizzle32((uint32_t)(row - a.base1), (uint32_t)a.swizzle1) * (uint32_t)a.stride1;
+  }
+  return a.X2 + (uint64_t)(uint32_t)(row - a.base2) * (uint32_t)a.stride2;
+}
+
+// One batch: rows of chunk slots [slot0, slot0 + count), count <= U (kFull: count == U, no tests at all), all
+// loads issued before the first is folded into acc, in slot order.
+template <int OP, int G, int U, int NSRC, int IDR, bool kFull>
+__device__ __forceinline__ void agg_grp_batch(const AggArgs& a, const int32_t (&myrow)[IDR], int32_t slot0, int32_t count,
+                                              uint32_t col_ld, float __attribute__((ext_vector_type(4)))& acc) {
+  typedef float vec_t __attribute__((ext_vector_type(4)));
+  int32_t row[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) row[u] = agg_chunk_get<G, IDR>(myrow, slot0 + u);
+  vec_t val[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (kFull || u < count) {
+      // an unknown id (row -1) reads row 0 and is replaced below: no divergent branch around the load
+      const int32_t r = row[u] >= 0 ? row[u] : 0;
+      val[u] = *reinterpret_cast<const vec_t*>(agg_row_ptr32<NSRC>(a, r) + col_ld);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (kFull || u < count) {
+      vec_t x = val[u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) x[v] = row[u] < 0 ? a.default_attr : x[v];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[v] = agg_combine<OP>(acc[v], x[v]);
+    }
+  }
+}
+
+template <int OP, int G, int U, int NSRC, int IDR>
+__global__ __launch_bounds__(256) void glx_aggregate_grp_kernel(AggArgs a) {
+  typedef float vec_t __attribute__((ext_vector_type(4)));
+  constexpr int kChunk = G * IDR;
+  static_assert(U <= kChunk, "a batch must fit the chunk");
+  constexpr int kGroupsPerBlock = 256 / G;
+  // XCD-affine column slices (a.xcd_slices > 1): workgroup b runs on XCD b % 8 (observed placement, used for speed
+  // only), so slice = b % xcd_slices keeps one column slice of EVERY row in one XCD's L2
+  const int32_t slice = a.xcd_slices > 1 ? (int32_t)(blockIdx.x % (unsigned)a.xcd_slices) : 0;
+  const int64_t blk = a.xcd_slices > 1 ? blockIdx.x / (unsigned)a.xcd_slices : blockIdx.x;
+  int64_t grp = blk * kGroupsPerBlock + threadIdx.x / G;
+  const int c = threadIdx.x & (G - 1);
+  const int32_t S = a.segs_per_group;
+  int64_t seg64 = grp * S;
+  if (seg64 >= a.num_segments) return;
+  int32_t seg_first = (int32_t)seg64;
+  if (G == 64) seg_first = __builtin_amdgcn_readfirstlane(seg_first);
+  const int32_t seg_last = (a.num_segments - seg_first) < S ? a.num_segments : seg_first + S;
+  // segment boundaries: arithmetic for a dense sampler response, else lane j of the group holds start[seg_first + j]
+  int32_t mystart = 0;
+  if (a.seg_start) mystart = a.seg_start[seg_first + (c <= seg_last - seg_first ? c : 0)];
+  const int32_t starts[1] = {mystart};
+  const int32_t pos_first = a.seg_start ? agg_chunk_get<G, 1>(starts, 0) : seg_first * a.fanout;
+  const int32_t pos_end = a.seg_start ? agg_chunk_get<G, 1>(starts, seg_last - seg_first) : seg_last * a.fanout;
+  const int32_t col_lo = a.col0 + slice * a.ncols;
+  const int32_t col_end = col_lo + a.ncols;
+  for (int32_t col_pass = col_lo; col_pass < col_end; col_pass += G * 4) {
+    const int32_t col = col_pass + c * 4;
+    const bool col_ok = col < col_end;
+    const uint32_t col_ld = col_ok ? (uint32_t)col : (uint32_t)col_lo;  // lanes past the end re-read lane 0's columns, unused
+    int32_t chunk_base = pos_first;
+    int32_t myrow[IDR];
+    agg_chunk_load<G, IDR>(a, chunk_base, pos_end, c, myrow);
+    for (int32_t sg = seg_first; sg < seg_last; ++sg) {
+      int32_t s0, s1;
+      if (a.seg_start) {
+        s0 = agg_chunk_get<G, 1>(starts, sg - seg_first);
+        s1 = agg_chunk_get<G, 1>(starts, sg - seg_first + 1);
+      } else {
+        s0 = sg * a.fanout;
+        s1 = s0 + a.fanout;
+      }
+      vec_t acc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[v] = agg_init<OP>();
+      for (int32_t base = s0; base < s1; base += U) {
+        const int32_t stop = (s1 - base) < U ? s1 : base + U;
+        if (stop > chunk_base + kChunk) {  // the batch runs past the chunk: next chunk starts at this batch
+          chunk_base = base;
+          agg_chunk_load<G, IDR>(a, chunk_base, pos_end, c, myrow);
+        }
+        if (stop - base == U) agg_grp_batch<OP, G, U, NSRC, IDR, true>(a, myrow, base - chunk_base, U, col_ld, acc);
+        else agg_grp_batch<OP, G, U, NSRC, IDR, false>(a, myrow, base - chunk_base, stop - base, col_ld, acc);
+      }
+      // FinalFunc: aggregator.cc:74-86 (empty -> default), mean_aggregator.cc:45-61.
+      const int32_t n = s1 - s0;
+      if (n == 0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = a.default_attr;
+      } else if (OP == GLX_AGG_MEAN) {
+        const float fn = (float)n;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = acc[v] / fn;
+      }
+      if (col_ok) *reinterpret_cast<vec_t*>(a.emb_out + sg * (int64_t)a.dim + col) = acc;
+      if (c == 0 && col_pass == 0) a.cnt_out[sg] = n;
+    }
   }
 }
 
@@ -260,9 +425,39 @@ __global__ __launch_bounds__(256) void glx_aggregate_mfma_kernel(AggArgs a) {
   if (threadIdx.x < nseg) a.cnt_out[seg0 + threadIdx.x] = f;
 }
 
+// ---- experiment knobs ------------------------------------------------------------------------------------
+// Read from the environment ONCE (first launch in the process; Process() runs on up to 32 pool threads and
+// getenv is not something to call per launch), and settable at run time through glx_tune() so a probe can A/B
+// kernels inside one process.  Every knob is an ablation / measurement aid: 0 = the product's default.
+struct AggKnobs {
+  std::atomic<int> mfma{0};     // GLX_AGG_MFMA=1: the LDS-staged MFMA formulation of Sum / Mean (ablation)
+  std::atomic<int> unroll{0};   // GLX_AGG_UNROLL: rows in flight per lane (0 = chosen from the fanout)
+  std::atomic<int> slices{0};   // GLX_AGG_SLICES=2|4|8: column slices as consecutive launches (ablation)
+  std::atomic<int> legacy{0};   // GLX_AGG_LEGACY=1: the round-1..3 kernel (one id load per row per lane)
+  std::atomic<int> segs{0};     // GLX_AGG_SEGS: segments per lane group (0 = chosen from fanout and grid size)
+  std::atomic<int> xcd{0};      // GLX_AGG_XCD_SLICES=2|4|8: column slice = workgroup % n (XCD-affine; experiment)
+};
+
+AggKnobs& agg_knobs() {
+  static AggKnobs k;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    auto env = [](const char* name) {
+      const char* e = getenv(name);
+      return e ? atoi(e) : 0;
+    };
+    k.mfma = env("GLX_AGG_MFMA");
+    k.unroll = env("GLX_AGG_UNROLL");
+    k.slices = env("GLX_AGG_SLICES");
+    k.legacy = env("GLX_AGG_LEGACY");
+    k.segs = env("GLX_AGG_SEGS");
+    k.xcd = env("GLX_AGG_XCD_SLICES");
+  });
+  return k;
+}
+
 bool agg_use_mfma(const AggArgs& a, int op) {
-  const char* e = getenv("GLX_AGG_MFMA");
-  if (!e || atoi(e) == 0) return false;
+  if (agg_knobs().mfma.load(std::memory_order_relaxed) == 0) return false;
   return (op == GLX_AGG_SUM || op == GLX_AGG_MEAN) && a.seg_start == nullptr && a.fanout > 0 && a.X1 == nullptr &&
          a.X2 == nullptr && (a.dim == 64 || a.dim == 128 || a.dim == 256) && (a.stride % 4) == 0 &&
          (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
@@ -277,57 +472,81 @@ void launch_agg_mfma(const AggArgs& a, hipStream_t s) {
   else glx_aggregate_mfma_kernel<OP, 4><<<grid, 256, lds, s>>>(a);
 }
 
-// Rows in flight per lane.  A/B in one process on the C3 hop-2 request (scripts/agg_unroll_probe.py,
-// profiles/r02/agg_unroll_probe.txt): 3 / 4 / 5 / 6 / 8 / 10 / 12 rows -> 2.26 / 2.19 / 2.11 / 2.10 / 2.21 / 2.49 /
-// 2.48 ms: fewer rows per lane cost fewer registers and let more waves hide the latency, down to 6; a
-// fanout-10 segment is then 6 + 4 loads.  The wide float4 shapes (dim >= 128) use 6, the narrow ones keep 8
-// (not measured).  GLX_AGG_UNROLL = 3|4|5|6|8|10|12 overrides it for the wide shapes, read per launch.
-int agg_unroll() {
-  const char* e = getenv("GLX_AGG_UNROLL");
-  const int v = e ? atoi(e) : 6;
-  return (v == 3 || v == 4 || v == 5 || v == 8 || v == 10 || v == 12) ? v : 6;
-}
-
+// ---- legacy kernel launch (narrow / unaligned shapes, and GLX_AGG_LEGACY=1) --------------------------------
+// Rows in flight per lane of glx_aggregate_kernel: A/B on the C3 hop-2 request (profiles/r02/agg_unroll_probe.txt)
+// 3 / 4 / 5 / 6 / 8 / 10 / 12 rows -> 2.26 / 2.19 / 2.11 / 2.10 / 2.21 / 2.49 / 2.48 ms; wide float4 shapes 6, narrow 8.
 template <int OP, int G, int VEC, int NSRC>
 void launch_agg_g(const AggArgs& a, hipStream_t s) {
   const int64_t threads = (int64_t)a.num_segments * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
   constexpr bool kWide = VEC == 4 && G >= 32;
-  if (!kWide) {
-    glx_aggregate_kernel<OP, G, VEC, 8, NSRC><<<grid, 256, 0, s>>>(a);
-    return;
-  }
-  switch (agg_unroll()) {
-    case 3: glx_aggregate_kernel<OP, G, VEC, kWide ? 3 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
-    case 4: glx_aggregate_kernel<OP, G, VEC, kWide ? 4 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
-    case 5: glx_aggregate_kernel<OP, G, VEC, kWide ? 5 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
-    case 8: glx_aggregate_kernel<OP, G, VEC, 8, NSRC><<<grid, 256, 0, s>>>(a); break;
-    case 10: glx_aggregate_kernel<OP, G, VEC, kWide ? 10 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
-    case 12: glx_aggregate_kernel<OP, G, VEC, kWide ? 12 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
-    default: glx_aggregate_kernel<OP, G, VEC, kWide ? 6 : 8, NSRC><<<grid, 256, 0, s>>>(a); break;
-  }
+  glx_aggregate_kernel<OP, G, VEC, kWide ? 6 : 8, NSRC><<<grid, 256, 0, s>>>(a);
 }
 
-// Column slices.  A hop-2 request of a power-law graph re-reads its hub rows from thousands of segments; whether
-// those re-reads are served by L2 / Infinity Cache or by HBM depends on how many distinct hot BYTES sit between two
-// uses.  Reducing the columns in S slices, one after the other (slice-major block order inside one launch order),
-// divides the hot working set of each phase by S at the price of reading the ids S times.
-// GLX_AGG_SLICES = 1|2|4|8 (read per launch).
-int agg_slices(const AggArgs& a) {
-  const char* e = getenv("GLX_AGG_SLICES");
-  const int v = e ? atoi(e) : 1;
-  if (v != 2 && v != 4 && v != 8) return 1;
-  if (a.dim % (4 * v) != 0) return 1;
-  return v;
+// ---- grouped kernel launch ---------------------------------------------------------------------------------
+// Rows in flight per lane (U): the fewest batches per segment wins, then the smaller batch (registers):
+// fanout 10 -> 10, 15 -> 15, 25 -> 15 (15 + 10), 20 -> 10, 5 -> 5 of 6.  GLX_AGG_UNROLL overrides.
+int agg_grp_unroll(int32_t fanout, int32_t avg_len) {
+  static const int kU[] = {6, 8, 10, 12, 15};
+  const int want = agg_knobs().unroll.load(std::memory_order_relaxed);
+  for (int u : kU) {
+    if (u == want) return u;
+  }
+  const int32_t f = fanout > 0 ? fanout : (avg_len > 0 ? avg_len : 10);
+  int best = 10, best_batches = INT32_MAX;
+  for (int u : kU) {
+    const int batches = (f + u - 1) / u;
+    if (batches < best_batches) {
+      best = u;
+      best_batches = batches;
+    }
+  }
+  return best;
+}
+
+template <int OP, int G, int NSRC, int IDR>
+void launch_agg_grp(AggArgs a, int32_t num_ids, hipStream_t s) {
+  constexpr int kChunk = G * IDR;
+  const int32_t avg = a.num_segments > 0 ? (int32_t)(num_ids / a.num_segments) : 0;
+  const int32_t f = a.seg_start ? (avg > 0 ? avg : 1) : (a.fanout > 0 ? a.fanout : 1);
+  // segments per group: as many as one chunk of ids serves, but keep >= ~16 K waves in the grid
+  int32_t S = kChunk / f;
+  const int64_t waves = (int64_t)a.num_segments * G / 64;
+  if (S > waves / 16384) S = (int32_t)(waves / 16384);
+  const int want = agg_knobs().segs.load(std::memory_order_relaxed);
+  if (want > 0) S = want;
+  if (S > G - 1) S = G - 1;  // lane j of the group holds the start of its j-th segment (and lane S the end)
+  if (S < 1) S = 1;
+  a.segs_per_group = S;
+  const int64_t groups = ((int64_t)a.num_segments + S - 1) / S;
+  const int64_t blocks = (groups + (256 / G) - 1) / (256 / G) * (a.xcd_slices > 1 ? a.xcd_slices : 1);
+  const unsigned grid = (unsigned)blocks;
+  switch (agg_grp_unroll(a.seg_start ? 0 : a.fanout, avg)) {
+    case 6: glx_aggregate_grp_kernel<OP, G, 6, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
+    case 8: glx_aggregate_grp_kernel<OP, G, 8, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
+    case 12: glx_aggregate_grp_kernel<OP, G, 12, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
+    case 15: glx_aggregate_grp_kernel<OP, G, 15, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
+    default: glx_aggregate_grp_kernel<OP, G, 10, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
+  }
 }
 
 template <int OP, int NSRC>
-void launch_agg_cols(const AggArgs& a, hipStream_t s) {
+void launch_agg_cols(const AggArgs& a, int32_t num_ids, hipStream_t s) {
   bool vec4 = a.dim % 4 == 0 && a.ncols % 4 == 0 && a.col0 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0 &&
               (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && (a.stride % 4) == 0;
   if (NSRC > 1) {
     vec4 = vec4 && (reinterpret_cast<uintptr_t>(a.X1) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.X2) & 15) == 0 &&
            (a.stride1 % 4) == 0 && (a.stride2 % 4) == 0;
+  }
+  // the grouped kernel reads row 0 in place of an unknown id's row: some row must exist
+  const bool has_rows = NSRC > 1 ? (a.X2 != nullptr || a.base2 > 0) : a.num_rows > 0;
+  if (vec4 && has_rows && a.ncols >= 32 && agg_knobs().legacy.load(std::memory_order_relaxed) == 0) {
+    const int lanes = a.ncols / 4;
+    if (lanes >= 64) launch_agg_grp<OP, 64, NSRC, 1>(a, num_ids, s);
+    else if (lanes >= 32) launch_agg_grp<OP, 32, NSRC, 1>(a, num_ids, s);
+    else if (lanes >= 16) launch_agg_grp<OP, 16, NSRC, 1>(a, num_ids, s);
+    else launch_agg_grp<OP, 8, NSRC, 2>(a, num_ids, s);
+    return;
   }
   if (vec4) {
     const int lanes = a.ncols / 4;
@@ -347,21 +566,37 @@ void launch_agg_cols(const AggArgs& a, hipStream_t s) {
   }
 }
 
+// Column slices, two experiments (both off by default; measurements in DESIGN.md 10):
+//  * GLX_AGG_SLICES = n: the columns in n slices, one LAUNCH after the other -- divides the hot working set of each
+//    phase by n at the price of reading the ids n times (profiles/r02: no gain);
+//  * GLX_AGG_XCD_SLICES = n: ONE launch, workgroup b reduces slice b % n -- with the observed b % 8 workgroup -> XCD
+//    placement each XCD's L2 then holds 1/n of every hub row instead of whole rows of 1/8 of the segments.
 template <int OP, int NSRC>
-void launch_agg_n(const AggArgs& a0, hipStream_t s) {
+void launch_agg_n(const AggArgs& a0, int32_t num_ids, hipStream_t s) {
   AggArgs a = a0;
-  const int slices = agg_slices(a);
+  a.col0 = 0;
+  a.ncols = a.dim;
+  a.xcd_slices = 0;
+  const int xcd = agg_knobs().xcd.load(std::memory_order_relaxed);
+  if ((xcd == 2 || xcd == 4 || xcd == 8) && a.dim % (4 * xcd) == 0 && a.dim / xcd >= 32) {
+    a.xcd_slices = xcd;
+    a.ncols = a.dim / xcd;
+    launch_agg_cols<OP, NSRC>(a, num_ids, s);
+    return;
+  }
+  int slices = agg_knobs().slices.load(std::memory_order_relaxed);
+  if ((slices != 2 && slices != 4 && slices != 8) || a.dim % (4 * slices) != 0) slices = 1;
   for (int c = 0; c < slices; ++c) {
     a.ncols = a.dim / slices;
     a.col0 = c * a.ncols;
-    launch_agg_cols<OP, NSRC>(a, s);
+    launch_agg_cols<OP, NSRC>(a, num_ids, s);
   }
 }
 
 template <int OP>
-void launch_agg(const AggArgs& a, hipStream_t s) {
-  if (a.X1 || a.X2) launch_agg_n<OP, 3>(a, s);
-  else launch_agg_n<OP, 1>(a, s);
+void launch_agg(const AggArgs& a, int32_t num_ids, hipStream_t s) {
+  if (a.X1 || a.X2) launch_agg_n<OP, 3>(a, num_ids, s);
+  else launch_agg_n<OP, 1>(a, num_ids, s);
 }
 
 // Upload: row r of the caller's dense [V, D] matrix -> its (swizzled, pitched) slot.
@@ -407,11 +642,11 @@ int run_aggregate(AggArgs& a, int op, const int32_t* d_seg, int32_t num_ids, hip
     return GLX_OK;
   }
   switch (op) {
-    case GLX_AGG_SUM: launch_agg<GLX_AGG_SUM>(a, s); break;
-    case GLX_AGG_MEAN: launch_agg<GLX_AGG_MEAN>(a, s); break;
-    case GLX_AGG_MAX: launch_agg<GLX_AGG_MAX>(a, s); break;
-    case GLX_AGG_MIN: launch_agg<GLX_AGG_MIN>(a, s); break;
-    case GLX_AGG_PROD: launch_agg<GLX_AGG_PROD>(a, s); break;
+    case GLX_AGG_SUM: launch_agg<GLX_AGG_SUM>(a, num_ids, s); break;
+    case GLX_AGG_MEAN: launch_agg<GLX_AGG_MEAN>(a, num_ids, s); break;
+    case GLX_AGG_MAX: launch_agg<GLX_AGG_MAX>(a, num_ids, s); break;
+    case GLX_AGG_MIN: launch_agg<GLX_AGG_MIN>(a, num_ids, s); break;
+    case GLX_AGG_PROD: launch_agg<GLX_AGG_PROD>(a, num_ids, s); break;
     default: break;
   }
   timer.stop();
@@ -573,6 +808,21 @@ int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, i
   hipError_t le = hipGetLastError();
   glx_scratch_free(scratch, s);
   GLX_HIP(le);
+  return GLX_OK;
+}
+
+extern "C" int glx_tune(const char* name, int32_t value) {
+  GLX_REQUIRE(name != nullptr, "name is NULL");
+  AggKnobs& k = agg_knobs();
+  std::atomic<int>* slot = nullptr;
+  if (strcmp(name, "agg_mfma") == 0) slot = &k.mfma;
+  else if (strcmp(name, "agg_unroll") == 0) slot = &k.unroll;
+  else if (strcmp(name, "agg_slices") == 0) slot = &k.slices;
+  else if (strcmp(name, "agg_legacy") == 0) slot = &k.legacy;
+  else if (strcmp(name, "agg_segs") == 0) slot = &k.segs;
+  else if (strcmp(name, "agg_xcd_slices") == 0) slot = &k.xcd;
+  GLX_REQUIRE(slot != nullptr, "unknown knob '%s'", name);
+  slot->store(value, std::memory_order_relaxed);
   return GLX_OK;
 }
 

@@ -59,7 +59,7 @@ EXPORTS = [
     "glx_dist_ledger_create", "glx_dist_ledger_destroy", "glx_dist_store_set_ledger", "glx_dist_confirm",
     "glx_dist_ledger_get_stats", "glx_dist_ledger_set_slack",
     "glx_plan_create", "glx_plan_run", "glx_plan_output", "glx_plan_destroy",
-    "glx_probe_bandwidth", "glx_subgraph_induce",
+    "glx_probe_bandwidth", "glx_tune", "glx_subgraph_induce",
     "glx_cond_table_create", "glx_cond_table_destroy", "glx_cond_negative_sample",
 ]
 
@@ -217,6 +217,7 @@ def lib():
         L.glx_subgraph_induce.argtypes = [ci, vp, i32, vp, vp, vp, vp, vp, vp, i64, ctypes.POINTER(i64), ci, vp]
         L.glx_probe_bandwidth.argtypes = [ci, ci, i64, i64, i32, i32, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), vp]
+        L.glx_tune.argtypes = [ctypes.c_char_p, i32]
         L.glx_plan_destroy.restype = None
         _lib = L
     return _lib
@@ -1222,6 +1223,11 @@ def probe_bandwidth(kind, nbytes, units=0, unit_bytes=0, reps=10, device=0):
                                      int(unit_bytes), int(reps), ctypes.byref(moved), ctypes.byref(ms),
                                      _stream(PTR_DEVICE, device)))
     return {"gbps": moved.value / (ms.value * 1e-3) / 1e9, "ms": ms.value, "moved_bytes": moved.value}
+
+
+def tune(name, value):
+    """glx_tune: set a measurement knob of the aggregation launch (agg_unroll, agg_legacy, agg_segs, ...)."""
+    _check(lib().glx_tune(name.encode(), int(value)))
 
 
 def profile_enable(on=True):
