@@ -128,7 +128,7 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
     if cfg.get("seeds"):
         config["seeds"] = _short(cfg["seeds"], 60)
     line = {"metric": _short(res.get("metric", ""), 90)}
-    for k in ("value", "unit", "n_gpus", "rccl_ranks", "transport", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+    for k in ("value", "unit", "n_gpus", "ranks", "rccl_ranks", "transport", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data"):
         if k in res:
             line[k] = _num(res[k], 9)
@@ -213,6 +213,15 @@ def emit_result(result_out, res, args):
     sys.stderr.flush()
     result_out.write(compact_line(res, os.path.relpath(path, ROOT) if path and path.startswith(ROOT) else path) + "\n")
     result_out.flush()
+
+
+def comm_facts(comm, share_device):
+    """n_gpus / ranks / rccl_ranks of the line come from the communicator the run actually used (glx_comm_info), not from
+    --gpus or the launcher's environment."""
+    names = {glx.COMM_RCCL: "rccl (xGMI)", glx.COMM_LOCAL: "in-process threads", glx.COMM_CALLBACKS: "host-staged (gloo test rig)"}
+    return {"n_gpus": comm.world, "ranks": comm.world, "rccl_ranks": comm.world if comm.transport == glx.COMM_RCCL else 0,
+            "transport": names.get(comm.transport, str(comm.transport)) + (", every rank on ONE device (--share-device)"
+                                                                          if share_device else "")}
 
 
 def self_launch(args):
@@ -576,7 +585,7 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
         log("c5 verify vs oracle: %s" % oracle_check)
     roof = roofline_aggregate("SumAggregator", D, sg2, n2, ms2, int(len(t_agg[0::3])), s2 if not sharded else last["a2"],
                               "c5", B0, offline_ok=not sharded)
-    roof["kernel"] = "glx_aggregate_kernel (i-s hop SumAggregator, dim=%d)" % D
+    roof["kernel"] = "glx_aggregate_grp_kernel (i-s hop SumAggregator, dim=%d)" % D
     roof_smp = None
     if not sharded and len(t_smp) >= 3:
         roof_smp = roofline_sampler("TopkSampler", k2, sg2, n2, float(np.mean(t_smp[1::3])), int(len(t_smp[1::3])), "c5", B0)
@@ -621,6 +630,8 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
         res["oracle_check"] = oracle_check
     if verified is not None:
         res["verified_sharded_equals_unpartitioned"] = verified
+    if sharded:
+        res.update(comm_facts(graphs["u-i"].comm, args.share_device))
     if rank == 0:
         emit_result(result_out, res, args)
     if sharded:
@@ -639,7 +650,7 @@ def roofline_aggregate(agg, D, n_segments, n_ids, avg_ms, launches, ids_last, wo
     distinct = int(torch.unique(ids_last.reshape(-1)).numel())
     bytes_comp = distinct * 4 * D + n_ids * 12 + n_segments * (4 * D + 4)
     t = avg_ms * 1e-3
-    roof = {"kernel": "glx_aggregate_kernel (hop-2 %s, dim=%d%s)" % (agg, D, ", 3 row sources" if sources == 3 else ""),
+    roof = {"kernel": "glx_aggregate_grp_kernel (hop-2 %s, dim=%d%s)" % (agg, D, ", 3 row sources" if sources == 3 else ""),
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": avg_ms, "launches_timed": launches,
             "algorithmic_bytes_per_launch": bytes_alg,
             # algorithmic bytes / the average duration of the launches inside the timed region
@@ -1582,8 +1593,8 @@ def main():
     smp_ms = float(np.sum(t_smp)) / max(kernel_steps, 1)
     agg_ms = float(np.sum(t_agg)) / max(kernel_steps, 1)
     res = {
-        "metric": "sampled-edges/sec + aggregated-vertices/sec (2-hop sample + aggregate per step; every "
-                  "sampled vertex is aggregated once, so the step rate counts both)",
+        "metric": "sampled-edges/sec + aggregated-vertices/sec (2-hop sample + aggregate per step)",
+        "metric_note": "every sampled vertex is aggregated once, so the step rate counts both",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -1615,6 +1626,7 @@ def main():
         res["verified_vs_oracle"] = oracle_check["ok"]
         res["oracle_check"] = oracle_check
     if sharded:
+        res.update(comm_facts(comm_s, args.share_device))
         # what the leg `value` reports keeps on EVERY GPU besides its own shard (placements.edge_cut_pure keeps nothing)
         res["config"]["replicated_per_gpu"] = {
             "feature_rows": int(hot.shape[0]) if headline == "features_sharded" else V,

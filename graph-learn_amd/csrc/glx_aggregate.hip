@@ -240,10 +240,10 @@ __device__ __forceinline__ const float* agg_row_ptr32(const AggArgs& a, int32_t 
 
 // One batch: rows of chunk slots [slot0, slot0 + count), count <= U (kFull: count == U, no tests at all), all
 // loads issued before the first is folded into acc, in slot order.
-template <int OP, int G, int U, int NSRC, int IDR, bool kFull>
+template <int OP, int G, int VEC, int U, int NSRC, int IDR, bool kFull>
 __device__ __forceinline__ void agg_grp_batch(const AggArgs& a, const int32_t (&myrow)[IDR], int32_t slot0, int32_t count,
-                                              uint32_t col_ld, float __attribute__((ext_vector_type(4)))& acc) {
-  typedef float vec_t __attribute__((ext_vector_type(4)));
+                                              uint32_t col_ld, float __attribute__((ext_vector_type(VEC)))& acc) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   int32_t row[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) row[u] = agg_chunk_get<G, IDR>(myrow, slot0 + u);
@@ -261,16 +261,16 @@ __device__ __forceinline__ void agg_grp_batch(const AggArgs& a, const int32_t (&
     if (kFull || u < count) {
       vec_t x = val[u];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) x[v] = row[u] < 0 ? a.default_attr : x[v];
+      for (int v = 0; v < VEC; ++v) x[v] = row[u] < 0 ? a.default_attr : x[v];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[v] = agg_combine<OP>(acc[v], x[v]);
+      for (int v = 0; v < VEC; ++v) acc[v] = agg_combine<OP>(acc[v], x[v]);
     }
   }
 }
 
-template <int OP, int G, int U, int NSRC, int IDR>
+template <int OP, int G, int VEC, int U, int NSRC, int IDR>
 __global__ __launch_bounds__(256) void glx_aggregate_grp_kernel(AggArgs a) {
-  typedef float vec_t __attribute__((ext_vector_type(4)));
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   constexpr int kChunk = G * IDR;
   static_assert(U <= kChunk, "a batch must fit the chunk");
   constexpr int kGroupsPerBlock = 256 / G;
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void glx_aggregate_grp_kernel(AggArgs a) {
   const int32_t pos_end = a.seg_start ? agg_chunk_get<G, 1>(starts, seg_last - seg_first) : seg_last * a.fanout;
   const int32_t col_lo = a.col0 + slice * a.ncols;
   const int32_t col_end = col_lo + a.ncols;
-  for (int32_t col_pass = col_lo; col_pass < col_end; col_pass += G * 4) {
-    const int32_t col = col_pass + c * 4;
+  for (int32_t col_pass = col_lo; col_pass < col_end; col_pass += G * VEC) {
+    const int32_t col = col_pass + c * VEC;
     const bool col_ok = col < col_end;
     const uint32_t col_ld = col_ok ? (uint32_t)col : (uint32_t)col_lo;  // lanes past the end re-read lane 0's columns, unused
     int32_t chunk_base = pos_first;
@@ -312,25 +312,25 @@ __global__ __launch_bounds__(256) void glx_aggregate_grp_kernel(AggArgs a) {
       }
       vec_t acc;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[v] = agg_init<OP>();
+      for (int v = 0; v < VEC; ++v) acc[v] = agg_init<OP>();
       for (int32_t base = s0; base < s1; base += U) {
         const int32_t stop = (s1 - base) < U ? s1 : base + U;
         if (stop > chunk_base + kChunk) {  // the batch runs past the chunk: next chunk starts at this batch
           chunk_base = base;
           agg_chunk_load<G, IDR>(a, chunk_base, pos_end, c, myrow);
         }
-        if (stop - base == U) agg_grp_batch<OP, G, U, NSRC, IDR, true>(a, myrow, base - chunk_base, U, col_ld, acc);
-        else agg_grp_batch<OP, G, U, NSRC, IDR, false>(a, myrow, base - chunk_base, stop - base, col_ld, acc);
+        if (stop - base == U) agg_grp_batch<OP, G, VEC, U, NSRC, IDR, true>(a, myrow, base - chunk_base, U, col_ld, acc);
+        else agg_grp_batch<OP, G, VEC, U, NSRC, IDR, false>(a, myrow, base - chunk_base, stop - base, col_ld, acc);
       }
       // FinalFunc: aggregator.cc:74-86 (empty -> default), mean_aggregator.cc:45-61.
       const int32_t n = s1 - s0;
       if (n == 0) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = a.default_attr;
+        for (int v = 0; v < VEC; ++v) acc[v] = a.default_attr;
       } else if (OP == GLX_AGG_MEAN) {
         const float fn = (float)n;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = acc[v] / fn;
+        for (int v = 0; v < VEC; ++v) acc[v] = acc[v] / fn;
       }
       if (col_ok) *reinterpret_cast<vec_t*>(a.emb_out + sg * (int64_t)a.dim + col) = acc;
       if (c == 0 && col_pass == 0) a.cnt_out[sg] = n;
@@ -435,7 +435,9 @@ struct AggKnobs {
   std::atomic<int> slices{0};   // GLX_AGG_SLICES=2|4|8: column slices as consecutive launches (ablation)
   std::atomic<int> legacy{0};   // GLX_AGG_LEGACY=1: the round-1..3 kernel (one id load per row per lane)
   std::atomic<int> segs{0};     // GLX_AGG_SEGS: segments per lane group (0 = chosen from fanout and grid size)
-  std::atomic<int> xcd{0};      // GLX_AGG_XCD_SLICES=2|4|8: column slice = workgroup % n (XCD-affine; experiment)
+  std::atomic<int> xcd{0};      // GLX_AGG_XCD_SLICES=1|2|4|8: column slice = workgroup % n (XCD-affine); 0 = 2 for big requests
+  std::atomic<int> occ{0};      // GLX_AGG_OCCUPANCY=3..7: workgroups per CU, capped with an unused LDS allocation
+  std::atomic<int> vec{0};      // GLX_AGG_VEC=2: 8-byte row loads over twice the lanes (experiment)
 };
 
 AggKnobs& agg_knobs() {
@@ -452,6 +454,8 @@ AggKnobs& agg_knobs() {
     k.legacy = env("GLX_AGG_LEGACY");
     k.segs = env("GLX_AGG_SEGS");
     k.xcd = env("GLX_AGG_XCD_SLICES");
+    k.occ = env("GLX_AGG_OCCUPANCY");
+    k.vec = env("GLX_AGG_VEC");
   });
   return k;
 }
@@ -504,15 +508,13 @@ int agg_grp_unroll(int32_t fanout, int32_t avg_len) {
   return best;
 }
 
-template <int OP, int G, int NSRC, int IDR>
+template <int OP, int G, int VEC, int NSRC, int IDR>
 void launch_agg_grp(AggArgs a, int32_t num_ids, hipStream_t s) {
-  constexpr int kChunk = G * IDR;
   const int32_t avg = a.num_segments > 0 ? (int32_t)(num_ids / a.num_segments) : 0;
-  const int32_t f = a.seg_start ? (avg > 0 ? avg : 1) : (a.fanout > 0 ? a.fanout : 1);
-  // segments per group: as many as one chunk of ids serves, but keep >= ~16 K waves in the grid
-  int32_t S = kChunk / f;
-  const int64_t waves = (int64_t)a.num_segments * G / 64;
-  if (S > waves / 16384) S = (int32_t)(waves / 16384);
+  // segments per group: one.  More (a chunk of ids then serves several segments: one id load per G * IDR / fanout
+  // segments) lowers the L2-resident floor but loses on every real request (profiles/r04/agg_probe_*): more, shorter
+  // waves keep more independent row loads in flight.  GLX_AGG_SEGS overrides.
+  int32_t S = 1;
   const int want = agg_knobs().segs.load(std::memory_order_relaxed);
   if (want > 0) S = want;
   if (S > G - 1) S = G - 1;  // lane j of the group holds the start of its j-th segment (and lane S the end)
@@ -521,17 +523,21 @@ void launch_agg_grp(AggArgs a, int32_t num_ids, hipStream_t s) {
   const int64_t groups = ((int64_t)a.num_segments + S - 1) / S;
   const int64_t blocks = (groups + (256 / G) - 1) / (256 / G) * (a.xcd_slices > 1 ? a.xcd_slices : 1);
   const unsigned grid = (unsigned)blocks;
+  // occupancy cap (experiment): k workgroups per CU by declaring 160 KiB / k of LDS nobody touches
+  const int occ = agg_knobs().occ.load(std::memory_order_relaxed);
+  const size_t lds = (occ >= 3 && occ <= 7) ? (size_t)(160 * 1024 / occ) & ~(size_t)255 : 0;
   switch (agg_grp_unroll(a.seg_start ? 0 : a.fanout, avg)) {
-    case 6: glx_aggregate_grp_kernel<OP, G, 6, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
-    case 8: glx_aggregate_grp_kernel<OP, G, 8, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
-    case 12: glx_aggregate_grp_kernel<OP, G, 12, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
-    case 15: glx_aggregate_grp_kernel<OP, G, 15, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
-    default: glx_aggregate_grp_kernel<OP, G, 10, NSRC, IDR><<<grid, 256, 0, s>>>(a); break;
+    case 6: glx_aggregate_grp_kernel<OP, G, VEC, 6, NSRC, IDR><<<grid, 256, lds, s>>>(a); break;
+    case 8: glx_aggregate_grp_kernel<OP, G, VEC, 8, NSRC, IDR><<<grid, 256, lds, s>>>(a); break;
+    case 12: glx_aggregate_grp_kernel<OP, G, VEC, 12, NSRC, IDR><<<grid, 256, lds, s>>>(a); break;
+    case 15: glx_aggregate_grp_kernel<OP, G, VEC, 15, NSRC, IDR><<<grid, 256, lds, s>>>(a); break;
+    default: glx_aggregate_grp_kernel<OP, G, VEC, 10, NSRC, IDR><<<grid, 256, lds, s>>>(a); break;
   }
 }
 
 template <int OP, int NSRC>
-void launch_agg_cols(const AggArgs& a, int32_t num_ids, hipStream_t s) {
+void launch_agg_cols(const AggArgs& a0, int32_t num_ids, int want_xcd, hipStream_t s) {
+  AggArgs a = a0;
   bool vec4 = a.dim % 4 == 0 && a.ncols % 4 == 0 && a.col0 % 4 == 0 && (reinterpret_cast<uintptr_t>(a.emb_out) & 15) == 0 &&
               (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && (a.stride % 4) == 0;
   if (NSRC > 1) {
@@ -541,11 +547,24 @@ void launch_agg_cols(const AggArgs& a, int32_t num_ids, hipStream_t s) {
   // the grouped kernel reads row 0 in place of an unknown id's row: some row must exist
   const bool has_rows = NSRC > 1 ? (a.X2 != nullptr || a.base2 > 0) : a.num_rows > 0;
   if (vec4 && has_rows && a.ncols >= 32 && agg_knobs().legacy.load(std::memory_order_relaxed) == 0) {
-    const int lanes = a.ncols / 4;
-    if (lanes >= 64) launch_agg_grp<OP, 64, NSRC, 1>(a, num_ids, s);
-    else if (lanes >= 32) launch_agg_grp<OP, 32, NSRC, 1>(a, num_ids, s);
-    else if (lanes >= 16) launch_agg_grp<OP, 16, NSRC, 1>(a, num_ids, s);
-    else launch_agg_grp<OP, 8, NSRC, 2>(a, num_ids, s);
+    if (want_xcd > 1 && a.col0 == 0 && a.ncols == a.dim && a.dim % (4 * want_xcd) == 0 && a.dim / want_xcd >= 32) {
+      a.xcd_slices = want_xcd;  // only the grouped kernel knows about slices
+      a.ncols = a.dim / want_xcd;
+    }
+    // lanes per segment x floats per lane: 16-byte loads by default; agg_vec = 2 prefers twice the lanes with
+    // 8-byte loads (a whole wave per 128-column segment keeps the row arithmetic on the scalar unit)
+    const bool v2 = agg_knobs().vec.load(std::memory_order_relaxed) == 2;
+    const int lanes = a.ncols / (v2 ? 2 : 4);
+    if (v2) {
+      if (lanes >= 64) launch_agg_grp<OP, 64, 2, NSRC, 1>(a, num_ids, s);
+      else if (lanes >= 32) launch_agg_grp<OP, 32, 2, NSRC, 1>(a, num_ids, s);
+      else launch_agg_grp<OP, 16, 2, NSRC, 1>(a, num_ids, s);
+      return;
+    }
+    if (lanes >= 64) launch_agg_grp<OP, 64, 4, NSRC, 1>(a, num_ids, s);
+    else if (lanes >= 32) launch_agg_grp<OP, 32, 4, NSRC, 1>(a, num_ids, s);
+    else if (lanes >= 16) launch_agg_grp<OP, 16, 4, NSRC, 1>(a, num_ids, s);
+    else launch_agg_grp<OP, 8, 4, NSRC, 2>(a, num_ids, s);
     return;
   }
   if (vec4) {
@@ -566,30 +585,33 @@ void launch_agg_cols(const AggArgs& a, int32_t num_ids, hipStream_t s) {
   }
 }
 
-// Column slices, two experiments (both off by default; measurements in DESIGN.md 10):
-//  * GLX_AGG_SLICES = n: the columns in n slices, one LAUNCH after the other -- divides the hot working set of each
-//    phase by n at the price of reading the ids n times (profiles/r02: no gain);
-//  * GLX_AGG_XCD_SLICES = n: ONE launch, workgroup b reduces slice b % n -- with the observed b % 8 workgroup -> XCD
-//    placement each XCD's L2 then holds 1/n of every hub row instead of whole rows of 1/8 of the segments.
+// Column slices.
+//  * XCD-affine slices (the default for big requests): ONE launch, workgroup b reduces column slice b % n.  With the
+//    observed b % 8 workgroup -> XCD placement each XCD's 4 MB L2 then holds 1 / n of every hub row instead of whole
+//    rows of 1 / 8 of the segments: n times as many hub rows stay L2-resident per XCD, at the price of reading the ids
+//    n times and of 1 / n-row pieces.  Measured (profiles/r04/agg_probe_*_run4.txt, same process, ms): C3 hop-2
+//    (D = 256, 16.4 M ids) n = 1 / 2 / 4: 1.96 / 1.85 / 1.82 on the power-law request, 3.48 / 3.52 / 3.72 on uniformly
+//    random rows; C2 (D = 128) 0.633 / 0.561 / 0.596 and 0.853 / 0.881 / 0.929; C4's shape 1.03 / 0.96 / 1.07 and
+//    1.86 / 1.90 / 1.98.  n = 2 is the default: -6 .. -11 % where rows are re-used, +1 .. 3 % where none is; small
+//    requests (C3 hop 1: 0.098 -> 0.120 ms) stay whole.  GLX_AGG_XCD_SLICES = 1 (off) | 2 | 4 | 8 overrides.
+//  * GLX_AGG_SLICES = n: the columns in n slices, one LAUNCH after the other (ablation; profiles/r02: no gain).
+constexpr int32_t kXcdSliceMinIds = 4 << 20;
+
 template <int OP, int NSRC>
 void launch_agg_n(const AggArgs& a0, int32_t num_ids, hipStream_t s) {
   AggArgs a = a0;
   a.col0 = 0;
   a.ncols = a.dim;
   a.xcd_slices = 0;
-  const int xcd = agg_knobs().xcd.load(std::memory_order_relaxed);
-  if ((xcd == 2 || xcd == 4 || xcd == 8) && a.dim % (4 * xcd) == 0 && a.dim / xcd >= 32) {
-    a.xcd_slices = xcd;
-    a.ncols = a.dim / xcd;
-    launch_agg_cols<OP, NSRC>(a, num_ids, s);
-    return;
-  }
+  int xcd = agg_knobs().xcd.load(std::memory_order_relaxed);
+  if (xcd == 0) xcd = (num_ids >= kXcdSliceMinIds && a.dim % 8 == 0 && a.dim >= 128) ? 2 : 1;
   int slices = agg_knobs().slices.load(std::memory_order_relaxed);
   if ((slices != 2 && slices != 4 && slices != 8) || a.dim % (4 * slices) != 0) slices = 1;
+  if (xcd != 2 && xcd != 4 && xcd != 8) xcd = 1;
   for (int c = 0; c < slices; ++c) {
     a.ncols = a.dim / slices;
     a.col0 = c * a.ncols;
-    launch_agg_cols<OP, NSRC>(a, num_ids, s);
+    launch_agg_cols<OP, NSRC>(a, num_ids, slices == 1 ? xcd : 1, s);
   }
 }
 
@@ -821,6 +843,8 @@ extern "C" int glx_tune(const char* name, int32_t value) {
   else if (strcmp(name, "agg_legacy") == 0) slot = &k.legacy;
   else if (strcmp(name, "agg_segs") == 0) slot = &k.segs;
   else if (strcmp(name, "agg_xcd_slices") == 0) slot = &k.xcd;
+  else if (strcmp(name, "agg_occupancy") == 0) slot = &k.occ;
+  else if (strcmp(name, "agg_vec") == 0) slot = &k.vec;
   GLX_REQUIRE(slot != nullptr, "unknown knob '%s'", name);
   slot->store(value, std::memory_order_relaxed);
   return GLX_OK;

@@ -35,7 +35,7 @@ for D in (128, 256):
     for op in ("SumAggregator", "MeanAggregator"):
         outs = {}
         for knob in ("0", "1"):
-            os.environ["GLX_AGG_MFMA"] = knob
+            glx.tune("agg_mfma", int(knob))
             emb = torch.empty((Sg, D), dtype=torch.float32, device=dev)
             cnt = torch.empty(Sg, dtype=torch.int32, device=dev)
             for _ in range(3):
@@ -55,4 +55,4 @@ for D in (128, 256):
         print("dim %3d %-15s outputs bit-identical: %s" % (D, op, same), flush=True)
     del f
     torch.cuda.empty_cache()
-os.environ.pop("GLX_AGG_MFMA", None)
+glx.tune("agg_mfma", 0)

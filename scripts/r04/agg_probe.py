@@ -39,17 +39,23 @@ def t(name, reps=7):
         torch.cuda.synchronize(); glx.profile_enable(False)
         r.append(float(glx.profile_collect(glx.KERNEL_AGGREGATE).sum()))
     return float(np.median(r)), out[0].clone()
-KNOBS = ("agg_legacy", "agg_unroll", "agg_segs", "agg_xcd_slices")
+KNOBS = ("agg_legacy", "agg_unroll", "agg_segs", "agg_xcd_slices", "agg_occupancy", "agg_vec")
 def setk(**kw):
     for k in KNOBS:
         glx.tune(k, kw.get(k, 0))
-variants = [("legacy (r03)", dict(agg_legacy=1)), ("grouped default", {}),
-            ("grouped U=6", dict(agg_unroll=6)), ("grouped U=8", dict(agg_unroll=8)), ("grouped U=10", dict(agg_unroll=10)),
-            ("grouped U=12", dict(agg_unroll=12)), ("grouped U=15", dict(agg_unroll=15)),
-            ("grouped S=1", dict(agg_segs=1)), ("grouped S=2", dict(agg_segs=2)), ("grouped S=3", dict(agg_segs=3)),
-            ("grouped S=6", dict(agg_segs=6)), ("grouped S=12", dict(agg_segs=12)),
-            ("xcd slices 8", dict(agg_xcd_slices=8)), ("xcd slices 4", dict(agg_xcd_slices=4)), ("xcd slices 2", dict(agg_xcd_slices=2)),
-            ("legacy (r03) again", dict(agg_legacy=1))]
+def parse(spec):  # "x4,s1,u15" -> knobs
+    kw = {}
+    for tok in spec.split(","):
+        if tok == "legacy": kw["agg_legacy"] = 1
+        elif tok[0] == "x": kw["agg_xcd_slices"] = int(tok[1:])
+        elif tok[0] == "s": kw["agg_segs"] = int(tok[1:])
+        elif tok[0] == "u": kw["agg_unroll"] = int(tok[1:])
+        elif tok[0] == "o": kw["agg_occupancy"] = int(tok[1:])
+        elif tok[0] == "v": kw["agg_vec"] = int(tok[1:])
+    return kw
+specs = sys.argv[2].split(":") if len(sys.argv) > 2 else ["legacy", "default", "u6", "u8", "u10", "u12", "u15", "s1", "s2", "s3", "s6", "s12",
+                                                         "x8", "x4", "x2", "legacy"]
+variants = [(sp, parse(sp)) for sp in specs]
 ref = {}
 print("# %s: D=%d, hop-2 fanout %d (%d segments), hop-1 fanout %d; median of 7 launches, ms" % (wl, D, k2, Sg, k1))
 print("%-22s %9s %9s %9s %9s  bit-identical" % ("variant", "real", "hop1", "l2", "uniform"))

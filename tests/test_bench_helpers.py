@@ -2,6 +2,7 @@
 import importlib.util
 import os
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,3 +39,59 @@ def test_committed_offline_traffic_is_labelled_and_bounded():
     r = bench.roofline_aggregate("MaxAggregator", 256, 1_638_400, 16_384_000, avg_ms=2.15, launches=20, ids_last=ids,
                                  workload="c3", B0=65536)
     assert r["traffic"] and "OFFLINE" in r["traffic_source"] and 0 < r["frac_traffic_offline"] <= 1
+
+
+def _canned(name):
+    import json
+    return json.load(open(os.path.join(ROOT, "profiles", "r03", name)))
+
+
+def test_headline_line_stays_under_the_drivers_tail():
+    """the driver keeps ~9 KB of stdout tail; round 3's 25 KB line was cut and never parsed.  The line built
+    from that very record must fit 4 KB and still carry the contract's keys, `roofline` and `cpu_baseline`."""
+    import json
+    res = _canned("bench_c3_n1_final.json")
+    assert len(json.dumps(res)) > 20000  # the record that broke the parser
+    line = bench.compact_line(res, "bench_detail.json")
+    assert len(line) <= bench.LINE_LIMIT < 6000 and "\n" not in line
+    got = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert got["value"] == pytest.approx(res["value"], rel=1e-6) and got["ms_per_step"] == pytest.approx(res["ms_per_step"], rel=1e-6)
+    assert got["config"]["workload"].startswith("c3") and "model" not in got["config"]
+    r = got["roofline"]
+    for k in ("kernel", "bound", "peak", "unit", "achieved", "frac", "frac_basis", "algorithmic_over_peak", "frac_compulsory", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and 0 < r["frac"] <= 1 and len(r["frac_basis"]) <= 80
+    c = got["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "threads", "nproc", "thread_sweep"):
+        assert k in c, k
+    assert got["verified_vs_oracle"] is True
+    oc = got["other_configs"]
+    assert set(oc) == {"c2", "c5", "c4", "c3-degree-seeds"}
+    for rec in oc.values():
+        assert set(rec) <= {"ms_per_step", "value", "frac", "frac_basis", "traffic", "verified", "error"}
+    assert got["detail"] == "bench_detail.json"
+
+
+def test_headline_line_trims_optional_blocks_before_it_would_outgrow_the_limit():
+    import json
+    res = _canned("bench_c3_n1_final.json")
+    res["other_configs"] = {"cfg%d" % i: dict(res["other_configs"]["c2"]) for i in range(60)}  # absurdly many
+    line = bench.compact_line(res, "bench_detail.json")
+    got = json.loads(line)
+    assert len(line) <= bench.LINE_LIMIT and "other_configs" in got["trimmed"]
+    assert got["roofline"]["frac"] > 0 and got["cpu_baseline"]["value"] > 0  # the judged blocks are never dropped
+
+
+def test_multi_gpu_line_is_compact_too():
+    import json
+    res = _canned("bench_world1_rccl_ledger.json")
+    line = bench.compact_line(res, "bench_detail.json")
+    got = json.loads(line)
+    assert len(line) <= bench.LINE_LIMIT
+    assert set(got["placements"]) >= {"features_sharded", "edge_cut_pure"}
+    for leg in got["placements"].values():
+        assert set(leg) <= {"ms_per_step", "value"}
+    assert got["verified_sharded_equals_unpartitioned"] is True and "placement" in got["config"]["workload"]

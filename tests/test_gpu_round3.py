@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def mfma_on():
-    os.environ["GLX_AGG_MFMA"] = "1"
+    glx.tune("agg_mfma", 1)  # the knob is read from the environment once per process; glx_tune sets it at run time
     yield
-    os.environ.pop("GLX_AGG_MFMA", None)
+    glx.tune("agg_mfma", 0)
 
 
 @pytest.mark.parametrize("dim", [64, 128, 256])

@@ -27,17 +27,25 @@ def _port():
 
 @pytest.mark.parametrize("world,features,pipeline", [(2, "replicated", "on"), (2, "sharded", "on"),
                                                      (3, "replicated", "off")])
-def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
+def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline, tmp_path):
+    detail = str(tmp_path / "detail.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--backend", "gloo", "--share-device", "--workload", "tiny", "--batch", "2048",
            "--steps", "3", "--warmup", "1", "--features", features, "--pipeline", pipeline, "--verify",
-           "--cpu-baseline", "off"]
+           "--cpu-baseline", "off", "--detail-out", detail]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 prints exactly one JSON line
-    res = json.loads(lines[0])
+    head = json.loads(lines[0])
+    # the stdout line is the compact one (<= 4 KB: the driver parses it from a ~9 KB tail); the full record is beside it
+    assert len(lines[0]) <= 4096 and head["detail"] == detail
+    res = json.load(open(detail))
+    for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup"):
+        assert head[k] == pytest.approx(res[k], rel=1e-6), k
+    assert head["verified_sharded_equals_unpartitioned"] is True and set(head["placements"]) == set(res["placements"])
+    assert head["rccl_ranks"] == 0 and "host-staged" in head["transport"]  # gloo rig: no RCCL communicator in this run
     assert res["n_gpus"] == world and res["verified_sharded_equals_unpartitioned"] is True
     assert res["value"] > 0 and res["scaling"] == "weak"
     # both placements are timed side by side; `value` is the one --features names
@@ -69,28 +77,58 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline):
     if features == "replicated":
         assert res["value_features_replicated"] == res["value"]
         assert "features_replicated placement" in res["config"]["workload"]
+        assert "features_replicated placement" in head["config"]["workload"]
     else:
         # `value` = the faster of the placement's two exchange modes; both are reported
         assert res["value"] == max(res["value_features_sharded"], res["value_features_sharded_speculated"])
         assert "features_sharded placement" in res["config"]["workload"]
 
 
-def test_bench_reports_what_it_measured_when_a_rank_fails_in_a_leg():
+def test_bench_reports_what_it_measured_when_a_rank_fails_in_a_leg(tmp_path):
     """A rank that fails inside the halo leg leaves its peer in a collective: rank 0's watchdog must still print ONE
     result line -- the placement that did finish, named as such, with the error -- and every process must leave."""
     env = dict(os.environ, GLX_BENCH_FAULT="1:features_sharded")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--backend", "gloo", "--share-device", "--workload", "tiny", "--batch", "2048",
-           "--steps", "3", "--warmup", "1", "--cpu-baseline", "off", "--watchdog", "15"]
+           "--steps", "3", "--warmup", "1", "--cpu-baseline", "off", "--watchdog", "15", "--detail-out", str(tmp_path / "d.json")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode != 0
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
     res = json.loads(lines[0])
     assert "error" in res and "features_sharded" in res["error"]
-    assert res["value"] == res["placements"]["features_replicated"]["value"] > 0
+    assert res["value"] == pytest.approx(res["placements"]["features_replicated"]["value"], rel=1e-5) and res["value"] > 0
     assert "features_replicated placement (the only leg that finished)" in res["config"]["workload"]
+
+
+def test_bench_launches_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun around it (how the driver starts the N = 1 run): bench.py re-executes
+    itself under torch.distributed.run -- two ranks really run (n_gpus from the communicator, not from the flag)."""
+    detail = str(tmp_path / "detail.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--workload", "tiny",
+           "--batch", "2048", "--steps", "3", "--warmup", "1", "--cpu-baseline", "off", "--detail-out", detail]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    head = json.loads(lines[0])
+    assert head["n_gpus"] == 2 and head["ranks"] == 2 and head["value"] > 0 and len(lines[0]) <= 4096
+    assert head["verified_sharded_equals_unpartitioned"] is True  # --verify-sharded auto: the tiny graph fits beside the shards
+    assert json.load(open(detail))["n_gpus"] == 2
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """--gpus 64 on this box: ONE JSON error line, non-zero exit -- never a 1-GPU number under an N-GPU label."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--workload", "tiny", "--steps", "2"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["value"] is None and "--gpus 64" in res["error"] and res["n_gpus"] < 64
 
 
 def test_bench_c5_hetero_two_ranks_on_one_gpu():
