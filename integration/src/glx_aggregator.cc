@@ -28,8 +28,9 @@ int GlxAggregatorId(const std::string& name) {  // the operator is looked up by 
 
 // [glx-aggregate]
 Status Aggregator::Aggregate(const AggregatingRequest* req, AggregatingResponse* res) {
-  const glx_features* feats = GlxFeaturesOf(graph_store_, req->Type());
-  if (feats == nullptr) return GlxStatus(GLX_INTERNAL);
+  const glx_features* feats = nullptr;
+  int rc = GlxFeaturesOf(graph_store_, req->Type(), &feats);
+  if (rc != GLX_OK) return GlxStatus(rc);
   int32_t dim = 0;
   glx_features_info(feats, nullptr, &dim, nullptr, nullptr);  // SideInfo.f_num
   const int32_t num_segments = req->NumSegments();
@@ -43,7 +44,7 @@ Status Aggregator::Aggregate(const AggregatingRequest* req, AggregatingResponse*
   std::vector<int32_t> cnt(num_segments);
   const int64_t* ids = req->tensors_.at(kNodeIds).GetInt64();
   const int32_t* segs = req->tensors_.at(kSegmentIds).GetInt32();
-  int rc = glx_aggregate(feats, op, ids, segs, req->NumIds(), num_segments, GLOBAL_FLAG(DefaultFloatAttribute),
+  rc = glx_aggregate(feats, op, ids, segs, req->NumIds(), num_segments, GLOBAL_FLAG(DefaultFloatAttribute),
                          emb.data(), cnt.data(), GLX_PTR_HOST, /*stream=*/nullptr);
   if (rc != GLX_OK) return GlxStatus(rc);
   for (int32_t s = 0; s < num_segments; ++s) {

@@ -22,7 +22,7 @@ int Device() {
 }
 
 // [glx-mirror-edge-type]
-glx_graph* MirrorEdgeType(Graph* graph, int device) {
+int MirrorEdgeType(Graph* graph, int device, glx_graph** out) {
   io::GraphStorage* st = graph->GetLocalStorage();          // graph_storage.h:40-57
   const io::IdArray srcs = st->GetAllSrcIds();              // distinct source ids = rows
   std::vector<int64_t> row_ptr{0}, col, eid, ids;
@@ -50,16 +50,18 @@ glx_graph* MirrorEdgeType(Graph* graph, int device) {
     glx_graph_destroy(g);
     g = nullptr;
   }
-  return g;                                                   // nullptr: glx_last_error() has the reason
+  *out = g;
+  return rc;                                                  // not GLX_OK: glx_last_error() has the reason
 }
 // [/glx-mirror-edge-type]
 
 // [glx-mirror-node-type]
-glx_features* MirrorNodeType(Noder* noder, int device) {
+int MirrorNodeType(Noder* noder, int device, glx_features** out) {
   io::NodeStorage* st = noder->GetLocalStorage();           // node_storage.h:38-78
   const io::IdArray ids = st->GetIds();
   const int32_t dim = st->GetSideInfo()->f_num;              // element_value.h:30-34
-  if (dim <= 0) return nullptr;                               // no float attributes: nothing to aggregate
+  *out = nullptr;
+  if (dim <= 0) return GLX_INVALID_ARGUMENT;                  // no float attributes: nothing to aggregate
   std::vector<float> X(static_cast<size_t>(ids.Size()) * dim);
   std::vector<int64_t> raw(ids.Size());
   for (int32_t r = 0; r < ids.Size(); ++r) {
@@ -69,9 +71,7 @@ glx_features* MirrorNodeType(Noder* noder, int device) {
     const float* f = attr->GetFloats(&len);
     for (int32_t c = 0; c < dim; ++c) X[static_cast<size_t>(r) * dim + c] = c < len ? f[c] : GLOBAL_FLAG(DefaultFloatAttribute);
   }
-  glx_features* out = nullptr;
-  int rc = glx_features_create(device, ids.Size(), dim, X.data(), raw.data(), GLX_PTR_HOST, nullptr, &out);
-  return rc == GLX_OK ? out : nullptr;
+  return glx_features_create(device, ids.Size(), dim, X.data(), raw.data(), GLX_PTR_HOST, nullptr, out);
 }
 // [/glx-mirror-node-type]
 
@@ -98,30 +98,46 @@ Mirror* MirrorOf(GraphStore* store) {
 
 }  // namespace
 
-const glx_graph* GlxGraphOf(GraphStore* store, const std::string& edge_type) {
+int GlxGraphOf(GraphStore* store, const std::string& edge_type, const glx_graph** out) {
   Mirror* m = MirrorOf(store);
   std::lock_guard<std::mutex> lock(m->mu);
   Graph* graph = store->GetGraph(edge_type);
   const int64_t edges = graph->GetLocalStorage()->GetEdgeCount();
   auto it = m->graphs.find(edge_type);
-  if (it != m->graphs.end() && it->second.edges == edges) return it->second.g;
-  if (it != m->graphs.end()) glx_graph_destroy(it->second.g);  // the storage grew since: mirror it again
-  glx_graph* g = MirrorEdgeType(graph, Device());
-  m->graphs[edge_type] = {g, edges};
-  return g;
+  if (it != m->graphs.end() && it->second.edges == edges) {
+    *out = it->second.g;
+    return GLX_OK;
+  }
+  if (it != m->graphs.end()) {  // the storage grew since: mirror it again
+    glx_graph_destroy(it->second.g);
+    m->graphs.erase(it);
+  }
+  glx_graph* g = nullptr;
+  const int rc = MirrorEdgeType(graph, Device(), &g);
+  if (rc == GLX_OK) m->graphs[edge_type] = {g, edges};
+  *out = g;
+  return rc;
 }
 
-const glx_features* GlxFeaturesOf(GraphStore* store, const std::string& node_type) {
+int GlxFeaturesOf(GraphStore* store, const std::string& node_type, const glx_features** out) {
   Mirror* m = MirrorOf(store);
   std::lock_guard<std::mutex> lock(m->mu);
   Noder* noder = store->GetNoder(node_type);
   const int64_t nodes = noder->GetLocalStorage()->Size();
   auto it = m->feats.find(node_type);
-  if (it != m->feats.end() && it->second.nodes == nodes) return it->second.f;
-  if (it != m->feats.end()) glx_features_destroy(it->second.f);
-  glx_features* f = MirrorNodeType(noder, Device());
-  m->feats[node_type] = {f, nodes};
-  return f;
+  if (it != m->feats.end() && it->second.nodes == nodes) {
+    *out = it->second.f;
+    return GLX_OK;
+  }
+  if (it != m->feats.end()) {
+    glx_features_destroy(it->second.f);
+    m->feats.erase(it);
+  }
+  glx_features* f = nullptr;
+  const int rc = MirrorNodeType(noder, Device(), &f);
+  if (rc == GLX_OK) m->feats[node_type] = {f, nodes};
+  *out = f;
+  return rc;
 }
 
 Status GlxStatus(int rc) {

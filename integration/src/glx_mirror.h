@@ -18,8 +18,9 @@ namespace op {
 
 // Device handles of one GraphStore, made on first use after Build() (graph_store.cc:252-276 fixes the adjacency
 // order) and remade when the storage has grown since.  Thread-safe: Process() runs on up to 32 pool threads.
-const glx_graph* GlxGraphOf(GraphStore* store, const std::string& edge_type);
-const glx_features* GlxFeaturesOf(GraphStore* store, const std::string& node_type);
+// Return the C-ABI's code (GLX_OK, or why the mirror could not be made: GLX_UNAVAILABLE without a GPU, ...).
+int GlxGraphOf(GraphStore* store, const std::string& edge_type, const glx_graph** out);
+int GlxFeaturesOf(GraphStore* store, const std::string& node_type, const glx_features** out);
 
 // Status of a failed C-ABI call: the code IS a graphlearn::error::Code, the text is glx_last_error().
 Status GlxStatus(int rc);

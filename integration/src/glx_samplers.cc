@@ -39,12 +39,12 @@ public:
     res->InitNeighborIds();
     res->InitEdgeIds();
 
-    const glx_graph* graph = GlxGraphOf(graph_store_, req->Type());
-    if (graph == nullptr) return GlxStatus(GLX_INTERNAL);
+    const glx_graph* graph = nullptr;
+    int rc = GlxGraphOf(graph_store_, req->Type(), &graph);
+    if (rc != GLX_OK) return GlxStatus(rc);
     std::vector<int64_t> nbr(static_cast<size_t>(batch_size) * count), eid(nbr.size());
     const uint64_t call = g_calls.fetch_add(1);
     const Filter* flt = req->GetFilter();
-    int rc;
     if (*flt) {  // op::Filter maps onto glx_filter one to one
       glx_filter f = {static_cast<int32_t>(flt->GetType()), static_cast<int32_t>(flt->GetField()),
                       flt->GetValue()->GetInt64(), GLOBAL_FLAG(SamplingRetryTimes), GLOBAL_FLAG(DefaultTimestamp)};
