@@ -95,3 +95,25 @@ def test_multi_gpu_line_is_compact_too():
     for leg in got["placements"].values():
         assert set(leg) <= {"ms_per_step", "value"}
     assert got["verified_sharded_equals_unpartitioned"] is True and "placement" in got["config"]["workload"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libglref.so")), reason="oracle/_ref not built")
+def test_cpu_baseline_runs_both_storage_modes_at_every_thread_count():
+    """the reference's CPU path on the whole graph, StorageMode 2 and 3, T = 1 / .. / nproc -> six numbers,
+    `value` = the best of them (here on the tiny workload with two thread counts)."""
+    import argparse
+    V, E = bench.WORKLOADS["tiny"][:2]
+    g = torch.Generator().manual_seed(1)
+    src = torch.randint(0, V, (E,), generator=g)
+    dst = torch.randint(0, V, (E,), generator=g)
+    w = torch.rand(E, generator=g) + 0.01
+    args = argparse.Namespace(workload="tiny", cpu_storage_modes="3,2", cpu_time_budget=0.2, cpu_seeds_per_request=16,
+                              cpu_thread_sweep="1,2", cpu_edge_limit=0, cpu_wall_limit=300.0)
+    r = bench.cpu_baseline(bench.WORKLOADS["tiny"], src, dst, w, args, torch.unique(src).numpy())
+    assert r["kind"] == "reference" and r["errors"] is None, r
+    assert set(r["modes"]) == {"2", "3"} and all(set(v) == {"1", "2"} for v in r["modes"].values())
+    six = [v for m in r["modes"].values() for v in m.values()]
+    assert r["value"] == max(six) > 0 and r["edges_built"] == E and r["feature_rows"] == V
+    assert r["cores"] in (1, 2) and r["storage_mode"] in (2, 3)
+    c = bench.compact_cpu(r)
+    assert set(c["modes"]) == {"2", "3"} and len(c["sample"]) <= 160 and c["storage_mode"] == r["storage_mode"]
