@@ -290,11 +290,12 @@ def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
         recs = {}
         for m, pr in procs:
             try:
+                so, se = "", ""
                 so, se = pr.communicate(timeout=args.cpu_wall_limit)
                 recs[m] = json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1])
             except Exception as ex:  # noqa: BLE001 -- a mode that fails is reported, the other still counts
                 pr.kill()
-                recs[m] = {"error": repr(ex)}
+                recs[m] = {"error": "%r (exit code %s): %s" % (ex, pr.returncode, (se or "")[-300:])}
             log("cpu baseline, StorageMode %d: %s" % (m, {k: v for k, v in recs[m].items() if k != "legs"}))
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -313,12 +314,13 @@ def cpu_baseline(wl, src, dst, weight, args, seed_pool=None):
         "thread_sweep": [{"cores": l["threads"], "value": l["value"], "sampling_edges_per_s": l["sampling_edges_per_s"],
                           "aggregation_vertices_per_s": l["aggregation_vertices_per_s"]} for l in r0["legs"]],
         "edges_built": r0["edges_built"], "feature_rows": r0["feature_rows"],
+        "feature_rows_by_mode": {str(m): r["feature_rows"] for m, r in good.items()},
         "build_s": {str(m): r["build_s"] for m, r in good.items()},
         "sample": ("reference C++ (oracle/_ref) %s [%d,%d] + %s, whole graph (%d of %d edges) + whole feature table (%d x %d), "
-                   "StorageMode 2 and 3 x T = %s request threads (one request per thread, %d seeds/request); value = best of "
-                   "those = mode %d at T = %d; per leg ~%.0fs sampling + ~%.0fs aggregation timed; value = 1/(1/sampling + "
+                   "StorageMode 2 and 3 (3: the %d rows its int32 attribute offsets reach) x T = %s request threads (one "
+                   "request per thread, %d seeds/request); value = best of those = mode %d at T = %d; per leg ~%.0fs sampling + ~%.0fs aggregation timed; value = 1/(1/sampling + "
                    "1/aggregation); aggregation ids = destinations of random edges (the in-degree-biased mix a sampler "
-                   "returns)" % (sampler, k1, k2, agg, r0["edges_built"], E, r0["feature_rows"], D,
+                   "returns)" % (sampler, k1, k2, agg, r0["edges_built"], E, r0["feature_rows"], D, min(V, (2 ** 31 - 1) // D),
                                  "/".join(str(l["threads"]) for l in r0["legs"]), args.cpu_seeds_per_request, mode,
                                  leg["threads"], args.cpu_time_budget, args.cpu_time_budget)),
         "errors": {str(m): r["error"] for m, r in recs.items() if "error" in r} or None,
@@ -347,8 +349,13 @@ def cpu_worker(args):
                               _p(np.ascontiguousarray(w[lo:hi])) if w is not None else None, hi - lo)
     ref.L.glref_build_graph(ref.h, b"e")
     block = np.random.default_rng(5).random((1 << 20, D), dtype=np.float32) * 2 - 1
-    for lo in range(0, V, 1 << 20):  # the whole table; every 1 M-row block gets the same values (timing only)
-        hi = min(lo + (1 << 20), V)
+    # StorageMode 3 keeps the float attributes of a node type in ONE flat array and computes a row's offset as an
+    # int32 product (compressed_memory_node_storage.cc:160-163: `it->second * side_info_.f_num`, both int32): rows past
+    # (2^31 - 1) / f_num are out of its reach (the whole 10 M x 256 table of C3 crashes it).  That mode therefore gets
+    # the largest table it can address, and its aggregation ids are folded into it.
+    rows = V if mode != 3 else min(V, (2 ** 31 - 1) // D)
+    for lo in range(0, rows, 1 << 20):  # the whole table; every 1 M-row block gets the same values (timing only)
+        hi = min(lo + (1 << 20), rows)
         ref.L.glref_add_nodes(ref.h, b"n", _p(np.arange(lo, hi, dtype=np.int64)), _p(block), hi - lo, D)
     ref.L.glref_build_nodes(ref.h, b"n")
     build_s = time.time() - t0
@@ -371,11 +378,11 @@ def cpu_worker(args):
             seeds = pool[rng.integers(0, pool.shape[0], B * tc * reps)]
             ds = ref.L.glref_time_sample_2hop(ref.h, b"e", sampler.encode(), _p(seeds), B, k1, k2, reps, tc, ctypes.byref(out))
             r_s = out.value / ds
-            ids = np.ascontiguousarray(dst[np.sort(rng.integers(0, n_edges, n_ids * tc))])
+            ids = np.ascontiguousarray(dst[np.sort(rng.integers(0, n_edges, n_ids * tc))]) % rows
             rng.shuffle(ids)
             d2 = ref.L.glref_time_aggregate(ref.h, b"n", agg.encode(), _p(ids), n_ids, k2, 1, tc, ctypes.byref(out))
             areps = int(max(1, min(64, args.cpu_time_budget / max(d2, 1e-3))))
-            ids = np.ascontiguousarray(dst[np.sort(rng.integers(0, n_edges, n_ids * tc * areps))])
+            ids = np.ascontiguousarray(dst[np.sort(rng.integers(0, n_edges, n_ids * tc * areps))]) % rows
             rng.shuffle(ids)
             da = ref.L.glref_time_aggregate(ref.h, b"n", agg.encode(), _p(ids), n_ids, k2, areps, tc, ctypes.byref(out))
             r_a = out.value / da
@@ -383,7 +390,7 @@ def cpu_worker(args):
                          "aggregation_vertices_per_s": r_a, "requests_per_thread": [reps, areps], "timed_s": [ds, da]})
         fcntl.flock(lock, fcntl.LOCK_UN)
     ref.close()
-    print(json.dumps({"storage_mode": mode, "build_s": build_s, "edges_built": n_edges, "feature_rows": V, "legs": legs}), flush=True)
+    print(json.dumps({"storage_mode": mode, "build_s": build_s, "edges_built": n_edges, "feature_rows": rows, "legs": legs}), flush=True)
 
 
 def cpu_baseline_port(wl, src, dst, weight, args, seed_pool=None):

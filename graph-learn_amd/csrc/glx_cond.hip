@@ -96,7 +96,7 @@ __global__ void glx_cond_set2_kernel(int64_t* p, int64_t a, int64_t b) {
 __device__ __forceinline__ void set_insert(int64_t* tab, uint64_t mask, int64_t v) {
   if (v == GLX_EMPTY_KEY) return;
   uint64_t h = glx_mix64((uint64_t)v) & mask;
-  while (true) {
+  for (uint64_t probes = 0; probes <= mask; ++probes) {  // bounded: a full table drops the id instead of spinning
     const unsigned long long prev =
         atomicCAS(reinterpret_cast<unsigned long long*>(&tab[h]), (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)v);
     if ((int64_t)prev == GLX_EMPTY_KEY || (int64_t)prev == v) return;
@@ -107,12 +107,13 @@ __device__ __forceinline__ void set_insert(int64_t* tab, uint64_t mask, int64_t 
 __device__ __forceinline__ bool set_has(const int64_t* tab, uint64_t mask, int64_t v) {
   if (v == GLX_EMPTY_KEY) return false;
   uint64_t h = glx_mix64((uint64_t)v) & mask;
-  while (true) {
+  for (uint64_t probes = 0; probes <= mask; ++probes) {
     const int64_t k = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == v) return true;
     if (k == GLX_EMPTY_KEY) return false;
     h = (h + 1) & mask;
   }
+  return false;
 }
 
 // ---- the exclusion set of a request WITHOUT `unique`, as a function of the row --------------------------------
@@ -232,7 +233,8 @@ __device__ __forceinline__ void cond_row(const CondArgs& a, int lane, int32_t i)
   int64_t* orow = a.out + (int64_t)i * a.count;
   int32_t taken = 0;
   uint32_t base = 0;
-  for (int32_t c = 0; c < a.ncols; ++c) {
+  // an empty candidate set (a condition table of an edge type without edges) has no group tables at all
+  for (int32_t c = 0; a.U > 0 && c < a.ncols; ++c) {
     const int32_t n = a.num_c[c];
     if (n <= 0) continue;
     const int64_t key = a.dst_keys[(int64_t)i * a.ncols + c];
@@ -489,7 +491,17 @@ extern "C" int glx_cond_negative_sample(const glx_cond_table* t, const glx_graph
     p_out = d_out.as<int64_t>();
   }
   std::vector<int32_t> num_c((size_t)(ncols > 0 ? ncols : 1), 0);
-  for (int32_t c = 0; c < ncols; ++c) num_c[(size_t)c] = (int32_t)((float)count * props[c]);  // neg_num * props[i]
+  int64_t by_columns = 0;
+  for (int32_t c = 0; c < ncols; ++c) {
+    GLX_REQUIRE(props[c] >= 0.0f && props[c] <= 1.0f, "props[%d] = %g is not a proportion", c, (double)props[c]);
+    num_c[(size_t)c] = (int32_t)((float)count * props[c]);  // neg_num * props[i]
+    by_columns += num_c[(size_t)c];
+  }
+  // the columns share one row of `count` slots; with `unique` every accepted id also enters the exclusion set, which is
+  // sized for count ids per row -- proportions that add up to more than one would overfill both (the Python wrapper
+  // refused them already; the C entry point must too: a full set makes its probe loop spin)
+  GLX_REQUIRE(by_columns <= count, "the column proportions ask for %lld of %d negatives per row (sum(props) > 1)",
+              (long long)by_columns, count);
   GLX_HIP(hipMalloc(&d_num.p, num_c.size() * 4));
   GLX_HIP(hipMemcpyAsync(d_num.p, num_c.data(), num_c.size() * 4, hipMemcpyHostToDevice, s));
   // everything the request can insert: its dst ids, the neighbours of its src ids, every accepted id

@@ -634,12 +634,18 @@ struct glx_dist_ledger {
   int device = 0;
   int64_t* d_words = nullptr;  // [1 + kLedgerClasses]
   int64_t* d_stage = nullptr;  // [kMaxWorld + 32 + kLedgerTail]: a count exchange's values + the tail
+  // Speculation is keyed by POSITION: the i-th glx_dist_sample call since the last confirmation point (a count exchange
+  // that is not a sampling call's own: the aggregation's, glx_dist_confirm, ...).  Whether call i speculates depends
+  // only on (i, what the ranks learned together at position i, hold) -- state every rank holds identically as long as
+  // the ranks issue the same SEQUENCE of calls -- never on this rank's request length: a rank with a short tail batch,
+  // or an idle rank with an empty request, still enters the same collectives as its peers (a decision
+  // taken from the local length let one rank take the fixed-capacity exchange while another took the count exchange).
   struct Shape {
-    int64_t n = 0;
-    double share = 0.0;
+    int64_t rows = 0;  // the largest bucket any rank sent to any owner at this position so far; 0 = not learned
+    int64_t n = 0;     // the longest request seen at this position (informational: largest_share)
   };
   Shape shapes[kLedgerClasses];
-  int num_shapes = 0;
+  int pos = 0;  // index of the next sampling call in the current window
   bool hold = false;
   int64_t epoch = 0;
   // speculated calls since the last exchange: how many, and a digest of their parameters (compared across ranks)
@@ -649,17 +655,17 @@ struct glx_dist_ledger {
   int64_t pad_rows = 1024;
   glx_dist_ledger_stats stats;
   std::vector<int64_t> h_tmp;
-  int shape_of(int64_t n) const {
-    for (int c = 0; c < num_shapes; ++c)
-      if (shapes[c].n == n) return c;
-    return -1;
-  }
+  bool learned(int c) const { return c >= 0 && c < kLedgerClasses && shapes[c].rows > 0; }
   int64_t capacity(int c) const {
-    const Shape& sh = shapes[c];
-    int64_t cap = (int64_t)((double)sh.n * sh.share * slack) + pad_rows;
+    int64_t cap = (int64_t)((double)shapes[c].rows * slack) + pad_rows;
     cap = (cap + 63) & ~(int64_t)63;
-    if (cap < 64) cap = 64;
-    return cap < sh.n ? cap : sh.n;
+    return cap < 64 ? 64 : cap;
+  }
+  void note_share(int c) {
+    if (shapes[c].n > 0) {
+      const double sh = (double)shapes[c].rows / (double)shapes[c].n;
+      if (sh > stats.largest_share) stats.largest_share = sh < 1.0 ? sh : 1.0;
+    }
   }
 };
 
@@ -699,8 +705,7 @@ __global__ __launch_bounds__(256) void glx_dist_spec_pack_kernel(const int64_t* 
     cnt_off[p] = c;
     cnt_off[P + p] = off;
     if (c > cap) atomicMax(reinterpret_cast<unsigned long long*>(words), (unsigned long long)tag);
-    const int64_t share_fp = ((c << 20) + n - 1) / n;
-    atomicMax(reinterpret_cast<unsigned long long*>(words + 1 + shape), (unsigned long long)share_fp);
+    atomicMax(reinterpret_cast<unsigned long long*>(words + 1 + shape), (unsigned long long)c);  // rows this bucket needed
   }
   const int64_t take = c < cap ? c : cap;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
@@ -801,7 +806,8 @@ void routing_from_matrix(const glx_dist_store* st, int nvals, Routing* r) {
 // The count exchange of a partitioned request: the one place its host thread waits for the other ranks.  With a
 // ledger the exchange is also the confirmation point of the calls that skipped theirs: GLX_ABORTED on every rank when
 // any rank's speculated message overflowed (or the ranks speculated on different requests).
-int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_t* h_out, hipStream_t s) {
+int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_t* h_out, hipStream_t s,
+                    bool window_end = true) {
   glx_dist_ledger* lg = st->ledger;
   const auto t0 = std::chrono::steady_clock::now();
   int rc;
@@ -823,13 +829,15 @@ int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_
         disagree = disagree || row[nvals + 1] != lg->pending || row[nvals + 2] != (int64_t)lg->digest;
         for (int c = 0; c < kLedgerClasses; ++c) need[c] = need[c] > row[nvals + 3 + c] ? need[c] : row[nvals + 3 + c];
       }
-      for (int c = 0; c < lg->num_shapes; ++c) {
-        const double sh = (double)need[c] / (double)(1 << 20);
-        if (sh > lg->shapes[c].share) lg->shapes[c].share = sh;
-        if (lg->shapes[c].share > lg->stats.largest_share) lg->stats.largest_share = lg->shapes[c].share;
+      for (int c = 0; c < kLedgerClasses; ++c) {
+        if (lg->shapes[c].rows > 0 && need[c] > lg->shapes[c].rows) lg->shapes[c].rows = need[c];  // what would have fitted
+        lg->note_share(c);
       }
       lg->pending = 0;
       lg->digest = 0;
+      // a confirmation point that is not a sampling call's own exchange starts the next window of positions; so does
+      // every abort (the caller repeats the window's calls)
+      if (window_end || overflow || disagree) lg->pos = 0;
       if (disagree) {
         lg->hold = true;
         lg->stats.holding = 1;
@@ -837,7 +845,7 @@ int exchange_counts(glx_dist_store* st, const int64_t* d_vals, int nvals, int64_
       if (overflow || disagree) {
         ++lg->stats.aborted;
         ++lg->epoch;
-        glx_set_error(disagree ? "speculated requests differ between the ranks (length, neighbor_count, sampler, padding, "
+        glx_set_error(disagree ? "speculated requests differ between the ranks (neighbor_count, sampler, padding, "
                                  "seed or call_counter): their results are void, and this ledger no longer speculates"
                                : "a speculated request did not fit its fixed-capacity messages: the results of the "
                                  "glx_dist_sample calls since the last count exchange are void -- repeat them (the "
@@ -1041,11 +1049,13 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
 }
 
 // A request whose shape the ledger knows: fixed-capacity messages, no count leaves the device (glx.h, ABI 4).
-// bucketed / order: the partitioned request (the store's request arena); counts in st->d_vals.
+// bucketed / order / counts: the partitioned request, all in the store's request arena -- NOT in st->d_vals: this call
+// returns without a host wait, and a call on another stream (an aggregation's resolve on a store that holds both a graph
+// and features) rewrites st->d_vals at once; the arena is ordered between sampling calls by ArenaOrder.
 int dist_sample_speculated(glx_dist_store* st, glx_dist_ledger* lg, int shape, int sampler, int64_t n, int32_t k,
                            int padding_mode, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
-                           const glx_graph* rg, const int64_t* bucketed, const int64_t* order, int64_t* nbr_out,
-                           int64_t* eid_out, hipStream_t s) {
+                           const glx_graph* rg, const int64_t* bucketed, const int64_t* order, const int64_t* counts,
+                           int64_t* nbr_out, int64_t* eid_out, hipStream_t s) {
   const int P = st->world;
   const int64_t cap = lg->capacity(shape), m = cap * P;
   GLX_REQUIRE(m * k <= (int64_t)INT32_MAX * 8, "speculated request too large");
@@ -1073,7 +1083,7 @@ int dist_sample_speculated(glx_dist_store* st, glx_dist_ledger* lg, int shape, i
   int64_t* cnt_off = reinterpret_cast<int64_t*>(base + o_co);
 
   const unsigned gx = (unsigned)((cap + 255) / 256 < 1024 ? (cap + 255) / 256 : 1024);
-  glx_dist_spec_pack_kernel<<<dim3(gx > 0 ? gx : 1, (unsigned)P), 256, 0, s>>>(bucketed, order, st->d_vals, P, cap, n, send_ids,
+  glx_dist_spec_pack_kernel<<<dim3(gx > 0 ? gx : 1, (unsigned)P), 256, 0, s>>>(bucketed, order, counts, P, cap, n, send_ids,
                                                                               send_rows, cnt_off, lg->d_words, shape,
                                                                               lg->epoch + 1);
   GLX_HIP(hipGetLastError());
@@ -1111,12 +1121,13 @@ int dist_sample_speculated(glx_dist_store* st, glx_dist_ledger* lg, int shape, i
                                                                                 nbr_out, eid_out);
   GLX_HIP(hipGetLastError());
   // what the ranks must have agreed on for the owners' answers to be the requesters' (compared at the confirmation)
-  const uint64_t words[7] = {seed, call_counter, (uint64_t)k, (uint64_t)sampler, (uint64_t)padding_mode,
-                             (uint64_t)default_neighbor_id, (uint64_t)n};
+  const uint64_t words[6] = {seed, call_counter, (uint64_t)k, (uint64_t)sampler, (uint64_t)padding_mode,
+                             (uint64_t)default_neighbor_id};  // not the length: ranks may differ in it (tail batches)
   uint64_t d = lg->digest;
   for (uint64_t w : words) d = glx_mix64(d ^ (w + 0x9e3779b97f4a7c15ull));
   lg->digest = d;
   ++lg->pending;
+  ++lg->pos;
   ++lg->stats.speculated;
   st->sample_rows = n;
   st->sample_rows_replica = -1;  // sizes of a speculated request stay on the device
@@ -1141,6 +1152,7 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   const size_t o_val = cv.take(filtered ? (size_t)(n > 0 ? n : 1) * 8 : 0);
   const size_t o_nb = cv.take((size_t)(n > 0 ? n : 1) * k * 8);
   const size_t o_eb = cv.take((size_t)(n > 0 ? n : 1) * k * 8);
+  const size_t o_cnt = cv.take((size_t)(P + 16) * 8);  // bucket sizes + request parameters: this call's own (see above)
   int rc = st->req.ensure(cv.at);
   if (rc != GLX_OK) return rc;
   int64_t* bucketed = reinterpret_cast<int64_t*>(st->req.p + o_buck);
@@ -1148,6 +1160,7 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   int64_t* vals_b = filtered ? reinterpret_cast<int64_t*>(st->req.p + o_val) : nullptr;
   int64_t* nbr_back = reinterpret_cast<int64_t*>(st->req.p + o_nb);
   int64_t* eid_back = reinterpret_cast<int64_t*>(st->req.p + o_eb);
+  int64_t* d_cnt = reinterpret_cast<int64_t*>(st->req.p + o_cnt);
 
   // Rows of vertices the graph replica holds are served here, from the same adjacency (and alias tables) their
   // owner holds and with the same random stream (their index in the request): they form one more bucket, last.
@@ -1155,9 +1168,9 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   const bool divert = rg != nullptr && !filtered && sampler != GLX_SAMPLER_IN_DEGREE &&
                       (sampler != GLX_SAMPLER_EDGE_WEIGHT || rg->weight != nullptr);
   if (divert) {
-    rc = glx_partition_divert(st->device, src, n, P, rg->map(), bucketed, order, st->d_vals, s);
+    rc = glx_partition_divert(st->device, src, n, P, rg->map(), bucketed, order, d_cnt, s);
   } else {
-    rc = glx_partition(st->device, src, n, P, bucketed, order, st->d_vals, s);
+    rc = glx_partition(st->device, src, n, P, bucketed, order, d_cnt, s);
   }
   if (rc != GLX_OK) return rc;
   if (filtered && n > 0) {
@@ -1170,10 +1183,11 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   memset(&mine, 0, sizeof(mine));
   mine.v[10] = n;
   glx_dist_ledger* lg = st->ledger;
-  const int shape = lg && !lg->hold && !filtered && n > 0 && k > 0 ? lg->shape_of(n) : -1;
+  // position-keyed: the same answer on every rank that issued the same sequence of calls (see glx_dist_ledger)
+  const int shape = lg && !lg->hold && !filtered && k > 0 && lg->learned(lg->pos) ? lg->pos : -1;
   if (shape >= 0) {
     return dist_sample_speculated(st, lg, shape, sampler, n, k, padding_mode, default_neighbor_id, seed, call_counter,
-                                  divert ? rg : nullptr, bucketed, order, nbr_out, eid_out, s);
+                                  divert ? rg : nullptr, bucketed, order, d_cnt, nbr_out, eid_out, s);
   }
   mine.v[0] = (int64_t)seed;
   mine.v[1] = (int64_t)call_counter;
@@ -1185,16 +1199,19 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   mine.v[7] = filtered ? filter->field : GLX_FILTER_FIELD_NONE;
   mine.v[8] = filtered ? filter->retry_times : 0;
   mine.v[9] = filtered ? filter->default_timestamp : 0;
-  glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P, mine, kParams);
+  glx_dist_set_params_kernel<<<1, 64, 0, s>>>(d_cnt + P, mine, kParams);
   const int nvals = P + kParams;
   st->h_mat.resize((size_t)P * nvals);
-  rc = exchange_counts(st, st->d_vals, nvals, st->h_mat.data(), s);
+  const int my_pos = lg ? lg->pos : 0;
+  rc = exchange_counts(st, d_cnt, nvals, st->h_mat.data(), s, /*window_end=*/false);
   if (rc != GLX_OK) return rc;
+  if (lg) ++lg->pos;  // this call's place in the window, speculated or not
   Routing rt;
   routing_from_matrix(st, nvals, &rt);
   const int64_t m = rt.n_recv;
   GLX_REQUIRE(m <= INT32_MAX, "more than 2^31 request rows arrived at one shard");
-  bool uniform = true, same_length = true;
+  bool uniform = true;
+  int64_t longest = 0;
   for (int q = 0; q < P; ++q) {
     const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
     // the response width and the set of tensors that travel are part of the exchange's shape
@@ -1203,27 +1220,21 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
     GLX_REQUIRE((pq[6] != GLX_FILTER_NONE) == filtered, "rank %d and this rank disagree on whether the request has a filter",
                 q);
     for (int j = 0; j < 10; ++j) uniform = uniform && pq[j] == mine.v[j];
-    same_length = same_length && pq[10] == n;
+    longest = longest > pq[10] ? longest : pq[10];
   }
-  if (lg && !lg->hold && !filtered && uniform && same_length && n > 0 && k > 0) {
-    // a request every rank issued alike: later ones of this length may skip the count exchange.  Its shape = the
-    // largest share of a request that any rank sent to any owner (the same number on every rank: the whole matrix
-    // is here).
-    int c = lg->shape_of(n);
-    if (c < 0 && lg->num_shapes < kLedgerClasses) {
-      c = lg->num_shapes++;
-      lg->shapes[c].n = n;
-      lg->shapes[c].share = 0.0;
-    }
-    if (c >= 0) {
-      int64_t most = 0;
-      for (int q = 0; q < P; ++q)
-        for (int p2 = 0; p2 < P; ++p2) most = most > st->h_mat[(size_t)q * nvals + p2] ? most : st->h_mat[(size_t)q * nvals + p2];
-      const double share = (double)most / (double)n;
-      if (share > lg->shapes[c].share) lg->shapes[c].share = share;
-      if (lg->shapes[c].share > lg->stats.largest_share) lg->stats.largest_share = lg->shapes[c].share;
-      ++lg->stats.learned;
-    }
+  if (lg && !lg->hold && !filtered && uniform && k > 0 && longest > 0 && my_pos < kLedgerClasses) {
+    // a request every rank issued with the same parameters: later calls at this position of the window may skip the
+    // count exchange.  Its shape = the largest bucket any rank sent to any owner (the same number on every rank: the
+    // whole matrix is here); lengths may differ between the ranks.
+    int64_t most = 0;
+    for (int q = 0; q < P; ++q)
+      for (int p2 = 0; p2 < P; ++p2) most = most > st->h_mat[(size_t)q * nvals + p2] ? most : st->h_mat[(size_t)q * nvals + p2];
+    glx_dist_ledger::Shape& sh = lg->shapes[my_pos];
+    if (most > sh.rows) sh.rows = most;
+    if (sh.rows < 1) sh.rows = 1;  // learned, even if every request at this position was served by a replica
+    if (longest > sh.n) sh.n = longest;
+    lg->note_share(my_pos);
+    ++lg->stats.learned;
   }
 
   Carver cr;

@@ -327,6 +327,12 @@ Status GraphStore::Build(const IndexOption& option) {
     Status s = n->Build(option);
     if (!s.ok()) return s;
   }
+  {
+    // what GetStats reports describes the data as built: statistics gathered before this Build (a GetStats issued
+    // while sources were still loading) are stale now -- the next GetStats gathers them again
+    std::lock_guard<std::mutex> g(mtx_);
+    stats_ = GraphStatistics();
+  }
   return Status::OK();
 }
 

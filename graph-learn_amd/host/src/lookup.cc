@@ -182,6 +182,7 @@ const char* kCountKey = "cnt";  // service/constants.cc:51
 }
 
 GetCountRequest::GetCountRequest() : OpRequest() {
+  DisableShard();  // carries no ids to partition: every server answers for itself (graph_store.cc:278-293)
   ADD_TENSOR(params_, kOpName, kString, 1);
   params_[kOpName].AddString("GetCount");
 }
@@ -198,6 +199,7 @@ int32_t GetCountResponse::Size() const {
 }
 
 GetStatsRequest::GetStatsRequest() : OpRequest() {
+  DisableShard();  // answered from the store's statistics, never partitioned (stats_getter.cc:25-48)
   ADD_TENSOR(params_, kOpName, kString, 1);
   params_[kOpName].AddString("GetStats");
 }
@@ -381,6 +383,8 @@ public:
   Status Process(const OpRequest*, OpResponse* res) override {
     GetStatsResponse* response = static_cast<GetStatsResponse*>(res);
     if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    // the statistics are dropped by every GraphStore::Build (the counts change with what was loaded) and gathered
+    // again by the first GetStats after it; with several servers that first call is collective (BuildStatistics)
     if (graph_store_->GetStatistics().GetCounts().empty()) {
       Status s = graph_store_->BuildStatistics();
       if (!s.ok()) return s;

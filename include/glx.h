@@ -32,7 +32,8 @@ extern "C" {
 
 /* 1: graph / features / samplers / aggregators / partition helpers.  2 (additions only): host registration, shard
  * communicator, distributed store (+ replicas), request plans.  3 (additions only): memory-system probes,
- * induced sub-graph, conditional negative sampling. */
+ * induced sub-graph, conditional negative sampling.  4 (additions only): the speculation ledger of the distributed store
+ * (glx_dist_ledger_*, glx_dist_confirm, GLX_ABORTED), glx_tune. */
 #define GLX_ABI_VERSION 4
 
 /* Exported symbols: libglx.so is built with -fvisibility=hidden. */
@@ -602,18 +603,22 @@ GLX_API int glx_dist_last_stats(const glx_dist_store* st, glx_dist_stats* out);
 /* ---- ABI 4: partitioned sampling WITHOUT a count exchange.  DistributeRunner waits for every shard's reply before it
  * goes on (RunInParallel, core/runner/op_runner.h:86-117); glx_dist_sample does the same once per request, at the count
  * exchange that tells the ranks how many rows each message carries -- a blocking host wait per hop.  A ledger removes it
- * for requests whose shape repeats: the first request of a length n goes through the count exchange as before and
- * records the largest share of it any rank sent to any owner; later requests of that length send FIXED-capacity messages
- * (that share x 1.25 + 1024 rows, padded with ids no shard knows), the owners answer every slot, and each requester keeps
- * the answers of its real rows -- no count leaves the device, the host never waits.  Whether every bucket fitted its
+ * for calls whose place in the step repeats: the i-th glx_dist_sample call after a confirmation point goes through the
+ * count exchange once and records the largest bucket any rank sent to any owner; later calls at position i send
+ * FIXED-capacity messages (that bucket x 1.25 + 1024 rows, padded with ids no shard knows), the owners answer every slot,
+ * and each requester keeps the answers of its real rows -- no count leaves the device, the host never waits.  Whether a
+ * call speculates depends only on its position and on what the ranks learned together, never on this rank's request
+ * length: a rank with a shorter tail batch (or an empty request) enters the same collectives as its peers.  Whether every bucket fitted its
  * message is recorded in a device word and travels with the NEXT count exchange of any store attached to the same
  * ledger (the aggregation's, glx_dist_aggregate_begin; or glx_dist_confirm): that call returns GLX_ABORTED on every rank
  * when any bucket of any rank did not fit, and the results of all speculated calls since the previous successful
  * exchange are void -- redo them (same call counters: same answers); the capacities have been raised to what was
  * needed, so the repeat fits (voided calls still in flight on other streams need no draining: an abort starts a new
  * epoch and their flags are not heeded).  Results of confirmed calls are bit-identical to the count-exchange path.
- * Contract (SPMD lockstep): every rank issues the same sequence of glx_dist_sample calls with the same request length,
- * neighbor_count, sampler, padding, seed and call_counter -- the owners serve all requesters with their OWN parameters.
+ * Contract (SPMD lockstep): every rank issues the same SEQUENCE of glx_dist_sample calls and confirmation points, with
+ * the same neighbor_count, sampler, padding, seed and call_counter -- the owners serve all requesters with their OWN
+ * parameters; request lengths may differ between the ranks.  (Ranks that issue different sequences of calls enter
+ * different collectives: that is a hang on RCCL, with or without a ledger.)
  * A digest of those parameters travels with the confirmation; ranks that disagree get GLX_ABORTED and the ledger stops
  * speculating for good.  Filtered requests, glx_dist_sample_full and random walks always take the count exchange.
  * One ledger per rank, shared by that rank's stores; calls that use it come from one host thread. */

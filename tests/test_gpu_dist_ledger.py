@@ -161,3 +161,46 @@ def test_two_stores_share_one_ledger(world):
         st_s.close()
         st_a.close()
     _run_ranks(2, body)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_a_rank_with_a_shorter_tail_batch_speculates_along_with_its_peers(world, P):
+    """the decision to speculate must not depend on a rank's own request length -- one rank with a tail
+    batch (or an empty request) would otherwise take the count exchange while its peers send fixed-capacity messages:
+    mismatched collectives.  Keyed by the call's position in the step, every rank takes the same path; the short rank's
+    answers still equal the unpartitioned operator's."""
+    whole, feats, dev = world["whole"], world["feats"], world["dev"]
+    gs, fs = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r], features=fs[r])
+        lg = glx.Ledger(0).attach(st)
+        assert _step(st, whole, feats, r, 0, dev)  # learns positions 0 and 1
+        for i, n_tail in ((1, 137), (2, 0), (3, B)):  # a short batch, an empty one, a full one again -- on rank 0 only
+            src = _seeds(r, i, dev)
+            if r == 0:
+                src = src[:n_tail].contiguous()
+            before = st.stats()["host_syncs"]
+            n1, e1 = st.sample("EdgeWeightSampler", src, K1, seed=5, call_counter=2 * i)
+            n2, e2 = st.sample("EdgeWeightSampler", n1.view(-1), K2, seed=5, call_counter=2 * i + 1)
+            st.confirm()
+            assert st.stats()["host_syncs"] - before == 1, (r, i)  # both hops speculated on every rank
+            w1, we1 = whole.sample("EdgeWeightSampler", src, K1, seed=5, call_counter=2 * i)
+            w2, we2 = whole.sample("EdgeWeightSampler", w1.view(-1), K2, seed=5, call_counter=2 * i + 1)
+            assert torch.equal(n1, w1) and torch.equal(e1, we1) and torch.equal(n2, w2) and torch.equal(e2, we2), (r, i)
+        s = lg.stats()
+        assert s["aborted"] == 0 and s["holding"] == 0 and s["speculated"] == 6, s
+        # a LONGER request than the position has seen may not fit: that is an abort on every rank, and the repeat fits
+        src = torch.cat([_seeds(r, 9, dev)] * 6) if r == 0 else _seeds(r, 9, dev)
+        try:
+            n1, e1 = st.sample("RandomSampler", src, K1, seed=5, call_counter=77)
+            st.confirm()
+        except glx.GlxError as ex:
+            assert ex.code == glx.ABORTED
+            n1, e1 = st.sample("RandomSampler", src, K1, seed=5, call_counter=77)
+            st.confirm()
+        w1, we1 = whole.sample("RandomSampler", src, K1, seed=5, call_counter=77)
+        assert torch.equal(n1, w1) and torch.equal(e1, we1)
+        lg.close()
+        st.close()
+    _run_ranks(P, body)

@@ -32,7 +32,7 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--backend", "gloo", "--share-device", "--workload", "tiny", "--batch", "2048",
-           "--steps", "3", "--warmup", "1", "--features", features, "--pipeline", pipeline, "--verify",
+           "--steps", "3", "--warmup", "2", "--features", features, "--pipeline", pipeline, "--verify",
            "--cpu-baseline", "off", "--detail-out", detail]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -65,7 +65,10 @@ def test_bench_multi_rank_path_on_one_gpu(world, features, pipeline, tmp_path):
     for name in ("features_sharded_speculated", "edge_cut_pure_speculated"):
         leg = res["placements"][name]
         assert leg["value"] > 0 and leg["ledger"]["holding"] == 0
-        assert leg["ledger"]["speculated"] >= 2 * 3 and leg["ledger"]["learned"] == 2, leg["ledger"]
+        # the ledger is keyed by a call's position between two confirmations: the pipelined legs issue the sampling of
+        # step i + 1 before the confirmation of step i, so their prologue visits positions 2 and 3 once
+        assert leg["ledger"]["speculated"] >= 2 * 3, leg["ledger"]
+        assert leg["ledger"]["learned"] == (4 if pipeline == "on" else 2), leg["ledger"]
         if pipeline == "on":  # (the flat leg does not count its exchanges)
             assert leg["count_exchanges_per_step"] == 1.0, leg
             assert res["placements"][name[:-11]]["count_exchanges_per_step"] == 3.0
