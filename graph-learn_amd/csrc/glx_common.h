@@ -666,6 +666,10 @@ struct GlxRowSource {
   int64_t swizzle_rows;  // glx_swizzle_row bound (0 = rows stored in order)
   int64_t rows;
 };
+// glx_negative.hip, for glx_dist.hip: InDegreeNegativeSampler on the rows an owner received
+int glx_negative_sample_rows_device(const glx_negative* t, const glx_graph* g, const int64_t* src, const int64_t* rng_rows,
+                                    int32_t batch, int32_t count, int64_t default_neighbor_id, uint64_t seed,
+                                    uint64_t call_counter, int64_t* out, hipStream_t s);
 int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, int op, const int32_t* vrows,
                                const int32_t* d_seg, int32_t num_ids, int32_t num_segments, float default_attr,
                                float* d_emb, int32_t* d_cnt, hipStream_t s);

@@ -748,6 +748,11 @@ struct glx_dist_store {
   uint64_t* bm_valid = nullptr;       // (same allocation) the known ids, only when some hot id is unknown to its owner
   int64_t bm_max = -1;
   int device = 0, rank = 0, world = 1;
+  // the destination ids this rank OWNS (llabs(id) % P == rank), ascending, with their in-degree summed over all shards:
+  // built collectively on first use (glx_dist_in_degrees, glx_dist_negative_create); -1 = not built
+  int64_t* own_id = nullptr;
+  int64_t* own_cnt = nullptr;
+  int64_t own_M = -1;
   bool shortcut = true;  // world == 1: call the local operator directly
   Arena req, recv;  // sampling: request-sized and receive-sized buffers
   Arena r_req, r_recv, r_back;  // design R (glx_dist_aggregate_partial): request-, receive- and partial-sized buffers
@@ -1313,15 +1318,21 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
 
 // Partitioned FullSampler.  Phase 1 (always): request rows to their owners, the owners' row sizes back, offsets.
 // Phase 2 (fill): the owners' values back, every row to its place.  Device pointers.
+// filter (device values, one per request row) may be NULL / GLX_FILTER_NONE.  With a filter every row's value travels
+// with its id, like every tensor of a partitioned request (hash_partitioner.h:69-74), and the owners answer with
+// glx_sample_full_filtered: the row sizes stay the unfiltered ones (full_sampler.cc:55-62), so the sizes half is the same.
 int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit, int32_t* deg_out,
                             int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out, int64_t capacity, bool fill,
-                            int64_t* total_out, hipStream_t s) {
+                            int64_t* total_out, hipStream_t s, const glx_filter* filter = nullptr,
+                            int padding_mode = GLX_PAD_CIRCULAR, int64_t default_neighbor_id = 0) {
   const int P = st->world;
   const int64_t n = batch, n1 = n > 0 ? n : 1;
+  const bool filtered = fill && filter != nullptr && filter->type != GLX_FILTER_NONE;
   ArenaOrder arena_order(st, s);
   Carver cv;
   const size_t o_buck = cv.take((size_t)n1 * 8);
   const size_t o_ord = cv.take((size_t)n1 * 8);
+  const size_t o_val = cv.take(filtered ? (size_t)n1 * 8 : 0);
   const size_t o_degb = cv.take((size_t)n1 * 8);
   const size_t o_soff = cv.take((size_t)(n1 + 1) * 8);
   const size_t o_d64 = cv.take((size_t)(n1 + 1) * 8);
@@ -1332,22 +1343,45 @@ int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batc
   int64_t* deg_b = reinterpret_cast<int64_t*>(st->req.p + o_degb);
   int64_t* src_off = reinterpret_cast<int64_t*>(st->req.p + o_soff);
   int64_t* deg64 = reinterpret_cast<int64_t*>(st->req.p + o_d64);
+  int64_t* vals_b = filtered ? reinterpret_cast<int64_t*>(st->req.p + o_val) : nullptr;
   rc = glx_partition(st->device, src, n, P, bucketed, order, st->d_vals, s);
   if (rc != GLX_OK) return rc;
-  st->h_mat.resize((size_t)P * P);
-  rc = exchange_counts(st, st->d_vals, P, st->h_mat.data(), s);
+  if (filtered && n > 0) {
+    glx_dist_gather_i64_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(filter->values, order, n, vals_b);
+  }
+  // the filter's kind rides with the counts: the owners serve every requester with ITS filter, and a rank without a
+  // filter among ranks with one is a mismatched request, not a silent difference
+  constexpr int kFullParams = 6;
+  ReqParams mine;
+  memset(&mine, 0, sizeof(mine));
+  mine.v[0] = filtered ? filter->type : GLX_FILTER_NONE;
+  mine.v[1] = filtered ? filter->field : GLX_FILTER_FIELD_NONE;
+  mine.v[2] = filtered ? filter->default_timestamp : 0;
+  mine.v[3] = padding_mode;
+  mine.v[4] = default_neighbor_id;
+  mine.v[5] = max_limit;
+  glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P, mine, kFullParams);
+  const int nvals = P + kFullParams;
+  st->h_mat.resize((size_t)P * nvals);
+  rc = exchange_counts(st, st->d_vals, nvals, st->h_mat.data(), s);
   if (rc != GLX_OK) return rc;
   Routing rt;
-  routing_from_matrix(st, P, &rt);
+  routing_from_matrix(st, nvals, &rt);
+  for (int q = 0; q < P; ++q) {
+    const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
+    GLX_REQUIRE((pq[0] != GLX_FILTER_NONE) == filtered, "rank %d and this rank disagree on whether the FullSampler request has a filter", q);
+    GLX_REQUIRE(pq[5] == max_limit, "rank %d asks for at most %lld neighbours per row, this rank for %d", q, (long long)pq[5], max_limit);
+  }
   const int64_t m = rt.n_recv, m1 = m > 0 ? m : 1;
   GLX_REQUIRE(m <= INT32_MAX, "more than 2^31 request rows arrived at one shard");
-  GlxTemp ids_in, deg_loc, off_loc, deg_loc64;
+  GlxTemp ids_in, deg_loc, off_loc, deg_loc64, vals_in;
   GLX_HIP(hipMalloc(&ids_in.p, (size_t)m1 * 8));
+  if (filtered) GLX_HIP(hipMalloc(&vals_in.p, (size_t)m1 * 8));
   GLX_HIP(hipMalloc(&deg_loc.p, (size_t)m1 * 4));
   GLX_HIP(hipMalloc(&off_loc.p, (size_t)(m1 + 1) * 8));
   GLX_HIP(hipMalloc(&deg_loc64.p, (size_t)m1 * 8));
-  GlxSeg seg_ids{bucketed, ids_in.p, 8};
-  rc = st->comm->alltoallv(&seg_ids, 1, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
+  GlxSeg seg_ids[2] = {{bucketed, ids_in.p, 8}, {vals_b, vals_in.p, 8}};
+  rc = st->comm->alltoallv(seg_ids, filtered ? 2 : 1, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
                            rt.recv_offs.data(), s);
   if (rc != GLX_OK) return rc;
   GLX_HIP(hipMemsetAsync(off_loc.p, 0, (size_t)(m1 + 1) * 8, s));
@@ -1410,10 +1444,29 @@ int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batc
   GLX_HIP(hipMalloc(&eid_loc.p, (size_t)(loc_total + 1) * 8));
   GLX_HIP(hipMalloc(&nbr_in.p, (size_t)(total + 1) * 8));
   GLX_HIP(hipMalloc(&eid_in.p, (size_t)(total + 1) * 8));
-  if (m > 0 && loc_total > 0) {
+  if (m > 0 && loc_total > 0 && !filtered) {
     rc = glx_sample_full(st->graph, ids_in.as<int64_t>(), (int32_t)m, max_limit, off_loc.as<int64_t>(),
                          nbr_loc.as<int64_t>(), eid_loc.as<int64_t>(), GLX_PTR_DEVICE, s);
     if (rc != GLX_OK) return rc;
+  } else if (m > 0 && loc_total > 0) {
+    // one launch per requester: its rows, its values, its filter kind / padding / default id.  (A timestamp > value
+    // filter uses the first value of the rows a launch serves for all of them, as the reference's servers do with the
+    // first value of the part they receive: filter.h:107-111, DESIGN quirk 11.)
+    for (int q = 0; q < P; ++q) {
+      const int64_t begin = rt.recv_offs[q], cnt = rt.recv_offs[q + 1] - begin;
+      if (cnt == 0) continue;
+      const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
+      glx_filter part;
+      part.type = (int32_t)pq[0];
+      part.field = (int32_t)pq[1];
+      part.values = vals_in.as<int64_t>() + begin;
+      part.retry_times = 0;
+      part.default_timestamp = pq[2];
+      rc = glx_sample_full_filtered(st->graph, ids_in.as<int64_t>() + begin, (int32_t)cnt, max_limit,
+                                    off_loc.as<int64_t>() + begin, (int)pq[3], pq[4], &part, nbr_loc.as<int64_t>(),
+                                    eid_loc.as<int64_t>(), GLX_PTR_DEVICE, s);
+      if (rc != GLX_OK) return rc;
+    }
   }
   GlxSeg seg_vals[2] = {{nbr_loc.p, nbr_in.p, 8}, {eid_loc.p, eid_in.p, 8}};
   rc = st->comm->alltoallv(seg_vals, 2, send_vals.data(), send_voffs.data(), recv_vals.data(), recv_voffs.data(), s);
@@ -1632,6 +1685,8 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
   if (st->cache) glx_features_destroy(st->cache);
   if (st->cache_slots) (void)hipFree(st->cache_slots);
   if (st->bm_member) (void)hipFree(st->bm_member);
+  if (st->own_id) (void)hipFree(st->own_id);
+  if (st->own_cnt) (void)hipFree(st->own_cnt);
   delete st;
 }
 
@@ -1766,9 +1821,13 @@ namespace {
 // Both entry points: host pointers are staged (ids in; sizes, offsets and values out), device pointers are used as given.
 int dist_sample_full_any(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit, int32_t* degrees_out,
                          int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out, int64_t capacity, bool fill, int ptr_kind,
-                         void* stream) {
+                         void* stream, const glx_filter* filter = nullptr, int padding_mode = GLX_PAD_CIRCULAR,
+                         int64_t default_neighbor_id = 0) {
   int rc = check_store(st, ptr_kind);
   if (rc != GLX_OK) return rc;
+  const bool filtered = fill && filter != nullptr && filter->type != GLX_FILTER_NONE;
+  GLX_REQUIRE(!filtered || batch == 0 || filter->values != nullptr, "the filter has no values");
+  GLX_REQUIRE(padding_mode == GLX_PAD_CIRCULAR || padding_mode == GLX_PAD_REPLICATE, "bad padding_mode %d", padding_mode);
   GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
   GLX_REQUIRE(batch >= 0 && offsets_out != nullptr && (batch == 0 || (src && degrees_out)), "bad request");
   GLX_REQUIRE(!fill || (capacity >= 0 && (capacity == 0 || (nbr_out && eid_out))), "bad response buffers");
@@ -1782,16 +1841,23 @@ int dist_sample_full_any(glx_dist_store* st, const int64_t* src, int32_t batch, 
   int64_t* d_off = offsets_out;
   int64_t* d_nbr = nbr_out;
   int64_t* d_eid = eid_out;
+  glx_filter dev_filter;
+  if (filtered) dev_filter = *filter;
   if (ptr_kind == GLX_PTR_HOST) {
     const size_t cap = fill ? (size_t)capacity : 0;
-    GLX_HIP(hipMalloc(&stage.p, (nb + (nb + 1) + 2 * cap + 2) * 8 + (nb + 2) * 4));
+    GLX_HIP(hipMalloc(&stage.p, (nb + (nb + 1) + 2 * cap + 2 + nb) * 8 + (nb + 2) * 4));
     int64_t* b = stage.as<int64_t>();
     if (nb) GLX_HIP(hipMemcpyAsync(b, src, nb * 8, hipMemcpyHostToDevice, s));
     d_src = b;
     d_off = b + nb;
     d_nbr = d_off + nb + 1;
     d_eid = d_nbr + cap;
-    d_deg = reinterpret_cast<int32_t*>(d_eid + cap);
+    int64_t* d_val = d_eid + cap;
+    d_deg = reinterpret_cast<int32_t*>(d_val + nb);
+    if (filtered && nb) {
+      GLX_HIP(hipMemcpyAsync(d_val, filter->values, nb * 8, hipMemcpyHostToDevice, s));
+      dev_filter.values = d_val;
+    }
   }
   int64_t total = 0;
   if (st->world == 1 && st->shortcut) {
@@ -1801,11 +1867,13 @@ int dist_sample_full_any(glx_dist_store* st, const int64_t* src, int32_t batch, 
     GLX_HIP(hipStreamSynchronize(s));
     if (fill) {
       GLX_REQUIRE(total <= capacity, "the response holds %lld values, the buffers %lld", (long long)total, (long long)capacity);
-      rc = glx_sample_full(st->graph, d_src, batch, max_limit, d_off, d_nbr, d_eid, GLX_PTR_DEVICE, s);
+      rc = glx_sample_full_filtered(st->graph, d_src, batch, max_limit, d_off, padding_mode, default_neighbor_id,
+                                    filtered ? &dev_filter : nullptr, d_nbr, d_eid, GLX_PTR_DEVICE, s);
       if (rc != GLX_OK) return rc;
     }
   } else {
-    rc = dist_sample_full_device(st, d_src, batch, max_limit, d_deg, d_off, d_nbr, d_eid, capacity, fill, &total, s);
+    rc = dist_sample_full_device(st, d_src, batch, max_limit, d_deg, d_off, d_nbr, d_eid, capacity, fill, &total, s,
+                                 filtered ? &dev_filter : nullptr, padding_mode, default_neighbor_id);
     if (rc != GLX_OK) return rc;
   }
   if (ptr_kind == GLX_PTR_HOST) {
@@ -1831,6 +1899,14 @@ extern "C" int glx_dist_sample_full(glx_dist_store* st, const int64_t* src, int3
                                     int64_t capacity, int ptr_kind, void* stream) {
   return dist_sample_full_any(st, src, batch, max_limit, degrees_out, offsets_out, nbr_out, eid_out, capacity, true, ptr_kind,
                               stream);
+}
+
+extern "C" int glx_dist_sample_full_filtered(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
+                                             int32_t* degrees_out, int64_t* offsets_out, int padding_mode,
+                                             int64_t default_neighbor_id, const glx_filter* filter, int64_t* nbr_out,
+                                             int64_t* eid_out, int64_t capacity, int ptr_kind, void* stream) {
+  return dist_sample_full_any(st, src, batch, max_limit, degrees_out, offsets_out, nbr_out, eid_out, capacity, true, ptr_kind,
+                              stream, filter, padding_mode, default_neighbor_id);
 }
 
 extern "C" int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
@@ -2530,6 +2606,240 @@ extern "C" int glx_dist_hot_ids(glx_dist_store* st, int64_t want, int64_t* ids_o
   GLX_HIP(hipMemcpyAsync(ids_out, fin_id.p, (size_t)take * 8, hipMemcpyDeviceToHost, s));
   GLX_HIP(hipStreamSynchronize(s));
   *n_out = take;
+  return GLX_OK;
+}
+
+namespace {
+// Collective on first use: every rank ends up holding the (id ascending, global in-degree) table of the destination
+// ids it owns -- the per-owner half of the unpartitioned storage's GetAllDstIds() / GetAllInDegrees()
+// (topo_statics.cc:32-69).
+int ensure_owner_table(glx_dist_store* st, hipStream_t s) {
+  if (st->own_M >= 0) return GLX_OK;
+  DstTotals t;
+  int rc = dst_totals(st, s, &t);
+  if (rc != GLX_OK) return rc;
+  st->own_id = t.own_id.as<int64_t>();
+  st->own_cnt = t.own_cnt.as<int64_t>();
+  t.own_id.p = nullptr;  // ownership moves to the store
+  t.own_cnt.p = nullptr;
+  st->own_M = t.M;
+  return GLX_OK;
+}
+
+__global__ void glx_dist_stitch_narrow_kernel(const int64_t* __restrict__ in, const int64_t* __restrict__ order, int64_t n,
+                                              int32_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[order[i]] = (int32_t)in[i];
+}
+
+__global__ void glx_dist_i64_to_f32_kernel(const int64_t* __restrict__ in, int64_t n, float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+}  // namespace
+
+// Collective.  GetDegree for DESTINATION ids across the shards (degree_getter.cc with node_from = kEdgeDst;
+// GraphStorage::GetInDegree, topo_statics.cc:62-69): the in-degree of an id is the sum over ALL shards of the edges
+// that point to it, held by the id's owner (llabs(id) % P); ids nobody points to answer 0.
+extern "C" int glx_dist_in_degrees(glx_dist_store* st, const int64_t* ids, int32_t n, int32_t* degrees_out, int ptr_kind,
+                                   void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(n >= 0 && (n == 0 || (ids && degrees_out)), "bad request");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  rc = ensure_owner_table(st, s);
+  if (rc != GLX_OK) return rc;
+  const int P = st->world;
+  const int64_t n1 = n > 0 ? n : 1;
+  GlxTemp d_ids, buck, ord, ids_in, cnt_in, cnt_b, d_out;
+  const int64_t* p_ids = ids;
+  int32_t* p_out = degrees_out;
+  if (ptr_kind == GLX_PTR_HOST) {
+    GLX_HIP(hipMalloc(&d_ids.p, (size_t)n1 * 8));
+    GLX_HIP(hipMalloc(&d_out.p, (size_t)n1 * 4));
+    if (n > 0) GLX_HIP(hipMemcpyAsync(d_ids.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    p_ids = d_ids.as<int64_t>();
+    p_out = d_out.as<int32_t>();
+  }
+  GLX_HIP(hipMalloc(&buck.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&ord.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&cnt_b.p, (size_t)n1 * 8));
+  rc = glx_partition(st->device, p_ids, n, P, buck.as<int64_t>(), ord.as<int64_t>(), st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  st->h_mat.resize((size_t)P * P);
+  rc = exchange_counts(st, st->d_vals, P, st->h_mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  Routing rt;
+  routing_from_matrix(st, P, &rt);
+  const int64_t m = rt.n_recv, m1 = m > 0 ? m : 1;
+  GLX_HIP(hipMalloc(&ids_in.p, (size_t)m1 * 8));
+  GLX_HIP(hipMalloc(&cnt_in.p, (size_t)m1 * 8));
+  GlxSeg out_seg{buck.p, ids_in.p, 8};
+  rc = st->comm->alltoallv(&out_seg, 1, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
+                           rt.recv_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  if (m > 0) {
+    glx_dist_total_of_kernel<<<(unsigned)((m + 255) / 256), 256, 0, s>>>(st->own_id, st->own_cnt, st->own_M,
+                                                                         ids_in.as<int64_t>(), m, cnt_in.as<int64_t>());
+  }
+  GlxSeg back_seg{cnt_in.p, cnt_b.p, 8};
+  rc = st->comm->alltoallv(&back_seg, 1, rt.recv_counts.data(), rt.recv_offs.data(), rt.send_counts.data(),
+                           rt.send_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  if (n > 0) {
+    glx_dist_stitch_narrow_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(cnt_b.as<int64_t>(), ord.as<int64_t>(), n, p_out);
+    GLX_HIP(hipGetLastError());
+    if (ptr_kind == GLX_PTR_HOST) GLX_HIP(hipMemcpyAsync(degrees_out, p_out, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  }
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
+}
+
+// Collective.  The candidate list of the negative samplers over the WHOLE edge type, on every rank
+// (random_negative_sampler.cc:30-63 / in_degree_negative_sampler.cc:29-135 draw from the storage's GetAllDstIds() /
+// GetAllInDegrees(); a shard's own storage only knows the destinations of its own edges): the owners' (id, global
+// in-degree) tables are gathered and merged, ids ascending -- the one order every shard count agrees on (a single
+// store's first-appearance order depends on edge insertion order, which shards do not share) -- and one alias table is
+// built over it.  The same table on every rank: glx_negative_sample on it draws exactly what an unpartitioned store
+// would draw from glx_negative_create(ids ascending, in-degrees).
+extern "C" int glx_dist_negative_create(glx_dist_store* st, int by_in_degree, void* stream, glx_negative** out) {
+  GLX_REQUIRE(st != nullptr && out != nullptr, "NULL argument");
+  *out = nullptr;
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = glx_stream(stream);
+  int rc = ensure_owner_table(st, s);
+  if (rc != GLX_OK) return rc;
+  const int P = st->world;
+  const int64_t M = st->own_M;
+  GLX_HIP(hipMemcpyAsync(st->d_vals, &M, 8, hipMemcpyHostToDevice, s));
+  std::vector<int64_t> sizes((size_t)P);
+  rc = exchange_counts(st, st->d_vals, 1, sizes.data(), s);
+  if (rc != GLX_OK) return rc;
+  std::vector<int64_t> offs((size_t)P + 1, 0), same((size_t)P, M), zero((size_t)P, 0);
+  for (int q = 0; q < P; ++q) offs[(size_t)q + 1] = offs[(size_t)q] + sizes[(size_t)q];
+  const size_t T = (size_t)offs[(size_t)P];
+  GLX_REQUIRE(T < (size_t)INT32_MAX, "more than 2^31 candidates");
+  GlxTemp all_id, all_cnt, s_id, s_cnt, w;
+  GLX_HIP(hipMalloc(&all_id.p, (T ? T : 1) * 8));
+  GLX_HIP(hipMalloc(&all_cnt.p, (T ? T : 1) * 8));
+  GlxSeg segs[2] = {{st->own_id, all_id.p, 8}, {st->own_cnt, all_cnt.p, 8}};
+  rc = st->comm->alltoallv(segs, 2, same.data(), zero.data(), sizes.data(), offs.data(), s);  // everyone gets every table
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(hipMalloc(&s_id.p, (T ? T : 1) * 8));
+  GLX_HIP(hipMalloc(&s_cnt.p, (T ? T : 1) * 8));
+  GLX_HIP(hipMalloc(&w.p, (T ? T : 1) * 4));
+  if (T > 0) {
+    // ascending as signed ids (rocPRIM orders signed keys as such)
+#define SORTN(tmp, bytes)                                                                                       \
+  rocprim::radix_sort_pairs(tmp, bytes, all_id.as<int64_t>(), s_id.as<int64_t>(), all_cnt.as<int64_t>(),        \
+                            s_cnt.as<int64_t>(), T, 0, 64, s)
+    GLX_ROCPRIM(SORTN);
+#undef SORTN
+    glx_dist_i64_to_f32_kernel<<<(unsigned)((T + 255) / 256), 256, 0, s>>>(s_cnt.as<int64_t>(), (int64_t)T, w.as<float>());
+    GLX_HIP(hipGetLastError());
+  }
+  rc = glx_negative_create(st->device, (int64_t)T, s_id.as<int64_t>(), by_in_degree ? w.as<float>() : nullptr, GLX_PTR_DEVICE,
+                           s, out);
+  if (rc != GLX_OK) return rc;
+  GLX_HIP(hipStreamSynchronize(s));
+  return GLX_OK;
+}
+
+// Collective for GLX_NEG_EXCLUDE_NEIGHBORS (InDegreeNegativeSampler, in_degree_negative_sampler.cc:29-135 behind
+// DistributeRunner): the exclusion set of a row is its source vertex's adjacency, which lives with the row's owner -- the
+// rows travel there (with their index in the request, the random stream they draw from), the owner samples from the
+// SAME candidate table every rank holds (glx_dist_negative_create) and the answers travel back.  The other modes need
+// nothing from another shard and run locally: what the caller gets is what an unpartitioned store with the same table
+// answers, for every shard count.  The store's graph shard needs glx_graph_enable_negative().
+extern "C" int glx_dist_negative_sample(glx_dist_store* st, const glx_negative* table, int exclude, const int64_t* src,
+                                        int32_t batch, int32_t count, int64_t default_neighbor_id, uint64_t seed,
+                                        uint64_t call_counter, int64_t* out, int ptr_kind, void* stream) {
+  int rc = check_store(st, ptr_kind);
+  if (rc != GLX_OK) return rc;
+  GLX_REQUIRE(table != nullptr, "table is NULL");
+  GLX_REQUIRE(exclude >= GLX_NEG_EXCLUDE_NONE && exclude <= GLX_NEG_EXCLUDE_BATCH, "unknown exclusion mode %d", exclude);
+  GLX_REQUIRE(batch >= 0 && count >= 0 && (int64_t)batch * count <= INT32_MAX, "bad batch / count");
+  if (exclude != GLX_NEG_EXCLUDE_NEIGHBORS || (st->world == 1 && st->shortcut)) {
+    return glx_negative_sample(table, exclude, st->graph, src, batch, count, default_neighbor_id, seed, call_counter, out,
+                               ptr_kind, stream);
+  }
+  GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
+  GLX_REQUIRE(batch == 0 || count == 0 || (src && out), "NULL data pointer");
+  GlxDeviceGuard guard(st->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+  hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  const int P = st->world;
+  const int64_t n = batch, n1 = n > 0 ? n : 1, k = count, k1 = k > 0 ? k : 1;
+  GlxTemp d_src, d_out, buck, ord, back, ids_in, rows_in, loc;
+  const int64_t* p_src = src;
+  int64_t* p_out = out;
+  if (ptr_kind == GLX_PTR_HOST) {
+    GLX_HIP(hipMalloc(&d_src.p, (size_t)n1 * 8));
+    GLX_HIP(hipMalloc(&d_out.p, (size_t)n1 * k1 * 8));
+    if (n > 0) GLX_HIP(hipMemcpyAsync(d_src.p, src, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    p_src = d_src.as<int64_t>();
+    p_out = d_out.as<int64_t>();
+  }
+  GLX_HIP(hipMalloc(&buck.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&ord.p, (size_t)n1 * 8));
+  GLX_HIP(hipMalloc(&back.p, (size_t)n1 * k1 * 8));
+  rc = glx_partition(st->device, p_src, n, P, buck.as<int64_t>(), ord.as<int64_t>(), st->d_vals, s);
+  if (rc != GLX_OK) return rc;
+  constexpr int kNegParams = 4;
+  ReqParams mine;
+  memset(&mine, 0, sizeof(mine));
+  mine.v[0] = (int64_t)seed;
+  mine.v[1] = (int64_t)call_counter;
+  mine.v[2] = count;
+  mine.v[3] = default_neighbor_id;
+  glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P, mine, kNegParams);
+  const int nvals = P + kNegParams;
+  st->h_mat.resize((size_t)P * nvals);
+  rc = exchange_counts(st, st->d_vals, nvals, st->h_mat.data(), s);
+  if (rc != GLX_OK) return rc;
+  Routing rt;
+  routing_from_matrix(st, nvals, &rt);
+  for (int q = 0; q < P; ++q) {
+    GLX_REQUIRE(st->h_mat[(size_t)q * nvals + P + 2] == count, "rank %d asks for %lld negatives per row, this rank for %d", q,
+                (long long)st->h_mat[(size_t)q * nvals + P + 2], count);
+  }
+  const int64_t m = rt.n_recv, m1 = m > 0 ? m : 1;
+  GLX_REQUIRE(m * k <= INT32_MAX, "more than 2^31 answers at one shard");
+  GLX_HIP(hipMalloc(&ids_in.p, (size_t)m1 * 8));
+  GLX_HIP(hipMalloc(&rows_in.p, (size_t)m1 * 8));
+  GLX_HIP(hipMalloc(&loc.p, (size_t)m1 * k1 * 8));
+  GlxSeg out_segs[2] = {{buck.p, ids_in.p, 8}, {ord.p, rows_in.p, 8}};
+  rc = st->comm->alltoallv(out_segs, 2, rt.send_counts.data(), rt.send_offs.data(), rt.recv_counts.data(),
+                           rt.recv_offs.data(), s);
+  if (rc != GLX_OK) return rc;
+  for (int q = 0; q < P && k > 0; ++q) {  // every requester's rows with ITS seed / call counter / default id
+    const int64_t begin = rt.recv_offs[q], cnt = rt.recv_offs[q + 1] - begin;
+    if (cnt == 0) continue;
+    const int64_t* pq = &st->h_mat[(size_t)q * nvals + P];
+    rc = glx_negative_sample_rows_device(table, st->graph, ids_in.as<int64_t>() + begin, rows_in.as<int64_t>() + begin,
+                                         (int32_t)cnt, count, pq[3], (uint64_t)pq[0], (uint64_t)pq[1],
+                                         loc.as<int64_t>() + begin * k, s);
+    if (rc != GLX_OK) return rc;
+  }
+  GlxSeg back_seg{loc.p, back.p, (size_t)k1 * 8};
+  if (k > 0) {
+    rc = st->comm->alltoallv(&back_seg, 1, rt.recv_counts.data(), rt.recv_offs.data(), rt.send_counts.data(),
+                             rt.send_offs.data(), s);
+    if (rc != GLX_OK) return rc;
+  }
+  if (n > 0 && k > 0) {
+    const int64_t total = n * k;
+    glx_dist_stitch2_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(back.as<int64_t>(), back.as<int64_t>(),
+                                                                            ord.as<int64_t>(), n, count, p_out, p_out);
+    GLX_HIP(hipGetLastError());
+    if (ptr_kind == GLX_PTR_HOST) GLX_HIP(hipMemcpyAsync(out, p_out, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+  }
+  GLX_HIP(hipStreamSynchronize(s));
   return GLX_OK;
 }
 

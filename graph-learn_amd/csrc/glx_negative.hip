@@ -91,6 +91,9 @@ struct NegArgs {
   const int64_t* nbr_sorted;
   // GLX_NEG_EXCLUDE_BATCH
   const int64_t* batch_sorted;
+  // rows of a partitioned request (glx_dist_negative_sample): row r draws from the stream of rng_rows[r], its index in
+  // the ORIGINAL request; nullptr = r itself
+  const int64_t* rng_rows;
 };
 
 // One group of W lanes (W = 8, 16, 32 or 64: the smallest that covers `count`, so a
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(256) void glx_negative_kernel(NegArgs a) {
   }
   const int32_t n = a.count;
   const uint64_t group_mask = W == 64 ? ~0ull : (((1ull << W) - 1ull) << (grp * W));
+  const uint32_t stream_row = (live && a.rng_rows) ? (uint32_t)a.rng_rows[row] : (uint32_t)row;
   int32_t taken = live ? 0 : n;
   // every lane of the wavefront runs the same trip count; finished groups just idle
   for (int32_t blk = 0; blk < 4; ++blk) {
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void glx_negative_kernel(NegArgs a) {
       bool ok = false;
       int64_t item = 0;
       if (taken < n && j < n) {
-        const uint64_t u = glx_draw64(a.seed, a.cc, (uint32_t)row, (uint32_t)(blk * n + j));
+        const uint64_t u = glx_draw64(a.seed, a.cc, stream_row, (uint32_t)(blk * n + j));
         const int64_t idx = a.table ? (int64_t)glx_alias_pick(u, a.num_ids, a.table)
                                     : (int64_t)glx_bounded(u, (uint64_t)a.num_ids);
         item = a.ids[idx];
@@ -366,6 +370,38 @@ extern "C" int glx_graph_enable_negative(glx_graph* g, void* stream) {
   g->slot_sorted = slots;
   own.p = nullptr;
   g->nbr_sorted = sorted;
+  return GLX_OK;
+}
+
+// glx_dist.hip: strict in-degree sampling for the rows an owner received (device pointers; rng_rows = their indices in
+// the requester's request).  Device already selected by the caller.
+int glx_negative_sample_rows_device(const glx_negative* t, const glx_graph* g, const int64_t* src, const int64_t* rng_rows,
+                                    int32_t batch, int32_t count, int64_t default_neighbor_id, uint64_t seed,
+                                    uint64_t call_counter, int64_t* out, hipStream_t s) {
+  GLX_REQUIRE(t != nullptr && g != nullptr, "NULL table / graph");
+  GLX_REQUIRE(g->nbr_sorted != nullptr, "call glx_graph_enable_negative(graph) first");
+  const int64_t total = (int64_t)batch * count;
+  if (total == 0) return GLX_OK;
+  if (t->num_ids == 0) {
+    glx_neg_fill_kernel<<<grid_for(total), 256, 0, s>>>(out, total, default_neighbor_id);
+  } else {
+    NegArgs a{};
+    a.ids = t->ids;
+    a.table = t->table;
+    a.num_ids = t->num_ids;
+    a.src = src;
+    a.batch = batch;
+    a.count = count;
+    a.seed = seed;
+    a.cc = call_counter;
+    a.out = out;
+    a.map = g->map();
+    a.row_ptr = g->row_ptr;
+    a.nbr_sorted = g->nbr_sorted;
+    a.rng_rows = rng_rows;
+    launch_negative<GLX_NEG_EXCLUDE_NEIGHBORS>(a, s);
+  }
+  GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
 

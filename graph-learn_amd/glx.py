@@ -51,7 +51,8 @@ EXPORTS = [
     "glx_comm_unique_id", "glx_comm_init_rccl", "glx_comm_init_local", "glx_comm_init_callbacks", "glx_comm_destroy",
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_store_set_graph_replica",
-    "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full", "glx_dist_random_walk",
+    "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full", "glx_dist_sample_full_filtered",
+    "glx_dist_in_degrees", "glx_dist_negative_create", "glx_dist_negative_sample", "glx_dist_random_walk",
     "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_partial", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_aggregate_end_range", "glx_dist_lookup",
@@ -187,6 +188,10 @@ def lib():
         L.glx_dist_random_walk.argtypes = [vp, vp, i32, i32, f32, f32, i64, u64, u64, vp, ci, vp]
         L.glx_dist_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
         L.glx_dist_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i64, ci, vp]
+        L.glx_dist_sample_full_filtered.argtypes = [vp, vp, i32, i32, vp, vp, ci, i64, vp, vp, vp, i64, ci, vp]
+        L.glx_dist_in_degrees.argtypes = [vp, vp, i32, vp, ci, vp]
+        L.glx_dist_negative_create.argtypes = [vp, ci, vp, ctypes.POINTER(vp)]
+        L.glx_dist_negative_sample.argtypes = [vp, vp, ci, vp, i32, i32, i64, u64, u64, vp, ci, vp]
         L.glx_dist_last_sample_rows.argtypes = [vp, vp, vp, vp]
         L.glx_dist_hot_ids.argtypes = [vp, i64, vp, ctypes.POINTER(i64), vp]
         L.glx_dist_enable_in_degree.argtypes = [vp, vp, vp]
@@ -871,9 +876,11 @@ class DistStore:
             self.set_graph_replica(g)
         return g
 
-    def sample_full(self, src, max_limit=0):
+    def sample_full(self, src, max_limit=0, filter_type=FILTER_NONE, filter_field=FILTER_FIELD_NONE, values=None,
+                    padding_mode=PAD_CIRCULAR, default_neighbor_id=0, default_timestamp=-1):
         """Collective FullSampler over the shards: -> (degrees[batch] int32, nbr[total], eid[total]) for this rank's
-        rows, as Graph.sample_full answers on one store (numpy in -> numpy out, torch CUDA in -> torch CUDA out)."""
+        rows, as Graph.sample_full / sample_full_filtered answer on one store (numpy in -> numpy out, torch CUDA in ->
+        torch CUDA out).  With a filter: values[batch], same kind as src; every rank passes the same kind of filter."""
         batch = int(src.shape[0])
         if _is_torch(src):
             import torch
@@ -888,9 +895,52 @@ class DistStore:
                                                 kind, stream))
         total = int(off[-1])
         nbr, eid = mk(total, i64t), mk(total, i64t)
+        if filter_type != FILTER_NONE:
+            flt = Filter(filter_type, filter_field, _ptr(values)[0] if batch else None, 0, default_timestamp)
+            _check(lib().glx_dist_sample_full_filtered(self._h, ps, batch, max_limit, _ptr(deg)[0] if batch else None,
+                                                       _ptr(off)[0], padding_mode, default_neighbor_id, ctypes.byref(flt),
+                                                       _ptr(nbr)[0] if total else None, _ptr(eid)[0] if total else None, total,
+                                                       kind, stream))
+            return deg, nbr, eid
         _check(lib().glx_dist_sample_full(self._h, ps, batch, max_limit, _ptr(deg)[0] if batch else None, _ptr(off)[0],
                                           _ptr(nbr)[0] if total else None, _ptr(eid)[0] if total else None, total, kind, stream))
         return deg, nbr, eid
+
+    def in_degrees(self, ids):
+        """Collective GetDegree for destination ids: in-degrees summed over all shards (int32; numpy or torch CUDA)."""
+        n = int(ids.shape[0])
+        if _is_torch(ids):
+            import torch
+            out, kind = torch.empty(n, dtype=torch.int32, device=ids.device), PTR_DEVICE
+        else:
+            out, kind = np.empty(n, np.int32), PTR_HOST
+        _check(lib().glx_dist_in_degrees(self._h, _ptr(ids)[0] if n else None, n, _ptr(out)[0] if n else None, kind,
+                                         _stream(kind, self.comm.device)))
+        return out
+
+    def negative_table(self, by_in_degree=False):
+        """Collective: the negative samplers' candidate list over the WHOLE edge type (every shard's destination ids,
+        ascending, uniform or weighted by global in-degree) -> a Negative, identical on every rank."""
+        t = Negative.__new__(Negative)
+        h = ctypes.c_void_p()
+        _check(lib().glx_dist_negative_create(self._h, 1 if by_in_degree else 0, _stream(PTR_DEVICE, self.comm.device),
+                                              ctypes.byref(h)))
+        t._h, t.device = h, self.comm.device
+        t._info()
+        return t
+
+    def negative_sample(self, table, src, count, exclude=NEG_EXCLUDE_NONE, default_neighbor_id=0, seed=0, call_counter=0):
+        """glx_negative_sample across the shards (collective for NEG_EXCLUDE_NEIGHBORS): -> out[batch, count]."""
+        batch = int(src.shape[0])
+        if _is_torch(src):
+            import torch
+            out, kind = torch.empty((batch, count), dtype=torch.int64, device=src.device), PTR_DEVICE
+        else:
+            out, kind = np.empty((batch, count), np.int64), PTR_HOST
+        _check(lib().glx_dist_negative_sample(self._h, table._h, exclude, _ptr(src)[0] if batch else None, batch, count,
+                                              default_neighbor_id, seed, call_counter,
+                                              _ptr(out)[0] if batch * count else None, kind, _stream(kind, self.comm.device)))
+        return out
 
     def random_walk(self, seeds, walk_len, p=1.0, q=1.0, default_neighbor_id=0, seed=0, call_counter=0):
         """Collective DeepWalk over the shards: -> walks[batch, walk_len], Graph.random_walk's draws (p = q = 1 only)."""

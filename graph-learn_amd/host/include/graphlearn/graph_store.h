@@ -186,6 +186,7 @@ public:
   const glx_features* Device() const { return dev_; }
   int64_t GetNodeCount() const { return (int64_t)ids_.size(); }
   const std::vector<int64_t>& Ids() const { return ids_; }  // NodeStorage::GetIds, insertion order
+  const std::vector<float>& Weights() const { return weights_; }  // NodeStorage::GetWeights (weighted types)
   // Candidate list of NodeWeightNegativeSampler: this type's ids weighted by node weight.
   Status Negative(const glx_negative** out);
 

@@ -83,6 +83,11 @@ public:
   // Device-resident distributed stores of one edge / node type, created on first use.
   Status EdgeStore(const std::string& edge_type, glx_dist_store** out);
   Status NodeStore(const std::string& node_type, glx_dist_store** out);
+  // Collective on first use.  The negative samplers' candidate list over the WHOLE type, the same on every server:
+  // an edge type's destination ids of all shards (ascending; uniform or weighted by the in-degree summed over all
+  // shards: glx_dist_negative_create), a node type's ids and node weights of all shards (ascending).  Owned by the Env.
+  Status EdgeNegativeTable(const std::string& edge_type, bool by_in_degree, const glx_negative** out);
+  Status NodeNegativeTable(const std::string& node_type, const glx_negative** out);
   // A distributed store keeps per-call state (request / receive arenas, exchange counters, halo slots) and every
   // partitioned request is a sequence of collectives: two requests of one server must not interleave, and all
   // servers must issue their requests in the same order.  The runners hold this lock for the whole request, so the
@@ -101,6 +106,7 @@ private:
   std::mutex run_mtx_;
   std::unordered_map<std::string, glx_dist_store*> edge_stores_, node_stores_;
   std::unordered_map<std::string, glx_graph*> graph_replicas_;  // built by ReplicateHotRows
+  std::unordered_map<std::string, glx_negative*> negative_tables_;
   std::atomic<uint64_t> call_counter_{0};
 };
 

@@ -11,8 +11,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -114,6 +116,76 @@ Env::~Env() {
   for (auto& kv : edge_stores_) glx_dist_store_destroy(kv.second);
   for (auto& kv : node_stores_) glx_dist_store_destroy(kv.second);
   for (auto& kv : graph_replicas_) glx_graph_destroy(kv.second);  // after the stores that borrowed them
+  for (auto& kv : negative_tables_) glx_negative_destroy(kv.second);
+}
+
+Status Env::EdgeNegativeTable(const std::string& edge_type, bool by_in_degree, const glx_negative** out) {
+  glx_dist_store* st = nullptr;
+  Status s = EdgeStore(edge_type, &st);
+  if (!s.ok()) return s;
+  std::lock_guard<std::mutex> lock(mtx_);
+  const std::string key = (by_in_degree ? "e/indeg/" : "e/uniform/") + edge_type;
+  auto it = negative_tables_.find(key);
+  if (it == negative_tables_.end()) {
+    glx_negative* t = nullptr;
+    int rc = glx_dist_negative_create(st, by_in_degree ? 1 : 0, nullptr, &t);  // collective
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    it = negative_tables_.emplace(key, t).first;
+  }
+  *out = it->second;
+  return Status::OK();
+}
+
+Status Env::NodeNegativeTable(const std::string& node_type, const glx_negative** out) {
+  std::lock_guard<std::mutex> lock(mtx_);
+  const std::string key = "n/" + node_type;
+  auto it = negative_tables_.find(key);
+  if (it == negative_tables_.end()) {
+    Noder* noder = store_->GetNoder(node_type);
+    if (!noder->GetSideInfo()->IsWeighted()) return error::InvalidArgument("node type '" + node_type + "' has no weights");
+    // every server's (id, weight) list to every server: the counts first, then the lists (each server sends its own
+    // list to all), merged by ascending id -- NodeStorage::GetIds() / GetWeights() of the unpartitioned storage up to order
+    const std::vector<int64_t>& ids = noder->Ids();
+    const std::vector<float>& weights = noder->Weights();
+    int64_t n = (int64_t)ids.size();
+    const size_t P = (size_t)server_count_;
+    std::vector<int64_t> counts(P);
+    int rc = glx_comm_allgather_i64(comm_, &n, 1, counts.data(), GLX_PTR_HOST, nullptr);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    struct Rec { int64_t id; int64_t w; };
+    std::vector<Rec> send(P * (size_t)n);
+    for (size_t p = 0; p < P; ++p) {
+      for (int64_t i = 0; i < n; ++i) {
+        int32_t bits = 0;
+        memcpy(&bits, &weights[(size_t)i], 4);
+        send[p * (size_t)n + (size_t)i] = {ids[(size_t)i], (int64_t)bits};
+      }
+    }
+    int64_t total = 0;
+    for (int64_t c : counts) total += c;
+    std::vector<Rec> recv((size_t)(total > 0 ? total : 1));
+    std::vector<int64_t> send_counts(P, n);
+    rc = glx_exchange_v(comm_, send.data(), send_counts.data(), recv.data(), counts.data(), (int64_t)sizeof(Rec), GLX_PTR_HOST,
+                        nullptr);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    recv.resize((size_t)total);
+    std::sort(recv.begin(), recv.end(), [](const Rec& a, const Rec& b) { return a.id < b.id; });
+    std::vector<int64_t> all_ids((size_t)total);
+    std::vector<float> all_w((size_t)total);
+    for (size_t i = 0; i < (size_t)total; ++i) {
+      all_ids[i] = recv[i].id;
+      const int32_t bits = (int32_t)recv[i].w;
+      memcpy(&all_w[i], &bits, 4);
+    }
+    int device = 0;
+    glx_comm_info(comm_, nullptr, nullptr, &device, nullptr);
+    glx_negative* t = nullptr;
+    rc = glx_negative_create(device, total, all_ids.data(), all_w.data(), GLX_PTR_HOST, nullptr, &t);
+    if (rc != GLX_OK) return error::FromGlx(rc);
+    it = negative_tables_.emplace(key, t).first;
+  }
+  *out = it->second;
+  return Status::OK();
 }
 
 Status Env::EdgeStore(const std::string& edge_type, glx_dist_store** out) {
@@ -214,8 +286,10 @@ int AggregatorIdOf(const std::string& name) {
 
 // FullSampler's sparse response across shards (full_sampler.cc:28-97 behind DistributeRunner): sizes, then values.
 Status RunFullSampling(Env* env, const SamplingRequest* req, SamplingResponse* res) {
-  if (req->HasFilter()) return error::Unimplemented("FullSampler with a filter is not served across shards");
   const int32_t batch_size = req->BatchSize();
+  if (req->HasFilter() && batch_size > 0 && !req->GetFilterValues()) {
+    return error::InvalidArgument("the request has a filter but not one filter value per src id");
+  }
   const int32_t max_limit = req->NeighborCount();
   glx_dist_store* st = nullptr;
   Status s = env->EdgeStore(req->Type(), &st);
@@ -230,13 +304,70 @@ Status RunFullSampling(Env* env, const SamplingRequest* req, SamplingResponse* r
   res->InitEdgeIds();
   res->ResizeDense();  // sizes both tensors to the sum of the counts
   // collective even when this server's rows are all empty: its peers may have values to fetch from it
+  if (req->HasFilter()) {  // full_sampler.cc:66-84 on the owners: the filter values travel with their rows
+    glx_filter filter;
+    filter.type = (int32_t)req->GetFilterType();
+    filter.field = (int32_t)req->GetFilterField();
+    filter.values = req->GetFilterValues();
+    filter.retry_times = 0;
+    filter.default_timestamp = GLOBAL_FLAG(DefaultTimestamp);
+    rc = glx_dist_sample_full_filtered(st, req->GetSrcIds(), batch_size, max_limit, degrees.data(), offsets.data(),
+                                       GLOBAL_FLAG(PaddingMode), GLOBAL_FLAG(DefaultNeighborId), &filter,
+                                       res->GetNeighborIds(), res->GetEdgeIds(), offsets[(size_t)batch_size], GLX_PTR_HOST,
+                                       nullptr);
+    return error::FromGlx(rc);
+  }
   rc = glx_dist_sample_full(st, req->GetSrcIds(), batch_size, max_limit, degrees.data(), offsets.data(),
                             res->GetNeighborIds(), res->GetEdgeIds(), offsets[(size_t)batch_size], GLX_PTR_HOST, nullptr);
   return error::FromGlx(rc);
 }
 
+// The negative samplers across shards (random_negative_sampler.cc:30-63, in_degree_negative_sampler.cc:29-135,
+// node_weight_negative_sampler.cc:29-110 behind DistributeRunner): candidates = the WHOLE type's list (the same table on
+// every server), strict in-degree sampling served by the owners of the source ids.
+Status RunNegativeSampling(Env* env, const SamplingRequest* req, SamplingResponse* res) {
+  const std::string& name = req->Strategy();
+  const int32_t count = req->NeighborCount(), batch_size = req->BatchSize();
+  res->SetShape(batch_size, count);
+  res->InitEdgeIds();
+  res->InitNeighborIds();
+  const glx_negative* table = nullptr;
+  glx_dist_store* st = nullptr;
+  int exclude = GLX_NEG_EXCLUDE_NONE;
+  Status s;
+  if (name == "NodeWeightNegativeSampler") {
+    exclude = GLX_NEG_EXCLUDE_BATCH;
+    s = env->NodeNegativeTable(req->Type(), &table);
+  } else {
+    const bool by_in_degree = name != "RandomNegativeSampler";
+    if (name == "InDegreeNegativeSampler") {
+      exclude = GLX_NEG_EXCLUDE_NEIGHBORS;
+      const glx_negative* local = nullptr;  // builds the shard's sorted neighbour lists (the exclusion test)
+      s = env->Store()->GetGraph(req->Type())->Negative(true, true, &local);
+      if (!s.ok()) return s;
+    }
+    s = env->EdgeNegativeTable(req->Type(), by_in_degree, &table);
+    if (s.ok()) s = env->EdgeStore(req->Type(), &st);
+  }
+  if (!s.ok()) return s;
+  res->ResizeNeighborIds();
+  const uint64_t cc = req->HasCallCounter() ? (uint64_t)req->CallCounter() : env->NextCallCounter();
+  int rc;
+  if (st != nullptr) {
+    rc = glx_dist_negative_sample(st, table, exclude, req->GetSrcIds(), batch_size, count, GLOBAL_FLAG(DefaultNeighborId),
+                                  (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, res->GetNeighborIds(), GLX_PTR_HOST, nullptr);
+  } else {  // node-weight sampling needs nothing from another shard once the table is global
+    rc = glx_negative_sample(table, exclude, nullptr, req->GetSrcIds(), batch_size, count, GLOBAL_FLAG(DefaultNeighborId),
+                             (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, res->GetNeighborIds(), GLX_PTR_HOST, nullptr);
+  }
+  return error::FromGlx(rc);
+}
+
 Status RunSampling(Env* env, const SamplingRequest* req, SamplingResponse* res) {
   if (req->Strategy() == "FullSampler") return RunFullSampling(env, req, res);
+  if (req->Strategy().find("NegativeSampler") != std::string::npos && req->Strategy() != "ConditionalNegativeSampler") {
+    return RunNegativeSampling(env, req, res);
+  }
   const int sampler = SamplerIdOf(req->Strategy());
   if (sampler < 0) {
     return error::Unimplemented("'" + req->Strategy() + "' is not served across shards (dense neighbour samplers are)");
@@ -322,15 +453,17 @@ Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpRespon
   if (auto* dreq = dynamic_cast<const GetDegreeRequest*>(req)) {
     auto* dres = dynamic_cast<GetDegreeResponse*>(res);
     if (!dres) return error::InvalidArgument("a GetDegreeRequest needs a GetDegreeResponse");
-    if (dreq->GetNodeFrom() != kEdgeSrc) {
-      return error::Unimplemented("in-degrees of destination ids are not served across shards (out-degrees are)");
-    }
-    // out-degrees live with the rows: the sizes half of the partitioned FullSampler, without a limit
     const int32_t n = dreq->Size();
     dres->InitDegrees(n);
     glx_dist_store* st = nullptr;
     Status s = env->EdgeStore(dreq->EdgeType(), &st);
     if (!s.ok()) return s;
+    if (dreq->GetNodeFrom() != kEdgeSrc) {
+      // in-degrees are sums over ALL shards, held by the ids' owners (glx_dist_in_degrees)
+      int rc = glx_dist_in_degrees(st, dreq->NodeIds(), n, dres->MutableDegrees(), GLX_PTR_HOST, nullptr);
+      return error::FromGlx(rc);
+    }
+    // out-degrees live with the rows: the sizes half of the partitioned FullSampler, without a limit
     std::vector<int64_t> offsets((size_t)n + 1, 0);
     int rc = glx_dist_sample_full_sizes(st, dreq->NodeIds(), n, 0, dres->MutableDegrees(), offsets.data(), GLX_PTR_HOST, nullptr);
     return error::FromGlx(rc);

@@ -531,6 +531,31 @@ GLX_API int glx_dist_sample_full_sizes(glx_dist_store* st, const int64_t* src, i
 GLX_API int glx_dist_sample_full(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
                                  int32_t* degrees_out, int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out,
                                  int64_t capacity, int ptr_kind, void* stream);
+/* glx_dist_sample_full with a filter (full_sampler.cc:66-84 behind DistributeRunner): every row's filter value travels
+ * with its id, the owners answer with glx_sample_full_filtered -- same sizes as without a filter, reserved neighbours
+ * padded up to them, rows whose neighbours all hit default-filled.  Every rank passes a filter of the same kind (or none). */
+GLX_API int glx_dist_sample_full_filtered(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit,
+                                          int32_t* degrees_out, int64_t* offsets_out, int padding_mode,
+                                          int64_t default_neighbor_id, const glx_filter* filter, int64_t* nbr_out,
+                                          int64_t* eid_out, int64_t capacity, int ptr_kind, void* stream);
+/* Collective.  GetDegree for DESTINATION ids over the shards (GraphStorage::GetInDegree, topo_statics.cc:62-69;
+ * degree_getter.cc): degrees_out[n] = edges pointing to ids[i] summed over ALL shards (held by the id's owner,
+ * llabs(id) % P, in a table built collectively on first use); ids nobody points to: 0. */
+GLX_API int glx_dist_in_degrees(glx_dist_store* st, const int64_t* ids, int32_t n, int32_t* degrees_out, int ptr_kind,
+                                void* stream);
+/* Collective.  The negative samplers' candidate list over the WHOLE edge type on every rank
+ * (random_negative_sampler.cc:30-63, in_degree_negative_sampler.cc:29-135: GetAllDstIds() / GetAllInDegrees() of the
+ * unpartitioned storage): every destination id of any shard, ids ascending, uniform (by_in_degree = 0) or weighted by
+ * the in-degree summed over all shards.  The result is an ordinary glx_negative, identical on every rank and equal to
+ * glx_negative_create(ids ascending, global in-degrees) on an unpartitioned store; destroy with glx_negative_destroy. */
+GLX_API int glx_dist_negative_create(glx_dist_store* st, int by_in_degree, void* stream, glx_negative** out);
+/* glx_negative_sample across the shards.  GLX_NEG_EXCLUDE_NEIGHBORS is collective: the rows travel to the owners of their
+ * source ids (whose adjacency is the exclusion set; the shard needs glx_graph_enable_negative) and draw there from their
+ * ORIGINAL row's random stream; the other modes run locally.  Every rank passes the same `table` contents and `count`;
+ * answers equal the unpartitioned glx_negative_sample on that table for every shard count. */
+GLX_API int glx_dist_negative_sample(glx_dist_store* st, const glx_negative* table, int exclude, const int64_t* src,
+                                     int32_t batch, int32_t count, int64_t default_neighbor_id, uint64_t seed,
+                                     uint64_t call_counter, int64_t* out, int ptr_kind, void* stream);
 /* Collective.  DeepWalk (random_walk.cc:168-190; p = q = 1 as RandomWalkRequest::IsDeepWalk decides) across the shards,
  * glx_random_walk's layout and draws: step t is one partitioned RandomSampler request with neighbor_count 1 and call
  * counter call_counter + t, walker i drawing from stream i.  node2vec (p, q != 1) needs the previous vertex's

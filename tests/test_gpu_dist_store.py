@@ -774,6 +774,91 @@ def test_dist_full_sampler_equals_unpartitioned(world, P):
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_dist_filtered_full_sampler_equals_unpartitioned(world, P, monkeypatch):
+    """FullSampler with an id filter through the shards (full_sampler.cc:66-84 behind DistributeRunner): the filter
+    values travel with their rows, the owners pad the reserved neighbours up to the unfiltered sizes."""
+    monkeypatch.setenv("GLX_DIST_NO_SHORTCUT", "1")
+    whole, dev = world["whole"], world["dev"]
+    gs, _ = world["shards"][P]
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        src = _requests(r, dev, n=0 if (P > 1 and r == 1) else 1200)[: (0 if (P > 1 and r == 1) else None)]
+        rng = np.random.default_rng(17 + r)
+        # a value that IS a neighbour of the row for half of the rows, a random id for the rest
+        d0, n0, _ = whole.sample_full(src, 1)
+        first = torch.zeros(src.shape[0], dtype=torch.int64, device=dev)
+        if src.shape[0]:
+            off = torch.cumsum(d0.to(torch.int64), 0) - d0.to(torch.int64)
+            has = d0 > 0
+            first[has] = n0[off[has]]
+        rnd = torch.from_numpy(rng.integers(0, V, src.shape[0]).astype(np.int64)).to(dev)
+        vals = torch.where(torch.arange(src.shape[0], device=dev) % 2 == 0, first, rnd)
+        for limit in (0, 4):
+            for pad in (glx.PAD_CIRCULAR, glx.PAD_REPLICATE):
+                got = st.sample_full(src, limit, filter_type=glx.FILTER_EQUAL, filter_field=glx.FILTER_FIELD_ID, values=vals,
+                                     padding_mode=pad, default_neighbor_id=-9)
+                want = whole.sample_full_filtered(src, limit, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, padding_mode=pad,
+                                                  default_neighbor_id=-9)
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b), (limit, pad, r)
+        # host pointers (the C++ runner's boundary)
+        hg = st.sample_full(src.cpu().numpy(), 4, filter_type=glx.FILTER_EQUAL, filter_field=glx.FILTER_FIELD_ID,
+                            values=vals.cpu().numpy(), default_neighbor_id=-9)
+        want = whole.sample_full_filtered(src, 4, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals, default_neighbor_id=-9)
+        for a, b in zip(hg, want):
+            assert np.array_equal(a, b.cpu().numpy()), (r, "host")
+    _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_dist_in_degrees_and_global_negative_samplers(world, P, monkeypatch):
+    """GetDegree for destination ids and the negative samplers over the shards: in-degrees are sums over ALL shards; the
+    candidate list is the whole edge type's (every shard's destination ids, ascending, global in-degrees) on every rank,
+    and every mode draws what an unpartitioned store draws from that same table -- for every shard count."""
+    monkeypatch.setenv("GLX_DIST_NO_SHORTCUT", "1")
+    whole, dev, col = world["whole"], world["dev"], world["col"]
+    gs, _ = world["shards"][P]
+    indeg = world["indeg"]
+    cand = np.flatnonzero(indeg > 0).astype(np.int64)  # ascending
+    whole.enable_negative()
+    ref_u = glx.Negative(torch.from_numpy(cand).to(dev))
+    ref_w = glx.Negative(torch.from_numpy(cand).to(dev), torch.from_numpy(indeg[cand].astype(np.float32)).to(dev))
+
+    def body(r, comm):
+        gs[r].enable_negative()
+        st = glx.DistStore(comm, graph=gs[r])
+        rng = np.random.default_rng(31 + r)
+        ids = torch.from_numpy(np.concatenate([rng.integers(0, V, 700), [-4, V + 9]]).astype(np.int64)).to(dev)
+        ids = ids[: (0 if (P > 1 and r == 1) else None)]
+        want = torch.from_numpy(np.where((ids.cpu().numpy() >= 0) & (ids.cpu().numpy() < V),
+                                         indeg[np.clip(ids.cpu().numpy(), 0, V - 1)], 0).astype(np.int32)).to(dev)
+        assert torch.equal(st.in_degrees(ids), want), r
+        assert np.array_equal(st.in_degrees(ids.cpu().numpy()), want.cpu().numpy()), (r, "host")
+        tu, tw = st.negative_table(False), st.negative_table(True)
+        for t, ref in ((tu, ref_u), (tw, ref_w)):
+            a, b = t.export(), ref.export()
+            assert np.array_equal(a[0], b[0]), r
+            if ref.weighted:
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2]), r
+        src = _requests(r, dev, n=0 if (P > 1 and r == 1) else 900)[: (0 if (P > 1 and r == 1) else None)]
+        for t, ref in ((tu, ref_u), (tw, ref_w)):
+            for mode in (glx.NEG_EXCLUDE_NONE, glx.NEG_EXCLUDE_NEIGHBORS, glx.NEG_EXCLUDE_BATCH):
+                for count in (5, 20):
+                    got = st.negative_sample(t, src, count, exclude=mode, default_neighbor_id=-1, seed=9, call_counter=100 + r)
+                    exp = ref.sample(src, count, exclude=mode, graph=whole, default_neighbor_id=-1, seed=9,
+                                     call_counter=100 + r)
+                    assert torch.equal(got, exp), (r, mode, count, ref.weighted)
+        hg = st.negative_sample(tw, src.cpu().numpy(), 7, exclude=glx.NEG_EXCLUDE_NEIGHBORS, seed=3, call_counter=5)
+        exp = ref_w.sample(src, 7, exclude=glx.NEG_EXCLUDE_NEIGHBORS, graph=whole, seed=3, call_counter=5)
+        assert np.array_equal(hg, exp.cpu().numpy()), (r, "host")
+        tu.close()
+        tw.close()
+        st.close()
+    _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
 def test_dist_deepwalk_equals_unpartitioned(world, P):
     """DeepWalk across the shards = one partitioned RandomSampler request per step: the single store's walks, vertex
     for vertex (dead ends continue from the default id, as there); node2vec is refused, on every rank alike."""
