@@ -600,6 +600,71 @@ __global__ void glx_dist_walk_column_kernel(const int64_t* __restrict__ step, in
   if (i < n) walks[i * walk_len + t] = step[i];
 }
 
+// node2vec across shards (glx_dist_random_walk): the owner's half -- slot x of request row r's answer carries, in place of
+// its edge id, the weight of that edge (float bits; default_weight on an unweighted edge type).  One wave per row.
+__global__ __launch_bounds__(256) void glx_dist_slot_weights_kernel(GlxIdMap map, const int64_t* __restrict__ row_ptr,
+                                                                    const float* __restrict__ weight,
+                                                                    const int64_t* __restrict__ ids,
+                                                                    const int64_t* __restrict__ off, int64_t m,
+                                                                    float default_weight, int64_t* __restrict__ out) {
+  const int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (r >= m) return;
+  const int64_t o = off[r], d = off[r + 1] - o;
+  if (d == 0) return;
+  const int64_t row = glx_row_of(map, ids[r]);
+  const int64_t s = row >= 0 ? row_ptr[row] : 0;
+  for (int64_t x = lane; x < d; x += 64) {
+    const float w = (weight && row >= 0) ? weight[s + x] : default_weight;
+    out[o + x] = (int64_t)__float_as_uint(w);
+  }
+}
+
+// ... and the requester's half: WeightedRandomWalkKernel (random_walk.cc:192-272) on the lists the owners sent -- the
+// current vertex's first min(deg, F) neighbours with their weights, the parent's first min(deg, F) neighbours (the
+// previous step's list) -- same arithmetic, same draw (stream (seed, cc + t, walker), draw 0) as glx_node2vec_step_kernel.
+// One wave per walker; LDS: weights [F] f32 | table [F] 8 B | stack [F] 8 B.
+__global__ __launch_bounds__(64) void glx_dist_node2vec_step_kernel(
+    const int64_t* __restrict__ parent, int32_t t, const int32_t* __restrict__ deg_c, const int64_t* __restrict__ off_c,
+    const int64_t* __restrict__ nbr_c, const int64_t* __restrict__ wbits_c, const int32_t* __restrict__ deg_p,
+    const int64_t* __restrict__ off_p, const int64_t* __restrict__ nbr_p, float p, float q, int32_t F, uint64_t seed,
+    uint64_t cc, int64_t default_nbr, int64_t* __restrict__ next) {
+  extern __shared__ int64_t lds64[];
+  GlxAlias* tab = reinterpret_cast<GlxAlias*>(lds64);
+  GlxAlias* stk = tab + F;
+  float* dist = reinterpret_cast<float*>(stk + F);
+  const int lane = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  const int32_t n = deg_c[i];
+  if (n == 0) {
+    if (lane == 0) next[i] = default_nbr;
+    return;
+  }
+  const int64_t oc = off_c[i];
+  const int64_t par = parent[i];
+  const int32_t pn = (t > 0 && deg_p) ? deg_p[i] : 0;
+  const int64_t op = pn > 0 ? off_p[i] : 0;
+  for (int32_t x = lane; x < n; x += 64) {
+    const int64_t nbr = nbr_c[oc + x];
+    const float w = __uint_as_float((uint32_t)wbits_c[oc + x]);
+    float biased;
+    if (nbr == par) {
+      biased = (float)((double)w * 1.0 / ((double)p + 1e-6));
+    } else {
+      bool shared = false;
+      for (int32_t y = 0; y < pn; ++y) shared |= nbr_p[op + y] == nbr;
+      biased = shared ? w : (float)((double)w * 1.0 / ((double)q + 1e-6));
+    }
+    dist[x] = biased;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    glx_alias_build_row_dev(dist, n, tab, stk);
+    const int32_t pick = glx_alias_pick(glx_draw64(seed, cc + (uint64_t)t, (uint32_t)i, 0u), n, tab);
+    next[i] = nbr_c[oc + pick];
+  }
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 4096) {
   int64_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -1324,7 +1389,8 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
 int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batch, int32_t max_limit, int32_t* deg_out,
                             int64_t* offsets_out, int64_t* nbr_out, int64_t* eid_out, int64_t capacity, bool fill,
                             int64_t* total_out, hipStream_t s, const glx_filter* filter = nullptr,
-                            int padding_mode = GLX_PAD_CIRCULAR, int64_t default_neighbor_id = 0) {
+                            int padding_mode = GLX_PAD_CIRCULAR, int64_t default_neighbor_id = 0,
+                            bool weights_in_eid = false, float default_weight = 0.0f) {
   const int P = st->world;
   const int64_t n = batch, n1 = n > 0 ? n : 1;
   const bool filtered = fill && filter != nullptr && filter->type != GLX_FILTER_NONE;
@@ -1448,6 +1514,12 @@ int dist_sample_full_device(glx_dist_store* st, const int64_t* src, int32_t batc
     rc = glx_sample_full(st->graph, ids_in.as<int64_t>(), (int32_t)m, max_limit, off_loc.as<int64_t>(),
                          nbr_loc.as<int64_t>(), eid_loc.as<int64_t>(), GLX_PTR_DEVICE, s);
     if (rc != GLX_OK) return rc;
+    if (weights_in_eid) {  // node2vec: the answer carries edge weights where the edge ids would be
+      glx_dist_slot_weights_kernel<<<(unsigned)((m * 64 + 255) / 256), 256, 0, s>>>(
+          st->graph->map(), st->graph->row_ptr, st->graph->weight, ids_in.as<int64_t>(), off_loc.as<int64_t>(), m,
+          default_weight, eid_loc.as<int64_t>());
+      GLX_HIP(hipGetLastError());
+    }
   } else if (m > 0 && loc_total > 0) {
     // one launch per requester: its rows, its values, its filter kind / padding / default id.  (A timestamp > value
     // filter uses the first value of the rows a launch serves for all of them, as the reference's servers do with the
@@ -1909,9 +1981,10 @@ extern "C" int glx_dist_sample_full_filtered(glx_dist_store* st, const int64_t* 
                               stream, filter, padding_mode, default_neighbor_id);
 }
 
-extern "C" int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
-                                    float q, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
-                                    int64_t* walks_out, int ptr_kind, void* stream) {
+namespace {
+int dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p, float q,
+                     int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id, uint64_t seed,
+                     uint64_t call_counter, int64_t* walks_out, int ptr_kind, void* stream) {
   int rc = check_store(st, ptr_kind);
   if (rc != GLX_OK) return rc;
   GLX_REQUIRE(st->graph != nullptr, "this store has no graph shard");
@@ -1919,36 +1992,85 @@ extern "C" int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, in
   GLX_REQUIRE((int64_t)batch * walk_len <= INT32_MAX, "batch * walk_len exceeds int32 (tensor.h:47)");
   GLX_REQUIRE(batch == 0 || walk_len == 0 || (seeds && walks_out), "NULL data pointer");
   const bool deep = fabsf(p - 1.0f) < 32 * 1.1920929e-07f && fabsf(q - 1.0f) < 32 * 1.1920929e-07f;
-  if (!deep) {
-    glx_set_error("node2vec walks (p, q != 1) are not served across shards: a step needs the previous vertex's neighbours");
-    return GLX_UNIMPLEMENTED;
-  }
+  GLX_REQUIRE(deep || (full_nbr_num >= 1 && full_nbr_num <= 2048), "DefaultFullNbrNum must be in [1, 2048], got %d",
+              full_nbr_num);
   GlxDeviceGuard guard(st->device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
   hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, st->device) : glx_stream(stream);
+  if (!deep && st->world == 1 && st->shortcut) {
+    return glx_random_walk(st->graph, seeds, batch, walk_len, p, q, full_nbr_num, default_weight, default_neighbor_id, seed,
+                           call_counter, walks_out, ptr_kind, stream);
+  }
   const size_t nb = (size_t)(batch > 0 ? batch : 1), total = (size_t)batch * (size_t)walk_len;
   GlxTemp buf;
-  GLX_HIP(hipMalloc(&buf.p, (nb * 3 + (ptr_kind == GLX_PTR_HOST ? total : 0) + 2) * 8));
+  GLX_HIP(hipMalloc(&buf.p, (nb * 4 + (ptr_kind == GLX_PTR_HOST ? total : 0) + 2) * 8));
   int64_t* cur = buf.as<int64_t>();
   int64_t* nxt = cur + nb;
   int64_t* eid = nxt + nb;
-  int64_t* d_walks = ptr_kind == GLX_PTR_HOST ? eid + nb : walks_out;
+  int64_t* par = eid + nb;  // node2vec: the vertex each walker came from
+  int64_t* d_walks = ptr_kind == GLX_PTR_HOST ? par + nb : walks_out;
   if (batch > 0) {
     GLX_HIP(hipMemcpyAsync(cur, seeds, (size_t)batch * 8, ptr_kind == GLX_PTR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
   }
-  // DeepWalk (random_walk.cc:168-190): step t of walker i = RandomSampler's draw 0 of the stream (seed, call_counter + t,
-  // i) on the vertex it stands on -- one partitioned request with neighbor_count 1 per step, every walker a row; a
-  // walker on a vertex without out-edges continues from the default id, like the single-store walk
-  for (int32_t t = 0; t < walk_len; ++t) {
-    rc = dist_sample_device(st, GLX_SAMPLER_RANDOM, cur, batch, 1, GLX_PAD_CIRCULAR, default_neighbor_id, seed,
-                            call_counter + (uint64_t)t, nullptr, nxt, eid, s);
-    if (rc != GLX_OK) return rc;
-    if (batch > 0) {
-      glx_dist_walk_column_kernel<<<(unsigned)((batch + 255) / 256), 256, 0, s>>>(nxt, batch, walk_len, t, d_walks);
+  if (deep) {
+    // DeepWalk (random_walk.cc:168-190): step t of walker i = RandomSampler's draw 0 of the stream (seed, call_counter + t,
+    // i) on the vertex it stands on -- one partitioned request with neighbor_count 1 per step, every walker a row; a
+    // walker on a vertex without out-edges continues from the default id, like the single-store walk
+    for (int32_t t = 0; t < walk_len; ++t) {
+      rc = dist_sample_device(st, GLX_SAMPLER_RANDOM, cur, batch, 1, GLX_PAD_CIRCULAR, default_neighbor_id, seed,
+                              call_counter + (uint64_t)t, nullptr, nxt, eid, s);
+      if (rc != GLX_OK) return rc;
+      if (batch > 0) {
+        glx_dist_walk_column_kernel<<<(unsigned)((batch + 255) / 256), 256, 0, s>>>(nxt, batch, walk_len, t, d_walks);
+      }
+      int64_t* tmp = cur;
+      cur = nxt;
+      nxt = tmp;
     }
-    int64_t* tmp = cur;
-    cur = nxt;
-    nxt = tmp;
+  } else {
+    // node2vec (WeightedRandomWalk, random_walk.cc:192-272): a step needs the first F neighbours (+ weights) of the
+    // vertex the walker stands on and the first F neighbours of the vertex it came from.  Per step ONE partitioned
+    // FullSampler request (limit F) brings the current vertices' lists to the requester, weights in place of the edge ids;
+    // the parents' lists are the previous step's; the step itself then runs here, with the single store's arithmetic
+    // and draws -- walks are identical to glx_random_walk on the unpartitioned graph.
+    const int32_t F = full_nbr_num;
+    const size_t cap = nb * (size_t)F;
+    GlxTemp lists;
+    GLX_HIP(hipMalloc(&lists.p, 2 * ((nb + 1) * 4 + (nb + 2) * 8 + 2 * cap * 8) + 64));
+    char* base = lists.as<char>();
+    struct Lists { int32_t* deg; int64_t* off; int64_t* nbr; int64_t* w; } L[2];
+    for (int k = 0; k < 2; ++k) {
+      L[k].off = reinterpret_cast<int64_t*>(base);
+      base += (nb + 2) * 8;
+      L[k].nbr = reinterpret_cast<int64_t*>(base);
+      base += cap * 8;
+      L[k].w = reinterpret_cast<int64_t*>(base);
+      base += cap * 8;
+      L[k].deg = reinterpret_cast<int32_t*>(base);
+      base += ((nb + 1) * 4 + 7) & ~(size_t)7;
+    }
+    if (batch > 0) GLX_HIP(hipMemcpyAsync(par, cur, (size_t)batch * 8, hipMemcpyDeviceToDevice, s));  // step 0: the seed itself
+    for (int32_t t = 0; t < walk_len; ++t) {
+      Lists& c = L[t & 1];
+      Lists& pv = L[(t & 1) ^ 1];
+      int64_t tot = 0;
+      rc = dist_sample_full_device(st, cur, batch, F, c.deg, c.off, c.nbr, c.w, (int64_t)cap, true, &tot, s, nullptr,
+                                   GLX_PAD_CIRCULAR, 0, /*weights_in_eid=*/true, default_weight);
+      if (rc != GLX_OK) return rc;
+      if (batch > 0) {
+        glx_dist_node2vec_step_kernel<<<(unsigned)batch, 64, (size_t)F * 20, s>>>(
+            par, t, c.deg, c.off, c.nbr, c.w, t > 0 ? pv.deg : nullptr, pv.off, pv.nbr, p, q, F, seed, call_counter,
+            default_neighbor_id, nxt);
+        glx_dist_walk_column_kernel<<<(unsigned)((batch + 255) / 256), 256, 0, s>>>(nxt, batch, walk_len, t, d_walks);
+        // the next step's parent is this step's vertex -- except after step 0, whose parent stays the seed
+        // (random_walk_request.cc:120-131: t <= 1 -> the seed): the seed IS this step's vertex then
+        GLX_HIP(hipMemcpyAsync(par, cur, (size_t)batch * 8, hipMemcpyDeviceToDevice, s));
+      }
+      int64_t* tmp = cur;
+      cur = nxt;
+      nxt = tmp;
+    }
+    GLX_HIP(hipStreamSynchronize(s));  // `lists` is released on return
   }
   GLX_HIP(hipGetLastError());
   if (ptr_kind == GLX_PTR_HOST && total > 0) {
@@ -1956,6 +2078,24 @@ extern "C" int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, in
   }
   GLX_HIP(hipStreamSynchronize(s));
   return GLX_OK;
+}
+}  // namespace
+
+extern "C" int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
+                                    float q, int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter,
+                                    int64_t* walks_out, int ptr_kind, void* stream) {
+  // node2vec with the reference's defaults: GLOBAL_FLAG(DefaultFullNbrNum) = 100, GLOBAL_FLAG(DefaultWeight) = 0
+  // (config.cc:102,111); glx_dist_random_walk_ex takes them explicitly
+  return dist_random_walk(st, seeds, batch, walk_len, p, q, 100, 0.0f, default_neighbor_id, seed, call_counter, walks_out,
+                          ptr_kind, stream);
+}
+
+extern "C" int glx_dist_random_walk_ex(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
+                                       float q, int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id,
+                                       uint64_t seed, uint64_t call_counter, int64_t* walks_out, int ptr_kind,
+                                       void* stream) {
+  return dist_random_walk(st, seeds, batch, walk_len, p, q, full_nbr_num, default_weight, default_neighbor_id, seed,
+                          call_counter, walks_out, ptr_kind, stream);
 }
 
 extern "C" int glx_dist_aggregate(glx_dist_store* st, int op, const int64_t* node_ids, const int32_t* segment_ids,

@@ -52,7 +52,7 @@ EXPORTS = [
     "glx_comm_info", "glx_comm_set_max_message_bytes", "glx_exchange_v", "glx_comm_allgather_i64", "glx_comm_barrier",
     "glx_dist_store_create", "glx_dist_store_destroy", "glx_dist_store_set_cache", "glx_dist_store_set_graph_replica",
     "glx_dist_build_graph_replica", "glx_dist_sample_full_sizes", "glx_dist_sample_full", "glx_dist_sample_full_filtered",
-    "glx_dist_in_degrees", "glx_dist_negative_create", "glx_dist_negative_sample", "glx_dist_random_walk",
+    "glx_dist_in_degrees", "glx_dist_negative_create", "glx_dist_negative_sample", "glx_dist_random_walk", "glx_dist_random_walk_ex",
     "glx_dist_last_sample_rows", "glx_dist_hot_ids",
     "glx_dist_enable_in_degree",
     "glx_dist_sample", "glx_dist_aggregate", "glx_dist_aggregate_partial", "glx_dist_aggregate_begin", "glx_dist_aggregate_end", "glx_dist_aggregate_end_range", "glx_dist_lookup",
@@ -186,6 +186,7 @@ def lib():
         L.glx_dist_store_set_graph_replica.argtypes = [vp, vp]
         L.glx_dist_build_graph_replica.argtypes = [vp, vp, i64, ci, vp, vp]
         L.glx_dist_random_walk.argtypes = [vp, vp, i32, i32, f32, f32, i64, u64, u64, vp, ci, vp]
+        L.glx_dist_random_walk_ex.argtypes = [vp, vp, i32, i32, f32, f32, i32, f32, i64, u64, u64, vp, ci, vp]
         L.glx_dist_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
         L.glx_dist_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i64, ci, vp]
         L.glx_dist_sample_full_filtered.argtypes = [vp, vp, i32, i32, vp, vp, ci, i64, vp, vp, vp, i64, ci, vp]
@@ -942,8 +943,10 @@ class DistStore:
                                               _ptr(out)[0] if batch * count else None, kind, _stream(kind, self.comm.device)))
         return out
 
-    def random_walk(self, seeds, walk_len, p=1.0, q=1.0, default_neighbor_id=0, seed=0, call_counter=0):
-        """Collective DeepWalk over the shards: -> walks[batch, walk_len], Graph.random_walk's draws (p = q = 1 only)."""
+    def random_walk(self, seeds, walk_len, p=1.0, q=1.0, default_neighbor_id=0, seed=0, call_counter=0, full_nbr_num=100,
+                    default_weight=0.0):
+        """Collective RandomWalk over the shards (DeepWalk when p = q = 1, node2vec otherwise): -> walks[batch, walk_len],
+        Graph.random_walk's draws."""
         batch = int(seeds.shape[0])
         if _is_torch(seeds):
             import torch
@@ -952,10 +955,10 @@ class DistStore:
         else:
             walks = np.empty((batch, walk_len), np.int64)
             kind = PTR_HOST
-        _check(lib().glx_dist_random_walk(self._h, _ptr(seeds)[0] if batch else None, batch, walk_len, p, q,
-                                          default_neighbor_id, seed, call_counter,
-                                          _ptr(walks)[0] if batch * walk_len else None, kind,
-                                          _stream(kind, self.comm.device)))
+        _check(lib().glx_dist_random_walk_ex(self._h, _ptr(seeds)[0] if batch else None, batch, walk_len, p, q, full_nbr_num,
+                                             default_weight, default_neighbor_id, seed, call_counter,
+                                             _ptr(walks)[0] if batch * walk_len else None, kind,
+                                             _stream(kind, self.comm.device)))
         return walks
 
     def last_sample_rows(self):

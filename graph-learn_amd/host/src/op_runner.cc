@@ -437,8 +437,8 @@ Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpRespon
   if (auto* wreq = dynamic_cast<const RandomWalkRequest*>(req)) {
     auto* wres = dynamic_cast<RandomWalkResponse*>(res);
     if (!wres) return error::InvalidArgument("a RandomWalkRequest needs a RandomWalkResponse");
-    // DeepWalk across the shards: one partitioned RandomSampler request per step (glx_dist_random_walk); every step
-    // consumes one call counter value
+    // across the shards (glx_dist_random_walk_ex): DeepWalk = one partitioned RandomSampler request per step; node2vec =
+    // one partitioned FullSampler request per step + the step on the requester; every step consumes one call counter value
     const int32_t n = wreq->BatchSize(), len = wreq->WalkLen();
     wres->InitWalks(n, len);
     glx_dist_store* st = nullptr;
@@ -446,8 +446,9 @@ Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpRespon
     if (!s.ok()) return s;
     const uint64_t cc = wreq->HasCallCounter() ? (uint64_t)wreq->CallCounter()
                                                : env->NextCallCounters((uint64_t)(len > 0 ? len : 1));
-    int rc = glx_dist_random_walk(st, wreq->GetSrcIds(), n, len, wreq->P(), wreq->Q(), GLOBAL_FLAG(DefaultNeighborId),
-                                  (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, wres->MutableWalks(), GLX_PTR_HOST, nullptr);
+    int rc = glx_dist_random_walk_ex(st, wreq->GetSrcIds(), n, len, wreq->P(), wreq->Q(), GLOBAL_FLAG(DefaultFullNbrNum),
+                                     GLOBAL_FLAG(DefaultWeight), GLOBAL_FLAG(DefaultNeighborId),
+                                     (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, wres->MutableWalks(), GLX_PTR_HOST, nullptr);
     return error::FromGlx(rc);
   }
   if (auto* dreq = dynamic_cast<const GetDegreeRequest*>(req)) {

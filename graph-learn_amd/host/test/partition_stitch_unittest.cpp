@@ -695,7 +695,7 @@ TEST(PartitionStitchTest, AServerWithoutEdgesOfATypeStillServes) {
 }
 
 // The shardable requests that round 3's DistributeRunner still refused (VERDICT r03 missing 4, 6): FullSampler with a
-// filter, GetDegree for destination ids, and the four negative samplers -- now served across P = 2, 3, 8 servers
+// filter, GetDegree for destination ids, node2vec walks and the four negative samplers -- now served across P = 2, 3, 8 servers
 // (host threads over the in-process transport), every server's answer equal to ONE store's.  For the negative samplers
 // "one store" means glx_negative_sample on the whole graph with the candidate table the servers build together: every
 // destination id of any shard (ascending) with in-degrees summed over all shards -- the unpartitioned storage's
@@ -782,7 +782,7 @@ void RunRemainingOps(int P) {
   struct Want {
     std::vector<int64_t> ids, fvals;
     std::vector<int32_t> full_deg, indeg;
-    std::vector<int64_t> full_nbr, full_eid, neg[4];
+    std::vector<int64_t> full_nbr, full_eid, neg[4], walks;
   };
   const char* neg_names[4] = {"RandomNegativeSampler", "SoftInDegreeNegativeSampler", "InDegreeNegativeSampler",
                               "NodeWeightNegativeSampler"};
@@ -817,6 +817,14 @@ void RunRemainingOps(int P) {
     GetDegreeResponse dres;
     EXPECT_TRUE(OpFactory::GetInstance()->Create("GetDegree")->Process(&dreq, &dres).ok());
     w.indeg.assign(dres.GetDegrees(), dres.GetDegrees() + n);
+    {  // node2vec walks (p = 0.5, q = 2): RandomWalk, random_walk.cc:192-272
+      RandomWalkRequest wreq("e", 0.5f, 2.0f, 4);
+      wreq.Set(w.ids.data(), n);
+      wreq.SetCallCounter(700 + 10 * r);
+      RandomWalkResponse wres;
+      EXPECT_TRUE(OpFactory::GetInstance()->Create("RandomWalk")->Process(&wreq, &wres).ok());
+      w.walks.assign(wres.GetWalks(), wres.GetWalks() + (size_t)n * 4);
+    }
     const glx_negative* tabs[4] = {t_uniform, t_indeg, t_indeg, t_node};
     for (int k = 0; k < 4; ++k) {
       w.neg[k].assign((size_t)n * 7, -5);
@@ -869,6 +877,21 @@ void RunRemainingOps(int P) {
         if (!s.ok()) fail(r, "GetDegree(dst): " + s.ToString());
         for (int i = 0; i < n && s.ok(); ++i) {
           if (res.GetDegrees()[i] != w.indeg[(size_t)i]) fail(r, "GetDegree(dst): mismatch");
+        }
+      }
+      {  // node2vec across the servers
+        std::unique_ptr<OpRunner> runner = GetOpRunner(&env, OpFactory::GetInstance()->Create("RandomWalk"));
+        RandomWalkRequest req("e", 0.5f, 2.0f, 4);
+        req.Set(w.ids.data(), n);
+        req.SetCallCounter(700 + 10 * r);
+        RandomWalkResponse res;
+        Status s = runner->Run(&req, &res);
+        if (!s.ok()) fail(r, "node2vec: " + s.ToString());
+        for (size_t i = 0; i < (size_t)n * 4 && s.ok(); ++i) {
+          if (res.GetWalks()[i] != w.walks[i]) {
+            fail(r, "node2vec: walk mismatch");
+            break;
+          }
         }
       }
       // (every server goes through every collective whatever it found so far: a server that stopped early would leave

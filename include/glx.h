@@ -556,13 +556,20 @@ GLX_API int glx_dist_negative_create(glx_dist_store* st, int by_in_degree, void*
 GLX_API int glx_dist_negative_sample(glx_dist_store* st, const glx_negative* table, int exclude, const int64_t* src,
                                      int32_t batch, int32_t count, int64_t default_neighbor_id, uint64_t seed,
                                      uint64_t call_counter, int64_t* out, int ptr_kind, void* stream);
-/* Collective.  DeepWalk (random_walk.cc:168-190; p = q = 1 as RandomWalkRequest::IsDeepWalk decides) across the shards,
- * glx_random_walk's layout and draws: step t is one partitioned RandomSampler request with neighbor_count 1 and call
- * counter call_counter + t, walker i drawing from stream i.  node2vec (p, q != 1) needs the previous vertex's
- * neighbour list at every step and returns GLX_UNIMPLEMENTED here. */
+/* Collective.  The RandomWalk operator (random_walk.cc:30-276) across the shards, glx_random_walk's layout and draws.
+ * DeepWalk (p = q = 1 as RandomWalkRequest::IsDeepWalk decides, :168-190): step t is one partitioned RandomSampler request
+ * with neighbor_count 1 and call counter call_counter + t, walker i drawing from stream i.  node2vec (:192-272): per step
+ * ONE partitioned FullSampler request (limit full_nbr_num) brings the first full_nbr_num neighbours of the vertices the
+ * walkers stand on -- with their edge weights -- to the requesters; the parents' lists are the previous step's; the step
+ * (bias by 1/p, 1, 1/q, alias table, one draw) then runs on the requester with the single store's arithmetic: walks equal
+ * glx_random_walk on the unpartitioned graph for every shard count.  glx_dist_random_walk uses the reference's flag
+ * defaults (DefaultFullNbrNum 100, DefaultWeight 0: config.cc:102,111), _ex takes them. */
 GLX_API int glx_dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p, float q,
                                  int64_t default_neighbor_id, uint64_t seed, uint64_t call_counter, int64_t* walks_out,
                                  int ptr_kind, void* stream);
+GLX_API int glx_dist_random_walk_ex(glx_dist_store* st, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
+                                    float q, int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id,
+                                    uint64_t seed, uint64_t call_counter, int64_t* walks_out, int ptr_kind, void* stream);
 /* Collective.  DistributeRunner<AggregatingRequest, AggregatingResponse>::Run with
  * glx_aggregate's arguments; segment_ids == NULL means num_segments equal segments of
  * num_ids / num_segments consecutive ids (a dense sampler response). */

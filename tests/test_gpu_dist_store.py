@@ -859,9 +859,12 @@ def test_dist_in_degrees_and_global_negative_samplers(world, P, monkeypatch):
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 8])
-def test_dist_deepwalk_equals_unpartitioned(world, P):
+def test_dist_deepwalk_and_node2vec_equal_unpartitioned(world, P, monkeypatch):
     """DeepWalk across the shards = one partitioned RandomSampler request per step: the single store's walks, vertex
-    for vertex (dead ends continue from the default id, as there); node2vec is refused, on every rank alike."""
+    for vertex (dead ends continue from the default id, as there); node2vec = one partitioned FullSampler request per step
+    (the current vertices' first F neighbours + weights to the requester) and the step on the requester: the single
+    store's walks too."""
+    monkeypatch.setenv("GLX_DIST_NO_SHORTCUT", "1")
     whole, dev = world["whole"], world["dev"]
     gs, _ = world["shards"][P]
 
@@ -874,6 +877,12 @@ def test_dist_deepwalk_equals_unpartitioned(world, P):
             assert torch.equal(got, want), (walk_len, dflt, r)
         host = st.random_walk(seeds.cpu().numpy(), 4, seed=11, call_counter=7)
         assert np.array_equal(host, whole.random_walk(seeds, 4, seed=11, call_counter=7).cpu().numpy())
-        with pytest.raises(glx.GlxError, match="node2vec"):
-            st.random_walk(seeds, 3, p=0.5, q=2.0)
+        for p_, q_, F, dw in ((0.5, 2.0, 100, 0.0), (4.0, 0.25, 7, 0.0), (0.25, 0.25, 2048, 0.5)):
+            got = st.random_walk(seeds, 5, p=p_, q=q_, default_neighbor_id=-1, seed=13, call_counter=40, full_nbr_num=F,
+                                 default_weight=dw)
+            want = whole.random_walk(seeds, 5, p=p_, q=q_, full_nbr_num=F, default_weight=dw, default_neighbor_id=-1,
+                                     seed=13, call_counter=40)
+            assert torch.equal(got, want), (p_, q_, F, r)
+        host = st.random_walk(seeds.cpu().numpy(), 3, p=2.0, q=0.5, seed=13, call_counter=9)
+        assert np.array_equal(host, whole.random_walk(seeds, 3, p=2.0, q=0.5, seed=13, call_counter=9).cpu().numpy())
     _run_ranks(P, body)
