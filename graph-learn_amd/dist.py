@@ -243,11 +243,35 @@ class ShardedStore:
         eid = _a2a(eid, recv, send, self.group, most)
         return self.ops.stitch(nbr, order), self.ops.stitch(eid, order)
 
-    def sample_full(self, src, max_limit=0):
-        """FullSampler over the shards (sparse response): -> (degrees, nbr, eid) of this rank's rows."""
+    def _native(self, what):
         if self.native is None:
-            raise NotImplementedError("the partitioned FullSampler runs in the C distributed store (device ops)")
-        return self.native.sample_full(src, max_limit)
+            raise NotImplementedError("%s runs in the C distributed store (device ops)" % what)
+        return self.native
+
+    def sample_full(self, src, max_limit=0, **filter_kwargs):
+        """FullSampler over the shards (sparse response): -> (degrees, nbr, eid) of this rank's rows.  With
+        filter_type / filter_field / values (+ padding_mode, default_neighbor_id): the filtered FullSampler."""
+        return self._native("the partitioned FullSampler").sample_full(src, max_limit, **filter_kwargs)
+
+    def in_degrees(self, ids):
+        """Collective: in-degrees of destination ids summed over ALL shards (GetDegree with node_from = dst)."""
+        return self._native("the partitioned in-degree lookup").in_degrees(ids)
+
+    def negative_table(self, by_in_degree=False):
+        """Collective: the negative samplers' candidate list over the WHOLE edge type (every shard's destination ids,
+        ascending; uniform or weighted by global in-degree) -> glx.Negative, identical on every rank."""
+        return self._native("the global negative candidate table").negative_table(by_in_degree)
+
+    def negative_sample(self, table, src, count, exclude=0, default_neighbor_id=0, seed=0, call_counter=0):
+        """Negative sampling over the shards from `table` (negative_table()): what an unpartitioned store with the same
+        table answers.  Collective when exclude = glx.NEG_EXCLUDE_NEIGHBORS (strict in-degree sampling)."""
+        return self._native("partitioned negative sampling").negative_sample(table, src, count, exclude=exclude,
+                                                                             default_neighbor_id=default_neighbor_id,
+                                                                             seed=seed, call_counter=call_counter)
+
+    def random_walk(self, seeds, walk_len, p=1.0, q=1.0, **kwargs):
+        """Collective RandomWalk over the shards: DeepWalk (p = q = 1) or node2vec, the single store's walks."""
+        return self._native("the partitioned random walk").random_walk(seeds, walk_len, p=p, q=q, **kwargs)
 
     def sample_filtered(self, sampler, src, k, filter_type, filter_field, values, seed=0, call_counter=0,
                         padding_mode=1, default_neighbor_id=0, retry_times=5, default_timestamp=-1):

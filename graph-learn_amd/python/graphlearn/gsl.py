@@ -415,6 +415,22 @@ class SubGraphStep(Step):
     return self._sampler.get(up.ids.reshape(-1))
 
 
+class _HostView(dict):
+  """results, with DeviceNodes values converted to Nodes on access (once per value)."""
+
+  def __init__(self, results):
+    dict.__init__(self, results)
+    self._host = {}
+
+  def __getitem__(self, step):
+    value = dict.__getitem__(self, step)
+    if hasattr(value, "to_host"):
+      if step not in self._host:
+        self._host[step] = value.to_host()
+      return self._host[step]
+    return value
+
+
 class Dataset(object):
   """dag_dataset.py Dataset: next() -> the query's values for one more batch of its source; raises OutOfRangeError
   at the end of an epoch (the following next() starts the next one).  `window` is the reference's prefetch depth and
@@ -423,8 +439,11 @@ class Dataset(object):
 
   _DENSE = ("random", "random_without_replacement", "topk", "in_degree", "edge_weight")
 
-  def __init__(self, query, window=10, drop_last=False, fuse_hops=False):
-    """fuse_hops (new): a chain .outV(e1).sample(k1).by(s).outV(e2).sample(k2).by(s)... of dense, unfiltered hops with
+  def __init__(self, query, window=10, drop_last=False, fuse_hops=False, device=False):
+    """device (new, with fuse_hops): the hops of a fused chain yield values.DeviceNodes -- ids, float attributes and
+    aggregates as torch CUDA tensors that never visit the host (`.to_host()` gives the ordinary Nodes).  A step
+    downstream of such a hop that is NOT part of the chain sees its upstream through .to_host().
+    fuse_hops (new): a chain .outV(e1).sample(k1).by(s).outV(e2).sample(k2).by(s)... of dense, unfiltered hops with
     one strategy runs as ONE engine call (glx_sample_hops through NeighborSampler.get_device: the frontiers stay in HBM,
     one copy back per hop) instead of one request per hop; values, shapes and types are the same, the random streams
     are the Dataset's own (seed = gl.set_sampling_seed's, a fresh call counter per batch)."""
@@ -434,6 +453,9 @@ class Dataset(object):
     self._window = int(window)
     self._drop_last = bool(drop_last)
     self._source = next(s for s in query.steps if isinstance(s, (VertexSource, EdgeSource)))
+    if device and not fuse_hops:
+      raise ValueError("device=True keeps the values of FUSED chains on the GPU: pass fuse_hops=True as well")
+    self._device_values = bool(device)
     self._chains = self._find_chains() if fuse_hops else {}
     self._fused_calls = int.from_bytes(__import__("os").urandom(6), "little") << 8
 
@@ -467,7 +489,11 @@ class Dataset(object):
     hops = sampler.get_device(ids, call_counter=self._fused_calls)
     rows = src.size
     for step, (nbr, _) in zip(chain, hops):
-      results[step] = graph.get_nodes(step._vertex_type(), nbr.cpu().numpy(), shape=(rows, step._count))  # pylint: disable=protected-access
+      if self._device_values:
+        from graphlearn.values import DeviceNodes
+        results[step] = DeviceNodes(nbr.reshape(rows, step._count), step._vertex_type(), graph)  # pylint: disable=protected-access
+      else:
+        results[step] = graph.get_nodes(step._vertex_type(), nbr.cpu().numpy(), shape=(rows, step._count))  # pylint: disable=protected-access
       rows *= step._count  # pylint: disable=protected-access
 
   def next(self):
@@ -478,7 +504,8 @@ class Dataset(object):
       if step in self._chains:
         self._run_chain(self._chains[step], results)
         continue
-      value = step._evaluate(results)  # pylint: disable=protected-access
+      # a step outside a fused chain runs through host requests: it sees device-resident values as ordinary Nodes
+      value = step._evaluate(_HostView(results) if self._device_values else results)  # pylint: disable=protected-access
       if step is self._source and self._drop_last:
         rows = value.src_ids.size if isinstance(step, EdgeSource) else value.ids.size
         if rows < step._batch_size:  # pylint: disable=protected-access

@@ -220,6 +220,50 @@ class Nodes(Values):
     return out.reshape(rows, self._get_decoder().float_attr_num)
 
 
+class DeviceNodes(object):
+  """A batch of vertices of one type whose ids -- and everything derived from them -- stay on the GPU: what
+  gl.Dataset(query, fuse_hops=True, device=True) yields for the hops of a fused chain (the reference keeps a query's
+  values in server-side tapes until the client asks, dag_node.py:183-210; here they never leave HBM until the caller
+  asks with .to_host()).  Torch CUDA tensors throughout:
+    ids [rows, k] int64, shape, type;
+    float_attrs [rows, k, D] float32 (one glx_lookup on the device, on first access);
+    embedding_agg(func) [rows, D] (one device aggregation over each row's k vertices -- Nodes.embedding_agg's result);
+    to_host() -> the ordinary Nodes value (one copy)."""
+
+  def __init__(self, ids, node_type, graph):
+    self._ids, self._type, self._graph = ids, node_type, graph
+    self._float_attrs = None
+
+  ids = property(lambda self: self._ids)
+  type = property(lambda self: self._type)
+  shape = property(lambda self: tuple(self._ids.shape))
+
+  def _features(self):
+    return self._graph.device_features(self._type)
+
+  @property
+  def float_attrs(self):
+    if self._float_attrs is None:
+      from graphlearn import settings
+      default = float(settings._MIRROR.get("default_float_attr", 0.0))  # pylint: disable=protected-access
+      flat = self._features().lookup(self._ids.reshape(-1), default)
+      self._float_attrs = flat.reshape(self.shape + (-1,))
+    return self._float_attrs
+
+  def embedding_agg(self, func="sum"):
+    if len(self.shape) != 2:
+      raise ValueError("embedding_agg is for Nodes with 2 dimension, and the default aggregated dimension is axis=1")
+    from graphlearn import settings
+    default = float(settings._MIRROR.get("default_float_attr", 0.0))  # pylint: disable=protected-access
+    rows = self.shape[0]
+    emb, _ = self._features().aggregate(strategy2op(func, "Aggregator"), self._ids.reshape(-1), None, rows,
+                                        default_attr=default)
+    return emb
+
+  def to_host(self):
+    return self._graph.get_nodes(self._type, self._ids.cpu().numpy(), shape=self.shape)
+
+
 class SparseNodes(Nodes, _Ragged):
   """Ragged 2-D Nodes (FullNeighborSampler): `ids` is flat, row i owns `offsets[i]` of them."""
 

@@ -284,6 +284,42 @@ def test_fused_hops_one_engine_call_per_chain(gl, g):
     assert gl.Dataset(q2.values(), fuse_hops=True)._chains == {}
 
 
+def test_device_resident_values_of_a_fused_chain(gl, g):
+    """Dataset(fuse_hops=True, device=True): the hops of a fused chain come back as DeviceNodes -- ids, float attributes
+    and aggregates are CUDA tensors -- equal to what the host values of the same draws hold; a step outside the chain
+    (another strategy) still works downstream, through the host view of its upstream."""
+    import torch
+    from graphlearn.values import DeviceNodes
+    q = g.V(NODE1).batch(6).alias('a') \
+         .outV(EDGE1).sample(3).by('random').alias('b') \
+         .outV(EDGE2).sample(4).by('random').alias('c') \
+         .outV(EDGE1).sample(2).by('topk').alias('d') \
+         .values()
+    ds = gl.Dataset(q, fuse_hops=True, device=True)
+    with pytest.raises(ValueError):
+        gl.Dataset(q, device=True)  # device values are what fused chains yield
+    res = ds.next()
+    b, c, d = res['b'], res['c'], res['d']
+    assert isinstance(b, DeviceNodes) and isinstance(c, DeviceNodes) and not isinstance(d, DeviceNodes)
+    n = res['a'].shape[0]
+    assert b.ids.is_cuda and b.ids.dtype == torch.int64 and b.shape == (n, 3) and c.shape == (3 * n, 4)
+    assert (b.type, c.type, d.type) == (NODE2, NODE1, NODE2) and d.shape == (12 * n, 2)
+    hb, hc = b.to_host(), c.to_host()
+    np.testing.assert_array_equal(hb.ids, b.ids.cpu().numpy())
+    for s, row in zip(res['a'].ids, hb.ids):
+        assert set(row.tolist()) <= set(fx.fixed_dst_ids(int(s), RANGE2)) | {-1}
+    # float attributes and the aggregate, computed on the device, equal the host values' (one lookup / one aggregator call)
+    fa = c.float_attrs
+    assert fa.is_cuda and fa.shape[:2] == c.shape
+    np.testing.assert_array_equal(fa.cpu().numpy(), hc.float_attrs)
+    for func in ("sum", "mean", "max", "min"):
+        np.testing.assert_array_equal(c.embedding_agg(func).cpu().numpy(), hc.embedding_agg(func))
+    # the topk hop below the chain saw the chain's ids
+    np.testing.assert_array_equal(d.ids.shape, (12 * n, 2))
+    want_d = g.neighbor_sampler(EDGE1, 2, strategy='topk').get(hc.ids.reshape(-1)).layer_nodes(1)
+    np.testing.assert_array_equal(d.ids, want_d.ids)
+
+
 def test_query_errors(gl, g):
     with pytest.raises(ValueError):
         g.V("no_such_type")
