@@ -195,11 +195,17 @@ __global__ __launch_bounds__(256) void glx_rwor_kernel(SampleArgs a) {
 // step l.  ~W^2 VALU compares instead of 3k serialised ds_bpermute round trips.
 template <int W, int K>
 __global__ __launch_bounds__(256) void glx_rwor_small_kernel(SampleArgs a) {
+  // W lanes per request row, 64 / W rows per wavefront.  W need not be a power of two (round 4): k = 10 takes W = 10 and
+  // six rows per wave instead of W = 16 and four with six idle lanes each -- this kernel is VALU-bound, so lanes are time.
+  // Lanes past the last whole group of a wave idle; every cross-lane read below names an absolute lane of the own group.
+  constexpr int kRowsPerWave = 64 / W;
   const int lane = threadIdx.x & 63;
-  const int l = lane & (W - 1);
+  const int grp = lane / W;
+  const int l = lane - grp * W;
   const int base = lane - l;
-  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / W;
-  const bool active = i < a.batch;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t i = wave * kRowsPerWave + grp;
+  const bool active = grp < kRowsPerWave && i < a.batch;
   int64_t start = 0, deg = 0;
   if (active) {
     const int64_t row = glx_row_of(a.map, a.src[i]);
@@ -319,9 +325,13 @@ void launch_rwor(const SampleArgs& a, hipStream_t s) {
 // group's width is the difference between VALU-bound and not)
 template <int K>
 void launch_rwor_small(const SampleArgs& a, hipStream_t s) {
-  constexpr int W = K <= 8 ? 8 : 16;
-  const int64_t threads = (int64_t)a.batch * W;
-  glx_rwor_small_kernel<W, K><<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+  // lanes per row: k itself when that packs more rows into a wavefront than the next power of two does (k = 3, 5, 6, 7,
+  // 9 .. 12), else the power of two (cheaper lane arithmetic, same packing)
+  constexpr int kPow2 = K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : 16;
+  constexpr int W = (64 / K > 64 / kPow2) ? K : kPow2;
+  constexpr int kRowsPerWave = 64 / W;
+  const int64_t waves = ((int64_t)a.batch + kRowsPerWave - 1) / kRowsPerWave;
+  glx_rwor_small_kernel<W, K><<<(unsigned)((waves + 3) / 4), 256, 0, s>>>(a);
 }
 
 void launch_rwor_small_k(const SampleArgs& a, hipStream_t s) {
