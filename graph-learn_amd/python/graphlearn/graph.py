@@ -305,8 +305,39 @@ class Graph(object):
     return self._degrees(ids, edge_type, pywrap.NodeFrom.EDGE_SRC)
 
   def in_degrees(self, ids, edge_type):
-    """In-degrees of destination ids of `edge_type` (0 for ids no edge points to)."""
+    """In-degrees of destination ids of `edge_type` (0 for ids no edge points to).  In SPMD mode (init(task_index,
+    task_count)) the call is collective and the counts are sums over ALL shards (glx_dist_in_degrees)."""
+    if getattr(self, "_shard", (0, 1))[1] > 1:
+      import numpy as np
+      arr = np.ascontiguousarray(np.asarray(ids).reshape(-1), dtype=np.int64)
+      out = self.sharded_store_cached(edge_type).in_degrees(arr)
+      return out.reshape(np.asarray(ids).shape)
     return self._degrees(ids, edge_type, pywrap.NodeFrom.EDGE_DST)
+
+  def global_negative_table(self, object_type, by_in_degree=False, node_weights=False):
+    """SPMD mode: the negative samplers' candidate list over the WHOLE type, the same glx.Negative on every rank
+    (collective on first use): an edge type's destination ids of all shards (ascending; uniform or weighted by the
+    in-degree summed over all shards), or -- node_weights=True -- a node type's ids and node weights of all shards."""
+    import numpy as np
+    import glx
+    tables = self.__dict__.setdefault("_negative_tables", {})
+    key = (object_type, bool(by_in_degree), bool(node_weights))
+    if key not in tables:
+      if node_weights:
+        import torch.distributed as torch_dist
+        mine = self._server.node_ids(object_type)
+        weights = self.get_nodes(object_type, mine).weights
+        parts = [None] * torch_dist.get_world_size()
+        torch_dist.all_gather_object(parts, (np.asarray(mine, np.int64), np.asarray(weights, np.float32)))
+        ids = np.concatenate([p[0] for p in parts])
+        w = np.concatenate([p[1] for p in parts])
+        order = np.argsort(ids, kind="stable")
+        tables[key] = glx.Negative(np.ascontiguousarray(ids[order]), np.ascontiguousarray(w[order]),
+                                   device=self.device_features(object_type).device
+                                   if self._server.device_features(object_type) else 0)
+      else:
+        tables[key] = self.sharded_store_cached(object_type).negative_table(by_in_degree)
+    return tables[key]
 
   # -- samplers -------------------------------------------------------------------
   def neighbor_sampler(self, meta_path, expand_factor, strategy="random"):
@@ -346,11 +377,12 @@ class Graph(object):
     import torch
     from graphlearn import settings
     if isinstance(ids, torch.Tensor) and getattr(self, "_shard", (0, 1))[1] > 1:
-      # SPMD mode: a collective walk over the shards (DeepWalk; glx_dist_random_walk), the single store's draws
+      # SPMD mode: a collective walk over the shards (DeepWalk and node2vec; glx_dist_random_walk_ex), the single store's draws
       flags = settings._MIRROR  # pylint: disable=protected-access
       return self.sharded_store_cached(edge_type).native.random_walk(
           ids, int(walk_len), p=float(p), q=float(q), default_neighbor_id=flags["default_neighbor_id"],
-          seed=flags["sampling_seed"], call_counter=call_counter or 0)
+          seed=flags["sampling_seed"], call_counter=call_counter or 0, full_nbr_num=flags["default_full_nbr_num"],
+          default_weight=flags["default_weight"])
     if isinstance(ids, torch.Tensor):
       flags = settings._MIRROR  # pylint: disable=protected-access
       return self.device_graph(edge_type).random_walk(

@@ -289,9 +289,34 @@ class NegativeSampler(object):
   def set_call_counter(self, value):
     self._call_counter = value
 
+  def _get_spmd(self, ids):
+    """SPMD mode (Graph.init(task_index, task_count)): candidates = the WHOLE type's list, the same table on every rank
+    (Graph.global_negative_table); strict in-degree sampling is a collective request to the owners of the source ids
+    (glx_dist_negative_sample).  What an unpartitioned store with that table draws, for every shard count."""
+    import glx
+    kind = {"RandomNegativeSampler": (False, glx.NEG_EXCLUDE_NONE), "SoftInDegreeNegativeSampler": (True, glx.NEG_EXCLUDE_NONE),
+            "InDegreeNegativeSampler": (True, glx.NEG_EXCLUDE_NEIGHBORS), "NodeWeightNegativeSampler": (None, glx.NEG_EXCLUDE_BATCH)}
+    by_in_degree, exclude = kind[self._op]
+    if self._call_counter is None:
+      self._spmd_calls = getattr(self, "_spmd_calls", 0) + 1
+    cc = int(self._call_counter) if self._call_counter is not None else self._spmd_calls
+    seed, default = _flag("sampling_seed"), _flag("default_neighbor_id")
+    if by_in_degree is None:  # node weights: nothing is needed from another shard once the table is global
+      table = self._graph.global_negative_table(self._object_type, node_weights=True)
+      out = table.sample(ids, self._expand_factor, exclude=exclude, default_neighbor_id=default, seed=seed, call_counter=cc)
+    else:
+      if exclude == glx.NEG_EXCLUDE_NEIGHBORS:
+        self._graph.device_graph(self._object_type).enable_negative()
+      table = self._graph.global_negative_table(self._object_type, by_in_degree=by_in_degree)
+      out = self._graph.sharded_store_cached(self._object_type).negative_sample(
+          table, ids, self._expand_factor, exclude=exclude, default_neighbor_id=default, seed=seed, call_counter=cc)
+    return self._graph.get_nodes(self._dst_type, out, shape=(ids.shape[0], self._expand_factor))
+
   def get(self, ids):
     """-> Nodes of shape [len(ids), expand_factor]"""
     ids = np.ascontiguousarray(np.array(ids).reshape(-1), dtype=np.int64)
+    if getattr(self._graph, "_shard", (0, 1))[1] > 1 and type(self) is not ConditionalNegativeSampler:  # pylint: disable=unidiomatic-typecheck
+      return self._get_spmd(ids)
     req = pywrap.new_sampling_request(self._object_type, self._op, self._expand_factor,
                                       pywrap.FilterType.OPERATOR_UNSPECIFIED, pywrap.FilterField.FIELD_UNSPECIFIED)
     pywrap.set_sampling_request(req, ids)

@@ -88,6 +88,40 @@ for strategy in ("edge_weight", "topk", "random_without_replacement"):
 ids = torch.from_numpy(gen.integers(0, 400, 150) * 3 - 200).to(dev)
 assert torch.equal(shard.random_walk("e", ids, 5, call_counter=80), whole.random_walk("e", ids, 5, call_counter=80)), rank
 
+# node2vec: one partitioned FullSampler request per step + the step on the requester -- the single store's walks
+assert torch.equal(shard.random_walk("e", ids, 4, p=0.5, q=2.0, call_counter=84),
+                   whole.random_walk("e", ids, 4, p=0.5, q=2.0, call_counter=84)), rank
+
+# in-degrees of destination ids are sums over ALL shards (collective in SPMD mode)
+probe = np.concatenate([gen.integers(0, 400, 120) * 3 - 200, [7, 10 ** 7]]).astype(np.int64)
+# (the expected counts come from the file: the operators of this process are bound to the LAST store initialised,
+# the shard's, so `whole.in_degrees` would count the shard's edges only)
+all_dst = np.loadtxt(edges, skiprows=1, usecols=1, dtype=np.int64)
+uniq_dst, uniq_cnt = np.unique(all_dst, return_counts=True)
+pos = np.searchsorted(uniq_dst, probe)
+hit = (pos < uniq_dst.shape[0]) & (uniq_dst[np.minimum(pos, uniq_dst.shape[0] - 1)] == probe)
+want_deg = np.where(hit, uniq_cnt[np.minimum(pos, uniq_dst.shape[0] - 1)], 0)
+got_deg = shard.in_degrees(probe, "e")
+assert np.array_equal(got_deg, want_deg), (rank, probe[got_deg != want_deg][:8], got_deg[got_deg != want_deg][:8])
+
+# the negative samplers draw from the WHOLE type's candidate list: every rank holds the same table (every shard's
+# destination ids, ascending, global in-degrees) and answers what one store answers from that table
+import glx  # noqa: E402
+cand_ids, indeg = uniq_dst, uniq_cnt.astype(np.float32)
+ref_tables = {False: glx.Negative(cand_ids, device=local), True: glx.Negative(cand_ids, indeg, device=local)}
+whole_graph.enable_negative()
+src_ids = np.ascontiguousarray(gen.integers(0, 400, 90) * 3 - 200, dtype=np.int64)
+for strategy, by_deg, mode in (("random", False, glx.NEG_EXCLUDE_NONE), ("soft_in_degree", True, glx.NEG_EXCLUDE_NONE),
+                               ("in_degree", True, glx.NEG_EXCLUDE_NEIGHBORS)):
+    smp = shard.negative_sampler("e", 6, strategy=strategy)
+    smp.set_call_counter(300 + rank)
+    got = smp.get(src_ids).ids
+    want = ref_tables[by_deg].sample(src_ids, 6, exclude=mode, graph=whole_graph, default_neighbor_id=-1, seed=77,
+                                     call_counter=300 + rank)
+    assert np.array_equal(got, want), (rank, strategy)
+t_u = shard.global_negative_table("e")
+assert np.array_equal(t_u.export()[0], cand_ids), rank
+
 # a replica of the hottest rows on every GPU changes where rows come from, never the answer
 hot_store = shard.sharded_store("e", "n", hot_nodes=50)
 emb, cnt = hot_store.aggregate("MeanAggregator", nbr.reshape(-1), seg, ids.shape[0])
