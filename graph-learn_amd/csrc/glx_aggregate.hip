@@ -437,7 +437,6 @@ struct AggKnobs {
   std::atomic<int> segs{0};     // GLX_AGG_SEGS: segments per lane group (0 = chosen from fanout and grid size)
   std::atomic<int> xcd{0};      // GLX_AGG_XCD_SLICES=1|2|4|8: column slice = workgroup % n (XCD-affine); 0 = 2 for big requests
   std::atomic<int> occ{0};      // GLX_AGG_OCCUPANCY=3..7: workgroups per CU, capped with an unused LDS allocation
-  std::atomic<int> vec{0};      // GLX_AGG_VEC=2: 8-byte row loads over twice the lanes (experiment)
 };
 
 AggKnobs& agg_knobs() {
@@ -455,7 +454,6 @@ AggKnobs& agg_knobs() {
     k.segs = env("GLX_AGG_SEGS");
     k.xcd = env("GLX_AGG_XCD_SLICES");
     k.occ = env("GLX_AGG_OCCUPANCY");
-    k.vec = env("GLX_AGG_VEC");
   });
   return k;
 }
@@ -551,16 +549,10 @@ void launch_agg_cols(const AggArgs& a0, int32_t num_ids, int want_xcd, hipStream
       a.xcd_slices = want_xcd;  // only the grouped kernel knows about slices
       a.ncols = a.dim / want_xcd;
     }
-    // lanes per segment x floats per lane: 16-byte loads by default; agg_vec = 2 prefers twice the lanes with
-    // 8-byte loads (a whole wave per 128-column segment keeps the row arithmetic on the scalar unit)
-    const bool v2 = agg_knobs().vec.load(std::memory_order_relaxed) == 2;
-    const int lanes = a.ncols / (v2 ? 2 : 4);
-    if (v2) {
-      if (lanes >= 64) launch_agg_grp<OP, 64, 2, NSRC, 1>(a, num_ids, s);
-      else if (lanes >= 32) launch_agg_grp<OP, 32, 2, NSRC, 1>(a, num_ids, s);
-      else launch_agg_grp<OP, 16, 2, NSRC, 1>(a, num_ids, s);
-      return;
-    }
+    // lanes per segment, 16-byte loads each.  (8-byte loads over twice the lanes -- a whole wave per 128-column slice
+    // keeps the scalar row path -- were measured and dropped: equal on uniform rows, 13 % slower on the power-law
+    // request; profiles/r04/agg_probe_*_run4.txt.  The kernel keeps its VEC parameter.)
+    const int lanes = a.ncols / 4;
     if (lanes >= 64) launch_agg_grp<OP, 64, 4, NSRC, 1>(a, num_ids, s);
     else if (lanes >= 32) launch_agg_grp<OP, 32, 4, NSRC, 1>(a, num_ids, s);
     else if (lanes >= 16) launch_agg_grp<OP, 16, 4, NSRC, 1>(a, num_ids, s);
@@ -844,7 +836,6 @@ extern "C" int glx_tune(const char* name, int32_t value) {
   else if (strcmp(name, "agg_segs") == 0) slot = &k.segs;
   else if (strcmp(name, "agg_xcd_slices") == 0) slot = &k.xcd;
   else if (strcmp(name, "agg_occupancy") == 0) slot = &k.occ;
-  else if (strcmp(name, "agg_vec") == 0) slot = &k.vec;
   GLX_REQUIRE(slot != nullptr, "unknown knob '%s'", name);
   slot->store(value, std::memory_order_relaxed);
   return GLX_OK;
