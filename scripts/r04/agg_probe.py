@@ -2,6 +2,7 @@
 kernel at several rows-in-flight (agg_unroll) / segments-per-group (agg_segs) / XCD column slice settings, on
   real   : the C3 hop-2 request (16.4 M ids -> 1.64 M segments of 10, D = 256) and its hop-1 request (f = 25)
   l2     : the same shape with ids uniform over 2048 rows (2 MB: L2 resident) -- the non-memory floor
+  mall   : ids uniform over 100,000 rows (102 MB at D = 256: Infinity-Cache resident, far beyond the L2s) -- the fabric ceiling
   uniform: ids uniform over all 10 M rows (cache-free: algorithmic bytes == HBM traffic)
 Every variant's output is compared bit for bit with the legacy kernel's."""
 import os, sys
@@ -29,6 +30,7 @@ n1, _ = g.sample(smp, seeds, k1, seed=1, call_counter=0)
 n2, _ = g.sample(smp, n1.view(-1), k2, seed=1, call_counter=1)
 ids = {"real": n2.view(-1).contiguous(), "hop1": n1.view(-1).contiguous(),
        "l2": torch.randint(0, 2048, (Sg * k2,), generator=gen, device=dev),
+       "mall": torch.randint(0, 100_000, (Sg * k2,), generator=gen, device=dev),
        "uniform": torch.randint(0, V, (Sg * k2,), generator=gen, device=dev)}
 def t(name, reps=7):
     i, sg, out = (ids[name], B0, (emb1, cnt1)) if name == "hop1" else (ids[name], Sg, (emb, cnt))
@@ -57,15 +59,15 @@ specs = sys.argv[2].split(":") if len(sys.argv) > 2 else ["legacy", "default", "
 variants = [(sp, parse(sp)) for sp in specs]
 ref = {}
 print("# %s: D=%d, hop-2 fanout %d (%d segments), hop-1 fanout %d; median of 7 launches, ms" % (wl, D, k2, Sg, k1))
-print("%-22s %9s %9s %9s %9s  bit-identical" % ("variant", "real", "hop1", "l2", "uniform"))
+print("%-22s %9s %9s %9s %9s %9s  bit-identical" % ("variant", "real", "hop1", "l2", "mall", "uniform"))
 for label, kw in variants:
     setk(**kw)
     row, same = [], True
-    for name in ("real", "hop1", "l2", "uniform"):
+    for name in ("real", "hop1", "l2", "mall", "uniform"):
         ms, out = t(name)
         if name not in ref:
             ref[name] = out
         same = same and bool(torch.equal(out.view(torch.int32), ref[name].view(torch.int32)))
         row.append(ms)
-    print("%-22s %9.3f %9.3f %9.3f %9.3f  %s" % (label, *row, same), flush=True)
+    print("%-22s %9.3f %9.3f %9.3f %9.3f %9.3f  %s" % (label, *row, same), flush=True)
 setk()
