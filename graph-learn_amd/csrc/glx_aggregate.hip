@@ -90,6 +90,7 @@ struct AggArgs {
   int32_t fanout;
   float default_attr;
   int32_t col0, ncols;       // the columns [col0, col0 + ncols) this launch reduces (a column slice, or all)
+  int32_t store_mode;        // glx_aggregate_grp_kernel: 0 non-temporal output stores (default), 1 plain stores (ablation)
   int32_t segs_per_group;    // glx_aggregate_grp_kernel: consecutive segments one lane group reduces
   int32_t xcd_slices;        // glx_aggregate_grp_kernel: > 1 = workgroup b reduces column slice b % xcd_slices (ncols each)
   // further row sources of the distributed store (glx_dist.hip): virtual row r lives in
@@ -332,7 +333,14 @@ __global__ __launch_bounds__(256) void glx_aggregate_grp_kernel(AggArgs a) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = acc[v] / fn;
       }
-      if (col_ok) *reinterpret_cast<vec_t*>(a.emb_out + sg * (int64_t)a.dim + col) = acc;
+      if (col_ok) {
+        vec_t* dst = reinterpret_cast<vec_t*>(a.emb_out + sg * (int64_t)a.dim + col);
+        // the outputs are written once and never read by this launch: the non-temporal hint (round 4, A/B in
+        // profiles/r04/agg_probe_run8_nt_stores.txt: uniform rows -2.4 .. -5 %, the power-law requests -1 %, L2-resident -12 .. -20 %;
+        // `sc1` write-through stores: no gain).  GLX_AGG_STORE=1 restores plain stores.
+        if (a.store_mode == 1) *dst = acc;
+        else __builtin_nontemporal_store(acc, dst);
+      }
       if (c == 0 && col_pass == 0) a.cnt_out[sg] = n;
     }
   }
@@ -437,6 +445,7 @@ struct AggKnobs {
   std::atomic<int> segs{0};     // GLX_AGG_SEGS: segments per lane group (0 = chosen from fanout and grid size)
   std::atomic<int> xcd{0};      // GLX_AGG_XCD_SLICES=1|2|4|8: column slice = workgroup % n (XCD-affine); 0 = 2 for big requests
   std::atomic<int> occ{0};      // GLX_AGG_OCCUPANCY=3..7: workgroups per CU, capped with an unused LDS allocation
+  std::atomic<int> store{0};    // GLX_AGG_STORE=1: plain output stores instead of non-temporal ones (ablation)
 };
 
 AggKnobs& agg_knobs() {
@@ -454,6 +463,7 @@ AggKnobs& agg_knobs() {
     k.segs = env("GLX_AGG_SEGS");
     k.xcd = env("GLX_AGG_XCD_SLICES");
     k.occ = env("GLX_AGG_OCCUPANCY");
+    k.store = env("GLX_AGG_STORE");
   });
   return k;
 }
@@ -518,6 +528,7 @@ void launch_agg_grp(AggArgs a, int32_t num_ids, hipStream_t s) {
   if (S > G - 1) S = G - 1;  // lane j of the group holds the start of its j-th segment (and lane S the end)
   if (S < 1) S = 1;
   a.segs_per_group = S;
+  a.store_mode = agg_knobs().store.load(std::memory_order_relaxed);
   const int64_t groups = ((int64_t)a.num_segments + S - 1) / S;
   const int64_t blocks = (groups + (256 / G) - 1) / (256 / G) * (a.xcd_slices > 1 ? a.xcd_slices : 1);
   const unsigned grid = (unsigned)blocks;
@@ -836,6 +847,7 @@ extern "C" int glx_tune(const char* name, int32_t value) {
   else if (strcmp(name, "agg_segs") == 0) slot = &k.segs;
   else if (strcmp(name, "agg_xcd_slices") == 0) slot = &k.xcd;
   else if (strcmp(name, "agg_occupancy") == 0) slot = &k.occ;
+  else if (strcmp(name, "agg_store") == 0) slot = &k.store;
   GLX_REQUIRE(slot != nullptr, "unknown knob '%s'", name);
   slot->store(value, std::memory_order_relaxed);
   return GLX_OK;

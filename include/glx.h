@@ -775,7 +775,7 @@ GLX_API int glx_probe_bandwidth(int device, int kind, int64_t bytes, int64_t uni
  * process.  Each is read from the environment once (first use) and may be set here at any time; 0 restores the
  * product's default.  Names: "agg_mfma" (GLX_AGG_MFMA), "agg_unroll" (GLX_AGG_UNROLL), "agg_slices" (GLX_AGG_SLICES),
  * "agg_legacy" (GLX_AGG_LEGACY), "agg_segs" (GLX_AGG_SEGS), "agg_xcd_slices" (GLX_AGG_XCD_SLICES), "agg_occupancy"
- * (GLX_AGG_OCCUPANCY).  Results are
+ * (GLX_AGG_OCCUPANCY), "agg_store" (GLX_AGG_STORE).  Results are
  * bit-identical under every setting.  Unknown name: GLX_INVALID_ARGUMENT. */
 GLX_API int glx_tune(const char* name, int32_t value);
 

@@ -41,7 +41,7 @@ def t(name, reps=7):
         torch.cuda.synchronize(); glx.profile_enable(False)
         r.append(float(glx.profile_collect(glx.KERNEL_AGGREGATE).sum()))
     return float(np.median(r)), out[0].clone()
-KNOBS = ("agg_legacy", "agg_unroll", "agg_segs", "agg_xcd_slices", "agg_occupancy")
+KNOBS = ("agg_legacy", "agg_unroll", "agg_segs", "agg_xcd_slices", "agg_occupancy", "agg_store")
 def setk(**kw):
     for k in KNOBS:
         glx.tune(k, kw.get(k, 0))
@@ -53,6 +53,7 @@ def parse(spec):  # "x4,s1,u15" -> knobs
         elif tok[0] == "s": kw["agg_segs"] = int(tok[1:])
         elif tok[0] == "u": kw["agg_unroll"] = int(tok[1:])
         elif tok[0] == "o": kw["agg_occupancy"] = int(tok[1:])
+        elif tok[0] == "w": kw["agg_store"] = int(tok[1:])
     return kw
 specs = sys.argv[2].split(":") if len(sys.argv) > 2 else ["legacy", "default", "u6", "u8", "u10", "u12", "u15", "s1", "s2", "s3", "s6", "s12",
                                                          "x8", "x4", "x2", "legacy"]

@@ -10,7 +10,7 @@ from oracle_bindings import Oracle
 
 pytestmark = pytest.mark.gpu
 AGGREGATORS = ["SumAggregator", "MeanAggregator", "MaxAggregator", "MinAggregator", "ProdAggregator"]
-KNOBS = ("agg_legacy", "agg_unroll", "agg_segs", "agg_xcd_slices", "agg_occupancy", "agg_slices", "agg_mfma")
+KNOBS = ("agg_legacy", "agg_unroll", "agg_segs", "agg_xcd_slices", "agg_occupancy", "agg_store", "agg_slices", "agg_mfma")
 
 
 def beq(a, b):
@@ -29,7 +29,7 @@ def knobs():
 SHAPES = [dict(), dict(agg_legacy=1), dict(agg_xcd_slices=1), dict(agg_xcd_slices=2), dict(agg_xcd_slices=4),
           dict(agg_xcd_slices=8), dict(agg_segs=3), dict(agg_segs=7, agg_xcd_slices=2), dict(agg_unroll=6),
           dict(agg_unroll=8, agg_xcd_slices=4), dict(agg_unroll=12), dict(agg_unroll=15), dict(agg_occupancy=4),
-          dict(agg_slices=2)]
+          dict(agg_slices=2), dict(agg_store=1), dict(agg_store=1, agg_xcd_slices=2)]
 
 
 @pytest.mark.parametrize("D", [32, 64, 96, 128, 160, 256, 320, 512, 1024])
