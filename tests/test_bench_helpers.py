@@ -117,3 +117,20 @@ def test_cpu_baseline_runs_both_storage_modes_at_every_thread_count():
     assert r["cores"] in (1, 2) and r["storage_mode"] in (2, 3)
     c = bench.compact_cpu(r)
     assert set(c["modes"]) == {"2", "3"} and len(c["sample"]) <= 160 and c["storage_mode"] == r["storage_mode"]
+
+
+def test_bench_refuses_more_gpus_than_are_visible_with_one_json_line():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run -- unless the box
+    has fewer devices than asked for: then ONE JSON error line and a non-zero exit, never a 1-GPU number under an N-GPU
+    label.  Here (any box with fewer than 64 GPUs, this CPU container included)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--workload", "tiny", "--steps", "2"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["value"] is None and "--gpus 64" in res["error"] and res["n_gpus"] < 64 and res["metric"]
