@@ -95,7 +95,8 @@ def compact_roofline(r):
         out["hbm_bytes_bracket"] = [_num(float(x)) for x in r["hbm_bytes_bracket"]]
     cf = r.get("cache_free")
     if cf:
-        out["cache_free"] = _pick(cf, ("avg_launch_ms", "achieved", "frac", "frac_of_measured_stream_peak"))
+        out["cache_free"] = _pick(cf, ("avg_launch_ms", "achieved", "frac", "frac_of_measured_stream_peak",
+                                        "frac_of_measured_row_gather"))
     pk = r.get("peak_measured")
     if pk:
         out["peak_measured_gbs"] = {k: _num(v, 4) for k, v in pk.items() if isinstance(v, float)}
@@ -1663,7 +1664,11 @@ def main():
                               "table_gb": V * D * 4 / 1e9,
                               "infinity_cache_share_upper_bound": min(1.0, 0.256 / (V * D * 4 / 1e9)),
                               "avg_launch_ms": ms, "launches_timed": 5, "achieved": cf, "frac": cf / HBM_PEAK_GBS,
-                              "frac_of_measured_stream_peak": min(1.0, cf / best)}
+                              "frac_of_measured_stream_peak": min(1.0, cf / best),
+                              # the same bytes/s against what THIS box gives a bare gather of uniformly random rows (no ids,
+                              # no reduce, almost no output): HBM's random-access ceiling, which no row layout moves
+                              # (profiles/r04/layout_probe.txt); not clamped -- the probe gathers from <= 8 GB
+                              "frac_of_measured_row_gather": cf / peaks["gather_rows_%dB_uniform" % row_b]}
         # the roofline fraction of the kernel: same kernel, same request shape, measured in this run, on the input
         # where bytes moved are known exactly
         roof["frac"] = cf / HBM_PEAK_GBS

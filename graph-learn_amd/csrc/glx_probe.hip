@@ -193,9 +193,9 @@ extern "C" int glx_probe_bandwidth(int device, int kind, int64_t bytes, int64_t 
         const int64_t threads = groups * G;
         const unsigned grid = (unsigned)((threads + 255) / 256);
         const uint64_t nrows = (uint64_t)(bytes / unit_bytes);
-        if (G == 64) glx_probe_gather_rows_kernel<64, 6><<<grid, 256, 0, s>>>(a.as<f4>(), nrows, row_f4, groups, rows_per_group, salt, b.as<f4>());
-        else if (G == 32) glx_probe_gather_rows_kernel<32, 6><<<grid, 256, 0, s>>>(a.as<f4>(), nrows, row_f4, groups, rows_per_group, salt, b.as<f4>());
-        else glx_probe_gather_rows_kernel<16, 6><<<grid, 256, 0, s>>>(a.as<f4>(), nrows, row_f4, groups, rows_per_group, salt, b.as<f4>());
+        if (G == 64) glx_probe_gather_rows_kernel<64, 10><<<grid, 256, 0, s>>>(a.as<f4>(), nrows, row_f4, groups, rows_per_group, salt, b.as<f4>());
+        else if (G == 32) glx_probe_gather_rows_kernel<32, 10><<<grid, 256, 0, s>>>(a.as<f4>(), nrows, row_f4, groups, rows_per_group, salt, b.as<f4>());
+        else glx_probe_gather_rows_kernel<16, 10><<<grid, 256, 0, s>>>(a.as<f4>(), nrows, row_f4, groups, rows_per_group, salt, b.as<f4>());
         break;
       }
     }
