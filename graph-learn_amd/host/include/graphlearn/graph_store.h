@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "graphlearn/op_request.h"
 #include "graphlearn/status.h"
 
 struct glx_graph;
@@ -86,30 +87,51 @@ struct IndexOption {  // include/index_option.h
   std::string name;
 };
 
-// Minimal UpdateEdges/UpdateNodes requests so that fixtures read like the
-// reference's tests (sampler_unittest.cpp:33-70); they only carry values.
-class UpdateEdgesRequest {
+// "UpdateEdges" / "UpdateNodes" (include/graph_request.h:36-124, service/request/graph_update_request.cc): a batch of
+// records for ONE edge / node type, routed by source id / node id (shard keys kSrcIds / kNodeIds,
+// graph_update_request.cc:151,234) -- what the reference's loader threads send to the servers that own the records
+// (core/graph/graph_store.cc:210-250).  Records are held as values (the reference packs them into tensors for the
+// wire: shards here exchange device buffers, not messages); Append / Size / Next keep the reference's cursor surface.
+class UpdateEdgesRequest : public OpRequest {
 public:
+  UpdateEdgesRequest();
   UpdateEdgesRequest(const io::SideInfo* info, int32_t batch_size);
+  std::string Name() const override { return "UpdateEdges"; }
+  OpRequest* Clone() const override;
+  int32_t Size() const { return (int32_t)values_.size(); }
   void Append(const io::EdgeValue* value);
+  bool Next(io::EdgeValue* value);  // graph_update_request.cc:205-231
   const io::SideInfo& GetSideInfo() const { return info_; }
   const std::vector<io::EdgeValue>& Values() const { return values_; }
 private:
   io::SideInfo info_;
   std::vector<io::EdgeValue> values_;
+  int32_t cursor_ = 0;
 };
-class UpdateEdgesResponse {};
-class UpdateNodesRequest {
+class UpdateEdgesResponse : public OpResponse {
 public:
+  OpResponse* New() const override { return new UpdateEdgesResponse; }
+};
+class UpdateNodesRequest : public OpRequest {
+public:
+  UpdateNodesRequest();
   UpdateNodesRequest(const io::SideInfo* info, int32_t batch_size);
+  std::string Name() const override { return "UpdateNodes"; }
+  OpRequest* Clone() const override;
+  int32_t Size() const { return (int32_t)values_.size(); }
   void Append(const io::NodeValue* value);
+  bool Next(io::NodeValue* value);
   const io::SideInfo& GetSideInfo() const { return info_; }
   const std::vector<io::NodeValue>& Values() const { return values_; }
 private:
   io::SideInfo info_;
   std::vector<io::NodeValue> values_;
+  int32_t cursor_ = 0;
 };
-class UpdateNodesResponse {};
+class UpdateNodesResponse : public OpResponse {
+public:
+  OpResponse* New() const override { return new UpdateNodesResponse; }
+};
 
 // One edge type.  Host staging + device CSR.
 class Graph {

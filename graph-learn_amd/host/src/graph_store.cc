@@ -9,14 +9,28 @@
 
 namespace graphlearn {
 
-UpdateEdgesRequest::UpdateEdgesRequest(const io::SideInfo* info, int32_t batch_size) : info_(*info) {
+UpdateEdgesRequest::UpdateEdgesRequest() : OpRequest(kSrcIds) {}
+UpdateEdgesRequest::UpdateEdgesRequest(const io::SideInfo* info, int32_t batch_size) : OpRequest(kSrcIds), info_(*info) {
   values_.reserve(batch_size > 0 ? batch_size : 0);
 }
+OpRequest* UpdateEdgesRequest::Clone() const { return new UpdateEdgesRequest(&info_, Size()); }
 void UpdateEdgesRequest::Append(const io::EdgeValue* value) { values_.push_back(*value); }
-UpdateNodesRequest::UpdateNodesRequest(const io::SideInfo* info, int32_t batch_size) : info_(*info) {
+bool UpdateEdgesRequest::Next(io::EdgeValue* value) {
+  if (cursor_ >= Size()) return false;
+  *value = values_[cursor_++];
+  return true;
+}
+UpdateNodesRequest::UpdateNodesRequest() : OpRequest(kNodeIds) {}
+UpdateNodesRequest::UpdateNodesRequest(const io::SideInfo* info, int32_t batch_size) : OpRequest(kNodeIds), info_(*info) {
   values_.reserve(batch_size > 0 ? batch_size : 0);
 }
+OpRequest* UpdateNodesRequest::Clone() const { return new UpdateNodesRequest(&info_, Size()); }
 void UpdateNodesRequest::Append(const io::NodeValue* value) { values_.push_back(*value); }
+bool UpdateNodesRequest::Next(io::NodeValue* value) {
+  if (cursor_ >= Size()) return false;
+  *value = values_[cursor_++];
+  return true;
+}
 
 // ------------------------------------------------------------------ Graph --
 Graph::Graph(const std::string& type)
@@ -117,6 +131,9 @@ Status Graph::AppendColumns(const io::SideInfo& info, io::EdgeColumns* c) {
 
 Status Graph::UpdateEdges(const UpdateEdgesRequest* req, UpdateEdgesResponse*) {
   std::lock_guard<std::mutex> g(mtx_);
+  // the device CSR is built once from everything staged (graph_store.h): records that arrive later would be held
+  // on the host and never sampled, so they are refused instead
+  if (dev_) return error::InvalidArgument("edge type '" + type_ + "' is already built: UpdateEdges must precede Build()");
   SetSideInfo(&req->GetSideInfo());
   for (const auto& v : req->Values()) Add(&v);
   return Status::OK();
@@ -273,6 +290,7 @@ Status Noder::AppendColumns(const io::SideInfo& info, io::NodeColumns* c) {
 
 Status Noder::UpdateNodes(const UpdateNodesRequest* req, UpdateNodesResponse*) {
   std::lock_guard<std::mutex> g(mtx_);
+  if (dev_) return error::InvalidArgument("node type '" + type_ + "' is already built: UpdateNodes must precede Build()");
   SetSideInfo(&req->GetSideInfo());
   for (const auto& v : req->Values()) Add(&v);
   return Status::OK();

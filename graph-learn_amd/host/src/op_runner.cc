@@ -421,7 +421,6 @@ Status RunAggregating(Env* env, const AggregatingRequest* req, AggregatingRespon
 }  // namespace
 
 Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpResponse* res) {
-  (void)op;  // the owner's Process() is the kernel behind the distributed store
   if (!env || !env->Comm() || !env->Store()) return error::InvalidArgument("the runner has no communicator / store");
   std::lock_guard<std::mutex> one_request_at_a_time(env->RunMutex());
   if (auto* sreq = dynamic_cast<const SamplingRequest*>(req)) {
@@ -468,6 +467,25 @@ Status RunDistributed(Env* env, op::Operator* op, const OpRequest* req, OpRespon
     std::vector<int64_t> offsets((size_t)n + 1, 0);
     int rc = glx_dist_sample_full_sizes(st, dreq->NodeIds(), n, 0, dres->MutableDegrees(), offsets.data(), GLX_PTR_HOST, nullptr);
     return error::FromGlx(rc);
+  }
+  // "UpdateEdges" / "UpdateNodes": the reference partitions the batch by source id / node id and every server adds
+  // its part (graph_update_request.cc:151,234 + HashPartitioner).  SPMD: every server is handed the same batch and
+  // keeps the records it owns -- the same shards, without the records crossing a link.  Not a collective.
+  const auto owns = [env](int64_t id) {
+    const uint64_t a = id < 0 ? (uint64_t)0 - (uint64_t)id : (uint64_t)id;
+    return (int32_t)(a % (uint64_t)env->ServerCount()) == env->ServerId();
+  };
+  if (auto* ureq = dynamic_cast<const UpdateEdgesRequest*>(req)) {
+    UpdateEdgesRequest mine(&ureq->GetSideInfo(), ureq->Size());
+    for (const auto& v : ureq->Values())
+      if (owns(v.src_id)) mine.Append(&v);
+    return op->Process(&mine, res);
+  }
+  if (auto* ureq = dynamic_cast<const UpdateNodesRequest*>(req)) {
+    UpdateNodesRequest mine(&ureq->GetSideInfo(), ureq->Size());
+    for (const auto& v : ureq->Values())
+      if (owns(v.id)) mine.Append(&v);
+    return op->Process(&mine, res);
   }
   return error::Unimplemented("request '" + req->Name() + "' is shardable but not served across shards");
 }

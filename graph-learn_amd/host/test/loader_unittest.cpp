@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <memory>
 #include <string>
 
 #include "graphlearn/graphlearn.h"
@@ -259,6 +260,78 @@ TEST(LoaderTest, RejectsWhatTheReferenceRejects) {
   EXPECT_TRUE(g->GetEdgeIntAttrs(-1) == nullptr);
   std::remove("glx_bad_schema");
   std::remove("glx_bad_attr");
+}
+
+TEST(UpdaterTest, RecordsArriveThroughTheRegistry) {
+  // The reference's loader hands every batch of records to the operator registered as "UpdateEdges" / "UpdateNodes"
+  // (edge_updater.cc:25-55, node_updater.cc; graph_store.cc:210-250).  Same names, same request surface here.
+  GraphStore store;
+  op::OpFactory::GetInstance()->Set(&store);
+  io::SideInfo einfo;
+  einfo.type = "click";
+  einfo.src_type = "user";
+  einfo.dst_type = "item";
+  einfo.format = kWeighted | kLabeled;
+  UpdateEdgesRequest ereq(&einfo, 5);
+  for (int32_t i = 0; i < 5; ++i) {
+    io::EdgeValue v;
+    v.src_id = i;
+    v.dst_id = 100 + i;
+    v.weight = 0.5f * i;
+    v.label = i % 2;
+    ereq.Append(&v);
+  }
+  EXPECT_EQ(ereq.Name(), std::string("UpdateEdges"));
+  EXPECT_EQ(ereq.ShardKey(), std::string(kSrcIds));
+  EXPECT_TRUE(ereq.IsShardable());
+  EXPECT_EQ(ereq.Size(), 5);
+  op::Operator* eop = op::OpFactory::GetInstance()->Create("UpdateEdges");
+  EXPECT_TRUE(eop != nullptr);
+  std::unique_ptr<OpResponse> eres(RequestFactory::GetInstance()->NewResponse("UpdateEdges"));
+  EXPECT_TRUE(dynamic_cast<UpdateEdgesResponse*>(eres.get()) != nullptr);
+  EXPECT_TRUE(eop->Process(&ereq, eres.get()).ok());
+  EXPECT_TRUE(eop->Process(&ereq, eres.get()).ok());  // a second batch appends: edge id = arrival order
+  Graph* g = store.GetGraph("click");
+  EXPECT_EQ(g->GetEdgeCount(), (int64_t)10);
+  EXPECT_EQ(g->GetSrcId(7), (int64_t)2);
+  EXPECT_EQ(g->GetDstId(7), (int64_t)102);
+  EXPECT_FLOAT_EQ(g->GetEdgeWeight(3), 1.5f);
+  EXPECT_EQ(g->GetEdgeLabel(3), 1);
+  io::EdgeValue back;
+  int32_t seen = 0;
+  while (ereq.Next(&back)) {  // the cursor the reference's storages read a batch with (local_graph.cc:57-62)
+    EXPECT_EQ(back.src_id, (int64_t)seen);
+    ++seen;
+  }
+  EXPECT_EQ(seen, 5);
+
+  io::SideInfo ninfo;
+  ninfo.type = "user";
+  ninfo.format = kWeighted | kAttributed;
+  ninfo.f_num = 2;
+  std::unique_ptr<OpRequest> made(RequestFactory::GetInstance()->NewRequest("UpdateNodes"));
+  EXPECT_TRUE(dynamic_cast<UpdateNodesRequest*>(made.get()) != nullptr);
+  UpdateNodesRequest nreq(&ninfo, 3);
+  for (int32_t i = 0; i < 3; ++i) {
+    io::NodeValue v;
+    v.id = 10 + i;
+    v.weight = 1.0f + i;
+    v.attrs = {0.25f * i, -1.0f};
+    nreq.Append(&v);
+  }
+  EXPECT_EQ(nreq.ShardKey(), std::string(kNodeIds));
+  op::Operator* nop = op::OpFactory::GetInstance()->Create("UpdateNodes");
+  EXPECT_TRUE(nop != nullptr);
+  UpdateNodesResponse nres;
+  EXPECT_TRUE(nop->Process(&nreq, &nres).ok());
+  EXPECT_TRUE(nop->Process(&nreq, &nres).ok());  // duplicate ids are ignored (node_storage.h:41)
+  Noder* n = store.GetNoder("user");
+  EXPECT_EQ(n->GetNodeCount(), (int64_t)3);
+  EXPECT_FLOAT_EQ(n->GetWeight(12), 3.0f);
+  EXPECT_FLOAT_EQ(n->GetFloatAttrs(n->RowOf(11))[0], 0.25f);
+  // the wrong request type is an error, not a crash
+  EXPECT_TRUE(error::IsInvalidArgument(nop->Process(&ereq, &nres)));
+  EXPECT_TRUE(error::IsInvalidArgument(eop->Process(&nreq, eres.get())));
 }
 
 int main() { return RunAllTests(); }

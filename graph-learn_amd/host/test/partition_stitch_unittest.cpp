@@ -930,6 +930,100 @@ void RunRemainingOps(int P) {
 }
 }  // namespace
 
+// "UpdateEdges" / "UpdateNodes" behind DistributeRunner: the reference partitions a batch by source id / node id and
+// each server adds its part (graph_update_request.cc:151,234).  Here every server is handed the same batch and keeps
+// what it owns: the shards are disjoint, complete, in arrival order -- and a built type refuses further records.
+TEST(PartitionStitchTest, UpdateRequestsOnThreeServersKeepWhatEachOwns) {
+  const int P = 3;
+  GraphStore shard[P];
+  io::SideInfo einfo;
+  einfo.type = "e";
+  einfo.format = io::kWeighted;
+  io::SideInfo ninfo;
+  ninfo.type = "n";
+  ninfo.format = io::kAttributed;
+  ninfo.f_num = 2;
+  UpdateEdgesRequest ereq(&einfo, 200);
+  for (int e = 0; e < 200; ++e) {
+    io::EdgeValue v;
+    v.src_id = (e * 7) % 50 - 10;  // negative ids too: owner = llabs(id) % P
+    v.dst_id = e;
+    v.weight = 1.0f + e;
+    ereq.Append(&v);
+  }
+  UpdateNodesRequest nreq(&ninfo, 40);
+  for (int i = 0; i < 40; ++i) {
+    io::NodeValue v;
+    v.id = i - 5;
+    v.attrs = {(float)i, (float)-i};
+    nreq.Append(&v);
+  }
+  bool ok[P] = {true, true, true};
+  std::string why[P];
+  auto server = [&](int r) {
+    glx_comm* comm = nullptr;
+    if (glx_comm_init_local(77140, 0, r, P, &comm) != GLX_OK) {
+      ok[r] = false;
+      why[r] = glx_last_error();
+      return;
+    }
+    {
+      Env env(comm, &shard[r]);
+      std::unique_ptr<op::Operator> eop((*op::OpRegistry::GetInstance()->Lookup("UpdateEdges"))());
+      std::unique_ptr<op::Operator> nop((*op::OpRegistry::GetInstance()->Lookup("UpdateNodes"))());
+      eop->Set(&shard[r]);
+      nop->Set(&shard[r]);
+      UpdateEdgesResponse eres;
+      UpdateNodesResponse nres;
+      DistOpRunner erun(&env, r, eop.get()), nrun(&env, r, nop.get());
+      Status s = erun.Run(&ereq, &eres);
+      if (s.ok()) s = nrun.Run(&nreq, &nres);
+      if (s.ok()) {
+        IndexOption opt;
+        opt.name = "sort";
+        s = shard[r].Build(opt);
+      }
+      if (s.ok()) {  // after Build() the device storage is immutable: refused, not silently staged
+        Status late = erun.Run(&ereq, &eres);
+        if (!error::IsInvalidArgument(late)) s = error::Internal("an update after Build() was accepted");
+      }
+      if (!s.ok()) {
+        ok[r] = false;
+        why[r] = s.ToString();
+      }
+    }
+    glx_comm_destroy(comm);
+  };
+  std::vector<std::thread> th;
+  for (int r = 0; r < P; ++r) th.emplace_back(server, r);
+  for (auto& t : th) t.join();
+  int64_t edges = 0, nodes = 0;
+  for (int r = 0; r < P; ++r) {
+    if (!ok[r]) std::printf("  server %d: %s\n", r, why[r].c_str());
+    EXPECT_TRUE(ok[r]);
+    Graph* g = shard[r].GetGraph("e");
+    int64_t at = 0;
+    for (const auto& v : ereq.Values()) {
+      const int64_t a = v.src_id < 0 ? -v.src_id : v.src_id;
+      if (a % P != r) continue;
+      EXPECT_EQ(g->GetSrcId(at), v.src_id);  // edge id = arrival order within the shard
+      EXPECT_EQ(g->GetDstId(at), v.dst_id);
+      EXPECT_FLOAT_EQ(g->GetEdgeWeight(at), v.weight);
+      ++at;
+    }
+    EXPECT_EQ(g->GetEdgeCount(), at);
+    edges += at;
+    Noder* n = shard[r].GetNoder("n");
+    for (const auto& v : nreq.Values()) {
+      const int64_t a = v.id < 0 ? -v.id : v.id;
+      EXPECT_EQ(n->RowOf(v.id) >= 0, a % P == r);
+    }
+    nodes += n->GetNodeCount();
+  }
+  EXPECT_EQ(edges, (int64_t)200);
+  EXPECT_EQ(nodes, (int64_t)40);
+}
+
 TEST(PartitionStitchTest, FilteredFullInDegreesAndNegativeSamplersOnTwoServers) { RunRemainingOps(2); }
 TEST(PartitionStitchTest, FilteredFullInDegreesAndNegativeSamplersOnThreeServers) { RunRemainingOps(3); }
 TEST(PartitionStitchTest, FilteredFullInDegreesAndNegativeSamplersOnEightServers) { RunRemainingOps(8); }

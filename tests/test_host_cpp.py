@@ -47,7 +47,7 @@ def test_loader_unittest_on_cpu(tmp_path):
     r = subprocess.run([os.path.join(LIB, "loader_unittest")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout
-    assert "5 test(s), 0 failure(s)" in r.stdout, r.stdout
+    assert "6 test(s), 0 failure(s)" in r.stdout, r.stdout
 
 
 def test_request_unittest_on_cpu():
