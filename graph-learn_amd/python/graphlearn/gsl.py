@@ -117,6 +117,14 @@ class Step(object):
   def _evaluate(self, results):
     raise NotImplementedError
 
+  def _describe(self):
+    """(decoder, is_edge, is_sparse) of the value this step yields, or None when it is not a Nodes / Edges batch:
+    what graphlearn.nn.Dataset derives an alias' Data layout from (nn/dataset.py:52-57)."""
+    return None
+
+  def _node_kind(self, sparse=False):
+    return self._query.graph.get_node_decoder(self._vertex_type()), False, sparse
+
 
 class _VertexTraversals(object):
   """What can follow a step that yields vertices (dag_node.py TraverseVertexDagNode:462-530)."""
@@ -203,6 +211,9 @@ class VertexSource(Step, _VertexTraversals):
   def _evaluate(self, results):
     return self._sampler.get()
 
+  def _describe(self):
+    return self._node_kind()
+
 
 class EdgeSource(Step):
   """g.E(edge_type): batches of edges; outV() / inV() give their end points."""
@@ -245,6 +256,9 @@ class EdgeSource(Step):
   def _evaluate(self, results):
     return self._sampler.get()
 
+  def _describe(self):
+    return self._query.graph.get_edge_decoder(self._stored_edge_type()), True, False
+
 
 class EndpointStep(Step, _VertexTraversals):
   """The source or destination vertices of the edges an upstream step yields (dag_node.py:583-593, 633-645)."""
@@ -266,6 +280,10 @@ class EndpointStep(Step, _VertexTraversals):
     if offsets is not None:
       return self._query.graph.get_nodes(self._type, ids, offsets=offsets, shape=edges.dense_shape)
     return self._query.graph.get_nodes(self._type, ids, shape=edges.shape)
+
+  def _describe(self):
+    up = self._upstream._describe()  # pylint: disable=protected-access
+    return self._node_kind(sparse=bool(up and up[2]))
 
 
 class _Sampled(Step):
@@ -326,6 +344,9 @@ class NeighborStep(_Sampled, _VertexTraversals):
   def _evaluate(self, results):
     return self._layer(results).layer_nodes(1)
 
+  def _describe(self):
+    return self._node_kind(sparse=self._strategy == "full")
+
 
 class NeighborEdgeStep(NeighborStep):
   """outE / inE: the same hop, the sampled EDGES as the value; inV() / outV() then give their end points."""
@@ -341,6 +362,9 @@ class NeighborEdgeStep(NeighborStep):
 
   def _evaluate(self, results):
     return self._layer(results).layer_edges(1)
+
+  def _describe(self):
+    return self._query.graph.get_edge_decoder(self._stored), True, self._strategy == "full"
 
 
 class NegativeStep(_Sampled, _VertexTraversals):
@@ -382,6 +406,9 @@ class NegativeStep(_Sampled, _VertexTraversals):
     sampler = graph.negative_sampler(self._stored, self._count, strategy=self._strategy, conditional=True, **condition)
     return sampler.get(src, dst)
 
+  def _describe(self):
+    return self._node_kind()
+
 
 class WalkStep(Step, _VertexTraversals):
   """random_walk(edge_type, walk_len, p, q) -> Nodes [upstream size, walk_len]."""
@@ -397,6 +424,9 @@ class WalkStep(Step, _VertexTraversals):
     src = np.ascontiguousarray(results[self._upstream].ids.reshape(-1), dtype=np.int64)
     walks = self._query.graph.random_walk(self._edge_type, src, self._walk_len, p=self._p, q=self._q)
     return self._query.graph.get_nodes(self._vertex_type(), walks.reshape(-1), shape=(src.size, self._walk_len))
+
+  def _describe(self):
+    return self._node_kind()
 
 
 class SubGraphStep(Step):
