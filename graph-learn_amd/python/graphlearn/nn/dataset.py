@@ -18,11 +18,14 @@ _FEATS = ("int_attr_num", "float_attr_num", "string_attr_num", "labeled", "weigh
 
 class Dataset(object):
 
-  def __init__(self, query, window=10, batch_size=1, drop_last=False):
+  def __init__(self, query, window=10, batch_size=1, drop_last=False, fuse_hops=False, device=False):
+    """fuse_hops / device (new): gsl.Dataset's -- chains of dense hops as one engine call, and their values left on
+    the GPU: such an alias' ids and float_attrs are torch CUDA tensors (the gather of the float attributes runs on the
+    device too); any other column of it is looked up through the host as usual."""
     if not isinstance(query, gsl.Query) or query.values_func is None:
       raise ValueError("Dataset takes a GSL query that ends with .values()")
     self._dag = query
-    self._ds = gsl.Dataset(query, window=window, drop_last=drop_last)
+    self._ds = gsl.Dataset(query, window=window, drop_last=drop_last, fuse_hops=fuse_hops, device=device)
     self.batch_size = batch_size
     self.drop_last = drop_last
     self._masks = OrderedDict()
@@ -74,12 +77,24 @@ class Dataset(object):
       out.append(shaper(getattr(value, name)) if wanted else None)  # an unwanted column is never looked up
     return out
 
+  def _device_row(self, value, feat_masks):
+    other = [m for i, m in enumerate(feat_masks) if i != 1]
+    host = self._reformat_features(value.to_host(), [m and i != 1 for i, m in enumerate(feat_masks)]) if any(other) \
+        else [None] * 6
+    if feat_masks[1]:
+      floats = value.float_attrs
+      host[1] = floats.reshape(-1, floats.shape[-1])
+    return [v for v, m in zip(host + [value.ids.reshape(-1)], feat_masks + [True]) if m]
+
   def get_flatten_values(self):
     """The raw arrays of a batch, alias by alias, in the order build_data_dict consumes them."""
     values = self._ds.next()
     res = []
     for alias, (feat_masks, id_masks, sparse_masks) in self._masks.items():
       value = values[alias]
+      if hasattr(value, "to_host"):  # values.DeviceNodes: ids and float attributes never leave the GPU
+        res.extend(self._device_row(value, feat_masks))
+        continue
       row = self._reformat_features(value, feat_masks)
       if id_masks[1]:
         row.extend([np.asarray(value.src_ids).reshape(-1), np.asarray(value.dst_ids).reshape(-1)])

@@ -3,7 +3,8 @@ is {alias: Data of torch tensors}, or after as_dict() {alias: {name: tensor}} fo
 `induce_func(data_dict)` returns (the reference hands it to a PyG Data builder).  String attributes stay numpy arrays
 of bytes (torch has no string tensor); as_dict() leaves them out so that the default collate function works.
 
-`device="cuda"` moves every tensor to the GPU the engine runs on (the sampling itself already ran there).  The lazy /
+`device="cuda"`: every tensor on the GPU the engine runs on; chains of dense hops then run as ONE engine call and their
+ids and float attributes are produced there and never visit the host (gsl.Dataset fuse_hops + device).  The lazy /
 client-server constructor arguments of the reference (graph=, cluster=) belong to its RPC deploy modes and raise."""
 import numpy as np
 import torch as th
@@ -18,9 +19,11 @@ class Dataset(th.utils.data.IterableDataset):
     if graph is not None or cluster is not None:
       raise NotImplementedError("lazy initialisation against a running server is a client / server deploy mode; "
                                 "this engine runs in process (pass the query of an initialised Graph)")
-    self._rds = RawDataset(query, window=window)
-    self._induce_func = induce_func
     self._device = th.device(device) if device is not None else None
+    on_gpu = self._device is not None and self._device.type == "cuda"
+    # on the GPU: chains of dense hops run as one engine call and their ids / float attributes stay in HBM
+    self._rds = RawDataset(query, window=window, fuse_hops=on_gpu, device=on_gpu)
+    self._induce_func = induce_func
     self._format = lambda x: x
     self._client_id = 0
 
@@ -50,6 +53,8 @@ class Dataset(th.utils.data.IterableDataset):
   def _convert_func(self, data):
     if isinstance(data, dict):
       return {k: self._convert_func(v) for k, v in data.items()}
+    if isinstance(data, th.Tensor):
+      return data.to(self._device) if self._device is not None else data
     arr = np.asarray(data)
     if arr.dtype.kind in "OSU":  # strings
       return arr

@@ -139,5 +139,20 @@ def test_tensors_on_the_gpu(gl, graph):
     it = iter(thg.Dataset(q, device="cuda"))
     data = next(it)
     assert data["hop"].ids.is_cuda and data["hop"].float_attrs.is_cuda and list(data["hop"].ids.shape) == [64]
+    # a chain of two dense hops is ONE engine call whose values never visit the host; every column still arrives
+    q2 = graph.V("u").batch(16).alias("seed") \
+              .outV("u-i").sample(4).by("random").alias("h1") \
+              .outV("i-i").sample(3).by("random").alias("h2").values()
+    data = next(iter(thg.Dataset(q2, device="cuda")))
+    h1, h2 = data["h1"], data["h2"]
+    assert h1.ids.is_cuda and list(h1.ids.shape) == [64] and list(h2.ids.shape) == [192]
+    assert h2.float_attrs.is_cuda and list(h2.float_attrs.shape) == [192, 1]
+    assert h2.int_attrs.is_cuda and list(h2.int_attrs.shape) == [192, 2]  # host-resident column, moved over
+    torch.testing.assert_close(h2.float_attrs[:, 0], (h2.ids.clamp(min=0) * 0.1).float(), rtol=1e-6, atol=0)
+    # hop 1 really holds neighbours of the seeds: compare with the ordinary (host) path's adjacency
+    full = graph.neighbor_sampler("u-i", 0, strategy="full").get(data["seed"].ids.cpu().numpy()).layer_nodes(1)
+    rows = np.split(full.ids, np.cumsum(full.offsets)[:-1])
+    for r, got in zip(rows, h1.ids.cpu().numpy().reshape(16, 4)):
+        assert set(got.tolist()) <= set(r.tolist())
     with pytest.raises(NotImplementedError):
         thg.Dataset(q, graph=graph)
