@@ -96,6 +96,28 @@ def main():
     rows = B * (1 + 25 + 250)
     print("NeighborLoader: %.2f ms/batch  %.3g sampled edges/s + %.3g feature rows/s gathered (%d floats each), device resident"
           % (t_ld * 1e3, edges_per_step / t_ld, rows / t_ld, D))
+    # the same work as a GSL query read through graphlearn.nn.pytorch.Dataset (the reference's PyTorch entry:
+    # python/nn/pytorch/data/dataset.py): host values converted to tensors, and device="cuda" (fused chain in HBM)
+    import graphlearn.nn.pytorch as thg
+    for device, label in ((None, "host values -> torch.from_numpy"), ("cuda", "device='cuda': fused chain, ids + floats stay in HBM")):
+        q = g.V("v").batch(B).shuffle(traverse=True).alias("seed") \
+             .outV("e").sample(25).by("edge_weight").alias("hop1") \
+             .outV("e").sample(10).by("edge_weight").alias("hop2").values()
+        it = iter(thg.Dataset(q, device=device))
+        for _ in range(2):
+            data = next(it)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        nb = 0
+        for data in it:
+            rows_seen = data["hop2"].float_attrs.shape[0] + data["hop1"].float_attrs.shape[0]
+            nb += 1
+            if nb == (40 if device else 5):
+                break
+        torch.cuda.synchronize()
+        t_q = (time.time() - t0) / nb
+        print("nn.pytorch.Dataset (%s): %.2f ms/batch  %.3g sampled edges/s + %.3g feature rows/s"
+              % (label, t_q * 1e3, edges_per_step / t_q, rows_seen / t_q))
     g.close()
 
 
