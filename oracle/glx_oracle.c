@@ -185,6 +185,112 @@ void glxo_sort_rows_by_weight_desc(const int64_t* row_ptr, int64_t V, int64_t* c
 static int g_reference_cost_model = 0;
 void glxo_set_reference_cost_model(int on) { g_reference_cost_model = on; }
 
+/* ---- L1 entropy: the reference's own random variates ------------------------------------------------------------
+ * The reference draws from one thread_local std::mt19937 per sampler translation unit -- random_sampler.cc:46-47,
+ * random_without_replacement_sampler.cc:53-54, alias_method.cc:114-115 (shared by EdgeWeightSampler and
+ * InDegreeSampler) -- seeded once per thread from std::random_device and consumed request after request through
+ * libstdc++'s uniform_int_distribution<int>, std::shuffle and uniform_real_distribution<double>.  With
+ * glxo_set_reference_entropy(1, seed) glxo_sample takes its variates the same way, so that its outputs can be compared
+ * with oracle/_ref (the reference's own code, random_device pinned to `seed`) DRAW FOR DRAW instead of by
+ * distribution: everything in the row algorithms but the entropy source -- row lookup, default fill, the alias
+ * compare on the float-cast variate, both padders -- is then pinned exactly.  Restated from the published algorithms:
+ * MT19937 (Matsumoto & Nishimura 1998; its outputs are fixed by the C++ standard, [rand.predef]); Lemire's nearly
+ * divisionless bounded integers (arXiv:1805.10941) as libstdc++ 11 applies them to a 32-bit engine
+ * (bits/uniform_int_dist.h, _S_nd); its std::shuffle, which draws two swap positions from one variate while
+ * n * n <= 2^32 - 1 (bits/stl_algo.h); generate_canonical<double, 53> = (lo + hi * 2^32) / 2^64 (bits/random.tcc).
+ * The distributions are implementation-defined: this matches libstdc++ 11.4, the library oracle/_ref is built with.
+ * The contract path (Philox, one stream per row) is untouched by this switch and stays the HIP kernels' target. */
+typedef struct {
+  uint32_t mt[624];
+  int at;
+  int seeded;
+} ref_engine;
+
+static int g_ref_entropy = 0;
+static uint32_t g_ref_seed = 0;
+static ref_engine g_ref_eng[3]; /* 0: RandomSampler, 1: RandomWithoutReplacementSampler, 2: AliasMethod::Sample */
+
+void glxo_set_reference_entropy(int on, uint32_t seed) {
+  g_ref_entropy = on;
+  g_ref_seed = seed;
+  for (int e = 0; e < 3; ++e) g_ref_eng[e].seeded = 0; /* "a fresh thread": every engine seeds at its first use */
+}
+
+static uint32_t ref_next(ref_engine* g) {
+  if (!g->seeded) { /* std::mt19937 engine(rd()) */
+    g->mt[0] = g_ref_seed;
+    for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->at = 624;
+    g->seeded = 1;
+  }
+  if (g->at >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->at = 0;
+  }
+  uint32_t y = g->mt[g->at++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+/* uniform_int_distribution{0, range - 1} over a 32-bit engine, 1 <= range <= 2^32 - 1 */
+static uint32_t ref_uniform_below(ref_engine* g, uint32_t range) {
+  uint64_t product = (uint64_t)ref_next(g) * range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (uint32_t)(0u - range) % range;
+    while (low < threshold) {
+      product = (uint64_t)ref_next(g) * range;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
+}
+
+/* std::shuffle(a, a + n, engine) for n >= 1 */
+static void ref_shuffle(ref_engine* g, int64_t* a, int64_t n) {
+  const uint64_t urngrange = 0xffffffffu, un = (uint64_t)n;
+  int64_t i = 1, t;
+  if (urngrange / un >= un) {
+    if ((un % 2) == 0) {
+      const uint32_t pos = ref_uniform_below(g, 2);
+      t = a[i]; a[i] = a[pos]; a[pos] = t;
+      ++i;
+    }
+    while (i != n) {
+      const uint64_t swap_range = (uint64_t)i + 1;
+      const uint32_t x = ref_uniform_below(g, (uint32_t)(swap_range * (swap_range + 1)));
+      const uint64_t p0 = x / (swap_range + 1), p1 = x % (swap_range + 1);
+      t = a[i]; a[i] = a[p0]; a[p0] = t;
+      ++i;
+      t = a[i]; a[i] = a[p1]; a[p1] = t;
+      ++i;
+    }
+    return;
+  }
+  for (; i != n; ++i) { /* one position per variate: uniform_int_distribution{0, i} */
+    const uint32_t pos = ref_uniform_below(g, (uint32_t)i + 1u);
+    t = a[i]; a[i] = a[pos]; a[pos] = t;
+  }
+}
+
+/* uniform_real_distribution<double>{0, b}(engine) */
+static double ref_uniform_real(ref_engine* g, double b) {
+  double sum = 0.0, tmp = 1.0;
+  for (int k = 0; k < 2; ++k) {
+    sum += (double)ref_next(g) * tmp;
+    tmp *= 4294967296.0;
+  }
+  double ret = sum / tmp;
+  if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+  return ret * (b - 0.0) + 0.0;
+}
+
 static void fill_default(int64_t* nbr, int64_t* eid, int32_t k, int64_t def) {
   /* SamplingResponse::FillWith, sampling_request.cc:279-290 */
   for (int32_t j = 0; j < k; ++j) { nbr[j] = def; eid[j] = -1; }
@@ -241,8 +347,8 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
       case GLXO_RANDOM:
         /* random_sampler.cc:61-71 without a filter: k draws in [0, deg). */
         for (int32_t j = 0; j < k; ++j) {
-          int64_t d = (int64_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j),
-                                       (uint64_t)deg);
+          int64_t d = g_ref_entropy ? (int64_t)ref_uniform_below(&g_ref_eng[0], (uint32_t)deg)
+                                    : (int64_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j), (uint64_t)deg);
           nbr[j] = rn[d];
           eid[j] = re[d];
         }
@@ -252,7 +358,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
          * Pad.  Contract: forward Fisher-Yates, step j swaps a[j] with
          * a[j + bounded(draw_j, deg - j)]; only the first min(k, deg) steps
          * can influence the padded output, so only those are run. */
-        if (padding_mode != GLXO_PAD_CIRCULAR) {
+        if (padding_mode != GLXO_PAD_CIRCULAR && !g_ref_entropy) {
           pad_row(rn, re, deg, NULL, deg, k, padding_mode, default_neighbor_id, nbr, eid);
           break;
         }
@@ -262,6 +368,12 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
           perm = (int64_t*)malloc(sizeof(int64_t) * (size_t)perm_cap);
         }
         for (int64_t t = 0; t < deg; ++t) perm[t] = t;
+        if (g_ref_entropy) {
+          /* the reference shuffles the WHOLE index list whatever k and the padder are (and so advances its engine) */
+          ref_shuffle(&g_ref_eng[1], perm, deg);
+          pad_row(rn, re, deg, perm, deg, k, padding_mode, default_neighbor_id, nbr, eid);
+          break;
+        }
         int64_t msteps = deg < k ? deg : k;
         for (int64_t j = 0; j < msteps; ++j) {
           int64_t r = j + (int64_t)bounded(
@@ -295,8 +407,13 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
           alias = tmp_a;
         }
         for (int32_t j = 0; j < k; ++j) {
-          uint64_t u = glxo_draw64(seed, call_counter, rr, (uint32_t)j);
-          double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
+          double rd;
+          if (g_ref_entropy) {
+            rd = ref_uniform_real(&g_ref_eng[2], (double)(deg - 1));
+          } else {
+            uint64_t u = glxo_draw64(seed, call_counter, rr, (uint32_t)j);
+            rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
+          }
           float rnd = (float)rd;
           int32_t ix = (int32_t)rnd;
           idx[j] = (probs[ix] <= (rnd - ix)) ? alias[ix] : ix;

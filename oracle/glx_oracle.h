@@ -11,8 +11,12 @@
  * reference's own sources) and against the reference's known-answer tests
  * (tests/golden/); the random samplers are checked distributionally against
  * the reference because the reference itself is unseeded
- * (random_sampler.cc:46-47); so are the filtered samplers and the RandomWalk
- * operator (tests/golden/filtered.npz, walk.npz: the reference's own filter.cc /
+ * (random_sampler.cc:46-47) -- and, since round 4, DRAW FOR DRAW: with
+ * glxo_set_reference_entropy() the same row code consumes the reference's own
+ * variates (sequential MT19937 + libstdc++'s distributions) and its outputs
+ * equal oracle/_ref's bit for bit (tests/test_oracle_refseq.py); the filtered
+ * samplers and the RandomWalk operator are checked distributionally
+ * (tests/golden/filtered.npz, walk.npz: the reference's own filter.cc /
  * random_walk.cc built into oracle/_ref).
  */
 #ifndef GLX_ORACLE_H_
@@ -151,6 +155,14 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
  * structure of the reference (edge_weight_sampler.cc:78-92 calls AliasMethod's
  * constructor per row per request).  Results are unchanged. */
 void glxo_set_reference_cost_model(int on);
+
+/* L1 entropy (tests/test_oracle_refseq.py): when on, glxo_sample draws the way the reference does -- one sequential
+ * MT19937 per sampler source file, seeded with `seed` at its first use after this call, through libstdc++ 11's
+ * uniform_int_distribution / std::shuffle / uniform_real_distribution -- instead of the contract's per-row Philox
+ * streams (seed / call_counter / rng_rows are then ignored).  Outputs equal oracle/_ref's draw for draw when its
+ * random_device is pinned to the same seed and the requests are issued in the same order in one thread.  Not
+ * thread-safe (process-wide engines, like the mode switch).  See glx_oracle.c for the restated algorithms. */
+void glxo_set_reference_entropy(int on, uint32_t seed);
 
 /* Restates Aggregator::Aggregate (aggregator.cc:25-59) with the Sum/Mean/Max/
  * Min/Prod Init/Agg/Final functions.  feats is [V, dim] row-major; ids as in

@@ -213,6 +213,40 @@ int glref_sample(void* h, const char* edge_type, const char* strategy, const int
   return rc;
 }
 
+// `calls` consecutive requests of the same (strategy, src, k) in ONE fresh thread: the reference's thread_local
+// engines carry their state from one request to the next, which is what the outputs [calls][batch][k] show.
+// strategies = calls names separated by ',' (e.g. "EdgeWeightSampler,InDegreeSampler": the two share
+// AliasMethod::Sample's engine, alias_method.cc:114-115).
+int glref_sample_sequence(void* h, const char* edge_type, const char* strategies, const int64_t* src, int32_t batch,
+                          int32_t k, int32_t calls, int64_t* nbr_out, int64_t* eid_out) {
+  (void)h;
+  int rc = 0;
+  std::vector<std::string> names;
+  {
+    std::string all(strategies), cur;
+    for (char c : all) {
+      if (c == ',') { names.push_back(cur); cur.clear(); } else { cur.push_back(c); }
+    }
+    names.push_back(cur);
+  }
+  if (static_cast<int32_t>(names.size()) != calls) return -2;
+  RunMaybeFresh(1, [&]() {
+    for (int32_t c = 0; c < calls; ++c) {
+      SamplingRequest req(edge_type, names[c], k);
+      SamplingResponse res;
+      req.Set(src, batch);
+      op::Operator* op = op::OpFactory::GetInstance()->Create(req.Name());
+      if (!op) { rc = -1; return; }
+      Status s = op->Process(&req, &res);
+      if (!s.ok()) { rc = static_cast<int>(s.code()); return; }
+      size_t n = static_cast<size_t>(batch) * k;
+      memcpy(nbr_out + c * n, res.GetNeighborIds(), n * sizeof(int64_t));
+      memcpy(eid_out + c * n, res.GetEdgeIds(), n * sizeof(int64_t));
+    }
+  });
+  return rc;
+}
+
 int glref_aggregate(void* h, const char* node_type, const char* strategy, const int64_t* ids,
                     const int32_t* segs, int32_t num_ids, int32_t num_segments, float* emb_out,
                     int32_t* cnt_out, int32_t* dim_out) {

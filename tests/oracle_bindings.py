@@ -156,6 +156,12 @@ class Oracle:
         self.L.glxo_sort_rows_by_weight_desc(_p(row_ptr), row_ptr.shape[0] - 1, _p(col), _p(eid), _p(weight))
         return col, eid, weight
 
+    def set_reference_entropy(self, on, seed=0):
+        """L1 entropy: glxo_sample draws like the reference (sequential MT19937 per sampler file + libstdc++'s
+        distributions) from now on; process-wide, switch it off again."""
+        self.L.glxo_set_reference_entropy.argtypes = [ctypes.c_int, ctypes.c_uint32]
+        self.L.glxo_set_reference_entropy(1 if on else 0, seed)
+
     def sample(self, g, sampler, src, k, seed=0, call_counter=0, padding_mode=1, default_neighbor_id=0,
                rng_rows=None):
         """g: dict(row_ptr, col, eid, weight=None, alias=(prob, idx)|None, ids=None)."""
@@ -418,6 +424,18 @@ class RefLib:
         eid = np.zeros((batch, k), np.int64)
         rc = self.L.glref_sample(self.h, etype.encode(), strategy.encode(), _p(src), batch, k, _p(nbr), _p(eid),
                                  1 if fresh_thread else 0)
+        assert rc == 0, rc
+        return nbr, eid
+
+    def sample_sequence(self, etype, strategies, src, k):
+        """len(strategies) consecutive requests in ONE fresh thread (engines carry over) -> ([calls, batch, k]) x 2."""
+        batch, calls = src.shape[0], len(strategies)
+        nbr = np.zeros((calls, batch, k), np.int64)
+        eid = np.zeros((calls, batch, k), np.int64)
+        self.L.glref_sample_sequence.argtypes = [VP, ctypes.c_char_p, ctypes.c_char_p, VP, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_int32, VP, VP]
+        rc = self.L.glref_sample_sequence(self.h, etype.encode(), ",".join(strategies).encode(), _p(src), batch, k, calls,
+                                          _p(nbr), _p(eid))
         assert rc == 0, rc
         return nbr, eid
 
