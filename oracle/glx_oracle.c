@@ -208,12 +208,16 @@ typedef struct {
 
 static int g_ref_entropy = 0;
 static uint32_t g_ref_seed = 0;
-static ref_engine g_ref_eng[3]; /* 0: RandomSampler, 1: RandomWithoutReplacementSampler, 2: AliasMethod::Sample */
+/* one engine per reference source file that owns one: 0 random_sampler.cc, 1 random_without_replacement_sampler.cc,
+ * 2 alias_method.cc (EdgeWeight / InDegree samplers, the in-degree / node-weight negative samplers, node2vec),
+ * 3 random_negative_sampler.cc, 4 random_walk.cc (DeepWalk) */
+enum { ENG_RANDOM = 0, ENG_RWOR = 1, ENG_ALIAS = 2, ENG_RANDOM_NEGATIVE = 3, ENG_WALK = 4, ENG_COUNT = 5 };
+static ref_engine g_ref_eng[ENG_COUNT];
 
 void glxo_set_reference_entropy(int on, uint32_t seed) {
   g_ref_entropy = on;
   g_ref_seed = seed;
-  for (int e = 0; e < 3; ++e) g_ref_eng[e].seeded = 0; /* "a fresh thread": every engine seeds at its first use */
+  for (int e = 0; e < ENG_COUNT; ++e) g_ref_eng[e].seeded = 0; /* "a fresh thread": every engine seeds at its first use */
 }
 
 static uint32_t ref_next(ref_engine* g) {
@@ -291,6 +295,16 @@ static double ref_uniform_real(ref_engine* g, double b) {
   return ret * (b - 0.0) + 0.0;
 }
 
+/* The two places entropy enters a row algorithm.  u = the contract's 64-bit draw for this position (ignored under the
+ * reference's entropy, whose engines are sequential). */
+static inline int64_t int_variate(int eng, uint64_t u, uint64_t n) { /* uniform in [0, n) */
+  return g_ref_entropy ? (int64_t)ref_uniform_below(&g_ref_eng[eng], (uint32_t)n) : (int64_t)bounded(u, n);
+}
+static inline float alias_variate(uint64_t u, double b) { /* AliasMethod::Sample's `float rand` in [0, b] */
+  const double rd = g_ref_entropy ? ref_uniform_real(&g_ref_eng[ENG_ALIAS], b) : ((double)(u >> 11) * 0x1.0p-53) * b;
+  return (float)rd;
+}
+
 static void fill_default(int64_t* nbr, int64_t* eid, int32_t k, int64_t def) {
   /* SamplingResponse::FillWith, sampling_request.cc:279-290 */
   for (int32_t j = 0; j < k; ++j) { nbr[j] = def; eid[j] = -1; }
@@ -347,8 +361,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
       case GLXO_RANDOM:
         /* random_sampler.cc:61-71 without a filter: k draws in [0, deg). */
         for (int32_t j = 0; j < k; ++j) {
-          int64_t d = g_ref_entropy ? (int64_t)ref_uniform_below(&g_ref_eng[0], (uint32_t)deg)
-                                    : (int64_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j), (uint64_t)deg);
+          int64_t d = int_variate(ENG_RANDOM, glxo_draw64(seed, call_counter, rr, (uint32_t)j), (uint64_t)deg);
           nbr[j] = rn[d];
           eid[j] = re[d];
         }
@@ -370,7 +383,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
         for (int64_t t = 0; t < deg; ++t) perm[t] = t;
         if (g_ref_entropy) {
           /* the reference shuffles the WHOLE index list whatever k and the padder are (and so advances its engine) */
-          ref_shuffle(&g_ref_eng[1], perm, deg);
+          ref_shuffle(&g_ref_eng[ENG_RWOR], perm, deg);
           pad_row(rn, re, deg, perm, deg, k, padding_mode, default_neighbor_id, nbr, eid);
           break;
         }
@@ -407,14 +420,7 @@ int glxo_sample(const glxo_graph* g, int op, const int64_t* src, const int64_t* 
           alias = tmp_a;
         }
         for (int32_t j = 0; j < k; ++j) {
-          double rd;
-          if (g_ref_entropy) {
-            rd = ref_uniform_real(&g_ref_eng[2], (double)(deg - 1));
-          } else {
-            uint64_t u = glxo_draw64(seed, call_counter, rr, (uint32_t)j);
-            rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(deg - 1);
-          }
-          float rnd = (float)rd;
+          float rnd = alias_variate(glxo_draw64(seed, call_counter, rr, (uint32_t)j), (double)(deg - 1));
           int32_t ix = (int32_t)rnd;
           idx[j] = (probs[ix] <= (rnd - ix)) ? alias[ix] : ix;
         }
@@ -538,7 +544,7 @@ int glxo_random_walk(const glxo_graph* g, const int64_t* seeds, int32_t batch, i
         int64_t row = row_of(g->ids, &m, g->V, cur);
         int64_t s = row < 0 ? 0 : g->row_ptr[row];
         int64_t d = row < 0 ? 0 : g->row_ptr[row + 1] - s;
-        walk[t] = d == 0 ? default_neighbor_id : g->col[s + (int64_t)bounded(u, (uint64_t)d)];
+        walk[t] = d == 0 ? default_neighbor_id : g->col[s + int_variate(ENG_WALK, u, (uint64_t)d)];
         continue;
       }
       int64_t s = 0;
@@ -546,8 +552,7 @@ int glxo_random_walk(const glxo_graph* g, const int64_t* seeds, int32_t batch, i
       if (n == 0) { walk[t] = default_neighbor_id; continue; }
       float* probs = w + F;
       alias_build_row(w, n, probs, tab, tab + F, tab + 2 * F);
-      double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(n - 1);
-      float rnd = (float)rd;
+      float rnd = alias_variate(u, (double)(n - 1));
       int32_t ix = (int32_t)rnd;
       walk[t] = g->col[s + ((probs[ix] <= (rnd - ix)) ? tab[ix] : ix)];
     }
@@ -648,7 +653,8 @@ int glxo_sample_filtered(const glxo_graph* g, int op, const int64_t* src, const 
       if (all) { fill_default(nbr, eid, k, default_neighbor_id); continue; }
       for (int32_t j = 0; j < k; ++j) {
         for (uint32_t a = 0;; ++a) {
-          int32_t d = (int32_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j + a * (uint32_t)k), (uint64_t)deg);
+          int32_t d = (int32_t)int_variate(ENG_RANDOM, glxo_draw64(seed, call_counter, rr, (uint32_t)j + a * (uint32_t)k),
+                                           (uint64_t)deg);
           if (!filter_hit(f, i, rn, rt, d) || --retry < 0) {
             nbr[j] = rn[d];
             eid[j] = re[d];
@@ -666,7 +672,9 @@ int glxo_sample_filtered(const glxo_graph* g, int op, const int64_t* src, const 
     } else if (op == GLXO_RANDOM_WITHOUT_REPLACEMENT) {
       /* shuffle(reserved) under the contract's forward Fisher-Yates, then Pad */
       for (int32_t t = 0; t < cnt; ++t) idx[t] = res[t];
-      if (padding_mode == GLXO_PAD_CIRCULAR) {
+      if (g_ref_entropy) {
+        if (cnt > 0) ref_shuffle(&g_ref_eng[ENG_RWOR], idx, cnt); /* std::shuffle of an empty range draws nothing */
+      } else if (padding_mode == GLXO_PAD_CIRCULAR) {
         int32_t steps = cnt < k ? cnt : k;
         for (int32_t j = 0; j < steps; ++j) {
           int64_t r = j + (int64_t)bounded(glxo_draw64(seed, call_counter, rr, (uint32_t)j), (uint64_t)(cnt - j));
@@ -686,9 +694,7 @@ int glxo_sample_filtered(const glxo_graph* g, int op, const int64_t* src, const 
       float* probs = dist + maxdeg;
       alias_build_row(dist, cnt, probs, tab, tab + maxdeg, tab + 2 * maxdeg);
       for (int32_t j = 0; j < k; ++j) {
-        uint64_t u = glxo_draw64(seed, call_counter, rr, (uint32_t)j);
-        double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(cnt - 1);
-        float rnd = (float)rd;
+        float rnd = alias_variate(glxo_draw64(seed, call_counter, rr, (uint32_t)j), (double)(cnt - 1));
         int32_t ix = (int32_t)rnd;
         idx[j] = res[(probs[ix] <= (rnd - ix)) ? tab[ix] : ix];
       }
@@ -932,12 +938,11 @@ int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const
         uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)j);
         int64_t ix;
         if (prob) {
-          double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(U - 1);
-          float rnd = (float)rd;
+          float rnd = alias_variate(u, (double)(U - 1));
           int32_t k = (int32_t)rnd;
           ix = (prob[k] <= (rnd - k)) ? alias[k] : k;
         } else {
-          ix = (int64_t)bounded(u, (uint64_t)U);
+          ix = int_variate(ENG_RANDOM_NEGATIVE, u, (uint64_t)U);
         }
         out[(int64_t)i * count + j] = ids[ix];
       }
@@ -949,12 +954,11 @@ int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const
         for (int32_t j = 0; j < count; ++j) { /* am->Sample(n, indices) */
           uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, (uint32_t)(blk * count + j));
           if (prob) {
-            double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(U - 1);
-            float rnd = (float)rd;
+            float rnd = alias_variate(u, (double)(U - 1));
             int32_t k = (int32_t)rnd;
             indices[j] = (prob[k] <= (rnd - k)) ? alias[k] : k;
           } else {
-            indices[j] = (int32_t)bounded(u, (uint64_t)U);
+            indices[j] = (int32_t)int_variate(ENG_RANDOM_NEGATIVE, u, (uint64_t)U);
           }
         }
         ++blk;
@@ -1128,8 +1132,7 @@ static int cmp_keypos(const void* a, const void* b) {
 
 static int32_t alias_draw(uint64_t u, int64_t n, const float* prob, const int32_t* alias) {
   /* AliasMethod::Sample (alias_method.cc:117-121) */
-  double rd = ((double)(u >> 11) * 0x1.0p-53) * (double)(n - 1);
-  float rnd = (float)rd;
+  float rnd = alias_variate(u, (double)(n - 1));
   int32_t k = (int32_t)rnd;
   return (prob[k] <= (rnd - k)) ? alias[k] : k;
 }
@@ -1183,6 +1186,8 @@ int glxo_cond_negative_sample(const int64_t* ids, const float* weights, int64_t 
   i64set_init(&S, cap);
   if (batch_share) for (int32_t i = 0; i < batch; ++i) i64set_add(&S, dst[i]);
   int32_t* num_c = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ncols > 0 ? ncols : 1));
+  int32_t* block_ix = NULL;
+  int32_t block_cap = 0;
   for (int32_t i = 0; i < batch; ++i) {
     if (!batch_share) {
       if (g) {
@@ -1210,9 +1215,19 @@ int glxo_cond_negative_sample(const int64_t* ids, const float* weights, int64_t 
         int32_t got = 0;
         for (int32_t blk = 0; blk < retry && got < n; ++blk) {
           const int32_t look = (blk == retry - 1) ? 1 : n; /* the last block: its first entry only */
+          if (g_ref_entropy) {
+            /* am->Sample(num, indices) draws the WHOLE block before its entries are looked at (attribute_nodes_map.h:
+             * 111-116): a sequential engine moves on by n variates per started block, used or not.  (Under the contract
+             * every position has its own draw, so unused ones simply are not computed.) */
+            if (n > block_cap) {
+              block_cap = n;
+              block_ix = (int32_t*)realloc(block_ix, sizeof(int32_t) * (size_t)block_cap);
+            }
+            for (int32_t j = 0; j < n; ++j) block_ix[j] = alias_draw(0, b - a, gprob[c] + a, galias[c] + a);
+          }
           for (int32_t j = 0; j < look && got < n; ++j) {
             uint64_t u = glxo_draw64(seed, call_counter, (uint32_t)i, base + (uint32_t)(blk * n + j));
-            int32_t ix = alias_draw(u, b - a, gprob[c] + a, galias[c] + a);
+            int32_t ix = g_ref_entropy ? block_ix[j] : alias_draw(u, b - a, gprob[c] + a, galias[c] + a);
             int64_t item = ids[order[c][a + ix].pos];
             if (!i64set_has(&S, item)) {
               if (taken < count) orow[taken] = item;
@@ -1248,6 +1263,7 @@ int glxo_cond_negative_sample(const int64_t* ids, const float* weights, int64_t 
     for (; taken < count; ++taken) orow[taken] = default_neighbor_id;
   }
   free(num_c);
+  free(block_ix);
   i64set_free(&S);
   if (g && g->ids) idmap_free(&m);
   free(dprob); free(dalias); free(stack);

@@ -117,3 +117,159 @@ def test_the_contract_path_is_untouched_by_the_switch(orc, small):
     orc.set_reference_entropy(False)
     b = orc.sample(g, RANDOM, src, 4, seed=9, call_counter=2)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------- the other operators that draw: filters, negatives, walks ---
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FILTERS = {"id_eq": (1, 1), "id_gt": (2, 1), "ts_eq": (1, 2), "ts_gt": (2, 2)}  # (FilterType, FilterField)
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+@pytest.mark.parametrize("name", [RANDOM, RWOR, EDGE_WEIGHT, IN_DEGREE])
+def test_filtered_samplers_equal_the_reference_draw_for_draw(orc, name):
+    """op::Filter in front of the random samplers (a6): HitAll + the retry budget that is NOT reset between rows
+    (random_sampler.cc:50,65-70), ActOn's reserved list under std::shuffle / a per-row alias table -- every filter
+    kind, the reference's graph of tests/golden/filtered.npz (timestamped + weighted), 30 fresh requests each."""
+    g = _load("filtered.npz")
+    og = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"], ts_slot=g["ts_slot"])
+    og["indeg_weight"] = orc.in_degree_alias(og)[1]
+    ref = RefLib()
+    try:
+        ref.add_edges_timestamped("flt", g["src"], g["dst"], g["ts"], g["w"])
+        rng = np.random.default_rng(21)
+        for trial in range(30):
+            ids = rng.choice(g["rows"], 40)
+            kind = list(FILTERS)[trial % 4]
+            ft, ff = FILTERS[kind]
+            vals = rng.integers(898, 913, ids.shape[0]) if ff == 1 else \
+                rng.choice(g["ts"], ids.shape[0]) + rng.integers(-1, 2, ids.shape[0])
+            pad = 1 if name in (EDGE_WEIGHT, IN_DEGREE) else (trial // 4) % 2
+            ref.set_flags(pad, -3, 0.0)
+            flt = dict(type=ft, field=ff, values=vals.astype(np.int64), retry_times=int(rng.integers(0, 4)))
+            k = int(rng.integers(1, 9))
+            ref.set_seed(1000 + trial)
+            want = ref.sample_filtered("flt", name, ids, k, flt, fresh_thread=True)
+            orc.set_reference_entropy(True, 1000 + trial)
+            got = orc.sample_filtered(og, name, ids, k, flt, padding_mode=pad, default_neighbor_id=-3)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, trial, kind, pad, k)
+    finally:
+        ref.close()
+        orc.set_reference_entropy(False)
+
+
+@pytest.mark.parametrize("name,exclude,weighted", [("RandomNegativeSampler", 0, False),
+                                                   ("SoftInDegreeNegativeSampler", 0, True),
+                                                   ("InDegreeNegativeSampler", 1, True)])
+def test_negative_samplers_equal_the_reference_draw_for_draw(orc, name, exclude, weighted):
+    """One candidate list + one alias table per edge type (negative.npz: the reference's own), blocks of `count`
+    draws, accepted candidates in draw order, the exclusion set dropped from the 4th block."""
+    g = _load("negative.npz")
+    ref = RefLib()
+    try:
+        ref.add_edges("neg", g["src"], g["dst"], g["w"])
+        graph = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"])
+        table = (g["indeg_prob"], g["indeg_alias"]) if weighted else None
+        rng = np.random.default_rng(4)
+        for trial, count in enumerate((1, 3, 6, 17)):
+            src = rng.choice(g["rows"], 150)
+            ref.set_seed(50 + trial)
+            want = ref.negative_sample("neg", name, src, count, fresh_thread=True)
+            orc.set_reference_entropy(True, 50 + trial)
+            got = orc.negative_sample(g["dst_ids"], table, exclude, graph, src, count)
+            assert np.array_equal(got, want), (name, count)
+    finally:
+        ref.close()
+        orc.set_reference_entropy(False)
+
+
+def test_node_weight_negative_sampler_equals_the_reference_draw_for_draw(orc):
+    g = _load("negative.npz")
+    ref = RefLib()
+    try:
+        nid, nw = g["node_ids"], g["node_weights"]
+        ref.add_weighted_nodes("nw", nid, nw)
+        batch = nid[np.random.default_rng(1).integers(0, nid.shape[0], 80)]
+        for seed, count in ((9, 2), (10, 5), (11, 12)):
+            ref.set_seed(seed)
+            want = ref.negative_sample("nw", "NodeWeightNegativeSampler", batch, count, fresh_thread=True)
+            orc.set_reference_entropy(True, seed)
+            got = orc.negative_sample(nid, (g["node_prob"], g["node_alias"]), 2, None, batch, count)
+            assert np.array_equal(got, want), count
+    finally:
+        ref.close()
+        orc.set_reference_entropy(False)
+
+
+@pytest.mark.parametrize("p,q,full_nbr_num", [(1.0, 1.0, 100), (0.5, 2.0, 100), (4.0, 0.25, 3)])
+def test_random_walks_equal_the_reference_draw_for_draw(orc, p, q, full_nbr_num):
+    """RandomWalk (random_walk.cc): DeepWalk steps draw from the operator's own engine, node2vec steps build a biased
+    alias table per walker per step and draw through AliasMethod's.  Every vertex of this graph has out-edges (the
+    reference's cursor slip past stuck walkers, :214-226, is the one behaviour the restatement leaves out)."""
+    rng = np.random.default_rng(12)
+    V = 60
+    deg = rng.integers(1, 9, V)
+    src = np.repeat(np.arange(V, dtype=np.int64), deg)
+    dst = rng.integers(0, V, src.shape[0]).astype(np.int64)
+    w = (rng.random(src.shape[0]) * 0.9 + 0.05 + np.arange(src.shape[0]) * 2.0 ** -20).astype(np.float32)
+    ref = RefLib(default_neighbor_id=-3)
+    try:
+        ref.add_edges("walk", src, dst, w)
+        rows = np.arange(V, dtype=np.int64)
+        rp, col, eid, ws = ref.export_csr("walk", rows, 16)
+        og = dict(row_ptr=rp, col=col, eid=eid, weight=ws, ids=rows)
+        seeds = rng.integers(0, V, 120).astype(np.int64)
+        for seed in (3, 4):
+            ref.set_seed(seed)
+            want = ref.random_walk("walk", seeds, 6, p, q, full_nbr_num=full_nbr_num, fresh_thread=True)
+            orc.set_reference_entropy(True, seed)
+            got = orc.random_walk(og, seeds, 6, p=p, q=q, full_nbr_num=full_nbr_num, default_neighbor_id=-3)
+            assert np.array_equal(got, want), (p, q, seed)
+    finally:
+        ref.close()
+        orc.set_reference_entropy(False)
+
+
+@pytest.mark.parametrize("name,strategy,share,unique", [
+    ("random", "random", False, False), ("random_unique", "random", False, True), ("random_share", "random", True, False),
+    ("in_degree", "in_degree", False, False), ("node_weight", "node_weight", False, True)])
+def test_conditional_negative_sampler_equals_the_reference_draw_for_draw(orc, name, strategy, share, unique):
+    """ConditionalNegativeSampler (conditional_negative_sampler.cc, condition_table.cc, attribute_nodes_map.h): one
+    alias table per attribute group + the default table, every draw through AliasMethod::Sample's engine; 60 seeded
+    requests of the fixture tests/golden/cond_negative.npz was generated from.  Requests in which a condition column
+    comes up short are skipped: the reference's response is misaligned there (its fill loop is dead code, quirk 14)."""
+    from test_oracle_cond_negative import GOLD as CG, setup
+    cand, w, keys, dk, g, _ = setup(strategy)
+    props = np.concatenate([CG["int_props"], CG["float_props"], CG["str_props"]])
+    count = int(CG["count"])
+    ref = RefLib()
+    compared = 0
+    try:
+        ref.add_attr_nodes("item", CG["items"], weights=CG["item_w"], int_attrs=CG["int_attr"].reshape(-1, 1),
+                           float_attrs=CG["float_attr"].reshape(-1, 1), str_attrs=[[bytes(x)] for x in CG["str_attr"]])
+        ref.set_flags(1, 0, 0.0)
+        etype = "item"
+        if strategy != "node_weight":
+            etype = "buy_rs_" + name
+            ref.add_edges(etype, CG["src"], CG["dst"], None)
+        for t in range(60):
+            ref.set_seed(7000 + t)
+            want = ref.cond_neg_sample(etype, strategy, "item", CG["req_src"], CG["req_dst"], count, int_cols=[0],
+                                       int_props=CG["int_props"], float_cols=[0], float_props=CG["float_props"],
+                                       str_cols=[0], str_props=CG["str_props"], batch_share=share, unique=unique)
+            orc.set_reference_entropy(True, 7000 + t)
+            got, filled = orc.cond_negative_sample(cand, w, keys, props, g, CG["req_src"], CG["req_dst"], dk, count,
+                                                   batch_share=share, unique=unique, with_filled=True)
+            if want.shape[0] != CG["req_src"].shape[0] * count:
+                continue
+            assert np.all(filled == count)
+            assert np.array_equal(got.reshape(-1), want), (name, t)
+            compared += 1
+        assert compared >= 50
+    finally:
+        ref.close()
+        orc.set_reference_entropy(False)
