@@ -26,6 +26,7 @@ class Dataset(object):
       raise ValueError("Dataset takes a GSL query that ends with .values()")
     self._dag = query
     self._ds = gsl.Dataset(query, window=window, drop_last=drop_last, fuse_hops=fuse_hops, device=device)
+    self._device = bool(device)
     self.batch_size = batch_size
     self.drop_last = drop_last
     self._masks = OrderedDict()
@@ -77,10 +78,21 @@ class Dataset(object):
       out.append(shaper(getattr(value, name)) if wanted else None)  # an unwanted column is never looked up
     return out
 
-  def _device_row(self, value, feat_masks):
+  def _on_device(self, nodes):
+    import torch
+    from graphlearn.values import DeviceNodes
+    graph = self._dag.graph
+    dev = torch.device("cuda", graph.device_features(nodes.type).device)
+    ids = torch.from_numpy(np.ascontiguousarray(nodes.ids, dtype=np.int64)).to(dev)
+    return DeviceNodes(ids, nodes.type, graph)
+
+  def _device_row(self, value, feat_masks, host=None):
     other = [m for i, m in enumerate(feat_masks) if i != 1]
-    host = self._reformat_features(value.to_host(), [m and i != 1 for i, m in enumerate(feat_masks)]) if any(other) \
-        else [None] * 6
+    if any(other):
+      host = self._reformat_features(host if host is not None else value.to_host(),
+                                     [m and i != 1 for i, m in enumerate(feat_masks)])
+    else:
+      host = [None] * 6
     if feat_masks[1]:
       floats = value.float_attrs
       host[1] = floats.reshape(-1, floats.shape[-1])
@@ -94,6 +106,11 @@ class Dataset(object):
       value = values[alias]
       if hasattr(value, "to_host"):  # values.DeviceNodes: ids and float attributes never leave the GPU
         res.extend(self._device_row(value, feat_masks))
+        continue
+      if self._device and not id_masks[1] and not sparse_masks[-1] and feat_masks[1]:
+        # a host-produced vertex batch (source, end points, negatives, walks) in device mode: its float attributes
+        # are gathered on the GPU from the ids instead of being looked up through the host and copied twice
+        res.extend(self._device_row(self._on_device(value), feat_masks, host=value))
         continue
       row = self._reformat_features(value, feat_masks)
       if id_masks[1]:
