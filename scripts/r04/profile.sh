@@ -34,7 +34,7 @@ for wl in $WLS; do
   rm -rf $RAW/${wl}_trace
 done
 # before / after on the headline workload: same command, round-3 kernel (GLX_AGG_LEGACY=1) vs the grouped kernel
-if echo "$WLS" | grep -q c3; then
+if echo "$WLS" | grep -q c3 && [ -z "$SKIP_AB" ]; then  # SKIP_AB=1: traces and traffic passes only
   B="python $R/bench.py --workload c3 $LEAN --roofline-probes off --steps 5 --warmup 1"
   for variant in legacy grouped; do
     if [ $variant = legacy ]; then export GLX_AGG_LEGACY=1; else unset GLX_AGG_LEGACY; fi

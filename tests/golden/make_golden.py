@@ -672,6 +672,34 @@ def gen_cond_negative(ref):
     np.savez_compressed(os.path.join(OUT_DIR, "cond_negative.npz"), **out)
 
 
+def gen_refseq(ref):
+    """The reference's random samplers under a PINNED random_device (fixed_rd.h), each request in a thread of its own:
+    the draw-for-draw vectors tests/test_oracle_golden.py::test_refseq_golden holds the oracle's reference-entropy mode to
+    (tests/test_oracle_refseq.py does the same live, and wider, where oracle/_ref exists)."""
+    rng = np.random.default_rng(99)
+    degrees = np.array([0, 1, 2, 3, 4, 5, 8, 13, 16, 33, 64, 257, 0, 7, 1, 100, 70000])
+    src = np.repeat(np.arange(len(degrees), dtype=np.int64), degrees)
+    dst = rng.integers(0, 40, src.shape[0]).astype(np.int64)
+    w = (rng.random(src.shape[0]) * 0.9 + 0.05 + np.arange(src.shape[0]) * 2.0 ** -22).astype(np.float32)
+    ref.set_flags(1, -3, 0.0)
+    ref.add_edges("refseq", src, dst, w)
+    rows = np.flatnonzero(degrees > 0).astype(np.int64)
+    rp, col, eid, ws = ref.export_csr("refseq", rows, int(degrees.max()) + 1)
+    query = np.concatenate([np.arange(len(degrees) + 2, dtype=np.int64), rng.integers(0, len(degrees), 120)])
+    out = dict(rows=rows, row_ptr=rp, col=col, eid=eid, w_slot=ws, query=query, seeds=np.array([1, 20240923], np.int64),
+               ks=np.array([1, 4, 9], np.int64))
+    for name in ("RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "InDegreeSampler"):
+        for seed in out["seeds"]:
+            for k in out["ks"]:
+                ref.set_seed(int(seed))
+                n, e = ref.sample("refseq", name, query, int(k), fresh_thread=True)
+                out["%s_s%d_k%d_nbr" % (name, seed, k)] = n
+                out["%s_s%d_k%d_eid" % (name, seed, k)] = e
+    ref.set_seed(0)
+    ref.set_flags(1, 0, 0.0)
+    np.savez_compressed(os.path.join(OUT_DIR, "refseq.npz"), **out)
+
+
 def generate():
     ref = RefLib(storage_mode=2)
     gen_kat(ref)
@@ -688,6 +716,7 @@ def generate():
     gen_walk(ref)
     gen_subgraph(ref)
     gen_cond_negative(ref)
+    gen_refseq(ref)
     ref.close()
 
 

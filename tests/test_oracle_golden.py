@@ -641,3 +641,25 @@ def test_filtered_samplers_live_against_reference(orc):
                 assert all(np.array_equal(x, y) for x, y in zip(a, b)), (trial, kind)
     finally:
         ref.close()
+
+
+def test_refseq_golden(orc):
+    """The oracle's random samplers against the reference DRAW FOR DRAW, from committed vectors (refseq.npz: the
+    reference's own samplers with random_device pinned, make_golden.py::gen_refseq): with glxo_set_reference_entropy
+    the row code consumes a sequential MT19937 through libstdc++ 11's distributions (restated in glx_oracle.c) and
+    must reproduce every neighbour and edge id -- rows of degree 0 .. 257 and one of 70,000 (std::shuffle's
+    one-position-per-variate branch), unknown ids, k = 1, 4, 9.  tests/test_oracle_refseq.py widens this live."""
+    g = load("refseq.npz")
+    og = dict(row_ptr=g["row_ptr"], col=g["col"], eid=g["eid"], weight=g["w_slot"], ids=g["rows"])
+    og["alias"] = orc.alias_build(g["row_ptr"], g["w_slot"])
+    og["indeg_alias"] = orc.in_degree_alias(og)[0]
+    try:
+        for name in ("RandomSampler", "RandomWithoutReplacementSampler", "EdgeWeightSampler", "InDegreeSampler"):
+            for seed in g["seeds"]:
+                for k in g["ks"]:
+                    orc.set_reference_entropy(True, int(seed))
+                    n, e = orc.sample(og, name, g["query"], int(k), padding_mode=1, default_neighbor_id=-3)
+                    key = "%s_s%d_k%d" % (name, seed, k)
+                    assert np.array_equal(n, g[key + "_nbr"]) and np.array_equal(e, g[key + "_eid"]), key
+    finally:
+        orc.set_reference_entropy(False)
