@@ -469,8 +469,13 @@ class Dataset(object):
 
   _DENSE = ("random", "random_without_replacement", "topk", "in_degree", "edge_weight")
 
-  def __init__(self, query, window=10, drop_last=False, fuse_hops=False, device=False):
-    """device (new, with fuse_hops): the hops of a fused chain yield values.DeviceNodes -- ids, float attributes and
+  def __init__(self, query, window=10, drop_last=False, fuse_hops=False, device=False, prefetch=False):
+    """prefetch (new): produce batches ahead of next() on a background thread, up to `window` of them -- what the
+    reference's tapes do for a query (dag_dataset.py / core/dag/tape.h: the scheduler fills a bounded queue that
+    next() pops).  The engine calls release the GIL and run on the GPU, so sampling batch i + 1 overlaps whatever the
+    caller does with batch i; batches arrive in the order a plain next() would produce them, OutOfRangeError included
+    (one per epoch, the following next() belongs to the next epoch).  close() -- or garbage collection -- stops the thread.
+    device (new, with fuse_hops): the hops of a fused chain yield values.DeviceNodes -- ids, float attributes and
     aggregates as torch CUDA tensors that never visit the host (`.to_host()` gives the ordinary Nodes).  A step
     downstream of such a hop that is NOT part of the chain sees its upstream through .to_host().
     fuse_hops (new): a chain .outV(e1).sample(k1).by(s).outV(e2).sample(k2).by(s)... of dense, unfiltered hops with
@@ -488,6 +493,10 @@ class Dataset(object):
     self._device_values = bool(device)
     self._chains = self._find_chains() if fuse_hops else {}
     self._fused_calls = int.from_bytes(__import__("os").urandom(6), "little") << 8
+    self._prefetch = bool(prefetch) and self._window > 0
+    self._queue = None
+    self._thread = None
+    self._stop = None
 
   def _find_chains(self):
     """first step -> the steps of a fusable chain of two or more hops."""
@@ -527,6 +536,76 @@ class Dataset(object):
       rows *= step._count  # pylint: disable=protected-access
 
   def next(self):
+    if not self._prefetch:
+      return self._produce()
+    if self._thread is None:
+      self._start()
+    kind, item = self._queue.get()
+    if kind == "raise":
+      raise item
+    return item
+
+  # -- prefetching -----------------------------------------------------------------------------
+  def _start(self):
+    import queue
+    import threading
+    import weakref
+    self._queue = queue.Queue(maxsize=self._window)
+    self._stop = threading.Event()
+    self._thread = threading.Thread(target=Dataset._worker, args=(weakref.ref(self), self._queue, self._stop),
+                                    name="gsl-prefetch", daemon=True)
+    self._thread.start()
+
+  @staticmethod
+  def _worker(ref, out, stop):
+    import queue
+    from graphlearn.errors import OutOfRangeError
+    while not stop.is_set():
+      self = ref()
+      if self is None:
+        return
+      try:
+        item = ("value", self._produce())
+        if self._device_values:  # CUDA tensors cross to the consumer's thread: finish them first
+          import torch
+          torch.cuda.current_stream().synchronize()
+      except OutOfRangeError as e:
+        item = ("raise", e)  # the end of an epoch is an item of the stream; production goes on with the next epoch
+      except BaseException as e:  # pylint: disable=broad-except
+        item = ("raise", e)
+        stop.set()
+      del self
+      while True:
+        try:
+          out.put(item, timeout=0.1)
+          break
+        except queue.Full:
+          if stop.is_set():
+            return
+      if item[0] == "raise" and not isinstance(item[1], OutOfRangeError):
+        return
+
+  def close(self):
+    """Stops the prefetch thread (a no-op without one); batches already produced are dropped."""
+    if self._thread is not None:
+      self._stop.set()
+      while self._thread.is_alive():
+        try:
+          self._queue.get_nowait()
+        except Exception:  # pylint: disable=broad-except
+          pass
+        self._thread.join(timeout=0.05)
+      self._thread = None
+      self._queue = None
+
+  def __del__(self):
+    try:
+      if self._stop is not None:
+        self._stop.set()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def _produce(self):
     results = {}
     for step in self._query.steps:
       if step in results:  # a later hop of a fused chain

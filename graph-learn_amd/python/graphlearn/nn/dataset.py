@@ -18,14 +18,15 @@ _FEATS = ("int_attr_num", "float_attr_num", "string_attr_num", "labeled", "weigh
 
 class Dataset(object):
 
-  def __init__(self, query, window=10, batch_size=1, drop_last=False, fuse_hops=False, device=False):
+  def __init__(self, query, window=10, batch_size=1, drop_last=False, fuse_hops=False, device=False, prefetch=False):
     """fuse_hops / device (new): gsl.Dataset's -- chains of dense hops as one engine call, and their values left on
     the GPU: such an alias' ids and float_attrs are torch CUDA tensors (the gather of the float attributes runs on the
     device too); any other column of it is looked up through the host as usual."""
     if not isinstance(query, gsl.Query) or query.values_func is None:
       raise ValueError("Dataset takes a GSL query that ends with .values()")
     self._dag = query
-    self._ds = gsl.Dataset(query, window=window, drop_last=drop_last, fuse_hops=fuse_hops, device=device)
+    self._ds = gsl.Dataset(query, window=window, drop_last=drop_last, fuse_hops=fuse_hops, device=device,
+                           prefetch=prefetch)
     self._device = bool(device)
     self.batch_size = batch_size
     self.drop_last = drop_last
@@ -47,6 +48,9 @@ class Dataset(object):
         except OutOfRangeError:
           break
     return iterator()
+
+  def close(self):
+    self._ds.close()
 
   @property
   def iterator(self):

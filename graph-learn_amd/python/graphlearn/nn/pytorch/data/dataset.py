@@ -14,7 +14,7 @@ from graphlearn.nn.dataset import Dataset as RawDataset
 
 class Dataset(th.utils.data.IterableDataset):
 
-  def __init__(self, query, window=10, induce_func=None, graph=None, cluster=None, device=None):
+  def __init__(self, query, window=10, induce_func=None, graph=None, cluster=None, device=None, prefetch=False):
     super(Dataset, self).__init__()
     if graph is not None or cluster is not None:
       raise NotImplementedError("lazy initialisation against a running server is a client / server deploy mode; "
@@ -22,7 +22,8 @@ class Dataset(th.utils.data.IterableDataset):
     self._device = th.device(device) if device is not None else None
     on_gpu = self._device is not None and self._device.type == "cuda"
     # on the GPU: chains of dense hops run as one engine call and their ids / float attributes stay in HBM
-    self._rds = RawDataset(query, window=window, fuse_hops=on_gpu, device=on_gpu)
+    # prefetch: up to `window` batches are sampled ahead on a background thread (gsl.Dataset), overlapping the model step
+    self._rds = RawDataset(query, window=window, fuse_hops=on_gpu, device=on_gpu, prefetch=prefetch)
     self._induce_func = induce_func
     self._format = lambda x: x
     self._client_id = 0
@@ -49,6 +50,9 @@ class Dataset(th.utils.data.IterableDataset):
 
   def lazy_init(self):
     return False
+
+  def close(self):
+    self._rds.close()
 
   def _convert_func(self, data):
     if isinstance(data, dict):

@@ -156,3 +156,25 @@ def test_tensors_on_the_gpu(gl, graph):
         assert set(got.tolist()) <= set(r.tolist())
     with pytest.raises(NotImplementedError):
         thg.Dataset(q, graph=graph)
+
+
+def test_prefetching_dataset_yields_whole_epochs(gl, graph):
+    """prefetch=True: batches are sampled ahead on a background thread (the reference's `window`); every epoch still
+    visits every seed exactly once, tensors arrive complete on the GPU, and the iterator ends with the epoch."""
+    import torch
+    import graphlearn.nn.pytorch as thg
+    q = graph.V("u").batch(16).alias("seed") \
+             .outV("u-i").sample(4).by("random").alias("h1") \
+             .outV("i-i").sample(3).by("random").alias("h2").values()
+    ds = thg.Dataset(q, window=3, device="cuda", prefetch=True)
+    for _ in ds:  # the by-order cursor of a node type is the operator's, shared with the tests above: finish its epoch
+        pass
+    for epoch in range(2):
+        seen = []
+        for data in ds:
+            assert data["h2"].float_attrs.is_cuda and list(data["h2"].ids.shape) == [data["seed"].ids.shape[0] * 12]
+            torch.testing.assert_close(data["h2"].float_attrs[:, 0], (data["h2"].ids.clamp(min=0) * 0.1).float(),
+                                       rtol=1e-6, atol=0)
+            seen.extend(data["seed"].ids.cpu().tolist())
+        assert sorted(seen) == list(range(100)), epoch
+    ds.close()

@@ -258,3 +258,59 @@ def test_validation():
     bad.outV("sim").sample(2).by("random").filter("a").alias("c")
     with pytest.raises(ValueError):
         gl.Dataset(bad.values()).next()
+
+
+def test_prefetch_delivers_the_same_stream_ahead_of_time():
+    """Dataset(prefetch=True): a background thread fills a queue of `window` batches (the reference's tapes,
+    dag_dataset.py / core/dag/tape.h); what next() hands out -- batches, the OutOfRangeError that ends each epoch, the
+    epoch after it -- is the stream a plain Dataset produces, and close() / garbage collection stop the thread."""
+    import gc
+    import threading
+    import time
+
+    def stream(ds, n):
+        out = []
+        for _ in range(n):
+            try:
+                out.append(ds.next()["a"].ids.tolist())
+            except gl.OutOfRangeError:
+                out.append("end")
+        return out
+
+    def query(g):
+        return gsl.VertexSource(gsl.Query(g), "user").batch(4).alias("a") \
+                  .outV("buy").sample(3).by("topk").alias("b").values()
+    plain = stream(gl.Dataset(query(FakeGraph())), 9)
+    assert plain == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9], "end"] * 2 + [[0, 1, 2, 3]]
+    g = FakeGraph()
+    ds = gl.Dataset(query(g), window=2, prefetch=True)
+    assert ds.next()["a"].ids.tolist() == [0, 1, 2, 3]
+    deadline = time.time() + 5
+    while len([r for r in g.requests if r[0] == "nodes"]) < 3 and time.time() < deadline:
+        time.sleep(0.01)  # the worker runs ahead: batch 1 handed out, batches 2 and 3 already produced ...
+    time.sleep(0.05)
+    assert len([r for r in g.requests if r[0] == "nodes"]) in (3, 4)  # ... but no further than the window (+ one in hand)
+    assert [[0, 1, 2, 3]] + stream(ds, 8) == plain
+    ds.close()
+    assert not any(t.name == "gsl-prefetch" and t.is_alive() for t in threading.enumerate())
+    assert ds.next()["a"].ids.tolist() is not None  # a closed dataset starts a fresh worker on demand
+    ds.close()
+
+    # an error inside a step reaches the caller and ends production
+    class Broken(FakeGraph):
+        def neighbor_sampler(self, *a, **k):
+            raise RuntimeError("boom")
+    bad = gl.Dataset(query(Broken()), window=2, prefetch=True)
+    with pytest.raises(RuntimeError):
+        bad.next()
+    bad.close()
+
+    # dropping the last reference stops the worker too
+    ds2 = gl.Dataset(query(FakeGraph()), window=1, prefetch=True)
+    ds2.next()
+    del ds2
+    gc.collect()
+    deadline = time.time() + 5
+    while any(t.name == "gsl-prefetch" and t.is_alive() for t in threading.enumerate()) and time.time() < deadline:
+        time.sleep(0.02)
+    assert not any(t.name == "gsl-prefetch" and t.is_alive() for t in threading.enumerate())
