@@ -178,3 +178,18 @@ def test_prefetching_dataset_yields_whole_epochs(gl, graph):
             seen.extend(data["seed"].ids.cpu().tolist())
         assert sorted(seen) == list(range(100)), epoch
     ds.close()
+
+
+def test_training_example_learns_from_the_sampled_neighbourhoods():
+    """examples/train_sage_pytorch.py in a process of its own: a vertex of that graph is hard to classify from its own
+    16 noisy features and easy from its neighbourhood's, so two epochs well above what the features alone give (and far
+    above the 0.2 of chance) mean the sampled two-hop neighbourhoods, their attributes and the labels line up."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_sage_pytorch.py"), "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("epoch ")]
+    assert len(lines) == 2, r.stdout[-2000:]
+    acc = [float(ln.split("accuracy ")[1].split(",")[0]) for ln in lines]
+    loss = [float(ln.split("loss ")[1].split(",")[0]) for ln in lines]
+    assert acc[1] > 0.7 and acc[1] > acc[0] and loss[1] < loss[0], lines
