@@ -886,3 +886,82 @@ def test_dist_deepwalk_and_node2vec_equal_unpartitioned(world, P, monkeypatch):
         host = st.random_walk(seeds.cpu().numpy(), 3, p=2.0, q=0.5, seed=13, call_counter=9)
         assert np.array_equal(host, whole.random_walk(seeds, 3, p=2.0, q=0.5, seed=13, call_counter=9).cpu().numpy())
     _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_dist_store_fuzz_round4_ops(case, monkeypatch):
+    """Random shapes for the partitioned operations of round 4 -- filtered FullSampler (id and timestamp filters), in-degrees
+    of destination ids, the global negative tables and the three exclusion modes, DeepWalk and node2vec -- on graphs with
+    sparse, partly negative ids, more ranks than vertices, empty shards and empty requests: always against one store."""
+    monkeypatch.setenv("GLX_DIST_NO_SHORTCUT", "1")
+    rng = np.random.default_rng(4400 + case)
+    dev = torch.device("cuda", 0)
+    Vf = int(rng.choice([4, 40, 700]))
+    Ef = int(rng.integers(2, 14 * Vf))
+    P = int(rng.choice([1, 2, 3, 5, 8]))
+    names = rng.permutation(np.arange(-Vf, 3 * Vf))[:Vf].astype(np.int64) * 3 + 2
+    src = names[rng.integers(0, Vf, Ef)]
+    dst = names[rng.integers(0, max(1, Vf // int(rng.choice([1, 3]))), Ef)]  # sometimes few, hot destinations
+    weighted = bool(case % 2)
+    wgt = (rng.random(Ef) + 0.01 + np.arange(Ef) * 1e-7).astype(np.float32) if weighted else None
+    ts = rng.permutation(Ef).astype(np.int64)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    whole = glx.Graph.from_edges(t(src), t(dst), t(wgt), timestamp=t(ts))
+    whole.enable_negative()
+    uniq, cnt = np.unique(dst, return_counts=True)  # ascending ids + global in-degrees: the table every rank must hold
+    ref_u = glx.Negative(t(uniq))
+    ref_w = glx.Negative(t(uniq), t(cnt.astype(np.float32)))
+    indeg = dict(zip(uniq.tolist(), cnt.tolist()))
+    shards = []
+    for r in range(P):
+        own = (np.abs(src) % P) == r
+        g = glx.Graph.from_edges(t(src[own]), t(dst[own]), t(None if wgt is None else wgt[own]),
+                                 edge_ids=t(np.nonzero(own)[0].astype(np.int64)), timestamp=t(ts[own]))
+        g.enable_negative()
+        shards.append(g)
+    count = int(rng.choice([1, 4, 13]))
+    limit = int(rng.choice([0, 1, 5]))
+    pad = int(rng.integers(0, 2))
+    by_ts = bool(case % 3 == 0)
+    wl = int(rng.integers(1, 5))  # a walk is walk_len collectives: the same on every rank, like the request's limits
+    F = int(rng.choice([1, 3, 100]))
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=shards[r])
+        rr = np.random.default_rng(70 * case + r)
+        n = 0 if (P > 1 and r == 1 and case % 4 == 0) else int(rr.integers(1, 250))
+        ids = t(np.concatenate([names[rr.integers(0, Vf, n)], [1, -8][: min(n, 2)]]).astype(np.int64))
+        # filtered FullSampler
+        if by_ts:
+            vals = t(rr.integers(0, Ef, ids.shape[0]).astype(np.int64))
+            ft, ff = glx.FILTER_EQUAL, glx.FILTER_FIELD_TIMESTAMP
+        else:
+            vals = t(names[rr.integers(0, Vf, ids.shape[0])])
+            ft, ff = glx.FILTER_EQUAL, glx.FILTER_FIELD_ID
+        got = st.sample_full(ids, limit, filter_type=ft, filter_field=ff, values=vals, padding_mode=pad, default_neighbor_id=-5)
+        want = whole.sample_full_filtered(ids, limit, ft, ff, vals, padding_mode=pad, default_neighbor_id=-5)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), (case, r, "filtered full")
+        # in-degrees of destination ids
+        want_deg = torch.tensor([indeg.get(int(v), 0) for v in ids.cpu().tolist()], dtype=torch.int32, device=dev)
+        assert torch.equal(st.in_degrees(ids), want_deg.reshape(ids.shape)), (case, r, "in-degrees")
+        # global negative tables and all three exclusion modes
+        tu, tw = st.negative_table(False), st.negative_table(True)
+        assert np.array_equal(tu.export()[0], uniq) and np.array_equal(tw.export()[0], uniq), (case, r)
+        for tab, ref in ((tu, ref_u), (tw, ref_w)):
+            for mode in (glx.NEG_EXCLUDE_NONE, glx.NEG_EXCLUDE_NEIGHBORS, glx.NEG_EXCLUDE_BATCH):
+                a = st.negative_sample(tab, ids, count, exclude=mode, default_neighbor_id=-1, seed=case, call_counter=50 + r)
+                b = ref.sample(ids, count, exclude=mode, graph=whole, default_neighbor_id=-1, seed=case, call_counter=50 + r)
+                assert torch.equal(a, b), (case, r, mode, ref.weighted)
+        tu.close()
+        tw.close()
+        # walks
+        a = st.random_walk(ids, wl, default_neighbor_id=-1, seed=case, call_counter=9)
+        assert torch.equal(a, whole.random_walk(ids, wl, default_neighbor_id=-1, seed=case, call_counter=9)), (case, r, "deepwalk")
+        a = st.random_walk(ids, wl, p=0.5, q=3.0, default_neighbor_id=-1, seed=case, call_counter=30, full_nbr_num=F,
+                           default_weight=0.25)
+        b = whole.random_walk(ids, wl, p=0.5, q=3.0, full_nbr_num=F, default_weight=0.25, default_neighbor_id=-1, seed=case,
+                              call_counter=30)
+        assert torch.equal(a, b), (case, r, "node2vec", F)
+        st.close()
+    _run_ranks(P, body)
