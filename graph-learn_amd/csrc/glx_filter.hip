@@ -1180,7 +1180,13 @@ extern "C" int glx_sample_full_filtered(const glx_graph* g, const int64_t* src, 
   hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
   FilterDev f{filter->type, filter->field, filter->values, g->ts, filter->default_timestamp, filter->retry_times};
   if (ptr_kind == GLX_PTR_DEVICE) {
-    GLX_REQUIRE(nbr_out && eid_out, "NULL output pointer");
+    if (!nbr_out || !eid_out) {  // an empty response has no buffer to point at: fine when the (device) offsets agree
+      int64_t total = -1;
+      GLX_HIP(hipMemcpyAsync(&total, offsets + batch, 8, hipMemcpyDeviceToHost, s));
+      GLX_HIP(hipStreamSynchronize(s));
+      GLX_REQUIRE(total == 0, "NULL output pointer for a response of %lld values", (long long)total);
+      return GLX_OK;
+    }
     return filtered_device(g, kFullSampler, src, nullptr, batch, 0, offsets, padding_mode, default_neighbor_id, 0, 0,
                            f, nbr_out, eid_out, s);
   }

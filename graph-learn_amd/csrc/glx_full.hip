@@ -277,7 +277,15 @@ extern "C" int glx_sample_full(const glx_graph* g, const int64_t* src, int32_t b
   hipStream_t s = ptr_kind == GLX_PTR_HOST ? glx_host_call_stream(stream, g->device) : glx_stream(stream);
   const unsigned blocks = (unsigned)(((int64_t)batch * 64 + 255) / 256);
   if (ptr_kind == GLX_PTR_DEVICE) {
-    GLX_REQUIRE(nbr_out && eid_out, "NULL output pointer");
+    if (!nbr_out || !eid_out) {
+      // an EMPTY response has no buffer to point at (an empty tensor's data pointer is NULL): fine when the offsets
+      // agree -- they live on the device, so this one case costs a host wait
+      int64_t total = -1;
+      GLX_HIP(hipMemcpyAsync(&total, offsets + batch, 8, hipMemcpyDeviceToHost, s));
+      GLX_HIP(hipStreamSynchronize(s));
+      GLX_REQUIRE(total == 0, "NULL output pointer for a response of %lld values", (long long)total);
+      return GLX_OK;
+    }
     glx_full_copy_kernel<<<blocks, 256, 0, s>>>(g->map(), g->row_ptr, g->adj, src, batch, offsets, nbr_out,
                                                 eid_out);
     GLX_HIP(hipGetLastError());

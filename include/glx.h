@@ -194,7 +194,9 @@ GLX_API int glx_graph_enable_in_degree(glx_graph* g, void* stream);
  *   glx_sample_full_sizes  -> degrees_out[batch] (the segments) and
  *                             offsets_out[batch+1] (exclusive prefix sum; the last
  *                             entry is the total number of values);
- *   glx_sample_full        -> nbr_out / eid_out[offsets[batch]], row i at offsets[i]. */
+ *   glx_sample_full        -> nbr_out / eid_out[offsets[batch]], row i at offsets[i]
+ *                             (both may be NULL for an empty response, offsets[batch] == 0;
+ *                             glx_sample_full_filtered likewise). */
 GLX_API int glx_sample_full_sizes(const glx_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,
                           int32_t* degrees_out, int64_t* offsets_out, int ptr_kind, void* stream);
 GLX_API int glx_sample_full(const glx_graph* g, const int64_t* src, int32_t batch, int32_t max_limit,

@@ -888,7 +888,7 @@ def test_dist_deepwalk_and_node2vec_equal_unpartitioned(world, P, monkeypatch):
     _run_ranks(P, body)
 
 
-@pytest.mark.parametrize("case", range(20))
+@pytest.mark.parametrize("case", list(range(20)) + [299])
 def test_dist_store_fuzz_round4_ops(case, monkeypatch):
     """Random shapes for the partitioned operations of round 4 -- filtered FullSampler (id and timestamp filters), in-degrees
     of destination ids, the global negative tables and the three exclusion modes, DeepWalk and node2vec -- on graphs with

@@ -288,3 +288,22 @@ def test_alias_samplers_share_one_table_per_vertex_and_value(orc, kind, monkeypa
                 assert np.array_equal(per_row[0], want[0]) and np.array_equal(per_row[1], want[1]), (name, kind)
                 assert np.array_equal(shared[0], want[0]) and np.array_equal(shared[1], want[1]), (name, kind, cap)
     dev.close()
+
+
+def test_full_sampler_with_an_empty_response_on_device_pointers():
+    """Every requested vertex unknown or without out-edges: the response has no values and an empty tensor has no buffer
+    to point at (its data pointer is NULL) -- both FullSampler entry points accept that for device pointers too (the
+    offsets, which live on the device, say the response is empty)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    g = glx.Graph.from_edges(t(np.array([1, 1, 2], np.int64)), t(np.array([5, 6, 7], np.int64)),
+                             t(np.array([0.5, 0.25, 1.0], np.float32)), timestamp=t(np.array([3, 4, 5], np.int64)))
+    ids = t(np.array([5, 6, 99, -4], np.int64))  # destinations and strangers: no out-edges
+    deg, nbr, eid = g.sample_full(ids, 0)
+    assert deg.tolist() == [0, 0, 0, 0] and nbr.numel() == 0 and eid.numel() == 0
+    vals = t(np.array([5, 5, 5, 5], np.int64))
+    deg, nbr, eid = g.sample_full_filtered(ids, 3, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals)
+    assert deg.tolist() == [0, 0, 0, 0] and nbr.numel() == 0 and eid.numel() == 0
+    deg, nbr, eid = g.sample_full_filtered(ids.cpu().numpy(), 3, glx.FILTER_EQUAL, glx.FILTER_FIELD_ID, vals.cpu().numpy())
+    assert deg.tolist() == [0, 0, 0, 0] and nbr.size == 0
