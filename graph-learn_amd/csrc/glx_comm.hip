@@ -230,15 +230,24 @@ struct LocalFabric {
       cv.notify_all();
       return GLX_OK;
     }
-    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || broken; }) || broken) {
+    if (!cv.wait_for(lk, std::chrono::seconds(deadline_s()), [&] { return gen != g || broken; }) || broken) {
       broken = true;
       cv.notify_all();
       return fail();
     }
     return GLX_OK;
   }
+  // 120 s unless GLX_LOCAL_COMM_TIMEOUT_S says otherwise (read once; test rigs that expect failures shorten it)
+  static int deadline_s() {
+    static const int s = [] {
+      const char* e = getenv("GLX_LOCAL_COMM_TIMEOUT_S");
+      const int v = e ? atoi(e) : 0;
+      return v > 0 ? v : 120;
+    }();
+    return s;
+  }
   static int fail() {
-    glx_set_error("local communicator: a peer rank did not reach the collective within 120 s");
+    glx_set_error("local communicator: a peer rank did not reach the collective within %d s", deadline_s());
     return GLX_UNAVAILABLE;
   }
 };

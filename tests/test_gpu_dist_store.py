@@ -26,6 +26,14 @@ V, D = 5000, 64
 _KEY = [1000]
 
 
+def _fuzz_cases(n):
+    """The fuzz tests' case numbers: 0 .. n-1, or GLX_FUZZ_FIRST .. GLX_FUZZ_FIRST + GLX_FUZZ_CASES - 1 when a wider (or
+    different) sweep is asked for -- a thousand cases take well under a minute (set GLX_LOCAL_COMM_TIMEOUT_S=15 with it:
+    a failing rank then costs its peers 15 s of waiting instead of 120)."""
+    first = int(os.environ.get("GLX_FUZZ_FIRST", "0"))
+    return list(range(first, first + int(os.environ.get("GLX_FUZZ_CASES", str(n)))))
+
+
 def _fabric_key():
     _KEY[0] += 1
     return _KEY[0]
@@ -583,7 +591,7 @@ def test_rccl_transport_call_pattern_with_several_ranks(P):
     assert r.returncode == 0 and ("fake-rccl ok: world size %d" % P) in r.stdout, r.stdout[-4000:]
 
 
-@pytest.mark.parametrize("case", range(40))
+@pytest.mark.parametrize("case", _fuzz_cases(40))
 def test_dist_store_fuzz(case):
     """Random shapes the fixed cases do not reach: tiny graphs with more ranks than vertices, empty shards, empty
     requests on some ranks, hot sets from nothing to everything (with ids nobody knows), replicas on or off,
@@ -659,7 +667,7 @@ def test_dist_store_fuzz(case):
     _run_ranks(P, body)
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", _fuzz_cases(24))
 def test_dist_store_fuzz_sparse_ids_filters_in_degree(case):
     """The same idea on graphs with sparse, partly negative vertex ids (hashed id maps, owner = llabs(id) % P, the
     replica's hash-map form), built on the device from edge lists; requests with id == value filters;
@@ -888,7 +896,7 @@ def test_dist_deepwalk_and_node2vec_equal_unpartitioned(world, P, monkeypatch):
     _run_ranks(P, body)
 
 
-@pytest.mark.parametrize("case", list(range(20)) + [299])
+@pytest.mark.parametrize("case", _fuzz_cases(20) + [299])
 def test_dist_store_fuzz_round4_ops(case, monkeypatch):
     """Random shapes for the partitioned operations of round 4 -- filtered FullSampler (id and timestamp filters), in-degrees
     of destination ids, the global negative tables and the three exclusion modes, DeepWalk and node2vec -- on graphs with
