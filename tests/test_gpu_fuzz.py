@@ -2,6 +2,8 @@
 hypothesis, HIP path vs oracle, bit-exact.  Catches the corner cases the
 hand-written tables miss (k around sub-group widths, deg 0/1/2, duplicate
 queries, tiny dims, ragged segments, stalled cursors)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -12,7 +14,9 @@ from oracle_bindings import AGGREGATORS, SAMPLERS, Oracle
 
 pytestmark = pytest.mark.gpu
 ORC = Oracle()
-COMMON = dict(deadline=None, max_examples=200, suppress_health_check=list(HealthCheck))
+# GLX_FUZZ_SCALE=10 runs ten times the examples (a one-off wider sweep; the default keeps the suite short)
+SCALE = max(1, int(os.environ.get("GLX_FUZZ_SCALE", "1")))
+COMMON = dict(deadline=None, max_examples=200 * SCALE, suppress_health_check=list(HealthCheck))
 
 
 def beq(a, b):
@@ -54,7 +58,7 @@ def test_fuzz_samplers(seed, V, maxdeg, k, pad, hashed, nq, rng_seed, cc):
     assert np.array_equal(d, od) and np.array_equal(n, on) and np.array_equal(e, oe)
 
 
-@settings(**dict(COMMON, max_examples=120))
+@settings(**dict(COMMON, max_examples=120 * SCALE))
 @given(seed=st.integers(0, 2 ** 31 - 1), V=st.integers(1, 30), maxdeg=st.integers(0, 150), k=st.integers(1, 40),
        pad=st.integers(0, 1), ftype=st.integers(1, 2), ffield=st.integers(0, 2), retry=st.integers(0, 6),
        sorted_ts=st.booleans(), rng_seed=st.integers(0, 2 ** 63 - 1), indexed=st.booleans(), shared=st.booleans())
