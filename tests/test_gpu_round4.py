@@ -111,3 +111,51 @@ def test_default_launch_slices_a_big_request_and_stays_bit_identical(knobs):
 def test_unknown_knob_is_an_error():
     with pytest.raises(glx.GlxError):
         glx.tune("no_such_knob", 1)
+
+
+def _fuzz_cases(n):
+    import os
+    first = int(os.environ.get("GLX_FUZZ_FIRST", "0"))
+    return list(range(first, first + int(os.environ.get("GLX_FUZZ_CASES", str(n)))))
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(40))
+def test_launch_shape_fuzz(knobs, case):
+    """Random feature widths (1 .. 1100, aligned or not), segment layouts (dense fanouts and ragged, with empty and very
+    long segments), table sizes, id kinds and random settings of every launch knob at once -- against the oracle, bit
+    for bit, for the five aggregators."""
+    rng = np.random.default_rng(8800 + case)
+    D = int(rng.choice([1, 3, 4, 8, 20, 32, 60, 64, 100, 128, 132, 256, 260, 384, 512, 1000, 1024, 1100]))
+    V = int(rng.choice([1, 7, 300, 5000]))
+    X = (rng.standard_normal((V, D)) * 3).astype(np.float32)
+    X[rng.random((V, D)) < 0.03] = -60.0
+    hashed = bool(rng.integers(0, 2))
+    raw = (rng.permutation(V * 4)[:V] - V).astype(np.int64)
+    pool = raw if hashed else np.arange(V, dtype=np.int64)
+    if rng.integers(0, 2):  # a dense sampler response: uniform fanout, no segment ids
+        Sg = int(rng.choice([1, 5, 257, 3000]))
+        fan = int(rng.choice([1, 2, 9, 10, 11, 25, 63, 64, 65, 200]))
+        seg, n = None, Sg * fan
+        seg_np = np.repeat(np.arange(Sg, dtype=np.int32), fan)
+    else:
+        Sg = int(rng.choice([1, 4, 300]))
+        sizes = rng.integers(0, int(rng.choice([3, 15, 90])), Sg)
+        if Sg > 2:
+            sizes[int(rng.integers(0, Sg))] = int(rng.choice([0, 129, 1500]))
+        seg_np = np.repeat(np.arange(Sg, dtype=np.int32), sizes)
+        seg, n = seg_np, int(seg_np.shape[0])
+    nid = pool[rng.integers(0, V, n)].copy() if n else np.zeros(0, np.int64)
+    nid[rng.random(n) < 0.04] = 10 ** 9 + 7  # unknown ids: the default row
+    shape = dict(agg_legacy=int(rng.random() < 0.15), agg_unroll=int(rng.choice([0, 6, 8, 10, 12, 15])),
+                 agg_segs=int(rng.choice([0, 0, 1, 2, 5, 12])), agg_xcd_slices=int(rng.choice([0, 1, 2, 4, 8])),
+                 agg_occupancy=int(rng.choice([0, 0, 3, 6])), agg_store=int(rng.integers(0, 2)),
+                 agg_slices=int(rng.choice([0, 0, 2, 4])))
+    knobs(**shape)
+    f = glx.Features(X, ids=(raw if hashed else None))
+    orc = Oracle()
+    dflt = float(rng.choice([0.0, -1.5, 7.25]))
+    for name in AGGREGATORS:
+        want = orc.aggregate(X, name, nid, seg_np, Sg, dflt, ids=(raw if hashed else None))
+        emb, cnt = f.aggregate(name, nid, seg, Sg, default_attr=dflt)
+        assert np.array_equal(cnt, want[1]), (case, name, D, shape)
+        assert beq(emb, want[0]), (case, name, D, shape)
