@@ -830,7 +830,12 @@ def test_alias_tables_fuzz_bit_exact():
     assert bad.size == 0, ("first mismatch in row", int(np.searchsorted(rp, bad[0], side="right") - 1), int(bad.size))
 
 
-@pytest.mark.parametrize("case", range(10))
+def _fuzz_cases(n):
+    first = int(os.environ.get("GLX_FUZZ_FIRST", "0"))
+    return list(range(first, first + int(os.environ.get("GLX_FUZZ_CASES", str(n)))))
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(10))
 def test_request_plan_fuzz(case):
     """Plans of random shape -- 1 to 3 hops, odd fanouts and batches (1 seed included), feature widths that are not a
     multiple of 4, either padding, with and without the aggregation -- replayed several times, against separate calls."""
