@@ -98,9 +98,9 @@ def test_subgraph_pipeline_equals_the_reference_golden(case, kind):
 
 
 def test_subgraph_induce_fuzz_equals_oracle():
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + int(_os.environ.get("GLX_FUZZ_FIRST", "0")))
     orc = Oracle()
-    for trial in range(30):
+    for trial in range(30 * max(1, int(_os.environ.get("GLX_FUZZ_CASES", "12")) // 12)):
         n = int(rng.integers(1, 400))
         ids_hi = int(rng.choice([n // 2 + 1, n * 4]))  # dense (many matches, duplicate nodes) or sparse
         nodes = rng.integers(-3, ids_hi, n).astype(np.int64)
@@ -147,7 +147,12 @@ def _cond_case(rng, U, ncols, n_users, deg, batch, hashed_ids):
     return items, weights, keys, dict(row_ptr=rp, col=dst, eid=np.arange(dst.shape[0], dtype=np.int64)), req_src, req_dst, dk
 
 
-@pytest.mark.parametrize("trial", range(12))
+def _fuzz_cases(n):
+    first = int(_os.environ.get("GLX_FUZZ_FIRST", "0"))
+    return list(range(first, first + int(_os.environ.get("GLX_FUZZ_CASES", str(n)))))
+
+
+@pytest.mark.parametrize("trial", _fuzz_cases(12))
 @pytest.mark.parametrize("rows", ["parallel", "sequential"])
 def test_conditional_negative_sampler_is_bit_identical_to_the_oracle(trial, rows, monkeypatch):
     """rows: without `unique` the rows of a request are sampled one wave each against the first-insertion table
