@@ -204,3 +204,64 @@ def test_a_rank_with_a_shorter_tail_batch_speculates_along_with_its_peers(world,
         lg.close()
         st.close()
     _run_ranks(P, body)
+
+
+def _fuzz_cases(n):
+    import os
+    first = int(os.environ.get("GLX_FUZZ_FIRST", "0"))
+    return list(range(first, first + int(os.environ.get("GLX_FUZZ_CASES", str(n)))))
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(12))
+def test_ledger_fuzz_ragged_windows(world, case):
+    """Windows of 1-3 speculated hops closed by a confirmation, with request lengths that differ from rank to rank and
+    from step to step -- empty requests, tails, requests several times longer than anything the position has seen (an
+    overflow: GLX_ABORTED on EVERY rank, the window is repeated until it fits).  Every rank issues the same sequence
+    of calls; what each ends up with equals the unpartitioned operator's answer, and nobody waits for a collective a
+    peer never enters."""
+    whole, dev = world["whole"], world["dev"]
+    rng = np.random.default_rng(6200 + case)
+    P = int(rng.choice([2, 3, 8]))
+    gs, _ = world["shards"][P]
+    hops = int(rng.integers(1, 4))
+    fan = [int(x) for x in rng.choice([1, 2, 5, 10], hops)]
+    steps = int(rng.integers(3, 7))
+    names = [str(x) for x in rng.choice(["RandomSampler", "EdgeWeightSampler", "TopkSampler", "RandomWithoutReplacementSampler"], hops)]
+    base = int(rng.choice([40, 600, 2500]))
+    # lengths[step][rank]: mostly around `base`, sometimes empty, sometimes several times longer
+    lengths = []
+    for i in range(steps):
+        row = []
+        for r in range(P):
+            u = rng.random()
+            row.append(0 if u < 0.12 else int(base * rng.integers(3, 7)) if u > 0.9 else int(rng.integers(1, base + 1)))
+        lengths.append(row)
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r])
+        lg = glx.Ledger(0).attach(st)
+        for i in range(steps):
+            rr = np.random.default_rng(97 * case + 13 * i + r)
+            src = torch.from_numpy(rr.integers(-2, V + 2, lengths[i][r]).astype(np.int64)).to(dev)
+            for attempt in range(8):
+                try:
+                    cur, outs = src, []
+                    for h in range(hops):
+                        n, e = st.sample(names[h], cur, fan[h], seed=case, call_counter=10 * i + h, default_neighbor_id=-1)
+                        outs.append((n, e))
+                        cur = n.view(-1)
+                    st.confirm()
+                    break
+                except glx.GlxError as ex:
+                    assert ex.code == glx.ABORTED, str(ex)  # on every rank alike: all repeat the window
+            else:
+                raise AssertionError("the window never fitted")
+            cur = src
+            for h in range(hops):
+                wn, we = whole.sample(names[h], cur, fan[h], seed=case, call_counter=10 * i + h, default_neighbor_id=-1)
+                assert torch.equal(outs[h][0], wn) and torch.equal(outs[h][1], we), (case, r, i, h)
+                cur = wn.view(-1)
+        assert lg.stats()["holding"] == 0
+        lg.close()
+        st.close()
+    _run_ranks(P, body)
