@@ -273,3 +273,42 @@ def test_conditional_negative_sampler_equals_the_reference_draw_for_draw(orc, na
     finally:
         ref.close()
         orc.set_reference_entropy(False)
+
+
+def _fuzz_cases(n):
+    first = int(os.environ.get("GLX_FUZZ_FIRST", "0"))
+    return list(range(first, first + int(os.environ.get("GLX_FUZZ_CASES", str(n)))))
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(12))
+def test_reference_entropy_fuzz(orc, case):
+    """Random graphs (degree 0 .. 300, a few hubs of thousands), random sequences of 1-5 requests of random samplers, k,
+    seeds and padding in ONE reference thread -- the oracle under the reference's entropy must reproduce every id."""
+    rng = np.random.default_rng(31000 + case)
+    V = int(rng.integers(1, 60))
+    degrees = rng.integers(0, int(rng.choice([3, 12, 300])), V)
+    if rng.random() < 0.3:
+        degrees[int(rng.integers(0, V))] = int(rng.integers(1000, 9000))
+    if degrees.sum() == 0:
+        degrees[0] = 1
+    ref, g = _graph(case, [int(d) for d in degrees], "fz%d" % case)
+    try:
+        g["alias"] = orc.alias_build(g["row_ptr"], g["weight"])
+        g["indeg_alias"] = orc.in_degree_alias(g)[0]
+        pad = int(rng.integers(0, 2))
+        ref.set_flags(padding_mode=pad, default_neighbor_id=-3)
+        pool = [RANDOM, RWOR] if pad == 0 else [RANDOM, RWOR, EDGE_WEIGHT, IN_DEGREE]  # quirk 3: see above
+        order = [str(x) for x in rng.choice(pool, int(rng.integers(1, 6)))]
+        k = int(rng.integers(1, 40))
+        src = rng.integers(-1, V + 1, int(rng.integers(1, 80))).astype(np.int64)
+        seed = int(rng.integers(0, 2 ** 32))
+        ref.set_seed(seed)
+        want_n, want_e = ref.sample_sequence("fz%d" % case, order, src, k)
+        orc.set_reference_entropy(True, seed)
+        for c, name in enumerate(order):
+            got_n, got_e = orc.sample(g, name, src, k, padding_mode=pad, default_neighbor_id=-3)
+            assert np.array_equal(got_n, want_n[c]) and np.array_equal(got_e, want_e[c]), (case, c, name, k, pad)
+    finally:
+        ref.set_flags(padding_mode=1, default_neighbor_id=-3)
+        ref.close()
+        orc.set_reference_entropy(False)
