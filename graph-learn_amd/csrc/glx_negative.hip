@@ -91,6 +91,11 @@ struct NegArgs {
   const int64_t* nbr_sorted;
   // GLX_NEG_EXCLUDE_BATCH
   const int64_t* batch_sorted;
+  // ... whose exclusion set is ONE object for the whole request in the reference (node_weight_negative_sampler.cc:68:
+  // `sets` is built before the row loop), so the `sets.clear()` of the first row that exhausts its retries (:80) also
+  // frees every LATER row from it.  first_dropped: the smallest such row index (atomicMin; batch = none), found by the
+  // main kernel; glx_negative_after_drop_kernel then redoes the rows behind it without a set.
+  unsigned long long* first_dropped;
   // rows of a partitioned request (glx_dist_negative_sample): row r draws from the stream of rng_rows[r], its index in
   // the ORIGINAL request; nullptr = r itself
   const int64_t* rng_rows;
@@ -126,6 +131,9 @@ __global__ __launch_bounds__(256) void glx_negative_kernel(NegArgs a) {
   // every lane of the wavefront runs the same trip count; finished groups just idle
   for (int32_t blk = 0; blk < 4; ++blk) {
     const bool strict = MODE != GLX_NEG_EXCLUDE_NONE && blk < 3;  // the 4th block drops the set
+    if (MODE == GLX_NEG_EXCLUDE_BATCH && blk == 3 && live && taken < n && sub == 0) {
+      atomicMin(a.first_dropped, (unsigned long long)row);  // this row clears the request's set
+    }
     for (int32_t base = 0; base < n; base += W) {
       if (__ballot(taken < n) == 0) return;
       const int32_t j = base + sub;
@@ -144,6 +152,21 @@ __global__ __launch_bounds__(256) void glx_negative_kernel(NegArgs a) {
       taken += (int32_t)__popcll(m);
     }
   }
+}
+
+// Rows behind the first one that dropped the request's set (see NegArgs::first_dropped): no exclusion at all, so the
+// first block's `count` draws are the answer.  One thread per output slot.
+__global__ void glx_negative_after_drop_kernel(NegArgs a) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.batch * a.count;
+  if (t >= total) return;
+  const int64_t row = t / a.count;
+  if ((unsigned long long)row <= *a.first_dropped) return;
+  const int32_t j = (int32_t)(t - row * a.count);
+  const uint32_t stream_row = a.rng_rows ? (uint32_t)a.rng_rows[row] : (uint32_t)row;
+  const uint64_t u = glx_draw64(a.seed, a.cc, stream_row, (uint32_t)j);
+  const int64_t idx = a.table ? (int64_t)glx_alias_pick(u, a.num_ids, a.table) : (int64_t)glx_bounded(u, (uint64_t)a.num_ids);
+  a.out[t] = a.ids[idx];
 }
 
 template <int MODE>
@@ -430,7 +453,7 @@ extern "C" int glx_negative_sample(const glx_negative* t, int exclude, const glx
   const bool need_src = exclude != GLX_NEG_EXCLUDE_NONE;
   const size_t out_bytes = host ? (size_t)total * 8 : 0;
   const size_t src_bytes = host && need_src ? (size_t)batch * 8 : 0;
-  const size_t sort_bytes = exclude == GLX_NEG_EXCLUDE_BATCH ? (size_t)batch * 8 : 0;
+  const size_t sort_bytes = exclude == GLX_NEG_EXCLUDE_BATCH ? (size_t)batch * 8 + 8 : 0;  // + first_dropped
   char* scratch = nullptr;
   if (out_bytes + src_bytes + sort_bytes > 0) {
     int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), out_bytes + src_bytes + sort_bytes, s, 0);
@@ -480,12 +503,17 @@ extern "C" int glx_negative_sample(const glx_negative* t, int exclude, const glx
       glx_scratch_free(tmp, s);
       GLX_HIP(e);
       a.batch_sorted = sorted;
+      a.first_dropped = reinterpret_cast<unsigned long long*>(sorted + batch);
+      glx_neg_fill_kernel<<<1, 64, 0, s>>>(reinterpret_cast<int64_t*>(a.first_dropped), 1, (int64_t)batch);
     }
     GlxKernelTimer timer(GLX_KERNEL_SAMPLE, s);
     switch (exclude) {
       case GLX_NEG_EXCLUDE_NONE: launch_negative<GLX_NEG_EXCLUDE_NONE>(a, s); break;
       case GLX_NEG_EXCLUDE_NEIGHBORS: launch_negative<GLX_NEG_EXCLUDE_NEIGHBORS>(a, s); break;
-      default: launch_negative<GLX_NEG_EXCLUDE_BATCH>(a, s); break;
+      default:
+        launch_negative<GLX_NEG_EXCLUDE_BATCH>(a, s);
+        glx_negative_after_drop_kernel<<<grid_for(total), 256, 0, s>>>(a);
+        break;
     }
     timer.stop();
   }

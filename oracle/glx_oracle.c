@@ -916,6 +916,10 @@ int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const
   idmap m;
   if (exclude == 1 && g->ids) idmap_build(&m, g->ids, g->V);
   int32_t* indices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(count > 0 ? count : 1));
+  /* exclude == 2 (NodeWeightNegativeSampler): the set of the request's own ids is ONE object for all rows
+   * (node_weight_negative_sampler.cc:68), so the sets.clear() of the first row that exhausts its retries (:80) frees
+   * every later row from it too.  exclude == 1 builds a set per row (in_degree_negative_sampler.cc:70-73). */
+  int batch_set_alive = 1;
   for (int32_t i = 0; i < batch; ++i) {
     /* the exclusion set of this row */
     const int64_t* ex = NULL;
@@ -930,7 +934,7 @@ int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const
       ex = src;
       exn = batch;
     }
-    int set_active = exclude != 0;
+    int set_active = exclude == 2 ? batch_set_alive : exclude != 0;
     int32_t taken = 0, cursor = 0, blk = 0;
     int32_t retry_times = 3 + 1; /* kRetryTimes + 1 */
     if (exclude == 0) { /* one block, every candidate is taken */
@@ -962,7 +966,10 @@ int glxo_negative_sample(const int64_t* ids, int64_t U, const float* prob, const
           }
         }
         ++blk;
-        if (--retry_times <= 0) set_active = 0; /* sets.clear() */
+        if (--retry_times <= 0) { /* sets.clear() */
+          set_active = 0;
+          if (exclude == 2) batch_set_alive = 0;
+        }
       }
       int64_t item = ids[indices[cursor++]];
       int found = 0;

@@ -606,6 +606,36 @@ def test_negative_sampling_exhausted_candidates_and_empty_list():
     assert (empty.sample(src, 3, default_neighbor_id=-4) == -4).all()
 
 
+def test_node_weight_negative_sampler_drops_its_set_for_the_rest_of_the_request():
+    """node_weight_negative_sampler.cc:68-80: the exclusion set (the request's own ids) is ONE object for all rows, so
+    when a row exhausts its retries and clears it, every LATER row is sampled without any exclusion -- a behaviour the
+    draw-for-draw comparison with the reference found (tests/test_oracle_refseq.py).  Six candidates, five of them in
+    the batch, one negative per row: most blocks miss, some row soon runs out of retries, and from the next row on the
+    batch's own ids come back.  Device == oracle, host and device pointers, also with larger counts."""
+    import torch
+    from oracle_bindings import Oracle
+    orc = Oracle()
+    ids = np.array([10, 11, 12, 13, 14, 15], np.int64)
+    w = np.array([5, 5, 5, 5, 5, 0.2], np.float32)
+    t = glx.Negative(ids, w)
+    _, prob, alias = t.export()
+    batch = np.tile(ids[:5], 40)
+    dropped = False
+    for count, seed in ((1, 1), (1, 2), (2, 3), (3, 4), (9, 5)):
+        want = orc.negative_sample(ids, (prob, alias), 2, None, batch, count, seed=seed, call_counter=3)
+        got = t.sample(batch, count, exclude=glx.NEG_EXCLUDE_BATCH, seed=seed, call_counter=3)
+        assert np.array_equal(got, want), (count, seed)
+        got_d = t.sample(torch.from_numpy(batch).cuda(), count, exclude=glx.NEG_EXCLUDE_BATCH, seed=seed, call_counter=3)
+        assert np.array_equal(got_d.cpu().numpy(), want), (count, seed)
+        inside = np.isin(want, ids[:5]).any(axis=1)
+        if inside.any():
+            first = int(np.argmax(inside))
+            free = orc.negative_sample(ids, (prob, alias), 0, None, batch, count, seed=seed, call_counter=3)
+            assert np.array_equal(want[first + 1:], free[first + 1:])  # behind the row that dropped the set: no exclusion
+            dropped = True
+    assert dropped
+
+
 def test_in_degree_lookup_equals_bincount():
     rng = np.random.default_rng(5)
     V, E = 3000, 40000

@@ -312,3 +312,83 @@ def test_reference_entropy_fuzz(orc, case):
         ref.set_flags(padding_mode=1, default_neighbor_id=-3)
         ref.close()
         orc.set_reference_entropy(False)
+
+
+@pytest.fixture(scope="module")
+def families(orc):
+    """The reference stores the wider sweeps below draw from, built once: the timestamped graph of filtered.npz, the
+    candidate graph of negative.npz (+ its weighted node type), a walk graph where every vertex has out-edges."""
+    f = _load("filtered.npz")
+    n = _load("negative.npz")
+    ref = RefLib(default_neighbor_id=-3)
+    ref.add_edges_timestamped("fam_flt", f["src"], f["dst"], f["ts"], f["w"])
+    ref.add_edges("fam_neg", n["src"], n["dst"], n["w"])
+    ref.add_weighted_nodes("fam_nw", n["node_ids"], n["node_weights"])
+    rng = np.random.default_rng(77)
+    V = 80
+    deg = rng.integers(1, 12, V)
+    src = np.repeat(np.arange(V, dtype=np.int64), deg)
+    dst = rng.integers(0, V, src.shape[0]).astype(np.int64)
+    w = (rng.random(src.shape[0]) * 0.9 + 0.05 + np.arange(src.shape[0]) * 2.0 ** -20).astype(np.float32)
+    ref.add_edges("fam_walk", src, dst, w)
+    rows = np.arange(V, dtype=np.int64)
+    rp, col, eid, ws = ref.export_csr("fam_walk", rows, 16)
+    og_f = dict(row_ptr=f["row_ptr"], col=f["col"], eid=f["eid"], weight=f["w_slot"], ids=f["rows"], ts_slot=f["ts_slot"])
+    og_f["indeg_weight"] = orc.in_degree_alias(og_f)[1]
+    og_n = dict(row_ptr=n["row_ptr"], col=n["col"], eid=n["eid"], weight=n["w_slot"], ids=n["rows"])
+    yield dict(ref=ref, f=f, n=n, og_f=og_f, og_n=og_n, og_w=dict(row_ptr=rp, col=col, eid=eid, weight=ws, ids=rows), V=V)
+    ref.close()
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(12))
+def test_reference_entropy_fuzz_filters_negatives_walks(orc, families, case):
+    """One random request per family and case -- a filtered sampler (any filter kind, retry budget 0-5), a negative
+    sampler (any of the four, counts 1-24), a walk (DeepWalk or node2vec, lengths 1-7, caps 1-100) -- each in a fresh
+    reference thread under a random seed: the oracle under the reference's entropy returns the same ids."""
+    rng = np.random.default_rng(52000 + case)
+    ref, f, n = families["ref"], families["f"], families["n"]
+    try:
+        # filtered sampler
+        name = str(rng.choice([RANDOM, RWOR, EDGE_WEIGHT, IN_DEGREE]))
+        kind = list(FILTERS)[int(rng.integers(0, 4))]
+        ft, ff = FILTERS[kind]
+        ids = rng.choice(f["rows"], int(rng.integers(1, 60)))
+        vals = rng.integers(898, 913, ids.shape[0]) if ff == 1 else rng.choice(f["ts"], ids.shape[0]) + rng.integers(-1, 2, ids.shape[0])
+        pad = 1 if name in (EDGE_WEIGHT, IN_DEGREE) else int(rng.integers(0, 2))
+        ref.set_flags(pad, -3, 0.0)
+        flt = dict(type=ft, field=ff, values=vals.astype(np.int64), retry_times=int(rng.integers(0, 6)))
+        k, seed = int(rng.integers(1, 14)), int(rng.integers(0, 2 ** 32))
+        ref.set_seed(seed)
+        want = ref.sample_filtered("fam_flt", name, ids, k, flt, fresh_thread=True)
+        orc.set_reference_entropy(True, seed)
+        got = orc.sample_filtered(families["og_f"], name, ids, k, flt, padding_mode=pad, default_neighbor_id=-3)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, name, kind, pad, k)
+        ref.set_flags(1, -3, 0.0)
+        # negative sampler
+        neg = [("RandomNegativeSampler", 0, None), ("SoftInDegreeNegativeSampler", 0, "indeg"),
+               ("InDegreeNegativeSampler", 1, "indeg"), ("NodeWeightNegativeSampler", 2, "node")][int(rng.integers(0, 4))]
+        count, seed = int(rng.integers(1, 25)), int(rng.integers(0, 2 ** 32))
+        ref.set_seed(seed)
+        orc.set_reference_entropy(True, seed)
+        if neg[2] == "node":
+            batch = n["node_ids"][rng.integers(0, n["node_ids"].shape[0], int(rng.integers(1, 90)))]
+            want = ref.negative_sample("fam_nw", neg[0], batch, count, fresh_thread=True)
+            got = orc.negative_sample(n["node_ids"], (n["node_prob"], n["node_alias"]), 2, None, batch, count)
+        else:
+            batch = rng.choice(n["rows"], int(rng.integers(1, 120)))
+            table = (n["indeg_prob"], n["indeg_alias"]) if neg[2] else None
+            want = ref.negative_sample("fam_neg", neg[0], batch, count, fresh_thread=True)
+            got = orc.negative_sample(n["dst_ids"], table, neg[1], families["og_n"], batch, count)
+        assert np.array_equal(got, want), (case, neg[0], count)
+        # walk
+        p, q = [(1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (1.0, 3.0)][int(rng.integers(0, 4))]
+        F, L, seed = int(rng.choice([1, 2, 5, 100])), int(rng.integers(1, 8)), int(rng.integers(0, 2 ** 32))
+        seeds = rng.integers(0, families["V"], int(rng.integers(1, 100))).astype(np.int64)
+        ref.set_seed(seed)
+        want = ref.random_walk("fam_walk", seeds, L, p, q, full_nbr_num=F, fresh_thread=True)
+        orc.set_reference_entropy(True, seed)
+        got = orc.random_walk(families["og_w"], seeds, L, p=p, q=q, full_nbr_num=F, default_neighbor_id=-3)
+        assert np.array_equal(got, want), (case, p, q, F, L)
+    finally:
+        ref.set_flags(1, -3, 0.0)
+        orc.set_reference_entropy(False)
