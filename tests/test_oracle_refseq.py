@@ -392,3 +392,52 @@ def test_reference_entropy_fuzz_filters_negatives_walks(orc, families, case):
     finally:
         ref.set_flags(1, -3, 0.0)
         orc.set_reference_entropy(False)
+
+
+@pytest.fixture(scope="module")
+def cond_world():
+    from test_oracle_cond_negative import GOLD as CG
+    ref = RefLib()
+    ref.add_attr_nodes("item", CG["items"], weights=CG["item_w"], int_attrs=CG["int_attr"].reshape(-1, 1),
+                       float_attrs=CG["float_attr"].reshape(-1, 1), str_attrs=[[bytes(x)] for x in CG["str_attr"]])
+    ref.set_flags(1, 0, 0.0)
+    for strategy in ("random", "in_degree"):
+        ref.add_edges("buy_fz_" + strategy, CG["src"], CG["dst"], None)
+    yield ref, CG
+    ref.close()
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(12))
+def test_reference_entropy_fuzz_conditional_negative(orc, cond_world, case):
+    """Random ConditionalNegativeSampler requests -- strategy, batch_share, unique, count, 1-12 random (src, dst) rows --
+    against the reference draw for draw (the columns and proportions stay those of the fixture: the reference caches
+    its condition table per type).  Requests the reference answers short (quirk 13c) are skipped."""
+    from test_oracle_cond_negative import float_key, setup
+    ref, CG = cond_world
+    rng = np.random.default_rng(88000 + case)
+    strategy = str(rng.choice(["random", "in_degree", "node_weight"]))
+    share, unique = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    count = int(rng.choice([4, 8, 12, 16]))
+    cand, w, keys, _, g, attr = setup(strategy)
+    n = int(rng.integers(1, 13))
+    req_src = rng.integers(0, 80, n).astype(np.int64)
+    req_dst = rng.choice(CG["items"], n).astype(np.int64)
+    sdict = {b"A": 0, b"B": 1}
+    dk = np.stack([np.array([attr[int(d)][0] for d in req_dst], np.int64), float_key([attr[int(d)][1] for d in req_dst]),
+                   np.array([sdict[attr[int(d)][2]] for d in req_dst], np.int64)], axis=1)
+    props = np.concatenate([CG["int_props"], CG["float_props"], CG["str_props"]])
+    etype = "item" if strategy == "node_weight" else "buy_fz_" + strategy
+    seed = int(rng.integers(0, 2 ** 32))
+    try:
+        ref.set_seed(seed)
+        want = ref.cond_neg_sample(etype, strategy, "item", req_src, req_dst, count, int_cols=[0], int_props=CG["int_props"],
+                                   float_cols=[0], float_props=CG["float_props"], str_cols=[0], str_props=CG["str_props"],
+                                   batch_share=share, unique=unique)
+        orc.set_reference_entropy(True, seed)
+        got, filled = orc.cond_negative_sample(cand, w, keys, props, g, req_src, req_dst, dk, count, batch_share=share,
+                                               unique=unique, with_filled=True)
+        if want.shape[0] == n * count:
+            assert np.all(filled == count)
+            assert np.array_equal(got.reshape(-1), want), (case, strategy, share, unique, count)
+    finally:
+        orc.set_reference_entropy(False)
