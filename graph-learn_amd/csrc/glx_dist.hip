@@ -629,6 +629,9 @@ __global__ __launch_bounds__(64) void glx_dist_node2vec_step_kernel(
     const int64_t* __restrict__ nbr_c, const int64_t* __restrict__ wbits_c, const int32_t* __restrict__ deg_p,
     const int64_t* __restrict__ off_p, const int64_t* __restrict__ nbr_p, float p, float q, int32_t F, uint64_t seed,
     uint64_t cc, int64_t default_nbr, int64_t* __restrict__ next) {
+  // off_p: where the reference's cursor stands in the concatenated parent lists when it reaches walker i -- it is not
+  // advanced for walkers whose current vertex has no out-edges (random_walk.cc:214-226), so behind a stuck walker the
+  // windows start too early; glx_dist_walk_cursor_kernel computes it (== the true offsets while nobody is stuck)
   extern __shared__ int64_t lds64[];
   GlxAlias* tab = reinterpret_cast<GlxAlias*>(lds64);
   GlxAlias* stk = tab + F;
@@ -662,6 +665,34 @@ __global__ __launch_bounds__(64) void glx_dist_node2vec_step_kernel(
     glx_alias_build_row_dev(dist, n, tab, stk);
     const int32_t pick = glx_alias_pick(glx_draw64(seed, cc + (uint64_t)t, (uint32_t)i, 0u), n, tab);
     next[i] = nbr_c[oc + pick];
+  }
+}
+
+// off_used[i] = sum over j < i of (deg_c[j] > 0 ? deg_p[j] : 0): the reference's cursor (see the step kernel).  One
+// workgroup: walk batches are small.
+__global__ __launch_bounds__(1024) void glx_dist_walk_cursor_kernel(const int32_t* __restrict__ deg_c,
+                                                                   const int32_t* __restrict__ deg_p, int64_t n,
+                                                                   int64_t* __restrict__ off_used) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024, lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  int64_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += deg_c[i] > 0 ? deg_p[i] : 0;
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    int64_t run = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const int64_t v = part[k];
+      part[k] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  sum = part[t];
+  for (int64_t i = lo; i < hi; ++i) {
+    off_used[i] = sum;
+    sum += deg_c[i] > 0 ? deg_p[i] : 0;
   }
 }
 
@@ -2036,7 +2067,7 @@ int dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, in
     const int32_t F = full_nbr_num;
     const size_t cap = nb * (size_t)F;
     GlxTemp lists;
-    GLX_HIP(hipMalloc(&lists.p, 2 * ((nb + 1) * 4 + (nb + 2) * 8 + 2 * cap * 8) + 64));
+    GLX_HIP(hipMalloc(&lists.p, 2 * ((nb + 1) * 4 + (nb + 2) * 8 + 2 * cap * 8) + 64 + (nb + 1) * 8));
     char* base = lists.as<char>();
     struct Lists { int32_t* deg; int64_t* off; int64_t* nbr; int64_t* w; } L[2];
     for (int k = 0; k < 2; ++k) {
@@ -2049,6 +2080,7 @@ int dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, in
       L[k].deg = reinterpret_cast<int32_t*>(base);
       base += ((nb + 1) * 4 + 7) & ~(size_t)7;
     }
+    int64_t* cursor = reinterpret_cast<int64_t*>(base);  // [nb]: the reference's cursor into the parents' lists
     if (batch > 0) GLX_HIP(hipMemcpyAsync(par, cur, (size_t)batch * 8, hipMemcpyDeviceToDevice, s));  // step 0: the seed itself
     for (int32_t t = 0; t < walk_len; ++t) {
       Lists& c = L[t & 1];
@@ -2058,8 +2090,9 @@ int dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, in
                                    GLX_PAD_CIRCULAR, 0, /*weights_in_eid=*/true, default_weight);
       if (rc != GLX_OK) return rc;
       if (batch > 0) {
+        if (t > 0) glx_dist_walk_cursor_kernel<<<1, 1024, 0, s>>>(c.deg, pv.deg, (int64_t)batch, cursor);
         glx_dist_node2vec_step_kernel<<<(unsigned)batch, 64, (size_t)F * 20, s>>>(
-            par, t, c.deg, c.off, c.nbr, c.w, t > 0 ? pv.deg : nullptr, pv.off, pv.nbr, p, q, F, seed, call_counter,
+            par, t, c.deg, c.off, c.nbr, c.w, t > 0 ? pv.deg : nullptr, cursor, pv.nbr, p, q, F, seed, call_counter,
             default_neighbor_id, nxt);
         glx_dist_walk_column_kernel<<<(unsigned)((batch + 255) / 256), 256, 0, s>>>(nxt, batch, walk_len, t, d_walks);
         // the next step's parent is this step's vertex -- except after step 0, whose parent stays the seed

@@ -25,7 +25,65 @@ struct WalkArgs {
   uint64_t seed, cc;
   float p, q, default_weight;
   int32_t batch, walk_len, step, full_nbr_num;
+  // node2vec, steps >= 1 -- the reference hands a step the parents' neighbour lists as ONE concatenated array and walks
+  // it with a cursor that it only advances for walkers whose current vertex has out-edges (random_walk.cc:214-226):
+  // behind a stuck walker every later walker reads a window that starts too early by that walker's list length.
+  // seg[i] = length of walker i's parent list, off_true[i] = where it really starts, off_used[i] = where the reference's
+  // cursor stands when it reaches walker i.  Equal offsets: the walker's own parent list (the common case).
+  const int32_t* seg;
+  const int64_t* off_true;
+  const int64_t* off_used;
 };
+
+__device__ __forceinline__ int64_t walk_parent_of(const WalkArgs& a, int64_t i) {
+  // the first step's parent is the seed itself, without neighbours (random_walk_request.cc:120-131)
+  return a.step <= 1 ? a.seeds[i] : a.walks[i * a.walk_len + a.step - 2];
+}
+
+// seg / seg-if-not-stuck of every walker for step a.step >= 1 (one thread per walker)
+__global__ void glx_walk_segments_kernel(WalkArgs a, int32_t* __restrict__ seg, int32_t* __restrict__ seg_live) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= a.batch) return;
+  const int64_t cur = a.walks[i * a.walk_len + a.step - 1];
+  const int64_t crow = glx_row_of(a.map, cur);
+  const bool live = crow >= 0 && a.row_ptr[crow + 1] > a.row_ptr[crow];
+  const int64_t prow = glx_row_of(a.map, walk_parent_of(a, i));
+  int32_t n = 0;
+  if (prow >= 0) {
+    const int64_t d = a.row_ptr[prow + 1] - a.row_ptr[prow];
+    n = (int32_t)(d < a.full_nbr_num ? d : a.full_nbr_num);
+  }
+  seg[i] = n;
+  seg_live[i] = live ? n : 0;
+}
+
+// exclusive prefix sums of two int32 arrays into int64 ones; one workgroup (walk batches are small next to a graph)
+__global__ __launch_bounds__(1024) void glx_walk_scan2_kernel(const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+                                                             int64_t n, int64_t* __restrict__ o0, int64_t* __restrict__ o1) {
+  __shared__ int64_t part[2][1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024, lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  int64_t s0 = 0, s1 = 0;
+  for (int64_t i = lo; i < hi; ++i) { s0 += a0[i]; s1 += a1[i]; }
+  part[0][t] = s0;
+  part[1][t] = s1;
+  __syncthreads();
+  if (t == 0) {
+    int64_t r0 = 0, r1 = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const int64_t v0 = part[0][k], v1 = part[1][k];
+      part[0][k] = r0; part[1][k] = r1;
+      r0 += v0; r1 += v1;
+    }
+  }
+  __syncthreads();
+  s0 = part[0][t];
+  s1 = part[1][t];
+  for (int64_t i = lo; i < hi; ++i) {
+    o0[i] = s0; o1[i] = s1;
+    s0 += a0[i]; s1 += a1[i];
+  }
+}
 
 // One wave per walker.  LDS: parent's neighbour ids [F] i64 | weights [F] f32 | table [F] 8 B |
 // stack pairs [F] 8 B = 28 F bytes (F <= 2048 keeps it under the 64 KiB a launch may ask for).
@@ -41,8 +99,7 @@ __global__ __launch_bounds__(64) void glx_node2vec_step_kernel(WalkArgs a) {
   int64_t* walk = a.walks + i * a.walk_len;
   const int32_t t = a.step;
   const int64_t cur = t == 0 ? a.seeds[i] : walk[t - 1];
-  // the first step's parent is the seed itself, without neighbours (random_walk_request.cc:120-131)
-  const int64_t parent = t <= 1 ? a.seeds[i] : walk[t - 2];
+  const int64_t parent = walk_parent_of(a, i);
   const int64_t row = glx_row_of(a.map, cur);
   int64_t s = 0;
   int32_t n = 0;
@@ -57,12 +114,26 @@ __global__ __launch_bounds__(64) void glx_node2vec_step_kernel(WalkArgs a) {
   }
   int32_t pn = 0;
   if (t > 0) {
-    const int64_t prow = glx_row_of(a.map, parent);
-    if (prow >= 0) {
-      const int64_t ps = a.row_ptr[prow];
-      const int64_t pd = a.row_ptr[prow + 1] - ps;
-      pn = (int32_t)(pd < F ? pd : F);
+    pn = a.seg[i];
+    const int64_t used = a.off_used[i];
+    if (used == a.off_true[i]) {  // no stuck walker with a parent list before this one: its own parent's list
+      const int64_t prow = glx_row_of(a.map, parent);
+      const int64_t ps = prow >= 0 ? a.row_ptr[prow] : 0;
       for (int32_t x = lane; x < pn; x += 64) pnbr[x] = a.adj[ps + x].nbr;
+    } else {
+      // the reference's window [used, used + pn) of the concatenated lists: element x belongs to the walker j with
+      // off_true[j] <= x < off_true[j] + seg[j] (the last j whose list starts at or before x)
+      for (int32_t x = lane; x < pn; x += 64) {
+        const int64_t flat = used + x;
+        int64_t lo = 0, hi = a.batch;  // largest j with off_true[j] <= flat
+        while (hi - lo > 1) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (a.off_true[mid] <= flat) lo = mid;
+          else hi = mid;
+        }
+        const int64_t prow = glx_row_of(a.map, walk_parent_of(a, lo));
+        pnbr[x] = a.adj[a.row_ptr[prow] + (flat - a.off_true[lo])].nbr;
+      }
     }
   }
   __syncthreads();
@@ -149,16 +220,37 @@ extern "C" int glx_random_walk(const glx_graph* g, const int64_t* seeds, int32_t
     a.seeds = seeds;
     a.walks = walks_out;
   }
+  a.seg = nullptr;
+  a.off_true = a.off_used = nullptr;
+  int32_t* d_seg = nullptr;
+  if (!deep && walk_len > 1) {  // [seg i32 | seg_live i32 | off_true i64 | off_used i64] per walker
+    int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d_seg), nb * 24 + 16, s, 1);
+    if (rc != GLX_OK) {
+      if (d) glx_scratch_free(d, s);
+      return rc;
+    }
+  }
+  int32_t* d_live = d_seg ? d_seg + nb : nullptr;
+  int64_t* d_true = d_seg ? reinterpret_cast<int64_t*>(d_seg + 2 * nb + (nb & 1)) : nullptr;
+  int64_t* d_used = d_seg ? d_true + nb : nullptr;
   GlxKernelTimer timer(GLX_KERNEL_SAMPLE, s);
   for (int32_t t = 0; t < walk_len; ++t) {
     a.step = t;
     if (deep) {
       glx_deepwalk_step_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(a);
     } else {
+      if (t > 0) {
+        glx_walk_segments_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(a, d_seg, d_live);
+        glx_walk_scan2_kernel<<<1, 1024, 0, s>>>(d_seg, d_live, (int64_t)batch, d_true, d_used);
+        a.seg = d_seg;
+        a.off_true = d_true;
+        a.off_used = d_used;
+      }
       glx_node2vec_step_kernel<<<(unsigned)batch, 64, (size_t)full_nbr_num * 28, s>>>(a);
     }
   }
   timer.stop();
+  if (d_seg) glx_scratch_free(d_seg, s);
   GLX_HIP(hipGetLastError());
   if (ptr_kind == GLX_PTR_HOST) {
     GLX_HIP(hipMemcpyAsync(walks_out, a.walks, n_out * 8, hipMemcpyDeviceToHost, s));

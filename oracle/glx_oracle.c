@@ -514,6 +514,31 @@ static int32_t node2vec_weights(const glxo_graph* g, const idmap* m, int64_t cur
   return n;
 }
 
+/* the same weights with the parent's neighbour list handed in (what WeightedRandomWalkKernel is given: a window
+ * [start, start + size) of the request's concatenated lists, random_walk.cc:228-262) */
+static int32_t node2vec_window_weights(const glxo_graph* g, const idmap* m, int64_t cur, int64_t parent, const int64_t* pl,
+                                       int32_t pn, float p, float q, int32_t F, float default_weight, float* w_out,
+                                       int64_t* start_out) {
+  int64_t row = row_of(g->ids, m, g->V, cur);
+  if (row < 0) return 0;
+  int64_t s = g->row_ptr[row], d = g->row_ptr[row + 1] - s;
+  int32_t n = (int32_t)(d < F ? d : F);
+  *start_out = s;
+  for (int32_t x = 0; x < n; ++x) {
+    float ew = g->weight ? g->weight[s + x] : default_weight;
+    if (g->col[s + x] == parent) {
+      w_out[x] = ew * 1.0 / (p + 1e-6);
+    } else {
+      int32_t y = 0;
+      for (; y < pn; ++y) {
+        if (pl[y] == g->col[s + x]) { w_out[x] = ew; break; }
+      }
+      if (y == pn) w_out[x] = ew * 1.0 / (q + 1e-6);
+    }
+  }
+  return n;
+}
+
 void glxo_node2vec_weights(const glxo_graph* g, int64_t cur, int64_t parent, int has_parent_nbrs, float p, float q,
                            int32_t full_nbr_num, float default_weight, float* w_out, int32_t* n_out) {
   idmap m;
@@ -534,7 +559,16 @@ int glxo_random_walk(const glxo_graph* g, const int64_t* seeds, int32_t batch, i
   const int32_t F = full_nbr_num > 0 ? full_nbr_num : 1;
   float* w = (float*)malloc(sizeof(float) * (size_t)F * 2);
   int32_t* tab = (int32_t*)malloc(sizeof(int32_t) * (size_t)F * 3);
+  /* node2vec: the parents' neighbour lists travel as ONE concatenated array (the previous step's answer), walked with a
+   * cursor that random_walk.cc:214-226 advances only for walkers whose current vertex has out-edges: behind a stuck
+   * walker every later walker's window starts too early by that walker's list length.  plist / pseg: the lists of the
+   * previous step's current vertices, walker by walker. */
+  int64_t* plist = deep ? NULL : (int64_t*)malloc(sizeof(int64_t) * ((size_t)batch * (size_t)F + 1));
+  int64_t* pnext = deep ? NULL : (int64_t*)malloc(sizeof(int64_t) * ((size_t)batch * (size_t)F + 1));
+  int32_t* pseg = deep ? NULL : (int32_t*)calloc((size_t)batch + 1, sizeof(int32_t));
+  int32_t* pseg_next = deep ? NULL : (int32_t*)calloc((size_t)batch + 1, sizeof(int32_t));
   for (int32_t t = 0; t < walk_len; ++t) {
+    int64_t cursor = 0, filled = 0;
     for (int32_t i = 0; i < batch; ++i) {
       int64_t* walk = walks_out + (int64_t)i * walk_len;
       const int64_t cur = t == 0 ? seeds[i] : walk[t - 1];
@@ -548,17 +582,27 @@ int glxo_random_walk(const glxo_graph* g, const int64_t* seeds, int32_t batch, i
         continue;
       }
       int64_t s = 0;
-      int32_t n = node2vec_weights(g, &m, cur, parent, t > 0, p, q, F, default_weight, w, &s);
-      if (n == 0) { walk[t] = default_neighbor_id; continue; }
+      int32_t n = node2vec_window_weights(g, &m, cur, parent, plist + cursor, t > 0 ? pseg[i] : 0, p, q, F, default_weight, w, &s);
+      /* this step's answer carries the current vertex's first min(deg, F) neighbours: the next step's parent lists */
+      pseg_next[i] = n;
+      for (int32_t x = 0; x < n; ++x) pnext[filled + x] = g->col[s + x];
+      filled += n;
+      if (n == 0) { walk[t] = default_neighbor_id; continue; } /* ... and the cursor stays where it is */
+      if (t > 0) cursor += pseg[i];
       float* probs = w + F;
       alias_build_row(w, n, probs, tab, tab + F, tab + 2 * F);
       float rnd = alias_variate(u, (double)(n - 1));
       int32_t ix = (int32_t)rnd;
       walk[t] = g->col[s + ((probs[ix] <= (rnd - ix)) ? tab[ix] : ix)];
     }
+    if (!deep) {
+      int64_t* tl = plist; plist = pnext; pnext = tl;
+      int32_t* ts = pseg; pseg = pseg_next; pseg_next = ts;
+    }
   }
   free(w);
   free(tab);
+  free(plist); free(pnext); free(pseg); free(pseg_next);
   if (g->ids) idmap_free(&m);
   return 0;
 }

@@ -116,8 +116,9 @@ int64_t glxo_sample_full_filtered(const glxo_graph* g, const int64_t* src, int32
  * DeepWalk (:168-190) when p = q = 1 within 32 FLT_EPSILON, node2vec otherwise
  * (WeightedRandomWalkKernel :228-272: biased weights over the first min(deg, full_nbr_num)
  * neighbours, AliasMethod over them, one draw).  walks_out[batch * walk_len] row-major.
- * Step t of walker i uses draw 0 of stream (seed, call_counter + t, i).  Every walker reads
- * its own parent's neighbour list (the reference's cursor slips past stuck walkers). */
+ * Step t of walker i uses draw 0 of stream (seed, call_counter + t, i).  The parents' neighbour
+ * lists are walked with the reference's cursor (:214-226: not advanced for a walker whose current
+ * vertex has no out-edges, so the walkers behind it read a window that starts too early). */
 int glxo_random_walk(const glxo_graph* g, const int64_t* seeds, int32_t batch, int32_t walk_len, float p, float q,
                      int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id, uint64_t seed,
                      uint64_t call_counter, int64_t* walks_out);

@@ -208,8 +208,8 @@ def test_node_weight_negative_sampler_equals_the_reference_draw_for_draw(orc):
 @pytest.mark.parametrize("p,q,full_nbr_num", [(1.0, 1.0, 100), (0.5, 2.0, 100), (4.0, 0.25, 3)])
 def test_random_walks_equal_the_reference_draw_for_draw(orc, p, q, full_nbr_num):
     """RandomWalk (random_walk.cc): DeepWalk steps draw from the operator's own engine, node2vec steps build a biased
-    alias table per walker per step and draw through AliasMethod's.  Every vertex of this graph has out-edges (the
-    reference's cursor slip past stuck walkers, :214-226, is the one behaviour the restatement leaves out)."""
+    alias table per walker per step and draw through AliasMethod's.  Every vertex of this graph has out-edges; graphs
+    with dead ends -- where the reference's cursor slips, :214-226 -- are test_node2vec_walks_with_dead_ends_equal_the_reference's."""
     rng = np.random.default_rng(12)
     V = 60
     deg = rng.integers(1, 9, V)
@@ -440,4 +440,39 @@ def test_reference_entropy_fuzz_conditional_negative(orc, cond_world, case):
             assert np.all(filled == count)
             assert np.array_equal(got.reshape(-1), want), (case, strategy, share, unique, count)
     finally:
+        orc.set_reference_entropy(False)
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(16))
+def test_node2vec_walks_with_dead_ends_equal_the_reference(orc, case):
+    """node2vec on graphs WITH vertices that have no out-edges: the reference walks the concatenated parent lists with
+    a cursor it only advances for walkers that can move (random_walk.cc:214-226), so every walker behind a stuck one
+    compares its neighbours with a window that starts too early -- reproduced since round 4 (oracle, kernels), and the
+    walks must match vertex for vertex.  The default neighbour id is a vertex that has out-edges, so stuck walkers keep
+    walking (and keep shifting the windows) on later steps."""
+    rng = np.random.default_rng(91000 + case)
+    V = int(rng.integers(6, 50))
+    deg = rng.integers(0, 9, V)
+    deg[rng.random(V) < 0.3] = 0  # dead ends
+    deg[0] = max(int(deg[0]), 2)
+    src = np.repeat(np.arange(V, dtype=np.int64), deg)
+    dst = rng.integers(0, V, src.shape[0]).astype(np.int64)
+    w = (rng.random(src.shape[0]) * 0.9 + 0.05 + np.arange(src.shape[0]) * 2.0 ** -20).astype(np.float32)
+    ref = RefLib(default_neighbor_id=0)
+    try:
+        tag = "dead%d" % case
+        ref.add_edges(tag, src, dst, w)
+        rows = np.flatnonzero(deg > 0).astype(np.int64)
+        rp, col, eid, ws = ref.export_csr(tag, rows, 16)
+        og = dict(row_ptr=rp, col=col, eid=eid, weight=ws, ids=rows)
+        seeds = rng.integers(0, V, int(rng.integers(2, 60))).astype(np.int64)
+        p, q = [(0.5, 2.0), (4.0, 0.25), (1.0, 3.0), (0.1, 0.1)][int(rng.integers(0, 4))]
+        F, L, seed = int(rng.choice([1, 2, 4, 100])), int(rng.integers(2, 8)), int(rng.integers(0, 2 ** 32))
+        ref.set_seed(seed)
+        want = ref.random_walk(tag, seeds, L, p, q, full_nbr_num=F, fresh_thread=True)
+        orc.set_reference_entropy(True, seed)
+        got = orc.random_walk(og, seeds, L, p=p, q=q, full_nbr_num=F, default_neighbor_id=0)
+        assert np.array_equal(got, want), (case, p, q, F, L)
+    finally:
+        ref.close()
         orc.set_reference_entropy(False)
