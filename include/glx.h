@@ -293,7 +293,8 @@ GLX_API int glx_sample_full_filtered(const glx_graph* g, const int64_t* src, int
  * weights of an unweighted graph (GLOBAL_FLAG(DefaultWeight)).  Step t of walker i uses draw 0
  * of the stream (seed, call_counter + t, i).  The reference does not advance its cursor
  * into the parents' neighbour lists past a walker that is stuck (:214-226), which shifts the
- * lists of all later walkers of the batch; glx keeps every walker on its own parent. */
+ * windows of all later walkers of the batch: reproduced (round 4) -- walks equal the reference's
+ * also on graphs with dead ends. */
 GLX_API int glx_random_walk(const glx_graph* g, const int64_t* seeds, int32_t batch, int32_t walk_len, float p,
                             float q, int32_t full_nbr_num, float default_weight, int64_t default_neighbor_id,
                             uint64_t seed, uint64_t call_counter, int64_t* walks_out, int ptr_kind, void* stream);
