@@ -663,3 +663,40 @@ def test_refseq_golden(orc):
                     assert np.array_equal(n, g[key + "_nbr"]) and np.array_equal(e, g[key + "_eid"]), key
     finally:
         orc.set_reference_entropy(False)
+
+
+def _fuzz_cases(n):
+    first = int(os.environ.get("GLX_FUZZ_FIRST", "0"))
+    return list(range(first, first + int(os.environ.get("GLX_FUZZ_CASES", str(n)))))
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("case", _fuzz_cases(10))
+def test_aggregators_live_fuzz_against_reference(orc, case):
+    """Random feature tables (values that overflow Prod, -50s below Max's -37 start, NaN-free), ragged non-decreasing
+    segment ids with empty and out-of-range tails (the cursor stalls there, aggregating_request.cc:86-105), unknown
+    ids, sparse raw ids, random default attributes: the five aggregators of the oracle against the reference's own
+    Aggregator::Aggregate, bit for bit."""
+    rng = np.random.default_rng(64000 + case)
+    V, D = int(rng.integers(1, 60)), int(rng.choice([1, 2, 3, 8, 17]))
+    X = (rng.standard_normal((V, D)) * float(rng.choice([1, 30]))).astype(np.float32)
+    X[rng.random((V, D)) < 0.05] = -50.0
+    raw = (rng.permutation(V * 3)[:V] - V).astype(np.int64)
+    dflt = float(rng.choice([0.0, 1.5, -2.0]))
+    ref = RefLib(default_float_attr=dflt)
+    try:
+        ref.add_nodes("agg_fz%d" % case, raw, X)
+        Sg = int(rng.integers(1, 30))
+        sizes = rng.integers(0, 9, Sg)
+        seg = np.repeat(np.arange(Sg, dtype=np.int32), sizes)
+        if rng.random() < 0.3 and seg.size:
+            seg = np.concatenate([seg, np.full(int(rng.integers(1, 4)), Sg, np.int32)])  # ids past the last segment
+        ids = raw[rng.integers(0, V, seg.shape[0])].copy() if seg.size else np.zeros(0, np.int64)
+        ids[rng.random(ids.shape[0]) < 0.1] = 10 ** 9  # unknown ids: the default row
+        for name in AGGREGATORS:
+            want = ref.aggregate("agg_fz%d" % case, name, ids, seg, Sg, D)
+            got = orc.aggregate(X, name, ids, seg, Sg, dflt, ids=raw)
+            assert np.array_equal(got[1], want[1]), (case, name)
+            assert beq(got[0], want[0]), (case, name)
+    finally:
+        ref.close()
