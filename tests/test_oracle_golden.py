@@ -700,3 +700,53 @@ def test_aggregators_live_fuzz_against_reference(orc, case):
             assert beq(got[0], want[0]), (case, name)
     finally:
         ref.close()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("case", _fuzz_cases(10))
+def test_deterministic_samplers_live_fuzz_against_reference(orc, case):
+    """Random timestamped + weighted graphs built by the reference itself (rows in its post-Build order), random
+    requests with unknown ids: TopkSampler under both padders, FullSampler with and without every filter kind and
+    limit -- the oracle against the reference's operators, id for id."""
+    rng = np.random.default_rng(73000 + case)
+    V = int(rng.integers(2, 50))
+    E = int(rng.integers(1, 12 * V))
+    src = rng.integers(0, V, E).astype(np.int64) * 3 - 7
+    dst = rng.integers(0, V + 5, E).astype(np.int64) * 3 - 7
+    w = (rng.random(E) * 0.9 + 0.05 + np.arange(E) * 2.0 ** -21).astype(np.float32)  # tie-free: topk order is defined
+    ts = rng.permutation(E).astype(np.int64) + 1000
+    ref = RefLib(default_neighbor_id=-3)
+    try:
+        tag = "det%d" % case
+        ref.add_edges_timestamped(tag, src, dst, ts, w)
+        rows = np.unique(src)
+        rp, col, eid, ws = ref.export_csr(tag, rows, E + 1)
+        ts_slot = ts[eid]
+        og = dict(row_ptr=rp, col=col, eid=eid, weight=ws, ids=rows, ts_slot=ts_slot)
+        q = np.concatenate([rows[rng.integers(0, rows.shape[0], int(rng.integers(1, 40)))], [10 ** 6, -10 ** 6]]).astype(np.int64)
+        for pad in (0, 1):
+            ref.set_flags(pad, -3, 0.0)
+            k = int(rng.integers(1, 12))
+            a = orc.sample(og, "TopkSampler", q, k, padding_mode=pad, default_neighbor_id=-3)
+            b = ref.sample(tag, "TopkSampler", q, k)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (case, "topk", pad, k)
+            limit = int(rng.choice([0, 1, 3, 20]))
+            a = orc.sample_full(og, q, limit)
+            b = ref.sample_full(tag, q, limit)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (case, "full", limit)
+            kind = list(FILTERS)[int(rng.integers(0, 4))]
+            ft, ff = FILTERS[kind]
+            vals = (q if ff == 1 else rng.choice(ts, q.shape[0]) + rng.integers(-1, 2, q.shape[0])).astype(np.int64)
+            if ff == 1:
+                vals = col[rng.integers(0, col.shape[0], q.shape[0])]
+            flt = dict(type=ft, field=ff, values=vals)
+            a = orc.sample_filtered(og, "TopkSampler", q, k, flt, padding_mode=pad, default_neighbor_id=-3)
+            b = ref.sample_filtered(tag, "TopkSampler", q, k, flt)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (case, "topk", kind, pad, k)
+            if pad == 0:  # replicate: no FillWith(dim2) on emptied rows (quirk 12)
+                a = orc.sample_full_filtered(og, q, limit, flt, padding_mode=pad, default_neighbor_id=-3)
+                b = ref.sample_filtered(tag, "FullSampler", q, limit, flt)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (case, "full", kind, limit)
+    finally:
+        ref.set_flags(1, 0, 0.0)
+        ref.close()
