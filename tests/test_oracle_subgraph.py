@@ -36,13 +36,15 @@ def test_later_slot_wins_for_multi_edges():
 
 @pytest.mark.skipif(not have_ref(), reason="reference library not built")
 def test_oracle_equals_live_reference_on_random_requests():
-    rng = np.random.default_rng(3)
+    import os
+    rng = np.random.default_rng(3 + int(os.environ.get("GLX_FUZZ_FIRST", "0")))
+    trials = 40 * max(1, int(os.environ.get("GLX_FUZZ_CASES", "1")))  # GLX_FUZZ_CASES=100: 4,000 random requests
     ref = RefLib(storage_mode=2)
     try:
         ref.add_edges("sub", GOLD["src"], GOLD["dst"], GOLD["w"])
         ref.set_flags(1, 0, 0.0)
         orc = Oracle()
-        for _ in range(40):
+        for _ in range(trials):
             seeds = rng.integers(0, 64, int(rng.integers(1, 9))).astype(np.int64)
             nn = [int(rng.integers(0, 7))]
             full = int(rng.choice([1, 2, 5, 100]))
