@@ -898,3 +898,45 @@ def test_request_plan_fuzz(case):
                 e, c = f.aggregate(agg, ref[h][0].reshape(-1), None, ref[h][0].shape[0], default_attr=1.5)
                 assert torch.equal(out[h]["cnt"], c) and torch.equal(out[h]["emb"].view(torch.int32), e.view(torch.int32)), (agg, h)
     plan.close()
+
+
+def test_alias_tables_of_degenerate_weight_rows_equal_the_oracle():
+    """Rows whose weights are all zero (the reference's sum is 0 and every probability NaN), partly zero, all equal,
+    spread over 60 orders of magnitude, or small integers: the device alias build (lane-serial and wave kernels) equals
+    the oracle's -- which equals the reference's AliasMethod on exactly such rows (20,000 live cases on the CPU) -- bit for
+    bit, NaNs included; and the EdgeWeight draws on them agree."""
+    from oracle_bindings import Oracle
+    orc = Oracle()
+    rng = np.random.default_rng(77)
+    degs, ws = [], []
+    for r in range(600):
+        n = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 5000])) if r % 50 == 0 else int(rng.integers(1, 40))
+        kind = r % 6
+        if kind == 0:
+            w = rng.random(n)
+        elif kind == 1:
+            w = np.zeros(n)
+        elif kind == 2:
+            w = rng.random(n) * (rng.random(n) < 0.5)
+        elif kind == 3:
+            w = np.full(n, rng.random())
+        elif kind == 4:
+            w = 10.0 ** rng.integers(-30, 30, n)
+        else:
+            w = rng.integers(1, 4, n)
+        degs.append(n)
+        ws.append(w.astype(np.float32))
+    rp = np.concatenate([[0], np.cumsum(degs)]).astype(np.int64)
+    w = np.concatenate(ws)
+    E = int(rp[-1])
+    col = (np.arange(E, dtype=np.int64) * 7) % 1000
+    eid = np.arange(E, dtype=np.int64)
+    dev = glx.Graph(rp, col, eid, w)
+    prob, alias = dev.export_alias()
+    oprob, oalias = orc.alias_build(rp, w)
+    assert np.array_equal(prob.view(np.uint32), oprob.view(np.uint32)) and np.array_equal(alias, oalias)
+    q = np.arange(600, dtype=np.int64)
+    og = dict(row_ptr=rp, col=col, eid=eid, weight=w, alias=(oprob, oalias))
+    n, e = dev.sample("EdgeWeightSampler", q, 9, seed=3, call_counter=1)
+    on, oe = orc.sample(og, "EdgeWeightSampler", q, 9, seed=3, call_counter=1)
+    assert np.array_equal(n, on) and np.array_equal(e, oe)
