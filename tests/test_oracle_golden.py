@@ -750,3 +750,34 @@ def test_deterministic_samplers_live_fuzz_against_reference(orc, case):
     finally:
         ref.set_flags(1, 0, 0.0)
         ref.close()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_alias_build_live_fuzz_degenerate_weights(orc):
+    """AliasMethod::Build (alias_method.cc:57-107) on rows the goldens do not hold: all-zero weights (sum 0, NaN
+    probabilities), partly zero, all equal, 60 orders of magnitude apart, small integers -- the oracle's tables equal the
+    reference's private probs_ / alias_ bit for bit, NaNs included.  GLX_FUZZ_CASES multiplies the 2,000 rows."""
+    rng = np.random.default_rng(5 + int(os.environ.get("GLX_FUZZ_FIRST", "0")))
+    ref = RefLib()
+    try:
+        for trial in range(2000 * max(1, int(os.environ.get("GLX_FUZZ_CASES", "1")))):
+            n = int(rng.integers(1, 40))
+            kind = trial % 6
+            if kind == 0:
+                w = rng.random(n)
+            elif kind == 1:
+                w = np.zeros(n)
+            elif kind == 2:
+                w = rng.random(n) * (rng.random(n) < 0.5)
+            elif kind == 3:
+                w = np.full(n, rng.random())
+            elif kind == 4:
+                w = 10.0 ** rng.integers(-30, 30, n)
+            else:
+                w = rng.integers(1, 4, n)
+            w = w.astype(np.float32)
+            p, a = ref.alias_build(w)
+            op, oa = orc.alias_build(np.array([0, n], np.int64), w)
+            assert beq(p, op) and np.array_equal(a, oa), (trial, kind, w)
+    finally:
+        ref.close()
