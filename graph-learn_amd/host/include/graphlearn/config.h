@@ -21,6 +21,7 @@ extern int64_t gDefaultTimestamp;       // config.cc:104 (-1)
 extern int32_t gIgnoreInvalid;          // config.cc:109 (1: skip records that fail to parse)
 extern int32_t gDefaultFullNbrNum;       // config.cc:111 (100: neighbours a node2vec step looks at)
 extern int32_t gSamplingRetryTimes;     // config.cc:108 (5; RandomSampler's redraws of filtered neighbours)
+extern int32_t gShuffleBufferSize;      // config.cc:88 (10240: a "shuffle" traversal shuffles this many consecutive ids at a time)
 // New (the reference has no seed flag, include/config.h:77-118): the seed of the
 // glx seeding contract, and the GPU this process' GraphStore lives on.
 extern int64_t gSamplingSeed;
@@ -37,6 +38,7 @@ void SetGlobalFlagDefaultTimestamp(int64_t v);
 void SetGlobalFlagIgnoreInvalid(int32_t v);
 void SetGlobalFlagSamplingRetryTimes(int32_t v);
 void SetGlobalFlagDefaultFullNbrNum(int32_t v);
+void SetGlobalFlagShuffleBufferSize(int32_t v);
 void SetGlobalFlagSamplingSeed(int64_t v);
 void SetGlobalFlagDeviceId(int32_t v);
 

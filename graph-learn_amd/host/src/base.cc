@@ -39,6 +39,7 @@ int64_t gDefaultTimestamp = -1;
 int32_t gIgnoreInvalid = 1;
 int32_t gSamplingRetryTimes = 5;
 int32_t gDefaultFullNbrNum = 100;
+int32_t gShuffleBufferSize = 10240;
 int64_t gSamplingSeed = 0;
 int32_t gDeviceId = 0;
 
@@ -53,6 +54,7 @@ void SetGlobalFlagDefaultTimestamp(int64_t v) { gDefaultTimestamp = v; }
 void SetGlobalFlagIgnoreInvalid(int32_t v) { gIgnoreInvalid = v; }
 void SetGlobalFlagSamplingRetryTimes(int32_t v) { gSamplingRetryTimes = v; }
 void SetGlobalFlagDefaultFullNbrNum(int32_t v) { gDefaultFullNbrNum = v; }
+void SetGlobalFlagShuffleBufferSize(int32_t v) { gShuffleBufferSize = v; }
 void SetGlobalFlagSamplingSeed(int64_t v) { gSamplingSeed = v; }
 void SetGlobalFlagDeviceId(int32_t v) { gDeviceId = v; }
 

@@ -100,9 +100,10 @@ namespace {
 
 // Cursor over [0, size): node_generator.h State + Ordered/Shuffled/Random generators in one.
 struct Traversal {
-  int64_t at = 0;
+  int64_t at = 0;  // State::cursor_: ids [0, at) have been handed out (by_order) or moved into a shuffle buffer
   int32_t epoch = 0;
-  std::vector<int64_t> perm;  // shuffle: this epoch's permutation
+  std::vector<int64_t> buffer;  // ShuffleBuffer: the shuffled positions of the current window ...
+  size_t buffer_at = 0;         // ... and how many of them have been handed out
   std::mt19937_64 rng;
 };
 
@@ -117,16 +118,32 @@ Status NextPositions(Traversal* t, const std::string& strategy, int64_t size, in
   }
   if (request_epoch < t->epoch) return error::OutOfRange("No more nodes exist.");  // node_getter.cc:71-73
   const bool shuffle = strategy == "shuffle";
-  if (shuffle && (int64_t)t->perm.size() != size) {
-    t->perm.resize((size_t)size);
-    std::iota(t->perm.begin(), t->perm.end(), 0);
-    std::shuffle(t->perm.begin(), t->perm.end(), t->rng);
+  for (int32_t i = 0; i < batch_size; ++i) {
+    if (!shuffle) {
+      if (t->at >= size) break;
+      pos->push_back(t->at++);
+      continue;
+    }
+    // ShuffledGenerator::Next (node_generator.h:205-216): an epoch is walked in windows of ShuffleBufferSize CONSECUTIVE
+    // ids, each shuffled as it is filled (ShuffleBuffer::Fill, :168-190) -- not one permutation of the whole type; a
+    // window outlives the request that filled it
+    if (t->buffer_at >= t->buffer.size()) {
+      const int64_t window = std::min<int64_t>(size - t->at, (int64_t)std::max(GLOBAL_FLAG(ShuffleBufferSize), 1));
+      t->buffer.clear();
+      t->buffer_at = 0;
+      if (window <= 0) break;
+      t->buffer.resize((size_t)window);
+      std::iota(t->buffer.begin(), t->buffer.end(), t->at);
+      std::shuffle(t->buffer.begin(), t->buffer.end(), t->rng);
+      t->at += window;
+    }
+    pos->push_back(t->buffer[t->buffer_at++]);
   }
-  for (int32_t i = 0; i < batch_size && t->at < size; ++i, ++t->at) pos->push_back(shuffle ? t->perm[t->at] : t->at);
   if (pos->empty()) {  // begin the next epoch (node_getter.cc:84-90)
     t->at = 0;
     ++t->epoch;
-    t->perm.clear();
+    t->buffer.clear();
+    t->buffer_at = 0;
     return error::OutOfRange("No more nodes exist.");
   }
   return Status::OK();

@@ -71,6 +71,12 @@ def set_sampler_retry_times(value):
   pywrap.set_sampler_retry_times(int(value))
 
 
+def set_shuffle_buffer_size(value):
+  """How many consecutive ids a "shuffle" traversal (node_sampler / edge_sampler / g.V().shuffle(traverse=True)) shuffles at
+  a time (GLOBAL_FLAG(ShuffleBufferSize), 10240: node_generator.h:168-190)."""
+  pywrap.set_shuffle_buffer_size(int(value))
+
+
 def set_sampling_seed(seed):
   """Seed of the counter-based random streams of the samplers (DESIGN.md section 3);
   the reference's samplers cannot be seeded."""
@@ -93,6 +99,6 @@ def _ignored(name):
 
 
 for _n in ("set_inter_threadnum", "set_intra_threadnum", "set_inner_threadnum", "set_datainit_batchsize",
-           "set_inmemory_queuesize", "set_shuffle_buffer_size", "set_tracker_mode", "set_storage_mode",
+           "set_inmemory_queuesize", "set_tracker_mode", "set_storage_mode",
            "set_retry_times", "set_timeout"):
   globals()[_n] = _ignored(_n)

@@ -72,11 +72,12 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("set_ignore_invalid", &SetGlobalFlagIgnoreInvalid);
   m.def("set_sampler_retry_times", &SetGlobalFlagSamplingRetryTimes);
   m.def("set_default_full_nbr_num", &SetGlobalFlagDefaultFullNbrNum);
+  m.def("set_shuffle_buffer_size", &SetGlobalFlagShuffleBufferSize);
   m.def("set_sampling_seed", &SetGlobalFlagSamplingSeed);
   m.def("set_device_id", &SetGlobalFlagDeviceId);
   // thread-pool / queue sizing of the reference's service layer: accepted, no effect
   for (const char* name : {"set_inter_threadnum", "set_inner_threadnum", "set_intra_threadnum",
-                           "set_datainit_batchsize", "set_inmemory_queuesize", "set_shuffle_buffer_size",
+                           "set_datainit_batchsize", "set_inmemory_queuesize",
                            "set_tracker_mode", "set_storage_mode", "set_retry_times", "set_timeout"}) {
     m.def(name, [](int32_t) {});
   }

@@ -398,6 +398,48 @@ def test_node_and_edge_traversal_samplers(gl, g):
     assert nbrs.layer_nodes(1).ids.shape == (16, 3)
 
 
+def test_shuffle_traversal_walks_windows_of_the_shuffle_buffer_size(gl, g):
+    """node_generator.h:168-216 / edge_generator.h: a "shuffle" epoch is NOT one permutation of the whole type -- the
+    ids are taken ShuffleBufferSize (10240 by default) consecutive ones at a time and shuffled inside that window, and a
+    window outlives the request that filled it.  With set_shuffle_buffer_size(16): ids 0..15 in some order, then
+    16..31, ... for nodes, edges and edge end points alike."""
+    gl.set_shuffle_buffer_size(16)
+    try:
+        for what in ("node", "edge"):
+            if what == "node":
+                s = g.node_sampler("entity", batch_size=10, strategy="shuffle")  # a type no other test shuffles
+                get = lambda: s.get().ids  # noqa: E731
+                all_ids = None
+            else:
+                s = g.edge_sampler(EDGE3, batch_size=10, strategy="shuffle")
+                get = lambda: s.get().edge_ids  # noqa: E731
+            for epoch in range(2):
+                got = []
+                while True:
+                    try:
+                        got.append(get())
+                    except gl.OutOfRangeError:
+                        break
+                flat = np.concatenate(got)
+                if what == "node":
+                    if all_ids is None:
+                        all_ids = np.sort(flat)  # the type's ids in storage order are ascending in this fixture
+                    order = {int(v): i for i, v in enumerate(all_ids)}
+                    pos = np.array([order[int(v)] for v in flat])
+                else:
+                    pos = flat
+                n = pos.shape[0]
+                assert sorted(pos.tolist()) == list(range(n))
+                shuffled_somewhere = False
+                for lo in range(0, n, 16):
+                    window = pos[lo:lo + 16]
+                    assert sorted(window.tolist()) == list(range(lo, min(n, lo + 16))), (what, epoch, lo)
+                    shuffled_somewhere |= window.tolist() != sorted(window.tolist())
+                assert shuffled_somewhere
+    finally:
+        gl.set_shuffle_buffer_size(10240)
+
+
 def test_neighbor_loader_device_batches(gl, g):
     """gl.NeighborLoader: every batch is produced and kept on the GPU; one epoch covers every seed once;
     a batch equals what the request-per-hop numpy path returns for the same pinned call counter."""
