@@ -109,14 +109,15 @@ struct Traversal {
 
 // -> positions of the next batch, or OUT_OF_RANGE at an epoch boundary
 Status NextPositions(Traversal* t, const std::string& strategy, int64_t size, int32_t batch_size,
-                     int32_t request_epoch, std::vector<int64_t>* pos) {
+                     int32_t request_epoch, std::vector<int64_t>* pos, const char* what = "nodes") {
+  const std::string done = std::string("No more ") + what + " exist.";  // node_getter.cc:72,89 / edge_getter.cc
   pos->clear();
   if (strategy == "random") {
-    if (size <= 0) return error::OutOfRange("No more nodes exist.");
+    if (size <= 0) return error::OutOfRange(done);
     for (int32_t i = 0; i < batch_size; ++i) pos->push_back((int64_t)(t->rng() % (uint64_t)size));
     return Status::OK();
   }
-  if (request_epoch < t->epoch) return error::OutOfRange("No more nodes exist.");  // node_getter.cc:71-73
+  if (request_epoch < t->epoch) return error::OutOfRange(done);  // node_getter.cc:71-73
   const bool shuffle = strategy == "shuffle";
   for (int32_t i = 0; i < batch_size; ++i) {
     if (!shuffle) {
@@ -144,7 +145,7 @@ Status NextPositions(Traversal* t, const std::string& strategy, int64_t size, in
     ++t->epoch;
     t->buffer.clear();
     t->buffer_at = 0;
-    return error::OutOfRange("No more nodes exist.");
+    return error::OutOfRange(done);
   }
   return Status::OK();
 }
@@ -217,7 +218,7 @@ public:
     Graph* graph = graph_store_->GetGraph(request->EdgeType());
     std::vector<int64_t> pos;
     Status s = NextPositions(&slot.state, request->Strategy(), graph->GetEdgeCount(), request->BatchSize(),
-                             request->Epoch(), &pos);
+                             request->Epoch(), &pos, "edges");
     if (!s.ok()) return s;
     for (int64_t p : pos) response->Append(graph->GetSrcId(p), graph->GetDstId(p), p);  // edge id = load order
     return Status::OK();
