@@ -15,6 +15,8 @@ from graphlearn.settings import *  # noqa: F401,F403
 from graphlearn.errors import *  # noqa: F401,F403
 from graphlearn.utils import Mask, get_mask_type, strategy2op  # noqa: F401
 from graphlearn.decoder import Decoder  # noqa: F401
+from graphlearn.feature_spec import (DenseSpec, DynamicMultivalSpec, DynamicSparseSpec, FeatureSpec,  # noqa: F401
+                                     MultivalSpec, SparseSpec)
 from graphlearn.topology import Topology  # noqa: F401
 from graphlearn.values import Values, Nodes, Edges, SparseNodes, SparseEdges, Layer, Layers  # noqa: F401
 from graphlearn.sampler import *  # noqa: F401,F403

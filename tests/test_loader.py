@@ -157,3 +157,35 @@ def test_deploy_modes():
     with pytest.raises(RuntimeError):
         g.sharded_store("e")  # no torch.distributed process group
     g.close()
+
+
+def test_decoder_feature_spec_follows_the_reference():
+    """Decoder.feature_spec (python/data/decoder.py:123-153, feature_spec.py): the attribute list of the reference's own
+    nn/pytorch dataset test -- ['float', ('string', 100), ('string', 50)] with attr_dims [None, 20, 10] -- and the other
+    shapes: dense ints, ints to embed (need_hash), dynamic string vocabularies, multi-valued strings, and the two
+    assertions (a string needs an attr_dim, a float must not have one)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd", "python"))
+    import graphlearn as gl
+    d = gl.Decoder(labeled=True, attr_types=["float", ("string", 100), ("string", 50)], attr_dims=[None, 20, 10])
+    fs = d.feature_spec
+    assert fs.labeled and not fs.weighted and fs.dimension == 1 + 20 + 10
+    assert len(fs.float_specs) == 1 and isinstance(fs.float_specs[0], gl.DenseSpec)
+    assert [(s.bucket_size, s.dimension, s.need_hash) for s in fs.int_specs] == [(100, 20, False), (50, 10, False)]
+    assert fs.string_specs == [] and d.feature_spec is fs  # built once
+    d = gl.Decoder(attr_types=["int", "int", "string", ("string", None, True), ("string", 30, True)],
+                   attr_dims=[None, 8, 4, 6, 5])
+    fs = d.feature_spec
+    assert isinstance(fs.int_specs[0], gl.DenseSpec)
+    assert isinstance(fs.int_specs[1], gl.DynamicSparseSpec) and fs.int_specs[1].need_hash and fs.int_specs[1].dimension == 8
+    kinds = [type(s).__name__ for s in fs.string_specs]
+    assert kinds == ["DynamicSparseSpec", "DynamicMultivalSpec", "MultivalSpec"] and fs.string_specs[2].bucket_size == 30
+    assert fs.dimension == 1 + 8 + 4 + 6 + 5
+    assert gl.Decoder(attr_types=["float"] * 3).feature_spec.dimension == 3
+    import pytest
+    with pytest.raises(AssertionError):
+        gl.Decoder(attr_types=["string"]).feature_spec  # a string needs an attr_dim
+    with pytest.raises(AssertionError):
+        gl.Decoder(attr_types=["float"], attr_dims=[4]).feature_spec
+    with pytest.raises(ValueError):
+        gl.Decoder(attr_types=["float", "int"], attr_dims=[None]).feature_spec
