@@ -24,6 +24,9 @@ from graphlearn.traversal import *  # noqa: F401,F403
 from graphlearn.graph import Graph  # noqa: F401
 from graphlearn.loader import NeighborLoader, NeighborBatch  # noqa: F401
 from graphlearn.gsl import Dataset  # noqa: F401
+from graphlearn.sampler import SubGraph  # noqa: F401  (python/data/values.py SubGraph: what subgraph_sampler().get() returns)
+from graphlearn.state import EdgeState, NodeState  # noqa: F401
+import graphlearn.nn as nn  # noqa: F401,E402  (gl.nn.Dataset / Data / SubGraph / HeteroSubGraph)
 
 NODE = pywrap.NodeFrom.NODE
 EDGE_SRC = pywrap.NodeFrom.EDGE_SRC

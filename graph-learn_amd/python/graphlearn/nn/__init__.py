@@ -3,3 +3,4 @@
 into {alias: Data}.  `graphlearn.nn.pytorch` wraps it as a torch IterableDataset."""
 from graphlearn.nn.data import Data  # noqa: F401
 from graphlearn.nn.dataset import Dataset  # noqa: F401
+from graphlearn.nn.subgraph import HeteroSubGraph, SubGraph  # noqa: F401

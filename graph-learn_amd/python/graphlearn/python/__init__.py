@@ -7,6 +7,7 @@ _ALIASES = {
     "nn": "graphlearn.nn",
     "nn.data": "graphlearn.nn.data",
     "nn.dataset": "graphlearn.nn.dataset",
+    "nn.subgraph": "graphlearn.nn.subgraph",
     "nn.pytorch": "graphlearn.nn.pytorch",
     "nn.pytorch.data": "graphlearn.nn.pytorch.data",
     "nn.pytorch.data.dataset": "graphlearn.nn.pytorch.data.dataset",

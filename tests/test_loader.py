@@ -189,3 +189,30 @@ def test_decoder_feature_spec_follows_the_reference():
         gl.Decoder(attr_types=["float"], attr_dims=[4]).feature_spec
     with pytest.raises(ValueError):
         gl.Decoder(attr_types=["float", "int"], attr_dims=[None]).feature_spec
+
+
+def test_package_exports_the_reference_names():
+    """graphlearn/__init__.py + python/data/__init__.py + python/nn/__init__.py of the reference: the names user code
+    imports from the package root resolve here too (the RPC deploy helpers aside)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd", "python"))
+    import numpy as np
+    import graphlearn as gl
+    for name in ("Graph", "Dataset", "Decoder", "FeatureSpec", "SparseSpec", "DenseSpec", "MultivalSpec", "NodeState",
+                 "EdgeState", "Topology", "Values", "Nodes", "Edges", "SparseNodes", "SparseEdges", "Layer", "Layers",
+                 "SubGraph", "IndexOption", "pywrap", "nn", "EDGE_SRC", "EDGE_DST", "NODE", "REPLICATE", "CIRCULAR", "Mask",
+                 "OutOfRangeError", "set_padding_mode", "set_shuffle_buffer_size", "set_default_neighbor_id"):
+        assert hasattr(gl, name), name
+    assert gl.nn.Dataset is not None and gl.nn.Data is not None
+    import graphlearn.python.nn as ref_path
+    assert ref_path.SubGraph is gl.nn.SubGraph and ref_path.HeteroSubGraph is gl.nn.HeteroSubGraph
+    sg = gl.nn.SubGraph(np.array([[0, 1, 2], [2, 3, 4]]), gl.nn.Data(ids=np.arange(5)), y=np.ones(5))
+    assert sg.num_nodes == 5 and sg.num_edges == 3 and "y" in sg.keys and sg["nope"] is None
+    hg = gl.nn.HeteroSubGraph({("user", "click", "item"): np.zeros((2, 4), np.int64)},
+                              {"user": np.arange(3), "item": gl.nn.Data(ids=np.arange(7))})
+    assert hg.num_nodes("item") == 7 and hg.num_nodes("user") == 3 and hg.num_edges(("user", "click", "item")) == 4
+    assert hg.node_types == ["user", "item"] and hg.edge_types == [("user", "click", "item")]
+    st = gl.NodeState()
+    st.inc("user", 5)
+    st.inc("user")
+    assert st.get("user") == 6 and st.get("item") == 0
