@@ -180,7 +180,20 @@ class Graph(object):
         store.graph_replica = store.native.build_graph_replica(hot)
     return store
 
+  def add_dataset(self, ds):
+    """graph.py:510-511: datasets register here (gsl.Dataset does it itself) so that close() can stop them -- with
+    prefetch=True a dataset owns a background thread that keeps issuing requests."""
+    if not hasattr(self, "_datasets"):
+      self._datasets = []
+    import weakref
+    self._datasets.append(weakref.ref(ds))
+
   def close(self):
+    for ref in getattr(self, "_datasets", []):
+      ds = ref()
+      if ds is not None:
+        ds.close()
+    self._datasets = []
     if self._client is not None:
       self._client.stop()
       self._client = None
@@ -189,6 +202,33 @@ class Graph(object):
       self._server = None
 
   wait_for_close = close
+
+  # -- the reference's other deployment entry points: its RPC client / server modes, the vineyard storage backend and the
+  # faiss KNN operator are not part of this engine; they fail by name, not by AttributeError
+  def _not_served(self, what):
+    raise NotImplementedError(what + " is not served by this engine: it runs in process, one process per GPU "
+                              "(init(task_index=rank, task_count=world_size) for several GPUs)")
+
+  def deploy_in_local_mode(self, *a, **k):
+    return self.init()
+
+  def deploy_in_server_mode(self, *a, **k):
+    self._not_served("the client / server deploy mode (deploy_in_server_mode)")
+
+  def deploy_in_worker_mode(self, *a, **k):
+    self._not_served("the client / server deploy mode (deploy_in_worker_mode)")
+
+  def vineyard(self, *a, **k):
+    self._not_served("the vineyard storage backend")
+
+  def init_vineyard(self, *a, **k):
+    self._not_served("the vineyard storage backend")
+
+  def node_view(self, *a, **k):
+    self._not_served("node_view (vineyard backend only in the reference too)")
+
+  def search(self, *a, **k):
+    self._not_served("the KNN operator (contrib/knn over faiss)")
 
   # -- introspection ----------------------------------------------------------------
   def get_client(self):
@@ -419,6 +459,20 @@ class Graph(object):
     if feed is not None:
       raise NotImplementedError("feeding a query from a generator is not served")
     return gsl.EdgeSource(gsl.Query(self), edge_type + "_reverse" if reverse else edge_type, mask=mask)
+
+  def SubGraph(self, seed_type, nbr_type, batch_size=64, strategy="random_node", num_nbrs=(0,), feed=None):  # pylint: disable=invalid-name
+    """graph.py:629-671: sub-graph sampling as a GSL entry -- batches of `seed_type` vertices ("random_node" /
+    "in_order_node") or edges ("random_edge" / "in_order_edge") and the sub-graph `nbr_type` induces around each batch
+    (+ num_nbrs sampled neighbours per hop).  -> the SubGraph step: .alias(name).values() closes the query."""
+    if feed is not None:
+      raise NotImplementedError("`feed` is not supported for now.")
+    if strategy not in ("random_node", "random_edge", "in_order_node", "in_order_edge"):
+      raise ValueError("strategy must be random_node / random_edge / in_order_node / in_order_edge, got {!r}".format(strategy))
+    source = self.V(seed_type) if strategy.endswith("node") else self.E(seed_type)
+    source = source.batch(batch_size)
+    if strategy.startswith("random"):
+      source = source.shuffle(traverse=True)
+    return source.SubGraph(nbr_type, num_nbrs=tuple(num_nbrs))
 
   def node_sampler(self, t, batch_size=64, strategy="by_order", node_from=pywrap.NodeFrom.NODE, mask=Mask.NONE):
     """Batches of seed vertices: strategy "by_order" | "shuffle" | "random" (see traversal.py)."""

@@ -494,6 +494,8 @@ class Dataset(object):
     self._chains = self._find_chains() if fuse_hops else {}
     self._fused_calls = int.from_bytes(__import__("os").urandom(6), "little") << 8
     self._prefetch = bool(prefetch) and self._window > 0
+    if hasattr(query.graph, "add_dataset"):
+      query.graph.add_dataset(self)  # dag_dataset.py:59: Graph.close() stops its datasets
     self._queue = None
     self._thread = None
     self._stop = None

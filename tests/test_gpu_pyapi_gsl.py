@@ -340,3 +340,26 @@ def test_query_errors(gl, g):
         gl.Dataset(q).next()
     with pytest.raises(NotImplementedError):
         g.V(NODE1, feed=iter([]))
+
+
+def test_graph_subgraph_entry_deploy_names_and_close_stops_datasets(gl, g):
+    """Graph.SubGraph (graph.py:629-671): sub-graph sampling as a query entry, node and edge seeds, in order and shuffled;
+    the deploy / vineyard / KNN entry points fail by name; a prefetching Dataset registers with its graph
+    (dag_dataset.py:59) -- Graph.close() stops its thread (checked on a graph of its own below)."""
+    import threading
+    q = g.SubGraph("entity", "relation", batch_size=8, strategy="in_order_node").alias("sub").values()
+    sub = gl.Dataset(q).next()["sub"]
+    assert sub.nodes.ids.size == 8 and sub.edge_index.shape[0] == 2
+    q = g.SubGraph("relation", "relation", batch_size=2, strategy="random_edge", num_nbrs=[2]).alias("sub").values()
+    sub = gl.Dataset(q).next()["sub"]
+    assert sub.nodes.ids.size >= 2
+    with pytest.raises(ValueError):
+        g.SubGraph("entity", "relation", strategy="by_magic")
+    for call in (lambda: g.deploy_in_server_mode(), lambda: g.vineyard("x"), lambda: g.search("entity", [[0.0]], None)):
+        with pytest.raises(NotImplementedError):
+            call()
+    ds = gl.Dataset(g.V("entity").batch(4).alias("a").values(), window=2, prefetch=True)
+    ds.next()
+    assert any(t.name == "gsl-prefetch" and t.is_alive() for t in threading.enumerate())
+    ds.close()
+    assert not any(t.name == "gsl-prefetch" and t.is_alive() for t in threading.enumerate())
