@@ -45,7 +45,22 @@ for _code, _cls in _CODE_NAMES:
   globals()[_cls] = _make(_cls)
   _BY_CODE[getattr(pywrap.ErrorCode, _code)] = globals()[_cls]
 
-__all__ = ["OpError", "raise_exception_on_not_ok_status"] + [c for _, c in _CODE_NAMES]
+globals()["RequestStopError"] = _make("RequestStopError")  # errors.py:168-171 (a stopped server: code REQUEST_STOP)
+_BY_CODE[pywrap.ErrorCode.REQUEST_STOP] = globals()["RequestStopError"]
+BaseError = OpError  # the reference's name for the root of these exceptions (errors.py:22-46)
+_BY_CLASS = dict((cls, code) for code, cls in _BY_CODE.items())
+
+
+def exception_type_from_error_code(error_code):
+  return _BY_CODE[error_code]
+
+
+def error_code_from_exception_type(cls):
+  return _BY_CLASS[cls]
+
+
+__all__ = ["OpError", "BaseError", "RequestStopError", "raise_exception_on_not_ok_status", "exception_type_from_error_code",
+           "error_code_from_exception_type"] + [c for _, c in _CODE_NAMES]
 
 
 def raise_exception_on_not_ok_status(status):

@@ -216,3 +216,34 @@ def test_package_exports_the_reference_names():
     st.inc("user", 5)
     st.inc("user")
     assert st.get("user") == 6 and st.get("item") == 0
+
+
+def test_error_and_topology_surface():
+    """python/errors.py: BaseError, one class per status code incl. RequestStopError, and the two lookups between codes and
+    classes; python/data/topology.py: EdgeInfo, get_edge_info, print_one, a conflicting re-declaration refused."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "graph-learn_amd", "python"))
+    import pytest
+    import graphlearn as gl
+    from graphlearn import errors
+    assert issubclass(gl.OutOfRangeError, gl.BaseError) and issubclass(gl.RequestStopError, errors.BaseError)
+    for name in ("CANCELLED", "OUT_OF_RANGE", "UNAVAILABLE", "REQUEST_STOP", "DATA_LOSS"):
+        code = getattr(gl.pywrap.ErrorCode, name)
+        cls = errors.exception_type_from_error_code(code)
+        assert errors.error_code_from_exception_type(cls) == code
+    assert errors.exception_type_from_error_code(gl.pywrap.ErrorCode.OUT_OF_RANGE) is gl.OutOfRangeError
+    e = gl.NotFoundError("nope", gl.pywrap.ErrorCode.NOT_FOUND)
+    assert e.message == "nope" and e.error_code == gl.pywrap.ErrorCode.NOT_FOUND and str(e) == "nope"
+    t = gl.Topology()
+    t.add("buy", "user", "item")
+    t.add("buy", "user", "item")  # the same declaration again (a second source file of the type)
+    with pytest.raises(ValueError):
+        t.add("buy", "item", "user")
+    info = t.get_edge_info("buy")
+    assert (info.src_type, info.dst_type) == ("user", "item") == (t.get_src_type("buy"), t.get_dst_type("buy"))
+    assert t.is_exist("buy") and not t.is_exist("sell")
+    with pytest.raises(ValueError):
+        t.get_edge_info("sell")
+    t.print_one("buy")
+    with pytest.warns(UserWarning):
+        t.print_one("sell")
