@@ -293,7 +293,9 @@ def test_prefetch_delivers_the_same_stream_ahead_of_time():
     assert [[0, 1, 2, 3]] + stream(ds, 8) == plain
     ds.close()
     assert not any(t.name == "gsl-prefetch" and t.is_alive() for t in threading.enumerate())
-    assert ds.next()["a"].ids.tolist() is not None  # a closed dataset starts a fresh worker on demand
+    # a closed dataset starts a fresh worker on demand; where the source's cursor stands depends on how far the stopped
+    # worker had run ahead, so the first thing it delivers may be the end of that epoch
+    assert stream(ds, 2)[-1] != "end" or stream(ds, 1)[0] != "end"
     ds.close()
 
     # an error inside a step reaches the caller and ends production
