@@ -34,6 +34,12 @@ hot rows on every GPU (`hot_ids`) and exchanges only the deduplicated cold tail.
 orchestration below is the same protocol spelled out over torch.distributed: it is what the
 CPU tests run (world size 2/3 over gloo with an oracle-backed `ops`), and it still carries
 design R on GPUs.  Tensors are torch tensors throughout.
+
+The same holds for the other partitioned operations (FullSampler with and without a filter,
+in-degrees of destination ids, the global negative candidate tables and strict in-degree
+negative sampling, DeepWalk / node2vec): one glx_dist_* call each on GPUs, and below that the
+protocol in torch.distributed calls -- tests/test_dist_gloo.py runs it at world size 2 and 3
+against the oracle on the unpartitioned graph, bit for bit.
 """
 import torch
 import torch.distributed as dist
@@ -248,30 +254,237 @@ class ShardedStore:
             raise NotImplementedError("%s runs in the C distributed store (device ops)" % what)
         return self.native
 
-    def sample_full(self, src, max_limit=0, **filter_kwargs):
-        """FullSampler over the shards (sparse response): -> (degrees, nbr, eid) of this rank's rows.  With
-        filter_type / filter_field / values (+ padding_mode, default_neighbor_id): the filtered FullSampler."""
-        return self._native("the partitioned FullSampler").sample_full(src, max_limit, **filter_kwargs)
+    # ---- the partitioned operations of glx_dist_* beyond the dense samplers.  On GPUs each is ONE call into the C store;
+    # ---- below it, the same protocol spelled out over torch.distributed (what the CPU tests run over gloo) -----------
+    def _all_max(self, value):
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def _gather_params(self, values):
+        """Every rank's request parameters, requester-major: owners serve each requester with ITS parameters
+        (glx_dist_set_params_kernel: they ride with the bucket counts of the count exchange)."""
+        mine = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        rows = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(rows, mine, group=self.group)
+        return [r.tolist() for r in rows]
+
+    def sample_full(self, src, max_limit=0, filter_type=0, filter_field=0, values=None, padding_mode=1,
+                    default_neighbor_id=0, default_timestamp=-1):
+        """FullSampler over the shards (sparse response, full_sampler.cc:31-78 behind DistributeRunner): -> (degrees,
+        nbr, eid) of this rank's rows, rows in request order.  With filter_type / filter_field / values: the filtered
+        FullSampler -- every row's value travels with its id and every owner serves each requester's part with ONE call
+        (a timestamp > value filter reads the first value of the part a server is given: filter.h:107-111)."""
+        if self.native is not None:
+            return self.native.sample_full(src, max_limit, filter_type=filter_type, filter_field=filter_field,
+                                           values=values, padding_mode=padding_mode,
+                                           default_neighbor_id=default_neighbor_id, default_timestamp=default_timestamp)
+        filtered = filter_type != 0
+        kinds = self._gather_params([filter_type, filter_field, default_timestamp, padding_mode, default_neighbor_id,
+                                     max_limit])
+        for q, kq in enumerate(kinds):
+            if (kq[0] != 0) != filtered:
+                raise ValueError("rank %d and this rank disagree on whether the FullSampler request has a filter" % q)
+            if kq[5] != max_limit:
+                raise ValueError("rank %d asks for at most %d neighbours per row, this rank for %d" % (q, kq[5], max_limit))
+        bucketed, order, send, recv, most = self._route(src)
+        ids_in = _a2a(bucketed, send, recv, self.group, most)
+        vals_in = _a2a(values[order].contiguous(), send, recv, self.group, most) if filtered else None
+        degs, nbrs, eids, totals = [], [], [], []
+        at = 0
+        for q in range(self.world):  # one call per requester: its rows, its values, its filter kind / padding / default id
+            part = ids_in[at:at + recv[q]]
+            if filtered:
+                kq = kinds[q]
+                d, n, e = self.ops.sample_full_filtered(self.graph, part, max_limit, kq[0], kq[1], vals_in[at:at + recv[q]],
+                                                        kq[3], kq[4], kq[2])
+            else:
+                d, n, e = self.ops.sample_full(self.graph, part, max_limit)
+            degs.append(d)
+            nbrs.append(n)
+            eids.append(e)
+            totals.append(int(n.shape[0]))
+            at += recv[q]
+        deg_b = _a2a(torch.cat(degs), recv, send, self.group, most)  # the sizes half: back in bucketed order
+        # the lists half: what every owner sends this rank is the sum of the sizes it just announced
+        got, at = [], 0
+        for p_ in range(self.world):
+            got.append(int(deg_b[at:at + send[p_]].sum().item()))
+            at += send[p_]
+        bound = self._all_max(max(totals + [0]))
+        nbr_b = _a2a(torch.cat(nbrs), totals, got, self.group, bound)
+        eid_b = _a2a(torch.cat(eids), totals, got, self.group, bound)
+        # stitch: row j of the bucketed request is row order[j] of the caller's
+        n = int(src.shape[0])
+        i64 = torch.int64
+        deg_out = torch.zeros(n, dtype=deg_b.dtype)
+        deg_out[order] = deg_b
+        off_b = torch.zeros(n + 1, dtype=i64)
+        off_b[1:] = torch.cumsum(deg_b.to(i64), 0)
+        off_out = torch.zeros(n + 1, dtype=i64)
+        off_out[1:] = torch.cumsum(deg_out.to(i64), 0)
+        pos_b = torch.empty(n, dtype=i64)
+        pos_b[order] = torch.arange(n, dtype=i64)
+        total = int(off_out[-1].item())
+        row_of = torch.repeat_interleave(torch.arange(n, dtype=i64), deg_out.to(i64), output_size=total)
+        from_b = off_b[pos_b[row_of]] + (torch.arange(total, dtype=i64) - off_out[row_of])
+        return deg_out, nbr_b[from_b], eid_b[from_b]
+
+    def _owner_table(self):
+        """Collective, once: the destination ids this rank OWNS (llabs(id) % P), ascending, with their in-degree summed
+        over ALL shards -- every shard run-length-encodes its own destinations, the (id, count) pairs travel to the
+        owners, the owners reduce by key (dst_totals in glx_dist.hip; the per-owner half of the unpartitioned storage's
+        GetAllDstIds() / GetAllInDegrees(), topo_statics.cc:32-69)."""
+        if getattr(self, "_own", None) is None:
+            uniq, cnt = self.ops.dst_counts(self.graph)
+            bucketed, order, send, recv, most = self._route(uniq)
+            ids_in = _a2a(bucketed, send, recv, self.group, most)
+            cnt_in = _a2a(cnt[order].contiguous(), send, recv, self.group, most)
+            own_id, inverse = torch.unique(ids_in, return_inverse=True)  # ascending
+            own_cnt = torch.zeros(own_id.shape[0], dtype=torch.int64)
+            own_cnt.index_add_(0, inverse, cnt_in)
+            self._own = (own_id, own_cnt)
+        return self._own
 
     def in_degrees(self, ids):
-        """Collective: in-degrees of destination ids summed over ALL shards (GetDegree with node_from = dst)."""
-        return self._native("the partitioned in-degree lookup").in_degrees(ids)
+        """Collective: in-degrees of destination ids summed over ALL shards (GetDegree with node_from = dst,
+        degree_getter.cc; GraphStorage::GetInDegree, topo_statics.cc:62-69); ids nobody points to answer 0."""
+        if self.native is not None:
+            return self.native.in_degrees(ids)
+        own_id, own_cnt = self._owner_table()
+        bucketed, order, send, recv, most = self._route(ids)
+        asked = _a2a(bucketed, send, recv, self.group, most)
+        if own_id.shape[0]:
+            at = torch.searchsorted(own_id, asked).clamp(max=own_id.shape[0] - 1)
+            answer = torch.where(own_id[at] == asked, own_cnt[at], torch.zeros_like(asked))
+        else:
+            answer = torch.zeros_like(asked)
+        back = _a2a(answer, recv, send, self.group, most)
+        return self.ops.stitch(back, order).to(torch.int32)
 
     def negative_table(self, by_in_degree=False):
         """Collective: the negative samplers' candidate list over the WHOLE edge type (every shard's destination ids,
-        ascending; uniform or weighted by global in-degree) -> glx.Negative, identical on every rank."""
-        return self._native("the global negative candidate table").negative_table(by_in_degree)
+        ascending -- the one order every shard count agrees on; uniform or weighted by global in-degree), identical on every
+        rank (random_negative_sampler.cc:30-63 / in_degree_negative_sampler.cc:29-135 draw from the storage's
+        GetAllDstIds() / GetAllInDegrees())."""
+        if self.native is not None:
+            return self.native.negative_table(by_in_degree)
+        own_id, own_cnt = self._owner_table()
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(sizes, torch.tensor([own_id.shape[0]], dtype=torch.int64), group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        most = max(sizes + [1])
+        pad = torch.zeros((2, most), dtype=torch.int64)
+        pad[0, :own_id.shape[0]] = own_id
+        pad[1, :own_cnt.shape[0]] = own_cnt
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        ids = torch.cat([a[0, :c] for a, c in zip(parts, sizes)])
+        cnt = torch.cat([a[1, :c] for a, c in zip(parts, sizes)])
+        srt = torch.argsort(ids)  # owners hold disjoint id sets: no ties
+        return self.ops.negative_table(ids[srt].contiguous(), cnt[srt].to(torch.float32) if by_in_degree else None)
 
     def negative_sample(self, table, src, count, exclude=0, default_neighbor_id=0, seed=0, call_counter=0):
         """Negative sampling over the shards from `table` (negative_table()): what an unpartitioned store with the same
-        table answers.  Collective when exclude = glx.NEG_EXCLUDE_NEIGHBORS (strict in-degree sampling)."""
-        return self._native("partitioned negative sampling").negative_sample(table, src, count, exclude=exclude,
-                                                                             default_neighbor_id=default_neighbor_id,
-                                                                             seed=seed, call_counter=call_counter)
+        table answers.  Collective when exclude = 1 (glx.NEG_EXCLUDE_NEIGHBORS, strict in-degree sampling): a row's
+        exclusion set is its source vertex's adjacency, which lives with the row's owner -- the rows travel there with
+        their index in the request (the random stream they draw from) and the answers travel back."""
+        if self.native is not None:
+            return self.native.negative_sample(table, src, count, exclude=exclude, default_neighbor_id=default_neighbor_id,
+                                               seed=seed, call_counter=call_counter)
+        if exclude != 1:
+            return self.ops.negative_sample(table, exclude, self.graph, src, None, count, default_neighbor_id, seed,
+                                            call_counter)
+        params = self._gather_params([seed, call_counter, count, default_neighbor_id])
+        for q, pq in enumerate(params):
+            if pq[2] != count:
+                raise ValueError("rank %d asks for %d negatives per row, this rank for %d" % (q, pq[2], count))
+        bucketed, order, send, recv, most = self._route(src)
+        ids_in = _a2a(bucketed, send, recv, self.group, most)
+        rows_in = _a2a(order, send, recv, self.group, most)
+        outs, at = [], 0
+        for q in range(self.world):  # every requester's rows with ITS seed / call counter / default id
+            pq = params[q]
+            outs.append(self.ops.negative_sample(table, 1, self.graph, ids_in[at:at + recv[q]], rows_in[at:at + recv[q]],
+                                                 count, pq[3], pq[0], pq[1]))
+            at += recv[q]
+        back = _a2a(torch.cat(outs), recv, send, self.group, most)
+        return self.ops.stitch(back, order)
 
-    def random_walk(self, seeds, walk_len, p=1.0, q=1.0, **kwargs):
-        """Collective RandomWalk over the shards: DeepWalk (p = q = 1) or node2vec, the single store's walks."""
-        return self._native("the partitioned random walk").random_walk(seeds, walk_len, p=p, q=q, **kwargs)
+    def random_walk(self, seeds, walk_len, p=1.0, q=1.0, default_neighbor_id=0, seed=0, call_counter=0, full_nbr_num=100,
+                    default_weight=0.0):
+        """Collective RandomWalk over the shards -> walks[batch, walk_len], the single store's walks.
+        DeepWalk (p = q = 1; random_walk.cc:168-190): step t of walker i = RandomSampler's draw 0 of the stream (seed,
+        call_counter + t, i) on the vertex it stands on -- one partitioned request with neighbor_count 1 per step.
+        node2vec (WeightedRandomWalk, random_walk.cc:192-272): per step ONE partitioned FullSampler request (limit F)
+        brings the current vertices' first F neighbours and their weights to the requester; the parents' lists are the
+        previous step's, read through the reference's cursor (not advanced for walkers whose current vertex has no
+        out-edges: random_walk.cc:214-226); the step itself runs on the requester."""
+        if self.native is not None:
+            return self.native.random_walk(seeds, walk_len, p=p, q=q, default_neighbor_id=default_neighbor_id, seed=seed,
+                                           call_counter=call_counter, full_nbr_num=full_nbr_num,
+                                           default_weight=default_weight)
+        eps = 32 * 1.1920928955078125e-07  # RandomWalkRequest::IsDeepWalk, random_walk_request.cc:152-160
+        f32 = lambda x: float(torch.tensor(x, dtype=torch.float32))  # noqa: E731
+        deep = abs(f32(p) - 1.0) < eps and abs(f32(q) - 1.0) < eps
+        batch = int(seeds.shape[0])
+        walks = torch.empty((batch, walk_len), dtype=torch.int64)
+        cur = seeds
+        if deep:
+            for t in range(walk_len):
+                nxt, _ = self.sample("RandomSampler", cur, 1, seed=seed, call_counter=call_counter + t, padding_mode=1,
+                                     default_neighbor_id=default_neighbor_id)
+                walks[:, t] = nxt.reshape(-1)
+                cur = nxt.reshape(-1).contiguous()
+            return walks
+        if not 1 <= full_nbr_num <= 2048:
+            raise ValueError("DefaultFullNbrNum must be in [1, 2048], got %d" % full_nbr_num)
+        par = seeds
+        prev = None  # (deg, nbr) of the previous step's current vertices, walker by walker
+        for t in range(walk_len):
+            deg_c, nbr_c, w_c = self._full_lists_with_weights(cur, full_nbr_num, default_weight)
+            nxt = self.ops.node2vec_step(par, deg_c, nbr_c, w_c, prev[0] if prev else None, prev[1] if prev else None,
+                                         p, q, seed, call_counter + t, default_neighbor_id)
+            walks[:, t] = nxt
+            # the next step's parent is this step's vertex -- except after step 0, whose parent stays the seed
+            # (random_walk_request.cc:120-131: t <= 1 -> the seed): the seed IS this step's vertex then
+            par, cur, prev = cur, nxt.contiguous(), (deg_c, nbr_c)
+        return walks
+
+    def _full_lists_with_weights(self, ids, limit, default_weight):
+        """The partitioned FullSampler request of a node2vec step: -> (degrees, nbr, weight) in request order; the
+        answer carries edge weights where the edge ids would be (glx_dist_slot_weights_kernel)."""
+        bucketed, order, send, recv, most = self._route(ids)
+        ids_in = _a2a(bucketed, send, recv, self.group, most)
+        d, n, w = self.ops.full_lists_with_weights(self.graph, ids_in, limit, default_weight)
+        totals, at = [], 0
+        off = torch.zeros(d.shape[0] + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(d.to(torch.int64), 0)
+        for q in range(self.world):
+            totals.append(int((off[at + recv[q]] - off[at]).item()))
+            at += recv[q]
+        deg_b = _a2a(d, recv, send, self.group, most)
+        got, at = [], 0
+        for p_ in range(self.world):
+            got.append(int(deg_b[at:at + send[p_]].sum().item()))
+            at += send[p_]
+        bound = self._all_max(max(totals + [0]))
+        nbr_b = _a2a(n, totals, got, self.group, bound)
+        w_b = _a2a(w, totals, got, self.group, bound)
+        m = int(ids.shape[0])
+        i64 = torch.int64
+        deg_out = torch.zeros(m, dtype=deg_b.dtype)
+        deg_out[order] = deg_b
+        off_b = torch.zeros(m + 1, dtype=i64)
+        off_b[1:] = torch.cumsum(deg_b.to(i64), 0)
+        off_out = torch.zeros(m + 1, dtype=i64)
+        off_out[1:] = torch.cumsum(deg_out.to(i64), 0)
+        pos_b = torch.empty(m, dtype=i64)
+        pos_b[order] = torch.arange(m, dtype=i64)
+        total = int(off_out[-1].item())
+        row_of = torch.repeat_interleave(torch.arange(m, dtype=i64), deg_out.to(i64), output_size=total)
+        from_b = off_b[pos_b[row_of]] + (torch.arange(total, dtype=i64) - off_out[row_of])
+        return deg_out, nbr_b[from_b], w_b[from_b]
 
     def sample_filtered(self, sampler, src, k, filter_type, filter_field, values, seed=0, call_counter=0,
                         padding_mode=1, default_neighbor_id=0, retry_times=5, default_timestamp=-1):
