@@ -7,6 +7,7 @@
 #ifndef GLX_HOST_CLIENT_H_
 #define GLX_HOST_CLIENT_H_
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,10 @@
 #include "graphlearn/status.h"
 
 namespace graphlearn {
+
+class DagRequest;
+class GetDagValuesRequest;
+class GetDagValuesResponse;
 
 class Client {
 public:
@@ -31,6 +36,12 @@ public:
   Status SubGraph(const SubGraphRequest* request, SubGraphResponse* response);
   Status GetStats(const GetStatsRequest* request, GetStatsResponse* response);
   Status RunOp(const OpRequest* request, OpResponse* response);
+  // GSL queries (include/client.h:57-58; service/executor.cc:46-71): RunDag registers the query and starts running
+  // it in the background (a known id is not an error); GetDagValues takes the next finished round, blocking until
+  // there is one.  `cancelled` (optional) lets a caller abandon the wait.  See dag.h.
+  Status RunDag(const DagRequest* request);
+  Status GetDagValues(const GetDagValuesRequest* request, GetDagValuesResponse* response,
+                      const std::function<bool()>* cancelled = nullptr);
   Status Stop();
 
 private:

@@ -42,6 +42,7 @@ struct NodeSource {
   int32_t format = kAttributed;
   AttributeInfo attr_info;
   IndexOption option;
+  std::string view_type, use_attrs;  // vineyard views (data_source.h:86-87): carried, never read
   bool IsWeighted() const { return format & kWeighted; }
   bool IsLabeled() const { return format & kLabeled; }
   bool IsTimestamped() const { return format & kTimestamped; }
@@ -55,6 +56,7 @@ struct EdgeSource {
   Direction direction = kOrigin;
   AttributeInfo attr_info;
   IndexOption option;
+  std::string view_type, use_attrs;  // :142-143, as above
   bool IsWeighted() const { return format & kWeighted; }
   bool IsLabeled() const { return format & kLabeled; }
   bool IsTimestamped() const { return format & kTimestamped; }

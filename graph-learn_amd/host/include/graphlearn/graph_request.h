@@ -24,6 +24,9 @@ public:
   LookupNodesRequest();
   explicit LookupNodesRequest(const std::string& node_type);
   OpRequest* Clone() const override;
+  using OpRequest::Set;
+  void Init(const Tensor::Map& params) override;
+  void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) override;
   void Set(const int64_t* node_ids, int32_t batch_size);
   const std::string& NodeType() const;
   int32_t Size() const;
@@ -39,6 +42,9 @@ public:
   LookupEdgesRequest();
   explicit LookupEdgesRequest(const std::string& edge_type);
   OpRequest* Clone() const override;
+  using OpRequest::Set;
+  void Init(const Tensor::Map& params) override;
+  void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) override;
   // src_ids route the request in distributed mode (graph_request.h:171-173); the
   // lookup itself is by edge id.
   void Set(const int64_t* edge_ids, const int64_t* src_ids, int32_t batch_size);
@@ -97,6 +103,9 @@ public:
   explicit GetDegreeRequest(const std::string& edge_type, NodeFrom node_from = kEdgeSrc);
   NodeFrom GetNodeFrom() const;
   OpRequest* Clone() const override;
+  using OpRequest::Set;
+  void Init(const Tensor::Map& params) override;
+  void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) override;
   void Set(const int64_t* node_ids, int32_t batch_size);
   const std::string& EdgeType() const;
   int32_t Size() const;
@@ -156,6 +165,9 @@ public:
   RandomWalkRequest();
   RandomWalkRequest(const std::string& type, float p, float q, int32_t walk_len = 1);
   OpRequest* Clone() const override;
+  using OpRequest::Set;
+  void Init(const Tensor::Map& params) override;
+  void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) override;
   void Set(const int64_t* src_ids, int32_t batch_size);
   const std::string& Type() const;
   float P() const;
@@ -194,6 +206,7 @@ public:
   GetNodesRequest(const std::string& type, const std::string& strategy, NodeFrom node_from, int32_t batch_size,
                   int32_t epoch = 0);
   OpRequest* Clone() const override;
+  void Init(const Tensor::Map& params) override;
   const std::string& Type() const;
   const std::string& Strategy() const;
   NodeFrom GetNodeFrom() const;
@@ -216,6 +229,7 @@ public:
   GetEdgesRequest();
   GetEdgesRequest(const std::string& edge_type, const std::string& strategy, int32_t batch_size, int32_t epoch = 0);
   OpRequest* Clone() const override;
+  void Init(const Tensor::Map& params) override;
   const std::string& EdgeType() const;
   const std::string& Strategy() const;
   int32_t BatchSize() const;

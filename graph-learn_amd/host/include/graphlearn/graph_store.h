@@ -83,8 +83,11 @@ struct NodeColumns {
 
 }  // namespace io
 
-struct IndexOption {  // include/index_option.h
-  std::string name;
+struct IndexOption {  // include/index_option.h:24-48
+  std::string name;  // "sort": Build() orders every adjacency row (timestamp, else weight)
+  // the KNN index parameters: carried, never read (no KNN operator here)
+  std::string index_type;
+  int32_t dimension = 0, nlist = 0, nprobe = 0, m = 0;
 };
 
 // "UpdateEdges" / "UpdateNodes" (include/graph_request.h:36-124, service/request/graph_update_request.cc): a batch of

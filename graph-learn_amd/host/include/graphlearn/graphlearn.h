@@ -4,6 +4,7 @@
 #include "graphlearn/aggregating_request.h"
 #include "graphlearn/client.h"
 #include "graphlearn/config.h"
+#include "graphlearn/dag.h"
 #include "graphlearn/data_source.h"
 #include "graphlearn/graph_request.h"
 #include "graphlearn/graph_store.h"

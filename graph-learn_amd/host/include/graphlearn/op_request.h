@@ -20,8 +20,15 @@ public:
   explicit OpRequest(const std::string& shard_key = kUnspecified);
   virtual ~OpRequest() = default;
 
+  // The two steps a DAG node's request is made in (core/runner/dag_node_runner.cc:100-109): Init from the node's
+  // parameters, Set from the tensors its in-edges deliver (dense ones by input name; ragged ones -- the output of
+  // a FullSampler upstream -- in sparse_tensors).
   virtual void Init(const Tensor::Map& params) { (void)params; }
-  virtual void Set(const Tensor::Map& tensors) { (void)tensors; }
+  virtual void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) {
+    (void)tensors;
+    (void)sparse_tensors;
+  }
+  void Set(const Tensor::Map& tensors) { Set(tensors, SparseTensor::Map()); }
   virtual std::string Name() const;
   virtual OpRequest* Clone() const;
   const std::string& ShardKey() const { return shard_key_; }

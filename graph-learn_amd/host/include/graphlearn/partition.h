@@ -23,8 +23,6 @@
 
 namespace graphlearn {
 
-extern const char* kRngRows;
-
 class Sticker {
 public:
   explicit Sticker(int32_t capacity) : values_(capacity) {}

@@ -36,7 +36,8 @@ public:
                   FilterField filter_field = kFieldUnspecified);
   OpRequest* Clone() const override;
   void Init(const Tensor::Map& params) override;
-  void Set(const Tensor::Map& tensors) override;
+  using OpRequest::Set;
+  void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) override;
   void Set(const int64_t* src_ids, int32_t batch_size);
 
   const std::string& Type() const;
@@ -81,6 +82,9 @@ public:
   ConditionalSamplingRequest(const std::string& type, const std::string& strategy, int32_t neighbor_count,
                              const std::string& dst_node_type, bool batch_share, bool unique);
   OpRequest* Clone() const override;
+  using SamplingRequest::Set;
+  void Init(const Tensor::Map& params) override;
+  void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) override;
   void SetIds(const int64_t* src_ids, const int64_t* dst_ids, int32_t batch_size);
   void SetSelectedCols(const std::vector<int32_t>& int_cols, const std::vector<float>& int_props,
                        const std::vector<int32_t>& float_cols, const std::vector<float>& float_props,

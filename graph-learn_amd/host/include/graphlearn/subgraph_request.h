@@ -28,7 +28,8 @@ public:
   void Set(const int64_t* seeds, int32_t count);
   // link sub-graphs: the batch is the source ids followed by the destination ids (subgraph_request.cc:82-87)
   void Set(const int64_t* sources, const int64_t* destinations, int32_t pairs);
-  void Set(const Tensor::Map& tensors) override;
+  using OpRequest::Set;
+  void Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) override;
   void Init(const Tensor::Map& params) override;
   OpRequest* Clone() const override;
 };

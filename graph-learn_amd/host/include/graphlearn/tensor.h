@@ -68,5 +68,24 @@ private:
 
 #undef GLX_TENSOR_TYPED_API
 
+// Ragged values: `segments` (int32, one count per row) + `values` (the rows back to back) -- what a
+// FullSampler answers with and what a DAG edge hands to the next node (include/sparse_tensor.h:26-60).
+// Copies share storage, like Tensor.
+class SparseTensor {
+public:
+  SparseTensor() : segments_(kInt32), values_(kInt64) {}
+  SparseTensor(const Tensor& segments, const Tensor& values) : segments_(segments), values_(values) {}
+  const Tensor& Segments() const { return segments_; }
+  const Tensor& Values() const { return values_; }
+  Tensor* MutableSegments() { return &segments_; }
+  Tensor* MutableValues() { return &values_; }
+
+  typedef std::unordered_map<std::string, SparseTensor> Map;
+
+private:
+  Tensor segments_;
+  Tensor values_;
+};
+
 }  // namespace graphlearn
 #endif  // GLX_HOST_TENSOR_H_

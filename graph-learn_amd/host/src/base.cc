@@ -2,7 +2,9 @@
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 #include <unordered_set>
+#include <string>
 #include <vector>
 #include <cstring>
 
@@ -40,6 +42,14 @@ int32_t gIgnoreInvalid = 1;
 int32_t gSamplingRetryTimes = 5;
 int32_t gDefaultFullNbrNum = 100;
 int32_t gShuffleBufferSize = 10240;
+int32_t gDeployMode = 0;
+int32_t gClientId = 0;
+int32_t gClientCount = 1;
+int32_t gServerCount = 1;
+int32_t gTimeout = 60;
+int32_t gTapeCapacity = 10;
+int32_t gDatasetCapacity = 10;
+int32_t gTrackerMode = 1;
 int64_t gSamplingSeed = 0;
 int32_t gDeviceId = 0;
 
@@ -55,35 +65,86 @@ void SetGlobalFlagIgnoreInvalid(int32_t v) { gIgnoreInvalid = v; }
 void SetGlobalFlagSamplingRetryTimes(int32_t v) { gSamplingRetryTimes = v; }
 void SetGlobalFlagDefaultFullNbrNum(int32_t v) { gDefaultFullNbrNum = v; }
 void SetGlobalFlagShuffleBufferSize(int32_t v) { gShuffleBufferSize = v; }
+void SetGlobalFlagDeployMode(int32_t v) { gDeployMode = v; }
+void SetGlobalFlagClientId(int32_t v) { gClientId = v; }
+void SetGlobalFlagClientCount(int32_t v) { gClientCount = v; }
+void SetGlobalFlagServerCount(int32_t v) { gServerCount = v; }
+void SetGlobalFlagTimeout(int32_t v) { gTimeout = v; }
+void SetGlobalFlagTapeCapacity(int32_t v) { gTapeCapacity = v; }
+void SetGlobalFlagDatasetCapacity(int32_t v) { gDatasetCapacity = v; }
+void SetGlobalFlagTrackerMode(int32_t v) { gTrackerMode = v; }
+int32_t GetGlobalFlagTrackerMode() { return gTrackerMode; }
+namespace {
+std::mutex g_unused_mtx;
+std::unordered_map<std::string, std::string>& UnusedFlags() {
+  static auto* m = new std::unordered_map<std::string, std::string>;
+  return *m;
+}
+}  // namespace
+void SetGlobalFlagUnused(const char* name, int64_t v) { SetGlobalFlagUnused(name, std::to_string(v)); }
+void SetGlobalFlagUnused(const char* name, const std::string& v) {
+  std::lock_guard<std::mutex> g(g_unused_mtx);
+  UnusedFlags()[name] = v;
+}
 void SetGlobalFlagSamplingSeed(int64_t v) { gSamplingSeed = v; }
 void SetGlobalFlagDeviceId(int32_t v) { gDeviceId = v; }
 
 // -------------------------------------------------------------- constants --
-// Key strings only need to be distinct and stable inside one process (the
-// reference ships them in protobuf messages; here nothing is serialised).
+// Key strings: the reference's values (service/constants.cc:20-72), see constants.h.
 const char* kUnspecified = "unspecified";
 const char* kOpName = "op";
-const char* kNodeType = "node_type";
-const char* kEdgeType = "edge_type";
-const char* kType = "type";
-const char* kSrcIds = "src_ids";
-const char* kNodeIds = "node_ids";
-const char* kEdgeIds = "edge_ids";
-const char* kNeighborCount = "neighbor_count";
-const char* kStrategy = "strategy";
-const char* kFloatAttrKey = "float_attrs";
-const char* kIntAttrKey = "int_attrs";
-const char* kWeightKey = "weights";
-const char* kLabelKey = "labels";
-const char* kTimestampKey = "timestamps";
-const char* kDegreeKey = "degrees";
-const char* kSideInfo = "side_info";
-const char* kSegmentIds = "segment_ids";
-const char* kNumSegments = "num_segments";
-const char* kSegments = "segments";
-const char* kFilterType = "ftype";    // service/constants.cc:60-62
+const char* kNodeType = "nt";
+const char* kEdgeType = "et";
+const char* kType = "tp";
+const char* kSrcType = "st";
+const char* kDstType = "dt";
+const char* kSrcIds = "sid";
+const char* kDstIds = "did";
+const char* kNodeIds = "nid";
+const char* kEdgeIds = "eid";
+const char* kNeighborCount = "nbc";
+const char* kNeighborIds = "nbi";
+const char* kBatchSize = "bs";
+const char* kIsSparse = "is";
+const char* kStrategy = "str";
+const char* kDegreeKey = "deg";
+const char* kWeightKey = "wei";
+const char* kLabelKey = "lb";
+const char* kTimestampKey = "ts";
+const char* kIntAttrKey = "ia";
+const char* kFloatAttrKey = "fa";
+const char* kStringAttrKey = "sa";
+const char* kSideInfo = "si";
+const char* kDirection = "dir";
+const char* kSegmentIds = "segi";
+const char* kNumSegments = "ns";
+const char* kSegments = "sm";
+const char* kDistances = "dis";
+const char* kRowIndices = "ridx";
+const char* kColIndices = "cidx";
+const char* kSeedType = "seedt";
+const char* kNbrType = "nbrt";
+const char* kCount = "cnt";
+const char* kBatchShare = "batch_share";
+const char* kUnique = "unique";
+const char* kIntCols = "icols";
+const char* kIntProps = "ipps";
+const char* kFloatCols = "fcols";
+const char* kFloatProps = "fpps";
+const char* kStrCols = "scols";
+const char* kStrProps = "spps";
+const char* kFilterType = "ftype";
 const char* kFilterField = "field";
 const char* kFilterValues = "filt";
+const char* kDegrees = "dg";
+const char* kEpoch = "ep";
+const char* kNodeFrom = "nf";
+const char* kNeedDist = "need_dist";
+const char* kDistToSrc = "dist_to_src";
+const char* kDistToDst = "dist_to_dst";
+const char* kSparseIds = "sparse_ids";
+const char* kCallCounter = "call_counter";
+const char* kRngRows = "rng_rows";
 
 // ----------------------------------------------------------------- tensor --
 // Storage of the numeric tensors.  A response of the device path is one large block

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <vector>
 
+#include "graphlearn/dag.h"
 #include "graphlearn/operator.h"
 
 namespace graphlearn {
@@ -92,6 +93,7 @@ uintptr_t Server::DeviceFeatures(const std::string& node_type) {
 
 void Server::Stop() {
   if (store_) {
+    DagScheduler::StopAll();  // the queries read this store: they end before it does
     if (bound_) {
       std::lock_guard<std::mutex> g(g_bound_mtx);
       for (size_t i = 0; i < g_bound.size(); ++i) {

@@ -24,17 +24,6 @@
 namespace graphlearn {
 
 namespace {
-const char* kStrategyKey = "strategy";     // kStrategy
-const char* kDstType = "dst_type";
-const char* kDstIds = "dst_ids";
-const char* kBatchShare = "batch_share";
-const char* kUnique = "unique";
-const char* kIntCols = "int_cols";
-const char* kIntProps = "int_props";
-const char* kFloatCols = "float_cols";
-const char* kFloatProps = "float_props";
-const char* kStrCols = "str_cols";
-const char* kStrProps = "str_props";
 
 std::vector<int32_t> Ints(const Tensor::Map& m, const char* k) {
   auto it = m.find(k);
@@ -54,8 +43,8 @@ ConditionalSamplingRequest::ConditionalSamplingRequest(const std::string& type, 
                                                        int32_t neighbor_count, const std::string& dst_node_type,
                                                        bool batch_share, bool unique)
     : SamplingRequest(type, "ConditionalNegativeSampler", neighbor_count) {
-  ADD_TENSOR(params_, kStrategyKey, kString, 1);
-  params_[kStrategyKey].AddString(strategy);
+  ADD_TENSOR(params_, kStrategy, kString, 1);
+  params_[kStrategy].AddString(strategy);
   ADD_TENSOR(params_, kDstType, kString, 1);
   params_[kDstType].AddString(dst_node_type);
   ADD_TENSOR(params_, kBatchShare, kInt32, 1);
@@ -63,6 +52,35 @@ ConditionalSamplingRequest::ConditionalSamplingRequest(const std::string& type, 
   ADD_TENSOR(params_, kUnique, kInt32, 1);
   params_[kUnique].AddInt32(unique ? 1 : 0);
   ADD_TENSOR(tensors_, kDstIds, kInt64, 64);
+}
+
+// DagNodeRunner-style construction (conditional_sampling_request.cc:99-181): the node `.outNeg(t).sample(n)
+// .by(strategy).where(target, condition)` of a query; kStrategy is the strategy WORD here ("random"), the operator
+// name is fixed.
+void ConditionalSamplingRequest::Init(const Tensor::Map& params) {
+  Tensor::Map base;
+  for (const char* k : {kEdgeType, kNeighborCount}) base.emplace(k, params.at(k));
+  ADD_TENSOR(base, kStrategy, kString, 1);
+  base[kStrategy].AddString("ConditionalNegativeSampler");
+  SamplingRequest::Init(base);
+  ADD_TENSOR(params_, kStrategy, kString, 1);
+  params_[kStrategy].AddString(params.at(kStrategy).GetString(0));
+  ADD_TENSOR(params_, kDstType, kString, 1);
+  params_[kDstType].AddString(params.at(kDstType).GetString(0));
+  ADD_TENSOR(params_, kBatchShare, kInt32, 1);
+  params_[kBatchShare].AddInt32(params.at(kBatchShare).GetInt32(0));
+  ADD_TENSOR(params_, kUnique, kInt32, 1);
+  params_[kUnique].AddInt32(params.at(kUnique).GetInt32(0));
+  ADD_TENSOR(tensors_, kDstIds, kInt64, 64);
+  SetSelectedCols(Ints(params, kIntCols), Floats(params, kIntProps), Ints(params, kFloatCols), Floats(params, kFloatProps),
+                  Ints(params, kStrCols), Floats(params, kStrProps));
+}
+
+void ConditionalSamplingRequest::Set(const Tensor::Map& tensors, const SparseTensor::Map&) {
+  const Tensor& src = tensors.at(kSrcIds);
+  const Tensor& dst = tensors.at(kDstIds);
+  Set(src.GetInt64(), src.Size());
+  tensors_[kDstIds].AddInt64(dst.GetInt64(), dst.GetInt64() + dst.Size());
 }
 
 OpRequest* ConditionalSamplingRequest::Clone() const {
@@ -99,7 +117,7 @@ void ConditionalSamplingRequest::SetSelectedCols(const std::vector<int32_t>& int
   put_f(kStrProps, str_props);
 }
 
-const std::string& ConditionalSamplingRequest::Strategy() const { return params_.at(kStrategyKey).GetString(0); }
+const std::string& ConditionalSamplingRequest::Strategy() const { return params_.at(kStrategy).GetString(0); }
 const std::string& ConditionalSamplingRequest::DstNodeType() const { return params_.at(kDstType).GetString(0); }
 bool ConditionalSamplingRequest::BatchShare() const { return params_.at(kBatchShare).GetInt32(0) != 0; }
 bool ConditionalSamplingRequest::Unique() const { return params_.at(kUnique).GetInt32(0) != 0; }

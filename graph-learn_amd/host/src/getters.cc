@@ -14,9 +14,6 @@
 namespace graphlearn {
 
 namespace {
-const char* kBatchSize = "batch_size";
-const char* kEpoch = "epoch";
-const char* kNodeFromKey = "node_from";
 
 void InitTraversal(Tensor::Map* params, const char* op, const char* type_key, const std::string& type,
                    const std::string& strategy, int32_t batch_size, int32_t epoch) {
@@ -38,15 +35,22 @@ GetNodesRequest::GetNodesRequest(const std::string& type, const std::string& str
                                  int32_t batch_size, int32_t epoch)
     : OpRequest(kNodeIds) {
   InitTraversal(&params_, "GetNodes", kType, type, strategy, batch_size, epoch);
-  ADD_TENSOR(params_, kNodeFromKey, kInt32, 1);
-  params_[kNodeFromKey].AddInt32((int32_t)node_from);
+  ADD_TENSOR(params_, kNodeFrom, kInt32, 1);
+  params_[kNodeFrom].AddInt32((int32_t)node_from);
+}
+// DagNodeRunner-style construction (graph_lookup_request.cc:146-157): the root of a `g.V(t).batch(n)` query.
+void GetNodesRequest::Init(const Tensor::Map& params) {
+  InitTraversal(&params_, "GetNodes", kType, params.at(kNodeType).GetString(0), params.at(kStrategy).GetString(0),
+                params.at(kBatchSize).GetInt32(0), params.at(kEpoch).GetInt32(0));
+  ADD_TENSOR(params_, kNodeFrom, kInt32, 1);
+  params_[kNodeFrom].AddInt32(params.at(kNodeFrom).GetInt32(0));
 }
 OpRequest* GetNodesRequest::Clone() const {
   return new GetNodesRequest(Type(), Strategy(), GetNodeFrom(), BatchSize(), Epoch());
 }
 const std::string& GetNodesRequest::Type() const { return params_.at(kType).GetString(0); }
 const std::string& GetNodesRequest::Strategy() const { return params_.at(kStrategy).GetString(0); }
-NodeFrom GetNodesRequest::GetNodeFrom() const { return (NodeFrom)params_.at(kNodeFromKey).GetInt32(0); }
+NodeFrom GetNodesRequest::GetNodeFrom() const { return (NodeFrom)params_.at(kNodeFrom).GetInt32(0); }
 int32_t GetNodesRequest::BatchSize() const { return params_.at(kBatchSize).GetInt32(0); }
 int32_t GetNodesRequest::Epoch() const { return params_.at(kEpoch).GetInt32(0); }
 
@@ -68,6 +72,11 @@ GetEdgesRequest::GetEdgesRequest(const std::string& edge_type, const std::string
     : OpRequest(kEdgeIds) {
   InitTraversal(&params_, "GetEdges", kEdgeType, edge_type, strategy, batch_size, epoch);
 }
+// graph_lookup_request.cc:50-60: the root of a `g.E(t).batch(n)` query.
+void GetEdgesRequest::Init(const Tensor::Map& params) {
+  InitTraversal(&params_, "GetEdges", kEdgeType, params.at(kEdgeType).GetString(0), params.at(kStrategy).GetString(0),
+                params.at(kBatchSize).GetInt32(0), params.at(kEpoch).GetInt32(0));
+}
 OpRequest* GetEdgesRequest::Clone() const { return new GetEdgesRequest(EdgeType(), Strategy(), BatchSize(), Epoch()); }
 const std::string& GetEdgesRequest::EdgeType() const { return params_.at(kEdgeType).GetString(0); }
 const std::string& GetEdgesRequest::Strategy() const { return params_.at(kStrategy).GetString(0); }
@@ -77,19 +86,19 @@ int32_t GetEdgesRequest::Epoch() const { return params_.at(kEpoch).GetInt32(0); 
 GetEdgesResponse::GetEdgesResponse() : OpResponse() {}
 void GetEdgesResponse::Init(int32_t batch_size) {
   batch_size_ = 0;
-  for (const char* key : {kSrcIds, kNodeIds, kEdgeIds}) {
+  for (const char* key : {kSrcIds, kDstIds, kEdgeIds}) {
     tensors_.erase(key);
     ADD_TENSOR(tensors_, key, kInt64, batch_size);
   }
 }
 void GetEdgesResponse::Append(int64_t src_id, int64_t dst_id, int64_t edge_id) {
   tensors_[kSrcIds].AddInt64(src_id);
-  tensors_[kNodeIds].AddInt64(dst_id);
+  tensors_[kDstIds].AddInt64(dst_id);
   tensors_[kEdgeIds].AddInt64(edge_id);
   ++batch_size_;
 }
 const int64_t* GetEdgesResponse::SrcIds() const { return tensors_.at(kSrcIds).GetInt64(); }
-const int64_t* GetEdgesResponse::DstIds() const { return tensors_.at(kNodeIds).GetInt64(); }
+const int64_t* GetEdgesResponse::DstIds() const { return tensors_.at(kDstIds).GetInt64(); }
 const int64_t* GetEdgesResponse::EdgeIds() const { return tensors_.at(kEdgeIds).GetInt64(); }
 
 REGISTER_REQUEST(GetNodes, GetNodesRequest, GetNodesResponse)

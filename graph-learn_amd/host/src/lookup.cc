@@ -26,6 +26,36 @@ LookupNodesRequest::LookupNodesRequest(const std::string& node_type) : OpRequest
 
 OpRequest* LookupNodesRequest::Clone() const { return new LookupNodesRequest(NodeType()); }
 
+namespace {
+// The ids a DAG edge delivers under `key`: a dense tensor, or the values of a ragged one
+// (graph_lookup_request.cc:368-385).
+const Tensor* IdsOf(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors, const char* key,
+                    const Tensor** segments = nullptr) {
+  if (segments) *segments = nullptr;
+  auto it = tensors.find(key);
+  if (it != tensors.end()) return &it->second;
+  auto sp = sparse_tensors.find(key);
+  if (sp == sparse_tensors.end()) return nullptr;
+  if (segments) *segments = &sp->second.Segments();
+  return &sp->second.Values();
+}
+}  // namespace
+
+// DagNodeRunner-style construction (graph_lookup_request.cc:353-385): the property lookup every traversal node of a
+// query gets (python/gsl/dag_node.py:455-461).
+void LookupNodesRequest::Init(const Tensor::Map& params) {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("LookupNodes");
+  ADD_TENSOR(params_, kNodeType, kString, 1);
+  params_[kNodeType].AddString(params.at(kNodeType).GetString(0));
+  ADD_TENSOR(tensors_, kNodeIds, kInt64, 64);
+}
+
+void LookupNodesRequest::Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) {
+  const Tensor* ids = IdsOf(tensors, sparse_tensors, kNodeIds);
+  if (ids) Set(ids->GetInt64(), ids->Size());
+}
+
 void LookupNodesRequest::Set(const int64_t* node_ids, int32_t batch_size) {
   tensors_[kNodeIds].AddInt64(node_ids, node_ids + batch_size);
 }
@@ -53,6 +83,45 @@ LookupEdgesRequest::LookupEdgesRequest(const std::string& edge_type) : OpRequest
 }
 
 OpRequest* LookupEdgesRequest::Clone() const { return new LookupEdgesRequest(EdgeType()); }
+
+// graph_lookup_request.cc:234-308.  The edge ids come from a sampler ([batch * k] dense, or ragged), the src ids
+// from the node the sampler started at ([batch]): each src id is repeated over its row -- by the row's count for
+// a ragged input, by the node's neighbour count for a dense one.
+void LookupEdgesRequest::Init(const Tensor::Map& params) {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("LookupEdges");
+  ADD_TENSOR(params_, kEdgeType, kString, 1);
+  params_[kEdgeType].AddString(params.at(kEdgeType).GetString(0));
+  auto nbc = params.find(kNeighborCount);
+  if (nbc != params.end()) {
+    ADD_TENSOR(params_, kNeighborCount, kInt32, 1);
+    params_[kNeighborCount].AddInt32(nbc->second.GetInt32(0));
+  }
+  ADD_TENSOR(tensors_, kEdgeIds, kInt64, 64);
+  ADD_TENSOR(tensors_, kSrcIds, kInt64, 64);
+}
+
+void LookupEdgesRequest::Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) {
+  const Tensor* segments = nullptr;
+  const Tensor* edge_ids = IdsOf(tensors, sparse_tensors, kEdgeIds, &segments);
+  const Tensor* src_ids = IdsOf(tensors, sparse_tensors, kSrcIds);
+  if (!edge_ids || !src_ids) return;  // the operator reports the size mismatch
+  Tensor& mine = tensors_[kSrcIds];
+  tensors_[kEdgeIds].AddInt64(edge_ids->GetInt64(), edge_ids->GetInt64() + edge_ids->Size());
+  const int32_t src_size = src_ids->Size();
+  if (edge_ids->Size() == src_size) {
+    mine.AddInt64(src_ids->GetInt64(), src_ids->GetInt64() + src_size);
+  } else if (segments) {
+    for (int32_t i = 0; i < src_size && i < segments->Size(); ++i) {
+      for (int32_t j = 0; j < segments->GetInt32(i); ++j) mine.AddInt64(src_ids->GetInt64(i));
+    }
+  } else if (params_.count(kNeighborCount)) {
+    const int32_t k = params_.at(kNeighborCount).GetInt32(0);
+    for (int32_t i = 0; i < src_size; ++i) {
+      for (int32_t j = 0; j < k; ++j) mine.AddInt64(src_ids->GetInt64(i));
+    }
+  }
+}
 
 void LookupEdgesRequest::Set(const int64_t* edge_ids, const int64_t* src_ids, int32_t batch_size) {
   tensors_[kEdgeIds].AddInt64(edge_ids, edge_ids + batch_size);
@@ -145,16 +214,30 @@ GetDegreeRequest::GetDegreeRequest() : OpRequest(kNodeIds) {}
 GetDegreeRequest::GetDegreeRequest(const std::string& edge_type, NodeFrom node_from) : OpRequest(kNodeIds) {
   ADD_TENSOR(params_, kOpName, kString, 1);
   params_[kOpName].AddString("GetDegree");
-  ADD_TENSOR(params_, "node_from", kInt32, 1);
-  params_["node_from"].AddInt32((int32_t)node_from);
+  ADD_TENSOR(params_, kNodeFrom, kInt32, 1);
+  params_[kNodeFrom].AddInt32((int32_t)node_from);
   ADD_TENSOR(params_, kEdgeType, kString, 1);
   params_[kEdgeType].AddString(edge_type);
   ADD_TENSOR(tensors_, kNodeIds, kInt64, 64);
 }
 
 OpRequest* GetDegreeRequest::Clone() const { return new GetDegreeRequest(EdgeType(), GetNodeFrom()); }
+// graph_lookup_request.cc:641-671: the degree node a traversal gets per outgoing hop (dag_node.py:66-75).
+void GetDegreeRequest::Init(const Tensor::Map& params) {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("GetDegree");
+  ADD_TENSOR(params_, kNodeFrom, kInt32, 1);
+  params_[kNodeFrom].AddInt32(params.at(kNodeFrom).GetInt32(0));
+  ADD_TENSOR(params_, kEdgeType, kString, 1);
+  params_[kEdgeType].AddString(params.at(kEdgeType).GetString(0));
+  ADD_TENSOR(tensors_, kNodeIds, kInt64, 64);
+}
+void GetDegreeRequest::Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) {
+  const Tensor* ids = IdsOf(tensors, sparse_tensors, kNodeIds);
+  if (ids) Set(ids->GetInt64(), ids->Size());
+}
 NodeFrom GetDegreeRequest::GetNodeFrom() const {
-  auto it = params_.find("node_from");
+  auto it = params_.find(kNodeFrom);
   return it == params_.end() ? kEdgeSrc : (NodeFrom)it->second.GetInt32(0);
 }
 void GetDegreeRequest::Set(const int64_t* node_ids, int32_t batch_size) {
@@ -167,20 +250,16 @@ const int64_t* GetDegreeRequest::NodeIds() const { return tensors_.at(kNodeIds).
 GetDegreeResponse::GetDegreeResponse() : OpResponse() {}
 void GetDegreeResponse::InitDegrees(int32_t batch_size) {
   batch_size_ = batch_size;
-  tensors_.erase(kDegreeKey);
-  ADD_TENSOR(tensors_, kDegreeKey, kInt32, batch_size);
-  tensors_[kDegreeKey].Resize(batch_size);
+  tensors_.erase(kDegrees);
+  ADD_TENSOR(tensors_, kDegrees, kInt32, batch_size);
+  tensors_[kDegrees].Resize(batch_size);
 }
-const int32_t* GetDegreeResponse::GetDegrees() const { return tensors_.at(kDegreeKey).GetInt32(); }
-int32_t* GetDegreeResponse::MutableDegrees() { return tensors_[kDegreeKey].MutableInt32(); }
+const int32_t* GetDegreeResponse::GetDegrees() const { return tensors_.at(kDegrees).GetInt32(); }
+int32_t* GetDegreeResponse::MutableDegrees() { return tensors_[kDegrees].MutableInt32(); }
 
 REGISTER_REQUEST(GetDegree, GetDegreeRequest, GetDegreeResponse)
 
 // ------------------------------------------------------ GetCount / GetStats --
-namespace {
-const char* kCountKey = "cnt";  // service/constants.cc:51
-}
-
 GetCountRequest::GetCountRequest() : OpRequest() {
   DisableShard();  // carries no ids to partition: every server answers for itself (graph_store.cc:278-293)
   ADD_TENSOR(params_, kOpName, kString, 1);
@@ -188,13 +267,13 @@ GetCountRequest::GetCountRequest() : OpRequest() {
 }
 GetCountResponse::GetCountResponse() : OpResponse() {}
 void GetCountResponse::Init(int32_t type_num) {
-  tensors_.erase(kCountKey);
-  ADD_TENSOR(tensors_, kCountKey, kInt32, type_num);
+  tensors_.erase(kCount);
+  ADD_TENSOR(tensors_, kCount, kInt32, type_num);
 }
-void GetCountResponse::Append(int32_t count) { tensors_[kCountKey].AddInt32(count); }
-const int32_t* GetCountResponse::Count() const { return tensors_.at(kCountKey).GetInt32(); }
+void GetCountResponse::Append(int32_t count) { tensors_[kCount].AddInt32(count); }
+const int32_t* GetCountResponse::Count() const { return tensors_.at(kCount).GetInt32(); }
 int32_t GetCountResponse::Size() const {
-  auto it = tensors_.find(kCountKey);
+  auto it = tensors_.find(kCount);
   return it == tensors_.end() ? 0 : it->second.Size();
 }
 
@@ -235,8 +314,8 @@ RandomWalkRequest::RandomWalkRequest(const std::string& type, float p, float q, 
   ADD_TENSOR(params_, kSideInfo, kFloat, 2);
   params_[kSideInfo].AddFloat(p);
   params_[kSideInfo].AddFloat(q);
-  ADD_TENSOR(params_, "walk_len", kInt32, 1);
-  params_["walk_len"].AddInt32(walk_len);
+  ADD_TENSOR(params_, kDistances, kInt32, 1);
+  params_[kDistances].AddInt32(walk_len);
   ADD_TENSOR(tensors_, kSrcIds, kInt64, 64);
 }
 
@@ -245,25 +324,44 @@ OpRequest* RandomWalkRequest::Clone() const {
   if (HasCallCounter()) r->SetCallCounter(CallCounter());
   return r;
 }
+// random_walk_request.cc:90-132: the node `.random_walk(edge_type, walk_len, p, q)` of a query.  Its second in-edge
+// (the parents, kNodeIds) is the reference operator's own bookkeeping between steps; all steps run in one device
+// call here.
+void RandomWalkRequest::Init(const Tensor::Map& params) {
+  ADD_TENSOR(params_, kOpName, kString, 1);
+  params_[kOpName].AddString("RandomWalk");
+  ADD_TENSOR(params_, kEdgeType, kString, 1);
+  params_[kEdgeType].AddString(params.at(kEdgeType).GetString(0));
+  ADD_TENSOR(params_, kSideInfo, kFloat, 2);
+  params_[kSideInfo].AddFloat(params.at(kSideInfo).GetFloat(0));
+  params_[kSideInfo].AddFloat(params.at(kSideInfo).GetFloat(1));
+  ADD_TENSOR(params_, kDistances, kInt32, 1);
+  params_[kDistances].AddInt32(params.at(kDistances).GetInt32(0));
+  ADD_TENSOR(tensors_, kSrcIds, kInt64, 64);
+}
+void RandomWalkRequest::Set(const Tensor::Map& tensors, const SparseTensor::Map&) {
+  const Tensor& src = tensors.at(kSrcIds);
+  Set(src.GetInt64(), src.Size());
+}
 void RandomWalkRequest::Set(const int64_t* src_ids, int32_t batch_size) {
   tensors_[kSrcIds].AddInt64(src_ids, src_ids + batch_size);
 }
 const std::string& RandomWalkRequest::Type() const { return params_.at(kEdgeType).GetString(0); }
 float RandomWalkRequest::P() const { return params_.at(kSideInfo).GetFloat(0); }
 float RandomWalkRequest::Q() const { return params_.at(kSideInfo).GetFloat(1); }
-int32_t RandomWalkRequest::WalkLen() const { return params_.at("walk_len").GetInt32(0); }
+int32_t RandomWalkRequest::WalkLen() const { return params_.at(kDistances).GetInt32(0); }
 bool RandomWalkRequest::IsDeepWalk() const {
   return std::fabs(P() - 1.0f) < 32 * FLT_EPSILON && std::fabs(Q() - 1.0f) < 32 * FLT_EPSILON;
 }
 int32_t RandomWalkRequest::BatchSize() const { return tensors_.at(kSrcIds).Size(); }
 const int64_t* RandomWalkRequest::GetSrcIds() const { return tensors_.at(kSrcIds).GetInt64(); }
 void RandomWalkRequest::SetCallCounter(int64_t call_counter) {
-  params_.erase("call_counter");
-  ADD_TENSOR(params_, "call_counter", kInt64, 1);
-  params_["call_counter"].AddInt64(call_counter);
+  params_.erase(kCallCounter);
+  ADD_TENSOR(params_, kCallCounter, kInt64, 1);
+  params_[kCallCounter].AddInt64(call_counter);
 }
-bool RandomWalkRequest::HasCallCounter() const { return params_.count("call_counter") != 0; }
-int64_t RandomWalkRequest::CallCounter() const { return params_.at("call_counter").GetInt64(0); }
+bool RandomWalkRequest::HasCallCounter() const { return params_.count(kCallCounter) != 0; }
+int64_t RandomWalkRequest::CallCounter() const { return params_.at(kCallCounter).GetInt64(0); }
 
 RandomWalkResponse::RandomWalkResponse() : OpResponse() {}
 void RandomWalkResponse::InitWalks(int32_t batch_size, int32_t walk_len) {

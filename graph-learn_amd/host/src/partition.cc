@@ -9,8 +9,6 @@
 
 namespace graphlearn {
 
-const char* kRngRows = "rng_rows";
-
 int32_t HashPartitioner::ShardOf(int64_t id) const { return (int32_t)(std::llabs(id) % range_); }
 
 namespace {

@@ -82,12 +82,12 @@ OpRequest* SamplingRequest::Clone() const {
 }
 
 void SamplingRequest::SetCallCounter(int64_t call_counter) {
-  params_.erase("call_counter");
-  ADD_TENSOR(params_, "call_counter", kInt64, 1);
-  params_["call_counter"].AddInt64(call_counter);
+  params_.erase(kCallCounter);
+  ADD_TENSOR(params_, kCallCounter, kInt64, 1);
+  params_[kCallCounter].AddInt64(call_counter);
 }
-bool SamplingRequest::HasCallCounter() const { return params_.count("call_counter") != 0; }
-int64_t SamplingRequest::CallCounter() const { return params_.at("call_counter").GetInt64(0); }
+bool SamplingRequest::HasCallCounter() const { return params_.count(kCallCounter) != 0; }
+int64_t SamplingRequest::CallCounter() const { return params_.at(kCallCounter).GetInt64(0); }
 
 // DagNodeRunner-style construction (sampling_request.cc:87-136).
 void SamplingRequest::Init(const Tensor::Map& params) {
@@ -99,8 +99,10 @@ void SamplingRequest::Init(const Tensor::Map& params) {
   InitParams(params.at(kEdgeType).GetString(0), params.at(kStrategy).GetString(0));
 }
 
-void SamplingRequest::Set(const Tensor::Map& tensors) {
-  const Tensor& ids = tensors.at(kSrcIds);
+void SamplingRequest::Set(const Tensor::Map& tensors, const SparseTensor::Map& sparse_tensors) {
+  // a ragged upstream (FullSampler) feeds its values: one request row per neighbour (TensorMap::Find, tensor_map.cc:57-71)
+  auto dense = tensors.find(kSrcIds);
+  const Tensor& ids = dense != tensors.end() ? dense->second : sparse_tensors.at(kSrcIds).Values();
   Set(ids.GetInt64(), ids.Size());
   if (HasFilter()) {
     // Filter::FillValues, filter.cc:53-67

@@ -9,6 +9,7 @@
 
 #include "glx.h"
 #include "graphlearn/config.h"
+#include "graphlearn/dag.h"
 #include "graphlearn/graph_store.h"
 #include "graphlearn/operator.h"
 #include "graphlearn/sampling_request.h"
@@ -31,10 +32,62 @@ glx_filter FilterOf(const SamplingRequest* req) {
 }
 }  // namespace
 
-class Sampler : public Operator {
+class Sampler : public Operator, public HopFusable {
 public:
   Status Process(const OpRequest* req, OpResponse* res) override {
     return Sample(static_cast<const SamplingRequest*>(req), static_cast<SamplingResponse*>(res));
+  }
+
+  // A chain of hops of a query (dag.h) as one glx_sample_hops call: hop h samples requests[h]'s neighbour count
+  // from requests[h]'s edge type for every neighbour hop h - 1 returned; only hop 0's source ids come from the
+  // host and only the responses travel back.  Draw for draw what Process would return hop after hop: hop h uses
+  // this operator's call counter + h.
+  Status ProcessHops(const std::vector<const OpRequest*>& requests, const std::vector<OpResponse*>& responses) override {
+    const size_t hops = requests.size();
+    if (!graph_store_) return error::InvalidArgument("operator is not bound to a GraphStore");
+    std::vector<const SamplingRequest*> reqs(hops);
+    std::vector<SamplingResponse*> ress(hops);
+    std::vector<const glx_graph*> graphs(hops);
+    std::vector<int32_t> fanouts(hops);
+    bool all_loaded = true;
+    for (size_t h = 0; h < hops; ++h) {
+      reqs[h] = static_cast<const SamplingRequest*>(requests[h]);
+      ress[h] = static_cast<SamplingResponse*>(responses[h]);
+      Graph* graph = graph_store_->GetGraph(reqs[h]->Type());
+      graphs[h] = graph->Device();
+      fanouts[h] = reqs[h]->NeighborCount();
+      if (!graphs[h] || reqs[h]->HasFilter()) all_loaded = false;
+      if (graphs[h] && SamplerId() == GLX_SAMPLER_IN_DEGREE) {
+        Status s = graph->EnsureInDegree();
+        if (!s.ok()) return s;
+      }
+    }
+    if (!all_loaded) {  // an edge type nobody loaded default-fills (Sample): hop by hop, each fed by the one before
+      for (size_t h = 0; h < hops; ++h) {
+        SamplingRequest next(reqs[h]->Type(), reqs[h]->Strategy(), fanouts[h]);
+        if (h > 0) next.Set(ress[h - 1]->GetNeighborIds(), (int32_t)ress[h - 1]->GetShape().size);
+        Status s = Sample(h == 0 ? reqs[0] : &next, ress[h]);
+        if (!s.ok()) return s;
+      }
+      return Status::OK();
+    }
+    std::vector<int64_t*> nbr_out(hops), eid_out(hops);
+    size_t rows = (size_t)reqs[0]->BatchSize();
+    for (size_t h = 0; h < hops; ++h) {
+      ress[h]->SetShape(rows, fanouts[h]);
+      ress[h]->InitNeighborIds();
+      ress[h]->InitEdgeIds();
+      ress[h]->ResizeDense();
+      nbr_out[h] = ress[h]->GetNeighborIds();
+      eid_out[h] = ress[h]->GetEdgeIds();
+      rows *= (size_t)fanouts[h];
+    }
+    const uint64_t cc = call_counter_.fetch_add(hops, std::memory_order_relaxed);
+    int rc = glx_sample_hops(graphs.data(), (int32_t)hops, SamplerId(), reqs[0]->GetSrcIds(), reqs[0]->BatchSize(),
+                             fanouts.data(), GLOBAL_FLAG(PaddingMode), GLOBAL_FLAG(DefaultNeighborId),
+                             (uint64_t)GLOBAL_FLAG(SamplingSeed), cc, nbr_out.data(), eid_out.data(), GLX_PTR_HOST,
+                             nullptr);
+    return error::FromGlx(rc);
   }
 
 protected:

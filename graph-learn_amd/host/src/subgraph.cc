@@ -24,12 +24,6 @@
 namespace graphlearn {
 
 namespace {
-const char* kNbrType = "nbrt";           // service/constants.cc:50
-const char* kNeedDist = "need_dist";     // :66
-const char* kRowIndices = "ridx";        // :47
-const char* kColIndices = "cidx";        // :48
-const char* kDistToSrc = "dist_to_src";  // :67
-const char* kDistToDst = "dist_to_dst";  // :68
 const int32_t kReservedSize = 64;
 }  // namespace
 
@@ -73,10 +67,10 @@ void SubGraphRequest::Set(const int64_t* src_id, const int64_t* dst_id, int32_t 
   tensors_[kSrcIds].AddInt64(dst_id, dst_id + batch_size);
 }
 
-void SubGraphRequest::Set(const Tensor::Map& tensors) {
+void SubGraphRequest::Set(const Tensor::Map& tensors, const SparseTensor::Map&) {
   const Tensor& src = tensors.at(kSrcIds);
   tensors_[kSrcIds].AddInt64(src.GetInt64(), src.GetInt64() + src.Size());
-  auto it = tensors.find("dst_ids");  // kDstIds, subgraph_request.cc:92-96
+  auto it = tensors.find(kDstIds);  // subgraph_request.cc:92-96
   if (it != tensors.end()) tensors_[kSrcIds].AddInt64(it->second.GetInt64(), it->second.GetInt64() + it->second.Size());
 }
 

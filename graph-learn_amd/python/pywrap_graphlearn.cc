@@ -1,11 +1,12 @@
 // pywrap_graphlearn: the pybind11 surface the reference's Python layer is written
-// against (graphlearn/python/c/py_export.cc:36-277, py_client.cc:36-527), for the
-// sampling / aggregation / lookup path in local deploy mode, bound to the glx host
-// mirror (libglx_host.so -> libglx.so -> HIP).  Function and attribute names are the
-// reference's, so python code written for `graphlearn.pywrap_graphlearn` runs as is;
-// entry points outside the path (RPC deploy modes, DAG/GSL, subgraph, KNN, vineyard)
-// are not bound.  New: set_sampling_seed / set_device_id (the glx seeding contract
-// and GPU placement).
+// against (graphlearn/python/c/py_export.cc:36-277, py_client.cc:36-627), bound to the
+// glx host mirror (libglx_host.so -> libglx.so -> HIP).  EVERY name the reference's Python
+// tree uses is here (tests/test_refpy_names.py greps them), so `graphlearn/__init__.py` +
+// `graphlearn/python/` of the reference run on this module unchanged in local deploy mode:
+// Graph.init(), the samplers, GSL queries (the DAG API + Dataset, see host dag.h).  What the
+// engine does not have -- RPC clients / servers, KNN, vineyard, the actor engine -- exists by
+// name and fails when CALLED (flag setters of those layers just store their value).
+// New: set_sampling_seed / set_device_id (the glx seeding contract and GPU placement).
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -52,6 +53,27 @@ T* As(Base* p, const char* what) {
   return t;
 }
 
+// A whole tensor as a 1-d numpy array over its storage (strings: an object array of bytes, py_wrapper.h:668-679).
+py::object TensorArray(const Tensor& t) {
+  const size_t n = (size_t)t.Size();
+  if (t.DType() == kString) {
+    py::list out;
+    for (size_t i = 0; i < n; ++i) out.append(py::bytes(t.GetString((int32_t)i)));
+    py::object arr = py::module_::import("numpy").attr("empty")(n, py::arg("dtype") = "object");
+    for (size_t i = 0; i < n; ++i) arr[py::int_(i)] = out[i];
+    return arr;
+  }
+  auto* keep = new std::shared_ptr<const void>(t.Owner());
+  py::capsule owner(keep, [](void* p) { delete static_cast<std::shared_ptr<const void>*>(p); });
+  switch (t.DType()) {
+    case kInt32: return py::array_t<int32_t>({n}, {sizeof(int32_t)}, t.GetInt32(), owner);
+    case kInt64: return py::array_t<int64_t>({n}, {sizeof(int64_t)}, t.GetInt64(), owner);
+    case kFloat: return py::array_t<float>({n}, {sizeof(float)}, t.GetFloat(), owner);
+    case kDouble: return py::array_t<double>({n}, {sizeof(double)}, t.GetDouble(), owner);
+    default: return py::none();
+  }
+}
+
 typedef py::array_t<int64_t, py::array::c_style | py::array::forcecast> I64Array;
 typedef py::array_t<int32_t, py::array::c_style | py::array::forcecast> I32Array;
 
@@ -59,6 +81,8 @@ typedef py::array_t<int32_t, py::array::c_style | py::array::forcecast> I32Array
 
 PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.doc() = "glx: MI355X-native engine behind graph-learn's pywrap_graphlearn interface (hot path only)";
+
+  py::enum_<DeployMode>(m, "DeployMode").value("LOCAL", kLocal).value("SERVER", kServer).value("WORKER", kWorker);
 
   // ---- global flags (py_export.cc:38-73) ----
   m.def("set_default_neighbor_id", &SetGlobalFlagDefaultNeighborId);
@@ -75,12 +99,53 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
   m.def("set_shuffle_buffer_size", &SetGlobalFlagShuffleBufferSize);
   m.def("set_sampling_seed", &SetGlobalFlagSamplingSeed);
   m.def("set_device_id", &SetGlobalFlagDeviceId);
-  // thread-pool / queue sizing of the reference's service layer: accepted, no effect
-  for (const char* name : {"set_inter_threadnum", "set_inner_threadnum", "set_intra_threadnum",
-                           "set_datainit_batchsize", "set_inmemory_queuesize",
-                           "set_tracker_mode", "set_storage_mode", "set_retry_times", "set_timeout"}) {
-    m.def(name, [](int32_t) {});
-  }
+  m.def("set_deploy_mode", [](int32_t mode) { SetGlobalFlagDeployMode(mode); });
+  m.def("set_deploy_mode", [](DeployMode mode) { SetGlobalFlagDeployMode((int32_t)mode); });
+  m.def("set_client_id", &SetGlobalFlagClientId);
+  m.def("set_client_count", &SetGlobalFlagClientCount);
+  m.def("set_server_count", &SetGlobalFlagServerCount);
+  m.def("set_timeout", &SetGlobalFlagTimeout);
+  m.def("set_tape_capacity", &SetGlobalFlagTapeCapacity);
+  m.def("set_dataset_capacity", &SetGlobalFlagDatasetCapacity);
+  m.def("set_tracker_mode", &SetGlobalFlagTrackerMode);
+  m.def("get_tracker_mode", &GetGlobalFlagTrackerMode);
+  // flags of layers this engine does not have (thread pools, queues, storage layout, RPC, KNN, vineyard, actors):
+  // stored under their name, never read (config.h)
+#define GLX_UNUSED_INT_FLAG(pyname) m.def(pyname, [](int64_t v) { SetGlobalFlagUnused(pyname, v); })
+#define GLX_UNUSED_STR_FLAG(pyname) m.def(pyname, [](const std::string& v) { SetGlobalFlagUnused(pyname, v); })
+  GLX_UNUSED_INT_FLAG("set_inter_threadnum");
+  GLX_UNUSED_INT_FLAG("set_inner_threadnum");
+  GLX_UNUSED_INT_FLAG("set_intra_threadnum");
+  GLX_UNUSED_INT_FLAG("set_datainit_batchsize");
+  GLX_UNUSED_INT_FLAG("set_inmemory_queuesize");
+  GLX_UNUSED_INT_FLAG("set_storage_mode");
+  GLX_UNUSED_INT_FLAG("set_retry_times");
+  GLX_UNUSED_INT_FLAG("set_rpc_message_max_size");
+  GLX_UNUSED_INT_FLAG("set_knn_metric");
+  GLX_UNUSED_INT_FLAG("set_local_node_cache_capacity");
+  GLX_UNUSED_INT_FLAG("set_enable_actor");
+  GLX_UNUSED_INT_FLAG("set_actor_local_shard_count");
+  GLX_UNUSED_INT_FLAG("set_vineyard_graph_id");
+  GLX_UNUSED_STR_FLAG("set_tracker");
+  GLX_UNUSED_STR_FLAG("set_server_hosts");
+  GLX_UNUSED_STR_FLAG("set_field_delimiter");
+  GLX_UNUSED_STR_FLAG("set_vineyard_ipc_socket");
+#undef GLX_UNUSED_INT_FLAG
+#undef GLX_UNUSED_STR_FLAG
+
+  // ---- tensor / parameter keys (py_export.cc:82-131) ----
+#define GLX_KEY(name) m.attr(#name) = name
+  GLX_KEY(kOpName); GLX_KEY(kNodeType); GLX_KEY(kEdgeType); GLX_KEY(kType); GLX_KEY(kSrcType); GLX_KEY(kDstType);
+  GLX_KEY(kSrcIds); GLX_KEY(kDstIds); GLX_KEY(kNodeIds); GLX_KEY(kEdgeIds); GLX_KEY(kNeighborCount);
+  GLX_KEY(kNeighborIds); GLX_KEY(kBatchSize); GLX_KEY(kIsSparse); GLX_KEY(kStrategy); GLX_KEY(kDegreeKey);
+  GLX_KEY(kWeightKey); GLX_KEY(kLabelKey); GLX_KEY(kIntAttrKey); GLX_KEY(kFloatAttrKey); GLX_KEY(kStringAttrKey);
+  GLX_KEY(kSideInfo); GLX_KEY(kDirection); GLX_KEY(kSegmentIds); GLX_KEY(kNumSegments); GLX_KEY(kSegments);
+  GLX_KEY(kDistances); GLX_KEY(kRowIndices); GLX_KEY(kColIndices); GLX_KEY(kSeedType); GLX_KEY(kNbrType);
+  GLX_KEY(kCount); GLX_KEY(kBatchShare); GLX_KEY(kUnique); GLX_KEY(kIntCols); GLX_KEY(kIntProps); GLX_KEY(kFloatCols);
+  GLX_KEY(kFloatProps); GLX_KEY(kStrCols); GLX_KEY(kStrProps); GLX_KEY(kFilterType); GLX_KEY(kFilterField);
+  GLX_KEY(kFilterValues); GLX_KEY(kDegrees); GLX_KEY(kEpoch); GLX_KEY(kNodeFrom); GLX_KEY(kNeedDist);
+  GLX_KEY(kDistToSrc); GLX_KEY(kDistToDst);
+#undef GLX_KEY
 
   py::enum_<error::Code>(m, "ErrorCode")
       .value("OK", error::OK)
@@ -110,6 +175,8 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       .value("STRING", kString);
 
   py::enum_<PaddingMode>(m, "PaddingMode").value("REPLICATE", kReplicate).value("CIRCULAR", kCircular);
+  py::enum_<PartitionMode>(m, "PartitionMode").value("NO_PARTITION", kNoPartition).value("BY_SOURCE_ID", kByHash);
+  py::enum_<TrackerMode>(m, "TrackerMode").value("RPC", kRpc).value("FILE_SYSTEM", kFileSystem);
 
   py::enum_<FilterType>(m, "FilterType")
       .value("OPERATOR_UNSPECIFIED", kOperatorUnspecified)
@@ -135,7 +202,14 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
 
   py::enum_<io::Direction>(m, "Direction").value("ORIGIN", io::kOrigin).value("REVERSED", io::kReversed);
 
-  py::class_<IndexOption>(m, "IndexOption").def(py::init<>()).def_readwrite("name", &IndexOption::name);
+  py::class_<IndexOption>(m, "IndexOption")
+      .def(py::init<>())
+      .def_readwrite("name", &IndexOption::name)
+      .def_readwrite("index_type", &IndexOption::index_type)
+      .def_readwrite("dimension", &IndexOption::dimension)
+      .def_readwrite("nlist", &IndexOption::nlist)
+      .def_readwrite("nprobe", &IndexOption::nprobe)
+      .def_readwrite("m", &IndexOption::m);
 
   py::class_<io::AttributeInfo>(m, "AttributeInfo")
       .def(py::init<>())
@@ -150,7 +224,9 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       .def_readwrite("id_type", &io::NodeSource::id_type)
       .def_readwrite("format", &io::NodeSource::format)
       .def_readwrite("attr_info", &io::NodeSource::attr_info)
-      .def_readwrite("option", &io::NodeSource::option);
+      .def_readwrite("option", &io::NodeSource::option)
+      .def_readwrite("view_type", &io::NodeSource::view_type)
+      .def_readwrite("use_attrs", &io::NodeSource::use_attrs);
 
   py::class_<io::EdgeSource>(m, "EdgeSource")
       .def(py::init<>())
@@ -161,7 +237,9 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
       .def_readwrite("format", &io::EdgeSource::format)
       .def_readwrite("direction", &io::EdgeSource::direction)
       .def_readwrite("attr_info", &io::EdgeSource::attr_info)
-      .def_readwrite("option", &io::EdgeSource::option);
+      .def_readwrite("option", &io::EdgeSource::option)
+      .def_readwrite("view_type", &io::EdgeSource::view_type)
+      .def_readwrite("use_attrs", &io::EdgeSource::use_attrs);
 
   py::class_<Status>(m, "Status")
       .def("ok", &Status::ok)
@@ -190,7 +268,9 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
         return CopyOut(ids.data(), ids.size());
       })
       .def("device_features", &Server::DeviceFeatures)
-      .def("stop", &Server::Stop);
+      .def("stop", &Server::Stop, py::call_guard<py::gil_scoped_release>())
+      .def("stop_sampling", [](Server&) { DagScheduler::StopAll(); }, py::call_guard<py::gil_scoped_release>())
+      .def("get_stats", [](Server& self) { return self.Store() ? self.Store()->GetStatistics().GetCounts() : Counts(); });
   m.def("server", &NewServer, py::return_value_policy::take_ownership, py::arg("server_id"),
         py::arg("server_count"), py::arg("server_host"), py::arg("tracker"));
 
@@ -250,8 +330,98 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
            py::call_guard<py::gil_scoped_release>())
       .def("get_nodes", [](Client& self, OpRequest* req, OpResponse* res) { return self.RunOp(req, res); })
       .def("get_edges", [](Client& self, OpRequest* req, OpResponse* res) { return self.RunOp(req, res); })
-      .def("run_op", &Client::RunOp, py::call_guard<py::gil_scoped_release>());
+      .def("run_op", &Client::RunOp, py::call_guard<py::gil_scoped_release>())
+      // GSL queries (py_client.cc:105-115)
+      .def("run_dag",
+           [](Client& self, DagDef* dag_def, bool copy) {
+             DagRequest req;
+             req.ParseFrom(dag_def, copy);
+             return self.RunDag(&req);
+           },
+           py::arg("dag_def"), py::arg("copy") = false)
+      .def("get_dag_values",
+           [](Client& self, GetDagValuesRequest* req, GetDagValuesResponse* res) { return self.GetDagValues(req, res); },
+           py::arg("request"), py::arg("response"), py::call_guard<py::gil_scoped_release>())
+      .def("get_own_servers", [](Client&) { return std::vector<int32_t>{0}; });
   m.def("in_memory_client", &NewInMemoryClient, py::return_value_policy::take_ownership);
+  m.def("rpc_client",
+        [](int32_t, bool) -> Client* {
+          throw std::runtime_error(
+              "rpc_client: this engine has no RPC service -- its servers are the GPUs of one node, reached through "
+              "the in-memory client (local deploy mode) or the RCCL shard communicator (graph-learn_amd/dist.py)");
+        },
+        py::arg("server_id") = -1, py::arg("client_own") = true);
+  // KNN (python/operator/knn_operator.py): no KNN operator here; present by name, fails when called
+  for (const char* name : {"new_knn_request", "new_knn_response", "set_knn_request", "get_knn_ids", "get_knn_distances"}) {
+    m.def(name, [name](py::args) -> py::object {
+      throw std::runtime_error(std::string(name) + ": the KNN operator (faiss) is not part of this engine");
+    });
+  }
+
+  // ---- GSL: the DAG definition a query is lowered to (py_client.cc:527-627; py_wrapper.h:34-130) ----
+  py::class_<DagDef>(m, "DagDef").def(py::init<>());
+  py::class_<DagNodeDef>(m, "DagNodeDef").def(py::init<>());
+  py::class_<DagEdgeDef>(m, "DagEdgeDef").def(py::init<>());
+  m.def("new_dag", []() { return new DagDef(); }, py::return_value_policy::take_ownership);
+  m.def("new_dag_node", []() { return new DagNodeDef(); }, py::return_value_policy::take_ownership);
+  m.def("new_dag_edge", []() { return new DagEdgeDef(); }, py::return_value_policy::take_ownership);
+  m.def("set_dag_id", [](DagDef* dag, int32_t dag_id) { dag->id = dag_id; });
+  m.def("debug_string", [](DagDef* dag) { return dag->DebugString(); });
+  m.def("add_dag_node", [](DagDef* dag, const DagNodeDef* node) { dag->nodes.push_back(*node); });
+  m.def("set_dag_node_id", [](DagNodeDef* node, int32_t node_id) { node->id = node_id; });
+  m.def("set_dag_node_op_name", [](DagNodeDef* node, const std::string& op_name) { node->op_name = op_name; });
+  m.def("add_dag_node_in_edge", [](DagNodeDef* node, const DagEdgeDef* edge) { node->in_edges.push_back(*edge); });
+  m.def("add_dag_node_out_edge", [](DagNodeDef* node, const DagEdgeDef* edge) { node->out_edges.push_back(*edge); });
+  m.def("add_dag_node_int_params", [](DagNodeDef* node, const std::string& name, int32_t value) {
+    Tensor t(kInt32, 1);
+    t.AddInt32(value);
+    node->params[name] = t;
+  });
+  m.def("add_dag_node_string_params", [](DagNodeDef* node, const std::string& name, const std::string& value) {
+    Tensor t(kString, 1);
+    t.AddString(value);
+    node->params[name] = t;
+  });
+  m.def("add_dag_node_int_vector_params", [](DagNodeDef* node, const std::string& name, const std::vector<int32_t>& values) {
+    Tensor t(kInt32, (int32_t)values.size());
+    t.AddInt32(values.data(), values.data() + values.size());
+    node->params[name] = t;
+  });
+  m.def("add_dag_node_float_vector_params", [](DagNodeDef* node, const std::string& name, const std::vector<float>& values) {
+    Tensor t(kFloat, (int32_t)values.size());
+    t.AddFloat(values.data(), values.data() + values.size());
+    node->params[name] = t;
+  });
+  m.def("set_dag_edge_id", [](DagEdgeDef* edge, int32_t id) { edge->id = id; });
+  m.def("set_dag_edge_src_output", [](DagEdgeDef* edge, const std::string& v) { edge->src_output = v; });
+  m.def("set_dag_edge_dst_input", [](DagEdgeDef* edge, const std::string& v) { edge->dst_input = v; });
+
+  // ---- GSL: a query's values (py_client.cc:492-525; py_wrapper.h:635-720) ----
+  py::class_<Dataset>(m, "Dataset")
+      .def(py::init<Client*, int32_t>(), py::keep_alive<1, 2>())
+      .def("close", &Dataset::Close, py::call_guard<py::gil_scoped_release>())
+      .def("next", &Dataset::Next, py::return_value_policy::reference, py::arg("epoch"),
+           py::call_guard<py::gil_scoped_release>());
+  py::class_<GetDagValuesRequest>(m, "GetDagValuesRequest").def(py::init<int32_t, int32_t>());
+  py::class_<GetDagValuesResponse>(m, "GetDagValuesResponse")
+      .def(py::init<>())
+      .def("valid", &GetDagValuesResponse::Valid)
+      .def("epoch", &GetDagValuesResponse::Epoch)
+      .def("index", &GetDagValuesResponse::Index);
+  m.def("del_get_dag_value_response", [](GetDagValuesResponse* res) { delete res; });
+  // One node's tensor as a 1-d array, None when the node recorded nothing under `key`.  Zero-copy: the array keeps
+  // the tensor's storage alive, so it also survives del_get_dag_value_response.
+  m.def("get_dag_value", [](GetDagValuesResponse* res, int32_t node_id, const std::string& key) -> py::object {
+    const Tensor* values = res->GetValue(node_id, key).first;
+    if (!values) return py::none();
+    return TensorArray(*values);
+  });
+  // The per-row counts of a ragged value (a FullSampler's output), None for a dense one.
+  m.def("get_dag_value_indice", [](GetDagValuesResponse* res, int32_t node_id, const std::string& key) -> py::object {
+    const Tensor* segments = res->GetValue(node_id, key).second;
+    if (!segments || segments->Size() == 0) return py::none();
+    return TensorArray(*segments);
+  });
 
   // ---- sampling (py_client.cc:292-363) ----
   m.def("new_sampling_request",

@@ -1,0 +1,40 @@
+"""The reference's own Python unit tests -- graphlearn/python/sampler/tests, gsl/tests and python/tests, staged
+UNCHANGED by scripts/stage_refpy.py together with the reference's whole Python layer -- run on this engine's
+pywrap_graphlearn module: Graph.init() loads the TSV sources into HBM, the samplers are the HIP kernels, and every
+GSL query is a DAG compiled and run by the host layer's scheduler (dag.h).  SURVEY 8(f)-3 as the survey states it:
+"lets GL/python/sampler/tests/* ... run against the new engine unchanged".  One file = one process = one working
+directory, like the reference's test_python_ut.sh."""
+import pytest
+
+import refpy
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not refpy.staged(), reason="reference python layer not staged (scripts/stage_refpy.py)")]
+
+# Files that cannot pass on ANY engine, with the reason (the reference's own defect, checked in its sources).
+KNOWN_BROKEN_IN_REFERENCE = {}
+
+FILES = refpy.test_files() if refpy.staged() else []
+
+
+@pytest.mark.parametrize("rel", FILES)
+def test_reference_python_test_file(rel, tmp_path):
+    if rel in KNOWN_BROKEN_IN_REFERENCE:
+        pytest.skip(KNOWN_BROKEN_IN_REFERENCE[rel])
+    out = refpy.run_file(rel, str(tmp_path))
+    assert out.returncode == 0, "%s\n%s" % (rel, out.stdout[-6000:])
+
+
+def test_the_reference_layer_really_ran_on_this_engine(tmp_path):
+    """Guards the harness itself: the process that ran the reference's tests had the REFERENCE's graphlearn package
+    and THIS engine's libglx.so mapped."""
+    import subprocess
+    import sys
+    code = ("import graphlearn as gl, os\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert 'libglx.so' in maps and 'libglx_host.so' in maps\n"
+            "assert '_refpy' in gl.__file__ and hasattr(gl.Graph, 'V')\n"
+            "print('OK')\n")
+    out = subprocess.run([sys.executable, "-c", code], env=refpy.env(), cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout

@@ -57,6 +57,14 @@ def test_request_unittest_on_cpu():
     assert "5 test(s), 0 failure(s)" in r.stdout, r.stdout
 
 
+def test_dag_unittest_on_cpu():
+    """The query-DAG machinery (host dag.h: compile + hop fusion, tapes, the scheduler thread, Dataset) with stand-in
+    operators: core/dag/test/*_unittest.cpp and core/runner/test/dag_scheduler_unittest.cpp restated.  No device."""
+    r = run("dag_unittest")
+    assert r.returncode == 0, r.stdout
+    assert "7 test(s), 0 failure(s)" in r.stdout, r.stdout
+
+
 def test_host_library_exports_registry():
     import subprocess as sp
     out = sp.run(["nm", "-DC", os.path.join(LIB, "libglx_host.so")], stdout=sp.PIPE, text=True).stdout
