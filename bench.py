@@ -83,12 +83,15 @@ def _pick(d, keys):
 def compact_roofline(r):
     if not r:
         return None
-    out = _pick(r, ("bound", "peak", "unit", "achieved", "frac", "algorithmic_over_peak", "frac_compulsory", "traffic",
-                    "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch",
-                    "traffic_over_algorithmic", "frac_of_gather_ceiling", "l2_hit_rate"))
+    out = _pick(r, ("bound", "peak", "unit", "achieved", "frac", "algorithmic_gbs", "memory_side_gbs", "algorithmic_over_peak",
+                    "frac_compulsory", "traffic", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
+                    "compulsory_bytes_per_launch", "traffic_over_algorithmic", "frac_of_gather_ceiling", "l2_hit_rate"))
     out["kernel"] = _short(r.get("kernel", ""), 72)
+    if r.get("achieved_basis"):
+        out["achieved_basis"] = r["achieved_basis"]
     if r.get("frac_basis"):
-        out["frac_basis"] = _short(r["frac_basis"], 80)
+        # whole sentences only: the basis of the fraction must not be cut mid-word
+        out["frac_basis"] = r["frac_basis"].split(" (")[0].split(";")[0]
     if r.get("traffic_source"):
         out["traffic_source"] = _short(r["traffic_source"], 60)
     if isinstance(r.get("hbm_bytes_bracket"), (list, tuple)):
@@ -126,8 +129,9 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
             config[k] = cfg[k]
     if cfg.get("parallelism"):
         config["parallelism"] = _short(cfg["parallelism"], 120)
-    if cfg.get("seeds"):
-        config["seeds"] = _short(cfg["seeds"], 60)
+    for k in ("seeds", "segment_ids"):
+        if cfg.get(k):
+            config[k] = cfg[k].split(" (")[0]  # the first clause, whole
     line = {"metric": _short(res.get("metric", ""), 90)}
     for k in ("value", "unit", "n_gpus", "ranks", "rccl_ranks", "transport", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data"):
@@ -141,6 +145,8 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
     for k in ("gpu_over_cpu", "verified_vs_oracle", "verified_sharded_equals_unpartitioned"):
         if res.get(k) is not None:
             line[k] = _num(res[k], 5)
+    if res.get("request_shapes"):
+        line["request_shapes"] = {k: _num(v, 5) for k, v in res["request_shapes"].items()}
     optional = []  # dropped from the back if the line would outgrow the limit
     if res.get("phases"):
         line["phases"] = _pick(res["phases"], ("sampling_kernels_ms_per_step", "aggregation_kernels_ms_per_step"))
@@ -164,7 +170,7 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
                 continue
             roof = rec.get("roofline") or {}
             oc[name] = dict(_pick(rec, ("ms_per_step", "value")), frac=_num(roof.get("frac"), 4),
-                            frac_basis=_short(roof.get("frac_basis", ""), 40), traffic=_num(roof.get("traffic"), 4),
+                            frac_basis=(roof.get("frac_basis") or "").split(":")[0], traffic=_num(roof.get("traffic"), 4),
                             verified=rec.get("verified_vs_oracle"))
         line["other_configs"] = oc
         optional.append("other_configs")
@@ -214,6 +220,24 @@ def emit_result(result_out, res, args):
     sys.stderr.flush()
     result_out.write(compact_line(res, os.path.relpath(path, ROOT) if path and path.startswith(ROOT) else path) + "\n")
     result_out.flush()
+
+
+def n1_extras(args, world, sharded, workload=None, batch=None):
+    """Which side measurements of the N = 1 line run.  They are N = 1 ONLY: with more than one rank (or the sharded
+    code path) none of them runs, so that an 8-rank job spends its lease on the placements (VERDICT r04 item 5;
+    tests/test_bench_helpers.py pins it)."""
+    workload = args.workload if workload is None else workload
+    batch = args.batch if batch is None else batch
+    one = world == 1 and not sharded
+    headline_c3 = one and workload == "c3" and batch == 65536
+    return {"cpu_baseline": one and args.cpu_baseline == "on",
+            "host_boundary": one and args.host_boundary == "on",
+            "roofline_probes": one and args.roofline_probes == "on",
+            "verify_oracle": one and args.verify_oracle == "on",
+            "request_shape_legs": one and args.request_shape_legs == "on",
+            "small_batches": one and args.small_batches == "on" and batch == 65536,
+            "edge_cut_probe": headline_c3 and args.edge_cut_probe == "on",
+            "other_configs": headline_c3 and bool(args.other_configs)}
 
 
 def comm_facts(comm, share_device):
@@ -608,7 +632,7 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
     ms2 = float(np.mean(t_agg[0::3]))  # i-s hop over the 1 M-row shop table: the longest launch of a step
     ms1 = float(np.mean(t_agg[1::3]))  # u-i hop over the 9 M-row item table: the roofline kernel (see below)
     oracle_check = None
-    if args.verify_oracle == "on" and not sharded and world == 1:
+    if extras["verify_oracle"]:
         # the last timed step's three sampler responses and three aggregates against the oracle, on row subsets cut from
         # the regenerated raw edge lists (tests/headline_check.py); outside the timed region
         try:
@@ -667,7 +691,7 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
     roof_smp = None
     if not sharded and len(t_smp) >= 3:
         roof_smp = roofline_sampler("TopkSampler", k2, sg2, n2, float(np.mean(t_smp[1::3])), int(len(t_smp[1::3])), "c5", B0)
-    if args.roofline_probes == "on" and not sharded:
+    if extras["roofline_probes"]:
         # cache-free leg: the same kernel on the same request shape with ids uniform over the 9 M item rows
         fake = torch.randint(0, n_item, (n1,), generator=gen, device=dev)
         for _ in range(2):
@@ -685,6 +709,8 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
                               "note": "a short launch (%d ids, %.2f GB): ramp-up and tail are a visible share of it" %
                                       (n1, roof["algorithmic_bytes_per_launch"] / 1e9)}
         roof["frac"] = cf / HBM_PEAK_GBS
+        roof["achieved"] = cf
+        roof["achieved_basis"] = "cache-free leg: algorithmic bytes (== memory-side traffic there) / its average launch time"
         roof["frac_basis"] = "cache-free leg of this run: u-i hop shape, ids uniform over the 9.2 GB item table / 8 TB/s"
         del fake
     res = {
@@ -735,12 +761,15 @@ def roofline_aggregate(agg, D, n_segments, n_ids, avg_ms, launches, ids_last, wo
     roof = {"kernel": "glx_aggregate_grp_kernel (hop-2 %s, dim=%d%s)" % (agg, D, ", 3 row sources" if sources == 3 else ""),
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": avg_ms, "launches_timed": launches,
             "algorithmic_bytes_per_launch": bytes_alg,
-            # algorithmic bytes / the average duration of the launches inside the timed region
-            "achieved": bytes_alg / t / 1e9,
+            # algorithmic bytes / the average duration of the launches inside the timed region.  NOT a
+            # bandwidth: every row occurrence is counted, so re-reads of hub rows served by L2 / Infinity Cache are in
+            # it -- the rate the kernel delivers to its consumer, which on a power-law request exceeds what HBM supplies
+            "algorithmic_gbs": bytes_alg / t / 1e9,
             "algorithmic_over_peak": bytes_alg / t / 1e9 / HBM_PEAK_GBS, "cache_assisted": True,
-            "note_achieved": "every row occurrence counted, so re-reads of hub rows served by L2 / Infinity Cache are in "
-                             "it: the rate the kernel delivers to its consumer, which on a power-law request exceeds what "
-                             "HBM supplies -- not a fraction of the HBM roofline; `frac` is",
+            # `achieved` is always a rate of bytes that provably crossed the memory system, so achieved / peak = frac <= 1:
+            # here the compulsory bytes of the live launch (a lower bound); the cache-free leg replaces it below
+            "achieved": bytes_comp / t / 1e9,
+            "achieved_basis": "compulsory bytes of the last timed launch / live average launch time",
             "distinct_rows_last_launch": distinct, "compulsory_bytes_per_launch": bytes_comp,
             "frac_compulsory": bytes_comp / t / 1e9 / HBM_PEAK_GBS,
             "note_compulsory": "lower bound for the timed launches: the distinct rows of the launch once + ids + outputs "
@@ -761,6 +790,8 @@ def roofline_aggregate(agg, D, n_segments, n_ids, avg_ms, launches, ids_last, wo
             roof["traffic_source"] = ("OFFLINE: profiles/pmc_traffic.json, rocprofv3 --pmc passes of this command on another "
                                       "box (FETCH_SIZE x2 + WRITE_SIZE per launch); not measured in this run")
             roof["frac_traffic_offline"] = min(1.0, traffic / t / 1e9 / HBM_PEAK_GBS)
+            # memory-side counter bytes / live launch time: what the fabric (HBM + Infinity Cache) moved per second
+            roof["memory_side_gbs"] = traffic / t / 1e9
             # what HBM itself delivered lies between the two: Infinity-Cache hits are inside the memory-side count
             roof["hbm_bytes_bracket"] = [bytes_comp, traffic]
             roof["traffic_over_algorithmic"] = traffic / bytes_alg
@@ -937,6 +968,10 @@ def main():
     ap.add_argument("--other-configs", default="c2,c5,c4,c3-degree-seeds",
                     help="N=1, headline workload at the default batch: also time these workloads (comma separated), each in a "
                          "process of its own, and report them under \"other_configs\"")
+    ap.add_argument("--request-shape-legs", default="on", choices=["on", "off"],
+                    help="N=1: time the same steps twice more -- with an explicit segment_ids tensor per aggregation (the "
+                         "reference's AggregatingRequest always carries one) and with seeds uniform over ALL vertices "
+                         "(SURVEY 8(d)) -- and make the slowest of the three the headline when it is more than 2%% slower")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded (RCCL) code path even with one process (testing)")
     ap.add_argument("--c5-scale", type=int, default=1, help="divide the c5 node / edge counts (test rig)")
@@ -1028,8 +1063,9 @@ def main():
 
     # The CPU baseline runs AFTER the timed GPU region (an idle GPU clocks down during
     # 1-2 minutes of host work); keep host copies of the edge list for it.
+    extras = n1_extras(args, world, sharded)
     host_edges = None
-    if args.cpu_baseline == "on" and world == 1:
+    if extras["cpu_baseline"]:
         host_edges = (src.cpu(), dst.cpu(), weight.cpu() if weight is not None else None,
                       seed_pool.cpu().numpy())
 
@@ -1147,6 +1183,7 @@ def main():
     n_steps = args.warmup + args.steps
     seeds = seed_pool[torch.randint(0, seed_pool.shape[0], (n_steps, B0), generator=gen, device=dev)]
     del seed_pool
+    cur = {"seeds": seeds}  # the request stream the steps read: the request-shape legs swap it
     n1, n2 = B0 * k1, B0 * k1 * k2
     emb2 = torch.empty((n1, D), dtype=torch.float32, device=dev)
     cnt2 = torch.empty((n1,), dtype=torch.int32, device=dev)
@@ -1174,10 +1211,10 @@ def main():
         cc = 4 * i
         nb1, ed1, nb2, ed2 = bufs[i % len(bufs)]
         if st_smp is None:
-            graph.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
+            graph.sample(sampler, cur["seeds"][i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
             graph.sample(sampler, nb1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nb2, ed2))
         else:
-            st_smp.sample(sampler, seeds[i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
+            st_smp.sample(sampler, cur["seeds"][i], k1, seed=42, call_counter=cc, out=(nb1, ed1))
             st_smp.sample(sampler, nb1.view(-1), k2, seed=42, call_counter=cc + 1, out=(nb2, ed2))
         return nb1, nb2
 
@@ -1189,10 +1226,13 @@ def main():
 
     # A dense sampler response implies its segments (segment i = the neighbours of request row i):
     # segment_ids = None skips the segment bookkeeping kernels and the read of a segment tensor.
-    def agg_local(table):
+    def agg_local(table, seg=(None, None)):
+        # seg = (hop-2, hop-1) int32 segment_ids tensors: the reference's request shape (AggregatingRequest::Set(node_ids,
+        # segment_ids, ...), include/aggregating_request.h:34-37), which runs the segment bookkeeping kernels
+        # (glx_seg_valid / glx_seg_start) and reads 4 B per input vertex on top
         def run(a, b, i):
-            table.aggregate(agg, b.view(-1), None, n1, out=(emb2, cnt2))
-            table.aggregate(agg, a.view(-1), None, B0, out=(emb1, cnt1))
+            table.aggregate(agg, b.view(-1), seg[0], n1, out=(emb2, cnt2))
+            table.aggregate(agg, a.view(-1), seg[1], B0, out=(emb1, cnt1))
         return run
 
     def agg_halo(a, b, i):
@@ -1361,6 +1401,7 @@ def main():
     kernel_steps = args.steps  # steps the per-kernel timers covered
     ctl = dev if args.backend == "nccl" else torch.device("cpu")  # control-plane tensors (gloo rig: host)
     legs = {}
+    request_legs = {}
     use_graph = not sharded and (args.graph == "on" or (args.graph == "auto" and B0 <= 8192))
     if use_graph:
         # launch-bound batch sizes: the whole step (2 sample + 2 aggregate kernels) is ONE hipGraph launch
@@ -1388,7 +1429,37 @@ def main():
         headline = "single GPU, one hipGraph launch per step"
         placement = "1 GPU; step = one hipGraph launch (glx_plan), %d plan(s) alternating on as many streams" % len(plans)
     elif not sharded:
-        elapsed, t_agg, t_smp = timed_leg(agg_local(feats), args.warmup, n_steps, args.warmup)
+        request_legs = {}
+        leg_runs = {}
+        if extras["request_shape_legs"]:
+            # the two request shapes VERDICT r04 asks for beside the headline's, each the same args.steps steps:
+            #  (b) every aggregation carries an explicit segment_ids tensor, as the reference's request always does
+            #  (c) seeds uniform over ALL V vertices, half of which have no out-edges in an RMAT graph
+            seg = (torch.arange(n2, dtype=torch.int32, device=dev) // k2, torch.arange(n1, dtype=torch.int32, device=dev) // k1)
+            gen_v = torch.Generator(device=dev)
+            gen_v.manual_seed(2000 + rank)
+            seeds_v = torch.randint(0, V, (n_steps, B0), generator=gen_v, device=dev)
+            cur["seeds"] = seeds_v
+            leg_runs["seeds_uniform_over_V"] = timed_leg(agg_local(feats), args.warmup, n_steps, args.warmup)
+            cur["seeds"] = seeds
+            leg_runs["with_segment_ids"] = timed_leg(agg_local(feats, seg), args.warmup, n_steps, args.warmup)
+        leg_runs["headline_shape"] = timed_leg(agg_local(feats), args.warmup, n_steps, args.warmup)
+        chosen = "headline_shape"
+        for name in ("with_segment_ids", "seeds_uniform_over_V"):
+            if name in leg_runs and leg_runs[name][0] > 1.02 * leg_runs[chosen][0]:
+                chosen = name  # more than 2 % slower: that is the number to quote
+        for name, (el, _, _) in leg_runs.items():
+            request_legs[name + "_ms"] = el / args.steps * 1e3
+        request_legs["headline_is"] = chosen
+        elapsed, t_agg, t_smp = leg_runs[chosen]
+        if chosen != "headline_shape":
+            # the buffers hold the headline-shaped leg's last step (it ran last); redo the chosen leg's last step so
+            # that the oracle check below looks at the request that was timed (the steps are deterministic)
+            if chosen == "seeds_uniform_over_V":
+                cur["seeds"] = seeds_v
+            a_r, b_r = do_sample(n_steps - 1)
+            agg_local(feats, seg if chosen == "with_segment_ids" else (None, None))(a_r, b_r, n_steps - 1)
+            torch.cuda.synchronize()
         headline = "single GPU"
     else:
         # A collective that never completes (a rank died, a link fault) would hang every rank forever: after
@@ -1594,7 +1665,7 @@ def main():
         nb1, ed1, nb2, ed2 = bufs[last_i % len(bufs)]
         torch.cuda.synchronize()
         try:
-            oracle_check = verify_vs_oracle(args, wl, dev, seeds[last_i],
+            oracle_check = verify_vs_oracle(args, wl, dev, cur["seeds"][last_i],
                                             dict(n1=nb1, e1=ed1, n2=nb2, e2=ed2, emb2=emb2, cnt2=cnt2, emb1=emb1, cnt1=cnt1),
                                             (4 * last_i, 4 * last_i + 1))
         except Exception as ex:  # noqa: BLE001 -- a checker that cannot run is reported, not fatal to the line
@@ -1672,6 +1743,8 @@ def main():
         # the roofline fraction of the kernel: same kernel, same request shape, measured in this run, on the input
         # where bytes moved are known exactly
         roof["frac"] = cf / HBM_PEAK_GBS
+        roof["achieved"] = cf
+        roof["achieved_basis"] = "cache-free leg: algorithmic bytes (== memory-side traffic there) / its average launch time"
         roof["frac_basis"] = ("cache-free leg of this run: the same kernel on the same request shape with ids uniform over the "
                               "table (algorithmic bytes == memory-side traffic; at most the 256 MB Infinity Cache's share of the "
                               "table -- cache_free.infinity_cache_share_upper_bound -- can be on-die hits) / 8 TB/s; the timed "
@@ -1701,8 +1774,16 @@ def main():
                                              "" if not sharded else "value = %s placement, %s (the faster of the two "
                                              "exchange modes timed; both are in placements) -- " % (headline, exchange_mode), desc),
                    "seeds_per_step_per_gpu": B0,
-                   "seeds": ("uniform over the vertices that have out-edges" if args.seed_dist == "uniform" else
+                   "seeds": ("uniform over ALL vertices (SURVEY 8(d)); about half have no out-edges and default-fill"
+                             if (not sharded and not use_graph and request_legs.get("headline_is") == "seeds_uniform_over_V")
+                             else "uniform over the vertices that have out-edges (a training set has neighbours; harder than "
+                                  "SURVEY 8(d)'s uniform over V, timed beside as request_shapes.seeds_uniform_over_V_ms)"
+                             if args.seed_dist == "uniform" else
                              "degree-biased: the sources of uniformly drawn edges") + ", fresh batch every step",
+                   "segment_ids": ("explicit int32 tensor per aggregation (the reference's request shape)"
+                                   if (not sharded and not use_graph and request_legs.get("headline_is") == "with_segment_ids")
+                                   else "implied by the dense sampler response (segment i = row i's neighbours); the explicit-"
+                                        "tensor shape is timed beside as request_shapes.with_segment_ids_ms"),
                    "fanout": [k1, k2], "sampler": sampler, "aggregator": agg, "dim": D,
                    "arithmetic": "int64 ids / edge ids (bit-exact), f32 features and aggregates",
                    "nodes": V, "edges": E, "hop2_rows_without_out_edges_fraction": empty_frac,
@@ -1721,6 +1802,8 @@ def main():
     }
     if roof_smp is not None:
         res["roofline_sampler"] = roof_smp
+    if not sharded and not use_graph and request_legs:
+        res["request_shapes"] = request_legs
     if oracle_check is not None:
         res["verified_vs_oracle"] = oracle_check["ok"]
         res["oracle_check"] = oracle_check
@@ -1753,9 +1836,9 @@ def main():
         res["verified_legs"] = verified_legs
     if cpu:
         res["gpu_over_cpu"] = value / cpu["value"]
-    if args.host_boundary == "on" and not sharded and rank == 0:
+    if extras["host_boundary"] and rank == 0:
         res["host_boundary"] = host_boundary_rate(args)
-    if args.small_batches == "on" and not sharded and world == 1 and B0 == 65536:
+    if extras["small_batches"]:
         # SURVEY 8(a) fixes B0 in {1024, 8192, 65536}: the launch-bound sizes on the same resident store, each step ONE
         # hipGraph launch (glx_plan), plans alternating over --graph-streams streams
         small = {}
@@ -1782,9 +1865,9 @@ def main():
             del plans, streams
         res["small_batches"] = dict(small, note="same store, B0 seeds per step, step = one hipGraph launch (glx_plan), %d plans "
                                                 "alternating on as many streams; value in edges/s" % args.graph_streams)
-    if args.edge_cut_probe == "on" and not sharded and world == 1 and args.workload == "c3" and B0 == 65536:
+    if extras["edge_cut_probe"]:
         res["edge_cut_world1"] = edge_cut_world1(args)
-    if args.other_configs and not sharded and world == 1 and args.workload == "c3" and B0 == 65536:
+    if extras["other_configs"]:
         # free this process's store first: c5 needs most of the HBM for its build
         del graph, feats
         import gc

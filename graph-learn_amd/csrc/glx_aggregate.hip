@@ -848,7 +848,17 @@ extern "C" int glx_tune(const char* name, int32_t value) {
   else if (strcmp(name, "agg_xcd_slices") == 0) slot = &k.xcd;
   else if (strcmp(name, "agg_occupancy") == 0) slot = &k.occ;
   else if (strcmp(name, "agg_store") == 0) slot = &k.store;
-  GLX_REQUIRE(slot != nullptr, "unknown knob '%s'", name);
+  if (slot == nullptr) {  // the side paths' knobs (glx_common.h GlxSideKnobs): -1 restores the default
+    GlxSideKnobs& sk = glx_side_knobs();
+    std::atomic<int64_t>* side = nullptr;
+    if (strcmp(name, "cond_sequential") == 0) side = &sk.cond_sequential;
+    else if (strcmp(name, "dist_no_bitmap") == 0) side = &sk.dist_no_bitmap;
+    else if (strcmp(name, "filter_span_cap") == 0) side = &sk.filter_span_cap;
+    else if (strcmp(name, "filter_dedup_min_rows") == 0) side = &sk.filter_dedup_min_rows;
+    GLX_REQUIRE(side != nullptr, "unknown knob '%s'", name);
+    side->store(value, std::memory_order_relaxed);
+    return GLX_OK;
+  }
   slot->store(value, std::memory_order_relaxed);
   return GLX_OK;
 }

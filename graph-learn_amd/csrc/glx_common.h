@@ -2,6 +2,7 @@
 // id->row translation shared by every kernel.  gfx950 (CDNA4) only; wave = 64.
 #ifndef GLX_COMMON_H_
 #define GLX_COMMON_H_
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -168,6 +169,17 @@ struct GlxEwRec {
   int64_t nbr_self;
   int64_t nbr_alias;
 };
+
+// Test / A-B knobs of the paths beside the hot one, read from the environment ONCE (first use: operators run on up to
+// 32 pool threads and getenv is not something to call per request) and settable at run time through glx_tune().
+// -1 = unset (the product's default).
+struct GlxSideKnobs {
+  std::atomic<int64_t> cond_sequential{-1};       // GLX_COND_SEQUENTIAL (set = 1): the one-wave walk for every conditional-negative request
+  std::atomic<int64_t> dist_no_bitmap{-1};        // GLX_DIST_NO_BITMAP (set = 1): the hot-row replica's membership test as a hash map
+  std::atomic<int64_t> filter_span_cap{-1};       // GLX_FILTER_SPAN_CAP: total degree per chunk of a filtered request
+  std::atomic<int64_t> filter_dedup_min_rows{-1}; // GLX_FILTER_DEDUP_MIN_ROWS: rows from which (vertex, value) pairs share a table; 0 disables
+};
+GlxSideKnobs& glx_side_knobs();  // glx_graph.hip
 
 struct glx_graph {
   int device;

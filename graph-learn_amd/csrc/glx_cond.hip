@@ -550,7 +550,7 @@ extern "C" int glx_cond_negative_sample(const glx_cond_table* t, const glx_graph
   a.out = p_out;
   const unsigned row_grid = (unsigned)(((int64_t)batch * 64 + 255) / 256);
   int replay = 1;
-  const bool force_seq = getenv("GLX_COND_SEQUENTIAL") != nullptr;  // A/B and test knob, read per call
+  const bool force_seq = glx_side_knobs().cond_sequential.load(std::memory_order_relaxed) > 0;  // A/B and test knob
   if (!unique && !force_seq) {
     // rows are independent given the first-insertion table: one wave per row
     GlxTemp d_first, d_flag;

@@ -2047,6 +2047,15 @@ int dist_random_walk(glx_dist_store* st, const int64_t* seeds, int32_t batch, in
     // DeepWalk (random_walk.cc:168-190): step t of walker i = RandomSampler's draw 0 of the stream (seed, call_counter + t,
     // i) on the vertex it stands on -- one partitioned request with neighbor_count 1 per step, every walker a row; a
     // walker on a vertex without out-edges continues from the default id, like the single-store walk
+    // Walks ALWAYS take the count exchange (glx.h): a step feeds the next one, so a step speculated on capacities
+    // learned from some other request's shape could lose rows and the walk would carry the loss on unnoticed until a
+    // later confirmation.  The ledger is detached for the steps (their positions are not recorded either).
+    struct LedgerOff {
+      glx_dist_store* st;
+      glx_dist_ledger* saved;
+      explicit LedgerOff(glx_dist_store* s) : st(s), saved(s->ledger) { st->ledger = nullptr; }
+      ~LedgerOff() { st->ledger = saved; }
+    } ledger_off(st);
     for (int32_t t = 0; t < walk_len; ++t) {
       rc = dist_sample_device(st, GLX_SAMPLER_RANDOM, cur, batch, 1, GLX_PAD_CIRCULAR, default_neighbor_id, seed,
                               call_counter + (uint64_t)t, nullptr, nxt, eid, s);
@@ -2576,7 +2585,7 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
   GLX_HIP(hipMemcpyAsync(&lo_hi[0], sorted.as<int64_t>(), 8, hipMemcpyDeviceToHost, s));
   GLX_HIP(hipMemcpyAsync(&lo_hi[1], sorted.as<int64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, s));
   GLX_HIP(hipStreamSynchronize(s));
-  const bool no_bitmap = getenv("GLX_DIST_NO_BITMAP") != nullptr;  // A/B and test knob, read per call
+  const bool no_bitmap = glx_side_knobs().dist_no_bitmap.load(std::memory_order_relaxed) > 0;  // A/B and test knob
   // ... and are dense enough: the bitmap costs 24 bytes per 64 ids of the RANGE, persistent, plus scratch -- one stray
   // id near 2^31 in a short hot list would pin ~800 MB per GPU.  Within 4 words per listed id (+ a floor) it never
   // exceeds ~100 bytes per hot row, a tenth of the row itself at dim 256; sparser lists keep the hash map.

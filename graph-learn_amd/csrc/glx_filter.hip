@@ -632,8 +632,7 @@ constexpr int kFullSampler = -1;
 // row) is returned to the device after the call.
 constexpr int64_t kSpanCap = (int64_t)1 << 30;
 int64_t span_cap(size_t bytes_per_position) {
-  const char* e = getenv("GLX_FILTER_SPAN_CAP");  // test knob: force many small chunks
-  const int64_t v = e ? atoll(e) : 0;
+  const int64_t v = glx_side_knobs().filter_span_cap.load(std::memory_order_relaxed);  // test knob: force many small chunks
   if (v > 0) return v;
   size_t free_b = 0, total_b = 0;
   int64_t cap = kSpanCap;
@@ -720,8 +719,8 @@ __global__ __launch_bounds__(256) void glx_filter_alias_slots_dedup_kernel(DrawA
 }
 
 int dedup_min_rows() {
-  const char* e = getenv("GLX_FILTER_DEDUP_MIN_ROWS");  // test knob; 0 disables
-  return e ? atoi(e) : 1024;
+  const int64_t v = glx_side_knobs().filter_dedup_min_rows.load(std::memory_order_relaxed);  // test knob; 0 disables
+  return v < 0 ? 1024 : (int)v;
 }
 
 #define GLX_FILTER_PRIM(call_with)                                             \

@@ -29,6 +29,18 @@ void glx_set_error(const char* fmt, ...) {
 extern "C" const char* glx_last_error(void) { return g_err; }
 extern "C" int glx_abi_version(void) { return GLX_ABI_VERSION; }
 
+GlxSideKnobs& glx_side_knobs() {
+  static GlxSideKnobs k;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (getenv("GLX_COND_SEQUENTIAL")) k.cond_sequential = 1;
+    if (getenv("GLX_DIST_NO_BITMAP")) k.dist_no_bitmap = 1;
+    if (const char* e = getenv("GLX_FILTER_SPAN_CAP")) k.filter_span_cap = atoll(e);
+    if (const char* e = getenv("GLX_FILTER_DEDUP_MIN_ROWS")) k.filter_dedup_min_rows = atoll(e);
+  });
+  return k;
+}
+
 extern "C" int glx_device_count(int* count) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -631,9 +643,10 @@ int glx_alias_build_launch(const int64_t* row_ptr, const float* weight, int64_t 
   return GLX_OK;
 }
 
-int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s) {
+// The per-row alias tables over g->weight, and the packed EdgeWeight records on top of them.
+static int glx_graph_build_alias(glx_graph* g, hipStream_t s) {
   const int64_t V = g->num_rows, E = g->num_edges;
-  if (g->weight) {
+  {
     GLX_HIP(hipMalloc(&g->alias, (size_t)(E > 0 ? E : 1) * sizeof(GlxAlias)));
     int rc = glx_alias_build_launch(g->row_ptr, g->weight, V, E, g->alias, s);
     if (rc != GLX_OK) return rc;
@@ -653,6 +666,15 @@ int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s) {
         g->ew = nullptr;
       }
     }
+  }
+  return GLX_OK;
+}
+
+int glx_graph_finalize(glx_graph* g, const int64_t* d_ids, hipStream_t s) {
+  const int64_t V = g->num_rows;
+  if (g->weight) {
+    int rc = glx_graph_build_alias(g, s);
+    if (rc != GLX_OK) return rc;
   }
   if (d_ids) {
     int rc = glx_idmap_build(d_ids, V, &g->idmap, s);
@@ -690,6 +712,25 @@ extern "C" int glx_graph_create(int device, int64_t num_rows, int64_t num_edges,
   }
   *out = g;
   return GLX_OK;
+}
+
+__global__ void glx_fill_float_kernel(float* __restrict__ p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+extern "C" int glx_graph_enable_default_weight(glx_graph* g, float default_weight, void* stream) {
+  GLX_REQUIRE(g != nullptr, "graph is NULL");
+  if (g->weight) return GLX_OK;  // a weighted type keeps its weights
+  GlxDeviceGuard guard(g->device);
+  GLX_REQUIRE(guard.ok, "cannot select device %d", g->device);
+  hipStream_t s = glx_stream(stream);
+  const int64_t E = g->num_edges;
+  GLX_HIP(hipMalloc(&g->weight, (size_t)(E > 0 ? E : 1) * sizeof(float)));
+  if (E > 0) glx_fill_float_kernel<<<grid_for(E), 256, 0, s>>>(g->weight, E, default_weight);
+  int rc = glx_graph_build_alias(g, s);
+  GLX_HIP(hipStreamSynchronize(s));
+  GLX_HIP(hipGetLastError());
+  return rc;
 }
 
 extern "C" void glx_graph_destroy(glx_graph* g) {

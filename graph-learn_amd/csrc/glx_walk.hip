@@ -231,7 +231,7 @@ extern "C" int glx_random_walk(const glx_graph* g, const int64_t* seeds, int32_t
     }
   }
   int32_t* d_live = d_seg ? d_seg + nb : nullptr;
-  int64_t* d_true = d_seg ? reinterpret_cast<int64_t*>(d_seg + 2 * nb + (nb & 1)) : nullptr;
+  int64_t* d_true = d_seg ? reinterpret_cast<int64_t*>(d_seg + 2 * nb)  /* 8 nb bytes in: 8-byte aligned */ : nullptr;
   int64_t* d_used = d_seg ? d_true + nb : nullptr;
   GlxKernelTimer timer(GLX_KERNEL_SAMPLE, s);
   for (int32_t t = 0; t < walk_len; ++t) {

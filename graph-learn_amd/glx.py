@@ -40,7 +40,7 @@ EXPORTS = [
     "glx_abi_version", "glx_device_count", "glx_last_error", "glx_host_register", "glx_host_unregister",
     "glx_graph_create", "glx_graph_build", "glx_graph_build_ordered", "glx_graph_destroy", "glx_graph_info", "glx_graph_export_alias",
     "glx_graph_degrees", "glx_graph_in_degrees", "glx_sample", "glx_sample_ex", "glx_sample_hops",
-    "glx_graph_enable_in_degree", "glx_sample_full_sizes", "glx_sample_full",
+    "glx_graph_enable_in_degree", "glx_graph_enable_default_weight", "glx_sample_full_sizes", "glx_sample_full",
     "glx_graph_set_timestamps", "glx_sample_filtered", "glx_sample_full_filtered", "glx_random_walk",
     "glx_features_create", "glx_features_view", "glx_features_destroy", "glx_features_info",
     "glx_aggregate", "glx_lookup",
@@ -138,6 +138,7 @@ def lib():
         L.glx_sample_ex.argtypes = [vp, ci, vp, vp, i32, i32, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_sample_hops.argtypes = [vp, i32, ci, vp, i32, vp, ci, i64, u64, u64, vp, vp, ci, vp]
         L.glx_graph_enable_in_degree.argtypes = [vp, vp]
+        L.glx_graph_enable_default_weight.argtypes = [vp, ctypes.c_float, vp]
         L.glx_sample_full_sizes.argtypes = [vp, vp, i32, i32, vp, vp, ci, vp]
         L.glx_sample_full.argtypes = [vp, vp, i32, i32, vp, vp, vp, ci, vp]
         L.glx_graph_set_timestamps.argtypes = [vp, vp, ci, vp]
@@ -341,6 +342,12 @@ class Graph:
     def enable_in_degree(self):
         """Build the in-degree alias tables InDegreeSampler needs (once, on the device)."""
         _check(lib().glx_graph_enable_in_degree(self._h, None))
+        return self
+
+    def enable_default_weight(self, default_weight=0.0):
+        """EdgeWeightSampler on an unweighted graph: every slot weighs `default_weight` (the reference's
+        GLOBAL_FLAG(DefaultWeight)); builds the alias tables of that.  No effect on a weighted graph."""
+        _check(lib().glx_graph_enable_default_weight(self._h, ctypes.c_float(default_weight), None))
         return self
 
     def sample_full(self, src, max_limit=0):

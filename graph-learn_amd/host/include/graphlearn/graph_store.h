@@ -160,6 +160,8 @@ public:
   Status Negative(bool by_in_degree, bool strict, const glx_negative** out);
   // In-degree alias tables for InDegreeSampler, built on first use.
   Status EnsureInDegree();
+  // Constant-weight alias tables for EdgeWeightSampler on an unweighted type, built on first use.
+  Status EnsureDefaultWeights();
   // The same for a shard of a partitioned edge type: in-degrees summed over all shards (collective).
   Status EnsureGlobalInDegree(glx_dist_store* store);
   // Per-row id-sorted index for id == value filters (and strict negative sampling), built on first use.
@@ -193,6 +195,7 @@ private:
   glx_negative* neg_in_degree_;
   bool neg_strict_ready_;
   bool in_degree_ready_;
+  bool default_weights_ready_ = false;
   bool global_in_degree_ready_;
   std::mutex mtx_;
 };

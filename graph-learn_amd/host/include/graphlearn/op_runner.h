@@ -99,6 +99,8 @@ public:
   uint64_t NextCallCounters(uint64_t count) { return call_counter_.fetch_add(count ? count : 1, std::memory_order_relaxed); }
 
 private:
+  bool LookupNegativeTable(const std::string& key, const glx_negative** out);
+  const glx_negative* KeepNegativeTable(const std::string& key, glx_negative* table);
   glx_comm* comm_;
   GraphStore* store_;
   int32_t server_id_, server_count_;

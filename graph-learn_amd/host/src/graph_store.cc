@@ -175,6 +175,18 @@ Status Graph::EnsureInDegree() {
   return Status::OK();
 }
 
+Status Graph::EnsureDefaultWeights() {
+  // EdgeWeightSampler on an unweighted type: every edge weighs GLOBAL_FLAG(DefaultWeight), as
+  // MemoryEdgeStorage::GetWeight answers for it (memory_edge_storage.cc:97-103); see glx_graph_enable_default_weight.
+  std::lock_guard<std::mutex> g(mtx_);
+  if (info_.IsWeighted() || default_weights_ready_) return Status::OK();
+  if (!dev_) return error::InvalidArgument("edge type '" + type_ + "' is not built on the device");
+  int rc = glx_graph_enable_default_weight(dev_, GLOBAL_FLAG(DefaultWeight), nullptr);
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  default_weights_ready_ = true;
+  return Status::OK();
+}
+
 Status Graph::EnsureGlobalInDegree(glx_dist_store* store) {
   // A shard of a partitioned edge type: InDegreeSampler's weights are in-degrees over ALL shards
   // (glx_dist_enable_in_degree: collective, every server gets here in the same Run()).

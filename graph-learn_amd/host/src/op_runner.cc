@@ -123,35 +123,56 @@ Status Env::EdgeNegativeTable(const std::string& edge_type, bool by_in_degree, c
   glx_dist_store* st = nullptr;
   Status s = EdgeStore(edge_type, &st);
   if (!s.ok()) return s;
-  std::lock_guard<std::mutex> lock(mtx_);
   const std::string key = (by_in_degree ? "e/indeg/" : "e/uniform/") + edge_type;
-  auto it = negative_tables_.find(key);
-  if (it == negative_tables_.end()) {
-    glx_negative* t = nullptr;
-    int rc = glx_dist_negative_create(st, by_in_degree ? 1 : 0, nullptr, &t);  // collective
-    if (rc != GLX_OK) return error::FromGlx(rc);
-    it = negative_tables_.emplace(key, t).first;
-  }
-  *out = it->second;
+  if (LookupNegativeTable(key, out)) return Status::OK();
+  // The collective runs WITHOUT mtx_: a server whose peers are late must not block its own threads' lookups of
+  // other tables / stores.  Two threads of one server cannot be in here for the same key: requests that need the
+  // table hold RunMutex() (op_runner.h).
+  glx_negative* t = nullptr;
+  int rc = glx_dist_negative_create(st, by_in_degree ? 1 : 0, nullptr, &t);  // collective
+  if (rc != GLX_OK) return error::FromGlx(rc);
+  *out = KeepNegativeTable(key, t);
   return Status::OK();
 }
 
-Status Env::NodeNegativeTable(const std::string& node_type, const glx_negative** out) {
+bool Env::LookupNegativeTable(const std::string& key, const glx_negative** out) {
   std::lock_guard<std::mutex> lock(mtx_);
-  const std::string key = "n/" + node_type;
   auto it = negative_tables_.find(key);
-  if (it == negative_tables_.end()) {
+  if (it == negative_tables_.end()) return false;
+  *out = it->second;
+  return true;
+}
+
+const glx_negative* Env::KeepNegativeTable(const std::string& key, glx_negative* table) {
+  std::lock_guard<std::mutex> lock(mtx_);
+  auto ins = negative_tables_.emplace(key, table);
+  if (!ins.second) glx_negative_destroy(table);  // somebody else's build of the same table got here first
+  return ins.first->second;
+}
+
+Status Env::NodeNegativeTable(const std::string& node_type, const glx_negative** out) {
+  const std::string key = "n/" + node_type;
+  if (LookupNegativeTable(key, out)) return Status::OK();
+  {  // collectives without mtx_, as in EdgeNegativeTable
     Noder* noder = store_->GetNoder(node_type);
-    if (!noder->GetSideInfo()->IsWeighted()) return error::InvalidArgument("node type '" + node_type + "' has no weights");
+    // A condition that could differ between the servers must not decide who enters the collective: every server
+    // takes part in the count exchange and says there whether its shard can contribute (-1: the type has no
+    // weights here); all of them then refuse together.
+    const bool usable = noder->GetSideInfo()->IsWeighted();
     // every server's (id, weight) list to every server: the counts first, then the lists (each server sends its own
     // list to all), merged by ascending id -- NodeStorage::GetIds() / GetWeights() of the unpartitioned storage up to order
     const std::vector<int64_t>& ids = noder->Ids();
     const std::vector<float>& weights = noder->Weights();
-    int64_t n = (int64_t)ids.size();
+    int64_t n = usable ? (int64_t)ids.size() : -1;
     const size_t P = (size_t)server_count_;
     std::vector<int64_t> counts(P);
     int rc = glx_comm_allgather_i64(comm_, &n, 1, counts.data(), GLX_PTR_HOST, nullptr);
     if (rc != GLX_OK) return error::FromGlx(rc);
+    for (size_t p = 0; p < P; ++p) {
+      if (counts[p] < 0) {
+        return error::InvalidArgument("node type '" + node_type + "' has no weights on server " + std::to_string(p));
+      }
+    }
     struct Rec { int64_t id; int64_t w; };
     std::vector<Rec> send(P * (size_t)n);
     for (size_t p = 0; p < P; ++p) {
@@ -169,7 +190,8 @@ Status Env::NodeNegativeTable(const std::string& node_type, const glx_negative**
                         nullptr);
     if (rc != GLX_OK) return error::FromGlx(rc);
     recv.resize((size_t)total);
-    std::sort(recv.begin(), recv.end(), [](const Rec& a, const Rec& b) { return a.id < b.id; });
+    // received in source-rank order: a stable sort by id breaks ties by rank, the same on every server
+    std::stable_sort(recv.begin(), recv.end(), [](const Rec& a, const Rec& b) { return a.id < b.id; });
     std::vector<int64_t> all_ids((size_t)total);
     std::vector<float> all_w((size_t)total);
     for (size_t i = 0; i < (size_t)total; ++i) {
@@ -182,9 +204,8 @@ Status Env::NodeNegativeTable(const std::string& node_type, const glx_negative**
     glx_negative* t = nullptr;
     rc = glx_negative_create(device, total, all_ids.data(), all_w.data(), GLX_PTR_HOST, nullptr, &t);
     if (rc != GLX_OK) return error::FromGlx(rc);
-    it = negative_tables_.emplace(key, t).first;
+    *out = KeepNegativeTable(key, t);
   }
-  *out = it->second;
   return Status::OK();
 }
 

@@ -61,6 +61,10 @@ public:
         Status s = graph->EnsureInDegree();
         if (!s.ok()) return s;
       }
+      if (graphs[h] && SamplerId() == GLX_SAMPLER_EDGE_WEIGHT) {
+        Status s = graph->EnsureDefaultWeights();
+        if (!s.ok()) return s;
+      }
     }
     if (!all_loaded) {  // an edge type nobody loaded default-fills (Sample): hop by hop, each fed by the one before
       for (size_t h = 0; h < hops; ++h) {
@@ -107,6 +111,10 @@ protected:
     const glx_graph* g = graph->Device();
     if (g && SamplerId() == GLX_SAMPLER_IN_DEGREE) {
       Status s = graph->EnsureInDegree();
+      if (!s.ok()) return s;
+    }
+    if (g && SamplerId() == GLX_SAMPLER_EDGE_WEIGHT) {
+      Status s = graph->EnsureDefaultWeights();
       if (!s.ok()) return s;
     }
     if (g && req->HasFilter() && (int32_t)req->GetFilterType() == GLX_FILTER_EQUAL &&

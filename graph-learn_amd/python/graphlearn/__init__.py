@@ -15,8 +15,6 @@ from graphlearn.settings import *  # noqa: F401,F403
 from graphlearn.errors import *  # noqa: F401,F403
 from graphlearn.utils import Mask, get_mask_type, strategy2op  # noqa: F401
 from graphlearn.decoder import Decoder  # noqa: F401
-from graphlearn.feature_spec import (DenseSpec, DynamicMultivalSpec, DynamicSparseSpec, FeatureSpec,  # noqa: F401
-                                     MultivalSpec, SparseSpec)
 from graphlearn.topology import Topology  # noqa: F401
 from graphlearn.values import Values, Nodes, Edges, SparseNodes, SparseEdges, Layer, Layers  # noqa: F401
 from graphlearn.sampler import *  # noqa: F401,F403
@@ -25,7 +23,6 @@ from graphlearn.graph import Graph  # noqa: F401
 from graphlearn.loader import NeighborLoader, NeighborBatch  # noqa: F401
 from graphlearn.gsl import Dataset  # noqa: F401
 from graphlearn.sampler import SubGraph  # noqa: F401  (python/data/values.py SubGraph: what subgraph_sampler().get() returns)
-from graphlearn.state import EdgeState, NodeState  # noqa: F401
 import graphlearn.nn as nn  # noqa: F401,E402  (gl.nn.Dataset / Data / SubGraph / HeteroSubGraph)
 
 NODE = pywrap.NodeFrom.NODE

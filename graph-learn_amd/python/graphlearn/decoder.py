@@ -62,34 +62,6 @@ class Decoder(object):
   string_attr_num = property(lambda self: self._counts["string"])
 
   @property
-  def feature_spec(self):
-    """decoder.py:123-153, 217-221: one spec per attribute -- no attr_dim: a dense numeric value (float or int, no
-    buckets); an attr_dim: an int or string to embed in that many dimensions (hashed into `bucket` buckets when given, a
-    dynamic vocabulary otherwise); multi-valued strings: a MultivalSpec."""
-    if getattr(self, "_fspec", None) is None:
-      from graphlearn.feature_spec import FeatureSpec
-      num = len(self._attr_types)
-      dims = self._attr_dims or [None] * num
-      if num != len(dims):
-        raise ValueError("The size of attr_dims must be equal with attr_types.")
-      spec = FeatureSpec(num, self._weighted, self._labeled, self._timestamped)
-      for attr_type, dim in zip(self._attr_types, dims):
-        name, bucket, multi = self.parse(attr_type)
-        if not dim:
-          assert name in ("float", "int") and bucket is None, \
-              "Must assign an attr_dim for {}, and bucket_size should None.".format(name)
-        else:
-          assert name in ("int", "string"), "Must assign an attr_dim with None for {}".format(name)
-        if multi:
-          spec.append_multival(bucket, dim, ",")
-        elif dim:
-          spec.append_sparse(bucket, dim, name == "int")
-        else:
-          spec.append_dense(name == "float")
-      self._fspec = spec
-    return self._fspec
-
-  @property
   def has_property(self):
     return self._weighted or self._labeled or self._timestamped or self.attributed
 

@@ -494,6 +494,10 @@ class Dataset(object):
     self._chains = self._find_chains() if fuse_hops else {}
     self._fused_calls = int.from_bytes(__import__("os").urandom(6), "little") << 8
     self._prefetch = bool(prefetch) and self._window > 0
+    if self._prefetch and getattr(query.graph, "_shard", (0, 1))[1] > 1:
+      # a prefetch thread issues requests beside the consumer's own: in SPMD mode every rank must issue its
+      # requests in the same order (partitioned requests are collectives), which two threads cannot promise
+      raise ValueError("prefetch=True is not available on a sharded graph (requests of all ranks must stay in order)")
     if hasattr(query.graph, "add_dataset"):
       query.graph.add_dataset(self)  # dag_dataset.py:59: Graph.close() stops its datasets
     self._queue = None
@@ -590,13 +594,20 @@ class Dataset(object):
   def close(self):
     """Stops the prefetch thread (a no-op without one); batches already produced are dropped."""
     if self._thread is not None:
+      import time
+      import warnings
       self._stop.set()
-      while self._thread.is_alive():
+      deadline = time.time() + 30.0
+      while self._thread.is_alive() and time.time() < deadline:
         try:
           self._queue.get_nowait()
         except Exception:  # pylint: disable=broad-except
           pass
         self._thread.join(timeout=0.05)
+      if self._thread.is_alive():
+        # blocked inside an engine call (e.g. a collective whose peers have stopped): give up on it rather than
+        # hang Graph.close(); the thread is a daemon and holds no lock of this object
+        warnings.warn("Dataset.close(): the prefetch thread did not stop within 30 s and was abandoned")
       self._thread = None
       self._queue = None
 

@@ -33,8 +33,10 @@ extern "C" {
 /* 1: graph / features / samplers / aggregators / partition helpers.  2 (additions only): host registration, shard
  * communicator, distributed store (+ replicas), request plans.  3 (additions only): memory-system probes,
  * induced sub-graph, conditional negative sampling.  4 (additions only): the speculation ledger of the distributed store
- * (glx_dist_ledger_*, glx_dist_confirm, GLX_ABORTED), glx_tune. */
-#define GLX_ABI_VERSION 4
+ * (glx_dist_ledger_*, glx_dist_confirm, GLX_ABORTED), glx_tune.  5 (additions only): glx_dist_sample_full_filtered,
+ * glx_dist_in_degrees, glx_dist_negative_create, glx_dist_negative_sample, glx_dist_random_walk_ex (all added during
+ * round 4 under 4), glx_graph_enable_default_weight. */
+#define GLX_ABI_VERSION 5
 
 /* Exported symbols: libglx.so is built with -fvisibility=hidden. */
 #if defined(__GNUC__)
@@ -148,6 +150,14 @@ GLX_API int glx_graph_build_ordered(int device, int64_t num_edges, const int64_t
 GLX_API void glx_graph_destroy(glx_graph* g);
 GLX_API int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* num_edges, int* weighted,
                    int* has_id_map, int* device);
+/* EdgeWeightSampler on an UNWEIGHTED edge type: the reference reads GLOBAL_FLAG(DefaultWeight) for every edge
+ * (MemoryEdgeStorage::GetWeight, memory_edge_storage.cc:97-103: an id beyond the empty weight array) and builds its
+ * alias row from that (edge_weight_sampler.cc:78-92) -- with the default 0.0 every prob is 0/0 = NaN, no slot takes its
+ * alias and a draw is idx = (int)(float)uniform[0, deg - 1) (alias_method.cc:117-121).  This gives the graph that
+ * constant weight per slot and the alias tables AliasMethod::Build makes of it (NaN rows included, bit for bit); it
+ * MUTATES the handle like glx_graph_enable_in_degree: call it once, before sampling from other threads.  A graph that
+ * has weights is left alone.  (ABI 5) */
+GLX_API int glx_graph_enable_default_weight(glx_graph* g, float default_weight, void* stream);
 /* Copy the device alias table out (parity checks against alias_method.cc:57-107). */
 GLX_API int glx_graph_export_alias(const glx_graph* g, float* prob, int32_t* alias, int ptr_kind,
                            void* stream);
@@ -779,7 +789,10 @@ GLX_API int glx_probe_bandwidth(int device, int kind, int64_t bytes, int64_t uni
  * product's default.  Names: "agg_mfma" (GLX_AGG_MFMA), "agg_unroll" (GLX_AGG_UNROLL), "agg_slices" (GLX_AGG_SLICES),
  * "agg_legacy" (GLX_AGG_LEGACY), "agg_segs" (GLX_AGG_SEGS), "agg_xcd_slices" (GLX_AGG_XCD_SLICES), "agg_occupancy"
  * (GLX_AGG_OCCUPANCY), "agg_store" (GLX_AGG_STORE).  Results are
- * bit-identical under every setting.  Unknown name: GLX_INVALID_ARGUMENT. */
+ * bit-identical under every setting.  Unknown name: GLX_INVALID_ARGUMENT.
+ * Test knobs of the side paths, same rules, -1 restores the default: "cond_sequential" (GLX_COND_SEQUENTIAL),
+ * "dist_no_bitmap" (GLX_DIST_NO_BITMAP), "filter_span_cap" (GLX_FILTER_SPAN_CAP), "filter_dedup_min_rows"
+ * (GLX_FILTER_DEDUP_MIN_ROWS). */
 GLX_API int glx_tune(const char* name, int32_t value);
 
 #ifdef __cplusplus

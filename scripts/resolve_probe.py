@@ -21,9 +21,9 @@ ids2 = n2.view(-1).contiguous()
 comm = glx.Comm.local(991, 0, 0, 1)
 for mode in ("bitmap", "hash", "bitmap", "hash"):
     if mode.startswith("hash"):
-        os.environ["GLX_DIST_NO_BITMAP"] = "1"
+        glx.tune("dist_no_bitmap", 1)
     else:
-        os.environ.pop("GLX_DIST_NO_BITMAP", None)
+        glx.tune("dist_no_bitmap", -1)
     st = glx.DistStore(comm, features=f)
     st.set_cache(hot)
     for _ in range(3):

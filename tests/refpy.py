@@ -9,9 +9,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE = os.path.join(ROOT, "graph-learn_amd", "python", "_refpy")
 PACKAGE = os.path.join(STAGE, "graphlearn")
 
-# The reference's own test files, relative to graphlearn/python/.  Not listed: nn/ (TensorFlow / torch_geometric
-# are not installed) and tests that need a second process of the RPC deployment.
-TEST_GLOBS = ["sampler/tests/test_*.py", "gsl/tests/test_*.py", "tests/test_*.py"]
+# The reference's own test files, relative to graphlearn/python/.  Not listed: nn/tf (TensorFlow is not installed).
+TEST_GLOBS = ["sampler/tests/test_*.py", "gsl/tests/test_*.py", "tests/test_*.py", "nn/pytorch/data/test/test_*.py"]
+
+# Tests that cannot pass on ANY engine, the reference's own included -- each with the defect in the reference's
+# sources.  A file maps to the test methods that ARE run (everything else in it is the defect), or to None when the
+# whole file is affected.
+_REPLICATE_OOB = (
+    "setUpClass selects REPLICATE padding (sampler/tests/test_sampling.py:114) and the test samples k = 6 (2-hop: 3) "
+    "neighbours of vertices with 1..4: under REPLICATE the alias samplers hand the padder `indices` of size k, which it "
+    "ignores, reading neighbors_[0..k) (core/operator/sampler/padder/replicate_padder.h:37-50) through an unchecked "
+    "io::Array::operator[] (core/graph/storage/types.h:73-75) -- out of bounds for every row shorter than k; the test "
+    "then requires each value read there to be a neighbour.  SURVEY 8(a) quirk 3: this engine default-fills instead of "
+    "reading past the row.")
+KNOWN_BROKEN_IN_REFERENCE = {
+    "sampler/tests/test_in_degree_neighbor_sampling.py": (
+        ["InDegreeNeighborSamplingTestCase.test_1hop_with_neighbor_missing"], _REPLICATE_OOB),
+    "sampler/tests/test_edge_weight_neighbor_sampling.py": (
+        ["EdgeWeightNeighborSamplingTestCase.test_1hop_with_neighbor_missing"], _REPLICATE_OOB),
+    "sampler/tests/test_subgraph_sampling.py": (
+        None, "the test calls g.subgraph_sampler(nbr_type=...) (test_subgraph_sampling.py:34) but Graph.subgraph_sampler "
+              "requires seed_type (python/graph.py:1059-1063): a TypeError inside the reference's own Python, before any "
+              "engine call."),
+}
 
 
 def staged():
@@ -32,8 +52,10 @@ def env():
     return e
 
 
-def run_file(rel, cwd, timeout=600, extra=()):
+def run_file(rel, cwd, timeout=600, tests=()):
     """One reference test file in its own process and its own working directory (the files write `.data_path/`
-    and `.tracker_path/` into the cwd), the way the reference's test_python_ut.sh runs them: one file, one process."""
-    cmd = [sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", os.path.join(PACKAGE, "python", rel)] + list(extra)
+    and `.tracker_path/` into the cwd), the way the reference's test_python_ut.sh runs them: `python <file>`, one
+    file per process (the files' __main__ blocks matter: gsl/tests/test_gsl_sampling.py raises the samplers' retry
+    count there).  `tests`: unittest names (Class.method) to run instead of the whole file."""
+    cmd = [sys.executable, os.path.join(PACKAGE, "python", rel), "-v"] + list(tests)
     return subprocess.run(cmd, cwd=cwd, env=env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True)

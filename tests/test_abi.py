@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(glx.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(L, s), "libglx.so does not export %s" % s
-    assert L.glx_abi_version() == 4
+    assert L.glx_abi_version() == 5
 
 
 def test_product_does_not_link_oracle():

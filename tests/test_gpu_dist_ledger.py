@@ -265,3 +265,37 @@ def test_ledger_fuzz_ragged_windows(world, case):
         lg.close()
         st.close()
     _run_ranks(P, body)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_random_walks_never_speculate_even_with_taught_positions(world, P):
+    """a DeepWalk step is a neighbor_count-1 sampling request, and position keys do not depend on the request
+    length -- so after two training hops have taught positions 0 and 1, a walk's first steps would have skipped their
+    count exchange on capacities learned from those hops.  glx.h promises walks always exchange counts: the steps run
+    with the ledger detached.  Walks equal the unpartitioned operator's, no call of the walk is counted as speculated,
+    every step blocks the host once, and the ledger keeps working for the training hops afterwards."""
+    whole, feats, dev = world["whole"], world["feats"], world["dev"]
+    gs, fs = world["shards"][P]
+    walk_len = 6
+
+    def body(r, comm):
+        st = glx.DistStore(comm, graph=gs[r], features=fs[r])
+        lg = glx.Ledger(0).attach(st)
+        for i in range(2):
+            assert _step(st, whole, feats, r, i, dev), (r, i)  # positions 0 and 1 are learned and speculated on
+        before = lg.stats()
+        assert before["learned"] == 2 and before["speculated"] == 2
+        seeds = _seeds(r, 9, dev)[:500].contiguous()
+        syncs0 = st.stats()["host_syncs"]
+        walks = st.random_walk(seeds, walk_len, seed=5, call_counter=100)
+        syncs1 = st.stats()["host_syncs"]
+        want = whole.random_walk(seeds, walk_len, seed=5, call_counter=100)
+        assert torch.equal(walks, want)
+        after = lg.stats()
+        assert after["speculated"] == before["speculated"] and after["learned"] == before["learned"], (before, after)
+        assert syncs1 - syncs0 == walk_len  # one count exchange per step
+        assert _step(st, whole, feats, r, 3, dev)  # the ledger is attached again: the hops speculate as before
+        assert lg.stats()["speculated"] == before["speculated"] + 2 and lg.stats()["aborted"] == 0
+        lg.close()
+        st.close()
+    _run_ranks(P, body)

@@ -181,8 +181,8 @@ def test_dist_aggregate_equals_unpartitioned(world, P, cache, monkeypatch):
     ("all": a negative id in the list; "partial_hashed": forced by GLX_DIST_NO_BITMAP)."""
     feats, dev = world["feats"], world["dev"]
     _, fs = world["shards"][P]
-    if cache == "partial_hashed":
-        monkeypatch.setenv("GLX_DIST_NO_BITMAP", "1")
+    # the knob is read from the environment once per process; glx.tune sets it at run time (-1 = default)
+    glx.tune("dist_no_bitmap", 1 if cache == "partial_hashed" else -1)
     hot = {"none": np.empty(0, np.int64), "partial": _hot(world, 400)[::-1].copy(), "partial_hashed": _hot(world, 400),
            "all": np.concatenate([np.arange(V, dtype=np.int64), [V + 5, -9]]),
            "all_ranked": np.concatenate([[V + 5], np.arange(V, dtype=np.int64)[::-1]])}[cache]

@@ -129,15 +129,15 @@ def test_chunked_requests_match_unchunked(orc, monkeypatch):
         ft, ff = FILTERS[kind]
         vals = make_values(rng, og, rows, ids, kind)
         for name in ALL_SAMPLERS[1:]:
-            monkeypatch.delenv("GLX_FILTER_SPAN_CAP", raising=False)
+            glx.tune("filter_span_cap", -1)
             whole = dev.sample_filtered(name, ids, 7, ft, ff, vals, seed=3, call_counter=9)
-            monkeypatch.setenv("GLX_FILTER_SPAN_CAP", "90")
+            glx.tune("filter_span_cap", 90)
             cut = dev.sample_filtered(name, ids, 7, ft, ff, vals, seed=3, call_counter=9)
             want = orc.sample_filtered(og, name, ids, 7, dict(type=ft, field=ff, values=vals), seed=3, call_counter=9)
             assert np.array_equal(cut[0], whole[0]) and np.array_equal(cut[1], whole[1]), (kind, name)
             assert np.array_equal(cut[0], want[0]) and np.array_equal(cut[1], want[1]), (kind, name)
         full = dev.sample_full_filtered(ids, 0, ft, ff, vals)
-        monkeypatch.delenv("GLX_FILTER_SPAN_CAP", raising=False)
+        glx.tune("filter_span_cap", -1)
         assert all(np.array_equal(a, b) for a, b in zip(full, dev.sample_full_filtered(ids, 0, ft, ff, vals)))
     dev.close()
 
@@ -275,16 +275,16 @@ def test_alias_samplers_share_one_table_per_vertex_and_value(orc, kind, monkeypa
                 flt = dict(type=ft, field=ff, values=vals)
                 want = orc.sample_filtered(og, name, ids, 6, flt, seed=31, call_counter=2, default_neighbor_id=-4,
                                            rng_rows=rr)
-                monkeypatch.setenv("GLX_FILTER_DEDUP_MIN_ROWS", "0")
+                glx.tune("filter_dedup_min_rows", 0)
                 per_row = dev.sample_filtered(name, ids, 6, ft, ff, vals, seed=31, call_counter=2,
                                               default_neighbor_id=-4, rng_rows=rr)
-                monkeypatch.setenv("GLX_FILTER_DEDUP_MIN_ROWS", "1")
+                glx.tune("filter_dedup_min_rows", 1)
                 if cap:
-                    monkeypatch.setenv("GLX_FILTER_SPAN_CAP", cap)
+                    glx.tune("filter_span_cap", int(cap))
                 shared = dev.sample_filtered(name, ids, 6, ft, ff, vals, seed=31, call_counter=2,
                                              default_neighbor_id=-4, rng_rows=rr)
-                monkeypatch.delenv("GLX_FILTER_SPAN_CAP", raising=False)
-                monkeypatch.delenv("GLX_FILTER_DEDUP_MIN_ROWS", raising=False)
+                glx.tune("filter_span_cap", -1)
+                glx.tune("filter_dedup_min_rows", -1)
                 assert np.array_equal(per_row[0], want[0]) and np.array_equal(per_row[1], want[1]), (name, kind)
                 assert np.array_equal(shared[0], want[0]) and np.array_equal(shared[1], want[1]), (name, kind, cap)
     dev.close()

@@ -68,7 +68,7 @@ def test_fuzz_filtered_samplers(seed, V, maxdeg, k, pad, ftype, ffield, retry, s
     indexed: with the id-sorted row index (id == value hit runs are read from it); shared: the alias samplers build one
     table per distinct (vertex, value) pair of the request instead of one per row."""
     import os
-    os.environ["GLX_FILTER_DEDUP_MIN_ROWS"] = "1" if shared else "0"
+    glx.tune("filter_dedup_min_rows", 1 if shared else 0)
     rng = np.random.default_rng(seed)
     deg = rng.integers(0, maxdeg + 1, V)
     deg[rng.random(V) < 0.2] = 0
@@ -103,7 +103,7 @@ def test_fuzz_filtered_samplers(seed, V, maxdeg, k, pad, ftype, ffield, retry, s
     want = ORC.sample_full_filtered(og, q, lim, flt, padding_mode=pad, default_neighbor_id=-11)
     assert all(np.array_equal(a, b) for a, b in zip(got, want)), (lim, pad, ftype, ffield)
     dev.close()
-    os.environ.pop("GLX_FILTER_DEDUP_MIN_ROWS", None)
+    glx.tune("filter_dedup_min_rows", -1)
 
 
 @settings(**COMMON)

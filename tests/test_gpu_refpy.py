@@ -11,18 +11,18 @@ import refpy
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not refpy.staged(), reason="reference python layer not staged (scripts/stage_refpy.py)")]
 
-# Files that cannot pass on ANY engine, with the reason (the reference's own defect, checked in its sources).
-KNOWN_BROKEN_IN_REFERENCE = {}
-
 FILES = refpy.test_files() if refpy.staged() else []
 
 
 @pytest.mark.parametrize("rel", FILES)
 def test_reference_python_test_file(rel, tmp_path):
-    if rel in KNOWN_BROKEN_IN_REFERENCE:
-        pytest.skip(KNOWN_BROKEN_IN_REFERENCE[rel])
-    out = refpy.run_file(rel, str(tmp_path))
+    run, reason = refpy.KNOWN_BROKEN_IN_REFERENCE.get(rel, ((), None))
+    if run is None:
+        pytest.skip("broken in the reference itself: " + reason)
+    out = refpy.run_file(rel, str(tmp_path), tests=run)
     assert out.returncode == 0, "%s\n%s" % (rel, out.stdout[-6000:])
+    # unittest's own verdict: "OK" (possibly with skips) after "Ran N tests"
+    assert "\nOK" in out.stdout and "FAILED" not in out.stdout, out.stdout[-3000:]
 
 
 def test_the_reference_layer_really_ran_on_this_engine(tmp_path):

@@ -157,8 +157,7 @@ def _fuzz_cases(n):
 def test_conditional_negative_sampler_is_bit_identical_to_the_oracle(trial, rows, monkeypatch):
     """rows: without `unique` the rows of a request are sampled one wave each against the first-insertion table
     (replayed row by row when a row drops the set); GLX_COND_SEQUENTIAL forces the one-wave walk `unique` always takes."""
-    if rows == "sequential":
-        monkeypatch.setenv("GLX_COND_SEQUENTIAL", "1")
+    glx.tune("cond_sequential", 1 if rows == "sequential" else -1)  # read from the environment once; set at run time
     rng = np.random.default_rng(100 + trial)
     U = int(rng.choice([1, 2, 7, 60, 300]))
     ncols = int(rng.integers(0, 4))
