@@ -523,6 +523,7 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
     llabs(src) % N (one ShardedStore per type: RCCL all-to-all per hop) and the two feature
     tables (9.2 GB + 1 GB) are replicated."""
     D, B0 = 256, args.batch
+    extras = n1_extras(args, world, sharded)
     sc = max(1, args.c5_scale)
     n_user, n_item, n_shop = 40_000_000 // sc, 9_000_000 // sc, 1_000_000 // sc
     spec = {"u-i": (n_user, n_item, 300_000_000 // sc, 10), "i-s": (n_item, n_shop, 100_000_000 // sc, 10),

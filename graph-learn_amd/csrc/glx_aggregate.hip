@@ -27,29 +27,103 @@ namespace {
 // order and hands id c to segment segment_ids[c] only while the sequence stays
 // non-decreasing and inside [0, num_segments); the first violation stalls the
 // cursor for good.  valid_len = index of that first violation.
-__global__ void glx_seg_valid_kernel(const int32_t* __restrict__ seg, int32_t n, int32_t num_segments,
-                                     int32_t* valid_len) {
-  int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int32_t cur = seg[i];
-  bool bad = cur < 0 || cur >= num_segments || (i > 0 && cur < seg[i - 1]);
-  if (bad) atomicMin(valid_len, i);
+//
+// One streaming pass over segment_ids does all of it (round 5; rounds 1-4 ran a validity pass and then one binary
+// search per segment -- 24 dependent loads each -- which cost 0.1 ms on the headline's 16.4 M ids, 5 % of the step):
+//   valid_len
+//   level = 0  when the request is what a dense sampler response implies -- segment s = ids [s f, (s + 1) f),
+//              f = n / num_segments -- and the reduce may use arithmetic segment bounds (no seg_start read);
+//           1  when the reduce must read seg_start;
+//           2  when the scan left seg_start incomplete and glx_seg_fixup_kernel fills it (the reduce reads it too)
+//   seg_start[s] = lower_bound(seg[0..valid_len), s), s in [0, num_segments]: position i writes it for every s in
+//                  (seg[i - 1], seg[i]] (the last position for the segments after seg[n - 1]).
+// A violation, or a run of more than kSegRunMax empty segments (one thread would write them all), leaves the rest
+// to the fix-up kernel: the old binary search, which exits at once otherwise.
+// valid_len and level live in two 64-bit words of a small per-stream buffer, each tagged with the call's epoch in its
+// high half and raised with atomicMax: a word whose tag is not this call's reads as "nothing raised", so no launch is
+// spent on resetting them (a launch costs as much as the whole scan of a small request).
+constexpr int32_t kSegRunMax = 64;
+
+struct SegState {
+  const unsigned long long* words;  // [0]: epoch << 32 | n - valid_len   [1]: epoch << 32 | level
+  uint32_t epoch;
+  int32_t floor_level;  // level the host already knows: 1 = the ids do not divide evenly, 2 = no ids at all
+};
+
+__device__ __forceinline__ int32_t seg_level(const SegState& st) {
+  const unsigned long long w = st.words[1];
+  const int32_t raised = (uint32_t)(w >> 32) == st.epoch ? (int32_t)(uint32_t)w : 0;
+  return raised > st.floor_level ? raised : st.floor_level;
+}
+__device__ __forceinline__ int32_t seg_valid_len(const SegState& st, int32_t n) {
+  const unsigned long long w = st.words[0];
+  return (uint32_t)(w >> 32) == st.epoch ? n - (int32_t)(uint32_t)w : n;
 }
 
-// seg_start[s] = lower_bound(seg[0..valid_len), s), s in [0, num_segments].
-__global__ void glx_seg_start_kernel(const int32_t* __restrict__ seg, const int32_t* valid_len,
-                                     int32_t num_segments, int32_t* __restrict__ seg_start) {
+__global__ void glx_seg_reset_kernel(unsigned long long* words) {  // captured launches only (see prepare_segments)
+  words[0] = 0;
+  words[1] = 0;
+}
+
+__global__ __launch_bounds__(256) void glx_seg_scan_kernel(const int32_t* __restrict__ seg, int32_t n, int32_t num_segments,
+                                                           int32_t f, unsigned long long* __restrict__ words, uint32_t epoch,
+                                                           int32_t* __restrict__ seg_start) {
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  int32_t v[4];
+  const int32_t m = (n - i0) < 4 ? (int32_t)(n - i0) : 4;
+  if (m == 4 && (reinterpret_cast<uintptr_t>(seg) & 15) == 0) {
+    const int4 q = *reinterpret_cast<const int4*>(seg + i0);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+    for (int j = 0; j < 4; ++j) v[j] = j < m ? seg[i0 + j] : 0;
+  }
+  int32_t prev = i0 > 0 ? seg[i0 - 1] : -1;
+  // the id before this thread's is itself out of range: a violation at or before it (its own thread reports it), so
+  // nothing from here on belongs to the request -- and `prev` is no segment to count on from
+  if (i0 > 0 && (prev < 0 || prev >= num_segments)) return;
+  int32_t quo = f > 0 ? (int32_t)(i0 / f) : 0, rem = f > 0 ? (int32_t)(i0 % f) : 0;  // i / f and i % f, carried along
+  bool nonuniform = false, incomplete = false;
+  int32_t bad_at = n;
+  for (int j = 0; j < m; ++j) {
+    const int32_t i = (int32_t)i0 + j, cur = v[j];
+    if (cur < 0 || cur >= num_segments || cur < prev) {  // prev == -1 before the first id
+      bad_at = i;
+      break;
+    }
+    if (cur != prev) {
+      if (cur - prev > kSegRunMax) incomplete = true;
+      else for (int32_t s = prev + 1; s <= cur; ++s) seg_start[s] = i;
+    }
+    if (f > 0) {
+      nonuniform |= cur != quo;
+      if (++rem == f) { rem = 0; ++quo; }
+    }
+    prev = cur;
+  }
+  if (bad_at == n && i0 + m == n) {  // the last ids: the segments after the last one used start (and end) at n
+    if (num_segments - prev > kSegRunMax) incomplete = true;
+    else for (int32_t s = prev + 1; s <= num_segments; ++s) seg_start[s] = n;
+  }
+  const unsigned long long tag = (unsigned long long)epoch << 32;
+  if (bad_at < n) atomicMax(&words[0], tag | (uint32_t)(n - bad_at));  // the largest n - i = the first violation
+  const int32_t level = (incomplete || bad_at < n) ? 2 : (nonuniform ? 1 : 0);
+  if (level) atomicMax(&words[1], tag | (uint32_t)level);
+}
+
+// seg_start[s] = lower_bound(seg[0..valid_len), s) for every s -- only when the scan left the table incomplete.
+__global__ void glx_seg_fixup_kernel(const int32_t* __restrict__ seg, SegState st, int32_t n, int32_t num_segments,
+                                     int32_t* __restrict__ seg_start) {
+  if (seg_level(st) != 2) return;
   int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > num_segments) return;
-  int32_t lo = 0, hi = *valid_len;
+  int32_t lo = 0, hi = seg_valid_len(st, n);
   while (lo < hi) {
     int32_t mid = lo + ((hi - lo) >> 1);
     if (seg[mid] < s) lo = mid + 1; else hi = mid;
   }
   seg_start[s] = lo;
 }
-
-__global__ void glx_set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
 
 // raw id -> feature row (int32, -1 = unknown id) for the hashed id map.
 __global__ void glx_rows_kernel(GlxIdMap map, const int64_t* __restrict__ ids, int64_t n,
@@ -80,6 +154,7 @@ struct AggArgs {
   const int64_t* node_ids;   // raw ids (dense map) ...
   const int32_t* rows;       // ... or pre-translated rows (hashed map / multi-source); one is null
   const int32_t* seg_start;  // [num_segments + 1], or null: uniform segments of `fanout` ids
+  SegState seg_state;        // with seg_start: level 0 -> the segments ARE uniform (`fanout` ids each), seg_start is not read
   float* emb_out;
   int32_t* cnt_out;
   int64_t num_rows;
@@ -128,7 +203,7 @@ __global__ __launch_bounds__(256) void glx_aggregate_kernel(AggArgs a) {
   const int c = threadIdx.x & (G - 1);
   if (gid >= a.num_segments) return;
   int32_t s0, s1;
-  if (a.seg_start) {
+  if (a.seg_start && seg_level(a.seg_state) != 0) {
     s0 = a.seg_start[gid];
     s1 = a.seg_start[gid + 1];
   } else {  // a dense sampler response: segment gid = ids [gid * fanout, (gid + 1) * fanout)
@@ -288,11 +363,13 @@ __global__ __launch_bounds__(256) void glx_aggregate_grp_kernel(AggArgs a) {
   if (G == 64) seg_first = __builtin_amdgcn_readfirstlane(seg_first);
   const int32_t seg_last = (a.num_segments - seg_first) < S ? a.num_segments : seg_first + S;
   // segment boundaries: arithmetic for a dense sampler response, else lane j of the group holds start[seg_first + j]
+  // (an explicit segment_ids tensor that spells out the dense response -- flags[1] == 0 -- takes the arithmetic too)
+  const bool use_starts = a.seg_start != nullptr && seg_level(a.seg_state) != 0;
   int32_t mystart = 0;
-  if (a.seg_start) mystart = a.seg_start[seg_first + (c <= seg_last - seg_first ? c : 0)];
+  if (use_starts) mystart = a.seg_start[seg_first + (c <= seg_last - seg_first ? c : 0)];
   const int32_t starts[1] = {mystart};
-  const int32_t pos_first = a.seg_start ? agg_chunk_get<G, 1>(starts, 0) : seg_first * a.fanout;
-  const int32_t pos_end = a.seg_start ? agg_chunk_get<G, 1>(starts, seg_last - seg_first) : seg_last * a.fanout;
+  const int32_t pos_first = use_starts ? agg_chunk_get<G, 1>(starts, 0) : seg_first * a.fanout;
+  const int32_t pos_end = use_starts ? agg_chunk_get<G, 1>(starts, seg_last - seg_first) : seg_last * a.fanout;
   const int32_t col_lo = a.col0 + slice * a.ncols;
   const int32_t col_end = col_lo + a.ncols;
   for (int32_t col_pass = col_lo; col_pass < col_end; col_pass += G * VEC) {
@@ -304,7 +381,7 @@ __global__ __launch_bounds__(256) void glx_aggregate_grp_kernel(AggArgs a) {
     agg_chunk_load<G, IDR>(a, chunk_base, pos_end, c, myrow);
     for (int32_t sg = seg_first; sg < seg_last; ++sg) {
       int32_t s0, s1;
-      if (a.seg_start) {
+      if (use_starts) {
         s0 = agg_chunk_get<G, 1>(starts, sg - seg_first);
         s1 = agg_chunk_get<G, 1>(starts, sg - seg_first + 1);
       } else {
@@ -680,39 +757,90 @@ int run_aggregate(AggArgs& a, int op, const int32_t* d_seg, int32_t num_ids, hip
 
 // Segment bookkeeping shared by the single-table and the multi-source entry: fills
 // a.seg_start (or a.fanout for uniform segments) from scratch laid out by the caller.
-// scratch = valid_len (1) + seg_start (Sg + 1).
-void prepare_segments(AggArgs& a, const int32_t* d_seg, int32_t num_ids, int32_t num_segments, int32_t* scratch,
-                      hipStream_t s) {
+// scratch = seg_start (Sg + 1).
+namespace {
+// Two 64-bit words per (calling thread, device, stream) -- the same scope as the scratch workspace, so that host
+// threads that share a stream (the default one, say) do not raise each other's words -- zeroed when made, freed with the
+// thread.  A recycled stream handle finds words tagged with an older epoch, which read as "nothing raised".
+struct SegWords {
+  std::vector<std::tuple<int, hipStream_t, unsigned long long*>> bufs;
+  ~SegWords() {
+    for (auto& e : bufs) {  // best effort: at process exit the runtime may already be gone
+      if (hipSetDevice(std::get<0>(e)) == hipSuccess) (void)hipFree(std::get<2>(e));
+    }
+    (void)hipGetLastError();
+  }
+};
+thread_local SegWords g_seg_words;
+std::atomic<uint32_t> g_seg_epoch{1};
+
+int seg_words_for(hipStream_t s, unsigned long long** out) {
+  int dev = 0;
+  GLX_HIP(hipGetDevice(&dev));
+  for (auto& e : g_seg_words.bufs) {
+    if (std::get<0>(e) == dev && std::get<1>(e) == s) {
+      *out = std::get<2>(e);
+      return GLX_OK;
+    }
+  }
+  unsigned long long* p = nullptr;
+  GLX_HIP(hipMalloc(&p, 256));
+  GLX_HIP(hipMemsetAsync(p, 0, 256, s));  // ordered before the first scan on this stream
+  g_seg_words.bufs.emplace_back(dev, s, p);
+  *out = p;
+  return GLX_OK;
+}
+}  // namespace
+
+int prepare_segments(AggArgs& a, const int32_t* d_seg, int32_t num_ids, int32_t num_segments, int32_t* scratch,
+                     hipStream_t s) {
+  a.fanout = num_segments > 0 ? num_ids / num_segments : 0;
+  memset(&a.seg_state, 0, sizeof(a.seg_state));
   if (d_seg == nullptr) {  // uniform segments: nothing to derive, nothing to read
     a.seg_start = nullptr;
-    a.fanout = num_segments > 0 ? num_ids / num_segments : 0;
-    return;
+    return GLX_OK;
   }
-  int32_t* valid_len = scratch;
-  int32_t* seg_start = scratch + 1;
-  glx_set_i32_kernel<<<1, 1, 0, s>>>(valid_len, num_ids);
+  int32_t* seg_start = scratch;
+  unsigned long long* words = nullptr;
+  int rc = seg_words_for(s, &words);
+  if (rc != GLX_OK) return rc;
+  // uniform segments are possible when the ids divide evenly; the scan then checks seg[i] == i / fanout
+  const int32_t f = (num_segments > 0 && num_ids > 0 && num_ids % num_segments == 0) ? num_ids / num_segments : 0;
+  SegState st;
+  st.words = words;
+  st.epoch = g_seg_epoch.fetch_add(1, std::memory_order_relaxed);
+  if (st.epoch == 0) st.epoch = g_seg_epoch.fetch_add(1, std::memory_order_relaxed);  // 0 tags the zeroed words
+  st.floor_level = num_ids == 0 ? 2 : (f > 0 ? 0 : 1);
+  // A captured launch is replayed with the SAME epoch: the words a replay raised would still carry it in the next
+  // replay.  Captured launches therefore reset the words first (one more node in the graph).
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+    glx_seg_reset_kernel<<<1, 1, 0, s>>>(words);
+  }
   if (num_ids > 0) {
-    glx_seg_valid_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(d_seg, num_ids, num_segments, valid_len);
+    glx_seg_scan_kernel<<<(unsigned)(((int64_t)num_ids + 1023) / 1024), 256, 0, s>>>(d_seg, num_ids, num_segments, f, words,
+                                                                                   st.epoch, seg_start);
   }
-  glx_seg_start_kernel<<<(unsigned)((num_segments + 1 + 255) / 256), 256, 0, s>>>(d_seg, valid_len, num_segments,
-                                                                                   seg_start);
+  glx_seg_fixup_kernel<<<(unsigned)((num_segments + 1 + 255) / 256), 256, 0, s>>>(d_seg, st, num_ids, num_segments, seg_start);
   a.seg_start = seg_start;
-  a.fanout = 0;
+  a.seg_state = st;
+  return GLX_OK;
 }
 
 int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const int32_t* d_seg,
                      int32_t num_ids, int32_t num_segments, float default_attr, float* d_emb,
                      int32_t* d_cnt, hipStream_t s) {
-  // scratch: valid_len (1) + seg_start (Sg+1) [+ rows (N) for hashed ids]
+  // scratch: seg_start (Sg+1) [+ rows (N) for hashed ids]
   const bool hashed = f->idmap.keys != nullptr;
-  const size_t n_i32 = 1 + (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
+  const size_t n_i32 = (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
   int32_t* scratch = nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s, 1);
   if (rc != GLX_OK) return rc;
-  int32_t* rows = hashed ? scratch + 1 + num_segments + 1 : nullptr;
+  int32_t* rows = hashed ? scratch + num_segments + 1 : nullptr;
   AggArgs a;
   memset(&a, 0, sizeof(a));
-  prepare_segments(a, d_seg, num_ids, num_segments, scratch, s);
+  rc = prepare_segments(a, d_seg, num_ids, num_segments, scratch, s);
+  if (rc != GLX_OK) return rc;
   if (hashed && num_ids > 0) {
     glx_rows_kernel<<<(unsigned)((num_ids + 255) / 256), 256, 0, s>>>(f->map(), d_ids, num_ids, rows);
   }
@@ -800,11 +928,12 @@ int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, i
                                const int32_t* d_seg, int32_t num_ids, int32_t num_segments, float default_attr,
                                float* d_emb, int32_t* d_cnt, hipStream_t s) {
   int32_t* scratch = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), ((size_t)num_segments + 2) * sizeof(int32_t), s, 1);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), ((size_t)num_segments + 1 + 2) * sizeof(int32_t), s, 1);
   if (rc != GLX_OK) return rc;
   AggArgs a;
   memset(&a, 0, sizeof(a));
-  prepare_segments(a, d_seg, num_ids, num_segments, scratch, s);
+  rc = prepare_segments(a, d_seg, num_ids, num_segments, scratch, s);
+  if (rc != GLX_OK) return rc;
   const GlxRowSource none{nullptr, dim, 0, 0};
   const GlxRowSource& s0 = nsrc > 0 ? src[0] : none;
   const GlxRowSource& s1 = nsrc > 1 ? src[1] : none;

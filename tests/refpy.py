@@ -46,6 +46,12 @@ def test_files():
     return [os.path.relpath(p, os.path.join(PACKAGE, "python")) for p in out if not p.endswith("sampler/tests/test_sampling.py")]
 
 
+def defines_tests(rel):
+    """Does the file hold a test method outside a comment?"""
+    with open(os.path.join(PACKAGE, "python", rel)) as f:
+        return any(line.lstrip().startswith("def test") for line in f)
+
+
 def env():
     e = dict(os.environ)
     e["PYTHONPATH"] = STAGE + (os.pathsep + e["PYTHONPATH"] if e.get("PYTHONPATH") else "")

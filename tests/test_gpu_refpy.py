@@ -21,8 +21,9 @@ def test_reference_python_test_file(rel, tmp_path):
         pytest.skip("broken in the reference itself: " + reason)
     out = refpy.run_file(rel, str(tmp_path), tests=run)
     assert out.returncode == 0, "%s\n%s" % (rel, out.stdout[-6000:])
-    # unittest's own verdict: "OK" (possibly with skips) after "Ran N tests"
-    assert "\nOK" in out.stdout and "FAILED" not in out.stdout, out.stdout[-3000:]
+    if refpy.defines_tests(rel):  # a few files are base classes or entirely commented out (test_random_node_subgraph_sampling.py)
+        # unittest's own verdict: "OK" (possibly with skips) after "Ran N tests"
+        assert "\nOK" in out.stdout and "FAILED" not in out.stdout, out.stdout[-3000:]
 
 
 def test_the_reference_layer_really_ran_on_this_engine(tmp_path):

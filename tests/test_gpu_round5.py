@@ -46,3 +46,68 @@ def test_edge_weight_sampler_on_an_unweighted_graph_is_the_reference_with_defaul
     assert dev.enable_default_weight(9.0) is dev  # a second call is a no-op
     prob2, _ = dev.export_alias()
     assert np.array_equal(prob2.view(np.uint32), prob.view(np.uint32))
+
+
+def _segment_cases(rng):
+    """(node count, segment count, segment_ids) shapes that exercise every branch of the one-pass bookkeeping."""
+    cases = []
+    for n, sg in ((0, 0), (0, 5), (1, 1), (7, 3), (4096, 512), (5000, 500), (100000, 10000), (1023, 1), (3, 4000)):
+        if sg == 0:
+            cases.append((n, sg, np.zeros(n, np.int32), "empty"))
+            continue
+        if n % sg == 0 and n > 0:
+            f = n // sg
+            cases.append((n, sg, (np.arange(n) // f).astype(np.int32), "uniform spelled out"))
+            swapped = (np.arange(n) // f).astype(np.int32)
+            if n > f + 1 and sg > 1:
+                swapped[f - 1] = 1  # same count per segment on average, but not the dense layout
+                cases.append((n, sg, swapped, "divisible but not uniform"))
+        ragged = np.sort(rng.integers(0, sg, n)).astype(np.int32)
+        cases.append((n, sg, ragged, "ragged"))
+        if n > 2:
+            gaps = np.sort(rng.choice(sg, min(sg, 3), replace=False))[rng.integers(0, min(sg, 3), n)]
+            cases.append((n, sg, np.sort(gaps).astype(np.int32), "long runs of empty segments"))
+            bad = ragged.copy()
+            at = int(rng.integers(1, n))
+            bad[at] = -1 if at % 3 == 0 else (sg if at % 3 == 1 else max(int(bad[at - 1]) - 1, -5))
+            cases.append((n, sg, bad, "violation at %d" % at))
+            neg = ragged.copy()
+            neg[n // 2] = -2  # the ids after it are in range again: nothing of them may be counted (or written anywhere)
+            cases.append((n, sg, neg, "a negative id in the middle"))
+            late = np.full(n, sg - 1, np.int32)  # every id in the LAST segment: everything before it is empty
+            cases.append((n, sg, late, "all in the last segment"))
+            early = np.zeros(n, np.int32)
+            cases.append((n, sg, early, "all in the first segment"))
+    return cases
+
+
+@pytest.mark.parametrize("dim", [256, 64, 7])
+def test_explicit_segment_ids_one_pass_bookkeeping_equals_the_oracle(dim):
+    """AggregatingRequest's cursor (aggregating_request.cc:86-105) over an explicit segment_ids tensor: the one-pass
+    device bookkeeping (validity, segment starts, 'this is just the dense layout' detection, the fix-up for violations
+    and for long runs of empty segments) gives the oracle's embeddings and counts bit for bit, for every aggregator, with
+    device and host pointers -- and the same as segment_ids = None when the tensor spells out the dense layout."""
+    import torch
+    orc = Oracle()
+    rng = np.random.default_rng(dim)
+    V = 3000
+    X = rng.standard_normal((V, dim)).astype(np.float32)
+    feats = glx.Features(X)
+    dev = torch.device("cuda", 0)
+    for n, sg, seg, what in _segment_cases(rng):
+        ids = rng.integers(-2, V + 2, n).astype(np.int64)
+        for name in glx.AGGREGATOR_IDS:
+            want_e, want_c = orc.aggregate(X, name, ids, seg, sg, default_attr=0.25)
+            got_e, got_c = feats.aggregate(name, ids, seg, sg, default_attr=0.25)
+            assert np.array_equal(got_c, want_c), (what, name, n, sg)
+            assert np.array_equal(got_e.view(np.uint32), want_e.view(np.uint32)), (what, name, n, sg)
+        if n > 0:
+            t_e, t_c = feats.aggregate("MeanAggregator", torch.from_numpy(ids).to(dev), torch.from_numpy(seg).to(dev), sg,
+                                       default_attr=0.25)
+            want_e, want_c = orc.aggregate(X, "MeanAggregator", ids, seg, sg, default_attr=0.25)
+            assert np.array_equal(t_c.cpu().numpy(), want_c) and np.array_equal(t_e.cpu().numpy().view(np.uint32), want_e.view(np.uint32)), what
+        if what == "uniform spelled out":
+            e0, c0 = feats.aggregate("SumAggregator", ids, None, sg, default_attr=0.25)
+            e1, c1 = feats.aggregate("SumAggregator", ids, seg, sg, default_attr=0.25)
+            assert np.array_equal(c0, c1) and np.array_equal(e0.view(np.uint32), e1.view(np.uint32))
+    feats.close()
