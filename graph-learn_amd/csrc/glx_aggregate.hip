@@ -831,7 +831,7 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
                      int32_t num_ids, int32_t num_segments, float default_attr, float* d_emb,
                      int32_t* d_cnt, hipStream_t s) {
   // scratch: seg_start (Sg+1) [+ rows (N) for hashed ids]
-  const bool hashed = f->idmap.keys != nullptr;
+  const bool hashed = f->idmap.any();  // raw ids are not rows: translate first (a table lookup, or arithmetic)
   const size_t n_i32 = (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
   int32_t* scratch = nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s, 1);
@@ -984,6 +984,7 @@ extern "C" int glx_tune(const char* name, int32_t value) {
     else if (strcmp(name, "dist_no_bitmap") == 0) side = &sk.dist_no_bitmap;
     else if (strcmp(name, "filter_span_cap") == 0) side = &sk.filter_span_cap;
     else if (strcmp(name, "filter_dedup_min_rows") == 0) side = &sk.filter_dedup_min_rows;
+    else if (strcmp(name, "idmap_hash_only") == 0) side = &sk.idmap_hash_only;
     GLX_REQUIRE(side != nullptr, "unknown knob '%s'", name);
     side->store(value, std::memory_order_relaxed);
     return GLX_OK;
@@ -995,6 +996,11 @@ extern "C" int glx_tune(const char* name, int32_t value) {
 extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, const float* X,
                                    const int64_t* ids, int ptr_kind, void* stream,
                                    glx_features** out) {
+  return glx_features_create_impl(device, num_rows, dim, X, ids, ptr_kind, stream, true, out);
+}
+
+int glx_features_create_impl(int device, int64_t num_rows, int32_t dim, const float* X, const int64_t* ids, int ptr_kind,
+                             void* stream, bool allow_arithmetic_ids, glx_features** out) {
   GLX_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   GLX_REQUIRE(num_rows >= 0 && dim > 0, "bad shape [%lld, %d]", (long long)num_rows, dim);
@@ -1053,7 +1059,9 @@ extern "C" int glx_features_create(int device, int64_t num_rows, int32_t dim, co
       if (e == hipSuccess) e = hipMemcpyAsync(tmp_ids, ids, (size_t)num_rows * sizeof(int64_t), hipMemcpyHostToDevice, s);
       d_ids = tmp_ids;
     }
-    if (e == hipSuccess) rc = glx_idmap_build(d_ids, num_rows, &f->idmap, s);
+    if (e == hipSuccess) {
+      rc = allow_arithmetic_ids ? glx_idmap_build_auto(d_ids, num_rows, &f->idmap, s) : glx_idmap_build(d_ids, num_rows, &f->idmap, s);
+    }
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (tmp_ids) (void)hipFree(tmp_ids);
@@ -1102,7 +1110,7 @@ extern "C" int glx_features_info(const glx_features* f, int64_t* num_rows, int32
   GLX_REQUIRE(f != nullptr, "features is NULL");
   if (num_rows) *num_rows = f->num_rows;
   if (dim) *dim = f->dim;
-  if (has_id_map) *has_id_map = f->idmap.keys != nullptr;
+  if (has_id_map) *has_id_map = f->idmap.any();
   if (device) *device = f->device;
   return GLX_OK;
 }

@@ -109,6 +109,11 @@ struct GlxIdMap {
   const int32_t* vals;  // [cap]
   uint64_t mask;        // cap - 1 (cap is a power of two)
   int64_t num_rows;
+  // step > 0 (keys == nullptr): the ids are the arithmetic progression base, base + step, ... -- what the reference's
+  // ownership rule llabs(id) % P leaves on shard r of a dense id space (r, r + P, r + 2P, ...).  The row is then
+  // arithmetic: no table, no random access per lookup (round 5: the partitioned aggregation resolves 18 M ids per
+  // step against the own shard's map; hashed, that was a quarter of the step's memory traffic at world size 1).
+  int64_t base, step;
 };
 
 __host__ __device__ __forceinline__ uint64_t glx_mix64(uint64_t x) {
@@ -119,7 +124,15 @@ __host__ __device__ __forceinline__ uint64_t glx_mix64(uint64_t x) {
 }
 
 __device__ __forceinline__ int64_t glx_row_of(const GlxIdMap& m, int64_t id) {
-  if (m.keys == nullptr) return (id >= 0 && id < m.num_rows) ? id : -1;
+  if (m.keys == nullptr) {
+    if (m.step > 0) {
+      const int64_t d = id - m.base;
+      if (id < m.base || d < 0) return -1;  // (d < 0: the subtraction wrapped)
+      const int64_t q = d / m.step;
+      return (q * m.step == d && q < m.num_rows) ? q : -1;
+    }
+    return (id >= 0 && id < m.num_rows) ? id : -1;
+  }
   if (id == GLX_EMPTY_KEY) return -1;
   uint64_t h = glx_mix64((uint64_t)id) & m.mask;
   while (true) {
@@ -134,9 +147,14 @@ struct GlxIdMapStorage {
   int64_t* keys = nullptr;
   int32_t* vals = nullptr;
   uint64_t cap = 0;
+  int64_t base = 0, step = 0;  // step > 0: arithmetic ids, no table (GlxIdMap)
+  bool any() const { return keys != nullptr || step > 0; }  // false: raw id v IS row v
+  GlxIdMap view(int64_t num_rows) const { return GlxIdMap{keys, vals, cap - 1, num_rows, base, step}; }
 };
 // Builds the table for ids[num_rows] (device pointer) on `s`.
 int glx_idmap_build(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out, hipStream_t s);
+// The same, but ids that form an arithmetic progression with a positive step get no table (synchronises `s`).
+int glx_idmap_build_auto(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out, hipStream_t s);
 // glx_sample_ex on device pointers where request row i draws from stream d_rows[i] AND answers into output row d_rows[i].
 int glx_sample_scatter_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rows,
                               int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
@@ -145,6 +163,11 @@ int glx_sample_scatter_device(const glx_graph* g, int sampler, const int64_t* d_
 int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert,
                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s);
 void glx_idmap_free(GlxIdMapStorage* m);
+struct glx_features;
+// glx_features_create; allow_arithmetic_ids = false keeps a hash table whatever the ids look like (the hot-row replica
+// of a distributed store packs that table into its own slots).
+int glx_features_create_impl(int device, int64_t num_rows, int32_t dim, const float* X, const int64_t* ids, int ptr_kind,
+                             void* stream, bool allow_arithmetic_ids, glx_features** out);
 
 // ---------------------------------------------------------------- handles ---
 struct GlxAdj {  // one CSR slot: a single 16-byte gather per draw
@@ -178,6 +201,7 @@ struct GlxSideKnobs {
   std::atomic<int64_t> dist_no_bitmap{-1};        // GLX_DIST_NO_BITMAP (set = 1): the hot-row replica's membership test as a hash map
   std::atomic<int64_t> filter_span_cap{-1};       // GLX_FILTER_SPAN_CAP: total degree per chunk of a filtered request
   std::atomic<int64_t> filter_dedup_min_rows{-1}; // GLX_FILTER_DEDUP_MIN_ROWS: rows from which (vertex, value) pairs share a table; 0 disables
+  std::atomic<int64_t> idmap_hash_only{-1};       // GLX_IDMAP_HASH_ONLY (set = 1): feature tables keep a hash table even for arithmetic ids (A/B)
 };
 GlxSideKnobs& glx_side_knobs();  // glx_graph.hip
 
@@ -198,7 +222,7 @@ struct glx_graph {
   GlxEwRec* ew;           // [E] packed EdgeWeight records, or nullptr (edge ids beyond int32)
   int64_t* ts;            // [E] GetEdgeTimestamp of every slot (timestamp filters), or nullptr
   GlxIdMapStorage idmap;
-  GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
+  GlxIdMap map() const { return idmap.view(num_rows); }
 };
 
 struct glx_features {
@@ -210,7 +234,7 @@ struct glx_features {
   float* X;  // [V, stride] row-major, base 256-byte aligned
   bool owns_x;
   GlxIdMapStorage idmap;
-  GlxIdMap map() const { return GlxIdMap{idmap.keys, idmap.vals, idmap.cap - 1, num_rows}; }
+  GlxIdMap map() const { return idmap.view(num_rows); }
 };
 
 // AliasMethod::Build (alias_method.cc:57-107) for ONE distribution of `count` weights,

@@ -1745,7 +1745,7 @@ extern "C" int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_gr
   if (replica != nullptr) {
     GLX_REQUIRE(replica->device == st->device, "the replica lives on device %d, the store on %d", replica->device,
                 st->device);
-    GLX_REQUIRE(replica->idmap.keys != nullptr, "a graph replica needs its vertex ids (glx_graph_build with ids)");
+    GLX_REQUIRE(replica->idmap.any(), "a graph replica needs its vertex ids (glx_graph_build with ids)");
     // the request partition gets one more bucket for the replica (glx_partition_divert: at most 64 buckets); refuse
     // here, where it is a configuration error, not inside a collective sample call
     GLX_REQUIRE(st->world + 1 <= 64, "a graph replica needs world size <= 63 (the request partition has 64 buckets), got %d",
@@ -2559,8 +2559,8 @@ extern "C" int glx_dist_store_set_cache(glx_dist_store* st, const int64_t* hot_i
   GLX_HIP(hipStreamSynchronize(s));
   (void)hipFree(table.p);
   table.p = nullptr;
-  rc = glx_features_create(st->device, n, dim, table_sorted.as<float>(), sorted_masked.as<int64_t>(), GLX_PTR_DEVICE, s,
-                           &st->cache);
+  rc = glx_features_create_impl(st->device, n, dim, table_sorted.as<float>(), sorted_masked.as<int64_t>(), GLX_PTR_DEVICE, s,
+                                false, &st->cache);
   if (rc != GLX_OK) return rc;
   // from here on a failure must not leave a half-installed replica behind: st->cache set while cache_slots (or the
   // bitmap) is missing would have the next resolve kernel dereference null slots

@@ -37,6 +37,7 @@ GlxSideKnobs& glx_side_knobs() {
     if (getenv("GLX_DIST_NO_BITMAP")) k.dist_no_bitmap = 1;
     if (const char* e = getenv("GLX_FILTER_SPAN_CAP")) k.filter_span_cap = atoll(e);
     if (const char* e = getenv("GLX_FILTER_DEDUP_MIN_ROWS")) k.filter_dedup_min_rows = atoll(e);
+    if (getenv("GLX_IDMAP_HASH_ONLY")) k.idmap_hash_only = 1;
   });
   return k;
 }
@@ -460,12 +461,53 @@ int glx_idmap_build(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out
   return GLX_OK;
 }
 
+// flag[0] |= 1 when ids is not ids[0] + i * (ids[1] - ids[0])
+__global__ void glx_idmap_affine_kernel(const int64_t* __restrict__ ids, int64_t n, int* flag) {
+  const int64_t base = ids[0], step = ids[1] - ids[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (ids[i] != base + i * step) {
+      *flag = 1;
+      return;
+    }
+  }
+}
+
+int glx_idmap_build_auto(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage* out, hipStream_t s) {
+  if (num_rows >= 2 && glx_side_knobs().idmap_hash_only.load(std::memory_order_relaxed) <= 0) {
+    int64_t first[2] = {0, 0};
+    GLX_HIP(hipMemcpyAsync(first, d_ids, 16, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+    const int64_t step = first[1] - first[0];
+    // (the last id must not overflow: base + (n - 1) * step computed in 128 bits)
+    const __int128 last = (__int128)first[0] + (__int128)(num_rows - 1) * (__int128)step;
+    if (step > 0 && first[1] > first[0] && last <= (__int128)INT64_MAX) {
+      GlxTemp flag;
+      GLX_HIP(hipMalloc(&flag.p, sizeof(int)));
+      GLX_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+      glx_idmap_affine_kernel<<<(unsigned)((num_rows + 255) / 256 < 4096 ? (num_rows + 255) / 256 : 4096), 256, 0, s>>>(d_ids, num_rows, flag.as<int>());
+      int h = 1;
+      GLX_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      GLX_HIP(hipStreamSynchronize(s));
+      if (h == 0) {
+        out->keys = nullptr;
+        out->vals = nullptr;
+        out->cap = 0;
+        out->base = first[0];
+        out->step = step;
+        return GLX_OK;
+      }
+    }
+  }
+  return glx_idmap_build(d_ids, num_rows, out, s);
+}
+
 void glx_idmap_free(GlxIdMapStorage* m) {
   if (m->keys) (void)hipFree(m->keys);
   if (m->vals) (void)hipFree(m->vals);
   m->keys = nullptr;
   m->vals = nullptr;
   m->cap = 0;
+  m->base = m->step = 0;
 }
 
 // ------------------------------------------------------------ CSR kernels --
@@ -745,7 +787,7 @@ extern "C" int glx_graph_info(const glx_graph* g, int64_t* num_rows, int64_t* nu
   if (num_rows) *num_rows = g->num_rows;
   if (num_edges) *num_edges = g->num_edges;
   if (weighted) *weighted = g->alias != nullptr;
-  if (has_id_map) *has_id_map = g->idmap.keys != nullptr;
+  if (has_id_map) *has_id_map = g->idmap.any();
   if (device) *device = g->device;
   return GLX_OK;
 }

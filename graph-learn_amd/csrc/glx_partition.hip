@@ -21,7 +21,7 @@ __device__ __forceinline__ int32_t shard_of(int64_t id, int32_t P) {
 // With a divert map the request has one bucket more: ids the map knows go to bucket P - 1 (rows a local replica
 // serves, glx_dist.hip), everything else to llabs(id) % (P - 1).
 __device__ __forceinline__ int32_t bucket_of(int64_t id, int32_t P, const GlxIdMap& divert) {
-  if (divert.keys == nullptr) return shard_of(id, P);
+  if (divert.keys == nullptr && divert.step == 0) return shard_of(id, P);
   return glx_row_of(divert, id) >= 0 ? P - 1 : shard_of(id, P - 1);
 }
 
@@ -211,7 +211,7 @@ extern "C" int glx_partition(int device, const int64_t* ids, int64_t n, int32_t 
 int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert,
                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s) {
   GLX_REQUIRE(num_shards >= 1 && num_shards + 1 <= kMaxShards, "num_shards must be in [1, %d)", kMaxShards);
-  GLX_REQUIRE(divert.keys != nullptr, "no divert map");
+  GLX_REQUIRE(divert.keys != nullptr || divert.step > 0, "no divert map");
   return partition_impl(device, ids, n, num_shards + 1, divert, bucketed, order, counts, s);
 }
 

@@ -792,7 +792,8 @@ GLX_API int glx_probe_bandwidth(int device, int kind, int64_t bytes, int64_t uni
  * bit-identical under every setting.  Unknown name: GLX_INVALID_ARGUMENT.
  * Test knobs of the side paths, same rules, -1 restores the default: "cond_sequential" (GLX_COND_SEQUENTIAL),
  * "dist_no_bitmap" (GLX_DIST_NO_BITMAP), "filter_span_cap" (GLX_FILTER_SPAN_CAP), "filter_dedup_min_rows"
- * (GLX_FILTER_DEDUP_MIN_ROWS). */
+ * (GLX_FILTER_DEDUP_MIN_ROWS), "idmap_hash_only" (GLX_IDMAP_HASH_ONLY: feature tables created afterwards keep a hash table
+ * even when their ids are an arithmetic progression). */
 GLX_API int glx_tune(const char* name, int32_t value);
 
 #ifdef __cplusplus

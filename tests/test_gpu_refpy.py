@@ -39,3 +39,26 @@ def test_the_reference_layer_really_ran_on_this_engine(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=refpy.env(), cwd=str(tmp_path), stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, text=True)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout
+
+
+def _run_script(name, args, cwd):
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(refpy.ROOT, "tests", "scripts", name)
+    out = subprocess.run([sys.executable, script] + list(args), env=refpy.env(), cwd=cwd, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-4000:]
+    return out.stdout
+
+
+def test_fused_hop_chain_of_a_query_equals_the_separate_requests(tmp_path):
+    """The DAG runner's hop fusion (a chain of dense sampling nodes -> one glx_sample_hops call, host dag.h) against the
+    same hops as separate SamplingRequests, both driven by the reference's Python layer: deterministic (topk) in one
+    process; random across two fresh processes, whose operators' call counters start at zero alike."""
+    for sub in ("t", "d1", "d2"):
+        (tmp_path / sub).mkdir()
+    assert "TOPK_OK" in _run_script("refpy_dag_fusion.py", ["topk"], str(tmp_path / "t"))
+    fused = [l for l in _run_script("refpy_dag_fusion.py", ["dag"], str(tmp_path / "d1")).splitlines() if l.startswith("VALUES")]
+    apart = [l for l in _run_script("refpy_dag_fusion.py", ["direct"], str(tmp_path / "d2")).splitlines() if l.startswith("VALUES")]
+    assert fused and fused == apart, (fused, apart)

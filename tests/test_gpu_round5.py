@@ -111,3 +111,49 @@ def test_explicit_segment_ids_one_pass_bookkeeping_equals_the_oracle(dim):
             e1, c1 = feats.aggregate("SumAggregator", ids, seg, sg, default_attr=0.25)
             assert np.array_equal(c0, c1) and np.array_equal(e0.view(np.uint32), e1.view(np.uint32))
     feats.close()
+
+
+@pytest.mark.parametrize("base,step,n", [(3, 8, 5000), (0, 2, 4096), (-70, 7, 333), (5, 1, 100), (10 ** 15, 10 ** 12, 50), (9, 4, 2),
+                                         (2 ** 62, 2 ** 60, 3)])
+def test_feature_tables_with_arithmetic_ids_need_no_hash_table(base, step, n):
+    """Shard r of a dense id space under the reference's ownership rule llabs(id) % P holds ids r, r + P, r + 2P, ...
+    (hash_partitioner.h:88-92): such a table translates ids by arithmetic.  Same answers as the hash table
+    (glx.tune("idmap_hash_only", 1): A/B in one process) and as the oracle, for ids inside, between, before and
+    after the progression; ids that only look arithmetic at the start keep the table."""
+    import torch
+    orc = Oracle()
+    rng = np.random.default_rng(n)
+    D = 20
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    ids = (base + step * np.arange(n, dtype=object)).astype(np.int64)
+    probe = np.concatenate([ids[rng.integers(0, n, 400)], ids[:50] + 1, ids[:50] - 1, [base - step, int(ids[-1]) + step if int(ids[-1]) + step < 2 ** 63 else 0,
+                                                                                       -1, 0, 2 ** 63 - 1, -2 ** 63]]).astype(np.int64)
+    seg = np.sort(rng.integers(0, 40, probe.shape[0])).astype(np.int32)
+    glx.tune("idmap_hash_only", 1)
+    hashed = glx.Features(X, ids=ids)
+    glx.tune("idmap_hash_only", -1)
+    arith = glx.Features(X, ids=ids)
+    try:
+        for name in glx.AGGREGATOR_IDS:
+            we, wc = orc.aggregate(X, name, probe, seg, 40, default_attr=1.5, ids=ids)
+            for f in (hashed, arith):
+                e, c = f.aggregate(name, probe, seg, 40, default_attr=1.5)
+                assert np.array_equal(c, wc) and np.array_equal(e.view(np.uint32), we.view(np.uint32)), name
+        a, b = hashed.lookup(probe, default_attr=-2.0), arith.lookup(probe, default_attr=-2.0)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        dev = torch.device("cuda", 0)
+        ta = arith.lookup(torch.from_numpy(probe).to(dev), default_attr=-2.0)
+        assert np.array_equal(ta.cpu().numpy().view(np.uint32), a.view(np.uint32))
+    finally:
+        hashed.close()
+        arith.close()
+    # almost arithmetic: one id off -- the table is kept and still right
+    if n > 3:
+        odd = ids.copy()
+        odd[n // 2] += 1
+        f = glx.Features(X, ids=odd)
+        q = np.array([odd[n // 2], ids[n // 2], odd[0], odd[-1]], np.int64)
+        got = f.lookup(q, default_attr=7.0)
+        want = np.stack([X[n // 2], np.full(D, 7.0, np.float32), X[0], X[-1]])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        f.close()
