@@ -126,10 +126,10 @@ __host__ __device__ __forceinline__ uint64_t glx_mix64(uint64_t x) {
 __device__ __forceinline__ int64_t glx_row_of(const GlxIdMap& m, int64_t id) {
   if (m.keys == nullptr) {
     if (m.step > 0) {
-      const int64_t d = id - m.base;
-      if (id < m.base || d < 0) return -1;  // (d < 0: the subtraction wrapped)
-      const int64_t q = d / m.step;
-      return (q * m.step == d && q < m.num_rows) ? q : -1;
+      if (id < m.base) return -1;
+      const uint64_t d = (uint64_t)id - (uint64_t)m.base;  // exact: id >= base, so the true difference fits 64 unsigned bits
+      const uint64_t q = d / (uint64_t)m.step;
+      return (q * (uint64_t)m.step == d && q < (uint64_t)m.num_rows) ? (int64_t)q : -1;
     }
     return (id >= 0 && id < m.num_rows) ? id : -1;
   }

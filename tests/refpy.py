@@ -1,13 +1,63 @@
 """Where the staged reference Python layer lives and how its test files are run (tests/test_refpy_names.py,
-tests/test_gpu_refpy.py).  Staging itself is scripts/stage_refpy.py -- test infrastructure, like oracle/_ref."""
+tests/test_gpu_refpy.py).  Staging itself is scripts/stage_refpy.py -- test infrastructure, like oracle/_ref: ONE
+git-ignored archive in the tree, unpacked here into a directory under /tmp beside a copy of the built extension."""
 import glob
+import hashlib
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
+import zipfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE = os.path.join(ROOT, "graph-learn_amd", "python", "_refpy")
-PACKAGE = os.path.join(STAGE, "graphlearn")
+ARCHIVE = os.path.join(ROOT, "graph-learn_amd", "python", "_refpy.zip")
+LIB = os.path.join(ROOT, "graph-learn_amd", "lib")
+
+
+def _module():
+    found = glob.glob(os.path.join(ROOT, "graph-learn_amd", "python", "graphlearn", "pywrap_graphlearn*.so"))
+    return found[0] if found else None
+
+
+def _unpack():
+    """-> the directory to put on PYTHONPATH: the archive's tree + the extension as built NOW (keyed by both)."""
+    mod = _module()
+    with open(ARCHIVE, "rb") as f:
+        digest = hashlib.sha1(f.read())
+    digest.update(("%s:%d:%d" % (mod, os.path.getsize(mod), os.stat(mod).st_mtime_ns)).encode())
+    key = digest.hexdigest()[:16]
+    stage = os.path.join(tempfile.gettempdir(), "glx_refpy_" + key)
+    if not os.path.isfile(os.path.join(stage, ".complete")):
+        tmp = tempfile.mkdtemp(prefix="glx_refpy_tmp_")
+        with zipfile.ZipFile(ARCHIVE) as z:
+            z.extractall(tmp)
+        shutil.copy2(mod, os.path.join(tmp, "graphlearn", os.path.basename(mod)))
+        open(os.path.join(tmp, ".complete"), "w").close()
+        try:
+            os.rename(tmp, stage)
+        except OSError:  # another process got there first
+            shutil.rmtree(tmp, ignore_errors=True)
+    return stage
+
+
+class _Lazy(object):
+    """STAGE / PACKAGE as strings that are made on first use (importing this module must not unpack anything)."""
+
+    def __init__(self, *tail):
+        self.tail = tail
+
+    def __str__(self):
+        return os.path.join(_unpack(), *self.tail)
+
+    __fspath__ = __str__
+
+    def __repr__(self):
+        return repr(str(self))
+
+
+STAGE = _Lazy()
+PACKAGE = _Lazy("graphlearn")
 
 # The reference's own test files, relative to graphlearn/python/.  Not listed: nn/tf (TensorFlow is not installed).
 TEST_GLOBS = ["sampler/tests/test_*.py", "gsl/tests/test_*.py", "tests/test_*.py", "nn/pytorch/data/test/test_*.py"]
@@ -35,7 +85,7 @@ KNOWN_BROKEN_IN_REFERENCE = {
 
 
 def staged():
-    return os.path.isfile(os.path.join(PACKAGE, "__init__.py")) and bool(glob.glob(os.path.join(PACKAGE, "pywrap_graphlearn*.so")))
+    return os.path.isfile(ARCHIVE) and _module() is not None
 
 
 def test_files():
@@ -54,7 +104,9 @@ def defines_tests(rel):
 
 def env():
     e = dict(os.environ)
-    e["PYTHONPATH"] = STAGE + (os.pathsep + e["PYTHONPATH"] if e.get("PYTHONPATH") else "")
+    e["PYTHONPATH"] = str(STAGE) + (os.pathsep + e["PYTHONPATH"] if e.get("PYTHONPATH") else "")
+    # the extension's copy sits outside the tree: its $ORIGIN-relative rpath no longer finds the engine
+    e["LD_LIBRARY_PATH"] = LIB + (os.pathsep + e["LD_LIBRARY_PATH"] if e.get("LD_LIBRARY_PATH") else "")
     return e
 
 
