@@ -85,6 +85,13 @@ public:
   // device path: the float attributes arrive as one block
   void SetShape(int32_t batch_size, int32_t float_attr_num);
   float* MutableFloatAttrs();
+  // bulk path of the host-resident columns: each sized for the whole batch at once (after SetSideInfo), then written
+  // through the pointer -- one pass per column instead of one tensor-map lookup per element and column
+  float* ResizeWeights();
+  int32_t* ResizeLabels();
+  int64_t* ResizeTimestamps();
+  int64_t* ResizeIntAttrs();
+  std::vector<std::string>* MutableStringAttrs() { return &strings_; }
 
 private:
   io::SideInfo info_;

@@ -224,6 +224,9 @@ public:
   float GetWeight(int64_t node_id) const;
   int32_t GetLabel(int64_t node_id) const;
   int64_t GetTimestamp(int64_t node_id) const;
+  float WeightAt(int32_t row) const { return weights_[(size_t)row]; }        // by row (RowOf >= 0), for bulk lookups
+  int32_t LabelAt(int32_t row) const { return labels_[(size_t)row]; }
+  int64_t TimestampAt(int32_t row) const { return timestamps_[(size_t)row]; }
   const int64_t* GetIntAttrs(int32_t row) const { return i_attrs_.data() + (int64_t)row * info_.i_num; }
   const float* GetFloatAttrs(int32_t row) const { return feats_.data() + (int64_t)row * info_.f_num; }
   const std::string* GetStringAttrs(int32_t row) const { return s_attrs_.data() + (int64_t)row * info_.s_num; }

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <sstream>
 #include <stdexcept>
@@ -385,12 +386,22 @@ namespace {
 void RunQuery(Env* env, const Dag* dag, TapeStorePtr store, std::shared_ptr<std::atomic<bool>> stop) {
   DagNodeRunner runner(env);
   auto stopped = [stop]() { return stop->load(); };
+  // GLX_DAG_TRACE=n (read once per query): the wall time of every step of the first n rounds on stderr
+  const char* trace_env = getenv("GLX_DAG_TRACE");
+  int trace_rounds = trace_env ? atoi(trace_env) : 0;
   while (!stopped()) {  // dag_scheduler.cc:45-60: round after round until the server stops
     Tape* tape = store->New();
     for (const Dag::Step& step : dag->Steps()) {
+      const auto t0 = std::chrono::steady_clock::now();
       runner.Run(step, tape);
+      if (trace_rounds > 0) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[glx dag %d] step %s%s (node %d): %.3f ms\n", dag->Id(), step.nodes[0]->OpName().c_str(),
+                step.nodes.size() > 1 ? " x hops" : "", step.nodes[0]->Id(), ms);
+      }
       if (tape->IsFaked() || tape->IsReady()) break;
     }
+    if (trace_rounds > 0) --trace_rounds;
     if (!tape->IsFaked() && !tape->IsReady()) tape->Fake();  // a query without a sink never completes a round
     if (!store->WaitAndPush(tape, stopped)) break;
   }
