@@ -201,6 +201,7 @@ struct GlxSideKnobs {
   std::atomic<int64_t> dist_no_bitmap{-1};        // GLX_DIST_NO_BITMAP (set = 1): the hot-row replica's membership test as a hash map
   std::atomic<int64_t> filter_span_cap{-1};       // GLX_FILTER_SPAN_CAP: total degree per chunk of a filtered request
   std::atomic<int64_t> filter_dedup_min_rows{-1}; // GLX_FILTER_DEDUP_MIN_ROWS: rows from which (vertex, value) pairs share a table; 0 disables
+  std::atomic<int64_t> resolve_ids{-1};           // GLX_RESOLVE_IDS=4|8: ids per thread per pass of the partitioned aggregation's resolve kernel (default 2)
   std::atomic<int64_t> idmap_hash_only{-1};       // GLX_IDMAP_HASH_ONLY (set = 1): feature tables keep a hash table even for arithmetic ids (A/B)
 };
 GlxSideKnobs& glx_side_knobs();  // glx_graph.hip

@@ -1061,7 +1061,10 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
         // 64 at a time (kQueue); without one every id takes that path and a queue would only add work
         static const bool kNoQueue = getenv("GLX_RESOLVE_NO_QUEUE") != nullptr;  // (ablation)
         if (a.has_cache && !kNoQueue) {
-          if (a.bm_member) glx_dist_resolve_kernel<2, true><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
+          const int64_t per = glx_side_knobs().resolve_ids.load(std::memory_order_relaxed);  // ids per thread per pass (A/B)
+          if (a.bm_member && per == 8) glx_dist_resolve_kernel<8, true><<<grid_for((n + 7) / 8, 1024), 256, 0, s>>>(a);
+          else if (a.bm_member && per == 4) glx_dist_resolve_kernel<4, true><<<grid_for((n + 3) / 4, 1024), 256, 0, s>>>(a);
+          else if (a.bm_member) glx_dist_resolve_kernel<2, true><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
           else glx_dist_resolve_kernel<1, true><<<grid_for(n, 1024), 256, 0, s>>>(a);
         } else if (a.bm_member) {
           glx_dist_resolve_kernel<2, false><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);

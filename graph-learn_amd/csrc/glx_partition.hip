@@ -25,17 +25,23 @@ __device__ __forceinline__ int32_t bucket_of(int64_t id, int32_t P, const GlxIdM
   return glx_row_of(divert, id) >= 0 ? P - 1 : shard_of(id, P - 1);
 }
 
-// block_counts is shard-major: [P][nblocks].
+// block_counts is shard-major: [P][nblocks].  bucket_cache (or null): the bucket of every id, written here and read by
+// the scatter kernel -- with a divert map a bucket costs a hash probe, which is then paid once per id, not twice.
 __global__ __launch_bounds__(256) void glx_part_count_kernel(const int64_t* __restrict__ ids, int64_t n,
                                                              int32_t P, int64_t nblocks, GlxIdMap divert,
-                                                             int64_t* __restrict__ block_counts) {
+                                                             int64_t* __restrict__ block_counts,
+                                                             uint8_t* __restrict__ bucket_cache) {
   __shared__ int32_t cnt[kMaxShards];
   if (threadIdx.x < kMaxShards) cnt[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = blockIdx.x * (int64_t)kTile;
   for (int it = 0; it < kTile / 256; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[bucket_of(ids[i], P, divert)], 1);
+    if (i < n) {
+      const int32_t b = bucket_of(ids[i], P, divert);
+      if (bucket_cache) bucket_cache[i] = (uint8_t)b;
+      atomicAdd(&cnt[b], 1);
+    }
   }
   __syncthreads();
   if (threadIdx.x < P) block_counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = cnt[threadIdx.x];
@@ -89,6 +95,7 @@ template <bool kOwnScan>
 __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __restrict__ ids, int64_t n,
                                                                int32_t P, int64_t nblocks, GlxIdMap divert,
                                                                const int64_t* __restrict__ block_off,
+                                                               const uint8_t* __restrict__ bucket_cache,
                                                                int64_t* __restrict__ bucketed,
                                                                int64_t* __restrict__ order,
                                                                int64_t* __restrict__ counts) {
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __
     const int64_t i = base + it * 256 + threadIdx.x;
     const bool valid = i < n;
     const int64_t id = valid ? ids[i] : 0;
-    const int32_t sh = valid ? bucket_of(id, P, divert) : -1;
+    const int32_t sh = !valid ? -1 : (bucket_cache ? (int32_t)bucket_cache[i] : bucket_of(id, P, divert));
     int32_t my_rank = 0;
     for (int32_t p = 0; p < P; ++p) {
       const uint64_t b = __ballot(sh == p);
@@ -175,17 +182,19 @@ static int partition_impl(int device, const int64_t* ids, int64_t n, int32_t num
   }
   const int64_t nblocks = (n + kTile - 1) / kTile;
   int64_t* block_counts = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&block_counts),
-                             (size_t)num_buckets * nblocks * sizeof(int64_t), s, 1);
+  const size_t cells_b = (size_t)num_buckets * nblocks * sizeof(int64_t);
+  const bool probe = divert.keys != nullptr || divert.step > 0;  // a bucket costs a lookup: remember it (one byte per id)
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&block_counts), cells_b + (probe ? (size_t)n : 0), s, 1);
   if (rc != GLX_OK) return rc;
-  glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts);
+  uint8_t* bucket_cache = probe ? reinterpret_cast<uint8_t*>(block_counts) + cells_b : nullptr;
+  glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts, bucket_cache);
   if ((int64_t)num_buckets * nblocks <= kOwnScanCells) {
     glx_part_scatter_kernel<true><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
-                                                                   bucketed, order, counts);
+                                                                   bucket_cache, bucketed, order, counts);
   } else {
     glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_buckets, counts);
     glx_part_scatter_kernel<false><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
-                                                                    bucketed, order, counts);
+                                                                    bucket_cache, bucketed, order, counts);
   }
   hipError_t e = hipGetLastError();
   glx_scratch_free(block_counts, s);
