@@ -350,4 +350,107 @@ TEST(GraphOpTest, NodeGetters) {
   for (int32_t i = 0; i < 500; ++i) EXPECT_TRUE(res.NodeIds()[i] >= 0 && res.NodeIds()[i] < 100);
 }
 
+// A GSL query as the Python layer lowers it (python/gsl/dag_node.py) -- GetNodes -> two Topk hops -> the lookups of
+// every traversal node -> Sink -- through Client::RunDag / GetDagValues on the device store: the two hops are ONE
+// compiled step (glx_sample_hops), every round's values equal the same operators called one by one, rounds arrive
+// in root order, and the root's OUT_OF_RANGE ends the epoch with an invalid response (core/runner/dag_node_runner.cc,
+// dag_scheduler.cc, service/executor.cc:46-71).
+TEST(GraphOpTest, QueryDagOnTheDeviceStore) {
+  SetUpStore();
+  auto str = [](const std::string& v) { Tensor t(kString, 1); t.AddString(v); return t; };
+  auto i32 = [](int32_t v) { Tensor t(kInt32, 1); t.AddInt32(v); return t; };
+  int32_t eid = 9000;
+  auto link = [&eid](DagNodeDef* src, DagNodeDef* dst, const char* out, const char* in) {
+    DagEdgeDef e;
+    e.id = eid++;
+    e.src_output = out;
+    e.dst_input = in;
+    src->out_edges.push_back(e);
+    dst->in_edges.push_back(e);
+  };
+  DagNodeDef root, look0, hop1, look1, hop2, look2, sink;
+  root.id = 1; root.op_name = "GetNodes";
+  root.params[kNodeType] = str("user"); root.params[kNodeFrom] = i32(kNode); root.params[kStrategy] = str("by_order");
+  root.params[kBatchSize] = i32(16); root.params[kEpoch] = i32(0x7fffffff);
+  look0.id = 2; look0.op_name = "LookupNodes"; look0.params[kNodeType] = str("user");
+  hop1.id = 3; hop1.op_name = "TopkSampler";
+  hop1.params[kEdgeType] = str("click"); hop1.params[kStrategy] = str("TopkSampler"); hop1.params[kNeighborCount] = i32(2);
+  look1.id = 4; look1.op_name = "LookupNodes"; look1.params[kNodeType] = str("item");
+  hop2.id = 5; hop2.op_name = "TopkSampler";
+  hop2.params[kEdgeType] = str("buy"); hop2.params[kStrategy] = str("TopkSampler"); hop2.params[kNeighborCount] = i32(3);
+  look2.id = 6; look2.op_name = "LookupNodes"; look2.params[kNodeType] = str("item");
+  sink.id = 7; sink.op_name = "Sink";
+  link(&root, &look0, kNodeIds, kNodeIds);
+  link(&root, &hop1, kNodeIds, kSrcIds);
+  link(&hop1, &look1, kNodeIds, kNodeIds);
+  link(&hop1, &hop2, kNodeIds, kSrcIds);
+  link(&hop2, &look2, kNodeIds, kNodeIds);
+  for (DagNodeDef* n : {&root, &look0, &hop1, &look1, &hop2, &look2}) link(n, &sink, "fake", "fake");
+  DagDef def;
+  def.id = 4711;
+  def.nodes = {root, look0, hop1, look1, hop2, look2, sink};
+  {
+    Dag probe(def);
+    EXPECT_TRUE(probe.Compile().ok());
+    size_t fused = 0;
+    for (const Dag::Step& st : probe.Steps()) fused += st.nodes.size() > 1 ? 1 : 0;
+    EXPECT_EQ(fused, (size_t)1);  // hop1 + hop2
+    EXPECT_EQ(probe.Steps().size(), (size_t)6);
+  }
+  SetGlobalFlagTapeCapacity(2);
+  Client* client = NewInMemoryClient();
+  DagRequest req;
+  req.ParseFrom(&def, false);
+  EXPECT_TRUE(client->RunDag(&req).ok());
+  for (int32_t round = 0; round < 8; ++round) {
+    GetDagValuesRequest get(4711);
+    GetDagValuesResponse res;
+    EXPECT_TRUE(client->GetDagValues(&get, &res).ok());
+    if (round == 7) {  // 100 ids = 6 x 16 + 4, then the epoch ends
+      EXPECT_TRUE(!res.Valid());
+      EXPECT_EQ(res.Epoch(), 0);
+      break;
+    }
+    EXPECT_TRUE(res.Valid());
+    const int32_t n = round < 6 ? 16 : 4;
+    const Tensor* ids = res.GetValue(1, kNodeIds).first;
+    EXPECT_TRUE(ids != nullptr && ids->Size() == n);
+    if (!ids) break;
+    for (int32_t i = 0; i < n; ++i) EXPECT_EQ(ids->GetInt64(i), (int64_t)(round * 16 + i));
+    // the same two hops as separate requests (Topk is deterministic)
+    SamplingRequest r1("click", "TopkSampler", 2);
+    SamplingResponse s1;
+    r1.Set(ids->GetInt64(), n);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("TopkSampler")->Process(&r1, &s1).ok());
+    SamplingRequest r2("buy", "TopkSampler", 3);
+    SamplingResponse s2;
+    r2.Set(s1.GetNeighborIds(), n * 2);
+    EXPECT_TRUE(OpFactory::GetInstance()->Create("TopkSampler")->Process(&r2, &s2).ok());
+    const Tensor* b = res.GetValue(3, kNodeIds).first;
+    const Tensor* be = res.GetValue(3, kEdgeIds).first;
+    const Tensor* c = res.GetValue(5, kNodeIds).first;
+    EXPECT_TRUE(b && be && c && b->Size() == n * 2 && c->Size() == n * 6);
+    if (!b || !be || !c) break;
+    for (int32_t i = 0; i < n * 2; ++i) {
+      EXPECT_EQ(b->GetInt64(i), s1.GetNeighborIds()[i]);
+      EXPECT_EQ(be->GetInt64(i), s1.GetEdgeIds()[i]);
+      EXPECT_EQ(b->GetInt64(i), ids->GetInt64(i / 2));  // edge i -> i, circular padding
+    }
+    for (int32_t i = 0; i < n * 6; ++i) EXPECT_EQ(c->GetInt64(i), s2.GetNeighborIds()[i]);
+    EXPECT_TRUE(res.GetValue(3, kNodeIds).second == nullptr);  // dense: no segments
+    // lookups: user weights (= id), item labels (= id) for both hops
+    const Tensor* w0 = res.GetValue(2, kWeightKey).first;
+    const Tensor* l1 = res.GetValue(4, kLabelKey).first;
+    const Tensor* l2 = res.GetValue(6, kLabelKey).first;
+    EXPECT_TRUE(w0 && l1 && l2 && w0->Size() == n && l1->Size() == n * 2 && l2->Size() == n * 6);
+    if (!w0 || !l1 || !l2) break;
+    for (int32_t i = 0; i < n; ++i) EXPECT_TRUE(w0->GetFloat(i) == (float)ids->GetInt64(i));
+    for (int32_t i = 0; i < n * 2; ++i) EXPECT_EQ((int64_t)l1->GetInt32(i), b->GetInt64(i));
+    for (int32_t i = 0; i < n * 6; ++i) EXPECT_EQ((int64_t)l2->GetInt32(i), c->GetInt64(i));
+    EXPECT_TRUE(res.GetValue(7, kNodeIds).first == nullptr);  // the sink records nothing
+  }
+  DagScheduler::StopAll();
+  delete client;
+}
+
 int main() { return RunAllTests(); }
