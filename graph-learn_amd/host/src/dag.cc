@@ -308,8 +308,9 @@ namespace {
 TensorMap Recorded(OpResponse* res) {
   TensorMap out;
   SamplingResponse* sampled = dynamic_cast<SamplingResponse*>(res);
-  if (sampled && sampled->GetShape().sparse) {
-    const std::vector<int32_t>& counts = sampled->GetShape().segments;
+  const Shape shape = sampled ? sampled->GetShape() : Shape();
+  if (sampled && shape.sparse) {
+    const std::vector<int32_t>& counts = shape.segments;
     Tensor segments(kInt32, (int32_t)counts.size());
     segments.AddInt32(counts.data(), counts.data() + counts.size());
     for (const char* key : {kNodeIds, kEdgeIds}) {
@@ -393,7 +394,11 @@ void RunQuery(Env* env, const Dag* dag, TapeStorePtr store, std::shared_ptr<std:
     Tape* tape = store->New();
     for (const Dag::Step& step : dag->Steps()) {
       const auto t0 = std::chrono::steady_clock::now();
-      runner.Run(step, tape);
+      try {
+        runner.Run(step, tape);
+      } catch (const std::exception&) {  // an operator that throws (out of memory, a malformed request) costs this
+        tape->Fake();                    // round, not the process: nobody above this thread could catch it
+      }
       if (trace_rounds > 0) {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         fprintf(stderr, "[glx dag %d] step %s%s (node %d): %.3f ms\n", dag->Id(), step.nodes[0]->OpName().c_str(),
