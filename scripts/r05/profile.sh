@@ -20,13 +20,16 @@ keep() {  # keep <raw dir> <out prefix>: the glx rows of every trace / counter C
 }
 for wl in $WLS; do
   B="python $R/bench.py --workload $wl $LEAN --detail-out $OUT/${wl}_detail.json"
+  if [ -z "$ONLY_PASS" ]; then  # ONLY_PASS=WRITE_SIZE: redo one counter pass (rocprofv3's own crash on c4 is intermittent)
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/${wl}_trace -o t -- $B --steps 20 --warmup 5 --roofline-probes off > $OUT/${wl}_bench_trace.json 2> $OUT/${wl}_trace.err
   keep $RAW/${wl}_trace $OUT/${wl}_trace
+  fi
   # c4: counter collection over the 1.6 B-edge build's dispatches crashes rocprofv3 (SIGSEGV in its own thread, r03 and
   # r05): collect counters for the path's kernels only
   ONLY=""; if [ $wl = c4 ]; then ONLY="--kernel-include-regex glx_aggregate|glx_sample|glx_rwor"; fi
   for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     tag=$(echo $pass | cut -d' ' -f1)
+    if [ -n "$ONLY_PASS" ] && [ "$ONLY_PASS" != "$tag" ]; then continue; fi
     timeout 900 rocprofv3 --pmc $pass $ONLY --kernel-trace --output-format csv -d $RAW/${wl}_$tag -o p -- $B --steps 5 --warmup 1 > $OUT/${wl}_bench_$tag.json 2> $OUT/${wl}_$tag.err
     keep $RAW/${wl}_$tag $OUT/${wl}_$tag
     rm -rf $RAW/${wl}_$tag
