@@ -986,6 +986,7 @@ extern "C" int glx_tune(const char* name, int32_t value) {
     else if (strcmp(name, "filter_dedup_min_rows") == 0) side = &sk.filter_dedup_min_rows;
     else if (strcmp(name, "idmap_hash_only") == 0) side = &sk.idmap_hash_only;
     else if (strcmp(name, "resolve_ids") == 0) side = &sk.resolve_ids;
+    else if (strcmp(name, "resolve_blocks") == 0) side = &sk.resolve_blocks;
     GLX_REQUIRE(side != nullptr, "unknown knob '%s'", name);
     side->store(value, std::memory_order_relaxed);
     return GLX_OK;

@@ -128,7 +128,9 @@ __device__ __forceinline__ int64_t glx_row_of(const GlxIdMap& m, int64_t id) {
     if (m.step > 0) {
       if (id < m.base) return -1;
       const uint64_t d = (uint64_t)id - (uint64_t)m.base;  // exact: id >= base, so the true difference fits 64 unsigned bits
-      const uint64_t q = d / (uint64_t)m.step;
+      // (a 64-bit division is ~100 instructions on this ISA; distances and steps nearly always fit 32 bits)
+      const uint64_t q = ((d | (uint64_t)m.step) <= 0xffffffffull) ? (uint64_t)((uint32_t)d / (uint32_t)m.step)
+                                                                  : d / (uint64_t)m.step;
       return (q * (uint64_t)m.step == d && q < (uint64_t)m.num_rows) ? (int64_t)q : -1;
     }
     return (id >= 0 && id < m.num_rows) ? id : -1;
@@ -159,8 +161,14 @@ int glx_idmap_build_auto(const int64_t* d_ids, int64_t num_rows, GlxIdMapStorage
 int glx_sample_scatter_device(const glx_graph* g, int sampler, const int64_t* d_src, const int64_t* d_rows,
                               int32_t batch, int32_t k, int padding_mode, int64_t default_neighbor_id, uint64_t seed,
                               uint64_t call_counter, int64_t* d_nbr, int64_t* d_eid, hipStream_t s);
+// Membership of non-negative ids as one bit each (bit id % 64 of bits[id / 64], ids in [0, max]); bits == nullptr: none.
+struct GlxMember {
+  const uint64_t* bits;
+  int64_t max;
+};
 // glx_partition with one more bucket (the last) for the ids `divert` knows; counts has num_shards + 1 entries.
-int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert,
+// `member` (optional): the same set as a bitmap -- a few MB that stay in L2 where the hash probe is a random DRAM access.
+int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert, GlxMember member,
                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s);
 void glx_idmap_free(GlxIdMapStorage* m);
 struct glx_features;
@@ -202,6 +210,7 @@ struct GlxSideKnobs {
   std::atomic<int64_t> filter_span_cap{-1};       // GLX_FILTER_SPAN_CAP: total degree per chunk of a filtered request
   std::atomic<int64_t> filter_dedup_min_rows{-1}; // GLX_FILTER_DEDUP_MIN_ROWS: rows from which (vertex, value) pairs share a table; 0 disables
   std::atomic<int64_t> resolve_ids{-1};           // GLX_RESOLVE_IDS=4|8: ids per thread per pass of the partitioned aggregation's resolve kernel (default 2)
+  std::atomic<int64_t> resolve_blocks{-1};        // GLX_RESOLVE_BLOCKS=n: workgroups of that kernel (default 1024)
   std::atomic<int64_t> idmap_hash_only{-1};       // GLX_IDMAP_HASH_ONLY (set = 1): feature tables keep a hash table even for arithmetic ids (A/B)
 };
 GlxSideKnobs& glx_side_knobs();  // glx_graph.hip

@@ -72,6 +72,8 @@ struct Carver {
 
 __device__ __forceinline__ int32_t dist_owner(int64_t id, int32_t P) {
   const uint64_t a = id < 0 ? (uint64_t)0 - (uint64_t)id : (uint64_t)id;  // llabs (hash_partitioner.h:90-92)
+  // a 64-bit remainder is ~100 instructions on this ISA, a 32-bit one a quarter of that -- and ids nearly always fit
+  if (a <= 0xffffffffull) return (int32_t)((uint32_t)a % (uint32_t)P);
   return (int32_t)(a % (uint64_t)P);
 }
 
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   int64_t* qid = s_qid[kQueue ? (threadIdx.x >> 6) : 0];
   int32_t* qi = s_qi[kQueue ? (threadIdx.x >> 6) : 0];
   int qn = 0;  // queued ids of this wave (wave-uniform)
+  const bool own_inline = a.own_map.keys == nullptr;  // arithmetic (or identity) own-shard ids
 
   // One id off the replica: own shard -> its row; remote -> its slot in the halo set (winner: the first to claim it).
   auto resolve_cold = [&](int64_t id, int32_t& owner, bool& winner, int32_t voided) -> int32_t {
@@ -300,6 +303,14 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
         if (r[j] >= 0) {
           a.loc[i] = a.cache_base + (int32_t)r[j];
           ++n_hit;
+        } else if (kQueue && own_inline && (id[j] == GLX_EMPTY_KEY || dist_owner(id[j], a.P) == a.me)) {
+          // off the replica but this rank's own, and the own shard's ids are arithmetic: the row is a division, no
+          // memory round trip to wait for -- nothing the queue could hide (every id off the replica of a world-1
+          // request, an eighth of them at P = 8, used to queue for it: 0.185 -> 0.135 ms for the 16.4 M ids of the
+          // headline's hop-2 request at world size 1, profiles/r05/world1_partition_resolve.txt)
+          const int64_t rr = glx_row_of(a.own_map, id[j]);
+          a.loc[i] = rr >= 0 ? (int32_t)rr : -1;
+          ++n_own;
         } else if (kQueue) {
           cold = true;
         } else {
@@ -829,6 +840,37 @@ __global__ __launch_bounds__(256) void glx_dist_spec_stitch_kernel(const int64_t
   }
 }
 
+// The live keys of an id hash table: their minimum / maximum, and one bit per key (glx_dist_store_set_graph_replica).
+__global__ __launch_bounds__(256) void glx_dist_keys_minmax_kernel(const int64_t* __restrict__ keys, int64_t cap,
+                                                                   long long* __restrict__ mm) {
+  long long lo = INT64_MAX, hi = INT64_MIN;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = keys[i];
+    if (k != GLX_EMPTY_KEY) {
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0 && lo <= hi) {
+    atomicMin(&mm[0], lo);
+    atomicMax(&mm[1], hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void glx_dist_keys_setbits_kernel(const int64_t* __restrict__ keys, int64_t cap,
+                                                                    unsigned long long* __restrict__ bits) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = keys[i];
+    if (k != GLX_EMPTY_KEY) atomicOr(&bits[k >> 6], 1ull << (k & 63));
+  }
+}
+
 }  // namespace
 
 struct glx_dist_store {
@@ -836,6 +878,8 @@ struct glx_dist_store {
   glx_comm* comm = nullptr;
   const glx_graph* graph = nullptr;
   const glx_graph* graph_replica = nullptr;  // complete rows of the hot vertices, borrowed (glx_dist_store_set_graph_replica)
+  uint64_t* rg_bits = nullptr;  // the replica's vertex ids as a bitmap over [0, rg_bits_max] (owned), or nullptr: the
+  int64_t rg_bits_max = -1;     // request partition tests membership there instead of probing the replica's hash map
   int64_t sample_rows = 0, sample_rows_replica = 0, sample_rows_remote = 0;  // the last glx_dist_sample
   const glx_features* feats = nullptr;
   glx_features* cache = nullptr;
@@ -1062,10 +1106,12 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
         static const bool kNoQueue = getenv("GLX_RESOLVE_NO_QUEUE") != nullptr;  // (ablation)
         if (a.has_cache && !kNoQueue) {
           const int64_t per = glx_side_knobs().resolve_ids.load(std::memory_order_relaxed);  // ids per thread per pass (A/B)
-          if (a.bm_member && per == 8) glx_dist_resolve_kernel<8, true><<<grid_for((n + 7) / 8, 1024), 256, 0, s>>>(a);
-          else if (a.bm_member && per == 4) glx_dist_resolve_kernel<4, true><<<grid_for((n + 3) / 4, 1024), 256, 0, s>>>(a);
-          else if (a.bm_member) glx_dist_resolve_kernel<2, true><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
-          else glx_dist_resolve_kernel<1, true><<<grid_for(n, 1024), 256, 0, s>>>(a);
+          const int64_t kb = glx_side_knobs().resolve_blocks.load(std::memory_order_relaxed);
+          const int64_t nb = kb > 0 ? kb : 1024;
+          if (a.bm_member && per == 8) glx_dist_resolve_kernel<8, true><<<grid_for((n + 7) / 8, nb), 256, 0, s>>>(a);
+          else if (a.bm_member && per == 4) glx_dist_resolve_kernel<4, true><<<grid_for((n + 3) / 4, nb), 256, 0, s>>>(a);
+          else if (a.bm_member) glx_dist_resolve_kernel<2, true><<<grid_for((n + 1) / 2, nb), 256, 0, s>>>(a);
+          else glx_dist_resolve_kernel<1, true><<<grid_for(n, nb), 256, 0, s>>>(a);
         } else if (a.bm_member) {
           glx_dist_resolve_kernel<2, false><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
         } else {
@@ -1272,7 +1318,8 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   const bool divert = rg != nullptr && !filtered && sampler != GLX_SAMPLER_IN_DEGREE &&
                       (sampler != GLX_SAMPLER_EDGE_WEIGHT || rg->weight != nullptr);
   if (divert) {
-    rc = glx_partition_divert(st->device, src, n, P, rg->map(), bucketed, order, d_cnt, s);
+    rc = glx_partition_divert(st->device, src, n, P, rg->map(), GlxMember{st->rg_bits, st->rg_bits_max}, bucketed, order,
+                              d_cnt, s);
   } else {
     rc = glx_partition(st->device, src, n, P, bucketed, order, d_cnt, s);
   }
@@ -1757,6 +1804,47 @@ extern "C" int glx_dist_store_set_graph_replica(glx_dist_store* st, const glx_gr
                     (replica->weight != nullptr) == (st->graph->weight != nullptr),
                 "the replica and the shard must both be weighted or both unweighted");
   }
+  st->graph_replica = nullptr;
+  if (st->rg_bits) (void)hipFree(st->rg_bits);
+  st->rg_bits = nullptr;
+  st->rg_bits_max = -1;
+  if (replica != nullptr && replica->idmap.keys != nullptr && replica->num_rows > 0 &&
+      glx_side_knobs().dist_no_bitmap.load(std::memory_order_relaxed) <= 0) {
+    // Hashed vertex ids: every id of every sampling request probes that table once to pick its bucket (a random DRAM
+    // access per id: 34 us for the 1.6 M ids of a hop-2 request).  When the ids are small non-negative numbers, one
+    // bit per id of the range answers the same question from a few MB that stay in L2.  Same bound on the range as
+    // the feature replica's rank records: at most 4 words per listed id (+ a floor), else the hash map stays.
+    GlxDeviceGuard guard(st->device);
+    GLX_REQUIRE(guard.ok, "cannot select device %d", st->device);
+    hipStream_t s = nullptr;
+    GlxTemp d_mm;
+    GLX_HIP(hipMalloc(&d_mm.p, 16));
+    const int64_t init[2] = {INT64_MAX, INT64_MIN};
+    GLX_HIP(hipMemcpyAsync(d_mm.p, init, 16, hipMemcpyHostToDevice, s));
+    const int64_t cap = (int64_t)replica->idmap.cap;
+    glx_dist_keys_minmax_kernel<<<grid_for(cap, 1024), 256, 0, s>>>(replica->idmap.keys, cap, d_mm.as<long long>());
+    int64_t mm[2] = {0, -1};
+    GLX_HIP(hipMemcpyAsync(mm, d_mm.p, 16, hipMemcpyDeviceToHost, s));
+    GLX_HIP(hipStreamSynchronize(s));
+    const int64_t words = mm[1] >= 0 ? (mm[1] >> 6) + 1 : 0;
+    if (mm[0] >= 0 && mm[1] < ((int64_t)1 << 33) && words <= 4 * replica->num_rows + 4096) {
+      uint64_t* bits = nullptr;
+      GLX_HIP(hipMalloc(reinterpret_cast<void**>(&bits), (size_t)words * 8));
+      hipError_t e = hipMemsetAsync(bits, 0, (size_t)words * 8, s);
+      if (e == hipSuccess) {
+        glx_dist_keys_setbits_kernel<<<grid_for(cap, 1024), 256, 0, s>>>(replica->idmap.keys, cap,
+                                                                         reinterpret_cast<unsigned long long*>(bits));
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) {
+        (void)hipFree(bits);
+        GLX_HIP(e);
+      }
+      st->rg_bits = bits;
+      st->rg_bits_max = mm[1];
+    }
+  }
   st->graph_replica = replica;
   return GLX_OK;
 }
@@ -1791,6 +1879,7 @@ extern "C" void glx_dist_store_destroy(glx_dist_store* st) {
   if (st->cache) glx_features_destroy(st->cache);
   if (st->cache_slots) (void)hipFree(st->cache_slots);
   if (st->bm_member) (void)hipFree(st->bm_member);
+  if (st->rg_bits) (void)hipFree(st->rg_bits);
   if (st->own_id) (void)hipFree(st->own_id);
   if (st->own_cnt) (void)hipFree(st->own_cnt);
   delete st;

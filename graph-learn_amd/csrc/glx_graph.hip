@@ -39,6 +39,7 @@ GlxSideKnobs& glx_side_knobs() {
     if (const char* e = getenv("GLX_FILTER_DEDUP_MIN_ROWS")) k.filter_dedup_min_rows = atoll(e);
     if (getenv("GLX_IDMAP_HASH_ONLY")) k.idmap_hash_only = 1;
     if (const char* e = getenv("GLX_RESOLVE_IDS")) k.resolve_ids = atoll(e);
+    if (const char* e = getenv("GLX_RESOLVE_BLOCKS")) k.resolve_blocks = atoll(e);
   });
   return k;
 }

@@ -8,37 +8,44 @@
 
 namespace {
 
-constexpr int kTile = 2048;  // ids per workgroup (8 passes of 256)
+constexpr int kTile = 2048;       // ids per workgroup (8 passes of 256) ...
+constexpr int kTileSmall = 512;   // ... and for requests up to kSmallIds: a 64 K-id request on 32 workgroups was eight
+constexpr int64_t kSmallIds = 1 << 18;  // dependent round trips long (44 us; the 1.6 M-id one beside it took 34)
 constexpr int kMaxShards = 64;
 constexpr int64_t kOwnScanCells = 32768;  // tile histogram cells (buckets x tiles) up to which the scatter kernel scans them itself
 
 __device__ __forceinline__ int32_t shard_of(int64_t id, int32_t P) {
   // llabs(id) % P (hash_partitioner.h:90-92)
   uint64_t a = id < 0 ? (uint64_t)0 - (uint64_t)id : (uint64_t)id;
+  if (a <= 0xffffffffull) return (int32_t)((uint32_t)a % (uint32_t)P);  // the 32-bit remainder is a quarter of the 64-bit one
   return (int32_t)(a % (uint64_t)P);
 }
 
 // With a divert map the request has one bucket more: ids the map knows go to bucket P - 1 (rows a local replica
 // serves, glx_dist.hip), everything else to llabs(id) % (P - 1).
-__device__ __forceinline__ int32_t bucket_of(int64_t id, int32_t P, const GlxIdMap& divert) {
+__device__ __forceinline__ int32_t bucket_of(int64_t id, int32_t P, const GlxIdMap& divert, const GlxMember& member) {
   if (divert.keys == nullptr && divert.step == 0) return shard_of(id, P);
+  if (member.bits != nullptr) {  // the divert map's ids, one bit each
+    const bool in = id >= 0 && id <= member.max && ((member.bits[id >> 6] >> (id & 63)) & 1ull);
+    return in ? P - 1 : shard_of(id, P - 1);
+  }
   return glx_row_of(divert, id) >= 0 ? P - 1 : shard_of(id, P - 1);
 }
 
 // block_counts is shard-major: [P][nblocks].  bucket_cache (or null): the bucket of every id, written here and read by
 // the scatter kernel -- with a divert map a bucket costs a hash probe, which is then paid once per id, not twice.
 __global__ __launch_bounds__(256) void glx_part_count_kernel(const int64_t* __restrict__ ids, int64_t n,
-                                                             int32_t P, int64_t nblocks, GlxIdMap divert,
-                                                             int64_t* __restrict__ block_counts,
+                                                             int32_t P, int64_t nblocks, int32_t tile, GlxIdMap divert,
+                                                             GlxMember member, int64_t* __restrict__ block_counts,
                                                              uint8_t* __restrict__ bucket_cache) {
   __shared__ int32_t cnt[kMaxShards];
   if (threadIdx.x < kMaxShards) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t base = blockIdx.x * (int64_t)kTile;
-  for (int it = 0; it < kTile / 256; ++it) {
+  const int64_t base = blockIdx.x * (int64_t)tile;
+  for (int it = 0; it < tile / 256; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
     if (i < n) {
-      const int32_t b = bucket_of(ids[i], P, divert);
+      const int32_t b = bucket_of(ids[i], P, divert, member);
       if (bucket_cache) bucket_cache[i] = (uint8_t)b;
       atomicAdd(&cnt[b], 1);
     }
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(1024) void glx_part_scan_kernel(int64_t* __restrict
 // 15 us beside a segmented reduce).  Block 0 also writes the bucket totals.  Otherwise block_off is the scanned table.
 template <bool kOwnScan>
 __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __restrict__ ids, int64_t n,
-                                                               int32_t P, int64_t nblocks, GlxIdMap divert,
+                                                               int32_t P, int64_t nblocks, int32_t tile, GlxIdMap divert,
+                                                               GlxMember member,
                                                                const int64_t* __restrict__ block_off,
                                                                const uint8_t* __restrict__ bucket_cache,
                                                                int64_t* __restrict__ bucketed,
@@ -132,12 +140,12 @@ __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __
     run[threadIdx.x] = block_off[(int64_t)threadIdx.x * nblocks + blockIdx.x];
   }
   __syncthreads();
-  const int64_t base = blockIdx.x * (int64_t)kTile;
-  for (int it = 0; it < kTile / 256; ++it) {
+  const int64_t base = blockIdx.x * (int64_t)tile;
+  for (int it = 0; it < tile / 256; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
     const bool valid = i < n;
     const int64_t id = valid ? ids[i] : 0;
-    const int32_t sh = !valid ? -1 : (bucket_cache ? (int32_t)bucket_cache[i] : bucket_of(id, P, divert));
+    const int32_t sh = !valid ? -1 : (bucket_cache ? (int32_t)bucket_cache[i] : bucket_of(id, P, divert, member));
     int32_t my_rank = 0;
     for (int32_t p = 0; p < P; ++p) {
       const uint64_t b = __ballot(sh == p);
@@ -175,26 +183,29 @@ __global__ __launch_bounds__(256) void glx_stitch_kernel(const T* __restrict__ i
 }  // namespace
 
 static int partition_impl(int device, const int64_t* ids, int64_t n, int32_t num_buckets, GlxIdMap divert,
-                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s) {
+                          GlxMember member, int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s) {
   if (n == 0) {
     GLX_HIP(hipMemsetAsync(counts, 0, (size_t)num_buckets * sizeof(int64_t), s));
     return GLX_OK;
   }
-  const int64_t nblocks = (n + kTile - 1) / kTile;
+  const int32_t tile = n <= kSmallIds ? kTileSmall : kTile;
+  const int64_t nblocks = (n + tile - 1) / tile;
   int64_t* block_counts = nullptr;
   const size_t cells_b = (size_t)num_buckets * nblocks * sizeof(int64_t);
-  const bool probe = divert.keys != nullptr || divert.step > 0;  // a bucket costs a lookup: remember it (one byte per id)
+  // a bucket that costs a hash probe is remembered (one byte per id); a bitmap or arithmetic test is cheaper recomputed
+  const bool probe = divert.keys != nullptr && member.bits == nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&block_counts), cells_b + (probe ? (size_t)n : 0), s, 1);
   if (rc != GLX_OK) return rc;
   uint8_t* bucket_cache = probe ? reinterpret_cast<uint8_t*>(block_counts) + cells_b : nullptr;
-  glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts, bucket_cache);
+  glx_part_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, tile, divert, member, block_counts,
+                                                          bucket_cache);
   if ((int64_t)num_buckets * nblocks <= kOwnScanCells) {
-    glx_part_scatter_kernel<true><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
-                                                                   bucket_cache, bucketed, order, counts);
+    glx_part_scatter_kernel<true><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, tile, divert, member,
+                                                                   block_counts, bucket_cache, bucketed, order, counts);
   } else {
     glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_buckets, counts);
-    glx_part_scatter_kernel<false><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, divert, block_counts,
-                                                                    bucket_cache, bucketed, order, counts);
+    glx_part_scatter_kernel<false><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, tile, divert, member,
+                                                                    block_counts, bucket_cache, bucketed, order, counts);
   }
   hipError_t e = hipGetLastError();
   glx_scratch_free(block_counts, s);
@@ -211,17 +222,17 @@ extern "C" int glx_partition(int device, const int64_t* ids, int64_t n, int32_t 
   if (rc != GLX_OK) return rc;
   GlxDeviceGuard guard(device);
   GLX_REQUIRE(guard.ok, "cannot select device %d", device);
-  return partition_impl(device, ids, n, num_shards, GlxIdMap{nullptr, nullptr, 0, 0}, bucketed, order, counts,
+  return partition_impl(device, ids, n, num_shards, GlxIdMap{nullptr, nullptr, 0, 0}, GlxMember{nullptr, -1}, bucketed, order, counts,
                         glx_stream(stream));
 }
 
 // The partition of a request that a local replica serves in part: buckets 0 .. num_shards - 1 as glx_partition,
 // bucket num_shards = the ids `divert` knows (counts has num_shards + 1 entries).  Device already selected.
-int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert,
+int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert, GlxMember member,
                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s) {
   GLX_REQUIRE(num_shards >= 1 && num_shards + 1 <= kMaxShards, "num_shards must be in [1, %d)", kMaxShards);
   GLX_REQUIRE(divert.keys != nullptr || divert.step > 0, "no divert map");
-  return partition_impl(device, ids, n, num_shards + 1, divert, bucketed, order, counts, s);
+  return partition_impl(device, ids, n, num_shards + 1, divert, member, bucketed, order, counts, s);
 }
 
 template <typename T>

@@ -504,12 +504,16 @@ def test_uniform_segments_single_gpu(world):
     assert np.array_equal(c, rc) and np.array_equal(e.view(np.uint32), re_.view(np.uint32))
 
 
-@pytest.mark.parametrize("P", [2, 3, 8])
-def test_graph_replica_serves_hot_rows_locally_with_the_same_draws(world, P):
+@pytest.mark.parametrize("P,membership", [(2, "bitmap"), (3, "bitmap"), (3, "hash"), (8, "bitmap")])
+def test_graph_replica_serves_hot_rows_locally_with_the_same_draws(world, P, membership):
     """glx_dist_store_set_graph_replica: the complete adjacency rows of the hottest vertices on every GPU.  Request
     rows the replica knows never leave the rank -- and the answers stay those of the unpartitioned graph, draw
-    for draw (the random stream is the row's index in the request, the rows and alias tables are the owner's)."""
+    for draw (the random stream is the row's index in the request, the rows and alias tables are the owner's).
+    The request partition asks "does the replica hold this id" of a bitmap when the replica's ids are small
+    non-negative numbers (the first replica here) and of the replica's hash map otherwise (the knob, and the replica
+    built from the shards below, whose list holds 10 ** 12)."""
     import dist as gdist
+    glx.tune("dist_no_bitmap", 1 if membership == "hash" else -1)
     whole, dev = world["whole"], world["dev"]
     gs, _ = world["shards"][P]
     rp, col, eid, w = (torch.from_numpy(a).to(dev) for a in synth.small_graph(V, 80000, seed=21, weighted=True,
@@ -567,7 +571,10 @@ def test_graph_replica_serves_hot_rows_locally_with_the_same_draws(world, P):
         assert st.last_sample_rows()["from_graph_replica"] > 0
         st.set_graph_replica(None)
         built.close()
-    _run_ranks(P, body)
+    try:
+        _run_ranks(P, body)
+    finally:
+        glx.tune("dist_no_bitmap", -1)
     replica.close()
 
 
