@@ -142,11 +142,15 @@ def test_fuzz_aggregators(seed, V, D, Sg, maxlen, hashed, corrupt, dflt):
 
 
 @settings(**COMMON)
-@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(0, 5000), P=st.integers(1, 64), width=st.integers(1, 7))
-def test_fuzz_partition_stitch(seed, n, P, width):
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(0, 5000), P=st.integers(1, 64), width=st.integers(1, 7),
+       bits=st.sampled_from([6, 20, 31, 32, 33, 40, 62]), more=st.sampled_from([0, 0, 0, 0, 0, 0, 258000, 300000]))
+def test_fuzz_partition_stitch(seed, n, P, width, bits, more):
+    """`bits`: ids on both sides of 2^32 (the shard of an id that fits 32 bits is computed with a 32-bit remainder);
+    `more`: requests on both sides of the 256 K ids up to which the partition uses its small tiles."""
     import torch
     rng = np.random.default_rng(seed)
-    ids = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    n += more
+    ids = rng.integers(-(1 << bits), 1 << bits, n).astype(np.int64)
     t = torch.from_numpy(ids).cuda()
     b, o, c = glx.partition(t, P)
     oo, oc = ORC.partition(ids, P)
