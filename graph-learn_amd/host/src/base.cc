@@ -91,60 +91,9 @@ void SetGlobalFlagDeviceId(int32_t v) { gDeviceId = v; }
 
 // -------------------------------------------------------------- constants --
 // Key strings: the reference's values (service/constants.cc:20-72), see constants.h.
-const char* kUnspecified = "unspecified";
-const char* kOpName = "op";
-const char* kNodeType = "nt";
-const char* kEdgeType = "et";
-const char* kType = "tp";
-const char* kSrcType = "st";
-const char* kDstType = "dt";
-const char* kSrcIds = "sid";
-const char* kDstIds = "did";
-const char* kNodeIds = "nid";
-const char* kEdgeIds = "eid";
-const char* kNeighborCount = "nbc";
-const char* kNeighborIds = "nbi";
-const char* kBatchSize = "bs";
-const char* kIsSparse = "is";
-const char* kStrategy = "str";
-const char* kDegreeKey = "deg";
-const char* kWeightKey = "wei";
-const char* kLabelKey = "lb";
-const char* kTimestampKey = "ts";
-const char* kIntAttrKey = "ia";
-const char* kFloatAttrKey = "fa";
-const char* kStringAttrKey = "sa";
-const char* kSideInfo = "si";
-const char* kDirection = "dir";
-const char* kSegmentIds = "segi";
-const char* kNumSegments = "ns";
-const char* kSegments = "sm";
-const char* kDistances = "dis";
-const char* kRowIndices = "ridx";
-const char* kColIndices = "cidx";
-const char* kSeedType = "seedt";
-const char* kNbrType = "nbrt";
-const char* kCount = "cnt";
-const char* kBatchShare = "batch_share";
-const char* kUnique = "unique";
-const char* kIntCols = "icols";
-const char* kIntProps = "ipps";
-const char* kFloatCols = "fcols";
-const char* kFloatProps = "fpps";
-const char* kStrCols = "scols";
-const char* kStrProps = "spps";
-const char* kFilterType = "ftype";
-const char* kFilterField = "field";
-const char* kFilterValues = "filt";
-const char* kDegrees = "dg";
-const char* kEpoch = "ep";
-const char* kNodeFrom = "nf";
-const char* kNeedDist = "need_dist";
-const char* kDistToSrc = "dist_to_src";
-const char* kDistToDst = "dist_to_dst";
-const char* kSparseIds = "sparse_ids";
-const char* kCallCounter = "call_counter";
-const char* kRngRows = "rng_rows";
+#define GLX_DEFINE_TENSOR_KEY(name, wire) const char* name = wire;
+GLX_TENSOR_KEYS(GLX_DEFINE_TENSOR_KEY)
+#undef GLX_DEFINE_TENSOR_KEY
 
 // ----------------------------------------------------------------- tensor --
 // Storage of the numeric tensors.  A response of the device path is one large block

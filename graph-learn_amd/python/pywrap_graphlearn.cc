@@ -134,17 +134,8 @@ PYBIND11_MODULE(pywrap_graphlearn, m) {
 #undef GLX_UNUSED_STR_FLAG
 
   // ---- tensor / parameter keys (py_export.cc:82-131) ----
-#define GLX_KEY(name) m.attr(#name) = name
-  GLX_KEY(kOpName); GLX_KEY(kNodeType); GLX_KEY(kEdgeType); GLX_KEY(kType); GLX_KEY(kSrcType); GLX_KEY(kDstType);
-  GLX_KEY(kSrcIds); GLX_KEY(kDstIds); GLX_KEY(kNodeIds); GLX_KEY(kEdgeIds); GLX_KEY(kNeighborCount);
-  GLX_KEY(kNeighborIds); GLX_KEY(kBatchSize); GLX_KEY(kIsSparse); GLX_KEY(kStrategy); GLX_KEY(kDegreeKey);
-  GLX_KEY(kWeightKey); GLX_KEY(kLabelKey); GLX_KEY(kIntAttrKey); GLX_KEY(kFloatAttrKey); GLX_KEY(kStringAttrKey);
-  GLX_KEY(kSideInfo); GLX_KEY(kDirection); GLX_KEY(kSegmentIds); GLX_KEY(kNumSegments); GLX_KEY(kSegments);
-  GLX_KEY(kDistances); GLX_KEY(kRowIndices); GLX_KEY(kColIndices); GLX_KEY(kSeedType); GLX_KEY(kNbrType);
-  GLX_KEY(kCount); GLX_KEY(kBatchShare); GLX_KEY(kUnique); GLX_KEY(kIntCols); GLX_KEY(kIntProps); GLX_KEY(kFloatCols);
-  GLX_KEY(kFloatProps); GLX_KEY(kStrCols); GLX_KEY(kStrProps); GLX_KEY(kFilterType); GLX_KEY(kFilterField);
-  GLX_KEY(kFilterValues); GLX_KEY(kDegrees); GLX_KEY(kEpoch); GLX_KEY(kNodeFrom); GLX_KEY(kNeedDist);
-  GLX_KEY(kDistToSrc); GLX_KEY(kDistToDst);
+#define GLX_KEY(name, wire) m.attr(#name) = name;
+  GLX_TENSOR_KEYS(GLX_KEY)  // the whole table of constants.h (a superset of what the reference exports)
 #undef GLX_KEY
 
   py::enum_<error::Code>(m, "ErrorCode")
