@@ -65,6 +65,15 @@ def test_dag_unittest_on_cpu():
     assert "7 test(s), 0 failure(s)" in r.stdout, r.stdout
 
 
+@pytest.mark.skipif(os.environ.get("GLX_TSAN") != "1", reason="opt-in (GLX_TSAN=1): a minute of instrumented compilation")
+def test_dag_unittest_under_thread_sanitizer():
+    """scripts/tsan_dag.sh: the same seven tests in a ThreadSanitizer build of the host sources -- the tape store, the
+    scheduler's query threads, Dataset's prefetch thread and close-while-starved leave no report."""
+    r = subprocess.run(["bash", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "tsan_dag.sh")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "ThreadSanitizer: no report" in r.stdout, r.stdout
+
+
 def test_host_library_exports_registry():
     import subprocess as sp
     out = sp.run(["nm", "-DC", os.path.join(LIB, "libglx_host.so")], stdout=sp.PIPE, text=True).stdout
