@@ -16,6 +16,8 @@ LIB = os.path.join(ROOT, "graph-learn_amd", "lib")
 
 
 def _module():
+    if os.environ.get("GLX_REFPY_MODULE"):  # an instrumented build of the extension (scripts/asan_refpy.sh)
+        return os.environ["GLX_REFPY_MODULE"]
     found = glob.glob(os.path.join(ROOT, "graph-learn_amd", "python", "graphlearn", "pywrap_graphlearn*.so"))
     return found[0] if found else None
 
@@ -107,6 +109,8 @@ def env():
     e["PYTHONPATH"] = str(STAGE) + (os.pathsep + e["PYTHONPATH"] if e.get("PYTHONPATH") else "")
     # the extension's copy sits outside the tree: its $ORIGIN-relative rpath no longer finds the engine
     e["LD_LIBRARY_PATH"] = LIB + (os.pathsep + e["LD_LIBRARY_PATH"] if e.get("LD_LIBRARY_PATH") else "")
+    if os.environ.get("GLX_REFPY_PRELOAD"):  # the sanitizer's runtime must be the first library of the interpreter
+        e["LD_PRELOAD"] = os.environ["GLX_REFPY_PRELOAD"]
     return e
 
 
