@@ -4,11 +4,12 @@
 #   bash scripts/asan_host.sh run          on a GPU box: runs them, exit code 0 = no report
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)/graph-learn_amd
-O=$R/lib/asan
+SAN=${SAN:-address}   # SAN=undefined: UndefinedBehaviorSanitizer instead
+O=$R/lib/san_$SAN
 if [ "$1" = build ]; then
   mkdir -p $O
   for t in sampler_unittest aggregating_op_unittest partition_stitch_unittest graph_op_unittest request_unittest loader_unittest dag_unittest; do
-    g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -fPIC -pthread -I$R/../include -I$R/host/include -I$R/host/test \
+    g++ -std=c++17 -O1 -g -fsanitize=$SAN -fno-sanitize-recover=all -fno-omit-frame-pointer -fPIC -pthread -I$R/../include -I$R/host/include -I$R/host/test \
       $R/host/src/*.cc $R/host/test/$t.cpp -o $O/$t -L$R/lib -lglx -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib &
   done
   wait
