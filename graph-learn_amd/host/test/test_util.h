@@ -40,6 +40,7 @@ struct TestRegistrar {
 #define EXPECT_FLOAT_EQ(a, b) EXPECT_TRUE(std::fabs((double)(a) - (double)(b)) <= 4e-7 * std::fabs((double)(b)))
 
 inline int RunAllTests() {
+  std::setvbuf(stdout, nullptr, _IOLBF, 0);  // a run that dies (or is killed by a tool) still shows how far it got
   for (auto& t : AllTests()) {
     int before = Failures();
     std::printf("[ RUN  ] %s\n", t.name.c_str());
@@ -47,6 +48,7 @@ inline int RunAllTests() {
     std::printf("[ %s ] %s\n", Failures() == before ? " OK " : "FAIL", t.name.c_str());
   }
   std::printf("%d test(s), %d failure(s)\n", (int)AllTests().size(), Failures());
+  std::fflush(stdout);
   return Failures() == 0 ? 0 : 1;
 }
 #endif
