@@ -4,6 +4,8 @@
 # mirror and its unit test programs with the same compiler and runtime.
 #   bash scripts/asan_device_lib_host_side.sh build     here (cross-compiles)
 #   bash scripts/asan_device_lib_host_side.sh run       on a GPU box; exit code 0 = no report
+# (The Python GPU tests cannot run this way: with the sanitizer runtime preloaded into an interpreter that also holds
+# torch's bundled HIP runtime, the runtime's hsa_amd_memory_pool_allocate interceptor fails every device allocation.)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 R=$ROOT/graph-learn_amd
