@@ -17,7 +17,7 @@ from oracle_bindings import Oracle  # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 orc = Oracle()
 dev = torch.device("cuda", 0)
-rng = np.random.default_rng(20260924)
+rng = np.random.default_rng(int(os.environ.get("GLX_SWEEP_SEED", "20260924")))
 tables = {}
 for D in (4, 64, 256):
     X = rng.standard_normal((2000, D)).astype(np.float32)
