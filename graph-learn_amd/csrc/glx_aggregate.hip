@@ -757,40 +757,70 @@ int run_aggregate(AggArgs& a, int op, const int32_t* d_seg, int32_t num_ids, hip
 
 // Segment bookkeeping shared by the single-table and the multi-source entry: fills
 // a.seg_start (or a.fanout for uniform segments) from scratch laid out by the caller.
-// scratch = seg_start (Sg + 1).
+// scratch = seg_start (Sg + 1) + kSegScratchExtra int32 (a captured call's two words).
 namespace {
 // Two 64-bit words per (calling thread, device, stream) -- the same scope as the scratch workspace, so that host
 // threads that share a stream (the default one, say) do not raise each other's words -- zeroed when made, freed with the
-// thread.  A recycled stream handle finds words tagged with an older epoch, which read as "nothing raised".
+// thread.  The epoch that tags them is the BUFFER's own counter (round 6; a process-wide counter wrapped after 2^32
+// explicit-segment_ids calls of all threads together, after which stale words carried larger tags than new calls and
+// atomicMax never landed: ADVICE r05): every call on a buffer is ordered on its stream, so when the counter wraps the
+// words are cleared by a memset on that stream and counting restarts at 1 -- no tag of an earlier lap can be seen again.
+// A recycled stream handle finds words of an older epoch of the same buffer, which read as "nothing raised".
+struct SegBuf {
+  int dev;
+  hipStream_t stream;
+  unsigned long long* words;
+  uint32_t epoch;  // the last epoch handed out (0 = none yet: 0 tags the zeroed words)
+};
+constexpr size_t kSegBufsMax = 64;  // streams a thread keeps words for; the oldest goes when a 65th shows up
 struct SegWords {
-  std::vector<std::tuple<int, hipStream_t, unsigned long long*>> bufs;
+  std::vector<SegBuf> bufs;
   ~SegWords() {
     for (auto& e : bufs) {  // best effort: at process exit the runtime may already be gone
-      if (hipSetDevice(std::get<0>(e)) == hipSuccess) (void)hipFree(std::get<2>(e));
+      if (hipSetDevice(e.dev) == hipSuccess) (void)hipFree(e.words);
     }
     (void)hipGetLastError();
   }
 };
 thread_local SegWords g_seg_words;
-std::atomic<uint32_t> g_seg_epoch{1};
 
-int seg_words_for(hipStream_t s, unsigned long long** out) {
+// *out = the words of (this thread, the current device, s) and the next epoch on them.  Never called while s is being
+// captured (prepare_segments keeps a captured call's words in the call's own scratch): it may allocate.
+int seg_words_for(hipStream_t s, unsigned long long** out, uint32_t* epoch) {
   int dev = 0;
   GLX_HIP(hipGetDevice(&dev));
+  SegBuf* buf = nullptr;
   for (auto& e : g_seg_words.bufs) {
-    if (std::get<0>(e) == dev && std::get<1>(e) == s) {
-      *out = std::get<2>(e);
-      return GLX_OK;
+    if (e.dev == dev && e.stream == s) {
+      buf = &e;
+      break;
     }
   }
-  unsigned long long* p = nullptr;
-  GLX_HIP(hipMalloc(&p, 256));
-  GLX_HIP(hipMemsetAsync(p, 0, 256, s));  // ordered before the first scan on this stream
-  g_seg_words.bufs.emplace_back(dev, s, p);
-  *out = p;
+  if (buf == nullptr) {
+    if (g_seg_words.bufs.size() >= kSegBufsMax) {  // streams come and go: drop the oldest (hipFree waits for its readers)
+      const SegBuf old = g_seg_words.bufs.front();
+      g_seg_words.bufs.erase(g_seg_words.bufs.begin());
+      GlxDeviceGuard guard(old.dev);
+      (void)hipFree(old.words);
+    }
+    unsigned long long* p = nullptr;
+    GLX_HIP(hipMalloc(&p, 256));
+    GLX_HIP(hipMemsetAsync(p, 0, 256, s));  // ordered before the first scan on this stream
+    g_seg_words.bufs.push_back(SegBuf{dev, s, p, 0u});
+    buf = &g_seg_words.bufs.back();
+  }
+  if (++buf->epoch == 0) {  // wrapped: clear the words behind every earlier call of this stream, restart at 1
+    GLX_HIP(hipMemsetAsync(buf->words, 0, 16, s));
+    buf->epoch = 1;
+  }
+  *out = buf->words;
+  *epoch = buf->epoch;
   return GLX_OK;
 }
 }  // namespace
+
+// int32 words a caller adds to its scratch allocation behind seg_start[num_segments + 1] for prepare_segments
+constexpr size_t kSegScratchExtra = 6;  // two 8-byte aligned 64-bit words
 
 int prepare_segments(AggArgs& a, const int32_t* d_seg, int32_t num_ids, int32_t num_segments, int32_t* scratch,
                      hipStream_t s) {
@@ -802,21 +832,25 @@ int prepare_segments(AggArgs& a, const int32_t* d_seg, int32_t num_ids, int32_t 
   }
   int32_t* seg_start = scratch;
   unsigned long long* words = nullptr;
-  int rc = seg_words_for(s, &words);
-  if (rc != GLX_OK) return rc;
-  // uniform segments are possible when the ids divide evenly; the scan then checks seg[i] == i / fanout
-  const int32_t f = (num_segments > 0 && num_ids > 0 && num_ids % num_segments == 0) ? num_ids / num_segments : 0;
   SegState st;
-  st.words = words;
-  st.epoch = g_seg_epoch.fetch_add(1, std::memory_order_relaxed);
-  if (st.epoch == 0) st.epoch = g_seg_epoch.fetch_add(1, std::memory_order_relaxed);  // 0 tags the zeroed words
-  st.floor_level = num_ids == 0 ? 2 : (f > 0 ? 0 : 1);
   // A captured launch is replayed with the SAME epoch: the words a replay raised would still carry it in the next
-  // replay.  Captured launches therefore reset the words first (one more node in the graph).
+  // replay -- and the per-stream buffer may not even exist yet (no allocation inside a capture), nor is the capture
+  // stream the one a replay runs on.  A captured call therefore keeps its two words in its OWN scratch (the plan's
+  // replayable arena), cleared by one more node of the graph.
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+    const uintptr_t at = (reinterpret_cast<uintptr_t>(scratch + (size_t)num_segments + 1) + 7) & ~(uintptr_t)7;
+    words = reinterpret_cast<unsigned long long*>(at);
+    st.epoch = 1;
     glx_seg_reset_kernel<<<1, 1, 0, s>>>(words);
+  } else {
+    int rc = seg_words_for(s, &words, &st.epoch);
+    if (rc != GLX_OK) return rc;
   }
+  // uniform segments are possible when the ids divide evenly; the scan then checks seg[i] == i / fanout
+  const int32_t f = (num_segments > 0 && num_ids > 0 && num_ids % num_segments == 0) ? num_ids / num_segments : 0;
+  st.words = words;
+  st.floor_level = num_ids == 0 ? 2 : (f > 0 ? 0 : 1);
   if (num_ids > 0) {
     glx_seg_scan_kernel<<<(unsigned)(((int64_t)num_ids + 1023) / 1024), 256, 0, s>>>(d_seg, num_ids, num_segments, f, words,
                                                                                    st.epoch, seg_start);
@@ -832,11 +866,11 @@ int aggregate_device(const glx_features* f, int op, const int64_t* d_ids, const 
                      int32_t* d_cnt, hipStream_t s) {
   // scratch: seg_start (Sg+1) [+ rows (N) for hashed ids]
   const bool hashed = f->idmap.any();  // raw ids are not rows: translate first (a table lookup, or arithmetic)
-  const size_t n_i32 = (size_t)num_segments + 1 + (hashed ? (size_t)num_ids : 0);
+  const size_t n_i32 = (size_t)num_segments + 1 + kSegScratchExtra + (hashed ? (size_t)num_ids : 0);
   int32_t* scratch = nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), n_i32 * sizeof(int32_t), s, 1);
   if (rc != GLX_OK) return rc;
-  int32_t* rows = hashed ? scratch + num_segments + 1 : nullptr;
+  int32_t* rows = hashed ? scratch + num_segments + 1 + kSegScratchExtra : nullptr;
   AggArgs a;
   memset(&a, 0, sizeof(a));
   rc = prepare_segments(a, d_seg, num_ids, num_segments, scratch, s);
@@ -928,7 +962,7 @@ int glx_aggregate_vrows_device(const GlxRowSource* src, int nsrc, int32_t dim, i
                                const int32_t* d_seg, int32_t num_ids, int32_t num_segments, float default_attr,
                                float* d_emb, int32_t* d_cnt, hipStream_t s) {
   int32_t* scratch = nullptr;
-  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), ((size_t)num_segments + 1 + 2) * sizeof(int32_t), s, 1);
+  int rc = glx_scratch_alloc(reinterpret_cast<void**>(&scratch), ((size_t)num_segments + 1 + kSegScratchExtra) * sizeof(int32_t), s, 1);
   if (rc != GLX_OK) return rc;
   AggArgs a;
   memset(&a, 0, sizeof(a));
@@ -977,6 +1011,12 @@ extern "C" int glx_tune(const char* name, int32_t value) {
   else if (strcmp(name, "agg_xcd_slices") == 0) slot = &k.xcd;
   else if (strcmp(name, "agg_occupancy") == 0) slot = &k.occ;
   else if (strcmp(name, "agg_store") == 0) slot = &k.store;
+  else if (strcmp(name, "seg_epochs_before_wrap") == 0) {
+    // test aid: the calling thread's segment-word buffers hand out `value` more epochs before their counter wraps
+    GLX_REQUIRE(value >= 0, "seg_epochs_before_wrap must be >= 0");
+    for (auto& e : g_seg_words.bufs) e.epoch = 0xffffffffu - (uint32_t)value;
+    return GLX_OK;
+  }
   if (slot == nullptr) {  // the side paths' knobs (glx_common.h GlxSideKnobs): -1 restores the default
     GlxSideKnobs& sk = glx_side_knobs();
     std::atomic<int64_t>* side = nullptr;
@@ -987,6 +1027,8 @@ extern "C" int glx_tune(const char* name, int32_t value) {
     else if (strcmp(name, "idmap_hash_only") == 0) side = &sk.idmap_hash_only;
     else if (strcmp(name, "resolve_ids") == 0) side = &sk.resolve_ids;
     else if (strcmp(name, "resolve_blocks") == 0) side = &sk.resolve_blocks;
+    else if (strcmp(name, "resolve_set_share") == 0) side = &sk.resolve_set_share;
+    else if (strcmp(name, "resolve_peek") == 0) side = &sk.resolve_peek;
     GLX_REQUIRE(side != nullptr, "unknown knob '%s'", name);
     side->store(value, std::memory_order_relaxed);
     return GLX_OK;

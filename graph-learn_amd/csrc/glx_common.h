@@ -170,6 +170,19 @@ struct GlxMember {
 // `member` (optional): the same set as a bitmap -- a few MB that stay in L2 where the hash probe is a random DRAM access.
 int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert, GlxMember member,
                          int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s);
+// Values the kernel that writes the bucket sizes also writes beside them (counts[at + j] = v[j], j < n; bucket sizes
+// from index `at` on are then NOT written -- the distributed store ships the P owners' sizes + the parameters and
+// keeps the diverted bucket's size to itself): a partitioned request's scalar parameters travel with its counts, and
+// a launch of their own to put them there costs as much as partitioning a small request (glx_dist.hip).
+struct GlxPartitionTail {
+  int64_t v[12];
+  int32_t n;
+  int32_t at;
+};
+// glx_partition (divert.keys == nullptr && divert.step == 0: num_buckets = num_shards) or glx_partition_divert
+// (num_buckets = num_shards + 1) with a tail; device already selected.  An empty request is ONE small launch.
+int glx_partition_tail(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert, GlxMember member,
+                       int64_t* bucketed, int64_t* order, int64_t* counts, const GlxPartitionTail& tail, hipStream_t s);
 void glx_idmap_free(GlxIdMapStorage* m);
 struct glx_features;
 // glx_features_create; allow_arithmetic_ids = false keeps a hash table whatever the ids look like (the hot-row replica
@@ -211,6 +224,8 @@ struct GlxSideKnobs {
   std::atomic<int64_t> filter_dedup_min_rows{-1}; // GLX_FILTER_DEDUP_MIN_ROWS: rows from which (vertex, value) pairs share a table; 0 disables
   std::atomic<int64_t> resolve_ids{-1};           // GLX_RESOLVE_IDS=4|8: ids per thread per pass of the partitioned aggregation's resolve kernel (default 2)
   std::atomic<int64_t> resolve_blocks{-1};        // GLX_RESOLVE_BLOCKS=n: workgroups of that kernel (default 1024)
+  std::atomic<int64_t> resolve_set_share{-1};     // GLX_RESOLVE_SET_SHARE=n: the halo id set holds at least n / 1024 of a request's ids (A/B; default 16 once a share is known)
+  std::atomic<int64_t> resolve_peek{-1};          // GLX_RESOLVE_PEEK=0: no plain load of a set slot before the compare-and-swap (A/B)
   std::atomic<int64_t> idmap_hash_only{-1};       // GLX_IDMAP_HASH_ONLY (set = 1): feature tables keep a hash table even for arithmetic ids (A/B)
 };
 GlxSideKnobs& glx_side_knobs();  // glx_graph.hip

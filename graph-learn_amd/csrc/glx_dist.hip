@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void glx_dist_stitch2_kernel(const int64_t* __
 //   [2P]       overflow flag (set table too small)  [2P+1..3] ids served by replica / own shard /
 //   [2P+4 ..]  exclusive offsets per owner (P + 1)            remote (with repeats)
 //   [3P+5]     distinct halo ids inserted so far (all owners)
+//   [3P+6]     workgroups of the resolve kernel that have finished (the last one turns the counts into offsets)
 // The replica's id map with key and row in ONE 16-byte slot: a probe is a single load (the generic GlxIdMap
 // keeps keys and rows in two arrays = two dependent random loads per hit, and every id of a request probes it).
 struct PackedSlot {
@@ -159,7 +160,46 @@ struct ResolveArgs {
   int64_t bm_max;
   int32_t insert_limit;  // distinct ids the set takes before it counts as too small (60 % of its slots)
   int32_t max_probe;     // probes before a lookup gives up on a set that is too small; unbounded at the safe size
+  // kQueue: where the remote cold ids sit in the request, so that pass 4 rewrites those entries only (round 6; it used
+  // to stream all of loc for the few percent that were pending).  Workgroup b owns cold_idx[b * region, (b + 1) * region)
+  // -- region = the ids one workgroup resolves, so its list cannot overflow and no global counter is shared -- and
+  // leaves its length in cold_cnt[b].
+  int32_t* cold_idx;
+  int32_t* cold_cnt;
+  int64_t region;
+  // pass 2, run by the LAST workgroup to finish (a launch of its own for one thread's work was the price of a small
+  // request's whole resolve): the values every rank shares, and the requester's default_attr behind them
+  int64_t* vals;
+  float default_attr;
+  int32_t peek;  // 1: load a set slot before trying to claim it (resolve_cold)
 };
+
+// Pass 2 (one thread): per-owner offsets, and the values every rank shares:
+// vals[0..P) = ids requested from each owner, [P] overflow, [P+1] distinct total,
+// [P+2..4] replica / own / remote id counts, [P+5] the requester's default_attr (float bits).
+// kCoherent: called by the last workgroup of the kernel whose other workgroups raised the counters with device-scope
+// atomics -- read them the same way (an atomic at the L2 / memory side; a plain load could be served by this CU's L1 or
+// this XCD's L2 with a line fetched before the peers' atomics landed).
+template <bool kCoherent>
+__device__ __forceinline__ void dist_offsets_body(int32_t* ctr, int32_t P, int64_t* vals, float default_attr) {
+  auto rd = [&](int32_t i) -> int32_t { return kCoherent ? atomicAdd(&ctr[i], 0) : ctr[i]; };
+  int32_t* off = ctr + 2 * P + 4;
+  int32_t total = 0;
+  for (int32_t p = 0; p < P; ++p) {
+    const int32_t c = rd(p);
+    off[p] = total;
+    vals[p] = c;
+    total += c;
+    ctr[P + p] = 0;
+  }
+  off[P] = total;
+  vals[P] = rd(2 * P);
+  vals[P + 1] = total;
+  vals[P + 2] = rd(2 * P + 1);
+  vals[P + 3] = rd(2 * P + 2);
+  vals[P + 4] = rd(2 * P + 3);
+  vals[P + 5] = (int64_t)(uint32_t)__float_as_uint(default_attr);
+}
 
 // Pass 1: every id -> a virtual row (own shard / replica), -1 (default row), or -(h + 2) when
 // it is remote and cold: h = its slot in the open-addressing set of distinct halo ids.
@@ -178,9 +218,12 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   __shared__ int32_t s_sum;
   __shared__ int32_t s_void;  // the overflow flag as of the last flush (reading the global flag per id made one
                               // L2 address the hot spot of the kernel)
+  __shared__ int32_t s_list_n;  // kQueue: entries of this workgroup's cold list
+  __shared__ int32_t s_last;
   if (threadIdx.x == 0) {
     s_void = 0;
     s_sum = 0;
+    s_list_n = 0;
   }
   if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
   if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
@@ -210,16 +253,27 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
       uint64_t h = glx_mix64((uint64_t)id) & a.tmask;
       int probes = 0;
       while (true) {
-        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&a.tkeys[h]),
-                                                  (unsigned long long)GLX_EMPTY_KEY, (unsigned long long)id);
-        if ((int64_t)prev == GLX_EMPTY_KEY || (int64_t)prev == id) {
-          winner = (int64_t)prev == GLX_EMPTY_KEY;
+        // A slot's key never changes once set, so a plain load that returns a key is final; one that returns "empty"
+        // may be stale (this XCD's L2 is not coherent with the others') and only then is the compare-and-swap paid.
+        // Most cold ids of a request repeat (0.63 M occurrences of 0.25 M distinct ids in the headline's 18 M-id
+        // request at P = 8): their later occurrences find the key with a load.
+        int64_t cur = a.peek ? *reinterpret_cast<const volatile int64_t*>(&a.tkeys[h]) : GLX_EMPTY_KEY;
+        if (cur == GLX_EMPTY_KEY) {
+          cur = (int64_t)atomicCAS(reinterpret_cast<unsigned long long*>(&a.tkeys[h]), (unsigned long long)GLX_EMPTY_KEY,
+                                   (unsigned long long)id);
+          if (cur == GLX_EMPTY_KEY) {
+            winner = true;  // the first to claim the slot
+            out = -(int32_t)h - 2;
+            break;
+          }
+        }
+        if (cur == id) {
           out = -(int32_t)h - 2;
           break;
         }
         h = (h + 1) & a.tmask;
         if (++probes > a.max_probe) {  // the set is too small: the host retries with a larger one
-          a.ctr[2 * a.P] = 1;
+          atomicExch(&a.ctr[2 * a.P], 1);
           break;
         }
       }
@@ -245,8 +299,22 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
     // the overflow flag once per 64 ids (per id it made one L2 address the hot spot of the kernel); no block-wide
     // flush in this mode: its barriers made every wave wait for whichever wave was serving its queue (0.51 -> 0.19 ms)
     const int32_t voided = __shfl(lane == 0 ? __atomic_load_n(&a.ctr[2 * a.P], __ATOMIC_RELAXED) : 0, 0);
-    if (lane < count) a.loc[qi[lane]] = resolve_cold(qid[lane], owner, winner, voided);
+    int32_t out = 0;
+    if (lane < count) {
+      out = resolve_cold(qid[lane], owner, winner, voided);
+      a.loc[qi[lane]] = out;
+    }
     count_winners(winner, owner);
+    // the entries pass 4 must rewrite (halo set slots): remembered per workgroup, one LDS atomic per batch
+    const uint64_t pend = __ballot(lane < count && out <= -2);
+    if (pend && a.cold_idx) {
+      int32_t at = 0;
+      if (lane == 0) at = atomicAdd(&s_list_n, __popcll(pend));
+      at = __shfl(at, 0);
+      if (lane < count && out <= -2) {
+        a.cold_idx[(int64_t)blockIdx.x * a.region + at + __popcll(pend & ((1ull << lane) - 1ull))] = qi[lane];
+      }
+    }
   };
   // kIds ids per thread per iteration: the loads of the replica lookup (the common case: a hop-2 request finds
   // ~96 % of its ids there) are independent and issued back to back; the rare rest is handled id by id.
@@ -353,7 +421,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
         s_sum = sum;
         if (fresh) {
           const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], fresh);
-          if (before + fresh > a.insert_limit) a.ctr[2 * a.P] = 1;
+          if (before + fresh > a.insert_limit) atomicExch(&a.ctr[2 * a.P], 1);
         }
         s_void = __atomic_load_n(&a.ctr[2 * a.P], __ATOMIC_RELAXED);
       }
@@ -365,6 +433,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   atomicAdd(&s_stat[1], n_own);
   atomicAdd(&s_stat[2], n_cold);
   __syncthreads();
+  // (every atomic below is fenced by its thread before the workgroup takes its ticket)
   if (threadIdx.x < 3 && s_stat[threadIdx.x]) atomicAdd(&a.ctr[2 * a.P + 1 + threadIdx.x], s_stat[threadIdx.x]);
   if ((int)threadIdx.x < a.P && s_cnt[threadIdx.x]) atomicAdd(&a.ctr[threadIdx.x], s_cnt[threadIdx.x]);
   if (threadIdx.x == 0) {
@@ -373,38 +442,55 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
     const int32_t fresh = sum - s_sum;
     if (fresh) {
       const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], fresh);
-      if (before + fresh > a.insert_limit) a.ctr[2 * a.P] = 1;
+      if (before + fresh > a.insert_limit) atomicExch(&a.ctr[2 * a.P], 1);
     }
+    if (kQueue && a.cold_cnt) a.cold_cnt[blockIdx.x] = s_list_n;
+  }
+  // Pass 2 in the same launch: the last workgroup to get here has every other workgroup's counts before it (each
+  // raised them with device-scope atomics, fenced, then took its ticket)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(&a.ctr[3 * a.P + 6], 1) == (int32_t)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    dist_offsets_body<true>(a.ctr, a.P, a.vals, a.default_attr);
   }
 }
 
-// Pass 2 (one wave): per-owner offsets, and the values every rank shares:
-// vals[0..P) = ids requested from each owner, [P] overflow, [P+1] distinct total,
-// [P+2..4] replica / own / remote id counts.
-__global__ void glx_dist_offsets_kernel(int32_t* ctr, int32_t P, uint64_t tcap, int64_t* vals) {
+// Pass 2 for a request without ids (no resolve launch): the shared values of an empty request.  The counter block need
+// not be cleared first: kZero treats it as zeros and leaves it so.
+__global__ void glx_dist_offsets_kernel(int32_t* ctr, int32_t P, int64_t* vals, float default_attr) {
   if (threadIdx.x != 0) return;
-  int32_t* off = ctr + 2 * P + 4;
-  int32_t total = 0;
-  for (int32_t p = 0; p < P; ++p) {
-    off[p] = total;
-    vals[p] = ctr[p];
-    total += ctr[p];
-    ctr[P + p] = 0;
+  for (int32_t i = 0; i < 3 * P + 8; ++i) ctr[i] = 0;
+  dist_offsets_body<false>(ctr, P, vals, default_attr);
+}
+
+// Pass 4 over the cold lists (kQueue resolve): workgroup b rewrites the entries workgroup b of the resolve listed.
+__global__ __launch_bounds__(256) void glx_dist_finalize_list_kernel(int32_t* __restrict__ loc,
+                                                                     const int32_t* __restrict__ cold_idx,
+                                                                     const int32_t* __restrict__ cold_cnt, int64_t region,
+                                                                     const int32_t* __restrict__ tvals, int32_t halo_base) {
+  const int32_t m = cold_cnt[blockIdx.x];
+  const int32_t* mine = cold_idx + (int64_t)blockIdx.x * region;
+  for (int32_t j = threadIdx.x; j < m; j += 256) {
+    const int32_t i = mine[j];
+    const int32_t v = loc[i];
+    if (v <= -2) loc[i] = halo_base + tvals[-(v + 2)];
   }
-  off[P] = total;
-  vals[P] = ctr[2 * P];
-  vals[P + 1] = total;
-  vals[P + 2] = ctr[2 * P + 1];
-  vals[P + 3] = ctr[2 * P + 2];
-  vals[P + 4] = ctr[2 * P + 3];
-  (void)tcap;
 }
 
 // Pass 3: compact the set into per-owner buckets (the ids each owner is asked for) and give
 // every member its halo row = position in that concatenation.  A block takes a tile of kAssignTile
-// slots at a time: count its members per owner in LDS, reserve the block's ranges with P global
-// atomics, then place the members (order inside a bucket is arbitrary; results do not depend on it).
-constexpr int kAssignTile = 4096;
+// slots at a time -- kAssignPer per thread, read ONCE and kept in registers: count its members per owner in LDS,
+// reserve the block's ranges with P global atomics, then place the members (order inside a bucket is arbitrary;
+// results do not depend on it).  (Rounds 2-5 read every tile twice, 4096 slots per tile: 0.10 ms for the 8 M slots
+// behind the headline's 18 M-id request, a few hundred workgroups of sixteen dependent passes each.)
+constexpr int kAssignPer = 4;
+constexpr int kAssignTile = 256 * kAssignPer;
 __global__ __launch_bounds__(256) void glx_dist_assign_kernel(const int64_t* __restrict__ tkeys, uint64_t tcap,
                                                               int32_t* __restrict__ tvals, int32_t* ctr, int32_t P,
                                                               int64_t* __restrict__ cold_ids) {
@@ -417,17 +503,26 @@ __global__ __launch_bounds__(256) void glx_dist_assign_kernel(const int64_t* __r
   if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   for (uint64_t tile = blockIdx.x * (uint64_t)kAssignTile; tile < tcap; tile += gridDim.x * (uint64_t)kAssignTile) {
-    // count
-    for (int j = 0; j < kAssignTile / 256; ++j) {
+    int64_t key[kAssignPer];
+    int32_t owner[kAssignPer];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kAssignPer; ++j) {
       const uint64_t h = tile + j * 256 + threadIdx.x;
-      const int64_t key = h < tcap ? tkeys[h] : GLX_EMPTY_KEY;
-      const bool live = key != GLX_EMPTY_KEY;
-      const int32_t owner = live ? dist_owner(key, P) : 0;
+      key[j] = h < tcap ? tkeys[h] : GLX_EMPTY_KEY;
+      any = any || key[j] != GLX_EMPTY_KEY;
+    }
+    if (!__syncthreads_or(any)) continue;  // an empty tile (the set is sized for a multiple of what it holds)
+    // count
+#pragma unroll
+    for (int j = 0; j < kAssignPer; ++j) {
+      const bool live = key[j] != GLX_EMPTY_KEY;
+      owner[j] = live ? dist_owner(key[j], P) : 0;
       uint64_t pending = __ballot(live);
       while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
-        const int32_t o = __shfl(owner, leader);
-        const uint64_t same = __ballot(live && owner == o);
+        const int32_t o = __shfl(owner[j], leader);
+        const uint64_t same = __ballot(live && owner[j] == o);
         if (lane == leader) atomicAdd(&s_cnt[o], __popcll(same));
         pending &= ~same;
       }
@@ -440,23 +535,22 @@ __global__ __launch_bounds__(256) void glx_dist_assign_kernel(const int64_t* __r
     }
     __syncthreads();
     // place
-    for (int j = 0; j < kAssignTile / 256; ++j) {
+#pragma unroll
+    for (int j = 0; j < kAssignPer; ++j) {
       const uint64_t h = tile + j * 256 + threadIdx.x;
-      const int64_t key = h < tcap ? tkeys[h] : GLX_EMPTY_KEY;
-      const bool live = key != GLX_EMPTY_KEY;
-      const int32_t owner = live ? dist_owner(key, P) : 0;
+      const bool live = key[j] != GLX_EMPTY_KEY;
       uint64_t pending = __ballot(live);
       while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
-        const int32_t o = __shfl(owner, leader);
-        const uint64_t same = __ballot(live && owner == o);
+        const int32_t o = __shfl(owner[j], leader);
+        const uint64_t same = __ballot(live && owner[j] == o);
         int32_t start = 0;
         if (lane == leader) start = atomicAdd(&s_cnt[o], __popcll(same));
         start = __shfl(start, leader);
-        if (live && owner == o) {
+        if (live && owner[j] == o) {
           const int32_t pos = off[o] + s_base[o] + start + __popcll(same & lt);
           tvals[h] = pos;
-          cold_ids[pos] = key;
+          cold_ids[pos] = key[j];
         }
         pending &= ~same;
       }
@@ -476,8 +570,10 @@ __global__ void glx_dist_finalize_kernel(int32_t* __restrict__ loc, int64_t n, c
   if (v <= -2) loc[i] = halo_base + tvals[-(v + 2)];
 }
 
-__global__ void glx_dist_fill_keys_kernel(int64_t* keys, uint64_t cap) {
+// ... and the counter block of the resolve passes, cleared by the same launch (it was a memset of its own)
+__global__ void glx_dist_fill_keys_kernel(int64_t* keys, uint64_t cap, int32_t* ctr, int32_t nctr) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && (int32_t)threadIdx.x < nctr) ctr[threadIdx.x] = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < cap; i += stride) keys[i] = GLX_EMPTY_KEY;
 }
@@ -917,6 +1013,7 @@ struct glx_dist_store {
   int64_t* d_vals = nullptr;  // [world + 8] values shared by the count exchange
   int32_t* d_ctr = nullptr;   // [3 * world + 8] counter block of the resolve passes
   double halo_share = 0.0;  // largest (distinct halo ids / request ids) seen so far
+  bool halo_share_known = false;  // ... by at least one request with ids
   // every count exchange blocks the calling host thread until the slowest rank's counts have arrived: how often, and
   // for how long, since the store was created (glx_dist_stats.host_syncs / host_stall_us)
   int64_t host_syncs = 0, host_stall_us = 0;
@@ -1045,22 +1142,51 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
   stat.ids = n;
 
   const int nvals = P + 6;  // + the requester's default_attr (what its unknown ids look like)
-  // request-sized buffers: loc[n] (int32) + cold_ids[n] (int64; at most n distinct)
+  // The resolve launch.  Few, long-lived blocks: every block pays global atomics at its flushes and exit (a 16 M-id
+  // request: 0.27 ms with 4096 blocks, 0.16 ms with 1024, 0.8 ms with 65536).  Two ids per thread-iteration with
+  // the rank records (0.10 ms; one: 0.12, four: 0.12), one with the hash map (0.30; two: 0.32, four: 0.34) --
+  // scripts/resolve_probe.py.  With a replica the ids it does not hold are a small share of the request: queued per
+  // wave and resolved 64 at a time (kQueue); without one every id takes that path and a queue would only add work.
+  static const bool kNoQueue = getenv("GLX_RESOLVE_NO_QUEUE") != nullptr;  // (ablation)
+  const bool has_cache = st->cache != nullptr;
+  const bool ranked = has_cache && st->bm_member != nullptr;
+  const bool queue = has_cache && !kNoQueue;
+  int per = ranked ? 2 : 1;  // ids per thread per pass
+  int64_t nb = 1024;
+  if (queue) {
+    const int64_t kper = glx_side_knobs().resolve_ids.load(std::memory_order_relaxed);  // (A/B)
+    const int64_t kb = glx_side_knobs().resolve_blocks.load(std::memory_order_relaxed);
+    if (ranked && (kper == 8 || kper == 4)) per = (int)kper;
+    if (kb > 0) nb = kb;
+  }
+  const unsigned rgrid = grid_for((n + per - 1) / per, nb);
+  // ids one workgroup resolves at most = its cold list's capacity (kQueue)
+  const int64_t tile = 256ll * per;
+  const int64_t region = ((n + (int64_t)rgrid * tile - 1) / ((int64_t)rgrid * tile)) * tile;
+  // request-sized buffers: loc[n] (int32) + cold_ids[n] (int64; at most n distinct) + the cold lists
   Carver cv;
   const size_t o_loc = cv.take((size_t)(n > 0 ? n : 1) * 4);
   const size_t o_cold = cv.take((size_t)(n > 0 ? n : 1) * 8);
+  const size_t o_list = cv.take(queue && P > 1 ? (size_t)rgrid * (size_t)region * 4 : 0);
+  const size_t o_lcnt = cv.take(queue && P > 1 ? (size_t)rgrid * 4 : 0);
   int rc = sl.req.ensure(cv.at);
   if (rc != GLX_OK) return rc;
   int32_t* loc = reinterpret_cast<int32_t*>(sl.req.p + o_loc);
   int64_t* cold_ids = reinterpret_cast<int64_t*>(sl.req.p + o_cold);
+  int32_t* cold_idx = queue && P > 1 ? reinterpret_cast<int32_t*>(sl.req.p + o_list) : nullptr;
+  int32_t* cold_cnt = queue && P > 1 ? reinterpret_cast<int32_t*>(sl.req.p + o_lcnt) : nullptr;
 
-  // Set of distinct halo ids.  Sized for the request at hand: a quarter of its ids, or 2.5x the largest share
-  // of distinct halo ids this store has seen (a hop-2 and a hop-1 request alternate: sizing from the PREVIOUS
-  // request's absolute count made every other call overflow), and regrown to the safe bound 2n -- on the ranks
-  // that overflowed, in lockstep with the others -- when that is not enough.
+  // Set of distinct halo ids.  Sized for the request at hand: 2.5x the largest share of distinct halo ids this store
+  // has seen (a hop-2 and a hop-1 request alternate: sizing from the PREVIOUS request's absolute count made every
+  // other call overflow) -- a quarter of the request's ids while nothing has been seen yet (round 6: that quarter
+  // used to be the floor for good: 8 M slots to clear and to compact for the 0.25 M distinct halo ids of the
+  // headline's 18 M-id request, 0.15 ms of a rank-step) -- and regrown to the safe bound 2n -- on the ranks that
+  // overflowed, in lockstep with the others -- when that is not enough.
   const uint64_t safe_cap = pow2_at_least((uint64_t)(n > 0 ? n : 1) * 2);
-  double share = 2.5 * st->halo_share;
-  if (share < 0.25) share = 0.25;
+  double share = st->halo_share_known ? 2.5 * st->halo_share : 0.25;
+  const int64_t floor_1024 = glx_side_knobs().resolve_set_share.load(std::memory_order_relaxed);
+  const double floor_share = floor_1024 > 0 ? (double)floor_1024 / 1024.0 : 1.0 / 64;
+  if (share < floor_share) share = floor_share;
   uint64_t tcap = P == 1 ? 64 : pow2_at_least((uint64_t)((double)(n > 0 ? n : 1) * share) + 65536);
   if (tcap > safe_cap) tcap = safe_cap;
   bool first = true, mine_overflow = false;
@@ -1073,60 +1199,58 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
       if (rc != GLX_OK) return rc;
       tkeys = reinterpret_cast<int64_t*>(sl.tab.p);
       tvals = reinterpret_cast<int32_t*>(sl.tab.p + (((size_t)tcap * 8 + 255) & ~(size_t)255));
-      glx_dist_fill_keys_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap);
-      GLX_HIP(hipMemsetAsync(st->d_ctr, 0, (size_t)(3 * P + 8) * 4, s));
-      ResolveArgs a;
-      a.cache_map = PackedMap{st->cache_slots, st->cache ? st->cache->idmap.cap - 1 : 0};
-      a.own_map = f->map();
-      a.ids = d_ids;
-      a.n = n;
-      a.loc = loc;
-      a.tkeys = tkeys;
-      a.tmask = tcap - 1;
-      a.ctr = st->d_ctr;
-      a.P = P;
-      a.me = me;
-      a.cache_base = (int32_t)n_own;
-      a.has_cache = st->cache != nullptr;
-      a.bm_member = st->cache ? st->bm_member : nullptr;
-      a.bm_valid = st->bm_valid;
-      a.bm_max = st->bm_max;
-      a.insert_limit = tcap >= safe_cap ? INT32_MAX : (int32_t)(tcap / 10 * 6);
-      // at the safe size (>= 2 slots per id of the request) the load stays <= 50 %: every probe sequence ends, and a
-      // capped one could only fail this rank AFTER its peers passed the count exchange -- leaving them in the
-      // row exchange waiting for it
-      a.max_probe = tcap >= safe_cap ? INT32_MAX : kMaxProbe;
-      // Few, long-lived blocks: every block pays global atomics at its flushes and exit (a 16 M-id request: 0.27 ms
-      // with 4096 blocks, 0.16 ms with 1024, 0.8 ms with 65536).  Two ids per thread-iteration with the rank
-      // records (0.10 ms; one: 0.12, four: 0.12), one with the hash map (0.30; two: 0.32, four: 0.34) --
-      // scripts/resolve_probe.py.
       if (n > 0) {
-        // with a replica the ids it does not hold are a small share of the request: queued per wave and resolved
-        // 64 at a time (kQueue); without one every id takes that path and a queue would only add work
-        static const bool kNoQueue = getenv("GLX_RESOLVE_NO_QUEUE") != nullptr;  // (ablation)
-        if (a.has_cache && !kNoQueue) {
-          const int64_t per = glx_side_knobs().resolve_ids.load(std::memory_order_relaxed);  // ids per thread per pass (A/B)
-          const int64_t kb = glx_side_knobs().resolve_blocks.load(std::memory_order_relaxed);
-          const int64_t nb = kb > 0 ? kb : 1024;
-          if (a.bm_member && per == 8) glx_dist_resolve_kernel<8, true><<<grid_for((n + 7) / 8, nb), 256, 0, s>>>(a);
-          else if (a.bm_member && per == 4) glx_dist_resolve_kernel<4, true><<<grid_for((n + 3) / 4, nb), 256, 0, s>>>(a);
-          else if (a.bm_member) glx_dist_resolve_kernel<2, true><<<grid_for((n + 1) / 2, nb), 256, 0, s>>>(a);
-          else glx_dist_resolve_kernel<1, true><<<grid_for(n, nb), 256, 0, s>>>(a);
-        } else if (a.bm_member) {
-          glx_dist_resolve_kernel<2, false><<<grid_for((n + 1) / 2, 1024), 256, 0, s>>>(a);
+        // one launch clears the set and the counter block; the resolve's last workgroup turns the counts into offsets
+        // and the shared values (rounds 1-5: memset + fill + resolve + offsets + parameter kernel)
+        glx_dist_fill_keys_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap, st->d_ctr, 3 * P + 8);
+        ResolveArgs a;
+        a.cache_map = PackedMap{st->cache_slots, st->cache ? st->cache->idmap.cap - 1 : 0};
+        a.own_map = f->map();
+        a.ids = d_ids;
+        a.n = n;
+        a.loc = loc;
+        a.tkeys = tkeys;
+        a.tmask = tcap - 1;
+        a.ctr = st->d_ctr;
+        a.P = P;
+        a.me = me;
+        a.cache_base = (int32_t)n_own;
+        a.has_cache = has_cache;
+        a.bm_member = has_cache ? st->bm_member : nullptr;
+        a.bm_valid = st->bm_valid;
+        a.bm_max = st->bm_max;
+        a.insert_limit = tcap >= safe_cap ? INT32_MAX : (int32_t)(tcap / 10 * 6);
+        // at the safe size (>= 2 slots per id of the request) the load stays <= 50 %: every probe sequence ends, and a
+        // capped one could only fail this rank AFTER its peers passed the count exchange -- leaving them in the
+        // row exchange waiting for it
+        a.max_probe = tcap >= safe_cap ? INT32_MAX : kMaxProbe;
+        a.cold_idx = cold_idx;
+        a.cold_cnt = cold_cnt;
+        a.region = region;
+        a.vals = st->d_vals;
+        a.default_attr = default_attr;
+        a.peek = glx_side_knobs().resolve_peek.load(std::memory_order_relaxed) != 0;
+        if (queue) {
+          if (ranked && per == 8) glx_dist_resolve_kernel<8, true><<<rgrid, 256, 0, s>>>(a);
+          else if (ranked && per == 4) glx_dist_resolve_kernel<4, true><<<rgrid, 256, 0, s>>>(a);
+          else if (ranked) glx_dist_resolve_kernel<2, true><<<rgrid, 256, 0, s>>>(a);
+          else glx_dist_resolve_kernel<1, true><<<rgrid, 256, 0, s>>>(a);
+        } else if (ranked) {
+          glx_dist_resolve_kernel<2, false><<<rgrid, 256, 0, s>>>(a);
         } else {
-          glx_dist_resolve_kernel<1, false><<<grid_for(n, 1024), 256, 0, s>>>(a);
+          glx_dist_resolve_kernel<1, false><<<rgrid, 256, 0, s>>>(a);
         }
-      }
-      glx_dist_offsets_kernel<<<1, 64, 0, s>>>(st->d_ctr, P, tcap, st->d_vals);
-      ReqParams prm;
-      memset(&prm, 0, sizeof(prm));
-      memcpy(&prm.v[0], &default_attr, sizeof(float));
-      glx_dist_set_params_kernel<<<1, 64, 0, s>>>(st->d_vals + P + 5, prm, 1);
-      if (P > 1 && n > 0) {
-        glx_dist_assign_kernel<<<grid_for((int64_t)(tcap / 16 + 1)), 256, 0, s>>>(tkeys, tcap, tvals, st->d_ctr, P, cold_ids);
-        glx_dist_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(loc, n, tvals,
-                                                                              (int32_t)(n_own + n_cache));
+        if (P > 1) {
+          glx_dist_assign_kernel<<<grid_for((int64_t)(tcap / kAssignPer + 1), 2048), 256, 0, s>>>(tkeys, tcap, tvals, st->d_ctr, P, cold_ids);
+          if (cold_idx) {
+            glx_dist_finalize_list_kernel<<<rgrid, 256, 0, s>>>(loc, cold_idx, cold_cnt, region, tvals,
+                                                                (int32_t)(n_own + n_cache));
+          } else {
+            glx_dist_finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(loc, n, tvals, (int32_t)(n_own + n_cache));
+          }
+        }
+      } else {
+        glx_dist_offsets_kernel<<<1, 64, 0, s>>>(st->d_ctr, P, st->d_vals, default_attr);  // an empty request: one launch
       }
       GLX_HIP(hipGetLastError());
     }
@@ -1143,6 +1267,7 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
   const int64_t* mine = &st->h_mat[(size_t)me * nvals];
   const int64_t U = mine[P + 1];
   if (n > 0 && (double)U / (double)n > st->halo_share) st->halo_share = (double)U / (double)n;
+  if (n > 0) st->halo_share_known = true;
   stat.remote_distinct = U;
   stat.from_replica = mine[P + 2];
   stat.from_own_shard = mine[P + 3];
@@ -1317,40 +1442,42 @@ int dist_sample_device(glx_dist_store* st, int sampler, const int64_t* src, int3
   const glx_graph* rg = st->graph_replica;
   const bool divert = rg != nullptr && !filtered && sampler != GLX_SAMPLER_IN_DEGREE &&
                       (sampler != GLX_SAMPLER_EDGE_WEIGHT || rg->weight != nullptr);
-  if (divert) {
-    rc = glx_partition_divert(st->device, src, n, P, rg->map(), GlxMember{st->rg_bits, st->rg_bits_max}, bucketed, order,
-                              d_cnt, s);
-  } else {
-    rc = glx_partition(st->device, src, n, P, bucketed, order, d_cnt, s);
+  constexpr int kParams = 11;
+  glx_dist_ledger* lg = st->ledger;
+  // position-keyed: the same answer on every rank that issued the same sequence of calls (see glx_dist_ledger)
+  const int shape = lg && !lg->hold && !filtered && k > 0 && lg->learned(lg->pos) ? lg->pos : -1;
+  // The request's scalar parameters ride behind its bucket sizes, written by the partition's own kernel (round 6: a
+  // launch of their own cost as much as partitioning a hop-1 request; a speculated request ships none)
+  GlxPartitionTail mine;
+  memset(&mine, 0, sizeof(mine));
+  if (shape < 0) {
+    mine.n = kParams;
+    mine.at = P;  // behind the P owners' sizes (the graph replica's own bucket size never leaves the rank)
+    mine.v[0] = (int64_t)seed;
+    mine.v[1] = (int64_t)call_counter;
+    mine.v[2] = k;
+    mine.v[3] = sampler;
+    mine.v[4] = padding_mode;
+    mine.v[5] = default_neighbor_id;
+    mine.v[6] = filtered ? filter->type : GLX_FILTER_NONE;
+    mine.v[7] = filtered ? filter->field : GLX_FILTER_FIELD_NONE;
+    mine.v[8] = filtered ? filter->retry_times : 0;
+    mine.v[9] = filtered ? filter->default_timestamp : 0;
+    mine.v[10] = n;
   }
+  rc = glx_partition_tail(st->device, src, n, P, divert ? rg->map() : GlxIdMap{nullptr, nullptr, 0, 0},
+                          divert ? GlxMember{st->rg_bits, st->rg_bits_max} : GlxMember{nullptr, -1}, bucketed, order, d_cnt,
+                          mine, s);
   if (rc != GLX_OK) return rc;
   if (filtered && n > 0) {
     // every row's filter value travels with its id (HashPartitioner copies every tensor of a
     // request: hash_partitioner.h:69-74)
     glx_dist_gather_i64_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(filter->values, order, n, vals_b);
   }
-  constexpr int kParams = 11;
-  ReqParams mine;
-  memset(&mine, 0, sizeof(mine));
-  mine.v[10] = n;
-  glx_dist_ledger* lg = st->ledger;
-  // position-keyed: the same answer on every rank that issued the same sequence of calls (see glx_dist_ledger)
-  const int shape = lg && !lg->hold && !filtered && k > 0 && lg->learned(lg->pos) ? lg->pos : -1;
   if (shape >= 0) {
     return dist_sample_speculated(st, lg, shape, sampler, n, k, padding_mode, default_neighbor_id, seed, call_counter,
                                   divert ? rg : nullptr, bucketed, order, d_cnt, nbr_out, eid_out, s);
   }
-  mine.v[0] = (int64_t)seed;
-  mine.v[1] = (int64_t)call_counter;
-  mine.v[2] = k;
-  mine.v[3] = sampler;
-  mine.v[4] = padding_mode;
-  mine.v[5] = default_neighbor_id;
-  mine.v[6] = filtered ? filter->type : GLX_FILTER_NONE;
-  mine.v[7] = filtered ? filter->field : GLX_FILTER_FIELD_NONE;
-  mine.v[8] = filtered ? filter->retry_times : 0;
-  mine.v[9] = filtered ? filter->default_timestamp : 0;
-  glx_dist_set_params_kernel<<<1, 64, 0, s>>>(d_cnt + P, mine, kParams);
   const int nvals = P + kParams;
   st->h_mat.resize((size_t)P * nvals);
   const int my_pos = lg ? lg->pos : 0;

@@ -40,6 +40,8 @@ GlxSideKnobs& glx_side_knobs() {
     if (getenv("GLX_IDMAP_HASH_ONLY")) k.idmap_hash_only = 1;
     if (const char* e = getenv("GLX_RESOLVE_IDS")) k.resolve_ids = atoll(e);
     if (const char* e = getenv("GLX_RESOLVE_BLOCKS")) k.resolve_blocks = atoll(e);
+    if (const char* e = getenv("GLX_RESOLVE_SET_SHARE")) k.resolve_set_share = atoll(e);
+    if (const char* e = getenv("GLX_RESOLVE_PEEK")) k.resolve_peek = atoll(e);
   });
   return k;
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void glx_part_count_kernel(const int64_t* __re
 // per-shard totals.
 __global__ __launch_bounds__(1024) void glx_part_scan_kernel(int64_t* __restrict__ block_counts,
                                                              int64_t nblocks, int32_t P,
-                                                             int64_t* __restrict__ counts) {
+                                                             int64_t* __restrict__ counts, GlxPartitionTail tail) {
   __shared__ int64_t wave_sum[16];
   __shared__ int64_t carry_s;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -89,8 +89,16 @@ __global__ __launch_bounds__(1024) void glx_part_scan_kernel(int64_t* __restrict
     const int64_t p = threadIdx.x;
     const int64_t begin = block_counts[p * nblocks];
     const int64_t end = (p + 1 < P) ? block_counts[(p + 1) * nblocks] : carry_s;
-    counts[p] = end - begin;
+    if (tail.n == 0 || p < tail.at) counts[p] = end - begin;
   }
+  if ((int)threadIdx.x < tail.n) counts[tail.at + threadIdx.x] = tail.v[threadIdx.x];
+}
+
+// An empty request: its bucket sizes (all zero) and its tail, in one launch.
+__global__ void glx_part_empty_kernel(int64_t* __restrict__ counts, int32_t P, GlxPartitionTail tail) {
+  const int t = threadIdx.x;
+  if (t < P && (tail.n == 0 || t < tail.at)) counts[t] = 0;
+  if (t < tail.n) counts[tail.at + t] = tail.v[t];
 }
 
 // kOwnScan: block_off holds the raw per-block counts of glx_part_count_kernel and every block derives its own
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __
                                                                const uint8_t* __restrict__ bucket_cache,
                                                                int64_t* __restrict__ bucketed,
                                                                int64_t* __restrict__ order,
-                                                               int64_t* __restrict__ counts) {
+                                                               int64_t* __restrict__ counts, GlxPartitionTail tail) {
   __shared__ int64_t run[kMaxShards];       // next output position per shard for this block
   __shared__ int32_t wave_cnt[4][kMaxShards];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -134,8 +142,9 @@ __global__ __launch_bounds__(256) void glx_part_scatter_kernel(const int64_t* __
       int64_t base = 0;
       for (int32_t q = 0; q < (int32_t)threadIdx.x; ++q) base += total[q];
       run[threadIdx.x] = base + before[threadIdx.x];
-      if (blockIdx.x == 0) counts[threadIdx.x] = total[threadIdx.x];
+      if (blockIdx.x == 0 && (tail.n == 0 || (int)threadIdx.x < tail.at)) counts[threadIdx.x] = total[threadIdx.x];
     }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail.n) counts[tail.at + threadIdx.x] = tail.v[threadIdx.x];
   } else if (threadIdx.x < P) {
     run[threadIdx.x] = block_off[(int64_t)threadIdx.x * nblocks + blockIdx.x];
   }
@@ -183,9 +192,11 @@ __global__ __launch_bounds__(256) void glx_stitch_kernel(const T* __restrict__ i
 }  // namespace
 
 static int partition_impl(int device, const int64_t* ids, int64_t n, int32_t num_buckets, GlxIdMap divert,
-                          GlxMember member, int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s) {
+                          GlxMember member, int64_t* bucketed, int64_t* order, int64_t* counts, hipStream_t s,
+                          const GlxPartitionTail& tail = GlxPartitionTail{{0}, 0, 0}) {
   if (n == 0) {
-    GLX_HIP(hipMemsetAsync(counts, 0, (size_t)num_buckets * sizeof(int64_t), s));
+    glx_part_empty_kernel<<<1, 64, 0, s>>>(counts, num_buckets, tail);
+    GLX_HIP(hipGetLastError());
     return GLX_OK;
   }
   const int32_t tile = n <= kSmallIds ? kTileSmall : kTile;
@@ -201,11 +212,12 @@ static int partition_impl(int device, const int64_t* ids, int64_t n, int32_t num
                                                           bucket_cache);
   if ((int64_t)num_buckets * nblocks <= kOwnScanCells) {
     glx_part_scatter_kernel<true><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, tile, divert, member,
-                                                                   block_counts, bucket_cache, bucketed, order, counts);
+                                                                   block_counts, bucket_cache, bucketed, order, counts, tail);
   } else {
-    glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_buckets, counts);
+    glx_part_scan_kernel<<<1, 1024, 0, s>>>(block_counts, nblocks, num_buckets, counts, tail);
     glx_part_scatter_kernel<false><<<(unsigned)nblocks, 256, 0, s>>>(ids, n, num_buckets, nblocks, tile, divert, member,
-                                                                    block_counts, bucket_cache, bucketed, order, counts);
+                                                                    block_counts, bucket_cache, bucketed, order, counts,
+                                                                    GlxPartitionTail{{0}, 0, 0});
   }
   hipError_t e = hipGetLastError();
   glx_scratch_free(block_counts, s);
@@ -233,6 +245,14 @@ int glx_partition_divert(int device, const int64_t* ids, int64_t n, int32_t num_
   GLX_REQUIRE(num_shards >= 1 && num_shards + 1 <= kMaxShards, "num_shards must be in [1, %d)", kMaxShards);
   GLX_REQUIRE(divert.keys != nullptr || divert.step > 0, "no divert map");
   return partition_impl(device, ids, n, num_shards + 1, divert, member, bucketed, order, counts, s);
+}
+
+int glx_partition_tail(int device, const int64_t* ids, int64_t n, int32_t num_shards, GlxIdMap divert, GlxMember member,
+                       int64_t* bucketed, int64_t* order, int64_t* counts, const GlxPartitionTail& tail, hipStream_t s) {
+  const bool diverted = divert.keys != nullptr || divert.step > 0;
+  GLX_REQUIRE(num_shards >= 1 && num_shards + (diverted ? 1 : 0) <= kMaxShards, "num_shards must be in [1, %d)", kMaxShards);
+  GLX_REQUIRE(tail.n >= 0 && tail.n <= 12 && (tail.n == 0 || tail.at >= 0), "a partition tail holds at most 12 values");
+  return partition_impl(device, ids, n, num_shards + (diverted ? 1 : 0), divert, member, bucketed, order, counts, s, tail);
 }
 
 template <typename T>

@@ -20,6 +20,12 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 hot_fraction = float(sys.argv[2]) if len(sys.argv) > 2 else 0.10
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 solo = len(sys.argv) > 4 and sys.argv[4] == "solo"
+# sym: every rank asks (the symmetric real case) and ALL ranks enqueue on ONE stream, so no two kernels overlap and
+# every kernel runs at its own duration; a rocprofv3 kernel trace filtered by rank 0's host thread (printed below,
+# scripts/r03/p8_solo_step.py --thread) is then exactly ONE rank's step at P = 8: its own request plus its service of
+# the seven peers' rows -- one sampling launch per hop and one row gather for all peers, as a real rank issues them
+# (solo spreads that service over eight owner "ranks": eight launches per hop of an eighth of the rows each).
+sym = len(sys.argv) > 4 and sys.argv[4] == "sym"
 dev = torch.device("cuda", 0)
 V, E, D, B0, k1, k2 = 10_000_000, 100_000_000, 256, 65536, 25, 10
 src, dst, w = synth.rmat_edges_torch(V, E, 4, dev)
@@ -41,6 +47,7 @@ del X
 torch.cuda.empty_cache()
 n1, n2 = B0 * k1, B0 * k1 * k2
 bar = threading.Barrier(P)
+shared_stream = torch.cuda.Stream(device=0) if sym else None
 hot_by = os.environ.get("HOT_BY", "indegree")
 acc_all = torch.zeros(V, dtype=torch.int32, device=dev)
 acc_lock = threading.Lock()
@@ -51,7 +58,9 @@ times, stats, ok = [None] * P, [None] * P, [True] * P
 def rank_main(r):
     try:
         comm = glx.Comm.local(4242, 0, r, P)
-        with torch.cuda.stream(torch.cuda.Stream(device=0)):
+        if sym and r == 0:
+            print("rank 0 host thread id: %d" % threading.get_native_id(), flush=True)
+        with torch.cuda.stream(shared_stream if sym else torch.cuda.Stream(device=0)):
             st_s = glx.DistStore(comm, graph=graphs[r])
             st_a = glx.DistStore(comm, features=fshards[r])
             if hot_by == "access" and hot_fraction > 0:
@@ -156,7 +165,11 @@ def rank_main(r):
 ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
 for t in ts: t.start()
 for t in ts: t.join(600)
-if solo:
+if sym:
+    print("P = %d ranks on one GPU, hot fraction %.2f, every rank asks, ONE stream (kernels never overlap): %.2f ms per step of "
+          "all ranks = %.2f ms per rank-step; answers equal the unpartitioned operators: %s"
+          % (P, hot_fraction, max(x or 0 for x in times) * 1e3, max(x or 0 for x in times) * 1e3 / P, all(ok)))
+elif solo:
     print("P = %d ranks on one GPU, hot fraction %.2f, ONLY rank 0 asks: %.2f ms per step = one rank's own work + the service "
           "work of all owners for it (= one GPU's share in the symmetric case), no link time; answers equal the unpartitioned "
           "operators: %s" % (P, hot_fraction, max(x or 0 for x in times) * 1e3, all(ok)))

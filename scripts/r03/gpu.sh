@@ -7,6 +7,8 @@
 #   p8             eight ranks as threads on one GPU (scripts/edge_cut_p8_probe.py): count exchange per request /
 #                  merged aggregation / speculation ledger
 #   p8-solo        the same with only rank 0 asking, under rocprofv3: per-kernel cost of one rank's step + the owners' service
+#   p8-sym         every rank asking on ONE stream, under rocprofv3, rank 0's launches only: one rank's step in the
+#                  symmetric case (its own request + one launch per hop / one row gather for all seven peers)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
@@ -34,5 +36,13 @@ case "$what" in
       python $R/scripts/edge_cut_p8_probe.py 8 0.25 6 solo 2>&1 | grep "ONLY rank 0"
     python $R/scripts/r03/p8_solo_step.py $(find $O/prof_solo -name '*kernel_trace.csv' | head -1) | tee $O/p8_solo_step.txt
     rm -rf $O/prof_solo ;;
-  *) echo "usage: gpu.sh tests|all|world1|p8|p8-solo"; exit 2 ;;
+  p8-sym)
+    # every rank asks, one stream for all (no kernel overlaps another): rank 0's host thread's kernels = ONE rank's step
+    cd /tmp && export TMPDIR=/tmp
+    GRAPH_REPLICA=1 MERGED=1 LEDGER=${LEDGER:-0} timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_sym -o p8 --output-format csv -- \
+      python $R/scripts/edge_cut_p8_probe.py 8 0.25 6 sym 2>&1 | grep -E "every rank asks|rank 0 host thread" | tee $O/p8_sym_run.txt
+    tid=$(grep "rank 0 host thread" $O/p8_sym_run.txt | grep -o '[0-9]*$')
+    python $R/scripts/r03/p8_solo_step.py $(find $O/prof_sym -name '*kernel_trace.csv' | head -1) --thread $tid | tee $O/p8_sym_step.txt
+    rm -rf $O/prof_sym ;;
+  *) echo "usage: gpu.sh tests|all|world1|p8|p8-solo|p8-sym"; exit 2 ;;
 esac

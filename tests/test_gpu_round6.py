@@ -1,0 +1,94 @@
+"""Round 6 additions on the device path."""
+import numpy as np
+import pytest
+
+import glx
+from oracle_bindings import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _requests(rng, V, n, sg):
+    """(what, ids, segment_ids) of the same length: the three answers the segment bookkeeping can give (level 0 / 1 / 2)."""
+    f = n // sg
+    ids = lambda: rng.integers(-2, V + 2, n).astype(np.int64)  # noqa: E731
+    dense = (np.arange(n) // f).astype(np.int32)
+    swapped = dense.copy()
+    swapped[f - 1] = 1  # divisible, not the dense layout: arithmetic segment bounds would be wrong
+    bad = np.sort(rng.integers(0, sg, n)).astype(np.int32)
+    bad[n // 3] = -1  # the cursor stalls here: nothing behind it may be counted
+    return [("dense spelled out", ids(), dense), ("divisible but not uniform", ids(), swapped), ("violation", ids(), bad),
+            ("ragged", ids(), np.sort(rng.integers(0, sg, n)).astype(np.int32))]
+
+
+def test_segment_words_survive_the_wrap_of_their_epoch_counter():
+    """the two words a segment scan raises are tagged with an epoch; the tag used to come from one
+    process-wide 32-bit counter, so after 2^32 calls stale words out-tagged new calls, atomicMax never landed and a
+    non-uniform or invalid segment_ids request whose length divides evenly was reduced with arithmetic bounds.  The
+    counter is now the buffer's own and the words are cleared (stream-ordered) when it wraps: requests issued across the
+    wrap -- the test knob leaves the calling thread's buffers three epochs short of it -- still equal the oracle."""
+    import torch
+    orc = Oracle()
+    rng = np.random.default_rng(66)
+    V, dim, n, sg = 2000, 64, 6000, 600
+    X = rng.standard_normal((V, dim)).astype(np.float32)
+    feats = glx.Features(X)
+    dev = torch.device("cuda", 0)
+    reqs = _requests(rng, V, n, sg)
+
+    def check(what, ids, seg):
+        e, c = feats.aggregate("SumAggregator", torch.from_numpy(ids).to(dev), torch.from_numpy(seg).to(dev), sg, default_attr=0.5)
+        we, wc = orc.aggregate(X, "SumAggregator", ids, seg, sg, default_attr=0.5)
+        assert np.array_equal(c.cpu().numpy(), wc), what
+        assert np.array_equal(e.cpu().numpy().view(np.uint32), we.view(np.uint32)), what
+
+    check(*reqs[1])  # makes this (thread, stream)'s words
+    glx.tune("seg_epochs_before_wrap", 3)
+    for lap in range(3):  # 12 calls: the counter wraps during the first lap
+        for what, ids, seg in reqs:
+            check("%s (lap %d)" % (what, lap), ids, seg)
+    # words raised just BEFORE the wrap (level 2, with the highest tags a buffer can carry) must not leak into the calls
+    # right after it
+    glx.tune("seg_epochs_before_wrap", 1)
+    check(*reqs[2])
+    check(*reqs[0])
+    check(*reqs[1])
+    feats.close()
+
+
+def test_a_captured_aggregate_with_segment_ids_keeps_its_words_in_its_own_scratch():
+    """the first explicit-segment_ids call on a (thread, stream) allocated its two words -- illegal
+    while the stream is being captured.  A captured call now takes them from its own scratch, cleared by a node of the
+    graph: capture on a stream that never ran such a call before, replay with three different inputs."""
+    import torch
+    orc = Oracle()
+    rng = np.random.default_rng(67)
+    V, dim, n, sg = 2000, 64, 6000, 600
+    X = rng.standard_normal((V, dim)).astype(np.float32)
+    feats = glx.Features(X)
+    dev = torch.device("cuda", 0)
+    reqs = _requests(rng, V, n, sg)
+    ids_t = torch.zeros(n, dtype=torch.int64, device=dev)
+    seg_t = torch.zeros(n, dtype=torch.int32, device=dev)
+    emb = torch.empty((sg, dim), dtype=torch.float32, device=dev)
+    cnt = torch.empty(sg, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        # warm-up WITHOUT segment ids: the stream's scratch workspace exists, its segment words do not
+        feats.aggregate("SumAggregator", ids_t, None, sg, out=(emb, cnt))
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        feats.aggregate("SumAggregator", ids_t, seg_t, sg, default_attr=0.5, out=(emb, cnt))
+    for what, ids, seg in reqs[1:] + reqs[:1]:
+        ids_t.copy_(torch.from_numpy(ids))
+        seg_t.copy_(torch.from_numpy(seg))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        we, wc = orc.aggregate(X, "SumAggregator", ids, seg, sg, default_attr=0.5)
+        assert np.array_equal(cnt.cpu().numpy(), wc), what
+        assert np.array_equal(emb.cpu().numpy().view(np.uint32), we.view(np.uint32)), what
+    del g
+    feats.close()
