@@ -85,7 +85,8 @@ def compact_roofline(r):
         return None
     out = _pick(r, ("bound", "peak", "unit", "achieved", "frac", "algorithmic_gbs", "memory_side_gbs", "algorithmic_over_peak",
                     "frac_compulsory", "traffic", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
-                    "compulsory_bytes_per_launch", "traffic_over_algorithmic", "frac_of_gather_ceiling", "l2_hit_rate"))
+                    "compulsory_bytes_per_launch", "traffic_over_algorithmic", "frac_of_gather_ceiling", "l2_hit_rate",
+                    "share_of_step", "offline_tcp_busy_frac", "offline_l1_hit_rate"))
     out["kernel"] = _short(r.get("kernel", ""), 72)
     if r.get("achieved_basis"):
         out["achieved_basis"] = r["achieved_basis"]
@@ -156,6 +157,9 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
         line["roofline_sampler"] = dict(_pick(rs, ("achieved", "frac", "traffic", "avg_launch_ms", "frac_of_gather_ceiling")),
                                         kernel=_short(rs.get("kernel", ""), 60))
         optional.append("roofline_sampler")
+    if res.get("roofline_u_i"):
+        line["roofline_u_i"] = compact_roofline(res["roofline_u_i"])
+        optional.append("roofline_u_i")
     if res.get("placements"):
         line["placements"] = {name: _pick(leg, ("ms_per_step", "value")) for name, leg in res["placements"].items()}
         optional.append("placements")
@@ -169,7 +173,7 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
                 oc[name] = {"error": _short(rec["error"], 60)}
                 continue
             roof = rec.get("roofline") or {}
-            oc[name] = dict(_pick(rec, ("ms_per_step", "value")), frac=_num(roof.get("frac"), 4),
+            oc[name] = dict(_pick(rec, ("ms_per_step", "value")), bound=roof.get("bound"), frac=_num(roof.get("frac"), 4),
                             frac_basis=(roof.get("frac_basis") or "").split(":")[0], traffic=_num(roof.get("traffic"), 4),
                             verified=rec.get("verified_vs_oracle"))
         line["other_configs"] = oc
@@ -187,8 +191,8 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
         line["detail"] = detail_path
     text = json.dumps(line, separators=(", ", ": "))
     trimmed = []
-    for k in ("small_batches", "host_boundary_edges_per_s", "verified_legs", "phases", "roofline_sampler", "placements",
-              "other_configs"):
+    for k in ("small_batches", "host_boundary_edges_per_s", "verified_legs", "phases", "roofline_sampler", "roofline_u_i",
+              "placements", "other_configs"):
         if len(text) <= limit:
             break
         if k in optional and k in line:
@@ -667,16 +671,27 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
         except Exception as ex:  # noqa: BLE001
             oracle_check = {"ok": None, "error": repr(ex)}
         log("c5 verify vs oracle: %s" % oracle_check)
-    # Roofline kernel of c5: the u-i hop's reduce (ids over the 9 M-row / 9.2 GB item table).  The i-s hop's launch is
-    # longer, but its 1 GB shop table stays cache-resident -- no input exists on which its HBM traffic is known -- so
-    # its rate is reported beside as cache-assisted.
-    roof = roofline_aggregate("SumAggregator", D, B0, n1, ms1, int(len(t_agg[1::3])), s1 if not sharded else last["a1"],
-                              "c5", B0, offline_ok=False)
-    roof["kernel"] = "glx_aggregate_grp_kernel (u-i hop SumAggregator over the 9 M-row item table, dim=%d)" % D
+    # c5's `roofline` is quoted on its DOMINANT launch: the i-s hop's reduce over the 1 M-row shop
+    # table -- two thirds of the step.  It is not an HBM-bound launch: the request touches ~0.4 GB of distinct rows, ~75 % of
+    # its row reads hit the CU's L1 (Topk's deterministic answers repeat; circular padding repeats rows inside a segment),
+    # and the per-CU vector-memory pipeline (TA -> TCP -> TD) is busy ~95 % of the launch (profiles/r06/c5_is_reduce.md).
+    # Its bound is that pipeline ("issue"), its ceiling the SAME launch with no cache miss at all -- ids uniform over
+    # 2,048 rows, resident in every XCD's L2 -- timed in this run; frac = floor time / live time.  The u-i hop's launch
+    # (ids over the 9.2 GB item table: HBM-bound, 9 % of the step) keeps its HBM roofline beside it as `roofline_u_i`.
+    roof_ui = roofline_aggregate("SumAggregator", D, B0, n1, ms1, int(len(t_agg[1::3])), s1 if not sharded else last["a1"],
+                                 "c5", B0, offline_ok=False)
+    roof_ui["kernel"] = "glx_aggregate_grp_kernel (u-i hop SumAggregator over the 9 M-row item table, dim=%d)" % D
     bytes_is = n2 * (4 * D + 12) + sg2 * (4 * D + 4)
-    roof["longest_launch"] = {"kernel": "i-s hop SumAggregator over the 1 M-row shop table (cache-resident: 1 GB)",
-                              "avg_launch_ms": ms2, "algorithmic_bytes_per_launch": bytes_is,
-                              "algorithmic_over_peak": bytes_is / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "cache_assisted": True}
+    step_ms = elapsed / args.steps * 1e3
+    roof = {"kernel": "glx_aggregate_grp_kernel (i-s hop SumAggregator: %d ids over the 1 M-row / 1 GB shop table, dim=%d)" % (n2, D),
+            "bound": "issue", "unit": "GB/s", "avg_launch_ms": ms2, "launches_timed": int(len(t_agg[0::3])),
+            "share_of_step": ms2 / step_ms, "algorithmic_bytes_per_launch": bytes_is,
+            "algorithmic_gbs": bytes_is / (ms2 * 1e-3) / 1e9, "algorithmic_over_peak": bytes_is / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "achieved": bytes_is / (ms2 * 1e-3) / 1e9, "cache_assisted": True,
+            "bound_detail": "per-CU vector-memory pipeline (TA/TCP/TD): busy ~95 % of the launch, about three quarters of the row reads hit L1, "
+                            "waves parked on memory 55 % of their cycles, 1 M-row table mostly on-die (rocprofv3 counter "
+                            "passes of scripts/r06/c5_is_probe.py: profiles/r06/c5_is_reduce.md); not HBM (memory-side traffic "
+                            "is a quarter of the algorithmic bytes) and not L2 bandwidth (half of 34.5 TB/s at the floor)"}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not sharded and os.path.exists(pmc):
         try:
@@ -684,35 +699,58 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
         except Exception:  # noqa: BLE001
             rec = {}
         if rec.get("aggregate_hop2_bytes_per_launch"):
-            roof["longest_launch"]["traffic"] = rec["aggregate_hop2_bytes_per_launch"]
-            roof["longest_launch"]["traffic_source"] = "OFFLINE: profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
+            roof["traffic"] = rec["aggregate_hop2_bytes_per_launch"]
+            roof["traffic_source"] = "OFFLINE: profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per i-s launch); not of this run"
+            roof["memory_side_gbs"] = rec["aggregate_hop2_bytes_per_launch"] / (ms2 * 1e-3) / 1e9
+        for k in ("is_tcp_busy_frac", "is_l1_hit_rate", "is_l2_hit_rate", "is_wave_wait_frac"):
+            if rec.get(k) is not None:
+                roof[k.replace("is_", "offline_")] = rec[k]
         if rec.get("aggregate_item_bytes_per_launch"):
-            roof["traffic"] = rec["aggregate_item_bytes_per_launch"]
-            roof["traffic_source"] = "OFFLINE: profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per u-i launch); not of this run"
+            roof_ui["traffic"] = rec["aggregate_item_bytes_per_launch"]
+            roof_ui["traffic_source"] = "OFFLINE: profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per u-i launch); not of this run"
     roof_smp = None
     if not sharded and len(t_smp) >= 3:
         roof_smp = roofline_sampler("TopkSampler", k2, sg2, n2, float(np.mean(t_smp[1::3])), int(len(t_smp[1::3])), "c5", B0)
     if extras["roofline_probes"]:
-        # cache-free leg: the same kernel on the same request shape with ids uniform over the 9 M item rows
+        def timed(f_tab, ids_t, n_seg, out, reps=10):
+            for _ in range(2):
+                f_tab.aggregate("SumAggregator", ids_t, None, n_seg, out=out)
+            torch.cuda.synchronize()
+            glx.profile_enable(True)
+            for _ in range(reps):
+                f_tab.aggregate("SumAggregator", ids_t, None, n_seg, out=out)
+            torch.cuda.synchronize()
+            glx.profile_enable(False)
+            return float(np.mean(glx.profile_collect(glx.KERNEL_AGGREGATE)))
+        # the i-s launch's floor: the same kernel, same request shape, every row read an L2 hit (2,048 rows = 2 MB)
+        fake = torch.randint(0, 2048, (n2,), generator=gen, device=dev)
+        ms_floor = timed(x_shop, fake, sg2, o2)
+        # ... and its HBM case: ids uniform over the whole 1 GB table (beyond the 256 MB Infinity Cache)
+        fake = torch.randint(0, n_shop, (n2,), generator=gen, device=dev)
+        ms_uni = timed(x_shop, fake, sg2, o2)
+        roof["peak"] = bytes_is / (ms_floor * 1e-3) / 1e9
+        roof["frac"] = ms_floor / ms2
+        roof["l2_resident_floor"] = {"rows": "ids uniform over 2,048 rows (2 MB: resident in every XCD's L2)", "avg_launch_ms": ms_floor,
+                                     "launches_timed": 10, "algorithmic_gbs": roof["peak"],
+                                     "frac_of_l2_peak_34500": roof["peak"] / 34500.0}
+        roof["uniform_over_table"] = {"rows": "ids uniform over all %d rows (1 GB)" % n_shop, "avg_launch_ms": ms_uni,
+                                      "launches_timed": 10, "algorithmic_gbs": bytes_is / (ms_uni * 1e-3) / 1e9,
+                                      "frac_of_hbm_peak": bytes_is / (ms_uni * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        roof["achieved_basis"] = "algorithmic bytes of the i-s launch / its average live launch time (cache-assisted: not a bandwidth)"
+        roof["frac_basis"] = ("L2-resident floor of this run: the same kernel on the same request shape with every row read an "
+                              "L2 hit / the live launch -- how close the launch is to the rate its own instruction stream allows")
+        # cache-free leg of the u-i launch: the same kernel on the same request shape with ids uniform over the 9 M item rows
         fake = torch.randint(0, n_item, (n1,), generator=gen, device=dev)
-        for _ in range(2):
-            x_item.aggregate("SumAggregator", fake, None, B0, out=o1)
-        torch.cuda.synchronize()
-        glx.profile_enable(True)
-        for _ in range(10):
-            x_item.aggregate("SumAggregator", fake, None, B0, out=o1)
-        torch.cuda.synchronize()
-        glx.profile_enable(False)
-        ms = float(np.mean(glx.profile_collect(glx.KERNEL_AGGREGATE)))
-        cf = roof["algorithmic_bytes_per_launch"] / (ms * 1e-3) / 1e9
-        roof["cache_free"] = {"rows": "uniform over the %d item rows (%.1f GB)" % (n_item, n_item * D * 4 / 1e9),
-                              "avg_launch_ms": ms, "launches_timed": 10, "achieved": cf, "frac": cf / HBM_PEAK_GBS,
-                              "note": "a short launch (%d ids, %.2f GB): ramp-up and tail are a visible share of it" %
-                                      (n1, roof["algorithmic_bytes_per_launch"] / 1e9)}
-        roof["frac"] = cf / HBM_PEAK_GBS
-        roof["achieved"] = cf
-        roof["achieved_basis"] = "cache-free leg: algorithmic bytes (== memory-side traffic there) / its average launch time"
-        roof["frac_basis"] = "cache-free leg of this run: u-i hop shape, ids uniform over the 9.2 GB item table / 8 TB/s"
+        ms = timed(x_item, fake, B0, o1)
+        cf = roof_ui["algorithmic_bytes_per_launch"] / (ms * 1e-3) / 1e9
+        roof_ui["cache_free"] = {"rows": "uniform over the %d item rows (%.1f GB)" % (n_item, n_item * D * 4 / 1e9),
+                                 "avg_launch_ms": ms, "launches_timed": 10, "achieved": cf, "frac": cf / HBM_PEAK_GBS,
+                                 "note": "a short launch (%d ids, %.2f GB): ramp-up and tail are a visible share of it" %
+                                         (n1, roof_ui["algorithmic_bytes_per_launch"] / 1e9)}
+        roof_ui["frac"] = cf / HBM_PEAK_GBS
+        roof_ui["achieved"] = cf
+        roof_ui["achieved_basis"] = "cache-free leg: algorithmic bytes (== memory-side traffic there) / its average launch time"
+        roof_ui["frac_basis"] = "cache-free leg of this run: u-i hop shape, ids uniform over the 9.2 GB item table / 8 TB/s"
         del fake
     res = {
         "metric": "sampled-edges/sec + aggregated-vertices/sec (per-edge-type Topk + type-wise Sum per step)",
@@ -730,6 +768,7 @@ def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
         "phases": {"sampling_kernels_ms_per_step": float(np.sum(t_smp)) / args.steps,
                    "aggregation_kernels_ms_per_step": float(np.sum(t_agg)) / args.steps},
         "roofline": roof,
+        "roofline_u_i": roof_ui,
         "cpu_baseline": None,
     }
     if roof_smp is not None:
@@ -865,7 +904,7 @@ def other_configs(args):
             rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             out[name] = {"workload": rec["config"]["workload"], "seeds": rec["config"].get("seeds"), "ms_per_step": rec["ms_per_step"], "value": rec["value"],
                          "unit": rec["unit"], "steps": rec["steps"], "phases": rec.get("phases"), "roofline": rec.get("roofline"),
-                         "roofline_sampler": rec.get("roofline_sampler"), "verified_vs_oracle": rec.get("verified_vs_oracle"),
+                         "roofline_u_i": rec.get("roofline_u_i"), "roofline_sampler": rec.get("roofline_sampler"), "verified_vs_oracle": rec.get("verified_vs_oracle"),
                          "wall_s": time.time() - t0}
         except Exception as ex:  # noqa: BLE001 -- never lose the headline line
             out[name] = {"error": repr(ex), "returncode": getattr(r, "returncode", None),

@@ -601,6 +601,14 @@ void launch_agg_grp(AggArgs a, int32_t num_ids, hipStream_t s) {
   // waves keep more independent row loads in flight.  GLX_AGG_SEGS overrides.
   int32_t S = 1;
   const int want = agg_knobs().segs.load(std::memory_order_relaxed);
+  // ... except over a table small enough that most of a big request is served on-die (<= 1 GiB = four Infinity Caches;
+  // round 6): such a launch is not waiting for HBM but for its own vector-memory pipeline -- C5's item -> shop reduce
+  // (6.55 M ids over the 1 GB shop table: three quarters of its row reads hit L1, the per-CU TA/TCP/TD path busy ~95 % of the
+  // launch, profiles/r06/c5_is_reduce.md) -- and there three segments per group (one id chunk serves all three, a
+  // third of the waves to launch and drain) took 0.49 -> 0.43 ms, while the same setting LOSES on the tables HBM
+  // serves: C2 (1.2 GB) 0.55 -> 0.63, C4 0.98 -> 1.08, C3 (10 GB) 1.84 -> 1.84 (profiles/r06/agg_probe_*_segs.txt).
+  // Small requests stay at one (a group per segment fills the chip sooner).
+  if (NSRC == 1 && (int64_t)a.num_rows * a.stride * 4 <= ((int64_t)1 << 30) && a.num_segments >= 3 * 32768) S = 3;
   if (want > 0) S = want;
   if (S > G - 1) S = G - 1;  // lane j of the group holds the start of its j-th segment (and lane S the end)
   if (S < 1) S = 1;

@@ -177,28 +177,49 @@ struct ResolveArgs {
 // Pass 2 (one thread): per-owner offsets, and the values every rank shares:
 // vals[0..P) = ids requested from each owner, [P] overflow, [P+1] distinct total,
 // [P+2..4] replica / own / remote id counts, [P+5] the requester's default_attr (float bits).
-// kCoherent: called by the last workgroup of the kernel whose other workgroups raised the counters with device-scope
-// atomics -- read them the same way (an atomic at the L2 / memory side; a plain load could be served by this CU's L1 or
-// this XCD's L2 with a line fetched before the peers' atomics landed).
-template <bool kCoherent>
-__device__ __forceinline__ void dist_offsets_body(int32_t* ctr, int32_t P, int64_t* vals, float default_attr) {
-  auto rd = [&](int32_t i) -> int32_t { return kCoherent ? atomicAdd(&ctr[i], 0) : ctr[i]; };
+// c[] = the counter block as read (LDS or global); writes the offsets / cleared cursors to ctr, the values to vals.
+__device__ __forceinline__ void dist_offsets_body(const int32_t* c, int32_t* ctr, int32_t P, int64_t* vals, float default_attr) {
   int32_t* off = ctr + 2 * P + 4;
   int32_t total = 0;
   for (int32_t p = 0; p < P; ++p) {
-    const int32_t c = rd(p);
     off[p] = total;
-    vals[p] = c;
-    total += c;
+    vals[p] = c[p];
+    total += c[p];
     ctr[P + p] = 0;
   }
   off[P] = total;
-  vals[P] = rd(2 * P);
+  vals[P] = c[2 * P];
   vals[P + 1] = total;
-  vals[P + 2] = rd(2 * P + 1);
-  vals[P + 3] = rd(2 * P + 2);
-  vals[P + 4] = rd(2 * P + 3);
+  vals[P + 2] = c[2 * P + 1];
+  vals[P + 3] = c[2 * P + 2];
+  vals[P + 4] = c[2 * P + 3];
   vals[P + 5] = (int64_t)(uint32_t)__float_as_uint(default_attr);
+}
+
+// ... by the last workgroup of the resolve kernel (all 256 threads call it).  The other workgroups raised the counters
+// with device-scope atomics, so they are read the same way (an atomic is performed where all XCDs agree; a plain load
+// could be served by this CU's L1 or this XCD's L2 from a line fetched before the peers' atomics landed) -- every
+// thread one counter, ONE round trip (thread 0 reading them one after the other put two dozen dependent round trips,
+// 40 us, at the end of the kernel).  The counts check themselves -- replica + own + remote ids = n, and the per-owner
+// counts add up to the running total of distinct ids -- so a count that were still on its way (it should not be: every
+// workgroup waited for its atomics' acknowledgement before it took its ticket) is waited for, not published.
+__device__ __forceinline__ void dist_offsets_last_block(int32_t* ctr, int32_t P, int64_t* vals, float default_attr, int64_t n) {
+  __shared__ int32_t s_c[3 * kMaxWorld + 8];
+  __shared__ int32_t s_ok;
+  for (int spin = 0; spin < 1024; ++spin) {
+    if ((int32_t)threadIdx.x < 3 * P + 8) s_c[threadIdx.x] = atomicAdd(&ctr[threadIdx.x], 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int64_t ids = (int64_t)s_c[2 * P + 1] + s_c[2 * P + 2] + s_c[2 * P + 3];
+      int64_t distinct = 0;
+      for (int32_t p = 0; p < P; ++p) distinct += s_c[p];
+      s_ok = ids == n && distinct == (int64_t)s_c[3 * P + 5];
+    }
+    __syncthreads();
+    if (s_ok) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (threadIdx.x == 0) dist_offsets_body(s_c, ctr, P, vals, default_attr);
 }
 
 // Pass 1: every id -> a virtual row (own shard / replica), -1 (default row), or -(h + 2) when
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   atomicAdd(&s_stat[1], n_own);
   atomicAdd(&s_stat[2], n_cold);
   __syncthreads();
-  // (every atomic below is fenced by its thread before the workgroup takes its ticket)
+  // (a thread waits for the acknowledgement of its atomics below before the workgroup takes its ticket)
   if (threadIdx.x < 3 && s_stat[threadIdx.x]) atomicAdd(&a.ctr[2 * a.P + 1 + threadIdx.x], s_stat[threadIdx.x]);
   if ((int)threadIdx.x < a.P && s_cnt[threadIdx.x]) atomicAdd(&a.ctr[threadIdx.x], s_cnt[threadIdx.x]);
   if (threadIdx.x == 0) {
@@ -446,19 +467,16 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
     }
     if (kQueue && a.cold_cnt) a.cold_cnt[blockIdx.x] = s_list_n;
   }
-  // Pass 2 in the same launch: the last workgroup to get here has every other workgroup's counts before it (each
-  // raised them with device-scope atomics, fenced, then took its ticket)
-  __threadfence();
+  // Pass 2 in the same launch: the last workgroup to take a ticket has every other workgroup's counts before it.
+  // No cache-flushing fence is involved (an agent-scope fence writes this XCD's L2 back: two per workgroup cost the
+  // kernel 70 us): the counters are raised with device-scope atomics, which are performed where all XCDs agree; a
+  // workgroup waits for the acknowledgement of its own (s_waitcnt) before it takes its ticket, and the last workgroup
+  // reads the counters with atomics too.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(&a.ctr[3 * a.P + 6], 1) == (int32_t)gridDim.x - 1;
-  }
+  if (threadIdx.x == 0) s_last = atomicAdd(&a.ctr[3 * a.P + 6], 1) == (int32_t)gridDim.x - 1;
   __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    __threadfence();
-    dist_offsets_body<true>(a.ctr, a.P, a.vals, a.default_attr);
-  }
+  if (s_last) dist_offsets_last_block(a.ctr, a.P, a.vals, a.default_attr, a.n);
 }
 
 // Pass 2 for a request without ids (no resolve launch): the shared values of an empty request.  The counter block need
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
 __global__ void glx_dist_offsets_kernel(int32_t* ctr, int32_t P, int64_t* vals, float default_attr) {
   if (threadIdx.x != 0) return;
   for (int32_t i = 0; i < 3 * P + 8; ++i) ctr[i] = 0;
-  dist_offsets_body<false>(ctr, P, vals, default_attr);
+  dist_offsets_body(ctr, ctr, P, vals, default_attr);
 }
 
 // Pass 4 over the cold lists (kQueue resolve): workgroup b rewrites the entries workgroup b of the resolve listed.

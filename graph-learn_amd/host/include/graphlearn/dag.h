@@ -186,13 +186,16 @@ public:
   bool WaitAndPush(Tape* tape, const std::function<bool()>& stop);
   // The oldest tape, numbered in pop order per client.  nullptr: `stop` became true while waiting.
   Tape* WaitAndPop(int32_t client_id, const std::function<bool()>& stop);
-  void Close();  // wakes every waiter; their `stop` decides
+  // Ends the store for good: wakes every waiter, a producer's push fails from now on, a consumer drains what is queued
+  // and then gets nullptr -- whenever it looks, not only while the stop that closed the store is still in progress.
+  void Close();
   ~TapeStore();
 
 private:
   const int32_t cap_;
   const Dag* dag_;
   int32_t epoch_ = 0;
+  bool closed_ = false;  // under mtx_
   std::mutex mtx_;
   std::condition_variable room_, data_;
   std::deque<Tape*> queue_;

@@ -113,8 +113,12 @@ Status Dag::Compile() {
       return error::InvalidArgument("dag edge " + std::to_string(it.first) + " is attached at one end only");
     }
   }
+  std::vector<bool> seen(nodes_.size() + 1, false);
   for (const auto& n : nodes_) {
     if (n->Id() < 1 || n->Id() > Size()) return error::InvalidArgument("dag node ids must be 1..size");
+    // a node's id is its tape slot: two nodes with one id would overwrite each other's record
+    if (seen[n->Id()]) return error::InvalidArgument("dag node id " + std::to_string(n->Id()) + " is used twice");
+    seen[n->Id()] = true;
   }
   std::vector<int32_t> waiting(nodes_.size() + 1, 0);
   std::vector<bool> emitted(nodes_.size() + 1, false);
@@ -218,8 +222,8 @@ bool TapeStore::WaitAndPush(Tape* tape, const std::function<bool()>& stop) {  //
   std::unique_lock<std::mutex> lock(mtx_);
   tape->SetEpoch(epoch_);
   if (tape->IsFaked()) ++epoch_;
-  while ((int32_t)queue_.size() >= cap_) {
-    if (stop()) {
+  while ((int32_t)queue_.size() >= cap_ || closed_) {
+    if (closed_ || stop()) {
       delete tape;
       return false;
     }
@@ -233,7 +237,9 @@ bool TapeStore::WaitAndPush(Tape* tape, const std::function<bool()>& stop) {  //
 Tape* TapeStore::WaitAndPop(int32_t client_id, const std::function<bool()>& stop) {  // :127-148
   std::unique_lock<std::mutex> lock(mtx_);
   while (queue_.empty()) {
-    if (stop()) return nullptr;
+    // closed_ is sticky: a consumer that wakes up after StopAll has already finished (its transient flag is down
+    // again, no producer is left) still learns that nothing more will come
+    if (closed_ || stop()) return nullptr;
     data_.wait_for(lock, kPoll);
   }
   Tape* tape = queue_.front();
@@ -246,6 +252,7 @@ Tape* TapeStore::WaitAndPop(int32_t client_id, const std::function<bool()>& stop
 
 void TapeStore::Close() {
   std::lock_guard<std::mutex> g(mtx_);
+  closed_ = true;
   room_.notify_all();
   data_.notify_all();
 }

@@ -56,7 +56,9 @@ public:
       Graph* graph = graph_store_->GetGraph(reqs[h]->Type());
       graphs[h] = graph->Device();
       fanouts[h] = reqs[h]->NeighborCount();
-      if (!graphs[h] || reqs[h]->HasFilter()) all_loaded = false;
+      // ... and a request that pins its call counter or its rows' random streams (a part of a partitioned request) is
+      // served by Sample(), which honours both (the fused call drew from the operator's own counter)
+      if (!graphs[h] || reqs[h]->HasFilter() || reqs[h]->HasCallCounter() || reqs[h]->GetRngRows() != nullptr) all_loaded = false;
       if (graphs[h] && SamplerId() == GLX_SAMPLER_IN_DEGREE) {
         Status s = graph->EnsureInDegree();
         if (!s.ok()) return s;
@@ -66,7 +68,7 @@ public:
         if (!s.ok()) return s;
       }
     }
-    if (!all_loaded) {  // an edge type nobody loaded default-fills (Sample): hop by hop, each fed by the one before
+    if (!all_loaded) {  // an edge type nobody loaded default-fills (Sample), a filter / pinned counter needs Sample: hop by hop, each fed by the one before
       for (size_t h = 0; h < hops; ++h) {
         SamplingRequest next(reqs[h]->Type(), reqs[h]->Strategy(), fanouts[h]);
         if (h > 0) next.Set(ress[h - 1]->GetNeighborIds(), (int32_t)ress[h - 1]->GetShape().size);

@@ -154,6 +154,27 @@ TEST(Dag, CompileRejectsBrokenDefinitions) {
   cyc.nodes[1].in_edges.push_back(back);
   Dag cycle(cyc);
   EXPECT_TRUE(!cycle.Compile().ok());
+  DagDef twice = ChainDag(4, 4);
+  twice.nodes[2].id = twice.nodes[1].id;  // two nodes, one tape slot
+  Dag dup(twice);
+  EXPECT_TRUE(!dup.Compile().ok());
+}
+
+TEST(TapeStore, CloseIsStickyForConsumersThatLookLater) {
+  // a consumer that wakes up after StopAll has finished (its transient flag is down again) must still
+  // learn that the store ended, instead of waiting for a producer that no longer exists
+  Dag dag(ChainDag(2, 4));
+  EXPECT_TRUE(dag.Compile().ok());
+  TapeStore store(2, &dag);
+  const std::function<bool()> never = []() { return false; };
+  Tape* t = store.New();
+  EXPECT_TRUE(store.WaitAndPush(t, never));
+  store.Close();
+  Tape* got = store.WaitAndPop(0, never);  // what was queued is still handed out ...
+  EXPECT_TRUE(got == t);
+  delete got;
+  EXPECT_TRUE(store.WaitAndPop(0, never) == nullptr);  // ... then the end, without a stop condition saying so
+  EXPECT_TRUE(!store.WaitAndPush(store.New(), never));  // and nothing more goes in
 }
 
 // `.outV(e1).sample(3).by("random").outV(e2).sample(2).by("random")` with the lookup / degree nodes the Python layer

@@ -8,6 +8,8 @@
       mall    : ids uniform over 100,000 rows (102 MB: Infinity-Cache resident)      -- the fabric ceiling
       uniform : ids uniform over all 1 M rows (1 GB: beyond the 256 MB Infinity Cache) -- the table's HBM case
       sorted  : the real request's SEGMENTS ordered by their first id (neighbouring groups share rows)
+  `default` is what the library picks for this shape (round 6: three segments per lane group for tables <= 1 GiB);
+  s1 = one segment per group (rounds 4-5), xN = XCD-affine column slices, uN = rows in flight, oN = occupancy cap.
   python scripts/r06/c5_is_probe.py pmc [N]    N launches of `real` at the default knobs and N of `l2`, nothing else in
                                                the timed part (run under rocprofv3 --pmc ...: counters per launch)
 Distinct rows / lines per request are printed so the traffic figures can be read against a byte count."""
@@ -95,8 +97,8 @@ def parse(spec):
     return kw
 
 
-specs = sys.argv[2].split(":") if len(sys.argv) > 2 else ["default", "x1", "x4", "x8", "s2", "s3", "s2,x1", "s3,x1", "s6,x1", "u6", "u8",
-                                                         "u12", "u15", "o4", "o6", "w1", "legacy", "default"]
+specs = sys.argv[2].split(":") if len(sys.argv) > 2 else ["default", "s1", "s1,x1", "s1,x4", "s2", "s3", "s4", "s3,x1", "s6,x1",
+                                                         "s1,u6", "s3,u6", "s1,o6", "s1,w1", "legacy", "default"]
 names = ("real", "sorted", "l2", "mall", "uniform")
 print("# median of 7 launches, ms; TB/s = algorithmic bytes / time on `real`")
 print("%-12s " % "variant" + " ".join("%9s" % n for n in names) + "   TB/s(real)  bit-identical")

@@ -27,7 +27,7 @@ case "$what" in
     for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD" \
                 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE" \
                 "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum" \
-                "TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+                "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUSY_avr" \
                 "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
                 "TD_TD_BUSY_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
                 "GRBM_GUI_ACTIVE GRBM_COUNT"; do
@@ -51,6 +51,15 @@ case "$what" in
     timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/rsp -o t -- python $R/scripts/r06/resolve_set_probe.py 2>&1 | grep -E "^phases|^last" | tee $O/resolve_set_probe.txt
     python $R/scripts/r06/resolve_set_parse.py $(find /tmp/rsp -name '*kernel_trace.csv' | head -1) | tee -a $O/resolve_set_probe.txt
     rm -rf /tmp/rsp; cd $R ;;
+  smp-lines)
+    # 128-byte lines the hop-2 sampler launch asks L2 for, per draw (would staging a row in LDS cut lines?)
+    cd /tmp && export TMPDIR=/tmp
+    timeout 600 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-include-regex "glx_sample_slots|glx_probe_gather32" --kernel-trace --output-format csv -d /tmp/smpl -o p -- \
+      python $R/bench.py --workload c3 --cpu-baseline off --host-boundary off --edge-cut-probe off --small-batches off --other-configs= --verify-oracle off --request-shape-legs off --steps 5 --warmup 1 > $O/smp_lines_bench.json 2> $O/smp_lines.err
+    f=$(find /tmp/smpl -name '*counter_collection.csv' | head -1); (head -1 $f; grep -E "glx_sample_slots|glx_probe_gather32" $f) > $O/smp_lines_pmc.csv
+    rm -rf /tmp/smpl; wc -l $O/smp_lines_pmc.csv; cd $R ;;
+  p8)
+    bash scripts/r03/gpu.sh p8 2>&1 | tail -12; cp $R/gpurun_out/r03/p8.txt $O/p8_all_asking.txt 2>/dev/null ;;
   agg-s)
     # segments per lane group on the other workloads' shapes (scripts/r04/agg_probe.py): does S > 1 pay anywhere else?
     for wl in c3 c2 c4; do

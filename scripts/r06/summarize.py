@@ -124,11 +124,15 @@ for wl in ("c3", "c2", "c5", "c4"):  # whichever profile.sh was run for
     if ad:
         out += ["", "Longest aggregate launch `%s`: %d dispatches in the workload's own steps, average **%.3f ms** in the trace."
                 % (an, len(ad), sum(ad) / len(ad))]
-    cf = (line.get("roofline") or {}).get("cache_free") or {}
-    if wl != "c5" and ad_probe and cf.get("launches_timed"):
+    cf = dict((line.get("roofline") or {}).get("cache_free") or {})
+    try:  # the full record of the same run (the compact line drops launches_timed)
+        cf.update((json.load(open(src("%s_detail_trace.json" % wl))).get("roofline") or {}).get("cache_free") or {})
+    except Exception:  # noqa: BLE001
+        pass
+    if wl != "c5" and ad_probe and cf.get("avg_launch_ms"):
         # the cache-free leg: the same kernel, same request shape, ids uniform over the table -- its timed launches are
         # the LAST launches_timed dispatches of that shape in the process
-        nt = int(cf["launches_timed"])
+        nt = int(cf.get("launches_timed", 5))
         timed = ad_probe[-nt:]
         alg_b = line["roofline"]["algorithmic_bytes_per_launch"]
         tr_ms = sum(timed) / len(timed)

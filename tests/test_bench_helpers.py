@@ -75,7 +75,7 @@ def test_headline_line_stays_under_the_drivers_tail():
     oc = got["other_configs"]
     assert set(oc) == {"c2", "c5", "c4", "c3-degree-seeds"}
     for rec in oc.values():
-        assert set(rec) <= {"ms_per_step", "value", "frac", "frac_basis", "traffic", "verified", "error"}
+        assert set(rec) <= {"ms_per_step", "value", "bound", "frac", "frac_basis", "traffic", "verified", "error"}
     assert got["detail"] == "bench_detail.json"
 
 
@@ -99,6 +99,19 @@ def test_multi_gpu_line_is_compact_too():
     for leg in got["placements"].values():
         assert set(leg) <= {"ms_per_step", "value"}
     assert got["verified_sharded_equals_unpartitioned"] is True and "placement" in got["config"]["workload"]
+    # the N > 1 line carries `roofline` (quoted on the 3-source reduce the partitioned step runs), parses
+    # under 4 KB with nothing trimmed, and every placement leg the run timed is in it
+    assert "trimmed" not in got
+    r = got["roofline"]
+    assert "3 row sources" in r["kernel"] and r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0 < r["frac"] <= 1 and r["avg_launch_ms"] > 0 and r["algorithmic_bytes_per_launch"] == 18658099200
+    assert set(got["placements"]) == {"features_sharded_serial", "features_replicated", "features_sharded", "features_sharded_speculated",
+                                      "edge_cut_pure", "edge_cut_pure_speculated", "edge_cut_pure_design_r"}
+    assert set(got["verified_legs"]) >= {"features_sharded", "features_sharded_speculated", "edge_cut_pure", "edge_cut_pure_design_r"}
+    assert all(got["verified_legs"].values())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "cpu_baseline"):
+        assert k in got, k
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libglref.so")), reason="oracle/_ref not built")
