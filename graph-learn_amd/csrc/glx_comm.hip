@@ -217,6 +217,7 @@ struct LocalFabric {
   bool broken = false;
   LocalPost post[64];
   hipEvent_t done[64];  // alltoallv: rank q has read what it needed from its peers' send buffers when done[q] fires
+  std::vector<std::pair<int, hipEvent_t>> retired;  // (device, event) of ranks that have left; under g_fabric_mtx
 
   // Generation barrier with a deadline: a rank that failed before the collective must not
   // hang its peers (and the GPU box) forever.
@@ -263,14 +264,25 @@ struct LocalComm : glx_comm {
     {
       GlxDeviceGuard guard(device);
       (void)hipDeviceSynchronize();  // peers' streams may still wait on this rank's events
-      if (ev_ready) (void)hipEventDestroy(ev_ready);
-      if (ev_done) (void)hipEventDestroy(ev_done);
       stage.release();
     }
+    // This rank's events outlive it: a slower peer may not have ENQUEUED its wait on this rank's `done` event yet when
+    // this rank has already left its last collective and is being torn down (the two host meetings of an exchange are
+    // behind both, the peer's hipStreamWaitEvent loop is not) -- destroying the event here was a use-after-free in the
+    // peer (round 6: one segmentation fault in a rank's last collective in ~50,000 fuzz cases, its peers already gone).
+    // The fabric destroys them when its last rank has gone.
     std::lock_guard<std::mutex> g(g_fabric_mtx);
-    if (fab && --fab->refs == 0) {
-      g_fabrics.erase(fab->key);
-      delete fab;
+    if (fab) {
+      if (ev_ready) fab->retired.emplace_back(device, ev_ready);
+      if (ev_done) fab->retired.emplace_back(device, ev_done);
+      if (--fab->refs == 0) {
+        for (auto& e : fab->retired) {
+          GlxDeviceGuard guard(e.first);
+          (void)hipEventDestroy(e.second);
+        }
+        g_fabrics.erase(fab->key);
+        delete fab;
+      }
     }
   }
 

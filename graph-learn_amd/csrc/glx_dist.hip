@@ -72,6 +72,7 @@ struct Carver {
 
 __device__ __forceinline__ int32_t dist_owner(int64_t id, int32_t P) {
   const uint64_t a = id < 0 ? (uint64_t)0 - (uint64_t)id : (uint64_t)id;  // llabs (hash_partitioner.h:90-92)
+  if ((P & (P - 1)) == 0) return (int32_t)(a & (uint64_t)(P - 1));  // 1, 2, 4, 8 ranks: a mask (P is kernel-uniform)
   // a 64-bit remainder is ~100 instructions on this ISA, a 32-bit one a quarter of that -- and ids nearly always fit
   if (a <= 0xffffffffull) return (int32_t)((uint32_t)a % (uint32_t)P);
   return (int32_t)(a % (uint64_t)P);
@@ -342,17 +343,24 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   for (int64_t base = blockIdx.x * (256ll * kIds); base < a.n; base += gridDim.x * (256ll * kIds), ++it) {
     int64_t id[kIds];
     int64_t r[kIds];
+    bool mine[kIds];
 #pragma unroll
     for (int j = 0; j < kIds; ++j) {
       const int64_t i = base + j * 256 + threadIdx.x;
       id[j] = i < a.n ? a.ids[i] : GLX_EMPTY_KEY;
       r[j] = -1;
+      mine[j] = false;
     }
     if (a.bm_member) {
       RankWord w[kIds];
 #pragma unroll
       for (int j = 0; j < kIds; ++j) {
-        const bool in = id[j] >= 0 && id[j] <= a.bm_max;
+        // An id this rank owns is read from its own shard whether or not the replica holds a copy (same row, same
+        // bytes): with arithmetic own-shard ids that is a division instead of the divergent 16-byte lookup -- an eighth
+        // of the lookups at P = 8, all of them at world size 1 (round 6: the resolve of the headline's 18 M ids at world
+        // size 1 0.145 -> see profiles/r06/world1_resolve.txt).  Its lane reads record 0 (one shared line).
+        mine[j] = kQueue && own_inline && id[j] != GLX_EMPTY_KEY && dist_owner(id[j], a.P) == a.me;
+        const bool in = id[j] >= 0 && id[j] <= a.bm_max && !mine[j];
         w[j] = a.bm_member[in ? (id[j] >> 6) : 0];
         if (!in) w[j].bits = 0;
       }
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
         if (r[j] >= 0) {
           a.loc[i] = a.cache_base + (int32_t)r[j];
           ++n_hit;
-        } else if (kQueue && own_inline && (id[j] == GLX_EMPTY_KEY || dist_owner(id[j], a.P) == a.me)) {
+        } else if (kQueue && own_inline && (mine[j] || id[j] == GLX_EMPTY_KEY || dist_owner(id[j], a.P) == a.me)) {
           // off the replica but this rank's own, and the own shard's ids are arithmetic: the row is a division, no
           // memory round trip to wait for -- nothing the queue could hide (every id off the replica of a world-1
           // request, an eighth of them at P = 8, used to queue for it: 0.185 -> 0.135 ms for the 16.4 M ids of the
