@@ -85,7 +85,7 @@ def compact_roofline(r):
         return None
     out = _pick(r, ("bound", "peak", "unit", "achieved", "frac", "algorithmic_gbs", "memory_side_gbs", "algorithmic_over_peak",
                     "frac_compulsory", "traffic", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
-                    "compulsory_bytes_per_launch", "traffic_over_algorithmic", "frac_of_gather_ceiling", "l2_hit_rate",
+                    "compulsory_bytes_per_launch", "frac_of_gather_ceiling", "l2_hit_rate",
                     "share_of_step", "offline_tcp_busy_frac", "offline_l1_hit_rate"))
     out["kernel"] = _short(r.get("kernel", ""), 72)
     if r.get("achieved_basis"):
@@ -95,8 +95,8 @@ def compact_roofline(r):
         out["frac_basis"] = r["frac_basis"].split(" (")[0].split(";")[0]
     if r.get("traffic_source"):
         out["traffic_source"] = _short(r["traffic_source"], 60)
-    if isinstance(r.get("hbm_bytes_bracket"), (list, tuple)):
-        out["hbm_bytes_bracket"] = [_num(float(x)) for x in r["hbm_bytes_bracket"]]
+    # (hbm_bytes_bracket = [compulsory_bytes_per_launch, traffic] and traffic_over_algorithmic stay in the detail record:
+    # both follow from keys that are in the line)
     cf = r.get("cache_free")
     if cf:
         out["cache_free"] = _pick(cf, ("avg_launch_ms", "achieved", "frac", "frac_of_measured_stream_peak",
@@ -174,7 +174,8 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
                 continue
             roof = rec.get("roofline") or {}
             oc[name] = dict(_pick(rec, ("ms_per_step", "value")), bound=roof.get("bound"), frac=_num(roof.get("frac"), 4),
-                            frac_basis=(roof.get("frac_basis") or "").split(":")[0], traffic=_num(roof.get("traffic"), 4),
+                            frac_basis=(roof.get("frac_basis") or "").split(":")[0].replace(" of this run", ""),
+                            traffic=_num(roof.get("traffic"), 4),
                             verified=rec.get("verified_vs_oracle"))
         line["other_configs"] = oc
         optional.append("other_configs")

@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
         // An id this rank owns is read from its own shard whether or not the replica holds a copy (same row, same
         // bytes): with arithmetic own-shard ids that is a division instead of the divergent 16-byte lookup -- an eighth
         // of the lookups at P = 8, all of them at world size 1 (round 6: the resolve of the headline's 18 M ids at world
-        // size 1 0.145 -> see profiles/r06/world1_resolve.txt).  Its lane reads record 0 (one shared line).
+        // size 1 0.145 -> 0.116 ms, at P = 8 0.265 -> 0.246: profiles/r06/world1_resolve.txt).  Its lane reads record 0
+        // (one shared line).
         mine[j] = kQueue && own_inline && id[j] != GLX_EMPTY_KEY && dist_owner(id[j], a.P) == a.me;
         const bool in = id[j] >= 0 && id[j] <= a.bm_max && !mine[j];
         w[j] = a.bm_member[in ? (id[j] >> 6) : 0];
