@@ -62,12 +62,12 @@ def test_dag_unittest_on_cpu():
     operators: core/dag/test/*_unittest.cpp and core/runner/test/dag_scheduler_unittest.cpp restated.  No device."""
     r = run("dag_unittest")
     assert r.returncode == 0, r.stdout
-    assert "7 test(s), 0 failure(s)" in r.stdout, r.stdout
+    assert "8 test(s), 0 failure(s)" in r.stdout, r.stdout
 
 
 @pytest.mark.skipif(os.environ.get("GLX_TSAN") != "1", reason="opt-in (GLX_TSAN=1): a minute of instrumented compilation")
 def test_dag_unittest_under_thread_sanitizer():
-    """scripts/tsan_dag.sh: the same seven tests in a ThreadSanitizer build of the host sources -- the tape store, the
+    """scripts/tsan_dag.sh: the same eight tests in a ThreadSanitizer build of the host sources -- the tape store, the
     scheduler's query threads, Dataset's prefetch thread and close-while-starved leave no report."""
     r = subprocess.run(["bash", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "tsan_dag.sh")], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
