@@ -1037,6 +1037,7 @@ extern "C" int glx_tune(const char* name, int32_t value) {
     else if (strcmp(name, "resolve_blocks") == 0) side = &sk.resolve_blocks;
     else if (strcmp(name, "resolve_set_share") == 0) side = &sk.resolve_set_share;
     else if (strcmp(name, "resolve_peek") == 0) side = &sk.resolve_peek;
+    else if (strcmp(name, "resolve_own_first") == 0) side = &sk.resolve_own_first;
     GLX_REQUIRE(side != nullptr, "unknown knob '%s'", name);
     side->store(value, std::memory_order_relaxed);
     return GLX_OK;

@@ -225,6 +225,7 @@ struct GlxSideKnobs {
   std::atomic<int64_t> resolve_ids{-1};           // GLX_RESOLVE_IDS=4|8: ids per thread per pass of the partitioned aggregation's resolve kernel (default 2)
   std::atomic<int64_t> resolve_blocks{-1};        // GLX_RESOLVE_BLOCKS=n: workgroups of that kernel (default 1024)
   std::atomic<int64_t> resolve_set_share{-1};     // GLX_RESOLVE_SET_SHARE=n: the halo id set holds at least n / 1024 of a request's ids (A/B; default 16 once a share is known)
+  std::atomic<int64_t> resolve_own_first{-1};     // GLX_RESOLVE_OWN_FIRST=1|0: ids this rank owns skip / take the replica lookup (default: skip at world size 1 only)
   std::atomic<int64_t> resolve_peek{-1};          // GLX_RESOLVE_PEEK=0: no plain load of a set slot before the compare-and-swap (A/B)
   std::atomic<int64_t> idmap_hash_only{-1};       // GLX_IDMAP_HASH_ONLY (set = 1): feature tables keep a hash table even for arithmetic ids (A/B)
 };

@@ -172,7 +172,14 @@ struct ResolveArgs {
   // request's whole resolve): the values every rank shares, and the requester's default_attr behind them
   int64_t* vals;
   float default_attr;
+  // One row of 3 + P int32 per workgroup: its replica / own / remote id counts and its new distinct ids per owner.
+  // The LAST workgroup adds the rows up.  (Rounds 1-5, and this round's first version, raised shared counters with
+  // 5 + P same-address atomics per workgroup; the workgroups all finish together, the atomics queue at the memory side
+  // one behind the other, and the kernel ended with ~0.1 us per WORKGROUP of nothing else: 235 us at 1024 workgroups,
+  // 380 at 2048, 1147 at 8192 for the same 18 M ids -- profiles/r06/resolve_set_probe.txt.)
+  int32_t* part;
   int32_t peek;  // 1: load a set slot before trying to claim it (resolve_cold)
+  int32_t own_first;  // 1: ids this rank owns skip the replica lookup (arithmetic own-shard ids)
 };
 
 // Pass 2 (one thread): per-owner offsets, and the values every rank shares:
@@ -197,30 +204,48 @@ __device__ __forceinline__ void dist_offsets_body(const int32_t* c, int32_t* ctr
   vals[P + 5] = (int64_t)(uint32_t)__float_as_uint(default_attr);
 }
 
-// ... by the last workgroup of the resolve kernel (all 256 threads call it).  The other workgroups raised the counters
-// with device-scope atomics, so they are read the same way (an atomic is performed where all XCDs agree; a plain load
-// could be served by this CU's L1 or this XCD's L2 from a line fetched before the peers' atomics landed) -- every
-// thread one counter, ONE round trip (thread 0 reading them one after the other put two dozen dependent round trips,
-// 40 us, at the end of the kernel).  The counts check themselves -- replica + own + remote ids = n, and the per-owner
-// counts add up to the running total of distinct ids -- so a count that were still on its way (it should not be: every
-// workgroup waited for its atomics' acknowledgement before it took its ticket) is waited for, not published.
-__device__ __forceinline__ void dist_offsets_last_block(int32_t* ctr, int32_t P, int64_t* vals, float default_attr, int64_t n) {
+// ... by the last workgroup of the resolve kernel (all 256 threads call it): adds up the workgroups' rows -- written
+// with agent-scope atomic stores and acknowledged before their owners took their tickets, read here with agent-scope
+// atomic loads (a plain load could be served by this CU's L1 or this XCD's L2 from a line fetched earlier) -- into the
+// counter block, decides whether the set was too small, and publishes offsets and shared values.  The counts check
+// themselves (replica + own + remote ids = n): a row that were still on its way is waited for, not published.
+__device__ __forceinline__ void dist_offsets_last_block(const int32_t* part, int32_t nblocks, int32_t* ctr, int32_t P,
+                                                        int64_t* vals, float default_attr, int64_t n, int32_t insert_limit) {
   __shared__ int32_t s_c[3 * kMaxWorld + 8];
   __shared__ int32_t s_ok;
+  const int32_t S = 3 + P;
   for (int spin = 0; spin < 1024; ++spin) {
-    if ((int32_t)threadIdx.x < 3 * P + 8) s_c[threadIdx.x] = atomicAdd(&ctr[threadIdx.x], 0);
+    if ((int32_t)threadIdx.x < 3 * P + 8) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    for (int32_t c = 0; c < S; ++c) {
+      int32_t sum = 0;
+      for (int32_t b = threadIdx.x; b < nblocks; b += 256) {
+        sum += __hip_atomic_load(&part[(int64_t)b * S + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+      // stats live at [2P + 1, 2P + 4), per-owner counts at [0, P)
+      if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&s_c[c < 3 ? 2 * P + 1 + c : c - 3], sum);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       const int64_t ids = (int64_t)s_c[2 * P + 1] + s_c[2 * P + 2] + s_c[2 * P + 3];
-      int64_t distinct = 0;
-      for (int32_t p = 0; p < P; ++p) distinct += s_c[p];
-      s_ok = ids == n && distinct == (int64_t)s_c[3 * P + 5];
+      s_ok = ids == n;
     }
     __syncthreads();
     if (s_ok) break;
     __builtin_amdgcn_s_sleep(8);
   }
-  if (threadIdx.x == 0) dist_offsets_body(s_c, ctr, P, vals, default_attr);
+  if (threadIdx.x == 0) {
+    int32_t distinct = 0;
+    for (int32_t p = 0; p < P; ++p) distinct += s_c[p];
+    // too small: more distinct ids than the set takes, or a probe sequence that gave up (its flag is an atomic in ctr)
+    s_c[2 * P] = (distinct > insert_limit || atomicAdd(&ctr[2 * P], 0) != 0) ? 1 : 0;
+    for (int32_t p = 0; p < P; ++p) ctr[p] = s_c[p];  // the compaction pass reads the per-owner counts through `off`
+    ctr[2 * P] = s_c[2 * P];
+    ctr[3 * P + 5] = distinct;
+    dist_offsets_body(s_c, ctr, P, vals, default_attr);
+  }
 }
 
 // Pass 1: every id -> a virtual row (own shard / replica), -1 (default row), or -(h + 2) when
@@ -355,12 +380,10 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
       RankWord w[kIds];
 #pragma unroll
       for (int j = 0; j < kIds; ++j) {
-        // An id this rank owns is read from its own shard whether or not the replica holds a copy (same row, same
-        // bytes): with arithmetic own-shard ids that is a division instead of the divergent 16-byte lookup -- an eighth
-        // of the lookups at P = 8, all of them at world size 1 (round 6: the resolve of the headline's 18 M ids at world
-        // size 1 0.145 -> 0.116 ms, at P = 8 0.265 -> 0.246: profiles/r06/world1_resolve.txt).  Its lane reads record 0
-        // (one shared line).
-        mine[j] = kQueue && own_inline && id[j] != GLX_EMPTY_KEY && dist_owner(id[j], a.P) == a.me;
+        // own_first (world size 1; see the launch site): an id this rank owns is read from its own shard whether or
+        // not the replica holds a copy (same row, same bytes) -- with arithmetic own-shard ids a remainder and a
+        // division instead of the divergent 16-byte lookup.  Its lane reads record 0 (one shared line).
+        mine[j] = kQueue && own_inline && a.own_first && id[j] != GLX_EMPTY_KEY && dist_owner(id[j], a.P) == a.me;
         const bool in = id[j] >= 0 && id[j] <= a.bm_max && !mine[j];
         w[j] = a.bm_member[in ? (id[j] >> 6) : 0];
         if (!in) w[j].bits = 0;
@@ -463,29 +486,34 @@ __global__ __launch_bounds__(256) void glx_dist_resolve_kernel(ResolveArgs a) {
   atomicAdd(&s_stat[1], n_own);
   atomicAdd(&s_stat[2], n_cold);
   __syncthreads();
-  // (a thread waits for the acknowledgement of its atomics below before the workgroup takes its ticket)
-  if (threadIdx.x < 3 && s_stat[threadIdx.x]) atomicAdd(&a.ctr[2 * a.P + 1 + threadIdx.x], s_stat[threadIdx.x]);
-  if ((int)threadIdx.x < a.P && s_cnt[threadIdx.x]) atomicAdd(&a.ctr[threadIdx.x], s_cnt[threadIdx.x]);
+  // This workgroup's row: no address is shared with another workgroup.
+  {
+    int32_t* row = a.part + (int64_t)blockIdx.x * (3 + a.P);
+    if (threadIdx.x < 3) __hip_atomic_store(&row[threadIdx.x], s_stat[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < a.P) __hip_atomic_store(&row[3 + threadIdx.x], s_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (threadIdx.x == 0) {
-    int32_t sum = 0;
-    for (int32_t p = 0; p < a.P; ++p) sum += s_cnt[p];
-    const int32_t fresh = sum - s_sum;
-    if (fresh) {
-      const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], fresh);
-      if (before + fresh > a.insert_limit) atomicExch(&a.ctr[2 * a.P], 1);
+    if (!kQueue) {  // (this variant keeps its running total for the early "too small" test of its flushes)
+      int32_t sum = 0;
+      for (int32_t p = 0; p < a.P; ++p) sum += s_cnt[p];
+      const int32_t fresh = sum - s_sum;
+      if (fresh) {
+        const int32_t before = atomicAdd(&a.ctr[3 * a.P + 5], fresh);
+        if (before + fresh > a.insert_limit) atomicExch(&a.ctr[2 * a.P], 1);
+      }
     }
     if (kQueue && a.cold_cnt) a.cold_cnt[blockIdx.x] = s_list_n;
   }
-  // Pass 2 in the same launch: the last workgroup to take a ticket has every other workgroup's counts before it.
-  // No cache-flushing fence is involved (an agent-scope fence writes this XCD's L2 back: two per workgroup cost the
-  // kernel 70 us): the counters are raised with device-scope atomics, which are performed where all XCDs agree; a
-  // workgroup waits for the acknowledgement of its own (s_waitcnt) before it takes its ticket, and the last workgroup
-  // reads the counters with atomics too.
+  // Pass 2 in the same launch: the last workgroup to take a ticket has every other workgroup's row before it.  No
+  // cache-flushing fence is involved (an agent-scope fence writes this XCD's L2 back: two per workgroup cost the kernel
+  // 50 us): the rows are written with agent-scope atomic stores, a workgroup waits for their acknowledgement
+  // (s_waitcnt) before it takes its ticket -- the ONE same-address atomic it issues -- and the last workgroup reads the
+  // rows with agent-scope atomic loads.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(&a.ctr[3 * a.P + 6], 1) == (int32_t)gridDim.x - 1;
   __syncthreads();
-  if (s_last) dist_offsets_last_block(a.ctr, a.P, a.vals, a.default_attr, a.n);
+  if (s_last) dist_offsets_last_block(a.part, (int32_t)gridDim.x, a.ctr, a.P, a.vals, a.default_attr, a.n, a.insert_limit);
 }
 
 // Pass 2 for a request without ids (no resolve launch): the shared values of an empty request.  The counter block need
@@ -1196,6 +1224,7 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
   const size_t o_cold = cv.take((size_t)(n > 0 ? n : 1) * 8);
   const size_t o_list = cv.take(queue && P > 1 ? (size_t)rgrid * (size_t)region * 4 : 0);
   const size_t o_lcnt = cv.take(queue && P > 1 ? (size_t)rgrid * 4 : 0);
+  const size_t o_part = cv.take((size_t)rgrid * (3 + P) * 4);
   int rc = sl.req.ensure(cv.at);
   if (rc != GLX_OK) return rc;
   int32_t* loc = reinterpret_cast<int32_t*>(sl.req.p + o_loc);
@@ -1256,7 +1285,14 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
         a.region = region;
         a.vals = st->d_vals;
         a.default_attr = default_attr;
+        a.part = reinterpret_cast<int32_t*>(sl.req.p + o_part);
         a.peek = glx_side_knobs().resolve_peek.load(std::memory_order_relaxed) != 0;
+        // own ids before the replica: only where it pays -- at world size 1 every lookup goes away (0.145 -> 0.116 ms
+        // for the headline's 18 M ids); with more ranks the test costs every id a remainder and saves 1 / P of the
+        // lookups: level at P = 2, +4 % at P = 4 and 8 (same-process A/B, profiles/r06/resolve_set_probe.txt).
+        // GLX_RESOLVE_OWN_FIRST = 1 / 0 forces it on / off.
+        const int64_t own_knob = glx_side_knobs().resolve_own_first.load(std::memory_order_relaxed);
+        a.own_first = own_knob < 0 ? P == 1 : own_knob != 0;
         if (queue) {
           if (ranked && per == 8) glx_dist_resolve_kernel<8, true><<<rgrid, 256, 0, s>>>(a);
           else if (ranked && per == 4) glx_dist_resolve_kernel<4, true><<<rgrid, 256, 0, s>>>(a);

@@ -42,6 +42,7 @@ GlxSideKnobs& glx_side_knobs() {
     if (const char* e = getenv("GLX_RESOLVE_BLOCKS")) k.resolve_blocks = atoll(e);
     if (const char* e = getenv("GLX_RESOLVE_SET_SHARE")) k.resolve_set_share = atoll(e);
     if (const char* e = getenv("GLX_RESOLVE_PEEK")) k.resolve_peek = atoll(e);
+    if (const char* e = getenv("GLX_RESOLVE_OWN_FIRST")) k.resolve_own_first = atoll(e);
   });
   return k;
 }

@@ -48,9 +48,12 @@ case "$what" in
       -m gpu -q -x > $O/pytest_dist.log 2>&1; tail -6 $O/pytest_dist.log ;;
   resolve-set)
     cd /tmp && export TMPDIR=/tmp
-    timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/rsp -o t -- python $R/scripts/r06/resolve_set_probe.py 2>&1 | grep -E "^phases|^last" | tee $O/resolve_set_probe.txt
-    python $R/scripts/r06/resolve_set_parse.py $(find /tmp/rsp -name '*kernel_trace.csv' | head -1) | tee -a $O/resolve_set_probe.txt
-    rm -rf /tmp/rsp; cd $R ;;
+    for P in ${RESOLVE_P:-8}; do
+      echo "=== P = $P" | tee -a $O/resolve_set_probe.txt
+      timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/rsp -o t -- python $R/scripts/r06/resolve_set_probe.py $P 2>&1 | grep -E "^phases|^last" | tee -a $O/resolve_set_probe.txt
+      python $R/scripts/r06/resolve_set_parse.py $(find /tmp/rsp -name '*kernel_trace.csv' | head -1) | tee -a $O/resolve_set_probe.txt
+      rm -rf /tmp/rsp
+    done; cd $R ;;
   smp-lines)
     # 128-byte lines the hop-2 sampler launch asks L2 for, per draw (would staging a row in LDS cut lines?)
     cd /tmp && export TMPDIR=/tmp
