@@ -108,7 +108,17 @@ __global__ __launch_bounds__(256) void glx_seg_scan_kernel(const int32_t* __rest
   const unsigned long long tag = (unsigned long long)epoch << 32;
   if (bad_at < n) atomicMax(&words[0], tag | (uint32_t)(n - bad_at));  // the largest n - i = the first violation
   const int32_t level = (incomplete || bad_at < n) ? 2 : (nonuniform ? 1 : 0);
-  if (level) atomicMax(&words[1], tag | (uint32_t)level);
+  // One atomic per WAVE, and none once the word already says as much (round 6): a ragged request whose length divides
+  // evenly raises level 1 from nearly every thread -- 4 M atomics on one address for the headline's 16.4 M ids, which
+  // queue at the memory side: +0.78 ms on a 3.6 ms aggregate (profiles/r06/seg_ragged_probe.txt).  The word only grows,
+  // so a (coherent) read that already shows this wave's level or more makes the atomic redundant.
+  // (ballots see the lanes still here: threads past the end of the request, or behind an out-of-range id, have left)
+  const uint64_t here = __ballot(true), at2 = __ballot(level == 2), at1 = __ballot(level >= 1);
+  const int32_t wave_level = at2 ? 2 : (at1 ? 1 : 0);
+  if (wave_level && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)here) - 1)) {
+    const unsigned long long mine = tag | (uint32_t)wave_level;
+    if (__hip_atomic_load(&words[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(&words[1], mine);
+  }
 }
 
 // seg_start[s] = lower_bound(seg[0..valid_len), s) for every s -- only when the scan left the table incomplete.
