@@ -269,7 +269,7 @@ struct LocalComm : glx_comm {
     // This rank's events outlive it: a slower peer may not have ENQUEUED its wait on this rank's `done` event yet when
     // this rank has already left its last collective and is being torn down (the two host meetings of an exchange are
     // behind both, the peer's hipStreamWaitEvent loop is not) -- destroying the event here was a use-after-free in the
-    // peer (round 6: one segmentation fault in a rank's last collective in ~50,000 fuzz cases, its peers already gone).
+    // peer (round 6: one segmentation fault in a rank's last collective in ~84,000 fuzz cases, its peers already gone).
     // The fabric destroys them when its last rank has gone.
     std::lock_guard<std::mutex> g(g_fabric_mtx);
     if (fab) {

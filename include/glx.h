@@ -793,7 +793,12 @@ GLX_API int glx_probe_bandwidth(int device, int kind, int64_t bytes, int64_t uni
  * Test knobs of the side paths, same rules, -1 restores the default: "cond_sequential" (GLX_COND_SEQUENTIAL),
  * "dist_no_bitmap" (GLX_DIST_NO_BITMAP), "filter_span_cap" (GLX_FILTER_SPAN_CAP), "filter_dedup_min_rows"
  * (GLX_FILTER_DEDUP_MIN_ROWS), "idmap_hash_only" (GLX_IDMAP_HASH_ONLY: feature tables created afterwards keep a hash table
- * even when their ids are an arithmetic progression). */
+ * even when their ids are an arithmetic progression); of the partitioned aggregation's resolve pass: "resolve_ids"
+ * (GLX_RESOLVE_IDS: ids per thread per pass), "resolve_blocks" (GLX_RESOLVE_BLOCKS: workgroups), "resolve_set_share"
+ * (GLX_RESOLVE_SET_SHARE: the halo id set holds at least n / 1024 of a request's ids), "resolve_peek" (GLX_RESOLVE_PEEK = 0:
+ * no plain load of a set slot before the compare-and-swap), "resolve_own_first" (GLX_RESOLVE_OWN_FIRST = 1 | 0: ids this
+ * rank owns skip / take the replica lookup; default: skip at world size 1 only).  Test aid: "seg_epochs_before_wrap" (the
+ * calling thread's segment-word buffers hand out `value` more epochs before their counter wraps). */
 GLX_API int glx_tune(const char* name, int32_t value);
 
 #ifdef __cplusplus
