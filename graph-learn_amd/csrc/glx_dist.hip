@@ -1197,11 +1197,13 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
   stat.ids = n;
 
   const int nvals = P + 6;  // + the requester's default_attr (what its unknown ids look like)
-  // The resolve launch.  Few, long-lived blocks: every block pays global atomics at its flushes and exit (a 16 M-id
-  // request: 0.27 ms with 4096 blocks, 0.16 ms with 1024, 0.8 ms with 65536).  Two ids per thread-iteration with
-  // the rank records (0.10 ms; one: 0.12, four: 0.12), one with the hash map (0.30; two: 0.32, four: 0.34) --
-  // scripts/resolve_probe.py.  With a replica the ids it does not hold are a small share of the request: queued per
-  // wave and resolved 64 at a time (kQueue); without one every id takes that path and a queue would only add work.
+  // The resolve launch.  Few, long-lived workgroups -- 1024, four per CU: every wave ends with a partial batch of its
+  // queue (a full chain of dependent round trips for a few ids), and more resident waves contend for the same gather
+  // path (P = 8, 18 M ids, round 6's kernel: 192 us at 768 workgroups x 4 ids, 199 at 1024 x 2, 205 at 1280, 236 at
+  // 1536, 290 at 2048: profiles/r06/resolve_probe_history.txt D).  Two ids per thread-iteration with the rank
+  // records, one with the hash map (scripts/resolve_probe.py).  With a replica the ids it does not hold are a small
+  // share of the request: queued per wave and resolved 64 at a time (kQueue); without one every id takes that path and
+  // a queue would only add work.
   static const bool kNoQueue = getenv("GLX_RESOLVE_NO_QUEUE") != nullptr;  // (ablation)
   const bool has_cache = st->cache != nullptr;
   const bool ranked = has_cache && st->bm_member != nullptr;
@@ -1259,7 +1261,7 @@ int resolve_and_fetch(glx_dist_store* st, int slot, const int64_t* d_ids, int64_
         // one launch clears the set and the counter block; the resolve's last workgroup turns the counts into offsets
         // and the shared values (rounds 1-5: memset + fill + resolve + offsets + parameter kernel)
         glx_dist_fill_keys_kernel<<<grid_for((int64_t)tcap), 256, 0, s>>>(tkeys, tcap, st->d_ctr, 3 * P + 8);
-        ResolveArgs a;
+        ResolveArgs a{};
         a.cache_map = PackedMap{st->cache_slots, st->cache ? st->cache->idmap.cap - 1 : 0};
         a.own_map = f->map();
         a.ids = d_ids;
