@@ -179,6 +179,11 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
                             verified=rec.get("verified_vs_oracle"))
         line["other_configs"] = oc
         optional.append("other_configs")
+    p8 = res.get("edge_cut_p8_one_gpu")
+    if isinstance(p8, dict) and p8.get("ms_per_rank_step"):
+        line["edge_cut_p8_one_gpu"] = dict(_pick(p8, ("ms_per_step_all_ranks", "ms_per_rank_step")),
+                                           verified=p8.get("answers_equal_unpartitioned"))
+        optional.append("edge_cut_p8_one_gpu")
     for k in ("host_boundary", "small_batches"):
         v = res.get(k)
         if isinstance(v, dict):
@@ -192,7 +197,7 @@ def compact_line(res, detail_path=None, limit=LINE_LIMIT):
         line["detail"] = detail_path
     text = json.dumps(line, separators=(", ", ": "))
     trimmed = []
-    for k in ("small_batches", "host_boundary_edges_per_s", "verified_legs", "phases", "roofline_sampler", "roofline_u_i",
+    for k in ("small_batches", "host_boundary_edges_per_s", "edge_cut_p8_one_gpu", "verified_legs", "phases", "roofline_sampler", "roofline_u_i",
               "placements", "other_configs"):
         if len(text) <= limit:
             break
@@ -517,6 +522,31 @@ def edge_cut_world1(args):
             "sampling_exchange_hop2": rec.get("sampling_exchange_hop2"),
             "note": "world size 1 over RCCL, generic path (GLX_DIST_NO_SHORTCUT=1): partition, self-exchange, resolve + "
                     "dedup, halo slots, 3-source reduce, 3-stage pipeline -- no link time; compare with ms_per_step above"}
+
+
+def edge_cut_p8_one_gpu(args):
+    """One GPU playing eight ranks (scripts/edge_cut_p8_probe.py in a process of its own): eight threads, each a rank with its
+    own shard of the headline graph and features, its own 65,536-seed step per iteration, the in-process transport (device
+    copies where xGMI would be), hot-row + graph replicas, merged aggregation, speculation ledger; every rank's answers
+    compared with the unpartitioned operators.  NOT a multi-GPU measurement: the eight ranks' kernels share one GPU and the
+    'links' are copies on it -- wall time of a step of ALL ranks / 8 bounds one rank's GPU work per step from above
+    (DESIGN 12 has the kernel-level figure from the same rig under rocprofv3)."""
+    import subprocess
+    exe = os.path.join(ROOT, "scripts", "edge_cut_p8_probe.py")
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, GRAPH_REPLICA="1", MERGED="1", LEDGER="1")
+    t0 = time.time()
+    try:
+        r = subprocess.run([sys.executable, exe, "8", str(args.hot_fraction), "12"], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=420)
+        rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{\"p8_probe\"")][-1])["p8_probe"]
+    except Exception as ex:  # noqa: BLE001 -- never lose the headline line
+        return {"error": repr(ex)}
+    rec["wall_s_incl_build"] = time.time() - t0
+    rec["note"] = ("eight ranks as threads sharing ONE GPU, in-process transport: not a multi-GPU number; ms_per_rank_step = "
+                   "wall time of a step of all ranks / 8, transport copies and the eight ranks' contention included")
+    return rec
 
 
 def bench_c5(args, dev, result_out, world=1, rank=0, sharded=False):
@@ -1908,6 +1938,10 @@ def main():
                                                 "alternating on as many streams; value in edges/s" % args.graph_streams)
     if extras["edge_cut_probe"]:
         res["edge_cut_world1"] = edge_cut_world1(args)
+        # (after this process's store is gone: eight ranks' shards, replicas and buffers want ~110 GB of the HBM)
+        want_p8 = True
+    else:
+        want_p8 = False
     if extras["other_configs"]:
         # free this process's store first: c5 needs most of the HBM for its build
         del graph, feats
@@ -1917,6 +1951,14 @@ def main():
         free_b, total_b = torch.cuda.mem_get_info(dev)
         log("before the other configs: %.1f of %.1f GB of HBM free in this process's view" % (free_b / 1e9, total_b / 1e9))
         res["other_configs"] = other_configs(args)
+    if want_p8 and rank == 0:
+        if "graph" in dir():
+            del graph, feats
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+        res["edge_cut_p8_one_gpu"] = edge_cut_p8_one_gpu(args)
+        log("eight ranks on this one GPU: %s" % res["edge_cut_p8_one_gpu"])
     if rank == 0:
         emit_result(result_out, res, args)
     if sharded:

@@ -180,4 +180,12 @@ else:
                                                                   max(x or 0 for x in times) * 1e3 / P, all(ok)))
 for r in (0, P - 1):
     print("rank %d hop-2 request:" % r, stats[r])
+import json
+print(json.dumps({"p8_probe": {"ranks": P, "mode": "sym" if sym else ("solo" if solo else "all"), "hot_fraction": hot_fraction,
+                               "steps": steps, "ms_per_step_all_ranks": max(x or 0 for x in times) * 1e3,
+                               "ms_per_rank_step": max(x or 0 for x in times) * 1e3 / (1 if solo else P),
+                               "answers_equal_unpartitioned": bool(all(ok)),
+                               "merged_aggregation": os.environ.get("MERGED", "0") == "1",
+                               "ledger": os.environ.get("LEDGER", "0") == "1",
+                               "graph_replica": graph_replica_on}}))
 sys.exit(0 if all(ok) else 1)

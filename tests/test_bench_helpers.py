@@ -79,6 +79,20 @@ def test_headline_line_stays_under_the_drivers_tail():
     assert got["detail"] == "bench_detail.json"
 
 
+def test_headline_line_carries_the_eight_ranks_on_one_gpu_leg():
+    """Round 6: the N = 1 run also times eight thread-ranks sharing the GPU (bench.edge_cut_p8_one_gpu); its two numbers and
+    its verification flag ride in the line, an error record does not."""
+    import json
+    res = _canned("bench_c3_n1_final.json")
+    res["edge_cut_p8_one_gpu"] = {"ranks": 8, "mode": "all", "ms_per_step_all_ranks": 24.54321, "ms_per_rank_step": 3.0679,
+                                  "answers_equal_unpartitioned": True, "note": "x" * 300}
+    got = json.loads(bench.compact_line(res, "bench_detail.json"))
+    assert got["edge_cut_p8_one_gpu"] == {"ms_per_step_all_ranks": 24.5432, "ms_per_rank_step": 3.0679, "verified": True}
+    res["edge_cut_p8_one_gpu"] = {"error": "TimeoutExpired"}
+    line = bench.compact_line(res, "bench_detail.json")
+    assert "edge_cut_p8_one_gpu" not in json.loads(line) and len(line) <= bench.LINE_LIMIT
+
+
 def test_headline_line_trims_optional_blocks_before_it_would_outgrow_the_limit():
     import json
     res = _canned("bench_c3_n1_final.json")
