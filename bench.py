@@ -88,8 +88,7 @@ def compact_roofline(r):
                     "compulsory_bytes_per_launch", "frac_of_gather_ceiling", "l2_hit_rate",
                     "share_of_step", "offline_tcp_busy_frac", "offline_l1_hit_rate"))
     out["kernel"] = _short(r.get("kernel", ""), 72)
-    if r.get("achieved_basis"):
-        out["achieved_basis"] = r["achieved_basis"]
+    # (achieved_basis stays in the detail record: frac_basis below says which launches achieved / frac come from)
     if r.get("frac_basis"):
         # whole sentences only: the basis of the fraction must not be cut mid-word
         out["frac_basis"] = r["frac_basis"].split(" (")[0].split(";")[0]
