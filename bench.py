@@ -977,9 +977,12 @@ def main():
                     help="N>1: auto = --verify whenever an unpartitioned copy of the graph and the feature table fits "
                          "beside the shards (<= 64 GiB): every partitioned leg of the line is then checked, bit for bit, "
                          "against the unpartitioned operators on every rank")
-    ap.add_argument("--hot-fraction", type=float, default=0.25,
+    ap.add_argument("--hot-fraction", type=float, default=0.5,
                     help="N>1: every GPU keeps a replica of this fraction of the feature rows (the top vertices by "
-                         "global in-degree); the rest is fetched per request (halo exchange of the cold tail)")
+                         "global in-degree); the rest is fetched per request (halo exchange of the cold tail).  0.5 since "
+                         "round 6 (5 GB of rows + 6 GB of adjacency per GPU on the headline graph, 4 %% of the HBM): one "
+                         "rank's step at P = 8 costs 3.12 / 2.72 / 2.50 / 2.51 ms of kernels at 0.10 / 0.25 / 0.50 / 1.0 "
+                         "and moves 8x fewer halo rows at 0.5 than at 0.25 (profiles/r06/p8_sym_hot_sweep.txt)")
     ap.add_argument("--host-boundary", default="on", choices=["on", "off"],
                     help="N=1: also run graph-learn_amd/lib/host_path_bench (requests through the C++ operator API "
                          "with host buffers) and report its PCIe-inclusive rate under \"host_boundary\"")

@@ -27,20 +27,20 @@ case "$what" in
     for mode in "0 0" "0 1" "1 1"; do
       set -- $mode
       echo "=== LEDGER=$1 MERGED=$2" >> $O/p8.txt
-      GRAPH_REPLICA=1 LEDGER=$1 MERGED=$2 timeout 600 python scripts/edge_cut_p8_probe.py 8 0.25 6 2>&1 | grep -v amdgpu.ids >> $O/p8.txt
+      GRAPH_REPLICA=1 LEDGER=$1 MERGED=$2 timeout 600 python scripts/edge_cut_p8_probe.py 8 ${HOT:-0.25} 6 2>&1 | grep -v amdgpu.ids >> $O/p8.txt
     done
     cut -c1-300 $O/p8.txt ;;
   p8-solo)
     cd /tmp && export TMPDIR=/tmp
     GRAPH_REPLICA=1 MERGED=1 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_solo -o p8 --output-format csv -- \
-      python $R/scripts/edge_cut_p8_probe.py 8 0.25 6 solo 2>&1 | grep "ONLY rank 0"
+      python $R/scripts/edge_cut_p8_probe.py 8 ${HOT:-0.25} 6 solo 2>&1 | grep "ONLY rank 0"
     python $R/scripts/r03/p8_solo_step.py $(find $O/prof_solo -name '*kernel_trace.csv' | head -1) | tee $O/p8_solo_step.txt
     rm -rf $O/prof_solo ;;
   p8-sym)
     # every rank asks, one stream for all (no kernel overlaps another): rank 0's host thread's kernels = ONE rank's step
     cd /tmp && export TMPDIR=/tmp
     GRAPH_REPLICA=1 MERGED=1 LEDGER=${LEDGER:-0} timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_sym -o p8 --output-format csv -- \
-      python $R/scripts/edge_cut_p8_probe.py 8 0.25 6 sym 2>&1 | grep -E "every rank asks|rank 0 host thread" | tee $O/p8_sym_run.txt
+      python $R/scripts/edge_cut_p8_probe.py 8 ${HOT:-0.25} 6 sym 2>&1 | grep -E "every rank asks|rank 0 host thread" | tee $O/p8_sym_run.txt
     tid=$(grep "rank 0 host thread" $O/p8_sym_run.txt | grep -o '[0-9]*$')
     python $R/scripts/r03/p8_solo_step.py $(find $O/prof_sym -name '*kernel_trace.csv' | head -1) --thread $tid | tee $O/p8_sym_step.txt
     rm -rf $O/prof_sym ;;
