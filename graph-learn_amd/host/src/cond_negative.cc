@@ -225,6 +225,14 @@ private:
   Status Lookup(const ConditionalSamplingRequest* request, CondEntry** out) {
     const std::string& type = request->Type();
     std::lock_guard<std::mutex> g(mtx_);
+    // The tables belong to ONE store: an entry keeps a pointer to the store's device graph.  The operator is a
+    // process-wide singleton (op_factory.cc:26-66) and outlives stores; bound to a new store it starts over (round 6: a
+    // second Graph with the same edge type name in one process found the first one's entry -- a dangling graph
+    // pointer, seen as a sporadic "graph and condition table live on different devices").
+    if (store_uid_ != graph_store_->Uid()) {
+      tables_.clear();
+      store_uid_ = graph_store_->Uid();
+    }
     auto it = tables_.find(type);
     if (it != tables_.end()) {
       *out = it->second.get();
@@ -299,6 +307,7 @@ private:
   }
 
   std::mutex mtx_;
+  uint64_t store_uid_ = 0;  // GraphStore::Uid() of the store tables_ was built over (uids start at 1)
   std::map<std::string, std::unique_ptr<CondEntry>> tables_;
   std::atomic<uint64_t> call_counter_{0};
 };

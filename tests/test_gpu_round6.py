@@ -92,3 +92,51 @@ def test_a_captured_aggregate_with_segment_ids_keeps_its_words_in_its_own_scratc
         assert np.array_equal(emb.cpu().numpy().view(np.uint32), we.view(np.uint32)), what
     del g
     feats.close()
+
+
+def test_conditional_negative_sampler_starts_over_on_a_new_store(tmp_path):
+    """The operator is a process-wide singleton that caches one condition table per edge type -- with a pointer to the
+    store's device graph.  A second Graph in the same process with the same type name must get tables of its OWN
+    candidates: with the cache of the first store (round 6: a sporadic 'graph and condition table live on different
+    devices' when two test modules built their fixtures one after the other) every negative would come from the first
+    graph's candidate ids."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "graph-learn_amd", "python"))
+    import graphlearn as gl
+    import pyapi_fixture as fx
+
+    def build(sub, nodes, edges):
+        d = str(tmp_path / sub)
+        os.makedirs(d)
+        cond = fx.write_cond_nodes(d, "cond_item", count=nodes)
+        rel = fx.write_relation_edges(d, "relation", count=edges)  # i -> i + 2, i + 3, i + 5 for i < edges
+        g = gl.Graph() \
+            .node(cond, "cond_item", gl.Decoder(attr_types=["int", "int", "float", "string"], weighted=True)) \
+            .edge(rel, ("cond_item", "cond_item", "cond_sim"), gl.Decoder(weighted=True), directed=True)
+        g.init(tracker=d)
+        return g
+
+    def negatives(g):
+        ns = g.negative_sampler("cond_sim", expand_factor=4, strategy="random", conditional=True, unique=False,
+                                batch_share=False, int_cols=[0, 1], int_props=[0.25, 0.25], str_cols=[0], str_props=[0.5])
+        out = []
+        src, dst = np.array([1, 2, 3, 4, 5]), np.array([12, 34, 2, 67, 88])
+        for cc in range(20):
+            ns.set_call_counter(cc)
+            ids = ns.get(src, dst).ids
+            assert ids.shape == (5, 4)
+            for i in range(5):
+                assert ids[i, 0] % 5 == dst[i] % 5 and ids[i, 1] % 4 == dst[i] % 4 and ids[i, 2] % 3 == dst[i] % 3
+            out.append(ids)
+        return np.concatenate(out).reshape(-1)
+
+    first = build("a", 200, 100)   # candidates: the distinct destinations 2 .. 104
+    a = negatives(first)
+    assert a.max() <= 104
+    first.close()
+    second = build("b", 400, 300)  # candidates: 2 .. 304
+    b = negatives(second)
+    assert b.max() > 104 and b.max() <= 304, "the second graph's negatives come from the first graph's candidates"
+    second.close()
