@@ -32,7 +32,9 @@ def sub_csr(orc, src, dst, weight, need_ids, sort_by_weight=True, with_alias=Tru
     hi = int(max(int(src.max().item()), int(need_ids.max()) if need_ids.size else 0)) + 1
     flag = torch.zeros(hi, dtype=torch.bool, device=dev)
     flag[need[(need >= 0) & (need < hi)]] = True
-    idx = torch.nonzero(flag[src]).view(-1)  # ascending = insertion order
+    step = 1 << 30  # torch.nonzero takes at most 2^31 elements: the 2.3 B-edge list goes through in pieces
+    idx = torch.cat([torch.nonzero(flag[src[lo:lo + step]]).view(-1) + lo for lo in range(0, max(1, src.shape[0]), step)])
+    # ascending = insertion order
     s = src[idx].cpu().numpy()
     d = dst[idx].cpu().numpy()
     e = idx.cpu().numpy().astype(np.int64)
