@@ -93,7 +93,15 @@ uintptr_t Server::DeviceFeatures(const std::string& node_type) {
 
 void Server::Stop() {
   if (store_) {
-    DagScheduler::StopAll();  // the queries read this store: they end before it does
+    // Queries reach a store only through the process-wide OpFactory, i.e. they read the store that is being served
+    // NOW: they end before it does.  A Server whose store the operators do not serve (an older one beside a newer
+    // one) takes nobody's queries with it (Server::Stop of any one Server stopped them all).
+    bool serving;
+    {
+      std::lock_guard<std::mutex> g(g_bound_mtx);
+      serving = bound_ && !g_bound.empty() && g_bound.back() == this;
+    }
+    if (serving) DagScheduler::StopAll();
     if (bound_) {
       std::lock_guard<std::mutex> g(g_bound_mtx);
       for (size_t i = 0; i < g_bound.size(); ++i) {

@@ -357,4 +357,35 @@ TEST(Dataset, ClosingWhileTheQueryIsStarvedDoesNotHang) {
   delete client;
 }
 
+// Queries read the store the operators serve NOW: stopping an older Server beside it leaves them running (ADVICE r05:
+// Server::Stop of any one Server ended every query of the process); stopping the serving one ends them.
+TEST(DagScheduler, OnlyTheServingServerTakesTheQueriesWithIt) {
+  g_counter_at = 0;
+  SetGlobalFlagTapeCapacity(2);
+  Server* older = NewServer(0, 1, "", "");
+  Server* serving = NewServer(0, 1, "", "");
+  older->Init({}, {});
+  serving->Init({}, {});  // the operators serve the most recently initialised store (client.cc)
+  EXPECT_TRUE(older->InitStatus().ok() && serving->InitStatus().ok());
+  Client* client = NewInMemoryClient();
+  DagRequest req;
+  DagDef def = ChainDag(15, 5);
+  req.ParseFrom(&def, true);
+  EXPECT_TRUE(client->RunDag(&req).ok());
+  GetDagValuesRequest get(15);
+  GetDagValuesResponse first;
+  EXPECT_TRUE(client->GetDagValues(&get, &first).ok() && first.Valid());
+  older->Stop();
+  for (int i = 0; i < 6; ++i) {  // more rounds than the tape store held when the older server went
+    GetDagValuesResponse more;
+    EXPECT_TRUE(client->GetDagValues(&get, &more).ok());
+  }
+  serving->Stop();
+  GetDagValuesResponse gone;
+  EXPECT_TRUE(!client->GetDagValues(&get, &gone).ok());
+  delete older;
+  delete serving;
+  delete client;
+}
+
 int main() { return RunAllTests(); }
