@@ -62,7 +62,7 @@ def test_dag_unittest_on_cpu():
     operators: core/dag/test/*_unittest.cpp and core/runner/test/dag_scheduler_unittest.cpp restated.  No device."""
     r = run("dag_unittest")
     assert r.returncode == 0, r.stdout
-    assert "8 test(s), 0 failure(s)" in r.stdout, r.stdout
+    assert "9 test(s), 0 failure(s)" in r.stdout, r.stdout
 
 
 @pytest.mark.skipif(os.environ.get("GLX_TSAN") != "1", reason="opt-in (GLX_TSAN=1): a minute of instrumented compilation")
