@@ -1203,8 +1203,8 @@ extern "C" int glx_aggregate(const glx_features* f, int op, const int64_t* node_
   const size_t emb_n = (size_t)num_segments * f->dim;
   // outputs go straight into the caller's buffers when those are pinned (glx_mapped_ptr): the embeddings are
   // by far the largest part of a response (4 * dim bytes per segment)
-  float* m_emb = static_cast<float*>(glx_mapped_ptr(emb_out));
-  int32_t* m_cnt = static_cast<int32_t*>(glx_mapped_ptr(cnt_out));
+  float* m_emb = static_cast<float*>(glx_mapped_ptr(emb_out, emb_n * 4));
+  int32_t* m_cnt = static_cast<int32_t*>(glx_mapped_ptr(cnt_out, (size_t)num_segments * 4));
   const bool direct = m_emb != nullptr && m_cnt != nullptr;
   const size_t out_b = direct ? 0 : ((emb_n * 4 + 15) & ~(size_t)15) + (size_t)num_segments * 4;
   const size_t bytes = (size_t)num_ids * 8 + (size_t)num_ids * 4 + out_b + 64;
@@ -1260,7 +1260,7 @@ extern "C" int glx_lookup(const glx_features* f, const int64_t* node_ids, int64_
   }
   GlxHostCallSlot admitted(f->device);
   const size_t out_bytes = (size_t)n * f->dim * 4;
-  float* m_out = static_cast<float*>(glx_mapped_ptr(out));  // pinned caller buffer: the kernel writes it directly
+  float* m_out = static_cast<float*>(glx_mapped_ptr(out, out_bytes));  // pinned caller buffer: the kernel writes it directly
   const size_t ids_b = ((size_t)n * 8 + 15) & ~(size_t)15;  // ids first, 16-byte aligned rows after them
   char* d = nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ids_b + (m_out ? 0 : out_bytes), s, 0);

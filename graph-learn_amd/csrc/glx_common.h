@@ -753,7 +753,10 @@ struct GlxHostCallSlot {
 // their kernels write results
 // straight into such a buffer -- the response crosses PCIe once, as the kernel's own coalesced stores, with no
 // staging copy and no copy engine in between; pageable buffers are served through a device workspace + copy.
-void* glx_mapped_ptr(const void* host_ptr);
+// The WHOLE of [host_ptr, host_ptr + bytes) must lie inside one registered range (round 6: only the first byte used to be
+// looked up -- a buffer that began inside a registered range and ran past its end would have been written directly,
+// beyond the mapping; now it takes the staged path, where the runtime refuses the copy across the boundary by name).
+void* glx_mapped_ptr(const void* host_ptr, size_t bytes);
 
 static inline hipStream_t glx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -1128,8 +1128,8 @@ extern "C" int glx_sample_filtered(const glx_graph* g, int sampler, const int64_
   }
   GlxHostCallSlot admitted(g->device);
   const size_t nb = (size_t)batch, n_out = nb * (size_t)k;
-  int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out));  // pinned caller buffers are written directly
-  int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out));
+  int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out, n_out * 8));  // pinned caller buffers are written directly
+  int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out, n_out * 8));
   const bool direct = m_nbr != nullptr && m_eid != nullptr;
   Staged st;
   rc = glx_scratch_alloc(reinterpret_cast<void**>(&st.d), (nb * 3 + (direct ? 0 : n_out * 2)) * 8, s, 0);

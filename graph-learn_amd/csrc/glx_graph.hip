@@ -138,7 +138,7 @@ GlxHostCallSlot::~GlxHostCallSlot() {
   g.cv.notify_one();
 }
 
-void* glx_mapped_ptr(const void* host_ptr) {
+void* glx_mapped_ptr(const void* host_ptr, size_t bytes) {
   static const bool off = [] {
     const char* e = getenv("GLX_HOST_ZERO_COPY");  // "0": always stage through a copy (A/B knob)
     return e && atoi(e) == 0;
@@ -150,7 +150,7 @@ void* glx_mapped_ptr(const void* host_ptr) {
     auto it = g_pinned.upper_bound(a);
     if (it == g_pinned.begin()) return nullptr;
     --it;
-    if (a >= it->first + it->second) return nullptr;  // not in a range glx_host_register pinned
+    if (a >= it->first + it->second || bytes > it->first + it->second - a) return nullptr;  // not (wholly) in a range glx_host_register pinned
   }
   void* dev = nullptr;
   if (hipHostGetDevicePointer(&dev, const_cast<void*>(host_ptr), 0) != hipSuccess) {

@@ -521,8 +521,8 @@ extern "C" int glx_sample_ex(const glx_graph* g, int sampler, const int64_t* src
   // into the caller's buffers when those are pinned (glx_mapped_ptr), else staged and copied.  Synchronous.
   GlxHostCallSlot admitted(g->device);
   const size_t n_out = (size_t)batch * k;
-  int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out));
-  int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out));
+  int64_t* m_nbr = static_cast<int64_t*>(glx_mapped_ptr(nbr_out, n_out * 8));
+  int64_t* m_eid = static_cast<int64_t*>(glx_mapped_ptr(eid_out, n_out * 8));
   const bool direct = m_nbr != nullptr && m_eid != nullptr;
   int64_t* d = nullptr;
   int rc = glx_scratch_alloc(reinterpret_cast<void**>(&d), ((size_t)batch * 2 + (direct ? 0 : 2 * n_out)) * 8, s, 0);

@@ -2,6 +2,8 @@
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <sys/mman.h>
+
 #include <unordered_map>
 #include <unordered_set>
 #include <string>
@@ -137,11 +139,38 @@ public:
         pin = true;
       }
     }
-    void* p = nullptr;
-    if (posix_memalign(&p, 4096, 1ull << c) != 0) throw std::bad_alloc();
-    if (pin) {
-      if (pin_) (void)glx_host_register(p, 1ull << c);  // best effort: an unregistered block is only slower
-      std::lock_guard<std::mutex> g(mtx_);
+    if (!pin) {  // beyond the pool's cap: an ordinary heap block, freed on return
+      void* p = nullptr;
+      if (posix_memalign(&p, 4096, 1ull << c) != 0) throw std::bad_alloc();
+      return p;
+    }
+    // The pool's blocks live in anonymous mappings of their OWN, 2 MiB aligned and whole 2 MiB granules -- never in the
+    // malloc heap (round 6).  A process that has hipHostRegister-ed ranges of its heap and ALSO holds heap memory
+    // marked MADV_HUGEPAGE (numpy does that to every array of 4 MiB or more) gets "an illegal memory access" from
+    // later pageable host-to-device copies on ROCm 7.0 -- reproduced without any glx code in
+    // scripts/r06/repro/hostreg_pageable.hip (registered ranges cut from the heap: a fault within ~50 rounds; cut from
+    // mappings of their own: none in 600), and seen once in ~10 runs of this repo's GPU suite.  Small classes are carved
+    // from 2 MiB slabs that are registered whole, ONCE (pinning costs milliseconds per call).
+    constexpr size_t kGranule = 2u << 20;
+    const size_t bytes_c = 1ull << c;
+    std::lock_guard<std::mutex> g(map_mtx_);
+    if (bytes_c < kGranule) {
+      if (slab_left_ < bytes_c) {
+        slab_ = MapAligned(kGranule, kGranule);
+        slab_left_ = kGranule;
+        if (pin_) (void)glx_host_register(slab_, kGranule);  // best effort: an unregistered block is only slower
+      }
+      void* p = slab_;
+      slab_ = static_cast<char*>(slab_) + bytes_c;
+      slab_left_ -= bytes_c;
+      std::lock_guard<std::mutex> g2(mtx_);
+      owned_.insert(p);
+      return p;
+    }
+    void* p = MapAligned(bytes_c, kGranule);
+    if (pin_) (void)glx_host_register(p, bytes_c);
+    {
+      std::lock_guard<std::mutex> g2(mtx_);
       owned_.insert(p);
     }
     return p;
@@ -163,6 +192,20 @@ public:
   }
 
 private:
+  // `bytes` (a multiple of `align`) of zero pages in a private anonymous mapping, aligned to `align`; never unmapped
+  static void* MapAligned(size_t bytes, size_t align) {
+    void* m = mmap(nullptr, bytes + align, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(m) + align - 1) & ~(uintptr_t)(align - 1);
+    // give the unaligned head and tail back: the pool's mappings must not share a granule with anything else
+    if (lo > reinterpret_cast<uintptr_t>(m)) (void)munmap(m, lo - reinterpret_cast<uintptr_t>(m));
+    const uintptr_t end = reinterpret_cast<uintptr_t>(m) + bytes + align;
+    if (end > lo + bytes) (void)munmap(reinterpret_cast<void*>(lo + bytes), end - (lo + bytes));
+    return reinterpret_cast<void*>(lo);
+  }
+  std::mutex map_mtx_;  // the slab cursor and the mappings (taken before mtx_)
+  void* slab_ = nullptr;
+  size_t slab_left_ = 0;
   std::mutex mtx_;
   std::vector<void*> free_[48];
   std::unordered_set<void*> owned_;  // the pool's blocks (in use or parked; pinned unless pinning is off)

@@ -94,12 +94,16 @@ GLX_API const char* glx_last_error(void);
  * of it are single DMA transfers instead of bouncing through the runtime's pageable staging -- what the
  * response tensors of the C++ layer are backed by (the role of the reference's RepeatedField storage,
  * service/tensor_impl.h:72-75,196-200, on this path).  Both return GLX_UNAVAILABLE without a GPU runtime;
- * an unregistered buffer works everywhere, only slower.  Register whole pages the buffer owns (page-aligned start, a
- * multiple of the page size): a range that shares a page with other data or another registration is left to the
- * runtime's bookkeeping.  Only ranges registered HERE are written directly; memory pinned by other means is staged.
- * After glx_host_unregister do not hand the pages back to the heap while the process still copies to the GPU from
- * ordinary heap memory: pageable copies from addresses that were registered once and recycled since were seen to
- * fault inside the runtime (ROCm 7.0).  Long-lived pools that never unregister (the C++ layer's) are the intended use. */
+ * an unregistered buffer works everywhere, only slower.  A result is written directly only when the WHOLE output extent
+ * lies inside one range registered HERE; memory pinned by other means is staged.  A buffer that straddles the end of a
+ * registered range is the caller's error (the runtime refuses a copy across that boundary: GLX_INTERNAL, "invalid argument").
+ * WHERE the memory comes from matters (ROCm 7.0, measured in round 6): register private anonymous mappings of their own
+ * -- mmap(MAP_PRIVATE | MAP_ANONYMOUS), 2 MiB aligned, whole 2 MiB granules -- NOT ranges of the malloc heap.  A process
+ * that has registered parts of its heap and also holds heap memory marked MADV_HUGEPAGE (numpy marks every array of
+ * 4 MiB or more) gets "an illegal memory access" from later PAGEABLE host-to-device copies, anywhere in the process:
+ * scripts/r06/repro/hostreg_pageable.hip shows it with the runtime alone (registered ranges cut from the heap: a fault
+ * within ~50 rounds of copies; cut from mappings of their own: none in 600), unregistered or not.  The C++ layer's
+ * response pool (host/src/base.cc) follows the rule; long-lived pools that never unregister are the intended use. */
 GLX_API int glx_host_register(void* p, uint64_t bytes);
 GLX_API int glx_host_unregister(void* p);
 
