@@ -201,6 +201,9 @@ private:
     if (lo > reinterpret_cast<uintptr_t>(m)) (void)munmap(m, lo - reinterpret_cast<uintptr_t>(m));
     const uintptr_t end = reinterpret_cast<uintptr_t>(m) + bytes + align;
     if (end > lo + bytes) (void)munmap(reinterpret_cast<void*>(lo + bytes), end - (lo + bytes));
+    // never a transparent huge page: a collapse would migrate pages the GPU runtime has mapped (the boxes measured run
+    // THP in `madvise` mode, where nobody asks for these ranges; this covers hosts that run it in `always` mode)
+    (void)madvise(reinterpret_cast<void*>(lo), bytes, MADV_NOHUGEPAGE);
     return reinterpret_cast<void*>(lo);
   }
   std::mutex map_mtx_;  // the slab cursor and the mappings (taken before mtx_)
