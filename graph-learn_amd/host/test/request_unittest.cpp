@@ -4,7 +4,9 @@
 // request's tensors (hash_partitioner.h:33-92), RandomWalkRequest::IsDeepWalk
 // (random_walk_request.cc:152-160), Clone() of every request kind.
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -167,6 +169,45 @@ TEST(RequestTest, UniqueIdTravelsThroughTheTrackerDirectory) {
   Status missing = ExchangeUniqueId(dir, "another-session", 1, 0.2, &other);
   EXPECT_TRUE(error::IsUnavailable(missing));
   EXPECT_TRUE(error::IsInvalidArgument(ExchangeUniqueId(dir, "a/b", 0, 1.0, &other)));
+}
+
+// Large tensors sit in the response pool's blocks: anonymous mappings of their own (2 MiB granules), never ranges of the
+// malloc heap -- registered heap ranges beside MADV_HUGEPAGE heap memory make later pageable copies fault on ROCm 7.0
+// (base.cc, scripts/r06/repro/hostreg_pageable.hip) -- and a released block is parked and handed out again.
+TEST(TensorPool, LargeTensorsLiveOutsideTheHeapAndAreRecycled) {
+  auto in_heap = [](const void* p) {  // inside the [heap] line of /proc/self/maps?
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return false;
+    char line[512];
+    bool hit = false;
+    while (fgets(line, sizeof(line), f)) {
+      unsigned long lo = 0, hi = 0;
+      if (sscanf(line, "%lx-%lx", &lo, &hi) == 2 && strstr(line, "[heap]") &&
+          reinterpret_cast<uintptr_t>(p) >= lo && reinterpret_cast<uintptr_t>(p) < hi) hit = true;
+    }
+    fclose(f);
+    return hit;
+  };
+  std::vector<void*> keep_heap_busy;  // make sure the heap exists and has room: a malloc of this size WOULD land there
+  for (int i = 0; i < 8; ++i) keep_heap_busy.push_back(malloc(100 << 10));
+  const int64_t* first = nullptr;
+  for (int32_t n : {40000, 300000, 1500000}) {  // 320 KB (a slab piece), 2.4 MB and 12 MB (mappings of their own)
+    Tensor t(kInt64, 0);
+    t.Resize(n);
+    int64_t* p = t.MutableInt64();
+    EXPECT_TRUE(p != nullptr && reinterpret_cast<uintptr_t>(p) % 4096 == 0);
+    EXPECT_TRUE(!in_heap(p));
+    p[0] = 1;
+    p[n - 1] = 2;  // the whole block is ours
+    if (n == 40000) first = p;
+  }
+  Tensor again(kInt64, 0);
+  again.Resize(40000);
+  EXPECT_TRUE(again.MutableInt64() == first);  // the parked block comes back
+  Tensor small(kInt64, 0);
+  small.Resize(100);  // below the pool's threshold: the ordinary heap
+  EXPECT_TRUE(small.MutableInt64() != nullptr);
+  for (void* p : keep_heap_busy) free(p);
 }
 
 int main() { return RunAllTests(); }

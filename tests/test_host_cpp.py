@@ -54,7 +54,7 @@ def test_request_unittest_on_cpu():
     """Request classes, Filter::FillValues, partitioning of filter values, RandomWalkRequest: no device involved."""
     r = run("request_unittest")
     assert r.returncode == 0, r.stdout
-    assert "5 test(s), 0 failure(s)" in r.stdout, r.stdout
+    assert "6 test(s), 0 failure(s)" in r.stdout, r.stdout
 
 
 def test_dag_unittest_on_cpu():
