@@ -74,6 +74,34 @@ extern "C" int glx_host_register(void* p, uint64_t bytes) {
   int n = 0;
   int rc = glx_device_count(&n);
   if (rc != GLX_OK) return rc;
+  // Ranges of the malloc heap are refused (round 6; GLX_HOST_REGISTER_HEAP=1 lifts it): registered heap ranges beside heap
+  // memory marked MADV_HUGEPAGE make later pageable copies of the process fault on ROCm 7.0 (include/glx.h,
+  // scripts/r06/repro/hostreg_pageable.hip).  Only the brk heap can be told apart here; the rule is the header's.
+  {
+    static const bool allow_heap = [] {
+      const char* e = getenv("GLX_HOST_REGISTER_HEAP");
+      return e && atoi(e) != 0;
+    }();
+    uintptr_t lo = 0, hi = 0;
+    if (!allow_heap) {
+      if (FILE* f = fopen("/proc/self/maps", "r")) {
+        char line[512];
+        while (fgets(line, sizeof(line), f)) {
+          unsigned long a = 0, b = 0;
+          if (strstr(line, "[heap]") && sscanf(line, "%lx-%lx", &a, &b) == 2) {
+            lo = a;
+            hi = b;
+            break;
+          }
+        }
+        fclose(f);
+      }
+    }
+    const uintptr_t at = reinterpret_cast<uintptr_t>(p);
+    GLX_REQUIRE(!(at < hi && at + bytes > lo),
+                "glx_host_register: the range lies in the malloc heap; register private anonymous mappings of their own "
+                "(mmap, 2 MiB aligned) instead -- see include/glx.h (GLX_HOST_REGISTER_HEAP=1 overrides)");
+  }
   hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();

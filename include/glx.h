@@ -103,7 +103,8 @@ GLX_API const char* glx_last_error(void);
  * 4 MiB or more) gets "an illegal memory access" from later PAGEABLE host-to-device copies, anywhere in the process:
  * scripts/r06/repro/hostreg_pageable.hip shows it with the runtime alone (registered ranges cut from the heap: a fault
  * within ~50 rounds of copies; cut from mappings of their own: none in 600), unregistered or not.  The C++ layer's
- * response pool (host/src/base.cc) follows the rule; long-lived pools that never unregister are the intended use. */
+ * response pool (host/src/base.cc) follows the rule; long-lived pools that never unregister are the intended use.
+ * A range inside the process's brk heap is refused with GLX_INVALID_ARGUMENT (GLX_HOST_REGISTER_HEAP=1 lifts the check). */
 GLX_API int glx_host_register(void* p, uint64_t bytes);
 GLX_API int glx_host_unregister(void* p);
 

@@ -54,6 +54,24 @@ def check():
         assert L.glx_host_register(ctypes.c_void_p(a.ctypes.data), span) == 0, L.glx_last_error()
         a.fill(0)
         return a
+    # a range of the brk heap is refused by name (the hazard of include/glx.h); nothing is registered
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    blocks = [libc.malloc(48 << 10) for _ in range(4)]  # below the mmap threshold: the main arena
+    heap_lo = heap_hi = 0
+    with open("/proc/self/maps") as fh:
+        for ln in fh:
+            if "[heap]" in ln:
+                heap_lo, heap_hi = (int(x, 16) for x in ln.split()[0].split("-"))
+    in_heap = [b for b in blocks if heap_lo <= b < heap_hi]
+    assert in_heap, "no small malloc block landed in the brk heap"
+    page = (in_heap[0] + 4095) // 4096 * 4096
+    assert L.glx_host_register(ctypes.c_void_p(page), 8192) == 3
+    assert b"malloc heap" in L.glx_last_error()
+    for b in blocks:
+        libc.free(b)
     bufs = []
     try:
         for name in glx.SAMPLER_IDS:
