@@ -1082,6 +1082,9 @@ def main():
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if torch.cuda.device_count() <= local_rank:  # a launcher that started more ranks than the node has GPUs
+        raise SystemExit("rank %d: local rank %d has no GPU of its own (%d visible); one process per GPU -- --share-device "
+                         "is the one-GPU test rig" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
