@@ -105,7 +105,8 @@ GLX_TENSOR_KEYS(GLX_DEFINE_TENSOR_KEY)
 // device->host copy into pageable memory bounces through the runtime's staging buffers (one
 // extra pass over every response byte, serialised between the pool threads), a copy into
 // registered memory is a single DMA straight into the response.  BlockPool recycles large
-// blocks (>= 64 KiB, power-of-two classes, at most kPoolCap bytes pinned in all) across requests and
+// blocks (>= 64 KiB, power-of-two classes, at most kPoolCap bytes pinned in all; anonymous mappings of the pool's own,
+// never the malloc heap -- see Take()) across requests and
 // registers each block with the GPU runtime ONCE, when it is first obtained
 // (glx_host_register; pinning costs milliseconds, recycling a pinned block nothing);
 // small tensors use the ordinary heap.  Without a GPU runtime registration fails and the
