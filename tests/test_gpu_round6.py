@@ -1,4 +1,6 @@
 """Round 6 additions on the device path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -140,3 +142,18 @@ def test_conditional_negative_sampler_starts_over_on_a_new_store(tmp_path):
     b = negatives(second)
     assert b.max() > 104 and b.max() <= 304, "the second graph's negatives come from the first graph's candidates"
     second.close()
+
+
+def test_response_pool_beside_numpy_arrays_and_pageable_copies():
+    """The C++ layer's response pool registers its blocks with the GPU runtime; numpy marks every array of 4 MiB or more
+    MADV_HUGEPAGE.  With the pool's blocks cut from the malloc heap (rounds 2-5) that combination made later pageable
+    host-to-device copies of the process fault on ROCm 7.0 within a few dozen rounds (scripts/r06/repro, the runtime
+    alone; profiles/r06/crash_hunt.txt) -- one GPU test run in ~10 died of it.  The blocks are anonymous mappings of
+    their own now: 60 rounds of pool-backed NeighborSampler responses beside glx.Graph builds from fresh numpy arrays of
+    0.1 - 8 MB, in a process of their own, end without an error."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r06", "pool_pageable_stress.py"), "60"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=540)
+    assert r.returncode == 0 and "no error" in r.stdout, r.stdout[-3000:]
