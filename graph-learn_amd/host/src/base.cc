@@ -150,8 +150,11 @@ public:
     // marked MADV_HUGEPAGE (numpy does that to every array of 4 MiB or more) gets "an illegal memory access" from
     // later pageable host-to-device copies on ROCm 7.0 -- reproduced without any glx code in
     // scripts/r06/repro/hostreg_pageable.hip (registered ranges cut from the heap: a fault within ~50 rounds; cut from
-    // mappings of their own: none in 600), and seen once in ~10 runs of this repo's GPU suite.  Small classes are carved
-    // from 2 MiB slabs that are registered whole, ONCE (pinning costs milliseconds per call).
+    // mappings of their own: none in 600); a test that registered numpy page ranges killed one run in ~10 of this repo's GPU
+    // suite that way.  The pool's former posix_memalign blocks stayed out of the brk heap only while glibc served their
+    // size as mmap chunks -- its threshold grows with every larger mmapped chunk freed -- so their placement is explicit
+    // now (the old pool did not fault in 1,200 rounds of scripts/r06/pool_pageable_stress.py: a precaution, not a repair).
+    // Small classes are carved from 2 MiB slabs that are registered whole, ONCE (pinning costs milliseconds per call).
     constexpr size_t kGranule = 2u << 20;
     const size_t bytes_c = 1ull << c;
     std::lock_guard<std::mutex> g(map_mtx_);

@@ -1,5 +1,5 @@
 """Round 6: the C++ layer's response pool (host/src/base.cc: blocks registered with the GPU runtime, since this round cut
-from anonymous mappings of their own) beside numpy arrays of 4 MiB and more (MADV_HUGEPAGE) and pageable host-to-device
+explicitly from anonymous mappings of their own; the old posix_memalign pool passes this stress too) beside numpy arrays of 4 MiB and more (MADV_HUGEPAGE) and pageable host-to-device
 copies, in ONE process: rounds of NeighborSampler requests through the Python API (responses of 0.3 - 8 MB in pool
 blocks) interleaved with glx.Graph builds from fresh numpy arrays.  Prints the round of the first GPU error, or none.
     python scripts/r06/pool_pageable_stress.py [rounds]"""

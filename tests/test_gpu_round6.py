@@ -146,10 +146,10 @@ def test_conditional_negative_sampler_starts_over_on_a_new_store(tmp_path):
 
 def test_response_pool_beside_numpy_arrays_and_pageable_copies():
     """The C++ layer's response pool registers its blocks with the GPU runtime; numpy marks every array of 4 MiB or more
-    MADV_HUGEPAGE.  With the pool's blocks cut from the malloc heap (rounds 2-5) that combination made later pageable
-    host-to-device copies of the process fault on ROCm 7.0 within a few dozen rounds (scripts/r06/repro, the runtime
-    alone; profiles/r06/crash_hunt.txt) -- one GPU test run in ~10 died of it.  The blocks are anonymous mappings of
-    their own now: 60 rounds of pool-backed NeighborSampler responses beside glx.Graph builds from fresh numpy arrays of
+    MADV_HUGEPAGE.  Registered ranges of the malloc HEAP beside such memory make later pageable host-to-device copies of the
+    process fault on ROCm 7.0 within a few dozen rounds (scripts/r06/repro, the runtime alone; a test that registered numpy
+    page ranges killed one GPU test run in ~10 that way: profiles/r06/crash_hunt.txt).  The pool's blocks are anonymous
+    mappings of their own (explicitly since round 6; by the allocator's grace before): 60 rounds of pool-backed NeighborSampler responses beside glx.Graph builds from fresh numpy arrays of
     0.1 - 8 MB, in a process of their own, end without an error."""
     import subprocess
     import sys
